@@ -1,0 +1,463 @@
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE itself.
+
+Runs only in the build container (needs /root/reference):
+
+    PYTHONPATH=oracle/ref_shim:/root/reference:/root/reference/custom_envs python -W ignore -m oracle.gen_golden
+
+The reference is imported unmodified under the third-party stand-ins of ``oracle/ref_shim`` (gym /
+wandb / mpl_scatter_density are not installed here).  Every golden file stores
+inputs + the reference's outputs (+ torch/numpy versions); at generation time the oracle restatement
+is checked against the reference on the same inputs and the max deviation is printed.
+Nothing of the reference's source is written anywhere — only arrays.
+"""
+import io
+import os
+import pickle
+import sys
+import zipfile
+
+import numpy as np
+import torch as th
+
+_orig_load = th.load
+th.load = lambda f, **k: _orig_load(f, **{**k, "weights_only": False})   # reference checkpoints hold numpy arrays
+
+import gym  # noqa: E402  (the shim)
+from stable_baselines3 import PPOLagrangian  # noqa: E402
+from stable_baselines3.common import logger as ref_logger  # noqa: E402
+from stable_baselines3.common.buffers import RolloutBufferWithCost  # noqa: E402
+from stable_baselines3.common.dual_variable import DualVariable  # noqa: E402
+from stable_baselines3.common.vec_env import VecCostWrapper, VecNormalizeWithCost  # noqa: E402
+from stable_baselines3.common.vec_env.base_vec_env import VecEnv  # noqa: E402
+from icrl.constraint_net import ConstraintNet  # noqa: E402
+import icrl.utils as ref_utils  # noqa: E402
+
+from oracle import cn as o_cn, gae as o_gae, loop as o_loop, nets as o_nets, ppo as o_ppo, stats as o_stats  # noqa: E402
+from oracle.synth_env import SynthVecEnv  # noqa: E402
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+META = dict(torch=th.__version__, numpy=np.__version__)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    arrays = {k: np.asarray(v) for k, v in arrays.items()}
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=np.array(repr(META)), **arrays)
+    print(f"  wrote {name}.npz ({os.path.getsize(os.path.join(OUT, name + '.npz')) / 1024:.0f} KB)")
+
+
+def maxdiff(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+class RefSynthVecEnv(VecEnv):
+    """The synthetic env behind the reference's own VecEnv ABC (ref: vec_env/base_vec_env.py:48-224).
+    Returns float64 obs / rewards like SubprocVecEnv does (np.stack of the workers' results)."""
+
+    def __init__(self, n_envs, kind="hc", seed=0, **kw):
+        self.e = SynthVecEnv(n_envs, kind, seed, **kw)
+        super().__init__(n_envs, gym.spaces.Box(-np.inf, np.inf, (self.e.obs_dim,), np.float64),
+                         gym.spaces.Box(-1, 1, (self.e.act_dim,), np.float32))
+
+    def reset(self):
+        return self.e.reset()
+
+    def step_async(self, actions):
+        self._a = actions
+
+    def step_wait(self):
+        o, r, d = self.e.step(self._a)
+        return o, r, d, [{} for _ in range(self.num_envs)]
+
+    def close(self): pass
+    def seed(self, seed=None): return [seed]
+    def get_attr(self, n, indices=None): return [getattr(self.e, n)]
+    def set_attr(self, *a, **k): pass
+    def env_method(self, *a, **k): return []
+
+
+# ------------------------------------------------------------------------------------------------
+def g1_gae():
+    print("G1 dual GAE")
+    rng = np.random.RandomState(1)
+    cases = {}
+    for name, (T, N, gr, lr_, gc, lc) in dict(t8n3=(8, 3, 0.99, 0.95, 0.99, 0.95), t2000n1=(2000, 1, 0.99, 0.95, 0.99, 0.95),
+                                               t256n16=(256, 16, 0.99, 0.9, 0.99, 0.9), t1n4=(1, 4, 0.99, 0.95, 0.97, 0.8),
+                                               t64n5=(64, 5, 0.99, 0.95, 0.99, 0.9)).items():
+        space_o, space_a = gym.spaces.Box(-1, 1, (3,), np.float32), gym.spaces.Box(-1, 1, (2,), np.float32)
+        b = RolloutBufferWithCost(T, space_o, space_a, "cpu", gr, lr_, gc, lc, n_envs=N)
+        b.rewards[:] = rng.randn(T, N); b.costs[:] = rng.rand(T, N) * 3
+        b.reward_values[:] = rng.randn(T, N); b.cost_values[:] = rng.randn(T, N)
+        b.dones[:] = (rng.rand(T, N) < 0.05)
+        lv_r, lv_c = th.tensor(rng.randn(N, 1), dtype=th.float32), th.tensor(rng.randn(N, 1), dtype=th.float32)
+        ld = rng.rand(N) < 0.3
+        b.compute_returns_and_advantage(lv_r, lv_c, ld)
+        o = o_gae.dual_gae(b.rewards, b.costs, b.reward_values, b.cost_values, b.dones, lv_r.numpy(), lv_c.numpy(), ld,
+                           gr, lr_, gc, lc)
+        for k in o:
+            assert np.array_equal(o[k], getattr(b, k)), (name, k, maxdiff(o[k], getattr(b, k)))
+            assert getattr(b, k).dtype == np.float32
+        for k in ("rewards", "costs", "reward_values", "cost_values", "dones", "reward_returns", "reward_advantages",
+                  "cost_returns", "cost_advantages"):
+            cases[f"{name}/{k}"] = getattr(b, k).copy()
+        cases[f"{name}/last_v_r"], cases[f"{name}/last_v_c"], cases[f"{name}/last_dones"] = lv_r.numpy().ravel(), lv_c.numpy().ravel(), ld
+        cases[f"{name}/params"] = np.array([gr, lr_, gc, lc])
+    print("  oracle == reference bit-for-bit on all cases")
+    save("g1_gae", **cases)
+
+
+def _cn_kwargs(obs_dim, acs_dim, hidden, expert_obs, expert_acs, **kw):
+    d = dict(obs_dim=obs_dim, acs_dim=acs_dim, hidden_sizes=hidden, batch_size=None, lr_schedule=lambda x: 0.05,
+             expert_obs=expert_obs, expert_acs=expert_acs, is_discrete=False, regularizer_coeff=0.5,
+             clip_obs=20, action_low=-np.ones(acs_dim, np.float32), action_high=np.ones(acs_dim, np.float32),
+             target_kl_old_new=10, target_kl_new_old=2.5)
+    d.update(kw)
+    return d
+
+
+def _sd_np(sd, prefix=""):
+    return {prefix + k: v.detach().numpy().copy() for k, v in sd.items()}
+
+
+def g2_cost_function():
+    print("G2 ConstraintNet.cost_function")
+    rng = np.random.RandomState(2)
+    out = {}
+    for name, (od, ad, hid, disc) in dict(hc=(18, 6, [20], False), ant=(113, 8, [40, 40], False), lgw=(1, 2, [20], True)).items():
+        th.manual_seed(3)
+        kw = _cn_kwargs(od, ad, hid, None, None, is_discrete=disc)
+        if disc:
+            kw.update(action_low=None, action_high=None)
+        ref = ConstraintNet(**kw)
+        obs = rng.randn(37, od) * 15                      # beyond clip_obs = 20 in places
+        acs = rng.randint(0, ad, (37, 1)).astype(np.float64) if disc else rng.randn(37, ad) * 2
+        cost = ref.cost_function(obs, acs)
+        orc = o_nets.CostNet(od, ad, hid, disc, None, None, 20, kw["action_low"], kw["action_high"])
+        orc.load_state_dict(ref.network.state_dict())
+        assert orc.select_dim == ref.select_dim
+        d = maxdiff(orc.cost_function(obs, acs), cost); assert d == 0.0, d
+        out.update({f"{name}/obs": obs, f"{name}/acs": acs, f"{name}/cost": cost,
+                    f"{name}/select_dim": np.array(ref.select_dim), f"{name}/hidden": np.array(hid)})
+        out.update(_sd_np(ref.network.state_dict(), f"{name}/w/"))
+    # the committed transfer checkpoint through the reference's own (positionally shifted) load()
+    path = f"{REF}/icrl/expert_data/ConstraintTransfer/ICRL/AntBroken/files/best_cn_model.pt"
+    raw = th.load(path)
+    loaded = ConstraintNet.load(path)
+    obs, acs = rng.randn(29, 113) * 30, rng.randn(29, 8) * 3
+    cost = loaded.cost_function(obs, acs)
+    print("  loaded net attrs: clip_obs", loaded.clip_obs, "action_low", type(loaded.action_low).__name__,
+          "action_high", loaded.action_high, "obs_mean", loaded.current_obs_mean)
+    orc = o_nets.CostNet(113, 8, raw["hidden_sizes"], False, raw["obs_select_dim"], raw["acs_select_dim"],
+                         clip_obs=None, action_low=None, action_high=None)   # what load() really builds
+    orc.load_state_dict(raw["cn_network"])
+    d = maxdiff(orc.cost_function(obs, acs), cost); assert d == 0.0, d
+    out.update({"antbroken/obs": obs, "antbroken/acs": acs, "antbroken/cost": cost,
+                "antbroken/hidden": np.array(raw["hidden_sizes"]), "antbroken/select_dim": np.array(loaded.select_dim)})
+    out.update(_sd_np(raw["cn_network"], "antbroken/w/"))
+    print("  oracle == reference bit-for-bit (fresh nets and ConstraintNet.load quirk)")
+    save("g2_cost_function", **out)
+
+
+class _ReplayVecEnv(VecEnv):
+    """Feeds a pre-generated (obs, rew, done) stream through the reference's wrappers."""
+
+    def __init__(self, obs, rew, done, reset_obs):
+        self.o, self.r, self.d, self.ro, self.t = obs, rew, done, reset_obs, 0
+        super().__init__(obs.shape[1], gym.spaces.Box(-np.inf, np.inf, (obs.shape[2],), np.float64),
+                         gym.spaces.Box(-1, 1, (2,), np.float32))
+
+    def reset(self): return self.ro.copy()
+    def step_async(self, a): pass
+    def step_wait(self):
+        t = self.t; self.t += 1
+        return self.o[t].copy(), self.r[t].copy(), self.d[t].copy(), [{} for _ in range(self.num_envs)]
+    def close(self): pass
+    def seed(self, seed=None): return [seed]
+    def get_attr(self, *a, **k): return []
+    def set_attr(self, *a, **k): pass
+    def env_method(self, *a, **k): return []
+
+
+def g3_vecnormalize():
+    print("G3 VecNormalizeWithCost stream")
+    rng = np.random.RandomState(4)
+    S, N, D = 50, 6, 5
+    obs = rng.randn(S, N, D) * np.array([1, 5, 0.1, 30, 2.0]) + np.array([0, 3, -1, 10, 0.5])
+    rew, done = rng.randn(S, N) * 4, rng.rand(S, N) < 0.1
+    costs = rng.rand(S, N).astype(np.float32)
+    reset_obs = rng.randn(N, D)
+    venv = VecCostWrapper(_ReplayVecEnv(obs, rew, done, reset_obs))
+    step_idx = {"t": 0}
+    venv.set_cost_function(lambda o, a: costs[step_idx["t"]])
+    env = VecNormalizeWithCost(venv, training=True, norm_obs=True, norm_reward=True, norm_cost=True,
+                               cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.97)
+    st = o_stats.NormState(N, D, reward_gamma=0.99, cost_gamma=0.97)
+    rec = {k: [] for k in ("obs_n", "rew_n", "cost_n", "obs_mean", "obs_var", "obs_count", "ret_var", "ret_count",
+                           "cost_var", "cost_count", "ret_mean", "cost_mean")}
+    o0 = env.reset(); o0_o = o_stats.norm_reset(st, reset_obs)
+    worst = maxdiff(o0, o0_o)
+    for t in range(S):
+        step_idx["t"] = t
+        o, r, d, infos = env.step(np.zeros((N, 2), np.float32))
+        c = np.array([i["cost"] for i in infos])
+        oo, ro, co = o_stats.norm_step(st, obs[t], rew[t], costs[t], done[t])
+        worst = max(worst, maxdiff(o, oo), maxdiff(r, ro), maxdiff(c, co), maxdiff(env.obs_rms.var, st.obs_rms.var),
+                    maxdiff(env.cost_rms.var, st.cost_rms.var), maxdiff(env.ret_rms.mean, st.ret_rms.mean))
+        assert np.array_equal(env.get_original_cost(), costs[t])
+        for k, v in (("obs_n", o), ("rew_n", r), ("cost_n", c), ("obs_mean", env.obs_rms.mean), ("obs_var", env.obs_rms.var),
+                     ("obs_count", env.obs_rms.count), ("ret_var", env.ret_rms.var), ("ret_count", env.ret_rms.count),
+                     ("cost_var", env.cost_rms.var), ("cost_count", env.cost_rms.count), ("ret_mean", env.ret_rms.mean),
+                     ("cost_mean", env.cost_rms.mean)):
+            rec[k].append(np.array(v, copy=True))
+    assert worst == 0.0, worst
+    print("  oracle == reference bit-for-bit over", S, "steps")
+    save("g3_vecnormalize", obs=obs, rew=rew, done=done, costs=costs, reset_obs=reset_obs, reset_obs_n=o0,
+         gammas=np.array([0.99, 0.97]), **{k: np.array(v) for k, v in rec.items()})
+
+
+def _make_ref_agent(n_envs, kind, seed, cn_hidden, **kw):
+    env = RefSynthVecEnv(n_envs, kind, seed)
+    env = VecCostWrapper(env)
+    env = VecNormalizeWithCost(env, training=True, norm_obs=True, norm_reward=True, norm_cost=True,
+                               cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    th.manual_seed(100 + seed)
+    cn = ConstraintNet(**_cn_kwargs(od, ad, cn_hidden, None, None, per_step_importance_sampling=True))
+    env.set_cost_function(cn.cost_function)
+    args = dict(n_steps=32, batch_size=16, n_epochs=3, target_kl=0.01, penalty_initial_value=1, penalty_learning_rate=0.1,
+                budget=0.0, seed=seed, device="cpu", verbose=0,
+                policy_kwargs=dict(net_arch=[dict(pi=[64, 64], vf=[64, 64], cvf=[64, 64])]))
+    args.update(kw)
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, **args)
+    return agent, env, cn
+
+
+def g4_ppo_minibatch():
+    print("G4 PPO-Lagrangian minibatch step + train()")
+    agent, env, cn = _make_ref_agent(4, "hc", 0, [20])
+    pol = agent.policy
+    sd0 = _sd_np(pol.state_dict())
+    rng = np.random.RandomState(5)
+    B = 64
+    obs = th.tensor(rng.randn(B, 18), dtype=th.float32); act = th.tensor(rng.randn(B, 6), dtype=th.float32)
+    old_lp = th.tensor(-8 + rng.randn(B) * 0.3, dtype=th.float32)
+    adv_r, adv_c = th.tensor(rng.randn(B), dtype=th.float32), th.tensor(rng.rand(B), dtype=th.float32)
+    ret_r, ret_c = th.tensor(rng.randn(B), dtype=th.float32), th.tensor(rng.randn(B), dtype=th.float32)
+    nu, clip = 0.731, 0.2
+    # oracle policy with the same weights
+    op = o_nets.TwoCriticPolicy(18, 6); op.load_state_dict(pol.state_dict())
+    oopt = th.optim.Adam(op.parameters(), lr=3e-4, eps=1e-5)
+    out = {}
+    for step in range(3):                                # three consecutive steps on the same batch (Adam state evolves)
+        # --- reference arithmetic, invoked through the reference's own policy/optimizer objects
+        v_r, v_c, lp, ent = pol.evaluate_actions(obs, act)
+        a_r = adv_r - adv_r.mean(); a_r = a_r / (adv_r.std() + 1e-8); a_c = adv_c - adv_c.mean()
+        ratio = th.exp(lp - old_lp)
+        pl = -th.min(a_r * ratio, a_r * th.clamp(ratio, 1 - clip, 1 + clip)).mean()
+        pl = (pl + nu * th.mean(a_c * ratio)) / (1 + nu)
+        rvl = th.nn.functional.mse_loss(ret_r, v_r.flatten()); cvl = th.nn.functional.mse_loss(ret_c, v_c.flatten())
+        loss = pl + 0.0 * (-th.mean(ent)) + 0.5 * rvl + 0.5 * cvl
+        pol.optimizer.zero_grad(); loss.backward()
+        grads = {k: p.grad.detach().numpy().copy() for k, p in pol.named_parameters()}
+        gn = th.nn.utils.clip_grad_norm_(pol.parameters(), 0.5)
+        pol.optimizer.step()
+        # --- oracle
+        oloss, tr = o_ppo.minibatch_loss(op, obs, act, old_lp, adv_r, adv_c, ret_r, ret_c, ret_r, ret_c, nu, clip)
+        oopt.zero_grad(); oloss.backward()
+        for k, p in op.params.items():
+            assert maxdiff(p.grad.numpy(), grads[k]) == 0.0, k
+        tot, coef = o_ppo.clip_coef_explicit([p.grad for p in op.parameters()], 0.5)
+        assert abs(tot - float(gn)) < 1e-5 * max(1, tot)
+        th.nn.utils.clip_grad_norm_(op.parameters(), 0.5); oopt.step()
+        for k, p in op.params.items():
+            assert maxdiff(p.detach().numpy(), pol.state_dict()[k].numpy()) == 0.0, k
+        out.update({f"s{step}/loss": loss.item(), f"s{step}/policy_loss": pl.item(), f"s{step}/rvl": rvl.item(),
+                    f"s{step}/cvl": cvl.item(), f"s{step}/entropy_loss": (-th.mean(ent)).item(),
+                    f"s{step}/approx_kl": th.mean(old_lp - lp).item(),
+                    f"s{step}/clip_fraction": th.mean((th.abs(ratio - 1) > clip).float()).item(),
+                    f"s{step}/grad_norm": float(gn), f"s{step}/log_prob": lp.detach().numpy(),
+                    f"s{step}/v_r": v_r.detach().numpy().ravel(), f"s{step}/v_c": v_c.detach().numpy().ravel()})
+        out.update({f"s{step}/grad/{k}": v for k, v in grads.items()})
+        out.update(_sd_np(pol.state_dict(), f"s{step}/after/"))
+    print("  oracle == reference bit-for-bit (loss terms, grads, params after 3 Adam steps)")
+    save("g4_ppo_minibatch", obs=obs.numpy(), act=act.numpy(), old_lp=old_lp.numpy(), adv_r=adv_r.numpy(),
+         adv_c=adv_c.numpy(), ret_r=ret_r.numpy(), ret_c=ret_c.numpy(), nu=nu, clip=clip, lr=3e-4,
+         **{f"w0/{k}": v for k, v in sd0.items()}, **out)
+
+
+def g5_dual():
+    print("G5 DualVariable trajectories")
+    rng = np.random.RandomState(6)
+    out = {}
+    for name, (nu0, lr, budget) in dict(a=(1.0, 0.1, 0.0), b=(0.1, 0.05, 0.0), c=(1.0, 1.0, 0.0), d=(0.1, 1.0, 0.02)).items():
+        costs = np.concatenate([rng.rand(60) * 0.5, np.zeros(90), rng.rand(50) * 0.05]).astype(np.float32)
+        d = DualVariable(budget, lr, nu0, None)
+        od = o_ppo.Dual(budget, lr, nu0, None)
+        traj, worst = [], 0.0
+        for c in costs:
+            d.update_parameter(c); od.update(c)
+            traj.append([d.nu().item(), d.loss.item(), d.nu.log_nu.item()])
+            worst = max(worst, abs(d.nu().item() - od.nu().item()))
+        assert worst == 0.0
+        out[f"{name}/costs"], out[f"{name}/traj"], out[f"{name}/params"] = costs, np.array(traj), np.array([nu0, lr, budget])
+        print(f"  {name}: nu0={nu0} lr={lr} -> min nu {np.min(np.array(traj)[:, 0]):.6g} (clamp floor)")
+    save("g5_dual", **out)
+
+
+def g6_constraint_net_train():
+    print("G6 compute_is_weights + ConstraintNet.train")
+    rng = np.random.RandomState(7)
+    out = {}
+    cases = dict(psis=(True, [30, 50, 20], 6, 10, 2.5), episode=(False, [10, 20, 70], 6, 10, 10),
+                 overflow=(True, [600, 400], 8, 10, 2.5), earlystop=(False, [40, 60], 12, 0.001, 0.0005))
+    for name, (psis, lengths, iters, tk_on, tk_no) in cases.items():
+        n_nom, n_exp = int(np.sum(lengths)), 150
+        exp_obs, exp_acs = rng.randn(n_exp, 18), rng.uniform(-1, 1, (n_exp, 6)).astype(np.float32)
+        nom_obs, nom_acs = rng.randn(n_nom, 18) * (3 if name == "overflow" else 1), rng.uniform(-1.5, 1.5, (n_nom, 6))
+        th.manual_seed(11)
+        ref = ConstraintNet(**_cn_kwargs(18, 6, [20], exp_obs, exp_acs, per_step_importance_sampling=psis,
+                                         target_kl_old_new=tk_on, target_kl_new_old=tk_no,
+                                         lr_schedule=(lambda x: 0.2) if name == "overflow" else (lambda x: 0.05)))
+        w0 = _sd_np(ref.network.state_dict())
+        orc = o_nets.CostNet(18, 6, [20], False, None, None, 20, ref.action_low, ref.action_high)
+        orc.load_state_dict(ref.network.state_dict())
+        oopt = th.optim.Adam(orc.parameters(), lr=ref.lr_schedule(1), eps=1e-5)
+        m = ref.train(iters, nom_obs, nom_acs, np.array(lengths))
+        om = o_cn.cn_train(orc, oopt, iters, orc.prepare(nom_obs, nom_acs), orc.prepare(exp_obs, exp_acs), np.array(lengths),
+                           reg_coeff=0.5, per_step=psis, target_kl_old_new=tk_on, target_kl_new_old=tk_no)
+        for k, v in m.items():
+            a, b = float(v), float(om[k])
+            assert (np.isnan(a) and np.isnan(b)) or a == b, (name, k, a, b)
+        for k, p in orc.params.items():
+            assert maxdiff(p.detach().numpy(), ref.network.state_dict()[k].numpy()) == 0.0
+        print(f"  {name}: early_stop_itr={m['backward/early_stop_itr']} kl_on={m['backward/kl_old_new']:.4g} kl_no={m['backward/kl_new_old']:.4g}")
+        out.update({f"{name}/exp_obs": exp_obs, f"{name}/exp_acs": exp_acs, f"{name}/nom_obs": nom_obs, f"{name}/nom_acs": nom_acs,
+                    f"{name}/lengths": np.array(lengths), f"{name}/cfg": np.array([psis, iters, tk_on, tk_no, ref.lr_schedule(1)], np.float64)})
+        out.update({f"{name}/w0/{k}": v for k, v in w0.items()})
+        out.update(_sd_np(ref.network.state_dict(), f"{name}/w1/"))
+        out.update({f"{name}/m/{k.split('/')[1]}": float(v) for k, v in m.items()})
+    # stand-alone compute_is_weights
+    ref = ConstraintNet(**_cn_kwargs(18, 6, [20], None, None, per_step_importance_sampling=False))
+    po, pn = th.tensor(rng.rand(30, 1), dtype=th.float32), th.tensor(rng.rand(30, 1), dtype=th.float32)
+    for psis in (False, True):
+        ref.per_step_importance_sampling = psis
+        w, a, b = ref.compute_is_weights(po.clone(), pn.clone(), np.array([10, 20]))
+        ow, oa, ob = o_cn.is_weights_and_kls(po.clone(), pn.clone(), np.array([10, 20]), 1e-5, psis)
+        assert w.shape == ow.shape and maxdiff(w, ow) == 0 and a == oa and b == ob
+        out.update({f"isw{int(psis)}/w": w.numpy(), f"isw{int(psis)}/kl": np.array([a.item(), b.item()])})
+    out.update({"isw/po": po.numpy(), "isw/pn": pn.numpy()})
+    print("  oracle == reference bit-for-bit (metrics, weights; inf/nan case included)")
+    save("g6_constraint_net", **out)
+
+
+def g9_learn_iteration():
+    """One learn() of the reference on the synthetic env (N=4, T=32) with the action noise and the minibatch
+    permutations recorded, against the CPU port teacher-forced with the same streams."""
+    print("G9 learn() iteration + sample_from_agent on the synthetic env")
+    import torch.distributions.normal as tdn
+    N, T = 4, 32
+    agent, env, cn = _make_ref_agent(N, "hc", 0, [20])
+    sd0 = _sd_np(agent.policy.state_dict()); cn0 = _sd_np(cn.network.state_dict())
+    noise, perms = [], []
+    orig_sn, orig_perm = tdn._standard_normal, np.random.permutation
+
+    def rec_sn(shape, dtype, device):
+        e = orig_sn(shape, dtype, device); noise.append(e.numpy().copy()); return e
+
+    def rec_perm(n):
+        p = orig_perm(n); perms.append(p.copy()); return p
+    tdn._standard_normal, np.random.permutation = rec_sn, rec_perm
+    try:
+        agent.learn(total_timesteps=2 * N * T, cost_function="cost")
+    finally:
+        tdn._standard_normal, np.random.permutation = orig_sn, orig_perm
+    logs = {k: float(v) for k, v in ref_logger.Logger.CURRENT.name_to_value.items() if k.startswith("train/")}
+    rb = agent.rollout_buffer
+    noise = np.array(noise).reshape(2, T, N, 6)
+    n_ep = [int(logs["train/early_stop_epoch"])]
+    print("  reference: early_stop_epoch", logs["train/early_stop_epoch"], "nu", logs["train/nu"], "perms drawn", len(perms))
+    # ---- CPU port, teacher-forced
+    stack = o_loop.make_stack(N, "hc", 0)
+    ocn = o_nets.CostNet(18, 6, [20], False, None, None, 20, -np.ones(6, np.float32), np.ones(6, np.float32))
+    ocn.load_state_dict(cn.network.state_dict())
+    stack.cost_fn = ocn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=T, batch_size=16, n_epochs=3, target_kl=0.01, seed=0)
+    port.policy.load_state_dict({k: th.as_tensor(v) for k, v in sd0.items()})
+    # split the recorded permutations per rollout (the reference stops drawing after an early stop)
+    per_iter, k = [], 0
+    port.num_timesteps = 0
+    port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
+    worst = {}
+    for it in range(2):
+        b = port.collect_rollouts(noise[it])
+        remaining = perms[k:]
+        res = port.train(lambda e, r=remaining: r[e])
+        used = res["train/early_stop_epoch"] + 1 if res["train/early_stop_epoch"] < 3 else 3
+        per_iter.append(np.array(remaining[:used])); k += used
+    assert k == len(perms), (k, len(perms))
+    for key in ("observations", "orig_observations", "new_observations", "actions", "rewards", "costs", "orig_costs", "dones",
+                "log_probs", "reward_values", "cost_values"):
+        a = getattr(rb, key); a = a.reshape(N, T, -1).swapaxes(0, 1) if a.shape[0] == N * T else a
+        worst[key] = maxdiff(a.reshape(T, N, -1), getattr(b, key).reshape(T, N, -1))
+    for key in ("reward_advantages", "cost_advantages", "reward_returns", "cost_returns"):
+        a = getattr(rb, key).reshape(N, T).swapaxes(0, 1)
+        worst[key] = maxdiff(a, getattr(b, key))
+    for key in ("train/nu", "train/average_cost", "train/approx_kl", "train/loss", "train/policy_gradient_loss", "train/std"):
+        worst[key] = abs(logs[key] - float(res[key]))
+    for kname, p in port.policy.params.items():
+        worst["w/" + kname] = maxdiff(p.detach().numpy(), agent.policy.state_dict()[kname].numpy())
+    print("  port vs reference, max abs deviation:", {k: v for k, v in worst.items() if v > 0} or "all exactly 0")
+    assert max(worst.values()) < 1e-5, worst
+    # ---- sample_from_agent pairing, reference vs port (1-env sampling env, synced stats)
+    from stable_baselines3.common.vec_env import sync_envs_normalization
+    senv = VecNormalizeWithCost(RefSynthVecEnv(1, "hc", 0), training=False, norm_obs=True, norm_reward=False, norm_cost=False)
+    sync_envs_normalization(env, senv)
+    snoise = []
+    tdn._standard_normal = lambda shape, dtype, device: (lambda e: (snoise.append(e.numpy().copy()), e)[1])(orig_sn(shape, dtype, device))
+    try:
+        r_oo, r_o, r_a, r_r, r_l = ref_utils.sample_from_agent(agent, senv, 2)
+    finally:
+        tdn._standard_normal = orig_sn
+    snoise = np.array(snoise).reshape(-1, 6)
+    sstack = o_loop.make_stack(1, "hc", 0, training=False, norm_reward=False, norm_cost=False)
+    o_loop.sync_normalization(stack.norm, sstack.norm)
+    port.stack = sstack
+    p_oo, p_o, p_a, p_r, p_l = o_loop.sample_from_agent(port, sstack, 2, snoise)
+    port.stack = stack
+    d = max(maxdiff(r_oo, p_oo), maxdiff(r_o, p_o), maxdiff(r_a, p_a), maxdiff(r_r, p_r)); assert np.array_equal(r_l, p_l)
+    print("  sample_from_agent port vs reference max dev", d, "lengths", r_l)
+    assert d < 1e-5
+    flat = lambda a: a.reshape(N, T, -1).swapaxes(0, 1).reshape(T, N, -1) if a.shape[0] == N * T else a.reshape(T, N, -1)
+    save("g9_learn_iteration", noise=noise, perms0=per_iter[0], perms1=per_iter[1], sample_noise=snoise,
+         sample_orig_obs=r_oo, sample_obs=r_o, sample_actions=r_a, sample_rewards=r_r, sample_lengths=r_l,
+         **{f"w0/{k}": v for k, v in sd0.items()}, **{f"cn/{k}": v for k, v in cn0.items()},
+         **{f"w1/{k}": v.numpy() for k, v in agent.policy.state_dict().items()},
+         **{f"buf/{k}": flat(getattr(rb, k)) for k in ("observations", "orig_observations", "new_observations", "actions", "rewards",
+                                                      "costs", "orig_costs", "dones", "log_probs", "reward_values", "cost_values",
+                                                      "reward_advantages", "cost_advantages", "reward_returns", "cost_returns")},
+         **{"log/" + k.split("/")[1]: v for k, v in logs.items()},
+         obs_rms_mean=env.obs_rms.mean, obs_rms_var=env.obs_rms.var, obs_rms_count=env.obs_rms.count,
+         ret_rms_var=env.ret_rms.var, cost_rms_var=env.cost_rms.var)
+
+
+def fixtures_expert():
+    """Re-pack the expert artefacts the runs need (data, not source): HC expert rollouts 0-9 and the expert agent's policy."""
+    print("expert fixtures")
+    obs, acs = [], []
+    for i in range(10):
+        d = pickle.load(open(f"{REF}/icrl/expert_data/HCWithPos-New/files/EXPERT/rollouts/{i}.pkl", "rb"))
+        obs.append(d["observations"]); acs.append(d["actions"])
+    z = zipfile.ZipFile(f"{REF}/icrl/expert_data/HCWithPos-New/files/best_model.zip")
+    sd = th.load(io.BytesIO(z.read("policy.pth")))
+    save("expert_hc", observations=np.concatenate(obs).astype(np.float32), actions=np.concatenate(acs).astype(np.float32),
+         **{f"policy/{k}": v.numpy() for k, v in sd.items()})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g9", "expert"]
+    table = dict(g1=g1_gae, g2=g2_cost_function, g3=g3_vecnormalize, g4=g4_ppo_minibatch, g5=g5_dual,
+                 g6=g6_constraint_net_train, g9=g9_learn_iteration, expert=fixtures_expert)
+    for w in which:
+        table[w]()

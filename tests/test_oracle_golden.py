@@ -1,0 +1,194 @@
+"""CPU: the oracle restatement replayed against the golden vectors produced by the reference itself
+(oracle/gen_golden.py).  Bit-exact where the arithmetic is numpy / identical torch ops."""
+import numpy as np
+import pytest
+import torch as th
+
+from oracle import cn as o_cn, gae as o_gae, nets as o_nets, ppo as o_ppo, stats as o_stats
+from oracle import loop as o_loop
+
+
+def _sub(g, prefix):
+    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("case", ["t8n3", "t2000n1", "t256n16", "t1n4", "t64n5"])
+def test_g1_gae_bit_exact(golden, case):
+    g = _sub(golden("g1_gae"), case + "/")
+    gr, lr_, gc, lc = g["params"]
+    o = o_gae.dual_gae(g["rewards"], g["costs"], g["reward_values"], g["cost_values"], g["dones"],
+                       g["last_v_r"], g["last_v_c"], g["last_dones"], gr, lr_, gc, lc)
+    for k in o:
+        assert o[k].dtype == np.float32
+        assert np.array_equal(o[k], g[k]), k
+
+
+def test_gae_f64_accumulation_matters():
+    """The scan must carry float64: an all-f32 scan differs on long horizons."""
+    rng = np.random.RandomState(0)
+    T, N = 2000, 4
+    r, v = rng.randn(T, N).astype(np.float32), rng.randn(T, N).astype(np.float32)
+    d = np.zeros((T, N), np.float32)
+    ret, adv = o_gae.gae_scan(r, v, d, v[-1], np.zeros(N, bool), 0.99, 0.95)
+    acc, adv32 = np.zeros(N, np.float32), np.zeros((T, N), np.float32)
+    for t in range(T - 1, -1, -1):
+        nv = v[-1] if t == T - 1 else v[t + 1]
+        acc = (r[t] + np.float32(0.99) * nv - v[t]) + np.float32(0.99 * 0.95) * acc
+        adv32[t] = acc
+    assert not np.array_equal(adv, adv32) and np.allclose(adv, adv32, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["hc", "ant", "lgw", "antbroken"])
+def test_g2_cost_function(golden, case):
+    g = _sub(golden("g2_cost_function"), case + "/")
+    disc = case == "lgw"
+    od, ad = g["obs"].shape[1], (2 if disc else g["acs"].shape[1])
+    if case == "antbroken":       # ConstraintNet.load's positional shift: no clipping at all (ref: constraint_net.py:394-399)
+        net = o_nets.CostNet(od, ad, list(g["hidden"]), False, None, None, None, None, None)
+    else:
+        lo = None if disc else -np.ones(ad, np.float32)
+        net = o_nets.CostNet(od, ad, list(g["hidden"]), disc, None, None, 20, lo, None if disc else -lo)
+    assert net.select_dim == list(g["select_dim"])
+    net.load_state_dict({k[2:]: g[k] for k in g if k.startswith("w/")})
+    assert np.array_equal(net.cost_function(g["obs"], g["acs"]), g["cost"])
+
+
+def test_g2_select_dim_quirk():
+    """acs_select_dim=None appends range(acs_dim), i.e. it re-selects the first obs columns, never the actions."""
+    net = o_nets.CostNet(18, 6, [20])
+    assert net.select_dim == list(range(18)) + list(range(6))
+
+
+def test_g3_vecnormalize_stream(golden):
+    g = golden("g3_vecnormalize")
+    S, N, D = g["obs"].shape
+    st = o_stats.NormState(N, D, reward_gamma=float(g["gammas"][0]), cost_gamma=float(g["gammas"][1]))
+    assert np.array_equal(o_stats.norm_reset(st, g["reset_obs"]), g["reset_obs_n"])
+    for t in range(S):
+        o, r, c = o_stats.norm_step(st, g["obs"][t], g["rew"][t], g["costs"][t], g["done"][t])
+        assert np.array_equal(o, g["obs_n"][t]) and np.array_equal(r, g["rew_n"][t]) and np.array_equal(c, g["cost_n"][t])
+        assert np.array_equal(st.obs_rms.mean, g["obs_mean"][t]) and np.array_equal(st.obs_rms.var, g["obs_var"][t])
+        assert st.ret_rms.var == g["ret_var"][t] and st.cost_rms.var == g["cost_var"][t]
+        assert st.obs_rms.count == g["obs_count"][t] and st.cost_rms.count == g["cost_count"][t]
+
+
+def test_g4_ppo_minibatch(golden):
+    g = golden("g4_ppo_minibatch")
+    pol = o_nets.TwoCriticPolicy(18, 6)
+    pol.load_state_dict(_sub(g, "w0/"))
+    opt = th.optim.Adam(pol.parameters(), lr=float(g["lr"]), eps=1e-5)
+    t = lambda k: th.as_tensor(g[k])
+    for s in range(3):
+        loss, tr = o_ppo.minibatch_loss(pol, t("obs"), t("act"), t("old_lp"), t("adv_r"), t("adv_c"), t("ret_r"),
+                                        t("ret_c"), t("ret_r"), t("ret_c"), float(g["nu"]), float(g["clip"]))
+        assert loss.item() == g[f"s{s}/loss"].item()
+        assert tr["policy_loss"].item() == g[f"s{s}/policy_loss"].item()
+        assert tr["approx_kl"].item() == g[f"s{s}/approx_kl"].item()
+        assert tr["clip_fraction"].item() == g[f"s{s}/clip_fraction"].item()
+        opt.zero_grad(); loss.backward()
+        for k, p in pol.params.items():
+            assert np.array_equal(p.grad.numpy(), g[f"s{s}/grad/{k}"]), k
+        total, coef = o_ppo.clip_coef_explicit([p.grad for p in pol.parameters()], 0.5)
+        assert abs(total - g[f"s{s}/grad_norm"].item()) <= 1e-5 * max(1.0, total)
+        th.nn.utils.clip_grad_norm_(pol.parameters(), 0.5); opt.step()
+        for k, p in pol.params.items():
+            assert np.array_equal(p.detach().numpy(), g[f"s{s}/after/{k}"]), k
+
+
+def test_explicit_adam_and_clip_match_torch():
+    """The published Adam / clip_grad_norm_ formulas the HIP kernels implement == torch's (fp32 tolerance)."""
+    th.manual_seed(0)
+    p = th.randn(257, requires_grad=True)
+    opt = th.optim.Adam([p], lr=3e-4, eps=1e-5)
+    pe, m, v = p.detach().clone(), th.zeros(257), th.zeros(257)
+    for step in range(1, 6):
+        g = th.randn(257) * 3
+        total, coef = o_ppo.clip_coef_explicit([g], 0.5)
+        p.grad = g.clone()
+        tn = th.nn.utils.clip_grad_norm_([p], 0.5)
+        assert abs(float(tn) - total) < 1e-5
+        opt.step()
+        pe, m, v = o_ppo.adam_step_explicit(pe, g * coef, m, v, step, 3e-4, eps=1e-5)
+        assert th.allclose(pe, p.detach(), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", "abcd")
+def test_g5_dual_trajectory(golden, case):
+    g = _sub(golden("g5_dual"), case + "/")
+    nu0, lr, budget = (float(x) for x in g["params"])     # python floats, as the reference passes them
+    d = o_ppo.Dual(budget, lr, nu0, None)
+    for c, (nu, loss, log_nu) in zip(g["costs"], g["traj"]):
+        d.update(c)
+        assert d.nu().item() == nu and d.log_nu.item() == log_nu
+
+
+def test_dual_clamp_floor_quirk():
+    """nu0 = 1: log_nu floor is inv_softplus(inv_softplus(1)) -> nu floor ~ 0.5413."""
+    d = o_ppo.Dual(10.0, 1.0, 1.0, None)          # huge budget: nu is driven down to the clamp
+    for _ in range(50):
+        d.update(0.0)
+    assert abs(d.nu().item() - 0.5413) < 1e-3
+
+
+@pytest.mark.parametrize("case", ["psis", "episode", "overflow", "earlystop"])
+def test_g6_constraint_net_train(golden, case):
+    g = _sub(golden("g6_constraint_net"), case + "/")
+    psis, iters, tk_on, tk_no, lr = g["cfg"]
+    lo = -np.ones(6, np.float32)
+    net = o_nets.CostNet(18, 6, [20], False, None, None, 20, lo, -lo)
+    net.load_state_dict(_sub(g, "w0/"))
+    opt = th.optim.Adam(net.parameters(), lr=float(lr), eps=1e-5)
+    m = o_cn.cn_train(net, opt, int(iters), net.prepare(g["nom_obs"], g["nom_acs"]), net.prepare(g["exp_obs"], g["exp_acs"]),
+                      g["lengths"], reg_coeff=0.5, per_step=bool(psis), target_kl_old_new=float(tk_on),
+                      target_kl_new_old=float(tk_no))
+    for k, v in m.items():
+        ref = g["m/" + k.split("/")[1]].item()
+        assert (np.isnan(ref) and np.isnan(v)) or ref == v, k
+    for k, p in net.params.items():
+        assert np.array_equal(p.detach().numpy(), g["w1/" + k]), k
+
+
+def test_g6_is_weight_shapes(golden):
+    g = golden("g6_constraint_net")
+    po, pn = th.as_tensor(g["isw/po"]), th.as_tensor(g["isw/pn"])
+    for psis in (0, 1):
+        w, a, b = o_cn.is_weights_and_kls(po, pn, np.array([10, 20]), 1e-5, bool(psis))
+        assert tuple(w.shape) == ((30, 1) if psis else (30,))
+        assert np.array_equal(w.numpy(), g[f"isw{psis}/w"]) and [a.item(), b.item()] == list(g[f"isw{psis}/kl"])
+
+
+def test_psis_broadcast_quirk_equals_product_of_means():
+    th.manual_seed(1)
+    w, logp = th.rand(40, 1) + 0.5, th.randn(40, 1)
+    full = th.mean(w[np.arange(40)][..., None] * logp)
+    assert abs(full.item() - (w.mean() * logp.mean()).item()) < 1e-6
+
+
+def test_g9_learn_iteration_teacher_forced(golden):
+    """A full learn() (2 rollouts + 2 train()) of the CPU port == the reference's, given the recorded streams."""
+    g = golden("g9_learn_iteration")
+    noise = g["noise"]
+    _, T, N, A = noise.shape
+    stack = o_loop.make_stack(N, "hc", 0)
+    lo = -np.ones(6, np.float32)
+    cn = o_nets.CostNet(18, 6, [20], False, None, None, 20, lo, -lo)
+    cn.load_state_dict(_sub(g, "cn/"))
+    stack.cost_fn = cn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=T, batch_size=16, n_epochs=3, target_kl=0.01, seed=0)
+    port.policy.load_state_dict(_sub(g, "w0/"))
+    perms = [g["perms0"], g["perms1"]]
+    port.learn(2 * N * T, noise_fn=lambda it: noise[it], perms_fn=lambda it: (lambda e, p=perms[it]: p[e]))
+    for k in ("observations", "orig_observations", "actions", "rewards", "costs", "orig_costs", "dones", "log_probs",
+              "reward_values", "cost_values", "reward_advantages", "cost_advantages", "reward_returns", "cost_returns"):
+        assert np.array_equal(getattr(port.buf, k).reshape(T, N, -1), g["buf/" + k]), k
+    for k, p in port.policy.params.items():
+        assert np.array_equal(p.detach().numpy(), g["w1/" + k]), k
+    assert port.logs["train/nu"] == g["log/nu"].item()
+    assert np.array_equal(stack.norm.obs_rms.mean, g["obs_rms_mean"]) and stack.norm.cost_rms.var == g["cost_rms_var"]
+    # nominal sampling: (s_{t+1}, a_t) pairing, clipped actions, auto-reset observation at episode ends
+    s1 = o_loop.make_stack(1, "hc", 0, training=False, norm_reward=False, norm_cost=False)
+    o_loop.sync_normalization(stack.norm, s1.norm)
+    port.stack = s1
+    oo, o, a, r, l = o_loop.sample_from_agent(port, s1, 2, g["sample_noise"])
+    assert np.array_equal(l, g["sample_lengths"]) and np.array_equal(oo, g["sample_orig_obs"])
+    assert np.array_equal(a, g["sample_actions"]) and np.allclose(r, g["sample_rewards"], rtol=0, atol=1e-9)
