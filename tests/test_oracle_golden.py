@@ -9,7 +9,8 @@ from oracle import loop as o_loop
 
 
 def _sub(g, prefix):
-    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+    keys = g.files if hasattr(g, "files") else list(g)
+    return {k[len(prefix):]: g[k] for k in keys if k.startswith(prefix)}
 
 
 @pytest.mark.parametrize("case", ["t8n3", "t2000n1", "t256n16", "t1n4", "t64n5"])
