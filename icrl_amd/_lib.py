@@ -1,0 +1,62 @@
+"""ctypes binding of libicrl_hip.so (the C ABI declared in include/icrl_hip.h).
+
+The library is the product path: if it is missing this module raises at import of the first symbol —
+there is no CPU / PyTorch fallback anywhere in ``icrl_amd``.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libicrl_hip.so")
+
+_lib = None
+
+c_void_p, c_int, c_double, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_float
+
+# name -> argtypes (restype is always int = hipError_t).  Kept in one table so that the CPU test-suite can check that
+# every symbol declared in include/icrl_hip.h is exported and bound.
+SIGNATURES = {
+    "icrl_abi_version": [],
+    "icrl_gae_dual": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_void_p],
+    "icrl_gae_dual_ex": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_int, c_void_p],
+}
+
+
+class HipExtensionMissing(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the shared library; torch must be imported first so that the process-wide HIP runtime
+    (libamdhip64.so.7 shipped inside the torch wheel) is the one the library binds to."""
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (loads libamdhip64 with RTLD_GLOBAL semantics for the soname lookup)
+        if not os.path.exists(LIB_PATH):
+            raise HipExtensionMissing(
+                f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C icrl_amd/csrc`). icrl_amd has no CPU fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = argtypes
+            fn.restype = c_int
+    return _lib
+
+
+def check(err, what):
+    if err != 0:
+        raise RuntimeError(f"{what} failed with hipError_t {err}")
+
+
+def ptr(t):
+    """data pointer of a contiguous CUDA(HIP) tensor, or None."""
+    if t is None:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "device-resident contiguous tensor required"
+    return t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

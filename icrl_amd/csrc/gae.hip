@@ -1,0 +1,219 @@
+// Dual (reward + cost) GAE scan over a time-major [T, N] rollout — gfx950.
+//
+// Replaces RolloutBufferWithCost._compute_returns_and_advantage x2
+// (ref: stable_baselines3/common/buffers.py:493-552) with ONE launch that reads r, c, V_r, V_c, dones once
+// and writes A_r, A_c, R_r, R_c once: 36 B per transition, HBM-bound.
+//
+// Layout / mapping
+//   * lane <-> environment column: a wave's 64 lanes read 64 consecutive floats of one time row (256 B,
+//     fully coalesced); time runs in the register dimension.
+//   * the recurrence A_t = delta_t + c_t * A_{t+1} is carried in float64 registers exactly as the reference's
+//     numpy code ends up doing (bool `dones` promote the accumulator to float64; delta_t itself is float32
+//     arithmetic for t < T-1).  Loads/stores stay float32.
+//   * large N (>= 512 column tiles): one wave per tile walks all T rows with a double-buffered batch of U rows
+//     in flight (5*U independent 256-B loads per wave) — bit-identical to the sequential reference.
+//   * small N (the BASELINE configs: 1..8 tiles): W waves of a workgroup split the time axis.  Pass 1 reduces
+//     each chunk to its affine map (P, Q) with A_in = Q + P * A_out (associative scan over affine maps,
+//     SURVEY.md §5 "long-context" row), the maps are exchanged through LDS, every wave folds the maps of the
+//     later chunks into its carry-in and pass 2 replays its chunk (inputs now L2-resident) writing outputs.
+//     The fold re-associates float64 products, so small-N results can differ from the sequential scan in the
+//     last float64 bit; after the float32 store that is invisible except for ~1e-8 of elements (<= 1 ulp).
+//
+// Built with -ffp-contract=off: every multiply/add below rounds separately, like the numpy reference.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/icrl_hip.h"
+
+namespace {
+
+constexpr int U = 8;  // time rows per register batch (x2 for the double buffer)
+
+struct GaeArgs {
+  const float *r, *c, *vr, *vc, *d, *lvr, *lvc;
+  const uint8_t* ld;
+  float *ar, *ac, *rr, *rc;
+  int T, N;
+  float g_r, gl_r, g_c, gl_c;
+};
+
+struct Batch {
+  float r[U], c[U], vr[U], vc[U], d[U];
+};
+
+__device__ __forceinline__ void load_batch(const GaeArgs& a, unsigned n, int t_top, int t0, Batch& b) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int t = t_top - u;
+    t = t < t0 ? t0 : t;  // clamped (uniform) — the value is ignored below t0
+    const size_t row = (size_t)t * a.N;  // wave-uniform: scalar row base + 32-bit lane offset
+    b.r[u] = (a.r + row)[n];
+    b.c[u] = (a.c + row)[n];
+    b.vr[u] = (a.vr + row)[n];
+    b.vc[u] = (a.vc + row)[n];
+    b.d[u] = (a.d + row)[n];
+  }
+}
+
+// carried state of one chunk walk
+struct Carry {
+  double Ar, Ac;      // running advantages (or Q of the affine map in the composite pass)
+  double Pr, Pc;      // product of coefficients (composite pass only)
+  float vr_next, vc_next, d_next;
+};
+
+template <bool WRITE>
+__device__ __forceinline__ void run_batch(const GaeArgs& a, unsigned n, bool live, int t_top, int t0, const Batch& b, Carry& s) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int t = t_top - u;
+    if (t >= t0) {
+      const float nnt = 1.0f - s.d_next;
+      // ref: buffers.py:535-537 — float32 delta, float32 coefficient, float64 accumulate
+      const float gvr = (a.g_r * s.vr_next) * nnt;
+      const float gvc = (a.g_c * s.vc_next) * nnt;
+      const float dr = (b.r[u] + gvr) - b.vr[u];
+      const float dc = (b.c[u] + gvc) - b.vc[u];
+      const float cr = a.gl_r * nnt;
+      const float cc = a.gl_c * nnt;
+      s.Ar = (double)dr + (double)cr * s.Ar;
+      s.Ac = (double)dc + (double)cc * s.Ac;
+      if (WRITE) {
+        if (live) {
+          const size_t row = (size_t)t * a.N;
+          const float fr = (float)s.Ar, fc = (float)s.Ac;
+          (a.ar + row)[n] = fr;
+          (a.ac + row)[n] = fc;
+          (a.rr + row)[n] = fr + b.vr[u];
+          (a.rc + row)[n] = fc + b.vc[u];
+        }
+      } else {
+        s.Pr = (double)cr * s.Pr;
+        s.Pc = (double)cc * s.Pc;
+      }
+      s.vr_next = b.vr[u];
+      s.vc_next = b.vc[u];
+      s.d_next = b.d[u];
+    }
+  }
+}
+
+// Walk t = t1-1 .. t0 for column n.  WRITE=false: compute the chunk's affine map into (s.Pr,s.Ar),(s.Pc,s.Ac)
+// starting from A=0,P=1.  WRITE=true: s.Ar/s.Ac hold the carry-in and outputs are stored.
+template <bool WRITE>
+__device__ __forceinline__ void walk_chunk(const GaeArgs& a, unsigned n, bool live, int t0, int t1, Carry& s) {
+  int t = t1 - 1;
+  if (t1 == a.T) {
+    // t = T-1: bootstrap from last values; `1.0 - last_dones(bool)` is float64 in the reference (buffers.py:530-531)
+    const size_t off = (size_t)t * a.N + n;
+    const float rew = a.r[off], cost = a.c[off], vr = a.vr[off], vc = a.vc[off], d = a.d[off];
+    const double nnt = 1.0 - (a.ld[n] ? 1.0 : 0.0);
+    const float gvr = a.g_r * a.lvr[n];
+    const float gvc = a.g_c * a.lvc[n];
+    s.Ar = ((double)rew + (double)gvr * nnt) - (double)vr;  // + gamma*lambda*nnt*0
+    s.Ac = ((double)cost + (double)gvc * nnt) - (double)vc;
+    if (WRITE) {
+      if (live) {
+        const float fr = (float)s.Ar, fc = (float)s.Ac;
+        a.ar[off] = fr;
+        a.ac[off] = fc;
+        a.rr[off] = fr + vr;
+        a.rc[off] = fc + vc;
+      }
+    } else {
+      s.Pr = 0.0;  // nothing beyond T feeds in
+      s.Pc = 0.0;
+    }
+    s.vr_next = vr;
+    s.vc_next = vc;
+    s.d_next = d;
+    --t;
+  } else {
+    const size_t off = (size_t)t1 * a.N + n;
+    s.vr_next = a.vr[off];
+    s.vc_next = a.vc[off];
+    s.d_next = a.d[off];
+  }
+  if (t < t0) return;
+  Batch b0, b1;
+  load_batch(a, n, t, t0, b0);
+  while (true) {
+    if (t - U >= t0) load_batch(a, n, t - U, t0, b1);
+    run_batch<WRITE>(a, n, live, t, t0, b0, s);
+    t -= U;
+    if (t < t0) break;
+    if (t - U >= t0) load_batch(a, n, t - U, t0, b0);
+    run_batch<WRITE>(a, n, live, t, t0, b1, s);
+    t -= U;
+    if (t < t0) break;
+  }
+}
+
+template <int W>
+__global__ void __launch_bounds__(64 * W) gae_dual_kernel(GaeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
+  const int col = blockIdx.x * 64 + lane;
+  const bool live = col < a.N;
+  const unsigned n = live ? col : a.N - 1;
+  const int chunk = (a.T + W - 1) / W;
+  const int t0 = wave * chunk;
+  const int t1 = (t0 + chunk < a.T) ? t0 + chunk : a.T;
+  Carry s;
+  s.Ar = 0.0; s.Ac = 0.0; s.Pr = 1.0; s.Pc = 1.0;
+  s.vr_next = 0.f; s.vc_next = 0.f; s.d_next = 0.f;
+  if (W > 1) {
+    __shared__ double maps[W][4][64];
+    if (t0 < t1) walk_chunk<false>(a, n, live, t0, t1, s);
+    maps[wave][0][lane] = s.Pr;
+    maps[wave][1][lane] = s.Ar;
+    maps[wave][2][lane] = s.Pc;
+    maps[wave][3][lane] = s.Ac;
+    __syncthreads();
+    double Ar = 0.0, Ac = 0.0;
+    for (int w = W - 1; w > wave; --w) {
+      Ar = maps[w][1][lane] + maps[w][0][lane] * Ar;
+      Ac = maps[w][3][lane] + maps[w][2][lane] * Ac;
+    }
+    s.Ar = Ar;
+    s.Ac = Ac;
+  }
+  if (t0 < t1) walk_chunk<true>(a, n, live, t0, t1, s);
+}
+
+}  // namespace
+
+extern "C" int icrl_gae_dual_ex(const float* rewards, const float* costs, const float* reward_values,
+                                const float* cost_values, const float* dones, const float* last_v_r,
+                                const float* last_v_c, const uint8_t* last_dones, float* adv_r, float* adv_c,
+                                float* ret_r, float* ret_c, int T, int N, double reward_gamma, double reward_gae_lambda,
+                                double cost_gamma, double cost_gae_lambda, int waves_per_tile, void* stream) {
+  if (T <= 0 || N <= 0) return (int)hipErrorInvalidValue;
+  GaeArgs a{rewards, costs, reward_values, cost_values, dones, last_v_r, last_v_c, last_dones,
+            adv_r, adv_c, ret_r, ret_c, T, N,
+            (float)reward_gamma, (float)(reward_gamma * reward_gae_lambda),   // Python double product, then f32
+            (float)cost_gamma, (float)(cost_gamma * cost_gae_lambda)};
+  const int tiles = (N + 63) / 64;
+  int W = waves_per_tile;
+  if (W != 1 && W != 4 && W != 16) {
+    W = tiles >= 512 ? 1 : (tiles >= 64 ? 4 : 16);
+    while (W > 1 && T / W < 2 * U) W /= 4;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (W == 1) hipLaunchKernelGGL(gae_dual_kernel<1>, dim3(tiles), dim3(64), 0, s, a);
+  else if (W == 4) hipLaunchKernelGGL(gae_dual_kernel<4>, dim3(tiles), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(gae_dual_kernel<16>, dim3(tiles), dim3(1024), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_gae_dual(const float* rewards, const float* costs, const float* reward_values,
+                             const float* cost_values, const float* dones, const float* last_v_r,
+                             const float* last_v_c, const uint8_t* last_dones, float* adv_r, float* adv_c,
+                             float* ret_r, float* ret_c, int T, int N, double reward_gamma, double reward_gae_lambda,
+                             double cost_gamma, double cost_gae_lambda, void* stream) {
+  return icrl_gae_dual_ex(rewards, costs, reward_values, cost_values, dones, last_v_r, last_v_c, last_dones, adv_r,
+                          adv_c, ret_r, ret_c, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, 0,
+                          stream);
+}
+
+extern "C" int icrl_abi_version(void) { return 100; }

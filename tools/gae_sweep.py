@@ -1,0 +1,32 @@
+"""GAE kernel sweep on the GPU: achieved algorithmic GB/s (36 B/transition) vs N and launch shape."""
+import sys
+import torch
+from icrl_amd import _lib
+
+L = _lib.lib()
+dev = torch.device("cuda:0")
+T = 2048
+print(torch.cuda.get_device_name(0), torch.cuda.get_device_properties(0).multi_processor_count, "CUs")
+for N in [64, 256, 512, 4096, 32768, 65536, 131072]:
+    ins = [torch.randn(T, N, device=dev) for _ in range(4)] + [(torch.rand(T, N, device=dev) < 0.001).float()]
+    lv = [torch.randn(N, device=dev) for _ in range(2)]
+    ld = torch.zeros(N, dtype=torch.uint8, device=dev)
+    outs = [torch.empty(T, N, device=dev) for _ in range(4)]
+    args = [_lib.ptr(x) for x in (*ins, *lv, ld, *outs)]
+    for W in (1, 4, 16):
+        if N >= 32768 and W == 16:
+            continue
+        st = _lib.current_stream()
+        for _ in range(3):
+            L.icrl_gae_dual_ex(*args, T, N, 0.99, 0.95, 0.99, 0.95, W, st)
+        torch.cuda.synchronize()
+        reps = 20 if N <= 4096 else 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            L.icrl_gae_dual_ex(*args, T, N, 0.99, 0.95, 0.99, 0.95, W, st)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gb = T * N * 36 / 1e9
+        print(f"N={N:7d} W={W:2d}  {ms*1e3:9.1f} us  {gb/ (ms/1e3):8.1f} GB/s  ({gb*1e3:.1f} MB)")
+    del ins, outs
