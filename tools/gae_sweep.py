@@ -1,5 +1,6 @@
 """GAE kernel sweep on the GPU: achieved algorithmic GB/s (36 B/transition) vs N and launch shape."""
-import sys
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from icrl_amd import _lib
 
