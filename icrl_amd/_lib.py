@@ -19,6 +19,15 @@ SIGNATURES = {
     "icrl_abi_version": [],
     "icrl_gae_dual": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_void_p],
     "icrl_gae_dual_ex": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_int, c_void_p],
+    "icrl_policy_prepare": [c_void_p, c_void_p],
+    "icrl_costnet_prepare": [c_void_p, c_void_p],
+    "icrl_policy_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8,
+    "icrl_cost_mlp_forward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "icrl_synth_env_reset": [c_void_p, c_void_p],
+    "icrl_synth_env_step": [c_void_p] * 5,
+    "icrl_vecnorm_reset": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
+    "icrl_vecnorm_step": [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 4,
+    "icrl_rollout_collect": [c_void_p] * 9 + [c_double] * 4 + [c_void_p],
 }
 
 
@@ -42,6 +51,9 @@ def lib():
             fn.argtypes = argtypes
             fn.restype = c_int
     return _lib
+
+
+byref = ctypes.byref
 
 
 def check(err, what):

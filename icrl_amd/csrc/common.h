@@ -1,0 +1,132 @@
+// Shared device helpers for libicrl_hip (gfx950 only: wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/icrl_hip.h"
+
+namespace icrl {
+
+constexpr int WAVE = 64;
+constexpr int MAX_OBS = 128;   // obs_dim limit of the rollout kernels (HC 18, Ant 113)
+constexpr int MAX_ACT = 16;    // act_dim limit (HC 6, Ant 8)
+constexpr int MAX_H = 64;      // hidden width limit of policy / cost nets
+constexpr int MAX_CN_IN = 160; // cost-net input limit (Ant: 121)
+
+// ---------------------------------------------------------------------------------------------------------------
+// counter-based random stream of the synthetic env (spec: oracle/synth_env.py u24())
+// ---------------------------------------------------------------------------------------------------------------
+__host__ __device__ inline uint32_t fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline uint32_t u24(uint32_t key, uint32_t ctr, uint32_t comp) {
+  uint32_t x = fmix32(key ^ 0x9E3779B9u);
+  x = fmix32(x + ctr * 0x9E3779B1u);
+  x = fmix32(x ^ (comp * 0x7FEB352Du));
+  return x >> 8;
+}
+__host__ __device__ inline double unit_uniform(uint32_t key, uint32_t ctr, uint32_t comp) {
+  return (double)u24(key, ctr, comp) / 16777216.0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// wave-level reductions (butterfly over 64 lanes; every lane ends with the total)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+  return v;
+}
+
+// numpy's pairwise summation of a contiguous float64 vector (np.sum / np.mean over a 1-D array); reproduces the
+// reference's reduction order exactly so that ret_rms / cost_rms match bit for bit.
+__device__ inline double np_pairwise_sum(const double* a, int n) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  if (n <= 128) {
+    double r[8];
+    for (int k = 0; k < 8; ++k) r[k] = a[k];
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+      for (int k = 0; k < 8; ++k) r[k] += a[i + k];
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += a[i];
+    return res;
+  }
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// flat parameter layouts
+// ---------------------------------------------------------------------------------------------------------------
+struct PolLayout {
+  int O, A, H1, H2, discrete, n;
+  int log_std;                      // -1 when discrete
+  int W1[3], b1[3], W2[3], b2[3];   // pi, vf, cvf
+  int Wa, ba, Wv, bv, Wc, bc;
+};
+
+__host__ __device__ inline PolLayout make_pol_layout(int O, int A, int H1, int H2, int discrete) {
+  PolLayout L;
+  L.O = O; L.A = A; L.H1 = H1; L.H2 = H2; L.discrete = discrete;
+  int off = 0;
+  if (discrete) L.log_std = -1; else { L.log_std = 0; off += A; }
+  for (int w = 0; w < 3; ++w) {
+    L.W1[w] = off; off += H1 * O;
+    L.b1[w] = off; off += H1;
+    L.W2[w] = off; off += H2 * H1;
+    L.b2[w] = off; off += H2;
+  }
+  L.Wa = off; off += A * H2;
+  L.ba = off; off += A;
+  L.Wv = off; off += H2;
+  L.bv = off; off += 1;
+  L.Wc = off; off += H2;
+  L.bc = off; off += 1;
+  L.n = off;
+  return L;
+}
+
+struct CnLayout {
+  int in, nh, H1, H2, n;
+  int W0, b0, W1, b1, Wo, bo;
+};
+
+__host__ __device__ inline CnLayout make_cn_layout(int in, int nh, int H1, int H2) {
+  CnLayout L;
+  L.in = in; L.nh = nh; L.H1 = H1; L.H2 = (nh == 2 ? H2 : H1);
+  int off = 0;
+  L.W0 = off; off += H1 * in;
+  L.b0 = off; off += H1;
+  if (nh == 2) { L.W1 = off; off += H2 * H1; L.b1 = off; off += H2; } else { L.W1 = L.b1 = -1; }
+  L.Wo = off; off += L.H2;
+  L.bo = off; off += 1;
+  L.n = off;
+  return L;
+}
+
+constexpr float LOG_SQRT_2PI_F = 0.918938533204672741780329736406f;  // log(sqrt(2*pi))
+constexpr float HALF_LOG_2PI_PLUS_HALF_F = 1.418938533204672741780329736406f;  // 0.5 + 0.5*log(2*pi)
+
+}  // namespace icrl

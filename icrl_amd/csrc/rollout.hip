@@ -1,0 +1,690 @@
+// Rollout-time kernels — gfx950.
+//
+// One environment step of OnPolicyWithCostAlgorithm.collect_rollouts
+// (ref: stable_baselines3/common/on_policy_algorithm.py:367-416) is two launches:
+//
+//   act_step_kernel   one workgroup (3 waves = pi | vf | cvf) per environment:
+//                     policy forward (ref: policies.py:716-731, torch_layers.py:245-254, distributions.py:143-171)
+//                     -> clip -> synthetic env step + auto-reset (spec: oracle/synth_env.py)
+//                     -> cost_function(previous raw obs, clipped action) (ref: icrl/constraint_net.py:121-130,258-299;
+//                        vec_cost_wrapper.py:51-66) -> the buffer fields that do not need the normaliser
+//                        (ref: buffers.py:554-592).
+//   norm_step_kernel  one workgroup for all environments: running-moment merge of obs / discounted reward return /
+//                     discounted cost return in float64 with numpy's reduction order, normalise + clip, remaining
+//                     buffer fields (ref: vec_normalize.py:81-123,220-261; running_mean_std.py:19-39).
+//
+// The same device functions back the fine-grained C-ABI entry points (icrl_policy_forward, icrl_cost_mlp_forward,
+// icrl_synth_env_step, icrl_vecnorm_step) that the Python VecEnv / ConstraintNet classes call one at a time.
+//
+// Weights are read from the transposed copies ([in][out]) written by *_prepare so that the 64 lanes of a wave
+// (one lane per output unit) load 256 contiguous bytes per input index.
+#include "common.h"
+
+namespace icrl {
+
+// =================================================================================================================
+// transposed weight copies
+// =================================================================================================================
+__global__ void policy_transpose_kernel(PolLayout L, const float* __restrict__ p, float* __restrict__ pt) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.n; i += gridDim.x * blockDim.x) {
+    int dst = i;
+    for (int w = 0; w < 3; ++w) {
+      if (i >= L.W1[w] && i < L.b1[w]) { int r = i - L.W1[w]; int j = r / L.O, k = r % L.O; dst = L.W1[w] + k * L.H1 + j; }
+      if (i >= L.W2[w] && i < L.b2[w]) { int r = i - L.W2[w]; int j = r / L.H1, k = r % L.H1; dst = L.W2[w] + k * L.H2 + j; }
+    }
+    if (i >= L.Wa && i < L.ba) { int r = i - L.Wa; int a = r / L.H2, j = r % L.H2; dst = L.Wa + j * L.A + a; }
+    pt[dst] = p[i];
+  }
+}
+
+__global__ void costnet_transpose_kernel(CnLayout L, const float* __restrict__ p, float* __restrict__ pt) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.n; i += gridDim.x * blockDim.x) {
+    int dst = i;
+    if (i >= L.W0 && i < L.b0) { int r = i - L.W0; int j = r / L.in, k = r % L.in; dst = L.W0 + k * L.H1 + j; }
+    if (L.nh == 2 && i >= L.W1 && i < L.b1) { int r = i - L.W1; int j = r / L.H1, k = r % L.H1; dst = L.W1 + k * L.H2 + j; }
+    pt[dst] = p[i];
+  }
+}
+
+// =================================================================================================================
+// device building blocks (called by a 192-thread workgroup handling ONE environment)
+// =================================================================================================================
+struct ActShared {
+  double s_old[MAX_OBS];   // raw observation before the step (== VecCostWrapper.previous_obs)
+  float x[MAX_OBS];        // normalised observation, float32 (policy input)
+  float h[3][MAX_H];
+  float g[3][MAX_H];
+  float cx[MAX_CN_IN];     // cost-net input
+  float ch[2][MAX_H];
+  float act_raw[MAX_ACT];
+  float act_clip[MAX_ACT];
+  float scal[4];           // v_r, v_c, log_prob, (unused)
+};
+
+// three tanh MLPs + heads for the observation in sh.x.  Must be called by all 192 threads.
+__device__ __forceinline__ void policy_forward_block(const PolLayout& L, const float* __restrict__ PT, ActShared& sh,
+                                                     const float* noise_row, int deterministic,
+                                                     const float* alow, const float* ahigh) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (lane < L.H1) {
+    const float* W = PT + L.W1[w];
+    float acc = 0.f;
+    for (int k = 0; k < L.O; ++k) acc = fmaf(W[k * L.H1 + lane], sh.x[k], acc);
+    sh.h[w][lane] = tanhf(acc + PT[L.b1[w] + lane]);
+  }
+  __syncthreads();
+  if (lane < L.H2) {
+    const float* W = PT + L.W2[w];
+    float acc = 0.f;
+    for (int k = 0; k < L.H1; ++k) acc = fmaf(W[k * L.H2 + lane], sh.h[w][k], acc);
+    sh.g[w][lane] = tanhf(acc + PT[L.b2[w] + lane]);
+  }
+  __syncthreads();
+  if (w == 0) {
+    float mean = 0.f;
+    if (lane < L.A) {
+      const float* W = PT + L.Wa;
+      float acc = 0.f;
+      for (int j = 0; j < L.H2; ++j) acc = fmaf(W[j * L.A + lane], sh.g[0][j], acc);
+      mean = acc + PT[L.ba + lane];
+    }
+    if (!L.discrete) {
+      float lp = 0.f;
+      if (lane < L.A) {
+        const float std = expf(PT[L.log_std + lane]);
+        float act = mean;
+        if (!deterministic) act = mean + noise_row[lane] * std;   // Normal.rsample: loc + eps * scale
+        const float diff = act - mean;
+        // Normal.log_prob: -((x - mu)^2) / (2 var) - log(std) - log(sqrt(2 pi))
+        lp = -(diff * diff) / (2.f * (std * std)) - logf(std) - LOG_SQRT_2PI_F;
+        sh.act_raw[lane] = act;
+        float c = act;
+        if (alow != nullptr && ahigh != nullptr) c = fminf(fmaxf(act, alow[lane]), ahigh[lane]);
+        sh.act_clip[lane] = c;
+      }
+      lp = wave_sum(lp);
+      if (lane == 0) sh.scal[2] = lp;
+    } else {
+      // Categorical(logits): log-softmax, inverse-CDF sample on the injected uniform (spec: oracle/nets.py forward)
+      float m = wave_max(lane < L.A ? mean : -INFINITY);
+      float e = lane < L.A ? expf(mean - m) : 0.f;
+      float lse = m + logf(wave_sum(e));
+      float logp = mean - lse;
+      float p = lane < L.A ? expf(logp) : 0.f;
+      // inclusive prefix sum over the first A lanes (A <= 16: sequential in lane 0 order, matches th.cumsum)
+      float cdf = 0.f;
+      int action = 0;
+      if (deterministic) {
+        float best = wave_max(lane < L.A ? p : -1.f);
+        unsigned long long ball = __ballot(lane < L.A && p == best);
+        action = __ffsll((long long)ball) - 1;
+      } else {
+        const float u = noise_row[0];
+        int cnt = 0;
+        for (int a = 0; a < L.A; ++a) {
+          cdf += __shfl(p, a, 64);
+          cnt += (u >= cdf) ? 1 : 0;
+        }
+        action = cnt < L.A - 1 ? cnt : L.A - 1;
+      }
+      const float lp = __shfl(logp, action, 64);
+      if (lane == 0) { sh.scal[2] = lp; sh.act_raw[0] = (float)action; sh.act_clip[0] = (float)action; }
+    }
+  } else {
+    const int off = (w == 1) ? L.Wv : L.Wc;
+    float part = lane < L.H2 ? PT[off + lane] * sh.g[w][lane] : 0.f;
+    part = wave_sum(part);
+    if (lane == 0) sh.scal[w - 1] = part + PT[(w == 1) ? L.bv : L.bc];
+  }
+}
+
+// cost = 1 - sigmoid(ReLU-MLP(prepare(obs, acs))); called by ONE wave. obs_row: float64 raw obs (LDS or global),
+// acs_row: float32 actions.  Returns the cost in every lane.
+__device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, const CnLayout& L, const double* obs_row,
+                                                   const float* acs_row, float* cx, float (*ch)[MAX_H]) {
+  const int lane = threadIdx.x & 63;
+  for (int i = lane; i < L.in; i += WAVE) {
+    const int sel = cn.select_dim[i];
+    float v;
+    if (sel < cn.obs_dim) {
+      double o = obs_row[sel];
+      if (cn.obs_mean != nullptr && cn.obs_var != nullptr) o = (o - cn.obs_mean[sel]) / sqrt(cn.obs_var[sel] + cn.eps);
+      if (cn.clip_obs >= 0.0) o = fmin(fmax(o, -cn.clip_obs), cn.clip_obs);
+      v = (float)o;
+    } else {
+      const int a = sel - cn.obs_dim;
+      float x;
+      if (cn.is_discrete) x = ((int)acs_row[0] == a) ? 1.f : 0.f;
+      else x = acs_row[a];
+      if (cn.action_low != nullptr && cn.action_high != nullptr) x = fminf(fmaxf(x, cn.action_low[a]), cn.action_high[a]);
+      v = x;
+    }
+    cx[i] = v;
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes of this wave visible to its own reads
+  const float* PT = cn.params_t;
+  if (lane < L.H1) {
+    float acc = 0.f;
+    for (int k = 0; k < L.in; ++k) acc = fmaf(PT[L.W0 + k * L.H1 + lane], cx[k], acc);
+    ch[0][lane] = fmaxf(acc + PT[L.b0 + lane], 0.f);
+  }
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  int last = 0;
+  if (L.nh == 2) {
+    if (lane < L.H2) {
+      float acc = 0.f;
+      for (int k = 0; k < L.H1; ++k) acc = fmaf(PT[L.W1 + k * L.H2 + lane], ch[0][k], acc);
+      ch[1][lane] = fmaxf(acc + PT[L.b1 + lane], 0.f);
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    last = 1;
+  }
+  float part = lane < L.H2 ? PT[L.Wo + lane] * ch[last][lane] : 0.f;
+  const float z = wave_sum(part) + PT[L.bo];
+  const float zeta = 1.f / (1.f + expf(-z));
+  return 1.f - zeta;
+}
+
+// synthetic env step for env n; called by ONE wave.  act: float32 clipped actions (LDS or global).
+// Returns reward / done in every lane; writes env.s, t_ep, step_count.  s_old: float64 previous state (LDS copy).
+__device__ __forceinline__ void env_step_wave(const icrl_env_t& e, int n, const double* s_old, const float* act,
+                                              double& reward, int& done) {
+  const int lane = threadIdx.x & 63;
+  const int O = e.obs_dim, A = e.act_dim;
+  double a[MAX_ACT];
+  double sq = 0.0;
+#pragma unroll
+  for (int j = 0; j < MAX_ACT; ++j) {
+    a[j] = 0.0;
+    if (j < A) {
+      a[j] = (double)act[j];
+      if (e.broken && j >= 4) a[j] = 0.0;
+      sq = sq + a[j] * a[j];
+    }
+  }
+  const uint32_t key = e.key[n];
+  const uint32_t ctr = e.step_count[n];
+  double ns[2];  // this lane's components i = lane, lane + 64
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = lane + r * WAVE;
+    ns[r] = 0.0;
+    if (i < O) {
+      double acc = 0.99 * s_old[i];
+      const double* Bi = e.B + (size_t)i * A;
+#pragma unroll
+      for (int j = 0; j < MAX_ACT; ++j)
+        if (j < A) acc = acc + Bi[j] * a[j];
+      const double eps = (unit_uniform(key, ctr, (uint32_t)i) - 0.5) * 3.4641016151377544;
+      ns[r] = acc + 0.01 * eps;
+    }
+  }
+  const double n0 = __shfl(ns[0], 0, 64);
+  const double n1 = __shfl(ns[0], 1, 64);
+  double rew;
+  if (e.reward_form == 0) rew = fabs(n0 - s_old[0]) / 0.05 - 0.1 * sq;
+  else rew = (sqrt(n0 * n0 + n1 * n1) + 1.0) - 0.5 * sq;
+  int d = 0;
+  if (e.wall_terminate && n0 <= -3.0) { rew = 0.0; d = 1; }
+  const int tep = e.t_ep[n] + 1;
+  if (tep >= e.max_steps) d = 1;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int i = lane + r * WAVE;
+    if (i < O) {
+      double v = ns[r];
+      if (d) v = (unit_uniform(key, ctr + 1u, (uint32_t)(O + i)) - 0.5) * 0.2;   // auto-reset draw
+      e.s[(size_t)n * O + i] = v;
+    }
+  }
+  if (lane == 0) {
+    e.t_ep[n] = d ? 0 : tep;
+    e.step_count[n] = ctr + 1u;
+  }
+  reward = rew;
+  done = d;
+}
+
+// =================================================================================================================
+// kernel A: policy forward + env step + cost + pre-normaliser buffer fields, one workgroup per env
+// =================================================================================================================
+struct ActStepArgs {
+  icrl_env_t env;
+  icrl_costnet_t cn;
+  icrl_buffer_t buf;
+  icrl_agent_t ag;
+  PolLayout pl;
+  CnLayout cl;
+  const float* PT;
+  const float* noise;   // [T,N,act] (or [T,N] uniforms when discrete)
+  const float* alow;
+  const float* ahigh;
+  int has_cn;
+};
+
+__global__ void __launch_bounds__(192) act_step_kernel(ActStepArgs a, int t) {
+  __shared__ ActShared sh;
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs;
+  const int AS = a.buf.act_store;
+  for (int i = tid; i < O; i += 192) {
+    sh.x[i] = (float)a.ag.last_obs[(size_t)n * O + i];     // preprocess_obs: .float()
+    sh.s_old[i] = a.env.s[(size_t)n * O + i];
+  }
+  __syncthreads();
+  const size_t tn = (size_t)t * N + n;
+  const float* noise_row = a.noise + tn * (a.pl.discrete ? 1 : A);
+  policy_forward_block(a.pl, a.PT, sh, noise_row, 0, a.alow, a.ahigh);
+  __syncthreads();
+  if (w == 0) {
+    double rew; int done;
+    env_step_wave(a.env, n, sh.s_old, sh.act_clip, rew, done);
+    float* nob = a.buf.new_orig_observations + tn * O;
+    for (int i = lane; i < O; i += WAVE) nob[i] = (float)a.env.s[(size_t)n * O + i];
+    if (lane == 0) { a.ag.raw_rew[n] = rew; a.ag.dones[n] = (uint8_t)done; }
+  } else if (w == 1) {
+    float cost = 0.f;
+    if (a.has_cn) cost = cost_forward_wave(a.cn, a.cl, sh.s_old, sh.act_clip, sh.cx, sh.ch);
+    if (lane == 0) { a.ag.raw_cost[n] = cost; a.buf.orig_costs[tn] = cost; }
+  } else {
+    float* ob = a.buf.observations + tn * O;
+    float* oob = a.buf.orig_observations + tn * O;
+    for (int i = lane; i < O; i += WAVE) { ob[i] = sh.x[i]; oob[i] = (float)sh.s_old[i]; }
+    if (lane < AS) a.buf.actions[tn * AS + lane] = sh.act_raw[lane];
+    if (lane < A && !a.pl.discrete) a.ag.act_clipped[(size_t)n * A + lane] = sh.act_clip[lane];
+    if (lane == 0) {
+      a.buf.dones[tn] = (float)a.ag.last_dones[n];
+      a.buf.reward_values[tn] = sh.scal[0];
+      a.buf.cost_values[tn] = sh.scal[1];
+      a.buf.log_probs[tn] = sh.scal[2];
+      a.ag.last_v_r[n] = sh.scal[0];
+      a.ag.last_v_c[n] = sh.scal[1];
+    }
+  }
+}
+
+// =================================================================================================================
+// kernel B: VecNormalizeWithCost.step_wait for all envs, one workgroup
+// =================================================================================================================
+struct NormStepArgs {
+  icrl_norm_t nm;
+  const double* raw_obs;   // [N,O]
+  const double* raw_rew;   // [N]
+  const float* raw_cost;   // [N] or NULL
+  const uint8_t* dones;    // [N]
+  int N, O;
+  double* obs_out;         // [N,O] float64 or NULL
+  double* rew_out;         // [N] or NULL
+  double* cost_out;        // [N] or NULL
+  float* obs_f32;          // buffer.new_observations[t] or NULL
+  float* rew_f32;          // buffer.rewards[t] or NULL
+  float* cost_f32;         // buffer.costs[t] or NULL
+  uint8_t* last_dones;     // [N] or NULL: receives dones
+};
+
+// Chan merge with the reference's operation order (running_mean_std.py:25-39).
+__device__ __forceinline__ void chan_merge(double& mean, double& var, double count, double b_mean, double b_var,
+                                           double b_count) {
+  const double delta = b_mean - mean;
+  const double tot = count + b_count;
+  const double new_mean = mean + delta * b_count / tot;
+  const double m_a = var * count;
+  const double m_b = b_var * b_count;
+  const double m_2 = m_a + m_b + (delta * delta) * count * b_count / (count + b_count);
+  mean = new_mean;
+  var = m_2 / (count + b_count);
+}
+
+// ---- numpy-ordered 1-D sum, parallelised without changing the rounding order -------------------------------------
+// np.sum of a contiguous float64 vector splits recursively (n2 = n/2 rounded down to a multiple of 8) until blocks of
+// <= 128 elements, sums each block with 8 strided accumulators + a fixed combine tree + sequential tail, and adds the
+// block results back up the recursion.  Blocks and accumulators are independent, so (block, accumulator) pairs map to
+// threads; only the tiny combine runs on one thread.
+constexpr int NORM_MAX_N = 1024;                 // envs handled by the single-workgroup normaliser
+constexpr int NORM_MAX_LEAVES = NORM_MAX_N / 64 + 2;
+constexpr int NORM_CHUNK = 4096;                 // doubles of raw obs staged in LDS per pass
+
+struct NormShared {
+  double chunk[NORM_CHUNK];
+  double vec[2][NORM_MAX_N];                     // ret / cost_ret (then their squared deviations)
+  double part[2][NORM_MAX_LEAVES][8];
+  double leaf[2][NORM_MAX_LEAVES];
+  double total[2];
+  int leaf_off[NORM_MAX_LEAVES], leaf_len[NORM_MAX_LEAVES], n_leaves;
+};
+
+__device__ inline double np_combine(int l, const double* leaf, int& idx) {
+  if (l <= 128) return leaf[idx++];
+  int n2 = l / 2;
+  n2 -= n2 % 8;
+  const double a = np_combine(n2, leaf, idx);
+  const double b = np_combine(l - n2, leaf, idx);
+  return a + b;
+}
+
+// sums sh.vec[0][0:n] and (if two) sh.vec[1][0:n] into sh.total[]; all threads of the block must call.
+__device__ inline void block_np_sum(NormShared& sh, int n, bool two) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  if (tid == 0) {
+    int so[16], sl[16], sp = 1, cnt = 0;
+    so[0] = 0; sl[0] = n;
+    while (sp) {
+      --sp;
+      const int o = so[sp], l = sl[sp];
+      if (l <= 128) { sh.leaf_off[cnt] = o; sh.leaf_len[cnt] = l; ++cnt; }
+      else { int n2 = l / 2; n2 -= n2 % 8; so[sp] = o + n2; sl[sp] = l - n2; ++sp; so[sp] = o; sl[sp] = n2; ++sp; }
+    }
+    sh.n_leaves = cnt;
+  }
+  __syncthreads();
+  const int nl = sh.n_leaves, nv = two ? 2 : 1;
+  for (int job = tid; job < nv * nl * 8; job += nt) {
+    const int v = job / (nl * 8), L = (job / 8) % nl, k = job % 8;
+    const int o = sh.leaf_off[L], l = sh.leaf_len[L];
+    const double* a = sh.vec[v] + o;
+    if (l >= 8) {
+      double r = a[k];
+      for (int i = 8; i < l - (l % 8); i += 8) r += a[i + k];
+      sh.part[v][L][k] = r;
+    }
+  }
+  __syncthreads();
+  for (int job = tid; job < nv * nl; job += nt) {
+    const int v = job / nl, L = job % nl;
+    const int o = sh.leaf_off[L], l = sh.leaf_len[L];
+    const double* a = sh.vec[v] + o;
+    double res;
+    if (l < 8) {
+      res = 0.0;
+      for (int i = 0; i < l; ++i) res += a[i];
+    } else {
+      const double* r = sh.part[v][L];
+      res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+      for (int i = l - (l % 8); i < l; ++i) res += a[i];
+    }
+    sh.leaf[v][L] = res;
+  }
+  __syncthreads();
+  if (tid < nv) { int idx = 0; sh.total[tid] = np_combine(n, sh.leaf[tid], idx); }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(1024) norm_step_kernel(NormStepArgs a) {
+  __shared__ NormShared sh;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int N = a.N, O = a.O;
+  const icrl_norm_t& nm = a.nm;
+  const bool has_cost = a.raw_cost != nullptr;
+  if (nm.training) {
+    // ---- discounted returns (vec_normalize.py:102-105, 245-248), then np.mean / np.var of them
+    for (int n = tid; n < N; n += nt) {
+      const double r = nm.ret[n] * nm.reward_gamma + a.raw_rew[n];
+      nm.ret[n] = r; sh.vec[0][n] = r;
+      if (has_cost) { const double c = nm.cost_ret[n] * nm.cost_gamma + (double)a.raw_cost[n]; nm.cost_ret[n] = c; sh.vec[1][n] = c; }
+    }
+    __syncthreads();
+    block_np_sum(sh, N, has_cost);
+    const double bm_r = sh.total[0] / (double)N, bm_c = sh.total[1] / (double)N;
+    __syncthreads();
+    for (int n = tid; n < N; n += nt) {
+      const double d = sh.vec[0][n] - bm_r; sh.vec[0][n] = d * d;
+      if (has_cost) { const double e = sh.vec[1][n] - bm_c; sh.vec[1][n] = e * e; }
+    }
+    __syncthreads();
+    block_np_sum(sh, N, has_cost);
+    if (tid == 0) {
+      double m = nm.ret_stats[0], v = nm.ret_stats[1];
+      chan_merge(m, v, nm.ret_stats[2], bm_r, sh.total[0] / (double)N, (double)N);
+      nm.ret_stats[0] = m; nm.ret_stats[1] = v; nm.ret_stats[2] = (double)N + nm.ret_stats[2];
+      if (has_cost) {
+        m = nm.cost_stats[0]; v = nm.cost_stats[1];
+        chan_merge(m, v, nm.cost_stats[2], bm_c, sh.total[1] / (double)N, (double)N);
+        nm.cost_stats[0] = m; nm.cost_stats[1] = v; nm.cost_stats[2] = (double)N + nm.cost_stats[2];
+      }
+    }
+    // ---- obs_rms.update: numpy's axis-0 reduction adds the rows in order; rows are staged through LDS in chunks
+    // (coalesced, all threads) and one thread per column accumulates them sequentially.
+    const int rows_per = NORM_CHUNK / O;
+    double sum = 0.0, bm = 0.0;
+    for (int pass = 0; pass < 2; ++pass) {
+      sum = 0.0;
+      for (int r0 = 0; r0 < N; r0 += rows_per) {
+        const int rows = (N - r0) < rows_per ? (N - r0) : rows_per;
+        __syncthreads();
+        for (int i = tid; i < rows * O; i += nt) sh.chunk[i] = a.raw_obs[(size_t)r0 * O + i];
+        __syncthreads();
+        if (tid < O) {
+          if (pass == 0) for (int r = 0; r < rows; ++r) sum += sh.chunk[r * O + tid];
+          else for (int r = 0; r < rows; ++r) { const double d = sh.chunk[r * O + tid] - bm; sum += d * d; }
+        }
+      }
+      if (pass == 0) bm = sum / (double)N;
+    }
+    if (tid < O) {
+      double m = nm.obs_mean[tid], v = nm.obs_var[tid];
+      chan_merge(m, v, nm.obs_count[0], bm, sum / (double)N, (double)N);
+      nm.obs_mean[tid] = m; nm.obs_var[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) nm.obs_count[0] = (double)N + nm.obs_count[0];
+    __threadfence_block();
+    __syncthreads();
+  }
+  // ---- normalise + clip (vec_normalize.py:107-123, 254-261)
+  for (int idx = tid; idx < N * O; idx += nt) {
+    const int j = idx % O;
+    double o = a.raw_obs[idx];
+    if (nm.norm_obs) o = fmin(fmax((o - nm.obs_mean[j]) / sqrt(nm.obs_var[j] + nm.epsilon), -nm.clip_obs), nm.clip_obs);
+    if (a.obs_out) a.obs_out[idx] = o;
+    if (a.obs_f32) a.obs_f32[idx] = (float)o;
+  }
+  const double rden = sqrt(nm.ret_stats[1] + nm.epsilon);
+  const double cden = sqrt(nm.cost_stats[1] + nm.epsilon);
+  for (int n = tid; n < N; n += nt) {
+    double r = a.raw_rew[n];
+    if (nm.norm_reward) r = fmin(fmax(r / rden, -nm.clip_reward), nm.clip_reward);
+    if (a.rew_out) a.rew_out[n] = r;
+    if (a.rew_f32) a.rew_f32[n] = (float)r;
+    const int d = a.dones[n];
+    if (d) nm.ret[n] = 0.0;
+    if (has_cost) {
+      double c = (double)a.raw_cost[n];
+      if (nm.norm_cost) c = fmin(fmax(c / cden, -nm.clip_cost), nm.clip_cost);
+      if (a.cost_out) a.cost_out[n] = c;
+      if (a.cost_f32) a.cost_f32[n] = (float)c;
+      if (d) nm.cost_ret[n] = 0.0;
+    }
+    if (a.last_dones) a.last_dones[n] = (uint8_t)d;
+  }
+}
+
+// VecNormalizeWithCost.reset (vec_normalize.py:148-157, 270-278)
+__global__ void __launch_bounds__(1024) norm_reset_kernel(icrl_norm_t nm, const double* raw_obs, int N, int O,
+                                                          double* obs_out) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int n = tid; n < N; n += nt) { nm.ret[n] = 0.0; nm.cost_ret[n] = 0.0; }
+  __syncthreads();
+  if (nm.training && tid == 0) {
+    // ret = ret * gamma + ret = 0 -> update with a zero batch: mean 0, var 0, count N
+    double m = nm.ret_stats[0], v = nm.ret_stats[1];
+    chan_merge(m, v, nm.ret_stats[2], 0.0, 0.0, (double)N);
+    nm.ret_stats[0] = m; nm.ret_stats[1] = v; nm.ret_stats[2] = (double)N + nm.ret_stats[2];
+    m = nm.cost_stats[0]; v = nm.cost_stats[1];
+    chan_merge(m, v, nm.cost_stats[2], 0.0, 0.0, (double)N);
+    nm.cost_stats[0] = m; nm.cost_stats[1] = v; nm.cost_stats[2] = (double)N + nm.cost_stats[2];
+  }
+  for (int idx = tid; idx < N * O; idx += nt) {
+    const int j = idx % O;
+    double o = raw_obs[idx];
+    if (nm.norm_obs) o = fmin(fmax((o - nm.obs_mean[j]) / sqrt(nm.obs_var[j] + nm.epsilon), -nm.clip_obs), nm.clip_obs);
+    obs_out[idx] = o;
+  }
+}
+
+// =================================================================================================================
+// fine-grained kernels behind the per-call C ABI
+// =================================================================================================================
+__global__ void __launch_bounds__(192) policy_forward_kernel(PolLayout pl, const float* PT, const double* obs,
+                                                             const float* noise, int deterministic, const float* alow,
+                                                             const float* ahigh, float* actions, float* act_clipped,
+                                                             float* v_r, float* v_c, float* log_prob) {
+  __shared__ ActShared sh;
+  const int n = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < pl.O; i += 192) sh.x[i] = (float)obs[(size_t)n * pl.O + i];
+  __syncthreads();
+  const float* noise_row = noise ? noise + (size_t)n * (pl.discrete ? 1 : pl.A) : nullptr;
+  policy_forward_block(pl, PT, sh, noise_row, deterministic || noise == nullptr, alow, ahigh);
+  __syncthreads();
+  const int AS = pl.discrete ? 1 : pl.A;
+  if (tid < AS) {
+    if (actions) actions[(size_t)n * AS + tid] = sh.act_raw[tid];
+    if (act_clipped) act_clipped[(size_t)n * AS + tid] = sh.act_clip[tid];
+  }
+  if (tid == 0) {
+    if (v_r) v_r[n] = sh.scal[0];
+    if (v_c) v_c[n] = sh.scal[1];
+    if (log_prob) log_prob[n] = sh.scal[2];
+  }
+}
+
+__global__ void __launch_bounds__(64) cost_forward_kernel(icrl_costnet_t cn, CnLayout cl, const double* obs,
+                                                          const float* acs, int N, float* cost) {
+  __shared__ float cx[MAX_CN_IN];
+  __shared__ float ch[2][MAX_H];
+  const int n = blockIdx.x;
+  const int AS = cn.is_discrete ? 1 : cn.acs_dim;
+  const float c = cost_forward_wave(cn, cl, obs + (size_t)n * cn.obs_dim, acs + (size_t)n * AS, cx, ch);
+  if (threadIdx.x == 0) cost[n] = c;
+}
+
+__global__ void __launch_bounds__(64) env_step_kernel(icrl_env_t e, const float* actions, double* raw_rew, uint8_t* dones) {
+  __shared__ double s_old[MAX_OBS];
+  const int n = blockIdx.x;
+  for (int i = threadIdx.x; i < e.obs_dim; i += WAVE) s_old[i] = e.s[(size_t)n * e.obs_dim + i];
+  __syncthreads();
+  double rew; int done;
+  env_step_wave(e, n, s_old, actions + (size_t)n * e.act_dim, rew, done);
+  if (threadIdx.x == 0) { raw_rew[n] = rew; dones[n] = (uint8_t)done; }
+}
+
+__global__ void env_reset_kernel(icrl_env_t e) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int O = e.obs_dim;
+  if (idx < e.n_envs * O) {
+    const int n = idx / O, i = idx % O;
+    e.s[idx] = (unit_uniform(e.key[n], e.step_count[n], (uint32_t)(O + i)) - 0.5) * 0.2;
+    if (i == 0) e.t_ep[n] = 0;
+  }
+}
+
+static bool dims_ok(int O, int A, int H1, int H2) {
+  return O > 0 && O <= MAX_OBS && A > 0 && A <= MAX_ACT && H1 > 0 && H1 <= MAX_H && H2 > 0 && H2 <= MAX_H;
+}
+static bool cn_ok(const icrl_costnet_t* cn) {
+  return cn->in_dim > 0 && cn->in_dim <= MAX_CN_IN && cn->h1 > 0 && cn->h1 <= MAX_H && (cn->n_hidden == 1 ||
+         (cn->n_hidden == 2 && cn->h2 > 0 && cn->h2 <= MAX_H)) && cn->obs_dim <= MAX_OBS && cn->acs_dim <= MAX_ACT;
+}
+
+}  // namespace icrl
+
+using namespace icrl;
+
+extern "C" int icrl_policy_prepare(const icrl_policy_t* p, void* stream) {
+  if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return (int)hipErrorInvalidValue;
+  PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
+  if (L.n != p->n_params) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(policy_transpose_kernel, dim3((L.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, p->params, p->params_t);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream) {
+  if (!cn_ok(cn)) return (int)hipErrorInvalidValue;
+  CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
+  if (L.n != cn->n_params) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(costnet_transpose_kernel, dim3((L.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, cn->params, cn->params_t);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_policy_forward(const icrl_policy_t* p, const double* obs, const float* noise, int N, int deterministic,
+                                   const float* action_low, const float* action_high, float* actions, float* act_clipped,
+                                   float* v_r, float* v_c, float* log_prob, void* stream) {
+  if (N <= 0 || !dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return (int)hipErrorInvalidValue;
+  PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
+  hipLaunchKernelGGL(policy_forward_kernel, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, noise,
+                     deterministic, action_low, action_high, actions, act_clipped, v_r, v_c, log_prob);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_cost_mlp_forward(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* cost,
+                                     void* stream) {
+  if (N <= 0 || !cn_ok(cn)) return (int)hipErrorInvalidValue;
+  CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
+  hipLaunchKernelGGL(cost_forward_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_synth_env_reset(const icrl_env_t* env, void* stream) {
+  if (env->obs_dim > MAX_OBS || env->act_dim > MAX_ACT) return (int)hipErrorInvalidValue;
+  const int total = env->n_envs * env->obs_dim;
+  hipLaunchKernelGGL(env_reset_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *env);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_synth_env_step(const icrl_env_t* env, const float* actions, double* raw_rew, uint8_t* dones, void* stream) {
+  if (env->obs_dim > MAX_OBS || env->act_dim > MAX_ACT) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(env_step_kernel, dim3(env->n_envs), dim3(64), 0, (hipStream_t)stream, *env, actions, raw_rew, dones);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_vecnorm_reset(const icrl_norm_t* nm, const double* raw_obs, int N, int obs_dim, double* obs_out, void* stream) {
+  if (N <= 0 || N > NORM_MAX_N || obs_dim > MAX_OBS) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(norm_reset_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *nm, raw_obs, N, obs_dim, obs_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_vecnorm_step(const icrl_norm_t* nm, const double* raw_obs, const double* raw_rew, const float* raw_cost,
+                                 const uint8_t* dones, int N, int obs_dim, double* obs_out, double* rew_out, double* cost_out,
+                                 void* stream) {
+  if (N <= 0 || N > NORM_MAX_N || obs_dim > MAX_OBS) return (int)hipErrorInvalidValue;
+  NormStepArgs a{*nm, raw_obs, raw_rew, raw_cost, dones, N, obs_dim, obs_out, rew_out, cost_out, nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(norm_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol,
+                                    const icrl_costnet_t* cn, const icrl_buffer_t* buf, const icrl_agent_t* ag,
+                                    const float* noise, const float* action_low, const float* action_high,
+                                    double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
+                                    void* stream) {
+  const int N = env->n_envs, O = env->obs_dim, T = buf->T;
+  if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2) || pol->obs_dim != O || buf->N != N || buf->obs_dim != O)
+    return (int)hipErrorInvalidValue;
+  if (cn != nullptr && !cn_ok(cn)) return (int)hipErrorInvalidValue;
+  if (N > NORM_MAX_N) return (int)hipErrorInvalidValue;
+  hipStream_t s = (hipStream_t)stream;
+  ActStepArgs a;
+  a.env = *env; a.buf = *buf; a.ag = *ag;
+  a.pl = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);
+  a.PT = pol->params_t; a.noise = noise; a.alow = action_low; a.ahigh = action_high;
+  a.has_cn = cn != nullptr;
+  if (cn) { a.cn = *cn; a.cl = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2); }
+  for (int t = 0; t < T; ++t) {
+    hipLaunchKernelGGL(act_step_kernel, dim3(N), dim3(192), 0, s, a, t);
+    const size_t row = (size_t)t * N;
+    NormStepArgs b{*nm, env->s, ag->raw_rew, cn ? ag->raw_cost : nullptr, ag->dones, N, O, ag->last_obs, nullptr, nullptr,
+                   buf->new_observations + row * O, buf->rewards + row, buf->costs + row, ag->last_dones};
+    hipLaunchKernelGGL(norm_step_kernel, dim3(1), dim3(1024), 0, s, b);
+  }
+  int err = (int)hipGetLastError();
+  if (err) return err;
+  return icrl_gae_dual(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
+                       ag->last_v_c, ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns,
+                       buf->cost_returns, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, stream);
+}

@@ -1,0 +1,199 @@
+"""PPOLagrangian — PPO-clip with a Lagrangian cost term and two critics, device-resident.
+
+ref: stable_baselines3/ppo_lag/ppo_lag.py:17-365 (PPOLagrangian: __init__, _setup_model, train, learn)
+     stable_baselines3/common/on_policy_algorithm.py:258-497 (OnPolicyWithCostAlgorithm: collect_rollouts, learn)
+     stable_baselines3/common/base_class.py:303-366 (_setup_learn: env reset on every learn())
+
+The host keeps the reference's control flow and attribute names (num_timesteps, rollout_buffer, dual, policy, ...);
+the work is enqueued as kernels of libicrl_hip.so:
+  collect_rollouts -> icrl_rollout_collect (2 launches per env step + dual GAE, no host sync)
+  train            -> icrl_ppo_lag_train   (ONE persistent launch for all epochs x minibatches) + icrl_dual_step
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import _lib, logger, spaces
+from .buffers import RolloutBufferWithCost
+from .dual_variable import DualVariable, PIDLagrangian
+from .policies import ActorTwoCriticsPolicy
+from .structs import AgentT, p
+from .vec_env import HipSynthVecEnv, VecCostWrapper, VecEnv, VecNormalize, VecNormalizeWithCost
+
+
+def _const_fn(v):
+    return v if callable(v) else (lambda _progress: v)
+
+
+class PPOLagrangian:
+    def __init__(self, policy, env, algo_type="lagrangian", learning_rate=3e-4, n_steps=2048, batch_size=64, n_epochs=10,
+                 reward_gamma=0.99, reward_gae_lambda=0.95, cost_gamma=0.99, cost_gae_lambda=0.95, clip_range=0.2,
+                 clip_range_reward_vf=None, clip_range_cost_vf=None, ent_coef=0.0, reward_vf_coef=0.5, cost_vf_coef=0.5,
+                 max_grad_norm=0.5, use_sde=False, sde_sample_freq=-1, target_kl=None, penalty_initial_value=1,
+                 penalty_learning_rate=0.01, penalty_min_value=None, update_penalty_after=1, budget=0.,
+                 tensorboard_log=None, create_eval_env=False, pid_kwargs=None, policy_kwargs=None, verbose=0, seed=None,
+                 device="cuda", _init_setup_model=True, action_noise="device", permutation="numpy"):
+        if use_sde:
+            raise NotImplementedError("gSDE is outside the hot path (no BASELINE config uses it)")
+        if policy not in ("TwoCriticsMlpPolicy", ActorTwoCriticsPolicy):
+            raise NotImplementedError(f"policy {policy!r}: only TwoCriticsMlpPolicy is on the ICRL hot path")
+        self.env: VecEnv = env
+        self.n_envs = env.num_envs
+        self.observation_space, self.action_space = env.observation_space, env.action_space
+        self.device = torch.device("cuda" if device in ("auto", "cpu", None) else device)
+        self.algo_type, self.learning_rate, self.n_steps = algo_type, learning_rate, n_steps
+        self.batch_size, self.n_epochs = batch_size, n_epochs
+        self.reward_gamma, self.reward_gae_lambda = reward_gamma, reward_gae_lambda
+        self.cost_gamma, self.cost_gae_lambda = cost_gamma, cost_gae_lambda
+        self.clip_range, self.clip_range_reward_vf, self.clip_range_cost_vf = clip_range, clip_range_reward_vf, clip_range_cost_vf
+        self.ent_coef, self.reward_vf_coef, self.cost_vf_coef, self.max_grad_norm = ent_coef, reward_vf_coef, cost_vf_coef, max_grad_norm
+        self.target_kl = target_kl
+        self.penalty_initial_value, self.penalty_learning_rate = penalty_initial_value, penalty_learning_rate
+        self.penalty_min_value, self.update_penalty_after, self.budget = penalty_min_value, update_penalty_after, budget
+        self.pid_kwargs, self.policy_kwargs = pid_kwargs, {} if policy_kwargs is None else policy_kwargs
+        self.verbose, self.seed = verbose, seed
+        # how the two random streams of the hot path are produced (both are explicit kernel inputs):
+        #   action_noise: "device" (torch.randn on the GPU) | "torch_cpu" (global CPU generator, one call per step: the
+        #                 reference's stream) | callable(T, N, A) -> array
+        #   permutation:  "numpy" (np.random.permutation per epoch: the reference's stream) | "device" | callable
+        self.action_noise, self.permutation = action_noise, permutation
+        self.num_timesteps, self._n_updates, self._total_timesteps = 0, 0, 0
+        self._current_progress_remaining = 1
+        self._last_obs = self._last_original_obs = self._last_dones = None
+        self.start_time = None
+        self._vec_normalize_env = env if isinstance(env, VecNormalize) else None
+        if _init_setup_model:
+            self._setup_model()
+
+    # ref: on_policy_algorithm.py:313-338, ppo_lag.py:147-175, common/utils.py:23-39
+    def _setup_model(self):
+        self.lr_schedule = _const_fn(self.learning_rate)
+        if self.seed is not None:
+            import random
+            random.seed(self.seed); np.random.seed(self.seed); torch.manual_seed(self.seed)
+            self.action_space.seed(self.seed)
+            self.env.seed(self.seed)
+        self.rollout_buffer = RolloutBufferWithCost(self.n_steps, self.observation_space, self.action_space, self.device,
+                                                    self.reward_gamma, self.reward_gae_lambda, self.cost_gamma,
+                                                    self.cost_gae_lambda, n_envs=self.n_envs)
+        self.policy = ActorTwoCriticsPolicy(self.observation_space, self.action_space, self.lr_schedule,
+                                            device=self.device, **self.policy_kwargs)
+        if self.algo_type == "lagrangian":
+            self.dual = DualVariable(self.budget, self.penalty_learning_rate, self.penalty_initial_value, self.penalty_min_value)
+        elif self.algo_type == "pidlagrangian":
+            self.dual = PIDLagrangian(**{k: self.pid_kwargs[k] for k in ("alpha", "penalty_init", "Kp", "Ki", "Kd", "pid_delay",
+                                                                         "delta_p_ema_alpha", "delta_d_ema_alpha")})
+        else:
+            raise ValueError("Unrecognized value for argument 'algo_type' in PPOLagrangian")
+        self.clip_range = _const_fn(self.clip_range)
+        if self.clip_range_reward_vf is not None:
+            self.clip_range_reward_vf = _const_fn(self.clip_range_reward_vf)
+        if self.clip_range_cost_vf is not None:
+            self.clip_range_cost_vf = _const_fn(self.clip_range_cost_vf)
+        N, dev = self.n_envs, self.device
+        A = 1 if isinstance(self.action_space, spaces.Discrete) else self.action_space.shape[0]
+        self._ag = dict(last_dones=torch.zeros(N, dtype=torch.uint8, device=dev), raw_rew=torch.zeros(N, dtype=torch.float64, device=dev),
+                        raw_cost=torch.zeros(N, device=dev), dones=torch.zeros(N, dtype=torch.uint8, device=dev),
+                        last_v_r=torch.zeros(N, device=dev), last_v_c=torch.zeros(N, device=dev),
+                        act_clipped=torch.zeros(N, A, device=dev))
+        if isinstance(self.action_space, spaces.Box):
+            self._alow = torch.as_tensor(self.action_space.low, device=dev).float().contiguous()
+            self._ahigh = torch.as_tensor(self.action_space.high, device=dev).float().contiguous()
+        else:
+            self._alow = self._ahigh = None
+
+    # ---- env-chain introspection: is this the device-native stack the fused rollout handles? ---------------------------
+    def _fused_chain(self):
+        env = self.env
+        if not isinstance(env, VecNormalizeWithCost):
+            return None
+        cw = env.venv
+        if not isinstance(cw, VecCostWrapper) or not isinstance(cw.venv, HipSynthVecEnv) or cw.constraint_net() is None:
+            return None
+        return env, cw, cw.venv
+
+    # ---- noise / permutation streams -------------------------------------------------------------------------------------
+    def _draw_action_noise(self, T):
+        N = self.n_envs
+        disc = isinstance(self.action_space, spaces.Discrete)
+        shape = (T, N) if disc else (T, N, self.action_space.shape[0])
+        if callable(self.action_noise):
+            return torch.as_tensor(np.asarray(self.action_noise(*shape), np.float32), device=self.device).reshape(shape).contiguous()
+        if self.action_noise == "torch_cpu":        # one generator call per env step, like Normal.rsample in the reference
+            rows = [torch.rand(shape[1:]) if disc else torch.randn(shape[1:]) for _ in range(T)]
+            return torch.stack(rows).to(self.device).contiguous()
+        return (torch.rand(shape, device=self.device) if disc else torch.randn(shape, device=self.device)).contiguous()
+
+    # ---- rollout ---------------------------------------------------------------------------------------------------------
+    def collect_rollouts(self, env, callback, rollout_buffer, n_rollout_steps, cost_function="cost", noise=None):
+        """ref: on_policy_algorithm.py:340-421."""
+        assert self._last_obs is not None, "No previous observation was provided"
+        chain = self._fused_chain()
+        if chain is None or not isinstance(cost_function, str) or n_rollout_steps != rollout_buffer.buffer_size:
+            raise NotImplementedError("generic (host-stepped) rollout path is not wired yet; use the device env stack")
+        rollout_buffer.reset()
+        if callback is not None:
+            callback.on_rollout_start()
+        nenv, cw, senv = chain
+        if noise is None:
+            noise = self._draw_action_noise(n_rollout_steps)
+        e, nm, pol, cn, buf = senv.struct(), nenv.struct(), self.policy.struct(), cw.constraint_net().struct(), rollout_buffer.struct()
+        ag = AgentT(p(self._last_obs), p(self._ag["last_dones"]), p(self._ag["raw_rew"]), p(self._ag["raw_cost"]), p(self._ag["dones"]),
+                    p(self._ag["last_v_r"]), p(self._ag["last_v_c"]), p(self._ag["act_clipped"]))
+        b = _lib.byref
+        _lib.check(_lib.lib().icrl_rollout_collect(b(e), b(nm), b(pol), b(cn), b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
+                                                   float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
+                                                   float(self.cost_gae_lambda), _lib.current_stream()), "icrl_rollout_collect")
+        self._keepalive = (noise,)
+        rollout_buffer.pos, rollout_buffer.full = n_rollout_steps, True
+        self.num_timesteps += env.num_envs * n_rollout_steps
+        # wrapper-visible "last step" state, as the reference leaves it
+        nenv.old_obs, nenv.old_reward, nenv.old_cost = senv.s, self._ag["raw_rew"], self._ag["raw_cost"]
+        cw.previous_obs = senv.s
+        self._last_original_obs = senv.s
+        self._last_dones = self._ag["last_dones"]
+        if callback is not None:
+            callback.on_rollout_end()
+        return True
+
+    def _setup_learn(self, total_timesteps, reset_num_timesteps=True):
+        """ref: base_class.py:303-366."""
+        self.start_time = time.time()
+        if reset_num_timesteps:
+            self.num_timesteps = 0
+        else:
+            total_timesteps += self.num_timesteps
+        self._total_timesteps = total_timesteps
+        if reset_num_timesteps or self._last_obs is None:
+            self._last_obs = self.env.reset().contiguous()
+            self._ag["last_dones"].zero_()
+            self._last_dones = self._ag["last_dones"]
+            self._last_original_obs = self._vec_normalize_env.get_original_obs() if self._vec_normalize_env is not None else self._last_obs
+        return total_timesteps
+
+    def learn(self, total_timesteps, cost_function="cost", callback=None, log_interval=1, eval_env=None, eval_freq=-1,
+              n_eval_episodes=5, tb_log_name="PPOLagrangian", eval_log_path=None, reset_num_timesteps=True):
+        """ref: on_policy_algorithm.py:430-492."""
+        iteration = 0
+        total_timesteps = self._setup_learn(total_timesteps, reset_num_timesteps)
+        if callback is not None:
+            callback.init_callback(self)
+            callback.on_training_start(locals(), globals())
+        while self.num_timesteps < total_timesteps:
+            if self.collect_rollouts(self.env, callback, self.rollout_buffer, self.n_steps, cost_function) is False:
+                break
+            iteration += 1
+            self._current_progress_remaining = 1.0 - float(self.num_timesteps) / float(total_timesteps)
+            logger.record("time/iterations", iteration)
+            logger.record("time/total_timesteps", self.num_timesteps)
+            self.train()
+        if callback is not None:
+            callback.on_training_end()
+        return self
+
+    def predict(self, observation, state=None, mask=None, deterministic=False, noise=None):
+        return self.policy.predict(observation, state, mask, deterministic, noise)
+
+    def train(self):
+        raise NotImplementedError

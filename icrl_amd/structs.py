@@ -1,0 +1,51 @@
+"""ctypes mirrors of the plain-C descriptors in include/icrl_hip.h (host structs holding device pointers)."""
+import ctypes as C
+
+i32, f64, vp = C.c_int32, C.c_double, C.c_void_p
+
+
+class EnvT(C.Structure):
+    _fields_ = [("n_envs", i32), ("obs_dim", i32), ("act_dim", i32), ("max_steps", i32), ("reward_form", i32),
+                ("wall_terminate", i32), ("broken", i32), ("_pad", i32),
+                ("B", vp), ("s", vp), ("t_ep", vp), ("step_count", vp), ("key", vp)]
+
+
+class NormT(C.Structure):
+    _fields_ = [("training", i32), ("norm_obs", i32), ("norm_reward", i32), ("norm_cost", i32),
+                ("clip_obs", f64), ("clip_reward", f64), ("clip_cost", f64), ("reward_gamma", f64), ("cost_gamma", f64),
+                ("epsilon", f64),
+                ("obs_mean", vp), ("obs_var", vp), ("obs_count", vp), ("ret_stats", vp), ("cost_stats", vp),
+                ("ret", vp), ("cost_ret", vp)]
+
+
+class PolicyT(C.Structure):
+    _fields_ = [("obs_dim", i32), ("act_dim", i32), ("h1", i32), ("h2", i32), ("discrete", i32), ("n_params", i32),
+                ("params", vp), ("params_t", vp)]
+
+
+class CostNetT(C.Structure):
+    _fields_ = [("obs_dim", i32), ("acs_dim", i32), ("in_dim", i32), ("n_hidden", i32), ("h1", i32), ("h2", i32),
+                ("is_discrete", i32), ("n_params", i32),
+                ("clip_obs", f64), ("select_dim", vp), ("action_low", vp), ("action_high", vp), ("obs_mean", vp),
+                ("obs_var", vp), ("eps", f64), ("params", vp), ("params_t", vp)]
+
+
+class BufferT(C.Structure):
+    _fields_ = [("T", i32), ("N", i32), ("obs_dim", i32), ("act_store", i32),
+                ("observations", vp), ("new_observations", vp), ("orig_observations", vp), ("new_orig_observations", vp),
+                ("actions", vp), ("dones", vp), ("log_probs", vp), ("rewards", vp), ("reward_values", vp), ("costs", vp),
+                ("orig_costs", vp), ("cost_values", vp), ("reward_advantages", vp), ("reward_returns", vp),
+                ("cost_advantages", vp), ("cost_returns", vp)]
+
+
+class AgentT(C.Structure):
+    _fields_ = [("last_obs", vp), ("last_dones", vp), ("raw_rew", vp), ("raw_cost", vp), ("dones", vp),
+                ("last_v_r", vp), ("last_v_c", vp), ("act_clipped", vp)]
+
+
+def p(t):
+    """device pointer of a contiguous tensor (or None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_contiguous()
+    return t.data_ptr()

@@ -13,6 +13,8 @@
  *   - one host thread per GPU / process; re-entrant across devices, not thread-safe on shared buffers;
  *   - [T,N,...] arrays are time-major, contiguous, float32 unless stated (RolloutBufferWithCost layout,
  *     stable_baselines3/common/buffers.py:468-491).
+ *   - structs are plain C, passed by pointer to HOST memory (they hold device pointers + scalars) and are
+ *     only read during the call.
  */
 #ifndef ICRL_HIP_H
 #define ICRL_HIP_H
@@ -23,15 +25,104 @@
 extern "C" {
 #endif
 
-/* library / build identification: returns ABI version (major*100+minor). */
+/* ------------------------------------------------------------------------------------------------------------------
+ * Data descriptors
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* Synthetic HCWithPos- / AntWall-shaped vectorised environment (oracle/synth_env.py is the spec).
+ * Stands in for SubprocVecEnv + gym envs (stable_baselines3/common/vec_env/subproc_vec_env.py:14-50,104-113;
+ * custom_envs/envs/half_cheetah.py:138-195, ant.py:40-108): float64 state, time-limit dones, auto-reset. */
+typedef struct {
+  int32_t n_envs, obs_dim, act_dim, max_steps;
+  int32_t reward_form;    /* 0: |dx|/dt - 0.1|a|^2 (HC)   1: |xy| + 1 - 0.5|a|^2 (Ant) */
+  int32_t wall_terminate; /* "Test" variants: done & reward 0 when obs[0] <= -3 */
+  int32_t broken;         /* AntWallBroken: action[4:] = 0 */
+  int32_t _pad;
+  const double* B;        /* [obs_dim, act_dim] dynamics matrix */
+  double* s;              /* [N, obs_dim] raw state == last raw observation (== VecCostWrapper.previous_obs) */
+  int32_t* t_ep;          /* [N] step inside the episode */
+  uint32_t* step_count;   /* [N] counter of the per-env random stream */
+  const uint32_t* key;    /* [N] stream key = seed + global env index */
+} icrl_env_t;
+
+/* VecNormalizeWithCost state (stable_baselines3/common/vec_env/vec_normalize.py:9-181,184-278;
+ * RunningMeanStd: common/running_mean_std.py:6-39).  All float64 as in the reference. */
+typedef struct {
+  int32_t training, norm_obs, norm_reward, norm_cost;
+  double clip_obs, clip_reward, clip_cost, reward_gamma, cost_gamma, epsilon;
+  double* obs_mean;   /* [obs_dim] */
+  double* obs_var;    /* [obs_dim] */
+  double* obs_count;  /* [1] */
+  double* ret_stats;  /* [3] mean, var, count of ret_rms */
+  double* cost_stats; /* [3] mean, var, count of cost_rms */
+  double* ret;        /* [N] discounted reward return */
+  double* cost_ret;   /* [N] discounted cost return */
+} icrl_norm_t;
+
+/* ActorTwoCriticsPolicy parameters (stable_baselines3/common/policies.py:598-779): three tanh MLPs obs->h1->h2
+ * (pi, vf, cvf), heads h2->act / 1 / 1, state-independent log_std.  `params` is ONE flat float32 buffer in the
+ * reference's state_dict order: log_std[A] (absent when discrete), then for pi, vf, cvf: W1[h1,obs] b1[h1] W2[h2,h1]
+ * b2[h2], then action_net W[A,h2] b[A], value_net W[1,h2] b[1], cost_value_net W[1,h2] b[1]. */
+typedef struct {
+  int32_t obs_dim, act_dim, h1, h2;
+  int32_t discrete; /* 1: Categorical over act_dim logits (LGW), 0: DiagGaussian */
+  int32_t n_params;
+  float* params;     /* [n_params] */
+  float* params_t;   /* [n_params] transposed copy for the rollout kernels (written by icrl_policy_prepare) */
+} icrl_policy_t;
+
+/* ConstraintNet zeta_theta (icrl/constraint_net.py:14-130,258-299): ReLU MLP + sigmoid over
+ * concat(clip(obs), clip(acs))[select_dim]; cost = 1 - zeta.  n_hidden in {1,2}.  params flat in state_dict order:
+ * W0[h1,in] b0[h1] (W1[h2,h1] b1[h2]) Wo[1,h] bo[1]. */
+typedef struct {
+  int32_t obs_dim, acs_dim, in_dim, n_hidden, h1, h2;
+  int32_t is_discrete;  /* one-hot the action first */
+  int32_t n_params;
+  double clip_obs;           /* < 0: no clipping (what ConstraintNet.load builds, constraint_net.py:394-399) */
+  const int32_t* select_dim; /* [in_dim] indices into concat(obs, acs) */
+  const float* action_low;   /* [acs_dim] or NULL: no action clipping */
+  const float* action_high;  /* [acs_dim] or NULL */
+  const double* obs_mean;    /* [obs_dim] or NULL (--cn_normalize) */
+  const double* obs_var;     /* [obs_dim] or NULL */
+  double eps;
+  float* params;             /* [n_params] */
+  float* params_t;           /* [n_params] transposed copy (written by icrl_costnet_prepare) */
+} icrl_costnet_t;
+
+/* RolloutBufferWithCost arrays (stable_baselines3/common/buffers.py:443-491), time-major [T,N,...] float32. */
+typedef struct {
+  int32_t T, N, obs_dim, act_store; /* act_store = act_dim (Box) or 1 (Discrete) */
+  float *observations, *new_observations, *orig_observations, *new_orig_observations; /* [T,N,obs] */
+  float* actions;                                                                      /* [T,N,act_store] */
+  float *dones, *log_probs, *rewards, *reward_values, *costs, *orig_costs, *cost_values;
+  float *reward_advantages, *reward_returns, *cost_advantages, *cost_returns; /* [T,N] */
+} icrl_buffer_t;
+
+/* What OnPolicyWithCostAlgorithm carries between steps (common/on_policy_algorithm.py:367-416, base_class.py:346-353)
+ * plus per-step scratch. */
+typedef struct {
+  double* last_obs;      /* [N,obs] normalised observation fed to the policy (== _last_obs) */
+  uint8_t* last_dones;   /* [N] */
+  double* raw_rew;       /* [N] scratch: un-normalised reward of the step (== get_original_reward) */
+  float* raw_cost;       /* [N] scratch: zeta-cost of the step (== get_original_cost) */
+  uint8_t* dones;        /* [N] scratch: done flags of the step */
+  float* last_v_r;       /* [N] values of the last forward (GAE bootstrap, on_policy_algorithm.py:417) */
+  float* last_v_c;       /* [N] */
+  float* act_clipped;    /* [N,act] scratch: action handed to the env */
+} icrl_agent_t;
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Entry points
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* ABI version (major*100+minor). */
 int icrl_abi_version(void);
 
 /* Dual reward+cost GAE over a [T,N] rollout in ONE launch.
  * Replaces RolloutBufferWithCost.compute_returns_and_advantage / _compute_returns_and_advantage
  *   (stable_baselines3/common/buffers.py:493-552), including its dtype behaviour: float32 delta for t<T-1,
  *   float64 running advantage, float32 rounding on store, returns = adv + values in float32.
- * dones[t,n] is the done flag ENTERING step t (what the buffer stores); last_dones[n] is the final step's done flag (0/1 bytes).
- * last_v_r / last_v_c: [N] bootstrap values.  Outputs adv_*, ret_*: [T,N].
+ * dones[t,n] is the done flag ENTERING step t (what the buffer stores); last_dones[n] the final step's flag (0/1 bytes).
  * Algorithmic traffic: 36 B per transition (5 loads + 4 stores of 4 B). */
 int icrl_gae_dual(const float* rewards, const float* costs, const float* reward_values, const float* cost_values,
                   const float* dones, const float* last_v_r, const float* last_v_c, const uint8_t* last_dones,
@@ -39,13 +130,55 @@ int icrl_gae_dual(const float* rewards, const float* costs, const float* reward_
                   int T, int N, double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
                   void* stream);
 
-/* Same kernel with the launch shape forced (for the roofline sweep in bench.py / tests):
- * waves_per_tile in {1,4,16} time-chunks per 64-env column tile; 0 = library heuristic. */
+/* Same kernel with the launch shape forced (roofline sweep): waves_per_tile in {1,4,16}; 0 = library heuristic. */
 int icrl_gae_dual_ex(const float* rewards, const float* costs, const float* reward_values, const float* cost_values,
                      const float* dones, const float* last_v_r, const float* last_v_c, const uint8_t* last_dones,
                      float* adv_r, float* adv_c, float* ret_r, float* ret_c,
                      int T, int N, double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
                      int waves_per_tile, void* stream);
+
+/* Write the transposed ([in][out]) weight copies the rollout-time kernels read coalesced.  Call after every change of
+ * `params` (policy: after train(); cost net: after ConstraintNet.train / load). */
+int icrl_policy_prepare(const icrl_policy_t* pol, void* stream);
+int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream);
+
+/* ActorTwoCriticsPolicy.forward (policies.py:716-731) for N observations: sample (mean + noise*std, or inverse-CDF on
+ * `noise` uniforms when discrete; deterministic: mean / argmax), log-prob, both values.
+ * obs: [N,obs] float64 (cast to float32 like preprocess_obs, preprocessing.py:61).  noise: [N,act] standard normals
+ * ([N] uniforms when discrete) or NULL when deterministic.  actions: [N,act_store] unclipped; act_clipped: [N,act]
+ * clipped to [low,high] (on_policy_algorithm.py:381-382; NULL low/high: no clipping).  Any output may be NULL. */
+int icrl_policy_forward(const icrl_policy_t* pol, const double* obs, const float* noise, int N, int deterministic,
+                        const float* action_low, const float* action_high,
+                        float* actions, float* act_clipped, float* v_r, float* v_c, float* log_prob, void* stream);
+
+/* ConstraintNet.cost_function (icrl/constraint_net.py:121-130): cost[n] = 1 - zeta(prepare(obs[n], acs[n])).
+ * obs [N,obs] float64, acs [N,acs] float32 (class index in acs[n,0] when discrete). */
+int icrl_cost_mlp_forward(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* cost, void* stream);
+
+/* SynthVecEnv.reset / .step: the batched stand-in for SubprocVecEnv.step_async/step_wait.  step: actions [N,act] float32
+ * (already clipped), writes raw reward [N] float64 and done [N] bytes, advances env->s in place (auto-reset). */
+int icrl_synth_env_reset(const icrl_env_t* env, void* stream);
+int icrl_synth_env_step(const icrl_env_t* env, const float* actions, double* raw_rew, uint8_t* dones, void* stream);
+
+/* VecNormalizeWithCost.reset (vec_normalize.py:148-157,270-278): zero ret / cost_ret, feed a zero batch into ret_rms /
+ * cost_rms when training, write normalize_obs(raw_obs) to obs_out [N,obs] float64. */
+int icrl_vecnorm_reset(const icrl_norm_t* nm, const double* raw_obs, int N, int obs_dim, double* obs_out, void* stream);
+
+/* VecNormalizeWithCost.step_wait after the env + cost wrapper (vec_normalize.py:81-100,220-243): running-moment merge
+ * (obs, discounted reward return, discounted cost return), normalise + clip, zero the returns of finished envs.
+ * raw_cost may be NULL (env stack without cost wrapper).  Outputs float64 [N,obs] / [N] / [N] (cost_out may be NULL). */
+int icrl_vecnorm_step(const icrl_norm_t* nm, const double* raw_obs, const double* raw_rew, const float* raw_cost,
+                      const uint8_t* dones, int N, int obs_dim, double* obs_out, double* rew_out, double* cost_out,
+                      void* stream);
+
+/* OnPolicyWithCostAlgorithm.collect_rollouts (common/on_policy_algorithm.py:340-421) fused on the device: T steps of
+ * {policy forward -> clip -> env step -> cost_function(previous raw obs, action) -> VecNormalizeWithCost -> buffer.add},
+ * then the dual GAE.  noise: [T,N,act] standard normals.  2 launches per step + 1 for GAE, no host sync. */
+int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const icrl_costnet_t* cn,
+                         const icrl_buffer_t* buf, const icrl_agent_t* ag, const float* noise,
+                         const float* action_low, const float* action_high,
+                         double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
+                         void* stream);
 
 #ifdef __cplusplus
 }

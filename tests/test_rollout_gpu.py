@@ -1,0 +1,214 @@
+"""GPU parity of the rollout-time kernels (policy forward, env step, cost net, normaliser, fused collect) vs the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import loop as o_loop, nets as o_nets, stats as o_stats
+from oracle.synth_env import SynthVecEnv
+
+pytestmark = pytest.mark.gpu
+
+
+def _sub(g, prefix):
+    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+@pytest.mark.parametrize("kind,wall,broken", [("hc", False, False), ("ant", False, False), ("hc", True, False), ("ant", False, True)])
+def test_synth_env_bit_exact(kind, wall, broken):
+    from icrl_amd.vec_env import HipSynthVecEnv
+    N, steps = 7, 1100 if kind == "hc" else 600
+    cpu = SynthVecEnv(N, kind, seed=3, wall_terminate=wall, broken=broken)
+    gpu = HipSynthVecEnv(N, kind, seed=3, wall_terminate=wall, broken=broken)
+    assert np.array_equal(cpu.reset(), gpu.reset().cpu().numpy())
+    rng = np.random.RandomState(0)
+    for t in range(steps):
+        a = rng.uniform(-1, 1, (N, cpu.act_dim)).astype(np.float32)
+        if wall and t % 50 < 25:
+            a = -np.sign(cpu.B[0])[None].repeat(N, 0).astype(np.float32)      # drive obs[0] towards the wall
+        o, r, d = cpu.step(a)
+        go, gr, gd, _ = gpu.step(a)
+        assert np.array_equal(o, go.cpu().numpy()), t
+        assert np.array_equal(r, gr.cpu().numpy()), t
+        assert np.array_equal(d, gd.cpu().numpy().astype(bool)), t
+    if wall:
+        assert cpu.step_count.max() > 0
+
+
+@pytest.mark.parametrize("case", ["hc", "ant", "lgw", "antbroken"])
+def test_cost_function_golden(golden, case):
+    from icrl_amd.constraint_net import ConstraintNet
+    g = _sub(golden("g2_cost_function"), case + "/")
+    disc = case == "lgw"
+    od, ad = g["obs"].shape[1], (2 if disc else g["acs"].shape[1])
+    kw = dict(clip_obs=20, action_low=None if disc else -np.ones(ad, np.float32), action_high=None if disc else np.ones(ad, np.float32))
+    if case == "antbroken":
+        kw = dict(clip_obs=None, action_low=None, action_high=None)
+    cn = ConstraintNet(od, ad, list(g["hidden"]), None, lambda x: 0.05, None, None, disc, **kw)
+    assert cn.select_dim == list(g["select_dim"])
+    cn.load_state_dict({k[2:]: g[k] for k in g if k.startswith("w/")})
+    got = cn.cost_function(g["obs"], g["acs"])
+    # fp32 MLP: summation order / expf differ from torch-CPU by a few ulp
+    assert np.allclose(got, g["cost"], rtol=2e-5, atol=2e-6)
+
+
+def test_vecnormalize_stream_golden(golden):
+    """float64 statistics reproduce numpy's reduction order: bit-exact against the reference stream."""
+    from icrl_amd.vec_env import VecEnv, VecCostWrapper, VecNormalizeWithCost, BatchedInfos
+    from icrl_amd import spaces
+    g = golden("g3_vecnormalize")
+    S, N, D = g["obs"].shape
+    dev = torch.device("cuda")
+
+    class Replay(VecEnv):
+        def __init__(self):
+            super().__init__(N, spaces.Box(-np.inf, np.inf, (D,), np.float64), spaces.Box(-1, 1, (2,), np.float32))
+            self.t, self.device = 0, dev
+        def reset(self): return torch.as_tensor(g["reset_obs"], device=dev)
+        def step_async(self, a): pass
+        def step_wait(self):
+            t = self.t; self.t += 1
+            return (torch.as_tensor(g["obs"][t], device=dev), torch.as_tensor(g["rew"][t], device=dev),
+                    torch.as_tensor(g["done"][t].astype(np.uint8), device=dev), BatchedInfos(N))
+    venv = VecCostWrapper(Replay())
+    step = {"t": 0}
+    venv.set_cost_function(lambda o, a: g["costs"][step["t"]])
+    env = VecNormalizeWithCost(venv, reward_gamma=float(g["gammas"][0]), cost_gamma=float(g["gammas"][1]))
+    assert np.array_equal(env.reset().cpu().numpy(), g["reset_obs_n"])
+    for t in range(S):
+        step["t"] = t
+        o, r, d, infos = env.step(np.zeros((N, 2), np.float32))
+        assert np.array_equal(o.cpu().numpy(), g["obs_n"][t]), t
+        assert np.array_equal(r.cpu().numpy(), g["rew_n"][t]), t
+        assert np.array_equal(infos.batch["cost"].cpu().numpy(), g["cost_n"][t]), t
+        assert np.array_equal(env.obs_rms.var, g["obs_var"][t]) and env.ret_rms.var == g["ret_var"][t]
+        assert env.cost_rms.var == g["cost_var"][t] and env.cost_rms.count == g["cost_count"][t]
+        assert np.array_equal(env.get_original_cost().cpu().numpy(), g["costs"][t])
+
+
+@pytest.mark.parametrize("N", [1, 8, 127, 128, 129, 300, 1000])
+def test_vecnormalize_numpy_reduction_order(N):
+    from icrl_amd.vec_env import HipSynthVecEnv, VecNormalizeWithCost, VecCostWrapper
+    rng = np.random.RandomState(N)
+    st = o_stats.NormState(N, 18)
+    env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, "hc")))
+    nm_obs = torch.zeros(N, 18, dtype=torch.float64, device="cuda")
+    o_stats.norm_reset(st, np.zeros((N, 18)))
+    env.reset()
+    for t in range(5):
+        obs, rew = rng.randn(N, 18) * 7 + 1, rng.randn(N) * 3
+        cost, done = rng.rand(N).astype(np.float32), rng.rand(N) < 0.2
+        oo, ro, co = o_stats.norm_step(st, obs, rew, cost, done)
+        dev = lambda x, dt: torch.as_tensor(x, device="cuda").to(dt).contiguous()
+        env._norm_call(dev(obs, torch.float64), dev(rew, torch.float64), dev(cost, torch.float32), dev(done, torch.uint8))
+        assert np.array_equal(env._obs_out.cpu().numpy(), oo) and np.array_equal(env._rew_out.cpu().numpy(), ro)
+        assert np.array_equal(env._cost_out.cpu().numpy(), co)
+        assert np.array_equal(env.ret.cpu().numpy(), st.ret) and env.ret_rms.var == st.ret_rms.var
+
+
+def test_policy_forward_vs_oracle(golden):
+    from icrl_amd.policies import ActorTwoCriticsPolicy
+    from icrl_amd import spaces
+    g = golden("g9_learn_iteration")
+    pol = ActorTwoCriticsPolicy(spaces.Box(-np.inf, np.inf, (18,), np.float64), spaces.Box(-1, 1, (6,), np.float32))
+    pol.load_state_dict(_sub(g, "w0/"))
+    assert all(torch.equal(v, torch.as_tensor(g["w0/" + k])) for k, v in pol.state_dict().items())
+    op = o_nets.TwoCriticPolicy(18, 6); op.load_state_dict(_sub(g, "w0/"))
+    rng = np.random.RandomState(1)
+    obs, noise = rng.randn(33, 18) * 2, rng.randn(33, 6).astype(np.float32)
+    a, vr, vc, lp = pol.forward(obs, noise=noise)
+    with torch.no_grad():
+        oa, ovr, ovc, olp = op.forward(torch.as_tensor(obs), torch.as_tensor(noise))
+    for got, ref in ((a, oa), (vr, ovr), (vc, ovc), (lp, olp)):
+        assert np.allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-6)
+    assert np.allclose(pol.last_clipped.cpu().numpy(), np.clip(oa.numpy(), -1, 1), atol=2e-6)
+    a_det = pol.forward(obs, deterministic=True)[0]
+    with torch.no_grad():
+        assert np.allclose(a_det.cpu().numpy(), op.forward(torch.as_tensor(obs), deterministic=True)[0].numpy(), atol=2e-6)
+
+
+def _build_stack(N, kind, cn_sd, seed=0):
+    from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
+    from icrl_amd.constraint_net import ConstraintNet
+    env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, kind, seed)), reward_gamma=0.99, cost_gamma=0.99)
+    od, ad = env.observation_space.shape[0], env.action_space.shape[0]
+    cn = ConstraintNet(od, ad, [20], None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20,
+                       action_low=-np.ones(ad, np.float32), action_high=np.ones(ad, np.float32), per_step_importance_sampling=True)
+    cn.load_state_dict(cn_sd)
+    env.set_cost_function(cn.cost_function)
+    return env, cn
+
+
+def test_fused_rollout_vs_reference_golden(golden):
+    """icrl_rollout_collect vs the REFERENCE's own first rollout (tests/golden/g9, N=4, T=32), teacher-forced noise.
+    Tolerance: fp32 policy / cost MLPs differ from torch-CPU in summation order (1e-5 relative on activations)."""
+    from icrl_amd.ppo_lag import PPOLagrangian
+    g = golden("g9_learn_iteration")
+    noise = g["noise"]
+    _, T, N, A = noise.shape
+    env, cn = _build_stack(N, "hc", _sub(g, "cn/"))
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, batch_size=16, n_epochs=3, target_kl=0.01, seed=0)
+    agent.policy.load_state_dict(_sub(g, "w0/"))
+    agent._setup_learn(2 * N * T)
+    agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost", noise=torch.as_tensor(noise[0], device="cuda").contiguous())
+    # the golden buffer holds the SECOND rollout (the reference re-uses the buffer); rebuild the first from the oracle port
+    stack = o_loop.make_stack(N, "hc", 0)
+    lo = -np.ones(6, np.float32)
+    ocn = o_nets.CostNet(18, 6, [20], False, None, None, 20, lo, -lo); ocn.load_state_dict(_sub(g, "cn/"))
+    stack.cost_fn = ocn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=T, batch_size=16, n_epochs=3, target_kl=0.01, seed=0)
+    port.policy.load_state_dict(_sub(g, "w0/"))
+    port.num_timesteps = 0
+    port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
+    b = port.collect_rollouts(noise[0])
+    rb = agent.rollout_buffer
+    for k in ("observations", "orig_observations", "new_observations", "new_orig_observations", "actions", "rewards", "costs",
+              "orig_costs", "dones", "log_probs", "reward_values", "cost_values", "reward_advantages", "cost_advantages",
+              "reward_returns", "cost_returns"):
+        got, ref = getattr(rb, k).cpu().numpy().reshape(T, N, -1), getattr(b, k).reshape(T, N, -1)
+        assert np.allclose(got, ref, rtol=2e-4, atol=2e-5), (k, np.abs(got - ref).max())
+    assert np.allclose(env.obs_rms.mean, stack.norm.obs_rms.mean, rtol=1e-6, atol=1e-7)
+    assert np.allclose(env.obs_rms.var, stack.norm.obs_rms.var, rtol=1e-6, atol=1e-9)
+    assert abs(env.cost_rms.var - stack.norm.cost_rms.var) < 1e-6 * max(1.0, stack.norm.cost_rms.var)
+    assert agent.num_timesteps == N * T
+
+
+@pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("ant", 96, 40)])
+def test_fused_rollout_vs_port(kind, N, T):
+    """same comparison at HC / Ant shapes with freshly initialised nets; also crosses episode ends (hc T=300 < 1000: none,
+    so the env is pre-stepped to t_ep = 900 first)."""
+    from icrl_amd.ppo_lag import PPOLagrangian
+    torch.manual_seed(5)
+    od, ad = (18, 6) if kind == "hc" else (113, 8)
+    hid = [20] if kind == "hc" else [40, 40]
+    lo = -np.ones(ad, np.float32)
+    ocn = o_nets.CostNet(od, ad, hid, False, None, None, 20, lo, -lo)
+    from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
+    from icrl_amd.constraint_net import ConstraintNet
+    env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, kind, 7)))
+    cn = ConstraintNet(od, ad, hid, None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
+    cn.load_state_dict(ocn.state_dict())
+    env.set_cost_function(cn.cost_function)
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=1)
+    stack = o_loop.make_stack(N, kind, 7); stack.cost_fn = ocn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=T, seed=1)
+    port.policy.load_state_dict(agent.policy.state_dict())        # same seed gives the same init; make it explicit anyway
+    if kind == "hc":
+        stack.env.t_ep[:] = 900; env.unwrapped.t_ep.fill_(900)
+    rng = np.random.RandomState(2)
+    noise = rng.randn(T, N, ad).astype(np.float32)
+    agent._setup_learn(N * T)
+    if kind == "hc":
+        env.unwrapped.t_ep.fill_(900)
+    port.num_timesteps = 0
+    port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
+    if kind == "hc":
+        stack.env.t_ep[:] = 900
+    agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost", noise=torch.as_tensor(noise, device="cuda"))
+    b = port.collect_rollouts(noise)
+    rb = agent.rollout_buffer
+    if kind == "hc":
+        assert b.dones.sum() == N            # every env crossed an episode end
+    for k in ("observations", "orig_observations", "new_observations", "actions", "rewards", "costs", "orig_costs", "dones",
+              "log_probs", "reward_values", "cost_values", "reward_advantages", "cost_advantages", "reward_returns", "cost_returns"):
+        got, ref = getattr(rb, k).cpu().numpy().reshape(T, N, -1), getattr(b, k).reshape(T, N, -1)
+        assert np.allclose(got, ref, rtol=5e-4, atol=5e-5), (k, np.abs(got - ref).max())
