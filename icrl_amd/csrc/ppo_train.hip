@@ -1,0 +1,654 @@
+// PPO-Lagrangian update as ONE persistent launch — gfx950.
+//
+// ref: stable_baselines3/ppo_lag/ppo_lag.py:196-299 (epoch / minibatch loop of PPOLagrangian.train),
+//      common/buffers.py:594-627 (get / _get_samples), common/policies.py:752-767 (evaluate_actions),
+//      common/distributions.py:143-171 (DiagGaussian log_prob / entropy), torch.optim.Adam, clip_grad_norm_.
+//
+// The reference performs n_epochs * ceil(T*N / batch) DEPENDENT optimiser steps on a 64..128-row minibatch through three
+// small independent MLPs (pi, vf, cvf: obs -> 64 -> 64 -> {act | 1 | 1}).  Parity forbids re-ordering or merging those
+// steps, so the step latency is what matters.  Mapping:
+//
+//   * grid = 3 workgroups x 256 threads (4 waves, one per SIMD): workgroup r owns network r.  The only quantity coupling
+//     the networks inside a step is the global gradient norm (clip_grad_norm_ over ALL policy parameters): each workgroup
+//     publishes its partial sum of squares as an 8-byte {step tag, value} granule (sc1 / agent-scope relaxed store) and
+//     polls the other two (guide: cdna_hip_programming.md §6 Guideline 16, form R2 — the datum is the flag).  Granule
+//     slots are double-buffered by step parity; a workgroup can never be more than one step ahead of the others.
+//   * the network's weights stay in LDS for the whole launch (fp32 master copy, rows padded to stride = 2 mod 32 so that
+//     the MFMA operand fetch `ds_read_b32 M[(i0 + lane%16) * S + k0 + lane/16]` is bank-conflict free);
+//     Adam moments and the accumulating weight gradients stay in REGISTERS in MFMA C-layout: the lane that receives
+//     dW[j][k] from the matrix core is the lane that owns m, v and the update of W[j][k].  Nothing but the gathered
+//     minibatch rows (and 3 granules) touches global memory inside the loop.
+//   * all eight GEMMs of a step (3 forward, 5 backward) run on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains): wave w
+//     owns the 16-row tile w of every 64-row operand, so forward activations never cross waves.
+//   * minibatches larger than 64 rows are processed in 64-row chunks that accumulate into the same gradient registers.
+//
+// Built with -ffp-contract=off; FMA is used only where written (fmaf / MFMA).
+#include "common.h"
+
+namespace icrl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+#define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int TH = 256;  // threads per workgroup
+constexpr int RB = 64;   // minibatch rows per chunk
+constexpr int HD = 64;   // hidden width (both layers)
+constexpr int SH = 66;   // LDS row stride of 64-wide matrices
+constexpr int SO = 18;   // LDS row stride of 16-wide matrices
+constexpr int MAXB = 128;
+
+template <int NT1>
+struct Smem {  // offsets in floats
+  static constexpr int O16 = 16 * NT1, SX = O16 + 2;
+  static constexpr int W1 = 0;
+  static constexpr int W2 = W1 + HD * SX;
+  static constexpr int WH = W2 + HD * SH;
+  static constexpr int B1 = WH + 16 * SH;
+  static constexpr int B2 = B1 + HD;
+  static constexpr int BH = B2 + HD;
+  static constexpr int LS = BH + 16;
+  static constexpr int X = LS + 16;
+  static constexpr int H1 = X + RB * SX;
+  static constexpr int H2 = H1 + RB * SH;
+  static constexpr int DZ = H2 + RB * SH;
+  static constexpr int OUT = DZ + RB * SH;
+  static constexpr int DO = OUT + RB * SO;
+  static constexpr int ACT = DO + RB * SO;      // [RB][16] actions of the chunk
+  static constexpr int OLP = ACT + RB * 16;     // [RB] old log-prob | (value roles) old value
+  static constexpr int ADR = OLP + RB;          // [RB] raw reward advantage | return
+  static constexpr int ADC = ADR + RB;          // [RB] raw cost advantage
+  static constexpr int RED1 = ADC + RB;         // [4][64] per-wave column sums of dz1
+  static constexpr int RED2 = RED1 + 4 * HD;    // [4][64] per-wave column sums of dz2
+  static constexpr int PBH = RED2 + 4 * HD;     // [4][16] per-wave column sums of dOut
+  static constexpr int PLS = PBH + 64;          // [4][16] per-wave d log_std partials
+  static constexpr int PST = PLS + 64;          // [4][8] per-wave loss statistics
+  static constexpr int MISC = PST + 32;         // [32] block-reduction scratch + broadcast scalars
+  static constexpr int TOTAL = MISC + 32;
+};
+
+struct TrainArgs {
+  PolLayout L;
+  float* params;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int* adam_t;
+  icrl_buffer_t buf;
+  const int* perms;
+  const float* nu;
+  icrl_ppo_hyper_t hp;
+  float* stats;
+  u64* xch;
+};
+
+__device__ __forceinline__ float block_sum(float v, float* scratch /* >= 8 floats */) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[w] = v;
+  __syncthreads();
+  return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
+}
+
+// sum over the 16 lanes sharing lane/16 (rows of one wave's loss phase)
+__device__ __forceinline__ float sum16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// column sums of a wave's 16x16 accumulator tile: every lane ends with the sum over the tile's 16 rows of column lane%16
+__device__ __forceinline__ float tile_colsum(const f32x4& t) {
+  float s = (t[0] + t[1]) + (t[2] + t[3]);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  return s;
+}
+
+template <int NT1>
+__global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
+  using S = Smem<NT1>;
+  constexpr int SX = S::SX, O16 = S::O16;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int role = blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const PolLayout& L = a.L;
+  const int O = L.O, A = L.A;
+  const int n_out = role == 0 ? A : 1;
+  const int T = a.buf.T, N = a.buf.N;
+  const int n_total = T * N;
+  const int B = a.hp.batch_size;
+  const int n_mb = (n_total + B - 1) / B;
+  const float nu = a.nu[0];
+
+  // ---- global offsets of this role's tensors in the flat parameter buffer
+  const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
+  const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
+  const int gbh = role == 0 ? L.ba : (role == 1 ? L.bv : L.bc);
+
+  // ---- load weights into LDS (zero padded), moments into registers (C-layout ownership)
+  for (int i = tid; i < HD * SX; i += TH) { const int j = i / SX, k = i % SX; sm[S::W1 + i] = k < O ? a.params[gW1 + j * O + k] : 0.f; }
+  for (int i = tid; i < HD * SH; i += TH) { const int j = i / SH, k = i % SH; sm[S::W2 + i] = k < HD ? a.params[gW2 + j * HD + k] : 0.f; }
+  for (int i = tid; i < 16 * SH; i += TH) { const int o = i / SH, k = i % SH; sm[S::WH + i] = (o < n_out && k < HD) ? a.params[gWh + o * HD + k] : 0.f; }
+  if (tid < HD) { sm[S::B1 + tid] = a.params[gb1 + tid]; sm[S::B2 + tid] = a.params[gb2 + tid]; }
+  if (tid < 16) { sm[S::BH + tid] = tid < n_out ? a.params[gbh + tid] : 0.f; sm[S::LS + tid] = (role == 0 && tid < A) ? a.params[L.log_std + tid] : 0.f; }
+
+  f32x4 mW1[NT1], vW1[NT1], gW1r[NT1], mW2[4], vW2[4], gW2r[4], mWh, vWh, gWhr;
+#pragma unroll
+  for (int c = 0; c < NT1; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      mW1[c][i] = k < O ? a.exp_avg[gW1 + j * O + k] : 0.f;
+      vW1[c][i] = k < O ? a.exp_avg_sq[gW1 + j * O + k] : 0.f;
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      mW2[c][i] = a.exp_avg[gW2 + j * HD + k];
+      vW2[c][i] = a.exp_avg_sq[gW2 + j * HD + k];
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = 4 * q + i, j = 16 * w + r;
+    mWh[i] = o < n_out ? a.exp_avg[gWh + o * HD + j] : 0.f;
+    vWh[i] = o < n_out ? a.exp_avg_sq[gWh + o * HD + j] : 0.f;
+  }
+  // thread-owned vector parameters: tid 0..63 b1, 64..127 b2, 128..143 head bias, 144..159 log_std (policy only)
+  int vec_g = -1;       // global index of the owned scalar (or -1)
+  int vec_s = 0;        // its LDS slot
+  if (tid < 64) { vec_g = gb1 + tid; vec_s = S::B1 + tid; }
+  else if (tid < 128) { vec_g = gb2 + tid - 64; vec_s = S::B2 + tid - 64; }
+  else if (tid < 144) { if (tid - 128 < n_out) { vec_g = gbh + tid - 128; vec_s = S::BH + tid - 128; } }
+  else if (tid < 160) { if (role == 0 && tid - 144 < A) { vec_g = L.log_std + tid - 144; vec_s = S::LS + tid - 144; } }
+  float mB = 0.f, vB = 0.f, gB = 0.f;
+  if (vec_g >= 0) { mB = a.exp_avg[vec_g]; vB = a.exp_avg_sq[vec_g]; }
+
+  const int t0 = a.adam_t[0];
+  double b1pow = pow((double)a.hp.adam_beta1, (double)t0), b2pow = pow((double)a.hp.adam_beta2, (double)t0);
+  const float w1 = (float)(1.0 - (double)a.hp.adam_beta1);
+  const float w2 = (float)(1.0 - (double)a.hp.adam_beta2);
+  const float clip = a.hp.clip_range;
+  const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
+  const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
+
+  // running statistics (thread 0 of each role)
+  float st_ent = 0.f, st_pg = 0.f, st_vl = 0.f, st_cf = 0.f, last_loss = 0.f;
+  int steps_done = 0, early_stop_epoch = a.hp.n_epochs, status = 0;
+  if (tid == 0) { sm[S::MISC + 12] = 0.f; sm[S::MISC + 13] = 0.f; }
+  __syncthreads();
+
+  unsigned step = 0;
+  bool stop = false;
+  for (int epoch = 0; epoch < a.hp.n_epochs && !stop; ++epoch) {
+    float kl_sum = 0.f;  // thread 0, policy role
+    const int* perm = a.perms + (size_t)epoch * n_total;
+    for (int mb = 0; mb < n_mb && !stop; ++mb) {
+      ++step;
+      const int base = mb * B;
+      const int nb = (n_total - base) < B ? (n_total - base) : B;
+      // ---- minibatch statistics of the advantages (policy role): mean / unbiased std of A_r, mean of A_c
+      float mean_r = 0.f, std_r = 1.f, mean_c = 0.f;
+      if (role == 0) {
+        float ar = 0.f, ac = 0.f;
+        if (tid < nb) {
+          const int idx = perm[base + tid];
+          const int env = idx / T, t = idx - env * T;
+          const size_t off = (size_t)t * N + env;
+          ar = a.buf.reward_advantages[off];
+          ac = a.buf.cost_advantages[off];
+        }
+        mean_r = block_sum(ar, sm + S::MISC) / (float)nb;
+        mean_c = block_sum(ac, sm + S::MISC) / (float)nb;
+        const float d = tid < nb ? ar - mean_r : 0.f;
+        const float ss = block_sum(d * d, sm + S::MISC);
+        std_r = sqrtf(ss / (float)(nb - 1));
+      }
+      // ---- zero gradient accumulators
+#pragma unroll
+      for (int c = 0; c < NT1; ++c) gW1r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) gW2r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
+      gB = 0.f;
+      float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f;  // thread 0: minibatch sums of the loss statistics
+
+      const int n_chunks = (nb + RB - 1) / RB;
+      for (int ch = 0; ch < n_chunks; ++ch) {
+        const int cbase = base + ch * RB;
+        const int nrows = (nb - ch * RB) < RB ? (nb - ch * RB) : RB;
+        // ================= gather the chunk's rows (flat env-major index -> [T,N] storage) =================
+        {
+          const int b = tid >> 2, part = tid & 3;
+          size_t off = 0;
+          const bool valid = b < nrows;
+          if (valid) {
+            const int idx = perm[cbase + b];
+            const int env = idx / T, t = idx - env * T;
+            off = (size_t)t * N + env;
+          }
+          const float* orow = a.buf.observations + off * O;
+          for (int k = part; k < SX; k += 4) sm[S::X + b * SX + k] = (valid && k < O) ? orow[k] : 0.f;
+          if (role == 0) {
+            const float* arow = a.buf.actions + off * a.buf.act_store;
+            for (int k = part; k < 16; k += 4) sm[S::ACT + b * 16 + k] = (valid && k < A) ? arow[k] : 0.f;
+            if (part == 0) {
+              sm[S::OLP + b] = valid ? a.buf.log_probs[off] : 0.f;
+              sm[S::ADR + b] = valid ? a.buf.reward_advantages[off] : 0.f;
+              sm[S::ADC + b] = valid ? a.buf.cost_advantages[off] : 0.f;
+            }
+          } else if (part == 0) {
+            const float* rets = role == 1 ? a.buf.reward_returns : a.buf.cost_returns;
+            const float* olds = role == 1 ? a.buf.reward_values : a.buf.cost_values;
+            sm[S::ADR + b] = valid ? rets[off] : 0.f;
+            sm[S::OLP + b] = valid ? olds[off] : 0.f;
+          }
+        }
+        __syncthreads();  // (1) chunk inputs in LDS
+        // ================= forward: wave w owns rows 16w..16w+15 =================
+        {
+          f32x4 acc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float* pa = sm + S::X + (16 * w + r) * SX + q;
+          const float* pb = sm + S::W1 + r * SX + q;
+#pragma unroll
+          for (int ks = 0; ks < O16 / 4; ++ks) {
+            const float av = pa[4 * ks];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av, pb[c * 16 * SX + 4 * ks], acc[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              sm[S::H1 + (16 * w + 4 * q + i) * SH + 16 * c + r] = tanhf(acc[c][i] + sm[S::B1 + 16 * c + r]);
+        }
+        {
+          f32x4 acc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float* pa = sm + S::H1 + (16 * w + r) * SH + q;
+          const float* pb = sm + S::W2 + r * SH + q;
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            const float av = pa[4 * ks];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av, pb[c * 16 * SH + 4 * ks], acc[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              sm[S::H2 + (16 * w + 4 * q + i) * SH + 16 * c + r] = tanhf(acc[c][i] + sm[S::B2 + 16 * c + r]);
+        }
+        {
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float* pa = sm + S::H2 + (16 * w + r) * SH + q;
+          const float* pb = sm + S::WH + r * SH + q;
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) acc = MFMA_F32(pa[4 * ks], pb[4 * ks], acc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sm[S::OUT + (16 * w + 4 * q + i) * SO + r] = acc[i] + sm[S::BH + r];
+        }
+        // ================= loss + d loss / d head output, rows of this wave on lanes 0..15 =================
+        {
+          const int b = 16 * w + r;          // every lane computes (4 replicas per row), lanes q == 0 write
+          const bool valid = b < nrows;
+          float* dor = sm + S::DO + b * SO;
+          const float* outr = sm + S::OUT + b * SO;
+          if (role == 0) {
+            float lp = 0.f;
+            for (int k = 0; k < A; ++k) {
+              const float sd = expf(sm[S::LS + k]);
+              const float d = sm[S::ACT + b * 16 + k] - outr[k];
+              lp += -(d * d) / (2.f * (sd * sd)) - logf(sd) - LOG_SQRT_2PI_F;
+            }
+            const float old_lp = sm[S::OLP + b];
+            const float ratio = expf(lp - old_lp);
+            const float Ar = (sm[S::ADR + b] - mean_r) / (std_r + 1e-8f);
+            const float Ac = sm[S::ADC + b] - mean_c;
+            const float s1 = Ar * ratio;
+            const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+            const float s2 = Ar * rc;
+            const float gsel = (s1 <= s2) ? Ar : 0.f;                       // d min(s1, s2) / d ratio
+            const float cpol = 1.f / ((1.f + nu) * (float)nb);
+            const float dlp = valid ? cpol * (-gsel + nu * Ac) * ratio : 0.f;  // d loss / d log_prob
+            float pls_acc = 0.f;
+            for (int k = 0; k < 16; ++k) {
+              float dk = 0.f, lk = 0.f;
+              if (k < A) {
+                const float sd = expf(sm[S::LS + k]);
+                const float var = sd * sd;
+                const float d = sm[S::ACT + b * 16 + k] - outr[k];
+                dk = dlp * (d / var);
+                lk = dlp * ((d * d) / var - 1.f);
+              }
+              if (q == 0) dor[k] = dk;
+              const float colsum = sum16(dk);
+              const float lssum = sum16(lk);
+              if (lane == 0) { sm[S::PBH + w * 16 + k] = colsum; sm[S::PLS + w * 16 + k] = lssum; }
+              (void)pls_acc;
+            }
+            const float v0 = sum16(valid ? fminf(s1, s2) : 0.f);
+            const float v1 = sum16(valid ? Ac * ratio : 0.f);
+            const float v2 = sum16(valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f);
+            const float v3 = sum16(valid ? old_lp - lp : 0.f);
+            if (lane == 0) { sm[S::PST + w * 8 + 0] = v0; sm[S::PST + w * 8 + 1] = v1; sm[S::PST + w * 8 + 2] = v2; sm[S::PST + w * 8 + 3] = v3; }
+          } else {
+            const float v = outr[0];
+            const float R = sm[S::ADR + b];
+            float vp = v, pass = 1.f;
+            if (vclip >= 0.f) {
+              const float old = sm[S::OLP + b];
+              const float dv = v - old;
+              vp = old + fminf(fmaxf(dv, -vclip), vclip);
+              pass = (dv >= -vclip && dv <= vclip) ? 1.f : 0.f;
+            }
+            const float e = vp - R;
+            const float d0 = valid ? vcoef * 2.f * e / (float)nb * pass : 0.f;
+            if (q == 0) {
+              dor[0] = d0;
+              for (int k = 1; k < 16; ++k) dor[k] = 0.f;
+            }
+            const float colsum = sum16(d0);
+            const float se = sum16(valid ? e * e : 0.f);
+            if (lane == 0) {
+              sm[S::PBH + w * 16] = colsum;
+              for (int k = 1; k < 16; ++k) sm[S::PBH + w * 16 + k] = 0.f;
+              sm[S::PST + w * 8 + 0] = se;
+            }
+          }
+        }
+        // ================= backward =================
+        {  // dH2 = dOut . Wh  -> dz2 = dH2 * (1 - h2^2) (own rows), column sums for d b2
+          f32x4 acc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float* pa = sm + S::DO + (16 * w + r) * SO + q;
+          const float* pb = sm + S::WH + q * SH + r;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const float av = pa[4 * ks];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av, pb[4 * ks * SH + 16 * c], acc[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int at = (16 * w + 4 * q + i) * SH + 16 * c + r;
+              const float h = sm[S::H2 + at];
+              acc[c][i] = acc[c][i] * (1.f - h * h);
+              sm[S::DZ + at] = acc[c][i];
+            }
+            const float cs = tile_colsum(acc[c]);
+            if (q == 0) sm[S::RED2 + w * HD + 16 * c + r] = cs;
+          }
+        }
+        __syncthreads();  // (2) dz2, dOut, h2 of ALL rows visible
+        {  // dWh[o][j] += sum_b dOut[b][o] h2[b][j]   (wave w: columns 16w..16w+15)
+          const float* pa = sm + S::DO + q * SO + r;
+          const float* pb = sm + S::H2 + q * SH + 16 * w + r;
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) gWhr = MFMA_F32(pa[4 * ks * SO], pb[4 * ks * SH], gWhr);
+        }
+        // owners fold the per-wave partials of this chunk (b2, head bias, log_std, loss statistics)
+        if (tid >= 64 && tid < 128) {
+          const int j = tid - 64;
+          gB += (sm[S::RED2 + j] + sm[S::RED2 + HD + j]) + (sm[S::RED2 + 2 * HD + j] + sm[S::RED2 + 3 * HD + j]);
+        } else if (tid >= 128 && tid < 144) {
+          const int k = tid - 128;
+          gB += (sm[S::PBH + k] + sm[S::PBH + 16 + k]) + (sm[S::PBH + 32 + k] + sm[S::PBH + 48 + k]);
+        } else if (tid >= 144 && tid < 160) {
+          const int k = tid - 144;
+          gB += (sm[S::PLS + k] + sm[S::PLS + 16 + k]) + (sm[S::PLS + 32 + k] + sm[S::PLS + 48 + k]);
+        }
+        if (tid == 0) {
+          mb_s0 += (sm[S::PST + 0] + sm[S::PST + 8]) + (sm[S::PST + 16] + sm[S::PST + 24]);
+          mb_s1 += (sm[S::PST + 1] + sm[S::PST + 9]) + (sm[S::PST + 17] + sm[S::PST + 25]);
+          mb_s2 += (sm[S::PST + 2] + sm[S::PST + 10]) + (sm[S::PST + 18] + sm[S::PST + 26]);
+          mb_s3 += (sm[S::PST + 3] + sm[S::PST + 11]) + (sm[S::PST + 19] + sm[S::PST + 27]);
+        }
+        __syncthreads();  // (2b) every wave is done reading h2: its buffer becomes dz1
+        {  // dW2[j][k] += sum_b dz2[b][j] h1[b][k]   (wave w: rows j = 16w..)
+          const float* pa = sm + S::DZ + q * SH + 16 * w + r;
+          const float* pb = sm + S::H1 + q * SH + r;
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            const float av = pa[4 * ks * SH];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) gW2r[c] = MFMA_F32(av, pb[4 * ks * SH + 16 * c], gW2r[c]);
+          }
+        }
+        {  // dH1 = dz2 . W2 (own rows) -> dz1 = dH1 * (1 - h1^2), stored over h2
+          f32x4 acc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          const float* pa = sm + S::DZ + (16 * w + r) * SH + q;
+          const float* pb = sm + S::W2 + q * SH + r;
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            const float av = pa[4 * ks];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av, pb[4 * ks * SH + 16 * c], acc[c]);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int at = (16 * w + 4 * q + i) * SH + 16 * c + r;
+              const float h = sm[S::H1 + at];
+              acc[c][i] = acc[c][i] * (1.f - h * h);
+              sm[S::H2 + at] = acc[c][i];
+            }
+            const float cs = tile_colsum(acc[c]);
+            if (q == 0) sm[S::RED1 + w * HD + 16 * c + r] = cs;
+          }
+        }
+        __syncthreads();  // (3) dz1 of all rows visible
+        {  // dW1[j][k] += sum_b dz1[b][j] x[b][k]
+          const float* pa = sm + S::H2 + q * SH + 16 * w + r;
+          const float* pb = sm + S::X + q * SX + r;
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) {
+            const float av = pa[4 * ks * SH];
+#pragma unroll
+            for (int c = 0; c < NT1; ++c) gW1r[c] = MFMA_F32(av, pb[4 * ks * SX + 16 * c], gW1r[c]);
+          }
+        }
+        if (tid < 64) gB += (sm[S::RED1 + tid] + sm[S::RED1 + HD + tid]) + (sm[S::RED1 + 2 * HD + tid] + sm[S::RED1 + 3 * HD + tid]);
+        __syncthreads();  // (4) chunk buffers free
+      }  // chunks
+
+      // entropy term of the policy loss: d(ent_coef * -mean(H)) / d log_std = -ent_coef (H = sum_a 0.5 + 0.5 log 2pi + log sigma)
+      if (role == 0 && tid >= 144 && tid < 144 + A) gB += -a.hp.ent_coef;
+
+      // ================= global gradient norm: local sum of squares -> 8-byte granules =================
+      float ss = 0.f;
+#pragma unroll
+      for (int c = 0; c < NT1; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss += gW1r[c][i] * gW1r[c][i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ss += gW2r[c][i] * gW2r[c][i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ss += gWhr[i] * gWhr[i];
+      if (vec_g >= 0) ss += gB * gB;
+      ss = block_sum(ss, sm + S::MISC);
+      // statistics + early-stop decision ride on the policy workgroup's granule
+      bool want_stop = false;
+      if (tid == 0) {
+        ++steps_done;
+        if (role == 0) {
+          float ent = 0.f;
+          for (int k = 0; k < A; ++k) ent += HALF_LOG_2PI_PLUS_HALF_F + sm[S::LS + k];
+          const float entropy_loss = -ent;
+          const float pl = (-(mb_s0 / (float)nb) + nu * (mb_s1 / (float)nb)) / (1.f + nu);
+          st_ent += entropy_loss; st_pg += pl; st_cf += mb_s2 / (float)nb;
+          kl_sum += mb_s3 / (float)nb;
+          last_loss = pl + a.hp.ent_coef * entropy_loss;
+          if (mb == n_mb - 1) {
+            const float mean_kl = kl_sum / (float)n_mb;
+            a.stats[32 + epoch] = mean_kl;
+            a.stats[7] = mean_kl;
+            if (a.hp.use_target_kl && mean_kl > 1.5f * a.hp.target_kl) { want_stop = true; early_stop_epoch = epoch; }
+          }
+        } else {
+          const float vl = mb_s0 / (float)nb;
+          st_vl += vl;
+          last_loss = vl;
+        }
+        const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
+        __hip_atomic_store(a.xch + (step & 1) * 4 + role, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (tid < 3) {
+        u64 v = 0;
+        int spins = 0;
+        bool ok = false;
+        while (spins < (1 << 24)) {
+          v = __hip_atomic_load(a.xch + (step & 1) * 4 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+          ++spins;
+        }
+        sm[S::MISC + 8 + tid] = __uint_as_float((unsigned)(v & 0xffffffffu));
+        if (tid == 0) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;
+        if (!ok) sm[S::MISC + 13] = 1.f;
+      } else if (tid == 3) {
+        // nothing: slot 13 is zeroed below on the success path
+      }
+      __syncthreads();
+      const float total = sqrtf((sm[S::MISC + 8] + sm[S::MISC + 9]) + sm[S::MISC + 10]);
+      stop = sm[S::MISC + 12] != 0.f;
+      if (sm[S::MISC + 13] != 0.f) { status = 1; stop = true; }
+      float coef = a.hp.max_grad_norm / (total + 1e-6f);
+      coef = coef > 1.f ? 1.f : coef;
+
+      // ================= Adam (torch.optim.Adam, single-tensor form) on register-resident moments =================
+      b1pow *= (double)a.hp.adam_beta1;
+      b2pow *= (double)a.hp.adam_beta2;
+      const float step_size = (float)((double)a.hp.lr / (1.0 - b1pow));
+      const float bc2_sqrt = (float)sqrt(1.0 - b2pow);
+      const float b2f = a.hp.adam_beta2, epsf = a.hp.adam_eps;
+      auto adam = [&](float g, float& m, float& v, float p) -> float {
+        g = g * coef;
+        m = m + (g - m) * w1;
+        v = v * b2f + w2 * (g * g);
+        const float denom = sqrtf(v) / bc2_sqrt + epsf;
+        return p - step_size * (m / denom);
+      };
+      if (status == 0) {
+#pragma unroll
+        for (int c = 0; c < NT1; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+            if (k < O) { float* pw = sm + S::W1 + j * SX + k; float m_ = mW1[c][i], v_ = vW1[c][i]; *pw = adam(gW1r[c][i], m_, v_, *pw); mW1[c][i] = m_; vW1[c][i] = v_; }
+          }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float* pw = sm + S::W2 + (16 * w + 4 * q + i) * SH + 16 * c + r;
+            float m_ = mW2[c][i], v_ = vW2[c][i];
+            *pw = adam(gW2r[c][i], m_, v_, *pw);
+            mW2[c][i] = m_; vW2[c][i] = v_;
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int o = 4 * q + i;
+          if (o < n_out) { float* pw = sm + S::WH + o * SH + 16 * w + r; float m_ = mWh[i], v_ = vWh[i]; *pw = adam(gWhr[i], m_, v_, *pw); mWh[i] = m_; vWh[i] = v_; }
+        }
+        if (vec_g >= 0) sm[vec_s] = adam(gB, mB, vB, sm[vec_s]);
+      }
+      if (tid == 0) { sm[S::MISC + 12] = 0.f; sm[S::MISC + 13] = 0.f; }
+      __syncthreads();
+    }  // minibatches
+  }    // epochs
+
+  // ---- write back weights, moments, statistics
+  for (int i = tid; i < HD * O; i += TH) { const int j = i / O, k = i % O; a.params[gW1 + i] = sm[S::W1 + j * SX + k]; }
+  for (int i = tid; i < HD * HD; i += TH) { const int j = i / HD, k = i % HD; a.params[gW2 + i] = sm[S::W2 + j * SH + k]; }
+  for (int i = tid; i < n_out * HD; i += TH) { const int o = i / HD, k = i % HD; a.params[gWh + i] = sm[S::WH + o * SH + k]; }
+  if (vec_g >= 0) { a.params[vec_g] = sm[vec_s]; a.exp_avg[vec_g] = mB; a.exp_avg_sq[vec_g] = vB; }
+#pragma unroll
+  for (int c = 0; c < NT1; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      if (k < O) { a.exp_avg[gW1 + j * O + k] = mW1[c][i]; a.exp_avg_sq[gW1 + j * O + k] = vW1[c][i]; }
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      a.exp_avg[gW2 + j * HD + k] = mW2[c][i];
+      a.exp_avg_sq[gW2 + j * HD + k] = vW2[c][i];
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = 4 * q + i, j = 16 * w + r;
+    if (o < n_out) { a.exp_avg[gWh + o * HD + j] = mWh[i]; a.exp_avg_sq[gWh + o * HD + j] = vWh[i]; }
+  }
+  if (tid == 0) {
+    if (role == 0) {
+      a.stats[0] = (float)early_stop_epoch;
+      a.stats[1] = (float)steps_done;
+      a.stats[2] = st_ent; a.stats[3] = st_pg; a.stats[6] = st_cf;
+      a.stats[8] = last_loss;
+      a.stats[11] = (float)status;
+      a.adam_t[0] = t0 + steps_done;
+    } else if (role == 1) {
+      a.stats[4] = st_vl; a.stats[9] = last_loss;
+    } else {
+      a.stats[5] = st_vl; a.stats[10] = last_loss;
+    }
+  }
+}
+
+}  // namespace icrl
+
+using namespace icrl;
+
+template <int NT1>
+static int launch_train(const TrainArgs& a, hipStream_t s) {
+  const size_t bytes = (size_t)Smem<NT1>::TOTAL * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_kernel<NT1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(ppo_train_kernel<NT1>, dim3(3), dim3(TH), bytes, s, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
+                                  const icrl_buffer_t* buf, const int32_t* perms, const float* nu,
+                                  const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, void* stream) {
+  if (pol->h1 != HD || pol->h2 != HD || pol->discrete || pol->obs_dim > 128 || pol->act_dim > 16 ||
+      hp->batch_size < 2 || hp->batch_size > MAXB || hp->n_epochs < 1 || buf->obs_dim != pol->obs_dim)
+    return (int)hipErrorInvalidValue;
+  TrainArgs a;
+  a.L = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);
+  a.params = pol->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
+  a.buf = *buf; a.perms = perms; a.nu = nu; a.hp = *hp; a.stats = stats; a.xch = (u64*)sync_ws;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(sync_ws, 0, 64, s);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemsetAsync(stats, 0, (32 + hp->n_epochs) * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  const int nt1 = (pol->obs_dim + 15) / 16;
+  if (nt1 <= 1) return launch_train<1>(a, s);
+  if (nt1 <= 2) return launch_train<2>(a, s);
+  if (nt1 <= 4) return launch_train<4>(a, s);
+  return launch_train<8>(a, s);
+}

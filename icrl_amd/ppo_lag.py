@@ -18,7 +18,7 @@ from . import _lib, logger, spaces
 from .buffers import RolloutBufferWithCost
 from .dual_variable import DualVariable, PIDLagrangian
 from .policies import ActorTwoCriticsPolicy
-from .structs import AgentT, p
+from .structs import AgentT, PpoHyperT, p
 from .vec_env import HipSynthVecEnv, VecCostWrapper, VecEnv, VecNormalize, VecNormalizeWithCost
 
 
@@ -195,5 +195,81 @@ class PPOLagrangian:
     def predict(self, observation, state=None, mask=None, deterministic=False, noise=None):
         return self.policy.predict(observation, state, mask, deterministic, noise)
 
-    def train(self):
-        raise NotImplementedError
+    # ---- update -----------------------------------------------------------------------------------------------------------
+    def _draw_permutations(self, n):
+        """[n_epochs, n] int32 on the device.  "numpy": np.random.permutation per epoch — the reference's stream
+        (ref: buffers.py:596); the generator is rewound afterwards to what the reference would have consumed (it stops
+        drawing once an epoch early-stops), see train()."""
+        if callable(self.permutation):
+            perms = np.stack([np.asarray(self.permutation(e, n)) for e in range(self.n_epochs)])
+            return torch.as_tensor(perms.astype(np.int32), device=self.device).contiguous(), None
+        if self.permutation == "device":
+            return torch.stack([torch.randperm(n, device=self.device) for _ in range(self.n_epochs)]).to(torch.int32).contiguous(), None
+        state = np.random.get_state()
+        perms = np.stack([np.random.permutation(n) for _ in range(self.n_epochs)])
+        return torch.as_tensor(perms.astype(np.int32), device=self.device).contiguous(), state
+
+    def train(self, perms=None):
+        """ref: ppo_lag.py:177-338."""
+        lr = float(self.lr_schedule(self._current_progress_remaining))
+        clip_range = float(self.clip_range(self._current_progress_remaining))
+        crv = -1.0 if self.clip_range_reward_vf is None else float(self.clip_range_reward_vf(self._current_progress_remaining))
+        ccv = -1.0 if self.clip_range_cost_vf is None else float(self.clip_range_cost_vf(self._current_progress_remaining))
+        rb, pol, dev = self.rollout_buffer, self.policy, self.device
+        n = rb.buffer_size * rb.n_envs
+        rng_state = None
+        if perms is None:
+            perms, rng_state = self._draw_permutations(n)
+        else:
+            perms = torch.as_tensor(np.asarray(perms).astype(np.int32), device=dev).contiguous()
+        current_penalty = float(self.dual.nu().item())
+        if not hasattr(self, "_train_ws"):
+            self._train_ws = dict(nu=torch.zeros(1, device=dev), stats=torch.zeros(32 + self.n_epochs, device=dev),
+                                  sync=torch.zeros(16, dtype=torch.int64, device=dev), t=torch.zeros(1, dtype=torch.int32, device=dev))
+        ws = self._train_ws
+        ws["nu"].fill_(current_penalty)
+        ws["t"].fill_(pol.adam_step)
+        hp = PpoHyperT(int(self.batch_size), int(self.n_epochs), int(self.target_kl is not None), 0, clip_range, float(self.ent_coef),
+                       float(self.reward_vf_coef), float(self.cost_vf_coef), float(self.max_grad_norm),
+                       float(self.target_kl or 0.0), crv, ccv, lr, 0.9, 0.999, float(pol.optimizer_kwargs.get("eps", 1e-8)))
+        ps, bs = pol.struct(), rb.struct()
+        b = _lib.byref
+        _lib.check(_lib.lib().icrl_ppo_lag_train(b(ps), p(pol.exp_avg), p(pol.exp_avg_sq), p(ws["t"]), b(bs), p(perms), p(ws["nu"]),
+                                                 b(hp), p(ws["stats"]), p(ws["sync"]), _lib.current_stream()), "icrl_ppo_lag_train")
+        pol.prepare()                                   # refresh the transposed copy for the next rollout
+        self._n_updates += self.n_epochs
+        # ---- the scalars the reference logs (one device->host read per train())
+        average_cost_t = rb.orig_costs.mean()
+        total_cost_t = rb.orig_costs.sum()
+        st = ws["stats"].cpu().numpy()
+        if st[11] != 0:
+            raise RuntimeError("icrl_ppo_lag_train: inter-workgroup exchange timed out")
+        pol.adam_step = int(ws["t"].item())
+        steps = max(int(st[1]), 1)
+        early_stop_epoch = int(st[0])
+        if rng_state is not None:       # leave np.random where the reference would: one permutation per executed epoch
+            np.random.set_state(rng_state)
+            for _ in range(min(early_stop_epoch + 1, self.n_epochs)):
+                np.random.permutation(n)
+        average_cost = float(average_cost_t.item())
+        if self.update_penalty_after is None or ((self._n_updates / self.n_epochs) % self.update_penalty_after == 0):
+            self.dual.update_parameter(np.float32(average_cost))
+        logger.record("train/entropy_loss", st[2] / steps)
+        logger.record("train/policy_gradient_loss", st[3] / steps)
+        logger.record("train/reward_value_loss", st[4] / steps)
+        logger.record("train/cost_value_loss", st[5] / steps)
+        logger.record("train/approx_kl", float(st[7]))
+        logger.record("train/clip_fraction", st[6] / steps)
+        logger.record("train/loss", float(st[8] + self.reward_vf_coef * st[9] + self.cost_vf_coef * st[10]))
+        logger.record("train/mean_reward_advantages", float(rb.reward_advantages.mean().item()))
+        logger.record("train/mean_cost_advantages", float(rb.cost_advantages.mean().item()))
+        logger.record("train/nu", self.dual.nu().item())
+        logger.record("train/nu_loss", self.dual.loss.item())
+        logger.record("train/average_cost", average_cost)
+        logger.record("train/total_cost", float(total_cost_t.item()))
+        logger.record("train/early_stop_epoch", early_stop_epoch)
+        if pol.log_std is not None:
+            logger.record("train/std", float(torch.exp(pol.log_std).mean().item()))
+        logger.record("train/n_updates", self._n_updates)
+        logger.record("train/clip_range", clip_range)
+        self.epoch_kls = st[32:32 + self.n_epochs].copy()

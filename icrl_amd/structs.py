@@ -43,6 +43,14 @@ class AgentT(C.Structure):
                 ("last_v_r", vp), ("last_v_c", vp), ("act_clipped", vp)]
 
 
+class PpoHyperT(C.Structure):
+    _fields_ = [("batch_size", i32), ("n_epochs", i32), ("use_target_kl", i32), ("_pad", i32),
+                ("clip_range", C.c_float), ("ent_coef", C.c_float), ("reward_vf_coef", C.c_float), ("cost_vf_coef", C.c_float),
+                ("max_grad_norm", C.c_float), ("target_kl", C.c_float), ("clip_range_reward_vf", C.c_float),
+                ("clip_range_cost_vf", C.c_float), ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float),
+                ("adam_eps", C.c_float)]
+
+
 def p(t):
     """device pointer of a contiguous tensor (or None -> NULL)."""
     if t is None:

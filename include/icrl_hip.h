@@ -111,6 +111,15 @@ typedef struct {
   float* act_clipped;    /* [N,act] scratch: action handed to the env */
 } icrl_agent_t;
 
+/* PPO-Lagrangian update hyper-parameters (stable_baselines3/ppo_lag/ppo_lag.py:67-103,177-196; Adam eps 1e-5 from
+ * common/policies.py:357-361). */
+typedef struct {
+  int32_t batch_size, n_epochs, use_target_kl, _pad;
+  float clip_range, ent_coef, reward_vf_coef, cost_vf_coef, max_grad_norm, target_kl;
+  float clip_range_reward_vf, clip_range_cost_vf; /* < 0: no value clipping (the default) */
+  float lr, adam_beta1, adam_beta2, adam_eps;
+} icrl_ppo_hyper_t;
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Entry points
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -179,6 +188,23 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
                          const float* action_low, const float* action_high,
                          double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
                          void* stream);
+
+/* PPOLagrangian.train (stable_baselines3/ppo_lag/ppo_lag.py:196-299) as ONE persistent launch: for every epoch, for every
+ * minibatch of the permutation: gather (buffers.py:594-627, env-major flat index i -> env = i / T, t = i % T),
+ * evaluate_actions (policies.py:752-767), advantage normalisation / centring, clipped surrogate + nu * cost term, two value
+ * MSEs, entropy, backward, global-norm clip (max_grad_norm), Adam, approx-KL early stop after a full epoch.
+ * Three workgroups (policy | reward critic | cost critic — the three MLPs are independent) keep their weights in LDS and
+ * their Adam moments in registers; the only coupling per step is the squared gradient norm (3 floats, 8-byte granules).
+ *   exp_avg / exp_avg_sq: [n_params] Adam moments (policy.optimizer state), adam_step: [1] int32 step counter (device);
+ *   perms: [n_epochs, T*N] int32 permutations;  nu: [1] current Lagrange multiplier (device);
+ *   stats: [32 + n_epochs] float32 (device): 0 early_stop_epoch, 1 optimiser steps done, 2..6 sums over minibatches of
+ *          entropy_loss / policy_loss / reward_value_loss / cost_value_loss / clip_fraction, 7 mean approx_kl of the last
+ *          epoch, 8..10 last minibatch's policy+entropy / reward-value / cost-value loss terms, 11 status (0 ok),
+ *          32+e mean approx_kl of epoch e;
+ *   sync_ws: >= 64 bytes of device scratch for the inter-workgroup granules (zeroed by the call). */
+int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
+                       const icrl_buffer_t* buf, const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp,
+                       float* stats, void* sync_ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,104 @@
+"""GPU parity of the persistent PPO-Lagrangian update kernel (icrl_ppo_lag_train) vs the reference (golden g4) and the
+oracle's epoch loop (teacher-forced permutations).  fp32 tolerance: the kernel's MFMA dot products, tanh/exp and Adam
+differ from torch-CPU by rounding order; after k dependent Adam steps parameters agree to ~1e-5 absolute (lr 3e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as o_nets, ppo as o_ppo
+
+pytestmark = pytest.mark.gpu
+
+
+def _sub(g, prefix):
+    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+def _agent(kind, N, T, **kw):
+    from icrl_amd.ppo_lag import PPOLagrangian
+    from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
+    env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, kind, 0)))
+    return PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=0, **kw)
+
+
+def _fill(agent, buf):
+    rb = agent.rollout_buffer
+    for k, v in buf.items():
+        getattr(rb, k).copy_(torch.as_tensor(np.asarray(v, np.float32)).reshape(getattr(rb, k).shape))
+    rb.full = True
+
+
+def test_three_steps_on_one_batch_golden(golden):
+    """tests/golden/g4: the reference's own policy/optimizer objects stepped 3x on one 64-row batch."""
+    g = golden("g4_ppo_minibatch")
+    agent = _agent("hc", 1, 64, batch_size=64, n_epochs=3, target_kl=None, learning_rate=float(g["lr"]))
+    agent.policy.load_state_dict(_sub(g, "w0/"))
+    z = np.zeros(64, np.float32)
+    _fill(agent, dict(observations=g["obs"], actions=g["act"], log_probs=g["old_lp"], reward_advantages=g["adv_r"],
+                      cost_advantages=g["adv_c"], reward_returns=g["ret_r"], cost_returns=g["ret_c"], reward_values=z,
+                      cost_values=z, orig_costs=z))
+    agent.dual.log_nu = np.float32(np.log(np.exp(float(g["nu"])) - 1))       # softplus^-1(nu)
+    assert abs(agent.dual.nu().item() - float(g["nu"])) < 1e-6
+    ident = np.tile(np.arange(64), (3, 1))
+    agent.train(perms=ident)
+    sd = agent.policy.state_dict()
+    worst = 0.0
+    for k, v in sd.items():
+        ref = g["s2/after/" + k]
+        worst = max(worst, float(np.abs(v.numpy() - ref).max()))
+        assert np.allclose(v.numpy(), ref, rtol=1e-4, atol=3e-6), (k, np.abs(v.numpy() - ref).max())
+    from icrl_amd import logger
+    lg = logger.Logger.CURRENT.name_to_value
+    assert lg["train/early_stop_epoch"] == 3
+    ref_pg = np.mean([g[f"s{s}/policy_loss"] for s in range(3)])
+    assert abs(lg["train/policy_gradient_loss"] - ref_pg) < 1e-5 + 1e-4 * abs(ref_pg)
+    assert abs(lg["train/reward_value_loss"] - np.mean([g[f"s{s}/rvl"] for s in range(3)])) < 1e-4
+    assert abs(lg["train/approx_kl"] - float(g["s2/approx_kl"])) < 1e-5
+    assert abs(lg["train/clip_fraction"] - np.mean([g[f"s{s}/clip_fraction"] for s in range(3)])) < 1e-6
+    assert agent.policy.adam_step == 3
+
+
+def _oracle_train(agent_sd, buf, perms, kind, nu, **h):
+    od, ad = (18, 6) if kind == "hc" else (113, 8)
+    pol = o_nets.TwoCriticPolicy(od, ad)
+    pol.load_state_dict(agent_sd)
+    opt = torch.optim.Adam(pol.parameters(), lr=h.pop("lr"), eps=1e-5)
+    out = o_ppo.ppo_lag_train(pol, opt, buf, perms, nu, **h)
+    return pol, out
+
+
+@pytest.mark.parametrize("kind,N,T,B,E,tk", [("hc", 8, 32, 64, 3, None), ("hc", 5, 40, 64, 2, None), ("ant", 24, 16, 128, 2, None),
+                                             ("hc", 16, 32, 64, 6, 0.002), ("hc", 4, 8, 16, 2, None)])
+def test_train_vs_oracle(kind, N, T, B, E, tk):
+    rng = np.random.RandomState(N * T)
+    od, ad = (18, 6) if kind == "hc" else (113, 8)
+    lr = 3e-4 if kind == "hc" else 3e-5
+    agent = _agent(kind, N, T, batch_size=B, n_epochs=E, target_kl=tk, learning_rate=lr, clip_range=0.2)
+    sd0 = agent.policy.state_dict()
+    obs = rng.randn(T, N, od).astype(np.float32)
+    # old log-probs from the current policy on sampled actions so that ratios start near 1 (as in a real rollout)
+    op = o_nets.TwoCriticPolicy(od, ad); op.load_state_dict(sd0)
+    with torch.no_grad():
+        a, vr, vc, lp = op.forward(torch.as_tensor(obs.reshape(-1, od)))
+    buf = dict(observations=obs, actions=a.numpy().reshape(T, N, ad), log_probs=lp.numpy().reshape(T, N),
+               reward_values=vr.numpy().reshape(T, N), cost_values=vc.numpy().reshape(T, N),
+               reward_advantages=rng.randn(T, N).astype(np.float32) * 2, cost_advantages=rng.rand(T, N).astype(np.float32),
+               reward_returns=rng.randn(T, N).astype(np.float32), cost_returns=rng.rand(T, N).astype(np.float32),
+               orig_costs=rng.rand(T, N).astype(np.float32))
+    _fill(agent, buf)
+    perms = np.stack([rng.permutation(T * N) for _ in range(E)])
+    nu = agent.dual.nu().item()
+    agent.train(perms=perms)
+    pol, out = _oracle_train(sd0, buf, perms, kind, nu, lr=lr, batch_size=B, n_epochs=E, clip_range=0.2, target_kl=tk)
+    from icrl_amd import logger
+    lg = logger.Logger.CURRENT.name_to_value
+    assert lg["train/early_stop_epoch"] == out["train/early_stop_epoch"]
+    n_steps = agent.policy.adam_step
+    for k, v in agent.policy.state_dict().items():
+        ref = pol.params[k].detach().numpy()
+        # Adam's normalised step is ~lr per step: allow a small fraction of the total travel
+        assert np.allclose(v.numpy(), ref, rtol=1e-3, atol=0.02 * lr * n_steps + 2e-6), (k, np.abs(v.numpy() - ref).max())
+    for key in ("train/policy_gradient_loss", "train/reward_value_loss", "train/cost_value_loss", "train/approx_kl",
+                "train/clip_fraction", "train/entropy_loss", "train/loss"):
+        assert abs(lg[key] - out[key]) < 2e-4 + 2e-3 * abs(out[key]), (key, lg[key], out[key])
+    assert np.allclose(agent.epoch_kls[:len(out["epoch_kls"])], out["epoch_kls"], atol=2e-5)
