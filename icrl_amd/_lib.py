@@ -22,6 +22,7 @@ SIGNATURES = {
     "icrl_policy_prepare": [c_void_p, c_void_p],
     "icrl_costnet_prepare": [c_void_p, c_void_p],
     "icrl_policy_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8,
+    "icrl_policy_evaluate": [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 5,
     "icrl_cost_mlp_forward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "icrl_synth_env_reset": [c_void_p, c_void_p],
     "icrl_synth_env_step": [c_void_p] * 5,
@@ -29,7 +30,11 @@ SIGNATURES = {
     "icrl_vecnorm_step": [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 4,
     "icrl_rollout_collect": [c_void_p] * 9 + [c_double] * 4 + [c_void_p],
     "icrl_ppo_lag_train": [c_void_p] * 11,
+    "icrl_cn_prepare": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "icrl_cn_train_work_floats": [c_int, c_int, c_int, c_int],
+    "icrl_cn_train": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
 }
+RESTYPES = {"icrl_cn_train_work_floats": ctypes.c_size_t}
 
 
 class HipExtensionMissing(RuntimeError):
@@ -50,7 +55,7 @@ def lib():
         for name, argtypes in SIGNATURES.items():
             fn = getattr(_lib, name)
             fn.argtypes = argtypes
-            fn.restype = c_int
+            fn.restype = RESTYPES.get(name, c_int)
     return _lib
 
 

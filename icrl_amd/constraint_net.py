@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .structs import CostNetT, p
+from .structs import CnHyperT, CostNetT, p
 
 
 class ConstraintNet:
@@ -132,3 +132,93 @@ class ConstraintNet:
                           for k in self.shapes])
         self.params.copy_(flat.to(self.device))
         self.prepare()
+
+    # ---- training (ref: constraint_net.py:137-229) ------------------------------------------------------------------------
+    def _update_learning_rate(self, current_progress_remaining):
+        self.current_progress_remaining = current_progress_remaining
+        self.lr = float(self.lr_schedule(current_progress_remaining))
+
+    def prepare_data(self, obs, acs):
+        """ref: constraint_net.py:258-270 -> device float32 [N, input_dims]."""
+        dev = self.device
+        obs = torch.as_tensor(np.asarray(obs) if not torch.is_tensor(obs) else obs, device=dev).to(torch.float64).reshape(-1, self.obs_dim).contiguous()
+        a_w = 1 if self.is_discrete else self.acs_dim
+        acs = torch.as_tensor(np.asarray(acs) if not torch.is_tensor(acs) else acs, device=dev).to(torch.float32).reshape(-1, a_w).contiguous()
+        out = torch.empty(obs.shape[0], self.input_dims, device=dev)
+        s = self.struct()
+        _lib.check(_lib.lib().icrl_cn_prepare(_lib.byref(s), p(obs), p(acs), obs.shape[0], p(out), _lib.current_stream()), "icrl_cn_prepare")
+        return out
+
+    def train(self, iterations, nominal_obs, nominal_acs, episode_lengths, obs_mean=None, obs_var=None,
+              current_progress_remaining=1):
+        if self.batch_size is not None:
+            raise NotImplementedError("cn_batch_size: only the reference's default full-batch mode is on the hot path")
+        self._update_learning_rate(current_progress_remaining)
+        self.current_obs_mean, self.current_obs_var = obs_mean, obs_var
+        self._refresh_consts()
+        nominal = self.prepare_data(nominal_obs, nominal_acs)
+        if getattr(self, "_expert_cache", None) is None or obs_mean is not None:
+            self._expert_cache = self.prepare_data(self.expert_obs, self.expert_acs)
+        expert = self._expert_cache
+        dev, iters = self.device, int(iterations)
+        lengths = np.asarray(episode_lengths, np.int64)
+        offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+        assert offs[-1] == nominal.shape[0], "episode_lengths must cover the nominal rows"
+        d_off = torch.as_tensor(offs, device=dev)
+        d_rowep = torch.as_tensor(np.repeat(np.arange(len(lengths), dtype=np.int32), lengths), device=dev)
+        L = _lib.lib()
+        n_work = L.icrl_cn_train_work_floats(self.n_params, nominal.shape[0], expert.shape[0], len(lengths))
+        work = torch.empty(n_work, device=dev)
+        metrics = torch.zeros(max(iters, 1), 24, device=dev)
+        t_dev = torch.tensor([self.adam_step], dtype=torch.int32, device=dev)
+        hp = CnHyperT(iters, int(self.importance_sampling), int(self.per_step_importance_sampling), int(bool(self.train_gail_lambda)),
+                      float(self.regularizer_coeff), float(self.eps), float(self.target_kl_old_new), float(self.target_kl_new_old),
+                      float(self.lr), 0.9, 0.999, float(self.optimizer_kwargs.get("eps", 1e-8)))
+        s = self.struct()
+        _lib.check(L.icrl_cn_train(_lib.byref(s), p(self.exp_avg), p(self.exp_avg_sq), p(t_dev), p(nominal), p(expert),
+                                   nominal.shape[0], expert.shape[0], p(d_off), p(d_rowep), len(lengths), _lib.byref(hp),
+                                   p(work), p(metrics), _lib.current_stream()), "icrl_cn_train")
+        self.prepare()
+        m = metrics.cpu().numpy()          # the only host sync of the backward step
+        self.adam_step = int(t_dev.item())
+        stopped = np.nonzero(m[:iters, 0] != 0)[0]
+        early_stop_itr = int(stopped[0]) if len(stopped) else iters
+        last_exec = early_stop_itr - 1 if len(stopped) else iters - 1       # iteration whose loss / preds the reference reports
+        last_is = min(early_stop_itr, iters - 1)
+        nanrow = np.full(24, np.nan, np.float32); nanrow[6] = np.inf
+        lo = m[last_exec] if last_exec >= 0 else nanrow
+        bw = {"backward/cn_loss": float(lo[6]), "backward/expert_loss": float(lo[7]),
+              "backward/unweighted_nominal_loss": float(lo[8]), "backward/nominal_loss": float(lo[9]),
+              "backward/regularizer_loss": float(lo[10]),
+              "backward/is_mean": float(m[last_is][3]), "backward/is_max": float(m[last_is][4]), "backward/is_min": float(m[last_is][5]),
+              "backward/nominal_preds_max": float(lo[11]), "backward/nominal_preds_min": float(lo[12]),
+              "backward/nominal_preds_mean": float(lo[13]), "backward/expert_preds_max": float(lo[14]),
+              "backward/expert_preds_min": float(lo[15]), "backward/expert_preds_mean": float(lo[16])}
+        if self.importance_sampling:
+            bw.update({"backward/kl_old_new": float(m[last_is][1]), "backward/kl_new_old": float(m[last_is][2]),
+                       "backward/early_stop_itr": early_stop_itr})
+        return bw
+
+    # ---- persistence (ref: constraint_net.py:323-402) -----------------------------------------------------------------------
+    def save(self, save_path):
+        torch.save(dict(cn_network=self.state_dict(), cn_optimizer=dict(exp_avg=self.exp_avg.cpu(), exp_avg_sq=self.exp_avg_sq.cpu(),
+                                                                         step=self.adam_step),
+                        obs_dim=self.obs_dim, acs_dim=self.acs_dim, is_discrete=self.is_discrete, obs_select_dim=self.obs_select_dim,
+                        acs_select_dim=self.acs_select_dim, clip_obs=self.clip_obs, obs_mean=self.current_obs_mean,
+                        obs_var=self.current_obs_var, action_low=self.action_low, action_high=self.action_high,
+                        device=str(self.device), hidden_sizes=self.hidden_sizes), save_path)
+
+    @classmethod
+    def load(cls, load_path, obs_dim=None, acs_dim=None, is_discrete=None, obs_select_dim=None, acs_select_dim=None,
+             clip_obs=None, obs_mean=None, obs_var=None, action_low=None, action_high=None, device="auto"):
+        """Loads the reference's .pt format.  The reference passes the constructor arguments positionally ONE SLOT OFF
+        (constraint_net.py:394-399), so a loaded net has clip_obs=None, no action clipping, no observation normalisation and
+        no optimizer — reproduced here because it is what the constraint-transfer runs (cpg) evaluate."""
+        sd = torch.load(load_path, map_location="cpu", weights_only=False) if not isinstance(load_path, dict) else load_path
+        g = lambda v, k: sd[k] if v is None else v
+        obs_dim, acs_dim, is_discrete = g(obs_dim, "obs_dim"), g(acs_dim, "acs_dim"), g(is_discrete, "is_discrete")
+        obs_select_dim, acs_select_dim = g(obs_select_dim, "obs_select_dim"), g(acs_select_dim, "acs_select_dim")
+        net = cls(obs_dim, acs_dim, sd["hidden_sizes"], None, (lambda x: 0.0), None, None, is_discrete, 0.0,
+                  obs_select_dim, acs_select_dim, optimizer_class=None, clip_obs=None, action_low=None, action_high=None)
+        net.load_state_dict(sd["cn_network"])
+        return net

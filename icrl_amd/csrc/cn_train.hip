@@ -1,0 +1,465 @@
+// ConstraintNet backward step (zeta_theta training) — gfx950.
+//
+// ref: icrl/constraint_net.py:137-229 (train), :231-256 (compute_is_weights), :258-299 (prepare_data).
+//
+// Full-batch mode (batch_size None — the reference's default and every README configuration): one optimiser step per
+// iteration over ALL nominal + expert rows.  Per iteration:
+//   cn_forward_kernel   blocks of 64 rows x 256 threads: ReLU-MLP + sigmoid forward, predictions and per-block partial sums
+//   cn_finalize_kernel  one workgroup: fixed-order reduction of the partials, per-episode float32 products of the
+//                       likelihood ratios (one wave per episode), KLs, importance weights, early-stop flag, losses
+//   cn_backward_kernel  blocks of 64 rows: recompute the forward from LDS, analytic backward, per-block gradient partials
+//   cn_adam_kernel      fixed-order sum of the partials over blocks + Adam (eps 1e-5, no gradient clipping)
+// All reductions have a fixed order (no atomics), so repeated runs are bit-identical.
+//
+// Quirks kept: per-step weights act through mean(w) * mean(log zeta_N) (the reference's [B,1,1] x [B,1]
+// broadcast); per-episode products are float32 and may overflow to inf / nan, in which case the comparisons of the
+// early-stop test are false.
+#include "common.h"
+
+namespace icrl {
+
+constexpr int CN_ROWS = 64;
+constexpr int CN_TH = 256;
+constexpr int CN_NPART = 16;   // statistics per block
+
+struct CnDims {
+  int D, nh, H1, H2, HL;       // input, hidden layers, widths, width of the last hidden layer
+  int W0, b0, W1, b1, Wo, bo, n_params;
+  // LDS offsets (floats)
+  int sW, sX, sH1, sH2, sD1, sD2, sZ, total;
+};
+
+__host__ __device__ inline CnDims make_cn_dims(int D, int nh, int H1, int H2) {
+  CnDims d;
+  CnLayout L = make_cn_layout(D, nh, H1, H2);
+  d.D = D; d.nh = nh; d.H1 = H1; d.H2 = (nh == 2 ? H2 : 0); d.HL = L.H2;
+  d.W0 = L.W0; d.b0 = L.b0; d.W1 = L.W1; d.b1 = L.b1; d.Wo = L.Wo; d.bo = L.bo; d.n_params = L.n;
+  int off = 0;
+  d.sW = off; off += L.n;
+  d.sX = off; off += CN_ROWS * (D + 1);
+  d.sH1 = off; off += CN_ROWS * (H1 + 1);
+  d.sH2 = off; off += (nh == 2 ? CN_ROWS * (H2 + 1) : 0);
+  d.sD1 = off; off += CN_ROWS * (H1 + 1);
+  d.sD2 = off; off += (nh == 2 ? CN_ROWS * (H2 + 1) : 0);
+  d.sZ = off; off += 2 * CN_ROWS;
+  d.total = off;
+  return d;
+}
+
+// scalars shared between the kernels of one train() call (device floats in `work`)
+enum { SC_STOPPED = 0, SC_MEAN_W, SC_ITER, SC_COUNT = 16 };
+
+struct CnTrainArgs {
+  CnDims d;
+  float* params;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int* adam_t;
+  const float* nominal;
+  const float* expert;
+  int Nn, Ne, n_ep, nb_n, nb_e;
+  const int* ep_off;
+  const int* row_ep;
+  icrl_cn_hyper_t hp;
+  float* start_preds;  // [Nn]
+  float* preds_n;      // [Nn]
+  float* preds_e;      // [Ne]
+  float* part;         // [nb_n + nb_e][CN_NPART]
+  float* ep_prod;      // [n_ep]
+  float* ep_slog;      // [n_ep]
+  float* normed;       // [n_ep]
+  float* scal;         // [SC_COUNT]
+  float* gpart;        // [nb_n + nb_e][n_params]
+  float* metrics;      // [iterations][ICRL_CN_METRICS]
+};
+
+// block-level forward of CN_ROWS rows starting at row0 of `src` ([n, D]); leaves x, h1, (h2) in LDS, zeta in sm[sZ + row]
+__device__ __forceinline__ void cn_block_forward(const CnDims& d, float* sm, const float* params, const float* src, int row0,
+                                                 int n_rows_total) {
+  const int tid = threadIdx.x;
+  const int row = tid & 63, part = __builtin_amdgcn_readfirstlane(tid >> 6);
+  for (int i = tid; i < d.n_params; i += CN_TH) sm[d.sW + i] = params[i];
+  const int D = d.D;
+  for (int i = tid; i < CN_ROWS * D; i += CN_TH) {
+    const int rr = i / D, k = i % D;
+    sm[d.sX + rr * (D + 1) + k] = (row0 + rr < n_rows_total) ? src[(size_t)(row0 + rr) * D + k] : 0.f;
+  }
+  __syncthreads();
+  const float* W = sm + d.sW;
+  const float* x = sm + d.sX + row * (D + 1);
+  float* h1 = sm + d.sH1 + row * (d.H1 + 1);
+  for (int j = part; j < d.H1; j += 4) {
+    float acc = 0.f;
+    const float* wr = W + d.W0 + j * D;
+    for (int k = 0; k < D; ++k) acc = fmaf(x[k], wr[k], acc);
+    h1[j] = fmaxf(acc + W[d.b0 + j], 0.f);
+  }
+  __syncthreads();
+  const float* hl = h1;
+  if (d.nh == 2) {
+    float* h2 = sm + d.sH2 + row * (d.H2 + 1);
+    for (int j = part; j < d.H2; j += 4) {
+      float acc = 0.f;
+      const float* wr = W + d.W1 + j * d.H1;
+      for (int k = 0; k < d.H1; ++k) acc = fmaf(h1[k], wr[k], acc);
+      h2[j] = fmaxf(acc + W[d.b1 + j], 0.f);
+    }
+    __syncthreads();
+    hl = h2;
+  }
+  if (part == 0) {
+    float acc = 0.f;
+    for (int j = 0; j < d.HL; ++j) acc = fmaf(hl[j], W[d.Wo + j], acc);
+    const float z = acc + W[d.bo];
+    sm[d.sZ + row] = 1.f / (1.f + expf(-z));
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(CN_TH) cn_forward_kernel(CnTrainArgs a, int itr) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  if (a.scal[SC_STOPPED] != 0.f) return;
+  const CnDims& d = a.d;
+  const int blk = blockIdx.x;
+  const bool nominal = blk < a.nb_n;
+  const int row0 = (nominal ? blk : blk - a.nb_n) * CN_ROWS;
+  const int n_tot = nominal ? a.Nn : a.Ne;
+  cn_block_forward(d, sm, a.params, nominal ? a.nominal : a.expert, row0, n_tot);
+  if (threadIdx.x < 64) {
+    const int row = threadIdx.x, g = row0 + row;
+    const bool valid = g < n_tot;
+    const float z = sm[d.sZ + row];
+    const float eps = a.hp.eps;
+    float ratio = 0.f;
+    if (valid) {
+      if (nominal) {
+        a.preds_n[g] = z;
+        if (itr == 0) a.start_preds[g] = z;
+        const float zo = itr == 0 ? z : a.start_preds[g];
+        ratio = (z + eps) / (zo + eps);
+      } else {
+        a.preds_e[g] = z;
+      }
+    }
+    const float lg = valid ? logf(z + eps) : 0.f;
+    // torch BCELoss clamps log at -100
+    const float bce = valid ? (nominal ? fmaxf(logf(1.f - z), -100.f) : fmaxf(logf(z), -100.f)) : 0.f;
+    const float s_log = wave_sum(lg);
+    const float s_om = wave_sum(valid ? 1.f - z : 0.f);
+    const float s_z = wave_sum(valid ? z : 0.f);
+    const float mx = wave_max(valid ? z : -INFINITY);
+    const float mn = wave_min(valid ? z : INFINITY);
+    const float s_r = wave_sum(ratio);
+    const float mxr = wave_max(valid ? ratio : -INFINITY);
+    const float mnr = wave_min(valid ? ratio : INFINITY);
+    const float s_b = wave_sum(bce);
+    if (row == 0) {
+      float* p = a.part + (size_t)blk * CN_NPART;
+      p[0] = s_log; p[1] = s_om; p[2] = s_z; p[3] = mx; p[4] = mn; p[5] = s_r; p[6] = mxr; p[7] = mnr; p[8] = s_b;
+    }
+  }
+}
+
+__device__ __forceinline__ float wave_prod(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v *= __shfl_xor(v, m, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(1024) cn_finalize_kernel(CnTrainArgs a, int itr) {
+  __shared__ float red[2][CN_NPART];
+  if (a.scal[SC_STOPPED] != 0.f) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const float eps = a.hp.eps;
+  // ---- fixed-order reduction of the per-block partials: wave <-> (set, stat) pair, lanes stride over the blocks
+  for (int pair = wv; pair < 2 * 9; pair += 16) {
+    const int set = pair / 9, s = pair % 9;
+    const int b0 = set == 0 ? 0 : a.nb_n, b1 = set == 0 ? a.nb_n : a.nb_n + a.nb_e;
+    const bool is_max = (s == 3 || s == 6), is_min = (s == 4 || s == 7);
+    float acc = is_max ? -INFINITY : (is_min ? INFINITY : 0.f);
+    for (int b = b0 + lane; b < b1; b += 64) {
+      const float v = a.part[(size_t)b * CN_NPART + s];
+      if (is_max) acc = fmaxf(acc, v);
+      else if (is_min) acc = fminf(acc, v);
+      else acc += v;
+    }
+    acc = is_max ? wave_max(acc) : (is_min ? wave_min(acc) : wave_sum(acc));
+    if (lane == 0) red[set][s] = acc;
+  }
+  // ---- per-episode float32 product of the ratios and sum of log(zeta + eps): one wave per episode
+  if (a.hp.importance_sampling) {
+    for (int e = wv; e < a.n_ep; e += 16) {
+      float pr = 1.f, sl = 0.f;
+      for (int i = a.ep_off[e] + lane; i < a.ep_off[e + 1]; i += 64) {
+        const float z = a.preds_n[i];
+        const float zo = itr == 0 ? z : a.start_preds[i];
+        pr *= (z + eps) / (zo + eps);
+        sl += logf(z + eps);
+      }
+      pr = wave_prod(pr);
+      sl = wave_sum(sl);
+      if (lane == 0) { a.ep_prod[e] = pr; a.ep_slog[e] = sl; }
+    }
+  }
+  __syncthreads();
+  if (tid != 0) return;
+  const float Nn = (float)a.Nn, Ne = (float)a.Ne;
+  float* m = a.metrics + (size_t)itr * ICRL_CN_METRICS;
+  float kl_on = 0.f, kl_no = 0.f, is_mean = 1.f, is_max = 1.f, is_min = 1.f;
+  float weighted = red[0][0] / Nn;   // nominal_loss for the no-IS case: mean(log(zeta_N + eps))
+  bool stop = false;
+  if (a.hp.importance_sampling) {
+    const int ne = a.n_ep;
+    float sum_p = 0.f;
+    for (int e = 0; e < ne; ++e) sum_p += a.ep_prod[e];
+    const float pm = sum_p / (float)ne;
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = 0; e < ne; ++e) {
+      const float lp = logf(a.ep_prod[e] + eps);
+      s1 += -lp;
+      s2 += (a.ep_prod[e] - pm) * lp / (pm + eps);
+    }
+    kl_on = s1 / (float)ne;
+    kl_no = s2 / (float)ne;
+    if (a.hp.per_step) {
+      const float mean_ratio = red[0][5] / Nn;
+      is_mean = (red[0][5] / mean_ratio) / Nn;
+      is_max = red[0][6] / mean_ratio;
+      is_min = red[0][7] / mean_ratio;
+      weighted = is_mean * (red[0][0] / Nn);        // mean over the [B,B,1] broadcast == mean(w) * mean(log)
+      a.scal[SC_MEAN_W] = is_mean;
+    } else {
+      float acc = 0.f, wsum = 0.f, wmax = -INFINITY, wmin = INFINITY;
+      for (int e = 0; e < ne; ++e) {
+        const float nw = (float)ne * a.ep_prod[e] / (sum_p + eps);
+        a.normed[e] = nw;
+        acc += nw * a.ep_slog[e];
+        wsum += nw * (float)(a.ep_off[e + 1] - a.ep_off[e]);
+        wmax = fmaxf(wmax, nw); wmin = fminf(wmin, nw);
+      }
+      weighted = acc / Nn;
+      is_mean = wsum / Nn; is_max = wmax; is_min = wmin;
+    }
+    stop = (a.hp.target_kl_old_new != -1.f && kl_on > a.hp.target_kl_old_new) ||
+           (a.hp.target_kl_new_old != -1.f && kl_no > a.hp.target_kl_new_old);
+  }
+  const float expert_loss = a.hp.gail ? -(red[1][8] / Ne) : red[1][0] / Ne;
+  const float unweighted = red[0][0] / Nn;
+  float nominal_loss, reg, loss;
+  if (a.hp.gail) {
+    nominal_loss = -(red[0][8] / Nn);
+    reg = 0.f;
+    loss = nominal_loss + expert_loss;
+  } else {
+    nominal_loss = weighted;
+    reg = a.hp.reg_coeff * (red[1][1] / Ne + red[0][1] / Nn);
+    loss = (-expert_loss + nominal_loss) + reg;
+  }
+  m[0] = stop ? 1.f : 0.f; m[1] = kl_on; m[2] = kl_no; m[3] = is_mean; m[4] = is_max; m[5] = is_min;
+  m[6] = loss; m[7] = expert_loss; m[8] = unweighted; m[9] = nominal_loss; m[10] = reg;
+  m[11] = red[0][3]; m[12] = red[0][4]; m[13] = red[0][2] / Nn;
+  m[14] = red[1][3]; m[15] = red[1][4]; m[16] = red[1][2] / Ne;
+  m[17] = 0.f;
+  if (stop) a.scal[SC_STOPPED] = 1.f;
+}
+
+__global__ void __launch_bounds__(CN_TH) cn_backward_kernel(CnTrainArgs a, int itr) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  if (a.scal[SC_STOPPED] != 0.f) return;
+  const CnDims& d = a.d;
+  const int blk = blockIdx.x, tid = threadIdx.x;
+  const bool nominal = blk < a.nb_n;
+  const int row0 = (nominal ? blk : blk - a.nb_n) * CN_ROWS;
+  const int n_tot = nominal ? a.Nn : a.Ne;
+  cn_block_forward(d, sm, a.params, nominal ? a.nominal : a.expert, row0, n_tot);
+  const int row = tid & 63, part = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* W = sm + d.sW;
+  // ---- d loss / d logit
+  if (part == 0) {
+    const int g = row0 + row;
+    float dz = 0.f;
+    if (g < n_tot) {
+      const float z = sm[d.sZ + row], eps = a.hp.eps;
+      float dzeta;
+      if (a.hp.gail) {
+        // BCE(zeta_N, 0) = -mean(max(log(1 - zeta), -100)); BCE(zeta_E, 1) = -mean(max(log zeta, -100))
+        if (nominal) dzeta = (logf(1.f - z) > -100.f) ? 1.f / ((float)a.Nn * (1.f - z)) : 0.f;
+        else dzeta = (logf(z) > -100.f) ? -1.f / ((float)a.Ne * z) : 0.f;
+      } else if (nominal) {
+        float wgt = 1.f;
+        if (a.hp.importance_sampling) wgt = a.hp.per_step ? a.scal[SC_MEAN_W] : a.normed[a.row_ep[g]];
+        dzeta = wgt / ((float)a.Nn * (z + eps)) - a.hp.reg_coeff / (float)a.Nn;
+      } else {
+        dzeta = -1.f / ((float)a.Ne * (z + eps)) - a.hp.reg_coeff / (float)a.Ne;
+      }
+      dz = dzeta * (z * (1.f - z));
+    }
+    sm[d.sZ + CN_ROWS + row] = dz;
+  }
+  __syncthreads();
+  const float dz = sm[d.sZ + CN_ROWS + row];
+  // ---- back through the last hidden layer (and the first, when there are two)
+  const float* h1 = sm + d.sH1 + row * (d.H1 + 1);
+  float* d1 = sm + d.sD1 + row * (d.H1 + 1);
+  if (d.nh == 2) {
+    const float* h2 = sm + d.sH2 + row * (d.H2 + 1);
+    float* d2 = sm + d.sD2 + row * (d.H2 + 1);
+    for (int j = part; j < d.H2; j += 4) d2[j] = h2[j] > 0.f ? dz * W[d.Wo + j] : 0.f;
+    __syncthreads();
+    for (int k = part; k < d.H1; k += 4) {
+      float acc = 0.f;
+      for (int j = 0; j < d.H2; ++j) acc = fmaf(d2[j], W[d.W1 + j * d.H1 + k], acc);
+      d1[k] = h1[k] > 0.f ? acc : 0.f;
+    }
+  } else {
+    for (int j = part; j < d.H1; j += 4) d1[j] = h1[j] > 0.f ? dz * W[d.Wo + j] : 0.f;
+  }
+  __syncthreads();
+  // ---- per-block parameter gradients: one thread per parameter, rows added in order
+  float* gp = a.gpart + (size_t)blk * d.n_params;
+  const int D = d.D;
+  for (int p = tid; p < d.n_params; p += CN_TH) {
+    float acc = 0.f;
+    if (p < d.b0) {                                   // W0[j][k]
+      const int j = p / D, k = p % D;
+      for (int rr = 0; rr < CN_ROWS; ++rr) acc = fmaf(sm[d.sD1 + rr * (d.H1 + 1) + j], sm[d.sX + rr * (D + 1) + k], acc);
+    } else if (p < d.b0 + d.H1) {                     // b0[j]
+      const int j = p - d.b0;
+      for (int rr = 0; rr < CN_ROWS; ++rr) acc += sm[d.sD1 + rr * (d.H1 + 1) + j];
+    } else if (d.nh == 2 && p < d.b1) {               // W1[j][k]
+      const int q = p - d.W1, j = q / d.H1, k = q % d.H1;
+      for (int rr = 0; rr < CN_ROWS; ++rr) acc = fmaf(sm[d.sD2 + rr * (d.H2 + 1) + j], sm[d.sH1 + rr * (d.H1 + 1) + k], acc);
+    } else if (d.nh == 2 && p < d.b1 + d.H2) {        // b1[j]
+      const int j = p - d.b1;
+      for (int rr = 0; rr < CN_ROWS; ++rr) acc += sm[d.sD2 + rr * (d.H2 + 1) + j];
+    } else if (p < d.bo) {                            // Wo[j]
+      const int j = p - d.Wo;
+      const int hb = d.nh == 2 ? d.sH2 : d.sH1, hs = d.HL + 1;
+      for (int rr = 0; rr < CN_ROWS; ++rr) acc = fmaf(sm[d.sZ + CN_ROWS + rr], sm[hb + rr * hs + j], acc);
+    } else {                                          // bo
+      for (int rr = 0; rr < CN_ROWS; ++rr) acc += sm[d.sZ + CN_ROWS + rr];
+    }
+    gp[p] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(256) cn_adam_kernel(CnTrainArgs a, int itr) {
+  if (a.scal[SC_STOPPED] != 0.f) return;
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nb = a.nb_n + a.nb_e;
+  const int t = a.adam_t[0] + itr + 1;   // adam_t is advanced once at the end by the host-visible counter kernel
+  if (p < a.d.n_params) {
+    float g = 0.f;
+    for (int b = 0; b < nb; ++b) g += a.gpart[(size_t)b * a.d.n_params + p];
+    const double b1 = a.hp.adam_beta1, b2 = a.hp.adam_beta2;
+    const float w1 = (float)(1.0 - b1), w2 = (float)(1.0 - b2);
+    float m = a.exp_avg[p], v = a.exp_avg_sq[p];
+    m = m + (g - m) * w1;
+    v = v * a.hp.adam_beta2 + w2 * (g * g);
+    const float step_size = (float)((double)a.hp.lr / (1.0 - pow(b1, (double)t)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow(b2, (double)t));
+    const float denom = sqrtf(v) / bc2_sqrt + a.hp.adam_eps;
+    a.params[p] = a.params[p] - step_size * (m / denom);
+    a.exp_avg[p] = m; a.exp_avg_sq[p] = v;
+  }
+  if (p == 0) { a.metrics[(size_t)itr * ICRL_CN_METRICS + 17] = 1.f; a.scal[SC_ITER] = (float)(itr + 1); }
+}
+
+__global__ void cn_commit_kernel(CnTrainArgs a) {
+  // advance the optimiser step counter by the number of executed updates
+  if (threadIdx.x == 0 && blockIdx.x == 0) a.adam_t[0] += (int)a.scal[SC_ITER];
+}
+
+__global__ void __launch_bounds__(64) cn_prepare_kernel(icrl_costnet_t cn, const double* obs, const float* acs, int N, float* out) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const double* obs_row = obs + (size_t)n * cn.obs_dim;
+  const float* acs_row = acs + (size_t)n * (cn.is_discrete ? 1 : cn.acs_dim);
+  for (int i = lane; i < cn.in_dim; i += 64) {
+    const int sel = cn.select_dim[i];
+    float v;
+    if (sel < cn.obs_dim) {
+      double o = obs_row[sel];
+      if (cn.obs_mean != nullptr && cn.obs_var != nullptr) o = (o - cn.obs_mean[sel]) / sqrt(cn.obs_var[sel] + cn.eps);
+      if (cn.clip_obs >= 0.0) o = fmin(fmax(o, -cn.clip_obs), cn.clip_obs);
+      v = (float)o;
+    } else {
+      const int k = sel - cn.obs_dim;
+      float x = cn.is_discrete ? (((int)acs_row[0] == k) ? 1.f : 0.f) : acs_row[k];
+      if (cn.action_low != nullptr && cn.action_high != nullptr) x = fminf(fmaxf(x, cn.action_low[k]), cn.action_high[k]);
+      v = x;
+    }
+    out[(size_t)n * cn.in_dim + i] = v;
+  }
+}
+
+static void cn_work_layout(int n_params, int Nn, int Ne, int n_ep, size_t* offs /* 9 */, size_t* total) {
+  const size_t nb = (size_t)((Nn + CN_ROWS - 1) / CN_ROWS + (Ne + CN_ROWS - 1) / CN_ROWS);
+  size_t o = 0;
+  offs[0] = o; o += (size_t)Nn;            // start_preds
+  offs[1] = o; o += (size_t)Nn;            // preds_n
+  offs[2] = o; o += (size_t)Ne;            // preds_e
+  offs[3] = o; o += nb * CN_NPART;         // part
+  offs[4] = o; o += (size_t)n_ep;          // ep_prod
+  offs[5] = o; o += (size_t)n_ep;          // ep_slog
+  offs[6] = o; o += (size_t)n_ep;          // normed
+  offs[7] = o; o += SC_COUNT;              // scal
+  offs[8] = o; o += nb * (size_t)n_params; // gpart
+  *total = o;
+}
+
+}  // namespace icrl
+
+using namespace icrl;
+
+extern "C" size_t icrl_cn_train_work_floats(int n_params, int Nn, int Ne, int n_ep) {
+  size_t offs[9], total;
+  cn_work_layout(n_params, Nn, Ne, n_ep, offs, &total);
+  return total;
+}
+
+extern "C" int icrl_cn_prepare(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, void* stream) {
+  if (N <= 0) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(cn_prepare_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, obs, acs, N, out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
+                             const float* nominal, const float* expert, int Nn, int Ne, const int32_t* ep_offsets,
+                             const int32_t* row_episode, int n_ep, const icrl_cn_hyper_t* hp, float* work, float* metrics,
+                             void* stream) {
+  if (Nn <= 0 || Ne <= 0 || n_ep <= 0 || hp->iterations < 0 || cn->n_hidden < 1 || cn->n_hidden > 2) return (int)hipErrorInvalidValue;
+  CnTrainArgs a;
+  a.d = make_cn_dims(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
+  if (a.d.n_params != cn->n_params) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)a.d.total * sizeof(float);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  a.params = cn->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
+  a.nominal = nominal; a.expert = expert; a.Nn = Nn; a.Ne = Ne; a.n_ep = n_ep;
+  a.nb_n = (Nn + CN_ROWS - 1) / CN_ROWS; a.nb_e = (Ne + CN_ROWS - 1) / CN_ROWS;
+  a.ep_off = ep_offsets; a.row_ep = row_episode; a.hp = *hp;
+  size_t offs[9], total;
+  cn_work_layout(cn->n_params, Nn, Ne, n_ep, offs, &total);
+  a.start_preds = work + offs[0]; a.preds_n = work + offs[1]; a.preds_e = work + offs[2]; a.part = work + offs[3];
+  a.ep_prod = work + offs[4]; a.ep_slog = work + offs[5]; a.normed = work + offs[6]; a.scal = work + offs[7];
+  a.gpart = work + offs[8]; a.metrics = metrics;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(a.scal, 0, SC_COUNT * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  if (hp->iterations > 0) {
+    e = hipMemsetAsync(metrics, 0, (size_t)hp->iterations * ICRL_CN_METRICS * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  e = hipFuncSetAttribute((const void*)cn_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute((const void*)cn_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  const int nb = a.nb_n + a.nb_e;
+  for (int itr = 0; itr < hp->iterations; ++itr) {
+    hipLaunchKernelGGL(cn_forward_kernel, dim3(nb), dim3(CN_TH), lds, s, a, itr);
+    hipLaunchKernelGGL(cn_finalize_kernel, dim3(1), dim3(1024), 0, s, a, itr);
+    hipLaunchKernelGGL(cn_backward_kernel, dim3(nb), dim3(CN_TH), lds, s, a, itr);
+    hipLaunchKernelGGL(cn_adam_kernel, dim3((cn->n_params + 255) / 256), dim3(256), 0, s, a, itr);
+  }
+  hipLaunchKernelGGL(cn_commit_kernel, dim3(1), dim3(64), 0, s, a);
+  return (int)hipGetLastError();
+}

@@ -64,7 +64,8 @@ struct ActShared {
 // three tanh MLPs + heads for the observation in sh.x.  Must be called by all 192 threads.
 __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const float* __restrict__ PT, ActShared& sh,
                                                      const float* noise_row, int deterministic,
-                                                     const float* alow, const float* ahigh) {
+                                                     const float* alow, const float* ahigh,
+                                                     const float* given = nullptr /* evaluate_actions: actions to score */) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (lane < L.H1) {
@@ -94,7 +95,8 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const f
       if (lane < L.A) {
         const float std = expf(PT[L.log_std + lane]);
         float act = mean;
-        if (!deterministic) act = mean + noise_row[lane] * std;   // Normal.rsample: loc + eps * scale
+        if (given != nullptr) act = given[lane];
+        else if (!deterministic) act = mean + noise_row[lane] * std;   // Normal.rsample: loc + eps * scale
         const float diff = act - mean;
         // Normal.log_prob: -((x - mu)^2) / (2 var) - log(std) - log(sqrt(2 pi))
         lp = -(diff * diff) / (2.f * (std * std)) - logf(std) - LOG_SQRT_2PI_F;
@@ -104,7 +106,9 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const f
         sh.act_clip[lane] = c;
       }
       lp = wave_sum(lp);
-      if (lane == 0) sh.scal[2] = lp;
+      // entropy of the diagonal Gaussian: sum_a 0.5 + 0.5 log(2 pi) + log sigma_a
+      const float ent = wave_sum(lane < L.A ? HALF_LOG_2PI_PLUS_HALF_F + logf(expf(PT[L.log_std + lane])) : 0.f);
+      if (lane == 0) { sh.scal[2] = lp; sh.scal[3] = ent; }
     } else {
       // Categorical(logits): log-softmax, inverse-CDF sample on the injected uniform (spec: oracle/nets.py forward)
       float m = wave_max(lane < L.A ? mean : -INFINITY);
@@ -115,7 +119,9 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const f
       // inclusive prefix sum over the first A lanes (A <= 16: sequential in lane 0 order, matches th.cumsum)
       float cdf = 0.f;
       int action = 0;
-      if (deterministic) {
+      if (given != nullptr) {
+        action = (int)given[0];
+      } else if (deterministic) {
         float best = wave_max(lane < L.A ? p : -1.f);
         unsigned long long ball = __ballot(lane < L.A && p == best);
         action = __ffsll((long long)ball) - 1;
@@ -129,7 +135,8 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const f
         action = cnt < L.A - 1 ? cnt : L.A - 1;
       }
       const float lp = __shfl(logp, action, 64);
-      if (lane == 0) { sh.scal[2] = lp; sh.act_raw[0] = (float)action; sh.act_clip[0] = (float)action; }
+      const float ent = -wave_sum(lane < L.A ? logp * p : 0.f);
+      if (lane == 0) { sh.scal[2] = lp; sh.scal[3] = ent; sh.act_raw[0] = (float)action; sh.act_clip[0] = (float)action; }
     }
   } else {
     const int off = (w == 1) ? L.Wv : L.Wc;
@@ -534,15 +541,17 @@ __global__ void __launch_bounds__(1024) norm_reset_kernel(icrl_norm_t nm, const 
 __global__ void __launch_bounds__(192) policy_forward_kernel(PolLayout pl, const float* PT, const double* obs,
                                                              const float* noise, int deterministic, const float* alow,
                                                              const float* ahigh, float* actions, float* act_clipped,
-                                                             float* v_r, float* v_c, float* log_prob) {
+                                                             float* v_r, float* v_c, float* log_prob,
+                                                             const float* given = nullptr, float* entropy = nullptr) {
   __shared__ ActShared sh;
   const int n = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < pl.O; i += 192) sh.x[i] = (float)obs[(size_t)n * pl.O + i];
   __syncthreads();
   const float* noise_row = noise ? noise + (size_t)n * (pl.discrete ? 1 : pl.A) : nullptr;
-  policy_forward_block(pl, PT, sh, noise_row, deterministic || noise == nullptr, alow, ahigh);
-  __syncthreads();
   const int AS = pl.discrete ? 1 : pl.A;
+  policy_forward_block(pl, PT, sh, noise_row, deterministic || noise == nullptr, alow, ahigh,
+                       given ? given + (size_t)n * AS : nullptr);
+  __syncthreads();
   if (tid < AS) {
     if (actions) actions[(size_t)n * AS + tid] = sh.act_raw[tid];
     if (act_clipped) act_clipped[(size_t)n * AS + tid] = sh.act_clip[tid];
@@ -551,6 +560,7 @@ __global__ void __launch_bounds__(192) policy_forward_kernel(PolLayout pl, const
     if (v_r) v_r[n] = sh.scal[0];
     if (v_c) v_c[n] = sh.scal[1];
     if (log_prob) log_prob[n] = sh.scal[2];
+    if (entropy) entropy[n] = sh.scal[3];
   }
 }
 
@@ -619,6 +629,16 @@ extern "C" int icrl_policy_forward(const icrl_policy_t* p, const double* obs, co
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
   hipLaunchKernelGGL(policy_forward_kernel, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, noise,
                      deterministic, action_low, action_high, actions, act_clipped, v_r, v_c, log_prob);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_policy_evaluate(const icrl_policy_t* p, const double* obs, const float* actions, int N, float* v_r,
+                                    float* v_c, float* log_prob, float* entropy, void* stream) {
+  if (N <= 0 || !dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return (int)hipErrorInvalidValue;
+  PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
+  hipLaunchKernelGGL(policy_forward_kernel, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs,
+                     (const float*)nullptr, 1, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                     v_r, v_c, log_prob, actions, entropy);
   return (int)hipGetLastError();
 }
 

@@ -147,3 +147,16 @@ class ActorTwoCriticsPolicy:
         """ref: policies.py:215-280 — sampled (or mode) action clipped to the action box; returns (actions, state)."""
         self.forward(observation, deterministic, noise)
         return self.last_clipped, state
+
+    def evaluate_actions(self, obs, actions):
+        """ref: policies.py:752-767 -> (reward_values, cost_values, log_prob, entropy); device tensors."""
+        dev = self.device
+        obs = torch.as_tensor(obs, device=dev).to(torch.float64).reshape(-1, self.obs_dim).contiguous()
+        a_store = 1 if self.discrete else self.act_dim
+        actions = torch.as_tensor(actions, device=dev).to(torch.float32).reshape(-1, a_store).contiguous()
+        n = obs.shape[0]
+        v_r, v_c, lp, ent = (torch.empty(n, device=dev) for _ in range(4))
+        s = self.struct()
+        _lib.check(_lib.lib().icrl_policy_evaluate(_lib.byref(s), p(obs), p(actions), n, p(v_r), p(v_c), p(lp), p(ent),
+                                                   _lib.current_stream()), "icrl_policy_evaluate")
+        return v_r.reshape(-1, 1), v_c.reshape(-1, 1), lp, ent

@@ -51,6 +51,12 @@ class PpoHyperT(C.Structure):
                 ("adam_eps", C.c_float)]
 
 
+class CnHyperT(C.Structure):
+    _fields_ = [("iterations", i32), ("importance_sampling", i32), ("per_step", i32), ("gail", i32),
+                ("reg_coeff", C.c_float), ("eps", C.c_float), ("target_kl_old_new", C.c_float), ("target_kl_new_old", C.c_float),
+                ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float)]
+
+
 def p(t):
     """device pointer of a contiguous tensor (or None -> NULL)."""
     if t is None:

@@ -120,6 +120,15 @@ typedef struct {
   float lr, adam_beta1, adam_beta2, adam_eps;
 } icrl_ppo_hyper_t;
 
+/* ConstraintNet.train hyper-parameters (icrl/constraint_net.py:15-42,137-229). */
+typedef struct {
+  int32_t iterations, importance_sampling, per_step, gail;
+  float reg_coeff, eps, target_kl_old_new, target_kl_new_old; /* target < 0 (== -1): that KL test is disabled */
+  float lr, adam_beta1, adam_beta2, adam_eps;
+} icrl_cn_hyper_t;
+
+#define ICRL_CN_METRICS 24 /* floats per iteration in the metrics array of icrl_cn_train */
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Entry points
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -159,6 +168,11 @@ int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream);
 int icrl_policy_forward(const icrl_policy_t* pol, const double* obs, const float* noise, int N, int deterministic,
                         const float* action_low, const float* action_high,
                         float* actions, float* act_clipped, float* v_r, float* v_c, float* log_prob, void* stream);
+
+/* ActorTwoCriticsPolicy.evaluate_actions (policies.py:752-767): values, log-prob of the GIVEN actions and the entropy of
+ * the action distribution (used by compute_kl, icrl/utils.py:421-437).  actions [N,act_store] float32. */
+int icrl_policy_evaluate(const icrl_policy_t* pol, const double* obs, const float* actions, int N, float* v_r, float* v_c,
+                         float* log_prob, float* entropy, void* stream);
 
 /* ConstraintNet.cost_function (icrl/constraint_net.py:121-130): cost[n] = 1 - zeta(prepare(obs[n], acs[n])).
  * obs [N,obs] float64, acs [N,acs] float32 (class index in acs[n,0] when discrete). */
@@ -205,6 +219,28 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
 int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                        const icrl_buffer_t* buf, const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp,
                        float* stats, void* sync_ws, void* stream);
+
+/* ConstraintNet.prepare_data (icrl/constraint_net.py:258-270): out[n,:] = float32(concat(clip(normalise(obs)), clip(one-hot?
+ * acs))[select_dim]).  obs [N,obs] float64, acs [N,acs] float32 (class index when discrete), out [N,in_dim] float32. */
+int icrl_cn_prepare(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, void* stream);
+
+/* ConstraintNet.train after prepare_data (icrl/constraint_net.py:155-229) for the default full-batch mode
+ * (batch_size None): per iteration {forward of all nominal + expert rows, compute_is_weights (:231-256: per-episode float32
+ * products, KL(old||new), KL(new||old), per-step or per-episode weights incl. the [B,1,1]x[B,1] broadcast of the per-step
+ * mode), early-stop test, loss (likelihood-ratio or BCE "gail" form), backward, Adam}.  4 launches per iteration, no host
+ * sync; iterations after an early stop are no-ops.
+ *   nominal [Nn,in_dim], expert [Ne,in_dim] float32;  ep_offsets [n_ep+1] int32 row offsets of the nominal episodes;
+ *   row_episode [Nn] int32;  exp_avg / exp_avg_sq [n_params], adam_step [1] int32 (device): optimiser state;
+ *   work: device scratch of icrl_cn_train_work_floats(...) floats;
+ *   metrics [iterations][ICRL_CN_METRICS] float32 (device), per iteration i (values of the forward pass made at the START of
+ *   iteration i): 0 stop flag, 1 kl_old_new, 2 kl_new_old, 3 is_mean, 4 is_max, 5 is_min, 6 cn_loss, 7 expert_loss,
+ *   8 unweighted_nominal_loss, 9 nominal_loss, 10 regularizer_loss, 11..13 nominal preds max/min/mean, 14..16 expert preds
+ *   max/min/mean, 17 executed (1 if the optimiser step of this iteration ran). */
+size_t icrl_cn_train_work_floats(int n_params, int Nn, int Ne, int n_ep);
+int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
+                  const float* nominal, const float* expert, int Nn, int Ne,
+                  const int32_t* ep_offsets, const int32_t* row_episode, int n_ep,
+                  const icrl_cn_hyper_t* hp, float* work, float* metrics, void* stream);
 
 #ifdef __cplusplus
 }

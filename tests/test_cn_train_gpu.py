@@ -1,0 +1,87 @@
+"""GPU parity of ConstraintNet.train (icrl_cn_train) vs the reference (tests/golden/g6) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import cn as o_cn, nets as o_nets
+
+pytestmark = pytest.mark.gpu
+
+
+def _sub(g, prefix):
+    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+def _close(a, b, rtol=2e-4, atol=2e-5):
+    if np.isnan(b):
+        return np.isnan(a)
+    if np.isinf(b):
+        return a == b
+    return abs(a - b) <= atol + rtol * abs(b)
+
+
+@pytest.mark.parametrize("case", ["psis", "episode", "overflow", "earlystop"])
+def test_cn_train_golden(golden, case):
+    from icrl_amd.constraint_net import ConstraintNet
+    g = _sub(golden("g6_constraint_net"), case + "/")
+    psis, iters, tk_on, tk_no, lr = g["cfg"]
+    lo = -np.ones(6, np.float32)
+    cn = ConstraintNet(18, 6, [20], None, lambda x: float(lr), g["exp_obs"], g["exp_acs"], False, 0.5, clip_obs=20,
+                       action_low=lo, action_high=-lo, per_step_importance_sampling=bool(psis),
+                       target_kl_old_new=float(tk_on), target_kl_new_old=float(tk_no))
+    cn.load_state_dict(_sub(g, "w0/"))
+    m = cn.train(int(iters), g["nom_obs"], g["nom_acs"], g["lengths"])
+    assert m["backward/early_stop_itr"] == int(g["m/early_stop_itr"])
+    for k, v in m.items():
+        ref = float(g["m/" + k.split("/")[1]])
+        if case == "overflow" and k in ("backward/kl_old_new", "backward/kl_new_old"):
+            continue    # float32 episode products overflow: the reference itself yields inf/nan here (order-dependent)
+        assert _close(v, ref, rtol=2e-3, atol=2e-4), (k, v, ref)
+    for k, v in cn.state_dict().items():
+        assert np.allclose(v.numpy(), g["w1/" + k], rtol=2e-3, atol=2e-4), (k, np.abs(v.numpy() - g["w1/" + k]).max())
+
+
+@pytest.mark.parametrize("kind,hidden,psis,Nn,Ne,eplen", [("hc", [20], True, 3000, 1500, 1000), ("ant", [40, 40], True, 1500, 900, 500),
+                                                          ("hc", [20], False, 400, 300, 100)])
+def test_cn_train_vs_oracle(kind, hidden, psis, Nn, Ne, eplen):
+    from icrl_amd.constraint_net import ConstraintNet
+    rng = np.random.RandomState(Nn)
+    od, ad = (18, 6) if kind == "hc" else (113, 8)
+    lo = -np.ones(ad, np.float32)
+    exp_obs, exp_acs = rng.randn(Ne, od), rng.uniform(-1, 1, (Ne, ad)).astype(np.float32)
+    nom_obs, nom_acs = rng.randn(Nn, od) * 1.5, rng.uniform(-1.2, 1.2, (Nn, ad))
+    lengths = np.array([eplen] * (Nn // eplen))
+    torch.manual_seed(1)
+    orc = o_nets.CostNet(od, ad, hidden, False, None, None, 20, lo, -lo)
+    cn = ConstraintNet(od, ad, hidden, None, lambda x: 0.01, exp_obs, exp_acs, False, 0.6, clip_obs=20, action_low=lo, action_high=-lo,
+                       per_step_importance_sampling=psis, target_kl_old_new=10, target_kl_new_old=2.5)
+    cn.load_state_dict(orc.state_dict())
+    opt = torch.optim.Adam(orc.parameters(), lr=0.01, eps=1e-5)
+    om = o_cn.cn_train(orc, opt, 5, orc.prepare(nom_obs, nom_acs), orc.prepare(exp_obs, exp_acs), lengths, reg_coeff=0.6,
+                       per_step=psis, target_kl_old_new=10, target_kl_new_old=2.5, factored=True)
+    m = cn.train(5, nom_obs, nom_acs, lengths)
+    assert np.array_equal(cn.prepare_data(nom_obs, nom_acs).cpu().numpy(), orc.prepare(nom_obs, nom_acs).numpy())
+    assert m["backward/early_stop_itr"] == om["backward/early_stop_itr"]
+    for k, v in m.items():
+        assert _close(v, float(om[k]), rtol=3e-3, atol=3e-4), (k, v, om[k])
+    for k, v in cn.state_dict().items():
+        ref = orc.params[k].detach().numpy()
+        assert np.allclose(v.numpy(), ref, rtol=3e-3, atol=3e-4), (k, np.abs(v.numpy() - ref).max())
+    # a second call continues the optimiser state (Adam step counter, moments)
+    assert cn.adam_step == (5 if m["backward/early_stop_itr"] == 5 else m["backward/early_stop_itr"])
+
+
+def test_policy_evaluate_actions(golden):
+    from icrl_amd.policies import ActorTwoCriticsPolicy
+    from icrl_amd import spaces
+    g = golden("expert_hc")
+    pol = ActorTwoCriticsPolicy(spaces.Box(-np.inf, np.inf, (18,), np.float64), spaces.Box(-1, 1, (6,), np.float32))
+    pol.load_state_dict(_sub(g, "policy/"))
+    op = o_nets.TwoCriticPolicy(18, 6); op.load_state_dict(_sub(g, "policy/"))
+    obs, act = g["observations"][:257], g["actions"][:257]
+    vr, vc, lp, ent = pol.evaluate_actions(obs, act)
+    with torch.no_grad():
+        ovr, ovc, olp, oent = op.evaluate_actions(torch.as_tensor(obs), torch.as_tensor(act))
+    assert np.allclose(lp.cpu().numpy(), olp.numpy(), rtol=2e-4, atol=2e-4)
+    assert np.allclose(vr.cpu().numpy(), ovr.numpy(), rtol=2e-4, atol=2e-4)
+    assert np.allclose(ent.cpu().numpy(), oent.numpy(), rtol=1e-5, atol=1e-5)
