@@ -594,6 +594,89 @@ __global__ void env_reset_kernel(icrl_env_t e) {
   }
 }
 
+// =================================================================================================================
+// persistent single-env episode sampler: sample_from_agent / evaluate_policy (icrl/utils.py:323-357, evaluation.py:10-67)
+// One workgroup per independent env stream runs its episodes start to finish inside ONE launch: frozen-statistics
+// normalise -> policy forward (sample or mode) -> clip -> env step (+auto-reset) -> record (s_{t+1}, a_t), reward.
+// =================================================================================================================
+struct SampleArgs {
+  icrl_env_t env;          // arrays sized [n_streams]; env.s etc. are this call's scratch state
+  icrl_norm_t nm;          // training must be 0: statistics are only read
+  PolLayout pl;
+  const float* PT;
+  int pt_in_lds;
+  const float* noise;      // [n_streams][rows_per_stream][act] or NULL (deterministic)
+  const float* alow;
+  const float* ahigh;
+  int episodes_per_stream, rows_per_stream, deterministic, do_reset;
+  double* orig_obs;        // [n_streams*rows_per_stream, obs] raw observation AFTER each step
+  double* obs;             // same, normalised
+  float* actions;          // [.., act_store] clipped action that produced it
+  double* ep_rewards;      // [n_streams*episodes_per_stream]
+  int* ep_lengths;         // [n_streams*episodes_per_stream]
+};
+
+__global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dyn[];
+  __shared__ ActShared sh;
+  __shared__ int s_done;
+  __shared__ double s_rew;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int O = a.pl.O, A = a.pl.A;
+  const int AS = a.pl.discrete ? 1 : A;
+  const float* PT = a.PT;
+  if (a.pt_in_lds) {
+    for (int i = tid; i < a.pl.n; i += 192) dyn[i] = a.PT[i];
+    PT = dyn;
+  }
+  if (a.do_reset) {
+    for (int i = tid; i < O; i += 192)
+      a.env.s[(size_t)n * O + i] = (unit_uniform(a.env.key[n], a.env.step_count[n], (uint32_t)(O + i)) - 0.5) * 0.2;
+    if (tid == 0) a.env.t_ep[n] = 0;
+  }
+  __syncthreads();
+  size_t row = (size_t)n * a.rows_per_stream;
+  for (int ep = 0; ep < a.episodes_per_stream; ++ep) {
+    double ep_rew = 0.0;
+    int ep_len = 0;
+    while (true) {
+      for (int i = tid; i < O; i += 192) {
+        const double raw = a.env.s[(size_t)n * O + i];
+        double o = raw;
+        if (a.nm.norm_obs) o = fmin(fmax((raw - a.nm.obs_mean[i]) / sqrt(a.nm.obs_var[i] + a.nm.epsilon), -a.nm.clip_obs), a.nm.clip_obs);
+        sh.s_old[i] = raw;
+        sh.x[i] = (float)o;
+      }
+      __syncthreads();
+      const float* noise_row = a.noise ? a.noise + row * AS : nullptr;
+      policy_forward_block(a.pl, PT, sh, noise_row, a.deterministic || a.noise == nullptr, a.alow, a.ahigh);
+      __syncthreads();
+      if (w == 0) {
+        double rew; int done;
+        env_step_wave(a.env, n, sh.s_old, sh.act_clip, rew, done);
+        if (lane == 0) { s_done = done; s_rew = rew; }
+        if (lane < AS) a.actions[row * AS + lane] = sh.act_clip[lane];
+      }
+      __syncthreads();
+      for (int i = tid; i < O; i += 192) {
+        const double raw = a.env.s[(size_t)n * O + i];
+        double o = raw;
+        if (a.nm.norm_obs) o = fmin(fmax((raw - a.nm.obs_mean[i]) / sqrt(a.nm.obs_var[i] + a.nm.epsilon), -a.nm.clip_obs), a.nm.clip_obs);
+        a.orig_obs[row * O + i] = raw;
+        a.obs[row * O + i] = o;
+      }
+      ep_rew += s_rew;     // episode_reward += reward (un-normalised: norm_reward is False on sampling / eval envs)
+      ++ep_len;
+      ++row;
+      const int done = s_done;
+      __syncthreads();
+      if (done) break;
+    }
+    if (tid == 0) { a.ep_rewards[(size_t)n * a.episodes_per_stream + ep] = ep_rew; a.ep_lengths[(size_t)n * a.episodes_per_stream + ep] = ep_len; }
+  }
+}
+
 static bool dims_ok(int O, int A, int H1, int H2) {
   return O > 0 && O <= MAX_OBS && A > 0 && A <= MAX_ACT && H1 > 0 && H1 <= MAX_H && H2 > 0 && H2 <= MAX_H;
 }
@@ -639,6 +722,26 @@ extern "C" int icrl_policy_evaluate(const icrl_policy_t* p, const double* obs, c
   hipLaunchKernelGGL(policy_forward_kernel, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs,
                      (const float*)nullptr, 1, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
                      v_r, v_c, log_prob, actions, entropy);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const float* noise,
+                                    const float* action_low, const float* action_high, int episodes_per_stream,
+                                    int rows_per_stream, int deterministic, int do_reset, double* orig_obs, double* obs,
+                                    float* actions, double* ep_rewards, int32_t* ep_lengths, void* stream) {
+  if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2) || env->obs_dim != pol->obs_dim || nm->training) return (int)hipErrorInvalidValue;
+  if (episodes_per_stream * env->max_steps > rows_per_stream) return (int)hipErrorInvalidValue;
+  SampleArgs a;
+  a.env = *env; a.nm = *nm; a.pl = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);
+  a.PT = pol->params_t; a.noise = noise; a.alow = action_low; a.ahigh = action_high;
+  a.episodes_per_stream = episodes_per_stream; a.rows_per_stream = rows_per_stream; a.deterministic = deterministic;
+  a.do_reset = do_reset; a.orig_obs = orig_obs; a.obs = obs; a.actions = actions; a.ep_rewards = ep_rewards; a.ep_lengths = ep_lengths;
+  size_t lds = (size_t)a.pl.n * sizeof(float);
+  a.pt_in_lds = lds <= 150 * 1024;
+  if (!a.pt_in_lds) lds = 0;
+  hipError_t e = hipFuncSetAttribute((const void*)sample_episodes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(sample_episodes_kernel, dim3(env->n_envs), dim3(192), lds, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

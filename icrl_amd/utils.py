@@ -1,0 +1,175 @@
+"""Host helpers of the ICRL loop with the reference's names and argument meaning.
+
+ref: icrl/utils.py:256-303 (make_env / make_train_env / make_eval_env), :323-357 (sample_from_agent),
+     :421-437 (compute_kl), :636-655 (get_net_arch); stable_baselines3/common/evaluation.py:10-67 (evaluate_policy);
+     icrl/icrl.py:25-43 (load_expert_data); stable_baselines3/common/save_util.py:284-418 (agent zip format).
+"""
+import io
+import os
+import pickle
+import types
+import zipfile
+
+import numpy as np
+import torch
+
+from . import _lib, spaces
+from .policies import ActorTwoCriticsPolicy
+from .structs import EnvT, p
+from .vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalize, VecNormalizeWithCost
+
+
+def make_train_env(env_id, save_dir, use_cost_wrapper, base_seed=0, num_threads=1, normalize_obs=True, normalize_reward=True,
+                   normalize_cost=True, env_index_offset=0, device="cuda", **kwargs):
+    """ref: icrl/utils.py:265-288.  SubprocVecEnv[num_threads] of gym envs -> one batched device env; env i is seeded
+    base_seed + env_index_offset + i (the offset shards envs across GPUs)."""
+    env = HipSynthVecEnv.make(env_id, num_threads, base_seed, device)
+    env.seed(base_seed, env_index_offset)
+    env._index_offset = env_index_offset
+    if use_cost_wrapper:
+        env = VecCostWrapper(env)
+    if normalize_reward and normalize_cost:
+        assert all(key in kwargs for key in ["cost_info_str", "reward_gamma", "cost_gamma"])
+        return VecNormalizeWithCost(env, training=True, norm_obs=normalize_obs, norm_reward=normalize_reward, norm_cost=normalize_cost,
+                                    cost_info_str=kwargs["cost_info_str"], reward_gamma=kwargs["reward_gamma"], cost_gamma=kwargs["cost_gamma"])
+    if normalize_reward:
+        return VecNormalizeWithCost(env, training=True, norm_obs=normalize_obs, norm_reward=normalize_reward, norm_cost=normalize_cost,
+                                    reward_gamma=kwargs["reward_gamma"])
+    return VecNormalizeWithCost(env, training=True, norm_obs=normalize_obs, norm_reward=normalize_reward, norm_cost=normalize_cost)
+
+
+def make_eval_env(env_id, use_cost_wrapper, normalize_obs=True, seed=0, device="cuda"):
+    """ref: icrl/utils.py:290-303 — one env, statistics frozen, rewards / costs not normalised."""
+    env = HipSynthVecEnv.make(env_id, 1, seed, device)
+    if use_cost_wrapper:
+        env = VecCostWrapper(env)
+    return VecNormalizeWithCost(env, training=False, norm_obs=normalize_obs, norm_reward=False, norm_cost=False)
+
+
+def get_net_arch(config):
+    """ref: icrl/utils.py:636-655."""
+    separate = dict(pi=list(config.policy_layers), vf=list(config.reward_vf_layers), cvf=list(config.cost_vf_layers))
+    if getattr(config, "shared_layers", None) is not None:
+        return [*config.shared_layers, separate]
+    return [separate]
+
+
+# ---- single-env episode loops, run as ONE persistent kernel launch (icrl_sample_episodes) -----------------------------------
+def _run_episodes(agent, env, n_episodes, deterministic, noise, parallel):
+    assert env.num_envs == 1, "You must pass only one environment when using this function"
+    senv = env.unwrapped
+    pol, dev = agent.policy, senv.device
+    max_steps, O = senv.max_steps, senv.obs_dim
+    A = 1 if pol.discrete else pol.act_dim
+    fixed_len = not senv.wall_terminate
+    n_streams = n_episodes if (parallel and fixed_len) else 1
+    eps_per = n_episodes // n_streams
+    rows_per = eps_per * max_steps
+    rows = n_streams * rows_per
+    if noise is None and not deterministic:
+        noise = torch.rand(rows, device=dev) if pol.discrete else torch.randn(rows, A, device=dev)
+    if noise is not None:
+        noise = torch.as_tensor(noise, device=dev).float().reshape(rows, -1).contiguous()
+    # per-stream copies of the env's random-stream position: stream e starts where the sequential loop would be
+    base = int(senv.step_count[0].item()) & 0xFFFFFFFF
+    sc = ((base + np.arange(n_streams, dtype=np.int64) * max_steps) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+    st = dict(s=senv.s.repeat(n_streams, 1).contiguous(), t_ep=senv.t_ep.repeat(n_streams).contiguous(),
+              step_count=torch.as_tensor(sc, device=dev), key=senv.key.repeat(n_streams).contiguous())
+    e = EnvT(n_streams, O, senv.act_dim, max_steps, senv.reward_form, int(senv.wall_terminate), int(senv.broken), 0,
+             p(senv.B), p(st["s"]), p(st["t_ep"]), p(st["step_count"]), p(st["key"]))
+    was_training = env.training
+    env.training = False
+    nm, ps = env.struct(), pol.struct()
+    env.training = was_training
+    out = dict(orig_obs=torch.empty(rows, O, dtype=torch.float64, device=dev), obs=torch.empty(rows, O, dtype=torch.float64, device=dev),
+               actions=torch.empty(rows, A, device=dev), ep_rewards=torch.empty(n_episodes, dtype=torch.float64, device=dev),
+               ep_lengths=torch.empty(n_episodes, dtype=torch.int32, device=dev))
+    lo = hi = None
+    if not pol.discrete:
+        lo = torch.as_tensor(pol.action_space.low, device=dev).float().contiguous()
+        hi = torch.as_tensor(pol.action_space.high, device=dev).float().contiguous()
+    b = _lib.byref
+    # streams > 0 of the parallel mode start from a reset as well: in the sequential loop their first state is the
+    # auto-reset draw made at exactly this counter value
+    _lib.check(_lib.lib().icrl_sample_episodes(b(e), b(nm), b(ps), p(noise), p(lo), p(hi), eps_per, rows_per, int(deterministic), 1,
+                                               p(out["orig_obs"]), p(out["obs"]), p(out["actions"]), p(out["ep_rewards"]),
+                                               p(out["ep_lengths"]), _lib.current_stream()), "icrl_sample_episodes")
+    lengths = out["ep_lengths"].cpu().numpy().astype(np.int64)
+    # leave the env where the sequential loop would have left it
+    total = int(lengths.sum())
+    senv.step_count.fill_(int(np.uint32((base + total) & 0xFFFFFFFF).view(np.int32)))
+    senv.s.copy_(st["s"][-1:]); senv.t_ep.zero_()
+    env.old_obs = senv.s
+    if n_streams == 1:
+        keep = torch.arange(total, device=dev)
+    else:
+        keep = torch.arange(rows, device=dev)        # fixed-length episodes: every row is used
+    return out, lengths, keep
+
+
+def sample_from_agent(agent, env, rollouts, noise=None, parallel=True):
+    """ref: icrl/utils.py:323-357.  Returns (orig_observations, observations, actions, rewards, lengths): the first three are
+    device tensors [sum(lengths), ...] holding the observation AFTER each step next to the (clipped) action of that step;
+    rewards / lengths are numpy arrays per episode.  With parallel=True the `rollouts` fixed-length episodes of the 1-env loop
+    run as independent streams whose random-stream counters are offset exactly as the sequential loop would advance them."""
+    out, lengths, keep = _run_episodes(agent, env, rollouts, False, noise, parallel)
+    return (out["orig_obs"][keep], out["obs"][keep], out["actions"][keep], out["ep_rewards"].cpu().numpy(), lengths)
+
+
+def evaluate_policy(model, env, n_eval_episodes=10, deterministic=True, render=False, callback=None, reward_threshold=None,
+                    return_episode_rewards=False, noise=None):
+    """ref: stable_baselines3/common/evaluation.py:10-67 (sequential episodes on one env)."""
+    out, lengths, _ = _run_episodes(model, env, n_eval_episodes, deterministic, noise, parallel=False)
+    ep_rewards = out["ep_rewards"].cpu().numpy()
+    if return_episode_rewards:
+        return list(ep_rewards), list(lengths)
+    mean_reward, std_reward = float(np.mean(ep_rewards)), float(np.std(ep_rewards))
+    if reward_threshold is not None:
+        assert mean_reward > reward_threshold
+    return mean_reward, std_reward
+
+
+def compute_kl(agent_2, observations, actions, agent_1=None):
+    """KL(agent_1 || agent_2) on samples of agent_1 (ref: icrl/utils.py:421-437; observations are fed un-normalised,
+    as the reference does)."""
+    kl = -agent_2.policy.evaluate_actions(observations, actions)[2]
+    if agent_1 is not None:
+        kl = kl + agent_1.policy.evaluate_actions(observations, actions)[2]
+    return float((kl.sum() / kl.shape[0]).item())
+
+
+# ---- on-disk artefacts -------------------------------------------------------------------------------------------------------
+def load_expert_data(expert_path, num_rollouts):
+    """ref: icrl/icrl.py:25-43 — `files/EXPERT/rollouts/{i}.pkl` dicts(observations, actions, rewards, lengths); also accepts the
+    re-packed fixture `<expert_path>.npz` (tests/golden/expert_hc.npz: 500-step rollouts concatenated)."""
+    if str(expert_path).endswith(".npz"):
+        d = np.load(expert_path)
+        L = 500
+        obs, acs = d["observations"][: num_rollouts * L], d["actions"][: num_rollouts * L]
+        return (obs, acs), float("nan")
+    rewards = []
+    obs, acs = [], []
+    for i in range(num_rollouts):
+        with open(os.path.join(expert_path, "files/EXPERT/rollouts", "%s.pkl" % str(i)), "rb") as f:
+            data = pickle.load(f)
+        obs.append(data["observations"]); acs.append(data["actions"]); rewards.append(data["rewards"])
+    return (np.concatenate(obs, axis=0), np.concatenate(acs, axis=0)), float(np.mean(rewards))
+
+
+def load_policy_state_dict(path):
+    """policy.pth out of a stable-baselines3 agent zip (no gym needed), or the `policy/*` arrays of the .npz fixture."""
+    if str(path).endswith(".npz"):
+        d = np.load(path)
+        return {k[len("policy/"):]: d[k] for k in d.files if k.startswith("policy/")}
+    with zipfile.ZipFile(path) as z:
+        return torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=False)
+
+
+def load_expert_agent(path, device="cuda"):
+    """stand-in for PPOLagrangian.load(best_model.zip) where only .policy.evaluate_actions is used (icrl/icrl.py:82,251-252)."""
+    sd = load_policy_state_dict(path)
+    obs_dim = int(np.asarray(sd["mlp_extractor.policy_net.0.weight"]).shape[1])
+    act_dim = int(np.asarray(sd["action_net.weight"]).shape[0])
+    pol = ActorTwoCriticsPolicy(spaces.Box(-np.inf, np.inf, (obs_dim,), np.float64), spaces.Box(-1.0, 1.0, (act_dim,), np.float32), device=device)
+    pol.load_state_dict(sd)
+    return types.SimpleNamespace(policy=pol)

@@ -174,6 +174,18 @@ int icrl_policy_forward(const icrl_policy_t* pol, const double* obs, const float
 int icrl_policy_evaluate(const icrl_policy_t* pol, const double* obs, const float* actions, int N, float* v_r, float* v_c,
                          float* log_prob, float* entropy, void* stream);
 
+/* sample_from_agent (icrl/utils.py:323-357) / evaluate_policy (stable_baselines3/common/evaluation.py:10-67) on single-env
+ * streams, one persistent workgroup per stream: env->n_envs independent streams each run `episodes_per_stream` episodes
+ * back to back (auto-reset between them, like a 1-env VecEnv) with FROZEN normaliser statistics (nm->training must be 0).
+ * Row k of a stream records the observation AFTER step k (raw in orig_obs, normalised in obs) next to the clipped action
+ * of step k — the (s_{t+1}, a_t) pairing of the reference — at rows [stream*rows_per_stream + k].  noise: standard normals
+ * [n_streams*rows_per_stream, act] (NULL or deterministic != 0: mode of the distribution).  do_reset: draw the initial
+ * state first (VecEnv.reset).  Per-episode un-normalised reward sums and lengths go to ep_rewards / ep_lengths. */
+int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const float* noise,
+                         const float* action_low, const float* action_high, int episodes_per_stream, int rows_per_stream,
+                         int deterministic, int do_reset, double* orig_obs, double* obs, float* actions,
+                         double* ep_rewards, int32_t* ep_lengths, void* stream);
+
 /* ConstraintNet.cost_function (icrl/constraint_net.py:121-130): cost[n] = 1 - zeta(prepare(obs[n], acs[n])).
  * obs [N,obs] float64, acs [N,acs] float32 (class index in acs[n,0] when discrete). */
 int icrl_cost_mlp_forward(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* cost, void* stream);

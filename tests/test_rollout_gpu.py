@@ -10,7 +10,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _sub(g, prefix):
-    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+    keys = g.files if hasattr(g, "files") else list(g)
+    return {k[len(prefix):]: g[k] for k in keys if k.startswith(prefix)}
 
 
 @pytest.mark.parametrize("kind,wall,broken", [("hc", False, False), ("ant", False, False), ("hc", True, False), ("ant", False, True)])
