@@ -30,6 +30,7 @@ SIGNATURES = {
     "icrl_vecnorm_reset": [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p],
     "icrl_vecnorm_step": [c_void_p] * 5 + [c_int, c_int] + [c_void_p] * 4,
     "icrl_rollout_collect": [c_void_p] * 9 + [c_double] * 4 + [c_void_p],
+    "icrl_rollout_collect_ex": [c_void_p] * 9 + [c_double] * 4 + [c_int, c_void_p],
     "icrl_ppo_lag_train": [c_void_p] * 11,
     "icrl_cn_prepare": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "icrl_cn_train_work_floats": [c_int, c_int, c_int, c_int],

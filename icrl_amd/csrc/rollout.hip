@@ -781,11 +781,11 @@ extern "C" int icrl_vecnorm_step(const icrl_norm_t* nm, const double* raw_obs, c
   return (int)hipGetLastError();
 }
 
-extern "C" int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol,
-                                    const icrl_costnet_t* cn, const icrl_buffer_t* buf, const icrl_agent_t* ag,
-                                    const float* noise, const float* action_low, const float* action_high,
-                                    double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
-                                    void* stream) {
+extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol,
+                                       const icrl_costnet_t* cn, const icrl_buffer_t* buf, const icrl_agent_t* ag,
+                                       const float* noise, const float* action_low, const float* action_high,
+                                       double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
+                                       int do_gae, void* stream) {
   const int N = env->n_envs, O = env->obs_dim, T = buf->T;
   if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2) || pol->obs_dim != O || buf->N != N || buf->obs_dim != O)
     return (int)hipErrorInvalidValue;
@@ -806,8 +806,17 @@ extern "C" int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm
     hipLaunchKernelGGL(norm_step_kernel, dim3(1), dim3(1024), 0, s, b);
   }
   int err = (int)hipGetLastError();
-  if (err) return err;
+  if (err || !do_gae) return err;
   return icrl_gae_dual(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
                        ag->last_v_c, ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns,
                        buf->cost_returns, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, stream);
+}
+
+extern "C" int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol,
+                                    const icrl_costnet_t* cn, const icrl_buffer_t* buf, const icrl_agent_t* ag,
+                                    const float* noise, const float* action_low, const float* action_high,
+                                    double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
+                                    void* stream) {
+  return icrl_rollout_collect_ex(env, nm, pol, cn, buf, ag, noise, action_low, action_high, reward_gamma, reward_gae_lambda,
+                                 cost_gamma, cost_gae_lambda, 1, stream);
 }

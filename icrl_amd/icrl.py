@@ -25,7 +25,8 @@ from .vec_env import VecNormalize, sync_envs_normalization
 from . import spaces
 
 
-def icrl(config, log=print):
+def setup(config):
+    """everything of icrl() before the loop (ref: icrl/icrl.py:45-197): env stacks, expert data, constraint net, nominal agent."""
     rank, world = getattr(config, "rank", 0), getattr(config, "world_size", 1)
     dev = config.device if str(config.device).startswith("cuda") else "cuda"
     train_env = utils.make_train_env(env_id=config.train_env_id, save_dir=config.save_dir, use_cost_wrapper=True,
@@ -49,8 +50,6 @@ def icrl(config, log=print):
     expert_agent = None
     if getattr(config, "expert_agent_path", None):
         expert_agent = utils.load_expert_agent(config.expert_agent_path, dev)
-    d_expert_obs = torch.as_tensor(np.asarray(expert_obs), device=dev)
-    d_expert_acs = torch.as_tensor(np.asarray(expert_acs), device=dev)
 
     cn_lr_schedule = lambda x: (config.anneal_clr_by_factor ** (config.n_iters * (1 - x))) * config.cn_learning_rate
     constraint_net = ConstraintNet(
@@ -62,7 +61,6 @@ def icrl(config, log=print):
         target_kl_old_new=config.cn_target_kl_old_new, target_kl_new_old=config.cn_target_kl_new_old,
         train_gail_lambda=config.train_gail_lambda, eps=config.cn_eps, device=dev)
     train_env.set_cost_function(constraint_net.cost_function)
-    true_cost_function = get_true_cost_function(config.eval_env_id)
 
     create_nominal_agent = lambda: PPOLagrangian(
         policy=config.policy_name, env=train_env, learning_rate=config.learning_rate, n_steps=config.n_steps,
@@ -79,80 +77,97 @@ def icrl(config, log=print):
                         delta_p_ema_alpha=config.proportional_cost_ema_alpha, delta_d_ema_alpha=config.derivative_cost_ema_alpha),
         policy_kwargs=dict(net_arch=utils.get_net_arch(config)),
         action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"))
-    nominal_agent = create_nominal_agent()
-    if world > 1:     # common history of the running moments for the exact cross-rank merge
-        rms_list = [train_env.obs_rms, train_env.ret_rms, train_env.cost_rms]
-        rms_prev = [D.moments_to_sums(r.mean, r.var, r.count) for r in rms_list]
-
-    timesteps = 0.
     if config.warmup_timesteps is not None:
         raise NotImplementedError("--warmup_timesteps (null_cost warm-up) is not on the benchmarked path")
-    start_time = time.time()
-    best_true_reward, best_true_cost, best_forward_kl, best_reverse_kl = -np.inf, np.inf, np.inf, np.inf
+    st = dict(config=config, rank=rank, world=world, train_env=train_env, sampling_env=sampling_env, eval_env=eval_env,
+              constraint_net=constraint_net, create_nominal_agent=create_nominal_agent, agent=create_nominal_agent(),
+              expert_agent=expert_agent, true_cost_function=get_true_cost_function(config.eval_env_id),
+              d_expert_obs=torch.as_tensor(np.asarray(expert_obs), device=dev),
+              d_expert_acs=torch.as_tensor(np.asarray(expert_acs), device=dev),
+              timesteps=0., start_time=time.time(),
+              best=dict(reward=-np.inf, cost=np.inf, fkl=np.inf, rkl=np.inf))
+    if world > 1:     # common history of the running moments for the exact cross-rank merge
+        st["rms_list"] = [train_env.obs_rms, train_env.ret_rms, train_env.cost_rms]
+        st["rms_prev"] = [D.moments_to_sums(r.mean, r.var, r.count) for r in st["rms_list"]]
+    return st
+
+
+def outer_iteration(st, itr):
+    """one pass of the loop body (ref: icrl/icrl.py:199-304)."""
+    config, rank, world = st["config"], st["rank"], st["world"]
+    train_env, sampling_env, eval_env, constraint_net = st["train_env"], st["sampling_env"], st["eval_env"], st["constraint_net"]
+    if config.reset_policy and itr != 0:
+        st["agent"] = st["create_nominal_agent"]()
+    nominal_agent = st["agent"]
+    current_progress_remaining = 1 - float(itr) / float(config.n_iters)
+    # ---- forward step
+    nominal_agent.learn(total_timesteps=config.forward_timesteps, cost_function="cost")
+    forward_metrics = dict(logger.Logger.CURRENT.name_to_value)
+    st["timesteps"] += nominal_agent.num_timesteps
+    # ---- nominal trajectories
+    sync_envs_normalization(train_env, sampling_env)
+    orig_observations, observations, actions, rewards, lengths = utils.sample_from_agent(
+        nominal_agent, sampling_env, config.expert_rollouts)
+    # ---- backward step
+    mean, var = None, None
+    if config.cn_normalize:
+        mean, var = sampling_env.obs_rms.mean, sampling_env.obs_rms.var
+    backward_metrics = constraint_net.train(config.backward_iters, orig_observations, actions, lengths, mean, var,
+                                            current_progress_remaining)
+    train_env.set_cost_function(constraint_net.cost_function)
+    # ---- the single collective of the iteration
+    if world > 1:
+        pol = nominal_agent.policy
+        st["rms_prev"] = D.allreduce_state([pol.params, pol.exp_avg, pol.exp_avg_sq, constraint_net.params, constraint_net.exp_avg,
+                                            constraint_net.exp_avg_sq], st["rms_list"], st["rms_prev"], world)
+        pol.prepare(); constraint_net.prepare()
+    # ---- evaluation
+    average_true_cost = mean_cost(st["true_cost_function"], orig_observations, actions)
+    samples_behind = float((orig_observations[..., 0] < -3).double().mean().item())
+    samples_infront = float((orig_observations[..., 0] > 3).double().mean().item())
+    sync_envs_normalization(train_env, eval_env)
+    average_true_reward, std_true_reward = utils.evaluate_policy(nominal_agent, eval_env, n_eval_episodes=10, deterministic=False)
+    forward_kl = reverse_kl = float("nan")
+    if st["expert_agent"] is not None:
+        forward_kl = utils.compute_kl(nominal_agent, st["d_expert_obs"], st["d_expert_acs"], st["expert_agent"])
+        reverse_kl = utils.compute_kl(st["expert_agent"], orig_observations, actions, nominal_agent)
+    # ---- save (ref: icrl.py:254-269)
+    best = st["best"]
+    if config.save_dir and itr % config.save_every == 0 and rank == 0:
+        path = os.path.join(config.save_dir, f"models/icrl_{itr}_itrs")
+        os.makedirs(path, exist_ok=True)
+        torch.save(nominal_agent.policy.state_dict(), os.path.join(path, "nominal_agent_policy.pth"))
+        constraint_net.save(os.path.join(path, "cn.pt"))
+        train_env.save(os.path.join(path, f"{itr}_train_env_stats.pkl"))
+    if average_true_reward > best["reward"] and config.save_dir and rank == 0:
+        torch.save(nominal_agent.policy.state_dict(), os.path.join(config.save_dir, "best_nominal_model_policy.pth"))
+        constraint_net.save(os.path.join(config.save_dir, "best_cn_model.pt"))
+        train_env.save(os.path.join(config.save_dir, "train_env_stats.pkl"))
+    best["reward"] = max(best["reward"], average_true_reward)
+    best["cost"] = min(best["cost"], average_true_cost)
+    best["fkl"] = min(best["fkl"], forward_kl) if forward_kl == forward_kl else best["fkl"]
+    best["rkl"] = min(best["rkl"], reverse_kl) if reverse_kl == reverse_kl else best["rkl"]
+    metrics = {"time(m)": (time.time() - st["start_time"]) / 60, "iteration": itr, "timesteps": st["timesteps"],
+               "true/reward": average_true_reward, "true/reward_std": std_true_reward, "true/cost": average_true_cost,
+               "true/samples_infront": samples_infront, "true/samples_behind": samples_behind,
+               "true/forward_kl": forward_kl, "true/reverse_kl": reverse_kl, "best_true/best_reward": best["reward"],
+               "best_true/best_cost": best["cost"], "best_true/best_forward_kl": best["fkl"],
+               "best_true/best_reverse_kl": best["rkl"]}
+    metrics.update({k.replace("train/", "forward/"): v for k, v in forward_metrics.items()})
+    metrics.update(backward_metrics)
+    return metrics
+
+
+def icrl(config, log=print):
+    st = setup(config)
     all_metrics = []
     for itr in range(config.n_iters):
-        if config.reset_policy and itr != 0:
-            nominal_agent = create_nominal_agent()
-        current_progress_remaining = 1 - float(itr) / float(config.n_iters)
-        # ---- forward step
-        nominal_agent.learn(total_timesteps=config.forward_timesteps, cost_function="cost")
-        forward_metrics = dict(logger.Logger.CURRENT.name_to_value)
-        timesteps += nominal_agent.num_timesteps
-        # ---- nominal trajectories
-        sync_envs_normalization(train_env, sampling_env)
-        orig_observations, observations, actions, rewards, lengths = utils.sample_from_agent(
-            nominal_agent, sampling_env, config.expert_rollouts)
-        # ---- backward step
-        mean, var = None, None
-        if config.cn_normalize:
-            mean, var = sampling_env.obs_rms.mean, sampling_env.obs_rms.var
-        backward_metrics = constraint_net.train(config.backward_iters, orig_observations, actions, lengths, mean, var,
-                                                current_progress_remaining)
-        train_env.set_cost_function(constraint_net.cost_function)
-        # ---- the single collective of the iteration
-        if world > 1:
-            pol = nominal_agent.policy
-            rms_prev = D.allreduce_state([pol.params, pol.exp_avg, pol.exp_avg_sq, constraint_net.params, constraint_net.exp_avg,
-                                          constraint_net.exp_avg_sq], rms_list, rms_prev, world)
-            pol.prepare(); constraint_net.prepare()
-        # ---- evaluation
-        average_true_cost = mean_cost(true_cost_function, orig_observations, actions)
-        samples_behind = float((orig_observations[..., 0] < -3).double().mean().item())
-        samples_infront = float((orig_observations[..., 0] > 3).double().mean().item())
-        sync_envs_normalization(train_env, eval_env)
-        average_true_reward, std_true_reward = utils.evaluate_policy(nominal_agent, eval_env, n_eval_episodes=10, deterministic=False)
-        forward_kl = reverse_kl = float("nan")
-        if expert_agent is not None:
-            forward_kl = utils.compute_kl(nominal_agent, d_expert_obs, d_expert_acs, expert_agent)
-            reverse_kl = utils.compute_kl(expert_agent, orig_observations, actions, nominal_agent)
-        # ---- save (ref: icrl.py:254-269)
-        if config.save_dir and itr % config.save_every == 0 and rank == 0:
-            path = os.path.join(config.save_dir, f"models/icrl_{itr}_itrs")
-            os.makedirs(path, exist_ok=True)
-            torch.save(nominal_agent.policy.state_dict(), os.path.join(path, "nominal_agent_policy.pth"))
-            constraint_net.save(os.path.join(path, "cn.pt"))
-            train_env.save(os.path.join(path, f"{itr}_train_env_stats.pkl"))
-        if average_true_reward > best_true_reward and config.save_dir and rank == 0:
-            torch.save(nominal_agent.policy.state_dict(), os.path.join(config.save_dir, "best_nominal_model_policy.pth"))
-            constraint_net.save(os.path.join(config.save_dir, "best_cn_model.pt"))
-            train_env.save(os.path.join(config.save_dir, "train_env_stats.pkl"))
-        best_true_reward = max(best_true_reward, average_true_reward)
-        best_true_cost = min(best_true_cost, average_true_cost)
-        best_forward_kl = min(best_forward_kl, forward_kl) if forward_kl == forward_kl else best_forward_kl
-        best_reverse_kl = min(best_reverse_kl, reverse_kl) if reverse_kl == reverse_kl else best_reverse_kl
-        metrics = {"time(m)": (time.time() - start_time) / 60, "iteration": itr, "timesteps": timesteps,
-                   "true/reward": average_true_reward, "true/reward_std": std_true_reward, "true/cost": average_true_cost,
-                   "true/samples_infront": samples_infront, "true/samples_behind": samples_behind,
-                   "true/forward_kl": forward_kl, "true/reverse_kl": reverse_kl, "best_true/best_reward": best_true_reward,
-                   "best_true/best_cost": best_true_cost, "best_true/best_forward_kl": best_forward_kl,
-                   "best_true/best_reverse_kl": best_reverse_kl}
-        metrics.update({k.replace("train/", "forward/"): v for k, v in forward_metrics.items()})
-        metrics.update(backward_metrics)
+        metrics = outer_iteration(st, itr)
         all_metrics.append(metrics)
-        if config.verbose > 0 and rank == 0 and log is not None:
+        if config.verbose > 0 and st["rank"] == 0 and log is not None:
             log(json.dumps({k: (round(float(v), 6) if isinstance(v, (int, float, np.floating, np.integer)) else str(v))
                             for k, v in metrics.items()}))
-    return all_metrics, nominal_agent, constraint_net, train_env
+    return all_metrics, st["agent"], st["constraint_net"], st["train_env"]
 
 
 def build_parser():

@@ -142,9 +142,17 @@ class PPOLagrangian:
         ag = AgentT(p(self._last_obs), p(self._ag["last_dones"]), p(self._ag["raw_rew"]), p(self._ag["raw_cost"]), p(self._ag["dones"]),
                     p(self._ag["last_v_r"]), p(self._ag["last_v_c"]), p(self._ag["act_clipped"]))
         b = _lib.byref
-        _lib.check(_lib.lib().icrl_rollout_collect(b(e), b(nm), b(pol), b(cn), b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
-                                                   float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
-                                                   float(self.cost_gae_lambda), _lib.current_stream()), "icrl_rollout_collect")
+        timed = getattr(self, "gae_events", None) is not None
+        _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn), b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
+                                                      float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
+                                                      float(self.cost_gae_lambda), int(not timed), _lib.current_stream()),
+                   "icrl_rollout_collect")
+        if timed:   # bench.py: the same GAE launch, bracketed by events on the stream it runs on
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rollout_buffer.compute_returns_and_advantage(self._ag["last_v_r"], self._ag["last_v_c"], self._ag["last_dones"])
+            e1.record()
+            self.gae_events.append((e0, e1))
         self._keepalive = (noise,)
         rollout_buffer.pos, rollout_buffer.full = n_rollout_steps, True
         self.num_timesteps += env.num_envs * n_rollout_steps
@@ -234,8 +242,14 @@ class PPOLagrangian:
                        float(self.target_kl or 0.0), crv, ccv, lr, 0.9, 0.999, float(pol.optimizer_kwargs.get("eps", 1e-8)))
         ps, bs = pol.struct(), rb.struct()
         b = _lib.byref
+        ev = None
+        if getattr(self, "train_events", None) is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         _lib.check(_lib.lib().icrl_ppo_lag_train(b(ps), p(pol.exp_avg), p(pol.exp_avg_sq), p(ws["t"]), b(bs), p(perms), p(ws["nu"]),
                                                  b(hp), p(ws["stats"]), p(ws["sync"]), _lib.current_stream()), "icrl_ppo_lag_train")
+        if ev is not None:
+            ev[1].record()
         pol.prepare()                                   # refresh the transposed copy for the next rollout
         self._n_updates += self.n_epochs
         # ---- the scalars the reference logs (one device->host read per train())
@@ -246,6 +260,8 @@ class PPOLagrangian:
             raise RuntimeError("icrl_ppo_lag_train: inter-workgroup exchange timed out")
         pol.adam_step = int(ws["t"].item())
         steps = max(int(st[1]), 1)
+        if ev is not None:
+            self.train_events.append((ev[0], ev[1], steps))
         early_stop_epoch = int(st[0])
         if rng_state is not None:       # leave np.random where the reference would: one permutation per executed epoch
             np.random.set_state(rng_state)

@@ -169,6 +169,14 @@ int icrl_policy_forward(const icrl_policy_t* pol, const double* obs, const float
                         const float* action_low, const float* action_high,
                         float* actions, float* act_clipped, float* v_r, float* v_c, float* log_prob, void* stream);
 
+/* same, with the final dual-GAE launch optional (do_gae = 0: the caller launches icrl_gae_dual itself, e.g. bracketed by
+ * events for the roofline measurement in bench.py). */
+int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const icrl_costnet_t* cn,
+                            const icrl_buffer_t* buf, const icrl_agent_t* ag, const float* noise,
+                            const float* action_low, const float* action_high,
+                            double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
+                            int do_gae, void* stream);
+
 /* ActorTwoCriticsPolicy.evaluate_actions (policies.py:752-767): values, log-prob of the GIVEN actions and the entropy of
  * the action distribution (used by compute_kl, icrl/utils.py:421-437).  actions [N,act_store] float32. */
 int icrl_policy_evaluate(const icrl_policy_t* pol, const double* obs, const float* actions, int N, float* v_r, float* v_c,
