@@ -71,6 +71,9 @@ def cpu_baseline():
     """oracle CPU port on a bounded sample of the same workload (one PPO iteration with n_steps 256 instead of 2048)."""
     from oracle import loop as o_loop, nets as o_nets
     n_envs, T = 64, 256
+    # the reference's own measurement used 8 intra-op threads (BASELINE.md §2); more threads only slow these tiny GEMMs down
+    threads = min(8, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     stack = o_loop.make_stack(n_envs, "hc", 0)
     lo = -np.ones(6, np.float32)
