@@ -1,0 +1,84 @@
+"""CPU: the C-ABI library loads and exports every symbol include/icrl_hip.h declares (no compute without a GPU);
+host-side logic that needs no kernel."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "icrl_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(icrl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from icrl_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    L = _lib.lib()
+    declared = _declared_symbols()
+    assert len(declared) >= 18
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/icrl_hip.h but not exported"
+        assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
+    assert L.icrl_abi_version() == 100
+    assert L.icrl_cn_train_work_floats(521, 10000, 5000, 10) > 521 * 235
+
+
+def test_struct_sizes_match_header_layout():
+    """natural alignment, no packing: sizes computed by hand from include/icrl_hip.h."""
+    from icrl_amd import structs as S
+    assert ctypes.sizeof(S.EnvT) == 8 * 4 + 5 * 8
+    assert ctypes.sizeof(S.NormT) == 4 * 4 + 6 * 8 + 7 * 8
+    assert ctypes.sizeof(S.PolicyT) == 6 * 4 + 2 * 8
+    assert ctypes.sizeof(S.CostNetT) == 8 * 4 + 8 + 5 * 8 + 8 + 2 * 8
+    assert ctypes.sizeof(S.BufferT) == 4 * 4 + 16 * 8
+    assert ctypes.sizeof(S.AgentT) == 8 * 8
+    assert ctypes.sizeof(S.PpoHyperT) == 4 * 4 + 12 * 4
+    assert ctypes.sizeof(S.CnHyperT) == 4 * 4 + 8 * 4
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from icrl_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libicrl_hip.so")
+    with pytest.raises(_lib.HipExtensionMissing):
+        _lib.lib()
+
+
+def test_product_package_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "icrl_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_dual_variable_matches_reference_trajectories(golden):
+    """host-side Lagrange multiplier (numpy float32) vs the reference's DualVariable (tests/golden/g5)."""
+    from icrl_amd.dual_variable import DualVariable
+    g = golden("g5_dual")
+    for case in "abcd":
+        nu0, lr, budget = (float(x) for x in g[case + "/params"])
+        d = DualVariable(budget, lr, nu0, None)
+        for c, (nu, loss, log_nu) in zip(g[case + "/costs"], g[case + "/traj"]):
+            d.update_parameter(c)
+            assert abs(d.nu().item() - nu) <= 2e-6 * max(1.0, abs(nu))
+
+
+def test_flag_set_matches_reference_readme_commands():
+    from icrl_amd.icrl import build_parser
+    p = build_parser()
+    a = p.parse_args("icrl -p ICRL-FE2 --group HC-ICRL -er 10 -ep x -tk 0.01 -cl 20 -bi 10 -ft 2e5 -ni 30 -tei HCWithPos-v0 "
+                     "-eei HCWithPosTest-v0 -clr 0.05 -aclr 0.9 -crc 0.5 -psis -ctkno 2.5".split())
+    assert a.forward_timesteps == 200000 and a.cn_layers == [20] and a.per_step_importance_sampling and a.cn_target_kl_new_old == 2.5
+    a = p.parse_args("icrl -ep x -er 45 -cl 40 40 -clr 0.005 -aclr 0.9 -crc 0.6 -bi 5 -ft 2e5 -ni 20 -tei AntWall-v0 -eei AntWallTest-v0 "
+                     "--batch_size 128 --reward_gae_lambda 0.9 --cost_gae_lambda 0.9 --n_epochs 20 --learning_rate 3e-5 "
+                     "--clip_range 0.4 -piv 0.1 -plr 0.05 -psis -tk 0.02 -ctkno 2.5".split())
+    assert a.cn_layers == [40, 40] and a.batch_size == 128 and a.penalty_initial_value == 0.1 and a.n_epochs == 20

@@ -1,0 +1,73 @@
+"""CPU, world_size 2 over gloo: the single per-iteration all-reduce averages parameters and merges the running moments
+EXACTLY (the merged statistics equal those of one process that saw both shards' streams)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class HostRms:
+    def __init__(self, n):
+        self.mean, self.var, self.count = np.zeros(n), np.ones(n), 1e-4
+
+    def assign(self, mean, var, count):
+        self.mean, self.var, self.count = np.atleast_1d(np.asarray(mean, np.float64)), np.atleast_1d(np.asarray(var, np.float64)), float(count)
+
+    def update(self, x):
+        from oracle.stats import Moments
+        m = Moments((len(self.mean),)); m.mean, m.var, m.count = self.mean.copy(), self.var.copy(), self.count
+        m.update(x)
+        self.mean, self.var, self.count = m.mean, m.var, m.count
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from icrl_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.RandomState(100 + rank)
+    params = torch.full((7,), float(rank + 1))
+    moments = torch.arange(5, dtype=torch.float32) * (rank + 1)
+    rms = HostRms(3)
+    common = np.random.RandomState(7).randn(40, 3)
+    rms.update(common)                                   # shared history
+    prev = [D.moments_to_sums(rms.mean, rms.var, rms.count)]
+    shard = rng.randn(25 + 10 * rank, 3) * (1 + rank) + rank
+    rms.update(shard)                                    # this rank's own stream
+    D.allreduce_state([params, moments], [rms], prev, world)
+    out[rank] = (params.numpy().copy(), moments.numpy().copy(), rms.mean.copy(), rms.var.copy(), rms.count, shard)
+    dist.destroy_process_group()
+
+
+def test_allreduce_state_world2():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    p0, m0, mean0, var0, c0, sh0 = out[0]
+    p1, m1, mean1, var1, c1, sh1 = out[1]
+    assert np.allclose(p0, 1.5) and np.array_equal(p0, p1)                   # average of 1 and 2
+    assert np.allclose(m0, np.arange(5) * 1.5) and np.array_equal(m0, m1)
+    assert np.array_equal(mean0, mean1) and np.array_equal(var0, var1) and c0 == c1
+    # ground truth: one stream that saw the common history and then both shards
+    ref = HostRms(3)
+    ref.update(np.random.RandomState(7).randn(40, 3)); ref.update(sh0); ref.update(sh1)
+    assert np.allclose(mean0, ref.mean, rtol=1e-12, atol=1e-12)
+    assert np.allclose(var0, ref.var, rtol=1e-10, atol=1e-12)
+    assert abs(c0 - ref.count) < 1e-9
+
+
+def test_single_rank_is_identity():
+    sys.path.insert(0, ROOT)
+    from icrl_amd import distributed as D
+    rms = HostRms(2); rms.update(np.random.RandomState(0).randn(10, 2))
+    before = (rms.mean.copy(), rms.var.copy(), rms.count)
+    t = torch.arange(4.0)
+    D.allreduce_state([t], [rms], [D.moments_to_sums(*before)], 1)
+    assert torch.equal(t, torch.arange(4.0)) and np.allclose(rms.mean, before[0]) and np.allclose(rms.var, before[1])
