@@ -126,6 +126,14 @@ __host__ __device__ inline CnLayout make_cn_layout(int in, int nh, int H1, int H
   return L;
 }
 
+// tanh through one v_exp_f32 and one v_rcp_f32: (e - 1) / (e + 1), e = exp(2x); |abs error| <~ 2e-7.
+// Used by BOTH the rollout-time forward and the training kernel so that old and new log-probs see the same activations.
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float xc = fminf(fmaxf(x, -15.f), 15.f);
+  const float e = __expf(2.f * xc);
+  return (e - 1.f) * __builtin_amdgcn_rcpf(e + 1.f);
+}
+
 constexpr float LOG_SQRT_2PI_F = 0.918938533204672741780329736406f;  // log(sqrt(2*pi))
 constexpr float HALF_LOG_2PI_PLUS_HALF_F = 1.418938533204672741780329736406f;  // 0.5 + 0.5*log(2*pi)
 

@@ -10,16 +10,19 @@
 //
 //   * grid = 3 workgroups x 256 threads (4 waves, one per SIMD): workgroup r owns network r.  The only quantity coupling
 //     the networks inside a step is the global gradient norm (clip_grad_norm_ over ALL policy parameters): each workgroup
-//     publishes its partial sum of squares as an 8-byte {step tag, value} granule (sc1 / agent-scope relaxed store) and
-//     polls the other two (guide: cdna_hip_programming.md §6 Guideline 16, form R2 — the datum is the flag).  Granule
-//     slots are double-buffered by step parity; a workgroup can never be more than one step ahead of the others.
-//   * the network's weights stay in LDS for the whole launch (fp32 master copy, rows padded to stride = 2 mod 32 so that
-//     the MFMA operand fetch `ds_read_b32 M[(i0 + lane%16) * S + k0 + lane/16]` is bank-conflict free);
-//     Adam moments and the accumulating weight gradients stay in REGISTERS in MFMA C-layout: the lane that receives
-//     dW[j][k] from the matrix core is the lane that owns m, v and the update of W[j][k].  Nothing but the gathered
-//     minibatch rows (and 3 granules) touches global memory inside the loop.
-//   * all eight GEMMs of a step (3 forward, 5 backward) run on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains): wave w
-//     owns the 16-row tile w of every 64-row operand, so forward activations never cross waves.
+//     publishes its partial sum of squares as an 8-byte {step tag, value} granule (agent-scope relaxed store) and polls the
+//     other two (guide: cdna_hip_programming.md §6 Guideline 16, form R2 — the datum is the flag).  Granule slots are
+//     double-buffered by step parity; a workgroup can never be more than one step ahead of the others.  While the granules
+//     are in flight the workgroup already stages the NEXT minibatch (LDS commit + advantage statistics).
+//   * the network's weights stay in LDS for the whole launch (fp32 master copy); Adam moments and the accumulating weight
+//     gradients stay in REGISTERS in MFMA C-layout: the lane that receives dW[j][k] from the matrix core owns m, v and the
+//     update of W[j][k].  Inside the loop only the gathered minibatch rows (prefetched one chunk ahead into registers,
+//     their permutation indices two chunks ahead) and the 3 granules touch global memory.
+//   * all eight GEMMs of a step (3 forward, 5 backward) run on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  Wave w owns
+//     the 16-row tile w of every 64-row operand, so forward activations never cross waves.  K is enumerated as
+//     k = 16*js + 4*(lane/16) + e: an operand whose K runs along the LDS row is fetched with ONE ds_read_b128 per four
+//     MFMA steps, conflict-free at row strides = 8 mod 16 floats; operands whose K runs across rows use ds_read_b32.
+//     Every GEMM first stages its operands in registers, then issues its MFMAs back to back.
 //   * minibatches larger than 64 rows are processed in 64-row chunks that accumulate into the same gradient registers.
 //
 // Built with -ffp-contract=off; FMA is used only where written (fmaf / MFMA).
@@ -34,13 +37,13 @@ typedef unsigned long long u64;
 constexpr int TH = 256;  // threads per workgroup
 constexpr int RB = 64;   // minibatch rows per chunk
 constexpr int HD = 64;   // hidden width (both layers)
-constexpr int SH = 66;   // LDS row stride of 64-wide matrices
-constexpr int SO = 18;   // LDS row stride of 16-wide matrices
+constexpr int SH = 72;   // LDS row stride of 64-wide matrices (= 8 mod 16: conflict-free ds_read_b128 operand fetch)
+constexpr int SO = 24;   // LDS row stride of 16-wide matrices
 constexpr int MAXB = 128;
 
 template <int NT1>
-struct Smem {  // offsets in floats
-  static constexpr int O16 = 16 * NT1, SX = O16 + 2;
+struct Smem {  // offsets in floats (all multiples of 4: 16-byte aligned rows)
+  static constexpr int O16 = 16 * NT1, SX = O16 + 8;
   static constexpr int W1 = 0;
   static constexpr int W2 = W1 + HD * SX;
   static constexpr int WH = W2 + HD * SH;
@@ -50,21 +53,19 @@ struct Smem {  // offsets in floats
   static constexpr int LS = BH + 16;
   static constexpr int X = LS + 16;
   static constexpr int H1 = X + RB * SX;
-  static constexpr int H2 = H1 + RB * SH;
-  static constexpr int DZ = H2 + RB * SH;
-  static constexpr int OUT = DZ + RB * SH;
-  static constexpr int DO = OUT + RB * SO;
-  static constexpr int ACT = DO + RB * SO;      // [RB][16] actions of the chunk
-  static constexpr int OLP = ACT + RB * 16;     // [RB] old log-prob | (value roles) old value
-  static constexpr int ADR = OLP + RB;          // [RB] raw reward advantage | return
-  static constexpr int ADC = ADR + RB;          // [RB] raw cost advantage
-  static constexpr int RED1 = ADC + RB;         // [4][64] per-wave column sums of dz1
-  static constexpr int RED2 = RED1 + 4 * HD;    // [4][64] per-wave column sums of dz2
-  static constexpr int PBH = RED2 + 4 * HD;     // [4][16] per-wave column sums of dOut
-  static constexpr int PLS = PBH + 64;          // [4][16] per-wave d log_std partials
-  static constexpr int PST = PLS + 64;          // [4][8] per-wave loss statistics
-  static constexpr int MISC = PST + 32;         // [32] block-reduction scratch + broadcast scalars
+  static constexpr int H2 = H1 + RB * SH;     // h2, later dz1
+  static constexpr int DZ = H2 + RB * SH;     // dz2; before the backward its rows hold the chunk's actions / scalars
+  static constexpr int DO = DZ + RB * SH;     // head output, overwritten in place by d loss / d output
+  static constexpr int RED1 = DO + RB * SO;   // [4][64] per-wave column sums of dz1
+  static constexpr int RED2 = RED1 + 4 * HD;  // [4][64] per-wave column sums of dz2
+  static constexpr int PBH = RED2 + 4 * HD;   // [4][16] per-wave column sums of dOut
+  static constexpr int PLS = PBH + 64;        // [4][16] per-wave d log_std partials
+  static constexpr int PST = PLS + 64;        // [4][8] per-wave loss statistics
+  static constexpr int MISC = PST + 32;       // [32] block-reduction scratch + broadcast scalars
   static constexpr int TOTAL = MISC + 32;
+  // per-row side data of the chunk lives in the (not yet used) dz rows: columns 0..15 actions, 16 old log-prob | old value,
+  // 17 raw reward advantage | return, 18 raw cost advantage
+  static constexpr int ACT = DZ, OLP = DZ + 16, ADR = DZ + 17, ADC = DZ + 18;
 };
 
 struct TrainArgs {
@@ -90,7 +91,7 @@ __device__ __forceinline__ float block_sum(float v, float* scratch /* >= 8 float
   return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
 }
 
-// sum over the 16 lanes sharing lane/16 (rows of one wave's loss phase)
+// sum over the 16 lanes sharing lane/16
 __device__ __forceinline__ float sum16(float v) {
   v += __shfl_xor(v, 1, 64);
   v += __shfl_xor(v, 2, 64);
@@ -107,10 +108,18 @@ __device__ __forceinline__ float tile_colsum(const f32x4& t) {
   return s;
 }
 
+__device__ __forceinline__ f32x4 lds128(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// position in the stream of 64-row chunks: (epoch, minibatch, chunk)
+struct ChunkPos {
+  int epoch, mb, ch;
+};
+
 template <int NT1>
 __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   using S = Smem<NT1>;
-  constexpr int SX = S::SX, O16 = S::O16;
+  constexpr int SX = S::SX;
+  constexpr int XR = (SX + 3) / 4;  // floats of an X row each of the 4 threads of a row stages
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int role = blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
   const int tid = threadIdx.x;
@@ -124,6 +133,7 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   const int n_total = T * N;
   const int B = a.hp.batch_size;
   const int n_mb = (n_total + B - 1) / B;
+  const int n_epochs = a.hp.n_epochs;
   const float nu = a.nu[0];
 
   // ---- global offsets of this role's tensors in the flat parameter buffer
@@ -162,8 +172,7 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
     vWh[i] = o < n_out ? a.exp_avg_sq[gWh + o * HD + j] : 0.f;
   }
   // thread-owned vector parameters: tid 0..63 b1, 64..127 b2, 128..143 head bias, 144..159 log_std (policy only)
-  int vec_g = -1;       // global index of the owned scalar (or -1)
-  int vec_s = 0;        // its LDS slot
+  int vec_g = -1, vec_s = 0;
   if (tid < 64) { vec_g = gb1 + tid; vec_s = S::B1 + tid; }
   else if (tid < 128) { vec_g = gb2 + tid - 64; vec_s = S::B2 + tid - 64; }
   else if (tid < 144) { if (tid - 128 < n_out) { vec_g = gbh + tid - 128; vec_s = S::BH + tid - 128; } }
@@ -179,37 +188,118 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
   const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
 
+  // ---------------------------------------------------------------------------------------------------------------
+  // chunk stream helpers
+  // ---------------------------------------------------------------------------------------------------------------
+  auto mb_rows = [&](int mb) { const int left = n_total - mb * B; return left < B ? left : B; };
+  auto advance = [&](ChunkPos p) {  // next chunk in the stream (epoch may run past n_epochs: the loaders check)
+    const int nch = (mb_rows(p.mb) + RB - 1) / RB;
+    if (p.ch + 1 < nch) { ++p.ch; return p; }
+    p.ch = 0;
+    if (p.mb + 1 < n_mb) { ++p.mb; return p; }
+    p.mb = 0; ++p.epoch;
+    return p;
+  };
+  auto chunk_rows = [&](const ChunkPos& p) { const int left = mb_rows(p.mb) - p.ch * RB; return left < RB ? left : RB; };
+  // this thread's row of the chunk: b = tid/4 (part = tid%4 splits the row's floats)
+  const int gb_row = tid >> 2, gpart = tid & 3;
+  auto load_idx = [&](const ChunkPos& p) -> int {
+    if (p.epoch >= n_epochs || gb_row >= chunk_rows(p)) return -1;
+    return a.perms[(size_t)p.epoch * n_total + p.mb * B + p.ch * RB + gb_row];
+  };
+  // row data of one chunk held in registers between "issue" and "commit"
+  float px[XR], pact[4], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
+  auto issue_rows = [&](int idx) {
+    size_t off = 0;
+    const bool valid = idx >= 0;
+    if (valid) { const int env = idx / T, t = idx - env * T; off = (size_t)t * N + env; }
+    const float* orow = a.buf.observations + off * O;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) { const int k = gpart + 4 * i; px[i] = (valid && k < O) ? orow[k] : 0.f; }
+    if (role == 0) {
+      const float* arow = a.buf.actions + off * a.buf.act_store;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int k = gpart + 4 * i; pact[i] = (valid && k < A) ? arow[k] : 0.f; }
+      if (gpart == 0) {
+        psc0 = valid ? a.buf.log_probs[off] : 0.f;
+        psc1 = valid ? a.buf.reward_advantages[off] : 0.f;
+        psc2 = valid ? a.buf.cost_advantages[off] : 0.f;
+      }
+    } else if (gpart == 0) {
+      const float* rets = role == 1 ? a.buf.reward_returns : a.buf.cost_returns;
+      const float* olds = role == 1 ? a.buf.reward_values : a.buf.cost_values;
+      psc1 = valid ? rets[off] : 0.f;
+      psc0 = valid ? olds[off] : 0.f;
+    }
+  };
+  auto commit_rows = [&]() {
+#pragma unroll
+    for (int i = 0; i < XR; ++i) { const int k = gpart + 4 * i; if (k < SX) sm[S::X + gb_row * SX + k] = px[i]; }
+    if (role == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sm[S::ACT + gb_row * SH + gpart + 4 * i] = pact[i];
+      if (gpart == 0) { sm[S::OLP + gb_row * SH] = psc0; sm[S::ADR + gb_row * SH] = psc1; sm[S::ADC + gb_row * SH] = psc2; }
+    } else if (gpart == 0) {
+      sm[S::OLP + gb_row * SH] = psc0; sm[S::ADR + gb_row * SH] = psc1;
+    }
+  };
+  // advantage statistics of a minibatch (policy role): thread tid < nb holds row tid's (A_r, A_c)
+  float sar = 0.f, sac = 0.f;
+  auto stat_idx = [&](int epoch, int mb) -> int {
+    if (role != 0 || epoch >= n_epochs || tid >= mb_rows(mb)) return -1;
+    return a.perms[(size_t)epoch * n_total + mb * B + tid];
+  };
+  auto issue_stats = [&](int idx) {
+    sar = 0.f; sac = 0.f;
+    if (idx >= 0) {
+      const int env = idx / T, t = idx - env * T;
+      const size_t off = (size_t)t * N + env;
+      sar = a.buf.reward_advantages[off];
+      sac = a.buf.cost_advantages[off];
+    }
+  };
+  float mean_r = 0.f, std_r = 1.f, mean_c = 0.f;
+  auto compute_stats = [&](int nb) {  // all threads of a policy workgroup; uses sar / sac
+    if (role != 0) return;
+    const bool in = tid < nb;
+    mean_r = block_sum(in ? sar : 0.f, sm + S::MISC) / (float)nb;
+    mean_c = block_sum(in ? sac : 0.f, sm + S::MISC) / (float)nb;
+    const float d = in ? sar - mean_r : 0.f;
+    std_r = sqrtf(block_sum(d * d, sm + S::MISC) / (float)(nb - 1));
+  };
+
   // running statistics (thread 0 of each role)
   float st_ent = 0.f, st_pg = 0.f, st_vl = 0.f, st_cf = 0.f, last_loss = 0.f;
-  int steps_done = 0, early_stop_epoch = a.hp.n_epochs, status = 0;
+  int steps_done = 0, early_stop_epoch = n_epochs, status = 0;
   if (tid == 0) { sm[S::MISC + 12] = 0.f; sm[S::MISC + 13] = 0.f; }
+
+  // ---- pipeline prologue: chunk 0 rows -> LDS, chunk 1 / 2 indices in flight; minibatch 0 statistics
+  ChunkPos pos_next = advance(ChunkPos{0, 0, 0});
+  ChunkPos pos_nx2 = advance(pos_next);
+  int idx_next = load_idx(pos_next);
+  int idx_nx2 = load_idx(pos_nx2);
+  issue_rows(load_idx(ChunkPos{0, 0, 0}));
+  issue_stats(stat_idx(0, 0));
+  int sidx_next = (n_mb > 1) ? stat_idx(0, 1) : stat_idx(1, 0);
+  __syncthreads();
+  commit_rows();
+  compute_stats(mb_rows(0));
   __syncthreads();
 
   unsigned step = 0;
   bool stop = false;
-  for (int epoch = 0; epoch < a.hp.n_epochs && !stop; ++epoch) {
+  for (int epoch = 0; epoch < n_epochs && !stop; ++epoch) {
     float kl_sum = 0.f;  // thread 0, policy role
-    const int* perm = a.perms + (size_t)epoch * n_total;
     for (int mb = 0; mb < n_mb && !stop; ++mb) {
       ++step;
-      const int base = mb * B;
-      const int nb = (n_total - base) < B ? (n_total - base) : B;
-      // ---- minibatch statistics of the advantages (policy role): mean / unbiased std of A_r, mean of A_c
-      float mean_r = 0.f, std_r = 1.f, mean_c = 0.f;
-      if (role == 0) {
-        float ar = 0.f, ac = 0.f;
-        if (tid < nb) {
-          const int idx = perm[base + tid];
-          const int env = idx / T, t = idx - env * T;
-          const size_t off = (size_t)t * N + env;
-          ar = a.buf.reward_advantages[off];
-          ac = a.buf.cost_advantages[off];
-        }
-        mean_r = block_sum(ar, sm + S::MISC) / (float)nb;
-        mean_c = block_sum(ac, sm + S::MISC) / (float)nb;
-        const float d = tid < nb ? ar - mean_r : 0.f;
-        const float ss = block_sum(d * d, sm + S::MISC);
-        std_r = sqrtf(ss / (float)(nb - 1));
+      const int nb = mb_rows(mb);
+      const float c_mean_r = mean_r, c_std_r = std_r, c_mean_c = mean_c;   // statistics of THIS minibatch
+      // statistics prefetch: advantages of the NEXT minibatch's rows (indices loaded a step ago), indices of the one after
+      issue_stats(sidx_next);
+      {
+        int e2 = epoch, m2 = mb + 2;
+        while (m2 >= n_mb) { m2 -= n_mb; ++e2; }
+        sidx_next = stat_idx(e2, m2);
       }
       // ---- zero gradient accumulators
 #pragma unroll
@@ -222,120 +312,136 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
 
       const int n_chunks = (nb + RB - 1) / RB;
       for (int ch = 0; ch < n_chunks; ++ch) {
-        const int cbase = base + ch * RB;
         const int nrows = (nb - ch * RB) < RB ? (nb - ch * RB) : RB;
-        // ================= gather the chunk's rows (flat env-major index -> [T,N] storage) =================
-        {
-          const int b = tid >> 2, part = tid & 3;
-          size_t off = 0;
-          const bool valid = b < nrows;
-          if (valid) {
-            const int idx = perm[cbase + b];
-            const int env = idx / T, t = idx - env * T;
-            off = (size_t)t * N + env;
-          }
-          const float* orow = a.buf.observations + off * O;
-          for (int k = part; k < SX; k += 4) sm[S::X + b * SX + k] = (valid && k < O) ? orow[k] : 0.f;
-          if (role == 0) {
-            const float* arow = a.buf.actions + off * a.buf.act_store;
-            for (int k = part; k < 16; k += 4) sm[S::ACT + b * 16 + k] = (valid && k < A) ? arow[k] : 0.f;
-            if (part == 0) {
-              sm[S::OLP + b] = valid ? a.buf.log_probs[off] : 0.f;
-              sm[S::ADR + b] = valid ? a.buf.reward_advantages[off] : 0.f;
-              sm[S::ADC + b] = valid ? a.buf.cost_advantages[off] : 0.f;
-            }
-          } else if (part == 0) {
-            const float* rets = role == 1 ? a.buf.reward_returns : a.buf.cost_returns;
-            const float* olds = role == 1 ? a.buf.reward_values : a.buf.cost_values;
-            sm[S::ADR + b] = valid ? rets[off] : 0.f;
-            sm[S::OLP + b] = valid ? olds[off] : 0.f;
-          }
+        if (ch > 0) {  // chunk 0 of a step was committed during the previous step's granule wait (or the prologue)
+          commit_rows();
+          __syncthreads();
         }
-        __syncthreads();  // (1) chunk inputs in LDS
+        // prefetch: rows of the next chunk of the stream, indices of the one after the next
+        issue_rows(idx_next);
+        idx_next = idx_nx2;
+        pos_nx2 = advance(pos_nx2);
+        idx_nx2 = load_idx(pos_nx2);
+
         // ================= forward: wave w owns rows 16w..16w+15 =================
+        f32x4 h1t[4], h2t[4];   // this wave's h1 / h2 tiles stay in registers for the backward epilogues
         {
+          f32x4 av[NT1], bv[4][NT1];
+          const float* pa = sm + S::X + (16 * w + r) * SX + 4 * q;
+          const float* pb = sm + S::W1 + r * SX + 4 * q;
+#pragma unroll
+          for (int js = 0; js < NT1; ++js) {
+            av[js] = lds128(pa + 16 * js);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c][js] = lds128(pb + c * 16 * SX + 16 * js);
+          }
+          __builtin_amdgcn_sched_barrier(0);   // all operand reads are issued before the first MFMA
           f32x4 acc[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const float* pa = sm + S::X + (16 * w + r) * SX + q;
-          const float* pb = sm + S::W1 + r * SX + q;
 #pragma unroll
-          for (int ks = 0; ks < O16 / 4; ++ks) {
-            const float av = pa[4 * ks];
+          for (int js = 0; js < NT1; ++js)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av, pb[c * 16 * SX + 4 * ks], acc[c]);
-          }
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int c = 0; c < 4; ++c)
+              for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av[js][e], bv[c][js][e], acc[c]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-              sm[S::H1 + (16 * w + 4 * q + i) * SH + 16 * c + r] = tanhf(acc[c][i] + sm[S::B1 + 16 * c + r]);
-        }
-        {
-          f32x4 acc[4];
+          for (int c = 0; c < 4; ++c) {
+            const float bias = sm[S::B1 + 16 * c + r];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const float* pa = sm + S::H1 + (16 * w + r) * SH + q;
-          const float* pb = sm + S::W2 + r * SH + q;
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks) {
-            const float av = pa[4 * ks];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av, pb[c * 16 * SH + 4 * ks], acc[c]);
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-              sm[S::H2 + (16 * w + 4 * q + i) * SH + 16 * c + r] = tanhf(acc[c][i] + sm[S::B2 + 16 * c + r]);
-        }
-        {
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-          const float* pa = sm + S::H2 + (16 * w + r) * SH + q;
-          const float* pb = sm + S::WH + r * SH + q;
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks) acc = MFMA_F32(pa[4 * ks], pb[4 * ks], acc);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) sm[S::OUT + (16 * w + 4 * q + i) * SO + r] = acc[i] + sm[S::BH + r];
-        }
-        // ================= loss + d loss / d head output, rows of this wave on lanes 0..15 =================
-        {
-          const int b = 16 * w + r;          // every lane computes (4 replicas per row), lanes q == 0 write
-          const bool valid = b < nrows;
-          float* dor = sm + S::DO + b * SO;
-          const float* outr = sm + S::OUT + b * SO;
-          if (role == 0) {
-            float lp = 0.f;
-            for (int k = 0; k < A; ++k) {
-              const float sd = expf(sm[S::LS + k]);
-              const float d = sm[S::ACT + b * 16 + k] - outr[k];
-              lp += -(d * d) / (2.f * (sd * sd)) - logf(sd) - LOG_SQRT_2PI_F;
+            for (int i = 0; i < 4; ++i) {
+              h1t[c][i] = fast_tanh(acc[c][i] + bias);
+              sm[S::H1 + (16 * w + 4 * q + i) * SH + 16 * c + r] = h1t[c][i];
             }
-            const float old_lp = sm[S::OLP + b];
-            const float ratio = expf(lp - old_lp);
-            const float Ar = (sm[S::ADR + b] - mean_r) / (std_r + 1e-8f);
-            const float Ac = sm[S::ADC + b] - mean_c;
+          }
+        }
+        {
+          f32x4 av[4], bv[4][4];
+          const float* pa = sm + S::H1 + (16 * w + r) * SH + 4 * q;
+          const float* pb = sm + S::W2 + r * SH + 4 * q;
+#pragma unroll
+          for (int js = 0; js < 4; ++js) {
+            av[js] = lds128(pa + 16 * js);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c][js] = lds128(pb + c * 16 * SH + 16 * js);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 acc[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av[js][e], bv[c][js][e], acc[c]);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float bias = sm[S::B2 + 16 * c + r];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              h2t[c][i] = fast_tanh(acc[c][i] + bias);
+              sm[S::H2 + (16 * w + 4 * q + i) * SH + 16 * c + r] = h2t[c][i];
+            }
+          }
+        }
+        {
+          f32x4 av[4], bv[4];
+          const float* pa = sm + S::H2 + (16 * w + r) * SH + 4 * q;
+          const float* pb = sm + S::WH + r * SH + 4 * q;
+#pragma unroll
+          for (int js = 0; js < 4; ++js) { av[js] = lds128(pa + 16 * js); bv[js] = lds128(pb + 16 * js); }
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 acc[4];   // four independent chains (one per js), summed afterwards
+#pragma unroll
+          for (int js = 0; js < 4; ++js) {
+            acc[js] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[js] = MFMA_F32(av[js][e], bv[js][e], acc[js]);
+          }
+          const float bias = sm[S::BH + r];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            sm[S::DO + (16 * w + 4 * q + i) * SO + r] = ((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i])) + bias;
+        }
+        // ================= loss + d loss / d head output: the wave's 16 rows, replicated over lane/16 =================
+        {
+          const int b = 16 * w + r;
+          const bool valid = b < nrows;
+          float* dor = sm + S::DO + b * SO;     // holds the head output of row b; overwritten with its gradient
+          if (role == 0) {
+            float dd[MAX_ACT], ivar[MAX_ACT];
+            float lp = 0.f;
+#pragma unroll
+            for (int k = 0; k < MAX_ACT; ++k) {
+              dd[k] = 0.f; ivar[k] = 0.f;
+              if (k < A) {
+                const float sd = __expf(sm[S::LS + k]);
+                const float var = sd * sd;
+                dd[k] = sm[S::ACT + b * SH + k] - dor[k];
+                ivar[k] = 1.f / var;
+                lp += -(dd[k] * dd[k]) / (2.f * var) - __logf(sd) - LOG_SQRT_2PI_F;
+              }
+            }
+            const float old_lp = sm[S::OLP + b * SH];
+            const float ratio = __expf(lp - old_lp);
+            const float Ar = (sm[S::ADR + b * SH] - c_mean_r) / (c_std_r + 1e-8f);
+            const float Ac = sm[S::ADC + b * SH] - c_mean_c;
             const float s1 = Ar * ratio;
             const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
             const float s2 = Ar * rc;
             const float gsel = (s1 <= s2) ? Ar : 0.f;                       // d min(s1, s2) / d ratio
             const float cpol = 1.f / ((1.f + nu) * (float)nb);
             const float dlp = valid ? cpol * (-gsel + nu * Ac) * ratio : 0.f;  // d loss / d log_prob
-            float pls_acc = 0.f;
-            for (int k = 0; k < 16; ++k) {
-              float dk = 0.f, lk = 0.f;
-              if (k < A) {
-                const float sd = expf(sm[S::LS + k]);
-                const float var = sd * sd;
-                const float d = sm[S::ACT + b * 16 + k] - outr[k];
-                dk = dlp * (d / var);
-                lk = dlp * ((d * d) / var - 1.f);
-              }
-              if (q == 0) dor[k] = dk;
-              const float colsum = sum16(dk);
-              const float lssum = sum16(lk);
+            // (same wave: LDS operations execute in program order, so every replica has read the row before it is overwritten)
+#pragma unroll
+            for (int k = 0; k < MAX_ACT; ++k) {
+              const float dk = dlp * (dd[k] * ivar[k]);
+              const float lk = dlp * ((dd[k] * dd[k]) * ivar[k] - 1.f);
+              if (q == 0) dor[k] = k < A ? dk : 0.f;
+              float colsum = 0.f, lssum = 0.f;
+              if (k < A) { colsum = sum16(dk); lssum = sum16(lk); }
               if (lane == 0) { sm[S::PBH + w * 16 + k] = colsum; sm[S::PLS + w * 16 + k] = lssum; }
-              (void)pls_acc;
             }
             const float v0 = sum16(valid ? fminf(s1, s2) : 0.f);
             const float v1 = sum16(valid ? Ac * ratio : 0.f);
@@ -343,11 +449,11 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
             const float v3 = sum16(valid ? old_lp - lp : 0.f);
             if (lane == 0) { sm[S::PST + w * 8 + 0] = v0; sm[S::PST + w * 8 + 1] = v1; sm[S::PST + w * 8 + 2] = v2; sm[S::PST + w * 8 + 3] = v3; }
           } else {
-            const float v = outr[0];
-            const float R = sm[S::ADR + b];
+            const float v = dor[0];
+            const float R = sm[S::ADR + b * SH];
             float vp = v, pass = 1.f;
             if (vclip >= 0.f) {
-              const float old = sm[S::OLP + b];
+              const float old = sm[S::OLP + b * SH];
               const float dv = v - old;
               vp = old + fminf(fmaxf(dv, -vclip), vclip);
               pass = (dv >= -vclip && dv <= vclip) ? 1.f : 0.f;
@@ -356,12 +462,14 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
             const float d0 = valid ? vcoef * 2.f * e / (float)nb * pass : 0.f;
             if (q == 0) {
               dor[0] = d0;
+#pragma unroll
               for (int k = 1; k < 16; ++k) dor[k] = 0.f;
             }
             const float colsum = sum16(d0);
             const float se = sum16(valid ? e * e : 0.f);
             if (lane == 0) {
               sm[S::PBH + w * 16] = colsum;
+#pragma unroll
               for (int k = 1; k < 16; ++k) sm[S::PBH + w * 16 + k] = 0.f;
               sm[S::PST + w * 8 + 0] = se;
             }
@@ -369,36 +477,49 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
         }
         // ================= backward =================
         {  // dH2 = dOut . Wh  -> dz2 = dH2 * (1 - h2^2) (own rows), column sums for d b2
+          const f32x4 av = lds128(sm + S::DO + (16 * w + r) * SO + 4 * q);   // k = a = 4q + e
+          float bv[4][4];
+          const float* pb = sm + S::WH + (4 * q) * SH + r;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bv[c][e] = pb[e * SH + 16 * c];
           f32x4 acc[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const float* pa = sm + S::DO + (16 * w + r) * SO + q;
-          const float* pb = sm + S::WH + q * SH + r;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const float av = pa[4 * ks];
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av, pb[4 * ks * SH + 16 * c], acc[c]);
-          }
+            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av[e], bv[c][e], acc[c]);
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int at = (16 * w + 4 * q + i) * SH + 16 * c + r;
-              const float h = sm[S::H2 + at];
-              acc[c][i] = acc[c][i] * (1.f - h * h);
-              sm[S::DZ + at] = acc[c][i];
+              acc[c][i] = acc[c][i] * (1.f - h2t[c][i] * h2t[c][i]);
+              sm[S::DZ + (16 * w + 4 * q + i) * SH + 16 * c + r] = acc[c][i];
             }
             const float cs = tile_colsum(acc[c]);
             if (q == 0) sm[S::RED2 + w * HD + 16 * c + r] = cs;
           }
         }
         __syncthreads();  // (2) dz2, dOut, h2 of ALL rows visible
-        {  // dWh[o][j] += sum_b dOut[b][o] h2[b][j]   (wave w: columns 16w..16w+15)
-          const float* pa = sm + S::DO + q * SO + r;
-          const float* pb = sm + S::H2 + q * SH + 16 * w + r;
+        {  // dWh[o][j] += sum_b dOut[b][o] h2[b][j]   (wave w: columns 16w..16w+15); b = 16 js + 4 q + e
+          float av[4][4], bv[4][4];
+          const float* pa = sm + S::DO + (4 * q) * SO + r;
+          const float* pb = sm + S::H2 + (4 * q) * SH + 16 * w + r;
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) gWhr = MFMA_F32(pa[4 * ks * SO], pb[4 * ks * SH], gWhr);
+          for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { av[js][e] = pa[(16 * js + e) * SO]; bv[js][e] = pb[(16 * js + e) * SH]; }
+          f32x4 acc[4];
+#pragma unroll
+          for (int js = 0; js < 4; ++js) {
+            acc[js] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[js] = MFMA_F32(av[js][e], bv[js][e], acc[js]);
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gWhr[i] += (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
         }
         // owners fold the per-wave partials of this chunk (b2, head bias, log_std, loss statistics)
         if (tid >= 64 && tid < 128) {
@@ -419,35 +540,53 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
         }
         __syncthreads();  // (2b) every wave is done reading h2: its buffer becomes dz1
         {  // dW2[j][k] += sum_b dz2[b][j] h1[b][k]   (wave w: rows j = 16w..)
-          const float* pa = sm + S::DZ + q * SH + 16 * w + r;
-          const float* pb = sm + S::H1 + q * SH + r;
+          float av[4][4];
+          const float* pa = sm + S::DZ + (4 * q) * SH + 16 * w + r;
+          const float* pb = sm + S::H1 + (4 * q) * SH + r;
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) {
-            const float av = pa[4 * ks * SH];
+          for (int js = 0; js < 4; ++js)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) gW2r[c] = MFMA_F32(av, pb[4 * ks * SH + 16 * c], gW2r[c]);
+            for (int e = 0; e < 4; ++e) av[js][e] = pa[(16 * js + e) * SH];
+#pragma unroll
+          for (int js = 0; js < 4; ++js) {
+            float bv[4][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) bv[c][e] = pb[(16 * js + e) * SH + 16 * c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) gW2r[c] = MFMA_F32(av[js][e], bv[c][e], gW2r[c]);
           }
         }
         {  // dH1 = dz2 . W2 (own rows) -> dz1 = dH1 * (1 - h1^2), stored over h2
+          f32x4 av[4];
+          const float* pa = sm + S::DZ + (16 * w + r) * SH + 4 * q;
+          const float* pb = sm + S::W2 + (4 * q) * SH + r;
+#pragma unroll
+          for (int js = 0; js < 4; ++js) av[js] = lds128(pa + 16 * js);
           f32x4 acc[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-          const float* pa = sm + S::DZ + (16 * w + r) * SH + q;
-          const float* pb = sm + S::W2 + q * SH + r;
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) {
-            const float av = pa[4 * ks];
+          for (int js = 0; js < 4; ++js) {
+            float bv[4][4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av, pb[4 * ks * SH + 16 * c], acc[c]);
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) bv[c][e] = pb[(16 * js + e) * SH + 16 * c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av[js][e], bv[c][e], acc[c]);
           }
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int at = (16 * w + 4 * q + i) * SH + 16 * c + r;
-              const float h = sm[S::H1 + at];
-              acc[c][i] = acc[c][i] * (1.f - h * h);
-              sm[S::H2 + at] = acc[c][i];
+              acc[c][i] = acc[c][i] * (1.f - h1t[c][i] * h1t[c][i]);
+              sm[S::H2 + (16 * w + 4 * q + i) * SH + 16 * c + r] = acc[c][i];
             }
             const float cs = tile_colsum(acc[c]);
             if (q == 0) sm[S::RED1 + w * HD + 16 * c + r] = cs;
@@ -455,13 +594,24 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
         }
         __syncthreads();  // (3) dz1 of all rows visible
         {  // dW1[j][k] += sum_b dz1[b][j] x[b][k]
-          const float* pa = sm + S::H2 + q * SH + 16 * w + r;
-          const float* pb = sm + S::X + q * SX + r;
+          float av[4][4];
+          const float* pa = sm + S::H2 + (4 * q) * SH + 16 * w + r;
+          const float* pb = sm + S::X + (4 * q) * SX + r;
 #pragma unroll
-          for (int ks = 0; ks < 16; ++ks) {
-            const float av = pa[4 * ks * SH];
+          for (int js = 0; js < 4; ++js)
 #pragma unroll
-            for (int c = 0; c < NT1; ++c) gW1r[c] = MFMA_F32(av, pb[4 * ks * SX + 16 * c], gW1r[c]);
+            for (int e = 0; e < 4; ++e) av[js][e] = pa[(16 * js + e) * SH];
+#pragma unroll
+          for (int js = 0; js < 4; ++js) {
+            float bv[NT1][4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < NT1; ++c) bv[c][e] = pb[(16 * js + e) * SX + 16 * c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+              for (int c = 0; c < NT1; ++c) gW1r[c] = MFMA_F32(av[js][e], bv[c][e], gW1r[c]);
           }
         }
         if (tid < 64) gB += (sm[S::RED1 + tid] + sm[S::RED1 + HD + tid]) + (sm[S::RED1 + 2 * HD + tid] + sm[S::RED1 + 3 * HD + tid]);
@@ -512,6 +662,13 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
         __hip_atomic_store(a.xch + (step & 1) * 4 + role, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
       }
+      // ---- while the granules travel: stage the next minibatch (rows -> LDS, advantage statistics)
+      commit_rows();
+      {
+        int mbn = mb + 1;
+        if (mbn >= n_mb) mbn = 0;
+        compute_stats(mb_rows(mbn));
+      }
       if (tid < 3) {
         u64 v = 0;
         int spins = 0;
@@ -525,8 +682,6 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
         sm[S::MISC + 8 + tid] = __uint_as_float((unsigned)(v & 0xffffffffu));
         if (tid == 0) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;
         if (!ok) sm[S::MISC + 13] = 1.f;
-      } else if (tid == 3) {
-        // nothing: slot 13 is zeroed below on the success path
       }
       __syncthreads();
       const float total = sqrtf((sm[S::MISC + 8] + sm[S::MISC + 9]) + sm[S::MISC + 10]);
@@ -624,6 +779,7 @@ using namespace icrl;
 
 template <int NT1>
 static int launch_train(const TrainArgs& a, hipStream_t s) {
+  static_assert(Smem<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
   const size_t bytes = (size_t)Smem<NT1>::TOTAL * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)ppo_train_kernel<NT1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;

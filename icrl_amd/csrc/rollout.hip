@@ -72,14 +72,14 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const f
     const float* W = PT + L.W1[w];
     float acc = 0.f;
     for (int k = 0; k < L.O; ++k) acc = fmaf(W[k * L.H1 + lane], sh.x[k], acc);
-    sh.h[w][lane] = tanhf(acc + PT[L.b1[w] + lane]);
+    sh.h[w][lane] = fast_tanh(acc + PT[L.b1[w] + lane]);
   }
   __syncthreads();
   if (lane < L.H2) {
     const float* W = PT + L.W2[w];
     float acc = 0.f;
     for (int k = 0; k < L.H1; ++k) acc = fmaf(W[k * L.H2 + lane], sh.h[w][k], acc);
-    sh.g[w][lane] = tanhf(acc + PT[L.b2[w] + lane]);
+    sh.g[w][lane] = fast_tanh(acc + PT[L.b2[w] + lane]);
   }
   __syncthreads();
   if (w == 0) {
