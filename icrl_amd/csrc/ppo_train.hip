@@ -62,7 +62,8 @@ struct Smem {  // offsets in floats (all multiples of 4: 16-byte aligned rows)
   static constexpr int PLS = PBH + 64;        // [4][16] per-wave d log_std partials
   static constexpr int PST = PLS + 64;        // [4][8] per-wave loss statistics
   static constexpr int MISC = PST + 32;       // [32] block-reduction scratch + broadcast scalars
-  static constexpr int TOTAL = MISC + 32;
+  static constexpr int GAU = MISC + 32;       // [3][16] per-action 1/var, 0.5/var, log(sd) + log(sqrt(2 pi))
+  static constexpr int TOTAL = GAU + 48;
   // per-row side data of the chunk lives in the (not yet used) dz rows: columns 0..15 actions, 16 old log-prob | old value,
   // 17 raw reward advantage | return, 18 raw cost advantage
   static constexpr int ACT = DZ, OLP = DZ + 16, ADR = DZ + 17, ADC = DZ + 18;
@@ -107,6 +108,21 @@ __device__ __forceinline__ float tile_colsum(const f32x4& t) {
   s += __shfl_xor(s, 32, 64);
   return s;
 }
+
+// diagnostic phase timer (only when hp._pad != 0: the stamp drains the LDS queue, so never in a timed run)
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define STAMP(slot)                                                        \
+  if (prof) {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    const unsigned long long now_ = stamp();                               \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    if (tid == 0) ph[slot] += (double)(now_ - t_last);                     \
+    t_last = now_;                                                         \
+  }
 
 __device__ __forceinline__ f32x4 lds128(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
@@ -259,15 +275,32 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
     }
   };
   float mean_r = 0.f, std_r = 1.f, mean_c = 0.f;
-  auto compute_stats = [&](int nb) {  // all threads of a policy workgroup; uses sar / sac
+  auto compute_stats = [&](int nb) {  // all threads of a policy workgroup; uses sar / sac.  ONE block reduction.
     if (role != 0) return;
     const bool in = tid < nb;
-    mean_r = block_sum(in ? sar : 0.f, sm + S::MISC) / (float)nb;
-    mean_c = block_sum(in ? sac : 0.f, sm + S::MISC) / (float)nb;
-    const float d = in ? sar - mean_r : 0.f;
-    std_r = sqrtf(block_sum(d * d, sm + S::MISC) / (float)(nb - 1));
+    float s_r = wave_sum(in ? sar : 0.f), s_c = wave_sum(in ? sac : 0.f), s_rr = wave_sum(in ? sar * sar : 0.f);
+    __syncthreads();
+    if (lane == 0) { sm[S::MISC + 16 + w] = s_r; sm[S::MISC + 20 + w] = s_c; sm[S::MISC + 24 + w] = s_rr; }
+    __syncthreads();
+    s_r = (sm[S::MISC + 16] + sm[S::MISC + 17]) + (sm[S::MISC + 18] + sm[S::MISC + 19]);
+    s_c = (sm[S::MISC + 20] + sm[S::MISC + 21]) + (sm[S::MISC + 22] + sm[S::MISC + 23]);
+    s_rr = (sm[S::MISC + 24] + sm[S::MISC + 25]) + (sm[S::MISC + 26] + sm[S::MISC + 27]);
+    mean_r = s_r / (float)nb;
+    mean_c = s_c / (float)nb;
+    // unbiased variance from the raw moments (advantages are O(1): fp32 cancellation stays ~1e-6 relative)
+    const float var = fmaxf(s_rr - s_r * mean_r, 0.f) / (float)(nb - 1);
+    std_r = sqrtf(var);
   };
-
+  auto refresh_gauss = [&]() {   // threads 144..159 own log_std: derived constants of the Gaussian head
+    if (role == 0 && tid >= 144 && tid < 160) {
+      const int k = tid - 144;
+      const float sd = __expf(sm[S::LS + k]);
+      const float iv = __builtin_amdgcn_rcpf(sd * sd);
+      sm[S::GAU + k] = k < A ? iv : 0.f;
+      sm[S::GAU + 16 + k] = k < A ? 0.5f * iv : 0.f;
+      sm[S::GAU + 32 + k] = k < A ? __logf(sd) + LOG_SQRT_2PI_F : 0.f;
+    }
+  };
   // running statistics (thread 0 of each role)
   float st_ent = 0.f, st_pg = 0.f, st_vl = 0.f, st_cf = 0.f, last_loss = 0.f;
   int steps_done = 0, early_stop_epoch = n_epochs, status = 0;
@@ -280,11 +313,16 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   int idx_nx2 = load_idx(pos_nx2);
   issue_rows(load_idx(ChunkPos{0, 0, 0}));
   issue_stats(stat_idx(0, 0));
+  refresh_gauss();
   int sidx_next = (n_mb > 1) ? stat_idx(0, 1) : stat_idx(1, 0);
   __syncthreads();
   commit_rows();
   compute_stats(mb_rows(0));
   __syncthreads();
+
+  const bool prof = a.hp._pad != 0;
+  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = prof ? stamp() : 0ull;
 
   unsigned step = 0;
   bool stop = false;
@@ -293,7 +331,9 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
     for (int mb = 0; mb < n_mb && !stop; ++mb) {
       ++step;
       const int nb = mb_rows(mb);
-      const float c_mean_r = mean_r, c_std_r = std_r, c_mean_c = mean_c;   // statistics of THIS minibatch
+      const float c_mean_r = mean_r, c_mean_c = mean_c;   // statistics of THIS minibatch
+      const float c_istd_r = 1.f / (std_r + 1e-8f);
+      const float cpol_nb = 1.f / ((1.f + nu) * (float)nb);
       // statistics prefetch: advantages of the NEXT minibatch's rows (indices loaded a step ago), indices of the one after
       issue_stats(sidx_next);
       {
@@ -404,44 +444,43 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
           for (int i = 0; i < 4; ++i)
             sm[S::DO + (16 * w + 4 * q + i) * SO + r] = ((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i])) + bias;
         }
+        STAMP(0)   // forward
         // ================= loss + d loss / d head output: the wave's 16 rows, replicated over lane/16 =================
         {
           const int b = 16 * w + r;
           const bool valid = b < nrows;
           float* dor = sm + S::DO + b * SO;     // holds the head output of row b; overwritten with its gradient
           if (role == 0) {
-            float dd[MAX_ACT], ivar[MAX_ACT];
+            float dd[4], iv[4];
             float lp = 0.f;
 #pragma unroll
-            for (int k = 0; k < MAX_ACT; ++k) {
-              dd[k] = 0.f; ivar[k] = 0.f;
-              if (k < A) {
-                const float sd = __expf(sm[S::LS + k]);
-                const float var = sd * sd;
-                dd[k] = sm[S::ACT + b * SH + k] - dor[k];
-                ivar[k] = 1.f / var;
-                lp += -(dd[k] * dd[k]) / (2.f * var) - __logf(sd) - LOG_SQRT_2PI_F;
-              }
+            for (int i = 0; i < 4; ++i) {
+              const int k = q + 4 * i;                      // this lane's actions of row b
+              dd[i] = sm[S::ACT + b * SH + k] - dor[k];     // pad actions / outputs are 0
+              iv[i] = sm[S::GAU + k];
+              lp += -(dd[i] * dd[i]) * sm[S::GAU + 16 + k] - sm[S::GAU + 32 + k];
             }
+            lp += __shfl_xor(lp, 16, 64);                   // sum over the 4 lane groups -> log-prob of row b in every replica
+            lp += __shfl_xor(lp, 32, 64);
             const float old_lp = sm[S::OLP + b * SH];
             const float ratio = __expf(lp - old_lp);
-            const float Ar = (sm[S::ADR + b * SH] - c_mean_r) / (c_std_r + 1e-8f);
+            const float Ar = (sm[S::ADR + b * SH] - c_mean_r) * c_istd_r;
             const float Ac = sm[S::ADC + b * SH] - c_mean_c;
             const float s1 = Ar * ratio;
             const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
             const float s2 = Ar * rc;
             const float gsel = (s1 <= s2) ? Ar : 0.f;                       // d min(s1, s2) / d ratio
-            const float cpol = 1.f / ((1.f + nu) * (float)nb);
-            const float dlp = valid ? cpol * (-gsel + nu * Ac) * ratio : 0.f;  // d loss / d log_prob
-            // (same wave: LDS operations execute in program order, so every replica has read the row before it is overwritten)
+            const float dlp = valid ? cpol_nb * (-gsel + nu * Ac) * ratio : 0.f;  // d loss / d log_prob
+            // (same wave: LDS operations execute in program order, so every lane has read the row before it is overwritten)
 #pragma unroll
-            for (int k = 0; k < MAX_ACT; ++k) {
-              const float dk = dlp * (dd[k] * ivar[k]);
-              const float lk = dlp * ((dd[k] * dd[k]) * ivar[k] - 1.f);
-              if (q == 0) dor[k] = k < A ? dk : 0.f;
-              float colsum = 0.f, lssum = 0.f;
-              if (k < A) { colsum = sum16(dk); lssum = sum16(lk); }
-              if (lane == 0) { sm[S::PBH + w * 16 + k] = colsum; sm[S::PLS + w * 16 + k] = lssum; }
+            for (int i = 0; i < 4; ++i) {
+              const int k = q + 4 * i;
+              const float dk = dlp * (dd[i] * iv[i]);
+              const float lk = (k < A) ? dlp * ((dd[i] * dd[i]) * iv[i] - 1.f) : 0.f;
+              dor[k] = dk;
+              const float colsum = sum16(dk);
+              const float lssum = sum16(lk);
+              if (r == 0) { sm[S::PBH + w * 16 + k] = colsum; sm[S::PLS + w * 16 + k] = lssum; }
             }
             const float v0 = sum16(valid ? fminf(s1, s2) : 0.f);
             const float v1 = sum16(valid ? Ac * ratio : 0.f);
@@ -475,6 +514,7 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
             }
           }
         }
+        STAMP(1)   // loss
         // ================= backward =================
         {  // dH2 = dOut . Wh  -> dz2 = dH2 * (1 - h2^2) (own rows), column sums for d b2
           const f32x4 av = lds128(sm + S::DO + (16 * w + r) * SO + 4 * q);   // k = a = 4q + e
@@ -616,6 +656,7 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
         }
         if (tid < 64) gB += (sm[S::RED1 + tid] + sm[S::RED1 + HD + tid]) + (sm[S::RED1 + 2 * HD + tid] + sm[S::RED1 + 3 * HD + tid]);
         __syncthreads();  // (4) chunk buffers free
+        STAMP(2)   // backward
       }  // chunks
 
       // entropy term of the policy loss: d(ent_coef * -mean(H)) / d log_std = -ent_coef (H = sum_a 0.5 + 0.5 log 2pi + log sigma)
@@ -635,9 +676,20 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
       for (int i = 0; i < 4; ++i) ss += gWhr[i] * gWhr[i];
       if (vec_g >= 0) ss += gB * gB;
       ss = block_sum(ss, sm + S::MISC);
-      // statistics + early-stop decision ride on the policy workgroup's granule
-      bool want_stop = false;
+      // the early-stop decision rides on the policy workgroup's granule; publish first, book-keep afterwards
       if (tid == 0) {
+        bool want_stop = false;
+        float mean_kl = 0.f;
+        if (role == 0) {
+          kl_sum += mb_s3 / (float)nb;
+          if (mb == n_mb - 1) {
+            mean_kl = kl_sum / (float)n_mb;
+            if (a.hp.use_target_kl && mean_kl > 1.5f * a.hp.target_kl) { want_stop = true; early_stop_epoch = epoch; }
+          }
+        }
+        const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
+        __hip_atomic_store(a.xch + (step & 1) * 4 + role, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
         ++steps_done;
         if (role == 0) {
           float ent = 0.f;
@@ -645,23 +697,15 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
           const float entropy_loss = -ent;
           const float pl = (-(mb_s0 / (float)nb) + nu * (mb_s1 / (float)nb)) / (1.f + nu);
           st_ent += entropy_loss; st_pg += pl; st_cf += mb_s2 / (float)nb;
-          kl_sum += mb_s3 / (float)nb;
           last_loss = pl + a.hp.ent_coef * entropy_loss;
-          if (mb == n_mb - 1) {
-            const float mean_kl = kl_sum / (float)n_mb;
-            a.stats[32 + epoch] = mean_kl;
-            a.stats[7] = mean_kl;
-            if (a.hp.use_target_kl && mean_kl > 1.5f * a.hp.target_kl) { want_stop = true; early_stop_epoch = epoch; }
-          }
+          if (mb == n_mb - 1) { a.stats[32 + epoch] = mean_kl; a.stats[7] = mean_kl; }
         } else {
           const float vl = mb_s0 / (float)nb;
           st_vl += vl;
           last_loss = vl;
         }
-        const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
-        __hip_atomic_store(a.xch + (step & 1) * 4 + role, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
       }
+      STAMP(3)   // gradient norm + publish
       // ---- while the granules travel: stage the next minibatch (rows -> LDS, advantage statistics)
       commit_rows();
       {
@@ -669,6 +713,7 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
         if (mbn >= n_mb) mbn = 0;
         compute_stats(mb_rows(mbn));
       }
+      STAMP(4)   // next-minibatch staging
       if (tid < 3) {
         u64 v = 0;
         int spins = 0;
@@ -684,6 +729,7 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
         if (!ok) sm[S::MISC + 13] = 1.f;
       }
       __syncthreads();
+      STAMP(5)   // granule wait
       const float total = sqrtf((sm[S::MISC + 8] + sm[S::MISC + 9]) + sm[S::MISC + 10]);
       stop = sm[S::MISC + 12] != 0.f;
       if (sm[S::MISC + 13] != 0.f) { status = 1; stop = true; }
@@ -694,14 +740,14 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
       b1pow *= (double)a.hp.adam_beta1;
       b2pow *= (double)a.hp.adam_beta2;
       const float step_size = (float)((double)a.hp.lr / (1.0 - b1pow));
-      const float bc2_sqrt = (float)sqrt(1.0 - b2pow);
+      const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2pow));
       const float b2f = a.hp.adam_beta2, epsf = a.hp.adam_eps;
       auto adam = [&](float g, float& m, float& v, float p) -> float {
         g = g * coef;
         m = m + (g - m) * w1;
         v = v * b2f + w2 * (g * g);
-        const float denom = sqrtf(v) / bc2_sqrt + epsf;
-        return p - step_size * (m / denom);
+        const float denom = __builtin_amdgcn_sqrtf(v) * inv_bc2_sqrt + epsf;     // v_sqrt_f32 / v_rcp_f32: 1 ulp each
+        return p - step_size * (m * __builtin_amdgcn_rcpf(denom));
       };
       if (status == 0) {
 #pragma unroll
@@ -726,9 +772,11 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
           if (o < n_out) { float* pw = sm + S::WH + o * SH + 16 * w + r; float m_ = mWh[i], v_ = vWh[i]; *pw = adam(gWhr[i], m_, v_, *pw); mWh[i] = m_; vWh[i] = v_; }
         }
         if (vec_g >= 0) sm[vec_s] = adam(gB, mB, vB, sm[vec_s]);
+        refresh_gauss();
       }
       if (tid == 0) { sm[S::MISC + 12] = 0.f; sm[S::MISC + 13] = 0.f; }
       __syncthreads();
+      STAMP(6)   // Adam
     }  // minibatches
   }    // epochs
 
@@ -756,6 +804,9 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   for (int i = 0; i < 4; ++i) {
     const int o = 4 * q + i, j = 16 * w + r;
     if (o < n_out) { a.exp_avg[gWh + o * HD + j] = mWh[i]; a.exp_avg_sq[gWh + o * HD + j] = vWh[i]; }
+  }
+  if (tid == 0 && prof) {
+    for (int k = 0; k < 7; ++k) a.stats[12 + 7 * role + k > 31 ? 31 : 12 + 7 * role + k] = (float)(ph[k] / (double)(steps_done > 0 ? steps_done : 1));
   }
   if (tid == 0) {
     if (role == 0) {

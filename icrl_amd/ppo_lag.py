@@ -237,7 +237,7 @@ class PPOLagrangian:
         ws = self._train_ws
         ws["nu"].fill_(current_penalty)
         ws["t"].fill_(pol.adam_step)
-        hp = PpoHyperT(int(self.batch_size), int(self.n_epochs), int(self.target_kl is not None), 0, clip_range, float(self.ent_coef),
+        hp = PpoHyperT(int(self.batch_size), int(self.n_epochs), int(self.target_kl is not None), int(getattr(self, "profile_phases", 0)), clip_range, float(self.ent_coef),
                        float(self.reward_vf_coef), float(self.cost_vf_coef), float(self.max_grad_norm),
                        float(self.target_kl or 0.0), crv, ccv, lr, 0.9, 0.999, float(pol.optimizer_kwargs.get("eps", 1e-8)))
         ps, bs = pol.struct(), rb.struct()
@@ -289,3 +289,4 @@ class PPOLagrangian:
         logger.record("train/n_updates", self._n_updates)
         logger.record("train/clip_range", clip_range)
         self.epoch_kls = st[32:32 + self.n_epochs].copy()
+        self.phase_cycles = st[12:32].copy()
