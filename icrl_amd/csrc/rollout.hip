@@ -61,45 +61,89 @@ struct ActShared {
   float scal[4];           // v_r, v_c, log_prob, (unused)
 };
 
-// three tanh MLPs + heads for the observation in sh.x.  Must be called by all 192 threads.
-__device__ __forceinline__ void policy_forward_block(const PolLayout& L, const float* __restrict__ PT, ActShared& sh,
+// One lane's slice of the three MLPs, held in registers: lane j of wave w (pi | vf | cvf) owns column j of W1^T and
+// W2^T of network w; lanes < A of wave 0 own a column of the action head, the value waves one head weight per lane.
+// All loads are issued back to back (one memory latency for the whole network instead of one per input index); a
+// persistent kernel loads them ONCE for all its steps.
+template <int OCT>
+struct PolRegs {
+  float w1[16 * OCT];
+  float w2[MAX_H];
+  float wh[MAX_H];   // wave 0: head column of action `lane`; waves 1/2: wh[0] = value-head weight of hidden unit `lane`
+  float b1, b2, bh, ls;
+};
+
+template <int OCT>
+__device__ __forceinline__ void load_pol_regs(const PolLayout& L, const float* __restrict__ PT, PolRegs<OCT>& R) {
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int j1 = lane < L.H1 ? lane : 0, j2 = lane < L.H2 ? lane : 0;
+#pragma unroll
+  for (int k = 0; k < 16 * OCT; ++k) R.w1[k] = (w < 3 && k < L.O) ? PT[L.W1[w] + k * L.H1 + j1] : 0.f;
+#pragma unroll
+  for (int k = 0; k < MAX_H; ++k) R.w2[k] = (w < 3 && k < L.H1) ? PT[L.W2[w] + k * L.H2 + j2] : 0.f;
+  R.b1 = w < 3 ? PT[L.b1[w] + j1] : 0.f;
+  R.b2 = w < 3 ? PT[L.b2[w] + j2] : 0.f;
+  R.bh = 0.f; R.ls = 0.f;
+  if (w == 0) {
+    const int a = lane < L.A ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < MAX_H; ++j) R.wh[j] = j < L.H2 ? PT[L.Wa + j * L.A + a] : 0.f;
+    R.bh = PT[L.ba + a];
+    if (!L.discrete) R.ls = PT[L.log_std + a];
+  } else if (w < 3) {
+#pragma unroll
+    for (int j = 1; j < MAX_H; ++j) R.wh[j] = 0.f;
+    R.wh[0] = PT[(w == 1 ? L.Wv : L.Wc) + j2];
+    R.bh = PT[w == 1 ? L.bv : L.bc];
+  }
+}
+
+// three tanh MLPs + heads for the observation in sh.x.  Must be called by all threads of the workgroup (waves >= 3 only
+// take part in the barriers).
+template <int OCT>
+__device__ __forceinline__ void policy_forward_block(const PolLayout& L, const PolRegs<OCT>& R, ActShared& sh,
                                                      const float* noise_row, int deterministic,
                                                      const float* alow, const float* ahigh,
                                                      const float* given = nullptr /* evaluate_actions: actions to score */) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (lane < L.H1) {
-    const float* W = PT + L.W1[w];
+  if (w < 3 && lane < L.H1) {
     float acc = 0.f;
-    for (int k = 0; k < L.O; ++k) acc = fmaf(W[k * L.H1 + lane], sh.x[k], acc);
-    sh.h[w][lane] = fast_tanh(acc + PT[L.b1[w] + lane]);
+#pragma unroll
+    for (int k = 0; k < 16 * OCT; ++k)
+      if (k < L.O) acc = fmaf(R.w1[k], sh.x[k], acc);
+    sh.h[w][lane] = fast_tanh(acc + R.b1);
   }
   __syncthreads();
-  if (lane < L.H2) {
-    const float* W = PT + L.W2[w];
+  if (w < 3 && lane < L.H2) {
     float acc = 0.f;
-    for (int k = 0; k < L.H1; ++k) acc = fmaf(W[k * L.H2 + lane], sh.h[w][k], acc);
-    sh.g[w][lane] = fast_tanh(acc + PT[L.b2[w] + lane]);
+#pragma unroll
+    for (int k = 0; k < MAX_H; ++k)
+      if (k < L.H1) acc = fmaf(R.w2[k], sh.h[w][k], acc);
+    sh.g[w][lane] = fast_tanh(acc + R.b2);
   }
   __syncthreads();
   if (w == 0) {
     float mean = 0.f;
     if (lane < L.A) {
-      const float* W = PT + L.Wa;
       float acc = 0.f;
-      for (int j = 0; j < L.H2; ++j) acc = fmaf(W[j * L.A + lane], sh.g[0][j], acc);
-      mean = acc + PT[L.ba + lane];
+#pragma unroll
+      for (int j = 0; j < MAX_H; ++j)
+        if (j < L.H2) acc = fmaf(R.wh[j], sh.g[0][j], acc);
+      mean = acc + R.bh;
     }
     if (!L.discrete) {
-      float lp = 0.f;
+      float lp = 0.f, entl = 0.f;
       if (lane < L.A) {
-        const float std = expf(PT[L.log_std + lane]);
+        const float std = expf(R.ls);
         float act = mean;
         if (given != nullptr) act = given[lane];
         else if (!deterministic) act = mean + noise_row[lane] * std;   // Normal.rsample: loc + eps * scale
         const float diff = act - mean;
         // Normal.log_prob: -((x - mu)^2) / (2 var) - log(std) - log(sqrt(2 pi))
         lp = -(diff * diff) / (2.f * (std * std)) - logf(std) - LOG_SQRT_2PI_F;
+        entl = HALF_LOG_2PI_PLUS_HALF_F + logf(std);
         sh.act_raw[lane] = act;
         float c = act;
         if (alow != nullptr && ahigh != nullptr) c = fminf(fmaxf(act, alow[lane]), ahigh[lane]);
@@ -107,7 +151,7 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const f
       }
       lp = wave_sum(lp);
       // entropy of the diagonal Gaussian: sum_a 0.5 + 0.5 log(2 pi) + log sigma_a
-      const float ent = wave_sum(lane < L.A ? HALF_LOG_2PI_PLUS_HALF_F + logf(expf(PT[L.log_std + lane])) : 0.f);
+      const float ent = wave_sum(entl);
       if (lane == 0) { sh.scal[2] = lp; sh.scal[3] = ent; }
     } else {
       // Categorical(logits): log-softmax, inverse-CDF sample on the injected uniform (spec: oracle/nets.py forward)
@@ -116,7 +160,6 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const f
       float lse = m + logf(wave_sum(e));
       float logp = mean - lse;
       float p = lane < L.A ? expf(logp) : 0.f;
-      // inclusive prefix sum over the first A lanes (A <= 16: sequential in lane 0 order, matches th.cumsum)
       float cdf = 0.f;
       int action = 0;
       if (given != nullptr) {
@@ -128,7 +171,7 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const f
       } else {
         const float u = noise_row[0];
         int cnt = 0;
-        for (int a = 0; a < L.A; ++a) {
+        for (int a = 0; a < L.A; ++a) {     // sequential inclusive prefix sum, like th.cumsum
           cdf += __shfl(p, a, 64);
           cnt += (u >= cdf) ? 1 : 0;
         }
@@ -138,11 +181,10 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const f
       const float ent = -wave_sum(lane < L.A ? logp * p : 0.f);
       if (lane == 0) { sh.scal[2] = lp; sh.scal[3] = ent; sh.act_raw[0] = (float)action; sh.act_clip[0] = (float)action; }
     }
-  } else {
-    const int off = (w == 1) ? L.Wv : L.Wc;
-    float part = lane < L.H2 ? PT[off + lane] * sh.g[w][lane] : 0.f;
+  } else if (w < 3) {
+    float part = lane < L.H2 ? R.wh[0] * sh.g[w][lane] : 0.f;
     part = wave_sum(part);
-    if (lane == 0) sh.scal[w - 1] = part + PT[(w == 1) ? L.bv : L.bc];
+    if (lane == 0) sh.scal[w - 1] = part + R.bh;
   }
 }
 
@@ -273,8 +315,11 @@ struct ActStepArgs {
   int has_cn;
 };
 
+template <int OCT>
 __global__ void __launch_bounds__(192) act_step_kernel(ActStepArgs a, int t) {
   __shared__ ActShared sh;
+  PolRegs<OCT> R;
+  load_pol_regs<OCT>(a.pl, a.PT, R);   // every weight load of the step is in flight before anything waits
   const int n = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -288,7 +333,7 @@ __global__ void __launch_bounds__(192) act_step_kernel(ActStepArgs a, int t) {
   __syncthreads();
   const size_t tn = (size_t)t * N + n;
   const float* noise_row = a.noise + tn * (a.pl.discrete ? 1 : A);
-  policy_forward_block(a.pl, a.PT, sh, noise_row, 0, a.alow, a.ahigh);
+  policy_forward_block<OCT>(a.pl, R, sh, noise_row, 0, a.alow, a.ahigh);
   __syncthreads();
   if (w == 0) {
     double rew; int done;
@@ -512,6 +557,110 @@ __global__ void __launch_bounds__(1024) norm_step_kernel(NormStepArgs a) {
   }
 }
 
+// ---- small-problem variant (N <= 128, N*O <= NORM_CHUNK: e.g. HCWithPos with 64 envs): every input is pulled into LDS /
+// registers with ONE round of global loads, the three statistics are computed concurrently by different waves
+// (observation columns: threads < O; reward return: wave 15; cost return: wave 14 — for N <= 128 numpy's pairwise sum is a
+// single 8-accumulator leaf, which 8 lanes reproduce exactly), one barrier, then everything is normalised from LDS.
+__device__ __forceinline__ double np_leaf_sum_wave(const double* a, int n) {
+  // numpy pairwise sum of n <= 128 contiguous doubles, evaluated by one wave; result valid in every lane
+  const int lane = threadIdx.x & 63;
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += a[i];
+    return r;
+  }
+  double r = 0.0;
+  if (lane < 8) {
+    r = a[lane];
+    for (int i = 8; i < n - (n % 8); i += 8) r += a[i + lane];
+  }
+  const double r0 = __shfl(r, 0, 64), r1 = __shfl(r, 1, 64), r2 = __shfl(r, 2, 64), r3 = __shfl(r, 3, 64);
+  const double r4 = __shfl(r, 4, 64), r5 = __shfl(r, 5, 64), r6 = __shfl(r, 6, 64), r7 = __shfl(r, 7, 64);
+  double res = ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7));
+  for (int i = n - (n % 8); i < n; ++i) res += a[i];
+  return res;
+}
+
+__global__ void __launch_bounds__(1024) norm_step_small_kernel(NormStepArgs a) {
+  __shared__ double chunk[NORM_CHUNK];
+  __shared__ double vec[2][128], dev2[2][128];
+  __shared__ double mean_s[MAX_OBS], var_s[MAX_OBS];
+  __shared__ double dens[2];
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wv = tid >> 6;
+  const int N = a.N, O = a.O;
+  const icrl_norm_t& nm = a.nm;
+  const bool has_cost = a.raw_cost != nullptr;
+  // ---- one round of loads
+  for (int i = tid; i < N * O; i += nt) chunk[i] = a.raw_obs[i];
+  if (tid < N) {
+    double r = nm.ret[tid], c = has_cost ? nm.cost_ret[tid] : 0.0;
+    if (nm.training) {
+      r = r * nm.reward_gamma + a.raw_rew[tid];
+      if (has_cost) c = c * nm.cost_gamma + (double)a.raw_cost[tid];
+    }
+    vec[0][tid] = r; vec[1][tid] = c;
+  }
+  double o_mean = 0.0, o_var = 1.0, o_cnt = 0.0;
+  if (tid < O) { o_mean = nm.obs_mean[tid]; o_var = nm.obs_var[tid]; o_cnt = nm.obs_count[0]; }
+  __syncthreads();
+  if (nm.training) {
+    if (tid < O) {           // obs_rms.update: rows added in order (numpy's axis-0 reduction)
+      double sum = 0.0;
+      for (int r = 0; r < N; ++r) sum += chunk[r * O + tid];
+      const double bm = sum / (double)N;
+      double sq = 0.0;
+      for (int r = 0; r < N; ++r) { const double d = chunk[r * O + tid] - bm; sq += d * d; }
+      chan_merge(o_mean, o_var, o_cnt, bm, sq / (double)N, (double)N);
+      nm.obs_mean[tid] = o_mean; nm.obs_var[tid] = o_var;
+      if (tid == 0) nm.obs_count[0] = (double)N + o_cnt;
+    }
+    if (wv == 15 || (wv == 14 && has_cost)) {     // ret_rms / cost_rms: numpy pairwise order
+      const int v = wv == 15 ? 0 : 1;
+      double* st = v == 0 ? nm.ret_stats : nm.cost_stats;
+      const double bm = np_leaf_sum_wave(vec[v], N) / (double)N;
+      for (int i = lane; i < N; i += 64) { const double d = vec[v][i] - bm; dev2[v][i] = d * d; }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      const double bv = np_leaf_sum_wave(dev2[v], N) / (double)N;
+      double m = st[0], var = st[1];
+      const double cnt = st[2];
+      chan_merge(m, var, cnt, bm, bv, (double)N);
+      if (lane == 0) { st[0] = m; st[1] = var; st[2] = (double)N + cnt; }
+      if (lane == 0) dens[v] = sqrt(var + nm.epsilon);
+    }
+  } else {
+    if (tid == 0) { dens[0] = sqrt(nm.ret_stats[1] + nm.epsilon); dens[1] = sqrt(nm.cost_stats[1] + nm.epsilon); }
+  }
+  if (nm.training && !has_cost && tid == 0) dens[1] = sqrt(nm.cost_stats[1] + nm.epsilon);
+  if (tid < O) { mean_s[tid] = o_mean; var_s[tid] = o_var; }
+  __syncthreads();
+  // ---- normalise + clip from LDS
+  for (int idx = tid; idx < N * O; idx += nt) {
+    const int j = idx % O;
+    double o = chunk[idx];
+    if (nm.norm_obs) o = fmin(fmax((o - mean_s[j]) / sqrt(var_s[j] + nm.epsilon), -nm.clip_obs), nm.clip_obs);
+    if (a.obs_out) a.obs_out[idx] = o;
+    if (a.obs_f32) a.obs_f32[idx] = (float)o;
+  }
+  if (tid < N) {
+    const int n = tid;
+    double r = a.raw_rew[n];
+    if (nm.norm_reward) r = fmin(fmax(r / dens[0], -nm.clip_reward), nm.clip_reward);
+    if (a.rew_out) a.rew_out[n] = r;
+    if (a.rew_f32) a.rew_f32[n] = (float)r;
+    const int d = a.dones[n];
+    if (nm.training || d) nm.ret[n] = d ? 0.0 : vec[0][n];
+    if (has_cost) {
+      double c = (double)a.raw_cost[n];
+      if (nm.norm_cost) c = fmin(fmax(c / dens[1], -nm.clip_cost), nm.clip_cost);
+      if (a.cost_out) a.cost_out[n] = c;
+      if (a.cost_f32) a.cost_f32[n] = (float)c;
+      if (nm.training || d) nm.cost_ret[n] = d ? 0.0 : vec[1][n];
+    }
+    if (a.last_dones) a.last_dones[n] = (uint8_t)d;
+  }
+}
+
 // VecNormalizeWithCost.reset (vec_normalize.py:148-157, 270-278)
 __global__ void __launch_bounds__(1024) norm_reset_kernel(icrl_norm_t nm, const double* raw_obs, int N, int O,
                                                           double* obs_out) {
@@ -538,19 +687,22 @@ __global__ void __launch_bounds__(1024) norm_reset_kernel(icrl_norm_t nm, const 
 // =================================================================================================================
 // fine-grained kernels behind the per-call C ABI
 // =================================================================================================================
+template <int OCT>
 __global__ void __launch_bounds__(192) policy_forward_kernel(PolLayout pl, const float* PT, const double* obs,
                                                              const float* noise, int deterministic, const float* alow,
                                                              const float* ahigh, float* actions, float* act_clipped,
                                                              float* v_r, float* v_c, float* log_prob,
-                                                             const float* given = nullptr, float* entropy = nullptr) {
+                                                             const float* given, float* entropy) {
   __shared__ ActShared sh;
+  PolRegs<OCT> R;
+  load_pol_regs<OCT>(pl, PT, R);
   const int n = blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < pl.O; i += 192) sh.x[i] = (float)obs[(size_t)n * pl.O + i];
   __syncthreads();
   const float* noise_row = noise ? noise + (size_t)n * (pl.discrete ? 1 : pl.A) : nullptr;
   const int AS = pl.discrete ? 1 : pl.A;
-  policy_forward_block(pl, PT, sh, noise_row, deterministic || noise == nullptr, alow, ahigh,
-                       given ? given + (size_t)n * AS : nullptr);
+  policy_forward_block<OCT>(pl, R, sh, noise_row, deterministic || noise == nullptr, alow, ahigh,
+                            given ? given + (size_t)n * AS : nullptr);
   __syncthreads();
   if (tid < AS) {
     if (actions) actions[(size_t)n * AS + tid] = sh.act_raw[tid];
@@ -616,20 +768,17 @@ struct SampleArgs {
   int* ep_lengths;         // [n_streams*episodes_per_stream]
 };
 
+template <int OCT>
 __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float dyn[];
   __shared__ ActShared sh;
+  PolRegs<OCT> R;
+  load_pol_regs<OCT>(a.pl, a.PT, R);    // once for every step of every episode of this stream
   __shared__ int s_done;
   __shared__ double s_rew;
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int O = a.pl.O, A = a.pl.A;
   const int AS = a.pl.discrete ? 1 : A;
-  const float* PT = a.PT;
-  if (a.pt_in_lds) {
-    for (int i = tid; i < a.pl.n; i += 192) dyn[i] = a.PT[i];
-    PT = dyn;
-  }
   if (a.do_reset) {
     for (int i = tid; i < O; i += 192)
       a.env.s[(size_t)n * O + i] = (unit_uniform(a.env.key[n], a.env.step_count[n], (uint32_t)(O + i)) - 0.5) * 0.2;
@@ -650,7 +799,7 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
       }
       __syncthreads();
       const float* noise_row = a.noise ? a.noise + row * AS : nullptr;
-      policy_forward_block(a.pl, PT, sh, noise_row, a.deterministic || a.noise == nullptr, a.alow, a.ahigh);
+      policy_forward_block<OCT>(a.pl, R, sh, noise_row, a.deterministic || a.noise == nullptr, a.alow, a.ahigh);
       __syncthreads();
       if (w == 0) {
         double rew; int done;
@@ -710,8 +859,14 @@ extern "C" int icrl_policy_forward(const icrl_policy_t* p, const double* obs, co
                                    float* v_r, float* v_c, float* log_prob, void* stream) {
   if (N <= 0 || !dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return (int)hipErrorInvalidValue;
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
-  hipLaunchKernelGGL(policy_forward_kernel, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, noise,
-                     deterministic, action_low, action_high, actions, act_clipped, v_r, v_c, log_prob);
+  if (L.O <= 32)
+    hipLaunchKernelGGL(policy_forward_kernel<2>, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, noise,
+                       deterministic, action_low, action_high, actions, act_clipped, v_r, v_c, log_prob,
+                       (const float*)nullptr, (float*)nullptr);
+  else
+    hipLaunchKernelGGL(policy_forward_kernel<8>, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, noise,
+                       deterministic, action_low, action_high, actions, act_clipped, v_r, v_c, log_prob,
+                       (const float*)nullptr, (float*)nullptr);
   return (int)hipGetLastError();
 }
 
@@ -719,9 +874,14 @@ extern "C" int icrl_policy_evaluate(const icrl_policy_t* p, const double* obs, c
                                     float* v_c, float* log_prob, float* entropy, void* stream) {
   if (N <= 0 || !dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return (int)hipErrorInvalidValue;
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
-  hipLaunchKernelGGL(policy_forward_kernel, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs,
-                     (const float*)nullptr, 1, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
-                     v_r, v_c, log_prob, actions, entropy);
+  if (L.O <= 32)
+    hipLaunchKernelGGL(policy_forward_kernel<2>, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs,
+                       (const float*)nullptr, 1, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       v_r, v_c, log_prob, actions, entropy);
+  else
+    hipLaunchKernelGGL(policy_forward_kernel<8>, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs,
+                       (const float*)nullptr, 1, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,
+                       v_r, v_c, log_prob, actions, entropy);
   return (int)hipGetLastError();
 }
 
@@ -736,12 +896,9 @@ extern "C" int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm
   a.PT = pol->params_t; a.noise = noise; a.alow = action_low; a.ahigh = action_high;
   a.episodes_per_stream = episodes_per_stream; a.rows_per_stream = rows_per_stream; a.deterministic = deterministic;
   a.do_reset = do_reset; a.orig_obs = orig_obs; a.obs = obs; a.actions = actions; a.ep_rewards = ep_rewards; a.ep_lengths = ep_lengths;
-  size_t lds = (size_t)a.pl.n * sizeof(float);
-  a.pt_in_lds = lds <= 150 * 1024;
-  if (!a.pt_in_lds) lds = 0;
-  hipError_t e = hipFuncSetAttribute((const void*)sample_episodes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(150 * 1024));
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(sample_episodes_kernel, dim3(env->n_envs), dim3(192), lds, (hipStream_t)stream, a);
+  a.pt_in_lds = 0;
+  if (a.pl.O <= 32) hipLaunchKernelGGL(sample_episodes_kernel<2>, dim3(env->n_envs), dim3(192), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(sample_episodes_kernel<8>, dim3(env->n_envs), dim3(192), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -766,6 +923,11 @@ extern "C" int icrl_synth_env_step(const icrl_env_t* env, const float* actions, 
   return (int)hipGetLastError();
 }
 
+static void launch_norm_step(const NormStepArgs& a, hipStream_t s) {
+  if (a.N <= 128 && a.N * a.O <= NORM_CHUNK) hipLaunchKernelGGL(norm_step_small_kernel, dim3(1), dim3(1024), 0, s, a);
+  else hipLaunchKernelGGL(norm_step_kernel, dim3(1), dim3(1024), 0, s, a);
+}
+
 extern "C" int icrl_vecnorm_reset(const icrl_norm_t* nm, const double* raw_obs, int N, int obs_dim, double* obs_out, void* stream) {
   if (N <= 0 || N > NORM_MAX_N || obs_dim > MAX_OBS) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(norm_reset_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *nm, raw_obs, N, obs_dim, obs_out);
@@ -777,7 +939,7 @@ extern "C" int icrl_vecnorm_step(const icrl_norm_t* nm, const double* raw_obs, c
                                  void* stream) {
   if (N <= 0 || N > NORM_MAX_N || obs_dim > MAX_OBS) return (int)hipErrorInvalidValue;
   NormStepArgs a{*nm, raw_obs, raw_rew, raw_cost, dones, N, obs_dim, obs_out, rew_out, cost_out, nullptr, nullptr, nullptr, nullptr};
-  hipLaunchKernelGGL(norm_step_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a);
+  launch_norm_step(a, (hipStream_t)stream);
   return (int)hipGetLastError();
 }
 
@@ -799,11 +961,12 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
   a.has_cn = cn != nullptr;
   if (cn) { a.cn = *cn; a.cl = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2); }
   for (int t = 0; t < T; ++t) {
-    hipLaunchKernelGGL(act_step_kernel, dim3(N), dim3(192), 0, s, a, t);
+    if (a.pl.O <= 32) hipLaunchKernelGGL(act_step_kernel<2>, dim3(N), dim3(192), 0, s, a, t);
+    else hipLaunchKernelGGL(act_step_kernel<8>, dim3(N), dim3(192), 0, s, a, t);
     const size_t row = (size_t)t * N;
     NormStepArgs b{*nm, env->s, ag->raw_rew, cn ? ag->raw_cost : nullptr, ag->dones, N, O, ag->last_obs, nullptr, nullptr,
                    buf->new_observations + row * O, buf->rewards + row, buf->costs + row, ag->last_dones};
-    hipLaunchKernelGGL(norm_step_kernel, dim3(1), dim3(1024), 0, s, b);
+    launch_norm_step(b, s);
   }
   int err = (int)hipGetLastError();
   if (err || !do_gae) return err;
