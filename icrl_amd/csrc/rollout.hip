@@ -49,11 +49,14 @@ __global__ void costnet_transpose_kernel(CnLayout L, const float* __restrict__ p
 // =================================================================================================================
 // device building blocks (called by a 192-thread workgroup handling ONE environment)
 // =================================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct ActShared {
-  double s_old[MAX_OBS];   // raw observation before the step (== VecCostWrapper.previous_obs)
-  float x[MAX_OBS];        // normalised observation, float32 (policy input)
-  float h[3][MAX_H];
-  float g[3][MAX_H];
+  alignas(16) double s_old[MAX_OBS];   // raw observation before the step (== VecCostWrapper.previous_obs)
+  alignas(16) double s_new[MAX_OBS];   // raw observation after the step (post auto-reset)
+  alignas(16) float x[MAX_OBS];        // normalised observation, float32 (policy input)
+  alignas(16) float h[3][MAX_H];
+  alignas(16) float g[3][MAX_H];
   float cx[MAX_CN_IN];     // cost-net input
   float ch[2][MAX_H];
   float act_raw[MAX_ACT];
@@ -108,29 +111,37 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const P
                                                      const float* given = nullptr /* evaluate_actions: actions to score */) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (w < 3 && lane < L.H1) {
+  // activations are pulled from LDS as whole float4 rows first (broadcast reads), then consumed from registers: one LDS
+  // latency per layer instead of one per input.  Pad weights are zero, so no bounds test is needed in the FMA chains.
+  if (w < 3) {
+    f32x4 xs[4 * OCT];
+#pragma unroll
+    for (int i = 0; i < 4 * OCT; ++i) xs[i] = *reinterpret_cast<const f32x4*>(&sh.x[4 * i]);
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16 * OCT; ++k)
-      if (k < L.O) acc = fmaf(R.w1[k], sh.x[k], acc);
-    sh.h[w][lane] = fast_tanh(acc + R.b1);
+    for (int k = 0; k < 16 * OCT; ++k) acc = fmaf(R.w1[k], xs[k >> 2][k & 3], acc);
+    sh.h[w][lane] = lane < L.H1 ? fast_tanh(acc + R.b1) : 0.f;   // pad lanes store 0 (0 * garbage would poison the next layer)
   }
   __syncthreads();
-  if (w < 3 && lane < L.H2) {
+  if (w < 3) {
+    f32x4 hs[MAX_H / 4];
+#pragma unroll
+    for (int i = 0; i < MAX_H / 4; ++i) hs[i] = *reinterpret_cast<const f32x4*>(&sh.h[w][4 * i]);
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAX_H; ++k)
-      if (k < L.H1) acc = fmaf(R.w2[k], sh.h[w][k], acc);
-    sh.g[w][lane] = fast_tanh(acc + R.b2);
+    for (int k = 0; k < MAX_H; ++k) acc = fmaf(R.w2[k], hs[k >> 2][k & 3], acc);
+    sh.g[w][lane] = lane < L.H2 ? fast_tanh(acc + R.b2) : 0.f;
   }
   __syncthreads();
   if (w == 0) {
     float mean = 0.f;
-    if (lane < L.A) {
+    {
+      f32x4 gs[MAX_H / 4];
+#pragma unroll
+      for (int i = 0; i < MAX_H / 4; ++i) gs[i] = *reinterpret_cast<const f32x4*>(&sh.g[0][4 * i]);
       float acc = 0.f;
 #pragma unroll
-      for (int j = 0; j < MAX_H; ++j)
-        if (j < L.H2) acc = fmaf(R.wh[j], sh.g[0][j], acc);
+      for (int j = 0; j < MAX_H; ++j) acc = fmaf(R.wh[j], gs[j >> 2][j & 3], acc);
       mean = acc + R.bh;
     }
     if (!L.discrete) {
@@ -241,6 +252,7 @@ __device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, con
 // synthetic env step for env n; called by ONE wave.  act: float32 clipped actions (LDS or global).
 // Returns reward / done in every lane; writes env.s, t_ep, step_count.  s_old: float64 previous state (LDS copy).
 __device__ __forceinline__ void env_step_wave(const icrl_env_t& e, int n, const double* s_old, const float* act,
+                                              uint32_t key, uint32_t& ctr_io, int& tep_io, double* s_new_lds,
                                               double& reward, int& done) {
   const int lane = threadIdx.x & 63;
   const int O = e.obs_dim, A = e.act_dim;
@@ -255,8 +267,7 @@ __device__ __forceinline__ void env_step_wave(const icrl_env_t& e, int n, const 
       sq = sq + a[j] * a[j];
     }
   }
-  const uint32_t key = e.key[n];
-  const uint32_t ctr = e.step_count[n];
+  const uint32_t ctr = ctr_io;
   double ns[2];  // this lane's components i = lane, lane + 64
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -279,7 +290,7 @@ __device__ __forceinline__ void env_step_wave(const icrl_env_t& e, int n, const 
   else rew = (sqrt(n0 * n0 + n1 * n1) + 1.0) - 0.5 * sq;
   int d = 0;
   if (e.wall_terminate && n0 <= -3.0) { rew = 0.0; d = 1; }
-  const int tep = e.t_ep[n] + 1;
+  const int tep = tep_io + 1;
   if (tep >= e.max_steps) d = 1;
 #pragma unroll
   for (int r = 0; r < 2; ++r) {
@@ -288,11 +299,14 @@ __device__ __forceinline__ void env_step_wave(const icrl_env_t& e, int n, const 
       double v = ns[r];
       if (d) v = (unit_uniform(key, ctr + 1u, (uint32_t)(O + i)) - 0.5) * 0.2;   // auto-reset draw
       e.s[(size_t)n * O + i] = v;
+      if (s_new_lds != nullptr) s_new_lds[i] = v;
     }
   }
+  tep_io = d ? 0 : tep;
+  ctr_io = ctr + 1u;
   if (lane == 0) {
-    e.t_ep[n] = d ? 0 : tep;
-    e.step_count[n] = ctr + 1u;
+    e.t_ep[n] = tep_io;
+    e.step_count[n] = ctr_io;
   }
   reward = rew;
   done = d;
@@ -321,14 +335,17 @@ __global__ void __launch_bounds__(192) act_step_kernel(ActStepArgs a, int t) {
   PolRegs<OCT> R;
   load_pol_regs<OCT>(a.pl, a.PT, R);   // every weight load of the step is in flight before anything waits
   const int n = blockIdx.x;
+  const uint32_t e_key = a.env.key[n];
+  uint32_t e_ctr = a.env.step_count[n];
+  int e_tep = a.env.t_ep[n];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs;
   const int AS = a.buf.act_store;
-  for (int i = tid; i < O; i += 192) {
-    sh.x[i] = (float)a.ag.last_obs[(size_t)n * O + i];     // preprocess_obs: .float()
-    sh.s_old[i] = a.env.s[(size_t)n * O + i];
+  for (int i = tid; i < MAX_OBS; i += 192) {
+    sh.x[i] = i < O ? (float)a.ag.last_obs[(size_t)n * O + i] : 0.f;     // preprocess_obs: .float(); pad = 0
+    if (i < O) sh.s_old[i] = a.env.s[(size_t)n * O + i];
   }
   __syncthreads();
   const size_t tn = (size_t)t * N + n;
@@ -337,9 +354,9 @@ __global__ void __launch_bounds__(192) act_step_kernel(ActStepArgs a, int t) {
   __syncthreads();
   if (w == 0) {
     double rew; int done;
-    env_step_wave(a.env, n, sh.s_old, sh.act_clip, rew, done);
+    env_step_wave(a.env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
     float* nob = a.buf.new_orig_observations + tn * O;
-    for (int i = lane; i < O; i += WAVE) nob[i] = (float)a.env.s[(size_t)n * O + i];
+    for (int i = lane; i < O; i += WAVE) nob[i] = (float)sh.s_new[i];
     if (lane == 0) { a.ag.raw_rew[n] = rew; a.ag.dones[n] = (uint8_t)done; }
   } else if (w == 1) {
     float cost = 0.f;
@@ -697,7 +714,7 @@ __global__ void __launch_bounds__(192) policy_forward_kernel(PolLayout pl, const
   PolRegs<OCT> R;
   load_pol_regs<OCT>(pl, PT, R);
   const int n = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < pl.O; i += 192) sh.x[i] = (float)obs[(size_t)n * pl.O + i];
+  for (int i = tid; i < MAX_OBS; i += 192) sh.x[i] = i < pl.O ? (float)obs[(size_t)n * pl.O + i] : 0.f;
   __syncthreads();
   const float* noise_row = noise ? noise + (size_t)n * (pl.discrete ? 1 : pl.A) : nullptr;
   const int AS = pl.discrete ? 1 : pl.A;
@@ -732,7 +749,9 @@ __global__ void __launch_bounds__(64) env_step_kernel(icrl_env_t e, const float*
   for (int i = threadIdx.x; i < e.obs_dim; i += WAVE) s_old[i] = e.s[(size_t)n * e.obs_dim + i];
   __syncthreads();
   double rew; int done;
-  env_step_wave(e, n, s_old, actions + (size_t)n * e.act_dim, rew, done);
+  uint32_t ctr = e.step_count[n];
+  int tep = e.t_ep[n];
+  env_step_wave(e, n, s_old, actions + (size_t)n * e.act_dim, e.key[n], ctr, tep, nullptr, rew, done);
   if (threadIdx.x == 0) { raw_rew[n] = rew; dones[n] = (uint8_t)done; }
 }
 
@@ -779,23 +798,31 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int O = a.pl.O, A = a.pl.A;
   const int AS = a.pl.discrete ? 1 : A;
-  if (a.do_reset) {
-    for (int i = tid; i < O; i += 192)
-      a.env.s[(size_t)n * O + i] = (unit_uniform(a.env.key[n], a.env.step_count[n], (uint32_t)(O + i)) - 0.5) * 0.2;
-    if (tid == 0) a.env.t_ep[n] = 0;
+  const uint32_t e_key = a.env.key[n];
+  uint32_t e_ctr = a.env.step_count[n];
+  int e_tep = a.env.t_ep[n];
+  // frozen normaliser statistics of this thread's observation components (i = tid, O <= 128 < 192)
+  double n_mean = 0.0, n_den = 1.0;
+  if (tid < O && a.nm.norm_obs) { n_mean = a.nm.obs_mean[tid]; n_den = sqrt(a.nm.obs_var[tid] + a.nm.epsilon); }
+  for (int i = tid; i < MAX_OBS; i += 192) sh.x[i] = 0.f;
+  if (tid < O) {
+    double v = a.env.s[(size_t)n * O + tid];
+    if (a.do_reset) v = (unit_uniform(e_key, e_ctr, (uint32_t)(O + tid)) - 0.5) * 0.2;
+    sh.s_new[tid] = v;
   }
+  if (a.do_reset) e_tep = 0;
   __syncthreads();
   size_t row = (size_t)n * a.rows_per_stream;
   for (int ep = 0; ep < a.episodes_per_stream; ++ep) {
     double ep_rew = 0.0;
     int ep_len = 0;
     while (true) {
-      for (int i = tid; i < O; i += 192) {
-        const double raw = a.env.s[(size_t)n * O + i];
+      if (tid < O) {
+        const double raw = sh.s_new[tid];
         double o = raw;
-        if (a.nm.norm_obs) o = fmin(fmax((raw - a.nm.obs_mean[i]) / sqrt(a.nm.obs_var[i] + a.nm.epsilon), -a.nm.clip_obs), a.nm.clip_obs);
-        sh.s_old[i] = raw;
-        sh.x[i] = (float)o;
+        if (a.nm.norm_obs) o = fmin(fmax((raw - n_mean) / n_den, -a.nm.clip_obs), a.nm.clip_obs);
+        sh.s_old[tid] = raw;
+        sh.x[tid] = (float)o;
       }
       __syncthreads();
       const float* noise_row = a.noise ? a.noise + row * AS : nullptr;
@@ -803,17 +830,17 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
       __syncthreads();
       if (w == 0) {
         double rew; int done;
-        env_step_wave(a.env, n, sh.s_old, sh.act_clip, rew, done);
+        env_step_wave(a.env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
         if (lane == 0) { s_done = done; s_rew = rew; }
         if (lane < AS) a.actions[row * AS + lane] = sh.act_clip[lane];
       }
       __syncthreads();
-      for (int i = tid; i < O; i += 192) {
-        const double raw = a.env.s[(size_t)n * O + i];
+      if (tid < O) {
+        const double raw = sh.s_new[tid];
         double o = raw;
-        if (a.nm.norm_obs) o = fmin(fmax((raw - a.nm.obs_mean[i]) / sqrt(a.nm.obs_var[i] + a.nm.epsilon), -a.nm.clip_obs), a.nm.clip_obs);
-        a.orig_obs[row * O + i] = raw;
-        a.obs[row * O + i] = o;
+        if (a.nm.norm_obs) o = fmin(fmax((raw - n_mean) / n_den, -a.nm.clip_obs), a.nm.clip_obs);
+        a.orig_obs[row * O + tid] = raw;
+        a.obs[row * O + tid] = o;
       }
       ep_rew += s_rew;     // episode_reward += reward (un-normalised: norm_reward is False on sampling / eval envs)
       ++ep_len;
