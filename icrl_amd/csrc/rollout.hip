@@ -57,8 +57,8 @@ struct ActShared {
   alignas(16) float x[MAX_OBS];        // normalised observation, float32 (policy input)
   alignas(16) float h[3][MAX_H];
   alignas(16) float g[3][MAX_H];
-  float cx[MAX_CN_IN];     // cost-net input
-  float ch[2][MAX_H];
+  alignas(16) float cx[MAX_CN_IN];     // cost-net input
+  alignas(16) float ch[2][MAX_H];
   float act_raw[MAX_ACT];
   float act_clip[MAX_ACT];
   float scal[4];           // v_r, v_c, log_prob, (unused)
@@ -199,52 +199,88 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const P
   }
 }
 
-// cost = 1 - sigmoid(ReLU-MLP(prepare(obs, acs))); called by ONE wave. obs_row: float64 raw obs (LDS or global),
-// acs_row: float32 actions.  Returns the cost in every lane.
-__device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, const CnLayout& L, const double* obs_row,
-                                                   const float* acs_row, float* cx, float (*ch)[MAX_H]) {
+// cost-net weights of one lane (lane j <-> hidden unit j), loaded with independent loads before they are needed
+template <int CIT>
+struct CnRegs {
+  float w0[16 * CIT];
+  float w1[MAX_H];
+  float wo, b0, b1, bo;
+  int sel[(16 * CIT + WAVE - 1) / WAVE];   // select_dim entries this lane prepares
+};
+
+template <int CIT>
+__device__ __forceinline__ void load_cn_regs(const icrl_costnet_t& cn, const CnLayout& L, CnRegs<CIT>& R) {
   const int lane = threadIdx.x & 63;
-  for (int i = lane; i < L.in; i += WAVE) {
-    const int sel = cn.select_dim[i];
-    float v;
-    if (sel < cn.obs_dim) {
-      double o = obs_row[sel];
-      if (cn.obs_mean != nullptr && cn.obs_var != nullptr) o = (o - cn.obs_mean[sel]) / sqrt(cn.obs_var[sel] + cn.eps);
-      if (cn.clip_obs >= 0.0) o = fmin(fmax(o, -cn.clip_obs), cn.clip_obs);
-      v = (float)o;
-    } else {
-      const int a = sel - cn.obs_dim;
-      float x;
-      if (cn.is_discrete) x = ((int)acs_row[0] == a) ? 1.f : 0.f;
-      else x = acs_row[a];
-      if (cn.action_low != nullptr && cn.action_high != nullptr) x = fminf(fmaxf(x, cn.action_low[a]), cn.action_high[a]);
-      v = x;
+  const float* PT = cn.params_t;
+  const int j1 = lane < L.H1 ? lane : 0, j2 = lane < L.H2 ? lane : 0;
+#pragma unroll
+  for (int k = 0; k < 16 * CIT; ++k) R.w0[k] = k < L.in ? PT[L.W0 + k * L.H1 + j1] : 0.f;
+#pragma unroll
+  for (int k = 0; k < MAX_H; ++k) R.w1[k] = (L.nh == 2 && k < L.H1) ? PT[L.W1 + k * L.H2 + j2] : 0.f;
+  R.b0 = PT[L.b0 + j1];
+  R.b1 = L.nh == 2 ? PT[L.b1 + j2] : 0.f;
+  R.wo = PT[L.Wo + j2];
+  R.bo = PT[L.bo];
+#pragma unroll
+  for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) { const int idx = lane + i * WAVE; R.sel[i] = idx < L.in ? cn.select_dim[idx] : -1; }
+}
+
+// cost = 1 - sigmoid(ReLU-MLP(prepare(obs, acs))); called by ONE wave. obs_row: float64 raw obs (LDS or global),
+// acs_row: float32 actions.  cx: >= 16*CIT floats (16-byte aligned), ch: [2][MAX_H].  Returns the cost in every lane.
+template <int CIT>
+__device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, const CnLayout& L, const CnRegs<CIT>& R,
+                                                   const double* obs_row, const float* acs_row, float* cx, float (*ch)[MAX_H]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) {
+    const int idx = lane + i * WAVE;
+    const int sel = R.sel[i];
+    float v = 0.f;
+    if (sel >= 0) {
+      if (sel < cn.obs_dim) {
+        double o = obs_row[sel];
+        if (cn.obs_mean != nullptr && cn.obs_var != nullptr) o = (o - cn.obs_mean[sel]) / sqrt(cn.obs_var[sel] + cn.eps);
+        if (cn.clip_obs >= 0.0) o = fmin(fmax(o, -cn.clip_obs), cn.clip_obs);
+        v = (float)o;
+      } else {
+        const int a = sel - cn.obs_dim;
+        float x;
+        if (cn.is_discrete) x = ((int)acs_row[0] == a) ? 1.f : 0.f;
+        else x = acs_row[a];
+        if (cn.action_low != nullptr && cn.action_high != nullptr) x = fminf(fmaxf(x, cn.action_low[a]), cn.action_high[a]);
+        v = x;
+      }
     }
-    cx[i] = v;
+    if (idx < 16 * CIT) cx[idx] = v;       // pad entries are written as 0
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): LDS writes of this wave visible to its own reads
-  const float* PT = cn.params_t;
-  if (lane < L.H1) {
+  {
+    f32x4 xs[4 * CIT];
+#pragma unroll
+    for (int i = 0; i < 4 * CIT; ++i) xs[i] = *reinterpret_cast<const f32x4*>(&cx[4 * i]);
     float acc = 0.f;
-    for (int k = 0; k < L.in; ++k) acc = fmaf(PT[L.W0 + k * L.H1 + lane], cx[k], acc);
-    ch[0][lane] = fmaxf(acc + PT[L.b0 + lane], 0.f);
+#pragma unroll
+    for (int k = 0; k < 16 * CIT; ++k) acc = fmaf(R.w0[k], xs[k >> 2][k & 3], acc);
+    ch[0][lane] = lane < L.H1 ? fmaxf(acc + R.b0, 0.f) : 0.f;
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);
   int last = 0;
   if (L.nh == 2) {
-    if (lane < L.H2) {
-      float acc = 0.f;
-      for (int k = 0; k < L.H1; ++k) acc = fmaf(PT[L.W1 + k * L.H2 + lane], ch[0][k], acc);
-      ch[1][lane] = fmaxf(acc + PT[L.b1 + lane], 0.f);
-    }
+    f32x4 hs[MAX_H / 4];
+#pragma unroll
+    for (int i = 0; i < MAX_H / 4; ++i) hs[i] = *reinterpret_cast<const f32x4*>(&ch[0][4 * i]);
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAX_H; ++k) acc = fmaf(R.w1[k], hs[k >> 2][k & 3], acc);
+    ch[1][lane] = lane < L.H2 ? fmaxf(acc + R.b1, 0.f) : 0.f;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     last = 1;
   }
-  float part = lane < L.H2 ? PT[L.Wo + lane] * ch[last][lane] : 0.f;
-  const float z = wave_sum(part) + PT[L.bo];
+  float part = lane < L.H2 ? R.wo * ch[last][lane] : 0.f;
+  const float z = wave_sum(part) + R.bo;
   const float zeta = 1.f / (1.f + expf(-z));
   return 1.f - zeta;
 }
@@ -329,11 +365,13 @@ struct ActStepArgs {
   int has_cn;
 };
 
-template <int OCT>
-__global__ void __launch_bounds__(192) act_step_kernel(ActStepArgs a, int t) {
+template <int OCT, int CIT>
+__global__ void __launch_bounds__(256) act_step_kernel(ActStepArgs a, int t) {
   __shared__ ActShared sh;
   PolRegs<OCT> R;
+  CnRegs<CIT> C;
   load_pol_regs<OCT>(a.pl, a.PT, R);   // every weight load of the step is in flight before anything waits
+  if (threadIdx.x >= 192 && a.has_cn) load_cn_regs<CIT>(a.cn, a.cl, C);   // wave 3 = cost net
   const int n = blockIdx.x;
   const uint32_t e_key = a.env.key[n];
   uint32_t e_ctr = a.env.step_count[n];
@@ -343,7 +381,7 @@ __global__ void __launch_bounds__(192) act_step_kernel(ActStepArgs a, int t) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs;
   const int AS = a.buf.act_store;
-  for (int i = tid; i < MAX_OBS; i += 192) {
+  for (int i = tid; i < MAX_OBS; i += 256) {
     sh.x[i] = i < O ? (float)a.ag.last_obs[(size_t)n * O + i] : 0.f;     // preprocess_obs: .float(); pad = 0
     if (i < O) sh.s_old[i] = a.env.s[(size_t)n * O + i];
   }
@@ -358,11 +396,11 @@ __global__ void __launch_bounds__(192) act_step_kernel(ActStepArgs a, int t) {
     float* nob = a.buf.new_orig_observations + tn * O;
     for (int i = lane; i < O; i += WAVE) nob[i] = (float)sh.s_new[i];
     if (lane == 0) { a.ag.raw_rew[n] = rew; a.ag.dones[n] = (uint8_t)done; }
-  } else if (w == 1) {
+  } else if (w == 3) {
     float cost = 0.f;
-    if (a.has_cn) cost = cost_forward_wave(a.cn, a.cl, sh.s_old, sh.act_clip, sh.cx, sh.ch);
+    if (a.has_cn) cost = cost_forward_wave<CIT>(a.cn, a.cl, C, sh.s_old, sh.act_clip, sh.cx, sh.ch);
     if (lane == 0) { a.ag.raw_cost[n] = cost; a.buf.orig_costs[tn] = cost; }
-  } else {
+  } else if (w == 2) {
     float* ob = a.buf.observations + tn * O;
     float* oob = a.buf.orig_observations + tn * O;
     for (int i = lane; i < O; i += WAVE) { ob[i] = sh.x[i]; oob[i] = (float)sh.s_old[i]; }
@@ -733,13 +771,16 @@ __global__ void __launch_bounds__(192) policy_forward_kernel(PolLayout pl, const
   }
 }
 
+template <int CIT>
 __global__ void __launch_bounds__(64) cost_forward_kernel(icrl_costnet_t cn, CnLayout cl, const double* obs,
                                                           const float* acs, int N, float* cost) {
-  __shared__ float cx[MAX_CN_IN];
-  __shared__ float ch[2][MAX_H];
+  __shared__ __attribute__((aligned(16))) float cx[MAX_CN_IN];
+  __shared__ __attribute__((aligned(16))) float ch[2][MAX_H];
+  CnRegs<CIT> C;
+  load_cn_regs<CIT>(cn, cl, C);
   const int n = blockIdx.x;
   const int AS = cn.is_discrete ? 1 : cn.acs_dim;
-  const float c = cost_forward_wave(cn, cl, obs + (size_t)n * cn.obs_dim, acs + (size_t)n * AS, cx, ch);
+  const float c = cost_forward_wave<CIT>(cn, cl, C, obs + (size_t)n * cn.obs_dim, acs + (size_t)n * AS, cx, ch);
   if (threadIdx.x == 0) cost[n] = c;
 }
 
@@ -933,7 +974,8 @@ extern "C" int icrl_cost_mlp_forward(const icrl_costnet_t* cn, const double* obs
                                      void* stream) {
   if (N <= 0 || !cn_ok(cn)) return (int)hipErrorInvalidValue;
   CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
-  hipLaunchKernelGGL(cost_forward_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost);
+  if (cn->in_dim <= 32) hipLaunchKernelGGL(cost_forward_kernel<2>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost);
+  else hipLaunchKernelGGL(cost_forward_kernel<10>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost);
   return (int)hipGetLastError();
 }
 
@@ -988,8 +1030,8 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
   a.has_cn = cn != nullptr;
   if (cn) { a.cn = *cn; a.cl = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2); }
   for (int t = 0; t < T; ++t) {
-    if (a.pl.O <= 32) hipLaunchKernelGGL(act_step_kernel<2>, dim3(N), dim3(192), 0, s, a, t);
-    else hipLaunchKernelGGL(act_step_kernel<8>, dim3(N), dim3(192), 0, s, a, t);
+    if (a.pl.O <= 32 && (!cn || cn->in_dim <= 32)) hipLaunchKernelGGL((act_step_kernel<2, 2>), dim3(N), dim3(256), 0, s, a, t);
+    else hipLaunchKernelGGL((act_step_kernel<8, 10>), dim3(N), dim3(256), 0, s, a, t);
     const size_t row = (size_t)t * N;
     NormStepArgs b{*nm, env->s, ag->raw_rew, cn ? ag->raw_cost : nullptr, ag->dones, N, O, ag->last_obs, nullptr, nullptr,
                    buf->new_observations + row * O, buf->rewards + row, buf->costs + row, ag->last_dones};
