@@ -8,21 +8,22 @@
 // small independent MLPs (pi, vf, cvf: obs -> 64 -> 64 -> {act | 1 | 1}).  Parity forbids re-ordering or merging those
 // steps, so the step latency is what matters.  Mapping:
 //
-//   * grid = 3 workgroups x 256 threads (4 waves, one per SIMD): workgroup r owns network r.  The only quantity coupling
-//     the networks inside a step is the global gradient norm (clip_grad_norm_ over ALL policy parameters): each workgroup
-//     publishes its partial sum of squares as an 8-byte {step tag, value} granule (agent-scope relaxed store) and polls the
-//     other two (guide: cdna_hip_programming.md §6 Guideline 16, form R2 — the datum is the flag).  Granule slots are
-//     double-buffered by step parity; a workgroup can never be more than one step ahead of the others.  While the granules
-//     are in flight the workgroup already stages the NEXT minibatch (LDS commit + advantage statistics).
+//   * grid = 3 workgroups x 512 threads: workgroup r owns network r.  The only quantity coupling the networks inside a
+//     step is the global gradient norm (clip_grad_norm_ over ALL policy parameters): each workgroup publishes its partial
+//     sum of squares as an 8-byte {step tag, value} granule (agent-scope relaxed store) and polls the other two (guide:
+//     cdna_hip_programming.md §6 Guideline 16, form R2 — the datum is the flag).  Granule slots are double-buffered by step
+//     parity; a workgroup can never be more than one step ahead of the others.  While the granules are in flight the
+//     workgroup already stages the NEXT minibatch (LDS commit + advantage statistics).
+//   * 8 waves = 2 per SIMD: wave (rt, hf) owns row tile rt (16 of the chunk's 64 rows) and column half hf of every 64-wide
+//     GEMM output, so while one wave of a SIMD runs its VALU epilogue / LDS traffic the other one feeds the matrix core.
 //   * the network's weights stay in LDS for the whole launch (fp32 master copy); Adam moments and the accumulating weight
 //     gradients stay in REGISTERS in MFMA C-layout: the lane that receives dW[j][k] from the matrix core owns m, v and the
 //     update of W[j][k].  Inside the loop only the gathered minibatch rows (prefetched one chunk ahead into registers,
 //     their permutation indices two chunks ahead) and the 3 granules touch global memory.
-//   * all eight GEMMs of a step (3 forward, 5 backward) run on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  Wave w owns
-//     the 16-row tile w of every 64-row operand, so forward activations never cross waves.  K is enumerated as
-//     k = 16*js + 4*(lane/16) + e: an operand whose K runs along the LDS row is fetched with ONE ds_read_b128 per four
-//     MFMA steps, conflict-free at row strides = 8 mod 16 floats; operands whose K runs across rows use ds_read_b32.
-//     Every GEMM first stages its operands in registers, then issues its MFMAs back to back.
+//   * all eight GEMMs of a step (3 forward, 5 backward) run on v_mfma_f32_16x16x4_f32 (exact fp32 FMA chains).  K is
+//     enumerated as k = 16*js + 4*(lane/16) + e: an operand whose K runs along the LDS row is fetched with ONE ds_read_b128
+//     per four MFMA steps, conflict-free at row strides = 8 mod 16 floats; operands whose K runs across rows use
+//     ds_read_b32.  Every GEMM first stages its operands in registers, then issues its MFMAs back to back.
 //   * minibatches larger than 64 rows are processed in 64-row chunks that accumulate into the same gradient registers.
 //
 // Built with -ffp-contract=off; FMA is used only where written (fmaf / MFMA).
@@ -34,7 +35,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned long long u64;
 #define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-constexpr int TH = 256;  // threads per workgroup
+constexpr int TH = 512;  // threads per workgroup (8 waves, 2 per SIMD)
 constexpr int RB = 64;   // minibatch rows per chunk
 constexpr int HD = 64;   // hidden width (both layers)
 constexpr int SH = 72;   // LDS row stride of 64-wide matrices (= 8 mod 16: conflict-free ds_read_b128 operand fetch)
@@ -55,14 +56,14 @@ struct Smem {  // offsets in floats (all multiples of 4: 16-byte aligned rows)
   static constexpr int H1 = X + RB * SX;
   static constexpr int H2 = H1 + RB * SH;     // h2, later dz1
   static constexpr int DZ = H2 + RB * SH;     // dz2; before the backward its rows hold the chunk's actions / scalars
-  static constexpr int DO = DZ + RB * SH;     // head output, overwritten in place by d loss / d output
-  static constexpr int RED1 = DO + RB * SO;   // [4][64] per-wave column sums of dz1
-  static constexpr int RED2 = RED1 + 4 * HD;  // [4][64] per-wave column sums of dz2
-  static constexpr int PBH = RED2 + 4 * HD;   // [4][16] per-wave column sums of dOut
-  static constexpr int PLS = PBH + 64;        // [4][16] per-wave d log_std partials
-  static constexpr int PST = PLS + 64;        // [4][8] per-wave loss statistics
-  static constexpr int MISC = PST + 32;       // [32] block-reduction scratch + broadcast scalars
-  static constexpr int GAU = MISC + 32;       // [3][16] per-action 1/var, 0.5/var, log(sd) + log(sqrt(2 pi))
+  static constexpr int DO = DZ + RB * SH;     // head output, overwritten (after a barrier) by d loss / d output
+  static constexpr int RED1 = DO + RB * SO;   // [4][64] per-row-tile column sums of dz1
+  static constexpr int RED2 = RED1 + 4 * HD;  // [4][64] per-row-tile column sums of dz2
+  static constexpr int PBH = RED2 + 4 * HD;   // [4][16] per-row-tile column sums of dOut
+  static constexpr int PLS = PBH + 64;        // [4][16] per-row-tile d log_std partials
+  static constexpr int PST = PLS + 64;        // [4][8] per-row-tile loss statistics
+  static constexpr int MISC = PST + 32;       // [48] block-reduction scratch + broadcast scalars
+  static constexpr int GAU = MISC + 48;       // [3][16] per-action 1/var, 0.5/var, log(sd) + log(sqrt(2 pi))
   static constexpr int TOTAL = GAU + 48;
   // per-row side data of the chunk lives in the (not yet used) dz rows: columns 0..15 actions, 16 old log-prob | old value,
   // 17 raw reward advantage | return, 18 raw cost advantage
@@ -81,16 +82,8 @@ struct TrainArgs {
   icrl_ppo_hyper_t hp;
   float* stats;
   u64* xch;
+  unsigned t_magic;   // floor(2^32 / T): fast division of a flat index by T
 };
-
-__device__ __forceinline__ float block_sum(float v, float* scratch /* >= 8 floats */) {
-  v = wave_sum(v);
-  const int w = threadIdx.x >> 6;
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) scratch[w] = v;
-  __syncthreads();
-  return (scratch[0] + scratch[1]) + (scratch[2] + scratch[3]);
-}
 
 // sum over the 16 lanes sharing lane/16
 __device__ __forceinline__ float sum16(float v) {
@@ -120,27 +113,30 @@ __device__ __forceinline__ unsigned long long stamp() {
     __builtin_amdgcn_sched_barrier(0);                                     \
     const unsigned long long now_ = stamp();                               \
     __builtin_amdgcn_sched_barrier(0);                                     \
-    if (tid == 0) ph[slot] += (double)(now_ - t_last);                     \
+    ph[slot] += now_ - t_last;                                             \
     t_last = now_;                                                         \
   }
 
 __device__ __forceinline__ f32x4 lds128(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
-// position in the stream of 64-row chunks: (epoch, minibatch, chunk)
-struct ChunkPos {
-  int epoch, mb, ch;
+// cursor into the stream of minibatch rows: epoch, position inside the epoch, position inside the minibatch
+struct Cursor {
+  int e, p, m;
 };
 
 template <int NT1>
-__global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
+__global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
   using S = Smem<NT1>;
   constexpr int SX = S::SX;
-  constexpr int XR = (SX + 3) / 4;  // floats of an X row each of the 4 threads of a row stages
+  constexpr int NT1H = NT1 / 2;     // W1 / dW1 column tiles per wave
+  constexpr int XR = (SX + 7) / 8;  // floats of an X row each of the 8 threads of a row stages
+  static_assert(NT1 >= 2, "obs tiles are split between the two column halves");
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int role = blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int rt = w & 3, hf = w >> 2;
   const int r = lane & 15, q = lane >> 4;
   const PolLayout& L = a.L;
   const int O = L.O, A = L.A;
@@ -164,28 +160,31 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   if (tid < HD) { sm[S::B1 + tid] = a.params[gb1 + tid]; sm[S::B2 + tid] = a.params[gb2 + tid]; }
   if (tid < 16) { sm[S::BH + tid] = tid < n_out ? a.params[gbh + tid] : 0.f; sm[S::LS + tid] = (role == 0 && tid < A) ? a.params[L.log_std + tid] : 0.f; }
 
-  f32x4 mW1[NT1], vW1[NT1], gW1r[NT1], mW2[4], vW2[4], gW2r[4], mWh, vWh, gWhr;
+  // wave (rt, hf) owns: W1 rows 16rt.. x column tiles hf*NT1H..; W2 rows 16rt.. x column tiles 2hf, 2hf+1;
+  // (hf == 0 only) head-weight columns 16rt..16rt+15
+  f32x4 mW1[NT1H], vW1[NT1H], gW1r[NT1H], mW2[2], vW2[2], gW2r[2], mWh, vWh, gWhr;
 #pragma unroll
-  for (int c = 0; c < NT1; ++c)
+  for (int c = 0; c < NT1H; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      const int j = 16 * rt + 4 * q + i, k = 16 * (hf * NT1H + c) + r;
       mW1[c][i] = k < O ? a.exp_avg[gW1 + j * O + k] : 0.f;
       vW1[c][i] = k < O ? a.exp_avg_sq[gW1 + j * O + k] : 0.f;
     }
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      const int j = 16 * rt + 4 * q + i, k = 16 * (2 * hf + c) + r;
       mW2[c][i] = a.exp_avg[gW2 + j * HD + k];
       vW2[c][i] = a.exp_avg_sq[gW2 + j * HD + k];
     }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int o = 4 * q + i, j = 16 * w + r;
-    mWh[i] = o < n_out ? a.exp_avg[gWh + o * HD + j] : 0.f;
-    vWh[i] = o < n_out ? a.exp_avg_sq[gWh + o * HD + j] : 0.f;
+    const int o = 4 * q + i, j = 16 * rt + r;
+    const bool own = hf == 0 && o < n_out;
+    mWh[i] = own ? a.exp_avg[gWh + o * HD + j] : 0.f;
+    vWh[i] = own ? a.exp_avg_sq[gWh + o * HD + j] : 0.f;
   }
   // thread-owned vector parameters: tid 0..63 b1, 64..127 b2, 128..143 head bias, 144..159 log_std (policy only)
   int vec_g = -1, vec_s = 0;
@@ -205,37 +204,46 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
 
   // ---------------------------------------------------------------------------------------------------------------
-  // chunk stream helpers
+  // row stream helpers
   // ---------------------------------------------------------------------------------------------------------------
-  auto mb_rows = [&](int mb) { const int left = n_total - mb * B; return left < B ? left : B; };
-  auto advance = [&](ChunkPos p) {  // next chunk in the stream (epoch may run past n_epochs: the loaders check)
-    const int nch = (mb_rows(p.mb) + RB - 1) / RB;
-    if (p.ch + 1 < nch) { ++p.ch; return p; }
-    p.ch = 0;
-    if (p.mb + 1 < n_mb) { ++p.mb; return p; }
-    p.mb = 0; ++p.epoch;
-    return p;
+  auto cur_rows = [&](const Cursor& c) {   // rows of the 64-row chunk that starts at c
+    int left = B - c.m;
+    if (n_total - c.p < left) left = n_total - c.p;
+    return left < RB ? left : RB;
   };
-  auto chunk_rows = [&](const ChunkPos& p) { const int left = mb_rows(p.mb) - p.ch * RB; return left < RB ? left : RB; };
-  // this thread's row of the chunk: b = tid/4 (part = tid%4 splits the row's floats)
-  const int gb_row = tid >> 2, gpart = tid & 3;
-  auto load_idx = [&](const ChunkPos& p) -> int {
-    if (p.epoch >= n_epochs || gb_row >= chunk_rows(p)) return -1;
-    return a.perms[(size_t)p.epoch * n_total + p.mb * B + p.ch * RB + gb_row];
+  auto cur_advance = [&](Cursor c) {
+    const int rows = cur_rows(c);
+    c.p += rows; c.m += rows;
+    if (c.p >= n_total) { c.p = 0; c.m = 0; ++c.e; }
+    else if (c.m >= B) c.m = 0;
+    return c;
+  };
+  // flat env-major index -> [T,N] storage offset (ref: buffers.py:53-65): env = idx / T, t = idx % T
+  auto to_off = [&](int idx) -> unsigned {
+    unsigned env = __umulhi((unsigned)idx, a.t_magic);
+    int t = idx - (int)env * T;
+    if (t >= T) { t -= T; ++env; }
+    if (t >= T) { t -= T; ++env; }
+    return (unsigned)t * (unsigned)N + env;
+  };
+  // this thread's row of a chunk: b = tid/8 (part = tid%8 splits the row's floats)
+  const int gb_row = tid >> 3, gpart = tid & 7;
+  auto load_idx = [&](const Cursor& c) -> int {
+    if (c.e >= n_epochs || gb_row >= cur_rows(c)) return -1;
+    return a.perms[(size_t)c.e * n_total + c.p + gb_row];
   };
   // row data of one chunk held in registers between "issue" and "commit"
-  float px[XR], pact[4], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
+  float px[XR], pact[2], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
   auto issue_rows = [&](int idx) {
-    size_t off = 0;
     const bool valid = idx >= 0;
-    if (valid) { const int env = idx / T, t = idx - env * T; off = (size_t)t * N + env; }
+    const size_t off = valid ? (size_t)to_off(idx) : 0;
     const float* orow = a.buf.observations + off * O;
 #pragma unroll
-    for (int i = 0; i < XR; ++i) { const int k = gpart + 4 * i; px[i] = (valid && k < O) ? orow[k] : 0.f; }
+    for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; px[i] = (valid && k < O) ? orow[k] : 0.f; }
     if (role == 0) {
       const float* arow = a.buf.actions + off * a.buf.act_store;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { const int k = gpart + 4 * i; pact[i] = (valid && k < A) ? arow[k] : 0.f; }
+      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; pact[i] = (valid && k < A) ? arow[k] : 0.f; }
       if (gpart == 0) {
         psc0 = valid ? a.buf.log_probs[off] : 0.f;
         psc1 = valid ? a.buf.reward_advantages[off] : 0.f;
@@ -250,10 +258,10 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   };
   auto commit_rows = [&]() {
 #pragma unroll
-    for (int i = 0; i < XR; ++i) { const int k = gpart + 4 * i; if (k < SX) sm[S::X + gb_row * SX + k] = px[i]; }
+    for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; if (k < SX) sm[S::X + gb_row * SX + k] = px[i]; }
     if (role == 0) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sm[S::ACT + gb_row * SH + gpart + 4 * i] = pact[i];
+      for (int i = 0; i < 2; ++i) sm[S::ACT + gb_row * SH + gpart + 8 * i] = pact[i];
       if (gpart == 0) { sm[S::OLP + gb_row * SH] = psc0; sm[S::ADR + gb_row * SH] = psc1; sm[S::ADC + gb_row * SH] = psc2; }
     } else if (gpart == 0) {
       sm[S::OLP + gb_row * SH] = psc0; sm[S::ADR + gb_row * SH] = psc1;
@@ -261,15 +269,15 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   };
   // advantage statistics of a minibatch (policy role): thread tid < nb holds row tid's (A_r, A_c)
   float sar = 0.f, sac = 0.f;
-  auto stat_idx = [&](int epoch, int mb) -> int {
-    if (role != 0 || epoch >= n_epochs || tid >= mb_rows(mb)) return -1;
-    return a.perms[(size_t)epoch * n_total + mb * B + tid];
+  auto mb_rows_at = [&](int p) { const int left = n_total - p; return left < B ? left : B; };
+  auto stat_idx = [&](int e, int p) -> int {   // minibatch starting at position p of epoch e
+    if (role != 0 || e >= n_epochs || tid >= mb_rows_at(p)) return -1;
+    return a.perms[(size_t)e * n_total + p + tid];
   };
   auto issue_stats = [&](int idx) {
     sar = 0.f; sac = 0.f;
     if (idx >= 0) {
-      const int env = idx / T, t = idx - env * T;
-      const size_t off = (size_t)t * N + env;
+      const unsigned off = to_off(idx);
       sar = a.buf.reward_advantages[off];
       sac = a.buf.cost_advantages[off];
     }
@@ -280,11 +288,12 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
     const bool in = tid < nb;
     float s_r = wave_sum(in ? sar : 0.f), s_c = wave_sum(in ? sac : 0.f), s_rr = wave_sum(in ? sar * sar : 0.f);
     __syncthreads();
-    if (lane == 0) { sm[S::MISC + 16 + w] = s_r; sm[S::MISC + 20 + w] = s_c; sm[S::MISC + 24 + w] = s_rr; }
+    if (lane == 0) { sm[S::MISC + 16 + w] = s_r; sm[S::MISC + 24 + w] = s_c; sm[S::MISC + 32 + w] = s_rr; }
     __syncthreads();
-    s_r = (sm[S::MISC + 16] + sm[S::MISC + 17]) + (sm[S::MISC + 18] + sm[S::MISC + 19]);
-    s_c = (sm[S::MISC + 20] + sm[S::MISC + 21]) + (sm[S::MISC + 22] + sm[S::MISC + 23]);
-    s_rr = (sm[S::MISC + 24] + sm[S::MISC + 25]) + (sm[S::MISC + 26] + sm[S::MISC + 27]);
+    // minibatches have <= 128 rows: only waves 0 and 1 carry data
+    s_r = sm[S::MISC + 16] + sm[S::MISC + 17];
+    s_c = sm[S::MISC + 24] + sm[S::MISC + 25];
+    s_rr = sm[S::MISC + 32] + sm[S::MISC + 33];
     mean_r = s_r / (float)nb;
     mean_c = s_c / (float)nb;
     // unbiased variance from the raw moments (advantages are O(1): fp32 cancellation stays ~1e-6 relative)
@@ -307,21 +316,24 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   if (tid == 0) { sm[S::MISC + 12] = 0.f; sm[S::MISC + 13] = 0.f; }
 
   // ---- pipeline prologue: chunk 0 rows -> LDS, chunk 1 / 2 indices in flight; minibatch 0 statistics
-  ChunkPos pos_next = advance(ChunkPos{0, 0, 0});
-  ChunkPos pos_nx2 = advance(pos_next);
-  int idx_next = load_idx(pos_next);
-  int idx_nx2 = load_idx(pos_nx2);
-  issue_rows(load_idx(ChunkPos{0, 0, 0}));
+  Cursor c_nx2 = cur_advance(Cursor{0, 0, 0});
+  int idx_next = load_idx(c_nx2);
+  c_nx2 = cur_advance(c_nx2);
+  int idx_nx2 = load_idx(c_nx2);
+  issue_rows(load_idx(Cursor{0, 0, 0}));
   issue_stats(stat_idx(0, 0));
   refresh_gauss();
-  int sidx_next = (n_mb > 1) ? stat_idx(0, 1) : stat_idx(1, 0);
+  // (epoch, position) of the minibatch whose statistics indices are in flight: the one after the current
+  int s_e = 0, s_p = mb_rows_at(0);
+  if (s_p >= n_total) { s_p = 0; s_e = 1; }
+  int sidx_next = stat_idx(s_e, s_p);
   __syncthreads();
   commit_rows();
-  compute_stats(mb_rows(0));
+  compute_stats(mb_rows_at(0));
   __syncthreads();
 
   const bool prof = a.hp._pad != 0;
-  double ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = prof ? stamp() : 0ull;
 
   unsigned step = 0;
@@ -330,22 +342,22 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
     float kl_sum = 0.f;  // thread 0, policy role
     for (int mb = 0; mb < n_mb && !stop; ++mb) {
       ++step;
-      const int nb = mb_rows(mb);
+      const int nb = mb_rows_at(mb * B);
       const float c_mean_r = mean_r, c_mean_c = mean_c;   // statistics of THIS minibatch
       const float c_istd_r = 1.f / (std_r + 1e-8f);
       const float cpol_nb = 1.f / ((1.f + nu) * (float)nb);
       // statistics prefetch: advantages of the NEXT minibatch's rows (indices loaded a step ago), indices of the one after
       issue_stats(sidx_next);
       {
-        int e2 = epoch, m2 = mb + 2;
-        while (m2 >= n_mb) { m2 -= n_mb; ++e2; }
-        sidx_next = stat_idx(e2, m2);
+        s_p += mb_rows_at(s_p);
+        if (s_p >= n_total) { s_p = 0; ++s_e; }
+        sidx_next = stat_idx(s_e, s_p);
       }
       // ---- zero gradient accumulators
 #pragma unroll
-      for (int c = 0; c < NT1; ++c) gW1r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < NT1H; ++c) gW1r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) gW2r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < 2; ++c) gW2r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
       gB = 0.f;
       float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f;  // thread 0: minibatch sums of the loss statistics
@@ -357,77 +369,80 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
           commit_rows();
           __syncthreads();
         }
-        // prefetch: rows of the next chunk of the stream, indices of the one after the next
-        issue_rows(idx_next);
-        idx_next = idx_nx2;
-        pos_nx2 = advance(pos_nx2);
-        idx_nx2 = load_idx(pos_nx2);
-
-        // ================= forward: wave w owns rows 16w..16w+15 =================
-        f32x4 h1t[4], h2t[4];   // this wave's h1 / h2 tiles stay in registers for the backward epilogues
+        // ================= forward: wave (rt, hf): rows 16rt.., output columns 32hf..32hf+31 =================
+        f32x4 h1t[2], h2t[2];   // this wave's h1 / h2 tiles stay in registers for the backward epilogues
         {
-          f32x4 av[NT1], bv[4][NT1];
-          const float* pa = sm + S::X + (16 * w + r) * SX + 4 * q;
-          const float* pb = sm + S::W1 + r * SX + 4 * q;
+          f32x4 av[NT1], bv[2][NT1];
+          const float* pa = sm + S::X + (16 * rt + r) * SX + 4 * q;
+          const float* pb = sm + S::W1 + (32 * hf + r) * SX + 4 * q;
 #pragma unroll
           for (int js = 0; js < NT1; ++js) {
             av[js] = lds128(pa + 16 * js);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) bv[c][js] = lds128(pb + c * 16 * SX + 16 * js);
+            for (int c = 0; c < 2; ++c) bv[c][js] = lds128(pb + c * 16 * SX + 16 * js);
           }
           __builtin_amdgcn_sched_barrier(0);   // all operand reads are issued before the first MFMA
-          f32x4 acc[4];
+          f32x4 acc[2];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int c = 0; c < 2; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int js = 0; js < NT1; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av[js][e], bv[c][js][e], acc[c]);
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA_F32(av[js][e], bv[c][js][e], acc[c]);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float bias = sm[S::B1 + 16 * c + r];
+          for (int c = 0; c < 2; ++c) {
+            const int col = 32 * hf + 16 * c + r;
+            const float bias = sm[S::B1 + col];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               h1t[c][i] = fast_tanh(acc[c][i] + bias);
-              sm[S::H1 + (16 * w + 4 * q + i) * SH + 16 * c + r] = h1t[c][i];
+              sm[S::H1 + (16 * rt + 4 * q + i) * SH + col] = h1t[c][i];
             }
           }
         }
+        // prefetch (under the first GEMM's shadow): rows of the next chunk of the stream, indices of the one after the next
+        issue_rows(idx_next);
+        idx_next = idx_nx2;
+        c_nx2 = cur_advance(c_nx2);
+        idx_nx2 = load_idx(c_nx2);
+        __syncthreads();  // (A1) both column halves of h1 written
         {
-          f32x4 av[4], bv[4][4];
-          const float* pa = sm + S::H1 + (16 * w + r) * SH + 4 * q;
-          const float* pb = sm + S::W2 + r * SH + 4 * q;
+          f32x4 av[4], bv[2][4];
+          const float* pa = sm + S::H1 + (16 * rt + r) * SH + 4 * q;
+          const float* pb = sm + S::W2 + (32 * hf + r) * SH + 4 * q;
 #pragma unroll
           for (int js = 0; js < 4; ++js) {
             av[js] = lds128(pa + 16 * js);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) bv[c][js] = lds128(pb + c * 16 * SH + 16 * js);
+            for (int c = 0; c < 2; ++c) bv[c][js] = lds128(pb + c * 16 * SH + 16 * js);
           }
           __builtin_amdgcn_sched_barrier(0);
-          f32x4 acc[4];
+          f32x4 acc[2];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int c = 0; c < 2; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int js = 0; js < 4; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av[js][e], bv[c][js][e], acc[c]);
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA_F32(av[js][e], bv[c][js][e], acc[c]);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const float bias = sm[S::B2 + 16 * c + r];
+          for (int c = 0; c < 2; ++c) {
+            const int col = 32 * hf + 16 * c + r;
+            const float bias = sm[S::B2 + col];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               h2t[c][i] = fast_tanh(acc[c][i] + bias);
-              sm[S::H2 + (16 * w + 4 * q + i) * SH + 16 * c + r] = h2t[c][i];
+              sm[S::H2 + (16 * rt + 4 * q + i) * SH + col] = h2t[c][i];
             }
           }
         }
-        {
+        __syncthreads();  // (A2) h2 complete
+        if (hf == 0) {    // head: [16 rows] x [16 outputs], K = 64
           f32x4 av[4], bv[4];
-          const float* pa = sm + S::H2 + (16 * w + r) * SH + 4 * q;
+          const float* pa = sm + S::H2 + (16 * rt + r) * SH + 4 * q;
           const float* pb = sm + S::WH + r * SH + 4 * q;
 #pragma unroll
           for (int js = 0; js < 4; ++js) { av[js] = lds128(pa + 16 * js); bv[js] = lds128(pb + 16 * js); }
@@ -442,12 +457,13 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
           const float bias = sm[S::BH + r];
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            sm[S::DO + (16 * w + 4 * q + i) * SO + r] = ((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i])) + bias;
+            sm[S::DO + (16 * rt + 4 * q + i) * SO + r] = ((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i])) + bias;
         }
+        __syncthreads();  // (A3) head outputs visible to both waves of a row tile
         STAMP(0)   // forward
-        // ================= loss + d loss / d head output: the wave's 16 rows, replicated over lane/16 =================
+        // ============ loss + d loss / d head output: row 16rt + r; lane group q and half hf split the actions ============
         {
-          const int b = 16 * w + r;
+          const int b = 16 * rt + r;
           const bool valid = b < nrows;
           float* dor = sm + S::DO + b * SO;     // holds the head output of row b; overwritten with its gradient
           if (role == 0) {
@@ -455,12 +471,12 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
             float lp = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int k = q + 4 * i;                      // this lane's actions of row b
+              const int k = q + 4 * i;                      // every wave of the pair evaluates the whole row
               dd[i] = sm[S::ACT + b * SH + k] - dor[k];     // pad actions / outputs are 0
               iv[i] = sm[S::GAU + k];
               lp += -(dd[i] * dd[i]) * sm[S::GAU + 16 + k] - sm[S::GAU + 32 + k];
             }
-            lp += __shfl_xor(lp, 16, 64);                   // sum over the 4 lane groups -> log-prob of row b in every replica
+            lp += __shfl_xor(lp, 16, 64);                   // sum over the 4 lane groups -> log-prob of row b
             lp += __shfl_xor(lp, 32, 64);
             const float old_lp = sm[S::OLP + b * SH];
             const float ratio = __expf(lp - old_lp);
@@ -471,22 +487,27 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
             const float s2 = Ar * rc;
             const float gsel = (s1 <= s2) ? Ar : 0.f;                       // d min(s1, s2) / d ratio
             const float dlp = valid ? cpol_nb * (-gsel + nu * Ac) * ratio : 0.f;  // d loss / d log_prob
-            // (same wave: LDS operations execute in program order, so every lane has read the row before it is overwritten)
+            __syncthreads();   // (L) both waves of the pair have read the head outputs before they are overwritten
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int ii = 0; ii < 2; ++ii) {
+              const int i = 2 * hf + ii;                    // this wave writes / reduces the actions k = q + 4i of its half
               const int k = q + 4 * i;
-              const float dk = dlp * (dd[i] * iv[i]);
-              const float lk = (k < A) ? dlp * ((dd[i] * dd[i]) * iv[i] - 1.f) : 0.f;
+              const float ddi = hf == 0 ? dd[ii] : dd[2 + ii];
+              const float ivi = hf == 0 ? iv[ii] : iv[2 + ii];
+              const float dk = dlp * (ddi * ivi);
+              const float lk = (k < A) ? dlp * ((ddi * ddi) * ivi - 1.f) : 0.f;
               dor[k] = dk;
               const float colsum = sum16(dk);
               const float lssum = sum16(lk);
-              if (r == 0) { sm[S::PBH + w * 16 + k] = colsum; sm[S::PLS + w * 16 + k] = lssum; }
+              if (r == 0) { sm[S::PBH + rt * 16 + k] = colsum; sm[S::PLS + rt * 16 + k] = lssum; }
             }
-            const float v0 = sum16(valid ? fminf(s1, s2) : 0.f);
-            const float v1 = sum16(valid ? Ac * ratio : 0.f);
-            const float v2 = sum16(valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f);
-            const float v3 = sum16(valid ? old_lp - lp : 0.f);
-            if (lane == 0) { sm[S::PST + w * 8 + 0] = v0; sm[S::PST + w * 8 + 1] = v1; sm[S::PST + w * 8 + 2] = v2; sm[S::PST + w * 8 + 3] = v3; }
+            if (hf == 0) {
+              const float v0 = sum16(valid ? fminf(s1, s2) : 0.f);
+              const float v1 = sum16(valid ? Ac * ratio : 0.f);
+              const float v2 = sum16(valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f);
+              const float v3 = sum16(valid ? old_lp - lp : 0.f);
+              if (lane == 0) { sm[S::PST + rt * 8 + 0] = v0; sm[S::PST + rt * 8 + 1] = v1; sm[S::PST + rt * 8 + 2] = v2; sm[S::PST + rt * 8 + 3] = v3; }
+            }
           } else {
             const float v = dor[0];
             const float R = sm[S::ADR + b * SH];
@@ -499,58 +520,64 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
             }
             const float e = vp - R;
             const float d0 = valid ? vcoef * 2.f * e / (float)nb * pass : 0.f;
-            if (q == 0) {
-              dor[0] = d0;
+            __syncthreads();   // (L)
+            if (hf == 0) {
+              if (q == 0) {
+                dor[0] = d0;
 #pragma unroll
-              for (int k = 1; k < 16; ++k) dor[k] = 0.f;
-            }
-            const float colsum = sum16(d0);
-            const float se = sum16(valid ? e * e : 0.f);
-            if (lane == 0) {
-              sm[S::PBH + w * 16] = colsum;
+                for (int k = 1; k < 16; ++k) dor[k] = 0.f;
+              }
+              const float colsum = sum16(d0);
+              const float se = sum16(valid ? e * e : 0.f);
+              if (lane == 0) {
+                sm[S::PBH + rt * 16] = colsum;
 #pragma unroll
-              for (int k = 1; k < 16; ++k) sm[S::PBH + w * 16 + k] = 0.f;
-              sm[S::PST + w * 8 + 0] = se;
+                for (int k = 1; k < 16; ++k) sm[S::PBH + rt * 16 + k] = 0.f;
+                sm[S::PST + rt * 8 + 0] = se;
+              }
             }
           }
         }
+        __syncthreads();  // (A4) d loss / d output of the row tile complete (written by both halves)
         STAMP(1)   // loss
         // ================= backward =================
-        {  // dH2 = dOut . Wh  -> dz2 = dH2 * (1 - h2^2) (own rows), column sums for d b2
-          const f32x4 av = lds128(sm + S::DO + (16 * w + r) * SO + 4 * q);   // k = a = 4q + e
-          float bv[4][4];
-          const float* pb = sm + S::WH + (4 * q) * SH + r;
+        {  // dH2 = dOut . Wh  -> dz2 = dH2 * (1 - h2^2) (own rows, own column half), column sums for d b2
+          const f32x4 av = lds128(sm + S::DO + (16 * rt + r) * SO + 4 * q);   // k = a = 4q + e
+          float bv[2][4];
+          const float* pb = sm + S::WH + (4 * q) * SH + 32 * hf + r;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) bv[c][e] = pb[e * SH + 16 * c];
-          f32x4 acc[4];
+            for (int c = 0; c < 2; ++c) bv[c][e] = pb[e * SH + 16 * c];
+          f32x4 acc[2];
 #pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int c = 0; c < 2; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av[e], bv[c][e], acc[c]);
+            for (int c = 0; c < 2; ++c) acc[c] = MFMA_F32(av[e], bv[c][e], acc[c]);
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
+          for (int c = 0; c < 2; ++c) {
+            const int col = 32 * hf + 16 * c + r;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               acc[c][i] = acc[c][i] * (1.f - h2t[c][i] * h2t[c][i]);
-              sm[S::DZ + (16 * w + 4 * q + i) * SH + 16 * c + r] = acc[c][i];
+              sm[S::DZ + (16 * rt + 4 * q + i) * SH + col] = acc[c][i];
             }
             const float cs = tile_colsum(acc[c]);
-            if (q == 0) sm[S::RED2 + w * HD + 16 * c + r] = cs;
+            if (q == 0) sm[S::RED2 + rt * HD + col] = cs;
           }
         }
         __syncthreads();  // (2) dz2, dOut, h2 of ALL rows visible
-        {  // dWh[o][j] += sum_b dOut[b][o] h2[b][j]   (wave w: columns 16w..16w+15); b = 16 js + 4 q + e
+        if (hf == 0) {  // dWh[o][j] += sum_b dOut[b][o] h2[b][j]   (columns 16rt..16rt+15); b = 16 js + 4 q + e
           float av[4][4], bv[4][4];
           const float* pa = sm + S::DO + (4 * q) * SO + r;
-          const float* pb = sm + S::H2 + (4 * q) * SH + 16 * w + r;
+          const float* pb = sm + S::H2 + (4 * q) * SH + 16 * rt + r;
 #pragma unroll
           for (int js = 0; js < 4; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e) { av[js][e] = pa[(16 * js + e) * SO]; bv[js][e] = pb[(16 * js + e) * SH]; }
+          __builtin_amdgcn_sched_barrier(0);
           f32x4 acc[4];
 #pragma unroll
           for (int js = 0; js < 4; ++js) {
@@ -561,7 +588,7 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) gWhr[i] += (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
         }
-        // owners fold the per-wave partials of this chunk (b2, head bias, log_std, loss statistics)
+        // owners fold the per-row-tile partials of this chunk (b2, head bias, log_std, loss statistics)
         if (tid >= 64 && tid < 128) {
           const int j = tid - 64;
           gB += (sm[S::RED2 + j] + sm[S::RED2 + HD + j]) + (sm[S::RED2 + 2 * HD + j] + sm[S::RED2 + 3 * HD + j]);
@@ -579,79 +606,80 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
           mb_s3 += (sm[S::PST + 3] + sm[S::PST + 11]) + (sm[S::PST + 19] + sm[S::PST + 27]);
         }
         __syncthreads();  // (2b) every wave is done reading h2: its buffer becomes dz1
-        {  // dW2[j][k] += sum_b dz2[b][j] h1[b][k]   (wave w: rows j = 16w..)
-          float av[4][4];
-          const float* pa = sm + S::DZ + (4 * q) * SH + 16 * w + r;
-          const float* pb = sm + S::H1 + (4 * q) * SH + r;
+        {  // dH1 = dz2 . W2 (own rows, own column half) -> dz1 = dH1 * (1 - h1^2), stored over h2
+          f32x4 av[4];
+          const float* pa = sm + S::DZ + (16 * rt + r) * SH + 4 * q;
+          const float* pb = sm + S::W2 + (4 * q) * SH + 32 * hf + r;
+#pragma unroll
+          for (int js = 0; js < 4; ++js) av[js] = lds128(pa + 16 * js);
+          float bv[4][2][4];
 #pragma unroll
           for (int js = 0; js < 4; ++js)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) av[js][e] = pa[(16 * js + e) * SH];
+            for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int js = 0; js < 4; ++js) {
-            float bv[4][4];
+              for (int c = 0; c < 2; ++c) bv[js][c][e] = pb[(16 * js + e) * SH + 16 * c];
+          __builtin_amdgcn_sched_barrier(0);
+          f32x4 acc[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) bv[c][e] = pb[(16 * js + e) * SH + 16 * c];
+              for (int c = 0; c < 2; ++c) acc[c] = MFMA_F32(av[js][e], bv[js][c][e], acc[c]);
+          // dW2[j][k] += sum_b dz2[b][j] h1[b][k]  (rows j = 16rt.., columns 32hf..): its MFMAs are independent of the
+          // epilogue below, so the scheduler can hide the epilogue's VALU / LDS work under them
+          float a2[4][4], b2v[4][2][4];
+          const float* pa2 = sm + S::DZ + (4 * q) * SH + 16 * rt + r;
+          const float* pb2 = sm + S::H1 + (4 * q) * SH + 32 * hf + r;
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              a2[js][e] = pa2[(16 * js + e) * SH];
+#pragma unroll
+              for (int c = 0; c < 2; ++c) b2v[js][c][e] = pb2[(16 * js + e) * SH + 16 * c];
+            }
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int c = 0; c < 4; ++c) gW2r[c] = MFMA_F32(av[js][e], bv[c][e], gW2r[c]);
-          }
-        }
-        {  // dH1 = dz2 . W2 (own rows) -> dz1 = dH1 * (1 - h1^2), stored over h2
-          f32x4 av[4];
-          const float* pa = sm + S::DZ + (16 * w + r) * SH + 4 * q;
-          const float* pb = sm + S::W2 + (4 * q) * SH + r;
+              for (int c = 0; c < 2; ++c) gW2r[c] = MFMA_F32(a2[js][e], b2v[js][c][e], gW2r[c]);
 #pragma unroll
-          for (int js = 0; js < 4; ++js) av[js] = lds128(pa + 16 * js);
-          f32x4 acc[4];
-#pragma unroll
-          for (int c = 0; c < 4; ++c) acc[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int js = 0; js < 4; ++js) {
-            float bv[4][4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-              for (int c = 0; c < 4; ++c) bv[c][e] = pb[(16 * js + e) * SH + 16 * c];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-              for (int c = 0; c < 4; ++c) acc[c] = MFMA_F32(av[js][e], bv[c][e], acc[c]);
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
+          for (int c = 0; c < 2; ++c) {
+            const int col = 32 * hf + 16 * c + r;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               acc[c][i] = acc[c][i] * (1.f - h1t[c][i] * h1t[c][i]);
-              sm[S::H2 + (16 * w + 4 * q + i) * SH + 16 * c + r] = acc[c][i];
+              sm[S::H2 + (16 * rt + 4 * q + i) * SH + col] = acc[c][i];
             }
             const float cs = tile_colsum(acc[c]);
-            if (q == 0) sm[S::RED1 + w * HD + 16 * c + r] = cs;
+            if (q == 0) sm[S::RED1 + rt * HD + col] = cs;
           }
         }
         __syncthreads();  // (3) dz1 of all rows visible
-        {  // dW1[j][k] += sum_b dz1[b][j] x[b][k]
+        {  // dW1[j][k] += sum_b dz1[b][j] x[b][k]   (rows j = 16rt.., column tiles hf*NT1H..)
           float av[4][4];
-          const float* pa = sm + S::H2 + (4 * q) * SH + 16 * w + r;
-          const float* pb = sm + S::X + (4 * q) * SX + r;
+          const float* pa = sm + S::H2 + (4 * q) * SH + 16 * rt + r;
+          const float* pb = sm + S::X + (4 * q) * SX + 16 * hf * NT1H + r;
 #pragma unroll
           for (int js = 0; js < 4; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e) av[js][e] = pa[(16 * js + e) * SH];
 #pragma unroll
           for (int js = 0; js < 4; ++js) {
-            float bv[NT1][4];
+            float bv[NT1H][4];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int c = 0; c < NT1; ++c) bv[c][e] = pb[(16 * js + e) * SX + 16 * c];
+              for (int c = 0; c < NT1H; ++c) bv[c][e] = pb[(16 * js + e) * SX + 16 * c];
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
-              for (int c = 0; c < NT1; ++c) gW1r[c] = MFMA_F32(av[js][e], bv[c][e], gW1r[c]);
+              for (int c = 0; c < NT1H; ++c) gW1r[c] = MFMA_F32(av[js][e], bv[c][e], gW1r[c]);
           }
         }
         if (tid < 64) gB += (sm[S::RED1 + tid] + sm[S::RED1 + HD + tid]) + (sm[S::RED1 + 2 * HD + tid] + sm[S::RED1 + 3 * HD + tid]);
@@ -665,19 +693,23 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
       // ================= global gradient norm: local sum of squares -> 8-byte granules =================
       float ss = 0.f;
 #pragma unroll
-      for (int c = 0; c < NT1; ++c)
+      for (int c = 0; c < NT1H; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) ss += gW1r[c][i] * gW1r[c][i];
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+      for (int c = 0; c < 2; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) ss += gW2r[c][i] * gW2r[c][i];
 #pragma unroll
       for (int i = 0; i < 4; ++i) ss += gWhr[i] * gWhr[i];
       if (vec_g >= 0) ss += gB * gB;
-      ss = block_sum(ss, sm + S::MISC);
+      ss = wave_sum(ss);
+      if (lane == 0) sm[S::MISC + w] = ss;
+      __syncthreads();
       // the early-stop decision rides on the policy workgroup's granule; publish first, book-keep afterwards
       if (tid == 0) {
+        ss = ((sm[S::MISC + 0] + sm[S::MISC + 1]) + (sm[S::MISC + 2] + sm[S::MISC + 3])) +
+             ((sm[S::MISC + 4] + sm[S::MISC + 5]) + (sm[S::MISC + 6] + sm[S::MISC + 7]));
         bool want_stop = false;
         float mean_kl = 0.f;
         if (role == 0) {
@@ -709,9 +741,8 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
       // ---- while the granules travel: stage the next minibatch (rows -> LDS, advantage statistics)
       commit_rows();
       {
-        int mbn = mb + 1;
-        if (mbn >= n_mb) mbn = 0;
-        compute_stats(mb_rows(mbn));
+        const int pn = (mb + 1 < n_mb) ? (mb + 1) * B : 0;
+        compute_stats(mb_rows_at(pn));
       }
       STAMP(4)   // next-minibatch staging
       if (tid < 3) {
@@ -751,25 +782,27 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
       };
       if (status == 0) {
 #pragma unroll
-        for (int c = 0; c < NT1; ++c)
+        for (int c = 0; c < NT1H; ++c)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+            const int j = 16 * rt + 4 * q + i, k = 16 * (hf * NT1H + c) + r;
             if (k < O) { float* pw = sm + S::W1 + j * SX + k; float m_ = mW1[c][i], v_ = vW1[c][i]; *pw = adam(gW1r[c][i], m_, v_, *pw); mW1[c][i] = m_; vW1[c][i] = v_; }
           }
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < 2; ++c)
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            float* pw = sm + S::W2 + (16 * w + 4 * q + i) * SH + 16 * c + r;
+            float* pw = sm + S::W2 + (16 * rt + 4 * q + i) * SH + 16 * (2 * hf + c) + r;
             float m_ = mW2[c][i], v_ = vW2[c][i];
             *pw = adam(gW2r[c][i], m_, v_, *pw);
             mW2[c][i] = m_; vW2[c][i] = v_;
           }
+        if (hf == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int o = 4 * q + i;
-          if (o < n_out) { float* pw = sm + S::WH + o * SH + 16 * w + r; float m_ = mWh[i], v_ = vWh[i]; *pw = adam(gWhr[i], m_, v_, *pw); mWh[i] = m_; vWh[i] = v_; }
+          for (int i = 0; i < 4; ++i) {
+            const int o = 4 * q + i;
+            if (o < n_out) { float* pw = sm + S::WH + o * SH + 16 * rt + r; float m_ = mWh[i], v_ = vWh[i]; *pw = adam(gWhr[i], m_, v_, *pw); mWh[i] = m_; vWh[i] = v_; }
+          }
         }
         if (vec_g >= 0) sm[vec_s] = adam(gB, mB, vB, sm[vec_s]);
         refresh_gauss();
@@ -786,27 +819,32 @@ __global__ void __launch_bounds__(TH, 1) ppo_train_kernel(TrainArgs a) {
   for (int i = tid; i < n_out * HD; i += TH) { const int o = i / HD, k = i % HD; a.params[gWh + i] = sm[S::WH + o * SH + k]; }
   if (vec_g >= 0) { a.params[vec_g] = sm[vec_s]; a.exp_avg[vec_g] = mB; a.exp_avg_sq[vec_g] = vB; }
 #pragma unroll
-  for (int c = 0; c < NT1; ++c)
+  for (int c = 0; c < NT1H; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      const int j = 16 * rt + 4 * q + i, k = 16 * (hf * NT1H + c) + r;
       if (k < O) { a.exp_avg[gW1 + j * O + k] = mW1[c][i]; a.exp_avg_sq[gW1 + j * O + k] = vW1[c][i]; }
     }
 #pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < 2; ++c)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      const int j = 16 * rt + 4 * q + i, k = 16 * (2 * hf + c) + r;
       a.exp_avg[gW2 + j * HD + k] = mW2[c][i];
       a.exp_avg_sq[gW2 + j * HD + k] = vW2[c][i];
     }
+  if (hf == 0) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int o = 4 * q + i, j = 16 * w + r;
-    if (o < n_out) { a.exp_avg[gWh + o * HD + j] = mWh[i]; a.exp_avg_sq[gWh + o * HD + j] = vWh[i]; }
+    for (int i = 0; i < 4; ++i) {
+      const int o = 4 * q + i, j = 16 * rt + r;
+      if (o < n_out) { a.exp_avg[gWh + o * HD + j] = mWh[i]; a.exp_avg_sq[gWh + o * HD + j] = vWh[i]; }
+    }
   }
   if (tid == 0 && prof) {
-    for (int k = 0; k < 7; ++k) a.stats[12 + 7 * role + k > 31 ? 31 : 12 + 7 * role + k] = (float)(ph[k] / (double)(steps_done > 0 ? steps_done : 1));
+    for (int k = 0; k < 7; ++k) {
+      const int slot = 12 + 7 * role + k;
+      if (slot < 32) a.stats[slot] = (float)((double)ph[k] / (double)(steps_done > 0 ? steps_done : 1));
+    }
   }
   if (tid == 0) {
     if (role == 0) {
@@ -842,19 +880,20 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
                                   const icrl_buffer_t* buf, const int32_t* perms, const float* nu,
                                   const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, void* stream) {
   if (pol->h1 != HD || pol->h2 != HD || pol->discrete || pol->obs_dim > 128 || pol->act_dim > 16 ||
-      hp->batch_size < 2 || hp->batch_size > MAXB || hp->n_epochs < 1 || buf->obs_dim != pol->obs_dim)
+      hp->batch_size < 2 || hp->batch_size > MAXB || hp->n_epochs < 1 || buf->obs_dim != pol->obs_dim || buf->T < 1 ||
+      (long long)buf->T * buf->N >= (1ll << 31))
     return (int)hipErrorInvalidValue;
   TrainArgs a;
   a.L = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);
   a.params = pol->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.buf = *buf; a.perms = perms; a.nu = nu; a.hp = *hp; a.stats = stats; a.xch = (u64*)sync_ws;
+  a.t_magic = buf->T == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned long long)buf->T);
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(sync_ws, 0, 64, s);
   if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(stats, 0, (32 + hp->n_epochs) * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   const int nt1 = (pol->obs_dim + 15) / 16;
-  if (nt1 <= 1) return launch_train<1>(a, s);
   if (nt1 <= 2) return launch_train<2>(a, s);
   if (nt1 <= 4) return launch_train<4>(a, s);
   return launch_train<8>(a, s);
