@@ -117,6 +117,10 @@ __device__ __forceinline__ unsigned long long stamp() {
     t_last = now_;                                                         \
   }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the global loads of the row prefetch
+// (s_waitcnt vmcnt(0)) at every one of the ~13 barriers of a step and expose their full latency each time
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ f32x4 lds128(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
 // cursor into the stream of minibatch rows: epoch, position inside the epoch, position inside the minibatch
@@ -287,9 +291,9 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
     if (role != 0) return;
     const bool in = tid < nb;
     float s_r = wave_sum(in ? sar : 0.f), s_c = wave_sum(in ? sac : 0.f), s_rr = wave_sum(in ? sar * sar : 0.f);
-    __syncthreads();
+    lds_barrier();
     if (lane == 0) { sm[S::MISC + 16 + w] = s_r; sm[S::MISC + 24 + w] = s_c; sm[S::MISC + 32 + w] = s_rr; }
-    __syncthreads();
+    lds_barrier();
     // minibatches have <= 128 rows: only waves 0 and 1 carry data
     s_r = sm[S::MISC + 16] + sm[S::MISC + 17];
     s_c = sm[S::MISC + 24] + sm[S::MISC + 25];
@@ -367,7 +371,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
         const int nrows = (nb - ch * RB) < RB ? (nb - ch * RB) : RB;
         if (ch > 0) {  // chunk 0 of a step was committed during the previous step's granule wait (or the prologue)
           commit_rows();
-          __syncthreads();
+          lds_barrier();
         }
         // ================= forward: wave (rt, hf): rows 16rt.., output columns 32hf..32hf+31 =================
         f32x4 h1t[2], h2t[2];   // this wave's h1 / h2 tiles stay in registers for the backward epilogues
@@ -407,7 +411,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
         idx_next = idx_nx2;
         c_nx2 = cur_advance(c_nx2);
         idx_nx2 = load_idx(c_nx2);
-        __syncthreads();  // (A1) both column halves of h1 written
+        lds_barrier();  // (A1) both column halves of h1 written
         {
           f32x4 av[4], bv[2][4];
           const float* pa = sm + S::H1 + (16 * rt + r) * SH + 4 * q;
@@ -439,7 +443,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
             }
           }
         }
-        __syncthreads();  // (A2) h2 complete
+        lds_barrier();  // (A2) h2 complete
         if (hf == 0) {    // head: [16 rows] x [16 outputs], K = 64
           f32x4 av[4], bv[4];
           const float* pa = sm + S::H2 + (16 * rt + r) * SH + 4 * q;
@@ -459,7 +463,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
           for (int i = 0; i < 4; ++i)
             sm[S::DO + (16 * rt + 4 * q + i) * SO + r] = ((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i])) + bias;
         }
-        __syncthreads();  // (A3) head outputs visible to both waves of a row tile
+        lds_barrier();  // (A3) head outputs visible to both waves of a row tile
         STAMP(0)   // forward
         // ============ loss + d loss / d head output: row 16rt + r; lane group q and half hf split the actions ============
         {
@@ -487,7 +491,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
             const float s2 = Ar * rc;
             const float gsel = (s1 <= s2) ? Ar : 0.f;                       // d min(s1, s2) / d ratio
             const float dlp = valid ? cpol_nb * (-gsel + nu * Ac) * ratio : 0.f;  // d loss / d log_prob
-            __syncthreads();   // (L) both waves of the pair have read the head outputs before they are overwritten
+            lds_barrier();   // (L) both waves of the pair have read the head outputs before they are overwritten
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii) {
               const int i = 2 * hf + ii;                    // this wave writes / reduces the actions k = q + 4i of its half
@@ -520,7 +524,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
             }
             const float e = vp - R;
             const float d0 = valid ? vcoef * 2.f * e / (float)nb * pass : 0.f;
-            __syncthreads();   // (L)
+            lds_barrier();   // (L)
             if (hf == 0) {
               if (q == 0) {
                 dor[0] = d0;
@@ -538,7 +542,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
             }
           }
         }
-        __syncthreads();  // (A4) d loss / d output of the row tile complete (written by both halves)
+        lds_barrier();  // (A4) d loss / d output of the row tile complete (written by both halves)
         STAMP(1)   // loss
         // ================= backward =================
         {  // dH2 = dOut . Wh  -> dz2 = dH2 * (1 - h2^2) (own rows, own column half), column sums for d b2
@@ -568,7 +572,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
             if (q == 0) sm[S::RED2 + rt * HD + col] = cs;
           }
         }
-        __syncthreads();  // (2) dz2, dOut, h2 of ALL rows visible
+        lds_barrier();  // (2) dz2, dOut, h2 of ALL rows visible
         if (hf == 0) {  // dWh[o][j] += sum_b dOut[b][o] h2[b][j]   (columns 16rt..16rt+15); b = 16 js + 4 q + e
           float av[4][4], bv[4][4];
           const float* pa = sm + S::DO + (4 * q) * SO + r;
@@ -605,7 +609,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
           mb_s2 += (sm[S::PST + 2] + sm[S::PST + 10]) + (sm[S::PST + 18] + sm[S::PST + 26]);
           mb_s3 += (sm[S::PST + 3] + sm[S::PST + 11]) + (sm[S::PST + 19] + sm[S::PST + 27]);
         }
-        __syncthreads();  // (2b) every wave is done reading h2: its buffer becomes dz1
+        lds_barrier();  // (2b) every wave is done reading h2: its buffer becomes dz1
         {  // dH1 = dz2 . W2 (own rows, own column half) -> dz1 = dH1 * (1 - h1^2), stored over h2
           f32x4 av[4];
           const float* pa = sm + S::DZ + (16 * rt + r) * SH + 4 * q;
@@ -660,7 +664,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
             if (q == 0) sm[S::RED1 + rt * HD + col] = cs;
           }
         }
-        __syncthreads();  // (3) dz1 of all rows visible
+        lds_barrier();  // (3) dz1 of all rows visible
         {  // dW1[j][k] += sum_b dz1[b][j] x[b][k]   (rows j = 16rt.., column tiles hf*NT1H..)
           float av[4][4];
           const float* pa = sm + S::H2 + (4 * q) * SH + 16 * rt + r;
@@ -683,7 +687,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
           }
         }
         if (tid < 64) gB += (sm[S::RED1 + tid] + sm[S::RED1 + HD + tid]) + (sm[S::RED1 + 2 * HD + tid] + sm[S::RED1 + 3 * HD + tid]);
-        __syncthreads();  // (4) chunk buffers free
+        lds_barrier();  // (4) chunk buffers free
         STAMP(2)   // backward
       }  // chunks
 
@@ -705,7 +709,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
       if (vec_g >= 0) ss += gB * gB;
       ss = wave_sum(ss);
       if (lane == 0) sm[S::MISC + w] = ss;
-      __syncthreads();
+      lds_barrier();
       // the early-stop decision rides on the policy workgroup's granule; publish first, book-keep afterwards
       if (tid == 0) {
         ss = ((sm[S::MISC + 0] + sm[S::MISC + 1]) + (sm[S::MISC + 2] + sm[S::MISC + 3])) +
@@ -759,7 +763,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
         if (tid == 0) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;
         if (!ok) sm[S::MISC + 13] = 1.f;
       }
-      __syncthreads();
+      lds_barrier();
       STAMP(5)   // granule wait
       const float total = sqrtf((sm[S::MISC + 8] + sm[S::MISC + 9]) + sm[S::MISC + 10]);
       stop = sm[S::MISC + 12] != 0.f;
@@ -808,11 +812,12 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
         refresh_gauss();
       }
       if (tid == 0) { sm[S::MISC + 12] = 0.f; sm[S::MISC + 13] = 0.f; }
-      __syncthreads();
+      lds_barrier();
       STAMP(6)   // Adam
     }  // minibatches
   }    // epochs
 
+  __syncthreads();
   // ---- write back weights, moments, statistics
   for (int i = tid; i < HD * O; i += TH) { const int j = i / O, k = i % O; a.params[gW1 + i] = sm[S::W1 + j * SX + k]; }
   for (int i = tid; i < HD * HD; i += TH) { const int j = i / HD, k = i % HD; a.params[gW2 + i] = sm[S::W2 + j * SH + k]; }
