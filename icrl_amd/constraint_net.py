@@ -214,7 +214,15 @@ class ConstraintNet:
         """Loads the reference's .pt format.  The reference passes the constructor arguments positionally ONE SLOT OFF
         (constraint_net.py:394-399), so a loaded net has clip_obs=None, no action clipping, no observation normalisation and
         no optimizer — reproduced here because it is what the constraint-transfer runs (cpg) evaluate."""
-        sd = torch.load(load_path, map_location="cpu", weights_only=False) if not isinstance(load_path, dict) else load_path
+        if isinstance(load_path, dict):
+            sd = load_path
+        elif str(load_path).endswith(".npz"):      # re-packed fixture of a reference checkpoint (tests/golden/cn_antbroken.npz)
+            z = np.load(load_path)
+            sd = dict(obs_dim=int(z["obs_dim"]), acs_dim=int(z["acs_dim"]), is_discrete=bool(z["is_discrete"]),
+                      obs_select_dim=None, acs_select_dim=None, hidden_sizes=[int(h) for h in z["hidden_sizes"]],
+                      cn_network={k[len("cn_network/"):]: torch.as_tensor(z[k]) for k in z.files if k.startswith("cn_network/")})
+        else:
+            sd = torch.load(load_path, map_location="cpu", weights_only=False)
         g = lambda v, k: sd[k] if v is None else v
         obs_dim, acs_dim, is_discrete = g(obs_dim, "obs_dim"), g(acs_dim, "acs_dim"), g(is_discrete, "is_discrete")
         obs_select_dim, acs_select_dim = g(obs_select_dim, "obs_select_dim"), g(acs_select_dim, "acs_select_dim")

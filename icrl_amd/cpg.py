@@ -1,0 +1,167 @@
+"""cpg — PPO-Lagrangian against a FIXED cost: constraint transfer (BASELINE configs[4]) and expert generation.
+
+ref: icrl/cpg.py:24-212 (cpg), :214-343 (flag set).  The cost is the frozen ConstraintNet loaded through the reference's
+(positionally shifted) ConstraintNet.load, the ground-truth wall cost, or the null cost.  One long
+``model.learn(timesteps, cost_function="cost")``; the reference's periodic EvalCallback / CheckpointCallback /
+AdjustedRewardCallback (host-side, outside the timed path; icrl/cpg.py:160-198) are reduced to an evaluation + checkpoint
+every ``eval_every`` rollouts.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+from . import distributed as D, logger, utils
+from .constraint_net import ConstraintNet
+from .ppo_lag import PPOLagrangian
+from .true_constraint_net import get_true_cost_function, null_cost
+from . import spaces
+
+
+class _PeriodicEval:
+    """stand-in for EvalCallback + CheckpointCallback + AdjustedRewardCallback (ref: icrl/cpg.py:160-186)."""
+
+    def __init__(self, model_ref, eval_env, every, save_dir, true_cost, log):
+        self.model, self.eval_env, self.every, self.save_dir, self.true_cost, self.log = model_ref, eval_env, every, save_dir, true_cost, log
+        self.n_rollouts, self.best, self.history = 0, -np.inf, []
+
+    def init_callback(self, model): self.model = model
+    def on_training_start(self, *a): pass
+    def on_rollout_start(self): pass
+    def on_training_end(self): pass
+
+    def on_rollout_end(self):
+        self.n_rollouts += 1
+        rb = self.model.rollout_buffer
+        # adjusted reward: mean reward of the rollout with violating steps zeroed (ref: icrl/utils.py:542-568)
+        viol = (rb.new_orig_observations[..., 0] <= -3).float()
+        adjusted = float((rb.rewards * (1 - viol)).mean().item())
+        rec = {"rollouts": self.n_rollouts, "timesteps": self.model.num_timesteps, "adjusted_reward": adjusted,
+               "true_cost": float(viol.mean().item())}
+        if self.every and self.n_rollouts % self.every == 0:
+            from .vec_env import sync_envs_normalization
+            sync_envs_normalization(self.model.env, self.eval_env)
+            mean_r, std_r = utils.evaluate_policy(self.model, self.eval_env, n_eval_episodes=5, deterministic=False)
+            rec.update(eval_reward=mean_r, eval_reward_std=std_r)
+            if mean_r > self.best and self.save_dir:
+                self.best = mean_r
+                torch.save(self.model.policy.state_dict(), os.path.join(self.save_dir, "best_model_policy.pth"))
+                self.model.env.save(os.path.join(self.save_dir, "train_env_stats.pkl"))
+        self.history.append(rec)
+        if self.log:
+            self.log(json.dumps(rec))
+
+
+def cpg(config, log=print):
+    rank = getattr(config, "rank", 0)
+    dev = config.device if str(config.device).startswith("cuda") else "cuda"
+    train_env = utils.make_train_env(env_id=config.train_env_id, save_dir=config.save_dir, use_cost_wrapper=True,
+                                     base_seed=config.seed, num_threads=config.num_threads,
+                                     normalize_obs=not config.dont_normalize_obs, normalize_reward=not config.dont_normalize_reward,
+                                     normalize_cost=not config.dont_normalize_cost, cost_info_str=config.cost_info_str,
+                                     reward_gamma=config.reward_gamma, cost_gamma=config.cost_gamma,
+                                     env_index_offset=rank * config.num_threads, device=dev)
+    eval_env = utils.make_eval_env(env_id=config.eval_env_id, use_cost_wrapper=True, normalize_obs=not config.dont_normalize_obs,
+                                   seed=config.seed + rank * config.num_threads, device=dev)
+    is_discrete = isinstance(train_env.action_space, spaces.Discrete)
+    obs_dim = train_env.observation_space.shape[0]
+    acs_dim = train_env.action_space.n if is_discrete else train_env.action_space.shape[0]
+    if config.use_null_cost:
+        cost_function = null_cost
+    elif config.cn_path is None:
+        cost_function = get_true_cost_function(config.eval_env_id)
+    elif config.load_gail:
+        raise NotImplementedError("--load_gail: the GAIL discriminator baseline is outside the ICRL hot path")
+    else:
+        constraint_net = ConstraintNet.load(config.cn_path, obs_dim=obs_dim, acs_dim=acs_dim, is_discrete=is_discrete,
+                                            obs_select_dim=config.cn_obs_select_dim, acs_select_dim=config.cn_acs_select_dim,
+                                            clip_obs=None, obs_mean=None, obs_var=None)
+        cost_function = constraint_net.cost_function
+    if not isinstance(getattr(cost_function, "__self__", None), ConstraintNet):
+        raise NotImplementedError("cpg on the device path needs a ConstraintNet cost (--cn_path); analytic costs run through the "
+                                  "generic VecCostWrapper callable path only")
+    train_env.set_cost_function(cost_function)
+    eval_env.set_cost_function(cost_function)
+    model = PPOLagrangian(
+        policy=config.policy_name, env=train_env, algo_type="pidlagrangian" if config.use_pid else "lagrangian",
+        learning_rate=config.learning_rate, n_steps=config.n_steps, batch_size=config.batch_size, n_epochs=config.n_epochs,
+        reward_gamma=config.reward_gamma, reward_gae_lambda=config.reward_gae_lambda, cost_gamma=config.cost_gamma,
+        cost_gae_lambda=config.cost_gae_lambda, clip_range=config.clip_range, clip_range_reward_vf=config.clip_range_reward_vf,
+        clip_range_cost_vf=config.clip_range_cost_vf, ent_coef=config.ent_coef, reward_vf_coef=config.reward_vf_coef,
+        cost_vf_coef=config.cost_vf_coef, max_grad_norm=config.max_grad_norm, use_sde=config.use_sde,
+        sde_sample_freq=config.sde_sample_freq, target_kl=config.target_kl, penalty_initial_value=config.penalty_initial_value,
+        penalty_learning_rate=config.penalty_learning_rate, update_penalty_after=config.update_penalty_after, budget=config.budget,
+        seed=config.seed, device=dev, verbose=config.verbose,
+        pid_kwargs=dict(alpha=config.budget, penalty_init=config.penalty_initial_value, Kp=config.proportional_control_coeff,
+                        Ki=config.integral_control_coeff, Kd=config.derivative_control_coeff, pid_delay=config.pid_delay,
+                        delta_p_ema_alpha=config.proportional_cost_ema_alpha, delta_d_ema_alpha=config.derivative_cost_ema_alpha),
+        policy_kwargs=dict(net_arch=utils.get_net_arch(config)),
+        action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"))
+    cb = _PeriodicEval(model, eval_env, int(getattr(config, "eval_every_rollouts", 0)), config.save_dir,
+                       get_true_cost_function(config.eval_env_id), log if (config.verbose > 0 and rank == 0) else None)
+    model.learn(total_timesteps=int(config.timesteps), cost_function="cost", callback=cb)
+    if config.save_dir and rank == 0:
+        torch.save(model.policy.state_dict(), os.path.join(config.save_dir, "final_model_policy.pth"))
+    return model, cb.history
+
+
+def build_parser():
+    """flag set of the reference's cpg (icrl/cpg.py:216-298); note -cl here is --cost_vf_layers."""
+    p = argparse.ArgumentParser()
+    a = p.add_argument
+    a("file_to_run", type=str, nargs="?", default="cpg")
+    a("--config_file", "-cf", type=str, default=None); a("--project", "-p", type=str, default="ABC"); a("--name", "-n", type=str, default=None)
+    a("--group", "-g", type=str, default=None); a("--message", "-m", type=str, default=None); a("--device", "-d", type=str, default="cuda")
+    a("--verbose", "-v", type=int, default=2); a("--wandb_sweep", "-ws", type=bool, default=False); a("--sync_wandb", "-sw", action="store_true")
+    a("--cost_info_str", "-cis", type=lambda x: None if str(x).lower() == "none" else str(x), default="cost")
+    a("--train_env_id", "-tei", type=str, default="AntWallBroken-v0"); a("--eval_env_id", "-eei", type=str, default="AntWallBrokenTest-v0")
+    a("--dont_normalize_obs", "-dno", action="store_true"); a("--dont_normalize_reward", "-dnr", action="store_true")
+    a("--dont_normalize_cost", "-dnc", action="store_true"); a("--seed", "-s", type=int, default=None)
+    a("--policy_name", "-pn", type=str, default="TwoCriticsMlpPolicy"); a("--shared_layers", "-sl", type=int, default=None, nargs="*")
+    a("--policy_layers", "-pl", type=int, default=[64, 64], nargs="*"); a("--reward_vf_layers", "-rl", type=int, default=[64, 64], nargs="*")
+    a("--cost_vf_layers", "-cl", type=int, default=[64, 64], nargs="*"); a("--cnn_features_dim", "-cfd", type=int, default=512)
+    a("--timesteps", "-t", type=lambda x: int(float(x)), default=1e6); a("--n_steps", "-ns", type=int, default=2048)
+    a("--batch_size", "-bs", type=int, default=64); a("--n_epochs", "-ne", type=int, default=10); a("--num_threads", "-nt", type=int, default=5)
+    a("--save_every", "-se", type=float, default=5e5); a("--eval_every", "-ee", type=float, default=2048); a("--plot_every", "-pe", type=float, default=2048)
+    a("--reward_gamma", "-rg", type=float, default=0.99); a("--reward_gae_lambda", "-rgl", type=float, default=0.95)
+    a("--cost_gamma", "-cg", type=float, default=0.99); a("--cost_gae_lambda", "-cgl", type=float, default=0.95)
+    a("--clip_range", "-cr", type=float, default=0.2); a("--clip_range_reward_vf", "-crv", type=float, default=None)
+    a("--clip_range_cost_vf", "-ccv", type=float, default=None); a("--ent_coef", "-ec", type=float, default=0.)
+    a("--reward_vf_coef", "-rvc", type=float, default=0.5); a("--cost_vf_coef", "-cvc", type=float, default=0.5)
+    a("--target_kl", "-tk", type=float, default=None); a("--max_grad_norm", "-mgn", type=float, default=0.5); a("--learning_rate", "-lr", type=float, default=3e-4)
+    a("--use_pid", "-upid", action="store_true"); a("--penalty_initial_value", "-piv", type=float, default=1); a("--budget", "-b", type=float, default=0.0)
+    a("--update_penalty_after", "-upa", type=int, default=1); a("--proportional_control_coeff", "-kp", type=float, default=10)
+    a("--derivative_control_coeff", "-kd", type=float, default=0); a("--integral_control_coeff", "-ki", type=float, default=0.0001)
+    a("--proportional_cost_ema_alpha", "-pema", type=float, default=0.5); a("--derivative_cost_ema_alpha", "-dema", type=float, default=0.5)
+    a("--pid_delay", "-pidd", type=int, default=1); a("--penalty_learning_rate", "-plr", type=float, default=0.1)
+    a("--use_sde", "-us", action="store_true"); a("--use_curiosity_driven_exploration", "-ucde", action="store_true")
+    a("--use_lambda_shaping", "-uls", action="store_true"); a("--sde_sample_freq", "-ssf", type=int, default=-1)
+    a("--use_null_cost", "-unc", action="store_true"); a("--cn_path", "-cp", type=str, default=None)
+    a("--cn_obs_select_dim", "-cosd", type=int, default=None, nargs="+"); a("--cn_acs_select_dim", "-casd", type=int, default=None, nargs="+")
+    a("--cn_device", "-cd", type=str, default=None); a("--load_gail", "-lg", action="store_true")
+    a("--save_dir", type=str, default=None); a("--eval_every_rollouts", type=int, default=0)
+    a("--action_noise", type=str, default="device"); a("--permutation", type=str, default="numpy")
+    return p
+
+
+def main(argv=None):
+    start = time.time()
+    config = vars(build_parser().parse_args(argv if argv is not None else sys.argv[1:]))
+    if config["seed"] is None:
+        config["seed"] = int(np.random.randint(0, 100))
+    rank, world = D.init_from_env()
+    config["rank"], config["world_size"] = rank, world
+    if config["save_dir"]:
+        os.makedirs(config["save_dir"], exist_ok=True)
+    cpg(types.SimpleNamespace(**config))
+    if rank == 0:
+        print("Time taken: %05.2f hours" % ((time.time() - start) / 3600))
+
+
+if __name__ == "__main__":
+    main()

@@ -762,6 +762,11 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
         sm[S::MISC + 8 + tid] = __uint_as_float((unsigned)(v & 0xffffffffu));
         if (tid == 0) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;
         if (!ok) sm[S::MISC + 13] = 1.f;
+      } else if (tid == 3) {   // Adam's bias corrections in double, once per step, while the others poll
+        b1pow *= (double)a.hp.adam_beta1;
+        b2pow *= (double)a.hp.adam_beta2;
+        sm[S::MISC + 14] = (float)((double)a.hp.lr / (1.0 - b1pow));
+        sm[S::MISC + 15] = (float)(1.0 / sqrt(1.0 - b2pow));
       }
       lds_barrier();
       STAMP(5)   // granule wait
@@ -772,10 +777,8 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
       coef = coef > 1.f ? 1.f : coef;
 
       // ================= Adam (torch.optim.Adam, single-tensor form) on register-resident moments =================
-      b1pow *= (double)a.hp.adam_beta1;
-      b2pow *= (double)a.hp.adam_beta2;
-      const float step_size = (float)((double)a.hp.lr / (1.0 - b1pow));
-      const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - b2pow));
+      const float step_size = sm[S::MISC + 14];
+      const float inv_bc2_sqrt = sm[S::MISC + 15];
       const float b2f = a.hp.adam_beta2, epsf = a.hp.adam_eps;
       auto adam = [&](float g, float& m, float& v, float p) -> float {
         g = g * coef;

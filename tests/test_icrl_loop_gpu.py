@@ -92,3 +92,21 @@ def test_icrl_entry_point_short_run(tmp_path, golden):
     from icrl_amd.constraint_net import ConstraintNet
     net = ConstraintNet.load(os.path.join(str(tmp_path), "best_cn_model.pt"))
     assert net.clip_obs is None and net.action_low is None
+
+
+def test_cpg_transfer_short_run(tmp_path):
+    """BASELINE configs[4] shape at reduced size: AntWallBroken with the committed AntBroken constraint net, frozen."""
+    import os, types
+    from icrl_amd.cpg import build_parser, cpg
+    here = os.path.dirname(os.path.abspath(__file__))
+    argv = ["cpg", "--cn_path", os.path.join(here, "golden/cn_antbroken.npz"), "-tei", "AntWallBroken-v0", "-eei", "AntWallBrokenTest-v0",
+            "-tk", "0.01", "--batch_size", "128", "--reward_gae_lambda", "0.9", "--n_epochs", "3", "--learning_rate", "3e-5",
+            "--clip_range", "0.4", "-t", "4096", "-plr", "1.0", "-nt", "16", "--n_steps", "128", "-s", "0", "-v", "0",
+            "--save_dir", str(tmp_path), "--eval_every_rollouts", "2"]
+    cfg = vars(build_parser().parse_args(argv)); cfg.update(rank=0, world_size=1)
+    model, hist = cpg(types.SimpleNamespace(**cfg), log=None)
+    assert model.num_timesteps == 4096 and len(hist) == 2 and "eval_reward" in hist[-1]
+    assert model.env.venv.constraint_net().clip_obs is None          # the load() quirk is what transfer runs evaluate
+    assert np.isfinite(model.dual.nu().item())
+    from icrl_amd import logger
+    assert np.isfinite(logger.Logger.CURRENT.name_to_value["train/average_cost"])
