@@ -143,8 +143,15 @@ def main():
     gae_bytes = T * N * 36
     gae_ach = gae_bytes / (np.mean(gae_us) * 1e-6) / 1e9
     sweep = gae_sweep_point()
+    traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), same shape
+    pmc_path = os.path.join(ROOT, "profiles", "r01_gae_pmc.json")
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        if pmc["T"] == sweep["T"] and pmc["N"] == sweep["envs"]:
+            traffic = int(pmc["traffic_bytes"])
     roofline = dict(kernel="gae_dual_kernel", bound="hbm", achieved=round(sweep["achieved"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(sweep["achieved"] / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(sweep["achieved"] / HBM_PEAK_GBS, 4), traffic=traffic,
                     at=f"T={sweep['T']}, N={sweep['envs']} envs: {sweep['bytes'] / 1e9:.2f} GB algorithmic (36 B/transition), "
                        f"{sweep['us']:.0f} us/launch — the size at which the working set leaves the 256 MB Infinity Cache",
                     in_loop=dict(achieved=round(gae_ach, 1), frac=round(gae_ach / HBM_PEAK_GBS, 5), us_per_launch=round(float(np.mean(gae_us)), 1),
