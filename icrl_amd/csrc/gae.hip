@@ -27,7 +27,7 @@
 
 namespace {
 
-constexpr int U = 8;  // time rows per register batch (x2 for the double buffer)
+constexpr int U_DEFAULT = 8;  // time rows per register batch (x2 for the double buffer)
 
 struct GaeArgs {
   const float *r, *c, *vr, *vc, *d, *lvr, *lvc;
@@ -37,21 +37,28 @@ struct GaeArgs {
   float g_r, gl_r, g_c, gl_c;
 };
 
+template <int U>
 struct Batch {
   float r[U], c[U], vr[U], vc[U], d[U];
 };
 
-__device__ __forceinline__ void load_batch(const GaeArgs& a, unsigned n, int t_top, int t0, Batch& b) {
+template <bool NT>
+__device__ __forceinline__ float ldg(const float* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT>
+__device__ __forceinline__ void stg(float* p, float v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
+template <int U, bool NT>
+__device__ __forceinline__ void load_batch(const GaeArgs& a, unsigned n, int t_top, int t0, Batch<U>& b) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     int t = t_top - u;
     t = t < t0 ? t0 : t;  // clamped (uniform) — the value is ignored below t0
     const size_t row = (size_t)t * a.N;  // wave-uniform: scalar row base + 32-bit lane offset
-    b.r[u] = (a.r + row)[n];
-    b.c[u] = (a.c + row)[n];
-    b.vr[u] = (a.vr + row)[n];
-    b.vc[u] = (a.vc + row)[n];
-    b.d[u] = (a.d + row)[n];
+    b.r[u] = ldg<NT>(a.r + row + n);
+    b.c[u] = ldg<NT>(a.c + row + n);
+    b.vr[u] = ldg<NT>(a.vr + row + n);
+    b.vc[u] = ldg<NT>(a.vc + row + n);
+    b.d[u] = ldg<NT>(a.d + row + n);
   }
 }
 
@@ -62,8 +69,8 @@ struct Carry {
   float vr_next, vc_next, d_next;
 };
 
-template <bool WRITE>
-__device__ __forceinline__ void run_batch(const GaeArgs& a, unsigned n, bool live, int t_top, int t0, const Batch& b, Carry& s) {
+template <bool WRITE, int U, bool NT>
+__device__ __forceinline__ void run_batch(const GaeArgs& a, unsigned n, bool live, int t_top, int t0, const Batch<U>& b, Carry& s) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     const int t = t_top - u;
@@ -82,10 +89,10 @@ __device__ __forceinline__ void run_batch(const GaeArgs& a, unsigned n, bool liv
         if (live) {
           const size_t row = (size_t)t * a.N;
           const float fr = (float)s.Ar, fc = (float)s.Ac;
-          (a.ar + row)[n] = fr;
-          (a.ac + row)[n] = fc;
-          (a.rr + row)[n] = fr + b.vr[u];
-          (a.rc + row)[n] = fc + b.vc[u];
+          stg<NT>(a.ar + row + n, fr);
+          stg<NT>(a.ac + row + n, fc);
+          stg<NT>(a.rr + row + n, fr + b.vr[u]);
+          stg<NT>(a.rc + row + n, fc + b.vc[u]);
         }
       } else {
         s.Pr = (double)cr * s.Pr;
@@ -100,7 +107,7 @@ __device__ __forceinline__ void run_batch(const GaeArgs& a, unsigned n, bool liv
 
 // Walk t = t1-1 .. t0 for column n.  WRITE=false: compute the chunk's affine map into (s.Pr,s.Ar),(s.Pc,s.Ac)
 // starting from A=0,P=1.  WRITE=true: s.Ar/s.Ac hold the carry-in and outputs are stored.
-template <bool WRITE>
+template <bool WRITE, int U, bool NT>
 __device__ __forceinline__ void walk_chunk(const GaeArgs& a, unsigned n, bool live, int t0, int t1, Carry& s) {
   int t = t1 - 1;
   if (t1 == a.T) {
@@ -135,25 +142,26 @@ __device__ __forceinline__ void walk_chunk(const GaeArgs& a, unsigned n, bool li
     s.d_next = a.d[off];
   }
   if (t < t0) return;
-  Batch b0, b1;
-  load_batch(a, n, t, t0, b0);
+  Batch<U> b0, b1;
+  load_batch<U, NT>(a, n, t, t0, b0);
   while (true) {
-    if (t - U >= t0) load_batch(a, n, t - U, t0, b1);
-    run_batch<WRITE>(a, n, live, t, t0, b0, s);
+    if (t - U >= t0) load_batch<U, NT>(a, n, t - U, t0, b1);
+    run_batch<WRITE, U, NT>(a, n, live, t, t0, b0, s);
     t -= U;
     if (t < t0) break;
-    if (t - U >= t0) load_batch(a, n, t - U, t0, b0);
-    run_batch<WRITE>(a, n, live, t, t0, b1, s);
+    if (t - U >= t0) load_batch<U, NT>(a, n, t - U, t0, b0);
+    run_batch<WRITE, U, NT>(a, n, live, t, t0, b1, s);
     t -= U;
     if (t < t0) break;
   }
 }
 
-template <int W>
-__global__ void __launch_bounds__(64 * W) gae_dual_kernel(GaeArgs a) {
+template <int W, int U, bool NT, int G = 1>
+__global__ void __launch_bounds__(64 * W * G) gae_dual_kernel(GaeArgs a) {
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
-  const int col = blockIdx.x * 64 + lane;
+  static_assert(W == 1 || G == 1, "G independent waves per workgroup only for the one-wave-per-tile shape");
+  const int wave = G > 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform -> SGPR
+  const int col = G > 1 ? blockIdx.x * 64 * G + threadIdx.x : blockIdx.x * 64 + lane;
   const bool live = col < a.N;
   const unsigned n = live ? col : a.N - 1;
   const int chunk = (a.T + W - 1) / W;
@@ -164,7 +172,7 @@ __global__ void __launch_bounds__(64 * W) gae_dual_kernel(GaeArgs a) {
   s.vr_next = 0.f; s.vc_next = 0.f; s.d_next = 0.f;
   if (W > 1) {
     __shared__ double maps[W][4][64];
-    if (t0 < t1) walk_chunk<false>(a, n, live, t0, t1, s);
+    if (t0 < t1) walk_chunk<false, U, NT>(a, n, live, t0, t1, s);
     maps[wave][0][lane] = s.Pr;
     maps[wave][1][lane] = s.Ar;
     maps[wave][2][lane] = s.Pc;
@@ -178,7 +186,7 @@ __global__ void __launch_bounds__(64 * W) gae_dual_kernel(GaeArgs a) {
     s.Ar = Ar;
     s.Ac = Ac;
   }
-  if (t0 < t1) walk_chunk<true>(a, n, live, t0, t1, s);
+  if (t0 < t1) walk_chunk<true, U, NT>(a, n, live, t0, t1, s);
 }
 
 }  // namespace
@@ -195,14 +203,22 @@ extern "C" int icrl_gae_dual_ex(const float* rewards, const float* costs, const 
             (float)cost_gamma, (float)(cost_gamma * cost_gae_lambda)};
   const int tiles = (N + 63) / 64;
   int W = waves_per_tile;
+  if (W >= 100) W = 1;
   if (W != 1 && W != 4 && W != 16) {
     W = tiles >= 512 ? 1 : (tiles >= 64 ? 4 : 16);
-    while (W > 1 && T / W < 2 * U) W /= 4;
+    while (W > 1 && T / W < 2 * U_DEFAULT) W /= 4;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (W == 1) hipLaunchKernelGGL(gae_dual_kernel<1>, dim3(tiles), dim3(64), 0, s, a);
-  else if (W == 4) hipLaunchKernelGGL(gae_dual_kernel<4>, dim3(tiles), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(gae_dual_kernel<16>, dim3(tiles), dim3(1024), 0, s, a);
+  // one wave per 64-env tile streams T rows; with >= 1024 tiles, 4 neighbouring tiles share a workgroup (1 KB contiguous per
+  // row and array, the 4 waves start together) and 16 rows x 5 arrays are in flight per wave: +5..8 % of HBM rate measured.
+  // waves_per_tile codes 101 / 105 / 106 force those shapes for tools/gae_variants.py.
+  int shape = waves_per_tile >= 100 ? waves_per_tile : (W == 1 ? (tiles >= 1024 ? 106 : 101) : W);
+  if (shape == 101) hipLaunchKernelGGL((gae_dual_kernel<1, 8, true>), dim3(tiles), dim3(64), 0, s, a);
+  else if (shape == 105) hipLaunchKernelGGL((gae_dual_kernel<1, 8, true, 4>), dim3((tiles + 3) / 4), dim3(256), 0, s, a);
+  else if (shape == 106) hipLaunchKernelGGL((gae_dual_kernel<1, 16, true, 4>), dim3((tiles + 3) / 4), dim3(256), 0, s, a);
+  else if (shape == 4) hipLaunchKernelGGL((gae_dual_kernel<4, 8, false>), dim3(tiles), dim3(256), 0, s, a);
+  else if (shape == 16) hipLaunchKernelGGL((gae_dual_kernel<16, 8, false>), dim3(tiles), dim3(1024), 0, s, a);
+  else return (int)hipErrorInvalidValue;
   return (int)hipGetLastError();
 }
 

@@ -148,7 +148,8 @@ int icrl_gae_dual(const float* rewards, const float* costs, const float* reward_
                   int T, int N, double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
                   void* stream);
 
-/* Same kernel with the launch shape forced (roofline sweep): waves_per_tile in {1,4,16}; 0 = library heuristic. */
+/* Same kernel with the launch shape forced (roofline sweep): waves_per_tile in {1,4,16}; 0 = library heuristic;
+ * 101 / 105 / 106 = one-wave-per-tile shapes with 1 / 4 / 4 tiles per workgroup and 8 / 8 / 16 rows in flight. */
 int icrl_gae_dual_ex(const float* rewards, const float* costs, const float* reward_values, const float* cost_values,
                      const float* dones, const float* last_v_r, const float* last_v_c, const uint8_t* last_dones,
                      float* adv_r, float* adv_c, float* ret_r, float* ret_c,
