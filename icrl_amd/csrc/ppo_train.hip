@@ -2,7 +2,8 @@
 //
 // ref: stable_baselines3/ppo_lag/ppo_lag.py:196-299 (epoch / minibatch loop of PPOLagrangian.train),
 //      common/buffers.py:594-627 (get / _get_samples), common/policies.py:752-767 (evaluate_actions),
-//      common/distributions.py:143-171 (DiagGaussian log_prob / entropy), torch.optim.Adam, clip_grad_norm_.
+//      common/distributions.py:143-171 (DiagGaussian log_prob / entropy), :274-288 (Categorical), torch.optim.Adam,
+//      clip_grad_norm_.
 //
 // The reference performs n_epochs * ceil(T*N / batch) DEPENDENT optimiser steps on a 64..128-row minibatch through three
 // small independent MLPs (pi, vf, cvf: obs -> 64 -> 64 -> {act | 1 | 1}).  Parity forbids re-ordering or merging those
@@ -128,7 +129,7 @@ struct Cursor {
   int e, p, m;
 };
 
-template <int NT1>
+template <int NT1, bool DISC>
 __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
   using S = Smem<NT1>;
   constexpr int SX = S::SX;
@@ -162,7 +163,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
   for (int i = tid; i < HD * SH; i += TH) { const int j = i / SH, k = i % SH; sm[S::W2 + i] = k < HD ? a.params[gW2 + j * HD + k] : 0.f; }
   for (int i = tid; i < 16 * SH; i += TH) { const int o = i / SH, k = i % SH; sm[S::WH + i] = (o < n_out && k < HD) ? a.params[gWh + o * HD + k] : 0.f; }
   if (tid < HD) { sm[S::B1 + tid] = a.params[gb1 + tid]; sm[S::B2 + tid] = a.params[gb2 + tid]; }
-  if (tid < 16) { sm[S::BH + tid] = tid < n_out ? a.params[gbh + tid] : 0.f; sm[S::LS + tid] = (role == 0 && tid < A) ? a.params[L.log_std + tid] : 0.f; }
+  if (tid < 16) { sm[S::BH + tid] = tid < n_out ? a.params[gbh + tid] : 0.f; sm[S::LS + tid] = (!DISC && role == 0 && tid < A) ? a.params[L.log_std + tid] : 0.f; }
 
   // wave (rt, hf) owns: W1 rows 16rt.. x column tiles hf*NT1H..; W2 rows 16rt.. x column tiles 2hf, 2hf+1;
   // (hf == 0 only) head-weight columns 16rt..16rt+15
@@ -195,7 +196,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
   if (tid < 64) { vec_g = gb1 + tid; vec_s = S::B1 + tid; }
   else if (tid < 128) { vec_g = gb2 + tid - 64; vec_s = S::B2 + tid - 64; }
   else if (tid < 144) { if (tid - 128 < n_out) { vec_g = gbh + tid - 128; vec_s = S::BH + tid - 128; } }
-  else if (tid < 160) { if (role == 0 && tid - 144 < A) { vec_g = L.log_std + tid - 144; vec_s = S::LS + tid - 144; } }
+  else if (tid < 160) { if (!DISC && role == 0 && tid - 144 < A) { vec_g = L.log_std + tid - 144; vec_s = S::LS + tid - 144; } }
   float mB = 0.f, vB = 0.f, gB = 0.f;
   if (vec_g >= 0) { mB = a.exp_avg[vec_g]; vB = a.exp_avg_sq[vec_g]; }
 
@@ -247,7 +248,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
     if (role == 0) {
       const float* arow = a.buf.actions + off * a.buf.act_store;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; pact[i] = (valid && k < A) ? arow[k] : 0.f; }
+      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; pact[i] = (valid && k < a.buf.act_store) ? arow[k] : 0.f; }
       if (gpart == 0) {
         psc0 = valid ? a.buf.log_probs[off] : 0.f;
         psc1 = valid ? a.buf.reward_advantages[off] : 0.f;
@@ -305,7 +306,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
     std_r = sqrtf(var);
   };
   auto refresh_gauss = [&]() {   // threads 144..159 own log_std: derived constants of the Gaussian head
-    if (role == 0 && tid >= 144 && tid < 160) {
+    if (!DISC && role == 0 && tid >= 144 && tid < 160) {
       const int k = tid - 144;
       const float sd = __expf(sm[S::LS + k]);
       const float iv = __builtin_amdgcn_rcpf(sd * sd);
@@ -364,7 +365,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
       for (int c = 0; c < 2; ++c) gW2r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
       gB = 0.f;
-      float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f;  // thread 0: minibatch sums of the loss statistics
+      float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f, mb_s4 = 0.f;  // thread 0: minibatch sums of the loss statistics
 
       const int n_chunks = (nb + RB - 1) / RB;
       for (int ch = 0; ch < n_chunks; ++ch) {
@@ -470,7 +471,68 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
           const int b = 16 * rt + r;
           const bool valid = b < nrows;
           float* dor = sm + S::DO + b * SO;     // holds the head output of row b; overwritten with its gradient
-          if (role == 0) {
+          if (role == 0 && DISC) {
+            // Categorical(logits) (ref: distributions.py:274-288): lane group q holds the logits k = q + 4 i of row b
+            float lg[4], pr[4], zmax = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int k = q + 4 * i;
+              lg[i] = k < A ? dor[k] : -INFINITY;
+              zmax = fmaxf(zmax, lg[i]);
+            }
+            zmax = fmaxf(zmax, __shfl_xor(zmax, 16, 64));
+            zmax = fmaxf(zmax, __shfl_xor(zmax, 32, 64));
+            float se = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) se += (q + 4 * i < A) ? expf(lg[i] - zmax) : 0.f;
+            se += __shfl_xor(se, 16, 64);
+            se += __shfl_xor(se, 32, 64);
+            const float lse = zmax + logf(se);
+            const int act = (int)sm[S::ACT + b * SH];
+            float lp = 0.f, ent = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int k = q + 4 * i;
+              lg[i] = k < A ? lg[i] - lse : 0.f;         // log-softmax
+              pr[i] = k < A ? expf(lg[i]) : 0.f;
+              lp += (k == act) ? lg[i] : 0.f;
+              ent -= pr[i] * lg[i];
+            }
+            lp += __shfl_xor(lp, 16, 64);
+            lp += __shfl_xor(lp, 32, 64);
+            ent += __shfl_xor(ent, 16, 64);               // entropy of row b
+            ent += __shfl_xor(ent, 32, 64);
+            const float old_lp = sm[S::OLP + b * SH];
+            const float ratio = __expf(lp - old_lp);
+            const float Ar = (sm[S::ADR + b * SH] - c_mean_r) * c_istd_r;
+            const float Ac = sm[S::ADC + b * SH] - c_mean_c;
+            const float s1 = Ar * ratio;
+            const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+            const float s2 = Ar * rc;
+            const float gsel = (s1 <= s2) ? Ar : 0.f;
+            const float dlp = valid ? cpol_nb * (-gsel + nu * Ac) * ratio : 0.f;
+            // loss += ent_coef * (-mean H):  d/dz_k = ent_coef / nb * p_k (log p_k + H)
+            const float dent = valid ? a.hp.ent_coef / (float)nb : 0.f;
+            lds_barrier();   // (L)
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+              const int k = q + 4 * (2 * hf + ii);
+              const float pk = hf == 0 ? pr[ii] : pr[2 + ii];
+              const float lk = hf == 0 ? lg[ii] : lg[2 + ii];
+              const float dk = k < A ? dlp * ((k == act ? 1.f : 0.f) - pk) + dent * (pk * (lk + ent)) : 0.f;
+              dor[k] = dk;
+              const float colsum = sum16(dk);
+              if (r == 0) { sm[S::PBH + rt * 16 + k] = colsum; sm[S::PLS + rt * 16 + k] = 0.f; }
+            }
+            if (hf == 0) {
+              const float v0 = sum16(valid ? fminf(s1, s2) : 0.f);
+              const float v1 = sum16(valid ? Ac * ratio : 0.f);
+              const float v2 = sum16(valid ? (fabsf(ratio - 1.f) > clip ? 1.f : 0.f) : 0.f);
+              const float v3 = sum16(valid ? old_lp - lp : 0.f);
+              const float v4 = sum16(valid ? ent : 0.f);
+              if (lane == 0) { sm[S::PST + rt * 8 + 0] = v0; sm[S::PST + rt * 8 + 1] = v1; sm[S::PST + rt * 8 + 2] = v2; sm[S::PST + rt * 8 + 3] = v3; sm[S::PST + rt * 8 + 4] = v4; }
+            }
+          } else if (role == 0) {
             float dd[4], iv[4];
             float lp = 0.f;
 #pragma unroll
@@ -608,6 +670,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
           mb_s1 += (sm[S::PST + 1] + sm[S::PST + 9]) + (sm[S::PST + 17] + sm[S::PST + 25]);
           mb_s2 += (sm[S::PST + 2] + sm[S::PST + 10]) + (sm[S::PST + 18] + sm[S::PST + 26]);
           mb_s3 += (sm[S::PST + 3] + sm[S::PST + 11]) + (sm[S::PST + 19] + sm[S::PST + 27]);
+          if (DISC) mb_s4 += (sm[S::PST + 4] + sm[S::PST + 12]) + (sm[S::PST + 20] + sm[S::PST + 28]);
         }
         lds_barrier();  // (2b) every wave is done reading h2: its buffer becomes dz1
         {  // dH1 = dz2 . W2 (own rows, own column half) -> dz1 = dH1 * (1 - h1^2), stored over h2
@@ -692,7 +755,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
       }  // chunks
 
       // entropy term of the policy loss: d(ent_coef * -mean(H)) / d log_std = -ent_coef (H = sum_a 0.5 + 0.5 log 2pi + log sigma)
-      if (role == 0 && tid >= 144 && tid < 144 + A) gB += -a.hp.ent_coef;
+      if (!DISC && role == 0 && tid >= 144 && tid < 144 + A) gB += -a.hp.ent_coef;
 
       // ================= global gradient norm: local sum of squares -> 8-byte granules =================
       float ss = 0.f;
@@ -729,7 +792,8 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
         ++steps_done;
         if (role == 0) {
           float ent = 0.f;
-          for (int k = 0; k < A; ++k) ent += HALF_LOG_2PI_PLUS_HALF_F + sm[S::LS + k];
+          if (DISC) ent = mb_s4 / (float)nb;
+          else for (int k = 0; k < A; ++k) ent += HALF_LOG_2PI_PLUS_HALF_F + sm[S::LS + k];
           const float entropy_loss = -ent;
           const float pl = (-(mb_s0 / (float)nb) + nu * (mb_s1 / (float)nb)) / (1.f + nu);
           st_ent += entropy_loss; st_pg += pl; st_cf += mb_s2 / (float)nb;
@@ -874,20 +938,20 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
 
 using namespace icrl;
 
-template <int NT1>
+template <int NT1, bool DISC>
 static int launch_train(const TrainArgs& a, hipStream_t s) {
   static_assert(Smem<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
   const size_t bytes = (size_t)Smem<NT1>::TOTAL * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_kernel<NT1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_kernel<NT1, DISC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(ppo_train_kernel<NT1>, dim3(3), dim3(TH), bytes, s, a);
+  hipLaunchKernelGGL((ppo_train_kernel<NT1, DISC>), dim3(3), dim3(TH), bytes, s, a);
   return (int)hipGetLastError();
 }
 
 extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                                   const icrl_buffer_t* buf, const int32_t* perms, const float* nu,
                                   const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, void* stream) {
-  if (pol->h1 != HD || pol->h2 != HD || pol->discrete || pol->obs_dim > 128 || pol->act_dim > 16 ||
+  if (pol->h1 != HD || pol->h2 != HD || pol->obs_dim > 128 || pol->act_dim > 16 ||
       hp->batch_size < 2 || hp->batch_size > MAXB || hp->n_epochs < 1 || buf->obs_dim != pol->obs_dim || buf->T < 1 ||
       (long long)buf->T * buf->N >= (1ll << 31))
     return (int)hipErrorInvalidValue;
@@ -902,7 +966,13 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
   e = hipMemsetAsync(stats, 0, (32 + hp->n_epochs) * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   const int nt1 = (pol->obs_dim + 15) / 16;
-  if (nt1 <= 2) return launch_train<2>(a, s);
-  if (nt1 <= 4) return launch_train<4>(a, s);
-  return launch_train<8>(a, s);
+  if (pol->discrete) {
+    if (buf->act_store != 1) return (int)hipErrorInvalidValue;
+    if (nt1 <= 2) return launch_train<2, true>(a, s);
+    if (nt1 <= 4) return launch_train<4, true>(a, s);
+    return launch_train<8, true>(a, s);
+  }
+  if (nt1 <= 2) return launch_train<2, false>(a, s);
+  if (nt1 <= 4) return launch_train<4, false>(a, s);
+  return launch_train<8, false>(a, s);
 }

@@ -287,9 +287,56 @@ __device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, con
 
 // synthetic env step for env n; called by ONE wave.  act: float32 clipped actions (LDS or global).
 // Returns reward / done in every lane; writes env.s, t_ep, step_count.  s_old: float64 previous state (LDS copy).
+// observation an env (re)starts from: the synthetic envs draw it from their stream, LapGridWorld always starts in cell 0
+__device__ __forceinline__ double env_reset_value(const icrl_env_t& e, uint32_t key, uint32_t ctr, int i) {
+  if (e.reward_form >= 2) return -1.0;   // ((0 - 0) * 2) / 40 - 1
+  return (unit_uniform(key, ctr, (uint32_t)(e.obs_dim + i)) - 0.5) * 0.2;
+}
+
+// LapGridWorld / ConstrainedLapGridWorld (ref: custom_envs/custom_envs/envs/lap_grid_world.py:62-119,197-240; spec:
+// oracle/lap_grid.py): 40 cells, coins worth 3 at 5/15/25/35, action 0 forward / 1 backward, 200-step episodes.
+// The state IS the observation 2*pos/40 - 1 (float64), so the cell index is recovered exactly by rounding.
+__device__ __forceinline__ void lap_grid_step_wave(const icrl_env_t& e, int n, const double* s_old, const float* act,
+                                                   uint32_t& ctr_io, int& tep_io, double* s_new_lds, double& reward,
+                                                   int& done) {
+  const int lane = threadIdx.x & 63;
+  const int pos_old = (int)llrint((s_old[0] + 1.0) * 20.0);
+  const int ac = (int)act[0];
+  int pos = pos_old, d = 0;
+  double rew;
+  if (ac == 0) {
+    pos = pos_old + 1 == 40 ? 0 : pos_old + 1;
+    rew = (pos % 10 == 5) ? 3.0 : 0.0;
+  } else if (e.reward_form == 3) {   // constrained: moving backward is penalised and ends the episode
+    rew = -1.0;
+    d = 1;
+  } else {
+    pos = pos_old == 0 ? 39 : pos_old - 1;
+    rew = (pos % 10 == 5) ? 3.0 : 0.0;
+  }
+  const int tep = tep_io + 1;
+  if (tep >= e.max_steps) d = 1;
+  if (d) pos = 0;
+  const double v = ((double)pos * 2.0) / 40.0 - 1.0;
+  tep_io = d ? 0 : tep;
+  ctr_io = ctr_io + 1u;
+  if (lane == 0) {
+    e.s[n] = v;
+    if (s_new_lds != nullptr) s_new_lds[0] = v;
+    e.t_ep[n] = tep_io;
+    e.step_count[n] = ctr_io;
+  }
+  reward = rew;
+  done = d;
+}
+
 __device__ __forceinline__ void env_step_wave(const icrl_env_t& e, int n, const double* s_old, const float* act,
                                               uint32_t key, uint32_t& ctr_io, int& tep_io, double* s_new_lds,
                                               double& reward, int& done) {
+  if (e.reward_form >= 2) {
+    lap_grid_step_wave(e, n, s_old, act, ctr_io, tep_io, s_new_lds, reward, done);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int O = e.obs_dim, A = e.act_dim;
   double a[MAX_ACT];
@@ -333,7 +380,7 @@ __device__ __forceinline__ void env_step_wave(const icrl_env_t& e, int n, const 
     const int i = lane + r * WAVE;
     if (i < O) {
       double v = ns[r];
-      if (d) v = (unit_uniform(key, ctr + 1u, (uint32_t)(O + i)) - 0.5) * 0.2;   // auto-reset draw
+      if (d) v = env_reset_value(e, key, ctr + 1u, i);   // auto-reset draw
       e.s[(size_t)n * O + i] = v;
       if (s_new_lds != nullptr) s_new_lds[i] = v;
     }
@@ -801,7 +848,7 @@ __global__ void env_reset_kernel(icrl_env_t e) {
   const int O = e.obs_dim;
   if (idx < e.n_envs * O) {
     const int n = idx / O, i = idx % O;
-    e.s[idx] = (unit_uniform(e.key[n], e.step_count[n], (uint32_t)(O + i)) - 0.5) * 0.2;
+    e.s[idx] = env_reset_value(e, e.key[n], e.step_count[n], i);
     if (i == 0) e.t_ep[n] = 0;
   }
 }
@@ -848,7 +895,7 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
   for (int i = tid; i < MAX_OBS; i += 192) sh.x[i] = 0.f;
   if (tid < O) {
     double v = a.env.s[(size_t)n * O + tid];
-    if (a.do_reset) v = (unit_uniform(e_key, e_ctr, (uint32_t)(O + tid)) - 0.5) * 0.2;
+    if (a.do_reset) v = env_reset_value(a.env, e_key, e_ctr, tid);
     sh.s_new[tid] = v;
   }
   if (a.do_reset) e_tep = 0;

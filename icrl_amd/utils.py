@@ -141,12 +141,13 @@ def compute_kl(agent_2, observations, actions, agent_1=None):
 # ---- on-disk artefacts -------------------------------------------------------------------------------------------------------
 def load_expert_data(expert_path, num_rollouts):
     """ref: icrl/icrl.py:25-43 — `files/EXPERT/rollouts/{i}.pkl` dicts(observations, actions, rewards, lengths); also accepts the
-    re-packed fixture `<expert_path>.npz` (tests/golden/expert_hc.npz: 500-step rollouts concatenated)."""
+    re-packed fixtures `<expert_path>.npz` (tests/golden/expert_hc.npz: 500-step rollouts concatenated; expert_lgw.npz carries
+    per-rollout `lengths`)."""
     if str(expert_path).endswith(".npz"):
         d = np.load(expert_path)
-        L = 500
-        obs, acs = d["observations"][: num_rollouts * L], d["actions"][: num_rollouts * L]
-        return (obs, acs), float("nan")
+        rows = int(np.sum(d["lengths"][:num_rollouts])) if "lengths" in d.files else num_rollouts * 500
+        mean_reward = float(np.mean(d["rewards"][:num_rollouts])) if "rewards" in d.files else float("nan")
+        return (d["observations"][:rows], d["actions"][:rows]), mean_reward
     rewards = []
     obs, acs = [], []
     for i in range(num_rollouts):
@@ -170,6 +171,7 @@ def load_expert_agent(path, device="cuda"):
     sd = load_policy_state_dict(path)
     obs_dim = int(np.asarray(sd["mlp_extractor.policy_net.0.weight"]).shape[1])
     act_dim = int(np.asarray(sd["action_net.weight"]).shape[0])
-    pol = ActorTwoCriticsPolicy(spaces.Box(-np.inf, np.inf, (obs_dim,), np.float64), spaces.Box(-1.0, 1.0, (act_dim,), np.float32), device=device)
+    act_space = spaces.Box(-1.0, 1.0, (act_dim,), np.float32) if "log_std" in sd else spaces.Discrete(act_dim)
+    pol = ActorTwoCriticsPolicy(spaces.Box(-np.inf, np.inf, (obs_dim,), np.float64), act_space, device=device)
     pol.load_state_dict(sd)
     return types.SimpleNamespace(policy=pol)

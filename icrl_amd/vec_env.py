@@ -22,17 +22,24 @@ import torch
 from . import _lib, spaces
 from .structs import EnvT, NormT, p
 
-KINDS = {"hc": (18, 6, 1000, 0), "ant": (113, 8, 500, 1)}   # obs, act, max_episode_steps, reward form
-ENV_IDS = {  # reference gym ids (custom_envs/__init__.py:43-57,194-224) -> (kind, wall_terminate, broken)
+# kind -> obs, act (width of the action vector handed to the env), max_episode_steps, reward form (icrl_env_t.reward_form)
+KINDS = {"hc": (18, 6, 1000, 0), "ant": (113, 8, 500, 1),
+         # LapGridWorld / ConstrainedLapGridWorld restated exactly (custom_envs/envs/lap_grid_world.py:29-240): Discrete(2)
+         "lgw": (1, 1, 200, 2), "clgw": (1, 1, 200, 3)}
+DISCRETE_ACTIONS = {"lgw": 2, "clgw": 2}
+ENV_IDS = {  # reference gym ids (custom_envs/__init__.py:43-57,194-224,357-370) -> (kind, early termination, broken)
     "HCWithPos-v0": ("hc", False, False), "HCWithPosTest-v0": ("hc", True, False),
     "AntWall-v0": ("ant", False, False), "AntWallTest-v0": ("ant", True, False),
     "AntWallBroken-v0": ("ant", False, True), "AntWallBrokenTest-v0": ("ant", True, True),
+    "LGW-v0": ("lgw", False, False), "CLGW-v0": ("clgw", True, False),
 }
 
 
 def dynamics_matrix(kind):
     """B ~ N(0, 0.05^2) drawn once from RandomState(1234)."""
     o, a, _, _ = KINDS[kind]
+    if kind in DISCRETE_ACTIONS:
+        return np.zeros((o, a), np.float64)      # no linear dynamics: the grid world is stepped exactly
     return (np.random.RandomState(1234).randn(o, a) * 0.05).astype(np.float64)
 
 
@@ -116,14 +123,18 @@ def _as_device_f32(x, device):
 
 
 class HipSynthVecEnv(VecEnv):
-    """N synthetic HCWithPos-/AntWall-shaped envs stepped by one kernel launch; float64 state in HBM."""
+    """N synthetic HCWithPos-/AntWall-shaped envs (or exact LapGridWorlds) stepped by one kernel launch; float64 state in HBM."""
 
     def __init__(self, n_envs, kind="hc", seed=0, env_index_offset=0, wall_terminate=False, broken=False, device="cuda"):
         self.kind, self.device = kind, torch.device(device)
         o, a, ms, rf = KINDS[kind]
         self.obs_dim, self.act_dim, self.max_steps, self.reward_form = o, a, ms, rf
         self.wall_terminate, self.broken = bool(wall_terminate), bool(broken)
-        super().__init__(n_envs, spaces.Box(-np.inf, np.inf, (o,), np.float64), spaces.Box(-1.0, 1.0, (a,), np.float32))
+        if kind in DISCRETE_ACTIONS:
+            # ref: lap_grid_world.py:50-53 — Box(0, 40) float32 observation space (the env itself emits 2 pos / 40 - 1)
+            super().__init__(n_envs, spaces.Box(0.0, 40.0, (o,), np.float32), spaces.Discrete(DISCRETE_ACTIONS[kind]))
+        else:
+            super().__init__(n_envs, spaces.Box(-np.inf, np.inf, (o,), np.float64), spaces.Box(-1.0, 1.0, (a,), np.float32))
         dev = self.device
         self.B = torch.as_tensor(dynamics_matrix(kind), device=dev)
         self.s = torch.zeros(n_envs, o, dtype=torch.float64, device=dev)

@@ -34,7 +34,9 @@ extern "C" {
  * custom_envs/envs/half_cheetah.py:138-195, ant.py:40-108): float64 state, time-limit dones, auto-reset. */
 typedef struct {
   int32_t n_envs, obs_dim, act_dim, max_steps;
-  int32_t reward_form;    /* 0: |dx|/dt - 0.1|a|^2 (HC)   1: |xy| + 1 - 0.5|a|^2 (Ant) */
+  int32_t reward_form;    /* 0: |dx|/dt - 0.1|a|^2 (HC)   1: |xy| + 1 - 0.5|a|^2 (Ant)
+                           * 2: LapGridWorld, 3: ConstrainedLapGridWorld (custom_envs/envs/lap_grid_world.py:62-240;
+                           *    obs_dim 1, act_dim 1 = the Discrete(2) action index as a float; B / key unused) */
   int32_t wall_terminate; /* "Test" variants: done & reward 0 when obs[0] <= -3 */
   int32_t broken;         /* AntWallBroken: action[4:] = 0 */
   int32_t _pad;

@@ -442,6 +442,98 @@ def g9_learn_iteration():
          ret_rms_var=env.ret_rms.var, cost_rms_var=env.cost_rms.var)
 
 
+def g10_lap_grid():
+    """configs[0]: the reference's LapGridWorld / ConstrainedLapGridWorld stepped through gym.make + DummyVecEnv against the
+    oracle restatement, then one learn() of the reference with a Categorical policy (actions and permutations recorded)
+    against the CPU port teacher-forced with the same actions."""
+    print("G10 LapGridWorld env + discrete-action learn()")
+    import custom_envs  # noqa: F401  (registers LGW-v0 / CLGW-v0 with the gym stand-in)
+    from stable_baselines3.common.vec_env import DummyVecEnv
+    from oracle.lap_grid import LapGridVecEnv
+    out = {}
+    rng = np.random.RandomState(11)
+    for env_id, constrained, p_back in (("LGW-v0", False, 0.3), ("CLGW-v0", True, 0.01)):
+        N, S = 3, 700
+        ref = DummyVecEnv([(lambda: gym.make(env_id)) for _ in range(N)])
+        mine = LapGridVecEnv(N, constrained=constrained)
+        acts = (rng.rand(S, N) < p_back).astype(np.int64)
+        o_r, o_m = ref.reset(), mine.reset()
+        assert maxdiff(o_r, o_m) == 0.0
+        obs, rew, done = [], [], []
+        for t in range(S):
+            o_r, r_r, d_r, _ = ref.step(acts[t])
+            o_m, r_m, d_m = mine.step(acts[t])
+            assert maxdiff(o_r, o_m.astype(np.float32)) == 0.0 and maxdiff(r_r, r_m) == 0.0 and np.array_equal(d_r, d_m), (env_id, t)
+            obs.append(o_m.copy()); rew.append(r_m.copy()); done.append(d_m.copy())
+        k = env_id.split("-")[0].lower()
+        out.update({f"{k}/actions": acts, f"{k}/obs": np.array(obs), f"{k}/rew": np.array(rew), f"{k}/done": np.array(done)})
+        print(f"  {env_id}: oracle == reference over {S} steps x {N} envs ({int(np.sum(done))} episode ends)")
+    # ---- learn() with the reference's classes on LGW-v0 (normalisation switched off as in README.md:25: -dno -dnr -dnc)
+    N, T = 2, 64
+    env = DummyVecEnv([(lambda: gym.make("LGW-v0")) for _ in range(N)])
+    env = VecCostWrapper(env)
+    env = VecNormalizeWithCost(env, training=True, norm_obs=False, norm_reward=False, norm_cost=False)
+    th.manual_seed(321)
+    cn = ConstraintNet(**_cn_kwargs(1, 2, [20], None, None, is_discrete=True))
+    env.set_cost_function(cn.cost_function)
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, batch_size=16, n_epochs=3, target_kl=0.01, penalty_initial_value=1,
+                          penalty_learning_rate=0.1, budget=0.0, seed=3, device="cpu", verbose=0, ent_coef=0.01,
+                          policy_kwargs=dict(net_arch=[dict(pi=[64, 64], vf=[64, 64], cvf=[64, 64])]))
+    sd0 = _sd_np(agent.policy.state_dict()); cn0 = _sd_np(cn.network.state_dict())
+    actions, perms = [], []
+    Cat = th.distributions.Categorical
+    orig_sample, orig_perm = Cat.sample, np.random.permutation
+
+    def rec_sample(self, sample_shape=th.Size()):
+        a = orig_sample(self, sample_shape); actions.append(a.numpy().copy()); return a
+
+    def rec_perm(n):
+        p = orig_perm(n); perms.append(p.copy()); return p
+    Cat.sample, np.random.permutation = rec_sample, rec_perm
+    try:
+        agent.learn(total_timesteps=2 * N * T, cost_function="cost")
+    finally:
+        Cat.sample, np.random.permutation = orig_sample, orig_perm
+    logs = {k: float(v) for k, v in ref_logger.Logger.CURRENT.name_to_value.items() if k.startswith("train/")}
+    rb = agent.rollout_buffer
+    acts = np.array(actions).reshape(2, T, N)
+    print("  reference: early_stop_epoch", logs["train/early_stop_epoch"], "nu", logs["train/nu"], "perms drawn", len(perms))
+    stack = o_loop.make_stack(N, "lgw", 0, norm_obs=False, norm_reward=False, norm_cost=False)
+    ocn = o_nets.CostNet(1, 2, [20], True, None, None, 20, None, None)
+    ocn.load_state_dict(cn.network.state_dict())
+    stack.cost_fn = ocn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=T, batch_size=16, n_epochs=3, target_kl=0.01, seed=3, discrete=True, ent_coef=0.01)
+    port.policy.load_state_dict({k: th.as_tensor(v) for k, v in sd0.items()})
+    port.num_timesteps = 0
+    port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
+    per_iter, k, worst = [], 0, {}
+    for it in range(2):
+        b = port.collect_rollouts(acts[it].astype(np.float32))    # uniforms 0.0 / 1.0 force action 0 / 1 (two classes)
+        remaining = perms[k:]
+        res = port.train(lambda e, r=remaining: r[e])
+        used = res["train/early_stop_epoch"] + 1 if res["train/early_stop_epoch"] < 3 else 3
+        per_iter.append(np.array(remaining[:used])); k += used
+    assert k == len(perms), (k, len(perms))
+    flat = lambda a: a.reshape(N, T, -1).swapaxes(0, 1).reshape(T, N, -1) if a.shape[0] == N * T else a.reshape(T, N, -1)
+    keys = ("observations", "orig_observations", "new_observations", "actions", "rewards", "costs", "orig_costs", "dones",
+            "log_probs", "reward_values", "cost_values", "reward_advantages", "cost_advantages", "reward_returns", "cost_returns")
+    for key in keys:
+        worst[key] = maxdiff(flat(getattr(rb, key)), getattr(b, key).reshape(T, N, -1))
+    for key in ("train/nu", "train/average_cost", "train/approx_kl", "train/loss", "train/policy_gradient_loss", "train/entropy_loss"):
+        worst[key] = abs(logs[key] - float(res[key]))
+    for kname, p in port.policy.params.items():
+        worst["w/" + kname] = maxdiff(p.detach().numpy(), agent.policy.state_dict()[kname].numpy())
+    print("  port vs reference, max abs deviation:", {k: v for k, v in worst.items() if v > 0} or "all exactly 0")
+    assert max(worst.values()) < 1e-5, worst
+    pad = lambda a: np.concatenate([a, -np.ones((3 - a.shape[0],) + a.shape[1:], a.dtype)]) if a.shape[0] < 3 else a
+    save("g10_lap_grid", **out, learn_actions=acts, perms0=pad(per_iter[0]), perms1=pad(per_iter[1]),
+         n_perms=np.array([len(per_iter[0]), len(per_iter[1])]),
+         **{f"w0/{k}": v for k, v in sd0.items()}, **{f"cn/{k}": v for k, v in cn0.items()},
+         **{f"w1/{k}": v.numpy() for k, v in agent.policy.state_dict().items()},
+         **{f"buf/{k}": flat(getattr(rb, k)) for k in keys},
+         **{"log/" + k.split("/")[1]: v for k, v in logs.items()})
+
+
 def fixtures_expert():
     """Re-pack the expert artefacts the runs need (data, not source): HC expert rollouts 0-9 and the expert agent's policy."""
     print("expert fixtures")
@@ -453,11 +545,23 @@ def fixtures_expert():
     sd = th.load(io.BytesIO(z.read("policy.pth")))
     save("expert_hc", observations=np.concatenate(obs).astype(np.float32), actions=np.concatenate(acs).astype(np.float32),
          **{f"policy/{k}": v.numpy() for k, v in sd.items()})
+    # LapGridWorld: the reference ships the expert agent but no rollouts (icrl/expert_data/LGW/files has no EXPERT/rollouts);
+    # they are produced the way icrl/run_policy.py does — 20 sampled episodes of that agent — on the restated env.
+    z = zipfile.ZipFile(f"{REF}/icrl/expert_data/LGW/files/best_model.zip")
+    sd = th.load(io.BytesIO(z.read("policy.pth")))
+    stack = o_loop.make_stack(1, "lgw", 0, training=False, norm_obs=False, norm_reward=False, norm_cost=False)
+    port = o_loop.PortAgent(stack, seed=0, discrete=True)
+    port.policy.load_state_dict(sd)
+    th.manual_seed(0)
+    oo, o, a, r, l = o_loop.sample_from_agent(port, stack, 20)
+    print("  LGW expert: episode rewards", sorted(set(r.tolist())), "backward moves", int(np.sum(a)))
+    save("expert_lgw", observations=oo.astype(np.float64), actions=a.astype(np.float32), rewards=r, lengths=l,
+         **{f"policy/{k}": v.numpy() for k, v in sd.items()})
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g9", "expert"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g9", "g10", "expert"]
     table = dict(g1=g1_gae, g2=g2_cost_function, g3=g3_vecnormalize, g4=g4_ppo_minibatch, g5=g5_dual,
-                 g6=g6_constraint_net_train, g9=g9_learn_iteration, expert=fixtures_expert)
+                 g6=g6_constraint_net_train, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
     for w in which:
         table[w]()

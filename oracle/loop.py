@@ -23,6 +23,7 @@ from .cn import cn_train
 from .gae import dual_gae
 from .nets import CostNet, TwoCriticPolicy
 from .ppo import Dual, ppo_lag_train
+from .lap_grid import LapGridVecEnv
 from .synth_env import SynthVecEnv
 
 F32, F64 = np.float32, np.float64
@@ -242,7 +243,10 @@ def compute_kl(policy_2, observations, actions, policy_1=None):
 
 def make_stack(n_envs, kind, seed, *, training=True, norm_reward=True, norm_cost=True, norm_obs=True,
                cost_fn=None, wall_terminate=False, broken=False, reward_gamma=0.99, cost_gamma=0.99):
-    env = SynthVecEnv(n_envs, kind, seed, wall_terminate=wall_terminate, broken=broken)
+    if kind in ("lgw", "clgw"):
+        env = LapGridVecEnv(n_envs, constrained=(kind == "clgw"))
+    else:
+        env = SynthVecEnv(n_envs, kind, seed, wall_terminate=wall_terminate, broken=broken)
     norm = stats.NormState(n_envs, env.obs_dim, training=training, norm_obs=norm_obs, norm_reward=norm_reward,
                            norm_cost=norm_cost, reward_gamma=reward_gamma, cost_gamma=cost_gamma)
     return EnvStack(env, norm, cost_fn)

@@ -132,7 +132,7 @@ class TwoCriticPolicy:
             logp_all = mean - mean.logsumexp(dim=-1, keepdim=True)
             a = actions.long().flatten()
             log_prob = logp_all.gather(1, a.reshape(-1, 1)).squeeze(1)
-            p = logp_all.exp()
+            p = th.softmax(logp_all, dim=-1)        # torch.distributions.Categorical: probs = softmax(normalised logits)
             entropy = -(logp_all * p).sum(-1)
             return v_r, v_c, log_prob, entropy
         return v_r, v_c, self.gaussian_log_prob(mean, actions), self.gaussian_entropy(mean)

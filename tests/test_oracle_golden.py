@@ -193,3 +193,38 @@ def test_g9_learn_iteration_teacher_forced(golden):
     oo, o, a, r, l = o_loop.sample_from_agent(port, s1, 2, g["sample_noise"])
     assert np.array_equal(l, g["sample_lengths"]) and np.array_equal(oo, g["sample_orig_obs"])
     assert np.array_equal(a, g["sample_actions"]) and np.allclose(r, g["sample_rewards"], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("env_id", ["lgw", "clgw"])
+def test_g10_lap_grid_env(golden, env_id):
+    """LapGridWorld / ConstrainedLapGridWorld restatement == the reference's gym envs behind DummyVecEnv (auto-reset)."""
+    from oracle.lap_grid import LapGridVecEnv
+    g = golden("g10_lap_grid")
+    acts = g[env_id + "/actions"]
+    env = LapGridVecEnv(acts.shape[1], constrained=(env_id == "clgw"))
+    assert np.array_equal(env.reset(), -np.ones((acts.shape[1], 1)))
+    for t in range(acts.shape[0]):
+        o, r, d = env.step(acts[t])
+        assert np.array_equal(o, g[env_id + "/obs"][t]) and np.array_equal(r, g[env_id + "/rew"][t]) and np.array_equal(d, g[env_id + "/done"][t])
+
+
+def test_g10_discrete_learn_teacher_forced(golden):
+    """configs[0] shapes: Categorical policy, one-hot cost net, normalisation off — port == reference bit for bit."""
+    g = golden("g10_lap_grid")
+    acts = g["learn_actions"]
+    _, T, N = acts.shape
+    stack = o_loop.make_stack(N, "lgw", 0, norm_obs=False, norm_reward=False, norm_cost=False)
+    cn = o_nets.CostNet(1, 2, [20], True, None, None, 20, None, None)
+    cn.load_state_dict(_sub(g, "cn/"))
+    stack.cost_fn = cn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=T, batch_size=16, n_epochs=3, target_kl=0.01, seed=3, discrete=True, ent_coef=0.01)
+    port.policy.load_state_dict(_sub(g, "w0/"))
+    perms = [g["perms0"][:g["n_perms"][0]], g["perms1"][:g["n_perms"][1]]]
+    port.learn(2 * N * T, noise_fn=lambda it: acts[it].astype(np.float32), perms_fn=lambda it: (lambda e, p=perms[it]: p[e]))
+    for k in ("observations", "actions", "rewards", "costs", "orig_costs", "dones", "log_probs", "reward_values", "cost_values",
+              "reward_advantages", "cost_advantages", "reward_returns", "cost_returns"):
+        assert np.array_equal(getattr(port.buf, k).reshape(T, N, -1), g["buf/" + k]), k
+    for k, p in port.policy.params.items():
+        assert np.array_equal(p.detach().numpy(), g["w1/" + k]), k
+    assert port.logs["train/nu"] == g["log/nu"].item()
+    assert port.logs["train/entropy_loss"] == pytest.approx(g["log/entropy_loss"].item(), abs=1e-7)
