@@ -33,6 +33,8 @@ class _PeriodicEval:
     def init_callback(self, model): self.model = model
     def on_training_start(self, *a): pass
     def on_rollout_start(self): pass
+    def update_locals(self, locals_): pass
+    def on_step(self): return True
     def on_training_end(self): pass
 
     def on_rollout_end(self):
@@ -82,9 +84,8 @@ def cpg(config, log=print):
                                             obs_select_dim=config.cn_obs_select_dim, acs_select_dim=config.cn_acs_select_dim,
                                             clip_obs=None, obs_mean=None, obs_var=None)
         cost_function = constraint_net.cost_function
-    if not isinstance(getattr(cost_function, "__self__", None), ConstraintNet):
-        raise NotImplementedError("cpg on the device path needs a ConstraintNet cost (--cn_path); analytic costs run through the "
-                                  "generic VecCostWrapper callable path only")
+    # a ConstraintNet cost runs inside the fused rollout launch; null_cost / the analytic true cost (numpy callables) go
+    # through VecCostWrapper's callable branch and the per-step rollout loop (PPOLagrangian._collect_rollouts_stepped)
     train_env.set_cost_function(cost_function)
     eval_env.set_cost_function(cost_function)
     model = PPOLagrangian(
@@ -104,7 +105,9 @@ def cpg(config, log=print):
         action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"))
     cb = _PeriodicEval(model, eval_env, int(getattr(config, "eval_every_rollouts", 0)), config.save_dir,
                        get_true_cost_function(config.eval_env_id), log if (config.verbose > 0 and rank == 0) else None)
-    model.learn(total_timesteps=int(config.timesteps), cost_function="cost", callback=cb)
+    # ref: icrl/cpg.py:201-203 — `-cis None` hands the callable itself to learn() (costs evaluated outside the env chain)
+    learn_cost = config.cost_info_str if config.cost_info_str is not None else cost_function
+    model.learn(total_timesteps=int(config.timesteps), cost_function=learn_cost, callback=cb)
     if config.save_dir and rank == 0:
         torch.save(model.policy.state_dict(), os.path.join(config.save_dir, "final_model_policy.pth"))
     return model, cb.history

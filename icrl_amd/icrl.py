@@ -77,8 +77,6 @@ def setup(config):
                         delta_p_ema_alpha=config.proportional_cost_ema_alpha, delta_d_ema_alpha=config.derivative_cost_ema_alpha),
         policy_kwargs=dict(net_arch=utils.get_net_arch(config)),
         action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"))
-    if config.warmup_timesteps is not None:
-        raise NotImplementedError("--warmup_timesteps (null_cost warm-up) is not on the benchmarked path")
     st = dict(config=config, rank=rank, world=world, train_env=train_env, sampling_env=sampling_env, eval_env=eval_env,
               constraint_net=constraint_net, create_nominal_agent=create_nominal_agent, agent=create_nominal_agent(),
               expert_agent=expert_agent, true_cost_function=get_true_cost_function(config.eval_env_id),
@@ -86,6 +84,9 @@ def setup(config):
               d_expert_acs=torch.as_tensor(np.asarray(expert_acs), device=dev),
               timesteps=0., start_time=time.time(),
               best=dict(reward=-np.inf, cost=np.inf, fkl=np.inf, rkl=np.inf))
+    if config.warmup_timesteps is not None:    # ref: icrl/icrl.py:185-193 — no cost is incurred during the warm-up
+        st["agent"].learn(total_timesteps=config.warmup_timesteps, cost_function=null_cost)
+        st["timesteps"] += st["agent"].num_timesteps
     if world > 1:     # common history of the running moments for the exact cross-rank merge
         st["rms_list"] = [train_env.obs_rms, train_env.ret_rms, train_env.cost_rms]
         st["rms_prev"] = [D.moments_to_sums(r.mean, r.var, r.count) for r in st["rms_list"]]

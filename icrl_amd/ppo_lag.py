@@ -131,7 +131,7 @@ class PPOLagrangian:
         assert self._last_obs is not None, "No previous observation was provided"
         chain = self._fused_chain()
         if chain is None or not isinstance(cost_function, str) or n_rollout_steps != rollout_buffer.buffer_size:
-            raise NotImplementedError("generic (host-stepped) rollout path is not wired yet; use the device env stack")
+            return self._collect_rollouts_stepped(env, callback, rollout_buffer, n_rollout_steps, cost_function, noise)
         rollout_buffer.reset()
         if callback is not None:
             callback.on_rollout_start()
@@ -161,6 +161,46 @@ class PPOLagrangian:
         cw.previous_obs = senv.s
         self._last_original_obs = senv.s
         self._last_dones = self._ag["last_dones"]
+        if callback is not None:
+            callback.on_rollout_end()
+        return True
+
+    def _collect_rollouts_stepped(self, env, callback, rollout_buffer, n_rollout_steps, cost_function, noise=None):
+        """The reference's per-step loop, kept for everything the fused launch does not cover: a callable `cost_function`
+        (warm-up with null_cost, icrl/icrl.py:187-193; costs are then evaluated on the observation AFTER the step and are not
+        normalised, on_policy_algorithm.py:392-394), an env cost that is an arbitrary Python function (cpg with the analytic
+        cost), partial rollouts.  One launch per call of the fine-grained C-ABI entry points; not the benchmarked path."""
+        rollout_buffer.reset()
+        if callback is not None:
+            callback.on_rollout_start()
+        is_box = isinstance(self.action_space, spaces.Box)
+        norm_env = env if isinstance(env, VecNormalizeWithCost) else None
+        v_r = v_c = dones = None
+        for t in range(n_rollout_steps):
+            actions, v_r, v_c, log_probs = self.policy.forward(self._last_obs, noise=None if noise is None else noise[t])
+            clipped = self.policy.last_clipped if is_box else actions
+            new_obs, rewards, dones, infos = env.step(clipped)
+            orig_obs = env.get_original_obs() if norm_env is not None else new_obs
+            if isinstance(cost_function, str):
+                costs = infos.batch.get(cost_function) if hasattr(infos, "batch") else None
+                if costs is None:
+                    costs = torch.zeros(env.num_envs, device=self.device)
+                orig_costs = env.get_original_cost() if norm_env is not None and norm_env.old_cost is not None else costs
+            else:    # numpy in / numpy out like the reference's callables (true_constraint_net.py)
+                costs = np.asarray(cost_function(orig_obs.cpu().numpy().copy(), clipped.cpu().numpy()), dtype=np.float32)
+                orig_costs = costs
+            self.num_timesteps += env.num_envs
+            if callback is not None and hasattr(callback, "on_step"):
+                if hasattr(callback, "update_locals"):
+                    callback.update_locals(locals())
+                if callback.on_step() is False:
+                    return False
+            rollout_buffer.add(self._last_obs, self._last_original_obs, new_obs, orig_obs, actions, rewards, costs, orig_costs,
+                               self._last_dones, v_r, v_c, log_probs)
+            self._last_obs, self._last_original_obs, self._last_dones = new_obs.contiguous(), orig_obs, dones
+        self._ag["last_dones"].copy_(torch.as_tensor(dones, device=self.device).to(torch.uint8))
+        self._last_dones = self._ag["last_dones"]
+        rollout_buffer.compute_returns_and_advantage(v_r, v_c, dones)
         if callback is not None:
             callback.on_rollout_end()
         return True

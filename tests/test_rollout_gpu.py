@@ -213,3 +213,99 @@ def test_fused_rollout_vs_port(kind, N, T):
               "log_probs", "reward_values", "cost_values", "reward_advantages", "cost_advantages", "reward_returns", "cost_returns"):
         got, ref = getattr(rb, k).cpu().numpy().reshape(T, N, -1), getattr(b, k).reshape(T, N, -1)
         assert np.allclose(got, ref, rtol=5e-4, atol=5e-5), (k, np.abs(got - ref).max())
+
+
+def _pair_of_agents(N, T, seed):
+    from icrl_amd.ppo_lag import PPOLagrangian
+    from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
+    from icrl_amd.constraint_net import ConstraintNet
+    out = []
+    lo = -np.ones(6, np.float32)
+    for _ in range(2):
+        torch.manual_seed(seed)
+        env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, "hc", seed)))
+        cn = ConstraintNet(18, 6, [20], None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
+        env.set_cost_function(cn.cost_function)
+        out.append((PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=seed), env, cn))
+    out[1][2].load_state_dict(out[0][2].state_dict())
+    out[1][0].policy.load_state_dict(out[0][0].policy.state_dict())
+    return out
+
+
+_BUF_KEYS = ("observations", "orig_observations", "new_observations", "new_orig_observations", "actions", "rewards", "costs",
+             "orig_costs", "dones", "log_probs", "reward_values", "cost_values", "reward_advantages", "cost_advantages",
+             "reward_returns", "cost_returns")
+
+
+def test_stepped_rollout_equals_fused_rollout():
+    """the per-step loop over the fine-grained entry points (the reference's own structure, on_policy_algorithm.py:340-421)
+    and the fused launch sequence are two drivers of the same kernels: identical buffers and normaliser statistics."""
+    N, T = 16, 48
+    (a_f, e_f, _), (a_s, e_s, _) = _pair_of_agents(N, T, 11)
+    noise = torch.as_tensor(np.random.RandomState(3).randn(2, T, N, 6).astype(np.float32), device="cuda")
+    a_f._setup_learn(2 * N * T); a_s._setup_learn(2 * N * T)
+    for it in range(2):
+        a_f.collect_rollouts(e_f, None, a_f.rollout_buffer, T, "cost", noise=noise[it])
+        a_s._collect_rollouts_stepped(e_s, None, a_s.rollout_buffer, T, "cost", noise=noise[it])
+        for k in _BUF_KEYS:
+            got, ref = getattr(a_s.rollout_buffer, k).cpu().numpy(), getattr(a_f.rollout_buffer, k).cpu().numpy()
+            assert np.allclose(got, ref, rtol=2e-5, atol=2e-6), (it, k, np.abs(got - ref).max())
+    assert np.allclose(e_s.obs_rms.mean, e_f.obs_rms.mean, rtol=0, atol=1e-12) and abs(e_s.cost_rms.var - e_f.cost_rms.var) < 1e-12
+    assert a_s.num_timesteps == a_f.num_timesteps == 2 * N * T
+
+
+def test_callable_cost_function_warmup_semantics():
+    """learn(cost_function=null_cost) (ref: icrl/icrl.py:187-193, on_policy_algorithm.py:392-394): the env chain still steps
+    with the cost net (cost_rms keeps updating), the buffer's costs come from the callable on (obs AFTER the step, clipped
+    action), un-normalised; a second callable checks that pairing."""
+    from icrl_amd.true_constraint_net import null_cost
+    N, T = 8, 40
+    (a_f, e_f, _), (a_s, e_s, _) = _pair_of_agents(N, T, 5)
+    noise = torch.as_tensor(np.random.RandomState(4).randn(T, N, 6).astype(np.float32), device="cuda")
+    a_f._setup_learn(N * T); a_s._setup_learn(N * T)
+    a_f.collect_rollouts(e_f, None, a_f.rollout_buffer, T, "cost", noise=noise)
+    seen = []
+
+    def probe(obs, acs):
+        seen.append((obs.copy(), acs.copy()))
+        return (obs[..., 0] > 0).astype(np.float32) + np.abs(acs).max(-1)
+
+    a_s.collect_rollouts(e_s, None, a_s.rollout_buffer, T, probe, noise=noise)
+    rf, rs = a_f.rollout_buffer, a_s.rollout_buffer
+    for k in ("observations", "new_orig_observations", "actions", "rewards", "log_probs", "reward_values", "cost_values",
+              "reward_advantages"):
+        assert np.allclose(getattr(rs, k).cpu().numpy(), getattr(rf, k).cpu().numpy(), rtol=2e-5, atol=2e-6), k
+    assert abs(e_s.cost_rms.var - e_f.cost_rms.var) < 1e-12          # the wrapper chain saw the cost net's costs
+    new_orig = rs.new_orig_observations.cpu().numpy()
+    clipped = np.clip(rs.actions.cpu().numpy(), -1, 1)
+    want = (new_orig[..., 0] > 0).astype(np.float32) + np.abs(clipped).max(-1)
+    assert np.allclose(rs.costs.cpu().numpy(), want, atol=1e-6) and np.array_equal(rs.costs.cpu().numpy(), rs.orig_costs.cpu().numpy())
+    assert len(seen) == T and seen[0][0].shape == (N, 18) and seen[0][1].shape == (N, 6)
+    assert np.abs(seen[3][1]).max() <= 1.0
+    # cost GAE of the callable's costs
+    from oracle.gae import dual_gae
+    g = dual_gae(rs.rewards.cpu().numpy(), rs.costs.cpu().numpy(), rs.reward_values.cpu().numpy(), rs.cost_values.cpu().numpy(),
+                 rs.dones.cpu().numpy(), rs.reward_values.cpu().numpy()[-1],
+                 rs.cost_values.cpu().numpy()[-1], a_s._last_dones.cpu().numpy().astype(bool), 0.99, 0.95, 0.99, 0.95)
+    assert np.allclose(rs.cost_advantages.cpu().numpy(), g["cost_advantages"], rtol=1e-5, atol=1e-5)
+    # null_cost through learn(): zero costs, a full update runs
+    a_s.learn(N * T, cost_function=null_cost)
+    assert float(a_s.rollout_buffer.costs.abs().max().item()) == 0.0 and float(a_s.rollout_buffer.orig_costs.abs().max().item()) == 0.0
+    assert a_s.policy.adam_step > 0
+
+
+def test_analytic_env_cost_through_cost_wrapper():
+    """cpg without --cn_path (ref: icrl/cpg.py:52-53,109): the env cost is the analytic wall_behind(-3) on (previous raw obs,
+    action); it flows through VecCostWrapper's callable branch, cost normalisation and the stepped rollout."""
+    from icrl_amd.ppo_lag import PPOLagrangian
+    from icrl_amd.true_constraint_net import get_true_cost_function
+    from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
+    N, T = 4, 30
+    env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, "hc", 2)), norm_cost=False)
+    env.set_cost_function(lambda o, a: (o[..., 0] <= 0.0))       # threshold 0 so that both outcomes occur on this env
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=2)
+    agent.learn(N * T, cost_function="cost")
+    rb = agent.rollout_buffer
+    want = (rb.orig_observations.cpu().numpy()[..., 0] <= 0.0).astype(np.float32)
+    assert np.array_equal(rb.orig_costs.cpu().numpy(), want) and 0.0 < want.mean() < 1.0
+    assert get_true_cost_function("HCWithPosTest-v0")(np.array([[-3.5, 0.0]]), None)[0]
