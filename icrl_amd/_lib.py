@@ -35,6 +35,8 @@ SIGNATURES = {
     "icrl_cn_prepare": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "icrl_cn_train_work_floats": [c_int, c_int, c_int, c_int],
     "icrl_cn_train": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "icrl_cn_train_minibatch": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                c_void_p, c_void_p],
 }
 RESTYPES = {"icrl_cn_train_work_floats": ctypes.c_size_t}
 

@@ -150,9 +150,10 @@ class ConstraintNet:
         return out
 
     def train(self, iterations, nominal_obs, nominal_acs, episode_lengths, obs_mean=None, obs_var=None,
-              current_progress_remaining=1):
-        if self.batch_size is not None:
-            raise NotImplementedError("cn_batch_size: only the reference's default full-batch mode is on the hot path")
+              current_progress_remaining=1, perms=None):
+        """ref: constraint_net.py:137-229.  `perms` ([iterations, min(Nn, Ne)], minibatch mode only) replaces the
+        np.random.permutation draws of get() (:300-316); by default they are drawn from numpy's global generator, which is
+        afterwards left where the reference would have left it (it stops drawing once an iteration early-stops)."""
         self._update_learning_rate(current_progress_remaining)
         self.current_obs_mean, self.current_obs_var = obs_mean, obs_var
         self._refresh_consts()
@@ -175,14 +176,31 @@ class ConstraintNet:
                       float(self.regularizer_coeff), float(self.eps), float(self.target_kl_old_new), float(self.target_kl_new_old),
                       float(self.lr), 0.9, 0.999, float(self.optimizer_kwargs.get("eps", 1e-8)))
         s = self.struct()
-        _lib.check(L.icrl_cn_train(_lib.byref(s), p(self.exp_avg), p(self.exp_avg_sq), p(t_dev), p(nominal), p(expert),
-                                   nominal.shape[0], expert.shape[0], p(d_off), p(d_rowep), len(lengths), _lib.byref(hp),
-                                   p(work), p(metrics), _lib.current_stream()), "icrl_cn_train")
+        rng_state = None
+        if self.batch_size is None:
+            _lib.check(L.icrl_cn_train(_lib.byref(s), p(self.exp_avg), p(self.exp_avg_sq), p(t_dev), p(nominal), p(expert),
+                                       nominal.shape[0], expert.shape[0], p(d_off), p(d_rowep), len(lengths), _lib.byref(hp),
+                                       p(work), p(metrics), _lib.current_stream()), "icrl_cn_train")
+        else:
+            size = min(nominal.shape[0], expert.shape[0])
+            if perms is None:
+                rng_state = np.random.get_state()
+                perms = np.stack([np.random.permutation(size) for _ in range(max(iters, 1))])
+            d_perms = torch.as_tensor(np.asarray(perms)[:max(iters, 1)].astype(np.int32), device=dev).contiguous()
+            assert d_perms.shape == (max(iters, 1), size), "perms must be [iterations, min(n_nominal, n_expert)]"
+            _lib.check(L.icrl_cn_train_minibatch(_lib.byref(s), p(self.exp_avg), p(self.exp_avg_sq), p(t_dev), p(nominal), p(expert),
+                                                 nominal.shape[0], expert.shape[0], p(d_off), p(d_rowep), len(lengths),
+                                                 _lib.byref(hp), p(d_perms), int(self.batch_size), p(work), p(metrics),
+                                                 _lib.current_stream()), "icrl_cn_train_minibatch")
         self.prepare()
         m = metrics.cpu().numpy()          # the only host sync of the backward step
         self.adam_step = int(t_dev.item())
         stopped = np.nonzero(m[:iters, 0] != 0)[0]
         early_stop_itr = int(stopped[0]) if len(stopped) else iters
+        if rng_state is not None and early_stop_itr < iters:      # rewind to the reference's consumption of the stream
+            np.random.set_state(rng_state)
+            for _ in range(early_stop_itr):
+                np.random.permutation(min(nominal.shape[0], expert.shape[0]))
         last_exec = early_stop_itr - 1 if len(stopped) else iters - 1       # iteration whose loss / preds the reference reports
         last_is = min(early_stop_itr, iters - 1)
         nanrow = np.full(24, np.nan, np.float32); nanrow[6] = np.inf

@@ -3,7 +3,7 @@
 // ref: icrl/constraint_net.py:137-229 (train), :231-256 (compute_is_weights), :258-299 (prepare_data).
 //
 // Full-batch mode (batch_size None — the reference's default and every README configuration): one optimiser step per
-// iteration over ALL nominal + expert rows.  Per iteration:
+// iteration over ALL nominal + expert rows (minibatch mode: see icrl_cn_train_minibatch below).  Per iteration:
 //   cn_forward_kernel   blocks of 64 rows x 256 threads: ReLU-MLP + sigmoid forward, predictions and per-block partial sums
 //   cn_finalize_kernel  one workgroup: fixed-order reduction of the partials, per-episode float32 products of the
 //                       likelihood ratios (one wave per episode), KLs, importance weights, early-stop flag, losses
@@ -47,7 +47,7 @@ __host__ __device__ inline CnDims make_cn_dims(int D, int nh, int H1, int H2) {
 }
 
 // scalars shared between the kernels of one train() call (device floats in `work`)
-enum { SC_STOPPED = 0, SC_MEAN_W, SC_ITER, SC_COUNT = 16 };
+enum { SC_STOPPED = 0, SC_MEAN_W, SC_ITER, SC_MEAN_RATIO, SC_COUNT = 16 };
 
 struct CnTrainArgs {
   CnDims d;
@@ -71,18 +71,22 @@ struct CnTrainArgs {
   float* scal;         // [SC_COUNT]
   float* gpart;        // [nb_n + nb_e][n_params]
   float* metrics;      // [iterations][ICRL_CN_METRICS]
+  const int* mb_idx;   // minibatch mode: the batch's row indices (the SAME rows of the nominal and the expert set) ...
+  int mb_n;            // ... and their number; nb_n == nb_e == ceil(mb_n / 64) in the arguments of those launches
 };
 
 // block-level forward of CN_ROWS rows starting at row0 of `src` ([n, D]); leaves x, h1, (h2) in LDS, zeta in sm[sZ + row]
 __device__ __forceinline__ void cn_block_forward(const CnDims& d, float* sm, const float* params, const float* src, int row0,
-                                                 int n_rows_total) {
+                                                 int n_rows_total, const int* gather = nullptr) {
   const int tid = threadIdx.x;
   const int row = tid & 63, part = __builtin_amdgcn_readfirstlane(tid >> 6);
   for (int i = tid; i < d.n_params; i += CN_TH) sm[d.sW + i] = params[i];
   const int D = d.D;
   for (int i = tid; i < CN_ROWS * D; i += CN_TH) {
     const int rr = i / D, k = i % D;
-    sm[d.sX + rr * (D + 1) + k] = (row0 + rr < n_rows_total) ? src[(size_t)(row0 + rr) * D + k] : 0.f;
+    float v = 0.f;
+    if (row0 + rr < n_rows_total) v = src[(size_t)(gather ? gather[row0 + rr] : row0 + rr) * D + k];
+    sm[d.sX + rr * (D + 1) + k] = v;
   }
   __syncthreads();
   const float* W = sm + d.sW;
@@ -223,6 +227,7 @@ __global__ void __launch_bounds__(1024) cn_finalize_kernel(CnTrainArgs a, int it
     kl_no = s2 / (float)ne;
     if (a.hp.per_step) {
       const float mean_ratio = red[0][5] / Nn;
+      a.scal[SC_MEAN_RATIO] = mean_ratio;
       is_mean = (red[0][5] / mean_ratio) / Nn;
       is_max = red[0][6] / mean_ratio;
       is_min = red[0][7] / mean_ratio;
@@ -263,6 +268,91 @@ __global__ void __launch_bounds__(1024) cn_finalize_kernel(CnTrainArgs a, int it
   if (stop) a.scal[SC_STOPPED] = 1.f;
 }
 
+
+// =================================================================================================================
+// minibatch mode (cn_batch_size; ref: constraint_net.py:181-206,300-316): after the importance weights / early-stop test of
+// the iteration (cn_forward_kernel + cn_finalize_kernel over ALL rows, as above), one optimiser step per batch of the
+// permutation; the batch takes the SAME row indices from the nominal and the expert set.
+// =================================================================================================================
+// importance weight of nominal row i as fixed at the start of the iteration
+__device__ __forceinline__ float cn_row_weight(const CnTrainArgs& a, int i) {
+  if (!a.hp.importance_sampling) return 1.f;
+  if (a.hp.per_step) return ((a.preds_n[i] + a.hp.eps) / (a.start_preds[i] + a.hp.eps)) / a.scal[SC_MEAN_RATIO];
+  return a.normed[a.row_ep[i]];
+}
+
+__global__ void __launch_bounds__(CN_TH) cn_mb_forward_kernel(CnTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  if (a.scal[SC_STOPPED] != 0.f) return;
+  const CnDims& d = a.d;
+  const int blk = blockIdx.x;
+  const bool nominal = blk < a.nb_n;
+  const int row0 = (nominal ? blk : blk - a.nb_n) * CN_ROWS;
+  cn_block_forward(d, sm, a.params, nominal ? a.nominal : a.expert, row0, a.mb_n, a.mb_idx);
+  if (threadIdx.x < 64) {
+    const int row = threadIdx.x, g = row0 + row;
+    const bool valid = g < a.mb_n;
+    const float z = sm[d.sZ + row], eps = a.hp.eps;
+    const float lg = valid ? logf(z + eps) : 0.f;
+    const float w = (valid && nominal) ? cn_row_weight(a, a.mb_idx[g]) : 0.f;
+    const float bce = valid ? (nominal ? fmaxf(logf(1.f - z), -100.f) : fmaxf(logf(z), -100.f)) : 0.f;
+    const float s_log = wave_sum(lg);
+    const float s_om = wave_sum(valid ? 1.f - z : 0.f);
+    const float s_z = wave_sum(valid ? z : 0.f);
+    const float mx = wave_max(valid ? z : -INFINITY);
+    const float mn = wave_min(valid ? z : INFINITY);
+    const float s_w = wave_sum(w);
+    const float s_wl = wave_sum(w * lg);
+    const float s_b = wave_sum(bce);
+    if (row == 0) {
+      float* p = a.part + (size_t)blk * CN_NPART;
+      p[0] = s_log; p[1] = s_om; p[2] = s_z; p[3] = mx; p[4] = mn; p[5] = s_w; p[6] = s_wl; p[7] = 0.f; p[8] = s_b;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(64) cn_mb_finalize_kernel(CnTrainArgs a, int itr) {
+  if (a.scal[SC_STOPPED] != 0.f) return;
+  const int lane = threadIdx.x;
+  float red[2][9];
+  for (int set = 0; set < 2; ++set)
+    for (int s = 0; s < 9; ++s) {
+      const int b0 = set == 0 ? 0 : a.nb_n, b1 = set == 0 ? a.nb_n : a.nb_n + a.nb_e;
+      const bool is_max = s == 3, is_min = s == 4;
+      float acc = is_max ? -INFINITY : (is_min ? INFINITY : 0.f);
+      for (int b = b0 + lane; b < b1; b += 64) {
+        const float v = a.part[(size_t)b * CN_NPART + s];
+        if (is_max) acc = fmaxf(acc, v);
+        else if (is_min) acc = fminf(acc, v);
+        else acc += v;
+      }
+      red[set][s] = is_max ? wave_max(acc) : (is_min ? wave_min(acc) : wave_sum(acc));
+    }
+  if (lane != 0) return;
+  const float n = (float)a.mb_n;
+  float* m = a.metrics + (size_t)itr * ICRL_CN_METRICS;
+  const float unweighted = red[0][0] / n;
+  float nominal_loss, expert_loss, reg, loss;
+  if (a.hp.gail) {
+    nominal_loss = -(red[0][8] / n);
+    expert_loss = -(red[1][8] / n);
+    reg = 0.f;
+    loss = nominal_loss + expert_loss;
+  } else {
+    expert_loss = red[1][0] / n;
+    const float mean_w = red[0][5] / n;
+    // per-step weights are [b,1,1] against [b,1] predictions: the mean over the broadcast is mean(w) * mean(log zeta)
+    nominal_loss = (a.hp.importance_sampling && a.hp.per_step) ? mean_w * unweighted : red[0][6] / n;
+    a.scal[SC_MEAN_W] = mean_w;
+    reg = a.hp.reg_coeff * (red[1][1] / n + red[0][1] / n);
+    loss = (-expert_loss + nominal_loss) + reg;
+  }
+  m[6] = loss; m[7] = expert_loss; m[8] = unweighted; m[9] = nominal_loss; m[10] = reg;
+  m[11] = red[0][3]; m[12] = red[0][4]; m[13] = red[0][2] / n;
+  m[14] = red[1][3]; m[15] = red[1][4]; m[16] = red[1][2] / n;
+}
+
+template <bool MB>
 __global__ void __launch_bounds__(CN_TH) cn_backward_kernel(CnTrainArgs a, int itr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   if (a.scal[SC_STOPPED] != 0.f) return;
@@ -270,8 +360,9 @@ __global__ void __launch_bounds__(CN_TH) cn_backward_kernel(CnTrainArgs a, int i
   const int blk = blockIdx.x, tid = threadIdx.x;
   const bool nominal = blk < a.nb_n;
   const int row0 = (nominal ? blk : blk - a.nb_n) * CN_ROWS;
-  const int n_tot = nominal ? a.Nn : a.Ne;
-  cn_block_forward(d, sm, a.params, nominal ? a.nominal : a.expert, row0, n_tot);
+  const int n_tot = MB ? a.mb_n : (nominal ? a.Nn : a.Ne);
+  const float cnt_n = (float)(MB ? a.mb_n : a.Nn), cnt_e = (float)(MB ? a.mb_n : a.Ne);
+  cn_block_forward(d, sm, a.params, nominal ? a.nominal : a.expert, row0, n_tot, MB ? a.mb_idx : nullptr);
   const int row = tid & 63, part = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float* W = sm + d.sW;
   // ---- d loss / d logit
@@ -283,14 +374,14 @@ __global__ void __launch_bounds__(CN_TH) cn_backward_kernel(CnTrainArgs a, int i
       float dzeta;
       if (a.hp.gail) {
         // BCE(zeta_N, 0) = -mean(max(log(1 - zeta), -100)); BCE(zeta_E, 1) = -mean(max(log zeta, -100))
-        if (nominal) dzeta = (logf(1.f - z) > -100.f) ? 1.f / ((float)a.Nn * (1.f - z)) : 0.f;
-        else dzeta = (logf(z) > -100.f) ? -1.f / ((float)a.Ne * z) : 0.f;
+        if (nominal) dzeta = (logf(1.f - z) > -100.f) ? 1.f / (cnt_n * (1.f - z)) : 0.f;
+        else dzeta = (logf(z) > -100.f) ? -1.f / (cnt_e * z) : 0.f;
       } else if (nominal) {
         float wgt = 1.f;
-        if (a.hp.importance_sampling) wgt = a.hp.per_step ? a.scal[SC_MEAN_W] : a.normed[a.row_ep[g]];
-        dzeta = wgt / ((float)a.Nn * (z + eps)) - a.hp.reg_coeff / (float)a.Nn;
+        if (a.hp.importance_sampling) wgt = a.hp.per_step ? a.scal[SC_MEAN_W] : a.normed[a.row_ep[MB ? a.mb_idx[g] : g]];
+        dzeta = wgt / (cnt_n * (z + eps)) - a.hp.reg_coeff / cnt_n;
       } else {
-        dzeta = -1.f / ((float)a.Ne * (z + eps)) - a.hp.reg_coeff / (float)a.Ne;
+        dzeta = -1.f / (cnt_e * (z + eps)) - a.hp.reg_coeff / cnt_e;
       }
       dz = dzeta * (z * (1.f - z));
     }
@@ -343,11 +434,11 @@ __global__ void __launch_bounds__(CN_TH) cn_backward_kernel(CnTrainArgs a, int i
   }
 }
 
-__global__ void __launch_bounds__(256) cn_adam_kernel(CnTrainArgs a, int itr) {
+__global__ void __launch_bounds__(256) cn_adam_kernel(CnTrainArgs a, int itr, int upd) {
   if (a.scal[SC_STOPPED] != 0.f) return;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int nb = a.nb_n + a.nb_e;
-  const int t = a.adam_t[0] + itr + 1;   // adam_t is advanced once at the end by the host-visible counter kernel
+  const int t = a.adam_t[0] + upd + 1;   // upd: optimiser steps before this one in the call; adam_t is advanced once at the end
   if (p < a.d.n_params) {
     float g = 0.f;
     for (int b = 0; b < nb; ++b) g += a.gpart[(size_t)b * a.d.n_params + p];
@@ -362,7 +453,7 @@ __global__ void __launch_bounds__(256) cn_adam_kernel(CnTrainArgs a, int itr) {
     a.params[p] = a.params[p] - step_size * (m / denom);
     a.exp_avg[p] = m; a.exp_avg_sq[p] = v;
   }
-  if (p == 0) { a.metrics[(size_t)itr * ICRL_CN_METRICS + 17] = 1.f; a.scal[SC_ITER] = (float)(itr + 1); }
+  if (p == 0) { a.metrics[(size_t)itr * ICRL_CN_METRICS + 17] = 1.f; a.scal[SC_ITER] = (float)(upd + 1); }
 }
 
 __global__ void cn_commit_kernel(CnTrainArgs a) {
@@ -441,7 +532,7 @@ extern "C" int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* ex
   cn_work_layout(cn->n_params, Nn, Ne, n_ep, offs, &total);
   a.start_preds = work + offs[0]; a.preds_n = work + offs[1]; a.preds_e = work + offs[2]; a.part = work + offs[3];
   a.ep_prod = work + offs[4]; a.ep_slog = work + offs[5]; a.normed = work + offs[6]; a.scal = work + offs[7];
-  a.gpart = work + offs[8]; a.metrics = metrics;
+  a.gpart = work + offs[8]; a.metrics = metrics; a.mb_idx = nullptr; a.mb_n = 0;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(a.scal, 0, SC_COUNT * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
@@ -451,14 +542,70 @@ extern "C" int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* ex
   }
   e = hipFuncSetAttribute((const void*)cn_forward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  e = hipFuncSetAttribute((const void*)cn_backward_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  e = hipFuncSetAttribute((const void*)cn_backward_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   const int nb = a.nb_n + a.nb_e;
   for (int itr = 0; itr < hp->iterations; ++itr) {
     hipLaunchKernelGGL(cn_forward_kernel, dim3(nb), dim3(CN_TH), lds, s, a, itr);
     hipLaunchKernelGGL(cn_finalize_kernel, dim3(1), dim3(1024), 0, s, a, itr);
-    hipLaunchKernelGGL(cn_backward_kernel, dim3(nb), dim3(CN_TH), lds, s, a, itr);
-    hipLaunchKernelGGL(cn_adam_kernel, dim3((cn->n_params + 255) / 256), dim3(256), 0, s, a, itr);
+    hipLaunchKernelGGL(cn_backward_kernel<false>, dim3(nb), dim3(CN_TH), lds, s, a, itr);
+    hipLaunchKernelGGL(cn_adam_kernel, dim3((cn->n_params + 255) / 256), dim3(256), 0, s, a, itr, itr);
+  }
+  hipLaunchKernelGGL(cn_commit_kernel, dim3(1), dim3(64), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_cn_train_minibatch(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
+                                       const float* nominal, const float* expert, int Nn, int Ne,
+                                       const int32_t* ep_offsets, const int32_t* row_episode, int n_ep,
+                                       const icrl_cn_hyper_t* hp, const int32_t* perms, int batch_size, float* work,
+                                       float* metrics, void* stream) {
+  if (Nn <= 0 || Ne <= 0 || n_ep <= 0 || hp->iterations < 0 || cn->n_hidden < 1 || cn->n_hidden > 2 || batch_size <= 0 ||
+      perms == nullptr)
+    return (int)hipErrorInvalidValue;
+  CnTrainArgs a;
+  a.d = make_cn_dims(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
+  if (a.d.n_params != cn->n_params) return (int)hipErrorInvalidValue;
+  const size_t lds = (size_t)a.d.total * sizeof(float);
+  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  a.params = cn->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
+  a.nominal = nominal; a.expert = expert; a.Nn = Nn; a.Ne = Ne; a.n_ep = n_ep;
+  a.nb_n = (Nn + CN_ROWS - 1) / CN_ROWS; a.nb_e = (Ne + CN_ROWS - 1) / CN_ROWS;
+  a.ep_off = ep_offsets; a.row_ep = row_episode; a.hp = *hp;
+  size_t offs[9], total;
+  cn_work_layout(cn->n_params, Nn, Ne, n_ep, offs, &total);
+  a.start_preds = work + offs[0]; a.preds_n = work + offs[1]; a.preds_e = work + offs[2]; a.part = work + offs[3];
+  a.ep_prod = work + offs[4]; a.ep_slog = work + offs[5]; a.normed = work + offs[6]; a.scal = work + offs[7];
+  a.gpart = work + offs[8]; a.metrics = metrics; a.mb_idx = nullptr; a.mb_n = 0;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(a.scal, 0, SC_COUNT * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  if (hp->iterations > 0) {
+    e = hipMemsetAsync(metrics, 0, (size_t)hp->iterations * ICRL_CN_METRICS * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+  }
+  const void* fns[3] = {(const void*)cn_forward_kernel, (const void*)cn_mb_forward_kernel, (const void*)cn_backward_kernel<true>};
+  for (const void* f : fns) {
+    e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  const int size = Nn < Ne ? Nn : Ne;                       // ref: constraint_net.py:304 — min(nom_size, exp_size)
+  const int n_batches = (size + batch_size - 1) / batch_size;
+  const int nb_all = a.nb_n + a.nb_e;
+  for (int itr = 0; itr < hp->iterations; ++itr) {
+    hipLaunchKernelGGL(cn_forward_kernel, dim3(nb_all), dim3(CN_TH), lds, s, a, itr);
+    hipLaunchKernelGGL(cn_finalize_kernel, dim3(1), dim3(1024), 0, s, a, itr);
+    for (int k = 0; k < n_batches; ++k) {
+      CnTrainArgs b = a;
+      b.mb_idx = perms + (size_t)itr * size + (size_t)k * batch_size;
+      b.mb_n = (k + 1) * batch_size <= size ? batch_size : size - k * batch_size;
+      b.nb_n = b.nb_e = (b.mb_n + CN_ROWS - 1) / CN_ROWS;
+      const int nb = 2 * b.nb_n;
+      hipLaunchKernelGGL(cn_mb_forward_kernel, dim3(nb), dim3(CN_TH), lds, s, b);
+      hipLaunchKernelGGL(cn_mb_finalize_kernel, dim3(1), dim3(64), 0, s, b, itr);
+      hipLaunchKernelGGL(cn_backward_kernel<true>, dim3(nb), dim3(CN_TH), lds, s, b, itr);
+      hipLaunchKernelGGL(cn_adam_kernel, dim3((cn->n_params + 255) / 256), dim3(256), 0, s, b, itr, itr * n_batches + k);
+    }
   }
   hipLaunchKernelGGL(cn_commit_kernel, dim3(1), dim3(64), 0, s, a);
   return (int)hipGetLastError();

@@ -265,6 +265,18 @@ int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, i
                   const int32_t* ep_offsets, const int32_t* row_episode, int n_ep,
                   const icrl_cn_hyper_t* hp, float* work, float* metrics, void* stream);
 
+/* Minibatch mode of ConstraintNet.train (`--cn_batch_size`; icrl/constraint_net.py:181-206 with get() :300-316): per
+ * iteration the importance weights / early-stop test on ALL nominal rows as above, then one optimiser step per batch of
+ * `batch_size` indices out of perms[iteration] ([iterations][min(Nn,Ne)] int32 on the device, the caller's
+ * np.random.permutation stream); a batch takes the same row indices from the nominal and the expert set.  metrics rows hold
+ * the importance-sampling statistics of the iteration and the loss terms / predictions of its LAST batch (what the
+ * reference reports).  work: icrl_cn_train_work_floats(...) floats as for icrl_cn_train. */
+int icrl_cn_train_minibatch(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
+                            const float* nominal, const float* expert, int Nn, int Ne,
+                            const int32_t* ep_offsets, const int32_t* row_episode, int n_ep,
+                            const icrl_cn_hyper_t* hp, const int32_t* perms, int batch_size, float* work,
+                            float* metrics, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -352,6 +352,56 @@ def g6_constraint_net_train():
     save("g6_constraint_net", **out)
 
 
+def g7_constraint_net_minibatch():
+    """ConstraintNet.train with cn_batch_size (constraint_net.py:181-206, get() :300-316): permutations recorded."""
+    print("G7 ConstraintNet.train, minibatch mode")
+    rng = np.random.RandomState(17)
+    out = {}
+    cases = dict(mb_psis=(True, [60, 90, 50], 4, 10, 2.5, 32, False), mb_episode=(False, [80, 70, 30], 3, 10, 10, 48, False),
+                 mb_nois=(False, [100, 60], 3, -1, -1, 64, True), mb_gail=(False, [70, 80], 3, -1, -1, 40, "gail"))
+    for name, (psis, lengths, iters, tk_on, tk_no, bs, mode) in cases.items():
+        n_nom, n_exp = int(np.sum(lengths)), 170
+        exp_obs, exp_acs = rng.randn(n_exp, 18), rng.uniform(-1, 1, (n_exp, 6)).astype(np.float32)
+        nom_obs, nom_acs = rng.randn(n_nom, 18), rng.uniform(-1.5, 1.5, (n_nom, 6))
+        th.manual_seed(13)
+        nois, gail = mode is True, mode == "gail"
+        ref = ConstraintNet(**_cn_kwargs(18, 6, [20], exp_obs, exp_acs, per_step_importance_sampling=psis, batch_size=bs,
+                                         target_kl_old_new=tk_on, target_kl_new_old=tk_no, no_importance_sampling=nois or gail,
+                                         train_gail_lambda=gail))
+        w0 = _sd_np(ref.network.state_dict())
+        orc = o_nets.CostNet(18, 6, [20], False, None, None, 20, ref.action_low, ref.action_high)
+        orc.load_state_dict(ref.network.state_dict())
+        oopt = th.optim.Adam(orc.parameters(), lr=ref.lr_schedule(1), eps=1e-5)
+        perms, orig_perm = [], np.random.permutation
+
+        def rec_perm(n):
+            p = orig_perm(n); perms.append(p.copy()); return p
+        np.random.permutation = rec_perm
+        try:
+            m = ref.train(iters, nom_obs, nom_acs, np.array(lengths))
+        finally:
+            np.random.permutation = orig_perm
+        replay = iter(perms)
+        om = o_cn.cn_train(orc, oopt, iters, orc.prepare(nom_obs, nom_acs), orc.prepare(exp_obs, exp_acs), np.array(lengths),
+                           reg_coeff=0.5, per_step=psis, target_kl_old_new=tk_on, target_kl_new_old=tk_no, batch_size=bs,
+                           importance_sampling=not (nois or gail), gail=gail,
+                           rng=type("R", (), {"permutation": staticmethod(lambda n: next(replay))}))
+        for k, v in m.items():
+            a, b = float(v), float(om[k])
+            assert (np.isnan(a) and np.isnan(b)) or a == b, (name, k, a, b)
+        for k, p in orc.params.items():
+            assert maxdiff(p.detach().numpy(), ref.network.state_dict()[k].numpy()) == 0.0
+        print(f"  {name}: {len(perms)} permutations, loss {m['backward/cn_loss']:.6f}")
+        out.update({f"{name}/exp_obs": exp_obs, f"{name}/exp_acs": exp_acs, f"{name}/nom_obs": nom_obs, f"{name}/nom_acs": nom_acs,
+                    f"{name}/lengths": np.array(lengths), f"{name}/perms": np.array(perms),
+                    f"{name}/cfg": np.array([psis, iters, tk_on, tk_no, ref.lr_schedule(1), bs, nois or gail, gail], np.float64)})
+        out.update({f"{name}/w0/{k}": v for k, v in w0.items()})
+        out.update(_sd_np(ref.network.state_dict(), f"{name}/w1/"))
+        out.update({f"{name}/m/{k.split('/')[1]}": float(v) for k, v in m.items()})
+    print("  oracle == reference bit-for-bit")
+    save("g7_constraint_net_minibatch", **out)
+
+
 def g9_learn_iteration():
     """One learn() of the reference on the synthetic env (N=4, T=32) with the action noise and the minibatch
     permutations recorded, against the CPU port teacher-forced with the same streams."""
@@ -560,8 +610,8 @@ def fixtures_expert():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g9", "g10", "expert"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert"]
     table = dict(g1=g1_gae, g2=g2_cost_function, g3=g3_vecnormalize, g4=g4_ppo_minibatch, g5=g5_dual,
-                 g6=g6_constraint_net_train, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
+                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
     for w in which:
         table[w]()

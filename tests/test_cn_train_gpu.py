@@ -86,3 +86,55 @@ def test_policy_evaluate_actions(golden):
     assert np.allclose(lp.cpu().numpy(), olp.numpy(), rtol=2e-4, atol=2e-4)
     assert np.allclose(vr.cpu().numpy(), ovr.numpy(), rtol=2e-4, atol=2e-4)
     assert np.allclose(ent.cpu().numpy(), oent.numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("case", ["mb_psis", "mb_episode", "mb_nois", "mb_gail"])
+def test_cn_train_minibatch_golden(golden, case):
+    """`--cn_batch_size` mode against the REFERENCE's train() with the recorded permutations (tests/golden/g7)."""
+    from icrl_amd.constraint_net import ConstraintNet
+    g = _sub(golden("g7_constraint_net_minibatch"), case + "/")
+    psis, iters, tk_on, tk_no, lr, bs, nois, gail = g["cfg"]
+    lo = -np.ones(6, np.float32)
+    cn = ConstraintNet(18, 6, [20], int(bs), lambda x: float(lr), g["exp_obs"], g["exp_acs"], False, 0.5, clip_obs=20,
+                       action_low=lo, action_high=-lo, per_step_importance_sampling=bool(psis), no_importance_sampling=bool(nois),
+                       train_gail_lambda=bool(gail), target_kl_old_new=float(tk_on), target_kl_new_old=float(tk_no))
+    cn.load_state_dict(_sub(g, "w0/"))
+    perms = g["perms"]
+    full = np.zeros((int(iters), perms.shape[1]), np.int64)
+    full[:len(perms)] = perms
+    m = cn.train(int(iters), g["nom_obs"], g["nom_acs"], g["lengths"], perms=full)
+    n_batches = -(-perms.shape[1] // int(bs))
+    assert cn.adam_step == len(perms) * n_batches
+    for k, v in m.items():
+        ref = float(g["m/" + k.split("/")[1]])
+        assert _close(v, ref, rtol=2e-3, atol=2e-4), (k, v, ref)
+    for k, v in cn.state_dict().items():
+        assert np.allclose(v.numpy(), g["w1/" + k], rtol=2e-3, atol=3e-4), (k, np.abs(v.numpy() - g["w1/" + k]).max())
+
+
+def test_cn_train_minibatch_default_stream_matches_oracle():
+    """without `perms` the batches come from np.random.permutation exactly like the reference's get()."""
+    from icrl_amd.constraint_net import ConstraintNet
+    rng = np.random.RandomState(9)
+    lo = -np.ones(6, np.float32)
+    exp_obs, exp_acs = rng.randn(200, 18), rng.uniform(-1, 1, (200, 6)).astype(np.float32)
+    nom_obs, nom_acs = rng.randn(300, 18), rng.uniform(-1.2, 1.2, (300, 6))
+    lengths = np.array([100, 100, 100])
+    torch.manual_seed(2)
+    orc = o_nets.CostNet(18, 6, [20], False, None, None, 20, lo, -lo)
+    cn = ConstraintNet(18, 6, [20], 64, lambda x: 0.01, exp_obs, exp_acs, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo,
+                       per_step_importance_sampling=True, target_kl_old_new=10, target_kl_new_old=2.5)
+    cn.load_state_dict(orc.state_dict())
+    opt = torch.optim.Adam(orc.parameters(), lr=0.01, eps=1e-5)
+    np.random.seed(123)
+    om = o_cn.cn_train(orc, opt, 4, orc.prepare(nom_obs, nom_acs), orc.prepare(exp_obs, exp_acs), lengths, reg_coeff=0.5,
+                       per_step=True, target_kl_old_new=10, target_kl_new_old=2.5, batch_size=64)
+    after_oracle = np.random.rand()
+    np.random.seed(123)
+    m = cn.train(4, nom_obs, nom_acs, lengths)
+    assert np.random.rand() == after_oracle            # the global stream is left where the reference leaves it
+    for k, v in m.items():
+        assert _close(v, float(om[k]), rtol=3e-3, atol=3e-4), (k, v, om[k])
+    for k, v in cn.state_dict().items():
+        ref = orc.params[k].detach().numpy()
+        assert np.allclose(v.numpy(), ref, rtol=3e-3, atol=3e-4), (k, np.abs(v.numpy() - ref).max())

@@ -228,3 +228,23 @@ def test_g10_discrete_learn_teacher_forced(golden):
         assert np.array_equal(p.detach().numpy(), g["w1/" + k]), k
     assert port.logs["train/nu"] == g["log/nu"].item()
     assert port.logs["train/entropy_loss"] == pytest.approx(g["log/entropy_loss"].item(), abs=1e-7)
+
+
+@pytest.mark.parametrize("case", ["mb_psis", "mb_episode", "mb_nois", "mb_gail"])
+def test_g7_constraint_net_minibatch(golden, case):
+    g = _sub(golden("g7_constraint_net_minibatch"), case + "/")
+    psis, iters, tk_on, tk_no, lr, bs, nois, gail = g["cfg"]
+    lo = -np.ones(6, np.float32)
+    net = o_nets.CostNet(18, 6, [20], False, None, None, 20, lo, -lo)
+    net.load_state_dict(_sub(g, "w0/"))
+    opt = th.optim.Adam(net.parameters(), lr=float(lr), eps=1e-5)
+    replay = iter(g["perms"])
+    m = o_cn.cn_train(net, opt, int(iters), net.prepare(g["nom_obs"], g["nom_acs"]), net.prepare(g["exp_obs"], g["exp_acs"]),
+                      g["lengths"], reg_coeff=0.5, per_step=bool(psis), target_kl_old_new=float(tk_on),
+                      target_kl_new_old=float(tk_no), batch_size=int(bs), importance_sampling=not bool(nois), gail=bool(gail),
+                      rng=type("R", (), {"permutation": staticmethod(lambda n: next(replay))}))
+    for k, v in m.items():
+        ref = g["m/" + k.split("/")[1]].item()
+        assert (np.isnan(ref) and np.isnan(v)) or ref == v, k
+    for k, p in net.params.items():
+        assert np.array_equal(p.detach().numpy(), g["w1/" + k]), k
