@@ -68,9 +68,9 @@ def gae_sweep_point(N=65536, T=2048, reps=5):
 
 
 def cpu_baseline():
-    """oracle CPU port on a bounded sample of the same workload (one PPO iteration with n_steps 256 instead of 2048)."""
+    """oracle CPU port on a bounded sample of the same workload (one PPO iteration with n_steps 1024 instead of 2048)."""
     from oracle import loop as o_loop, nets as o_nets
-    n_envs, T = 64, 256
+    n_envs, T = 64, 1024
     # the reference's own measurement used 8 intra-op threads (BASELINE.md §2); more threads only slow these tiny GEMMs down
     threads = min(8, os.cpu_count() or 1)
     torch.set_num_threads(threads)
@@ -144,7 +144,9 @@ def main():
     gae_ach = gae_bytes / (np.mean(gae_us) * 1e-6) / 1e9
     sweep = gae_sweep_point()
     traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), same shape
-    pmc_path = os.path.join(ROOT, "profiles", "r01_gae_pmc.json")
+    import glob
+    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gae_pmc.json")))      # latest round's passes
+    pmc_path = pmc_files[-1] if pmc_files else ""
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)

@@ -1,0 +1,83 @@
+"""Turn the rocprofv3 outputs of tools/profile_round.sh (under gpurun_out/) into the tracked summaries under profiles/.
+
+    python tools/summarize_profiles.py <tag>          e.g. r01_v2
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def find(pattern):
+    hits = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True))
+    return hits[-1] if hits else None
+
+
+def kernel_stats(tag):
+    src = find(f"prof_{tag}/**/*kernel_stats.csv")
+    if src is None:
+        print("no kernel_stats.csv"); return
+    rows = list(csv.DictReader(open(src)))
+    dst = os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats")
+    with open(dst + ".csv", "w") as f:
+        f.write(open(src).read())
+    bench = ""
+    log = os.path.join(ROOT, "gpurun_out", f"prof_{tag}.log")
+    if os.path.exists(log):
+        for line in open(log):
+            if line.startswith("{\"metric\""):
+                j = json.loads(line)
+                bench = f"bench line of that (profiled) run: {j['value']:.0f} env-steps/s, {j['ms_per_step']:.0f} ms per outer iteration"
+    with open(dst + ".md", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats — bench.py --steps 2 --warmup 1 ({tag})\n\n"
+                "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag> -- python3 bench.py --steps 2 "
+                "--warmup 1 --no_cpu_baseline` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 65 536)\n\n"
+                f"{bench}\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        for r in rows[:24]:
+            name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
+            f.write(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+    print("wrote", dst + ".md")
+
+
+def gae_pmc(tag, T=2048, N=65536):
+    out = {}
+    for name, key in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
+        src = find(f"pmc_{tag}_{key}/**/*counter_collection.csv")
+        if src is None:
+            print("no counter csv for", name); return
+        vals, keep = [], []
+        for r in csv.DictReader(open(src)):
+            if "gae_dual_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+                vals.append(float(r["Counter_Value"])); keep.append(r)
+        out[name] = vals
+        with open(os.path.join(ROOT, "profiles", f"{tag}_gae_pmc_{'fetch' if key == 'f' else 'write'}.csv"), "w") as f:
+            w = csv.DictWriter(f, fieldnames=list(keep[0].keys())); w.writeheader(); w.writerows(keep)
+        kname = keep[0]["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+    fetch_kb, write_kb = max(out["FETCH_SIZE"]), max(out["WRITE_SIZE"])      # per dispatch (identical dispatches)
+    alg = T * N * 36
+    j = dict(kernel=kname, T=T, N=N, algorithmic_bytes=alg, FETCH_SIZE_kb=fetch_kb, WRITE_SIZE_kb=write_kb,
+             fetch_bytes_raw=fetch_kb * 1024, fetch_bytes_corrected=fetch_kb * 1024 * 2, write_bytes=write_kb * 1024,
+             traffic_bytes=fetch_kb * 1024 * 2 + write_kb * 1024,
+             note="separate --pmc passes (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md §HBM prescribes; on gfx950 FETCH_SIZE counts "
+                  "128-B requests at 64 B, so the read side is doubled; non-temporal loads / stores do not change the counts")
+    with open(os.path.join(ROOT, "profiles", f"{tag}_gae_pmc.json"), "w") as f:
+        json.dump(j, f, indent=1)
+    with open(os.path.join(ROOT, "profiles", f"{tag}_gae_pmc.md"), "w") as f:
+        f.write(f"# GAE kernel HBM traffic from PMC counters ({tag})\n\n"
+                "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_<tag>_f -- python3 tools/gae_once.py\n"
+                "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_<tag>_w -- python3 tools/gae_once.py\n\n"
+                f"`{kname}`, T = {T}, N = {N}: algorithmic {alg} B (36 B x {T * N} transitions), per dispatch:\n\n"
+                "| counter | raw KB | bytes | note |\n|---|---|---|---|\n"
+                f"| FETCH_SIZE | {fetch_kb:.0f} | {fetch_kb * 1024:.0f} | x2 on gfx950 = {fetch_kb * 2048:.0f} B (algorithmic loads {T * N * 20} B) |\n"
+                f"| WRITE_SIZE | {write_kb:.0f} | {write_kb * 1024:.0f} | algorithmic stores {T * N * 16} B |\n"
+                f"| **traffic** | | **{j['traffic_bytes']:.0f}** | {100 * (j['traffic_bytes'] / alg - 1):+.2f} % vs algorithmic |\n")
+    print("wrote", f"profiles/{tag}_gae_pmc.json", j["traffic_bytes"] / alg)
+
+
+if __name__ == "__main__":
+    tag = sys.argv[1]
+    kernel_stats(tag)
+    gae_pmc(tag)
