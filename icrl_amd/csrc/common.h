@@ -54,6 +54,35 @@ __device__ __forceinline__ float wave_min(float v) {
   return v;
 }
 
+// ---- the same reductions on the VALU only (DPP row operations + gfx950's v_permlane{16,32}_swap): ~8 instructions instead of
+// six dependent ds_bpermute round trips through the LDS crossbar.  Summation order differs from the butterflies above.
+__device__ __forceinline__ float xor32_sum(float v) {   // v[lane] + v[lane ^ 32]
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor16_sum(float v) {   // v[lane] + v[lane ^ 16]
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float xor32_max(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xor16_max(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+#define ICRL_DPP_F32(v, ctrl) __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float row_sum(float v) {     // sum over the 16 lanes of the lane's row, in every lane
+  v += ICRL_DPP_F32(v, 0xB1);    // quad_perm [1,0,3,2]
+  v += ICRL_DPP_F32(v, 0x4E);    // quad_perm [2,3,0,1]
+  v += ICRL_DPP_F32(v, 0x141);   // row_half_mirror
+  v += ICRL_DPP_F32(v, 0x140);   // row_mirror
+  return v;
+}
+__device__ __forceinline__ float quad_rows_sum(float v) { return xor16_sum(xor32_sum(v)); }   // over the 4 lanes lane % 16
+__device__ __forceinline__ float wave_sum_fast(float v) { return row_sum(quad_rows_sum(v)); }
+
 // numpy's pairwise summation of a contiguous float64 vector (np.sum / np.mean over a 1-D array); reproduces the
 // reference's reduction order exactly so that ret_rms / cost_rms match bit for bit.
 __device__ inline double np_pairwise_sum(const double* a, int n) {
@@ -126,12 +155,12 @@ __host__ __device__ inline CnLayout make_cn_layout(int in, int nh, int H1, int H
   return L;
 }
 
-// tanh through one v_exp_f32 and one v_rcp_f32: (e - 1) / (e + 1), e = exp(2x); |abs error| <~ 2e-7.
-// Used by BOTH the rollout-time forward and the training kernel so that old and new log-probs see the same activations.
+// tanh through one v_exp_f32 and one v_rcp_f32: 1 - 2 / (2^(2 x log2 e) + 1); |abs error| <~ 2e-7, saturates to +-1 without
+// clamps (2^big = inf -> rcp = 0; 2^-big = 0 -> rcp(1) = 1).  Used by BOTH the rollout-time forward and the training kernels
+// so that old and new log-probs see the same activations.
 __device__ __forceinline__ float fast_tanh(float x) {
-  const float xc = fminf(fmaxf(x, -15.f), 15.f);
-  const float e = __expf(2.f * xc);
-  return (e - 1.f) * __builtin_amdgcn_rcpf(e + 1.f);
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+  return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
 }
 
 constexpr float LOG_SQRT_2PI_F = 0.918938533204672741780329736406f;  // log(sqrt(2*pi))

@@ -1,0 +1,94 @@
+// Shared pieces of the two PPO-Lagrangian update kernels (ppo_train.hip: column-split tiles, any obs width;
+// ppo_train_rows.hip: row-owning waves, obs <= 64) — gfx950.
+#pragma once
+#include "common.h"
+
+namespace icrl {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned long long u64;
+#define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+constexpr int RB = 64;   // minibatch rows per chunk
+constexpr int HD = 64;   // hidden width (both layers)
+constexpr int SH = 72;   // LDS row stride of 64-wide matrices (= 8 mod 16: conflict-free ds_read_b128 operand fetch)
+constexpr int MAXB = 128;
+
+struct TrainArgs {
+  PolLayout L;
+  float* params;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int* adam_t;
+  icrl_buffer_t buf;
+  const int* perms;
+  const float* nu;
+  icrl_ppo_hyper_t hp;
+  float* stats;
+  u64* xch;
+  unsigned t_magic;   // floor(2^32 / T): fast division of a flat index by T
+  const struct PlanStep* plan_steps;     // rows kernel: per optimiser step (+2 zero entries)
+  const struct PlanChunk* plan_chunks;   // rows kernel: per 64-row chunk (+5 zero entries)
+  int n_steps;
+};
+
+// the schedule of a launch, tabulated once by ppo_plan_kernel so that the persistent kernel carries no epoch / minibatch /
+// cursor arithmetic in scalar registers: which rows of which permutation form each minibatch and chunk, and Adam's bias
+// corrections (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), evaluated in double like torch)
+struct PlanStep {
+  float step_size, inv_bc2_sqrt;
+  int nb_flags;    // rows | first minibatch of the epoch << 8 | last << 9 | epoch << 10
+  int perm_base;   // epoch * T*N + position of the minibatch's first row in the permutation
+};
+struct PlanChunk {
+  int perm_base, rows;
+};
+
+// sum over the 16 lanes sharing lane/16
+__device__ __forceinline__ float sum16(float v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+// column sums of a wave's 16x16 accumulator tile: every lane ends with the sum over the tile's 16 rows of column lane%16
+__device__ __forceinline__ float tile_colsum(const f32x4& t) {
+  float s = (t[0] + t[1]) + (t[2] + t[3]);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  return s;
+}
+
+// diagnostic phase timer (only when hp._pad != 0: the stamp drains the LDS queue, so never in a timed run)
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define STAMP(slot)                                                        \
+  if (prof) {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    const unsigned long long now_ = stamp();                               \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    ph[slot] += now_ - t_last;                                             \
+    t_last = now_;                                                         \
+  }
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the global loads of the row prefetch
+// (s_waitcnt vmcnt(0)) at every one of the ~13 barriers of a step and expose their full latency each time
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ f32x4 lds128(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// cursor into the stream of minibatch rows: epoch, position inside the epoch, position inside the minibatch
+struct Cursor {
+  int e, p, m;
+};
+
+// ppo_train_rows.hip: row-owning-wave kernel for obs_dim <= 64 (nt1 = ceil(obs / 16) <= 4)
+int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, hipStream_t s);
+
+
+}  // namespace icrl

@@ -28,20 +28,12 @@
 //   * minibatches larger than 64 rows are processed in 64-row chunks that accumulate into the same gradient registers.
 //
 // Built with -ffp-contract=off; FMA is used only where written (fmaf / MFMA).
-#include "common.h"
+#include "ppo_common.h"
 
 namespace icrl {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned long long u64;
-#define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
-
 constexpr int TH = 512;  // threads per workgroup (8 waves, 2 per SIMD)
-constexpr int RB = 64;   // minibatch rows per chunk
-constexpr int HD = 64;   // hidden width (both layers)
-constexpr int SH = 72;   // LDS row stride of 64-wide matrices (= 8 mod 16: conflict-free ds_read_b128 operand fetch)
 constexpr int SO = 24;   // LDS row stride of 16-wide matrices
-constexpr int MAXB = 128;
 
 template <int NT1>
 struct Smem {  // offsets in floats (all multiples of 4: 16-byte aligned rows)
@@ -69,64 +61,6 @@ struct Smem {  // offsets in floats (all multiples of 4: 16-byte aligned rows)
   // per-row side data of the chunk lives in the (not yet used) dz rows: columns 0..15 actions, 16 old log-prob | old value,
   // 17 raw reward advantage | return, 18 raw cost advantage
   static constexpr int ACT = DZ, OLP = DZ + 16, ADR = DZ + 17, ADC = DZ + 18;
-};
-
-struct TrainArgs {
-  PolLayout L;
-  float* params;
-  float* exp_avg;
-  float* exp_avg_sq;
-  int* adam_t;
-  icrl_buffer_t buf;
-  const int* perms;
-  const float* nu;
-  icrl_ppo_hyper_t hp;
-  float* stats;
-  u64* xch;
-  unsigned t_magic;   // floor(2^32 / T): fast division of a flat index by T
-};
-
-// sum over the 16 lanes sharing lane/16
-__device__ __forceinline__ float sum16(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
-  return v;
-}
-
-// column sums of a wave's 16x16 accumulator tile: every lane ends with the sum over the tile's 16 rows of column lane%16
-__device__ __forceinline__ float tile_colsum(const f32x4& t) {
-  float s = (t[0] + t[1]) + (t[2] + t[3]);
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  return s;
-}
-
-// diagnostic phase timer (only when hp._pad != 0: the stamp drains the LDS queue, so never in a timed run)
-__device__ __forceinline__ unsigned long long stamp() {
-  unsigned long long t;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-  return t;
-}
-#define STAMP(slot)                                                        \
-  if (prof) {                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                     \
-    const unsigned long long now_ = stamp();                               \
-    __builtin_amdgcn_sched_barrier(0);                                     \
-    ph[slot] += now_ - t_last;                                             \
-    t_last = now_;                                                         \
-  }
-
-// workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the global loads of the row prefetch
-// (s_waitcnt vmcnt(0)) at every one of the ~13 barriers of a step and expose their full latency each time
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__device__ __forceinline__ f32x4 lds128(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
-// cursor into the stream of minibatch rows: epoch, position inside the epoch, position inside the minibatch
-struct Cursor {
-  int e, p, m;
 };
 
 template <int NT1, bool DISC>
@@ -337,7 +271,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
   compute_stats(mb_rows_at(0));
   __syncthreads();
 
-  const bool prof = a.hp._pad != 0;
+  const bool prof = (a.hp._pad & 1) != 0;
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = prof ? stamp() : 0ull;
 
@@ -934,6 +868,25 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
   }
 }
 
+__global__ void ppo_plan_kernel(const int* adam_t, int n_steps, int n_mb, int n_total, int B, double lr, double b1, double b2,
+                                PlanStep* steps, PlanChunk* chunks) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_steps + 2) return;
+  if (i >= n_steps) { steps[i] = PlanStep{0.f, 0.f, 0, 0}; return; }
+  const int e = i / n_mb, mb = i % n_mb, p = mb * B;
+  const int nb = n_total - p < B ? n_total - p : B;
+  const int cpm = (B + RB - 1) / RB;
+  const int nb_last = n_total - (n_mb - 1) * B;
+  const int cpe = (n_mb - 1) * cpm + (nb_last + RB - 1) / RB;
+  const int g0 = e * cpe + mb * cpm, nch = (nb + RB - 1) / RB;
+  const double t = (double)(adam_t[0] + i + 1);
+  steps[i] = PlanStep{(float)(lr / (1.0 - pow(b1, t))), (float)(1.0 / sqrt(1.0 - pow(b2, t))),
+                      nb | ((mb == 0) << 8) | ((mb == n_mb - 1) << 9) | (e << 10), e * n_total + p};
+  for (int c = 0; c < nch; ++c) chunks[g0 + c] = PlanChunk{e * n_total + p + RB * c, nb - RB * c < RB ? nb - RB * c : RB};
+  if (i == n_steps - 1)
+    for (int c = 0; c < 5; ++c) chunks[g0 + nch + c] = PlanChunk{0, 0};
+}
+
 }  // namespace icrl
 
 using namespace icrl;
@@ -960,12 +913,26 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
   a.params = pol->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.buf = *buf; a.perms = perms; a.nu = nu; a.hp = *hp; a.stats = stats; a.xch = (u64*)sync_ws;
   a.t_magic = buf->T == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned long long)buf->T);
+  a.plan_steps = nullptr; a.plan_chunks = nullptr; a.n_steps = 0;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sync_ws, 0, 64, s);
+  hipError_t e = hipMemsetAsync(sync_ws, 0, 256, s);
   if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(stats, 0, (32 + hp->n_epochs) * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   const int nt1 = (pol->obs_dim + 15) / 16;
+  // obs <= 64: row-owning waves (3 barriers per step); wider observations (AntWall: 113) or hp._pad & 2: column-split tiles
+  if (nt1 <= 4 && !(hp->_pad & 2)) {
+    const int n_total = buf->T * buf->N;
+    const int n_mb = (n_total + hp->batch_size - 1) / hp->batch_size;
+    const long long n_steps = (long long)hp->n_epochs * n_mb;
+    if (n_steps >= (1ll << 21)) return (int)hipErrorInvalidValue;      // epoch index lives in the upper bits of nb_flags
+    PlanStep* steps = reinterpret_cast<PlanStep*>((char*)sync_ws + 256);
+    PlanChunk* chunks = reinterpret_cast<PlanChunk*>(steps + n_steps + 2);
+    a.plan_steps = steps; a.plan_chunks = chunks; a.n_steps = (int)n_steps;
+    hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
+                       n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks);
+    return launch_train_rows(a, nt1, pol->discrete != 0, s);
+  }
   if (pol->discrete) {
     if (buf->act_store != 1) return (int)hipErrorInvalidValue;
     if (nt1 <= 2) return launch_train<2, true>(a, s);

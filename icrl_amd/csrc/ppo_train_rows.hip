@@ -1,0 +1,804 @@
+// PPO-Lagrangian update, row-owning-wave variant (obs_dim <= 64) — gfx950.
+//
+// ref: stable_baselines3/ppo_lag/ppo_lag.py:196-299, common/buffers.py:594-627, common/policies.py:752-767,
+//      common/distributions.py:143-171,274-288, torch.optim.Adam, clip_grad_norm_  (same contract as ppo_train.hip).
+//
+// Same launch shape and exchange protocol as ppo_train.hip (3 persistent workgroups = pi | vf | cvf, weights in LDS, Adam
+// moments and gradients in registers, 8-byte granules for the global gradient norm) but a different decomposition inside the
+// workgroup, built to remove its barriers — the update is a chain of ~10^5 dependent optimiser steps, so the step LATENCY is
+// the whole cost and every s_barrier with eight skewed waves was ~1 us of it:
+//
+//   * 4 waves (one per SIMD); wave w owns minibatch rows 16w..16w+15 through the WHOLE forward and the backward of the
+//     activations.  All GEMMs are evaluated transposed, Z^T[feature][row] = W[feature][k] . H^T[k][row]: the weights are the
+//     A operand (rows of the LDS master copy, one ds_read_b128 per four MFMA steps), the activations the B operand.  With K
+//     enumerated as k = 16 js + 4 (lane/16) + e, the C layout of v_mfma_f32_16x16x4_f32 (lane holds features
+//     16 t + 4 (lane/16) + i of row lane%16) IS the B-operand layout of the next layer: h1, h2, d out, dz2, dz1 never leave
+//     registers and the forward + activation backward need NO barrier and no LDS round trip.
+//   * the weight gradients need all 64 rows: each wave stores its 16 columns of h1^T, h2^T, dz1^T, dz2^T, dOut^T once, ONE
+//     barrier, then wave w computes rows 16w.. of dW2 / dW1 and columns 16w.. of dWh with K = 64 rows; bias gradients are
+//     row sums of the A operands it already holds.
+//   * every wave publishes its own partial squared norm (12 granules per step instead of 3), so no reduction barrier sits
+//     between the last MFMA and the publish; while the granules travel the workgroup stages the next minibatch
+//     (double-buffered X) and its advantage statistics; 12 lanes poll.
+//   * 3 barriers per optimiser step (activations stored | norm + staging visible | weights updated) instead of 14.
+//
+// Built with -ffp-contract=off; FMA is used only where written (fmaf / MFMA).
+#include "ppo_common.h"
+
+namespace icrl {
+
+constexpr int TH4 = 256;   // 4 waves, one per SIMD (up to 512 VGPRs each)
+constexpr int ST = 72;     // row stride of the [feature][row] matrices (64 rows + 8: conflict-free ds_read_b128)
+constexpr int SA = 24;     // row stride of the per-row action block and of the transposed head weights
+
+template <int NT1>
+struct SmemR {  // offsets in floats (multiples of 4)
+  static constexpr int O16 = 16 * NT1, SX = O16 + 8;
+  static constexpr bool XDB = NT1 <= 2;        // second X buffer (next minibatch staged while dW1 still reads this one)
+  static constexpr bool W2TC = NT1 <= 2;       // transposed copy of W2 (ds_read_b128 operand fetch in the backward); LDS budget
+  static constexpr int W1 = 0;                 // [64][SX]
+  static constexpr int W2 = W1 + HD * SX;      // [64][SH]
+  static constexpr int W2T = W2 + HD * SH;     // [64][SH]  W2T[k][j] = W2[j][k]
+  static constexpr int WH = W2T + (W2TC ? HD * SH : 0);   // [16][SH]
+  static constexpr int WHT = WH + 16 * SH;     // [64][SA]  WHT[j][o] = WH[o][j]
+  static constexpr int B1 = WHT + HD * SA;
+  static constexpr int B2 = B1 + HD;
+  static constexpr int BH = B2 + HD;
+  static constexpr int LS = BH + 16;
+  static constexpr int GAU = LS + 16;          // [3][16] per-action 1/var, 0.5/var, log(sd) + log(sqrt(2 pi))
+  static constexpr int XT0 = GAU + 48;         // [16 NT1][ST] x^T of the chunk: XT[k][row]
+  static constexpr int XT1 = XDB ? XT0 + O16 * ST : XT0;
+  static constexpr int H1T = XT1 + O16 * ST;   // [64][ST] h1^T
+  static constexpr int H2T = H1T + HD * ST;
+  static constexpr int DZ1T = H2T + HD * ST;
+  static constexpr int DZ2T = DZ1T + HD * ST;
+  static constexpr int DOT = DZ2T + HD * ST;   // [16][ST] d loss / d head output, transposed
+  static constexpr int ACT = DOT + 16 * ST;    // [64][SA] actions of the chunk's rows
+  static constexpr int OLP = ACT + RB * SA;    // [64] old log-prob | old value
+  static constexpr int ADR = OLP + RB;         // [64] raw reward advantage | return
+  static constexpr int ADC = ADR + RB;         // [64] raw cost advantage
+  static constexpr int PST = ADC + RB;         // [4][8] per-wave loss statistics
+  static constexpr int PLS = PST + 32;         // [4][16] per-wave d log_std partial sums
+  static constexpr int MISC = PLS + 64;        // [64] granule values, flags, advantage-statistics partials
+  static constexpr int TOTAL = MISC + 64;
+};
+
+// the kernel arguments, re-read from the kernel-argument segment (scalar loads, scalar-cache resident) at the few places
+// that need pointers: keeps ~30 scalar registers out of the loop-carried state (the SGPR file spills otherwise)
+#define KARGS() ([]() { const TrainArgs* k_ = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(k_)); return k_; }())
+
+template <int NT1, bool DISC>
+__global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
+  using S = SmemR<NT1>;
+  constexpr int SX = S::SX;
+  constexpr int XR = (S::O16 + 3) / 4;  // floats of an X row each of the 4 threads of a row stages
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int role = blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 15, q = lane >> 4;
+  const int O = a.L.O, A = a.L.A;
+  const int n_out = role == 0 ? A : 1;
+  const int T = a.buf.T, N = a.buf.N;
+  const float nu = a.nu[0];
+  const int n_steps = a.n_steps;
+  const PlanStep* __restrict__ const plan_steps = a.plan_steps;
+  const PlanChunk* __restrict__ const plan_chunks = a.plan_chunks;
+  const int* __restrict__ const perms = a.perms;
+  // per-row side data of this role, selected once:
+  //   policy: old log-prob, reward advantage, cost advantage;  critics: old value, return, (unused)
+  const float* const p_s0 = role == 0 ? a.buf.log_probs : (role == 1 ? a.buf.reward_values : a.buf.cost_values);
+  const float* const p_s1 = role == 0 ? a.buf.reward_advantages : (role == 1 ? a.buf.reward_returns : a.buf.cost_returns);
+  const float* const p_s2 = a.buf.cost_advantages;
+  const float* const p_obs = a.buf.observations;
+  const float* const p_act = a.buf.actions;
+  const int AS = a.buf.act_store;
+
+  // wave w owns W1 / W2 rows 16w..16w+15 (element j = 16w + 4q + i, k = 16c + r) and head-weight columns 16w..16w+15
+  // (element o = 4q + i, j = 16w + r); b1 / b2 entries 16w + r (replicated over q, lane q == 0 stores); wave 0: head bias r,
+  // wave 1: log_std r.  The owner keeps the fp32 master value, both Adam moments and the accumulating gradient in registers;
+  // LDS holds the operand copies every wave reads.
+  f32x4 wW1[NT1], mW1[NT1], vW1[NT1], gW1r[NT1], wW2[4], mW2[4], vW2[4], gW2r[4], wWh, mWh, vWh, gWhr;
+  const int jb = 16 * w + r;
+  float wb1, mb1, vb1, wb2, mb2, vb2, gb1r = 0.f, gb2r = 0.f;
+  float wex = 0.f, mex = 0.f, vex = 0.f, gex = 0.f;
+  int ex_g = -1, ex_s = S::MISC + 63;          // "extra" vector entry: wave 0 head bias r, wave 1 log_std r (Gaussian policy)
+  {
+    const PolLayout& L = a.L;
+    const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
+    const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
+    const int gbh = role == 0 ? L.ba : (role == 1 ? L.bv : L.bc);
+#pragma unroll
+    for (int c = 0; c < NT1; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+        wW1[c][i] = k < O ? a.params[gW1 + j * O + k] : 0.f;
+        mW1[c][i] = k < O ? a.exp_avg[gW1 + j * O + k] : 0.f;
+        vW1[c][i] = k < O ? a.exp_avg_sq[gW1 + j * O + k] : 0.f;
+      }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+        wW2[c][i] = a.params[gW2 + j * HD + k];
+        mW2[c][i] = a.exp_avg[gW2 + j * HD + k];
+        vW2[c][i] = a.exp_avg_sq[gW2 + j * HD + k];
+      }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = 4 * q + i, j = 16 * w + r;
+      wWh[i] = o < n_out ? a.params[gWh + o * HD + j] : 0.f;
+      mWh[i] = o < n_out ? a.exp_avg[gWh + o * HD + j] : 0.f;
+      vWh[i] = o < n_out ? a.exp_avg_sq[gWh + o * HD + j] : 0.f;
+    }
+    wb1 = a.params[gb1 + jb]; mb1 = a.exp_avg[gb1 + jb]; vb1 = a.exp_avg_sq[gb1 + jb];
+    wb2 = a.params[gb2 + jb]; mb2 = a.exp_avg[gb2 + jb]; vb2 = a.exp_avg_sq[gb2 + jb];
+    if (w == 0 && r < n_out) { ex_g = gbh + r; ex_s = S::BH + r; }
+    if (w == 1 && !DISC && role == 0 && r < A) { ex_g = L.log_std + r; ex_s = S::LS + r; }
+    if (ex_g >= 0) { wex = a.params[ex_g]; mex = a.exp_avg[ex_g]; vex = a.exp_avg_sq[ex_g]; }
+  }
+  // operand copies: every owner stores its elements (also used after each Adam step)
+  auto store_weights = [&]() {
+#pragma unroll
+    for (int c = 0; c < NT1; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sm[S::W1 + (16 * w + 4 * q + i) * SX + 16 * c + r] = wW1[c][i];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sm[S::W2 + (16 * w + 4 * q + i) * SH + 16 * c + r] = wW2[c][i];
+      if (S::W2TC) *reinterpret_cast<f32x4*>(sm + S::W2T + (16 * c + r) * SH + 16 * w + 4 * q) = wW2[c];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm[S::WH + (4 * q + i) * SH + 16 * w + r] = wWh[i];
+    *reinterpret_cast<f32x4*>(sm + S::WHT + (16 * w + r) * SA + 4 * q) = wWh;
+    if (q == 0) {
+      sm[S::B1 + jb] = wb1; sm[S::B2 + jb] = wb2;
+      sm[ex_s] = wex;                       // lanes without an extra entry hit a scratch word
+    }
+  };
+  for (int i = tid; i < S::TOTAL; i += TH4) sm[i] = 0.f;
+  __syncthreads();
+  store_weights();
+
+  const int t0 = a.adam_t[0];
+  const float w1 = (float)(1.0 - (double)a.hp.adam_beta1);
+  const float w2 = (float)(1.0 - (double)a.hp.adam_beta2);
+  const float clip = a.hp.clip_range;
+  const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
+  const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
+  const float ent_coef = a.hp.ent_coef;
+
+  // ---------------------------------------------------------------------------------------------------------------
+  // row stream: rows of chunk g+1 are prefetched into registers while chunk g is processed, their permutation indices two
+  // chunks earlier; the schedule comes from the plan tables (uniform scalar loads)
+  // ---------------------------------------------------------------------------------------------------------------
+  auto to_off = [&](int idx) -> unsigned {   // flat env-major index -> [T,N] storage offset (ref: buffers.py:53-65)
+    unsigned env = __umulhi((unsigned)idx, a.t_magic);
+    int t = idx - (int)env * T;
+    if (t >= T) { t -= T; ++env; }
+    if (t >= T) { t -= T; ++env; }
+    return (unsigned)t * (unsigned)N + env;
+  };
+  // this thread's row of a chunk: b = tid/4 — a row of wave w's own tile, so the per-row side data is wave-private
+  const int gb_row = tid >> 2, gpart = tid & 3;
+  // Both index streams are software-pipelined one stage deeper than the data they address: a plan entry is loaded one
+  // step / chunk before the permutation entry it locates (a dependent pair of global loads would otherwise stall the wave
+  // for a full memory round trip at the point where the second address is formed).
+  auto chunk_idx = [&](const PlanChunk& c) -> int { return gb_row < c.rows ? perms[c.perm_base + gb_row] : -1; };
+  auto stat_idx = [&](const PlanStep& p) -> int {       // row tid of that step's minibatch (policy role)
+    return (role == 0 && tid < (p.nb_flags & 0xff)) ? perms[p.perm_base + tid] : -1;
+  };
+  float px[XR], pact[4], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
+  bool pvalid = false;
+  auto issue_rows = [&](int idx) {
+    // every load is issued unconditionally at a clamped (always valid) address; the values are masked only when they are
+    // committed to LDS, so nothing waits on the loads here and all of them are in flight together
+    pvalid = idx >= 0;
+    const size_t off = pvalid ? (size_t)to_off(idx) : 0;
+    const float* orow = p_obs + off * O;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) { const int k = gpart + 4 * i; px[i] = orow[k < O ? k : O - 1]; }
+    if (role == 0) {
+      const float* arow = p_act + off * AS;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int k = gpart + 4 * i; pact[i] = arow[k < AS ? k : AS - 1]; }
+    }
+    psc0 = p_s0[off]; psc1 = p_s1[off]; psc2 = p_s2[off];
+  };
+  auto commit_rows = [&](int xbase) {
+#pragma unroll
+    for (int i = 0; i < XR; ++i) { const int k = gpart + 4 * i; sm[xbase + k * ST + gb_row] = (pvalid && k < O) ? px[i] : 0.f; }
+    if (role == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const int k = gpart + 4 * i; sm[S::ACT + gb_row * SA + k] = (pvalid && k < AS) ? pact[i] : 0.f; }
+    }
+    if (gpart == 0) { sm[S::OLP + gb_row] = pvalid ? psc0 : 0.f; sm[S::ADR + gb_row] = pvalid ? psc1 : 0.f; sm[S::ADC + gb_row] = pvalid ? psc2 : 0.f; }
+  };
+  // advantage statistics of a minibatch (policy role): thread tid < nb (<= 128: waves 0 and 1) holds row tid's (A_r, A_c)
+  float sar = 0.f, sac = 0.f;
+  auto issue_stats = [&](int idx) {
+    const unsigned off = idx >= 0 ? to_off(idx) : 0u;     // rows beyond the minibatch are masked in stats_partials
+    sar = p_s1[off];                                       // (only the policy role uses them)
+    sac = p_s2[off];
+  };
+  // per-wave partial sums into MISC[16 + 3w ..]; combined by everybody after the next barrier (fixed order)
+  auto stats_partials = [&](int nb) {
+    if (role != 0 || w >= 2) return;
+    const bool in = tid < nb;
+    const float s_r = wave_sum_fast(in ? sar : 0.f), s_c = wave_sum_fast(in ? sac : 0.f), s_rr = wave_sum_fast(in ? sar * sar : 0.f);
+    if (lane == 0) { sm[S::MISC + 16 + 3 * w] = s_r; sm[S::MISC + 17 + 3 * w] = s_c; sm[S::MISC + 18 + 3 * w] = s_rr; }
+  };
+  float mean_r = 0.f, istd_r = 1.f, mean_c = 0.f;
+  auto read_stats = [&](int nb) {
+    if (role != 0) return;
+    const float s_r = sm[S::MISC + 16] + sm[S::MISC + 19];
+    const float s_c = sm[S::MISC + 17] + sm[S::MISC + 20];
+    const float s_rr = sm[S::MISC + 18] + sm[S::MISC + 21];
+    const float inv = __builtin_amdgcn_rcpf((float)nb);
+    mean_r = s_r * inv;
+    mean_c = s_c * inv;
+    // unbiased variance from the raw moments (advantages are O(1): fp32 cancellation stays ~1e-6 relative)
+    const float var = fmaxf(s_rr - s_r * mean_r, 0.f) * __builtin_amdgcn_rcpf((float)(nb - 1));
+    istd_r = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var) + 1e-8f);
+  };
+  auto refresh_gauss = [&]() {   // wave 1, lanes q == 0 own log_std r: derived constants of the Gaussian head
+    if (!DISC && role == 0 && w == 1 && q == 0) {
+      const float sd = __expf(wex);
+      const float iv = __builtin_amdgcn_rcpf(sd * sd);
+      sm[S::GAU + r] = r < A ? iv : 0.f;
+      sm[S::GAU + 16 + r] = r < A ? 0.5f * iv : 0.f;
+      sm[S::GAU + 32 + r] = r < A ? wex + LOG_SQRT_2PI_F : 0.f;     // log(sd) = log_std
+    }
+  };
+  float st_ent = 0.f, st_pg = 0.f, st_vl = 0.f, st_cf = 0.f, last_loss = 0.f, kl_sum = 0.f;   // thread 0 of each role
+  int steps_done = 0, early_stop_epoch = a.hp.n_epochs, status = 0;
+
+  // ---- pipeline prologue
+  int g_chunk = 0;                      // global index of the chunk being processed
+  int idx_next = chunk_idx(plan_chunks[1]), idx_nx2 = chunk_idx(plan_chunks[2]);
+  PlanChunk pc_nx3 = plan_chunks[3];    // entry of chunk g + 3, loaded one chunk before its indices are
+  issue_rows(chunk_idx(plan_chunks[0]));
+  PlanStep ps_next = plan_steps[0], ps_nx2 = plan_steps[1], ps_nx3 = plan_steps[2];   // steps st, st + 1, st + 2 at the loop top
+  issue_stats(stat_idx(ps_next));
+  int sidx_next = stat_idx(ps_nx2);
+  refresh_gauss();
+  int xcur = S::XT0;                    // X^T buffer of the chunk being processed
+  commit_rows(xcur);
+  stats_partials(ps_next.nb_flags & 0xff);
+  __syncthreads();
+  read_stats(ps_next.nb_flags & 0xff);
+  const float inv_n_mb = 1.f / (float)((T * N + a.hp.batch_size - 1) / a.hp.batch_size);
+
+  const bool prof = (a.hp._pad & 1) != 0;
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t_last = prof ? stamp() : 0ull;
+
+  bool stop = false;
+  for (int st = 0; st < n_steps && !stop; ++st) {
+    const unsigned step = (unsigned)st + 1u;
+    const PlanStep ps = ps_next;
+    ps_next = ps_nx2; ps_nx2 = ps_nx3;
+    ps_nx3 = plan_steps[st + 3 < n_steps + 2 ? st + 3 : n_steps + 1];     // (the table carries two zero entries at its end)
+    const int nb = ps.nb_flags & 0xff;
+    const float inv_nb = __builtin_amdgcn_rcpf((float)nb);
+    const float c_mean_r = mean_r, c_mean_c = mean_c, c_istd_r = istd_r;   // statistics of THIS minibatch
+    const float cpol_nb = inv_nb * __builtin_amdgcn_rcpf(1.f + nu);
+    issue_stats(sidx_next);              // advantages of the NEXT minibatch's rows (indices loaded a step ago) ...
+    sidx_next = stat_idx(ps_nx2);        // ... and the indices of the one after (step st + 2; its plan entry came a step ago)
+    float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f, mb_s4 = 0.f;  // thread 0: minibatch sums of the loss statistics
+
+    const int n_chunks = (nb + RB - 1) / RB;
+    for (int ch = 0; ch < n_chunks; ++ch, ++g_chunk) {
+      const int nrows = (nb - ch * RB) < RB ? (nb - ch * RB) : RB;
+      if (ch > 0) {  // chunk 0 of a step was committed during the previous step's granule wait (or the prologue); the
+        // chunk-end barrier below separates this from the previous chunk's readers, and the forward reads only this wave's
+        // own rows, which this wave's threads stage
+        if (S::XDB) xcur = xcur == S::XT0 ? S::XT1 : S::XT0;
+        commit_rows(xcur);
+      }
+      const int b = 16 * w + r;             // this lane's row of the chunk (all four q lanes share it)
+      const bool valid = b < nrows;
+      // ================= forward, transposed: rows of the weights x this wave's 16 rows =================
+      f32x4 h1c[4], h2c[4], outc;
+      {
+        float bx[NT1][4];                   // x[row b][k = 16 js + 4q + e]
+        const float* pb = sm + xcur + (4 * q) * ST + b;
+#pragma unroll
+        for (int js = 0; js < NT1; ++js)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bx[js][e] = pb[(16 * js + e) * ST];
+        const float* pa = sm + S::W1 + r * SX + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x4 aw[NT1];
+#pragma unroll
+          for (int js = 0; js < NT1; ++js) aw[js] = lds128(pa + t * 16 * SX + 16 * js);
+          const f32x4 bias = lds128(sm + S::B1 + 16 * t + 4 * q);
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int js = 0; js < NT1; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[js][e], bx[js][e], acc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) h1c[t][i] = fast_tanh(acc[i] + bias[i]);
+        }
+      }
+      // prefetch: rows of the next chunk of the stream, indices of the chunk three ahead.  Issued this early on purpose: the
+      // gathered rows are random 72-byte pieces of a 47 MB buffer and take several microseconds to arrive (measured: issuing
+      // them after the activation backward instead costs 4 000 cycles per step)
+      issue_rows(idx_next);
+      idx_next = idx_nx2;
+      idx_nx2 = chunk_idx(pc_nx3);
+      pc_nx3 = plan_chunks[g_chunk + 4];
+      {
+        const float* pa = sm + S::W2 + r * SH + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x4 aw[4];
+#pragma unroll
+          for (int js = 0; js < 4; ++js) aw[js] = lds128(pa + t * 16 * SH + 16 * js);
+          const f32x4 bias = lds128(sm + S::B2 + 16 * t + 4 * q);
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[js][e], h1c[js][e], acc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) h2c[t][i] = fast_tanh(acc[i] + bias[i]);
+        }
+      }
+      {  // head: outputs o = 4q + i of row b; four independent chains
+        f32x4 aw[4];
+        const float* pa = sm + S::WH + r * SH + 4 * q;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) aw[js] = lds128(pa + 16 * js);
+        const f32x4 bias = lds128(sm + S::BH + 4 * q);
+        f32x4 acc[4];
+#pragma unroll
+        for (int js = 0; js < 4; ++js) {
+          acc[js] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[js] = MFMA_F32(aw[js][e], h2c[js][e], acc[js]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) outc[i] = ((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i])) + bias[i];
+      }
+      // this wave's 16 columns of h1^T / h2^T (read by the weight-gradient GEMMs after the barrier)
+      float* const pt = sm + (4 * q) * ST + b;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          pt[S::H1T + (16 * t + i) * ST] = h1c[t][i];
+          pt[S::H2T + (16 * t + i) * ST] = h2c[t][i];
+        }
+      STAMP(0)   // forward
+      // ============ loss + d loss / d head output, in the C layout (== B operand of the backward) ============
+      f32x4 dout = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;   // per-row statistics (identical in the four q lanes)
+        if (role == 0) {
+          float lp = 0.f, ent = 0.f;
+          f32x4 g1 = f32x4{0.f, 0.f, 0.f, 0.f}, g2 = f32x4{0.f, 0.f, 0.f, 0.f};   // d log-prob / d out, second term
+          if (DISC) {
+            // Categorical(logits) (ref: distributions.py:274-288)
+            float lg[4], zmax = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { lg[i] = (4 * q + i < A) ? outc[i] : -INFINITY; zmax = fmaxf(zmax, lg[i]); }
+            zmax = xor16_max(xor32_max(zmax));
+            float se = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) se += (4 * q + i < A) ? expf(lg[i] - zmax) : 0.f;
+            se = quad_rows_sum(se);
+            const float lse = zmax + logf(se);
+            const int act = (int)sm[S::ACT + b * SA];
+            float pr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int k = 4 * q + i;
+              lg[i] = k < A ? lg[i] - lse : 0.f;
+              pr[i] = k < A ? expf(lg[i]) : 0.f;
+              lp += (k == act) ? lg[i] : 0.f;
+              ent -= pr[i] * lg[i];
+            }
+            lp = quad_rows_sum(lp);
+            ent = quad_rows_sum(ent);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int k = 4 * q + i;
+              g1[i] = k < A ? ((k == act ? 1.f : 0.f) - pr[i]) : 0.f;
+              g2[i] = k < A ? pr[i] * (lg[i] + ent) : 0.f;     // d(-H)/dz_k = p_k (log p_k + H)
+            }
+          } else {
+            const f32x4 actv = lds128(sm + S::ACT + b * SA + 4 * q);
+            const f32x4 iv = lds128(sm + S::GAU + 4 * q), hiv = lds128(sm + S::GAU + 16 + 4 * q), lsd = lds128(sm + S::GAU + 32 + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float dd = actv[i] - outc[i];                 // pad actions / outputs are 0
+              lp += -(dd * dd) * hiv[i] - lsd[i];
+              g1[i] = dd * iv[i];
+              g2[i] = (4 * q + i < A) ? (dd * dd) * iv[i] - 1.f : 0.f;   // d log-prob / d log_std
+            }
+            lp = quad_rows_sum(lp);
+          }
+          const float old_lp = sm[S::OLP + b];
+          const float ratio = __expf(lp - old_lp);
+          const float Ar = (sm[S::ADR + b] - c_mean_r) * c_istd_r;
+          const float Ac = sm[S::ADC + b] - c_mean_c;
+          const float s1 = Ar * ratio;
+          const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+          const float s2 = Ar * rc;
+          const float gsel = (s1 <= s2) ? Ar : 0.f;                       // d min(s1, s2) / d ratio
+          const float dlp = valid ? cpol_nb * (-gsel + nu * Ac) * ratio : 0.f;  // d loss / d log_prob
+          if (DISC) {
+            const float dent = valid ? ent_coef * inv_nb : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dout[i] = dlp * g1[i] + dent * g2[i];
+          } else {
+            f32x4 t;       // d log_std: sum over this wave's 16 rows, per output o = 4q + i
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dout[i] = dlp * g1[i]; t[i] = row_sum(dlp * g2[i]); }
+            if (r == 0) *reinterpret_cast<f32x4*>(sm + S::PLS + 16 * w + 4 * q) = t;
+          }
+          const bool cnt = valid && q == 0;
+          v0 = cnt ? fminf(s1, s2) : 0.f; v1 = cnt ? Ac * ratio : 0.f; v2 = (cnt && fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
+          v3 = cnt ? old_lp - lp : 0.f; v4 = cnt ? ent : 0.f;
+        } else {
+          const float v = quad_rows_sum(q == 0 ? outc[0] : 0.f);      // lane (r, q = 0) holds output 0 of row b
+          const float R = sm[S::ADR + b];
+          float vp = v, pass = 1.f;
+          if (vclip >= 0.f) {
+            const float old = sm[S::OLP + b];
+            const float dv = v - old;
+            vp = old + fminf(fmaxf(dv, -vclip), vclip);
+            pass = (dv >= -vclip && dv <= vclip) ? 1.f : 0.f;
+          }
+          const float e = vp - R;
+          const float d0 = valid ? vcoef * 2.f * e * inv_nb * pass : 0.f;
+          dout[0] = q == 0 ? d0 : 0.f;
+          v0 = (valid && q == 0) ? e * e : 0.f;
+        }
+        // only the q == 0 lanes carry a value: sum over the 16 lanes of row 0
+        v0 = row_sum(v0); v1 = row_sum(v1); v2 = row_sum(v2); v3 = row_sum(v3);
+        if (DISC) v4 = row_sum(v4);
+        if (lane == 0) { float* pst = sm + S::PST + 8 * w; pst[0] = v0; pst[1] = v1; pst[2] = v2; pst[3] = v3; pst[4] = v4; }
+      }
+      STAMP(1)   // loss
+      // ================= backward of the activations (registers only) =================
+      f32x4 dz2c[4], dz1c[4];
+      {  // dH2^T = Wh^T . dOut^T: A = WHT[j = 16t + r][o = 4q + e] (K = 16 outputs)
+        const float* pa = sm + S::WHT + r * SA + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 aw = lds128(pa + t * 16 * SA);
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[e], dout[e], acc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dz2c[t][i] = fmaf(-(h2c[t][i] * h2c[t][i]), acc[i], acc[i]);   // acc (1 - h2^2)
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pt[S::DZ2T + (16 * t + i) * ST] = dz2c[t][i];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pt[S::DOT + i * ST] = dout[i];
+      {  // dH1^T = W2^T . dz2^T: A = W2T[k = 16t + r][j = 16 js + 4q + e]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x4 aw[4];
+          if (S::W2TC) {
+            const float* pa = sm + S::W2T + (16 * t + r) * SH + 4 * q;
+#pragma unroll
+            for (int js = 0; js < 4; ++js) aw[js] = lds128(pa + 16 * js);
+          } else {
+            const float* pa = sm + S::W2 + (4 * q) * SH + 16 * t + r;
+#pragma unroll
+            for (int js = 0; js < 4; ++js)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) aw[js][e] = pa[(16 * js + e) * SH];
+          }
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[js][e], dz2c[js][e], acc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dz1c[t][i] = fmaf(-(h1c[t][i] * h1c[t][i]), acc[i], acc[i]);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pt[S::DZ1T + (16 * t + i) * ST] = dz1c[t][i];
+      lds_barrier();  // (B1) all 64 rows of the activations / their gradients are visible
+      STAMP(2)   // activation backward
+      if (ch == 0) {   // gradient accumulators start their life here
+#pragma unroll
+        for (int c = 0; c < NT1; ++c) gW1r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) gW2r[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
+        gb1r = 0.f; gb2r = 0.f; gex = 0.f;
+      }
+      // ================= weight gradients: rows 16w.. of dW2 / dW1, columns 16w.. of dWh; K = the 64 rows =================
+      {
+        f32x4 az[4];   // dz2^T[j = 16w + r][rows 16 js + 4q + e]
+        const float* pa = sm + S::DZ2T + (16 * w + r) * ST + 4 * q;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) az[js] = lds128(pa + 16 * js);
+        const float* pb = sm + S::H1T + r * ST + 4 * q;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          f32x4 bh[4];
+#pragma unroll
+          for (int js = 0; js < 4; ++js) bh[js] = lds128(pb + t * 16 * ST + 16 * js);
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gW2r[t] = MFMA_F32(az[js][e], bh[js][e], gW2r[t]);
+        }
+        float s = 0.f;     // d b2[16w + r] = sum over the rows
+#pragma unroll
+        for (int js = 0; js < 4; ++js) s += (az[js][0] + az[js][1]) + (az[js][2] + az[js][3]);
+        gb2r += quad_rows_sum(s);
+      }
+      {
+        f32x4 az[4];   // dz1^T[j = 16w + r][rows]
+        const float* pa = sm + S::DZ1T + (16 * w + r) * ST + 4 * q;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) az[js] = lds128(pa + 16 * js);
+        const float* pb = sm + xcur + r * ST + 4 * q;     // x^T[k = 16c + r][rows 16 js + 4q + e]
+#pragma unroll
+        for (int c = 0; c < NT1; ++c) {
+          f32x4 bx[4];
+#pragma unroll
+          for (int js = 0; js < 4; ++js) bx[js] = lds128(pb + c * 16 * ST + 16 * js);
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gW1r[c] = MFMA_F32(az[js][e], bx[js][e], gW1r[c]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) s += (az[js][0] + az[js][1]) + (az[js][2] + az[js][3]);
+        gb1r += quad_rows_sum(s);
+      }
+      {
+        f32x4 ao[4], bh[4];   // dOut^T[o = r][rows], h2^T[j = 16w + r][rows]
+        const float* pa = sm + S::DOT + r * ST + 4 * q;
+        const float* pb = sm + S::H2T + (16 * w + r) * ST + 4 * q;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) { ao[js] = lds128(pa + 16 * js); bh[js] = lds128(pb + 16 * js); }
+        f32x4 acc[4];
+#pragma unroll
+        for (int js = 0; js < 4; ++js) {
+          acc[js] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[js] = MFMA_F32(ao[js][e], bh[js][e], acc[js]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gWhr[i] += (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
+        float s = 0.f;      // head bias (wave 0 keeps it): row sums of dOut^T
+#pragma unroll
+        for (int js = 0; js < 4; ++js) s += (ao[js][0] + ao[js][1]) + (ao[js][2] + ao[js][3]);
+        s = quad_rows_sum(s);
+        // wave 1 (Gaussian policy): d log_std r = sum of the four per-wave partials
+        const float sl = (sm[S::PLS + r] + sm[S::PLS + 16 + r]) + (sm[S::PLS + 32 + r] + sm[S::PLS + 48 + r]);
+        gex += w == 0 ? s : ((!DISC && role == 0 && w == 1) ? sl : 0.f);
+      }
+      if (tid == 0) {
+        mb_s0 += (sm[S::PST + 0] + sm[S::PST + 8]) + (sm[S::PST + 16] + sm[S::PST + 24]);
+        mb_s1 += (sm[S::PST + 1] + sm[S::PST + 9]) + (sm[S::PST + 17] + sm[S::PST + 25]);
+        mb_s2 += (sm[S::PST + 2] + sm[S::PST + 10]) + (sm[S::PST + 18] + sm[S::PST + 26]);
+        mb_s3 += (sm[S::PST + 3] + sm[S::PST + 11]) + (sm[S::PST + 19] + sm[S::PST + 27]);
+        if (DISC) mb_s4 += (sm[S::PST + 4] + sm[S::PST + 12]) + (sm[S::PST + 20] + sm[S::PST + 28]);
+      }
+      if (ch + 1 < n_chunks || !S::XDB) lds_barrier();  // chunk buffers free (single X buffer: also before it is restaged)
+      STAMP(3)   // weight gradients
+    }  // chunks
+
+    // entropy term of the Gaussian policy loss: d(ent_coef * -mean(H)) / d log_std = -ent_coef
+    if (!DISC && role == 0 && w == 1 && r < A) gex += -ent_coef;
+
+    // ================= global gradient norm: this wave's partial sum of squares -> its own 8-byte granule =================
+    float ss = 0.f;
+#pragma unroll
+    for (int c = 0; c < NT1; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ss = fmaf(gW1r[c][i], gW1r[c][i], ss);
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ss = fmaf(gW2r[c][i], gW2r[c][i], ss);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ss = fmaf(gWhr[i], gWhr[i], ss);
+    {
+      const float sb = fmaf(gb1r, gb1r, gb2r * gb2r) + (ex_g >= 0 ? gex * gex : 0.f);
+      ss += q == 0 ? sb : 0.f;
+    }
+    ss = wave_sum_fast(ss);
+    if (lane == 0) {
+      bool want_stop = false;
+      float mean_kl = 0.f;
+      const bool last_mb = (ps.nb_flags >> 9) & 1;
+      const int epoch = ps.nb_flags >> 10;
+      if (tid == 0 && role == 0) {   // the early-stop decision rides on the policy workgroup's first granule
+        if ((ps.nb_flags >> 8) & 1) kl_sum = 0.f;
+        kl_sum += mb_s3 * inv_nb;
+        if (last_mb) {
+          mean_kl = kl_sum * inv_n_mb;
+          const TrainArgs* k_ = KARGS();
+          if (k_->hp.use_target_kl && mean_kl > 1.5f * k_->hp.target_kl) { want_stop = true; early_stop_epoch = epoch; }
+        }
+      }
+      const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
+      __hip_atomic_store(a.xch + (step & 1) * 16 + role * 4 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (tid == 0) {
+        ++steps_done;
+        if (role == 0) {
+          float ent = 0.f;
+          if (DISC) ent = mb_s4 * inv_nb;
+          else for (int k = 0; k < A; ++k) ent += HALF_LOG_2PI_PLUS_HALF_F + sm[S::LS + k];
+          const float entropy_loss = -ent;
+          const float pl = (-(mb_s0 * inv_nb) + nu * (mb_s1 * inv_nb)) * __builtin_amdgcn_rcpf(1.f + nu);
+          st_ent += entropy_loss; st_pg += pl; st_cf += mb_s2 * inv_nb;
+          last_loss = pl + ent_coef * entropy_loss;
+          if (last_mb) { float* stats = KARGS()->stats; stats[32 + epoch] = mean_kl; stats[7] = mean_kl; }
+        } else {
+          const float vl = mb_s0 * inv_nb;
+          st_vl += vl;
+          last_loss = vl;
+        }
+      }
+    }
+    STAMP(4)   // gradient norm + publish
+    // ---- while the granules travel: stage the next minibatch (rows -> the other X^T buffer, advantage statistics)
+    const int xnext = S::XDB ? (xcur == S::XT0 ? S::XT1 : S::XT0) : xcur;
+    commit_rows(xnext);
+    const int nb_next = ps_next.nb_flags & 0xff;
+    stats_partials(nb_next);
+    xcur = xnext;
+    if (tid < 12) {
+      u64 v = 0;
+      int spins = 0;
+      bool ok = false;
+      const u64* const slot = a.xch + (step & 1) * 16 + tid;
+      while (spins < (1 << 24)) {
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+      }
+      sm[S::MISC + tid] = __uint_as_float((unsigned)(v & 0xffffffffu));
+      if (tid == 0) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;
+      if (!ok) sm[S::MISC + 13] = 1.f;
+    }
+    lds_barrier();   // (B3) norm partials, next minibatch and its statistics visible
+    STAMP(5)   // staging + granule wait
+    float total;
+    {
+      const f32x4 n0 = lds128(sm + S::MISC), n1 = lds128(sm + S::MISC + 4), n2 = lds128(sm + S::MISC + 8), fl = lds128(sm + S::MISC + 12);
+      total = ((n0[0] + n0[1]) + (n0[2] + n0[3])) + (((n1[0] + n1[1]) + (n1[2] + n1[3])) + ((n2[0] + n2[1]) + (n2[2] + n2[3])));
+      stop = fl[0] != 0.f;
+      if (fl[1] != 0.f) { status = 1; stop = true; }
+    }
+    total = __builtin_amdgcn_sqrtf(total);
+    float coef = a.hp.max_grad_norm * __builtin_amdgcn_rcpf(total + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    read_stats(nb_next > 0 ? nb_next : 2);
+
+    // ================= Adam (torch.optim.Adam, single-tensor form) on register-resident weights and moments =================
+    if (status == 0) {
+      const float step_size = ps.step_size, inv_bc2_sqrt = ps.inv_bc2_sqrt;
+      const float b2f = a.hp.adam_beta2, epsf = a.hp.adam_eps;
+      auto adam = [&](float g, float& m, float& v, float& p) {
+        g = g * coef;
+        m = m + (g - m) * w1;
+        v = v * b2f + w2 * (g * g);
+        const float denom = __builtin_amdgcn_sqrtf(v) * inv_bc2_sqrt + epsf;     // v_sqrt_f32 / v_rcp_f32: 1 ulp each
+        p = p - step_size * (m * __builtin_amdgcn_rcpf(denom));
+      };
+      // pad elements (k >= obs, o >= n_out) have g = m = v = p = 0 and stay 0: no masks needed
+#pragma unroll
+      for (int c = 0; c < NT1; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { float m_ = mW1[c][i], v_ = vW1[c][i], p_ = wW1[c][i]; adam(gW1r[c][i], m_, v_, p_); mW1[c][i] = m_; vW1[c][i] = v_; wW1[c][i] = p_; }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { float m_ = mW2[c][i], v_ = vW2[c][i], p_ = wW2[c][i]; adam(gW2r[c][i], m_, v_, p_); mW2[c][i] = m_; vW2[c][i] = v_; wW2[c][i] = p_; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { float m_ = mWh[i], v_ = vWh[i], p_ = wWh[i]; adam(gWhr[i], m_, v_, p_); mWh[i] = m_; vWh[i] = v_; wWh[i] = p_; }
+      adam(gb1r, mb1, vb1, wb1);          // identical arithmetic in the four q lanes, lane q == 0 stores
+      adam(gb2r, mb2, vb2, wb2);
+      adam(ex_g >= 0 ? gex : 0.f, mex, vex, wex);
+      store_weights();
+      refresh_gauss();
+    }
+    lds_barrier();   // (B4) updated weights visible
+    STAMP(6)   // Adam
+  }  // optimiser steps
+
+  __syncthreads();
+  // ---- write back weights, moments, statistics.  The pointers / offsets are re-read from the kernel-argument segment here
+  // instead of being kept in scalar registers across the whole optimisation loop.
+  {
+  const TrainArgs* ka = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const TrainArgs& a = *ka;
+  const PolLayout& L = a.L;
+  const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
+  const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
+#pragma unroll
+  for (int c = 0; c < NT1; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      if (k < O) { a.params[gW1 + j * O + k] = wW1[c][i]; a.exp_avg[gW1 + j * O + k] = mW1[c][i]; a.exp_avg_sq[gW1 + j * O + k] = vW1[c][i]; }
+    }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      a.params[gW2 + j * HD + k] = wW2[c][i];
+      a.exp_avg[gW2 + j * HD + k] = mW2[c][i];
+      a.exp_avg_sq[gW2 + j * HD + k] = vW2[c][i];
+    }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int o = 4 * q + i, j = 16 * w + r;
+    if (o < n_out) { a.params[gWh + o * HD + j] = wWh[i]; a.exp_avg[gWh + o * HD + j] = mWh[i]; a.exp_avg_sq[gWh + o * HD + j] = vWh[i]; }
+  }
+  if (q == 0) {
+    a.params[gb1 + jb] = wb1; a.exp_avg[gb1 + jb] = mb1; a.exp_avg_sq[gb1 + jb] = vb1;
+    a.params[gb2 + jb] = wb2; a.exp_avg[gb2 + jb] = mb2; a.exp_avg_sq[gb2 + jb] = vb2;
+    if (ex_g >= 0) { a.params[ex_g] = wex; a.exp_avg[ex_g] = mex; a.exp_avg_sq[ex_g] = vex; }
+  }
+  if (tid == 0 && prof) {
+    for (int k = 0; k < 7; ++k) {
+      const int slot = 12 + 7 * role + k;
+      if (slot < 32) a.stats[slot] = (float)((double)ph[k] / (double)(steps_done > 0 ? steps_done : 1));
+    }
+  }
+  if (tid == 0) {
+    if (role == 0) {
+      a.stats[0] = (float)early_stop_epoch;
+      a.stats[1] = (float)steps_done;
+      a.stats[2] = st_ent; a.stats[3] = st_pg; a.stats[6] = st_cf;
+      a.stats[8] = last_loss;
+      a.stats[11] = (float)status;
+      a.adam_t[0] = t0 + steps_done;
+    } else if (role == 1) {
+      a.stats[4] = st_vl; a.stats[9] = last_loss;
+    } else {
+      a.stats[5] = st_vl; a.stats[10] = last_loss;
+    }
+  }
+  }
+}
+
+template <int NT1, bool DISC>
+static int launch_rows(const TrainArgs& a, hipStream_t s) {
+  static_assert(SmemR<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
+  const size_t bytes = (size_t)SmemR<NT1>::TOTAL * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_kernel<NT1, DISC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((ppo_train_rows_kernel<NT1, DISC>), dim3(3), dim3(TH4), bytes, s, a);
+  return (int)hipGetLastError();
+}
+
+int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, hipStream_t s) {
+  if (nt1 <= 2) return discrete ? launch_rows<2, true>(a, s) : launch_rows<2, false>(a, s);
+  if (nt1 <= 4) return discrete ? launch_rows<4, true>(a, s) : launch_rows<4, false>(a, s);
+  return (int)hipErrorInvalidValue;
+}
+
+}  // namespace icrl

@@ -16,3 +16,19 @@ agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost")
 torch.cuda.synchronize(); t0 = time.time()
 agent.train()
 torch.cuda.synchronize(); print("train ms", 1e3 * (time.time() - t0))
+agent.train_events = []
+for variant in ("tiles", "auto", "tiles", "auto"):
+    agent.train_kernel = variant
+    agent.train_events.clear()
+    agent.train()
+    torch.cuda.synchronize()
+    e0, e1, n = agent.train_events[-1]
+    print(variant, "us/step", 1e3 * e0.elapsed_time(e1) / n, "steps", n)
+for variant in ("tiles", "auto"):
+    agent.train_kernel = variant
+    agent.profile_phases = 1
+    agent.train()
+    torch.cuda.synchronize()
+    st = agent._train_ws["stats"].cpu().numpy()
+    print(variant, "cycles/step per phase (role 0 | 1 | 2[:6]):", np.round(st[12:19]), np.round(st[19:26]), np.round(st[26:32]))
+agent.profile_phases = 0

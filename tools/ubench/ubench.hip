@@ -1,0 +1,276 @@
+// Micro-benchmarks of the building blocks of the PPO update kernel on gfx950 (one wave per SIMD unless stated):
+// cycles (s_memtime, 100 MHz-independent shader clock) per operation.  Build: hipcc --offload-arch=gfx950 -O3 ubench.hip -o ubench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ unsigned long long now() {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  const float xc = fminf(fmaxf(x, -15.f), 15.f);
+  const float e = __expf(2.f * xc);
+  return (e - 1.f) * __builtin_amdgcn_rcpf(e + 1.f);
+}
+__device__ __forceinline__ float fast_tanh2(float x) {   // 1 - 2 / (exp2(c x) + 1)
+  const float e = __builtin_amdgcn_exp2f(x * 2.885390081777927f);
+  return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
+}
+
+template <int CHAINS>
+__global__ void k_mfma(float* out, unsigned long long* cyc, int iters) {
+  f32x4 acc[CHAINS];
+  for (int c = 0; c < CHAINS; ++c) acc[c] = f32x4{0, 0, 0, 0};
+  float a = threadIdx.x * 0.001f, b = threadIdx.x * 0.002f;
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+#pragma unroll
+      for (int c = 0; c < CHAINS; ++c) acc[c] = MFMA(a, b, acc[c]);
+  }
+  unsigned long long t1 = now();
+  float s = 0;
+  for (int c = 0; c < CHAINS; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+template <int WHICH>
+__global__ void k_tanh(float* out, unsigned long long* cyc, int iters) {
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 0.01f + i;
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i)
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = WHICH == 0 ? fast_tanh(v[u] + 0.1f) : fast_tanh2(v[u] + 0.1f);
+  unsigned long long t1 = now();
+  float s = 0;
+  for (int i = 0; i < 16; ++i) s += v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+// MFMA interleaved with independent tanh work: does the VALU work hide under the matrix pipe?
+__global__ void k_mix(float* out, unsigned long long* cyc, int iters) {
+  f32x4 acc[4];
+  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0, 0, 0, 0};
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 0.01f + i;
+  float a = threadIdx.x * 0.001f, b = threadIdx.x * 0.002f;
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = MFMA(a, b, acc[c]);
+      v[u] = fast_tanh2(v[u] + 0.1f);
+    }
+  }
+  unsigned long long t1 = now();
+  float s = 0;
+  for (int c = 0; c < 4; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  for (int i = 0; i < 16; ++i) s += v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+// the same mix with the interleaving forced: 1 MFMA, then up to 2 VALU, ... (sched_group_barrier masks: 0x8 MFMA, 0x2 VALU)
+__global__ void k_mix_sched(float* out, unsigned long long* cyc, int iters) {
+  f32x4 acc[4];
+  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0, 0, 0, 0};
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 0.01f + i;
+  float a = threadIdx.x * 0.001f, b = threadIdx.x * 0.002f;
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = MFMA(a, b, acc[c]);
+      v[u] = fast_tanh2(v[u] + 0.1f);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+      }
+    }
+  }
+  unsigned long long t1 = now();
+  float s = 0;
+  for (int c = 0; c < 4; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  for (int i = 0; i < 16; ++i) s += v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+// 4 MFMA + 16 independent plain VALU ops (4 per MFMA shadow)
+__global__ void k_mix_valu(float* out, unsigned long long* cyc, int iters, int mode) {
+  f32x4 acc[4];
+  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0, 0, 0, 0};
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 0.01f + i;
+  float a = threadIdx.x * 0.001f, b = threadIdx.x * 0.002f;
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = MFMA(a, b, acc[c]);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = fmaf(v[k], 1.0001f, 0.5f);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x2, 4, 0);
+      }
+    }
+  }
+  unsigned long long t1 = now();
+  float s = 0;
+  for (int c = 0; c < 4; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  for (int i = 0; i < 16; ++i) s += v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+// two waves per SIMD in different phases: waves 0-3 only MFMA, waves 4-7 only VALU (does the VALU work of ANOTHER wave hide?)
+__global__ void k_split(float* out, unsigned long long* cyc, int iters) {
+  f32x4 acc[4];
+  for (int c = 0; c < 4; ++c) acc[c] = f32x4{0, 0, 0, 0};
+  float v[16];
+  for (int i = 0; i < 16; ++i) v[i] = threadIdx.x * 0.01f + i;
+  float a = threadIdx.x * 0.001f, b = threadIdx.x * 0.002f;
+  const bool matrix = threadIdx.x < 256;
+  unsigned long long t0 = now();
+  if (matrix) {
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = MFMA(a, b, acc[c]);
+  } else {
+    for (int i = 0; i < iters; ++i)
+#pragma unroll
+      for (int u = 0; u < 32; ++u)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = fmaf(v[k], 1.0001f, 0.5f);
+  }
+  unsigned long long t1 = now();
+  float s = 0;
+  for (int c = 0; c < 4; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  for (int i = 0; i < 16; ++i) s += v[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 255) == 0) cyc[threadIdx.x >> 8] = t1 - t0;
+}
+
+// LDS: batch of NB ds_read_b128 with the operand pattern of the kernel (row stride S), then use
+template <int NB, int S>
+__global__ void k_lds128(float* out, unsigned long long* cyc, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  for (int i = threadIdx.x; i < 64 * S; i += blockDim.x) sm[i] = i;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  float s = 0;
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i) {
+    f32x4 v[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) v[u] = *reinterpret_cast<const f32x4*>(sm + ((u / 4) * 16 + r) * S + 16 * (u % 4) + 4 * q);
+#pragma unroll
+    for (int u = 0; u < NB; ++u) s += v[u][0] + v[u][3];
+    asm volatile("" ::: "memory");
+  }
+  unsigned long long t1 = now();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+// transposed b32 reads (dH1 A operand): NB reads at (16 js + 4 q + e) * S + 16 t + r
+template <int NB, int S>
+__global__ void k_lds32(float* out, unsigned long long* cyc, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  for (int i = threadIdx.x; i < 64 * S; i += blockDim.x) sm[i] = i;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  float s = 0;
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i) {
+    float v[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) v[u] = sm[(16 * ((u / 4) % 4) + 4 * q + (u % 4)) * S + 16 * (u / 16) + r];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) s += v[u];
+    asm volatile("" ::: "memory");
+  }
+  unsigned long long t1 = now();
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
+__global__ void k_barrier(float* out, unsigned long long* cyc, int iters) {
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  unsigned long long t1 = now();
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+  out[threadIdx.x] = 0;
+}
+
+// agent-scope granule round trip between two workgroups (ping-pong)
+__global__ void k_pingpong(unsigned long long* flag, unsigned long long* cyc, int iters) {
+  if (threadIdx.x != 0) return;
+  const int me = blockIdx.x;
+  unsigned long long t0 = now();
+  for (int i = 1; i <= iters; ++i) {
+    if (me == 0) {
+      __hip_atomic_store(flag, (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      while (__hip_atomic_load(flag + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)i) {}
+    } else {
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (unsigned long long)i) {}
+      __hip_atomic_store(flag + 16, (unsigned long long)i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  unsigned long long t1 = now();
+  cyc[me] = t1 - t0;
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+int main() {
+  float* out; unsigned long long* cyc; unsigned long long* flag;
+  CK(hipMalloc(&out, 1 << 20)); CK(hipMalloc(&cyc, 4096)); CK(hipMalloc(&flag, 4096));
+  CK(hipMemset(flag, 0, 4096));
+  std::vector<unsigned long long> h(16);
+  const int it = 200;
+  auto rd = [&](const char* name, double per) { hipDeviceSynchronize(); hipMemcpy(h.data(), cyc, 64, hipMemcpyDeviceToHost); printf("%-46s %8.1f cycles\n", name, (double)h[0] / per); return 0; };
+  hipLaunchKernelGGL(k_mfma<1>, dim3(1), dim3(64), 0, 0, out, cyc, it); rd("mfma 16x16x4 f32, 1 dependent chain, 1 wave", it * 16.0);
+  hipLaunchKernelGGL(k_mfma<2>, dim3(1), dim3(64), 0, 0, out, cyc, it); rd("mfma, 2 chains, per mfma", it * 32.0);
+  hipLaunchKernelGGL(k_mfma<4>, dim3(1), dim3(64), 0, 0, out, cyc, it); rd("mfma, 4 chains, per mfma", it * 64.0);
+  hipLaunchKernelGGL(k_mfma<4>, dim3(1), dim3(256), 0, 0, out, cyc, it); rd("mfma, 4 chains, 4 waves (1/SIMD), per mfma", it * 64.0);
+  hipLaunchKernelGGL(k_mfma<4>, dim3(1), dim3(512), 0, 0, out, cyc, it); rd("mfma, 4 chains, 8 waves (2/SIMD), per mfma/wave", it * 64.0);
+  hipLaunchKernelGGL(k_tanh<0>, dim3(1), dim3(64), 0, 0, out, cyc, it); rd("fast_tanh (clamp, exp, rcp) per value", it * 16.0);
+  hipLaunchKernelGGL(k_tanh<1>, dim3(1), dim3(64), 0, 0, out, cyc, it); rd("fast_tanh2 (exp2, rcp, fma) per value", it * 16.0);
+  hipLaunchKernelGGL(k_mix, dim3(1), dim3(64), 0, 0, out, cyc, it); rd("4 mfma + 1 tanh2 interleaved, per group", it * 16.0);
+  hipLaunchKernelGGL(k_mix_sched, dim3(1), dim3(64), 0, 0, out, cyc, it); rd("4 mfma + 1 tanh2, forced interleave, per group", it * 16.0);
+  hipLaunchKernelGGL(k_mix_valu, dim3(1), dim3(64), 0, 0, out, cyc, it, 0); rd("4 mfma + 16 fma forced interleave (4 per mfma)", it * 4.0);
+  hipLaunchKernelGGL(k_split, dim3(1), dim3(512), 0, 0, out, cyc, it); hipDeviceSynchronize(); hipMemcpy(h.data(), cyc, 64, hipMemcpyDeviceToHost);
+  printf("split phases, 2 waves/SIMD: matrix waves %.0f cycles / 64 mfma (alone: 2048), vector waves %.0f cycles / 512 fma (alone: ~2048)\n", (double)h[0] / it, (double)h[1] / it);
+  hipLaunchKernelGGL((k_lds128<16, 72>), dim3(1), dim3(64), 72 * 64 * 4, 0, out, cyc, it); rd("16 x ds_read_b128 stride 72, 1 wave, per batch", it);
+  hipLaunchKernelGGL((k_lds128<16, 72>), dim3(1), dim3(256), 72 * 64 * 4, 0, out, cyc, it); rd("16 x ds_read_b128 stride 72, 4 waves, per batch", it);
+  hipLaunchKernelGGL((k_lds128<16, 68>), dim3(1), dim3(256), 72 * 64 * 4, 0, out, cyc, it); rd("16 x ds_read_b128 stride 68, 4 waves, per batch", it);
+  hipLaunchKernelGGL((k_lds128<4, 72>), dim3(1), dim3(256), 72 * 64 * 4, 0, out, cyc, it); rd("4 x ds_read_b128 stride 72, 4 waves, per batch", it);
+  hipLaunchKernelGGL((k_lds32<64, 72>), dim3(1), dim3(256), 72 * 64 * 4, 0, out, cyc, it); rd("64 x ds_read_b32 transposed stride 72, 4 waves", it);
+  hipLaunchKernelGGL((k_lds32<64, 68>), dim3(1), dim3(256), 72 * 64 * 4, 0, out, cyc, it); rd("64 x ds_read_b32 transposed stride 68, 4 waves", it);
+  hipLaunchKernelGGL((k_lds32<16, 72>), dim3(1), dim3(256), 72 * 64 * 4, 0, out, cyc, it); rd("16 x ds_read_b32 transposed stride 72, 4 waves", it);
+  hipLaunchKernelGGL(k_barrier, dim3(1), dim3(256), 0, 0, out, cyc, it); rd("s_barrier, 4 waves", it);
+  hipLaunchKernelGGL(k_barrier, dim3(1), dim3(512), 0, 0, out, cyc, it); rd("s_barrier, 8 waves", it);
+  hipLaunchKernelGGL(k_pingpong, dim3(2), dim3(64), 0, 0, flag, cyc, it); rd("granule round trip between 2 workgroups", it);
+  // shader clock vs wall clock
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0); hipLaunchKernelGGL(k_mfma<4>, dim3(1), dim3(64), 0, 0, out, cyc, 20000); hipEventRecord(e1); hipDeviceSynchronize();
+  float ms; hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h.data(), cyc, 64, hipMemcpyDeviceToHost);
+  printf("s_memtime ticks per us: %.1f  (ticks %llu over %.3f ms)\n", (double)h[0] / (ms * 1e3), h[0], ms);
+  return 0;
+}
