@@ -45,20 +45,11 @@ struct PlanChunk {
 };
 
 // sum over the 16 lanes sharing lane/16
-__device__ __forceinline__ float sum16(float v) {
-  v += __shfl_xor(v, 1, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 8, 64);
-  return v;
-}
+__device__ __forceinline__ float sum16(float v) { return row_sum(v); }   // DPP row operations (common.h)
 
 // column sums of a wave's 16x16 accumulator tile: every lane ends with the sum over the tile's 16 rows of column lane%16
 __device__ __forceinline__ float tile_colsum(const f32x4& t) {
-  float s = (t[0] + t[1]) + (t[2] + t[3]);
-  s += __shfl_xor(s, 16, 64);
-  s += __shfl_xor(s, 32, 64);
-  return s;
+  return quad_rows_sum((t[0] + t[1]) + (t[2] + t[3]));
 }
 
 // diagnostic phase timer (only when hp._pad != 0: the stamp drains the LDS queue, so never in a timed run)

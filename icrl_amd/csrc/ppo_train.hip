@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
   auto compute_stats = [&](int nb) {  // all threads of a policy workgroup; uses sar / sac.  ONE block reduction.
     if (role != 0) return;
     const bool in = tid < nb;
-    float s_r = wave_sum(in ? sar : 0.f), s_c = wave_sum(in ? sac : 0.f), s_rr = wave_sum(in ? sar * sar : 0.f);
+    float s_r = wave_sum_fast(in ? sar : 0.f), s_c = wave_sum_fast(in ? sac : 0.f), s_rr = wave_sum_fast(in ? sar * sar : 0.f);
     lds_barrier();
     if (lane == 0) { sm[S::MISC + 16 + w] = s_r; sm[S::MISC + 24 + w] = s_c; sm[S::MISC + 32 + w] = s_rr; }
     lds_barrier();
@@ -414,13 +414,11 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
               lg[i] = k < A ? dor[k] : -INFINITY;
               zmax = fmaxf(zmax, lg[i]);
             }
-            zmax = fmaxf(zmax, __shfl_xor(zmax, 16, 64));
-            zmax = fmaxf(zmax, __shfl_xor(zmax, 32, 64));
+            zmax = xor16_max(xor32_max(zmax));
             float se = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) se += (q + 4 * i < A) ? expf(lg[i] - zmax) : 0.f;
-            se += __shfl_xor(se, 16, 64);
-            se += __shfl_xor(se, 32, 64);
+            se = quad_rows_sum(se);
             const float lse = zmax + logf(se);
             const int act = (int)sm[S::ACT + b * SH];
             float lp = 0.f, ent = 0.f;
@@ -432,10 +430,8 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
               lp += (k == act) ? lg[i] : 0.f;
               ent -= pr[i] * lg[i];
             }
-            lp += __shfl_xor(lp, 16, 64);
-            lp += __shfl_xor(lp, 32, 64);
-            ent += __shfl_xor(ent, 16, 64);               // entropy of row b
-            ent += __shfl_xor(ent, 32, 64);
+            lp = quad_rows_sum(lp);
+            ent = quad_rows_sum(ent);
             const float old_lp = sm[S::OLP + b * SH];
             const float ratio = __expf(lp - old_lp);
             const float Ar = (sm[S::ADR + b * SH] - c_mean_r) * c_istd_r;
@@ -476,8 +472,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
               iv[i] = sm[S::GAU + k];
               lp += -(dd[i] * dd[i]) * sm[S::GAU + 16 + k] - sm[S::GAU + 32 + k];
             }
-            lp += __shfl_xor(lp, 16, 64);                   // sum over the 4 lane groups -> log-prob of row b
-            lp += __shfl_xor(lp, 32, 64);
+            lp = quad_rows_sum(lp);
             const float old_lp = sm[S::OLP + b * SH];
             const float ratio = __expf(lp - old_lp);
             const float Ar = (sm[S::ADR + b * SH] - c_mean_r) * c_istd_r;
@@ -704,7 +699,7 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) ss += gWhr[i] * gWhr[i];
       if (vec_g >= 0) ss += gB * gB;
-      ss = wave_sum(ss);
+      ss = wave_sum_fast(ss);
       if (lane == 0) sm[S::MISC + w] = ss;
       lds_barrier();
       // the early-stop decision rides on the policy workgroup's granule; publish first, book-keep afterwards
