@@ -74,6 +74,7 @@ struct PolRegs {
   float w2[MAX_H];
   float wh[MAX_H];   // wave 0: head column of action `lane`; waves 1/2: wh[0] = value-head weight of hidden unit `lane`
   float b1, b2, bh, ls;
+  float sd, lsd, i2v;   // Gaussian head constants of action `lane`: exp(log_std), log(exp(log_std)), 1 / (2 sd^2) denominators
 };
 
 template <int OCT>
@@ -87,13 +88,15 @@ __device__ __forceinline__ void load_pol_regs(const PolLayout& L, const float* _
   for (int k = 0; k < MAX_H; ++k) R.w2[k] = (w < 3 && k < L.H1) ? PT[L.W2[w] + k * L.H2 + j2] : 0.f;
   R.b1 = w < 3 ? PT[L.b1[w] + j1] : 0.f;
   R.b2 = w < 3 ? PT[L.b2[w] + j2] : 0.f;
-  R.bh = 0.f; R.ls = 0.f;
+  R.bh = 0.f; R.ls = 0.f; R.sd = 1.f; R.lsd = 0.f; R.i2v = 2.f;
   if (w == 0) {
     const int a = lane < L.A ? lane : 0;
 #pragma unroll
     for (int j = 0; j < MAX_H; ++j) R.wh[j] = j < L.H2 ? PT[L.Wa + j * L.A + a] : 0.f;
     R.bh = PT[L.ba + a];
     if (!L.discrete) R.ls = PT[L.log_std + a];
+    // constants of the whole rollout: evaluated once here instead of once per env step (same expressions as before)
+    R.sd = expf(R.ls); R.lsd = logf(R.sd); R.i2v = 2.f * (R.sd * R.sd);
   } else if (w < 3) {
 #pragma unroll
     for (int j = 1; j < MAX_H; ++j) R.wh[j] = 0.f;
@@ -147,22 +150,22 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const P
     if (!L.discrete) {
       float lp = 0.f, entl = 0.f;
       if (lane < L.A) {
-        const float std = expf(R.ls);
+        const float std = R.sd;
         float act = mean;
         if (given != nullptr) act = given[lane];
         else if (!deterministic) act = mean + noise_row[lane] * std;   // Normal.rsample: loc + eps * scale
         const float diff = act - mean;
         // Normal.log_prob: -((x - mu)^2) / (2 var) - log(std) - log(sqrt(2 pi))
-        lp = -(diff * diff) / (2.f * (std * std)) - logf(std) - LOG_SQRT_2PI_F;
-        entl = HALF_LOG_2PI_PLUS_HALF_F + logf(std);
+        lp = -(diff * diff) / R.i2v - R.lsd - LOG_SQRT_2PI_F;
+        entl = HALF_LOG_2PI_PLUS_HALF_F + R.lsd;
         sh.act_raw[lane] = act;
         float c = act;
         if (alow != nullptr && ahigh != nullptr) c = fminf(fmaxf(act, alow[lane]), ahigh[lane]);
         sh.act_clip[lane] = c;
       }
-      lp = wave_sum(lp);
+      lp = wave_sum_fast(lp);
       // entropy of the diagonal Gaussian: sum_a 0.5 + 0.5 log(2 pi) + log sigma_a
-      const float ent = wave_sum(entl);
+      const float ent = wave_sum_fast(entl);
       if (lane == 0) { sh.scal[2] = lp; sh.scal[3] = ent; }
     } else {
       // Categorical(logits): log-softmax, inverse-CDF sample on the injected uniform (spec: oracle/nets.py forward)
@@ -194,7 +197,7 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const P
     }
   } else if (w < 3) {
     float part = lane < L.H2 ? R.wh[0] * sh.g[w][lane] : 0.f;
-    part = wave_sum(part);
+    part = wave_sum_fast(part);
     if (lane == 0) sh.scal[w - 1] = part + R.bh;
   }
 }
@@ -280,7 +283,7 @@ __device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, con
     last = 1;
   }
   float part = lane < L.H2 ? R.wo * ch[last][lane] : 0.f;
-  const float z = wave_sum(part) + R.bo;
+  const float z = wave_sum_fast(part) + R.bo;
   const float zeta = 1.f / (1.f + expf(-z));
   return 1.f - zeta;
 }
@@ -763,6 +766,250 @@ __global__ void __launch_bounds__(1024) norm_step_small_kernel(NormStepArgs a) {
   }
 }
 
+// =================================================================================================================
+// persistent rollout: ALL T steps of collect_rollouts in one launch (N <= 128 envs, N * obs <= NORM_CHUNK)
+//
+// One workgroup per env runs kernel A's work for its env; the normaliser needs every env's raw observation / reward / cost of
+// the step, so the workgroups exchange them through global memory and meet at ONE device-wide barrier per step.  After
+// the barrier EVERY workgroup evaluates kernel B's statistics update redundantly — same inputs, same (numpy) summation order,
+// hence bit-identical replicas of obs_rms / ret_rms / cost_rms / ret / cost_ret in each workgroup's registers and LDS — and
+// normalises only its own env.  The exchange arrays are double-buffered by step parity, which is what makes a single barrier
+// per step sufficient (a workgroup can be at most one phase ahead of the slowest one).  Policy / cost-net weights, the
+// dynamics matrix and the replicated statistics are loaded once for the whole rollout.
+// =================================================================================================================
+// diagnostic: cycles per phase of workgroup 0 of the last persistent rollout (policy+env | barrier | statistics), steps
+__device__ unsigned long long g_rollout_prof[8];
+__device__ __forceinline__ unsigned long long prof_now() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+
+struct PersistArgs {
+  ActStepArgs act;
+  icrl_norm_t nm;
+  int T;
+  double* xch_obs;     // [2][N][O]
+  double* xch_rew;     // [2][N]
+  float* xch_cost;     // [2][N]
+  unsigned* xch_done;  // [2][N]
+  unsigned* counter;   // [N] barrier flags, zeroed before the launch
+  int prof;            // diagnostic phase timers (do_gae bit 2)
+};
+
+// Exchange between the workgroups of the persistent rollout.  Every exchanged word is written and read with agent-scope
+// relaxed atomics (write-through stores / cache-bypassing loads: cdna_hip_programming.md Guideline 16), so no bulk cache
+// write-back / invalidate fence is needed — those cost ~4 us per step on this part.  Ordering: the publisher drains its
+// stores (s_waitcnt vmcnt(0)) before it raises its flag; consumers read data only after they have seen the flag.
+__device__ __forceinline__ void xstore(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xstore(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xstore(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double xload(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ float xload(const float* p) {
+  return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ unsigned xload(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// device-wide barrier over the N (<= 128) workgroups: workgroup n raises its own flag word to `value` (no read-modify-write
+// contention on one address), wave 0 polls all N flags with one or two loads per lane.  Flags only grow: no reset.
+__device__ __forceinline__ void grid_barrier(unsigned* flags, int N, int n, unsigned value) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's exchange stores have been performed
+  __syncthreads();                                      // ... and everybody else's in the workgroup
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    if (lane == 0) xstore(flags + n, value);
+    int spins = 0;
+    while (spins < (1 << 24)) {
+      const unsigned v0 = lane < N ? xload(flags + lane) : value;
+      const unsigned v1 = lane + 64 < N ? xload(flags + lane + 64) : value;
+      if (__all(v0 >= value && v1 >= value)) break;
+      ++spins;
+    }
+  }
+  __syncthreads();
+}
+
+template <int OCT, int CIT>
+__global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) {
+  __shared__ ActShared sh;
+  __shared__ double chunk[NORM_CHUNK];
+  __shared__ double vec[2][128], dev2[2][128], ret_s[128], cret_s[128], rawr_s[128];
+  __shared__ float rawc_s[128];
+  __shared__ double dens[2];
+  __shared__ double Bl[MAX_OBS * MAX_ACT];
+  __shared__ float noise_s[MAX_ACT];
+  __shared__ int done_s[128];
+  __shared__ int last_done_s;
+  const ActStepArgs& a = p.act;
+  const icrl_norm_t& nm = p.nm;
+  PolRegs<OCT> R;
+  CnRegs<CIT> C;
+  load_pol_regs<OCT>(a.pl, a.PT, R);
+  if (threadIdx.x >= 192 && a.has_cn) load_cn_regs<CIT>(a.cn, a.cl, C);
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs, T = p.T;
+  const int AS = a.buf.act_store;
+  const int NA = a.pl.discrete ? 1 : A;       // noise values per env step
+  const bool has_cost = a.has_cn != 0;
+  const uint32_t e_key = a.env.key[n];
+  uint32_t e_ctr = a.env.step_count[n];
+  int e_tep = a.env.t_ep[n];
+  icrl_env_t env = a.env;
+  for (int i = tid; i < O * a.env.act_dim; i += 256) Bl[i] = a.env.B[i];
+  env.B = Bl;
+  for (int i = tid; i < MAX_OBS; i += 256) {
+    sh.x[i] = i < O ? (float)a.ag.last_obs[(size_t)n * O + i] : 0.f;
+    if (i < O) sh.s_old[i] = a.env.s[(size_t)n * O + i];
+  }
+  if (tid < N) { ret_s[tid] = nm.ret[tid]; cret_s[tid] = nm.cost_ret[tid]; }
+  if (tid == 0) last_done_s = a.ag.last_dones[n];
+  // replicated running statistics: observation columns in threads < O, ret_rms in wave 3, cost_rms in wave 2
+  double o_mean = 0.0, o_var = 1.0, o_cnt = 0.0, o_last = 0.0;
+  if (tid < O) { o_mean = nm.obs_mean[tid]; o_var = nm.obs_var[tid]; o_cnt = nm.obs_count[0]; o_last = a.ag.last_obs[(size_t)n * O + tid]; }
+  double st_m = 0.0, st_v = 1.0, st_c = 0.0;
+  if (w == 3) { st_m = nm.ret_stats[0]; st_v = nm.ret_stats[1]; st_c = nm.ret_stats[2]; }
+  if (w == 2) { st_m = nm.cost_stats[0]; st_v = nm.cost_stats[1]; st_c = nm.cost_stats[2]; }
+  float noise_reg = (tid < NA) ? a.noise[(size_t)n * NA + tid] : 0.f;
+  double fin_rew = 0.0; float fin_cost = 0.f; int fin_done = 0;
+  unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, tl = p.prof ? prof_now() : 0ull;
+  for (int t = 0; t < T; ++t) {
+    const int par = t & 1;
+    const size_t tn = (size_t)t * N + n;
+    if (tid < NA) {
+      noise_s[tid] = noise_reg;
+      if (t + 1 < T) noise_reg = a.noise[((size_t)(t + 1) * N + n) * NA + tid];     // lands during this step
+    }
+    __syncthreads();
+    // ---------------- phase A: kernel A's work for env n ----------------
+    policy_forward_block<OCT>(a.pl, R, sh, noise_s, 0, a.alow, a.ahigh);
+    __syncthreads();
+    if (w == 0) {
+      double rew; int done;
+      env_step_wave(env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
+      float* nob = a.buf.new_orig_observations + tn * O;
+      double* xo = p.xch_obs + ((size_t)par * N + n) * O;
+      for (int i = lane; i < O; i += WAVE) { const double v = sh.s_new[i]; nob[i] = (float)v; xstore(xo + i, v); }
+      if (lane == 0) { xstore(p.xch_rew + par * N + n, rew); xstore(p.xch_done + par * N + n, (unsigned)done); }
+    } else if (w == 3) {
+      float cost = 0.f;
+      if (a.has_cn) cost = cost_forward_wave<CIT>(a.cn, a.cl, C, sh.s_old, sh.act_clip, sh.cx, sh.ch);
+      if (lane == 0) { xstore(p.xch_cost + par * N + n, cost); a.buf.orig_costs[tn] = cost; }
+    } else if (w == 2) {
+      float* ob = a.buf.observations + tn * O;
+      float* oob = a.buf.orig_observations + tn * O;
+      for (int i = lane; i < O; i += WAVE) { ob[i] = sh.x[i]; oob[i] = (float)sh.s_old[i]; }
+      if (lane < AS) a.buf.actions[tn * AS + lane] = sh.act_raw[lane];
+      if (lane < A && !a.pl.discrete) a.ag.act_clipped[(size_t)n * A + lane] = sh.act_clip[lane];
+      if (lane == 0) {
+        a.buf.dones[tn] = (float)last_done_s;
+        a.buf.reward_values[tn] = sh.scal[0];
+        a.buf.cost_values[tn] = sh.scal[1];
+        a.buf.log_probs[tn] = sh.scal[2];
+        a.ag.last_v_r[n] = sh.scal[0];
+        a.ag.last_v_c[n] = sh.scal[1];
+      }
+    }
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }
+    grid_barrier(p.counter, N, n, (unsigned)(t + 1));
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }
+    // ---------------- phase B: kernel B's statistics, replicated; normalise own env ----------------
+    {
+      const double* xo = p.xch_obs + (size_t)par * N * O;
+      for (int i = tid; i < N * O; i += 256) chunk[i] = xload(xo + i);
+      if (tid < N) {
+        const double rr = xload(p.xch_rew + par * N + tid);
+        const float rc = has_cost ? xload(p.xch_cost + par * N + tid) : 0.f;
+        rawr_s[tid] = rr; rawc_s[tid] = rc; done_s[tid] = (int)xload(p.xch_done + par * N + tid);
+        double r = ret_s[tid], c = has_cost ? cret_s[tid] : 0.0;
+        if (nm.training) {
+          r = r * nm.reward_gamma + rr;
+          if (has_cost) c = c * nm.cost_gamma + (double)rc;
+        }
+        vec[0][tid] = r; vec[1][tid] = c;
+      }
+    }
+    __syncthreads();
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc3 += tn_ - tl; tl = tn_; }
+    if (nm.training) {
+      if (tid < O) {           // obs_rms.update: rows added in order (numpy's axis-0 reduction)
+        double sum = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < N; ++r) sum += chunk[r * O + tid];
+        const double bm = sum / (double)N;
+        double sq = 0.0;
+#pragma unroll 8
+        for (int r = 0; r < N; ++r) { const double d = chunk[r * O + tid] - bm; sq += d * d; }
+        chan_merge(o_mean, o_var, o_cnt, bm, sq / (double)N, (double)N);
+        o_cnt = (double)N + o_cnt;
+      }
+      if (w == 3 || (w == 2 && has_cost)) {     // ret_rms / cost_rms: numpy pairwise order
+        const int v = w == 3 ? 0 : 1;
+        const double bm = np_leaf_sum_wave(vec[v], N) / (double)N;
+        for (int i = lane; i < N; i += 64) { const double d = vec[v][i] - bm; dev2[v][i] = d * d; }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        const double bv = np_leaf_sum_wave(dev2[v], N) / (double)N;
+        chan_merge(st_m, st_v, st_c, bm, bv, (double)N);
+        st_c = (double)N + st_c;
+      }
+    }
+    if (lane == 0 && w == 3) dens[0] = sqrt(st_v + nm.epsilon);
+    if (lane == 0 && w == 2) dens[1] = sqrt(st_v + nm.epsilon);
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc4 += tn_ - tl; tl = tn_; }
+    if (tid < O) {             // own env: normalise + clip, next policy input
+      double o = chunk[n * O + tid];
+      if (nm.norm_obs) o = fmin(fmax((o - o_mean) / sqrt(o_var + nm.epsilon), -nm.clip_obs), nm.clip_obs);
+      o_last = o;
+      sh.x[tid] = (float)o;
+      a.buf.new_observations[tn * O + tid] = (float)o;
+      sh.s_old[tid] = sh.s_new[tid];
+    }
+    __syncthreads();
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc5 += tn_ - tl; tl = tn_; }
+    if (tid < N) {
+      const int d = done_s[tid];
+      if (nm.training || d) { ret_s[tid] = d ? 0.0 : vec[0][tid]; if (has_cost) cret_s[tid] = d ? 0.0 : vec[1][tid]; }
+    }
+    if (tid == 0) {
+      double r = rawr_s[n];
+      fin_rew = r; fin_cost = rawc_s[n]; fin_done = done_s[n];
+      if (nm.norm_reward) r = fmin(fmax(r / dens[0], -nm.clip_reward), nm.clip_reward);
+      a.buf.rewards[tn] = (float)r;
+      if (has_cost) {
+        double c = (double)rawc_s[n];
+        if (nm.norm_cost) c = fmin(fmax(c / dens[1], -nm.clip_cost), nm.clip_cost);
+        a.buf.costs[tn] = (float)c;
+      }
+      last_done_s = done_s[n];
+    }
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc2 += tn_ - tl; tl = tn_; }
+  }
+  if (p.prof && n == 0 && tid == 0) { g_rollout_prof[0] = pc0; g_rollout_prof[1] = pc1; g_rollout_prof[2] = pc2; g_rollout_prof[3] = (unsigned long long)T; g_rollout_prof[4] = pc3; g_rollout_prof[5] = pc4; g_rollout_prof[6] = pc5; }
+  // ---- leave the agent / wrapper state exactly where the per-step path leaves it
+  __syncthreads();
+  if (tid < O) a.ag.last_obs[(size_t)n * O + tid] = o_last;
+  if (tid == 0) {
+    a.ag.last_dones[n] = (uint8_t)last_done_s;
+    a.ag.raw_rew[n] = fin_rew; a.ag.dones[n] = (uint8_t)fin_done;
+    if (has_cost) a.ag.raw_cost[n] = fin_cost;
+  }
+  if (n == 0) {
+    if (tid < O) { nm.obs_mean[tid] = o_mean; nm.obs_var[tid] = o_var; }
+    if (tid == 0) nm.obs_count[0] = o_cnt;
+    if (lane == 0 && w == 3) { nm.ret_stats[0] = st_m; nm.ret_stats[1] = st_v; nm.ret_stats[2] = st_c; }
+    if (lane == 0 && w == 2 && has_cost) { nm.cost_stats[0] = st_m; nm.cost_stats[1] = st_v; nm.cost_stats[2] = st_c; }
+    if (tid < N) { nm.ret[tid] = ret_s[tid]; if (has_cost) nm.cost_ret[tid] = cret_s[tid]; }
+  }
+}
+
 // VecNormalizeWithCost.reset (vec_normalize.py:148-157, 270-278)
 __global__ void __launch_bounds__(1024) norm_reset_kernel(icrl_norm_t nm, const double* raw_obs, int N, int O,
                                                           double* obs_out) {
@@ -1059,6 +1306,10 @@ extern "C" int icrl_vecnorm_step(const icrl_norm_t* nm, const double* raw_obs, c
   return (int)hipGetLastError();
 }
 
+extern "C" int icrl_debug_rollout_profile(unsigned long long* out4) {
+  return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_rollout_prof), sizeof(unsigned long long) * 8);
+}
+
 extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol,
                                        const icrl_costnet_t* cn, const icrl_buffer_t* buf, const icrl_agent_t* ag,
                                        const float* noise, const float* action_low, const float* action_high,
@@ -1076,6 +1327,31 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
   a.PT = pol->params_t; a.noise = noise; a.alow = action_low; a.ahigh = action_high;
   a.has_cn = cn != nullptr;
   if (cn) { a.cn = *cn; a.cl = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2); }
+  // persistent path: one launch for all T steps (see rollout_persistent_kernel).  Its exchange arrays live in the not yet
+  // computed reward_advantages plane of the buffer (GAE fills that afterwards).  do_gae & 2 forces the per-step launches.
+  {
+    const size_t need = (size_t)16 * N * O + (size_t)16 * N + (size_t)8 * N + (size_t)8 * N + 1024;
+    if (!(do_gae & 2) && N <= 128 && N * O <= NORM_CHUNK && O * env->act_dim <= MAX_OBS * MAX_ACT && T >= 1 &&
+        (size_t)T * N * sizeof(float) >= need) {
+      PersistArgs p;
+      p.act = a; p.nm = *nm; p.T = T; p.prof = (do_gae & 4) != 0;
+      char* base = reinterpret_cast<char*>(buf->reward_advantages);
+      p.xch_obs = reinterpret_cast<double*>(base); base += (size_t)16 * N * O;
+      p.xch_rew = reinterpret_cast<double*>(base); base += (size_t)16 * N;
+      p.xch_cost = reinterpret_cast<float*>(base); base += (size_t)8 * N;
+      p.xch_done = reinterpret_cast<unsigned*>(base); base += ((size_t)8 * N + 255) / 256 * 256;
+      p.counter = reinterpret_cast<unsigned*>(base);
+      hipError_t e = hipMemsetAsync(p.counter, 0, 512, s);
+      if (e != hipSuccess) return (int)e;
+      if (a.pl.O <= 32 && (!cn || cn->in_dim <= 32)) hipLaunchKernelGGL((rollout_persistent_kernel<2, 2>), dim3(N), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((rollout_persistent_kernel<8, 10>), dim3(N), dim3(256), 0, s, p);
+      int err = (int)hipGetLastError();
+      if (err || !(do_gae & 1)) return err;
+      return icrl_gae_dual(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
+                           ag->last_v_c, ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns,
+                           buf->cost_returns, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, stream);
+    }
+  }
   for (int t = 0; t < T; ++t) {
     if (a.pl.O <= 32 && (!cn || cn->in_dim <= 32)) hipLaunchKernelGGL((act_step_kernel<2, 2>), dim3(N), dim3(256), 0, s, a, t);
     else hipLaunchKernelGGL((act_step_kernel<8, 10>), dim3(N), dim3(256), 0, s, a, t);
@@ -1085,7 +1361,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
     launch_norm_step(b, s);
   }
   int err = (int)hipGetLastError();
-  if (err || !do_gae) return err;
+  if (err || !(do_gae & 1)) return err;
   return icrl_gae_dual(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
                        ag->last_v_c, ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns,
                        buf->cost_returns, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, stream);

@@ -145,7 +145,8 @@ class PPOLagrangian:
         timed = getattr(self, "gae_events", None) is not None
         _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn), b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
                                                       float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
-                                                      float(self.cost_gae_lambda), int(not timed), _lib.current_stream()),
+                                                      float(self.cost_gae_lambda), int(not timed) | (2 if getattr(self, "rollout_kernel", "auto") == "steps" else 0) | (4 if getattr(self, "profile_phases", 0) else 0),
+                                                      _lib.current_stream()),
                    "icrl_rollout_collect")
         if timed:   # bench.py: the same GAE launch, bracketed by events on the stream it runs on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

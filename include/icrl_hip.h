@@ -173,8 +173,11 @@ int icrl_policy_forward(const icrl_policy_t* pol, const double* obs, const float
                         const float* action_low, const float* action_high,
                         float* actions, float* act_clipped, float* v_r, float* v_c, float* log_prob, void* stream);
 
-/* same, with the final dual-GAE launch optional (do_gae = 0: the caller launches icrl_gae_dual itself, e.g. bracketed by
- * events for the roofline measurement in bench.py). */
+/* same, with options in `do_gae`: bit 0 = run the final dual-GAE launch (0: the caller launches icrl_gae_dual itself, e.g.
+ * bracketed by events); bit 1 = force one launch pair per env step; bit 2 = diagnostic phase timers.  By default, when N <= 128 and N * obs_dim <= 4096, ALL
+ * T steps run in ONE persistent launch (one workgroup per env, one device-wide barrier per step, normaliser statistics
+ * replicated bit-identically in every workgroup); the not yet computed reward_advantages plane of the buffer serves as its
+ * exchange scratch. */
 int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const icrl_costnet_t* cn,
                             const icrl_buffer_t* buf, const icrl_agent_t* ag, const float* noise,
                             const float* action_low, const float* action_high,

@@ -309,3 +309,32 @@ def test_analytic_env_cost_through_cost_wrapper():
     want = (rb.orig_observations.cpu().numpy()[..., 0] <= 0.0).astype(np.float32)
     assert np.array_equal(rb.orig_costs.cpu().numpy(), want) and 0.0 < want.mean() < 1.0
     assert get_true_cost_function("HCWithPosTest-v0")(np.array([[-3.5, 0.0]]), None)[0]
+
+
+@pytest.mark.parametrize("N,T", [(64, 300), (7, 33), (128, 20)])
+def test_persistent_rollout_equals_per_step_launches(N, T):
+    """the one-launch rollout (device-wide barrier per step, replicated normaliser statistics) against the launch pair per
+    step: every buffer plane, the normaliser state and the agent's carry-over state are bit-identical, across two
+    consecutive rollouts and across episode ends."""
+    (a_p, e_p, _), (a_s, e_s, _) = _pair_of_agents(N, T, 13)
+    a_s.rollout_kernel = "steps"
+    noise = torch.as_tensor(np.random.RandomState(8).randn(2, T, N, 6).astype(np.float32), device="cuda")
+    a_p._setup_learn(2 * N * T); a_s._setup_learn(2 * N * T)
+    for env in (e_p, e_s):
+        env.unwrapped.t_ep.fill_(1000 - T // 2)           # every env crosses its time limit inside the first rollout
+    for it in range(2):
+        a_p.collect_rollouts(e_p, None, a_p.rollout_buffer, T, "cost", noise=noise[it])
+        a_s.collect_rollouts(e_s, None, a_s.rollout_buffer, T, "cost", noise=noise[it])
+        for k in _BUF_KEYS:
+            got, ref = getattr(a_p.rollout_buffer, k).cpu().numpy(), getattr(a_s.rollout_buffer, k).cpu().numpy()
+            assert np.array_equal(got, ref), (it, k, np.abs(got - ref).max())
+        assert a_p.rollout_buffer.dones.sum().item() == (N if it == 0 else a_s.rollout_buffer.dones.sum().item())
+    for name in ("obs_rms", "ret_rms", "cost_rms"):
+        rp, rs = getattr(e_p, name), getattr(e_s, name)
+        assert np.array_equal(np.asarray(rp.mean), np.asarray(rs.mean)) and np.array_equal(np.asarray(rp.var), np.asarray(rs.var))
+        assert rp.count == rs.count
+    assert torch.equal(e_p.ret, e_s.ret) and torch.equal(e_p.cost_ret, e_s.cost_ret)
+    assert torch.equal(a_p._last_obs, a_s._last_obs) and torch.equal(a_p._ag["last_dones"], a_s._ag["last_dones"])
+    assert torch.equal(e_p.unwrapped.s, e_s.unwrapped.s) and torch.equal(e_p.unwrapped.t_ep, e_s.unwrapped.t_ep)
+    for k in ("raw_rew", "raw_cost", "dones", "last_v_r", "last_v_c", "act_clipped"):
+        assert torch.equal(a_p._ag[k], a_s._ag[k]), k

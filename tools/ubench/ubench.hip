@@ -167,6 +167,43 @@ __global__ void k_split(float* out, unsigned long long* cyc, int iters) {
   if ((threadIdx.x & 255) == 0) cyc[threadIdx.x >> 8] = t1 - t0;
 }
 
+// float64: dependent add chain, division, sqrt (the normaliser's statistics are a serial float64 recurrence)
+__global__ void k_f64(double* out, unsigned long long* cyc, int iters, int which) {
+  double v = 1.0 + threadIdx.x * 1e-3, u = 3.0 + threadIdx.x;
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (which == 0) v = v + u;
+      else if (which == 1) v = v / u + 1.5;
+      else if (which == 2) v = sqrt(v + u);
+      else v = fma(v, u, 0.25);
+    }
+  }
+  unsigned long long t1 = now();
+  out[threadIdx.x] = v;
+  if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+__global__ void k_f64_lds(double* out, unsigned long long* cyc, int iters) {
+  __shared__ double sm[64 * 18];
+  for (int i = threadIdx.x; i < 64 * 18; i += blockDim.x) sm[i] = i * 0.5;
+  __syncthreads();
+  double acc = 0.0;
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i) {
+    double sum = 0.0;
+    if (threadIdx.x < 18) {
+#pragma unroll 8
+      for (int r = 0; r < 64; ++r) sum += sm[r * 18 + threadIdx.x];
+    }
+    acc += sum;
+    asm volatile("" ::: "memory");
+  }
+  unsigned long long t1 = now();
+  out[threadIdx.x] = acc;
+  if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
+
 // LDS: batch of NB ds_read_b128 with the operand pattern of the kernel (row stride S), then use
 template <int NB, int S>
 __global__ void k_lds128(float* out, unsigned long long* cyc, int iters) {
@@ -220,9 +257,10 @@ __global__ void k_barrier(float* out, unsigned long long* cyc, int iters) {
 }
 
 // agent-scope granule round trip between two workgroups (ping-pong)
-__global__ void k_pingpong(unsigned long long* flag, unsigned long long* cyc, int iters) {
+__global__ void k_pingpong(unsigned long long* flag, unsigned long long* cyc, int iters, int other = 1) {
   if (threadIdx.x != 0) return;
-  const int me = blockIdx.x;
+  if (blockIdx.x != 0 && (int)blockIdx.x != other) return;
+  const int me = blockIdx.x == 0 ? 0 : 1;
   unsigned long long t0 = now();
   for (int i = 1; i <= iters; ++i) {
     if (me == 0) {
@@ -255,6 +293,12 @@ int main() {
   hipLaunchKernelGGL(k_mix, dim3(1), dim3(64), 0, 0, out, cyc, it); rd("4 mfma + 1 tanh2 interleaved, per group", it * 16.0);
   hipLaunchKernelGGL(k_mix_sched, dim3(1), dim3(64), 0, 0, out, cyc, it); rd("4 mfma + 1 tanh2, forced interleave, per group", it * 16.0);
   hipLaunchKernelGGL(k_mix_valu, dim3(1), dim3(64), 0, 0, out, cyc, it, 0); rd("4 mfma + 16 fma forced interleave (4 per mfma)", it * 4.0);
+  { double* dout; hipMalloc(&dout, 4096);
+    hipLaunchKernelGGL(k_f64, dim3(1), dim3(64), 0, 0, dout, cyc, it, 0); rd("f64 dependent add, per op", it * 16.0);
+    hipLaunchKernelGGL(k_f64, dim3(1), dim3(64), 0, 0, dout, cyc, it, 3); rd("f64 dependent fma, per op", it * 16.0);
+    hipLaunchKernelGGL(k_f64, dim3(1), dim3(64), 0, 0, dout, cyc, it, 1); rd("f64 division (+add), per op", it * 16.0);
+    hipLaunchKernelGGL(k_f64, dim3(1), dim3(64), 0, 0, dout, cyc, it, 2); rd("f64 sqrt (+add), per op", it * 16.0);
+    hipLaunchKernelGGL(k_f64_lds, dim3(1), dim3(64), 0, 0, dout, cyc, it); rd("64-row sequential f64 column sum from LDS", it); }
   hipLaunchKernelGGL(k_split, dim3(1), dim3(512), 0, 0, out, cyc, it); hipDeviceSynchronize(); hipMemcpy(h.data(), cyc, 64, hipMemcpyDeviceToHost);
   printf("split phases, 2 waves/SIMD: matrix waves %.0f cycles / 64 mfma (alone: 2048), vector waves %.0f cycles / 512 fma (alone: ~2048)\n", (double)h[0] / it, (double)h[1] / it);
   hipLaunchKernelGGL((k_lds128<16, 72>), dim3(1), dim3(64), 72 * 64 * 4, 0, out, cyc, it); rd("16 x ds_read_b128 stride 72, 1 wave, per batch", it);
@@ -266,7 +310,11 @@ int main() {
   hipLaunchKernelGGL((k_lds32<16, 72>), dim3(1), dim3(256), 72 * 64 * 4, 0, out, cyc, it); rd("16 x ds_read_b32 transposed stride 72, 4 waves", it);
   hipLaunchKernelGGL(k_barrier, dim3(1), dim3(256), 0, 0, out, cyc, it); rd("s_barrier, 4 waves", it);
   hipLaunchKernelGGL(k_barrier, dim3(1), dim3(512), 0, 0, out, cyc, it); rd("s_barrier, 8 waves", it);
-  hipLaunchKernelGGL(k_pingpong, dim3(2), dim3(64), 0, 0, flag, cyc, it); rd("granule round trip between 2 workgroups", it);
+  hipLaunchKernelGGL(k_pingpong, dim3(2), dim3(64), 0, 0, flag, cyc, it, 1); rd("granule round trip, workgroups 0 and 1 (different XCDs)", it);
+  CK(hipMemset(flag, 0, 4096));
+  hipLaunchKernelGGL(k_pingpong, dim3(9), dim3(64), 0, 0, flag, cyc, it, 8); rd("granule round trip, workgroups 0 and 8 (same XCD)", it);
+  CK(hipMemset(flag, 0, 4096));
+  hipLaunchKernelGGL(k_pingpong, dim3(17), dim3(64), 0, 0, flag, cyc, it, 16); rd("granule round trip, workgroups 0 and 16 (same XCD)", it);
   // shader clock vs wall clock
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0); hipLaunchKernelGGL(k_mfma<4>, dim3(1), dim3(64), 0, 0, out, cyc, 20000); hipEventRecord(e1); hipDeviceSynchronize();
