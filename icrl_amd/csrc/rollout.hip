@@ -686,6 +686,32 @@ __device__ __forceinline__ double np_leaf_sum_wave(const double* a, int n) {
   return res;
 }
 
+// obs_rms.update's batch moments of one observation column, in numpy's axis-0 order (rows added one after the other — a serial
+// float64 recurrence).  The LDS reads are issued sixteen at a time and only the additions stay on the dependent chain; left
+// to itself the compiler pairs every read with its add and exposes the LDS latency 2 N times.
+__device__ __forceinline__ void column_moments(const double* col, int stride, int N, double& bm, double& bv) {
+  double sum = 0.0;
+  for (int r0 = 0; r0 < N; r0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = col[(r0 + k < N ? r0 + k : N - 1) * stride];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (r0 + k < N) sum += v[k];
+  }
+  bm = sum / (double)N;
+  double sq = 0.0;
+  for (int r0 = 0; r0 < N; r0 += 16) {
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const double d = col[(r0 + k < N ? r0 + k : N - 1) * stride] - bm; v[k] = d * d; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (r0 + k < N) sq += v[k];
+  }
+  bv = sq / (double)N;
+}
+
 __global__ void __launch_bounds__(1024) norm_step_small_kernel(NormStepArgs a) {
   __shared__ double chunk[NORM_CHUNK];
   __shared__ double vec[2][128], dev2[2][128];
@@ -710,12 +736,9 @@ __global__ void __launch_bounds__(1024) norm_step_small_kernel(NormStepArgs a) {
   __syncthreads();
   if (nm.training) {
     if (tid < O) {           // obs_rms.update: rows added in order (numpy's axis-0 reduction)
-      double sum = 0.0;
-      for (int r = 0; r < N; ++r) sum += chunk[r * O + tid];
-      const double bm = sum / (double)N;
-      double sq = 0.0;
-      for (int r = 0; r < N; ++r) { const double d = chunk[r * O + tid] - bm; sq += d * d; }
-      chan_merge(o_mean, o_var, o_cnt, bm, sq / (double)N, (double)N);
+      double bm, bv;
+      column_moments(chunk + tid, O, N, bm, bv);
+      chan_merge(o_mean, o_var, o_cnt, bm, bv, (double)N);
       nm.obs_mean[tid] = o_mean; nm.obs_var[tid] = o_var;
       if (tid == 0) nm.obs_count[0] = (double)N + o_cnt;
     }
@@ -940,14 +963,9 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc3 += tn_ - tl; tl = tn_; }
     if (nm.training) {
       if (tid < O) {           // obs_rms.update: rows added in order (numpy's axis-0 reduction)
-        double sum = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < N; ++r) sum += chunk[r * O + tid];
-        const double bm = sum / (double)N;
-        double sq = 0.0;
-#pragma unroll 8
-        for (int r = 0; r < N; ++r) { const double d = chunk[r * O + tid] - bm; sq += d * d; }
-        chan_merge(o_mean, o_var, o_cnt, bm, sq / (double)N, (double)N);
+        double bm, bv;
+        column_moments(chunk + tid, O, N, bm, bv);
+        chan_merge(o_mean, o_var, o_cnt, bm, bv, (double)N);
         o_cnt = (double)N + o_cnt;
       }
       if (w == 3 || (w == 2 && has_cost)) {     // ret_rms / cost_rms: numpy pairwise order
@@ -1129,10 +1147,15 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
   load_pol_regs<OCT>(a.pl, a.PT, R);    // once for every step of every episode of this stream
   __shared__ int s_done;
   __shared__ double s_rew;
+  __shared__ double Bl[MAX_OBS * MAX_ACT];     // dynamics matrix: read every step, kept out of the global-memory latency
+  __shared__ float noise_s[MAX_ACT];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int O = a.pl.O, A = a.pl.A;
   const int AS = a.pl.discrete ? 1 : A;
+  icrl_env_t env = a.env;
+  for (int i = tid; i < O * a.env.act_dim; i += 192) Bl[i] = a.env.B[i];
+  env.B = Bl;
   const uint32_t e_key = a.env.key[n];
   uint32_t e_ctr = a.env.step_count[n];
   int e_tep = a.env.t_ep[n];
@@ -1148,6 +1171,8 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
   if (a.do_reset) e_tep = 0;
   __syncthreads();
   size_t row = (size_t)n * a.rows_per_stream;
+  const size_t row_end = row + a.rows_per_stream;
+  float noise_reg = (a.noise != nullptr && tid < AS) ? a.noise[row * AS + tid] : 0.f;   // noise of the first step
   for (int ep = 0; ep < a.episodes_per_stream; ++ep) {
     double ep_rew = 0.0;
     int ep_len = 0;
@@ -1159,13 +1184,16 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
         sh.s_old[tid] = raw;
         sh.x[tid] = (float)o;
       }
+      if (a.noise != nullptr && tid < AS) {
+        noise_s[tid] = noise_reg;
+        if (row + 1 < row_end) noise_reg = a.noise[(row + 1) * AS + tid];      // next step's noise lands during this step
+      }
       __syncthreads();
-      const float* noise_row = a.noise ? a.noise + row * AS : nullptr;
-      policy_forward_block<OCT>(a.pl, R, sh, noise_row, a.deterministic || a.noise == nullptr, a.alow, a.ahigh);
+      policy_forward_block<OCT>(a.pl, R, sh, a.noise ? noise_s : nullptr, a.deterministic || a.noise == nullptr, a.alow, a.ahigh);
       __syncthreads();
       if (w == 0) {
         double rew; int done;
-        env_step_wave(a.env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
+        env_step_wave(env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
         if (lane == 0) { s_done = done; s_rew = rew; }
         if (lane < AS) a.actions[row * AS + lane] = sh.act_clip[lane];
       }

@@ -55,46 +55,64 @@ def get_net_arch(config):
 
 
 # ---- single-env episode loops, run as ONE persistent kernel launch (icrl_sample_episodes) -----------------------------------
+SPECULATIVE_EPISODES = True
+
+
 def _run_episodes(agent, env, n_episodes, deterministic, noise, parallel):
+    """`n_episodes` sequential episodes of a 1-env loop (icrl/utils.py:323-357, evaluation.py:10-67) as ONE persistent launch.
+    Episodes are independent once their position in the env's random stream is known, and that position is the number of
+    steps taken before them: with fixed-length episodes it is known up front and the episodes run as parallel streams.  When
+    episodes may end early (the "Test" envs, CLGW) they are first run SPECULATIVELY as parallel full-length streams; if
+    every episode did run to the time limit the result is exactly the sequential one, otherwise the call is repeated
+    sequentially (same noise, same start state)."""
     assert env.num_envs == 1, "You must pass only one environment when using this function"
     senv = env.unwrapped
     pol, dev = agent.policy, senv.device
     max_steps, O = senv.max_steps, senv.obs_dim
     A = 1 if pol.discrete else pol.act_dim
     fixed_len = not senv.wall_terminate
-    n_streams = n_episodes if (parallel and fixed_len) else 1
-    eps_per = n_episodes // n_streams
-    rows_per = eps_per * max_steps
-    rows = n_streams * rows_per
+    rows = n_episodes * max_steps
     if noise is None and not deterministic:
         noise = torch.rand(rows, device=dev) if pol.discrete else torch.randn(rows, A, device=dev)
     if noise is not None:
         noise = torch.as_tensor(noise, device=dev).float().reshape(rows, -1).contiguous()
-    # per-stream copies of the env's random-stream position: stream e starts where the sequential loop would be
     base = int(senv.step_count[0].item()) & 0xFFFFFFFF
-    sc = ((base + np.arange(n_streams, dtype=np.int64) * max_steps) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
-    st = dict(s=senv.s.repeat(n_streams, 1).contiguous(), t_ep=senv.t_ep.repeat(n_streams).contiguous(),
-              step_count=torch.as_tensor(sc, device=dev), key=senv.key.repeat(n_streams).contiguous())
-    e = EnvT(n_streams, O, senv.act_dim, max_steps, senv.reward_form, int(senv.wall_terminate), int(senv.broken), 0,
-             p(senv.B), p(st["s"]), p(st["t_ep"]), p(st["step_count"]), p(st["key"]))
     was_training = env.training
     env.training = False
     nm, ps = env.struct(), pol.struct()
     env.training = was_training
-    out = dict(orig_obs=torch.empty(rows, O, dtype=torch.float64, device=dev), obs=torch.empty(rows, O, dtype=torch.float64, device=dev),
-               actions=torch.empty(rows, A, device=dev), ep_rewards=torch.empty(n_episodes, dtype=torch.float64, device=dev),
-               ep_lengths=torch.empty(n_episodes, dtype=torch.int32, device=dev))
     lo = hi = None
     if not pol.discrete:
         lo = torch.as_tensor(pol.action_space.low, device=dev).float().contiguous()
         hi = torch.as_tensor(pol.action_space.high, device=dev).float().contiguous()
     b = _lib.byref
-    # streams > 0 of the parallel mode start from a reset as well: in the sequential loop their first state is the
-    # auto-reset draw made at exactly this counter value
-    _lib.check(_lib.lib().icrl_sample_episodes(b(e), b(nm), b(ps), p(noise), p(lo), p(hi), eps_per, rows_per, int(deterministic), 1,
-                                               p(out["orig_obs"]), p(out["obs"]), p(out["actions"]), p(out["ep_rewards"]),
-                                               p(out["ep_lengths"]), _lib.current_stream()), "icrl_sample_episodes")
-    lengths = out["ep_lengths"].cpu().numpy().astype(np.int64)
+
+    def launch(n_streams):
+        eps_per = n_episodes // n_streams
+        rows_per = eps_per * max_steps
+        # per-stream copies of the env's random-stream position: stream e starts where the sequential loop would be
+        sc = ((base + np.arange(n_streams, dtype=np.int64) * max_steps) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        st = dict(s=senv.s.repeat(n_streams, 1).contiguous(), t_ep=senv.t_ep.repeat(n_streams).contiguous(),
+                  step_count=torch.as_tensor(sc, device=dev), key=senv.key.repeat(n_streams).contiguous())
+        e = EnvT(n_streams, O, senv.act_dim, max_steps, senv.reward_form, int(senv.wall_terminate), int(senv.broken), 0,
+                 p(senv.B), p(st["s"]), p(st["t_ep"]), p(st["step_count"]), p(st["key"]))
+        out = dict(orig_obs=torch.empty(rows, O, dtype=torch.float64, device=dev), obs=torch.empty(rows, O, dtype=torch.float64, device=dev),
+                   actions=torch.empty(rows, A, device=dev), ep_rewards=torch.empty(n_episodes, dtype=torch.float64, device=dev),
+                   ep_lengths=torch.empty(n_episodes, dtype=torch.int32, device=dev))
+        # streams > 0 of the parallel mode start from a reset as well: in the sequential loop their first state is the
+        # auto-reset draw made at exactly this counter value
+        _lib.check(_lib.lib().icrl_sample_episodes(b(e), b(nm), b(ps), p(noise), p(lo), p(hi), eps_per, rows_per, int(deterministic), 1,
+                                                   p(out["orig_obs"]), p(out["obs"]), p(out["actions"]), p(out["ep_rewards"]),
+                                                   p(out["ep_lengths"]), _lib.current_stream()), "icrl_sample_episodes")
+        return out, st, out["ep_lengths"].cpu().numpy().astype(np.int64)
+
+    # parallel=False keeps fixed-length episodes sequential (a test hook); early-ending envs are tried speculatively unless
+    # SPECULATIVE_EPISODES is switched off
+    n_streams = 1 if (n_episodes == 1 or (fixed_len and not parallel) or (not fixed_len and not SPECULATIVE_EPISODES)) else n_episodes
+    out, st, lengths = launch(n_streams)
+    if n_streams > 1 and not fixed_len and not np.all(lengths == max_steps):
+        n_streams = 1                                  # an episode ended early: its successors' stream positions were wrong
+        out, st, lengths = launch(1)
     # leave the env where the sequential loop would have left it
     total = int(lengths.sum())
     senv.step_count.fill_(int(np.uint32((base + total) & 0xFFFFFFFF).view(np.int32)))
@@ -103,7 +121,7 @@ def _run_episodes(agent, env, n_episodes, deterministic, noise, parallel):
     if n_streams == 1:
         keep = torch.arange(total, device=dev)
     else:
-        keep = torch.arange(rows, device=dev)        # fixed-length episodes: every row is used
+        keep = torch.arange(rows, device=dev)        # full-length episodes: every row is used
     return out, lengths, keep
 
 

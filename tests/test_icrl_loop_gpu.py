@@ -110,3 +110,27 @@ def test_cpg_transfer_short_run(tmp_path):
     assert np.isfinite(model.dual.nu().item())
     from icrl_amd import logger
     assert np.isfinite(logger.Logger.CURRENT.name_to_value["train/average_cost"])
+
+
+def test_speculative_parallel_evaluation_equals_sequential():
+    """evaluate_policy on a "Test" env whose episodes all run to the time limit: the speculative parallel streams give exactly
+    the sequential result (rewards, lengths, env left in the same state); see utils._run_episodes."""
+    from icrl_amd import utils
+    from icrl_amd.ppo_lag import PPOLagrangian
+    from icrl_amd.constraint_net import ConstraintNet
+    train_env = utils.make_train_env("HCWithPos-v0", None, True, 5, 4, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    lo = -np.ones(6, np.float32)
+    cn = ConstraintNet(18, 6, [20], None, lambda x: 0.05, None, None, False, clip_obs=20, action_low=lo, action_high=-lo)
+    train_env.set_cost_function(cn.cost_function)
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", train_env, n_steps=32, seed=5)
+    noise = np.random.RandomState(1).randn(4 * 1000, 6).astype(np.float32)
+    res = []
+    for spec in (True, False):
+        utils.SPECULATIVE_EPISODES = spec
+        eenv = utils.make_eval_env("HCWithPosTest-v0", False, seed=5)
+        r, l = utils.evaluate_policy(agent, eenv, 4, deterministic=False, noise=noise, return_episode_rewards=True)
+        res.append((np.array(r), np.array(l), eenv.unwrapped.s.cpu().numpy().copy(), int(eenv.unwrapped.step_count[0].item())))
+    utils.SPECULATIVE_EPISODES = True
+    assert list(res[0][1]) == [1000] * 4
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
