@@ -43,7 +43,7 @@ def config2(n_iters_total, seed, rank, world):
     return types.SimpleNamespace(**cfg)
 
 
-def gae_sweep_point(N=65536, T=2048, reps=5):
+def gae_sweep_point(N=65536, T=2048, reps=20):
     """same kernel, working set 4.8 GB >> 256 MB Infinity Cache: the HBM-streaming regime."""
     from icrl_amd import _lib
     L = _lib.lib()
@@ -54,7 +54,7 @@ def gae_sweep_point(N=65536, T=2048, reps=5):
     outs = [torch.empty(T, N, device=dev) for _ in range(4)]
     args = [_lib.ptr(x) for x in (*ins, *lv, ld, *outs)]
     st = _lib.current_stream()
-    for _ in range(2):
+    for _ in range(5):
         L.icrl_gae_dual(*args, T, N, 0.99, 0.95, 0.99, 0.95, st)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -166,11 +166,12 @@ def main():
     flops_step = 3 * 2 * B * (O * H + H * H) * 3 + 2 * B * H * (A + 2) * 3      # fwd + 2x bwd of the three MLPs (+ heads)
     us_per_step = 1e3 * float(np.sum(tr_ms)) / max(1, int(np.sum(tr_steps)))
     ppo_tflops = flops_step / (us_per_step * 1e-6) / 1e12
-    roofline_ppo = dict(kernel="ppo_train_kernel", bound="mfma", achieved=round(ppo_tflops, 4), peak=round(F32_MFMA_PEAK_TFLOPS * 3 / 256, 3),
+    roofline_ppo = dict(kernel="ppo_train_rows_kernel", bound="mfma", achieved=round(ppo_tflops, 4), peak=round(F32_MFMA_PEAK_TFLOPS * 3 / 256, 3),
                         unit="TFLOP/s", frac=round(ppo_tflops / (F32_MFMA_PEAK_TFLOPS * 3 / 256), 4),
                         us_per_optimizer_step=round(us_per_step, 2), optimizer_steps=int(np.sum(tr_steps)),
                         note="dependent optimiser steps of the reference algorithm: 3 workgroups (one per MLP) = 3 of 256 CUs; "
-                             "peak = fp32 MFMA rate of those 3 CUs")
+                             "peak = fp32 MFMA rate of those 3 CUs; the padded 16x16x4 MFMA work actually issued is 304 instructions "
+                             "per wave and step = 9.7k of the ~27k cycles of a step")
     out = dict(metric="env-steps/sec (ICRL outer loop, HCWithPos-v0)", value=round(env_steps / dt, 1), unit="env-steps/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * dt / a.steps, 2), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
