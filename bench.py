@@ -103,7 +103,7 @@ def main():
     rank, world = D.init_from_env()
     if world == 1 and a.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
 
     from icrl_amd import icrl as I, logger, utils
     from icrl_amd.vec_env import sync_envs_normalization
@@ -128,10 +128,10 @@ def main():
     dt = time.time() - t0
     env_steps = st["timesteps"] - steps0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=D.reduce_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        s = torch.tensor([env_steps], dtype=torch.float64, device="cuda")
+        s = torch.tensor([env_steps], dtype=torch.float64, device=D.reduce_device())
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         env_steps = float(s.item())
     if rank != 0:

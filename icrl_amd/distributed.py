@@ -21,12 +21,18 @@ def init_from_env():
         return 0, 1
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
+    # ICRL_DIST_BACKEND=gloo: functional check of the multi-rank path on a box with fewer GPUs than ranks (ranks then share
+    # device LOCAL_RANK % device_count; the reduction goes through host memory)
+    backend = os.environ.get("ICRL_DIST_BACKEND", "nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl")
-    else:
-        dist.init_process_group("gloo")
+        torch.cuda.set_device(local % torch.cuda.device_count())
+    dist.init_process_group(backend)
     return rank, world
+
+
+def reduce_device(default="cuda"):
+    """where collectives' tensors live: device memory for RCCL, host memory for gloo."""
+    return "cpu" if (dist.is_initialized() and dist.get_backend() == "gloo") else default
 
 
 def moments_to_sums(mean, var, count):
@@ -59,7 +65,12 @@ def allreduce_state(avg_tensors, rms_list, rms_prev_sums, world, group=None):
     sums = [moments_to_sums(r.mean, r.var, r.count) for r in rms_list]
     buf = pack(avg_tensors, sums)
     if world > 1:
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        if buf.device.type == "cuda" and reduce_device() == "cpu":
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            buf = host.to(buf.device)
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     off = 0
     for t in avg_tensors:
         n = t.numel()
