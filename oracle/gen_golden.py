@@ -595,6 +595,15 @@ def fixtures_expert():
     sd = th.load(io.BytesIO(z.read("policy.pth")))
     save("expert_hc", observations=np.concatenate(obs).astype(np.float32), actions=np.concatenate(acs).astype(np.float32),
          **{f"policy/{k}": v.numpy() for k, v in sd.items()})
+    # AntWall (configs[2] / [4]): 5 of the reference's expert rollouts (float32) and the expert agent's policy
+    obs, acs, rews, lens = [], [], [], []
+    for i in range(5):
+        d = pickle.load(open(f"{REF}/icrl/expert_data/AntWall/files/EXPERT/rollouts/{i}.pkl", "rb"))
+        obs.append(d["observations"]); acs.append(d["actions"]); rews.append(float(d["rewards"][0])); lens.append(int(d["lengths"][0]))
+    z = zipfile.ZipFile(f"{REF}/icrl/expert_data/AntWall/files/best_model.zip")
+    sd = th.load(io.BytesIO(z.read("policy.pth")))
+    save("expert_ant", observations=np.concatenate(obs).astype(np.float32), actions=np.concatenate(acs).astype(np.float32),
+         rewards=np.array(rews), lengths=np.array(lens), **{f"policy/{k}": v.numpy() for k, v in sd.items()})
     # LapGridWorld: the reference ships the expert agent but no rollouts (icrl/expert_data/LGW/files has no EXPERT/rollouts);
     # they are produced the way icrl/run_policy.py does — 20 sampled episodes of that agent — on the restated env.
     z = zipfile.ZipFile(f"{REF}/icrl/expert_data/LGW/files/best_model.zip")

@@ -134,3 +134,23 @@ def test_speculative_parallel_evaluation_equals_sequential():
     assert list(res[0][1]) == [1000] * 4
     assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
     assert np.array_equal(res[0][2], res[1][2]) and res[0][3] == res[1][3]
+
+
+def test_icrl_entry_point_antwall_shapes(tmp_path):
+    """BASELINE configs[2] shapes at a reduced size: AntWall-v0 (obs 113, act 8), 2-layer cost net [40, 40], batch 128 (two
+    64-row chunks per minibatch in the update kernel), per-step rollout launches with the generic normaliser kernel."""
+    from icrl_amd.icrl import build_parser, icrl
+    import types, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    ex = os.path.join(here, "golden/expert_ant.npz")
+    argv = ["icrl", "-er", "3", "-ep", ex, "--expert_agent_path", ex, "-tei", "AntWall-v0", "-eei", "AntWallTest-v0", "-tk", "0.02",
+            "-cl", "40", "40", "-clr", "0.005", "-crc", "0.6", "-bi", "3", "-ft", "4096", "-ni", "2", "-nt", "32", "--n_steps", "128",
+            "-bs", "128", "-ne", "3", "-lr", "3e-5", "-psis", "-ctkno", "2.5", "-s", "0", "--save_dir", str(tmp_path), "-v", "0"]
+    cfg = vars(build_parser().parse_args(argv))
+    cfg.update(rank=0, world_size=1)
+    metrics, agent, cn, env = icrl(types.SimpleNamespace(**cfg), log=None)
+    m = metrics[-1]
+    assert cn.input_dims == 121 and agent.policy.obs_dim == 113
+    for k in ("true/reward", "true/cost", "true/forward_kl", "true/reverse_kl", "forward/nu", "forward/approx_kl", "backward/cn_loss"):
+        assert np.isfinite(m[k]), k
+    assert m["timesteps"] == 2 * 4096
