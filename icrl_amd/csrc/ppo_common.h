@@ -78,7 +78,7 @@ struct Cursor {
   int e, p, m;
 };
 
-// ppo_train_rows.hip: row-owning-wave kernel for obs_dim <= 64 (nt1 = ceil(obs / 16) <= 4)
+// ppo_train_rows.hip: row-owning-wave kernel (nt1 = ceil(obs / 16) <= 8)
 int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, hipStream_t s);
 
 

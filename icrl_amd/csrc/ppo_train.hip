@@ -915,8 +915,8 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
   e = hipMemsetAsync(stats, 0, (32 + hp->n_epochs) * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   const int nt1 = (pol->obs_dim + 15) / 16;
-  // obs <= 64: row-owning waves (3 barriers per step); wider observations (AntWall: 113) or hp._pad & 2: column-split tiles
-  if (nt1 <= 4 && !(hp->_pad & 2)) {
+  // row-owning waves (3 barriers per step; 5 when obs > 64); hp._pad & 2 forces the column-split tiles kernel
+  if (nt1 <= 8 && !(hp->_pad & 2)) {
     const int n_total = buf->T * buf->N;
     const int n_mb = (n_total + hp->batch_size - 1) / hp->batch_size;
     const long long n_steps = (long long)hp->n_epochs * n_mb;

@@ -1,4 +1,4 @@
-// PPO-Lagrangian update, row-owning-wave variant (obs_dim <= 64) — gfx950.
+// PPO-Lagrangian update, row-owning-wave variant (obs_dim <= 128) — gfx950.
 //
 // ref: stable_baselines3/ppo_lag/ppo_lag.py:196-299, common/buffers.py:594-627, common/policies.py:752-767,
 //      common/distributions.py:143-171,274-288, torch.optim.Adam, clip_grad_norm_  (same contract as ppo_train.hip).
@@ -36,12 +36,14 @@ struct SmemR {  // offsets in floats (multiples of 4)
   static constexpr int O16 = 16 * NT1, SX = O16 + 8;
   static constexpr bool XDB = NT1 <= 2;        // second X buffer (next minibatch staged while dW1 still reads this one)
   static constexpr bool W2TC = NT1 <= 2;       // transposed copy of W2 (ds_read_b128 operand fetch in the backward); LDS budget
+  static constexpr bool WHTC = NT1 <= 4;       // transposed copy of the head weights
+  static constexpr bool DZ1A = NT1 > 4;        // dz1^T shares h2^T's storage (written after dW2 / dWh have read h2^T): LDS budget
   static constexpr int W1 = 0;                 // [64][SX]
   static constexpr int W2 = W1 + HD * SX;      // [64][SH]
   static constexpr int W2T = W2 + HD * SH;     // [64][SH]  W2T[k][j] = W2[j][k]
   static constexpr int WH = W2T + (W2TC ? HD * SH : 0);   // [16][SH]
   static constexpr int WHT = WH + 16 * SH;     // [64][SA]  WHT[j][o] = WH[o][j]
-  static constexpr int B1 = WHT + HD * SA;
+  static constexpr int B1 = WHT + (WHTC ? HD * SA : 0);
   static constexpr int B2 = B1 + HD;
   static constexpr int BH = B2 + HD;
   static constexpr int LS = BH + 16;
@@ -50,8 +52,8 @@ struct SmemR {  // offsets in floats (multiples of 4)
   static constexpr int XT1 = XDB ? XT0 + O16 * ST : XT0;
   static constexpr int H1T = XT1 + O16 * ST;   // [64][ST] h1^T
   static constexpr int H2T = H1T + HD * ST;
-  static constexpr int DZ1T = H2T + HD * ST;
-  static constexpr int DZ2T = DZ1T + HD * ST;
+  static constexpr int DZ1T = DZ1A ? H2T : H2T + HD * ST;
+  static constexpr int DZ2T = H2T + (DZ1A ? 1 : 2) * HD * ST;
   static constexpr int DOT = DZ2T + HD * ST;   // [16][ST] d loss / d head output, transposed
   static constexpr int ACT = DOT + 16 * ST;    // [64][SA] actions of the chunk's rows
   static constexpr int OLP = ACT + RB * SA;    // [64] old log-prob | old value
@@ -154,7 +156,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) sm[S::WH + (4 * q + i) * SH + 16 * w + r] = wWh[i];
-    *reinterpret_cast<f32x4*>(sm + S::WHT + (16 * w + r) * SA + 4 * q) = wWh;
+    if (S::WHTC) *reinterpret_cast<f32x4*>(sm + S::WHT + (16 * w + r) * SA + 4 * q) = wWh;
     if (q == 0) {
       sm[S::B1 + jb] = wb1; sm[S::B2 + jb] = wb2;
       sm[ex_s] = wex;                       // lanes without an extra entry hit a scratch word
@@ -471,10 +473,15 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       // ================= backward of the activations (registers only) =================
       f32x4 dz2c[4], dz1c[4];
       {  // dH2^T = Wh^T . dOut^T: A = WHT[j = 16t + r][o = 4q + e] (K = 16 outputs)
-        const float* pa = sm + S::WHT + r * SA + 4 * q;
+        const float* pa = S::WHTC ? sm + S::WHT + r * SA + 4 * q : sm + S::WH + (4 * q) * SH + r;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          const f32x4 aw = lds128(pa + t * 16 * SA);
+          f32x4 aw;
+          if (S::WHTC) aw = lds128(pa + t * 16 * SA);
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) aw[e] = pa[e * SH + 16 * t];
+          }
           f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[e], dout[e], acc);
@@ -512,10 +519,12 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
           for (int i = 0; i < 4; ++i) dz1c[t][i] = fmaf(-(h1c[t][i] * h1c[t][i]), acc[i], acc[i]);
         }
       }
+      if (!S::DZ1A) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pt[S::DZ1T + (16 * t + i) * ST] = dz1c[t][i];
+          for (int i = 0; i < 4; ++i) pt[S::DZ1T + (16 * t + i) * ST] = dz1c[t][i];
+      }
       lds_barrier();  // (B1) all 64 rows of the activations / their gradients are visible
       STAMP(2)   // activation backward
       if (ch == 0) {   // gradient accumulators start their life here
@@ -549,27 +558,6 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
         gb2r += quad_rows_sum(s);
       }
       {
-        f32x4 az[4];   // dz1^T[j = 16w + r][rows]
-        const float* pa = sm + S::DZ1T + (16 * w + r) * ST + 4 * q;
-#pragma unroll
-        for (int js = 0; js < 4; ++js) az[js] = lds128(pa + 16 * js);
-        const float* pb = sm + xcur + r * ST + 4 * q;     // x^T[k = 16c + r][rows 16 js + 4q + e]
-#pragma unroll
-        for (int c = 0; c < NT1; ++c) {
-          f32x4 bx[4];
-#pragma unroll
-          for (int js = 0; js < 4; ++js) bx[js] = lds128(pb + c * 16 * ST + 16 * js);
-#pragma unroll
-          for (int js = 0; js < 4; ++js)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) gW1r[c] = MFMA_F32(az[js][e], bx[js][e], gW1r[c]);
-        }
-        float s = 0.f;
-#pragma unroll
-        for (int js = 0; js < 4; ++js) s += (az[js][0] + az[js][1]) + (az[js][2] + az[js][3]);
-        gb1r += quad_rows_sum(s);
-      }
-      {
         f32x4 ao[4], bh[4];   // dOut^T[o = r][rows], h2^T[j = 16w + r][rows]
         const float* pa = sm + S::DOT + r * ST + 4 * q;
         const float* pb = sm + S::H2T + (16 * w + r) * ST + 4 * q;
@@ -591,6 +579,35 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
         // wave 1 (Gaussian policy): d log_std r = sum of the four per-wave partials
         const float sl = (sm[S::PLS + r] + sm[S::PLS + 16 + r]) + (sm[S::PLS + 32 + r] + sm[S::PLS + 48 + r]);
         gex += w == 0 ? s : ((!DISC && role == 0 && w == 1) ? sl : 0.f);
+      }
+      if (S::DZ1A) {   // every wave has read h2^T: its storage now takes dz1^T
+        lds_barrier();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pt[S::DZ1T + (16 * t + i) * ST] = dz1c[t][i];
+        lds_barrier();
+      }
+      {
+        f32x4 az[4];   // dz1^T[j = 16w + r][rows]
+        const float* pa = sm + S::DZ1T + (16 * w + r) * ST + 4 * q;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) az[js] = lds128(pa + 16 * js);
+        const float* pb = sm + xcur + r * ST + 4 * q;     // x^T[k = 16c + r][rows 16 js + 4q + e]
+#pragma unroll
+        for (int c = 0; c < NT1; ++c) {
+          f32x4 bx[4];
+#pragma unroll
+          for (int js = 0; js < 4; ++js) bx[js] = lds128(pb + c * 16 * ST + 16 * js);
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gW1r[c] = MFMA_F32(az[js][e], bx[js][e], gW1r[c]);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) s += (az[js][0] + az[js][1]) + (az[js][2] + az[js][3]);
+        gb1r += quad_rows_sum(s);
       }
       if (tid == 0) {
         mb_s0 += (sm[S::PST + 0] + sm[S::PST + 8]) + (sm[S::PST + 16] + sm[S::PST + 24]);
@@ -798,6 +815,7 @@ static int launch_rows(const TrainArgs& a, hipStream_t s) {
 int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, hipStream_t s) {
   if (nt1 <= 2) return discrete ? launch_rows<2, true>(a, s) : launch_rows<2, false>(a, s);
   if (nt1 <= 4) return discrete ? launch_rows<4, true>(a, s) : launch_rows<4, false>(a, s);
+  if (nt1 <= 8) return discrete ? launch_rows<8, true>(a, s) : launch_rows<8, false>(a, s);
   return (int)hipErrorInvalidValue;
 }
 

@@ -14,7 +14,8 @@ agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, batch_size=128, n_e
 agent._setup_learn(N * T)
 agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost")
 agent.train_events = []
-for _ in range(3):
+for variant in ("tiles", "auto", "tiles", "auto"):
+    agent.train_kernel = variant
     agent.train_events.clear(); agent.train(); torch.cuda.synchronize()
     e0, e1, n = agent.train_events[-1]
-    print("ant B=128 us/step", 1e3 * e0.elapsed_time(e1) / n, "steps", n)
+    print(variant, "ant B=128 us/step", 1e3 * e0.elapsed_time(e1) / n, "steps", n)
