@@ -682,6 +682,17 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     const int nb_next = ps_next.nb_flags & 0xff;
     stats_partials(nb_next);
     xcur = xnext;
+    // the part of Adam that does not need the clip coefficient, done while the granules travel: m <- (1 - w1) m, v <- beta2 v
+    // (the update below then needs one FMA per moment: m + (coef w1) g,  v + (coef^2 w2) g^2)
+    {
+      const float omw1 = 1.f - w1, b2f_ = a.hp.adam_beta2;
+#pragma unroll
+      for (int c = 0; c < NT1; ++c) { mW1[c] *= omw1; vW1[c] *= b2f_; }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { mW2[c] *= omw1; vW2[c] *= b2f_; }
+      mWh *= omw1; vWh *= b2f_;
+      mb1 *= omw1; vb1 *= b2f_; mb2 *= omw1; vb2 *= b2f_; mex *= omw1; vex *= b2f_;
+    }
     if (tid < 12) {
       u64 v = 0;
       int spins = 0;
@@ -714,13 +725,13 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     // ================= Adam (torch.optim.Adam, single-tensor form) on register-resident weights and moments =================
     if (status == 0) {
       const float step_size = ps.step_size, inv_bc2_sqrt = ps.inv_bc2_sqrt;
-      const float b2f = a.hp.adam_beta2, epsf = a.hp.adam_eps;
-      auto adam = [&](float g, float& m, float& v, float& p) {
-        g = g * coef;
-        m = m + (g - m) * w1;
-        v = v * b2f + w2 * (g * g);
-        const float denom = __builtin_amdgcn_sqrtf(v) * inv_bc2_sqrt + epsf;     // v_sqrt_f32 / v_rcp_f32: 1 ulp each
-        p = p - step_size * (m * __builtin_amdgcn_rcpf(denom));
+      const float epsf = a.hp.adam_eps;
+      const float cw1 = coef * w1, c2w2 = (coef * coef) * w2;
+      auto adam = [&](float g, float& m, float& v, float& p) {   // m, v were pre-scaled by (1 - w1) and beta2 above
+        m = fmaf(cw1, g, m);
+        v = fmaf(c2w2, g * g, v);
+        const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_bc2_sqrt, epsf);     // v_sqrt_f32 / v_rcp_f32: 1 ulp each
+        p = fmaf(-step_size, m * __builtin_amdgcn_rcpf(denom), p);
       };
       // pad elements (k >= obs, o >= n_out) have g = m = v = p = 0 and stay 0: no masks needed
 #pragma unroll
