@@ -863,6 +863,16 @@ __global__ void __launch_bounds__(TH, 2) ppo_train_kernel(TrainArgs a) {
   }
 }
 
+// flat env-major indices of the permutations (buffers.py:53-65: i -> env = i / T, t = i % T) -> [T,N] storage offsets, once per
+// launch instead of once per gathered row inside the persistent kernel
+__global__ void ppo_perm_offsets_kernel(const int* __restrict__ perms, long long n, int T, int N, int* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int idx = perms[i];
+  const int env = idx / T, t = idx - env * T;
+  out[i] = t * N + env;
+}
+
 __global__ void ppo_plan_kernel(const int* adam_t, int n_steps, int n_mb, int n_total, int B, double lr, double b1, double b2,
                                 PlanStep* steps, PlanChunk* chunks) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -924,6 +934,12 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
     PlanStep* steps = reinterpret_cast<PlanStep*>((char*)sync_ws + 256);
     PlanChunk* chunks = reinterpret_cast<PlanChunk*>(steps + n_steps + 2);
     a.plan_steps = steps; a.plan_chunks = chunks; a.n_steps = (int)n_steps;
+    {
+      int* offs = reinterpret_cast<int*>((char*)sync_ws + 512 + 32 * (size_t)n_steps);       // after the plan tables
+      const long long n = (long long)hp->n_epochs * n_total;
+      hipLaunchKernelGGL(ppo_perm_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perms, n, buf->T, buf->N, offs);
+      a.perms = offs;
+    }
     hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
                        n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks);
     return launch_train_rows(a, nt1, pol->discrete != 0, s);

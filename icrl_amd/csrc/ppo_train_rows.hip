@@ -178,13 +178,10 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   // row stream: rows of chunk g+1 are prefetched into registers while chunk g is processed, their permutation indices two
   // chunks earlier; the schedule comes from the plan tables (uniform scalar loads)
   // ---------------------------------------------------------------------------------------------------------------
-  auto to_off = [&](int idx) -> unsigned {   // flat env-major index -> [T,N] storage offset (ref: buffers.py:53-65)
-    unsigned env = __umulhi((unsigned)idx, a.t_magic);
-    int t = idx - (int)env * T;
-    if (t >= T) { t -= T; ++env; }
-    if (t >= T) { t -= T; ++env; }
-    return (unsigned)t * (unsigned)N + env;
-  };
+  // `perms` holds STORAGE offsets here: ppo_perm_offsets_kernel has already mapped the flat env-major indices of the
+  // permutations (ref: buffers.py:53-65, i -> env = i / T, t = i % T) to t * N + env
+  auto to_off = [&](int idx) -> unsigned { return (unsigned)idx; };
+
   // this thread's row of a chunk: b = tid/4 — a row of wave w's own tile, so the per-row side data is wave-private
   const int gb_row = tid >> 2, gpart = tid & 3;
   // Both index streams are software-pipelined one stage deeper than the data they address: a plan entry is loaded one
@@ -202,6 +199,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     pvalid = idx >= 0;
     const size_t off = pvalid ? (size_t)to_off(idx) : 0;
     const float* orow = p_obs + off * O;
+    // component k = gpart + 4 i: the four threads of a row read 16 consecutive bytes per instruction
 #pragma unroll
     for (int i = 0; i < XR; ++i) { const int k = gpart + 4 * i; px[i] = orow[k < O ? k : O - 1]; }
     if (role == 0) {
@@ -305,7 +303,17 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       const int b = 16 * w + r;             // this lane's row of the chunk (all four q lanes share it)
       const bool valid = b < nrows;
       // ================= forward, transposed: rows of the weights x this wave's 16 rows =================
+      // Operand fetches are software-pipelined by hand: the ds_reads of tile t + 1 (or of the next layer's first tile) are
+      // issued before the MFMAs of tile t, with a scheduling fence so that they stay there — a wave otherwise stalls for
+      // the full LDS latency (~130 cycles) in front of every group of MFMAs, ~25 times per step.
       f32x4 h1c[4], h2c[4], outc;
+      f32x4 w2p[2][4], b2p[2];              // W2 tile operands / bias, ping-pong
+      auto load_w2 = [&](int t, f32x4 (&aw)[4], f32x4& bias) {
+        const float* pa = sm + S::W2 + (16 * t + r) * SH + 4 * q;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) aw[js] = lds128(pa + 16 * js);
+        bias = lds128(sm + S::B2 + 16 * t + 4 * q);
+      };
       {
         float bx[NT1][4];                   // x[row b][k = 16 js + 4q + e]
         const float* pb = sm + xcur + (4 * q) * ST + b;
@@ -313,20 +321,26 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
         for (int js = 0; js < NT1; ++js)
 #pragma unroll
           for (int e = 0; e < 4; ++e) bx[js][e] = pb[(16 * js + e) * ST];
-        const float* pa = sm + S::W1 + r * SX + 4 * q;
+        f32x4 w1p[2][NT1], b1p[2];
+        auto load_w1 = [&](int t, f32x4 (&aw)[NT1], f32x4& bias) {
+          const float* pa = sm + S::W1 + (16 * t + r) * SX + 4 * q;
+#pragma unroll
+          for (int js = 0; js < NT1; ++js) aw[js] = lds128(pa + 16 * js);
+          bias = lds128(sm + S::B1 + 16 * t + 4 * q);
+        };
+        load_w1(0, w1p[0], b1p[0]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          f32x4 aw[NT1];
-#pragma unroll
-          for (int js = 0; js < NT1; ++js) aw[js] = lds128(pa + t * 16 * SX + 16 * js);
-          const f32x4 bias = lds128(sm + S::B1 + 16 * t + 4 * q);
+          if (t < 3) load_w1(t + 1, w1p[(t + 1) & 1], b1p[(t + 1) & 1]);
+          else load_w2(0, w2p[0], b2p[0]);
+          __builtin_amdgcn_sched_barrier(0);
           f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int js = 0; js < NT1; ++js)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[js][e], bx[js][e], acc);
+            for (int e = 0; e < 4; ++e) acc = MFMA_F32(w1p[t & 1][js][e], bx[js][e], acc);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) h1c[t][i] = fast_tanh(acc[i] + bias[i]);
+          for (int i = 0; i < 4; ++i) h1c[t][i] = fast_tanh(acc[i] + b1p[t & 1][i]);
         }
       }
       // prefetch: rows of the next chunk of the stream, indices of the chunk three ahead.  Issued this early on purpose: the
@@ -336,38 +350,37 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       idx_next = idx_nx2;
       idx_nx2 = chunk_idx(pc_nx3);
       pc_nx3 = plan_chunks[g_chunk + 4];
+      f32x4 whp[4], bhp;                    // head operands
       {
-        const float* pa = sm + S::W2 + r * SH + 4 * q;
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          f32x4 aw[4];
+          if (t < 3) load_w2(t + 1, w2p[(t + 1) & 1], b2p[(t + 1) & 1]);
+          else {
+            const float* pa = sm + S::WH + r * SH + 4 * q;
 #pragma unroll
-          for (int js = 0; js < 4; ++js) aw[js] = lds128(pa + t * 16 * SH + 16 * js);
-          const f32x4 bias = lds128(sm + S::B2 + 16 * t + 4 * q);
+            for (int js = 0; js < 4; ++js) whp[js] = lds128(pa + 16 * js);
+            bhp = lds128(sm + S::BH + 4 * q);
+          }
+          __builtin_amdgcn_sched_barrier(0);
           f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int js = 0; js < 4; ++js)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[js][e], h1c[js][e], acc);
+            for (int e = 0; e < 4; ++e) acc = MFMA_F32(w2p[t & 1][js][e], h1c[js][e], acc);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) h2c[t][i] = fast_tanh(acc[i] + bias[i]);
+          for (int i = 0; i < 4; ++i) h2c[t][i] = fast_tanh(acc[i] + b2p[t & 1][i]);
         }
       }
       {  // head: outputs o = 4q + i of row b; four independent chains
-        f32x4 aw[4];
-        const float* pa = sm + S::WH + r * SH + 4 * q;
-#pragma unroll
-        for (int js = 0; js < 4; ++js) aw[js] = lds128(pa + 16 * js);
-        const f32x4 bias = lds128(sm + S::BH + 4 * q);
         f32x4 acc[4];
 #pragma unroll
         for (int js = 0; js < 4; ++js) {
           acc[js] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[js] = MFMA_F32(aw[js][e], h2c[js][e], acc[js]);
+          for (int e = 0; e < 4; ++e) acc[js] = MFMA_F32(whp[js][e], h2c[js][e], acc[js]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) outc[i] = ((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i])) + bias[i];
+        for (int i = 0; i < 4; ++i) outc[i] = ((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i])) + bhp[i];
       }
       // this wave's 16 columns of h1^T / h2^T (read by the weight-gradient GEMMs after the barrier)
       float* const pt = sm + (4 * q) * ST + b;

@@ -274,7 +274,7 @@ class PPOLagrangian:
         current_penalty = float(self.dual.nu().item())
         if not hasattr(self, "_train_ws"):
             self._train_ws = dict(nu=torch.zeros(1, device=dev), stats=torch.zeros(32 + self.n_epochs, device=dev),
-                                  sync=torch.zeros(64 + 4 * self.n_epochs * (-(-n // int(self.batch_size))), dtype=torch.int64, device=dev), t=torch.zeros(1, dtype=torch.int32, device=dev))
+                                  sync=torch.zeros(64 + 4 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2, dtype=torch.int64, device=dev), t=torch.zeros(1, dtype=torch.int32, device=dev))
         ws = self._train_ws
         ws["nu"].fill_(current_penalty)
         ws["t"].fill_(pol.adam_step)
