@@ -181,7 +181,7 @@ def main():
                            envs_per_gpu=N, n_steps=T, batch_size=B, n_epochs=cfg.n_epochs, forward_timesteps=cfg.forward_timesteps,
                            parallelism=f"env-shards x{world}, 1 all-reduce / outer iteration"),
                roofline=roofline, roofline_ppo=roofline_ppo)
-    out["cpu_baseline"] = None if a.no_cpu_baseline else cpu_baseline()
+    out["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline()      # reported at N = 1 only
     print(json.dumps(out))
 
 
