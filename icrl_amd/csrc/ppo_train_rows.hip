@@ -252,9 +252,15 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       sm[S::GAU + r] = r < A ? iv : 0.f;
       sm[S::GAU + 16 + r] = r < A ? 0.5f * iv : 0.f;
       sm[S::GAU + 32 + r] = r < A ? wex + LOG_SQRT_2PI_F : 0.f;     // log(sd) = log_std
+      // entropy of the diagonal Gaussian, sum_a 0.5 + 0.5 log(2 pi) + log sigma_a (one value per step for the statistics)
+      const float ent = row_sum(r < A ? HALF_LOG_2PI_PLUS_HALF_F + wex : 0.f);
+      if (r == 0) sm[S::MISC + 22] = ent;
     }
   };
-  float st_ent = 0.f, st_pg = 0.f, st_vl = 0.f, st_cf = 0.f, last_loss = 0.f, kl_sum = 0.f;   // thread 0 of each role
+  // the running statistics live in lane 0 of wave 3 of each role: wave 0 polls the granules, the other waves would idle at
+  // the barrier anyway, so the bookkeeping stays off the path that decides when the workgroup can go on
+  const bool book = tid == 192;
+  float st_ent = 0.f, st_pg = 0.f, st_vl = 0.f, st_cf = 0.f, last_loss = 0.f, kl_sum = 0.f;
   int steps_done = 0, early_stop_epoch = a.hp.n_epochs, status = 0;
 
   // ---- pipeline prologue
@@ -622,7 +628,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
         for (int js = 0; js < 4; ++js) s += (az[js][0] + az[js][1]) + (az[js][2] + az[js][3]);
         gb1r += quad_rows_sum(s);
       }
-      if (tid == 0) {
+      if (book) {
         mb_s0 += (sm[S::PST + 0] + sm[S::PST + 8]) + (sm[S::PST + 16] + sm[S::PST + 24]);
         mb_s1 += (sm[S::PST + 1] + sm[S::PST + 9]) + (sm[S::PST + 17] + sm[S::PST + 25]);
         mb_s2 += (sm[S::PST + 2] + sm[S::PST + 10]) + (sm[S::PST + 18] + sm[S::PST + 26]);
@@ -658,7 +664,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       float mean_kl = 0.f;
       const bool last_mb = (ps.nb_flags >> 9) & 1;
       const int epoch = ps.nb_flags >> 10;
-      if (tid == 0 && role == 0) {   // the early-stop decision rides on the policy workgroup's first granule
+      if (book && role == 0) {   // the early-stop decision rides on the granule of the policy workgroup's wave 3
         if ((ps.nb_flags >> 8) & 1) kl_sum = 0.f;
         kl_sum += mb_s3 * inv_nb;
         if (last_mb) {
@@ -670,12 +676,12 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
       __hip_atomic_store(a.xch + (step & 1) * 16 + role * 4 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
-      if (tid == 0) {
+      if (book) {
         ++steps_done;
         if (role == 0) {
           float ent = 0.f;
           if (DISC) ent = mb_s4 * inv_nb;
-          else for (int k = 0; k < A; ++k) ent += HALF_LOG_2PI_PLUS_HALF_F + sm[S::LS + k];
+          else ent = sm[S::MISC + 22];
           const float entropy_loss = -ent;
           const float pl = (-(mb_s0 * inv_nb) + nu * (mb_s1 * inv_nb)) * __builtin_amdgcn_rcpf(1.f + nu);
           st_ent += entropy_loss; st_pg += pl; st_cf += mb_s2 * inv_nb;
@@ -718,7 +724,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
         ++spins;
       }
       sm[S::MISC + tid] = __uint_as_float((unsigned)(v & 0xffffffffu));
-      if (tid == 0) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;
+      if (tid == 3) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;     // granule 3 = (policy, wave 3) carries the stop flag
       if (!ok) sm[S::MISC + 13] = 1.f;
     }
     lds_barrier();   // (B3) norm partials, next minibatch and its statistics visible
@@ -806,10 +812,10 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   if (tid == 0 && prof) {
     for (int k = 0; k < 7; ++k) {
       const int slot = 12 + 7 * role + k;
-      if (slot < 32) a.stats[slot] = (float)((double)ph[k] / (double)(steps_done > 0 ? steps_done : 1));
+      if (slot < 32) a.stats[slot] = (float)((double)ph[k] / (double)(a.n_steps > 0 ? a.n_steps : 1));   // (full runs only)
     }
   }
-  if (tid == 0) {
+  if (book) {
     if (role == 0) {
       a.stats[0] = (float)early_stop_epoch;
       a.stats[1] = (float)steps_done;
