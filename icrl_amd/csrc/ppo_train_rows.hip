@@ -187,9 +187,10 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   // Both index streams are software-pipelined one stage deeper than the data they address: a plan entry is loaded one
   // step / chunk before the permutation entry it locates (a dependent pair of global loads would otherwise stall the wave
   // for a full memory round trip at the point where the second address is formed).
+  const int stid = tid - 64;      // advantage statistics: row stid of the minibatch lives in waves 1 (and 2); wave 0 polls
   auto chunk_idx = [&](const PlanChunk& c) -> int { return gb_row < c.rows ? perms[c.perm_base + gb_row] : -1; };
   auto stat_idx = [&](const PlanStep& p) -> int {       // row tid of that step's minibatch (policy role)
-    return (role == 0 && tid < (p.nb_flags & 0xff)) ? perms[p.perm_base + tid] : -1;
+    return (role == 0 && stid >= 0 && stid < (p.nb_flags & 0xff)) ? perms[p.perm_base + stid] : -1;
   };
   float px[XR], pact[4], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
   bool pvalid = false;
@@ -218,19 +219,19 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     }
     if (gpart == 0) { sm[S::OLP + gb_row] = pvalid ? psc0 : 0.f; sm[S::ADR + gb_row] = pvalid ? psc1 : 0.f; sm[S::ADC + gb_row] = pvalid ? psc2 : 0.f; }
   };
-  // advantage statistics of a minibatch (policy role): thread tid < nb (<= 128: waves 0 and 1) holds row tid's (A_r, A_c)
+  // advantage statistics of a minibatch (policy role): thread 64 + i, i < nb (<= 128: waves 1 and 2) holds row i's (A_r, A_c)
   float sar = 0.f, sac = 0.f;
   auto issue_stats = [&](int idx) {
     const unsigned off = idx >= 0 ? to_off(idx) : 0u;     // rows beyond the minibatch are masked in stats_partials
     sar = p_s1[off];                                       // (only the policy role uses them)
     sac = p_s2[off];
   };
-  // per-wave partial sums into MISC[16 + 3w ..]; combined by everybody after the next barrier (fixed order)
+  // per-wave partial sums (waves 1, 2) into MISC[16..21]; combined by everybody after the next barrier (fixed order)
   auto stats_partials = [&](int nb) {
-    if (role != 0 || w >= 2) return;
-    const bool in = tid < nb;
+    if (role != 0 || w == 0 || w == 3) return;
+    const bool in = stid < nb;
     const float s_r = wave_sum_fast(in ? sar : 0.f), s_c = wave_sum_fast(in ? sac : 0.f), s_rr = wave_sum_fast(in ? sar * sar : 0.f);
-    if (lane == 0) { sm[S::MISC + 16 + 3 * w] = s_r; sm[S::MISC + 17 + 3 * w] = s_c; sm[S::MISC + 18 + 3 * w] = s_rr; }
+    if (lane == 0) { sm[S::MISC + 13 + 3 * w] = s_r; sm[S::MISC + 14 + 3 * w] = s_c; sm[S::MISC + 15 + 3 * w] = s_rr; }
   };
   float mean_r = 0.f, istd_r = 1.f, mean_c = 0.f;
   auto read_stats = [&](int nb) {
