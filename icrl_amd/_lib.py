@@ -35,6 +35,7 @@ SIGNATURES = {
     "icrl_cn_prepare": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "icrl_cn_train_work_floats": [c_int, c_int, c_int, c_int],
     "icrl_cn_train": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "icrl_debug_rollout_profile": [c_void_p],
     "icrl_cn_train_minibatch": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p],
 }

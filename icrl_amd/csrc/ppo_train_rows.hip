@@ -180,7 +180,6 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   // ---------------------------------------------------------------------------------------------------------------
   // `perms` holds STORAGE offsets here: ppo_perm_offsets_kernel has already mapped the flat env-major indices of the
   // permutations (ref: buffers.py:53-65, i -> env = i / T, t = i % T) to t * N + env
-  auto to_off = [&](int idx) -> unsigned { return (unsigned)idx; };
 
   // this thread's row of a chunk: b = tid/4 — a row of wave w's own tile, so the per-row side data is wave-private
   const int gb_row = tid >> 2, gpart = tid & 3;
@@ -198,7 +197,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     // every load is issued unconditionally at a clamped (always valid) address; the values are masked only when they are
     // committed to LDS, so nothing waits on the loads here and all of them are in flight together
     pvalid = idx >= 0;
-    const size_t off = pvalid ? (size_t)to_off(idx) : 0;
+    const size_t off = pvalid ? (size_t)idx : 0;
     const float* orow = p_obs + off * O;
     // component k = gpart + 4 i: the four threads of a row read 16 consecutive bytes per instruction
 #pragma unroll
@@ -222,7 +221,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   // advantage statistics of a minibatch (policy role): thread 64 + i, i < nb (<= 128: waves 1 and 2) holds row i's (A_r, A_c)
   float sar = 0.f, sac = 0.f;
   auto issue_stats = [&](int idx) {
-    const unsigned off = idx >= 0 ? to_off(idx) : 0u;     // rows beyond the minibatch are masked in stats_partials
+    const unsigned off = idx >= 0 ? (unsigned)idx : 0u;     // rows beyond the minibatch are masked in stats_partials
     sar = p_s1[off];                                       // (only the policy role uses them)
     sac = p_s2[off];
   };
@@ -296,7 +295,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     const float cpol_nb = inv_nb * __builtin_amdgcn_rcpf(1.f + nu);
     issue_stats(sidx_next);              // advantages of the NEXT minibatch's rows (indices loaded a step ago) ...
     sidx_next = stat_idx(ps_nx2);        // ... and the indices of the one after (step st + 2; its plan entry came a step ago)
-    float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f, mb_s4 = 0.f;  // thread 0: minibatch sums of the loss statistics
+    float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f, mb_s4 = 0.f;  // bookkeeping lane: minibatch sums of the loss statistics
 
     const int n_chunks = (nb + RB - 1) / RB;
     for (int ch = 0; ch < n_chunks; ++ch, ++g_chunk) {

@@ -273,6 +273,10 @@ int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, i
                   const int32_t* ep_offsets, const int32_t* row_episode, int n_ep,
                   const icrl_cn_hyper_t* hp, float* work, float* metrics, void* stream);
 
+/* Diagnostic: cycles per phase of workgroup 0 of the last persistent rollout that ran with do_gae bit 2 set
+ * (out8: policy+env, barrier, tail, steps, exchange load, statistics, normalise, 0). */
+int icrl_debug_rollout_profile(unsigned long long* out8);
+
 /* Minibatch mode of ConstraintNet.train (`--cn_batch_size`; icrl/constraint_net.py:181-206 with get() :300-316): per
  * iteration the importance weights / early-stop test on ALL nominal rows as above, then one optimiser step per batch of
  * `batch_size` indices out of perms[iteration] ([iterations][min(Nn,Ne)] int32 on the device, the caller's

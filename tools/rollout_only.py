@@ -24,7 +24,7 @@ for mode in ("steps", "auto", "steps", "auto"):
         out = (ctypes.c_ulonglong * 8)()
         f = _lib.lib().icrl_debug_rollout_profile
         if f is not None:
-            f.argtypes = [ctypes.c_void_p]; f(out)
+            f(out)
             print("  cycles/step: policy+env %.0f | barrier %.0f | rest %.0f || load exchange %.0f | statistics %.0f | normalise own %.0f" % tuple(out[i] / max(out[3], 1) for i in (0, 1, 2, 4, 5, 6)))
 senv = utils_mod = None
 from icrl_amd import utils as _u
