@@ -690,24 +690,82 @@ __device__ __forceinline__ double np_leaf_sum_wave(const double* a, int n) {
 // float64 recurrence).  The LDS reads are issued sixteen at a time and only the additions stay on the dependent chain; left
 // to itself the compiler pairs every read with its add and exposes the LDS latency 2 N times.
 __device__ __forceinline__ void column_moments(const double* col, int stride, int N, double& bm, double& bv) {
-  double sum = 0.0;
-  for (int r0 = 0; r0 < N; r0 += 16) {
-    double v[16];
+  // two register batches in flight: the reads of batch k + 1 are issued before the additions of batch k
+  auto load16 = [&](int r0, double (&v)[16]) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = col[(r0 + k < N ? r0 + k : N - 1) * stride];
+  };
+  double va[16], vb[16];
+  double sum = 0.0;
+  load16(0, va);
+  for (int r0 = 0; r0 < N; r0 += 32) {
+    load16(r0 + 16 < N ? r0 + 16 : 0, vb);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) if (r0 + k < N) sum += v[k];
+    for (int k = 0; k < 16; ++k) if (r0 + k < N) sum += va[k];
+    load16(r0 + 32 < N ? r0 + 32 : 0, va);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (r0 + 16 + k < N) sum += vb[k];
   }
   bm = sum / (double)N;
   double sq = 0.0;
-  for (int r0 = 0; r0 < N; r0 += 16) {
-    double v[16];
+  // (va holds rows 0..15 again: the last prefetch of the loop above wrapped around)
+  for (int r0 = 0; r0 < N; r0 += 32) {
+    load16(r0 + 16 < N ? r0 + 16 : 0, vb);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { const double d = col[(r0 + k < N ? r0 + k : N - 1) * stride] - bm; v[k] = d * d; }
+    for (int k = 0; k < 16; ++k) { const double d = va[k] - bm; va[k] = d * d; }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) if (r0 + k < N) sq += v[k];
+    for (int k = 0; k < 16; ++k) if (r0 + k < N) sq += va[k];
+    load16(r0 + 32 < N ? r0 + 32 : 0, va);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const double d = vb[k] - bm; vb[k] = d * d; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (r0 + 16 + k < N) sq += vb[k];
+  }
+  bv = sq / (double)N;
+}
+
+// the same moments for a column stored CONTIGUOUSLY (persistent rollout: the exchanged observations are transposed into LDS), so
+// every read is a ds_read with an immediate offset from one running base; the column is padded with >= 32 readable entries.
+__device__ __forceinline__ void column_moments_contig(const double* col, int N, double& bm, double& bv) {
+  double va[16], vb[16];
+  double sum = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) va[k] = col[k];
+  for (int r0 = 0; r0 < N; r0 += 32) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) vb[k] = col[r0 + 16 + k];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (r0 + k < N) sum += va[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) va[k] = col[r0 + 32 + k];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (r0 + 16 + k < N) sum += vb[k];
+  }
+  bm = sum / (double)N;
+  double sq = 0.0;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) va[k] = col[k];
+  for (int r0 = 0; r0 < N; r0 += 32) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) vb[k] = col[r0 + 16 + k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const double d = va[k] - bm; va[k] = d * d; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (r0 + k < N) sq += va[k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) va[k] = col[r0 + 32 + k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const double d = vb[k] - bm; vb[k] = d * d; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (r0 + 16 + k < N) sq += vb[k];
   }
   bv = sq / (double)N;
 }
@@ -861,7 +919,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* flags, int N, int n, unsi
 template <int OCT, int CIT>
 __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) {
   __shared__ ActShared sh;
-  __shared__ double chunk[NORM_CHUNK];
+  __shared__ double chunk[NORM_CHUNK + 64 * MAX_OBS];     // raw observations of the step, TRANSPOSED: [obs][NP], NP = N + 64
   __shared__ double vec[2][128], dev2[2][128], ret_s[128], cret_s[128], rawr_s[128];
   __shared__ float rawc_s[128];
   __shared__ double dens[2];
@@ -881,6 +939,8 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
   const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs, T = p.T;
   const int AS = a.buf.act_store;
   const int NA = a.pl.discrete ? 1 : A;       // noise values per env step
+  const int NP = N + 64;                      // padded column length of the transposed observation block
+  for (int i = tid; i < NORM_CHUNK + 64 * MAX_OBS; i += 256) chunk[i] = 0.0;
   const bool has_cost = a.has_cn != 0;
   const uint32_t e_key = a.env.key[n];
   uint32_t e_ctr = a.env.step_count[n];
@@ -946,7 +1006,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
     // ---------------- phase B: kernel B's statistics, replicated; normalise own env ----------------
     {
       const double* xo = p.xch_obs + (size_t)par * N * O;
-      for (int i = tid; i < N * O; i += 256) chunk[i] = xload(xo + i);
+      for (int i = tid; i < N * O; i += 256) { const int rr = i / O, j = i - rr * O; chunk[j * NP + rr] = xload(xo + i); }
       if (tid < N) {
         const double rr = xload(p.xch_rew + par * N + tid);
         const float rc = has_cost ? xload(p.xch_cost + par * N + tid) : 0.f;
@@ -964,7 +1024,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
     if (nm.training) {
       if (tid < O) {           // obs_rms.update: rows added in order (numpy's axis-0 reduction)
         double bm, bv;
-        column_moments(chunk + tid, O, N, bm, bv);
+        column_moments_contig(chunk + tid * NP, N, bm, bv);
         chan_merge(o_mean, o_var, o_cnt, bm, bv, (double)N);
         o_cnt = (double)N + o_cnt;
       }
@@ -983,7 +1043,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
     if (lane == 0 && w == 2) dens[1] = sqrt(st_v + nm.epsilon);
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc4 += tn_ - tl; tl = tn_; }
     if (tid < O) {             // own env: normalise + clip, next policy input
-      double o = chunk[n * O + tid];
+      double o = chunk[tid * NP + n];
       if (nm.norm_obs) o = fmin(fmax((o - o_mean) / sqrt(o_var + nm.epsilon), -nm.clip_obs), nm.clip_obs);
       o_last = o;
       sh.x[tid] = (float)o;
