@@ -344,7 +344,9 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
 #pragma unroll
           for (int js = 0; js < NT1; ++js)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = MFMA_F32(w1p[t & 1][js][e], bx[js][e], acc);
+            for (int e = 0; e < 4; ++e)
+              if (16 * js + e < O)      // the step's components are 16 js + 4 q + e: all padding beyond obs -> nothing to add
+                acc = MFMA_F32(w1p[t & 1][js][e], bx[js][e], acc);
 #pragma unroll
           for (int i = 0; i < 4; ++i) h1c[t][i] = fast_tanh(acc[i] + b1p[t & 1][i]);
         }

@@ -173,7 +173,7 @@ def test_fused_rollout_vs_reference_golden(golden):
     assert agent.num_timesteps == N * T
 
 
-@pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("ant", 96, 40)])
+@pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("ant", 96, 40), ("ant", 32, 60)])      # ant 96: per-step launches; 32: persistent
 def test_fused_rollout_vs_port(kind, N, T):
     """same comparison at HC / Ant shapes with freshly initialised nets; also crosses episode ends (hc T=300 < 1000: none,
     so the env is pre-stepped to t_ep = 900 first)."""
