@@ -334,10 +334,11 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
           for (int js = 0; js < NT1; ++js) aw[js] = lds128(pa + 16 * js);
           bias = lds128(sm + S::B1 + 16 * t + 4 * q);
         };
+        constexpr bool PF1 = NT1 <= 4;      // wide observations: a second W1 operand tile in flight would spill registers
         load_w1(0, w1p[0], b1p[0]);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-          if (t < 3) load_w1(t + 1, w1p[(t + 1) & 1], b1p[(t + 1) & 1]);
+          if (t < 3) { if (PF1) load_w1(t + 1, w1p[(t + 1) & 1], b1p[(t + 1) & 1]); }
           else load_w2(0, w2p[0], b2p[0]);
           __builtin_amdgcn_sched_barrier(0);
           f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -345,10 +346,11 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
           for (int js = 0; js < NT1; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (16 * js + e < O)      // the step's components are 16 js + 4 q + e: all padding beyond obs -> nothing to add
+              if (js < NT1 - 1 || 16 * js + e < O)      // last k-block: components 16 js + 4 q + e all beyond obs -> nothing to add
                 acc = MFMA_F32(w1p[t & 1][js][e], bx[js][e], acc);
 #pragma unroll
           for (int i = 0; i < 4; ++i) h1c[t][i] = fast_tanh(acc[i] + b1p[t & 1][i]);
+          if (!PF1 && t < 3) load_w1(t + 1, w1p[(t + 1) & 1], b1p[(t + 1) & 1]);
         }
       }
       // prefetch: rows of the next chunk of the stream, indices of the chunk three ahead.  Issued this early on purpose: the
