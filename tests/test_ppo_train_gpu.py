@@ -69,7 +69,9 @@ def _oracle_train(agent_sd, buf, perms, kind, nu, **h):
 
 
 @pytest.mark.parametrize("kind,N,T,B,E,tk", [("hc", 8, 32, 64, 3, None), ("hc", 5, 40, 64, 2, None), ("ant", 24, 16, 128, 2, None),
-                                             ("hc", 16, 32, 64, 6, 0.002), ("hc", 4, 8, 16, 2, None)])
+                                             ("hc", 16, 32, 64, 6, 0.002), ("hc", 4, 8, 16, 2, None),
+                                             ("hc", 5, 40, 128, 2, None),      # 200 rows: minibatches of 128 and 72 = chunks 64 + 64, 64 + 8
+                                             ("ant", 3, 50, 100, 2, None)])    # 150 rows: minibatches of 100 and 50 = chunks 64 + 36, 50
 def test_train_vs_oracle(kind, N, T, B, E, tk):
     rng = np.random.RandomState(N * T)
     od, ad = (18, 6) if kind == "hc" else (113, 8)
