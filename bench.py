@@ -168,6 +168,7 @@ def main():
     ppo_tflops = flops_step / (us_per_step * 1e-6) / 1e12
     roofline_ppo = dict(kernel="ppo_train_rows_kernel", bound="mfma", achieved=round(ppo_tflops, 4), peak=round(F32_MFMA_PEAK_TFLOPS * 3 / 256, 3),
                         unit="TFLOP/s", frac=round(ppo_tflops / (F32_MFMA_PEAK_TFLOPS * 3 / 256), 4),
+                        chip_peak=F32_MFMA_PEAK_TFLOPS, frac_chip=round(ppo_tflops / F32_MFMA_PEAK_TFLOPS, 5),
                         us_per_optimizer_step=round(us_per_step, 2), optimizer_steps=int(np.sum(tr_steps)),
                         note="dependent optimiser steps of the reference algorithm: 3 workgroups (one per MLP) = 3 of 256 CUs; "
                              "peak = fp32 MFMA rate of those 3 CUs; the padded 16x16x4 MFMA work actually issued is 304 instructions "
