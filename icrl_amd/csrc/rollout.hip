@@ -875,6 +875,8 @@ struct PersistArgs {
   float* xch_cost;     // [2][N]
   unsigned* xch_done;  // [2][N]
   unsigned* counter;   // [N] barrier flags, zeroed before the launch
+  unsigned long long* xg;   // granule mode: [2][N][2 obs + 4] self-validating 8-byte words {step tag | 32 payload bits}, zeroed
+  unsigned g_magic;         // floor(2^32 / (2 obs + 4)) for the index split
   int prof;            // diagnostic phase timers (do_gae bit 2)
 };
 
@@ -896,6 +898,12 @@ __device__ __forceinline__ float xload(const float* p) {
   return __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 __device__ __forceinline__ unsigned xload(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void gstore(unsigned long long* p, unsigned tag, unsigned payload) {
+  __hip_atomic_store(p, ((unsigned long long)tag << 32) | (unsigned long long)payload, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long gload(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // device-wide barrier over the N (<= 128) workgroups: workgroup n raises its own flag word to `value` (no read-modify-write
 // contention on one address), wave 0 polls all N flags with one or two loads per lane.  Flags only grow: no reset.
@@ -916,7 +924,12 @@ __device__ __forceinline__ void grid_barrier(unsigned* flags, int N, int n, unsi
   __syncthreads();
 }
 
-template <int OCT, int CIT>
+constexpr int GRAN_MAX = 12;    // granules a thread polls per step in granule mode (N (2 obs + 4) <= 256 * GRAN_MAX)
+
+// GRAN: every exchanged 32-bit half-word travels in its own 8-byte granule together with the step number (the datum is the
+// flag: cdna_hip_programming.md Guideline 16).  Consumers poll the granules themselves, so a step costs ONE trip through the
+// memory system after the slowest producer instead of three (drain stores -> raise flag -> see flag -> fetch data).
+template <int OCT, int CIT, bool GRAN>
 __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) {
   __shared__ ActShared sh;
   __shared__ double chunk[NORM_CHUNK + 64 * MAX_OBS];     // raw observations of the step, TRANSPOSED: [obs][NP], NP = N + 64
@@ -940,6 +953,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
   const int AS = a.buf.act_store;
   const int NA = a.pl.discrete ? 1 : A;       // noise values per env step
   const int NP = N + 64;                      // padded column length of the transposed observation block
+  const int G = 2 * O + 4;                    // granules per env and step: obs halves, reward halves, cost, done
   for (int i = tid; i < NORM_CHUNK + 64 * MAX_OBS; i += 256) chunk[i] = 0.0;
   const bool has_cost = a.has_cn != 0;
   const uint32_t e_key = a.env.key[n];
@@ -966,6 +980,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
   for (int t = 0; t < T; ++t) {
     const int par = t & 1;
     const size_t tn = (size_t)t * N + n;
+    const unsigned gtag = (unsigned)(t + 1);
     if (tid < NA) {
       noise_s[tid] = noise_reg;
       if (t + 1 < T) noise_reg = a.noise[((size_t)(t + 1) * N + n) * NA + tid];     // lands during this step
@@ -978,13 +993,32 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
       double rew; int done;
       env_step_wave(env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
       float* nob = a.buf.new_orig_observations + tn * O;
-      double* xo = p.xch_obs + ((size_t)par * N + n) * O;
-      for (int i = lane; i < O; i += WAVE) { const double v = sh.s_new[i]; nob[i] = (float)v; xstore(xo + i, v); }
-      if (lane == 0) { xstore(p.xch_rew + par * N + n, rew); xstore(p.xch_done + par * N + n, (unsigned)done); }
+      if (GRAN) {
+        unsigned long long* xg = p.xg + ((size_t)par * N + n) * G;
+        for (int i = lane; i < O; i += WAVE) {
+          const double v = sh.s_new[i];
+          nob[i] = (float)v;
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+          gstore(xg + 2 * i, gtag, (unsigned)bits); gstore(xg + 2 * i + 1, gtag, (unsigned)(bits >> 32));
+        }
+        if (lane == 0) {
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(rew);
+          gstore(xg + 2 * O, gtag, (unsigned)bits); gstore(xg + 2 * O + 1, gtag, (unsigned)(bits >> 32));
+          gstore(xg + 2 * O + 3, gtag, (unsigned)done);
+        }
+      } else {
+        double* xo = p.xch_obs + ((size_t)par * N + n) * O;
+        for (int i = lane; i < O; i += WAVE) { const double v = sh.s_new[i]; nob[i] = (float)v; xstore(xo + i, v); }
+        if (lane == 0) { xstore(p.xch_rew + par * N + n, rew); xstore(p.xch_done + par * N + n, (unsigned)done); }
+      }
     } else if (w == 3) {
       float cost = 0.f;
       if (a.has_cn) cost = cost_forward_wave<CIT>(a.cn, a.cl, C, sh.s_old, sh.act_clip, sh.cx, sh.ch);
-      if (lane == 0) { xstore(p.xch_cost + par * N + n, cost); a.buf.orig_costs[tn] = cost; }
+      if (lane == 0) {
+        if (GRAN) gstore(p.xg + ((size_t)par * N + n) * G + 2 * O + 2, gtag, __float_as_uint(cost));
+        else xstore(p.xch_cost + par * N + n, cost);
+        a.buf.orig_costs[tn] = cost;
+      }
     } else if (w == 2) {
       float* ob = a.buf.observations + tn * O;
       float* oob = a.buf.orig_observations + tn * O;
@@ -1001,16 +1035,54 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
       }
     }
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }
-    grid_barrier(p.counter, N, n, (unsigned)(t + 1));
+    if (GRAN) {
+      // poll this thread's granules of ALL envs until every one carries this step's tag, then scatter the payload words
+      const unsigned long long* xg = p.xg + (size_t)par * N * G;
+      const int total = N * G;
+      unsigned long long g[GRAN_MAX];
+#pragma unroll
+      for (int k = 0; k < GRAN_MAX; ++k) g[k] = (k * 256 + tid < total) ? gload(xg + k * 256 + tid) : ((unsigned long long)gtag << 32);
+      for (int spins = 0; spins < (1 << 22); ++spins) {
+        bool ok = true;
+#pragma unroll
+        for (int k = 0; k < GRAN_MAX; ++k)
+          if ((unsigned)(g[k] >> 32) != gtag) { g[k] = gload(xg + k * 256 + tid); ok = false; }
+        if (ok) break;
+      }
+      unsigned* cw = reinterpret_cast<unsigned*>(chunk);
+#pragma unroll
+      for (int k = 0; k < GRAN_MAX; ++k) {
+        const int idx = k * 256 + tid;
+        if (idx < total) {
+          unsigned rr = __umulhi((unsigned)idx, p.g_magic);
+          int slot = idx - (int)rr * G;
+          if (slot >= G) { slot -= G; ++rr; }
+          const unsigned pay = (unsigned)g[k];
+          if (slot < 2 * O) cw[2 * ((slot >> 1) * NP + (int)rr) + (slot & 1)] = pay;
+          else if (slot < 2 * O + 2) reinterpret_cast<unsigned*>(rawr_s)[2 * rr + (slot - 2 * O)] = pay;
+          else if (slot == 2 * O + 2) rawc_s[rr] = has_cost ? __uint_as_float(pay) : 0.f;
+          else done_s[rr] = (int)pay;
+        }
+      }
+      __syncthreads();
+    } else {
+      grid_barrier(p.counter, N, n, (unsigned)(t + 1));
+    }
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }
     // ---------------- phase B: kernel B's statistics, replicated; normalise own env ----------------
     {
-      const double* xo = p.xch_obs + (size_t)par * N * O;
-      for (int i = tid; i < N * O; i += 256) { const int rr = i / O, j = i - rr * O; chunk[j * NP + rr] = xload(xo + i); }
+      if (!GRAN) {
+        const double* xo = p.xch_obs + (size_t)par * N * O;
+        for (int i = tid; i < N * O; i += 256) { const int rr = i / O, j = i - rr * O; chunk[j * NP + rr] = xload(xo + i); }
+      }
       if (tid < N) {
-        const double rr = xload(p.xch_rew + par * N + tid);
-        const float rc = has_cost ? xload(p.xch_cost + par * N + tid) : 0.f;
-        rawr_s[tid] = rr; rawc_s[tid] = rc; done_s[tid] = (int)xload(p.xch_done + par * N + tid);
+        if (!GRAN) {
+          rawr_s[tid] = xload(p.xch_rew + par * N + tid);
+          rawc_s[tid] = has_cost ? xload(p.xch_cost + par * N + tid) : 0.f;
+          done_s[tid] = (int)xload(p.xch_done + par * N + tid);
+        }
+        const double rr = rawr_s[tid];
+        const float rc = rawc_s[tid];
         double r = ret_s[tid], c = has_cost ? cret_s[tid] : 0.0;
         if (nm.training) {
           r = r * nm.reward_gamma + rr;
@@ -1418,7 +1490,9 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
   // persistent path: one launch for all T steps (see rollout_persistent_kernel).  Its exchange arrays live in the not yet
   // computed reward_advantages plane of the buffer (GAE fills that afterwards).  do_gae & 2 forces the per-step launches.
   {
-    const size_t need = (size_t)16 * N * O + (size_t)16 * N + (size_t)8 * N + (size_t)8 * N + 1024;
+    const int G = 2 * O + 4;
+    const bool gran = (size_t)N * G <= (size_t)256 * GRAN_MAX;
+    const size_t need = (size_t)16 * N * O + (size_t)16 * N + (size_t)8 * N + (size_t)8 * N + 1024 + (gran ? (size_t)16 * N * G : 0);
     if (!(do_gae & 2) && N <= 128 && N * O <= NORM_CHUNK && O * env->act_dim <= MAX_OBS * MAX_ACT && T >= 1 &&
         (size_t)T * N * sizeof(float) >= need) {
       PersistArgs p;
@@ -1428,11 +1502,16 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
       p.xch_rew = reinterpret_cast<double*>(base); base += (size_t)16 * N;
       p.xch_cost = reinterpret_cast<float*>(base); base += (size_t)8 * N;
       p.xch_done = reinterpret_cast<unsigned*>(base); base += ((size_t)8 * N + 255) / 256 * 256;
-      p.counter = reinterpret_cast<unsigned*>(base);
-      hipError_t e = hipMemsetAsync(p.counter, 0, 512, s);
+      p.counter = reinterpret_cast<unsigned*>(base); base += 512;
+      p.xg = reinterpret_cast<unsigned long long*>(base);
+      p.g_magic = (unsigned)((1ull << 32) / (unsigned long long)G);
+      hipError_t e = hipMemsetAsync(p.counter, 0, 512 + (gran ? (size_t)16 * N * G : 0), s);
       if (e != hipSuccess) return (int)e;
-      if (a.pl.O <= 32 && (!cn || cn->in_dim <= 32)) hipLaunchKernelGGL((rollout_persistent_kernel<2, 2>), dim3(N), dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((rollout_persistent_kernel<8, 10>), dim3(N), dim3(256), 0, s, p);
+      const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
+      if (small && gran) hipLaunchKernelGGL((rollout_persistent_kernel<2, 2, true>), dim3(N), dim3(256), 0, s, p);
+      else if (small) hipLaunchKernelGGL((rollout_persistent_kernel<2, 2, false>), dim3(N), dim3(256), 0, s, p);
+      else if (gran) hipLaunchKernelGGL((rollout_persistent_kernel<8, 10, true>), dim3(N), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((rollout_persistent_kernel<8, 10, false>), dim3(N), dim3(256), 0, s, p);
       int err = (int)hipGetLastError();
       if (err || !(do_gae & 1)) return err;
       return icrl_gae_dual(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
