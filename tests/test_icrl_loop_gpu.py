@@ -1,5 +1,7 @@
 """GPU: nominal sampling / evaluation kernel vs the oracle port, and a short end-to-end ICRL run through the reference-
 shaped entry point."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -154,3 +156,28 @@ def test_icrl_entry_point_antwall_shapes(tmp_path):
     for k in ("true/reward", "true/cost", "true/forward_kl", "true/reverse_kl", "forward/nu", "forward/approx_kl", "backward/cn_loss"):
         assert np.isfinite(m[k]), k
     assert m["timesteps"] == 2 * 4096
+
+
+def test_expert_rollout_files_round_trip(tmp_path):
+    """run_policy.save_rollouts writes the reference's per-episode .pkl layout; utils.load_expert_data (which also reads the
+    reference's own files/EXPERT/rollouts) reads it back."""
+    import pickle
+    from icrl_amd import run_policy, utils
+    from icrl_amd.ppo_lag import PPOLagrangian
+    from icrl_amd.constraint_net import ConstraintNet
+    train_env = utils.make_train_env("HCWithPos-v0", None, True, 2, 4, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    lo = -np.ones(6, np.float32)
+    cn = ConstraintNet(18, 6, [20], None, lambda x: 0.05, None, None, False, clip_obs=20, action_low=lo, action_high=-lo)
+    train_env.set_cost_function(cn.cost_function)
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", train_env, n_steps=32, seed=2)
+    senv = utils.make_eval_env("HCWithPos-v0", False, seed=2)
+    root = tmp_path / "expert" / "files" / "EXPERT"
+    paths = run_policy.save_rollouts(agent, senv, 3, str(root))
+    assert [os.path.basename(p) for p in paths] == ["0.pkl", "1.pkl", "2.pkl"]
+    d = pickle.load(open(paths[1], "rb"))
+    assert d["observations"].shape == (1000, 18) and d["observations"].dtype == np.float64
+    assert d["actions"].shape == (1000, 6) and d["actions"].dtype == np.float32 and np.abs(d["actions"]).max() <= 1.0
+    assert d["rewards"].shape == (1,) and d["lengths"].tolist() == [1000] and d["save_scheme"] == "not_airl"
+    (obs, acs), mean_reward = utils.load_expert_data(str(tmp_path / "expert"), 3)
+    assert obs.shape == (3000, 18) and acs.shape == (3000, 6) and np.array_equal(obs[1000:2000], d["observations"])
+    assert np.isfinite(mean_reward)
