@@ -48,6 +48,12 @@ class DualVariable:
     def nu(self):
         return _Scalar(self._softplus(self.log_nu))
 
+    def state_dict(self):
+        return dict(log_nu=float(self.log_nu), adam_m=float(self.m), adam_v=float(self.v), adam_t=int(self.t))
+
+    def load_state_dict(self, sd):
+        self.log_nu, self.m, self.v, self.t = F32(sd["log_nu"]), F32(sd["adam_m"]), F32(sd["adam_v"]), int(sd["adam_t"])
+
     def update_parameter(self, cost):
         """ref: dual_variable.py:47-57: loss = -nu * (cost - alpha); Adam(lr, betas (0.9, 0.999), eps 1e-8); clamp."""
         c = F32(cost - self.alpha)

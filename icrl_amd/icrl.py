@@ -141,6 +141,7 @@ def outer_iteration(st, itr):
         constraint_net.save(os.path.join(path, "cn.pt"))
         train_env.save(os.path.join(path, f"{itr}_train_env_stats.pkl"))
     if average_true_reward > best["reward"] and config.save_dir and rank == 0:
+        nominal_agent.save(os.path.join(config.save_dir, "best_nominal_model"))          # SB3-style archive (ref: icrl.py:266)
         torch.save(nominal_agent.policy.state_dict(), os.path.join(config.save_dir, "best_nominal_model_policy.pth"))
         constraint_net.save(os.path.join(config.save_dir, "best_cn_model.pt"))
         train_env.save(os.path.join(config.save_dir, "train_env_stats.pkl"))

@@ -113,6 +113,29 @@ class ActorTwoCriticsPolicy:
         self.params.copy_(flat.to(self.device))
         self.prepare()
 
+    def optimizer_state_dict(self, lr=None, eps=1e-5):
+        """policy.optimizer.state_dict() in torch.optim.Adam's own layout (what SB3 stores as policy.optimizer.pth):
+        parameters numbered in state_dict order, per-parameter step / exp_avg / exp_avg_sq."""
+        state, off = {}, 0
+        m, v = self.exp_avg.detach().cpu(), self.exp_avg_sq.detach().cpu()
+        for i, (k, shp) in enumerate(self.shapes.items()):
+            n = int(np.prod(shp))
+            state[i] = dict(step=torch.tensor(float(self.adam_step)), exp_avg=m[off:off + n].reshape(shp).clone(),
+                            exp_avg_sq=v[off:off + n].reshape(shp).clone())
+            off += n
+        group = dict(lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=0, amsgrad=False, params=list(range(len(self.shapes))))
+        return dict(state=state if self.adam_step > 0 else {}, param_groups=[group])
+
+    def load_optimizer_state_dict(self, osd):
+        state = osd.get("state", {})
+        if not state:
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.adam_step = 0
+            return
+        m = torch.cat([state[i]["exp_avg"].detach().float().reshape(-1) for i in range(len(self.shapes))])
+        v = torch.cat([state[i]["exp_avg_sq"].detach().float().reshape(-1) for i in range(len(self.shapes))])
+        self.exp_avg.copy_(m.to(self.device)); self.exp_avg_sq.copy_(v.to(self.device))
+        self.adam_step = int(float(state[0]["step"]))
+
     @property
     def log_std(self):
         return None if self.discrete else self.params[:self.act_dim]

@@ -241,6 +241,46 @@ class PPOLagrangian:
             callback.on_training_end()
         return self
 
+    # ---- persistence (ref: common/base_class.py save / load, common/save_util.py:284-418) ---------------------------------
+    def save(self, path):
+        """SB3-style archive: `<path>.zip` with `policy.pth` (state dict under the reference's parameter names),
+        `policy.optimizer.pth` (torch Adam layout), `pytorch_variables.pth` (the dual variable) and `data` (JSON of the plain
+        hyper-parameters).  The pickled gym spaces of the reference's `data` entry are not reproduced (no gym here), so the
+        reference can read the tensors out of the archive but not `PPOLagrangian.load` it; this build reads both kinds."""
+        import io, json, zipfile
+        path = str(path)
+        path = path if path.endswith(".zip") else path + ".zip"
+        def blob(obj):
+            b = io.BytesIO(); torch.save(obj, b); return b.getvalue()
+        data = {k: getattr(self, k) for k in ("n_steps", "batch_size", "n_epochs", "reward_gamma", "reward_gae_lambda", "cost_gamma",
+                                               "cost_gae_lambda", "ent_coef", "reward_vf_coef", "cost_vf_coef", "max_grad_norm",
+                                               "target_kl", "n_envs", "num_timesteps", "_n_updates", "seed")}
+        data.update(policy_class="ActorTwoCriticsPolicy", observation_dim=int(self.policy.obs_dim), action_dim=int(self.policy.act_dim),
+                    discrete=bool(self.policy.discrete), adam_step=int(self.policy.adam_step))
+        with zipfile.ZipFile(path, "w") as z:
+            z.writestr("data", json.dumps(data, default=lambda o: str(o)))
+            z.writestr("policy.pth", blob(self.policy.state_dict()))
+            z.writestr("policy.optimizer.pth", blob(self.policy.optimizer_state_dict(lr=float(self.lr_schedule(1.0)))))
+            z.writestr("pytorch_variables.pth", blob(self.dual.state_dict() if hasattr(self.dual, "state_dict") else {}))
+            z.writestr("_stable_baselines3_version", "0.9.0a0+icrl_amd")
+        return path
+
+    def load_parameters(self, path):
+        """restore policy weights (+ optimizer moments and dual variable when present) from an archive written by save() or by
+        the reference (`best_model.zip`)."""
+        import io, zipfile
+        with zipfile.ZipFile(str(path)) as z:
+            names = set(z.namelist())
+            rd = lambda n: torch.load(io.BytesIO(z.read(n)), map_location="cpu", weights_only=False)
+            self.policy.load_state_dict(rd("policy.pth"))
+            if "policy.optimizer.pth" in names:
+                self.policy.load_optimizer_state_dict(rd("policy.optimizer.pth"))
+            if "pytorch_variables.pth" in names and hasattr(self.dual, "load_state_dict"):
+                pv = rd("pytorch_variables.pth")
+                if isinstance(pv, dict) and pv:
+                    self.dual.load_state_dict(pv)
+        return self
+
     def predict(self, observation, state=None, mask=None, deterministic=False, noise=None):
         return self.policy.predict(observation, state, mask, deterministic, noise)
 

@@ -181,3 +181,36 @@ def test_expert_rollout_files_round_trip(tmp_path):
     (obs, acs), mean_reward = utils.load_expert_data(str(tmp_path / "expert"), 3)
     assert obs.shape == (3000, 18) and acs.shape == (3000, 6) and np.array_equal(obs[1000:2000], d["observations"])
     assert np.isfinite(mean_reward)
+
+
+def test_agent_archive_round_trip(tmp_path):
+    """PPOLagrangian.save writes an SB3-style .zip (policy.pth under the reference's names, torch-layout Adam state, dual
+    variable); load_parameters restores it, and the archive serves as --expert_agent_path."""
+    import zipfile
+    from icrl_amd import utils
+    from icrl_amd.ppo_lag import PPOLagrangian
+    from icrl_amd.constraint_net import ConstraintNet
+    def make(seed):
+        env = utils.make_train_env("HCWithPos-v0", None, True, seed, 4, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+        lo = -np.ones(6, np.float32)
+        cn = ConstraintNet(18, 6, [20], None, lambda x: 0.05, None, None, False, clip_obs=20, action_low=lo, action_high=-lo)
+        env.set_cost_function(cn.cost_function)
+        return PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=32, batch_size=64, n_epochs=2, seed=seed)
+    a = make(1)
+    a.learn(2 * 4 * 32)
+    path = a.save(str(tmp_path / "best_nominal_model"))
+    with zipfile.ZipFile(path) as z:
+        assert {"data", "policy.pth", "policy.optimizer.pth", "pytorch_variables.pth"} <= set(z.namelist())
+    b = make(9).load_parameters(path)
+    for k, v in a.policy.state_dict().items():
+        assert torch.equal(v, b.policy.state_dict()[k]), k
+    assert torch.equal(a.policy.exp_avg, b.policy.exp_avg) and torch.equal(a.policy.exp_avg_sq, b.policy.exp_avg_sq)
+    assert a.policy.adam_step == b.policy.adam_step > 0 and a.dual.nu().item() == b.dual.nu().item()
+    # torch's own Adam accepts the optimizer blob (layout check)
+    sd = a.policy.state_dict()
+    params = [torch.nn.Parameter(v.clone()) for v in sd.values()]
+    opt = torch.optim.Adam(params, lr=3e-4, eps=1e-5)
+    opt.load_state_dict(a.policy.optimizer_state_dict(lr=3e-4))
+    expert = utils.load_expert_agent(path)
+    obs = torch.randn(5, 18, dtype=torch.float64, device="cuda"); acs = torch.rand(5, 6, device="cuda")
+    assert torch.equal(expert.policy.evaluate_actions(obs, acs)[2], a.policy.evaluate_actions(obs, acs)[2])
