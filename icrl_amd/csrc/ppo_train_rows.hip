@@ -187,9 +187,22 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   // step / chunk before the permutation entry it locates (a dependent pair of global loads would otherwise stall the wave
   // for a full memory round trip at the point where the second address is formed).
   const int stid = tid - 64;      // advantage statistics: row stid of the minibatch lives in waves 1 (and 2); wave 0 polls
-  auto chunk_idx = [&](const PlanChunk& c) -> int { return gb_row < c.rows ? perms[c.perm_base + gb_row] : -1; };
-  auto stat_idx = [&](const PlanStep& p) -> int {       // row tid of that step's minibatch (policy role)
-    return (role == 0 && stid >= 0 && stid < (p.nb_flags & 0xff)) ? perms[p.perm_base + stid] : -1;
+  // Plan entries are fetched as VECTOR values and kept opaque until the step / chunk they describe becomes the current one:
+  // left to itself the compiler scalarises a uniform load at once (v_readfirstlane right behind the load = a full memory
+  // round trip per step, plus the spill traffic of three rotating 4-dword structs in the scalar file).
+  // (the INDEX is laundered through a vector register, not the loaded value: an asm operand on the value would itself wait
+  // for the load)
+  auto ld_step = [&](int i) -> int4 {
+    asm volatile("" : "+v"(i));
+    return *reinterpret_cast<const int4*>(plan_steps + i);
+  };
+  auto ld_chunk = [&](int g) -> int2 {
+    asm volatile("" : "+v"(g));
+    return *reinterpret_cast<const int2*>(plan_chunks + g);
+  };
+  auto chunk_idx = [&](const int2& c) -> int { return gb_row < c.y ? perms[c.x + gb_row] : -1; };      // {perm_base, rows}
+  auto stat_idx = [&](const int4& p) -> int {       // row stid of that step's minibatch (policy role); p.z = nb_flags, p.w = perm_base
+    return (role == 0 && stid >= 0 && stid < (p.z & 0xff)) ? perms[p.w + stid] : -1;
   };
   float px[XR], pact[4], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
   bool pvalid = false;
@@ -265,18 +278,18 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
 
   // ---- pipeline prologue
   int g_chunk = 0;                      // global index of the chunk being processed
-  int idx_next = chunk_idx(plan_chunks[1]), idx_nx2 = chunk_idx(plan_chunks[2]);
-  PlanChunk pc_nx3 = plan_chunks[3];    // entry of chunk g + 3, loaded one chunk before its indices are
-  issue_rows(chunk_idx(plan_chunks[0]));
-  PlanStep ps_next = plan_steps[0], ps_nx2 = plan_steps[1], ps_nx3 = plan_steps[2];   // steps st, st + 1, st + 2 at the loop top
+  int idx_next = chunk_idx(ld_chunk(1)), idx_nx2 = chunk_idx(ld_chunk(2));
+  int2 pc_nx3 = ld_chunk(3);            // entry of chunk g + 3, loaded one chunk before its indices are
+  issue_rows(chunk_idx(ld_chunk(0)));
+  int4 ps_next = ld_step(0), ps_nx2 = ld_step(1), ps_nx3 = ld_step(2);   // steps st, st + 1, st + 2 at the loop top
   issue_stats(stat_idx(ps_next));
   int sidx_next = stat_idx(ps_nx2);
   refresh_gauss();
   int xcur = S::XT0;                    // X^T buffer of the chunk being processed
   commit_rows(xcur);
-  stats_partials(ps_next.nb_flags & 0xff);
+  stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & 0xff);
   __syncthreads();
-  read_stats(ps_next.nb_flags & 0xff);
+  read_stats(__builtin_amdgcn_readfirstlane(ps_next.z) & 0xff);
   const float inv_n_mb = 1.f / (float)((T * N + a.hp.batch_size - 1) / a.hp.batch_size);
 
   const bool prof = (a.hp._pad & 1) != 0;
@@ -286,9 +299,13 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   bool stop = false;
   for (int st = 0; st < n_steps && !stop; ++st) {
     const unsigned step = (unsigned)st + 1u;
-    const PlanStep ps = ps_next;
+    PlanStep ps;                           // this step's entry becomes scalar only now (it was loaded three steps ago)
+    ps.step_size = __int_as_float(__builtin_amdgcn_readfirstlane(ps_next.x));
+    ps.inv_bc2_sqrt = __int_as_float(__builtin_amdgcn_readfirstlane(ps_next.y));
+    ps.nb_flags = __builtin_amdgcn_readfirstlane(ps_next.z);
+    ps.perm_base = 0;
     ps_next = ps_nx2; ps_nx2 = ps_nx3;
-    ps_nx3 = plan_steps[st + 3 < n_steps + 2 ? st + 3 : n_steps + 1];     // (the table carries two zero entries at its end)
+    ps_nx3 = ld_step(st + 3 < n_steps + 2 ? st + 3 : n_steps + 1);     // (the table carries two zero entries at its end)
     const int nb = ps.nb_flags & 0xff;
     const float inv_nb = __builtin_amdgcn_rcpf((float)nb);
     const float c_mean_r = mean_r, c_mean_c = mean_c, c_istd_r = istd_r;   // statistics of THIS minibatch
@@ -359,7 +376,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       issue_rows(idx_next);
       idx_next = idx_nx2;
       idx_nx2 = chunk_idx(pc_nx3);
-      pc_nx3 = plan_chunks[g_chunk + 4];
+      pc_nx3 = ld_chunk(g_chunk + 4);
       f32x4 whp[4], bhp;                    // head operands
       {
 #pragma unroll
@@ -702,7 +719,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     // ---- while the granules travel: stage the next minibatch (rows -> the other X^T buffer, advantage statistics)
     const int xnext = S::XDB ? (xcur == S::XT0 ? S::XT1 : S::XT0) : xcur;
     commit_rows(xnext);
-    const int nb_next = ps_next.nb_flags & 0xff;
+    const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & 0xff;
     stats_partials(nb_next);
     xcur = xnext;
     // the part of Adam that does not need the clip coefficient, done while the granules travel: m <- (1 - w1) m, v <- beta2 v
