@@ -11,7 +11,7 @@ Weak scaling: every rank owns its own 64 envs; one all-reduce of parameters / mo
 
 The JSON line also carries
   roofline      the dual-GAE kernel (the kernel BASELINE.json's metric names): algorithmic 36 B/transition / live event timing
-                of the in-loop launches, plus the same kernel at N = 65 536 envs where the 4.8 GB working set streams from HBM
+                of the in-loop launches, plus the same kernel at N = 131 072 envs where the 9.7 GB working set streams from HBM
   roofline_ppo  the persistent PPO-Lagrangian kernel (where the time goes): fp32 MFMA flops vs the 3 CUs it occupies
   cpu_baseline  the oracle CPU port (same algorithmic structure as the reference) timed on a bounded sample on the host.
 """
@@ -43,8 +43,8 @@ def config2(n_iters_total, seed, rank, world):
     return types.SimpleNamespace(**cfg)
 
 
-def gae_sweep_point(N=65536, T=2048, reps=20):
-    """same kernel, working set 4.8 GB >> 256 MB Infinity Cache: the HBM-streaming regime."""
+def gae_sweep_point(N=131072, T=2048, reps=20):
+    """same kernel, working set 9.7 GB >> 256 MB Infinity Cache: the HBM-streaming regime (2 workgroups per CU)."""
     from icrl_amd import _lib
     L = _lib.lib()
     dev = torch.device("cuda")
@@ -155,7 +155,7 @@ def main():
     roofline = dict(kernel="gae_dual_kernel", bound="hbm", achieved=round(sweep["achieved"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(sweep["achieved"] / HBM_PEAK_GBS, 4), traffic=traffic,
                     at=f"T={sweep['T']}, N={sweep['envs']} envs: {sweep['bytes'] / 1e9:.2f} GB algorithmic (36 B/transition), "
-                       f"{sweep['us']:.0f} us/launch — the size at which the working set leaves the 256 MB Infinity Cache",
+                       f"{sweep['us']:.0f} us/launch — far beyond the 256 MB Infinity Cache, 2 workgroups per CU",
                     in_loop=dict(achieved=round(gae_ach, 1), frac=round(gae_ach / HBM_PEAK_GBS, 5), us_per_launch=round(float(np.mean(gae_us)), 1),
                                  launches=len(gae_us), bytes_per_launch=gae_bytes,
                                  note="config-size launch (4.7 MB, cache-resident, launch/latency-bound)"))

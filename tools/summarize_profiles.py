@@ -34,7 +34,7 @@ def kernel_stats(tag):
     with open(dst + ".md", "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats — bench.py --steps 2 --warmup 1 ({tag})\n\n"
                 "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag> -- python3 bench.py --steps 2 "
-                "--warmup 1 --no_cpu_baseline` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 65 536)\n\n"
+                "--warmup 1 --no_cpu_baseline` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 131 072)\n\n"
                 f"{bench}\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
         for r in rows[:24]:
             name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
@@ -42,7 +42,7 @@ def kernel_stats(tag):
     print("wrote", dst + ".md")
 
 
-def gae_pmc(tag, T=2048, N=65536):
+def gae_pmc(tag, T=2048, N=131072):
     out = {}
     for name, key in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
         src = find(f"pmc_{tag}_{key}/**/*counter_collection.csv")
