@@ -907,19 +907,21 @@ __device__ __forceinline__ unsigned long long gload(const unsigned long long* p)
 
 // device-wide barrier over the N (<= 128) workgroups: workgroup n raises its own flag word to `value` (no read-modify-write
 // contention on one address), wave 0 polls all N flags with one or two loads per lane.  Flags only grow: no reset.
-__device__ __forceinline__ void grid_barrier(unsigned* flags, int N, int n, unsigned value) {
+__device__ __forceinline__ void grid_barrier(unsigned* flags, int N, int n, unsigned value, int& spin_limit) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this thread's exchange stores have been performed
   __syncthreads();                                      // ... and everybody else's in the workgroup
   if (threadIdx.x < 64) {
     const int lane = threadIdx.x;
     if (lane == 0) xstore(flags + n, value);
     int spins = 0;
-    while (spins < (1 << 24)) {
+    bool ok = false;
+    while (spins < spin_limit && !ok) {
       const unsigned v0 = lane < N ? xload(flags + lane) : value;
       const unsigned v1 = lane + 64 < N ? xload(flags + lane + 64) : value;
-      if (__all(v0 >= value && v1 >= value)) break;
+      ok = __all(v0 >= value && v1 >= value);
       ++spins;
     }
+    if (!ok) spin_limit = 1;
   }
   __syncthreads();
 }
@@ -977,6 +979,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
   float noise_reg = (tid < NA) ? a.noise[(size_t)n * NA + tid] : 0.f;
   double fin_rew = 0.0; float fin_cost = 0.f; int fin_done = 0;
   unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, tl = p.prof ? prof_now() : 0ull;
+  int spin_limit = 1 << 22;
   for (int t = 0; t < T; ++t) {
     const int par = t & 1;
     const size_t tn = (size_t)t * N + n;
@@ -1042,13 +1045,14 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
       unsigned long long g[GRAN_MAX];
 #pragma unroll
       for (int k = 0; k < GRAN_MAX; ++k) g[k] = (k * 256 + tid < total) ? gload(xg + k * 256 + tid) : ((unsigned long long)gtag << 32);
-      for (int spins = 0; spins < (1 << 22); ++spins) {
-        bool ok = true;
+      bool ok = false;
+      for (int spins = 0; spins < spin_limit && !ok; ++spins) {
+        ok = true;
 #pragma unroll
         for (int k = 0; k < GRAN_MAX; ++k)
           if ((unsigned)(g[k] >> 32) != gtag) { g[k] = gload(xg + k * 256 + tid); ok = false; }
-        if (ok) break;
       }
+      if (!ok) spin_limit = 1;      // a peer never showed up (cannot happen with all workgroups resident): do not wait ~2 s per step
       unsigned* cw = reinterpret_cast<unsigned*>(chunk);
 #pragma unroll
       for (int k = 0; k < GRAN_MAX; ++k) {
@@ -1066,7 +1070,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
       }
       __syncthreads();
     } else {
-      grid_barrier(p.counter, N, n, (unsigned)(t + 1));
+      grid_barrier(p.counter, N, n, (unsigned)(t + 1), spin_limit);
     }
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }
     // ---------------- phase B: kernel B's statistics, replicated; normalise own env ----------------
