@@ -939,7 +939,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
   __shared__ float rawc_s[128];
   __shared__ double dens[2];
   __shared__ double Bl[MAX_OBS * MAX_ACT];
-  __shared__ float noise_s[MAX_ACT];
+  __shared__ float noise_s[MAX_ACT], alow_s[MAX_ACT], ahigh_s[MAX_ACT];     // action box: read every step, kept out of global memory
   __shared__ int done_s[128];
   __shared__ int last_done_s;
   const ActStepArgs& a = p.act;
@@ -964,6 +964,8 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
   icrl_env_t env = a.env;
   for (int i = tid; i < O * a.env.act_dim; i += 256) Bl[i] = a.env.B[i];
   env.B = Bl;
+  const bool has_box = a.alow != nullptr && a.ahigh != nullptr;
+  if (tid < MAX_ACT) { alow_s[tid] = (has_box && tid < A) ? a.alow[tid] : 0.f; ahigh_s[tid] = (has_box && tid < A) ? a.ahigh[tid] : 0.f; }
   for (int i = tid; i < MAX_OBS; i += 256) {
     sh.x[i] = i < O ? (float)a.ag.last_obs[(size_t)n * O + i] : 0.f;
     if (i < O) sh.s_old[i] = a.env.s[(size_t)n * O + i];
@@ -990,7 +992,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
     }
     __syncthreads();
     // ---------------- phase A: kernel A's work for env n ----------------
-    policy_forward_block<OCT>(a.pl, R, sh, noise_s, 0, a.alow, a.ahigh);
+    policy_forward_block<OCT>(a.pl, R, sh, noise_s, 0, has_box ? alow_s : nullptr, has_box ? ahigh_s : nullptr);
     __syncthreads();
     if (w == 0) {
       double rew; int done;
@@ -1284,7 +1286,7 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
   __shared__ int s_done;
   __shared__ double s_rew;
   __shared__ double Bl[MAX_OBS * MAX_ACT];     // dynamics matrix: read every step, kept out of the global-memory latency
-  __shared__ float noise_s[MAX_ACT];
+  __shared__ float noise_s[MAX_ACT], alow_s[MAX_ACT], ahigh_s[MAX_ACT];
   const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int O = a.pl.O, A = a.pl.A;
@@ -1292,6 +1294,8 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
   icrl_env_t env = a.env;
   for (int i = tid; i < O * a.env.act_dim; i += 192) Bl[i] = a.env.B[i];
   env.B = Bl;
+  const bool has_box = a.alow != nullptr && a.ahigh != nullptr;
+  if (tid < MAX_ACT) { alow_s[tid] = (has_box && tid < A) ? a.alow[tid] : 0.f; ahigh_s[tid] = (has_box && tid < A) ? a.ahigh[tid] : 0.f; }
   const uint32_t e_key = a.env.key[n];
   uint32_t e_ctr = a.env.step_count[n];
   int e_tep = a.env.t_ep[n];
@@ -1325,7 +1329,8 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
         if (row + 1 < row_end) noise_reg = a.noise[(row + 1) * AS + tid];      // next step's noise lands during this step
       }
       __syncthreads();
-      policy_forward_block<OCT>(a.pl, R, sh, a.noise ? noise_s : nullptr, a.deterministic || a.noise == nullptr, a.alow, a.ahigh);
+      policy_forward_block<OCT>(a.pl, R, sh, a.noise ? noise_s : nullptr, a.deterministic || a.noise == nullptr,
+                                has_box ? alow_s : nullptr, has_box ? ahigh_s : nullptr);
       __syncthreads();
       if (w == 0) {
         double rew; int done;
