@@ -76,7 +76,8 @@ def setup(config):
                         Ki=config.integral_control_coeff, Kd=config.derivative_control_coeff, pid_delay=config.pid_delay,
                         delta_p_ema_alpha=config.proportional_cost_ema_alpha, delta_d_ema_alpha=config.derivative_cost_ema_alpha),
         policy_kwargs=dict(net_arch=utils.get_net_arch(config)),
-        action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"))
+        action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"),
+        streams=getattr(config, "streams", None))
     st = dict(config=config, rank=rank, world=world, train_env=train_env, sampling_env=sampling_env, eval_env=eval_env,
               constraint_net=constraint_net, create_nominal_agent=create_nominal_agent, agent=create_nominal_agent(),
               expert_agent=expert_agent, true_cost_function=get_true_cost_function(config.eval_env_id),
@@ -107,8 +108,11 @@ def outer_iteration(st, itr):
     st["timesteps"] += nominal_agent.num_timesteps
     # ---- nominal trajectories
     sync_envs_normalization(train_env, sampling_env)
+    streams = getattr(config, "streams", None)       # explicit random streams (tests: teacher forcing); None = device RNG
+    A = 1 if nominal_agent.policy.discrete else nominal_agent.policy.act_dim
     orig_observations, observations, actions, rewards, lengths = utils.sample_from_agent(
-        nominal_agent, sampling_env, config.expert_rollouts)
+        nominal_agent, sampling_env, config.expert_rollouts,
+        noise=None if streams is None else streams.sample_noise(config.expert_rollouts * sampling_env.unwrapped.max_steps, A))
     # ---- backward step
     mean, var = None, None
     if config.cn_normalize:
@@ -127,7 +131,9 @@ def outer_iteration(st, itr):
     samples_behind = float((orig_observations[..., 0] < -3).double().mean().item())
     samples_infront = float((orig_observations[..., 0] > 3).double().mean().item())
     sync_envs_normalization(train_env, eval_env)
-    average_true_reward, std_true_reward = utils.evaluate_policy(nominal_agent, eval_env, n_eval_episodes=10, deterministic=False)
+    average_true_reward, std_true_reward = utils.evaluate_policy(
+        nominal_agent, eval_env, n_eval_episodes=10, deterministic=False,
+        noise=None if streams is None else streams.eval_noise(10 * eval_env.unwrapped.max_steps, A))
     forward_kl = reverse_kl = float("nan")
     if st["expert_agent"] is not None:
         forward_kl = utils.compute_kl(nominal_agent, st["d_expert_obs"], st["d_expert_acs"], st["expert_agent"])

@@ -33,7 +33,7 @@ class PPOLagrangian:
                  max_grad_norm=0.5, use_sde=False, sde_sample_freq=-1, target_kl=None, penalty_initial_value=1,
                  penalty_learning_rate=0.01, penalty_min_value=None, update_penalty_after=1, budget=0.,
                  tensorboard_log=None, create_eval_env=False, pid_kwargs=None, policy_kwargs=None, verbose=0, seed=None,
-                 device="cuda", _init_setup_model=True, action_noise="device", permutation="numpy"):
+                 device="cuda", _init_setup_model=True, action_noise="device", permutation="numpy", streams=None):
         if use_sde:
             raise NotImplementedError("gSDE is outside the hot path (no BASELINE config uses it)")
         if policy not in ("TwoCriticsMlpPolicy", ActorTwoCriticsPolicy):
@@ -57,7 +57,9 @@ class PPOLagrangian:
         #   action_noise: "device" (torch.randn on the GPU) | "torch_cpu" (global CPU generator, one call per step: the
         #                 reference's stream) | callable(T, N, A) -> array
         #   permutation:  "numpy" (np.random.permutation per epoch: the reference's stream) | "device" | callable
-        self.action_noise, self.permutation = action_noise, permutation
+        #   streams:      optional object with rollout_noise(T, N, A), permutation(epoch, n), consumed(executed_epochs): every
+        #                 draw of learn() comes from it (teacher forcing against the reference / the CPU oracle in the tests)
+        self.action_noise, self.permutation, self.streams = action_noise, permutation, streams
         self.num_timesteps, self._n_updates, self._total_timesteps = 0, 0, 0
         self._current_progress_remaining = 1
         self._last_obs = self._last_original_obs = self._last_dones = None
@@ -118,6 +120,9 @@ class PPOLagrangian:
         N = self.n_envs
         disc = isinstance(self.action_space, spaces.Discrete)
         shape = (T, N) if disc else (T, N, self.action_space.shape[0])
+        if self.streams is not None:
+            noise = np.asarray(self.streams.rollout_noise(T, N, 1 if disc else shape[2]), np.float32)
+            return torch.as_tensor(noise, device=self.device).reshape(shape).contiguous()
         if callable(self.action_noise):
             return torch.as_tensor(np.asarray(self.action_noise(*shape), np.float32), device=self.device).reshape(shape).contiguous()
         if self.action_noise == "torch_cpu":        # one generator call per env step, like Normal.rsample in the reference
@@ -289,8 +294,9 @@ class PPOLagrangian:
         """[n_epochs, n] int32 on the device.  "numpy": np.random.permutation per epoch — the reference's stream
         (ref: buffers.py:596); the generator is rewound afterwards to what the reference would have consumed (it stops
         drawing once an epoch early-stops), see train()."""
-        if callable(self.permutation):
-            perms = np.stack([np.asarray(self.permutation(e, n)) for e in range(self.n_epochs)])
+        if self.streams is not None or callable(self.permutation):
+            draw = self.streams.permutation if self.streams is not None else self.permutation
+            perms = np.stack([np.asarray(draw(e, n)) for e in range(self.n_epochs)])
             return torch.as_tensor(perms.astype(np.int32), device=self.device).contiguous(), None
         if self.permutation == "device":
             return torch.stack([torch.randperm(n, device=self.device) for _ in range(self.n_epochs)]).to(torch.int32).contiguous(), None
@@ -306,7 +312,7 @@ class PPOLagrangian:
         ccv = -1.0 if self.clip_range_cost_vf is None else float(self.clip_range_cost_vf(self._current_progress_remaining))
         rb, pol, dev = self.rollout_buffer, self.policy, self.device
         n = rb.buffer_size * rb.n_envs
-        rng_state = None
+        rng_state, injected = None, perms is not None
         if perms is None:
             perms, rng_state = self._draw_permutations(n)
         else:
@@ -344,6 +350,8 @@ class PPOLagrangian:
         if ev is not None:
             self.train_events.append((ev[0], ev[1], steps))
         early_stop_epoch = int(st[0])
+        if self.streams is not None and not injected:
+            self.streams.consumed(min(early_stop_epoch + 1, self.n_epochs))
         if rng_state is not None:       # leave np.random where the reference would: one permutation per executed epoch
             np.random.set_state(rng_state)
             for _ in range(min(early_stop_epoch + 1, self.n_epochs)):

@@ -148,11 +148,12 @@ def evaluate_policy(model, env, n_eval_episodes=10, deterministic=True, render=F
 
 
 def compute_kl(agent_2, observations, actions, agent_1=None):
-    """KL(agent_1 || agent_2) on samples of agent_1 (ref: icrl/utils.py:421-437; observations are fed un-normalised,
-    as the reference does)."""
-    kl = -agent_2.policy.evaluate_actions(observations, actions)[2]
+    """ref: icrl/utils.py:421-437; observations are fed un-normalised, as the reference does.  QUIRK kept: the reference
+    takes element [1] of evaluate_actions(), which for the two-critics policy is the cost value (policies.py:752-767 returns
+    values, cost_values, log_prob, entropy), so the logged "KL" is mean(V_c^{agent_1} - V_c^{agent_2})."""
+    kl = -agent_2.policy.evaluate_actions(observations, actions)[1].reshape(-1)
     if agent_1 is not None:
-        kl = kl + agent_1.policy.evaluate_actions(observations, actions)[2]
+        kl = kl + agent_1.policy.evaluate_actions(observations, actions)[1].reshape(-1)
     return float((kl.sum() / kl.shape[0]).item())
 
 

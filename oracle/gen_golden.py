@@ -402,6 +402,123 @@ def g7_constraint_net_minibatch():
     save("g7_constraint_net_minibatch", **out)
 
 
+G8_ARGV = ["icrl", "-er", "20", "-tei", "LGW-v0", "-eei", "CLGW-v0", "-tk", "0.01", "-cl", "20", "-clr", "0.003", "-ft", "800", "-ni", "3",
+           "-bi", "20", "-dno", "-dnr", "-dnc", "--n_steps", "200", "-nt", "2", "-s", "7", "-d", "cpu"]
+
+
+def _lgw_expert_dir(tmp):
+    """the reference ships no LGW expert rollouts: write the committed fixture in the reference's on-disk layout
+    (files/EXPERT/rollouts/{i}.pkl, icrl/icrl.py:25-43) next to the reference's own expert agent archive."""
+    d = np.load(os.path.join(OUT, "expert_lgw.npz"))
+    ep = os.path.join(tmp, "LGW")
+    os.makedirs(os.path.join(ep, "files/EXPERT/rollouts"))
+    os.symlink(f"{REF}/icrl/expert_data/LGW/files/best_model.zip", os.path.join(ep, "files/best_model.zip"))
+    off = 0
+    for i, L in enumerate(d["lengths"]):
+        L = int(L)
+        with open(os.path.join(ep, f"files/EXPERT/rollouts/{i}.pkl"), "wb") as f:
+            pickle.dump(dict(observations=d["observations"][off:off + L], actions=d["actions"][off:off + L],
+                             rewards=np.array([d["rewards"][i]]), lengths=np.array([L]), save_scheme="not_airl"), f)
+        off += L
+    return ep, d
+
+
+def g8_icrl_lgw():
+    """configs[0] end to end: the reference's OWN icrl(config) (icrl/icrl.py:45-312; real SubprocVecEnv workers, Monitor,
+    plotting) on LGW-v0 / CLGW-v0 with the README.md:25 flags at a reduced size, 3 outer iterations.  Every random draw is
+    recorded (Categorical.sample, np.random.permutation) together with the initial weights and the per-iteration metrics;
+    the CPU port, teacher-forced with those draws, must reproduce the metrics."""
+    print("G8 reference icrl() on LGW-v0, 3 outer iterations")
+    import tempfile
+    import types
+    import wandb
+    import icrl.icrl as ref_icrl
+    from icrl_amd.icrl import build_parser          # same flag names / defaults as icrl/icrl.py:316-417 (host code, no GPU use)
+    from oracle.streams import RecordedStreams
+    tmp = tempfile.mkdtemp(prefix="g8_")
+    ep, expert = _lgw_expert_dir(tmp)
+    cfg = vars(build_parser().parse_args(G8_ARGV + ["-ep", ep]))
+    cfg.update(save_dir=os.path.join(tmp, "run"), wandb_sweep=True)       # wandb_sweep: skip the final video (icrl.py:307-309)
+    os.makedirs(cfg["save_dir"])
+    # ---- recorders
+    Cat = th.distributions.Categorical
+    orig_sample, orig_perm = Cat.sample, np.random.permutation
+    phase = ["learn"]
+    draws = dict(learn=[], sample=[], eval=[])
+    perms, snaps, logs = [], {}, []
+
+    def rec_sample(self, sample_shape=th.Size()):
+        a = orig_sample(self, sample_shape); draws[phase[0]].append(a.numpy().copy()); return a
+
+    def rec_perm(n):
+        p = orig_perm(n); perms.append(p.copy()); return p
+
+    class RecPPO(ref_icrl.PPOLagrangian):
+        def _setup_model(self):
+            super()._setup_model()
+            if "policy" not in snaps and self.env is not None:           # the nominal agent (the expert agent has env=None)
+                snaps["policy"] = _sd_np(self.policy.state_dict()); snaps["agent"] = self
+
+    class RecCN(ref_icrl.ConstraintNet):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            snaps["cn"] = _sd_np(self.network.state_dict()); snaps["cn_obj"] = self
+
+    def phased(name, fn, counts):
+        def wrapped(*a, **k):
+            phase[0] = name; n0 = len(draws[name])
+            try:
+                return fn(*a, **k)
+            finally:
+                phase[0] = "learn"; counts.append(len(draws[name]) - n0)
+        return wrapped
+    sample_counts, eval_counts = [], []
+    saved = (ref_icrl.PPOLagrangian, ref_icrl.ConstraintNet, ref_icrl.utils.sample_from_agent, ref_icrl.evaluate_policy, wandb.log)
+    ref_icrl.PPOLagrangian, ref_icrl.ConstraintNet = RecPPO, RecCN
+    ref_icrl.utils.sample_from_agent = phased("sample", saved[2], sample_counts)
+    ref_icrl.evaluate_policy = phased("eval", saved[3], eval_counts)
+    wandb.log = lambda m: logs.append({k: float(v) for k, v in m.items() if np.ndim(v) == 0 and not isinstance(v, str)})
+    Cat.sample, np.random.permutation = rec_sample, rec_perm
+    try:
+        ref_icrl.icrl(types.SimpleNamespace(**cfg))
+    finally:
+        Cat.sample, np.random.permutation = orig_sample, orig_perm
+        (ref_icrl.PPOLagrangian, ref_icrl.ConstraintNet, ref_icrl.utils.sample_from_agent, ref_icrl.evaluate_policy, wandb.log) = saved
+    T, N, ni = cfg["n_steps"], cfg["num_threads"], cfg["n_iters"]
+    learn_actions = np.array(draws["learn"]).reshape(-1, T, N)
+    sample_actions = np.array(draws["sample"]).reshape(ni, -1)
+    eval_actions = np.array(draws["eval"]).reshape(-1)
+    assert sample_actions.shape[1] == cfg["expert_rollouts"] * 200 and len(eval_counts) == ni and sum(eval_counts) == len(eval_actions)
+    print(f"  reference: {learn_actions.shape[0]} rollouts, {len(perms)} permutations, eval steps per iteration {eval_counts}")
+    print("  nu", [round(m["forward/nu"], 6) for m in logs], "true/cost", [m["true/cost"] for m in logs])
+    g = dict(learn_actions=learn_actions.astype(np.int8), perms=np.array(perms).astype(np.int16), sample_actions=sample_actions.astype(np.int8),
+             eval_actions=eval_actions.astype(np.int8), eval_counts=np.array(eval_counts))
+    # ---- the CPU port, teacher-forced
+    esd = th.load(io.BytesIO(zipfile.ZipFile(os.path.join(ep, "files/best_model.zip")).read("policy.pth")))
+    port_cfg = {k: cfg[k] for k in o_loop.PORT_DEFAULTS if k in cfg}
+    om, _, _, objs = o_loop.icrl_port(port_cfg, expert["observations"][:4000], expert["actions"][:4000], esd, streams=RecordedStreams(g),
+                                      init=dict(policy=snaps["policy"], cn=snaps["cn"]))
+    keys = sorted(k for k in logs[0] if k in om[0] and k != "time(m)")
+    worst = {}
+    for it in range(ni):
+        for k in keys:
+            a, b = logs[it][k], float(om[it][k])
+            worst[k] = max(worst.get(k, 0.0), 0.0 if (np.isnan(a) and np.isnan(b)) else abs(a - b) / max(1.0, abs(a)))
+    missing = sorted(k for k in logs[0] if k not in om[0])
+    print("  port vs reference, worst relative deviation per key (>0 only):", {k: float(f"{v:.3g}") for k, v in worst.items() if v > 0})
+    print("  reference keys the port does not produce:", missing)
+    assert max(worst.values()) < 2e-5, worst
+    fin_p, fin_c = snaps["agent"].policy.state_dict(), snaps["cn_obj"].network.state_dict()
+    dw = max(maxdiff(objs["agent"].policy.params[k].detach().numpy(), fin_p[k].numpy()) for k in fin_p)
+    dc = max(maxdiff(objs["cn"].params[k].detach().numpy(), fin_c[k].numpy()) for k in fin_c)
+    print(f"  final weights port vs reference: policy {dw:.3g}, constraint net {dc:.3g}")
+    assert dw < 1e-5 and dc < 1e-5
+    save("g8_icrl_lgw", argv=np.array(G8_ARGV), metric_keys=np.array(keys), metrics=np.array([[logs[it][k] for k in keys] for it in range(ni)]),
+         **g, **{f"w0/{k}": v for k, v in snaps["policy"].items()}, **{f"cn0/{k}": v for k, v in snaps["cn"].items()},
+         **{f"w1/{k}": v.numpy() for k, v in fin_p.items()}, **{f"cn1/{k}": v.numpy() for k, v in fin_c.items()},
+         **{f"expert_policy/{k}": v.numpy() for k, v in esd.items()})
+
+
 def g9_learn_iteration():
     """One learn() of the reference on the synthetic env (N=4, T=32) with the action noise and the minibatch
     permutations recorded, against the CPU port teacher-forced with the same streams."""
@@ -619,8 +736,8 @@ def fixtures_expert():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8"]
     table = dict(g1=g1_gae, g2=g2_cost_function, g3=g3_vecnormalize, g4=g4_ppo_minibatch, g5=g5_dual,
-                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
+                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
     for w in which:
         table[w]()

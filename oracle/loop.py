@@ -162,16 +162,24 @@ class PortAgent:
         self.logs = out
         return out
 
-    def learn(self, total_timesteps, noise_fn=None, perms_fn=None):
-        """ref: on_policy_algorithm.py:430-492 with reset_num_timesteps=True: env reset on every call."""
+    def learn(self, total_timesteps, noise_fn=None, perms_fn=None, streams=None):
+        """ref: on_policy_algorithm.py:430-492 with reset_num_timesteps=True: env reset on every call.
+        streams: an oracle.streams object; its permutation cursor advances by the EXECUTED epochs of each train()."""
         self.num_timesteps = 0
         self._last_obs = self.stack.reset()
         self._last_dones = np.zeros(self.stack.num_envs, bool)
         self._last_original_obs = self.stack.old_obs.copy()
+        T, N, n_epochs = self.h["n_steps"], self.stack.num_envs, self.h["n_epochs"]
+        A = 1 if self.discrete else self.act_dim
         it = 0
         while self.num_timesteps < total_timesteps:
-            self.collect_rollouts(None if noise_fn is None else noise_fn(it))
-            self.train(None if perms_fn is None else perms_fn(it))
+            if streams is not None:
+                self.collect_rollouts(streams.rollout_noise(T, N, A))
+                out = self.train(lambda e: streams.permutation(e, T * N))
+                streams.consumed(min(int(out["train/early_stop_epoch"]) + 1, n_epochs))
+            else:
+                self.collect_rollouts(None if noise_fn is None else noise_fn(it))
+                self.train(None if perms_fn is None else perms_fn(it))
             it += 1
         return self
 
@@ -231,13 +239,16 @@ def evaluate_policy(agent, stack1, n_eval_episodes=10, noise=None, deterministic
 
 
 def compute_kl(policy_2, observations, actions, policy_1=None):
-    """ref: icrl/utils.py:421-437 — mean(-log p2 [+ log p1]) on *unnormalised* observations."""
+    """ref: icrl/utils.py:421-437 on *unnormalised* observations.  QUIRK kept: the reference reads element [1] of
+    evaluate_actions(), which for the two-critics policy (policies.py:752-767 -> values, cost_values, log_prob, entropy) is the
+    COST VALUE, not the log-probability; the logged `true/forward_kl` / `true/reverse_kl` are therefore
+    mean(V_c^{agent_1} - V_c^{agent_2}) (pinned by tests/golden/g8_icrl_lgw.npz)."""
     o = th.tensor(np.asarray(observations), dtype=th.float32)
     a = th.tensor(np.asarray(actions), dtype=th.float32)
     with th.no_grad():
-        kl = -policy_2.evaluate_actions(o, a)[2]
+        kl = -policy_2.evaluate_actions(o, a)[1]
         if policy_1 is not None:
-            kl = kl + policy_1.evaluate_actions(o, a)[2]
+            kl = kl + policy_1.evaluate_actions(o, a)[1]
     return (kl.sum() / o.shape[0]).item()
 
 
@@ -252,61 +263,107 @@ def make_stack(n_envs, kind, seed, *, training=True, norm_reward=True, norm_cost
     return EnvStack(env, norm, cost_fn)
 
 
-def icrl_port(cfg, expert_obs, expert_acs, expert_policy_sd=None, n_iters=None, log=None):
-    """The ICRL outer loop (ref: icrl/icrl.py:45-304) on the synthetic env, CPU port.
-    cfg: dict with the reference's flag names.  Returns (per-iteration metrics list, env_steps, seconds)."""
-    c = dict(kind="hc", num_threads=64, seed=0, n_steps=2048, batch_size=64, n_epochs=10, learning_rate=3e-4,
-             reward_gamma=0.99, reward_gae_lambda=0.95, cost_gamma=0.99, cost_gae_lambda=0.95, clip_range=0.2,
-             target_kl=0.01, penalty_initial_value=1.0, penalty_learning_rate=0.1, budget=0.0,
-             cn_layers=(20,), cn_learning_rate=0.05, anneal_clr_by_factor=0.9, cn_reg_coeff=0.5,
-             per_step_importance_sampling=True, cn_target_kl_old_new=10, cn_target_kl_new_old=2.5,
-             backward_iters=10, forward_timesteps=200000, n_iters=30, expert_rollouts=10, clip_obs=20,
-             cn_eps=1e-5, factored=False)
+ENV_KINDS = {  # reference gym id -> (oracle env kind, early termination, broken); custom_envs/__init__.py:43-57,194-224,357-370
+    "HCWithPos-v0": ("hc", False, False), "HCWithPosTest-v0": ("hc", True, False),
+    "AntWall-v0": ("ant", False, False), "AntWallTest-v0": ("ant", True, False),
+    "AntWallBroken-v0": ("ant", False, True), "AntWallBrokenTest-v0": ("ant", True, True),
+    "LGW-v0": ("lgw", False, False), "CLGW-v0": ("clgw", True, False)}
+
+PORT_DEFAULTS = dict(   # the reference's flag names and parser defaults (icrl/icrl.py:316-417)
+    train_env_id="HCWithPos-v0", eval_env_id="HCWithPosTest-v0", num_threads=5, seed=0, n_steps=2048, batch_size=64, n_epochs=10,
+    learning_rate=3e-4, reward_gamma=0.99, reward_gae_lambda=0.95, cost_gamma=0.99, cost_gae_lambda=0.95, clip_range=0.2,
+    ent_coef=0.0, reward_vf_coef=0.5, cost_vf_coef=0.5, max_grad_norm=0.5, target_kl=None, penalty_initial_value=1.0,
+    penalty_learning_rate=0.1, budget=0.0, cn_layers=(64, 64), cn_learning_rate=3e-4, anneal_clr_by_factor=1.0, cn_reg_coeff=0.0,
+    no_importance_sampling=False, per_step_importance_sampling=False, cn_target_kl_old_new=10, cn_target_kl_new_old=10,
+    cn_batch_size=None, train_gail_lambda=False, cn_normalize=False, backward_iters=10, forward_timesteps=1000000, n_iters=100,
+    expert_rollouts=20, clip_obs=20, cn_eps=1e-5, dont_normalize_obs=False, dont_normalize_reward=False,
+    dont_normalize_cost=False, warmup_timesteps=None, reset_policy=False, factored=False)
+
+
+def true_cost(eval_env_id, orig_obs, acts):
+    """ref: icrl/true_constraint_net.py:11-55,104-111."""
+    if eval_env_id == "CLGW-v0":
+        return float(np.mean(np.asarray(acts).reshape(len(acts), -1)[:, 0] == 1))
+    if eval_env_id.endswith("Test-v0"):
+        return float(np.mean(orig_obs[..., 0] <= -3))
+    return 0.0
+
+
+def icrl_port(cfg, expert_obs, expert_acs, expert_policy_sd=None, n_iters=None, log=None, streams=None, init=None):
+    """The ICRL outer loop (ref: icrl/icrl.py:45-304), CPU port.
+    cfg: dict with the reference's flag names (PORT_DEFAULTS).  streams: an oracle.streams object (teacher forcing) or None
+    (the global numpy / torch generators, like the reference).  init: optional dict(policy=state_dict, cn=state_dict) of
+    initial weights.  Returns (per-iteration metrics list, env_steps, seconds, dict(agent, cn, train))."""
+    c = dict(PORT_DEFAULTS)
     c.update(cfg)
     n_iters = c["n_iters"] if n_iters is None else n_iters
-    train = make_stack(c["num_threads"], c["kind"], c["seed"], reward_gamma=c["reward_gamma"], cost_gamma=c["cost_gamma"])
-    sampling = make_stack(1, c["kind"], c["seed"], training=False, norm_reward=False, norm_cost=False)
-    evalst = make_stack(1, c["kind"], c["seed"], training=False, norm_reward=False, norm_cost=False, wall_terminate=True)
+    kind, _, broken = ENV_KINDS[c["train_env_id"]]
+    ekind, ewall, ebroken = ENV_KINDS[c["eval_env_id"]]
+    discrete = kind in ("lgw", "clgw")
+    nobs, nrew, ncost = not c["dont_normalize_obs"], not c["dont_normalize_reward"], not c["dont_normalize_cost"]
+    train = make_stack(c["num_threads"], kind, c["seed"], norm_obs=nobs, norm_reward=nrew, norm_cost=ncost, broken=broken,
+                       reward_gamma=c["reward_gamma"], cost_gamma=c["cost_gamma"])
+    sampling = make_stack(1, kind, c["seed"], training=False, norm_obs=nobs, norm_reward=False, norm_cost=False, broken=broken)
+    evalst = make_stack(1, ekind, c["seed"], training=False, norm_obs=nobs, norm_reward=False, norm_cost=False,
+                        wall_terminate=ewall, broken=ebroken)
     env = train.env
-    cn = CostNet(env.obs_dim, env.act_dim, c["cn_layers"], False, None, None, c["clip_obs"],
-                 env.action_low, env.action_high, c["cn_eps"])
-    lr_sched = lambda x: (c["anneal_clr_by_factor"] ** (c["n_iters"] * (1 - x))) * c["cn_learning_rate"]
-    cn_opt = th.optim.Adam(cn.parameters(), lr=lr_sched(1), eps=1e-5)
-    train.cost_fn = cn.cost_function
     agent = PortAgent(train, n_steps=c["n_steps"], batch_size=c["batch_size"], n_epochs=c["n_epochs"],
                       learning_rate=c["learning_rate"], reward_gamma=c["reward_gamma"],
                       reward_gae_lambda=c["reward_gae_lambda"], cost_gamma=c["cost_gamma"],
-                      cost_gae_lambda=c["cost_gae_lambda"], clip_range=c["clip_range"], target_kl=c["target_kl"],
-                      penalty_initial_value=c["penalty_initial_value"], penalty_learning_rate=c["penalty_learning_rate"],
-                      budget=c["budget"], seed=c["seed"])
+                      cost_gae_lambda=c["cost_gae_lambda"], clip_range=c["clip_range"], ent_coef=c["ent_coef"],
+                      reward_vf_coef=c["reward_vf_coef"], cost_vf_coef=c["cost_vf_coef"], max_grad_norm=c["max_grad_norm"],
+                      target_kl=c["target_kl"], penalty_initial_value=c["penalty_initial_value"],
+                      penalty_learning_rate=c["penalty_learning_rate"], budget=c["budget"], seed=c["seed"], discrete=discrete)
+    # NB the reference builds the constraint net BEFORE the agent (icrl.py:88-117 vs :139-178) but the agent's constructor
+    # re-seeds every generator (common/utils.py:23-39), so the construction order only matters for the net's own draw.
+    cn = CostNet(env.obs_dim, env.act_dim, c["cn_layers"], discrete, None, None, c["clip_obs"],
+                 env.action_low, env.action_high, c["cn_eps"])
+    if c["cn_normalize"]:
+        cn.obs_mean, cn.obs_var = np.zeros(env.obs_dim), np.ones(env.obs_dim)
+    if init is not None:
+        agent.policy.load_state_dict(init["policy"]); cn.load_state_dict(init["cn"])
+    lr_sched = lambda x: (c["anneal_clr_by_factor"] ** (c["n_iters"] * (1 - x))) * c["cn_learning_rate"]
+    cn_opt = th.optim.Adam(cn.parameters(), lr=lr_sched(1), eps=1e-5)
+    train.cost_fn = cn.cost_function
     expert_policy = None
     if expert_policy_sd is not None:
-        expert_policy = TwoCriticPolicy(env.obs_dim, env.act_dim)
+        expert_policy = TwoCriticPolicy(env.obs_dim, env.act_dim, discrete=discrete)
         expert_policy.load_state_dict(expert_policy_sd)
-    expert_data = cn.prepare(expert_obs, expert_acs)
+    A = 1 if discrete else env.act_dim
     out, steps, t0 = [], 0, time.time()
+    best = {"reward": -np.inf, "cost": np.inf}
+    if c["warmup_timesteps"] is not None:
+        raise NotImplementedError("warm-up with null_cost is exercised through PortAgent directly")
     for itr in range(n_iters):
         progress = 1 - float(itr) / float(c["n_iters"])
-        agent.learn(c["forward_timesteps"])
+        agent.learn(c["forward_timesteps"], streams=streams)
         steps += agent.num_timesteps
         fwd = dict(agent.logs)
         sync_normalization(train.norm, sampling.norm)
-        sampling_agent = agent
         agent.stack, keep = sampling, agent.stack          # predict() clips with the sampling env's action box
-        orig_obs, obs, acts, rews, lens = sample_from_agent(sampling_agent, sampling, c["expert_rollouts"])
+        noise = None if streams is None else streams.sample_noise(c["expert_rollouts"] * sampling.env.max_steps, A)
+        orig_obs, obs, acts, rews, lens = sample_from_agent(agent, sampling, c["expert_rollouts"], noise)
         for g in cn_opt.param_groups:
             g["lr"] = lr_sched(progress)
+        if c["cn_normalize"]:                              # ref: icrl.py:232-236, constraint_net.py:148-153
+            cn.obs_mean, cn.obs_var = sampling.norm.obs_rms.mean.copy(), sampling.norm.obs_rms.var.copy()
         nominal = cn.prepare(orig_obs, acts)
+        expert_data = cn.prepare(expert_obs, expert_acs)   # re-prepared on every train() (constraint_net.py:156)
+        nois = c["no_importance_sampling"] or c["train_gail_lambda"]
         bw = cn_train(cn, cn_opt, c["backward_iters"], nominal, expert_data, lens, reg_coeff=c["cn_reg_coeff"],
-                      per_step=c["per_step_importance_sampling"], target_kl_old_new=c["cn_target_kl_old_new"],
-                      target_kl_new_old=c["cn_target_kl_new_old"], eps=c["cn_eps"], factored=c["factored"])
-        true_cost = float(np.mean(orig_obs[..., 0] <= -3))
+                      importance_sampling=not nois, per_step=c["per_step_importance_sampling"],
+                      target_kl_old_new=c["cn_target_kl_old_new"], target_kl_new_old=c["cn_target_kl_new_old"],
+                      eps=c["cn_eps"], gail=c["train_gail_lambda"], batch_size=c["cn_batch_size"], factored=c["factored"])
+        tc = true_cost(c["eval_env_id"], orig_obs, acts)
         sync_normalization(train.norm, evalst.norm)
         agent.stack = evalst
-        rew_mean, rew_std = evaluate_policy(agent, evalst, 10)
+        enoise = None if streams is None else streams.eval_noise(10 * evalst.env.max_steps, A)
+        rew_mean, rew_std = evaluate_policy(agent, evalst, 10, enoise)
         agent.stack = keep
-        m = {"iteration": itr, "timesteps": steps, "true/reward": rew_mean, "true/reward_std": rew_std,
-             "true/cost": true_cost}
+        best["reward"], best["cost"] = max(best["reward"], rew_mean), min(best["cost"], tc)
+        m = {"iteration": itr, "timesteps": steps, "true/reward": rew_mean, "true/reward_std": rew_std, "true/cost": tc,
+             "true/samples_behind": float(np.mean(orig_obs[..., 0] < -3)), "true/samples_infront": float(np.mean(orig_obs[..., 0] > 3)),
+             "best_true/best_reward": best["reward"], "best_true/best_cost": best["cost"]}
         if expert_policy is not None:
             m["true/forward_kl"] = compute_kl(agent.policy, expert_obs, expert_acs, expert_policy)
             m["true/reverse_kl"] = compute_kl(expert_policy, orig_obs, acts, agent.policy)
@@ -315,4 +372,4 @@ def icrl_port(cfg, expert_obs, expert_acs, expert_policy_sd=None, n_iters=None, 
         out.append(m)
         if log:
             log(m)
-    return out, steps, time.time() - t0
+    return out, steps, time.time() - t0, dict(agent=agent, cn=cn, train=train, sampling=sampling)

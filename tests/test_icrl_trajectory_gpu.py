@@ -1,0 +1,127 @@
+"""GPU: trajectory-level parity of the ICRL outer loop (icrl/icrl.py:199-304): >= 3 outer iterations of
+forward -> sample -> backward -> new cost function -> forward on the HIP path against
+  (1) the metrics the REFERENCE's own icrl() logged on LGW-v0 / CLGW-v0 (tests/golden/g8_icrl_lgw.npz), and
+  (2) the CPU port (oracle.loop.icrl_port, pinned by g8) on HCWithPos shapes,
+both teacher-forced with the same action-noise / permutation streams (oracle/streams.py).
+
+Tolerances (fp32 MLP arithmetic on the GPU vs torch-CPU; float64 env / statistics are bit-exact):
+  train/nu                      1e-5 absolute (north_star's "Lagrange multiplier trajectory")
+  train/average_cost, losses    1e-5 + 1e-4 relative
+  true/cost                     exact on LGW (discrete actions are teacher-forced), one sample of the batch on HC
+  true/reward                   exact on LGW, 1e-4 relative on HC
+  backward/*                    the g6 tolerances of tests/test_cn_train_gpu.py (2e-3 relative + 2e-4)
+"""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loop as o_loop
+from oracle.streams import RecordedStreams, SeededStreams
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _sub(g, prefix):
+    keys = g.files if hasattr(g, "files") else list(g)
+    return {k[len(prefix):]: g[k] for k in keys if k.startswith(prefix)}
+
+
+def _close(a, b, rtol, atol):
+    if np.isnan(b) or np.isinf(b):
+        return (np.isnan(a) and np.isnan(b)) or a == b
+    return abs(a - b) <= atol + rtol * abs(b)
+
+
+EXACT_INT = ("forward/early_stop_epoch", "backward/early_stop_itr", "forward/n_updates", "timesteps", "iteration")
+
+
+def _compare(it, got, ref, keys, discrete, n_nominal):
+    worst = {}
+    for k in keys:
+        a, b = float(got[k]), float(ref[k])
+        if k in EXACT_INT:
+            ok = a == b
+        elif k == "forward/nu":
+            ok = abs(a - b) <= 1e-5
+        elif k in ("true/cost", "best_true/best_cost", "true/samples_behind", "true/samples_infront"):
+            ok = a == b if discrete else abs(a - b) <= 1.0 / n_nominal + 1e-12
+        elif k in ("true/reward", "true/reward_std", "best_true/best_reward"):
+            ok = _close(a, b, 0.0 if discrete else 1e-4, 1e-9 if discrete else 1e-4)
+        elif k.startswith("backward/"):
+            ok = _close(a, b, 2e-3, 2e-4)
+        elif k in ("forward/approx_kl", "forward/clip_fraction"):
+            ok = _close(a, b, 2e-3, 2e-4)        # means of per-minibatch quantities of size ~1e-3 .. 1e-1
+        else:
+            ok = _close(a, b, 1e-4, 1e-5)
+        assert ok, (it, k, a, b)
+        if np.isfinite(b):
+            worst[k] = max(worst.get(k, 0.0), abs(a - b))
+    return worst
+
+
+def test_icrl_lgw_three_iterations_vs_reference(golden):
+    """HIP icrl() vs the reference's own icrl() run (g8): README.md:25 flags at the recorded reduced size."""
+    from icrl_amd.icrl import build_parser, setup, outer_iteration
+    g = golden("g8_icrl_lgw")
+    expert = os.path.join(HERE, "golden/expert_lgw.npz")
+    argv = [str(a) for a in g["argv"]] + ["-ep", expert, "--expert_agent_path", expert, "-v", "0"]
+    argv[argv.index("-d") + 1] = "cuda"
+    cfg = vars(build_parser().parse_args(argv))
+    cfg.update(rank=0, world_size=1, streams=RecordedStreams(g))
+    st = setup(types.SimpleNamespace(**cfg))
+    # the reference's expert agent (expert_lgw.npz carries best_model.zip's policy.pth) must be what g8 recorded
+    for k, v in _sub(g, "expert_policy/").items():
+        assert np.array_equal(st["expert_agent"].policy.state_dict()[k].numpy(), v), k
+    st["agent"].policy.load_state_dict(_sub(g, "w0/"))
+    st["constraint_net"].load_state_dict(_sub(g, "cn0/"))
+    keys = [str(k) for k in g["metric_keys"]]
+    worst = {}
+    for it in range(3):
+        m = outer_iteration(st, it)
+        missing = [k for k in keys if k not in m]
+        assert not missing, missing
+        ref = dict(zip(keys, g["metrics"][it]))
+        for k, v in _compare(it, m, ref, keys, True, 4000).items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    print("worst absolute deviation from the reference over 3 outer iterations:",
+          {k: float(f"{v:.3g}") for k, v in sorted(worst.items()) if v > 0})
+    # final weights after 3 x (2 rollouts + 2 x <=10 epochs x 7 minibatches) Adam steps and 3 x 20 constraint-net iterations
+    for k, v in st["agent"].policy.state_dict().items():
+        assert np.allclose(v.numpy(), g["w1/" + k], rtol=1e-3, atol=2e-5), (k, np.abs(v.numpy() - g["w1/" + k]).max())
+    for k, v in st["constraint_net"].state_dict().items():
+        assert np.allclose(v.numpy(), g["cn1/" + k], rtol=2e-3, atol=2e-4), (k, np.abs(v.numpy() - g["cn1/" + k]).max())
+
+
+def test_icrl_hc_three_iterations_vs_port(golden):
+    """HIP icrl() vs the CPU port on HCWithPos shapes (N = 8, T = 128), README.md:38 flags, 3 outer iterations, same
+    noise / permutation streams.  The port itself is pinned to the reference by g8 (outer loop) and g9 (HC learn())."""
+    from icrl_amd.icrl import build_parser, setup, outer_iteration
+    expert = os.path.join(HERE, "golden/expert_hc.npz")
+    argv = ["icrl", "-er", "2", "-ep", expert, "--expert_agent_path", expert, "-tk", "0.01", "-cl", "20", "-bi", "10", "-ft", "2000",
+            "-ni", "3", "-tei", "HCWithPos-v0", "-eei", "HCWithPosTest-v0", "-clr", "0.05", "-aclr", "0.9", "-crc", "0.5", "-psis",
+            "-ctkno", "2.5", "-nt", "8", "--n_steps", "128", "-s", "3", "-v", "0"]
+    cfg = vars(build_parser().parse_args(argv))
+    cfg.update(rank=0, world_size=1, streams=SeededStreams(11))
+    st = setup(types.SimpleNamespace(**cfg))
+    init = dict(policy={k: v.numpy().copy() for k, v in st["agent"].policy.state_dict().items()},
+                cn={k: v.numpy().copy() for k, v in st["constraint_net"].state_dict().items()})
+    ex = golden("expert_hc")
+    port_cfg = {k: cfg[k] for k in o_loop.PORT_DEFAULTS if k in cfg}
+    om, steps, _, objs = o_loop.icrl_port(port_cfg, ex["observations"][:1000], ex["actions"][:1000], _sub(ex, "policy/"),
+                                          streams=SeededStreams(11), init=init)
+    keys = sorted(k for k in om[0] if k not in ("forward/std",))
+    worst = {}
+    for it in range(3):
+        m = outer_iteration(st, it)
+        for k, v in _compare(it, m, om[it], [k for k in keys if k in m], False, 2000).items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        assert abs(m["forward/std"] - om[it]["forward/std"]) < 1e-5
+    assert st["timesteps"] == steps == 3 * 2048
+    print("worst absolute deviation from the CPU port over 3 outer iterations:",
+          {k: float(f"{v:.3g}") for k, v in sorted(worst.items()) if v > 0})
+    nus = [m_["forward/nu"] for m_ in om]
+    assert len(set(np.round(nus, 4))) == 3          # the multiplier actually moves between iterations

@@ -248,3 +248,30 @@ def test_g7_constraint_net_minibatch(golden, case):
         assert (np.isnan(ref) and np.isnan(v)) or ref == v, k
     for k, p in net.params.items():
         assert np.array_equal(p.detach().numpy(), g["w1/" + k]), k
+
+
+def test_g8_icrl_outer_loop_reference(golden):
+    """The reference's OWN icrl(config) on LGW-v0 / CLGW-v0 (3 outer iterations, real SubprocVecEnv workers; g8): the CPU port,
+    teacher-forced with the recorded action / permutation draws, reproduces every per-iteration metric the reference logged
+    (train/nu, train/average_cost, true/cost, true/reward, the two "KL"s, all backward/*) and the final weights."""
+    from oracle.streams import RecordedStreams
+    from icrl_amd.icrl import build_parser            # host-side flag parser only (no GPU use)
+    g = golden("g8_icrl_lgw")
+    ex = golden("expert_lgw")
+    cfg = vars(build_parser().parse_args([str(a) for a in g["argv"]]))
+    port_cfg = {k: cfg[k] for k in o_loop.PORT_DEFAULTS if k in cfg}
+    om, steps, _, objs = o_loop.icrl_port(port_cfg, ex["observations"][:4000], ex["actions"][:4000], _sub(g, "expert_policy/"),
+                                          streams=RecordedStreams(g), init=dict(policy=_sub(g, "w0/"), cn=_sub(g, "cn0/")))
+    keys = [str(k) for k in g["metric_keys"]]
+    assert {"forward/nu", "forward/average_cost", "true/cost", "true/reward", "true/forward_kl", "true/reverse_kl",
+            "backward/cn_loss", "backward/kl_new_old", "backward/early_stop_itr"} <= set(keys)
+    assert steps == 3 * 800
+    for it in range(3):
+        for j, k in enumerate(keys):
+            ref, got = float(g["metrics"][it, j]), float(om[it][k])
+            # identical torch / numpy ops in the same order: exact, up to the float64-vs-float32 mean of two logged averages
+            assert got == ref or abs(got - ref) <= 2e-7 * max(1.0, abs(ref)), (it, k, got, ref)
+    for k, v in _sub(g, "w1/").items():
+        assert np.array_equal(objs["agent"].policy.params[k].detach().numpy(), v), k
+    for k, v in _sub(g, "cn1/").items():
+        assert np.array_equal(objs["cn"].params[k].detach().numpy(), v), k
