@@ -158,9 +158,13 @@ class ConstraintNet:
         self.current_obs_mean, self.current_obs_var = obs_mean, obs_var
         self._refresh_consts()
         nominal = self.prepare_data(nominal_obs, nominal_acs)
-        if getattr(self, "_expert_cache", None) is None or obs_mean is not None:
-            self._expert_cache = self.prepare_data(self.expert_obs, self.expert_acs)
-        expert = self._expert_cache
+        # the reference re-runs prepare_data(expert) on every train() (constraint_net.py:157): the normalisation / clipping
+        # constants may have changed since the last call.  Only the raw expert rows are cached on the device.
+        if getattr(self, "_expert_dev", None) is None:
+            a_w = 1 if self.is_discrete else self.acs_dim
+            self._expert_dev = (torch.as_tensor(np.asarray(self.expert_obs), device=self.device).to(torch.float64).reshape(-1, self.obs_dim).contiguous(),
+                                torch.as_tensor(np.asarray(self.expert_acs), device=self.device).to(torch.float32).reshape(-1, a_w).contiguous())
+        expert = self.prepare_data(*self._expert_dev)
         dev, iters = self.device, int(iterations)
         lengths = np.asarray(episode_lengths, np.int64)
         offs = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)

@@ -921,7 +921,7 @@ __device__ __forceinline__ void grid_barrier(unsigned* flags, int N, int n, unsi
       ok = __all(v0 >= value && v1 >= value);
       ++spins;
     }
-    if (!ok) spin_limit = 1;
+    if (!ok) spin_limit = 1;      // caller reports through icrl_agent_t.status
   }
   __syncthreads();
 }
@@ -1054,7 +1054,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
         for (int k = 0; k < GRAN_MAX; ++k)
           if ((unsigned)(g[k] >> 32) != gtag) { g[k] = gload(xg + k * 256 + tid); ok = false; }
       }
-      if (!ok) spin_limit = 1;      // a peer never showed up (cannot happen with all workgroups resident): do not wait ~2 s per step
+      if (!ok) spin_limit = 1;      // a peer never showed up (a workgroup was not resident): stop waiting ~2 s per step; reported below
       unsigned* cw = reinterpret_cast<unsigned*>(chunk);
 #pragma unroll
       for (int k = 0; k < GRAN_MAX; ++k) {
@@ -1149,6 +1149,8 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc2 += tn_ - tl; tl = tn_; }
   }
   if (p.prof && n == 0 && tid == 0) { g_rollout_prof[0] = pc0; g_rollout_prof[1] = pc1; g_rollout_prof[2] = pc2; g_rollout_prof[3] = (unsigned long long)T; g_rollout_prof[4] = pc3; g_rollout_prof[5] = pc4; g_rollout_prof[6] = pc5; }
+  // a timed-out exchange means stale granules went into the statistics and the buffer: tell the host (it raises)
+  if (spin_limit == 1 && a.ag.status != nullptr && (tid & 63) == 0) atomicOr(a.ag.status, 1);
   // ---- leave the agent / wrapper state exactly where the per-step path leaves it
   __syncthreads();
   if (tid < O) a.ag.last_obs[(size_t)n * O + tid] = o_last;
@@ -1479,6 +1481,18 @@ extern "C" int icrl_debug_rollout_profile(unsigned long long* out4) {
   return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_rollout_prof), sizeof(unsigned long long) * 8);
 }
 
+// all N workgroups of the persistent rollout must be co-resident (they wait for each other every step): ask the runtime
+// how many blocks of this kernel one CU takes.  The answer is advisory (MI355X_MICROARCH.md: it can read one high for
+// SGPR-heavy kernels), hence the bounded spins + status word as the backstop.
+template <typename K>
+static bool persistent_fits(K kernel, int blocks) {
+  int dev = 0, cus = 0, per_cu = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess) return false;
+  return (long long)per_cu * cus >= blocks;
+}
+
 extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol,
                                        const icrl_costnet_t* cn, const icrl_buffer_t* buf, const icrl_agent_t* ag,
                                        const float* noise, const float* action_low, const float* action_high,
@@ -1517,17 +1531,25 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
       hipError_t e = hipMemsetAsync(p.counter, 0, 512 + (gran ? (size_t)16 * N * G : 0), s);
       if (e != hipSuccess) return (int)e;
       const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
-      if (small && gran) hipLaunchKernelGGL((rollout_persistent_kernel<2, 2, true>), dim3(N), dim3(256), 0, s, p);
-      else if (small) hipLaunchKernelGGL((rollout_persistent_kernel<2, 2, false>), dim3(N), dim3(256), 0, s, p);
-      else if (gran) hipLaunchKernelGGL((rollout_persistent_kernel<8, 10, true>), dim3(N), dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((rollout_persistent_kernel<8, 10, false>), dim3(N), dim3(256), 0, s, p);
+      auto go = [&](auto kernel) -> bool {
+        if (!persistent_fits(kernel, N)) return false;
+        hipLaunchKernelGGL(kernel, dim3(N), dim3(256), 0, s, p);
+        return true;
+      };
+      bool launched;
+      if (small && gran) launched = go(rollout_persistent_kernel<2, 2, true>);
+      else if (small) launched = go(rollout_persistent_kernel<2, 2, false>);
+      else if (gran) launched = go(rollout_persistent_kernel<8, 10, true>);
+      else launched = go(rollout_persistent_kernel<8, 10, false>);
       int err = (int)hipGetLastError();
+      if (!launched) goto per_step;
       if (err || !(do_gae & 1)) return err;
       return icrl_gae_dual(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
                            ag->last_v_c, ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns,
                            buf->cost_returns, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, stream);
     }
   }
+per_step:
   for (int t = 0; t < T; ++t) {
     if (a.pl.O <= 32 && (!cn || cn->in_dim <= 32)) hipLaunchKernelGGL((act_step_kernel<2, 2>), dim3(N), dim3(256), 0, s, a, t);
     else hipLaunchKernelGGL((act_step_kernel<8, 10>), dim3(N), dim3(256), 0, s, a, t);

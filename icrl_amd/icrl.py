@@ -62,22 +62,28 @@ def setup(config):
         train_gail_lambda=config.train_gail_lambda, eps=config.cn_eps, device=dev)
     train_env.set_cost_function(constraint_net.cost_function)
 
-    create_nominal_agent = lambda: PPOLagrangian(
-        policy=config.policy_name, env=train_env, learning_rate=config.learning_rate, n_steps=config.n_steps,
-        batch_size=config.batch_size, n_epochs=config.n_epochs, reward_gamma=config.reward_gamma,
-        reward_gae_lambda=config.reward_gae_lambda, cost_gamma=config.cost_gamma, cost_gae_lambda=config.cost_gae_lambda,
-        clip_range=config.clip_range, clip_range_reward_vf=config.clip_range_reward_vf, clip_range_cost_vf=config.clip_range_cost_vf,
-        ent_coef=config.ent_coef, reward_vf_coef=config.reward_vf_coef, cost_vf_coef=config.cost_vf_coef,
-        max_grad_norm=config.max_grad_norm, use_sde=config.use_sde, sde_sample_freq=config.sde_sample_freq,
-        target_kl=config.target_kl, penalty_initial_value=config.penalty_initial_value,
-        penalty_learning_rate=config.penalty_learning_rate, budget=config.budget, seed=config.seed, device=dev, verbose=0,
-        algo_type="pidlagrangian" if getattr(config, "use_pid", False) else "lagrangian",
-        pid_kwargs=dict(alpha=config.budget, penalty_init=config.penalty_initial_value, Kp=config.proportional_control_coeff,
-                        Ki=config.integral_control_coeff, Kd=config.derivative_control_coeff, pid_delay=config.pid_delay,
-                        delta_p_ema_alpha=config.proportional_cost_ema_alpha, delta_d_ema_alpha=config.derivative_cost_ema_alpha),
-        policy_kwargs=dict(net_arch=utils.get_net_arch(config)),
-        action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"),
-        streams=getattr(config, "streams", None))
+    def create_nominal_agent():
+        agent = PPOLagrangian(
+            policy=config.policy_name, env=train_env, learning_rate=config.learning_rate, n_steps=config.n_steps,
+            batch_size=config.batch_size, n_epochs=config.n_epochs, reward_gamma=config.reward_gamma,
+            reward_gae_lambda=config.reward_gae_lambda, cost_gamma=config.cost_gamma, cost_gae_lambda=config.cost_gae_lambda,
+            clip_range=config.clip_range, clip_range_reward_vf=config.clip_range_reward_vf, clip_range_cost_vf=config.clip_range_cost_vf,
+            ent_coef=config.ent_coef, reward_vf_coef=config.reward_vf_coef, cost_vf_coef=config.cost_vf_coef,
+            max_grad_norm=config.max_grad_norm, use_sde=config.use_sde, sde_sample_freq=config.sde_sample_freq,
+            target_kl=config.target_kl, penalty_initial_value=config.penalty_initial_value,
+            penalty_learning_rate=config.penalty_learning_rate, budget=config.budget, seed=config.seed, device=dev, verbose=0,
+            algo_type="pidlagrangian" if getattr(config, "use_pid", False) else "lagrangian",
+            pid_kwargs=dict(alpha=config.budget, penalty_init=config.penalty_initial_value, Kp=config.proportional_control_coeff,
+                            Ki=config.integral_control_coeff, Kd=config.derivative_control_coeff, pid_delay=config.pid_delay,
+                            delta_p_ema_alpha=config.proportional_cost_ema_alpha, delta_d_ema_alpha=config.derivative_cost_ema_alpha),
+            policy_kwargs=dict(net_arch=utils.get_net_arch(config)),
+            action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"),
+            streams=getattr(config, "streams", None))
+        # the constructor seeded every generator with config.seed (common/utils.py:23-39): all ranks now hold the SAME initial
+        # networks; from here on rank r draws its own action noise / minibatch permutations
+        D.decorrelate_streams(config.seed, rank)
+        return agent
+
     st = dict(config=config, rank=rank, world=world, train_env=train_env, sampling_env=sampling_env, eval_env=eval_env,
               constraint_net=constraint_net, create_nominal_agent=create_nominal_agent, agent=create_nominal_agent(),
               expert_agent=expert_agent, true_cost_function=get_true_cost_function(config.eval_env_id),
@@ -85,13 +91,32 @@ def setup(config):
               d_expert_acs=torch.as_tensor(np.asarray(expert_acs), device=dev),
               timesteps=0., start_time=time.time(),
               best=dict(reward=-np.inf, cost=np.inf, fkl=np.inf, rkl=np.inf))
+    if world > 1:     # common history of the running moments for the exact cross-rank merge: the (identical) initial state
+        st["rms_list"] = [train_env.obs_rms, train_env.ret_rms, train_env.cost_rms]
+        st["rms_prev"] = [D.moments_to_sums(r.mean, r.var, r.count) for r in st["rms_list"]]
     if config.warmup_timesteps is not None:    # ref: icrl/icrl.py:185-193 — no cost is incurred during the warm-up
         st["agent"].learn(total_timesteps=config.warmup_timesteps, cost_function=null_cost)
         st["timesteps"] += st["agent"].num_timesteps
-    if world > 1:     # common history of the running moments for the exact cross-rank merge
-        st["rms_list"] = [train_env.obs_rms, train_env.ret_rms, train_env.cost_rms]
-        st["rms_prev"] = [D.moments_to_sums(r.mean, r.var, r.count) for r in st["rms_list"]]
+        synchronise(st)                        # the ranks' warm-ups saw different shards: merge before the loop starts
     return st
+
+
+def synchronise(st):
+    """the single collective of an outer iteration (no-op on one rank): average policy / constraint-net parameters and Adam
+    moments and the dual variable, agree on the step counters, merge the three running-moment sets exactly."""
+    if st["world"] <= 1:
+        return
+    agent, cn = st["agent"], st["constraint_net"]
+    pol, dual = agent.policy, agent.dual
+    if hasattr(dual, "log_nu"):
+        scal = D.Scalars(avg=[(dual, "log_nu"), (dual, "m"), (dual, "v")],
+                         counters=[(pol, "adam_step"), (cn, "adam_step"), (dual, "t")])
+    else:       # PIDLagrangian: controller state is averaged; its derivative history (a deque of past EMAs) stays per rank
+        scal = D.Scalars(avg=[(dual, "pid_i"), (dual, "cost_penalty"), (dual, "_delta_p"), (dual, "_cost_delta")],
+                         counters=[(pol, "adam_step"), (cn, "adam_step")])
+    st["rms_prev"] = D.allreduce_state([pol.params, pol.exp_avg, pol.exp_avg_sq, cn.params, cn.exp_avg, cn.exp_avg_sq],
+                                       st["rms_list"], st["rms_prev"], st["world"], scalars=scal)
+    pol.prepare(); cn.prepare()
 
 
 def outer_iteration(st, itr):
@@ -121,11 +146,7 @@ def outer_iteration(st, itr):
                                             current_progress_remaining)
     train_env.set_cost_function(constraint_net.cost_function)
     # ---- the single collective of the iteration
-    if world > 1:
-        pol = nominal_agent.policy
-        st["rms_prev"] = D.allreduce_state([pol.params, pol.exp_avg, pol.exp_avg_sq, constraint_net.params, constraint_net.exp_avg,
-                                            constraint_net.exp_avg_sq], st["rms_list"], st["rms_prev"], world)
-        pol.prepare(); constraint_net.prepare()
+    synchronise(st)
     # ---- evaluation
     average_true_cost = mean_cost(st["true_cost_function"], orig_observations, actions)
     samples_behind = float((orig_observations[..., 0] < -3).double().mean().item())
@@ -230,20 +251,26 @@ def build_parser():
     return p
 
 
+def explicit_dests(parser, argv):
+    """dests of the options that appear on the command line under ANY of their spellings (-s / --seed): the reference maps
+    short and long names through one table (icrl/utils.py:176-219).  Precedence: command line > config file > default."""
+    by_flag = {s: act.dest for act in parser._actions for s in act.option_strings}
+    return {by_flag[a.split("=")[0]] for a in argv if a.split("=")[0] in by_flag}
+
+
 def main(argv=None):
     start = time.time()
-    args = build_parser().parse_args(argv if argv is not None else sys.argv[1:])
+    parser = build_parser()
+    args = parser.parse_args(argv if argv is not None else sys.argv[1:])
     config = vars(args)
     if config["config_file"] is not None and config["config_file"].endswith(".json"):
         with open(config["config_file"]) as f:
             file_cfg = json.load(f)
-        explicit = {a.lstrip("-") for a in (argv or sys.argv[1:]) if a.startswith("-")}
-        for k, v in file_cfg.items():        # precedence: command line > file > parser default (ref: icrl/utils.py:176-219)
-            if k not in explicit:
-                config[k] = v
-    if config["seed"] is None:
-        config["seed"] = int(np.random.randint(0, 100))
+        config.update({k: v for k, v in file_cfg.items() if k not in explicit_dests(parser, argv if argv is not None else sys.argv[1:])})
     rank, world = D.init_from_env()
+    if config["seed"] is None and rank == 0:
+        config["seed"] = int(np.random.randint(0, 100))
+    config["seed"] = D.broadcast_seed(config["seed"], rank, world)     # every rank builds the same initial networks
     config["rank"], config["world_size"] = rank, world
     if config["save_dir"]:
         os.makedirs(config["save_dir"], exist_ok=True)

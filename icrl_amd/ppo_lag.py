@@ -6,8 +6,10 @@ ref: stable_baselines3/ppo_lag/ppo_lag.py:17-365 (PPOLagrangian: __init__, _setu
 
 The host keeps the reference's control flow and attribute names (num_timesteps, rollout_buffer, dual, policy, ...);
 the work is enqueued as kernels of libicrl_hip.so:
-  collect_rollouts -> icrl_rollout_collect (2 launches per env step + dual GAE, no host sync)
-  train            -> icrl_ppo_lag_train   (ONE persistent launch for all epochs x minibatches) + icrl_dual_step
+  collect_rollouts -> icrl_rollout_collect (ONE persistent launch for all T steps, or 2 launches per env step, + dual GAE;
+                      no host sync)
+  train            -> icrl_ppo_lag_train   (ONE persistent launch for all epochs x minibatches); the dual variable is one
+                      float32 scalar updated on the host (dual_variable.py)
 """
 import time
 
@@ -98,7 +100,7 @@ class PPOLagrangian:
         self._ag = dict(last_dones=torch.zeros(N, dtype=torch.uint8, device=dev), raw_rew=torch.zeros(N, dtype=torch.float64, device=dev),
                         raw_cost=torch.zeros(N, device=dev), dones=torch.zeros(N, dtype=torch.uint8, device=dev),
                         last_v_r=torch.zeros(N, device=dev), last_v_c=torch.zeros(N, device=dev),
-                        act_clipped=torch.zeros(N, A, device=dev))
+                        act_clipped=torch.zeros(N, A, device=dev), status=torch.zeros(1, dtype=torch.int32, device=dev))
         if isinstance(self.action_space, spaces.Box):
             self._alow = torch.as_tensor(self.action_space.low, device=dev).float().contiguous()
             self._ahigh = torch.as_tensor(self.action_space.high, device=dev).float().contiguous()
@@ -145,7 +147,7 @@ class PPOLagrangian:
             noise = self._draw_action_noise(n_rollout_steps)
         e, nm, pol, cn, buf = senv.struct(), nenv.struct(), self.policy.struct(), cw.constraint_net().struct(), rollout_buffer.struct()
         ag = AgentT(p(self._last_obs), p(self._ag["last_dones"]), p(self._ag["raw_rew"]), p(self._ag["raw_cost"]), p(self._ag["dones"]),
-                    p(self._ag["last_v_r"]), p(self._ag["last_v_c"]), p(self._ag["act_clipped"]))
+                    p(self._ag["last_v_r"]), p(self._ag["last_v_c"]), p(self._ag["act_clipped"]), p(self._ag["status"]))
         b = _lib.byref
         timed = getattr(self, "gae_events", None) is not None
         _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn), b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
@@ -170,6 +172,14 @@ class PPOLagrangian:
         if callback is not None:
             callback.on_rollout_end()
         return True
+
+    def check_rollout_status(self):
+        """raise if the persistent rollout kernel reported a timed-out exchange (icrl_agent_t.status): its buffer rows and
+        running moments are then invalid.  One 4-byte read; train() calls it next to its own statistics read-back."""
+        if int(self._ag["status"].item()) != 0:
+            self._ag["status"].zero_()
+            raise RuntimeError("icrl_rollout_collect: inter-workgroup exchange timed out (a workgroup of the persistent "
+                               "rollout was not resident); rollout buffer and normaliser statistics are invalid")
 
     def _collect_rollouts_stepped(self, env, callback, rollout_buffer, n_rollout_steps, cost_function, noise=None):
         """The reference's per-step loop, kept for everything the fused launch does not cover: a callable `cost_function`
@@ -345,6 +355,7 @@ class PPOLagrangian:
         st = ws["stats"].cpu().numpy()
         if st[11] != 0:
             raise RuntimeError("icrl_ppo_lag_train: inter-workgroup exchange timed out")
+        self.check_rollout_status()
         pol.adam_step = int(ws["t"].item())
         steps = max(int(st[1]), 1)
         if ev is not None:

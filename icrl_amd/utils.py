@@ -23,9 +23,7 @@ def make_train_env(env_id, save_dir, use_cost_wrapper, base_seed=0, num_threads=
                    normalize_cost=True, env_index_offset=0, device="cuda", **kwargs):
     """ref: icrl/utils.py:265-288.  SubprocVecEnv[num_threads] of gym envs -> one batched device env; env i is seeded
     base_seed + env_index_offset + i (the offset shards envs across GPUs)."""
-    env = HipSynthVecEnv.make(env_id, num_threads, base_seed, device)
-    env.seed(base_seed, env_index_offset)
-    env._index_offset = env_index_offset
+    env = HipSynthVecEnv.make(env_id, num_threads, base_seed, device, env_index_offset=env_index_offset)
     if use_cost_wrapper:
         env = VecCostWrapper(env)
     if normalize_reward and normalize_cost:

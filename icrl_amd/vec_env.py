@@ -144,20 +144,25 @@ class HipSynthVecEnv(VecEnv):
         self.raw_rew = torch.zeros(n_envs, dtype=torch.float64, device=dev)
         self.dones = torch.zeros(n_envs, dtype=torch.uint8, device=dev)
         self._actions = None
-        self.seed(seed, env_index_offset)
+        self._index_offset = int(env_index_offset)
+        self.seed(seed)
 
     @classmethod
-    def make(cls, env_id, n_envs, seed=0, device="cuda"):
+    def make(cls, env_id, n_envs, seed=0, device="cuda", env_index_offset=0):
         kind, wall, broken = ENV_IDS[env_id]
-        return cls(n_envs, kind, seed, 0, wall, broken, device)
+        return cls(n_envs, kind, seed, env_index_offset, wall, broken, device)
 
-    def seed(self, seed=None, env_index_offset=0):
-        """env i gets stream key seed + i (ref: icrl/utils.py:256-263, subproc_vec_env.py:115-118)."""
+    def seed(self, seed=None, env_index_offset=None):
+        """env i gets stream key seed + (global index of env i) (ref: icrl/utils.py:256-263, subproc_vec_env.py:115-118).  The
+        global index is i + the shard offset given at construction (rank * envs per rank on a multi-GPU run), so re-seeding
+        through the wrapper chain (PPOLagrangian._setup_model -> env.seed(seed)) keeps every rank on its own shard."""
         seed = 0 if seed is None else int(seed)
-        keys = (np.arange(self.num_envs, dtype=np.int64) + seed + env_index_offset) & 0xFFFFFFFF
+        if env_index_offset is not None:
+            self._index_offset = int(env_index_offset)
+        keys = (np.arange(self.num_envs, dtype=np.int64) + seed + self._index_offset) & 0xFFFFFFFF
         self.key.copy_(torch.as_tensor(keys.astype(np.uint32).view(np.int32), device=self.device))
         self.step_count.zero_(); self.t_ep.zero_(); self.s.zero_()
-        return [seed + i for i in range(self.num_envs)]
+        return [seed + self._index_offset + i for i in range(self.num_envs)]
 
     def struct(self):
         return EnvT(self.num_envs, self.obs_dim, self.act_dim, self.max_steps, self.reward_form, int(self.wall_terminate),

@@ -111,6 +111,8 @@ typedef struct {
   float* last_v_r;       /* [N] values of the last forward (GAE bootstrap, on_policy_algorithm.py:417) */
   float* last_v_c;       /* [N] */
   float* act_clipped;    /* [N,act] scratch: action handed to the env */
+  int* status;           /* [1] or NULL: the persistent rollout ORs bit 0 into it when an inter-workgroup exchange timed out
+                          * (a workgroup was not resident); the buffer contents are then invalid and the caller must raise */
 } icrl_agent_t;
 
 /* PPO-Lagrangian update hyper-parameters (stable_baselines3/ppo_lag/ppo_lag.py:67-103,177-196; Adam eps 1e-5 from
@@ -224,7 +226,8 @@ int icrl_vecnorm_step(const icrl_norm_t* nm, const double* raw_obs, const double
 
 /* OnPolicyWithCostAlgorithm.collect_rollouts (common/on_policy_algorithm.py:340-421) fused on the device: T steps of
  * {policy forward -> clip -> env step -> cost_function(previous raw obs, action) -> VecNormalizeWithCost -> buffer.add},
- * then the dual GAE.  noise: [T,N,act] standard normals.  2 launches per step + 1 for GAE, no host sync. */
+ * then the dual GAE.  noise: [T,N,act] standard normals.  ONE persistent launch for all T steps where the shape allows
+ * (see icrl_rollout_collect_ex), otherwise 2 launches per step; + 1 launch for GAE; no host sync. */
 int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const icrl_costnet_t* cn,
                          const icrl_buffer_t* buf, const icrl_agent_t* ag, const float* noise,
                          const float* action_low, const float* action_high,

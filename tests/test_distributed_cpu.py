@@ -40,8 +40,13 @@ def _worker(rank, world, port, out):
     prev = [D.moments_to_sums(rms.mean, rms.var, rms.count)]
     shard = rng.randn(25 + 10 * rank, 3) * (1 + rank) + rank
     rms.update(shard)                                    # this rank's own stream
-    D.allreduce_state([params, moments], [rms], prev, world)
-    out[rank] = (params.numpy().copy(), moments.numpy().copy(), rms.mean.copy(), rms.var.copy(), rms.count, shard)
+    import types
+    dual = types.SimpleNamespace(log_nu=np.float32(0.5 + rank), m=np.float32(0.1 * rank), v=np.float32(0.2), t=3)
+    pol = types.SimpleNamespace(adam_step=100 + 30 * rank)          # ranks early-stopped at different epochs
+    scal = D.Scalars(avg=[(dual, "log_nu"), (dual, "m"), (dual, "v")], counters=[(pol, "adam_step"), (dual, "t")])
+    D.allreduce_state([params, moments], [rms], prev, world, scalars=scal)
+    out[rank] = (params.numpy().copy(), moments.numpy().copy(), rms.mean.copy(), rms.var.copy(), rms.count, shard,
+                 (float(dual.log_nu), float(dual.m), float(dual.v), dual.t, pol.adam_step, type(dual.log_nu).__name__))
     dist.destroy_process_group()
 
 
@@ -50,8 +55,10 @@ def test_allreduce_state_world2():
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
-    p0, m0, mean0, var0, c0, sh0 = out[0]
-    p1, m1, mean1, var1, c1, sh1 = out[1]
+    p0, m0, mean0, var0, c0, sh0, d0 = out[0]
+    p1, m1, mean1, var1, c1, sh1, d1 = out[1]
+    # dual variable averaged (stays float32), step counters agreed on: round(mean)
+    assert d0 == d1 and d0[:3] == (1.0, float(np.float32(0.05)), float(np.float32(0.2))) and d0[3:] == (3, 115, "float32")
     assert np.allclose(p0, 1.5) and np.array_equal(p0, p1)                   # average of 1 and 2
     assert np.allclose(m0, np.arange(5) * 1.5) and np.array_equal(m0, m1)
     assert np.array_equal(mean0, mean1) and np.array_equal(var0, var1) and c0 == c1

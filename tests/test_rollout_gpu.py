@@ -173,46 +173,65 @@ def test_fused_rollout_vs_reference_golden(golden):
     assert agent.num_timesteps == N * T
 
 
-@pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("ant", 96, 40), ("ant", 32, 60)])      # ant 96: per-step launches; 32: persistent
+# ant 96 / hc 256 / antbroken 512: per-step launches (generic normaliser kernel); the others: persistent kernel.
+# hc 256 = the per-GPU shard of BASELINE configs[3] (2048 envs / 8), antbroken 512 = that of configs[4] (4096 envs / 8) with the
+# reference's committed AntBroken constraint net loaded through the (quirky) ConstraintNet.load and action[4:] zeroed.
+@pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("ant", 96, 40), ("ant", 32, 60), ("hc", 256, 40), ("antbroken", 512, 12)])
 def test_fused_rollout_vs_port(kind, N, T):
     """same comparison at HC / Ant shapes with freshly initialised nets; also crosses episode ends (hc T=300 < 1000: none,
     so the env is pre-stepped to t_ep = 900 first)."""
+    import os
     from icrl_amd.ppo_lag import PPOLagrangian
     torch.manual_seed(5)
-    od, ad = (18, 6) if kind == "hc" else (113, 8)
-    hid = [20] if kind == "hc" else [40, 40]
+    broken = kind == "antbroken"
+    ekind = "ant" if broken else kind
+    od, ad = (18, 6) if ekind == "hc" else (113, 8)
+    hid = [20] if ekind == "hc" else [40, 40]
     lo = -np.ones(ad, np.float32)
-    ocn = o_nets.CostNet(od, ad, hid, False, None, None, 20, lo, -lo)
     from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
     from icrl_amd.constraint_net import ConstraintNet
-    env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, kind, 7)))
-    cn = ConstraintNet(od, ad, hid, None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
-    cn.load_state_dict(ocn.state_dict())
+    env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, ekind, 7, broken=broken)))
+    if broken:
+        cn = ConstraintNet.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden/cn_antbroken.npz"))
+        assert cn.clip_obs is None and cn.action_low is None and list(cn.hidden_sizes) == [40, 40]
+        ocn = o_nets.CostNet(od, ad, hid, False, None, None, None, None, None)      # what the off-by-one load() leaves
+        ocn.load_state_dict(cn.state_dict())
+    else:
+        ocn = o_nets.CostNet(od, ad, hid, False, None, None, 20, lo, -lo)
+        cn = ConstraintNet(od, ad, hid, None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
+        cn.load_state_dict(ocn.state_dict())
     env.set_cost_function(cn.cost_function)
     agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=7)   # learn() re-seeds the env with the agent seed
-    stack = o_loop.make_stack(N, kind, 7); stack.cost_fn = ocn.cost_function
+    stack = o_loop.make_stack(N, ekind, 7, broken=broken); stack.cost_fn = ocn.cost_function
     port = o_loop.PortAgent(stack, n_steps=T, seed=7)
     port.policy.load_state_dict(agent.policy.state_dict())        # same seed gives the same init; make it explicit anyway
-    if kind == "hc":
-        stack.env.t_ep[:] = 900; env.unwrapped.t_ep.fill_(900)
+    near_end = {"hc": 1000 - T // 3, "antbroken": 500 - T // 3}.get(kind)      # cross an episode end inside the rollout
     rng = np.random.RandomState(2)
     noise = rng.randn(T, N, ad).astype(np.float32)
     agent._setup_learn(N * T)
-    if kind == "hc":
-        env.unwrapped.t_ep.fill_(900)
+    if near_end is not None:
+        env.unwrapped.t_ep.fill_(near_end)
     port.num_timesteps = 0
     port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
-    if kind == "hc":
-        stack.env.t_ep[:] = 900
+    if near_end is not None:
+        stack.env.t_ep[:] = near_end
     agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost", noise=torch.as_tensor(noise, device="cuda"))
+    agent.check_rollout_status()
     b = port.collect_rollouts(noise)
     rb = agent.rollout_buffer
-    if kind == "hc":
+    if near_end is not None:
         assert b.dones.sum() == N            # every env crossed an episode end
+    if broken:                               # ant.py:105-108 — the env ignores action[4:]; the buffer keeps what the policy drew
+        assert np.abs(rb.actions.cpu().numpy()[..., 4:]).max() > 0
     for k in ("observations", "orig_observations", "new_observations", "actions", "rewards", "costs", "orig_costs", "dones",
               "log_probs", "reward_values", "cost_values", "reward_advantages", "cost_advantages", "reward_returns", "cost_returns"):
         got, ref = getattr(rb, k).cpu().numpy().reshape(T, N, -1), getattr(b, k).reshape(T, N, -1)
         assert np.allclose(got, ref, rtol=5e-4, atol=5e-5), (k, np.abs(got - ref).max())
+    # float64 running moments over N x T samples (the samples themselves carry the fp32 action differences)
+    assert np.allclose(env.obs_rms.mean, stack.norm.obs_rms.mean, rtol=1e-5, atol=1e-6)
+    assert np.allclose(env.obs_rms.var, stack.norm.obs_rms.var, rtol=1e-5, atol=1e-8)
+    assert abs(env.ret_rms.var - stack.norm.ret_rms.var) <= 1e-5 * max(1.0, stack.norm.ret_rms.var)
+    assert env.obs_rms.count == stack.norm.obs_rms.count
 
 
 def _pair_of_agents(N, T, seed):
