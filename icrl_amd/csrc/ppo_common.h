@@ -73,6 +73,19 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 
 __device__ __forceinline__ f32x4 lds128(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// a value parked in the accumulation-register half of the (unified, 512-entry) register file: VALU instructions cannot name
+// those registers, so the value costs nothing of the 256 VALU-addressable ones while it is not in use.  Both directions are one
+// v_accvgpr move.  (The "a" constraint makes the register allocator keep the value in an AGPR between the two asm statements.)
+__device__ __forceinline__ void acc_put(float& slot, float v) { asm("v_accvgpr_write_b32 %0, %1" : "=a"(slot) : "v"(v)); }
+// in-place update of a loop-carried slot: the tied operand pins the value to ONE register across the loop (with a fresh "=a"
+// definition per iteration the allocator re-homes the slot and copies it back on the loop edge, one v_accvgpr_mov per value)
+__device__ __forceinline__ void acc_set(float& slot, float v) { asm("v_accvgpr_write_b32 %0, %1" : "+a"(slot) : "v"(v)); }
+__device__ __forceinline__ float acc_get(const float& slot) {
+  float v;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(slot));
+  return v;
+}
+
 // cursor into the stream of minibatch rows: epoch, position inside the epoch, position inside the minibatch
 struct Cursor {
   int e, p, m;

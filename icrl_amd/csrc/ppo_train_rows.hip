@@ -101,70 +101,109 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   // (element o = 4q + i, j = 16w + r); b1 / b2 entries 16w + r (replicated over q, lane q == 0 stores); wave 0: head bias r,
   // wave 1: log_std r.  The owner keeps the fp32 master value, both Adam moments and the accumulating gradient in registers;
   // LDS holds the operand copies every wave reads.
-  f32x4 wW1[NT1], mW1[NT1], vW1[NT1], gW1r[NT1], wW2[4], mW2[4], vW2[4], gW2r[4], wWh, mWh, vWh, gWhr;
+  // Register plan (one wave per SIMD): the fp32 MASTER weights live in LDS only (the operand copies ARE the master values; the
+  // owner lane re-reads its elements for the Adam step), both Adam moments live in the accumulation-register half of the
+  // register file and are touched only inside the Adam step (explicit v_accvgpr moves: 2 reads + 2 writes per element and
+  // step), the gradient accumulators are MFMA destinations.  This keeps ~90 long-lived values out of the 256 VALU-addressable
+  // registers, which the forward / backward phases need for operand pipelining.
+  constexpr int E_W2 = 4 * NT1, E_WH = E_W2 + 16, E_B1 = E_WH + 4, E_B2 = E_B1 + 1, E_EX = E_B2 + 1, NEL = E_EX + 1;
+  float mA[NEL], vA[NEL];                      // AGPR-resident (acc_put / acc_get)
+  f32x4 gW1r[NT1], gW2r[4], gWhr;
   const int jb = 16 * w + r;
-  float wb1, mb1, vb1, wb2, mb2, vb2, gb1r = 0.f, gb2r = 0.f;
-  float wex = 0.f, mex = 0.f, vex = 0.f, gex = 0.f;
+  float gb1r = 0.f, gb2r = 0.f, gex = 0.f;
   int ex_g = -1, ex_s = S::MISC + 63;          // "extra" vector entry: wave 0 head bias r, wave 1 log_std r (Gaussian policy)
   {
     const PolLayout& L = a.L;
     const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
     const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
     const int gbh = role == 0 ? L.ba : (role == 1 ? L.bv : L.bc);
-#pragma unroll
-    for (int c = 0; c < NT1; ++c)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 16 * w + 4 * q + i, k = 16 * c + r;
-        wW1[c][i] = k < O ? a.params[gW1 + j * O + k] : 0.f;
-        mW1[c][i] = k < O ? a.exp_avg[gW1 + j * O + k] : 0.f;
-        vW1[c][i] = k < O ? a.exp_avg_sq[gW1 + j * O + k] : 0.f;
-      }
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int j = 16 * w + 4 * q + i, k = 16 * c + r;
-        wW2[c][i] = a.params[gW2 + j * HD + k];
-        mW2[c][i] = a.exp_avg[gW2 + j * HD + k];
-        vW2[c][i] = a.exp_avg_sq[gW2 + j * HD + k];
-      }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int o = 4 * q + i, j = 16 * w + r;
-      wWh[i] = o < n_out ? a.params[gWh + o * HD + j] : 0.f;
-      mWh[i] = o < n_out ? a.exp_avg[gWh + o * HD + j] : 0.f;
-      vWh[i] = o < n_out ? a.exp_avg_sq[gWh + o * HD + j] : 0.f;
-    }
-    wb1 = a.params[gb1 + jb]; mb1 = a.exp_avg[gb1 + jb]; vb1 = a.exp_avg_sq[gb1 + jb];
-    wb2 = a.params[gb2 + jb]; mb2 = a.exp_avg[gb2 + jb]; vb2 = a.exp_avg_sq[gb2 + jb];
     if (w == 0 && r < n_out) { ex_g = gbh + r; ex_s = S::BH + r; }
     if (w == 1 && !DISC && role == 0 && r < A) { ex_g = L.log_std + r; ex_s = S::LS + r; }
-    if (ex_g >= 0) { wex = a.params[ex_g]; mex = a.exp_avg[ex_g]; vex = a.exp_avg_sq[ex_g]; }
   }
-  // operand copies: every owner stores its elements (also used after each Adam step)
-  auto store_weights = [&]() {
+  // operand copies (= master values): every owner lane stores / re-reads its own elements
+  auto store_w1 = [&](int c, const f32x4& v) {
 #pragma unroll
-    for (int c = 0; c < NT1; ++c)
+    for (int i = 0; i < 4; ++i) sm[S::W1 + (16 * w + 4 * q + i) * SX + 16 * c + r] = v[i];
+  };
+  auto load_own_w1 = [&](int c) -> f32x4 {
+    f32x4 v;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sm[S::W1 + (16 * w + 4 * q + i) * SX + 16 * c + r] = wW1[c][i];
+    for (int i = 0; i < 4; ++i) v[i] = sm[S::W1 + (16 * w + 4 * q + i) * SX + 16 * c + r];
+    return v;
+  };
+  auto store_w2 = [&](int c, const f32x4& v) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
+    for (int i = 0; i < 4; ++i) sm[S::W2 + (16 * w + 4 * q + i) * SH + 16 * c + r] = v[i];
+    if (S::W2TC) *reinterpret_cast<f32x4*>(sm + S::W2T + (16 * c + r) * SH + 16 * w + 4 * q) = v;
+  };
+  auto load_own_w2 = [&](int c) -> f32x4 {
+    if (S::W2TC) return lds128(sm + S::W2T + (16 * c + r) * SH + 16 * w + 4 * q);
+    f32x4 v;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) sm[S::W2 + (16 * w + 4 * q + i) * SH + 16 * c + r] = wW2[c][i];
-      if (S::W2TC) *reinterpret_cast<f32x4*>(sm + S::W2T + (16 * c + r) * SH + 16 * w + 4 * q) = wW2[c];
-    }
+    for (int i = 0; i < 4; ++i) v[i] = sm[S::W2 + (16 * w + 4 * q + i) * SH + 16 * c + r];
+    return v;
+  };
+  auto store_wh = [&](const f32x4& v) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) sm[S::WH + (4 * q + i) * SH + 16 * w + r] = wWh[i];
-    if (S::WHTC) *reinterpret_cast<f32x4*>(sm + S::WHT + (16 * w + r) * SA + 4 * q) = wWh;
-    if (q == 0) {
-      sm[S::B1 + jb] = wb1; sm[S::B2 + jb] = wb2;
-      sm[ex_s] = wex;                       // lanes without an extra entry hit a scratch word
-    }
+    for (int i = 0; i < 4; ++i) sm[S::WH + (4 * q + i) * SH + 16 * w + r] = v[i];
+    if (S::WHTC) *reinterpret_cast<f32x4*>(sm + S::WHT + (16 * w + r) * SA + 4 * q) = v;
+  };
+  auto load_own_wh = [&]() -> f32x4 {
+    if (S::WHTC) return lds128(sm + S::WHT + (16 * w + r) * SA + 4 * q);
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = sm[S::WH + (4 * q + i) * SH + 16 * w + r];
+    return v;
   };
   for (int i = tid; i < S::TOTAL; i += TH4) sm[i] = 0.f;
   __syncthreads();
-  store_weights();
+  {
+    const PolLayout& L = a.L;
+    const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
+    const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
+#pragma unroll
+    for (int c = 0; c < NT1; ++c) {
+      f32x4 pv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+        pv[i] = k < O ? a.params[gW1 + j * O + k] : 0.f;
+        acc_put(mA[4 * c + i], k < O ? a.exp_avg[gW1 + j * O + k] : 0.f);
+        acc_put(vA[4 * c + i], k < O ? a.exp_avg_sq[gW1 + j * O + k] : 0.f);
+      }
+      store_w1(c, pv);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      f32x4 pv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+        pv[i] = a.params[gW2 + j * HD + k];
+        acc_put(mA[E_W2 + 4 * c + i], a.exp_avg[gW2 + j * HD + k]);
+        acc_put(vA[E_W2 + 4 * c + i], a.exp_avg_sq[gW2 + j * HD + k]);
+      }
+      store_w2(c, pv);
+    }
+    {
+      f32x4 pv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = 4 * q + i, j = 16 * w + r;
+        pv[i] = o < n_out ? a.params[gWh + o * HD + j] : 0.f;
+        acc_put(mA[E_WH + i], o < n_out ? a.exp_avg[gWh + o * HD + j] : 0.f);
+        acc_put(vA[E_WH + i], o < n_out ? a.exp_avg_sq[gWh + o * HD + j] : 0.f);
+      }
+      store_wh(pv);
+    }
+    acc_put(mA[E_B1], a.exp_avg[gb1 + jb]); acc_put(vA[E_B1], a.exp_avg_sq[gb1 + jb]);
+    acc_put(mA[E_B2], a.exp_avg[gb2 + jb]); acc_put(vA[E_B2], a.exp_avg_sq[gb2 + jb]);
+    acc_put(mA[E_EX], ex_g >= 0 ? a.exp_avg[ex_g] : 0.f); acc_put(vA[E_EX], ex_g >= 0 ? a.exp_avg_sq[ex_g] : 0.f);
+    if (q == 0) {
+      sm[S::B1 + jb] = a.params[gb1 + jb]; sm[S::B2 + jb] = a.params[gb2 + jb];
+      sm[ex_s] = ex_g >= 0 ? a.params[ex_g] : 0.f;          // lanes without an extra entry hit a scratch word
+    }
+  }
 
   const int t0 = a.adam_t[0];
   const float w1 = (float)(1.0 - (double)a.hp.adam_beta1);
@@ -260,6 +299,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   };
   auto refresh_gauss = [&]() {   // wave 1, lanes q == 0 own log_std r: derived constants of the Gaussian head
     if (!DISC && role == 0 && w == 1 && q == 0) {
+      const float wex = sm[S::LS + r];
       const float sd = __expf(wex);
       const float iv = __builtin_amdgcn_rcpf(sd * sd);
       sm[S::GAU + r] = r < A ? iv : 0.f;
@@ -358,7 +398,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
           if (t < 3) { if (PF1) load_w1(t + 1, w1p[(t + 1) & 1], b1p[(t + 1) & 1]); }
           else load_w2(0, w2p[0], b2p[0]);
           __builtin_amdgcn_sched_barrier(0);
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 acc = b1p[t & 1];             // the bias is the accumulator's initial value (C input of the first MFMA)
 #pragma unroll
           for (int js = 0; js < NT1; ++js)
 #pragma unroll
@@ -366,7 +406,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
               if (js < NT1 - 1 || 16 * js + e < O)      // last k-block: components 16 js + 4 q + e all beyond obs -> nothing to add
                 acc = MFMA_F32(w1p[t & 1][js][e], bx[js][e], acc);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) h1c[t][i] = fast_tanh(acc[i] + b1p[t & 1][i]);
+          for (int i = 0; i < 4; ++i) h1c[t][i] = fast_tanh(acc[i]);
           if (!PF1 && t < 3) load_w1(t + 1, w1p[(t + 1) & 1], b1p[(t + 1) & 1]);
         }
       }
@@ -389,25 +429,25 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
             bhp = lds128(sm + S::BH + 4 * q);
           }
           __builtin_amdgcn_sched_barrier(0);
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          f32x4 acc = b2p[t & 1];
 #pragma unroll
           for (int js = 0; js < 4; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc = MFMA_F32(w2p[t & 1][js][e], h1c[js][e], acc);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) h2c[t][i] = fast_tanh(acc[i] + b2p[t & 1][i]);
+          for (int i = 0; i < 4; ++i) h2c[t][i] = fast_tanh(acc[i]);
         }
       }
       {  // head: outputs o = 4q + i of row b; four independent chains
         f32x4 acc[4];
 #pragma unroll
         for (int js = 0; js < 4; ++js) {
-          acc[js] = f32x4{0.f, 0.f, 0.f, 0.f};
+          acc[js] = js == 0 ? bhp : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[js] = MFMA_F32(whp[js][e], h2c[js][e], acc[js]);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) outc[i] = ((acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i])) + bhp[i];
+        for (int i = 0; i < 4; ++i) outc[i] = (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
       }
       // this wave's 16 columns of h1^T / h2^T (read by the weight-gradient GEMMs after the barrier)
       float* const pt = sm + (4 * q) * ST + b;
@@ -722,17 +762,6 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & 0xff;
     stats_partials(nb_next);
     xcur = xnext;
-    // the part of Adam that does not need the clip coefficient, done while the granules travel: m <- (1 - w1) m, v <- beta2 v
-    // (the update below then needs one FMA per moment: m + (coef w1) g,  v + (coef^2 w2) g^2)
-    {
-      const float omw1 = 1.f - w1, b2f_ = a.hp.adam_beta2;
-#pragma unroll
-      for (int c = 0; c < NT1; ++c) { mW1[c] *= omw1; vW1[c] *= b2f_; }
-#pragma unroll
-      for (int c = 0; c < 4; ++c) { mW2[c] *= omw1; vW2[c] *= b2f_; }
-      mWh *= omw1; vWh *= b2f_;
-      mb1 *= omw1; vb1 *= b2f_; mb2 *= omw1; vb2 *= b2f_; mex *= omw1; vex *= b2f_;
-    }
     if (tid < 12) {
       u64 v = 0;
       int spins = 0;
@@ -763,31 +792,44 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     read_stats(nb_next > 0 ? nb_next : 2);
 
     // ================= Adam (torch.optim.Adam, single-tensor form) on register-resident weights and moments =================
-    if (status == 0) {
+    {   // unconditional: after a timed-out exchange (status != 0) the launch ends with the status word set and the host raises
       const float step_size = ps.step_size, inv_bc2_sqrt = ps.inv_bc2_sqrt;
       const float epsf = a.hp.adam_eps;
+      const float omw1 = 1.f - w1, b2f_ = a.hp.adam_beta2;
       const float cw1 = coef * w1, c2w2 = (coef * coef) * w2;
-      auto adam = [&](float g, float& m, float& v, float& p) {   // m, v were pre-scaled by (1 - w1) and beta2 above
-        m = fmaf(cw1, g, m);
-        v = fmaf(c2w2, g * g, v);
-        const float denom = fmaf(__builtin_amdgcn_sqrtf(v), inv_bc2_sqrt, epsf);     // v_sqrt_f32 / v_rcp_f32: 1 ulp each
-        p = fmaf(-step_size, m * __builtin_amdgcn_rcpf(denom), p);
+      // four elements at a time, stage by stage (independent chains keep the transcendental unit and the FMA pipe busy; one
+      // wave per SIMD has nobody else to cover a dependent v_sqrt -> v_rcp chain)
+      auto adam4 = [&](const f32x4& g, float* mA4, float* vA4, f32x4& p) {
+        f32x4 m, v, d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m[i] = acc_get(mA4[i]); v[i] = acc_get(vA4[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m[i] = fmaf(cw1, g[i], omw1 * m[i]); v[i] = fmaf(c2w2, g[i] * g[i], b2f_ * v[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = fmaf(__builtin_amdgcn_sqrtf(v[i]), inv_bc2_sqrt, epsf);   // v_sqrt_f32 / v_rcp_f32: 1 ulp each
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = fmaf(-step_size, m[i] * __builtin_amdgcn_rcpf(d[i]), p[i]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { acc_set(mA4[i], m[i]); acc_set(vA4[i], v[i]); }
       };
       // pad elements (k >= obs, o >= n_out) have g = m = v = p = 0 and stay 0: no masks needed
 #pragma unroll
-      for (int c = 0; c < NT1; ++c)
+      for (int c = 0; c < NT1; ++c) { f32x4 p_ = load_own_w1(c); adam4(gW1r[c], mA + 4 * c, vA + 4 * c, p_); store_w1(c, p_); }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { float m_ = mW1[c][i], v_ = vW1[c][i], p_ = wW1[c][i]; adam(gW1r[c][i], m_, v_, p_); mW1[c][i] = m_; vW1[c][i] = v_; wW1[c][i] = p_; }
+      for (int c = 0; c < 4; ++c) { f32x4 p_ = load_own_w2(c); adam4(gW2r[c], mA + E_W2 + 4 * c, vA + E_W2 + 4 * c, p_); store_w2(c, p_); }
+      { f32x4 p_ = load_own_wh(); adam4(gWhr, mA + E_WH, vA + E_WH, p_); store_wh(p_); }
+      {   // b1 / b2 / extra entry: identical arithmetic in the four q lanes, lane q == 0 stores (elements E_B1, E_B2, E_EX are adjacent)
+        f32x4 g_ = f32x4{gb1r, gb2r, ex_g >= 0 ? gex : 0.f, 0.f}, p_ = f32x4{sm[S::B1 + jb], sm[S::B2 + jb], sm[ex_s], 0.f};
+        float m3[4], v3[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c)
+        for (int i = 0; i < 3; ++i) { m3[i] = mA[E_B1 + i]; v3[i] = vA[E_B1 + i]; }
+        acc_put(m3[3], 0.f); acc_put(v3[3], 0.f);
+        adam4(g_, m3, v3, p_);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { float m_ = mW2[c][i], v_ = vW2[c][i], p_ = wW2[c][i]; adam(gW2r[c][i], m_, v_, p_); mW2[c][i] = m_; vW2[c][i] = v_; wW2[c][i] = p_; }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { float m_ = mWh[i], v_ = vWh[i], p_ = wWh[i]; adam(gWhr[i], m_, v_, p_); mWh[i] = m_; vWh[i] = v_; wWh[i] = p_; }
-      adam(gb1r, mb1, vb1, wb1);          // identical arithmetic in the four q lanes, lane q == 0 stores
-      adam(gb2r, mb2, vb2, wb2);
-      adam(ex_g >= 0 ? gex : 0.f, mex, vex, wex);
-      store_weights();
+        for (int i = 0; i < 3; ++i) { mA[E_B1 + i] = m3[i]; vA[E_B1 + i] = v3[i]; }
+        if (q == 0) { sm[S::B1 + jb] = p_[0]; sm[S::B2 + jb] = p_[1]; sm[ex_s] = p_[2]; }
+      }
+      __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this lane's log_std store has landed before refresh_gauss re-reads it
       refresh_gauss();
     }
     lds_barrier();   // (B4) updated weights visible
@@ -804,31 +846,40 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   const PolLayout& L = a.L;
   const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
   const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
+  const int gbh = role == 0 ? L.ba : (role == 1 ? L.bv : L.bc);
+  (void)gbh;
 #pragma unroll
-  for (int c = 0; c < NT1; ++c)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
-      if (k < O) { a.params[gW1 + j * O + k] = wW1[c][i]; a.exp_avg[gW1 + j * O + k] = mW1[c][i]; a.exp_avg_sq[gW1 + j * O + k] = vW1[c][i]; }
-    }
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
+  for (int c = 0; c < NT1; ++c) {
+    const f32x4 pv = load_own_w1(c);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int j = 16 * w + 4 * q + i, k = 16 * c + r;
-      a.params[gW2 + j * HD + k] = wW2[c][i];
-      a.exp_avg[gW2 + j * HD + k] = mW2[c][i];
-      a.exp_avg_sq[gW2 + j * HD + k] = vW2[c][i];
+      if (k < O) { a.params[gW1 + j * O + k] = pv[i]; a.exp_avg[gW1 + j * O + k] = acc_get(mA[4 * c + i]); a.exp_avg_sq[gW1 + j * O + k] = acc_get(vA[4 * c + i]); }
     }
+  }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int o = 4 * q + i, j = 16 * w + r;
-    if (o < n_out) { a.params[gWh + o * HD + j] = wWh[i]; a.exp_avg[gWh + o * HD + j] = mWh[i]; a.exp_avg_sq[gWh + o * HD + j] = vWh[i]; }
+  for (int c = 0; c < 4; ++c) {
+    const f32x4 pv = load_own_w2(c);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * w + 4 * q + i, k = 16 * c + r;
+      a.params[gW2 + j * HD + k] = pv[i];
+      a.exp_avg[gW2 + j * HD + k] = acc_get(mA[E_W2 + 4 * c + i]);
+      a.exp_avg_sq[gW2 + j * HD + k] = acc_get(vA[E_W2 + 4 * c + i]);
+    }
+  }
+  {
+    const f32x4 pv = load_own_wh();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = 4 * q + i, j = 16 * w + r;
+      if (o < n_out) { a.params[gWh + o * HD + j] = pv[i]; a.exp_avg[gWh + o * HD + j] = acc_get(mA[E_WH + i]); a.exp_avg_sq[gWh + o * HD + j] = acc_get(vA[E_WH + i]); }
+    }
   }
   if (q == 0) {
-    a.params[gb1 + jb] = wb1; a.exp_avg[gb1 + jb] = mb1; a.exp_avg_sq[gb1 + jb] = vb1;
-    a.params[gb2 + jb] = wb2; a.exp_avg[gb2 + jb] = mb2; a.exp_avg_sq[gb2 + jb] = vb2;
-    if (ex_g >= 0) { a.params[ex_g] = wex; a.exp_avg[ex_g] = mex; a.exp_avg_sq[ex_g] = vex; }
+    a.params[gb1 + jb] = sm[S::B1 + jb]; a.exp_avg[gb1 + jb] = acc_get(mA[E_B1]); a.exp_avg_sq[gb1 + jb] = acc_get(vA[E_B1]);
+    a.params[gb2 + jb] = sm[S::B2 + jb]; a.exp_avg[gb2 + jb] = acc_get(mA[E_B2]); a.exp_avg_sq[gb2 + jb] = acc_get(vA[E_B2]);
+    if (ex_g >= 0) { a.params[ex_g] = sm[ex_s]; a.exp_avg[ex_g] = acc_get(mA[E_EX]); a.exp_avg_sq[ex_g] = acc_get(vA[E_EX]); }
   }
   if (tid == 0 && prof) {
     for (int k = 0; k < 7; ++k) {
