@@ -68,25 +68,33 @@ def gae_sweep_point(N=131072, T=2048, reps=20):
 
 
 def cpu_baseline():
-    """oracle CPU port on a bounded sample of the same workload (one PPO iteration with n_steps 1024 instead of 2048)."""
-    from oracle import loop as o_loop, nets as o_nets
-    n_envs, T = 64, 1024
-    # the reference's own measurement used 8 intra-op threads (BASELINE.md §2); more threads only slow these tiny GEMMs down
-    threads = min(8, os.cpu_count() or 1)
-    torch.set_num_threads(threads)
-    torch.manual_seed(0)
-    stack = o_loop.make_stack(n_envs, "hc", 0)
-    lo = -np.ones(6, np.float32)
-    cn = o_nets.CostNet(18, 6, [20], False, None, None, 20, lo, -lo)
-    stack.cost_fn = cn.cost_function
-    agent = o_loop.PortAgent(stack, n_steps=T, batch_size=64, n_epochs=10, target_kl=None, seed=0)
-    t0 = time.time()
-    agent.learn(n_envs * T)
-    dt = time.time() - t0
-    return dict(value=n_envs * T / dt, unit="env-steps/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"one PPO-Lagrangian iteration of the same workload with n_steps={T} instead of 2048 "
-                       f"(64 envs, batch 64, 10 epochs, no early stop: {n_envs * T} env steps, {10 * n_envs * T // 64} optimiser steps, "
-                       f"{dt:.1f} s); host {os.cpu_count()} logical cores, torch threads {torch.get_num_threads()}")
+    """oracle CPU port (`oracle.loop.icrl_port`, pinned bit-for-bit to the reference's own icrl() by tests/golden/g8) timed on
+    a BOUNDED sample of the same workload: one whole outer ICRL iteration of configs[1] — forward step (rollouts + PPO-Lagrangian
+    updates), 10 nominal + 10 evaluation episodes, constraint-net update, both KL metrics — with n_steps 256 instead of 2048.
+    The forward step's cost is proportional to n_steps (same work per env step and per minibatch), the rest does not depend on
+    it, so the full-size iteration time is 8 x t_forward + t_rest; value = 2 x 64 x 2048 env steps / that.  Run with the 8 torch
+    intra-op threads the reference's own measurement used, and with 1."""
+    from oracle import loop as o_loop
+    ex = np.load(os.path.join(ROOT, "tests/golden/expert_hc.npz"))
+    esd = {k[len("policy/"):]: ex[k] for k in ex.files if k.startswith("policy/")}
+    T, scale = 256, 8
+    cfg = dict(train_env_id="HCWithPos-v0", eval_env_id="HCWithPosTest-v0", num_threads=64, seed=0, n_steps=T, batch_size=64, n_epochs=10,
+               target_kl=0.01, cn_layers=(20,), cn_learning_rate=0.05, anneal_clr_by_factor=0.9, cn_reg_coeff=0.5,
+               per_step_importance_sampling=True, cn_target_kl_new_old=2.5, backward_iters=10, forward_timesteps=2 * 64 * T - 1,
+               n_iters=30, expert_rollouts=10)
+    res = {}
+    for threads in (min(8, os.cpu_count() or 1), 1):
+        torch.set_num_threads(threads)
+        m, steps, dt, _ = o_loop.icrl_port(cfg, ex["observations"][:5000], ex["actions"][:5000], esd, n_iters=1)
+        full = scale * m[0]["time/forward_s"] + m[0]["time/rest_s"]
+        res[threads] = (scale * steps / full, m[0]["time/forward_s"], m[0]["time/rest_s"], steps)
+    k = max(res)
+    return dict(value=res[k][0], unit="env-steps/s", cores=k, kind="port", value_1_thread=res[1][0],
+                sample=f"one whole outer ICRL iteration of the same workload with n_steps={T} instead of 2048 ({res[k][3]} env steps of "
+                       f"the forward step: {res[k][1]:.1f} s on {k} torch threads / {res[1][1]:.1f} s on 1; sampling + constraint-net update "
+                       f"+ evaluation + KL metrics: {res[k][2]:.1f} s / {res[1][2]:.1f} s), extrapolated to n_steps 2048 as 8 x forward + rest; "
+                       f"host {os.cpu_count()} logical cores.  In the build container the port's learn() step runs 1.46x the "
+                       f"reference's (BASELINE.md section 2: 1382 vs 944 env-steps/s)")
 
 
 def main():

@@ -2,9 +2,10 @@
 
 ref: icrl/cpg.py:24-212 (cpg), :214-343 (flag set).  The cost is the frozen ConstraintNet loaded through the reference's
 (positionally shifted) ConstraintNet.load, the ground-truth wall cost, or the null cost.  One long
-``model.learn(timesteps, cost_function="cost")``; the reference's periodic EvalCallback / CheckpointCallback /
-AdjustedRewardCallback (host-side, outside the timed path; icrl/cpg.py:160-198) are reduced to an evaluation + checkpoint
-every ``eval_every`` rollouts.
+``model.learn(timesteps, cost_function="cost")`` with the reference's callbacks (icrl/cpg.py:160-198): CheckpointCallback every
+``save_every`` calls, EvalCallback every ``eval_every`` calls (5 stochastic episodes on the cost-wrapped 1-env test stack,
+best model + env statistics saved), AdjustedRewardCallback after every rollout — icrl_amd/callbacks.py, counted in
+vectorised env steps like the reference.
 """
 import argparse
 import json
@@ -16,50 +17,33 @@ import types
 import numpy as np
 import torch
 
-from . import distributed as D, logger, utils
+from . import callbacks, distributed as D, logger, utils
 from .constraint_net import ConstraintNet
 from .ppo_lag import PPOLagrangian
 from .true_constraint_net import get_true_cost_function, null_cost
 from . import spaces
 
 
-class _PeriodicEval:
-    """stand-in for EvalCallback + CheckpointCallback + AdjustedRewardCallback (ref: icrl/cpg.py:160-186)."""
+class _History(callbacks.BaseCallback):
+    """one record per rollout of what the other callbacks logged (returned by cpg() for the tests / the caller)."""
 
-    def __init__(self, model_ref, eval_env, every, save_dir, true_cost, log):
-        self.model, self.eval_env, self.every, self.save_dir, self.true_cost, self.log = model_ref, eval_env, every, save_dir, true_cost, log
-        self.n_rollouts, self.best, self.history = 0, -np.inf, []
+    def __init__(self, log):
+        super().__init__()
+        self.log, self.history = log, []
 
-    def init_callback(self, model): self.model = model
-    def on_training_start(self, *a): pass
-    def on_rollout_start(self): pass
-    def update_locals(self, locals_): pass
-    def on_step(self): return True
-    def on_training_end(self): pass
-
-    def on_rollout_end(self):
-        self.n_rollouts += 1
-        rb = self.model.rollout_buffer
-        # adjusted reward: mean reward of the rollout with violating steps zeroed (ref: icrl/utils.py:542-568)
-        viol = (rb.new_orig_observations[..., 0] <= -3).float()
-        adjusted = float((rb.rewards * (1 - viol)).mean().item())
-        rec = {"rollouts": self.n_rollouts, "timesteps": self.model.num_timesteps, "adjusted_reward": adjusted,
-               "true_cost": float(viol.mean().item())}
-        if self.every and self.n_rollouts % self.every == 0:
-            from .vec_env import sync_envs_normalization
-            sync_envs_normalization(self.model.env, self.eval_env)
-            mean_r, std_r = utils.evaluate_policy(self.model, self.eval_env, n_eval_episodes=5, deterministic=False)
-            rec.update(eval_reward=mean_r, eval_reward_std=std_r)
-            if mean_r > self.best and self.save_dir:
-                self.best = mean_r
-                torch.save(self.model.policy.state_dict(), os.path.join(self.save_dir, "best_model_policy.pth"))
-                self.model.env.save(os.path.join(self.save_dir, "train_env_stats.pkl"))
+    def _on_rollout_end(self):
+        lg = logger.Logger.CURRENT.name_to_value
+        rec = {"rollouts": len(self.history) + 1, "timesteps": self.model.num_timesteps, "nu": float(self.model.dual.nu().item())}
+        for k in ("rollout/adjusted_reward", "eval/true_cost", "eval/mean_reward", "eval/best_mean_reward"):
+            if k in lg:
+                rec[k] = float(lg[k])
         self.history.append(rec)
         if self.log:
             self.log(json.dumps(rec))
 
 
 def cpg(config, log=print):
+    logger.configure()          # a fresh scalar log per run (the reference configures its logger in learn())
     rank = getattr(config, "rank", 0)
     dev = config.device if str(config.device).startswith("cuda") else "cuda"
     train_env = utils.make_train_env(env_id=config.train_env_id, save_dir=config.save_dir, use_cost_wrapper=True,
@@ -102,15 +86,24 @@ def cpg(config, log=print):
                         Ki=config.integral_control_coeff, Kd=config.derivative_control_coeff, pid_delay=config.pid_delay,
                         delta_p_ema_alpha=config.proportional_cost_ema_alpha, delta_d_ema_alpha=config.derivative_cost_ema_alpha),
         policy_kwargs=dict(net_arch=utils.get_net_arch(config)),
-        action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"))
-    cb = _PeriodicEval(model, eval_env, int(getattr(config, "eval_every_rollouts", 0)), config.save_dir,
-                       get_true_cost_function(config.eval_env_id), log if (config.verbose > 0 and rank == 0) else None)
+        action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"),
+        streams=getattr(config, "streams", None))
+    # ref: icrl/cpg.py:160-176
+    hist = _History(log if (config.verbose > 0 and rank == 0) else None)
+    eval_every = int(config.eval_every) if not getattr(config, "eval_every_rollouts", 0) else int(config.eval_every_rollouts) * int(config.n_steps)
+    cbs = [callbacks.EvalCallback(eval_env, eval_freq=eval_every, best_model_save_path=config.save_dir if rank == 0 else None,
+                                  deterministic=False, verbose=0,
+                                  callback_on_new_best=callbacks.SaveEnvStatsCallback(train_env, config.save_dir if rank == 0 else None)),
+           callbacks.AdjustedRewardCallback(get_true_cost_function(config.eval_env_id)), hist]
+    if config.save_dir and rank == 0:
+        cbs.insert(0, callbacks.CheckpointCallback(int(config.save_every), os.path.join(config.save_dir, "models"), verbose=0))
+    cb = callbacks.CallbackList(cbs)
     # ref: icrl/cpg.py:201-203 — `-cis None` hands the callable itself to learn() (costs evaluated outside the env chain)
     learn_cost = config.cost_info_str if config.cost_info_str is not None else cost_function
     model.learn(total_timesteps=int(config.timesteps), cost_function=learn_cost, callback=cb)
     if config.save_dir and rank == 0:
         torch.save(model.policy.state_dict(), os.path.join(config.save_dir, "final_model_policy.pth"))
-    return model, cb.history
+    return model, hist.history
 
 
 def build_parser():

@@ -88,7 +88,7 @@ class PIDLagrangian:
 
     def update_parameter(self, cost):
         cost = float(cost)
-        self.loss = _Scalar(cost)
+        self.loss = _Scalar(F32(cost))        # torch.tensor(cost): float32, kept for interface parity with DualVariable
         delta = cost - self.budget
         self.pid_i = max(0, self.pid_i + self.Ki * delta)
         self._delta_p = self.delta_p_ema_alpha * self._delta_p + (1 - self.delta_p_ema_alpha) * delta
@@ -98,4 +98,4 @@ class PIDLagrangian:
         self.cost_deltas.append(self._cost_delta)
 
     def nu(self):
-        return _Scalar(self.cost_penalty)
+        return _Scalar(F32(self.cost_penalty))      # the reference hands it out as torch.tensor(float): float32

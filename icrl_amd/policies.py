@@ -131,10 +131,15 @@ class ActorTwoCriticsPolicy:
         if not state:
             self.exp_avg.zero_(); self.exp_avg_sq.zero_(); self.adam_step = 0
             return
-        m = torch.cat([state[i]["exp_avg"].detach().float().reshape(-1) for i in range(len(self.shapes))])
-        v = torch.cat([state[i]["exp_avg_sq"].detach().float().reshape(-1) for i in range(len(self.shapes))])
+        # parameter order = param_groups[0]["params"]: 0..n-1 in current torch, the parameters' id()s in the torch 1.5 files the
+        # reference wrote (expert_data/*/files/best_model.zip); both follow policy.parameters() = state_dict order
+        keys = [k for g in osd.get("param_groups", []) for k in g["params"]] or sorted(state)
+        assert len(keys) == len(self.shapes), "optimizer state does not match the policy's parameter list"
+        m = torch.cat([state[k]["exp_avg"].detach().float().reshape(-1) for k in keys])
+        v = torch.cat([state[k]["exp_avg_sq"].detach().float().reshape(-1) for k in keys])
+        assert m.numel() == self.exp_avg.numel()
         self.exp_avg.copy_(m.to(self.device)); self.exp_avg_sq.copy_(v.to(self.device))
-        self.adam_step = int(float(state[0]["step"]))
+        self.adam_step = int(float(state[keys[0]]["step"]))
 
     @property
     def log_std(self):

@@ -28,6 +28,15 @@ def _const_fn(v):
     return v if callable(v) else (lambda _progress: v)
 
 
+class _SpacesOnlyEnv(VecEnv):
+    """what a loaded agent holds when no env was given (reference: env=None, prediction only)."""
+
+    def reset(self):
+        raise RuntimeError("this agent was loaded without an environment")
+
+    step_async = step_wait = reset
+
+
 class PPOLagrangian:
     def __init__(self, policy, env, algo_type="lagrangian", learning_rate=3e-4, n_steps=2048, batch_size=64, n_epochs=10,
                  reward_gamma=0.99, reward_gae_lambda=0.95, cost_gamma=0.99, cost_gae_lambda=0.95, clip_range=0.2,
@@ -170,6 +179,8 @@ class PPOLagrangian:
         self._last_original_obs = senv.s
         self._last_dones = self._ag["last_dones"]
         if callback is not None:
+            if hasattr(callback, "on_steps") and callback.on_steps(n_rollout_steps) is False:     # n_steps on_step() calls at once
+                return False
             callback.on_rollout_end()
         return True
 
@@ -280,7 +291,44 @@ class PPOLagrangian:
             z.writestr("_stable_baselines3_version", "0.9.0a0+icrl_amd")
         return path
 
-    def load_parameters(self, path):
+    @classmethod
+    def load(cls, path, env=None, device="auto", **kwargs):
+        """ref: common/base_class.py:564-645 + save_util.py:284-418 — rebuild an agent from an archive written by the reference
+        (`best_model.zip`) or by save().  As in the reference, `_setup_model()` runs AFTER the stored attributes are restored, so
+        the dual variable is re-created: a loaded agent's nu is back at penalty_initial_value.  `env` may be
+        None (prediction / evaluate_actions only).  Entries the reference stored as cloud-pickled objects are not un-pickled:
+        spaces are rebuilt from their printable fields, the schedules from `learning_rate` / `kwargs` (clip_range defaults to
+        0.2 unless passed)."""
+        import io, zipfile
+        from .utils import parse_sb3_data
+        with zipfile.ZipFile(str(path)) as z:
+            data = parse_sb3_data(z.read("data"))
+        if "observation_dim" in data and "observation_space" not in data:      # archive written by save() of this build
+            o, a = int(data["observation_dim"]), int(data["action_dim"])
+            data["observation_space"] = spaces.Box(-np.inf, np.inf, (o,), np.float64)
+            data["action_space"] = spaces.Discrete(a) if data.get("discrete") else spaces.Box(-1.0, 1.0, (a,), np.float32)
+        if "observation_space" not in data or "action_space" not in data:
+            raise KeyError("The observation_space and action_space were not given, can't verify new environments")
+        if env is not None:
+            if tuple(env.observation_space.shape) != tuple(data["observation_space"].shape):
+                raise ValueError(f"Observation spaces do not match: {env.observation_space.shape} != {data['observation_space'].shape}")
+        else:
+            env = _SpacesOnlyEnv(int(data.get("n_envs", 1)), data["observation_space"], data["action_space"])
+        model = cls("TwoCriticsMlpPolicy", env, device=device, _init_setup_model=False)
+        skip = {"policy_class", "observation_space", "action_space", "device", "policy_kwargs", "observation_dim", "action_dim",
+                "discrete", "policy_class_name", "adam_step", "n_envs"}
+        for k, v in data.items():
+            if k not in skip:
+                setattr(model, k, v)
+        for k in ("clip_range", "lr_schedule"):          # stored as pickled closures by the reference
+            if callable(getattr(model, k, None)) is False and not isinstance(getattr(model, k, None), (int, float)):
+                setattr(model, k, 0.2 if k == "clip_range" else None)
+        model.__dict__.update(kwargs)
+        model._setup_model()
+        model.load_parameters(path, dual=False)
+        return model
+
+    def load_parameters(self, path, dual=True):
         """restore policy weights (+ optimizer moments and dual variable when present) from an archive written by save() or by
         the reference (`best_model.zip`)."""
         import io, zipfile
@@ -290,7 +338,7 @@ class PPOLagrangian:
             self.policy.load_state_dict(rd("policy.pth"))
             if "policy.optimizer.pth" in names:
                 self.policy.load_optimizer_state_dict(rd("policy.optimizer.pth"))
-            if "pytorch_variables.pth" in names and hasattr(self.dual, "load_state_dict"):
+            if dual and "pytorch_variables.pth" in names and hasattr(self.dual, "load_state_dict"):
                 pv = rd("pytorch_variables.pth")
                 if isinstance(pv, dict) and pv:
                     self.dual.load_state_dict(pv)

@@ -174,6 +174,53 @@ def load_expert_data(expert_path, num_rollouts):
     return (np.concatenate(obs, axis=0), np.concatenate(acs, axis=0)), float(np.mean(rewards))
 
 
+class _RefObject:
+    """stand-in for an instance of a reference / gym class inside one of the reference's pickles: keeps the attribute dict."""
+
+    def __init__(self, *a, **k):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__.update(state if isinstance(state, dict) else {"state": state})
+
+
+class _RefUnpickler(pickle.Unpickler):
+    """reads pickles written by the reference (train_env_stats.pkl = a pickled VecNormalizeWithCost, vec_normalize.py:42-64)
+    without importing stable_baselines3 / gym: their classes become attribute bags, numpy / builtins load normally."""
+
+    SAFE = ("numpy", "builtins", "collections", "copyreg", "_codecs")
+
+    def find_class(self, module, name):
+        if module.split(".")[0] in self.SAFE:
+            return super().find_class(module, name)
+        return type(name, (_RefObject,), {"__module__": module})
+
+
+def load_reference_pickle(path):
+    with open(path, "rb") as f:
+        return _RefUnpickler(f).load()
+
+
+def parse_sb3_data(raw):
+    """the `data` JSON of a stable-baselines3 archive (save_util.py:72-176): plain values as they are; entries the reference
+    cloud-pickled keep their printable fields only (enough to rebuild Box / Discrete spaces: dtype, shape, low, high, n)."""
+    import json
+    d = json.loads(raw) if isinstance(raw, (bytes, str)) else raw
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict) and ":serialized:" in v:
+            t = v.get(":type:", "")
+            if "spaces.box.Box" in t:
+                shape = tuple(int(x) for x in (v["shape"] if isinstance(v["shape"], (list, tuple)) else str(v["shape"]).strip("[]()").replace(",", " ").split()))
+                num = lambda s_: np.array([float(x) for x in str(s_).strip("[]").replace(",", " ").split()], np.float64).reshape(shape)
+                out[k] = spaces.Box(num(v["low"]), num(v["high"]), shape, np.dtype(v["dtype"]).type)
+            elif "spaces.discrete.Discrete" in t:
+                out[k] = spaces.Discrete(int(v["n"]))
+            continue            # functions (lr_schedule, clip_range), buffers, the pickled dual variable: rebuilt by _setup_model
+        out[k] = v
+    return out
+
+
 def load_policy_state_dict(path):
     """policy.pth out of a stable-baselines3 agent zip (no gym needed), or the `policy/*` arrays of the .npz fixture."""
     if str(path).endswith(".npz"):

@@ -361,8 +361,19 @@ class VecNormalize(VecEnvWrapper):
 
     @classmethod
     def load(cls, load_path, venv):
-        with open(load_path, "rb") as f:
-            st = pickle.load(f)
+        """reads the statistics file written by save() or by the REFERENCE (a pickled VecNormalize[WithCost] object,
+        vec_normalize.py:42-64,159-181: its class instances are read as attribute bags, no stable_baselines3 / gym needed)."""
+        from .utils import load_reference_pickle
+        st = load_reference_pickle(load_path)
+        if not isinstance(st, dict):
+            ref = st.__dict__
+            rms = lambda r: (np.asarray(r.mean), np.asarray(r.var), float(r.count))
+            st = dict(obs_rms=rms(ref["obs_rms"]), ret_rms=rms(ref["ret_rms"]),
+                      cost_rms=rms(ref["cost_rms"]) if "cost_rms" in ref else (0.0, 1.0, 1e-4))
+            for k in ("clip_obs", "clip_reward", "clip_cost", "gamma", "cost_gamma", "epsilon", "training", "norm_obs", "norm_reward",
+                      "norm_cost", "cost_str"):
+                if k in ref:
+                    st[k] = ref[k]
         obj = cls(venv)
         for k in ("obs_rms", "ret_rms", "cost_rms"):
             getattr(obj, k).assign(*st.pop(k))

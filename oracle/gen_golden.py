@@ -141,6 +141,19 @@ def g2_cost_function():
         out.update({f"{name}/obs": obs, f"{name}/acs": acs, f"{name}/cost": cost,
                     f"{name}/select_dim": np.array(ref.select_dim), f"{name}/hidden": np.array(hid)})
         out.update(_sd_np(ref.network.state_dict(), f"{name}/w/"))
+    # --cn_normalize (constraint_net.py:275-299): observations standardised with the given mean / var (eps 1e-5) BEFORE clipping
+    th.manual_seed(3)
+    mean, var = rng.randn(18) * 2, rng.rand(18) * 4 + 0.05
+    kw = _cn_kwargs(18, 6, [20], None, None, initial_obs_mean=mean, initial_obs_var=var)
+    ref = ConstraintNet(**kw)
+    obs, acs = rng.randn(41, 18) * 12 + 1, rng.randn(41, 6) * 2
+    cost = ref.cost_function(obs, acs)
+    orc = o_nets.CostNet(18, 6, [20], False, None, None, 20, kw["action_low"], kw["action_high"])
+    orc.load_state_dict(ref.network.state_dict()); orc.obs_mean, orc.obs_var = mean, var
+    d = maxdiff(orc.cost_function(obs, acs), cost); assert d == 0.0, d
+    out.update({"hc_norm/obs": obs, "hc_norm/acs": acs, "hc_norm/cost": cost, "hc_norm/mean": mean, "hc_norm/var": var,
+                "hc_norm/select_dim": np.array(ref.select_dim), "hc_norm/hidden": np.array([20])})
+    out.update(_sd_np(ref.network.state_dict(), "hc_norm/w/"))
     # the committed transfer checkpoint through the reference's own (positionally shifted) load()
     path = f"{REF}/icrl/expert_data/ConstraintTransfer/ICRL/AntBroken/files/best_cn_model.pt"
     raw = th.load(path)
@@ -306,6 +319,30 @@ def g5_dual():
     save("g5_dual", **out)
 
 
+def g11_pid():
+    """PIDLagrangian (cpg --use_pid; dual_variable.py:60-122): 3 parameter sets x 200 costs."""
+    print("G11 PIDLagrangian trajectories")
+    from stable_baselines3.common.dual_variable import PIDLagrangian
+    rng = np.random.RandomState(12)
+    out = {}
+    sets = dict(default_cpg=dict(alpha=0.0, penalty_init=1.0, Kp=10, Ki=0.0001, Kd=0, pid_delay=1, delta_p_ema_alpha=0.5, delta_d_ema_alpha=0.5),
+                derivative=dict(alpha=0.02, penalty_init=0.1, Kp=1.0, Ki=0.01, Kd=5.0, pid_delay=10, delta_p_ema_alpha=0.95, delta_d_ema_alpha=0.9),
+                integral=dict(alpha=0.1, penalty_init=0.0, Kp=0.0, Ki=0.5, Kd=0.0, pid_delay=3, delta_p_ema_alpha=0.0, delta_d_ema_alpha=0.0))
+    for name, kw in sets.items():
+        costs = np.concatenate([rng.rand(50) * 0.3, np.zeros(40), np.linspace(0, 0.5, 60), rng.rand(50) * 0.05]).astype(np.float32)
+        ref, orc = PIDLagrangian(**kw), o_ppo.PID(**kw)
+        traj = []
+        for c in costs:
+            ref.update_parameter(c); orc.update(c)
+            assert ref.nu().item() == orc.nu().item() and ref.loss.item() == orc.loss.item()
+            traj.append([ref.nu().item(), ref.loss.item(), ref.pid_i, ref._delta_p, ref._cost_delta])
+        out[f"{name}/costs"], out[f"{name}/traj"] = costs, np.array(traj)
+        out[f"{name}/params"] = np.array([kw[k] for k in ("alpha", "penalty_init", "Kp", "Ki", "Kd", "pid_delay", "delta_p_ema_alpha", "delta_d_ema_alpha")])
+        print(f"  {name}: nu range [{np.min(np.array(traj)[:, 0]):.4g}, {np.max(np.array(traj)[:, 0]):.4g}]")
+    print("  oracle == reference bit-for-bit")
+    save("g11_pid", **out)
+
+
 def g6_constraint_net_train():
     print("G6 compute_is_weights + ConstraintNet.train")
     rng = np.random.RandomState(7)
@@ -356,8 +393,9 @@ def g7_constraint_net_minibatch():
     """ConstraintNet.train with cn_batch_size (constraint_net.py:181-206, get() :300-316): permutations recorded."""
     print("G7 ConstraintNet.train, minibatch mode")
     rng = np.random.RandomState(17)
+    np.random.seed(29)          # get() draws its permutations from the global generator (constraint_net.py:300-316)
     out = {}
-    cases = dict(mb_psis=(True, [60, 90, 50], 4, 10, 2.5, 32, False), mb_episode=(False, [80, 70, 30], 3, 10, 10, 48, False),
+    cases = dict(mb_psis=(True, [60, 90, 50], 4, -1, 200.0, 32, False), mb_episode=(False, [80, 70, 30], 3, 10, 10, 48, False),
                  mb_nois=(False, [100, 60], 3, -1, -1, 64, True), mb_gail=(False, [70, 80], 3, -1, -1, 40, "gail"))
     for name, (psis, lengths, iters, tk_on, tk_no, bs, mode) in cases.items():
         n_nom, n_exp = int(np.sum(lengths)), 170
@@ -721,6 +759,36 @@ def fixtures_expert():
     sd = th.load(io.BytesIO(z.read("policy.pth")))
     save("expert_ant", observations=np.concatenate(obs).astype(np.float32), actions=np.concatenate(acs).astype(np.float32),
          rewards=np.array(rews), lengths=np.array(lens), **{f"policy/{k}": v.numpy() for k, v in sd.items()})
+    # the AntWall -> AntBroken transfer checkpoint (configs[4]; README.md:78) re-packed as arrays for the tests that need the weights
+    raw = th.load(f"{REF}/icrl/expert_data/ConstraintTransfer/ICRL/AntBroken/files/best_cn_model.pt")
+    save("cn_antbroken", obs_dim=raw["obs_dim"], acs_dim=raw["acs_dim"], is_discrete=raw["is_discrete"],
+         hidden_sizes=np.array(raw["hidden_sizes"]), clip_obs=raw["clip_obs"],
+         **{f"cn_network/{k}": v.numpy() for k, v in raw["cn_network"].items()})
+    # artefacts exactly as the REFERENCE wrote them (bytes of its data files, not source): the on-disk formats the build must read
+    import shutil
+    art = os.path.join(OUT, "ref_artifacts"); os.makedirs(art, exist_ok=True)
+    for src, dst in ((f"{REF}/icrl/expert_data/HCWithPos-New/files/EXPERT/rollouts/0.pkl", "hc_expert_rollout_0.pkl"),
+                     (f"{REF}/icrl/expert_data/ConstraintTransfer/ICRL/AntBroken/files/best_cn_model.pt", "antbroken_best_cn_model.pt"),
+                     (f"{REF}/icrl/expert_data/HCWithPos-New/files/best_model.zip", "hc_best_model.zip"),
+                     (f"{REF}/icrl/expert_data/HCWithPos-New/files/train_env_stats.pkl", "hc_train_env_stats.pkl")):
+        shutil.copyfile(src, os.path.join(art, dst)); os.chmod(os.path.join(art, dst), 0o644)
+        print(f"  copied {dst} ({os.path.getsize(os.path.join(art, dst)) / 1024:.0f} KB)")
+    # what the reference itself reads out of them (expected values for the readers' tests)
+    from stable_baselines3.common.vec_env import VecNormalize as RefVecNormalize
+    agent = PPOLagrangian.load(os.path.join(art, "hc_best_model.zip"))
+    robs = np.random.RandomState(3).randn(7, 18)
+    with th.no_grad():
+        v_r, v_c, lp, ent = agent.policy.evaluate_actions(th.tensor(robs, dtype=th.float32), th.zeros(7, 6))
+    opt = agent.policy.optimizer.state_dict()
+    with open(os.path.join(art, "hc_train_env_stats.pkl"), "rb") as f:
+        vn = pickle.load(f)
+    save("ref_artifacts_expected", probe_obs=robs, v_r=v_r.numpy(), v_c=v_c.numpy(), log_prob=lp.numpy(), entropy=ent.numpy(),
+         nu=agent.dual.nu().item(), num_timesteps=agent.num_timesteps, n_updates=agent._n_updates, n_envs=agent.n_envs,
+         adam_step=float(opt["state"][0]["step"]), exp_avg_0=opt["state"][0]["exp_avg"].numpy(), exp_avg_sq_5=opt["state"][5]["exp_avg_sq"].numpy(),
+         lr=opt["param_groups"][0]["lr"], eps=opt["param_groups"][0]["eps"],
+         obs_rms_mean=vn.obs_rms.mean, obs_rms_var=vn.obs_rms.var, obs_rms_count=vn.obs_rms.count, ret_rms_var=vn.ret_rms.var,
+         cost_rms_var=getattr(vn, "cost_rms", vn.ret_rms).var, clip_obs=vn.clip_obs, norm_flags=np.array([vn.norm_obs, vn.norm_reward, getattr(vn, "norm_cost", False)]),
+         vn_class=np.array(type(vn).__name__))
     # LapGridWorld: the reference ships the expert agent but no rollouts (icrl/expert_data/LGW/files has no EXPERT/rollouts);
     # they are produced the way icrl/run_policy.py does — 20 sampled episodes of that agent — on the restated env.
     z = zipfile.ZipFile(f"{REF}/icrl/expert_data/LGW/files/best_model.zip")
@@ -736,8 +804,8 @@ def fixtures_expert():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11"]
     table = dict(g1=g1_gae, g2=g2_cost_function, g3=g3_vecnormalize, g4=g4_ppo_minibatch, g5=g5_dual,
-                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
+                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
     for w in which:
         table[w]()

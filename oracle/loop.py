@@ -22,7 +22,7 @@ from . import stats
 from .cn import cn_train
 from .gae import dual_gae
 from .nets import CostNet, TwoCriticPolicy
-from .ppo import Dual, ppo_lag_train
+from .ppo import Dual, PID, ppo_lag_train
 from .lap_grid import LapGridVecEnv
 from .synth_env import SynthVecEnv
 
@@ -82,7 +82,7 @@ class PortAgent:
                  reward_gamma=0.99, reward_gae_lambda=0.95, cost_gamma=0.99, cost_gae_lambda=0.95,
                  clip_range=0.2, ent_coef=0.0, reward_vf_coef=0.5, cost_vf_coef=0.5, max_grad_norm=0.5,
                  target_kl=None, penalty_initial_value=1.0, penalty_learning_rate=0.1, budget=0.0,
-                 hidden=(64, 64), seed=0, discrete=False):
+                 hidden=(64, 64), seed=0, discrete=False, pid_kwargs=None):
         self.stack = stack
         env = stack.env
         self.obs_dim, self.act_dim = env.obs_dim, env.act_dim
@@ -95,7 +95,8 @@ class PortAgent:
         random.seed(seed); np.random.seed(seed); th.manual_seed(seed)
         self.policy = TwoCriticPolicy(self.obs_dim, self.act_dim, hidden, discrete=discrete)
         self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)  # ref: policies.py:357-361
-        self.dual = Dual(budget, penalty_learning_rate, penalty_initial_value, None)
+        # ref: ppo_lag.py:147-160 — algo_type "lagrangian" | "pidlagrangian"
+        self.dual = PID(**pid_kwargs) if pid_kwargs is not None else Dual(budget, penalty_learning_rate, penalty_initial_value, None)
         self.discrete = discrete
         self.num_timesteps = 0
         self._n_updates = 0
@@ -336,7 +337,9 @@ def icrl_port(cfg, expert_obs, expert_acs, expert_policy_sd=None, n_iters=None, 
         raise NotImplementedError("warm-up with null_cost is exercised through PortAgent directly")
     for itr in range(n_iters):
         progress = 1 - float(itr) / float(c["n_iters"])
+        t_it = time.time()
         agent.learn(c["forward_timesteps"], streams=streams)
+        t_fwd = time.time() - t_it
         steps += agent.num_timesteps
         fwd = dict(agent.logs)
         sync_normalization(train.norm, sampling.norm)
@@ -369,6 +372,7 @@ def icrl_port(cfg, expert_obs, expert_acs, expert_policy_sd=None, n_iters=None, 
             m["true/reverse_kl"] = compute_kl(expert_policy, orig_obs, acts, agent.policy)
         m.update({k.replace("train/", "forward/"): v for k, v in fwd.items() if k.startswith("train/")})
         m.update(bw)
+        m["time/forward_s"], m["time/rest_s"] = t_fwd, time.time() - t_it - t_fwd      # wall clock (bench.py's cpu_baseline)
         out.append(m)
         if log:
             log(m)

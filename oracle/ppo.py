@@ -166,3 +166,32 @@ class Dual:
         self.loss.backward()
         self.opt.step()
         self.log_nu.data.clamp_(min=inv_softplus_floor(self.clamp_at))
+
+
+class PID:
+    """PID controller on the Lagrange multiplier (cpg --use_pid).  ref: dual_variable.py:60-122: integral term clipped at 0,
+    proportional term on an EMA of (cost - budget), derivative term max(0, EMA(cost) - EMA(cost) pid_delay updates ago);
+    nu() hands the penalty out as a float32 tensor."""
+
+    def __init__(self, alpha=0, penalty_init=1, Kp=0, Kd=0, Ki=1, pid_delay=10, delta_d_ema_alpha=0.95, delta_p_ema_alpha=0.95):
+        from collections import deque
+        self.budget, self.Kp, self.Ki, self.Kd = alpha, Kp, Ki, Kd
+        self.pid_i = self.cost_penalty = penalty_init
+        self.history = deque([0], maxlen=pid_delay)
+        self.delta_p = self.cost_ema = 0
+        self.a_d, self.a_p = delta_d_ema_alpha, delta_p_ema_alpha
+        self.loss = th.tensor(0.0)
+
+    def update(self, cost):
+        cost = float(cost)
+        self.loss = th.tensor(cost)
+        delta = cost - self.budget
+        self.pid_i = max(0, self.pid_i + self.Ki * delta)
+        self.delta_p = self.a_p * self.delta_p + (1 - self.a_p) * delta
+        self.cost_ema = self.a_d * self.cost_ema + (1 - self.a_d) * cost
+        pid_d = max(0, self.cost_ema - self.history[0])
+        self.cost_penalty = max(0, self.Kp * self.delta_p + self.Kd * pid_d + self.pid_i)
+        self.history.append(self.cost_ema)
+
+    def nu(self):
+        return th.tensor(self.cost_penalty)

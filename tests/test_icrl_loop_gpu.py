@@ -107,7 +107,8 @@ def test_cpg_transfer_short_run(tmp_path):
             "--save_dir", str(tmp_path), "--eval_every_rollouts", "2"]
     cfg = vars(build_parser().parse_args(argv)); cfg.update(rank=0, world_size=1)
     model, hist = cpg(types.SimpleNamespace(**cfg), log=None)
-    assert model.num_timesteps == 4096 and len(hist) == 2 and "eval_reward" in hist[-1]
+    assert model.num_timesteps == 4096 and len(hist) == 2 and "eval/mean_reward" in hist[-1] and "eval/mean_reward" not in hist[0]
+    assert np.isfinite(hist[-1]["rollout/adjusted_reward"]) and 0.0 <= hist[-1]["eval/true_cost"] <= 1.0
     assert model.env.venv.constraint_net().clip_obs is None          # the load() quirk is what transfer runs evaluate
     assert np.isfinite(model.dual.nu().item())
     from icrl_amd import logger
@@ -214,3 +215,50 @@ def test_agent_archive_round_trip(tmp_path):
     expert = utils.load_expert_agent(path)
     obs = torch.randn(5, 18, dtype=torch.float64, device="cuda"); acs = torch.rand(5, 6, device="cuda")
     assert torch.equal(expert.policy.evaluate_actions(obs, acs)[2], a.policy.evaluate_actions(obs, acs)[2])
+
+
+def test_cpg_pid_lagrangian_and_callback_cadence(tmp_path):
+    """cpg --use_pid (icrl/cpg.py:118-158, dual_variable.py:60-122) on HCWithPos shapes: the nu trajectory over 4 rollouts equals
+    the CPU port's (same noise / permutation streams; the controller itself is pinned by g11), and the reference's callbacks fire
+    at the reference's cadence, counted in VECTORISED env steps (callbacks.py:216-379, icrl/cpg.py:160-176): with n_steps = 64,
+    --eval_every 128 evaluates after rollouts 2 and 4, --save_every 96 checkpoints inside rollouts 2 and 3 at calls 96 and 192
+    (names carry call x n_envs timesteps), the adjusted reward is logged after every rollout."""
+    import os, types
+    from icrl_amd.cpg import build_parser, cpg
+    from oracle.streams import SeededStreams
+    here = os.path.dirname(os.path.abspath(__file__))
+    N, T = 4, 64
+    argv = ["cpg", "--cn_path", os.path.join(here, "golden/ref_artifacts/antbroken_best_cn_model.pt"), "-tei", "AntWallBroken-v0",
+            "-eei", "AntWallBrokenTest-v0", "-tk", "0.01", "--batch_size", "128", "--reward_gae_lambda", "0.9", "--n_epochs", "2",
+            "--learning_rate", "3e-5", "--clip_range", "0.4", "-t", str(4 * N * T), "-nt", str(N), "--n_steps", str(T), "-s", "6", "-v", "0",
+            "--use_pid", "-kp", "10", "-ki", "0.05", "-kd", "2", "-pidd", "2", "-b", "0.01", "--save_dir", str(tmp_path),
+            "--eval_every", "128", "--save_every", "96"]
+    cfg = vars(build_parser().parse_args(argv)); cfg.update(rank=0, world_size=1, streams=SeededStreams(31))
+    model, hist = cpg(types.SimpleNamespace(**cfg), log=None)
+    assert model.num_timesteps == 4 * N * T and len(hist) == 4
+    # ---- cadence
+    assert ["eval/mean_reward" in h for h in hist] == [False, True, True, True]      # (a logged value stays in the logger once written)
+    assert sorted(os.listdir(tmp_path / "models")) == [f"rl_model_{96 * N}_steps.zip", f"rl_model_{192 * N}_steps.zip"]
+    assert os.path.exists(tmp_path / "best_model.zip") and os.path.exists(tmp_path / "train_env_stats.pkl")
+    assert all(np.isfinite(h["rollout/adjusted_reward"]) and 0.0 <= h["eval/true_cost"] <= 1.0 for h in hist)
+    # ---- nu trajectory vs the CPU port
+    pid_kwargs = dict(alpha=0.01, penalty_init=1.0, Kp=10.0, Ki=0.05, Kd=2.0, pid_delay=2, delta_p_ema_alpha=0.5, delta_d_ema_alpha=0.5)
+    ocn = o_nets.CostNet(113, 8, [40, 40], False, None, None, None, None, None)
+    ocn.load_state_dict(model.env.venv.constraint_net().state_dict())
+    stack = o_loop.make_stack(N, "ant", 6, broken=True); stack.cost_fn = ocn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=T, batch_size=128, n_epochs=2, learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9,
+                            target_kl=0.01, seed=6, pid_kwargs=pid_kwargs)
+    nus = []
+    streams = SeededStreams(31)
+    port.num_timesteps = 0
+    port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
+    for it in range(4):
+        port.collect_rollouts(streams.rollout_noise(T, N, 8))
+        out = port.train(lambda e: streams.permutation(e, T * N))
+        streams.consumed(min(int(out["train/early_stop_epoch"]) + 1, 2))
+        nus.append(out["train/nu"])
+    # the history records nu when a rollout ends, i.e. BEFORE that rollout's update; train() then moves it
+    got = [h["nu"] for h in hist][1:] + [model.dual.nu().item()]
+    assert hist[0]["nu"] == 1.0 and np.allclose(got, nus, rtol=0, atol=1e-5), (got, nus)
+    assert len(set(np.round(nus, 6))) > 1                     # the controller moved the multiplier
+

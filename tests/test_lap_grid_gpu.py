@@ -15,6 +15,7 @@ import torch
 from oracle import loop as o_loop, nets as o_nets, ppo as o_ppo
 
 pytestmark = pytest.mark.gpu
+ADAM_DEV_BOUND = 5e-4      # 3 x the largest deviation measured on MI355X (1.7e-4 x lr x steps; absolute: <= 9e-8, ~1 ulp)
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
@@ -82,7 +83,9 @@ def test_learn_matches_reference_golden(golden):
     assert lg["train/early_stop_epoch"] == g["log/early_stop_epoch"].item()
     for k, v in agent.policy.state_dict().items():
         ref = g["w1/" + k]
-        assert np.allclose(v.numpy(), ref, rtol=1e-3, atol=0.02 * 3e-4 * 48 + 2e-6), (k, np.abs(v.numpy() - ref).max())
+        dev = float(np.abs(v.numpy() - ref).max())
+        print(f"ADAM_DEV lgw-golden {k}: {dev:.3g} = {dev / (3e-4 * 48):.3g} x lr x steps")
+        assert dev <= ADAM_DEV_BOUND * 3e-4 * 48 + 2e-7, (k, dev)
     assert abs(lg["train/nu"] - g["log/nu"].item()) < 1e-5
     assert abs(lg["train/entropy_loss"] - g["log/entropy_loss"].item()) < 1e-4
     assert abs(lg["train/policy_gradient_loss"] - g["log/policy_gradient_loss"].item()) < 2e-4
@@ -128,7 +131,9 @@ def test_categorical_update_vs_oracle(O, A, N, T, B, E, ent):
     n_steps = agent.policy.adam_step
     for k, v in agent.policy.state_dict().items():
         ref = op.params[k].detach().numpy()
-        assert np.allclose(v.numpy(), ref, rtol=1e-3, atol=0.02 * 3e-4 * n_steps + 2e-6), (k, np.abs(v.numpy() - ref).max())
+        dev = float(np.abs(v.numpy() - ref).max())
+        print(f"ADAM_DEV lgw-oracle {k}: {dev:.3g} = {dev / (3e-4 * n_steps):.3g} x lr x steps")
+        assert dev <= ADAM_DEV_BOUND * 3e-4 * n_steps + 2e-7, (k, dev)
     for key in ("train/policy_gradient_loss", "train/reward_value_loss", "train/cost_value_loss", "train/approx_kl",
                 "train/clip_fraction", "train/entropy_loss", "train/loss"):
         assert abs(lg[key] - out[key]) < 2e-4 + 2e-3 * abs(out[key]), (key, lg[key], out[key])

@@ -275,3 +275,48 @@ def test_g8_icrl_outer_loop_reference(golden):
         assert np.array_equal(objs["agent"].policy.params[k].detach().numpy(), v), k
     for k, v in _sub(g, "cn1/").items():
         assert np.array_equal(objs["cn"].params[k].detach().numpy(), v), k
+
+
+@pytest.mark.parametrize("case", ["default_cpg", "derivative", "integral"])
+def test_g11_pid_lagrangian(golden, case):
+    """PIDLagrangian (cpg --use_pid): the oracle restatement AND the product's host-side controller against the reference's
+    trajectories, bit for bit (pure float arithmetic in the same order)."""
+    from icrl_amd.dual_variable import PIDLagrangian
+    g = _sub(golden("g11_pid"), case + "/")
+    names = ("alpha", "penalty_init", "Kp", "Ki", "Kd", "pid_delay", "delta_p_ema_alpha", "delta_d_ema_alpha")
+    kw = {k: float(v) for k, v in zip(names, g["params"])}; kw["pid_delay"] = int(kw["pid_delay"])
+    orc, prod = o_ppo.PID(**kw), PIDLagrangian(**kw)
+    for c, (nu, loss, pid_i, dp, cd) in zip(g["costs"], g["traj"]):
+        orc.update(c); prod.update_parameter(c)
+        assert orc.nu().item() == nu and orc.loss.item() == loss
+        assert prod.nu().item() == nu and prod.loss.item() == loss
+        assert prod.pid_i == pid_i and prod._delta_p == dp and prod._cost_delta == cd
+
+
+def test_reference_written_files_host_readers(golden, tmp_path):
+    """files exactly as the REFERENCE wrote them (tests/golden/ref_artifacts): the expert-rollout pickle (icrl/icrl.py:25-43), the
+    `data` JSON of an agent archive (save_util.py:72-176) and the pickled VecNormalizeWithCost statistics
+    (vec_normalize.py:42-64) are read by the build's host code without stable_baselines3 / gym."""
+    import os, shutil, zipfile
+    from icrl_amd import utils
+    art = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden/ref_artifacts")
+    exp = golden("ref_artifacts_expected")
+    d = tmp_path / "HC" / "files" / "EXPERT" / "rollouts"
+    d.mkdir(parents=True)
+    for i in range(2):
+        shutil.copyfile(os.path.join(art, "hc_expert_rollout_0.pkl"), d / f"{i}.pkl")
+    (obs, acs), mean_reward = utils.load_expert_data(str(tmp_path / "HC"), 2)
+    hc = golden("expert_hc")
+    assert obs.shape == (1000, 18) and obs.dtype == np.float64 and acs.shape == (1000, 6) and acs.dtype == np.float32
+    assert np.array_equal(obs[:500].astype(np.float32), hc["observations"][:500]) and np.array_equal(acs[:500], hc["actions"][:500])
+    assert np.isfinite(mean_reward)
+    with zipfile.ZipFile(os.path.join(art, "hc_best_model.zip")) as z:
+        data = utils.parse_sb3_data(z.read("data"))
+    assert data["observation_space"].shape == (18,) and data["action_space"].shape == (6,)
+    assert np.all(data["action_space"].low == -1) and np.all(np.isinf(data["observation_space"].high))
+    assert data["num_timesteps"] == int(exp["num_timesteps"]) and data["_n_updates"] == int(exp["n_updates"]) and data["n_envs"] == int(exp["n_envs"])
+    assert data["target_kl"] == 0.01 and data["algo_type"] == "lagrangian" and "lr_schedule" not in data and "dual" not in data
+    vn = utils.load_reference_pickle(os.path.join(art, "hc_train_env_stats.pkl"))
+    assert type(vn).__name__ == str(exp["vn_class"])
+    assert np.array_equal(vn.obs_rms.mean, exp["obs_rms_mean"]) and np.array_equal(vn.obs_rms.var, exp["obs_rms_var"])
+    assert vn.obs_rms.count == float(exp["obs_rms_count"]) and vn.ret_rms.var == float(exp["ret_rms_var"]) and vn.clip_obs == float(exp["clip_obs"])

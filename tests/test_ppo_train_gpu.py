@@ -59,6 +59,9 @@ def test_three_steps_on_one_batch_golden(golden):
     assert agent.policy.adam_step == 3
 
 
+ADAM_DEV_BOUND = 5e-4      # 3 x the largest deviation measured on MI355X (1.7e-4 x lr x steps; absolute: <= 9e-8, ~1 ulp)
+
+
 def _oracle_train(agent_sd, buf, perms, kind, nu, **h):
     od, ad = (18, 6) if kind == "hc" else (113, 8)
     pol = o_nets.TwoCriticPolicy(od, ad)
@@ -97,10 +100,15 @@ def test_train_vs_oracle(kind, N, T, B, E, tk):
     lg = logger.Logger.CURRENT.name_to_value
     assert lg["train/early_stop_epoch"] == out["train/early_stop_epoch"]
     n_steps = agent.policy.adam_step
+    worst = 0.0
     for k, v in agent.policy.state_dict().items():
         ref = pol.params[k].detach().numpy()
-        # Adam's normalised step is ~lr per step: allow a small fraction of the total travel
-        assert np.allclose(v.numpy(), ref, rtol=1e-3, atol=0.02 * lr * n_steps + 2e-6), (k, np.abs(v.numpy() - ref).max())
+        worst = max(worst, float(np.abs(v.numpy() - ref).max()))
+    # measured on MI355X (printed below): after up to 48 dependent Adam steps no parameter is further than 9e-8 (about one
+    # float32 ulp) from the oracle's, at most 1.7e-4 of the distance a parameter can travel (lr per step).  The bound is 3x
+    # that plus one ulp; a wrong bias correction or moment update shifts every step by O(lr) and lands 3 orders above it.
+    print(f"ADAM_DEV {kind} B={B} steps={n_steps}: max |param - oracle| = {worst:.3g} = {worst / (lr * n_steps):.3g} x lr x steps")
+    assert worst <= ADAM_DEV_BOUND * lr * n_steps + 2e-7, (worst, worst / (lr * n_steps))
     for key in ("train/policy_gradient_loss", "train/reward_value_loss", "train/cost_value_loss", "train/approx_kl",
                 "train/clip_fraction", "train/entropy_loss", "train/loss"):
         assert abs(lg[key] - out[key]) < 2e-4 + 2e-3 * abs(out[key]), (key, lg[key], out[key])

@@ -1,0 +1,96 @@
+"""GPU: interop with files written by the REFERENCE itself (tests/golden/ref_artifacts: bytes of its committed data files; the
+expected values in ref_artifacts_expected.npz were read out of the same files by the reference's own loaders,
+oracle/gen_golden.py:fixtures_expert) — SURVEY.md §8 f-2."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ART = os.path.join(HERE, "golden/ref_artifacts")
+
+
+def _sub(g, prefix):
+    keys = g.files if hasattr(g, "files") else list(g)
+    return {k[len(prefix):]: g[k] for k in keys if k.startswith(prefix)}
+
+
+def test_constraint_net_load_reference_checkpoint(golden):
+    """ConstraintNet.load on the reference's best_cn_model.pt (constraint_net.py:323-402 incl. the positional off-by-one):
+    costs equal what the reference's own load() + cost_function produced (g2 `antbroken`)."""
+    from icrl_amd.constraint_net import ConstraintNet
+    g = _sub(golden("g2_cost_function"), "antbroken/")
+    cn = ConstraintNet.load(os.path.join(ART, "antbroken_best_cn_model.pt"))
+    assert cn.obs_dim == 113 and cn.acs_dim == 8 and list(cn.hidden_sizes) == [40, 40]
+    assert cn.clip_obs is None and cn.action_low is None and cn.action_high is None
+    assert np.allclose(cn.cost_function(g["obs"], g["acs"]), g["cost"], rtol=2e-5, atol=2e-6)
+    for k, v in cn.state_dict().items():
+        assert np.array_equal(v.numpy(), g["w/" + k]), k
+
+
+def test_agent_load_reference_archive(golden):
+    """PPOLagrangian.load on the reference's best_model.zip (base_class.py:564-645): weights, Adam state, counters; nu is back at
+    penalty_initial_value because _setup_model() re-creates the dual variable after the attributes are restored."""
+    from icrl_amd.ppo_lag import PPOLagrangian
+    exp = golden("ref_artifacts_expected")
+    path = os.path.join(ART, "hc_best_model.zip")
+    agent = PPOLagrangian.load(path)
+    assert agent.num_timesteps == int(exp["num_timesteps"]) and agent._n_updates == int(exp["n_updates"]) and agent.n_envs == int(exp["n_envs"])
+    assert agent.n_steps == 2048 and agent.batch_size == 64 and agent.target_kl == 0.01 and agent.seed == 27
+    assert abs(agent.dual.nu().item() - float(exp["nu"])) < 1e-7 and abs(float(exp["nu"]) - 1.0) < 1e-6
+    obs = torch.as_tensor(exp["probe_obs"], device="cuda")
+    v_r, v_c, lp, ent = agent.policy.evaluate_actions(obs, torch.zeros(7, 6, device="cuda"))
+    for got, key in ((v_r, "v_r"), (v_c, "v_c"), (lp, "log_prob"), (ent, "entropy")):
+        assert np.allclose(got.cpu().numpy().reshape(-1), exp[key].reshape(-1), rtol=2e-5, atol=2e-5), key
+    assert agent.policy.adam_step == int(exp["adam_step"])
+    osd = agent.policy.optimizer_state_dict(lr=float(exp["lr"]))
+    assert np.array_equal(osd["state"][0]["exp_avg"].numpy(), exp["exp_avg_0"])
+    assert np.array_equal(osd["state"][5]["exp_avg_sq"].numpy(), exp["exp_avg_sq_5"])
+    assert agent.policy.optimizer_kwargs.get("eps", None) == float(exp["eps"])
+    # load_parameters into an existing agent reads the same bytes
+    from icrl_amd import utils
+    env = utils.make_train_env("HCWithPos-v0", None, True, 0, 4, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    other = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=32, seed=1).load_parameters(path)
+    assert torch.equal(other.policy.params, agent.policy.params) and torch.equal(other.policy.exp_avg_sq, agent.policy.exp_avg_sq)
+    # and an env of the wrong shape is refused like check_for_correct_spaces does
+    ant = utils.make_train_env("AntWall-v0", None, True, 0, 2, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    with pytest.raises(ValueError):
+        PPOLagrangian.load(path, env=ant)
+
+
+def test_vecnormalize_load_reference_statistics(golden):
+    from icrl_amd import utils
+    from icrl_amd.vec_env import VecNormalizeWithCost
+    exp = golden("ref_artifacts_expected")
+    env = utils.make_train_env("HCWithPos-v0", None, True, 0, 4, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    vn = VecNormalizeWithCost.load(os.path.join(ART, "hc_train_env_stats.pkl"), env.venv)
+    assert np.array_equal(vn.obs_rms.mean, exp["obs_rms_mean"]) and np.array_equal(vn.obs_rms.var, exp["obs_rms_var"])
+    assert vn.obs_rms.count == float(exp["obs_rms_count"]) and vn.ret_rms.var == float(exp["ret_rms_var"])
+    assert vn.clip_obs == float(exp["clip_obs"]) and [bool(vn.norm_obs), bool(vn.norm_reward)] == [bool(x) for x in exp["norm_flags"][:2]]
+    o = vn.normalize_obs(np.zeros((1, 18)))
+    want = np.clip((0 - exp["obs_rms_mean"]) / np.sqrt(exp["obs_rms_var"] + 1e-8), -vn.clip_obs, vn.clip_obs)
+    assert np.allclose(o.cpu().numpy()[0], want, rtol=1e-12, atol=1e-12)
+
+
+def test_compute_kl_vs_oracle(golden):
+    """utils.compute_kl (icrl/utils.py:421-437, element [1] of evaluate_actions = the cost value: see the docstring) on the
+    reference's HC expert data, nominal agent = fresh policy, expert agent = the reference's best_model policy."""
+    from icrl_amd import utils
+    from icrl_amd.ppo_lag import PPOLagrangian
+    from oracle import loop as o_loop, nets as o_nets
+    ex = golden("expert_hc")
+    env = utils.make_train_env("HCWithPos-v0", None, True, 0, 4, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=32, seed=3)
+    expert = utils.load_expert_agent(os.path.join(HERE, "golden/expert_hc.npz"))
+    op, oe = o_nets.TwoCriticPolicy(18, 6), o_nets.TwoCriticPolicy(18, 6)
+    op.load_state_dict(agent.policy.state_dict()); oe.load_state_dict(_sub(ex, "policy/"))
+    obs, acs = ex["observations"][:2000], ex["actions"][:2000]
+    d_obs, d_acs = torch.as_tensor(obs, device="cuda"), torch.as_tensor(acs, device="cuda")
+    fwd, rev = utils.compute_kl(agent, d_obs, d_acs, expert), utils.compute_kl(expert, d_obs, d_acs, agent)
+    o_fwd, o_rev = o_loop.compute_kl(op, obs, acs, oe), o_loop.compute_kl(oe, obs, acs, op)
+    assert abs(fwd - o_fwd) < 1e-4 * max(1.0, abs(o_fwd)) and abs(rev - o_rev) < 1e-4 * max(1.0, abs(o_rev))
+    assert abs(fwd + rev) < 1e-4 * max(1.0, abs(o_fwd))               # the two are negatives of each other by construction
+    one = utils.compute_kl(agent, d_obs, d_acs)
+    assert abs(one - o_loop.compute_kl(op, obs, acs)) < 1e-4 * max(1.0, abs(one))

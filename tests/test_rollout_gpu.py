@@ -35,7 +35,7 @@ def test_synth_env_bit_exact(kind, wall, broken):
         assert cpu.step_count.max() > 0
 
 
-@pytest.mark.parametrize("case", ["hc", "ant", "lgw", "antbroken"])
+@pytest.mark.parametrize("case", ["hc", "ant", "lgw", "antbroken", "hc_norm"])
 def test_cost_function_golden(golden, case):
     from icrl_amd.constraint_net import ConstraintNet
     g = _sub(golden("g2_cost_function"), case + "/")
@@ -44,6 +44,8 @@ def test_cost_function_golden(golden, case):
     kw = dict(clip_obs=20, action_low=None if disc else -np.ones(ad, np.float32), action_high=None if disc else np.ones(ad, np.float32))
     if case == "antbroken":
         kw = dict(clip_obs=None, action_low=None, action_high=None)
+    if case == "hc_norm":        # --cn_normalize: (obs - mean) / sqrt(var + 1e-5) before the clip (constraint_net.py:275-283)
+        kw.update(initial_obs_mean=g["mean"], initial_obs_var=g["var"])
     cn = ConstraintNet(od, ad, list(g["hidden"]), None, lambda x: 0.05, None, None, disc, **kw)
     assert cn.select_dim == list(g["select_dim"])
     cn.load_state_dict({k[2:]: g[k] for k in g if k.startswith("w/")})
