@@ -91,8 +91,10 @@ struct Cursor {
   int e, p, m;
 };
 
-// ppo_train_rows.hip: row-owning-wave kernel (nt1 = ceil(obs / 16) <= 8)
+// ppo_train_rows.hip: row-owning-wave kernel (nt1 = ceil(obs / 16) <= 8), one wave per SIMD
 int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, hipStream_t s);
+// ppo_train_pairs.hip: wave-pair kernel, two waves per SIMD (nt1 rounded up to an even tile count)
+int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s);
 
 
 }  // namespace icrl

@@ -920,29 +920,32 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
   a.t_magic = buf->T == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned long long)buf->T);
   a.plan_steps = nullptr; a.plan_chunks = nullptr; a.n_steps = 0;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(sync_ws, 0, 256, s);
+  hipError_t e = hipMemsetAsync(sync_ws, 0, 512, s);      // granule slots: 2 step parities x (3 roles x 8 waves, padded to 32) x 8 B
   if (e != hipSuccess) return (int)e;
   e = hipMemsetAsync(stats, 0, (32 + hp->n_epochs) * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   const int nt1 = (pol->obs_dim + 15) / 16;
-  // row-owning waves (3 barriers per step; 5 when obs > 64); hp._pad & 2 forces the column-split tiles kernel
+  // default: wave pairs (two waves per SIMD, 6 barriers per step); hp._pad & 4: row-owning waves (one wave per SIMD, 3 barriers
+  // per step; 5 when obs > 64); hp._pad & 2: the column-split tiles kernel
   if (nt1 <= 8 && !(hp->_pad & 2)) {
     const int n_total = buf->T * buf->N;
     const int n_mb = (n_total + hp->batch_size - 1) / hp->batch_size;
     const long long n_steps = (long long)hp->n_epochs * n_mb;
     if (n_steps >= (1ll << 21)) return (int)hipErrorInvalidValue;      // epoch index lives in the upper bits of nb_flags
-    PlanStep* steps = reinterpret_cast<PlanStep*>((char*)sync_ws + 256);
+    PlanStep* steps = reinterpret_cast<PlanStep*>((char*)sync_ws + 512);
     PlanChunk* chunks = reinterpret_cast<PlanChunk*>(steps + n_steps + 2);
     a.plan_steps = steps; a.plan_chunks = chunks; a.n_steps = (int)n_steps;
     {
-      int* offs = reinterpret_cast<int*>((char*)sync_ws + 512 + 32 * (size_t)n_steps);       // after the plan tables
+      int* offs = reinterpret_cast<int*>((char*)sync_ws + 768 + 32 * (size_t)n_steps);       // after the plan tables
       const long long n = (long long)hp->n_epochs * n_total;
       hipLaunchKernelGGL(ppo_perm_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perms, n, buf->T, buf->N, offs);
       a.perms = offs;
     }
     hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
                        n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks);
-    return launch_train_rows(a, nt1, pol->discrete != 0, s);
+    // obs <= 64: wave pairs; wider (AntWall 113: dz1^T must share h2^T's LDS, two chunks per minibatch) the row-owning waves
+    if ((hp->_pad & 4) || nt1 > 4) return launch_train_rows(a, nt1, pol->discrete != 0, s);
+    return launch_train_pairs(a, nt1, pol->discrete != 0, s);
   }
   if (pol->discrete) {
     if (buf->act_store != 1) return (int)hipErrorInvalidValue;

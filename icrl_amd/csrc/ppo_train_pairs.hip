@@ -1,0 +1,969 @@
+// PPO-Lagrangian update, wave-PAIR variant (obs_dim <= 128) — gfx950.
+//
+// ref: stable_baselines3/ppo_lag/ppo_lag.py:196-299, common/buffers.py:594-627, common/policies.py:752-767,
+//      common/distributions.py:143-171,274-288, torch.optim.Adam, clip_grad_norm_  (same contract as ppo_train_rows.hip).
+//
+// Same launch shape (3 persistent workgroups = pi | vf | cvf), exchange protocol, LDS images and transposed-GEMM trick as
+// ppo_train_rows.hip, but EIGHT waves per workgroup = two per SIMD.  Why: the fp32 MFMA (v_mfma_f32_16x16x4_f32) executes on
+// the SIMD's fp32 FMA lanes, so a wave's own VALU work never hides under its MFMAs, and a single wave per SIMD issues a VALU
+// instruction only every 4 cycles (the SIMD takes one every 2): with one wave per SIMD a step is
+// MFMA time + VALU time + every LDS / transcendental latency, fully exposed.  Here the two waves of a SIMD split the work of
+// one 16-row tile so that
+//   * the MFMA pipe sees the same ~300 instructions per step (no redundant GEMM work),
+//   * everything else (tanh, loss tails, stores, Adam, operand fetches) is halved per wave and the two halves issue in
+//     alternate cycles, and one wave's LDS / MFMA-result latency is covered by the other's instructions,
+//   * each wave needs half the registers (<= 256, the limit at two waves per SIMD): no accumulation-register shuffling.
+//
+// Wave w = (rt = w % 4, fh = w / 4); waves (rt, 0) and (rt, 1) sit on the same SIMD and own minibatch rows 16 rt .. 16 rt + 15.
+//   forward / activation backward: wave (rt, fh) computes the feature tiles t in {2 fh, 2 fh + 1} of every layer for its rows;
+//     the partner's half of h1 / dz2 (the K dimension of the next GEMM) is read back from the [feature][row] images both
+//     waves store anyway for the weight-gradient GEMMs; the 16-output head is split over K instead (8 MFMAs each, partial
+//     tiles exchanged through LDS) and both waves then evaluate the loss tail on the full head output;
+//   weight gradients (K = all 64 rows): wave (jt = rt, kh = fh) forms rows 16 jt.. of dW2 for the column tiles {2 kh, 2 kh + 1},
+//     of dW1 for its half of the observation tiles, and (kh = 0) columns 16 jt.. of dWh; it owns exactly those elements'
+//     Adam state.
+//   3 pair hand-offs (h1 | head partials | dz2) and 3 workgroup barriers (dz1 | norm + staging | weights) per optimiser step.
+//
+// Built with -ffp-contract=off; FMA is used only where written (fmaf / MFMA).
+#include "ppo_common.h"
+
+namespace icrl {
+
+constexpr int TH8 = 512;   // 8 waves, two per SIMD (<= 256 registers each)
+constexpr int ST = 72;     // row stride of the [feature][row] matrices (64 rows + 8: conflict-free ds_read_b128)
+constexpr int SA = 24;     // row stride of the per-row action block and of the transposed head weights
+
+template <int NT1>
+struct SmemP {  // offsets in floats (multiples of 4); same images as SmemR in ppo_train_rows.hip
+  static constexpr int O16 = 16 * NT1, SX = O16 + 8;
+  static constexpr bool XDB = NT1 <= 2;        // second X buffer (next minibatch staged while dW1 still reads this one)
+  static constexpr bool W2TC = NT1 <= 2;       // transposed copy of W2 (ds_read_b128 operand fetch in the backward); LDS budget
+  static constexpr bool WHTC = NT1 <= 4;       // transposed copy of the head weights
+  static constexpr bool DZ1A = NT1 > 4;        // dz1^T shares h2^T's storage (written after dWh has read h2^T): LDS budget
+  static constexpr int W1 = 0;                 // [64][SX]
+  static constexpr int W2 = W1 + HD * SX;      // [64][SH]
+  static constexpr int W2T = W2 + HD * SH;     // [64][SH]  W2T[k][j] = W2[j][k]
+  static constexpr int WH = W2T + (W2TC ? HD * SH : 0);   // [16][SH]
+  static constexpr int WHT = WH + 16 * SH;     // [64][SA]  WHT[j][o] = WH[o][j]
+  static constexpr int B1 = WHT + (WHTC ? HD * SA : 0);
+  static constexpr int B2 = B1 + HD;
+  static constexpr int BH = B2 + HD;
+  static constexpr int LS = BH + 16;
+  static constexpr int GAU = LS + 16;          // [3][16] per-action 1/var, 0.5/var, log(sd) + log(sqrt(2 pi))
+  static constexpr int XT0 = GAU + 48;         // [16 NT1][ST] x^T of the chunk: XT[k][row]
+  static constexpr int XT1 = XDB ? XT0 + O16 * ST : XT0;
+  static constexpr int H1T = XT1 + O16 * ST;   // [64][ST] h1^T
+  static constexpr int H2T = H1T + HD * ST;
+  static constexpr int DZ1T = DZ1A ? H2T : H2T + HD * ST;
+  static constexpr int DZ2T = H2T + (DZ1A ? 1 : 2) * HD * ST;
+  static constexpr int DOT = DZ2T + HD * ST;   // [16][ST] d loss / d head output, transposed
+  static constexpr int ACT = DOT + 16 * ST;    // [64][SA] actions of the chunk's rows
+  static constexpr int OLP = ACT + RB * SA;    // [64] old log-prob | old value
+  static constexpr int ADR = OLP + RB;         // [64] raw reward advantage | return
+  static constexpr int ADC = ADR + RB;         // [64] raw cost advantage
+  static constexpr int PST = ADC + RB;         // [4][8] per-row-tile loss statistics
+  static constexpr int PLS = PST + 32;         // [4][16] per-row-tile d log_std partial sums
+  static constexpr int MISC = PLS + 64;        // [64] granule values, flags, advantage-statistics partials
+  static constexpr int TOTAL = MISC + 64;
+  // head partial tiles of a pair (2 x [64 lanes] x f32x4) live in the pair's own 16 columns of the dz1^T image (rows 0..31):
+  // that image is written by the same pair only after both waves have read the partials (behind the pair's dz2 hand-off).
+  static constexpr int HPX = DZ1T;
+};
+
+// -DICRL_FINE_PROF (tools only, never the shipped build): 20 finer phase timers of the policy workgroup instead of the 7 coarse ones
+#ifdef ICRL_FINE_PROF
+#undef STAMP
+#define STAMP(slot)
+#define FSTAMP(k)                                                          \
+  if (prof) {                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    const unsigned long long now_ = stamp();                               \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    fph[k] += now_ - t_last;                                               \
+    t_last = now_;                                                         \
+  }
+#else
+#define FSTAMP(k)
+#endif
+
+#define KARGS() ([]() { const TrainArgs* k_ = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(k_)); return k_; }())
+
+template <int NT1, bool DISC>
+__global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
+  using S = SmemP<NT1>;
+  constexpr int SX = S::SX;
+  constexpr int NW1 = NT1 / 2;          // observation column tiles of dW1 per wave
+  constexpr int XR = (S::O16 + 7) / 8;  // floats of an X row each of the 8 threads of a row stages
+  static_assert(NT1 % 2 == 0, "the two waves of a pair split the observation tiles");
+  static_assert(!S::DZ1A, "wide observations (dz1^T sharing h2^T's storage) stay on the row-owning kernel");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int role = blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Which two waves form a pair, and how they hand data to each other, is a speed choice only (nothing depends on the
+  // placement).  Measured on MI355X, HC shapes, us per optimiser step (the row-owning kernel: 10.5):
+  //   partners w, w + 4 (a workgroup's waves go to the SIMDs round-robin: the partners SHARE a SIMD), LDS flags   9.6
+  //   partners w, w + 4, workgroup barriers instead of flags                                                       9.9
+  //   partners w, w ^ 1 (different SIMDs), workgroup barriers 10.6; flags 10.4
+#ifndef ICRL_PAIR_ADJ
+#define ICRL_PAIR_ADJ 0
+#endif
+#ifndef ICRL_PAIR_FLAGS
+#define ICRL_PAIR_FLAGS 1
+#endif
+#if ICRL_PAIR_ADJ
+  const int rt = w >> 1, fh = w & 1;       // row tile, feature half (= jt, kh in the weight-gradient phase)
+  constexpr int LS_WAVE = 2;               // the low wave (fh == 0) that owns log_std (wave 0 owns the head bias)
+  const int partner = w ^ 1;
+#else
+  const int rt = w & 3, fh = w >> 2;
+  constexpr int LS_WAVE = 1;
+  const int partner = w ^ 4;
+#endif
+  const int r = lane & 15, q = lane >> 4;
+  const int O = a.L.O, A = a.L.A;
+  const int n_out = role == 0 ? A : 1;
+  const int T = a.buf.T, N = a.buf.N;
+  const float nu = a.nu[0];
+  const int n_steps = a.n_steps;
+  const PlanStep* __restrict__ const plan_steps = a.plan_steps;
+  const PlanChunk* __restrict__ const plan_chunks = a.plan_chunks;
+  const int* __restrict__ const perms = a.perms;
+  const float* const p_s0 = role == 0 ? a.buf.log_probs : (role == 1 ? a.buf.reward_values : a.buf.cost_values);
+  const float* const p_s1 = role == 0 ? a.buf.reward_advantages : (role == 1 ? a.buf.reward_returns : a.buf.cost_returns);
+  const float* const p_s2 = a.buf.cost_advantages;
+  const float* const p_obs = a.buf.observations;
+  const float* const p_act = a.buf.actions;
+  const int AS = a.buf.act_store;
+
+  // ---- Adam ownership of wave (jt = rt, kh = fh): element (row j = 16 jt + 4 q + i, column k = 16 c + r) of
+  //   W2 for c in {2 kh, 2 kh + 1};  W1 for c in {NW1 kh .. NW1 kh + NW1 - 1};  and for kh == 0 only: head-weight element
+  //   (o = 4 q + i, j = 16 jt + r), b1 / b2 entry 16 jt + r (replicated over q, lane q == 0 stores), wave 0: head bias r,
+  //   wave 1: log_std r.  Master weights live in LDS (the operand images), the moments and the accumulating gradients in
+  //   registers.
+  f32x4 mW1[NW1], vW1[NW1], gW1r[NW1], mW2[2], vW2[2], gW2r[2], mWh, vWh, gWhr;
+  const int jb = 16 * rt + r;
+  float mb1 = 0.f, vb1 = 0.f, mb2 = 0.f, vb2 = 0.f, mex = 0.f, vex = 0.f, gb1r = 0.f, gb2r = 0.f, gex = 0.f;
+  int ex_g = -1, ex_s = S::MISC + 63;
+  const bool low = fh == 0;     // wave-uniform: owns the head column block, the biases and the extra entries
+  auto w1_addr = [&](int cc, int i) { return S::W1 + (16 * rt + 4 * q + i) * SX + 16 * (NW1 * fh + cc) + r; };
+  auto w2_addr = [&](int cc, int i) { return S::W2 + (16 * rt + 4 * q + i) * SH + 16 * (2 * fh + cc) + r; };
+  auto store_w1 = [&](int cc, const f32x4& v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm[w1_addr(cc, i)] = v[i];
+  };
+  auto load_own_w1 = [&](int cc) -> f32x4 {
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = sm[w1_addr(cc, i)];
+    return v;
+  };
+  auto store_w2 = [&](int cc, const f32x4& v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm[w2_addr(cc, i)] = v[i];
+    if (S::W2TC) *reinterpret_cast<f32x4*>(sm + S::W2T + (16 * (2 * fh + cc) + r) * SH + 16 * rt + 4 * q) = v;
+  };
+  auto load_own_w2 = [&](int cc) -> f32x4 {
+    if (S::W2TC) return lds128(sm + S::W2T + (16 * (2 * fh + cc) + r) * SH + 16 * rt + 4 * q);
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = sm[w2_addr(cc, i)];
+    return v;
+  };
+  auto store_wh = [&](const f32x4& v) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sm[S::WH + (4 * q + i) * SH + 16 * rt + r] = v[i];
+    if (S::WHTC) *reinterpret_cast<f32x4*>(sm + S::WHT + (16 * rt + r) * SA + 4 * q) = v;
+  };
+  auto load_own_wh = [&]() -> f32x4 {
+    if (S::WHTC) return lds128(sm + S::WHT + (16 * rt + r) * SA + 4 * q);
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = sm[S::WH + (4 * q + i) * SH + 16 * rt + r];
+    return v;
+  };
+  for (int i = tid; i < S::TOTAL; i += TH8) sm[i] = 0.f;
+  __syncthreads();
+  {
+    const PolLayout& L = a.L;
+    const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
+    const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
+    const int gbh = role == 0 ? L.ba : (role == 1 ? L.bv : L.bc);
+#pragma unroll
+    for (int cc = 0; cc < NW1; ++cc) {
+      f32x4 pv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * rt + 4 * q + i, k = 16 * (NW1 * fh + cc) + r;
+        pv[i] = k < O ? a.params[gW1 + j * O + k] : 0.f;
+        mW1[cc][i] = k < O ? a.exp_avg[gW1 + j * O + k] : 0.f;
+        vW1[cc][i] = k < O ? a.exp_avg_sq[gW1 + j * O + k] : 0.f;
+      }
+      store_w1(cc, pv);
+    }
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc) {
+      f32x4 pv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * rt + 4 * q + i, k = 16 * (2 * fh + cc) + r;
+        pv[i] = a.params[gW2 + j * HD + k];
+        mW2[cc][i] = a.exp_avg[gW2 + j * HD + k];
+        vW2[cc][i] = a.exp_avg_sq[gW2 + j * HD + k];
+      }
+      store_w2(cc, pv);
+    }
+    mWh = vWh = gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (low) {
+      f32x4 pv;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = 4 * q + i, j = 16 * rt + r;
+        pv[i] = o < n_out ? a.params[gWh + o * HD + j] : 0.f;
+        mWh[i] = o < n_out ? a.exp_avg[gWh + o * HD + j] : 0.f;
+        vWh[i] = o < n_out ? a.exp_avg_sq[gWh + o * HD + j] : 0.f;
+      }
+      store_wh(pv);
+      mb1 = a.exp_avg[gb1 + jb]; vb1 = a.exp_avg_sq[gb1 + jb];
+      mb2 = a.exp_avg[gb2 + jb]; vb2 = a.exp_avg_sq[gb2 + jb];
+      if (w == 0 && r < n_out) { ex_g = gbh + r; ex_s = S::BH + r; }
+      if (w == LS_WAVE && !DISC && role == 0 && r < A) { ex_g = L.log_std + r; ex_s = S::LS + r; }
+      if (ex_g >= 0) { mex = a.exp_avg[ex_g]; vex = a.exp_avg_sq[ex_g]; }
+      if (q == 0) {
+        sm[S::B1 + jb] = a.params[gb1 + jb]; sm[S::B2 + jb] = a.params[gb2 + jb];
+        sm[ex_s] = ex_g >= 0 ? a.params[ex_g] : 0.f;        // lanes without an extra entry hit a scratch word
+      }
+    }
+  }
+
+  const int t0 = a.adam_t[0];
+  const float w1 = (float)(1.0 - (double)a.hp.adam_beta1);
+  const float w2 = (float)(1.0 - (double)a.hp.adam_beta2);
+  const float clip = a.hp.clip_range;
+  const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
+  const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
+  const float ent_coef = a.hp.ent_coef;
+
+  // ---------------------------------------------------------------------------------------------------------------
+  // row stream (see ppo_train_rows.hip): `perms` holds storage offsets; rows of chunk g + 1 are prefetched into registers
+  // while chunk g is processed.  The 16 rows of tile rt are staged by the 128 threads of the wave pair (rt, *): 8 per row.
+  // ---------------------------------------------------------------------------------------------------------------
+  const int gb_row = 16 * rt + (lane >> 2), gpart = (lane & 3) + 4 * fh;
+  const int stid = tid - 64;      // advantage statistics: row stid of the minibatch lives in waves 1 (and 2)
+  auto ld_step = [&](int i) -> int4 {
+    asm volatile("" : "+v"(i));
+    return *reinterpret_cast<const int4*>(plan_steps + i);
+  };
+  auto ld_chunk = [&](int g) -> int2 {
+    asm volatile("" : "+v"(g));
+    return *reinterpret_cast<const int2*>(plan_chunks + g);
+  };
+  auto chunk_idx = [&](const int2& c) -> int { return gb_row < c.y ? perms[c.x + gb_row] : -1; };      // {perm_base, rows}
+  auto stat_idx = [&](const int4& p) -> int {
+    return (role == 0 && stid >= 0 && stid < (p.z & 0xff)) ? perms[p.w + stid] : -1;
+  };
+  float px[XR], pact[2], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
+  bool pvalid = false;
+  auto issue_rows = [&](int idx) {
+    pvalid = idx >= 0;
+    const size_t off = pvalid ? (size_t)idx : 0;
+    const float* orow = p_obs + off * O;
+#pragma unroll
+    for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; px[i] = orow[k < O ? k : O - 1]; }
+    if (role == 0) {
+      const float* arow = p_act + off * AS;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; pact[i] = arow[k < AS ? k : AS - 1]; }
+    }
+    psc0 = p_s0[off]; psc1 = p_s1[off]; psc2 = p_s2[off];
+  };
+  auto commit_rows = [&](int xbase) {
+#pragma unroll
+    for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; if (k < S::O16) sm[xbase + k * ST + gb_row] = (pvalid && k < O) ? px[i] : 0.f; }
+    if (role == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; sm[S::ACT + gb_row * SA + k] = (pvalid && k < AS) ? pact[i] : 0.f; }
+    }
+    if (gpart == 0) { sm[S::OLP + gb_row] = pvalid ? psc0 : 0.f; sm[S::ADR + gb_row] = pvalid ? psc1 : 0.f; sm[S::ADC + gb_row] = pvalid ? psc2 : 0.f; }
+  };
+  float sar = 0.f, sac = 0.f;
+  auto issue_stats = [&](int idx) {
+    const unsigned off = idx >= 0 ? (unsigned)idx : 0u;
+    sar = p_s1[off];
+    sac = p_s2[off];
+  };
+  auto stats_partials = [&](int nb) {
+    if (role != 0 || (w != 1 && w != 2)) return;
+    const bool in = stid < nb;
+    const float s_r = wave_sum_fast(in ? sar : 0.f), s_c = wave_sum_fast(in ? sac : 0.f), s_rr = wave_sum_fast(in ? sar * sar : 0.f);
+    if (lane == 0) { sm[S::MISC + 13 + 3 * w] = s_r; sm[S::MISC + 14 + 3 * w] = s_c; sm[S::MISC + 15 + 3 * w] = s_rr; }
+  };
+  float mean_r = 0.f, istd_r = 1.f, mean_c = 0.f;
+  auto read_stats = [&](int nb) {
+    if (role != 0) return;
+    const float s_r = sm[S::MISC + 16] + sm[S::MISC + 19];
+    const float s_c = sm[S::MISC + 17] + sm[S::MISC + 20];
+    const float s_rr = sm[S::MISC + 18] + sm[S::MISC + 21];
+    const float inv = __builtin_amdgcn_rcpf((float)nb);
+    mean_r = s_r * inv;
+    mean_c = s_c * inv;
+    const float var = fmaxf(s_rr - s_r * mean_r, 0.f) * __builtin_amdgcn_rcpf((float)(nb - 1));
+    istd_r = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var) + 1e-8f);
+  };
+  auto refresh_gauss = [&]() {   // wave 1, lanes q == 0 own log_std r: derived constants of the Gaussian head
+    if (!DISC && role == 0 && w == LS_WAVE && q == 0) {
+      const float wex = sm[S::LS + r];
+      const float sd = __expf(wex);
+      const float iv = __builtin_amdgcn_rcpf(sd * sd);
+      sm[S::GAU + r] = r < A ? iv : 0.f;
+      sm[S::GAU + 16 + r] = r < A ? 0.5f * iv : 0.f;
+      sm[S::GAU + 32 + r] = r < A ? wex + LOG_SQRT_2PI_F : 0.f;
+      const float ent = row_sum(r < A ? HALF_LOG_2PI_PLUS_HALF_F + wex : 0.f);
+      if (r == 0) sm[S::MISC + 22] = ent;
+    }
+  };
+  // ---- synchronisation between the two waves of a pair: a phase counter per wave in LDS.  The producer drains its LDS stores
+  // (they complete in issue order) and raises its counter; the consumer polls the partner's counter, then reads.  A wave only
+  // ever exchanges data with its partner before the dz1 barrier, so the other pairs need not be there yet.
+  int* const pflag = reinterpret_cast<int*>(sm + S::MISC + 48);      // [8] one word per wave
+  int pphase = 0;
+#if ICRL_PAIR_FLAGS
+  auto pair_signal = [&]() {
+    ++pphase;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_store(pflag + w, pphase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto pair_wait = [&]() {
+    while (__hip_atomic_load(pflag + partner, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < pphase) __builtin_amdgcn_s_sleep(0);
+    asm volatile("" ::: "memory");
+  };
+#else
+  auto pair_signal = [&]() { (void)pflag; (void)pphase; (void)partner; lds_barrier(); };
+  auto pair_wait = [&]() {};
+#endif
+  const bool book = tid == 192;      // wave 3 lane 0 keeps the running statistics of the role
+  float st_ent = 0.f, st_pg = 0.f, st_vl = 0.f, st_cf = 0.f, last_loss = 0.f, kl_sum = 0.f;
+  int steps_done = 0, early_stop_epoch = a.hp.n_epochs, status = 0;
+
+  // ---- pipeline prologue
+  int g_chunk = 0;
+  int idx_next = chunk_idx(ld_chunk(1)), idx_nx2 = chunk_idx(ld_chunk(2));
+  int2 pc_nx3 = ld_chunk(3);
+  issue_rows(chunk_idx(ld_chunk(0)));
+  int4 ps_next = ld_step(0), ps_nx2 = ld_step(1), ps_nx3 = ld_step(2);
+  issue_stats(stat_idx(ps_next));
+  int sidx_next = stat_idx(ps_nx2);
+  __syncthreads();                      // initial weights visible (refresh_gauss reads log_std)
+  refresh_gauss();
+  int xcur = S::XT0;
+  commit_rows(xcur);
+  stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & 0xff);
+  __syncthreads();
+  read_stats(__builtin_amdgcn_readfirstlane(ps_next.z) & 0xff);
+  const float inv_n_mb = 1.f / (float)((T * N + a.hp.batch_size - 1) / a.hp.batch_size);
+
+  const bool prof = (a.hp._pad & 1) != 0;
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef ICRL_FINE_PROF
+  unsigned long long fph[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  unsigned long long t_last = prof ? stamp() : 0ull;
+
+  bool stop = false;
+  for (int st = 0; st < n_steps && !stop; ++st) {
+    const unsigned step = (unsigned)st + 1u;
+    PlanStep ps;
+    ps.step_size = __int_as_float(__builtin_amdgcn_readfirstlane(ps_next.x));
+    ps.inv_bc2_sqrt = __int_as_float(__builtin_amdgcn_readfirstlane(ps_next.y));
+    ps.nb_flags = __builtin_amdgcn_readfirstlane(ps_next.z);
+    ps.perm_base = 0;
+    ps_next = ps_nx2; ps_nx2 = ps_nx3;
+    ps_nx3 = ld_step(st + 3 < n_steps + 2 ? st + 3 : n_steps + 1);
+    const int nb = ps.nb_flags & 0xff;
+    const float inv_nb = __builtin_amdgcn_rcpf((float)nb);
+    const float c_mean_r = mean_r, c_mean_c = mean_c, c_istd_r = istd_r;
+    const float cpol_nb = inv_nb * __builtin_amdgcn_rcpf(1.f + nu);
+    issue_stats(sidx_next);
+    sidx_next = stat_idx(ps_nx2);
+    float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f, mb_s4 = 0.f;
+
+    const int n_chunks = (nb + RB - 1) / RB;
+    for (int ch = 0; ch < n_chunks; ++ch, ++g_chunk) {
+      const int nrows = (nb - ch * RB) < RB ? (nb - ch * RB) : RB;
+      if (ch > 0) {
+        if (S::XDB) xcur = xcur == S::XT0 ? S::XT1 : S::XT0;
+        commit_rows(xcur);
+        lds_barrier();                      // a row is staged by threads of both waves of its pair
+      }
+      const int b = 16 * rt + r;            // this lane's row of the chunk (all four q lanes share it)
+      const bool valid = b < nrows;
+      float* const pt = sm + (4 * q) * ST + b;     // + image + (16 t + i) ST: element [feature 16 t + 4 q + i][row b]
+      // ================= forward =================
+      f32x4 h1c[2], h2c[2], outc;           // own feature tiles t = 2 fh + tt
+      {
+        float bx[NT1][4];                   // x[row b][k = 16 js + 4 q + e]
+        const float* pb = sm + xcur + (4 * q) * ST + b;
+#pragma unroll
+        for (int js = 0; js < NT1; ++js)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bx[js][e] = pb[(16 * js + e) * ST];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * fh + tt;
+          const float* pa = sm + S::W1 + (16 * t + r) * SX + 4 * q;
+          f32x4 aw[NT1];
+#pragma unroll
+          for (int js = 0; js < NT1; ++js) aw[js] = lds128(pa + 16 * js);
+          f32x4 acc = lds128(sm + S::B1 + 16 * t + 4 * q);      // the bias is the accumulator's initial value
+#pragma unroll
+          for (int js = 0; js < NT1; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (js < NT1 - 1 || 16 * js + e < O) acc = MFMA_F32(aw[js][e], bx[js][e], acc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) h1c[tt][i] = fast_tanh(acc[i]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pt[S::H1T + (16 * t + i) * ST] = h1c[tt][i];
+        }
+      }
+      FSTAMP(0)   // L1
+      // prefetch the next chunk's rows (random 72-byte pieces of the rollout buffer: several microseconds away)
+      issue_rows(idx_next);
+      idx_next = idx_nx2;
+      idx_nx2 = chunk_idx(pc_nx3);
+      pc_nx3 = ld_chunk(g_chunk + 4);
+      FSTAMP(1)   // row prefetch issue
+      pair_signal(); pair_wait();    // (P1) the pair's columns of h1^T are complete
+      FSTAMP(2)   // S1
+      {
+        float hpart[2][4];                  // the partner's half of h1 as B operand: features 16 js + 4 q + e, js = 2 (1 - fh) + jj
+        const float* ph1 = sm + S::H1T + (4 * q) * ST + b + 32 * (1 - fh) * ST;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) hpart[jj][e] = ph1[(16 * jj + e) * ST];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * fh + tt;
+          // (operand tiles addressed, never indexed, by the runtime half fh: a runtime-indexed register array goes to scratch)
+          const float* pa = sm + S::W2 + (16 * t + r) * SH + 4 * q;
+          f32x4 awo[2], awp[2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) { awo[jj] = lds128(pa + 32 * fh + 16 * jj); awp[jj] = lds128(pa + 32 * (1 - fh) + 16 * jj); }
+          f32x4 acc = lds128(sm + S::B2 + 16 * t + 4 * q);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)      // own half of K first (registers), then the partner's
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = MFMA_F32(awo[jj][e], h1c[jj][e], acc);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = MFMA_F32(awp[jj][e], hpart[jj][e], acc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) h2c[tt][i] = fast_tanh(acc[i]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pt[S::H2T + (16 * t + i) * ST] = h2c[tt][i];
+        }
+      }
+      FSTAMP(3)   // L2
+      {  // head, split over K: this wave's 32 features; partial tiles exchanged through LDS
+        const float* pa = sm + S::WH + r * SH + 4 * q + 32 * fh;
+        f32x4 acc = low ? lds128(sm + S::BH + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+          const f32x4 aw = lds128(pa + 16 * jj);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[e], h2c[jj][e], acc);
+        }
+        // the pair's partial tiles live in the pair's OWN columns (16 rt ..) of the dz1^T image: rows 16 fh + lane / 4
+        float* const hpx = sm + S::HPX + (lane >> 2) * ST + 16 * rt + 4 * (lane & 3);
+        *reinterpret_cast<f32x4*>(hpx + 16 * fh * ST) = acc;
+        FSTAMP(4)   // head MFMA + partial store
+        pair_signal(); pair_wait();  // (P3) both partial tiles stored
+        FSTAMP(5)   // S3
+        const f32x4 p0 = lds128(hpx), p1 = lds128(hpx + 16 * ST);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) outc[i] = p0[i] + p1[i];
+      }
+      STAMP(0)   // forward
+      // ============ loss + d loss / d head output (both waves of a pair: identical values) ============
+      f32x4 dout = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+        if (role == 0) {
+          float lp = 0.f, ent = 0.f;
+          f32x4 g1 = f32x4{0.f, 0.f, 0.f, 0.f}, g2 = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (DISC) {
+            float lg[4], zmax = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { lg[i] = (4 * q + i < A) ? outc[i] : -INFINITY; zmax = fmaxf(zmax, lg[i]); }
+            zmax = xor16_max(xor32_max(zmax));
+            float se = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) se += (4 * q + i < A) ? expf(lg[i] - zmax) : 0.f;
+            se = quad_rows_sum(se);
+            const float lse = zmax + logf(se);
+            const int act = (int)sm[S::ACT + b * SA];
+            float pr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int k = 4 * q + i;
+              lg[i] = k < A ? lg[i] - lse : 0.f;
+              pr[i] = k < A ? expf(lg[i]) : 0.f;
+              lp += (k == act) ? lg[i] : 0.f;
+              ent -= pr[i] * lg[i];
+            }
+            lp = quad_rows_sum(lp);
+            ent = quad_rows_sum(ent);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const int k = 4 * q + i;
+              g1[i] = k < A ? ((k == act ? 1.f : 0.f) - pr[i]) : 0.f;
+              g2[i] = k < A ? pr[i] * (lg[i] + ent) : 0.f;
+            }
+          } else {
+            const f32x4 actv = lds128(sm + S::ACT + b * SA + 4 * q);
+            const f32x4 iv = lds128(sm + S::GAU + 4 * q), hiv = lds128(sm + S::GAU + 16 + 4 * q), lsd = lds128(sm + S::GAU + 32 + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float dd = actv[i] - outc[i];
+              lp += -(dd * dd) * hiv[i] - lsd[i];
+              g1[i] = dd * iv[i];
+              g2[i] = (4 * q + i < A) ? (dd * dd) * iv[i] - 1.f : 0.f;
+            }
+            lp = quad_rows_sum(lp);
+          }
+          const float old_lp = sm[S::OLP + b];
+          const float ratio = __expf(lp - old_lp);
+          const float Ar = (sm[S::ADR + b] - c_mean_r) * c_istd_r;
+          const float Ac = sm[S::ADC + b] - c_mean_c;
+          const float s1 = Ar * ratio;
+          const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+          const float s2 = Ar * rc;
+          const float gsel = (s1 <= s2) ? Ar : 0.f;
+          const float dlp = valid ? cpol_nb * (-gsel + nu * Ac) * ratio : 0.f;
+          if (DISC) {
+            const float dent = valid ? ent_coef * inv_nb : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) dout[i] = dlp * g1[i] + dent * g2[i];
+          } else {
+            f32x4 t;       // d log_std: sum over this tile's 16 rows, per output o = 4q + i
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { dout[i] = dlp * g1[i]; t[i] = row_sum(dlp * g2[i]); }
+            if (low && r == 0) *reinterpret_cast<f32x4*>(sm + S::PLS + 16 * rt + 4 * q) = t;
+          }
+          const bool cnt = valid && q == 0;
+          v0 = cnt ? fminf(s1, s2) : 0.f; v1 = cnt ? Ac * ratio : 0.f; v2 = (cnt && fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
+          v3 = cnt ? old_lp - lp : 0.f; v4 = cnt ? ent : 0.f;
+        } else {
+          const float v = quad_rows_sum(q == 0 ? outc[0] : 0.f);
+          const float R = sm[S::ADR + b];
+          float vp = v, pass = 1.f;
+          if (vclip >= 0.f) {
+            const float old = sm[S::OLP + b];
+            const float dv = v - old;
+            vp = old + fminf(fmaxf(dv, -vclip), vclip);
+            pass = (dv >= -vclip && dv <= vclip) ? 1.f : 0.f;
+          }
+          const float e = vp - R;
+          const float d0 = valid ? vcoef * 2.f * e * inv_nb * pass : 0.f;
+          dout[0] = q == 0 ? d0 : 0.f;
+          v0 = (valid && q == 0) ? e * e : 0.f;
+        }
+        if (low) {     // one wave of the pair reports the tile's statistics
+          v0 = row_sum(v0); v1 = row_sum(v1); v2 = row_sum(v2); v3 = row_sum(v3);
+          if (DISC) v4 = row_sum(v4);
+          if (lane == 0) { float* pst = sm + S::PST + 8 * rt; pst[0] = v0; pst[1] = v1; pst[2] = v2; pst[3] = v3; pst[4] = v4; }
+        }
+      }
+      STAMP(1)   // loss
+      FSTAMP(6)   // partial read + loss
+      // ================= backward of the activations =================
+      f32x4 dz2c[2], dz1c[2];
+      {  // dH2^T = Wh^T . dOut^T for the own feature tiles: A = WHT[j = 16 t + r][o = 4 q + e] (K = 16 outputs)
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * fh + tt;
+          f32x4 aw;
+          if (S::WHTC) aw = lds128(sm + S::WHT + (16 * t + r) * SA + 4 * q);
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) aw[e] = sm[S::WH + (4 * q + e) * SH + 16 * t + r];
+          }
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[e], dout[e], acc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dz2c[tt][i] = fmaf(-(h2c[tt][i] * h2c[tt][i]), acc[i], acc[i]);   // acc (1 - h2^2)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pt[S::DZ2T + (16 * t + i) * ST] = dz2c[tt][i];
+        }
+        if (low) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pt[S::DOT + i * ST] = dout[i];
+        }
+      }
+      FSTAMP(7)   // dH2
+      pair_signal(); pair_wait();  // (P4) the pair's columns of dz2^T complete
+      FSTAMP(8)   // S4
+      {  // dH1^T = W2^T . dz2^T: A = W2T[k = 16 t + r][j = 16 js + 4 q + e]; the partner's half of dz2 from the image
+        float dp[2][4];
+        const float* pz = sm + S::DZ2T + (4 * q) * ST + b + 32 * (1 - fh) * ST;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dp[jj][e] = pz[(16 * jj + e) * ST];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * fh + tt;
+          f32x4 awo[2], awp[2];
+          if (S::W2TC) {
+            const float* pa = sm + S::W2T + (16 * t + r) * SH + 4 * q;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) { awo[jj] = lds128(pa + 32 * fh + 16 * jj); awp[jj] = lds128(pa + 32 * (1 - fh) + 16 * jj); }
+          } else {
+            const float* pa = sm + S::W2 + (4 * q) * SH + 16 * t + r;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                awo[jj][e] = pa[(32 * fh + 16 * jj + e) * SH];
+                awp[jj][e] = pa[(32 * (1 - fh) + 16 * jj + e) * SH];
+              }
+          }
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = MFMA_F32(awo[jj][e], dz2c[jj][e], acc);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = MFMA_F32(awp[jj][e], dp[jj][e], acc);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dz1c[tt][i] = fmaf(-(h1c[tt][i] * h1c[tt][i]), acc[i], acc[i]);
+        }
+      }
+#pragma unroll
+      for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pt[S::DZ1T + (16 * (2 * fh + tt) + i) * ST] = dz1c[tt][i];
+      STAMP(2)   // activation backward
+      FSTAMP(9)   // dH1 + dz1 store
+      if (ch == 0) {   // gradient accumulators start their life here
+#pragma unroll
+        for (int cc = 0; cc < NW1; ++cc) gW1r[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gW2r[0] = gW2r[1] = gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
+        gb1r = 0.f; gb2r = 0.f; gex = 0.f;
+      }
+      lds_barrier();  // (S5) every pair's columns of h1^T, h2^T, dz1^T, dz2^T, dOut^T (and the loss partials) are complete
+      FSTAMP(12)  // S5
+      // ================= weight gradients (K = the 64 rows) =================
+      {  // dW2 rows 16 rt.., column tiles 2 fh, 2 fh + 1
+        f32x4 az[4];   // dz2^T[j = 16 rt + r][rows 16 js + 4 q + e]
+        const float* pa = sm + S::DZ2T + (16 * rt + r) * ST + 4 * q;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) az[js] = lds128(pa + 16 * js);
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+          const float* pb = sm + S::H1T + (16 * (2 * fh + cc) + r) * ST + 4 * q;
+          f32x4 bh[4];
+#pragma unroll
+          for (int js = 0; js < 4; ++js) bh[js] = lds128(pb + 16 * js);
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gW2r[cc] = MFMA_F32(az[js][e], bh[js][e], gW2r[cc]);
+        }
+        if (low) {
+          float s = 0.f;     // d b2[16 rt + r] = sum over the rows
+#pragma unroll
+          for (int js = 0; js < 4; ++js) s += (az[js][0] + az[js][1]) + (az[js][2] + az[js][3]);
+          gb2r += quad_rows_sum(s);
+        }
+      }
+      FSTAMP(10)  // dW2
+      if (low) {   // dWh columns 16 rt..: A = dOut^T[o = r][rows], B = h2^T[j = 16 rt + r][rows]
+        f32x4 ao[4], bh[4];
+        const float* pa = sm + S::DOT + r * ST + 4 * q;
+        const float* pb = sm + S::H2T + (16 * rt + r) * ST + 4 * q;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) { ao[js] = lds128(pa + 16 * js); bh[js] = lds128(pb + 16 * js); }
+        f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int js = 0; js < 4; ++js)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[js & 1] = MFMA_F32(ao[js][e], bh[js][e], acc[js & 1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gWhr[i] += acc[0][i] + acc[1][i];
+        float s = 0.f;      // head bias (wave 0 keeps it): row sums of dOut^T
+#pragma unroll
+        for (int js = 0; js < 4; ++js) s += (ao[js][0] + ao[js][1]) + (ao[js][2] + ao[js][3]);
+        s = quad_rows_sum(s);
+        // log_std's wave (Gaussian policy): d log_std r = sum of the four per-tile partials
+        const float sl = (sm[S::PLS + r] + sm[S::PLS + 16 + r]) + (sm[S::PLS + 32 + r] + sm[S::PLS + 48 + r]);
+        gex += w == 0 ? s : ((!DISC && role == 0 && w == LS_WAVE) ? sl : 0.f);
+      }
+      FSTAMP(11)  // dWh
+      {  // dW1 rows 16 rt.., observation tiles NW1 fh ..
+        f32x4 az[4];   // dz1^T[j = 16 rt + r][rows]
+        const float* pa = sm + S::DZ1T + (16 * rt + r) * ST + 4 * q;
+#pragma unroll
+        for (int js = 0; js < 4; ++js) az[js] = lds128(pa + 16 * js);
+#pragma unroll
+        for (int cc = 0; cc < NW1; ++cc) {
+          const float* pb = sm + xcur + (16 * (NW1 * fh + cc) + r) * ST + 4 * q;     // x^T[k][rows 16 js + 4 q + e]
+          f32x4 bx[4];
+#pragma unroll
+          for (int js = 0; js < 4; ++js) bx[js] = lds128(pb + 16 * js);
+#pragma unroll
+          for (int js = 0; js < 4; ++js)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) gW1r[cc] = MFMA_F32(az[js][e], bx[js][e], gW1r[cc]);
+        }
+        if (low) {
+          float s = 0.f;
+#pragma unroll
+          for (int js = 0; js < 4; ++js) s += (az[js][0] + az[js][1]) + (az[js][2] + az[js][3]);
+          gb1r += quad_rows_sum(s);
+        }
+      }
+      if (book) {
+        mb_s0 += (sm[S::PST + 0] + sm[S::PST + 8]) + (sm[S::PST + 16] + sm[S::PST + 24]);
+        mb_s1 += (sm[S::PST + 1] + sm[S::PST + 9]) + (sm[S::PST + 17] + sm[S::PST + 25]);
+        mb_s2 += (sm[S::PST + 2] + sm[S::PST + 10]) + (sm[S::PST + 18] + sm[S::PST + 26]);
+        mb_s3 += (sm[S::PST + 3] + sm[S::PST + 11]) + (sm[S::PST + 19] + sm[S::PST + 27]);
+        if (DISC) mb_s4 += (sm[S::PST + 4] + sm[S::PST + 12]) + (sm[S::PST + 20] + sm[S::PST + 28]);
+      }
+      if (ch + 1 < n_chunks || !S::XDB) lds_barrier();  // chunk buffers free (single X buffer: also before it is restaged)
+      STAMP(3)   // weight gradients
+      FSTAMP(13)  // dW1
+    }  // chunks
+
+    // entropy term of the Gaussian policy loss: d(ent_coef * -mean(H)) / d log_std = -ent_coef
+    if (!DISC && role == 0 && w == LS_WAVE && r < A) gex += -ent_coef;
+
+    // ================= global gradient norm: this wave's partial sum of squares -> its own 8-byte granule =================
+    float ss = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < NW1; ++cc)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ss = fmaf(gW1r[cc][i], gW1r[cc][i], ss);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ss = fmaf(gW2r[cc][i], gW2r[cc][i], ss);
+    if (low) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) ss = fmaf(gWhr[i], gWhr[i], ss);
+      const float sb = fmaf(gb1r, gb1r, gb2r * gb2r) + (ex_g >= 0 ? gex * gex : 0.f);
+      ss += q == 0 ? sb : 0.f;
+    }
+    ss = wave_sum_fast(ss);
+    if (lane == 0) {
+      bool want_stop = false;
+      float mean_kl = 0.f;
+      const bool last_mb = (ps.nb_flags >> 9) & 1;
+      const int epoch = ps.nb_flags >> 10;
+      if (book && role == 0) {   // the early-stop decision rides on the granule of the policy workgroup's wave 3
+        if ((ps.nb_flags >> 8) & 1) kl_sum = 0.f;
+        kl_sum += mb_s3 * inv_nb;
+        if (last_mb) {
+          mean_kl = kl_sum * inv_n_mb;
+          const TrainArgs* k_ = KARGS();
+          if (k_->hp.use_target_kl && mean_kl > 1.5f * k_->hp.target_kl) { want_stop = true; early_stop_epoch = epoch; }
+        }
+      }
+      const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
+      __hip_atomic_store(a.xch + (step & 1) * 32 + role * 8 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (book) {
+        ++steps_done;
+        if (role == 0) {
+          float ent = 0.f;
+          if (DISC) ent = mb_s4 * inv_nb;
+          else ent = sm[S::MISC + 22];
+          const float entropy_loss = -ent;
+          const float pl = (-(mb_s0 * inv_nb) + nu * (mb_s1 * inv_nb)) * __builtin_amdgcn_rcpf(1.f + nu);
+          st_ent += entropy_loss; st_pg += pl; st_cf += mb_s2 * inv_nb;
+          last_loss = pl + ent_coef * entropy_loss;
+          if (last_mb) { float* stats = KARGS()->stats; stats[32 + epoch] = mean_kl; stats[7] = mean_kl; }
+        } else {
+          const float vl = mb_s0 * inv_nb;
+          st_vl += vl;
+          last_loss = vl;
+        }
+      }
+    }
+    STAMP(4)   // gradient norm + publish
+    FSTAMP(14)  // norm + publish
+    // ---- while the granules travel: stage the next minibatch (rows -> the other X^T buffer, advantage statistics)
+    const int xnext = S::XDB ? (xcur == S::XT0 ? S::XT1 : S::XT0) : xcur;
+    commit_rows(xnext);
+    const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & 0xff;
+    stats_partials(nb_next);
+    xcur = xnext;
+    FSTAMP(15)  // staging
+    if (tid < 24) {     // granule (role rr, wave ww) = slot 8 rr + ww
+      u64 v = 0;
+      int spins = 0;
+      bool ok = false;
+      const u64* const slot = a.xch + (step & 1) * 32 + tid;
+      while (spins < (1 << 24)) {
+        v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; break; }
+        __builtin_amdgcn_s_sleep(1);
+        ++spins;
+      }
+      sm[S::MISC + 24 + tid] = __uint_as_float((unsigned)(v & 0xffffffffu));
+      if (tid == 3) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;     // granule 3 = (policy, wave 3) carries the stop flag
+      if (!ok) sm[S::MISC + 13] = 1.f;
+    }
+    lds_barrier();   // (S6) norm partials, next minibatch and its statistics visible
+    STAMP(5)   // staging + granule wait
+    FSTAMP(16)  // poll + S6
+    float total = 0.f;
+    {
+#pragma unroll
+      for (int g = 0; g < 6; ++g) {     // fixed order: every wave of every role forms the same total
+        const f32x4 n = lds128(sm + S::MISC + 24 + 4 * g);
+        total += (n[0] + n[1]) + (n[2] + n[3]);
+      }
+      const f32x4 fl = lds128(sm + S::MISC + 12);
+      stop = fl[0] != 0.f;
+      if (fl[1] != 0.f) { status = 1; stop = true; }
+    }
+    total = __builtin_amdgcn_sqrtf(total);
+    float coef = a.hp.max_grad_norm * __builtin_amdgcn_rcpf(total + 1e-6f);
+    coef = coef > 1.f ? 1.f : coef;
+    read_stats(nb_next > 0 ? nb_next : 2);
+
+    // ================= Adam (torch.optim.Adam, single-tensor form) on the wave's own elements =================
+    {
+      const float step_size = ps.step_size, inv_bc2_sqrt = ps.inv_bc2_sqrt;
+      const float epsf = a.hp.adam_eps;
+      const float omw1 = 1.f - w1, b2f_ = a.hp.adam_beta2;
+      const float cw1 = coef * w1, c2w2 = (coef * coef) * w2;
+      auto adam4 = [&](const f32x4& g, f32x4& m, f32x4& v, f32x4& p) {   // stage by stage: four independent chains
+        f32x4 d;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { m[i] = fmaf(cw1, g[i], omw1 * m[i]); v[i] = fmaf(c2w2, g[i] * g[i], b2f_ * v[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[i] = fmaf(__builtin_amdgcn_sqrtf(v[i]), inv_bc2_sqrt, epsf);   // v_sqrt_f32 / v_rcp_f32: 1 ulp each
+#pragma unroll
+        for (int i = 0; i < 4; ++i) p[i] = fmaf(-step_size, m[i] * __builtin_amdgcn_rcpf(d[i]), p[i]);
+      };
+      // pad elements (k >= obs, o >= n_out) have g = m = v = p = 0 and stay 0: no masks needed
+#pragma unroll
+      for (int cc = 0; cc < NW1; ++cc) { f32x4 p_ = load_own_w1(cc); adam4(gW1r[cc], mW1[cc], vW1[cc], p_); store_w1(cc, p_); }
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) { f32x4 p_ = load_own_w2(cc); adam4(gW2r[cc], mW2[cc], vW2[cc], p_); store_w2(cc, p_); }
+      if (low) {
+        { f32x4 p_ = load_own_wh(); adam4(gWhr, mWh, vWh, p_); store_wh(p_); }
+        f32x4 g_ = f32x4{gb1r, gb2r, ex_g >= 0 ? gex : 0.f, 0.f}, p_ = f32x4{sm[S::B1 + jb], sm[S::B2 + jb], sm[ex_s], 0.f};
+        f32x4 m_ = f32x4{mb1, mb2, mex, 0.f}, v_ = f32x4{vb1, vb2, vex, 0.f};
+        adam4(g_, m_, v_, p_);     // identical arithmetic in the four q lanes, lane q == 0 stores
+        mb1 = m_[0]; mb2 = m_[1]; mex = m_[2]; vb1 = v_[0]; vb2 = v_[1]; vex = v_[2];
+        if (q == 0) { sm[S::B1 + jb] = p_[0]; sm[S::B2 + jb] = p_[1]; sm[ex_s] = p_[2]; }
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the log_std store has landed before refresh_gauss re-reads it
+        refresh_gauss();
+      }
+    }
+    FSTAMP(17)  // Adam
+    lds_barrier();   // (S7) updated weights visible
+    STAMP(6)   // Adam
+    FSTAMP(18)  // S7
+  }  // optimiser steps
+
+  __syncthreads();
+  // ---- write back weights, moments, statistics
+  {
+  const TrainArgs* ka = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  const TrainArgs& a = *ka;
+  const PolLayout& L = a.L;
+  const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
+  const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
+#pragma unroll
+  for (int cc = 0; cc < NW1; ++cc) {
+    const f32x4 pv = load_own_w1(cc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * rt + 4 * q + i, k = 16 * (NW1 * fh + cc) + r;
+      if (k < O) { a.params[gW1 + j * O + k] = pv[i]; a.exp_avg[gW1 + j * O + k] = mW1[cc][i]; a.exp_avg_sq[gW1 + j * O + k] = vW1[cc][i]; }
+    }
+  }
+#pragma unroll
+  for (int cc = 0; cc < 2; ++cc) {
+    const f32x4 pv = load_own_w2(cc);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * rt + 4 * q + i, k = 16 * (2 * fh + cc) + r;
+      a.params[gW2 + j * HD + k] = pv[i];
+      a.exp_avg[gW2 + j * HD + k] = mW2[cc][i];
+      a.exp_avg_sq[gW2 + j * HD + k] = vW2[cc][i];
+    }
+  }
+  if (low) {
+    const f32x4 pv = load_own_wh();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int o = 4 * q + i, j = 16 * rt + r;
+      if (o < n_out) { a.params[gWh + o * HD + j] = pv[i]; a.exp_avg[gWh + o * HD + j] = mWh[i]; a.exp_avg_sq[gWh + o * HD + j] = vWh[i]; }
+    }
+    if (q == 0) {
+      a.params[gb1 + jb] = sm[S::B1 + jb]; a.exp_avg[gb1 + jb] = mb1; a.exp_avg_sq[gb1 + jb] = vb1;
+      a.params[gb2 + jb] = sm[S::B2 + jb]; a.exp_avg[gb2 + jb] = mb2; a.exp_avg_sq[gb2 + jb] = vb2;
+      if (ex_g >= 0) { a.params[ex_g] = sm[ex_s]; a.exp_avg[ex_g] = mex; a.exp_avg_sq[ex_g] = vex; }
+    }
+  }
+#ifdef ICRL_FINE_PROF
+  if (tid == 0 && prof && role == 0)
+    for (int k = 0; k < 20; ++k) a.stats[12 + k] = (float)((double)fph[k] / (double)(a.n_steps > 0 ? a.n_steps : 1));
+#endif
+  if (tid == 0 && prof) {
+#ifdef ICRL_FINE_PROF
+    for (int k = 0; k < 0; ++k) {
+#else
+    for (int k = 0; k < 7; ++k) {
+#endif
+      const int slot = 12 + 7 * role + k;
+      if (slot < 32) a.stats[slot] = (float)((double)ph[k] / (double)(a.n_steps > 0 ? a.n_steps : 1));   // (full runs only)
+    }
+  }
+  if (book) {
+    if (role == 0) {
+      a.stats[0] = (float)early_stop_epoch;
+      a.stats[1] = (float)steps_done;
+      a.stats[2] = st_ent; a.stats[3] = st_pg; a.stats[6] = st_cf;
+      a.stats[8] = last_loss;
+      a.stats[11] = (float)status;
+      a.adam_t[0] = t0 + steps_done;
+    } else if (role == 1) {
+      a.stats[4] = st_vl; a.stats[9] = last_loss;
+    } else {
+      a.stats[5] = st_vl; a.stats[10] = last_loss;
+    }
+  }
+  }
+}
+
+template <int NT1, bool DISC>
+static int launch_pairs(const TrainArgs& a, hipStream_t s) {
+  static_assert(SmemP<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
+
+  const size_t bytes = (size_t)SmemP<NT1>::TOTAL * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_kernel<NT1, DISC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((ppo_train_pairs_kernel<NT1, DISC>), dim3(3), dim3(TH8), bytes, s, a);
+  return (int)hipGetLastError();
+}
+
+int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s) {
+  if (nt1 <= 2) return discrete ? launch_pairs<2, true>(a, s) : launch_pairs<2, false>(a, s);
+  if (nt1 <= 4) return discrete ? launch_pairs<4, true>(a, s) : launch_pairs<4, false>(a, s);
+  return (int)hipErrorInvalidValue;
+}
+
+}  // namespace icrl

@@ -378,11 +378,11 @@ class PPOLagrangian:
         current_penalty = float(self.dual.nu().item())
         if not hasattr(self, "_train_ws"):
             self._train_ws = dict(nu=torch.zeros(1, device=dev), stats=torch.zeros(32 + self.n_epochs, device=dev),
-                                  sync=torch.zeros(64 + 4 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2, dtype=torch.int64, device=dev), t=torch.zeros(1, dtype=torch.int32, device=dev))
+                                  sync=torch.zeros(96 + 4 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2, dtype=torch.int64, device=dev), t=torch.zeros(1, dtype=torch.int32, device=dev))
         ws = self._train_ws
         ws["nu"].fill_(current_penalty)
         ws["t"].fill_(pol.adam_step)
-        hp = PpoHyperT(int(self.batch_size), int(self.n_epochs), int(self.target_kl is not None), int(getattr(self, "profile_phases", 0)) | (2 if getattr(self, "train_kernel", "auto") == "tiles" else 0), clip_range, float(self.ent_coef),
+        hp = PpoHyperT(int(self.batch_size), int(self.n_epochs), int(self.target_kl is not None), int(getattr(self, "profile_phases", 0)) | {"tiles": 2, "rows": 4}.get(getattr(self, "train_kernel", "auto"), 0), clip_range, float(self.ent_coef),
                        float(self.reward_vf_coef), float(self.cost_vf_coef), float(self.max_grad_norm),
                        float(self.target_kl or 0.0), crv, ccv, lr, 0.9, 0.999, float(pol.optimizer_kwargs.get("eps", 1e-8)))
         ps, bs = pol.struct(), rb.struct()

@@ -132,7 +132,7 @@ typedef struct {
 } icrl_cn_hyper_t;
 
 #define ICRL_PPO_SYNC_BYTES(n_epochs, n_minibatches, n_rows) \
-  (512 + 32 * (size_t)(n_epochs) * (size_t)(n_minibatches) + 4 * (size_t)(n_epochs) * (size_t)(n_rows))
+  (768 + 32 * (size_t)(n_epochs) * (size_t)(n_minibatches) + 4 * (size_t)(n_epochs) * (size_t)(n_rows))
 #define ICRL_CN_METRICS 24 /* floats per iteration in the metrics array of icrl_cn_train */
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -249,7 +249,8 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
  *   sync_ws: >= ICRL_PPO_SYNC_BYTES(n_epochs, ceil(T*N / batch_size), T*N) bytes of device scratch: the inter-workgroup granules
  *            (zeroed by the call) + the schedule tables the call fills (per optimiser step: minibatch rows, Adam bias
  *            corrections; per 64-row chunk: permutation offset; the permutations mapped to storage offsets).
- *   hp->_pad: bit 0 = write per-phase cycle counts to stats[12..31] (diagnostic), bit 1 = force the column-split kernel. */
+ *   hp->_pad: bit 0 = write per-phase cycle counts to stats[12..31] (diagnostic); kernel selection (default: wave pairs, two
+ *            waves per SIMD): bit 2 = row-owning waves (one wave per SIMD), bit 1 = the column-split tiles kernel. */
 int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                        const icrl_buffer_t* buf, const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp,
                        float* stats, void* sync_ws, void* stream);
