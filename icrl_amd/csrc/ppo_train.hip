@@ -911,7 +911,7 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
                                   const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, void* stream) {
   if (pol->h1 != HD || pol->h2 != HD || pol->obs_dim > 128 || pol->act_dim > 16 ||
       hp->batch_size < 2 || hp->batch_size > MAXB || hp->n_epochs < 1 || buf->obs_dim != pol->obs_dim || buf->T < 1 ||
-      (long long)buf->T * buf->N >= (1ll << 31))
+      (long long)buf->T * buf->N >= (1ll << 31) || (long long)buf->T * buf->N * (pol->obs_dim > 16 ? pol->obs_dim : 16) >= (1ll << 30))
     return (int)hipErrorInvalidValue;
   TrainArgs a;
   a.L = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);

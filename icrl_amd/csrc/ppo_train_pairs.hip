@@ -259,33 +259,41 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
     asm volatile("" : "+v"(g));
     return *reinterpret_cast<const int2*>(plan_chunks + g);
   };
-  auto chunk_idx = [&](const int2& c) -> int { return gb_row < c.y ? perms[c.x + gb_row] : -1; };      // {perm_base, rows}
+  // Every load of the two index streams is UNCONDITIONAL, at a clamped (always valid) position, and its value is not touched
+  // before the step that consumes it: a load inside an exec-masked branch, or a select on the fresh value, makes the compiler
+  // wait for ALL outstanding vector-memory operations right there (s_waitcnt vmcnt(0)) — i.e. for the row gathers issued a
+  // few instructions earlier, a full trip to the Infinity Cache (~1.2 k cycles per step, measured).  Rows beyond the minibatch
+  // simply re-read its first row; they are masked where it matters (`valid`, stats_partials).
+  auto chunk_idx = [&](const int2& c) -> int { return perms[c.x + (gb_row < c.y ? gb_row : 0)]; };      // {perm_base, rows}
   auto stat_idx = [&](const int4& p) -> int {
-    return (role == 0 && stid >= 0 && stid < (p.z & 0xff)) ? perms[p.w + stid] : -1;
+    const int nbp = p.z & 0xff;
+    return perms[p.w + ((stid >= 0 && stid < nbp) ? stid : 0)];
   };
+  // Rows beyond the minibatch (idx < 0) and observation components beyond obs are fetched from a clamped, always valid address
+  // and staged as they are: a row b >= nrows contributes nothing (its d loss / d output is forced to 0 by `valid`), and the
+  // k >= obs columns of X only ever meet the zero pad columns of W1 (the dW1 step below keeps those at zero).  So the staging
+  // path carries no masks and no branches; offsets are 32-bit element indices (the C ABI checks T * N * obs < 2^30).
   float px[XR], pact[2], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
-  bool pvalid = false;
   auto issue_rows = [&](int idx) {
-    pvalid = idx >= 0;
-    const size_t off = pvalid ? (size_t)idx : 0;
-    const float* orow = p_obs + off * O;
+    const unsigned off = idx >= 0 ? (unsigned)idx : 0u;
+    const unsigned ob = off * (unsigned)O;
 #pragma unroll
-    for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; px[i] = orow[k < O ? k : O - 1]; }
-    if (role == 0) {
-      const float* arow = p_act + off * AS;
+    for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; px[i] = p_obs[ob + (unsigned)(k < O ? k : O - 1)]; }
+    {   // (the critics fetch the action bytes too: two loads are cheaper than a branch in the middle of the load stream)
+      const unsigned ab = off * (unsigned)AS;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; pact[i] = arow[k < AS ? k : AS - 1]; }
+      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; pact[i] = p_act[ab + (unsigned)(k < AS ? k : AS - 1)]; }
     }
     psc0 = p_s0[off]; psc1 = p_s1[off]; psc2 = p_s2[off];
   };
   auto commit_rows = [&](int xbase) {
 #pragma unroll
-    for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; if (k < S::O16) sm[xbase + k * ST + gb_row] = (pvalid && k < O) ? px[i] : 0.f; }
+    for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; if (k < S::O16) sm[xbase + k * ST + gb_row] = px[i]; }
     if (role == 0) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; sm[S::ACT + gb_row * SA + k] = (pvalid && k < AS) ? pact[i] : 0.f; }
+      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; sm[S::ACT + gb_row * SA + k] = k < AS ? pact[i] : 0.f; }   // pad actions are 0
     }
-    if (gpart == 0) { sm[S::OLP + gb_row] = pvalid ? psc0 : 0.f; sm[S::ADR + gb_row] = pvalid ? psc1 : 0.f; sm[S::ADC + gb_row] = pvalid ? psc2 : 0.f; }
+    if (gpart == 0) { sm[S::OLP + gb_row] = psc0; sm[S::ADR + gb_row] = psc1; sm[S::ADC + gb_row] = psc2; }
   };
   float sar = 0.f, sac = 0.f;
   auto issue_stats = [&](int idx) {
@@ -408,6 +416,7 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
         for (int js = 0; js < NT1; ++js)
 #pragma unroll
           for (int e = 0; e < 4; ++e) bx[js][e] = pb[(16 * js + e) * ST];
+        f32x4 z[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * fh + tt;
@@ -415,24 +424,30 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
           f32x4 aw[NT1];
 #pragma unroll
           for (int js = 0; js < NT1; ++js) aw[js] = lds128(pa + 16 * js);
-          f32x4 acc = lds128(sm + S::B1 + 16 * t + 4 * q);      // the bias is the accumulator's initial value
+          z[tt] = lds128(sm + S::B1 + 16 * t + 4 * q);      // the bias is the accumulator's initial value
 #pragma unroll
           for (int js = 0; js < NT1; ++js)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (js < NT1 - 1 || 16 * js + e < O) acc = MFMA_F32(aw[js][e], bx[js][e], acc);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) h1c[tt][i] = fast_tanh(acc[i]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) pt[S::H1T + (16 * t + i) * ST] = h1c[tt][i];
+            for (int e = 0; e < 4; ++e) z[tt] = MFMA_F32(aw[js][e], bx[js][e], z[tt]);     // (k >= obs: zero weights)
         }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) h1c[tt][i] = fast_tanh(z[tt][i]);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pt[S::H1T + (16 * (2 * fh + tt) + i) * ST] = h1c[tt][i];
       }
       FSTAMP(0)   // L1
       // prefetch the next chunk's rows (random 72-byte pieces of the rollout buffer: several microseconds away)
-      issue_rows(idx_next);
-      idx_next = idx_nx2;
-      idx_nx2 = chunk_idx(pc_nx3);
-      pc_nx3 = ld_chunk(g_chunk + 4);
+      {
+        const int idx_now = idx_next;
+        idx_next = idx_nx2;
+        idx_nx2 = chunk_idx(pc_nx3);        // (older loads first: what they wait for arrived a step ago)
+        pc_nx3 = ld_chunk(g_chunk + 4);
+        issue_rows(idx_now);
+      }
       FSTAMP(1)   // row prefetch issue
       pair_signal(); pair_wait();    // (P1) the pair's columns of h1^T are complete
       FSTAMP(2)   // S1
@@ -443,6 +458,7 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
           for (int e = 0; e < 4; ++e) hpart[jj][e] = ph1[(16 * jj + e) * ST];
+        f32x4 z[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * fh + tt;
@@ -451,20 +467,24 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
           f32x4 awo[2], awp[2];
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj) { awo[jj] = lds128(pa + 32 * fh + 16 * jj); awp[jj] = lds128(pa + 32 * (1 - fh) + 16 * jj); }
-          f32x4 acc = lds128(sm + S::B2 + 16 * t + 4 * q);
+          z[tt] = lds128(sm + S::B2 + 16 * t + 4 * q);
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj)      // own half of K first (registers), then the partner's
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = MFMA_F32(awo[jj][e], h1c[jj][e], acc);
+            for (int e = 0; e < 4; ++e) z[tt] = MFMA_F32(awo[jj][e], h1c[jj][e], z[tt]);
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = MFMA_F32(awp[jj][e], hpart[jj][e], acc);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) h2c[tt][i] = fast_tanh(acc[i]);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) pt[S::H2T + (16 * t + i) * ST] = h2c[tt][i];
+            for (int e = 0; e < 4; ++e) z[tt] = MFMA_F32(awp[jj][e], hpart[jj][e], z[tt]);
         }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) h2c[tt][i] = fast_tanh(z[tt][i]);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) pt[S::H2T + (16 * (2 * fh + tt) + i) * ST] = h2c[tt][i];
       }
       FSTAMP(3)   // L2
       {  // head, split over K: this wave's 32 features; partial tiles exchanged through LDS
@@ -721,6 +741,8 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
           for (int js = 0; js < 4; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e) gW1r[cc] = MFMA_F32(az[js][e], bx[js][e], gW1r[cc]);
+          // observation pad columns (k >= obs): X holds unmasked fill there; their weights, gradients and moments stay 0
+          if (ch + 1 == n_chunks && 16 * (NW1 * fh + cc) + r >= O) gW1r[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (low) {
           float s = 0.f;
