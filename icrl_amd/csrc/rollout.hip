@@ -1168,6 +1168,288 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
   }
 }
 
+// =================================================================================================================
+// persistent rollout for MANY environments (128 < N <= 1024, or N x obs > 4096): BASELINE configs[2..4] per-GPU shards
+// =================================================================================================================
+// Same contract as rollout_persistent_kernel (ALL T steps in one launch, buffers / normaliser / agent state bit-identical to
+// the per-step launches), different statistics phase.  Replicating the whole [N, obs] observation block in every workgroup
+// costs N x obs granule reads per workgroup and step (59 k at AntWall x 256); here the float64 statistics are PARTITIONED:
+//   workgroup j < obs        owns observation column j: gathers that column from all N envs (2 N granules), runs numpy's
+//                            axis-0 reduction for it (one sequential chain per column: the order, hence every bit, is kept),
+//                            merges into the running moments and publishes (mean_j, var_j) as 4 granules;
+//   workgroup obs, obs + 1   own ret_rms / cost_rms: discounted returns of all envs, numpy's pairwise sums, merged moments ->
+//                            the two normalisation denominators as granules;
+//   every workgroup          then reads the 4 obs + 4 statistics granules and normalises its own envs.
+// Two hops per step instead of one, but 2 N + 4 obs granules per workgroup instead of N (2 obs + 4).  A workgroup serves
+// E = ceil(N / grid) envs one after the other (grid <= what is co-resident: one workgroup per CU at AntWall widths).
+constexpr int WIDE_E = 4;
+
+struct WideArgs {
+  ActStepArgs act;
+  icrl_norm_t nm;
+  int T, G;                    // steps; grid size (workgroup g serves envs g, g + G, ...)
+  unsigned long long* xg;      // [2][N][2 obs + 4] env granules {step tag | 32 payload bits}, zeroed before the launch
+  unsigned long long* sg;      // [2][4 obs + 4] statistics granules, zeroed before the launch
+};
+
+template <int OCT, int CIT>
+__global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
+  __shared__ ActShared sh[WIDE_E];
+  __shared__ double Bl[MAX_OBS * MAX_ACT];
+  __shared__ double colbuf[NORM_MAX_N + 64], dev2buf[NORM_MAX_N], retbuf[NORM_MAX_N];
+  __shared__ double mean_s[MAX_OBS], var_s[MAX_OBS], dens_s[2];
+  __shared__ double olast[WIDE_E][MAX_OBS], rew_s[WIDE_E];
+  __shared__ float noise_s[2][WIDE_E][MAX_ACT], alow_s[MAX_ACT], ahigh_s[MAX_ACT], cost_s[WIDE_E];
+  __shared__ unsigned ctr_s[WIDE_E];
+  __shared__ int tep_s[WIDE_E], last_done_s[WIDE_E], done_s[WIDE_E], done_all[NORM_MAX_N];
+  const ActStepArgs& a = p.act;
+  const icrl_norm_t& nm = p.nm;
+  PolRegs<OCT> R;
+  CnRegs<CIT> C;
+  load_pol_regs<OCT>(a.pl, a.PT, R);
+  if (threadIdx.x >= 192 && a.has_cn) load_cn_regs<CIT>(a.cn, a.cl, C);
+  const int g = blockIdx.x, G = p.G;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs, T = p.T;
+  const int AS = a.buf.act_store;
+  const int NA = a.pl.discrete ? 1 : A;
+  const int GX = 2 * O + 4, GS = 4 * O + 4;
+  const int E = (N - g + G - 1) / G;                 // envs of this workgroup (>= 1: G <= N)
+  const bool has_cost = a.has_cn != 0;
+  const bool has_box = a.alow != nullptr && a.ahigh != nullptr;
+  icrl_env_t env = a.env;
+  for (int i = tid; i < O * a.env.act_dim; i += 256) Bl[i] = a.env.B[i];
+  env.B = Bl;
+  if (tid < MAX_ACT) { alow_s[tid] = (has_box && tid < A) ? a.alow[tid] : 0.f; ahigh_s[tid] = (has_box && tid < A) ? a.ahigh[tid] : 0.f; }
+  for (int e = 0; e < E; ++e) {
+    const int n = g + e * G;
+    for (int i = tid; i < MAX_OBS; i += 256) {
+      sh[e].x[i] = i < O ? (float)a.ag.last_obs[(size_t)n * O + i] : 0.f;
+      if (i < O) { sh[e].s_old[i] = a.env.s[(size_t)n * O + i]; olast[e][i] = a.ag.last_obs[(size_t)n * O + i]; }
+    }
+    if (tid == 0) { ctr_s[e] = a.env.step_count[n]; tep_s[e] = a.env.t_ep[n]; last_done_s[e] = a.ag.last_dones[n]; }
+  }
+  // owner roles of this workgroup (its wave 1 does the owner work)
+  const int own_col = g < O ? g : -1;
+  const bool own_ret = g == O, own_cost = has_cost && g == O + 1;
+  double o_mean = 0.0, o_var = 1.0, o_cnt = 0.0;         // wave 1: running moments of the owned statistic
+  if (own_col >= 0) { o_mean = nm.obs_mean[own_col]; o_var = nm.obs_var[own_col]; o_cnt = nm.obs_count[0]; }
+  if (own_ret) { o_mean = nm.ret_stats[0]; o_var = nm.ret_stats[1]; o_cnt = nm.ret_stats[2]; }
+  if (own_cost) { o_mean = nm.cost_stats[0]; o_var = nm.cost_stats[1]; o_cnt = nm.cost_stats[2]; }
+  if (own_ret || own_cost)
+    for (int i = tid; i < N; i += 256) retbuf[i] = own_ret ? nm.ret[i] : nm.cost_ret[i];
+  // noise of step 0
+  if (tid < WIDE_E * MAX_ACT) {
+    const int e = tid / MAX_ACT, k = tid % MAX_ACT;
+    if (e < E && k < NA) noise_s[0][e][k] = a.noise[((size_t)(g + e * G)) * NA + k];
+  }
+  int spin_limit = 1 << 22;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int par = t & 1;
+    const unsigned gtag = (unsigned)(t + 1);
+    // prefetch the next step's noise (lands during this step)
+    float noise_next = 0.f;
+    const int pe = tid / MAX_ACT, pk = tid % MAX_ACT;
+    const bool pf = tid < WIDE_E * MAX_ACT && pe < E && pk < NA && t + 1 < T;
+    if (pf) noise_next = a.noise[((size_t)(t + 1) * N + g + pe * G) * NA + pk];
+    // ---------------- phase A: policy forward, env step, cost, buffer rows for each env of this workgroup ----------------
+    for (int e = 0; e < E; ++e) {
+      const int n = g + e * G;
+      const size_t tn = (size_t)t * N + n;
+      policy_forward_block<OCT>(a.pl, R, sh[e], noise_s[par][e], 0, has_box ? alow_s : nullptr, has_box ? ahigh_s : nullptr);
+      __syncthreads();
+      unsigned long long* xg = p.xg + ((size_t)par * N + n) * GX;
+      if (w == 0) {
+        double rew; int done;
+        uint32_t e_ctr = ctr_s[e];
+        int e_tep = tep_s[e];
+        env_step_wave(env, n, sh[e].s_old, sh[e].act_clip, a.env.key[n], e_ctr, e_tep, sh[e].s_new, rew, done);
+        float* nob = a.buf.new_orig_observations + tn * O;
+        for (int i = lane; i < O; i += WAVE) {
+          const double v = sh[e].s_new[i];
+          nob[i] = (float)v;
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+          gstore(xg + 2 * i, gtag, (unsigned)bits); gstore(xg + 2 * i + 1, gtag, (unsigned)(bits >> 32));
+        }
+        if (lane == 0) {
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(rew);
+          gstore(xg + 2 * O, gtag, (unsigned)bits); gstore(xg + 2 * O + 1, gtag, (unsigned)(bits >> 32));
+          gstore(xg + 2 * O + 3, gtag, (unsigned)done);
+          ctr_s[e] = e_ctr; tep_s[e] = e_tep; rew_s[e] = rew; done_s[e] = done;
+        }
+      } else if (w == 3) {
+        float cost = 0.f;
+        if (a.has_cn) cost = cost_forward_wave<CIT>(a.cn, a.cl, C, sh[e].s_old, sh[e].act_clip, sh[e].cx, sh[e].ch);
+        if (lane == 0) {
+          gstore(xg + 2 * O + 2, gtag, __float_as_uint(cost));
+          a.buf.orig_costs[tn] = cost;
+          cost_s[e] = cost;
+        }
+      } else if (w == 2) {
+        float* ob = a.buf.observations + tn * O;
+        float* oob = a.buf.orig_observations + tn * O;
+        for (int i = lane; i < O; i += WAVE) { ob[i] = sh[e].x[i]; oob[i] = (float)sh[e].s_old[i]; }
+        if (lane < AS) a.buf.actions[tn * AS + lane] = sh[e].act_raw[lane];
+        if (lane < A && !a.pl.discrete) a.ag.act_clipped[(size_t)n * A + lane] = sh[e].act_clip[lane];
+        if (lane == 0) {
+          a.buf.dones[tn] = (float)last_done_s[e];
+          a.buf.reward_values[tn] = sh[e].scal[0];
+          a.buf.cost_values[tn] = sh[e].scal[1];
+          a.buf.log_probs[tn] = sh[e].scal[2];
+          a.ag.last_v_r[n] = sh[e].scal[0];
+          a.ag.last_v_c[n] = sh[e].scal[1];
+        }
+      }
+    }
+    // ---------------- phase B1: the owners (wave 1) gather their statistic from all envs and publish it ----------------
+    if (w == 1 && (own_col >= 0 || own_ret || own_cost)) {
+      const unsigned long long* xb = p.xg + (size_t)par * N * GX;
+      const int slot = own_col >= 0 ? 2 * own_col : (own_ret ? 2 * O : 2 * O + 2);
+      const bool wide = !own_cost;                                   // two granules (a float64) per env, or one (the float32 cost)
+      // four blocks of 64 envs per polling round: all their loads are in flight together (one trip through the memory system
+      // per round instead of one per block)
+      for (int i0 = 0; i0 < N; i0 += 4 * WAVE) {
+        unsigned long long g0[4], g1[4], g2[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { g0[k] = g1[k] = g2[k] = 0; ok[k] = i0 + k * WAVE + lane >= N; }
+        for (int spins = 0; spins < spin_limit; ++spins) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * WAVE + lane;
+            if (!ok[k]) {
+              g0[k] = gload(xb + (size_t)i * GX + slot);
+              g1[k] = wide ? gload(xb + (size_t)i * GX + slot + 1) : g0[k];
+              g2[k] = own_col >= 0 ? g0[k] : gload(xb + (size_t)i * GX + 2 * O + 3);      // done flag (return owners)
+            }
+          }
+          bool all = true;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) ok[k] = (unsigned)(g0[k] >> 32) == gtag && (unsigned)(g1[k] >> 32) == gtag && (unsigned)(g2[k] >> 32) == gtag;
+            all = all && ok[k];
+          }
+          if (__all(all)) break;
+          if (spins + 1 == spin_limit) spin_limit = 1;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * WAVE + lane;
+          if (i < N) {
+            double v;
+            if (wide) v = __longlong_as_double((long long)(((unsigned long long)(unsigned)g1[k] << 32) | (unsigned long long)(unsigned)g0[k]));
+            else v = (double)__uint_as_float((unsigned)g0[k]);
+            if (own_col >= 0) colbuf[i] = v;
+            else {
+              const double ret = retbuf[i] * (own_ret ? nm.reward_gamma : nm.cost_gamma) + v;     // vec_normalize.py:102, 245
+              colbuf[i] = ret;
+              done_all[i] = (int)(unsigned)g2[k];
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      double bm, bv;
+      if (own_col >= 0) {
+        column_moments_contig(colbuf, N, bm, bv);                   // every lane computes the same chain (numpy's axis-0 order)
+      } else {
+        bm = np_pairwise_sum(colbuf, N) / (double)N;                // numpy's 1-D pairwise order
+        for (int i = lane; i < N; i += WAVE) { const double d = colbuf[i] - bm; dev2buf[i] = d * d; }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        bv = np_pairwise_sum(dev2buf, N) / (double)N;
+      }
+      chan_merge(o_mean, o_var, o_cnt, bm, bv, (double)N);
+      o_cnt = (double)N + o_cnt;
+      unsigned long long* sb = p.sg + (size_t)par * GS;
+      if (lane == 0) {
+        if (own_col >= 0) {
+          const unsigned long long mb = (unsigned long long)__double_as_longlong(o_mean), vb = (unsigned long long)__double_as_longlong(o_var);
+          gstore(sb + 4 * own_col, gtag, (unsigned)mb); gstore(sb + 4 * own_col + 1, gtag, (unsigned)(mb >> 32));
+          gstore(sb + 4 * own_col + 2, gtag, (unsigned)vb); gstore(sb + 4 * own_col + 3, gtag, (unsigned)(vb >> 32));
+        } else {
+          const unsigned long long db = (unsigned long long)__double_as_longlong(sqrt(o_var + nm.epsilon));
+          const int k = 4 * O + (own_ret ? 0 : 2);
+          gstore(sb + k, gtag, (unsigned)db); gstore(sb + k + 1, gtag, (unsigned)(db >> 32));
+        }
+      }
+      if (own_col < 0)      // returns of finished episodes restart at 0 (vec_normalize.py:99, 241)
+        for (int i = lane; i < N; i += WAVE) retbuf[i] = done_all[i] ? 0.0 : colbuf[i];
+    }
+    // ---------------- phase B2: everybody reads the statistics granules, then normalises its own envs ----------------
+    {
+      const unsigned long long* sb = p.sg + (size_t)par * GS;
+      const int total = has_cost ? GS : GS - 2;
+      unsigned* ms = reinterpret_cast<unsigned*>(mean_s);
+      unsigned* vs = reinterpret_cast<unsigned*>(var_s);
+      unsigned* ds = reinterpret_cast<unsigned*>(dens_s);
+      for (int i0 = 0; i0 < total; i0 += 256) {
+        const int i = i0 + tid;
+        unsigned long long gv = (unsigned long long)gtag << 32;
+        bool ok = i >= total;
+        for (int spins = 0; spins < spin_limit && !ok; ++spins) {
+          gv = gload(sb + i);
+          ok = (unsigned)(gv >> 32) == gtag;
+          if (!ok) __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) spin_limit = 1;
+        if (i < total) {
+          const unsigned pay = (unsigned)gv;
+          if (i < 4 * O) { const int j = i >> 2, h = i & 3; if (h < 2) ms[2 * j + h] = pay; else vs[2 * j + (h - 2)] = pay; }
+          else ds[i - 4 * O] = pay;
+        }
+      }
+    }
+    __syncthreads();
+    for (int e = 0; e < E; ++e) {
+      const int n = g + e * G;
+      const size_t tn = (size_t)t * N + n;
+      if (tid < O) {
+        double o = sh[e].s_new[tid];
+        if (nm.norm_obs) o = fmin(fmax((o - mean_s[tid]) / sqrt(var_s[tid] + nm.epsilon), -nm.clip_obs), nm.clip_obs);
+        olast[e][tid] = o;
+        sh[e].x[tid] = (float)o;
+        a.buf.new_observations[tn * O + tid] = (float)o;
+        sh[e].s_old[tid] = sh[e].s_new[tid];
+      }
+      if (tid == 64) {
+        double r = rew_s[e];
+        if (nm.norm_reward) r = fmin(fmax(r / dens_s[0], -nm.clip_reward), nm.clip_reward);
+        a.buf.rewards[tn] = (float)r;
+        if (has_cost) {
+          double c = (double)cost_s[e];
+          if (nm.norm_cost) c = fmin(fmax(c / dens_s[1], -nm.clip_cost), nm.clip_cost);
+          a.buf.costs[tn] = (float)c;
+        }
+        last_done_s[e] = done_s[e];
+      }
+    }
+    if (pf) noise_s[par ^ 1][pe][pk] = noise_next;
+    __syncthreads();
+  }
+  if (spin_limit == 1 && a.ag.status != nullptr && (tid & 63) == 0) atomicOr(a.ag.status, 1);
+  // ---- leave the agent / wrapper / normaliser state exactly where the per-step path leaves it
+  for (int e = 0; e < E; ++e) {
+    const int n = g + e * G;
+    if (tid < O) a.ag.last_obs[(size_t)n * O + tid] = olast[e][tid];
+    if (tid == 0) {
+      a.ag.last_dones[n] = (uint8_t)last_done_s[e];
+      a.ag.raw_rew[n] = rew_s[e]; a.ag.dones[n] = (uint8_t)done_s[e];
+      if (has_cost) a.ag.raw_cost[n] = cost_s[e];
+    }
+  }
+  if (w == 1 && lane == 0) {
+    if (own_col >= 0) { nm.obs_mean[own_col] = o_mean; nm.obs_var[own_col] = o_var; if (own_col == 0) nm.obs_count[0] = o_cnt; }
+    if (own_ret) { nm.ret_stats[0] = o_mean; nm.ret_stats[1] = o_var; nm.ret_stats[2] = o_cnt; }
+    if (own_cost) { nm.cost_stats[0] = o_mean; nm.cost_stats[1] = o_var; nm.cost_stats[2] = o_cnt; }
+  }
+  if (w == 1 && (own_ret || own_cost))
+    for (int i = lane; i < N; i += WAVE) { if (own_ret) nm.ret[i] = retbuf[i]; else nm.cost_ret[i] = retbuf[i]; }
+}
+
 // VecNormalizeWithCost.reset (vec_normalize.py:148-157, 270-278)
 __global__ void __launch_bounds__(1024) norm_reset_kernel(icrl_norm_t nm, const double* raw_obs, int N, int O,
                                                           double* obs_out) {
@@ -1510,17 +1792,49 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
   a.PT = pol->params_t; a.noise = noise; a.alow = action_low; a.ahigh = action_high;
   a.has_cn = cn != nullptr;
   if (cn) { a.cn = *cn; a.cl = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2); }
+  // many environments: persistent launch with the statistics partitioned by observation column (rollout_wide_kernel)
+  if (!(do_gae & 2) && nm->training && (N > 128 || N * O > NORM_CHUNK) && N <= NORM_MAX_N && O * env->act_dim <= MAX_OBS * MAX_ACT && T >= 1) {
+    const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
+    const void* kfn = small ? (const void*)rollout_wide_kernel<2, 2> : (const void*)rollout_wide_kernel<8, 10>;
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, 0) == hipSuccess && per_cu > 0) {
+      const int max_g = per_cu * cus;
+      const int E = (N + max_g - 1) / max_g;                 // envs per workgroup
+      const int G = (N + E - 1) / E;                         // balanced grid
+      const size_t GX = 2 * (size_t)O + 4, GS = 4 * (size_t)O + 4;
+      const size_t need = 16 * (size_t)N * GX + 16 * GS + 256;
+      void* ws = (ag->xch_ws != nullptr && (size_t)ag->xch_ws_bytes >= need) ? ag->xch_ws
+                 : ((size_t)T * N * sizeof(float) >= need ? (void*)buf->reward_advantages : nullptr);
+      if (E <= WIDE_E && G >= O + 2 && ws != nullptr) {
+        WideArgs p;
+        p.act = a; p.nm = *nm; p.T = T; p.G = G;
+        p.xg = reinterpret_cast<unsigned long long*>(ws);
+        p.sg = p.xg + 2 * (size_t)N * GX;
+        hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
+        if (e != hipSuccess) return (int)e;
+        if (small) hipLaunchKernelGGL((rollout_wide_kernel<2, 2>), dim3(G), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((rollout_wide_kernel<8, 10>), dim3(G), dim3(256), 0, s, p);
+        int err = (int)hipGetLastError();
+        if (err || !(do_gae & 1)) return err;
+        return icrl_gae_dual(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
+                             ag->last_v_c, ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns,
+                             buf->cost_returns, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, stream);
+      }
+    }
+  }
   // persistent path: one launch for all T steps (see rollout_persistent_kernel).  Its exchange arrays live in the not yet
   // computed reward_advantages plane of the buffer (GAE fills that afterwards).  do_gae & 2 forces the per-step launches.
   {
     const int G = 2 * O + 4;
     const bool gran = (size_t)N * G <= (size_t)256 * GRAN_MAX;
     const size_t need = (size_t)16 * N * O + (size_t)16 * N + (size_t)8 * N + (size_t)8 * N + 1024 + (gran ? (size_t)16 * N * G : 0);
-    if (!(do_gae & 2) && N <= 128 && N * O <= NORM_CHUNK && O * env->act_dim <= MAX_OBS * MAX_ACT && T >= 1 &&
-        (size_t)T * N * sizeof(float) >= need) {
+    char* ws = (ag->xch_ws != nullptr && (size_t)ag->xch_ws_bytes >= need) ? reinterpret_cast<char*>(ag->xch_ws)
+               : ((size_t)T * N * sizeof(float) >= need ? reinterpret_cast<char*>(buf->reward_advantages) : nullptr);
+    if (!(do_gae & 2) && N <= 128 && N * O <= NORM_CHUNK && O * env->act_dim <= MAX_OBS * MAX_ACT && T >= 1 && ws != nullptr) {
       PersistArgs p;
       p.act = a; p.nm = *nm; p.T = T; p.prof = (do_gae & 4) != 0;
-      char* base = reinterpret_cast<char*>(buf->reward_advantages);
+      char* base = ws;
       p.xch_obs = reinterpret_cast<double*>(base); base += (size_t)16 * N * O;
       p.xch_rew = reinterpret_cast<double*>(base); base += (size_t)16 * N;
       p.xch_cost = reinterpret_cast<float*>(base); base += (size_t)8 * N;

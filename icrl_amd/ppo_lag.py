@@ -109,7 +109,10 @@ class PPOLagrangian:
         self._ag = dict(last_dones=torch.zeros(N, dtype=torch.uint8, device=dev), raw_rew=torch.zeros(N, dtype=torch.float64, device=dev),
                         raw_cost=torch.zeros(N, device=dev), dones=torch.zeros(N, dtype=torch.uint8, device=dev),
                         last_v_r=torch.zeros(N, device=dev), last_v_c=torch.zeros(N, device=dev),
-                        act_clipped=torch.zeros(N, A, device=dev), status=torch.zeros(1, dtype=torch.int32, device=dev))
+                        act_clipped=torch.zeros(N, A, device=dev), status=torch.zeros(1, dtype=torch.int32, device=dev),
+                        # exchange workspace of the persistent rollout: ICRL_ROLLOUT_WS_BYTES(N, obs)
+                        xch_ws=torch.zeros((16 * N * (2 * self.observation_space.shape[0] + 4) + 16 * (4 * self.observation_space.shape[0] + 4) + 1024) // 8 + 1,
+                                           dtype=torch.int64, device=dev))
         if isinstance(self.action_space, spaces.Box):
             self._alow = torch.as_tensor(self.action_space.low, device=dev).float().contiguous()
             self._ahigh = torch.as_tensor(self.action_space.high, device=dev).float().contiguous()
@@ -156,7 +159,8 @@ class PPOLagrangian:
             noise = self._draw_action_noise(n_rollout_steps)
         e, nm, pol, cn, buf = senv.struct(), nenv.struct(), self.policy.struct(), cw.constraint_net().struct(), rollout_buffer.struct()
         ag = AgentT(p(self._last_obs), p(self._ag["last_dones"]), p(self._ag["raw_rew"]), p(self._ag["raw_cost"]), p(self._ag["dones"]),
-                    p(self._ag["last_v_r"]), p(self._ag["last_v_c"]), p(self._ag["act_clipped"]), p(self._ag["status"]))
+                    p(self._ag["last_v_r"]), p(self._ag["last_v_c"]), p(self._ag["act_clipped"]), p(self._ag["status"]),
+                    p(self._ag["xch_ws"]), self._ag["xch_ws"].numel() * 8)
         b = _lib.byref
         timed = getattr(self, "gae_events", None) is not None
         _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn), b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),

@@ -40,7 +40,7 @@ class BufferT(C.Structure):
 
 class AgentT(C.Structure):
     _fields_ = [("last_obs", vp), ("last_dones", vp), ("raw_rew", vp), ("raw_cost", vp), ("dones", vp),
-                ("last_v_r", vp), ("last_v_c", vp), ("act_clipped", vp), ("status", vp)]
+                ("last_v_r", vp), ("last_v_c", vp), ("act_clipped", vp), ("status", vp), ("xch_ws", vp), ("xch_ws_bytes", C.c_longlong)]
 
 
 class PpoHyperT(C.Structure):

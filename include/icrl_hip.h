@@ -113,7 +113,11 @@ typedef struct {
   float* act_clipped;    /* [N,act] scratch: action handed to the env */
   int* status;           /* [1] or NULL: the persistent rollout ORs bit 0 into it when an inter-workgroup exchange timed out
                           * (a workgroup was not resident); the buffer contents are then invalid and the caller must raise */
+  void* xch_ws;          /* optional exchange workspace of the persistent rollout (device memory, any contents) ... */
+  long long xch_ws_bytes;/* ... and its size; >= ICRL_ROLLOUT_WS_BYTES(N, obs) always suffices.  NULL / too small: the not yet
+                          * computed reward_advantages plane of the buffer is used when T is large enough, else per-step launches */
 } icrl_agent_t;
+#define ICRL_ROLLOUT_WS_BYTES(n_envs, obs_dim) (16 * (size_t)(n_envs) * (2 * (size_t)(obs_dim) + 4) + 16 * (4 * (size_t)(obs_dim) + 4) + 1024)
 
 /* PPO-Lagrangian update hyper-parameters (stable_baselines3/ppo_lag/ppo_lag.py:67-103,177-196; Adam eps 1e-5 from
  * common/policies.py:357-361). */

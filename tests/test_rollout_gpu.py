@@ -236,16 +236,18 @@ def test_fused_rollout_vs_port(kind, N, T):
     assert env.obs_rms.count == stack.norm.obs_rms.count
 
 
-def _pair_of_agents(N, T, seed):
+def _pair_of_agents(N, T, seed, kind="hc", broken=False):
     from icrl_amd.ppo_lag import PPOLagrangian
     from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
     from icrl_amd.constraint_net import ConstraintNet
     out = []
-    lo = -np.ones(6, np.float32)
+    od, ad = (18, 6) if kind == "hc" else (113, 8)
+    hid = [20] if kind == "hc" else [40, 40]
+    lo = -np.ones(ad, np.float32)
     for _ in range(2):
         torch.manual_seed(seed)
-        env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, "hc", seed)))
-        cn = ConstraintNet(18, 6, [20], None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
+        env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, kind, seed, broken=broken)))
+        cn = ConstraintNet(od, ad, hid, None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
         env.set_cost_function(cn.cost_function)
         out.append((PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=seed), env, cn))
     out[1][2].load_state_dict(out[0][2].state_dict())
@@ -332,20 +334,28 @@ def test_analytic_env_cost_through_cost_wrapper():
     assert get_true_cost_function("HCWithPosTest-v0")(np.array([[-3.5, 0.0]]), None)[0]
 
 
-@pytest.mark.parametrize("N,T", [(64, 300), (7, 33), (128, 20)])
-def test_persistent_rollout_equals_per_step_launches(N, T):
-    """the one-launch rollout (device-wide barrier per step, replicated normaliser statistics) against the launch pair per
+# N <= 128: rollout_persistent_kernel (statistics replicated per workgroup); beyond: rollout_wide_kernel (statistics partitioned by
+# observation column, two hops per step; 512 envs = two envs per workgroup).  hc 256 / ant 256 / antbroken 512 are the per-GPU
+# shards of BASELINE configs[3], [2] and [4].
+@pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("hc", 7, 33), ("hc", 128, 20), ("hc", 256, 40), ("hc", 130, 24), ("ant", 256, 12),
+                                      ("antbroken", 512, 10), ("hc", 1000, 6)])
+def test_persistent_rollout_equals_per_step_launches(kind, N, T):
+    """the one-launch rollout (device-wide exchange per step inside the kernel) against the launch pair per
     step: every buffer plane, the normaliser state and the agent's carry-over state are bit-identical, across two
     consecutive rollouts and across episode ends."""
-    (a_p, e_p, _), (a_s, e_s, _) = _pair_of_agents(N, T, 13)
+    ekind = "ant" if kind == "antbroken" else kind
+    ad = 6 if ekind == "hc" else 8
+    limit = 1000 if ekind == "hc" else 500
+    (a_p, e_p, _), (a_s, e_s, _) = _pair_of_agents(N, T, 13, ekind, broken=kind == "antbroken")
     a_s.rollout_kernel = "steps"
-    noise = torch.as_tensor(np.random.RandomState(8).randn(2, T, N, 6).astype(np.float32), device="cuda")
+    noise = torch.as_tensor(np.random.RandomState(8).randn(2, T, N, ad).astype(np.float32), device="cuda")
     a_p._setup_learn(2 * N * T); a_s._setup_learn(2 * N * T)
     for env in (e_p, e_s):
-        env.unwrapped.t_ep.fill_(1000 - T // 2)           # every env crosses its time limit inside the first rollout
+        env.unwrapped.t_ep.fill_(limit - T // 2)           # every env crosses its time limit inside the first rollout
     for it in range(2):
         a_p.collect_rollouts(e_p, None, a_p.rollout_buffer, T, "cost", noise=noise[it])
         a_s.collect_rollouts(e_s, None, a_s.rollout_buffer, T, "cost", noise=noise[it])
+        a_p.check_rollout_status()
         for k in _BUF_KEYS:
             got, ref = getattr(a_p.rollout_buffer, k).cpu().numpy(), getattr(a_s.rollout_buffer, k).cpu().numpy()
             assert np.array_equal(got, ref), (it, k, np.abs(got - ref).max())
