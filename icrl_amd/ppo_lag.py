@@ -135,8 +135,10 @@ class PPOLagrangian:
         disc = isinstance(self.action_space, spaces.Discrete)
         shape = (T, N) if disc else (T, N, self.action_space.shape[0])
         if self.streams is not None:
-            noise = np.asarray(self.streams.rollout_noise(T, N, 1 if disc else shape[2]), np.float32)
-            return torch.as_tensor(noise, device=self.device).reshape(shape).contiguous()
+            noise = self.streams.rollout_noise(T, N, 1 if disc else shape[2])
+            if not torch.is_tensor(noise):
+                noise = torch.as_tensor(np.asarray(noise, np.float32), device=self.device)
+            return noise.to(device=self.device, dtype=torch.float32).reshape(shape).contiguous()
         if callable(self.action_noise):
             return torch.as_tensor(np.asarray(self.action_noise(*shape), np.float32), device=self.device).reshape(shape).contiguous()
         if self.action_noise == "torch_cpu":        # one generator call per env step, like Normal.rsample in the reference
@@ -163,11 +165,13 @@ class PPOLagrangian:
                     p(self._ag["xch_ws"]), self._ag["xch_ws"].numel() * 8)
         b = _lib.byref
         timed = getattr(self, "gae_events", None) is not None
-        _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn), b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
-                                                      float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
-                                                      float(self.cost_gae_lambda), int(not timed) | (2 if getattr(self, "rollout_kernel", "auto") == "steps" else 0) | (4 if getattr(self, "profile_phases", 0) else 0),
-                                                      _lib.current_stream()),
-                   "icrl_rollout_collect")
+        flags = int(not timed) | (2 if getattr(self, "rollout_kernel", "auto") == "steps" else 0) | (4 if getattr(self, "profile_phases", 0) else 0)
+        from .seed_batch import budgeted
+        with budgeted(0 if flags & 2 else self.n_envs):      # persistent launch: one CU per environment (several runs on one GPU)
+            _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn), b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
+                                                          float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
+                                                          float(self.cost_gae_lambda), flags, _lib.current_stream()),
+                       "icrl_rollout_collect")
         if timed:   # bench.py: the same GAE launch, bracketed by events on the stream it runs on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -395,8 +399,10 @@ class PPOLagrangian:
         if getattr(self, "train_events", None) is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        _lib.check(_lib.lib().icrl_ppo_lag_train(b(ps), p(pol.exp_avg), p(pol.exp_avg_sq), p(ws["t"]), b(bs), p(perms), p(ws["nu"]),
-                                                 b(hp), p(ws["stats"]), p(ws["sync"]), _lib.current_stream()), "icrl_ppo_lag_train")
+        from .seed_batch import budgeted
+        with budgeted(3):                                    # three persistent workgroups, a CU each
+            _lib.check(_lib.lib().icrl_ppo_lag_train(b(ps), p(pol.exp_avg), p(pol.exp_avg_sq), p(ws["t"]), b(bs), p(perms), p(ws["nu"]),
+                                                     b(hp), p(ws["stats"]), p(ws["sync"]), _lib.current_stream()), "icrl_ppo_lag_train")
         if ev is not None:
             ev[1].record()
         pol.prepare()                                   # refresh the transposed copy for the next rollout

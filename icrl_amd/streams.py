@@ -1,0 +1,39 @@
+"""Per-run random streams (host side).
+
+By default a run draws from the process-wide generators exactly like the reference (torch for action noise, numpy for
+minibatch permutations, common/utils.py:23-39).  When several independent runs share one process (icrl_amd/seed_batch.py)
+each needs generators of its own, otherwise the runs' draws interleave and no run is reproducible: PrivateStreams answers the
+`streams` protocol of PPOLagrangian / icrl.outer_iteration (rollout_noise, permutation, consumed, sample_noise, eval_noise —
+the protocol the parity tests use for teacher forcing, oracle/streams.py) from a private device generator and a private numpy
+RandomState seeded with the run's seed.
+"""
+import numpy as np
+import torch
+
+
+class PrivateStreams:
+    def __init__(self, seed, device="cuda", discrete=False):
+        self.device, self.discrete = torch.device(device), discrete
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(int(seed))
+        self.np = np.random.RandomState(int(seed))
+
+    def _draw(self, *shape):
+        if self.discrete:
+            return torch.rand(shape[:-1], device=self.device, generator=self.gen)
+        return torch.randn(shape, device=self.device, generator=self.gen)
+
+    def rollout_noise(self, T, N, A):
+        return self._draw(T, N, A)
+
+    def permutation(self, epoch, n):
+        return self.np.permutation(n)
+
+    def consumed(self, executed_epochs):
+        pass
+
+    def sample_noise(self, rows, A):
+        return self._draw(rows, A)
+
+    def eval_noise(self, rows, A):
+        return self._draw(rows, A)

@@ -23,6 +23,11 @@ def make_train_env(env_id, save_dir, use_cost_wrapper, base_seed=0, num_threads=
                    normalize_cost=True, env_index_offset=0, device="cuda", **kwargs):
     """ref: icrl/utils.py:265-288.  SubprocVecEnv[num_threads] of gym envs -> one batched device env; env i is seeded
     base_seed + env_index_offset + i (the offset shards envs across GPUs)."""
+    # ref: icrl/utils.py:256-263 — make_env() calls set_random_seed(base_seed) (common/utils.py:23-39): python, numpy and torch
+    # generators are seeded HERE, so whatever is built next without a seed of its own (the ConstraintNet, icrl.py:88-117) is
+    # initialised reproducibly per seed
+    import random
+    random.seed(base_seed); np.random.seed(base_seed); torch.manual_seed(base_seed)
     env = HipSynthVecEnv.make(env_id, num_threads, base_seed, device, env_index_offset=env_index_offset)
     if use_cost_wrapper:
         env = VecCostWrapper(env)
