@@ -232,7 +232,8 @@ __device__ __forceinline__ void load_cn_regs(const icrl_costnet_t& cn, const CnL
 // acs_row: float32 actions.  cx: >= 16*CIT floats (16-byte aligned), ch: [2][MAX_H].  Returns the cost in every lane.
 template <int CIT>
 __device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, const CnLayout& L, const CnRegs<CIT>& R,
-                                                   const double* obs_row, const float* acs_row, float* cx, float (*ch)[MAX_H]) {
+                                                   const double* obs_row, const float* acs_row, float* cx, float (*ch)[MAX_H],
+                                                   int mode = 0 /* 0: cost = 1 - zeta; 1: zeta; 2: log(zeta + eps) */) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
   for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) {
@@ -285,6 +286,8 @@ __device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, con
   float part = lane < L.H2 ? R.wo * ch[last][lane] : 0.f;
   const float z = wave_sum_fast(part) + R.bo;
   const float zeta = 1.f / (1.f + expf(-z));
+  if (mode == 1) return zeta;
+  if (mode == 2) return logf(zeta + (float)cn.eps);
   return 1.f - zeta;
 }
 
@@ -1507,14 +1510,14 @@ __global__ void __launch_bounds__(192) policy_forward_kernel(PolLayout pl, const
 
 template <int CIT>
 __global__ void __launch_bounds__(64) cost_forward_kernel(icrl_costnet_t cn, CnLayout cl, const double* obs,
-                                                          const float* acs, int N, float* cost) {
+                                                          const float* acs, int N, float* cost, int mode = 0) {
   __shared__ __attribute__((aligned(16))) float cx[MAX_CN_IN];
   __shared__ __attribute__((aligned(16))) float ch[2][MAX_H];
   CnRegs<CIT> C;
   load_cn_regs<CIT>(cn, cl, C);
   const int n = blockIdx.x;
   const int AS = cn.is_discrete ? 1 : cn.acs_dim;
-  const float c = cost_forward_wave<CIT>(cn, cl, C, obs + (size_t)n * cn.obs_dim, acs + (size_t)n * AS, cx, ch);
+  const float c = cost_forward_wave<CIT>(cn, cl, C, obs + (size_t)n * cn.obs_dim, acs + (size_t)n * AS, cx, ch, mode);
   if (threadIdx.x == 0) cost[n] = c;
 }
 
@@ -1721,8 +1724,18 @@ extern "C" int icrl_cost_mlp_forward(const icrl_costnet_t* cn, const double* obs
                                      void* stream) {
   if (N <= 0 || !cn_ok(cn)) return (int)hipErrorInvalidValue;
   CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
-  if (cn->in_dim <= 32) hipLaunchKernelGGL(cost_forward_kernel<2>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost);
-  else hipLaunchKernelGGL(cost_forward_kernel<10>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost);
+  if (cn->in_dim <= 32) hipLaunchKernelGGL(cost_forward_kernel<2>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost, 0);
+  else hipLaunchKernelGGL(cost_forward_kernel<10>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost, 0);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_disc_reward(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, int apply_log,
+                                void* stream) {
+  if (N <= 0 || !cn_ok(cn)) return (int)hipErrorInvalidValue;
+  CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
+  const int mode = apply_log ? 2 : 1;
+  if (cn->in_dim <= 32) hipLaunchKernelGGL(cost_forward_kernel<2>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, out, mode);
+  else hipLaunchKernelGGL(cost_forward_kernel<10>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, out, mode);
   return (int)hipGetLastError();
 }
 

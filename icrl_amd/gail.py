@@ -1,0 +1,149 @@
+"""gail — the GAIL-constraint baseline of the paper's comparison (`python run_me.py gail <flags>`).
+
+ref: icrl/gail.py:48-208 (gail), :210-330 (flag set).  Plain PPO on an env chain WITHOUT a cost wrapper; after every rollout the
+GailCallback (icrl_amd/gail_utils.py) trains the discriminator on (rollout, expert) and relabels the rollout's rewards with
+log D (added to the env reward with --learn_cost, -lc, as in the README commands).
+
+PPO here is PPOLagrangian with the cost path switched off: costs are identically 0 (no cost wrapper), nu ~ 1e-8
+(penalty_initial_value 0), cost_vf_coef 0 — PPO.train (ppo/ppo.py:150-215) is PPOLagrangian.train (ppo_lag.py:196-299) minus
+the cost term, so the same update kernel computes it; the idle cost critic receives zero gradients and never changes
+(tests/golden/g12_gail.npz pins this against the reference's own PPO).
+"""
+import argparse
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+
+from . import callbacks, distributed as D, logger, spaces, utils
+from .gail_utils import GailCallback, GailDiscriminator
+from .ppo_lag import PPOLagrangian
+from .true_constraint_net import get_true_cost_function
+
+
+class PPO(PPOLagrangian):
+    """ref: stable_baselines3/ppo/ppo.py:17-147 — constructor names of plain PPO (gamma, gae_lambda, clip_range_vf, vf_coef)."""
+
+    def __init__(self, policy, env, learning_rate=3e-4, n_steps=2048, batch_size=64, n_epochs=10, gamma=0.99, gae_lambda=0.95,
+                 clip_range=0.2, clip_range_vf=None, ent_coef=0.0, vf_coef=0.5, max_grad_norm=0.5, use_sde=False, sde_sample_freq=-1,
+                 target_kl=None, policy_kwargs=None, verbose=0, seed=None, device="cuda", **kw):
+        if policy in ("MlpPolicy",):
+            policy = "TwoCriticsMlpPolicy"          # same policy / value networks; the (idle) cost critic rides along
+        super().__init__(policy, env, learning_rate=learning_rate, n_steps=n_steps, batch_size=batch_size, n_epochs=n_epochs,
+                         reward_gamma=gamma, reward_gae_lambda=gae_lambda, cost_gamma=gamma, cost_gae_lambda=gae_lambda,
+                         clip_range=clip_range, clip_range_reward_vf=clip_range_vf, ent_coef=ent_coef, reward_vf_coef=vf_coef,
+                         cost_vf_coef=0.0, max_grad_norm=max_grad_norm, use_sde=use_sde, sde_sample_freq=sde_sample_freq,
+                         target_kl=target_kl, penalty_initial_value=0.0, penalty_learning_rate=0.0, budget=0.0,
+                         policy_kwargs=policy_kwargs, verbose=verbose, seed=seed, device=device, **kw)
+
+
+def gail(config, log=print):
+    logger.configure()
+    rank = getattr(config, "rank", 0)
+    dev = config.device if str(config.device).startswith("cuda") else "cuda"
+    train_env = utils.make_train_env(env_id=config.train_env_id, save_dir=config.save_dir, use_cost_wrapper=False,
+                                     base_seed=config.seed, num_threads=config.num_threads,
+                                     normalize_obs=not config.dont_normalize_obs, normalize_reward=not config.dont_normalize_reward,
+                                     normalize_cost=False, reward_gamma=config.reward_gamma,
+                                     env_index_offset=rank * config.num_threads, device=dev)
+    eval_env = utils.make_eval_env(env_id=config.eval_env_id, use_cost_wrapper=False, normalize_obs=not config.dont_normalize_obs,
+                                   seed=config.seed + rank * config.num_threads, device=dev)
+    is_discrete = isinstance(train_env.action_space, spaces.Discrete)
+    obs_dim = train_env.observation_space.shape[0]
+    acs_dim = train_env.action_space.n if is_discrete else train_env.action_space.shape[0]
+    action_low = action_high = None
+    if isinstance(train_env.action_space, spaces.Box):
+        action_low, action_high = train_env.action_space.low, train_env.action_space.high
+    (expert_obs, expert_acs), _ = utils.load_expert_data(config.expert_path, config.expert_rollouts)
+    if config.gail_path is not None:
+        discriminator = GailDiscriminator.load(config.gail_path, obs_dim=obs_dim, acs_dim=acs_dim, is_discrete=is_discrete,
+                                               expert_obs=expert_obs, expert_acs=expert_acs,
+                                               obs_select_dim=config.disc_obs_select_dim, acs_select_dim=config.disc_acs_select_dim,
+                                               clip_obs=None, obs_mean=None, obs_var=None, action_low=action_low, action_high=action_high)
+        discriminator.freeze_weights = config.freeze_gail_weights
+    else:
+        discriminator = GailDiscriminator(obs_dim, acs_dim, config.disc_layers, config.disc_batch_size, (lambda _p: config.disc_learning_rate),
+                                          expert_obs, expert_acs, is_discrete, config.disc_obs_select_dim, config.disc_acs_select_dim,
+                                          clip_obs=config.clip_obs, action_low=action_low, action_high=action_high,
+                                          num_spurious_features=config.num_spurious_features, freeze_weights=config.freeze_gail_weights,
+                                          eps=config.disc_eps, device=dev)
+    if getattr(config, "use_cost_shaping_callback", False):
+        raise NotImplementedError("--use_cost_shaping_callback (a shaping ablation of the reference) is outside the hot path")
+    gail_update = GailCallback(discriminator, config.learn_cost, get_true_cost_function(config.eval_env_id), config.save_dir)
+    model = PPO(policy=config.policy_name, env=train_env, learning_rate=config.learning_rate, n_steps=config.n_steps,
+                batch_size=config.batch_size, n_epochs=config.n_epochs, gamma=config.reward_gamma, gae_lambda=config.reward_gae_lambda,
+                clip_range=config.clip_range, clip_range_vf=config.clip_range_reward_vf, ent_coef=config.ent_coef,
+                vf_coef=config.reward_vf_coef, max_grad_norm=config.max_grad_norm, use_sde=config.use_sde,
+                sde_sample_freq=config.sde_sample_freq, target_kl=config.target_kl, seed=config.seed, device=dev, verbose=config.verbose,
+                policy_kwargs=dict(net_arch=[dict(pi=list(config.policy_layers), vf=list(config.reward_vf_layers), cvf=list(config.reward_vf_layers))]),
+                action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"),
+                streams=getattr(config, "streams", None))
+    cbs = [gail_update]
+    if config.save_dir and rank == 0:
+        cbs.append(callbacks.CheckpointCallback(int(config.save_every), os.path.join(config.save_dir, "models"), verbose=0))
+    cbs.append(callbacks.EvalCallback(eval_env, eval_freq=int(config.eval_every), deterministic=False, verbose=0,
+                                      best_model_save_path=config.save_dir if rank == 0 else None,
+                                      callback_on_new_best=callbacks.SaveEnvStatsCallback(train_env, config.save_dir if rank == 0 else None)))
+    model.learn(total_timesteps=int(config.timesteps), callback=callbacks.CallbackList(cbs))
+    if config.save_dir and rank == 0:
+        if not config.freeze_gail_weights:
+            discriminator.save(os.path.join(config.save_dir, "gail_discriminator.pt"))
+        train_env.save(os.path.join(config.save_dir, "train_env_stats.pkl"))
+    return model, discriminator, gail_update.history
+
+
+def build_parser():
+    """flag set of the reference's gail (icrl/gail.py:210-330)."""
+    p = argparse.ArgumentParser()
+    a = p.add_argument
+    a("file_to_run", type=str, nargs="?", default="gail")
+    a("--config_file", "-cf", type=str, default=None); a("--project", "-p", type=str, default="ABC"); a("--group", "-g", type=str, default=None)
+    a("--name", "-n", type=str, default=None); a("--device", "-d", type=str, default="cuda"); a("--verbose", "-v", type=int, default=2)
+    a("--wandb_sweep", "-ws", type=bool, default=False); a("--sync_wandb", "-sw", action="store_true")
+    a("--cost_info_str", "-cis", type=str, default="cost")
+    a("--train_env_id", "-tei", type=str, default="HCWithPos-v0"); a("--eval_env_id", "-eei", type=str, default="HCWithPosTest-v0")
+    a("--dont_normalize_obs", "-dno", action="store_true"); a("--dont_normalize_reward", "-dnr", action="store_true")
+    a("--seed", "-s", type=int, default=None)
+    a("--policy_name", "-pn", type=str, default="MlpPolicy"); a("--shared_layers", "-sl", type=int, default=None, nargs="*")
+    a("--policy_layers", "-pl", type=int, default=[64, 64], nargs="*"); a("--reward_vf_layers", "-rl", type=int, default=[64, 64], nargs="*")
+    a("--timesteps", "-t", type=lambda x: int(float(x)), default=1e6); a("--n_steps", "-ns", type=int, default=2048)
+    a("--batch_size", "-bs", type=int, default=64); a("--n_epochs", "-ne", type=int, default=10); a("--num_threads", "-nt", type=int, default=5)
+    a("--save_every", "-se", type=float, default=5e5); a("--eval_every", "-ee", type=float, default=2048); a("--plot_every", "-pe", type=float, default=2048)
+    a("--reward_gamma", "-rg", type=float, default=0.99); a("--reward_gae_lambda", "-rgl", type=float, default=0.95)
+    a("--clip_range", "-cr", type=float, default=0.2); a("--clip_range_reward_vf", "-crv", type=float, default=None)
+    a("--ent_coef", "-ec", type=float, default=0.); a("--reward_vf_coef", "-rvc", type=float, default=0.5)
+    a("--target_kl", "-tk", type=float, default=None); a("--max_grad_norm", "-mgn", type=float, default=0.5)
+    a("--learning_rate", "-lr", type=float, default=3e-4); a("--use_sde", "-us", action="store_true"); a("--sde_sample_freq", "-ssf", type=int, default=-1)
+    a("--freeze_gail_weights", "-fgw", action="store_true"); a("--gail_path", "-gp", type=str, default=None)
+    a("--learn_cost", "-lc", action="store_true"); a("--disc_layers", "-dl", type=int, default=[64, 64], nargs="*")
+    a("--disc_learning_rate", "-dlr", type=float, default=3e-4); a("--disc_batch_size", "-dbs", type=int, default=None)
+    a("--disc_obs_select_dim", "-dosd", type=int, default=None, nargs="+"); a("--disc_acs_select_dim", "-dasd", type=int, default=None, nargs="+")
+    a("--disc_plot_every", "-dpe", type=int, default=1); a("--disc_normalize", "-cn", action="store_true"); a("--disc_eps", "-de", type=float, default=1e-5)
+    a("--clip_obs", "-co", type=int, default=20)
+    a("--expert_path", "-ep", type=str, default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests/golden/expert_hc.npz"))
+    a("--expert_rollouts", "-er", type=int, default=20); a("--num_spurious_features", "-nsf", type=int, default=None)
+    a("--use_cost_shaping_callback", "-ucsc", action="store_true"); a("--use_cost_net", "-ucn", action="store_true")
+    a("--save_dir", type=str, default=None); a("--action_noise", type=str, default="device"); a("--permutation", type=str, default="numpy")
+    return p
+
+
+def main(argv=None):
+    start = time.time()
+    config = vars(build_parser().parse_args(argv if argv is not None else sys.argv[1:]))
+    rank, world = D.init_from_env()
+    if config["seed"] is None and rank == 0:
+        config["seed"] = int(np.random.randint(0, 100))
+    config["seed"] = D.broadcast_seed(config["seed"], rank, world)
+    config["rank"], config["world_size"] = rank, world
+    if config["save_dir"]:
+        os.makedirs(config["save_dir"], exist_ok=True)
+    gail(types.SimpleNamespace(**config))
+    if rank == 0:
+        print("Time taken: %05.2f hours" % ((time.time() - start) / 3600))
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,8 @@ class PPOLagrangian:
         if not isinstance(env, VecNormalizeWithCost):
             return None
         cw = env.venv
+        if isinstance(cw, HipSynthVecEnv):           # no cost wrapper in the chain (the GAIL baseline, icrl/gail.py:50-59): costs are 0
+            return env, None, cw
         if not isinstance(cw, VecCostWrapper) or not isinstance(cw.venv, HipSynthVecEnv) or cw.constraint_net() is None:
             return None
         return env, cw, cw.venv
@@ -159,7 +161,8 @@ class PPOLagrangian:
         nenv, cw, senv = chain
         if noise is None:
             noise = self._draw_action_noise(n_rollout_steps)
-        e, nm, pol, cn, buf = senv.struct(), nenv.struct(), self.policy.struct(), cw.constraint_net().struct(), rollout_buffer.struct()
+        e, nm, pol, buf = senv.struct(), nenv.struct(), self.policy.struct(), rollout_buffer.struct()
+        cn = cw.constraint_net().struct() if cw is not None else None
         ag = AgentT(p(self._last_obs), p(self._ag["last_dones"]), p(self._ag["raw_rew"]), p(self._ag["raw_cost"]), p(self._ag["dones"]),
                     p(self._ag["last_v_r"]), p(self._ag["last_v_c"]), p(self._ag["act_clipped"]), p(self._ag["status"]),
                     p(self._ag["xch_ws"]), self._ag["xch_ws"].numel() * 8)
@@ -168,7 +171,7 @@ class PPOLagrangian:
         flags = int(not timed) | (2 if getattr(self, "rollout_kernel", "auto") == "steps" else 0) | (4 if getattr(self, "profile_phases", 0) else 0)
         from .seed_batch import budgeted
         with budgeted(0 if flags & 2 else self.n_envs):      # persistent launch: one CU per environment (several runs on one GPU)
-            _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn), b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
+            _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn) if cn is not None else None, b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
                                                           float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
                                                           float(self.cost_gae_lambda), flags, _lib.current_stream()),
                        "icrl_rollout_collect")
@@ -183,7 +186,8 @@ class PPOLagrangian:
         self.num_timesteps += env.num_envs * n_rollout_steps
         # wrapper-visible "last step" state, as the reference leaves it
         nenv.old_obs, nenv.old_reward, nenv.old_cost = senv.s, self._ag["raw_rew"], self._ag["raw_cost"]
-        cw.previous_obs = senv.s
+        if cw is not None:
+            cw.previous_obs = senv.s
         self._last_original_obs = senv.s
         self._last_dones = self._ag["last_dones"]
         if callback is not None:

@@ -212,6 +212,12 @@ int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm, const icr
  * obs [N,obs] float64, acs [N,acs] float32 (class index in acs[n,0] when discrete). */
 int icrl_cost_mlp_forward(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* cost, void* stream);
 
+/* GailDiscriminator.reward_function (icrl/gail_utils.py:147-157): the same network read the other way round — the
+ * discriminator output D = sigmoid(MLP(prepare(obs, acs))) itself (apply_log = 0) or log(D + eps) (apply_log = 1, the
+ * GAIL-constraint baseline's reward, eps = cn->eps).  out: [N] float32. */
+int icrl_disc_reward(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, int apply_log,
+                     void* stream);
+
 /* SynthVecEnv.reset / .step: the batched stand-in for SubprocVecEnv.step_async/step_wait.  step: actions [N,act] float32
  * (already clipped), writes raw reward [N] float64 and done [N] bytes, advances env->s in place (auto-reset). */
 int icrl_synth_env_reset(const icrl_env_t* env, void* stream);

@@ -557,6 +557,107 @@ def g8_icrl_lgw():
          **{f"expert_policy/{k}": v.numpy() for k, v in esd.items()})
 
 
+def g12_gail():
+    """GAIL-constraint baseline (SURVEY f-4): the reference's GailDiscriminator + GailCallback + plain PPO on the synthetic env,
+    2 rollouts, every draw recorded; the CPU port (oracle/gail.py on the two-critics PortAgent with zero costs) teacher-forced."""
+    print("G12 GAIL discriminator + callback + PPO")
+    import tempfile
+    import torch.distributions.normal as tdn
+    from stable_baselines3 import PPO
+    from icrl.gail_utils import GailCallback, GailDiscriminator
+    from oracle import gail as o_gail
+    N, T = 4, 32
+    ex = np.load(os.path.join(OUT, "expert_hc.npz"))
+    exp_obs, exp_acs = ex["observations"][:300].astype(np.float64), ex["actions"][:300]
+    env = VecNormalizeWithCost(RefSynthVecEnv(N, "hc", 0), training=True, norm_obs=True, norm_reward=True, norm_cost=False, reward_gamma=0.99)
+    th.manual_seed(5)
+    disc = GailDiscriminator(18, 6, [20], 48, lambda x: 0.01, exp_obs, exp_acs, False, clip_obs=20, eps=1e-5)
+    d0 = _sd_np(disc.network.state_dict())
+    agent = PPO("MlpPolicy", env, n_steps=T, batch_size=16, n_epochs=3, target_kl=0.02, seed=0, device="cpu", verbose=0,
+                policy_kwargs=dict(net_arch=[dict(pi=[64, 64], vf=[64, 64])]))
+    sd0 = _sd_np(agent.policy.state_dict())
+    wall = lambda o, a: (o[..., 0] <= -0.05)
+    cb = GailCallback(disc, False, wall, tempfile.mkdtemp(prefix="g12_"), plot_disc=False)
+    noise, perms, tags, phase, disc_metrics, relabelled = [], [], [], ["ppo"], [], []
+    orig_sn, orig_perm, orig_train, orig_end = tdn._standard_normal, np.random.permutation, disc.train, cb._on_rollout_end
+
+    def rec_sn(shape, dtype, device):
+        e = orig_sn(shape, dtype, device); noise.append(e.numpy().copy()); return e
+
+    def rec_perm(n):
+        p = orig_perm(n); perms.append(p.copy()); tags.append(phase[0]); return p
+
+    def rec_train(*a, **k):
+        phase[0] = "disc"
+        try:
+            m = orig_train(*a, **k); disc_metrics.append(dict(m)); return m
+        finally:
+            phase[0] = "ppo"
+
+    def rec_end():
+        orig_end()
+        relabelled.append((agent.rollout_buffer.rewards.copy(), agent.rollout_buffer.advantages.copy(), agent.rollout_buffer.returns.copy(),
+                           float(ref_logger.Logger.CURRENT.name_to_value["eval/mean_cost"])))
+    tdn._standard_normal, np.random.permutation, disc.train, cb._on_rollout_end = rec_sn, rec_perm, rec_train, rec_end
+    try:
+        agent.learn(total_timesteps=2 * N * T, callback=cb)
+    finally:
+        tdn._standard_normal, np.random.permutation = orig_sn, orig_perm
+    logs = {k: float(v) for k, v in ref_logger.Logger.CURRENT.name_to_value.items() if k.startswith("train/")}
+    noise = np.array(noise).reshape(2, T, N, 6)
+    print("  reference: permutations", tags, "disc loss", [round(m["discriminator/disc_loss"], 5) for m in disc_metrics],
+          "mean cost", [r[3] for r in relabelled])
+    # ---- CPU port, teacher-forced
+    stack = o_loop.make_stack(N, "hc", 0, norm_cost=False)
+    port = o_loop.PortAgent(stack, n_steps=T, batch_size=16, n_epochs=3, target_kl=0.02, seed=0, cost_vf_coef=0.0, penalty_initial_value=0.0)
+    psd = {k: v.clone() for k, v in port.policy.state_dict().items()}
+    for k, v in sd0.items():
+        psd[k] = th.as_tensor(v)
+    port.policy.load_state_dict(psd)
+    onet = o_gail.make_disc(18, 6, [20])
+    onet.load_state_dict({k: th.as_tensor(v) for k, v in d0.items()})
+    oopt = th.optim.Adam(onet.parameters(), lr=0.01, eps=1e-5)
+    port.num_timesteps = 0
+    port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
+    cursor, worst = 0, {}
+    for it in range(2):
+        port.collect_rollouts(noise[it])
+        assert tags[cursor] == "disc"
+        replay = iter([perms[cursor]]); cursor += 1
+        m = o_gail.rollout_end(port, onet, oopt, exp_obs, exp_acs, port.last_values, port.last_dones_out, batch_size=48,
+                               true_cost_fn=wall, rng=type("R", (), {"permutation": staticmethod(lambda n: next(replay))}))
+        for k, v in disc_metrics[it].items():
+            worst["disc/" + k] = max(worst.get("disc/" + k, 0.0), abs(v - m[k]))
+        worst["mean_cost"] = max(worst.get("mean_cost", 0.0), abs(relabelled[it][3] - m["eval/mean_cost"]))
+        flat = lambda a: a.reshape(N, T).swapaxes(0, 1) if a.shape[0] == N * T else a.reshape(T, N)
+        worst["rewards"] = max(worst.get("rewards", 0.0), maxdiff(relabelled[it][0].reshape(T, N), port.buf.rewards))
+        worst["advantages"] = max(worst.get("advantages", 0.0), maxdiff(relabelled[it][1].reshape(T, N), port.buf.reward_advantages))
+        remaining = perms[cursor:]
+        res = port.train(lambda e, r=remaining: r[e])
+        used = min(int(res["train/early_stop_epoch"]) + 1, 3)
+        assert all(t == "ppo" for t in tags[cursor:cursor + used])
+        cursor += used
+    assert cursor == len(perms), (cursor, len(perms))
+    for k in sd0:
+        worst["w/" + k] = maxdiff(port.policy.params[k].detach().numpy(), agent.policy.state_dict()[k].numpy())
+    for k in d0:
+        worst["d/" + k] = maxdiff(onet.params[k].detach().numpy(), disc.network.state_dict()[k].numpy())
+    for a, b in (("train/approx_kl", "train/approx_kl"), ("train/value_loss", "train/reward_value_loss"), ("train/policy_gradient_loss", "train/policy_gradient_loss")):
+        worst[a] = abs(logs[a] - float(res[b]))
+    print("  port vs reference, max abs deviation:", {k: v for k, v in worst.items() if v > 0} or "all exactly 0")
+    assert max(worst.values()) < 1e-6, worst
+    rng = np.random.RandomState(3)
+    po, pa = rng.randn(2, 5, 18) * 3, rng.uniform(-1, 1, (2, 5, 6)).astype(np.float32)
+    save("g12_gail", noise=noise, perms=np.array(perms), perm_is_disc=np.array([t == "disc" for t in tags]), exp_obs=exp_obs, exp_acs=exp_acs,
+         **{f"w0/{k}": v for k, v in sd0.items()}, **{f"d0/{k}": v for k, v in d0.items()},
+         **{f"w1/{k}": v.numpy() for k, v in agent.policy.state_dict().items()}, **_sd_np(disc.network.state_dict(), "d1/"),
+         **{f"disc_metrics/{it}/{k.split('/')[1]}": v for it, m in enumerate(disc_metrics) for k, v in m.items()},
+         rewards=np.array([r[0].reshape(T, N) for r in relabelled]), advantages=np.array([r[1].reshape(T, N) for r in relabelled]),
+         returns=np.array([r[2].reshape(T, N) for r in relabelled]), mean_cost=np.array([r[3] for r in relabelled]),
+         probe_obs=po, probe_acs=pa, probe_reward=disc.reward_function(po, pa), probe_d=disc.reward_function(po, pa, apply_log=False),
+         **{"log/" + k.split("/")[1]: v for k, v in logs.items()})
+
+
 def g9_learn_iteration():
     """One learn() of the reference on the synthetic env (N=4, T=32) with the action noise and the minibatch
     permutations recorded, against the CPU port teacher-forced with the same streams."""
@@ -804,8 +905,8 @@ def fixtures_expert():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11", "g12"]
     table = dict(g1=g1_gae, g2=g2_cost_function, g3=g3_vecnormalize, g4=g4_ppo_minibatch, g5=g5_dual,
-                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
+                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g12=g12_gail, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
     for w in which:
         table[w]()

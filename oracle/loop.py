@@ -117,7 +117,9 @@ class PortAgent:
             clipped = actions if self.discrete else np.clip(actions, env.action_low, env.action_high)
             new_obs, rewards, dones, costs = self.stack.step(clipped)
             orig_obs = self.stack.old_obs.copy()
-            orig_costs = self.stack.old_cost.copy()
+            if costs is None:                        # no cost wrapper in the env chain (the GAIL baseline): zero costs
+                costs = np.zeros(N, F32)
+            orig_costs = costs.copy() if self.stack.old_cost is None else self.stack.old_cost.copy()
             self.num_timesteps += N
             buf.observations[t] = self._last_obs
             buf.orig_observations[t] = self._last_original_obs
@@ -139,6 +141,7 @@ class PortAgent:
         buf.reward_returns, buf.reward_advantages = g["reward_returns"], g["reward_advantages"]
         buf.cost_returns, buf.cost_advantages = g["cost_returns"], g["cost_advantages"]
         self.buf = buf
+        self.last_values, self.last_dones_out = v_r.numpy().flatten(), dones      # PPO's `extras` (on_policy_algorithm.py:190)
         return buf
 
     # -- update --------------------------------------------------------------------------------

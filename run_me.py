@@ -1,11 +1,13 @@
-"""Entry point with the reference's dispatch (ref: run_me.py:7-32): `python run_me.py icrl <flags>` / `python run_me.py cpg <flags>`."""
+"""Entry point with the reference's dispatch (ref: run_me.py:7-32): `python run_me.py {icrl,cpg,gail} <flags>`."""
 import sys
 
 if __name__ == "__main__":
-    if len(sys.argv) < 2 or sys.argv[1] not in ("icrl", "cpg"):
-        raise SystemExit("usage: python run_me.py {icrl,cpg} <flags>   (gail / run_policy / random_agent are outside the hot path)")
+    if len(sys.argv) < 2 or sys.argv[1] not in ("icrl", "cpg", "gail"):
+        raise SystemExit("usage: python run_me.py {icrl,cpg,gail} <flags>   (run_policy / random_agent are host-side utilities: icrl_amd/run_policy.py)")
     if sys.argv[1] == "icrl":
         from icrl_amd.icrl import main
-    else:
+    elif sys.argv[1] == "cpg":
         from icrl_amd.cpg import main
+    else:
+        from icrl_amd.gail import main
     main(sys.argv[1:])

@@ -320,3 +320,47 @@ def test_reference_written_files_host_readers(golden, tmp_path):
     assert type(vn).__name__ == str(exp["vn_class"])
     assert np.array_equal(vn.obs_rms.mean, exp["obs_rms_mean"]) and np.array_equal(vn.obs_rms.var, exp["obs_rms_var"])
     assert vn.obs_rms.count == float(exp["obs_rms_count"]) and vn.ret_rms.var == float(exp["ret_rms_var"]) and vn.clip_obs == float(exp["clip_obs"])
+
+
+def test_g12_gail_baseline_reference(golden):
+    """GAIL-constraint baseline (icrl/gail_utils.py, icrl/gail.py): the CPU port — discriminator, rollout-end hook and plain PPO
+    expressed through the two-critics agent with the cost path off — teacher-forced with the draws recorded from the reference's
+    GailDiscriminator + GailCallback + PPO (g12).  The port differs from the reference by at most 1 ulp per quantity (the idle
+    cost critic's zero gradients change the association of clip_grad_norm_'s sum), hence 1e-6, not bit equality."""
+    from oracle import gail as o_gail
+    g = golden("g12_gail")
+    noise, perms, is_disc = g["noise"], g["perms"], g["perm_is_disc"]
+    _, T, N, _ = noise.shape
+    stack = o_loop.make_stack(N, "hc", 0, norm_cost=False)
+    port = o_loop.PortAgent(stack, n_steps=T, batch_size=16, n_epochs=3, target_kl=0.02, seed=0, cost_vf_coef=0.0, penalty_initial_value=0.0)
+    psd = {k: v.clone() for k, v in port.policy.state_dict().items()}
+    psd.update({k: th.as_tensor(v) for k, v in _sub(g, "w0/").items()})
+    port.policy.load_state_dict(psd)
+    net = o_gail.make_disc(18, 6, [20])
+    net.load_state_dict({k: th.as_tensor(v) for k, v in _sub(g, "d0/").items()})
+    opt = th.optim.Adam(net.parameters(), lr=0.01, eps=1e-5)
+    wall = lambda o, a: (o[..., 0] <= -0.05)
+    port.num_timesteps = 0
+    port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
+    cursor = 0
+    for it in range(2):
+        port.collect_rollouts(noise[it])
+        assert is_disc[cursor]
+        replay = iter([perms[cursor]]); cursor += 1
+        m = o_gail.rollout_end(port, net, opt, g["exp_obs"], g["exp_acs"], port.last_values, port.last_dones_out, batch_size=48,
+                               true_cost_fn=wall, rng=type("R", (), {"permutation": staticmethod(lambda n: next(replay))}))
+        for k in ("disc_loss", "expert_loss", "nominal_loss", "mean_nominal_preds", "mean_expert_preds"):
+            assert abs(m["discriminator/" + k] - float(g[f"disc_metrics/{it}/{k}"])) < 1e-6, (it, k)
+        assert m["eval/mean_cost"] == float(g["mean_cost"][it])
+        assert np.allclose(port.buf.rewards, g["rewards"][it], rtol=0, atol=1e-6)
+        assert np.allclose(port.buf.reward_advantages, g["advantages"][it], rtol=0, atol=5e-6)
+        assert np.allclose(port.buf.reward_returns, g["returns"][it], rtol=0, atol=5e-6)
+        remaining = perms[cursor:]
+        res = port.train(lambda e, r=remaining: r[e])
+        cursor += min(int(res["train/early_stop_epoch"]) + 1, 3)
+    assert cursor == len(perms)
+    for k, v in _sub(g, "w1/").items():
+        assert np.allclose(port.policy.params[k].detach().numpy(), v, rtol=0, atol=1e-6), k
+    for k, v in _sub(g, "d1/").items():
+        assert np.allclose(net.params[k].detach().numpy(), v, rtol=0, atol=1e-6), k
+    assert np.allclose(o_gail.disc_reward(net, g["probe_obs"], g["probe_acs"]), g["probe_reward"], rtol=0, atol=1e-5)
