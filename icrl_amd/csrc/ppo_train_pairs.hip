@@ -106,6 +106,9 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
   //   partners w, w + 4 (a workgroup's waves go to the SIMDs round-robin: the partners SHARE a SIMD), LDS flags   9.6
   //   partners w, w + 4, workgroup barriers instead of flags                                                       9.9
   //   partners w, w ^ 1 (different SIMDs), workgroup barriers 10.6; flags 10.4
+#ifndef ICRL_OWN_LDS
+#define ICRL_OWN_LDS 1
+#endif
 #ifndef ICRL_PAIR_ADJ
 #define ICRL_PAIR_ADJ 0
 #endif
@@ -800,6 +803,13 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
       const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
       __hip_atomic_store(a.xch + (step & 1) * 32 + role * 8 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
+      // this workgroup reads its OWN eight partials from LDS (same floats, same summation order as everybody else's view of
+      // them): the role that publishes last — the policy, the critical path — does not wait for its own stores to come back
+      // through the memory system (~870 cycles)
+#if ICRL_OWN_LDS
+      sm[S::MISC + 24 + role * 8 + w] = ss;
+      if (book && role == 0) sm[S::MISC + 12] = want_stop ? 1.f : 0.f;
+#endif
       if (book) {
         ++steps_done;
         if (role == 0) {
@@ -827,7 +837,7 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
     stats_partials(nb_next);
     xcur = xnext;
     FSTAMP(15)  // staging
-    if (tid < 24) {     // granule (role rr, wave ww) = slot 8 rr + ww
+    if (tid < 24 && (!ICRL_OWN_LDS || (tid >> 3) != role)) {     // granule (role rr, wave ww) = slot 8 rr + ww; the other two roles' sixteen
       u64 v = 0;
       int spins = 0;
       bool ok = false;

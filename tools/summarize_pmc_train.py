@@ -1,0 +1,57 @@
+"""SQ counters of the PPO-Lagrangian update kernels (tools/pmc_train.sh) -> profiles/<tag>_train_pmc.md.
+
+    python tools/summarize_pmc_train.py r02
+Per launch of tools/train_only.py: 2 epochs x 2048 minibatches = 4096 optimiser steps, 3 workgroups.  rocprofv3 sums a counter
+over all waves of the dispatch; SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles (x 4 = shader cycles)."""
+import collections
+import csv
+import glob
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+STEPS = 4096
+QUAD = {"SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
+        "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA"}
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+waves = {}
+for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_train_{tag}_*", "**", "*counter_collection.csv"), recursive=True)):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"]
+        if "ppo_train_" not in k or "perm" in k or "plan" in k:
+            continue
+        name = k.split("<")[0].split("::")[-1].replace("void ", "")
+        per[(name, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        waves[name] = int(r["Workgroup_Size"]) // 64 * 3
+    for (name, _), c in per.items():
+        for cn, v in c.items():
+            agg[name][cn].append(v)
+lines = [f"# SQ counters of the PPO-Lagrangian update kernels ({tag}) — HCWithPos shapes, batch 64, per WAVE and optimiser step",
+         "", "command: `bash tools/pmc_train.sh <tag>` on the GPU box = two `rocprofv3 --pmc <8 SQ counters> --kernel-trace` passes over "
+         "`tools/train_only.py` (VARIANTS=rows,auto: the row-owning kernel with one wave per SIMD, 12 waves, and the wave-pair kernel with two, "
+         "24 waves; 4096 optimiser steps per launch); raw csv: gpurun_out/pmc_train_<tag>_{a,b} (scratch).  Values below = median over the "
+         "launches / waves of the kernel / 4096; cycle-type counters converted from quad-cycles to shader cycles.", ""]
+names = sorted(agg)
+cols = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_SALU",
+        "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_SMEM",
+        "SQ_INSTS_VMEM_RD"]
+lines.append("| counter | " + " | ".join(f"`{n}` ({waves[n]} waves)" for n in names) + " |")
+lines.append("|---|" + "---|" * len(names))
+for c in cols:
+    row = []
+    for n in names:
+        v = agg[n].get(c)
+        if not v:
+            row.append("-"); continue
+        med = sorted(v)[len(v) // 2] / waves[n] / STEPS * (4 if c in QUAD else 1)
+        row.append(f"{med:,.0f}")
+    lines.append(f"| {c}{' (cycles)' if c in QUAD else ''} | " + " | ".join(row) + " |")
+lines += ["", "Reading: SQ_WAVE_CYCLES = ACTIVE_INST_ANY (issuing) + WAIT_INST_ANY (issue stalled: here the shared fp32 MFMA / VALU pipe, "
+          "304 MFMAs x 32 cycles = 9.7 k cycles per SIMD and step) + WAIT_ANY (parked at s_waitcnt / s_barrier).  MFMA_MOPS_F32 / 4 = "
+          "v_mfma_f32_16x16x4_f32 instructions.  With two waves per SIMD each wave issues half the instructions (761 vs 1733 VALU), "
+          "and the step shortens by what the two waves overlap; what remains parked (WAIT_ANY) is the exchange hop, the three "
+          "workgroup barriers and LDS latency both waves of a SIMD meet at the same time."]
+open(os.path.join(ROOT, "profiles", f"{tag}_train_pmc.md"), "w").write("\n".join(lines) + "\n")
+print("\n".join(lines))
