@@ -370,9 +370,11 @@ class PPOLagrangian:
             return torch.as_tensor(perms.astype(np.int32), device=self.device).contiguous(), None
         if self.permutation == "device":
             return torch.stack([torch.randperm(n, device=self.device) for _ in range(self.n_epochs)]).to(torch.int32).contiguous(), None
-        state = np.random.get_state()
-        perms = np.stack([np.random.permutation(n) for _ in range(self.n_epochs)])
-        return torch.as_tensor(perms.astype(np.int32), device=self.device).contiguous(), state
+        perms, states = np.empty((self.n_epochs, n), np.int32), []
+        for e in range(self.n_epochs):
+            perms[e] = np.random.permutation(n)
+            states.append(np.random.get_state())             # generator state after e + 1 epochs' draws
+        return torch.as_tensor(perms, device=self.device).contiguous(), states
 
     def train(self, perms=None):
         """ref: ppo_lag.py:177-338."""
@@ -426,9 +428,7 @@ class PPOLagrangian:
         if self.streams is not None and not injected:
             self.streams.consumed(min(early_stop_epoch + 1, self.n_epochs))
         if rng_state is not None:       # leave np.random where the reference would: one permutation per executed epoch
-            np.random.set_state(rng_state)
-            for _ in range(min(early_stop_epoch + 1, self.n_epochs)):
-                np.random.permutation(n)
+            np.random.set_state(rng_state[min(early_stop_epoch + 1, self.n_epochs) - 1])
         average_cost = float(average_cost_t.item())
         if self.update_penalty_after is None or ((self._n_updates / self.n_epochs) % self.update_penalty_after == 0):
             self.dual.update_parameter(np.float32(average_cost))

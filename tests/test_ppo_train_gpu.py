@@ -113,3 +113,26 @@ def test_train_vs_oracle(kind, N, T, B, E, tk):
                 "train/clip_fraction", "train/entropy_loss", "train/loss"):
         assert abs(lg[key] - out[key]) < 2e-4 + 2e-3 * abs(out[key]), (key, lg[key], out[key])
     assert np.allclose(agent.epoch_kls[:len(out["epoch_kls"])], out["epoch_kls"], atol=2e-5)
+
+
+@pytest.mark.parametrize("tk", [None, 1e-6])
+def test_numpy_stream_position_after_train(tk):
+    """The reference draws one np.random.permutation per EXECUTED epoch (buffers.py:596 inside the epoch loop,
+    ppo_lag.py:203-263: the KL break leaves the loop before the next epoch's get()).  The product draws all epochs' permutations
+    before its single launch and then puts the global generator where the reference's would be; minibatch order is the
+    numpy stream's."""
+    N, T, E = 8, 32, 4
+    agent = _agent("hc", N, T, batch_size=64, n_epochs=E, target_kl=tk)
+    agent._setup_learn(N * T)
+    agent.collect_rollouts(agent.env, None, agent.rollout_buffer, T, "cost")
+    np.random.seed(1234)
+    agent.train()
+    from icrl_amd import logger
+    stop = int(logger.Logger.CURRENT.name_to_value["train/early_stop_epoch"])
+    executed = min(stop + 1, E)
+    assert (executed < E) == (tk is not None)
+    after = np.random.randint(1 << 30)
+    np.random.seed(1234)
+    for _ in range(executed):
+        np.random.permutation(N * T)
+    assert after == np.random.randint(1 << 30)

@@ -1,33 +1,54 @@
-"""wall-clock timeline of one outer ICRL iteration (host side, with a device sync after each stage)."""
-import os, sys, time, types
+"""Where one outer ICRL iteration of the benchmark configuration spends its wall time (run on the GPU box):
+each section of icrl_amd.icrl.outer_iteration is wrapped with a synchronise + host timer (SYNC=1, default: section = host + GPU
+time, serialised) or only a host timer (SYNC=0: what the host thread itself spends, with the GPU running behind it)."""
+import os, sys, time, json, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
+import torch
 import bench
-from icrl_amd import icrl as I, utils, logger
-from icrl_amd.vec_env import sync_envs_normalization
+from icrl_amd import icrl as I, utils, ppo_lag, constraint_net
+
+SYNC = os.environ.get("SYNC", "1") == "1"
+acc = collections.OrderedDict()
+
+
+def wrap(owner, name, label):
+    fn = getattr(owner, name)
+
+    def timed(*a, **k):
+        if SYNC:
+            torch.cuda.synchronize()
+        t0 = time.time()
+        out = fn(*a, **k)
+        if SYNC:
+            torch.cuda.synchronize()
+        acc[label] = acc.get(label, 0.0) + time.time() - t0
+        return out
+    setattr(owner, name, timed)
+
+
+wrap(ppo_lag.PPOLagrangian, "collect_rollouts", "rollout (launch + GAE)")
+wrap(ppo_lag.PPOLagrangian, "_draw_permutations", "  of which permutations (host)")
+wrap(ppo_lag.PPOLagrangian, "train", "update")
+wrap(utils, "sample_from_agent", "nominal episodes")
+wrap(constraint_net.ConstraintNet, "train", "constraint-net update")
+wrap(utils, "evaluate_policy", "evaluation episodes")
+wrap(utils, "compute_kl", "KL metrics")
+wrap(I, "mean_cost", "true cost")
+wrap(I, "synchronise", "synchronise")
 
 cfg = bench.config2(4, 0, 0, 1)
 st = I.setup(cfg)
 I.outer_iteration(st, 0)
-agent = st["agent"]
-for it in range(1, 3):
-    torch.cuda.synchronize(); t = [time.time()]
-    def mark():
-        torch.cuda.synchronize(); t.append(time.time())
-    # forward step, split
-    total = agent._setup_learn(cfg.forward_timesteps, True)
-    while agent.num_timesteps < total:
-        agent.collect_rollouts(agent.env, None, agent.rollout_buffer, agent.n_steps, "cost"); mark()
-        agent.train(); mark()
-    st["timesteps"] += agent.num_timesteps
-    sync_envs_normalization(st["train_env"], st["sampling_env"])
-    oo, o, a, r, l = utils.sample_from_agent(agent, st["sampling_env"], cfg.expert_rollouts); mark()
-    bw = st["constraint_net"].train(cfg.backward_iters, oo, a, l, None, None, 1 - it / cfg.n_iters); mark()
-    st["train_env"].set_cost_function(st["constraint_net"].cost_function)
-    sync_envs_normalization(st["train_env"], st["eval_env"])
-    utils.evaluate_policy(agent, st["eval_env"], n_eval_episodes=10, deterministic=False); mark()
-    fk = utils.compute_kl(agent, st["d_expert_obs"], st["d_expert_acs"], st["expert_agent"])
-    rk = utils.compute_kl(st["expert_agent"], oo, a, agent); mark()
-    names = ["rollout", "train", "rollout", "train", "sample", "cn.train", "evaluate", "kl"]
-    d = np.diff(t) * 1e3
-    print("iteration", it, " ".join(f"{n}={x:.1f}" for n, x in zip(names, d)), f"total={d.sum():.1f} ms")
+acc.clear()
+torch.cuda.synchronize(); t0 = time.time()
+n = 3
+for it in range(1, 1 + n):
+    I.outer_iteration(st, it)
+torch.cuda.synchronize(); dt = time.time() - t0
+print(f"SYNC={int(SYNC)}  {1e3 * dt / n:.1f} ms per outer iteration")
+tot = 0.0
+for k, v in acc.items():
+    print(f"  {k:34s} {1e3 * v / n:8.2f} ms")
+    if not k.startswith("  "):
+        tot += v
+print(f"  {'(outside the sections)':34s} {1e3 * (dt - tot) / n:8.2f} ms")
