@@ -18,6 +18,8 @@ c_void_p, c_int, c_double, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_dou
 # every symbol declared in include/icrl_hip.h is exported and bound.
 SIGNATURES = {
     "icrl_abi_version": [],
+    "icrl_last_error": [],
+    "icrl_clear_error": [],
     "icrl_gae_dual": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_void_p],
     "icrl_gae_dual_ex": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_int, c_void_p],
     "icrl_policy_prepare": [c_void_p, c_void_p],
@@ -41,7 +43,7 @@ SIGNATURES = {
     "icrl_cn_train_minibatch": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p],
 }
-RESTYPES = {"icrl_cn_train_work_floats": ctypes.c_size_t}
+RESTYPES = {"icrl_cn_train_work_floats": ctypes.c_size_t, "icrl_last_error": ctypes.c_char_p, "icrl_clear_error": None}
 
 
 class HipExtensionMissing(RuntimeError):
@@ -70,7 +72,13 @@ byref = ctypes.byref
 
 
 def check(err, what):
+    """hipError_t -> exception.  Refused arguments (hipErrorInvalidValue = 1) carry the library's reason and raise ValueError, as
+    the reference's argument checks do; anything else is a runtime failure of the launch."""
     if err != 0:
+        reason = lib().icrl_last_error().decode() if err == 1 else ""
+        if reason:
+            lib().icrl_clear_error()
+            raise ValueError(f"{what}: {reason}")
         raise RuntimeError(f"{what} failed with hipError_t {err}")
 
 

@@ -509,7 +509,7 @@ extern "C" size_t icrl_cn_train_work_floats(int n_params, int Nn, int Ne, int n_
 }
 
 extern "C" int icrl_cn_prepare(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, void* stream) {
-  if (N <= 0) return (int)hipErrorInvalidValue;
+  if (N <= 0) return fail("icrl_cn_prepare: N = %d rows", N);
   hipLaunchKernelGGL(cn_prepare_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, obs, acs, N, out);
   return (int)hipGetLastError();
 }
@@ -518,12 +518,15 @@ extern "C" int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* ex
                              const float* nominal, const float* expert, int Nn, int Ne, const int32_t* ep_offsets,
                              const int32_t* row_episode, int n_ep, const icrl_cn_hyper_t* hp, float* work, float* metrics,
                              void* stream) {
-  if (Nn <= 0 || Ne <= 0 || n_ep <= 0 || hp->iterations < 0 || cn->n_hidden < 1 || cn->n_hidden > 2) return (int)hipErrorInvalidValue;
+  if (Nn <= 0 || Ne <= 0 || n_ep <= 0 || hp->iterations < 0 || cn->n_hidden < 1 || cn->n_hidden > 2)
+    return fail("icrl_cn_train: needs nominal rows (%d), expert rows (%d), episodes (%d) > 0, iterations (%d) >= 0 and 1 or 2 hidden layers (%d)",
+                Nn, Ne, n_ep, hp->iterations, cn->n_hidden);
   CnTrainArgs a;
   a.d = make_cn_dims(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
-  if (a.d.n_params != cn->n_params) return (int)hipErrorInvalidValue;
+  if (a.d.n_params != cn->n_params)
+    return fail("constraint net: n_params = %d but in_dim %d / hidden (%d, %d) x %d layers need %d", cn->n_params, cn->in_dim, cn->h1, cn->h2, cn->n_hidden, a.d.n_params);
   const size_t lds = (size_t)a.d.total * sizeof(float);
-  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  if (lds > 160 * 1024) return fail("constraint net update: %zu B of LDS needed for in_dim %d / hidden (%d, %d), 160 KB available", lds, cn->in_dim, cn->h1, cn->h2);
   a.params = cn->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.nominal = nominal; a.expert = expert; a.Nn = Nn; a.Ne = Ne; a.n_ep = n_ep;
   a.nb_n = (Nn + CN_ROWS - 1) / CN_ROWS; a.nb_e = (Ne + CN_ROWS - 1) / CN_ROWS;
@@ -562,12 +565,14 @@ extern "C" int icrl_cn_train_minibatch(const icrl_costnet_t* cn, float* exp_avg,
                                        float* metrics, void* stream) {
   if (Nn <= 0 || Ne <= 0 || n_ep <= 0 || hp->iterations < 0 || cn->n_hidden < 1 || cn->n_hidden > 2 || batch_size <= 0 ||
       perms == nullptr)
-    return (int)hipErrorInvalidValue;
+    return fail("icrl_cn_train_minibatch: needs nominal rows (%d), expert rows (%d), episodes (%d), batch_size (%d) > 0, iterations (%d) >= 0, "
+                "1 or 2 hidden layers (%d) and a permutation table", Nn, Ne, n_ep, batch_size, hp->iterations, cn->n_hidden);
   CnTrainArgs a;
   a.d = make_cn_dims(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
-  if (a.d.n_params != cn->n_params) return (int)hipErrorInvalidValue;
+  if (a.d.n_params != cn->n_params)
+    return fail("constraint net: n_params = %d but in_dim %d / hidden (%d, %d) x %d layers need %d", cn->n_params, cn->in_dim, cn->h1, cn->h2, cn->n_hidden, a.d.n_params);
   const size_t lds = (size_t)a.d.total * sizeof(float);
-  if (lds > 160 * 1024) return (int)hipErrorInvalidValue;
+  if (lds > 160 * 1024) return fail("constraint net update: %zu B of LDS needed for in_dim %d / hidden (%d, %d), 160 KB available", lds, cn->in_dim, cn->h1, cn->h2);
   a.params = cn->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.nominal = nominal; a.expert = expert; a.Nn = Nn; a.Ne = Ne; a.n_ep = n_ep;
   a.nb_n = (Nn + CN_ROWS - 1) / CN_ROWS; a.nb_e = (Ne + CN_ROWS - 1) / CN_ROWS;

@@ -13,6 +13,9 @@ constexpr int MAX_ACT = 16;    // act_dim limit (HC 6, Ant 8)
 constexpr int MAX_H = 64;      // hidden width limit of policy / cost nets
 constexpr int MAX_CN_IN = 160; // cost-net input limit (Ant: 121)
 
+// argument rejection: formats the reason into the calling thread's icrl_last_error() text, returns hipErrorInvalidValue
+int fail(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
 // ---------------------------------------------------------------------------------------------------------------
 // counter-based random stream of the synthetic env (spec: oracle/synth_env.py u24())
 // ---------------------------------------------------------------------------------------------------------------

@@ -25,6 +25,9 @@
 
 #include "../../include/icrl_hip.h"
 
+namespace icrl { int fail(const char* fmt, ...) __attribute__((format(printf, 1, 2))); }   // errors.hip
+using icrl::fail;
+
 namespace {
 
 constexpr int U_DEFAULT = 8;  // time rows per register batch (x2 for the double buffer)
@@ -196,7 +199,7 @@ extern "C" int icrl_gae_dual_ex(const float* rewards, const float* costs, const 
                                 const float* last_v_c, const uint8_t* last_dones, float* adv_r, float* adv_c,
                                 float* ret_r, float* ret_c, int T, int N, double reward_gamma, double reward_gae_lambda,
                                 double cost_gamma, double cost_gae_lambda, int waves_per_tile, void* stream) {
-  if (T <= 0 || N <= 0) return (int)hipErrorInvalidValue;
+  if (T <= 0 || N <= 0) return fail("icrl_gae_dual: T = %d, N = %d", T, N);
   GaeArgs a{rewards, costs, reward_values, cost_values, dones, last_v_r, last_v_c, last_dones,
             adv_r, adv_c, ret_r, ret_c, T, N,
             (float)reward_gamma, (float)(reward_gamma * reward_gae_lambda),   // Python double product, then f32
@@ -218,7 +221,7 @@ extern "C" int icrl_gae_dual_ex(const float* rewards, const float* costs, const 
   else if (shape == 106) hipLaunchKernelGGL((gae_dual_kernel<1, 16, true, 4>), dim3((tiles + 3) / 4), dim3(256), 0, s, a);
   else if (shape == 4) hipLaunchKernelGGL((gae_dual_kernel<4, 8, false>), dim3(tiles), dim3(256), 0, s, a);
   else if (shape == 16) hipLaunchKernelGGL((gae_dual_kernel<16, 8, false>), dim3(tiles), dim3(1024), 0, s, a);
-  else return (int)hipErrorInvalidValue;
+  else return fail("icrl_gae_dual_ex: waves_per_tile = %d (0 = automatic, 1, 4, 16 or a shape code 101 / 105 / 106)", waves_per_tile);
   return (int)hipGetLastError();
 }
 

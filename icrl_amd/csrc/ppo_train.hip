@@ -909,10 +909,16 @@ static int launch_train(const TrainArgs& a, hipStream_t s) {
 extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                                   const icrl_buffer_t* buf, const int32_t* perms, const float* nu,
                                   const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, void* stream) {
-  if (pol->h1 != HD || pol->h2 != HD || pol->obs_dim > 128 || pol->act_dim > 16 ||
-      hp->batch_size < 2 || hp->batch_size > MAXB || hp->n_epochs < 1 || buf->obs_dim != pol->obs_dim || buf->T < 1 ||
-      (long long)buf->T * buf->N >= (1ll << 31) || (long long)buf->T * buf->N * (pol->obs_dim > 16 ? pol->obs_dim : 16) >= (1ll << 30))
-    return (int)hipErrorInvalidValue;
+  if (pol->h1 != HD || pol->h2 != HD)
+    return fail("icrl_ppo_lag_train: hidden widths (%d, %d); the update kernels are built for %d x %d (the reference's default net_arch)", pol->h1, pol->h2, HD, HD);
+  if (pol->obs_dim < 1 || pol->obs_dim > 128 || pol->act_dim < 1 || pol->act_dim > 16)
+    return fail("icrl_ppo_lag_train: obs_dim %d (1..128) / act_dim %d (1..16)", pol->obs_dim, pol->act_dim);
+  if (hp->batch_size < 2 || hp->batch_size > MAXB || hp->n_epochs < 1)
+    return fail("icrl_ppo_lag_train: batch_size %d (2..%d: one minibatch = at most two 64-row chunks of one workgroup), n_epochs %d (>= 1)", hp->batch_size, MAXB, hp->n_epochs);
+  if (buf->obs_dim != pol->obs_dim || buf->T < 1)
+    return fail("icrl_ppo_lag_train: buffer obs_dim %d vs policy %d, T = %d", buf->obs_dim, pol->obs_dim, buf->T);
+  if ((long long)buf->T * buf->N >= (1ll << 31) || (long long)buf->T * buf->N * (pol->obs_dim > 16 ? pol->obs_dim : 16) >= (1ll << 30))
+    return fail("icrl_ppo_lag_train: %d x %d transitions x obs_dim %d overflow the kernel's 32-bit element offsets (limit 2^30 floats per plane)", buf->T, buf->N, pol->obs_dim);
   TrainArgs a;
   a.L = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);
   a.params = pol->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
@@ -931,7 +937,7 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
     const int n_total = buf->T * buf->N;
     const int n_mb = (n_total + hp->batch_size - 1) / hp->batch_size;
     const long long n_steps = (long long)hp->n_epochs * n_mb;
-    if (n_steps >= (1ll << 21)) return (int)hipErrorInvalidValue;      // epoch index lives in the upper bits of nb_flags
+    if (n_steps >= (1ll << 21)) return fail("icrl_ppo_lag_train: %lld optimiser steps per call, limit 2^21", n_steps);      // epoch index lives in the upper bits of nb_flags
     PlanStep* steps = reinterpret_cast<PlanStep*>((char*)sync_ws + 512);
     PlanChunk* chunks = reinterpret_cast<PlanChunk*>(steps + n_steps + 2);
     a.plan_steps = steps; a.plan_chunks = chunks; a.n_steps = (int)n_steps;
@@ -948,7 +954,7 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
     return launch_train_pairs(a, nt1, pol->discrete != 0, s);
   }
   if (pol->discrete) {
-    if (buf->act_store != 1) return (int)hipErrorInvalidValue;
+    if (buf->act_store != 1) return fail("icrl_ppo_lag_train: discrete policy needs act_store = 1 (action index), got %d", buf->act_store);
     if (nt1 <= 2) return launch_train<2, true>(a, s);
     if (nt1 <= 4) return launch_train<4, true>(a, s);
     return launch_train<8, true>(a, s);

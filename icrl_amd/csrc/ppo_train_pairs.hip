@@ -995,7 +995,7 @@ static int launch_pairs(const TrainArgs& a, hipStream_t s) {
 int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s) {
   if (nt1 <= 2) return discrete ? launch_pairs<2, true>(a, s) : launch_pairs<2, false>(a, s);
   if (nt1 <= 4) return discrete ? launch_pairs<4, true>(a, s) : launch_pairs<4, false>(a, s);
-  return (int)hipErrorInvalidValue;
+  return fail("update (wave pairs): obs_dim tiles %d > 4", nt1);
 }
 
 }  // namespace icrl

@@ -114,8 +114,6 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   int ex_g = -1, ex_s = S::MISC + 63;          // "extra" vector entry: wave 0 head bias r, wave 1 log_std r (Gaussian policy)
   {
     const PolLayout& L = a.L;
-    const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
-    const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
     const int gbh = role == 0 ? L.ba : (role == 1 ? L.bv : L.bc);
     if (w == 0 && r < n_out) { ex_g = gbh + r; ex_s = S::BH + r; }
     if (w == 1 && !DISC && role == 0 && r < A) { ex_g = L.log_std + r; ex_s = S::LS + r; }
@@ -918,7 +916,7 @@ int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, hipStream_t s)
   if (nt1 <= 2) return discrete ? launch_rows<2, true>(a, s) : launch_rows<2, false>(a, s);
   if (nt1 <= 4) return discrete ? launch_rows<4, true>(a, s) : launch_rows<4, false>(a, s);
   if (nt1 <= 8) return discrete ? launch_rows<8, true>(a, s) : launch_rows<8, false>(a, s);
-  return (int)hipErrorInvalidValue;
+  return fail("update (row-owning waves): obs_dim tiles %d > 8", nt1);
 }
 
 }  // namespace icrl

@@ -1651,23 +1651,30 @@ static bool cn_ok(const icrl_costnet_t* cn) {
   return cn->in_dim > 0 && cn->in_dim <= MAX_CN_IN && cn->h1 > 0 && cn->h1 <= MAX_H && (cn->n_hidden == 1 ||
          (cn->n_hidden == 2 && cn->h2 > 0 && cn->h2 <= MAX_H)) && cn->obs_dim <= MAX_OBS && cn->acs_dim <= MAX_ACT;
 }
+static int bad_dims(const char* who, int O, int A, int H1, int H2) {
+  return fail("%s: policy obs_dim %d (1..%d), act_dim %d (1..%d), hidden (%d, %d) (1..%d each)", who, O, MAX_OBS, A, MAX_ACT, H1, H2, MAX_H);
+}
+static int bad_cn(const char* who, const icrl_costnet_t* cn) {
+  return fail("%s: constraint net in_dim %d (1..%d), %d hidden layers (1 or 2) of (%d, %d) (1..%d), obs_dim %d (<= %d), acs_dim %d (<= %d)", who,
+              cn->in_dim, MAX_CN_IN, cn->n_hidden, cn->h1, cn->h2, MAX_H, cn->obs_dim, MAX_OBS, cn->acs_dim, MAX_ACT);
+}
 
 }  // namespace icrl
 
 using namespace icrl;
 
 extern "C" int icrl_policy_prepare(const icrl_policy_t* p, void* stream) {
-  if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return (int)hipErrorInvalidValue;
+  if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("icrl_policy_prepare", p->obs_dim, p->act_dim, p->h1, p->h2);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
-  if (L.n != p->n_params) return (int)hipErrorInvalidValue;
+  if (L.n != p->n_params) return fail("icrl_policy_prepare: n_params = %d, the layout needs %d", p->n_params, L.n);
   hipLaunchKernelGGL(policy_transpose_kernel, dim3((L.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, p->params, p->params_t);
   return (int)hipGetLastError();
 }
 
 extern "C" int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream) {
-  if (!cn_ok(cn)) return (int)hipErrorInvalidValue;
+  if (!cn_ok(cn)) return bad_cn("icrl_costnet_prepare", cn);
   CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
-  if (L.n != cn->n_params) return (int)hipErrorInvalidValue;
+  if (L.n != cn->n_params) return fail("icrl_costnet_prepare: n_params = %d, the layout needs %d", cn->n_params, L.n);
   hipLaunchKernelGGL(costnet_transpose_kernel, dim3((L.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, cn->params, cn->params_t);
   return (int)hipGetLastError();
 }
@@ -1675,7 +1682,8 @@ extern "C" int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream) {
 extern "C" int icrl_policy_forward(const icrl_policy_t* p, const double* obs, const float* noise, int N, int deterministic,
                                    const float* action_low, const float* action_high, float* actions, float* act_clipped,
                                    float* v_r, float* v_c, float* log_prob, void* stream) {
-  if (N <= 0 || !dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return (int)hipErrorInvalidValue;
+  if (N <= 0) return fail("policy forward / evaluate: N = %d rows", N);
+  if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("policy forward / evaluate", p->obs_dim, p->act_dim, p->h1, p->h2);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
   if (L.O <= 32)
     hipLaunchKernelGGL(policy_forward_kernel<2>, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, noise,
@@ -1690,7 +1698,8 @@ extern "C" int icrl_policy_forward(const icrl_policy_t* p, const double* obs, co
 
 extern "C" int icrl_policy_evaluate(const icrl_policy_t* p, const double* obs, const float* actions, int N, float* v_r,
                                     float* v_c, float* log_prob, float* entropy, void* stream) {
-  if (N <= 0 || !dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return (int)hipErrorInvalidValue;
+  if (N <= 0) return fail("policy forward / evaluate: N = %d rows", N);
+  if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("policy forward / evaluate", p->obs_dim, p->act_dim, p->h1, p->h2);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
   if (L.O <= 32)
     hipLaunchKernelGGL(policy_forward_kernel<2>, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs,
@@ -1707,8 +1716,11 @@ extern "C" int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm
                                     const float* action_low, const float* action_high, int episodes_per_stream,
                                     int rows_per_stream, int deterministic, int do_reset, double* orig_obs, double* obs,
                                     float* actions, double* ep_rewards, int32_t* ep_lengths, void* stream) {
-  if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2) || env->obs_dim != pol->obs_dim || nm->training) return (int)hipErrorInvalidValue;
-  if (episodes_per_stream * env->max_steps > rows_per_stream) return (int)hipErrorInvalidValue;
+  if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2)) return bad_dims("icrl_sample_episodes", pol->obs_dim, pol->act_dim, pol->h1, pol->h2);
+  if (env->obs_dim != pol->obs_dim || nm->training)
+    return fail("icrl_sample_episodes: env obs_dim %d vs policy %d; the normaliser must be frozen (training = %d)", env->obs_dim, pol->obs_dim, nm->training);
+  if (episodes_per_stream * env->max_steps > rows_per_stream)
+    return fail("icrl_sample_episodes: %d episodes x %d steps do not fit %d rows per stream", episodes_per_stream, env->max_steps, rows_per_stream);
   SampleArgs a;
   a.env = *env; a.nm = *nm; a.pl = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);
   a.PT = pol->params_t; a.noise = noise; a.alow = action_low; a.ahigh = action_high;
@@ -1722,7 +1734,8 @@ extern "C" int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm
 
 extern "C" int icrl_cost_mlp_forward(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* cost,
                                      void* stream) {
-  if (N <= 0 || !cn_ok(cn)) return (int)hipErrorInvalidValue;
+  if (N <= 0) return fail("cost forward: N = %d rows", N);
+  if (!cn_ok(cn)) return bad_cn("cost forward", cn);
   CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
   if (cn->in_dim <= 32) hipLaunchKernelGGL(cost_forward_kernel<2>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost, 0);
   else hipLaunchKernelGGL(cost_forward_kernel<10>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost, 0);
@@ -1731,7 +1744,8 @@ extern "C" int icrl_cost_mlp_forward(const icrl_costnet_t* cn, const double* obs
 
 extern "C" int icrl_disc_reward(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, int apply_log,
                                 void* stream) {
-  if (N <= 0 || !cn_ok(cn)) return (int)hipErrorInvalidValue;
+  if (N <= 0) return fail("cost forward: N = %d rows", N);
+  if (!cn_ok(cn)) return bad_cn("cost forward", cn);
   CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
   const int mode = apply_log ? 2 : 1;
   if (cn->in_dim <= 32) hipLaunchKernelGGL(cost_forward_kernel<2>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, out, mode);
@@ -1740,14 +1754,14 @@ extern "C" int icrl_disc_reward(const icrl_costnet_t* cn, const double* obs, con
 }
 
 extern "C" int icrl_synth_env_reset(const icrl_env_t* env, void* stream) {
-  if (env->obs_dim > MAX_OBS || env->act_dim > MAX_ACT) return (int)hipErrorInvalidValue;
+  if (env->obs_dim > MAX_OBS || env->act_dim > MAX_ACT) return fail("synthetic env: obs_dim %d (<= %d), act_dim %d (<= %d)", env->obs_dim, MAX_OBS, env->act_dim, MAX_ACT);
   const int total = env->n_envs * env->obs_dim;
   hipLaunchKernelGGL(env_reset_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *env);
   return (int)hipGetLastError();
 }
 
 extern "C" int icrl_synth_env_step(const icrl_env_t* env, const float* actions, double* raw_rew, uint8_t* dones, void* stream) {
-  if (env->obs_dim > MAX_OBS || env->act_dim > MAX_ACT) return (int)hipErrorInvalidValue;
+  if (env->obs_dim > MAX_OBS || env->act_dim > MAX_ACT) return fail("synthetic env: obs_dim %d (<= %d), act_dim %d (<= %d)", env->obs_dim, MAX_OBS, env->act_dim, MAX_ACT);
   hipLaunchKernelGGL(env_step_kernel, dim3(env->n_envs), dim3(64), 0, (hipStream_t)stream, *env, actions, raw_rew, dones);
   return (int)hipGetLastError();
 }
@@ -1758,7 +1772,8 @@ static void launch_norm_step(const NormStepArgs& a, hipStream_t s) {
 }
 
 extern "C" int icrl_vecnorm_reset(const icrl_norm_t* nm, const double* raw_obs, int N, int obs_dim, double* obs_out, void* stream) {
-  if (N <= 0 || N > NORM_MAX_N || obs_dim > MAX_OBS) return (int)hipErrorInvalidValue;
+  if (N <= 0 || N > NORM_MAX_N || obs_dim > MAX_OBS)
+    return fail("VecNormalize step: %d envs (1..%d per GPU: the float64 statistics are one numpy-ordered chain per column), obs_dim %d (<= %d)", N, NORM_MAX_N, obs_dim, MAX_OBS);
   hipLaunchKernelGGL(norm_reset_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *nm, raw_obs, N, obs_dim, obs_out);
   return (int)hipGetLastError();
 }
@@ -1766,7 +1781,8 @@ extern "C" int icrl_vecnorm_reset(const icrl_norm_t* nm, const double* raw_obs, 
 extern "C" int icrl_vecnorm_step(const icrl_norm_t* nm, const double* raw_obs, const double* raw_rew, const float* raw_cost,
                                  const uint8_t* dones, int N, int obs_dim, double* obs_out, double* rew_out, double* cost_out,
                                  void* stream) {
-  if (N <= 0 || N > NORM_MAX_N || obs_dim > MAX_OBS) return (int)hipErrorInvalidValue;
+  if (N <= 0 || N > NORM_MAX_N || obs_dim > MAX_OBS)
+    return fail("VecNormalize step: %d envs (1..%d per GPU: the float64 statistics are one numpy-ordered chain per column), obs_dim %d (<= %d)", N, NORM_MAX_N, obs_dim, MAX_OBS);
   NormStepArgs a{*nm, raw_obs, raw_rew, raw_cost, dones, N, obs_dim, obs_out, rew_out, cost_out, nullptr, nullptr, nullptr, nullptr};
   launch_norm_step(a, (hipStream_t)stream);
   return (int)hipGetLastError();
@@ -1794,10 +1810,13 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
                                        double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
                                        int do_gae, void* stream) {
   const int N = env->n_envs, O = env->obs_dim, T = buf->T;
-  if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2) || pol->obs_dim != O || buf->N != N || buf->obs_dim != O)
-    return (int)hipErrorInvalidValue;
-  if (cn != nullptr && !cn_ok(cn)) return (int)hipErrorInvalidValue;
-  if (N > NORM_MAX_N) return (int)hipErrorInvalidValue;
+  if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2)) return bad_dims("icrl_rollout_collect", pol->obs_dim, pol->act_dim, pol->h1, pol->h2);
+  if (pol->obs_dim != O || buf->N != N || buf->obs_dim != O)
+    return fail("icrl_rollout_collect: env (%d envs, obs_dim %d) vs policy obs_dim %d vs buffer (%d envs, obs_dim %d)", N, O, pol->obs_dim, buf->N, buf->obs_dim);
+  if (cn != nullptr && !cn_ok(cn)) return bad_cn("icrl_rollout_collect", cn);
+  if (N > NORM_MAX_N)
+    return fail("icrl_rollout_collect: %d envs on one GPU, limit %d (shard the envs over ranks: the float64 normaliser statistics are one "
+                "numpy-ordered chain per column)", N, NORM_MAX_N);
   hipStream_t s = (hipStream_t)stream;
   ActStepArgs a;
   a.env = *env; a.buf = *buf; a.ag = *ag;

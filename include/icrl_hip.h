@@ -146,6 +146,13 @@ typedef struct {
 /* ABI version (major*100+minor). */
 int icrl_abi_version(void);
 
+/* Every entry point returns a hipError_t.  When it is hipErrorInvalidValue because the arguments are outside what the
+ * kernels were built for (env count, widths, batch size ...; the reference's Python raises ValueError / AssertionError with a
+ * message at the same places, e.g. stable_baselines3/common/buffers.py:352, on_policy_algorithm.py:141), the reason is kept
+ * as text for the calling host thread until the next refusal; icrl_clear_error() empties it. */
+const char* icrl_last_error(void);
+void icrl_clear_error(void);
+
 /* Dual reward+cost GAE over a [T,N] rollout in ONE launch.
  * Replaces RolloutBufferWithCost.compute_returns_and_advantage / _compute_returns_and_advantage
  *   (stable_baselines3/common/buffers.py:493-552), including its dtype behaviour: float32 delta for t<T-1,
@@ -237,7 +244,9 @@ int icrl_vecnorm_step(const icrl_norm_t* nm, const double* raw_obs, const double
 /* OnPolicyWithCostAlgorithm.collect_rollouts (common/on_policy_algorithm.py:340-421) fused on the device: T steps of
  * {policy forward -> clip -> env step -> cost_function(previous raw obs, action) -> VecNormalizeWithCost -> buffer.add},
  * then the dual GAE.  noise: [T,N,act] standard normals.  ONE persistent launch for all T steps where the shape allows
- * (see icrl_rollout_collect_ex), otherwise 2 launches per step; + 1 launch for GAE; no host sync. */
+ * (see icrl_rollout_collect_ex: <= 128 envs one workgroup per env with replicated statistics, up to 1024 envs 4 envs per
+ * workgroup with the float64 statistics partitioned by observation column), otherwise 2 launches per step; + 1 launch for
+ * GAE; no host sync. */
 int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const icrl_costnet_t* cn,
                          const icrl_buffer_t* buf, const icrl_agent_t* ag, const float* noise,
                          const float* action_low, const float* action_high,

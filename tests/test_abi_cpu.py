@@ -31,6 +31,30 @@ def test_library_exports_every_declared_symbol():
     assert L.icrl_cn_train_work_floats(521, 10000, 5000, 10) > 521 * 235
 
 
+def test_refused_arguments_carry_a_reason():
+    """hard limits of the kernels are reported with text, not a bare hipErrorInvalidValue (argument checks run on the host,
+    before any launch: no GPU needed)."""
+    import pytest
+    from icrl_amd import _lib, structs as S
+    L = _lib.lib()
+    pol = S.PolicyT(18, 6, 32, 64, 0, 1, None, None)                    # hidden (32, 64): the update kernels are 64 x 64
+    buf = S.BufferT(8, 4, 18, 0)
+    hp = S.PpoHyperT(64, 2, 0, 0)
+    err = L.icrl_ppo_lag_train(ctypes.byref(pol), None, None, None, ctypes.byref(buf), None, None, ctypes.byref(hp), None, None, None)
+    assert err == 1
+    with pytest.raises(ValueError, match=r"hidden widths \(32, 64\).*64 x 64"):
+        _lib.check(err, "icrl_ppo_lag_train")
+    assert L.icrl_last_error() == b""                                  # consumed by check()
+    err = L.icrl_gae_dual(*([None] * 12), 0, 5, 0.99, 0.95, 0.99, 0.95, None)
+    with pytest.raises(ValueError, match="T = 0, N = 5"):
+        _lib.check(err, "icrl_gae_dual")
+    hp = S.PpoHyperT(256, 2, 0, 0)
+    pol = S.PolicyT(18, 6, 64, 64, 0, 1, None, None)
+    err = L.icrl_ppo_lag_train(ctypes.byref(pol), None, None, None, ctypes.byref(buf), None, None, ctypes.byref(hp), None, None, None)
+    with pytest.raises(ValueError, match="batch_size 256"):
+        _lib.check(err, "icrl_ppo_lag_train")
+
+
 def test_struct_sizes_match_header_layout():
     """natural alignment, no packing: sizes computed by hand from include/icrl_hip.h."""
     from icrl_amd import structs as S
