@@ -22,6 +22,7 @@ SIGNATURES = {
     "icrl_clear_error": [],
     "icrl_gae_dual": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_void_p],
     "icrl_gae_dual_ex": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_int, c_void_p],
+    "icrl_gae_dual_ws": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_int, c_void_p, ctypes.c_longlong, c_void_p],
     "icrl_policy_prepare": [c_void_p, c_void_p],
     "icrl_costnet_prepare": [c_void_p, c_void_p],
     "icrl_policy_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8,

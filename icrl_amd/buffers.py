@@ -42,6 +42,8 @@ class RolloutBufferWithCost:
         self.actions = torch.zeros(T, N, self.action_dim, device=dev)
         for k in _SCALARS:
             setattr(self, k, torch.zeros(T, N, device=dev))
+        from .structs import GAE_WS_BYTES
+        self.gae_ws = torch.zeros(GAE_WS_BYTES // 8 + 1, dtype=torch.int64, device=dev)      # written by GAE launches only
         self.pos, self.full, self.generator_ready = 0, False, False
 
     def struct(self):
@@ -49,7 +51,7 @@ class RolloutBufferWithCost:
                        p(self.observations), p(self.new_observations), p(self.orig_observations), p(self.new_orig_observations),
                        p(self.actions), p(self.dones), p(self.log_probs), p(self.rewards), p(self.reward_values), p(self.costs),
                        p(self.orig_costs), p(self.cost_values), p(self.reward_advantages), p(self.reward_returns),
-                       p(self.cost_advantages), p(self.cost_returns))
+                       p(self.cost_advantages), p(self.cost_returns), p(self.gae_ws), self.gae_ws.numel() * 8)
 
     def reset(self):
         """ref: buffers.py:468-491 (the reference re-allocates zeros; here the arrays are zeroed in place)."""
@@ -83,11 +85,12 @@ class RolloutBufferWithCost:
         lvr = torch.as_tensor(reward_last_value, device=dev).float().flatten().contiguous()
         lvc = torch.as_tensor(cost_last_value, device=dev).float().flatten().contiguous()
         ld = torch.as_tensor(dones, device=dev).to(torch.uint8).flatten().contiguous()
-        _lib.check(_lib.lib().icrl_gae_dual(
+        _lib.check(_lib.lib().icrl_gae_dual_ws(
             p(self.rewards), p(self.costs), p(self.reward_values), p(self.cost_values), p(self.dones), p(lvr), p(lvc), p(ld),
             p(self.reward_advantages), p(self.cost_advantages), p(self.reward_returns), p(self.cost_returns),
             self.buffer_size, self.n_envs, float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
-            float(self.cost_gae_lambda), _lib.current_stream()), "icrl_gae_dual")
+            float(self.cost_gae_lambda), int(getattr(self, "gae_shape", 0)), p(self.gae_ws), self.gae_ws.numel() * 8,
+            _lib.current_stream()), "icrl_gae_dual")
 
     # ---- reference-compatible sampling ---------------------------------------------------------------------------------
     def env_major(self, name):

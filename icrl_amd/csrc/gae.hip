@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/icrl_hip.h"
 
 namespace icrl { int fail(const char* fmt, ...) __attribute__((format(printf, 1, 2))); }   // errors.hip
@@ -192,13 +194,81 @@ __global__ void __launch_bounds__(64 * W * G) gae_dual_kernel(GaeArgs a) {
   if (t0 < t1) walk_chunk<true, U, NT>(a, n, live, t0, t1, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// small N, long T (the BASELINE configs: 1..16 column tiles x 256..2048 rows): the time axis is split over C workgroups of
+// SW waves each, so a wave walks T / (C * SW) rows instead of T / 16.  Level 1 is the scan above inside a workgroup; level 2
+// composes each workgroup's SW maps into one, publishes it (2 KB + a flag holding this launch's tag) and folds the maps of the
+// workgroups holding LATER rows into the carry-in.  A workgroup only ever waits for workgroups with a lower blockIdx (the
+// latest rows are blockIdx 0), which the dispatcher has started before it: no co-residency assumption.
+// Same re-association caveat as above (<= 1 ulp in float64 before the float32 store).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int SPLIT_W = 8;         // waves per workgroup
+constexpr int SPLIT_CMAX = 16;     // workgroups per column tile
+
+__global__ void __launch_bounds__(64 * SPLIT_W) gae_dual_split_kernel(GaeArgs a, int C, unsigned tag, double* maps, unsigned* flags) {
+  constexpr int W = SPLIT_W, U = U_DEFAULT;
+  __shared__ double own[W][4][64];
+  __shared__ double ext[SPLIT_CMAX - 1][4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x / C;
+  const int c = C - 1 - (blockIdx.x - tile * C);       // time chunk of this workgroup: latest rows first
+  const int col = tile * 64 + lane;
+  const bool live = col < a.N;
+  const unsigned n = live ? col : a.N - 1;
+  const int Tc = (a.T + C - 1) / C;
+  const int wt0 = c * Tc < a.T ? c * Tc : a.T, wt1 = wt0 + Tc < a.T ? wt0 + Tc : a.T;
+  const int sub = (Tc + W - 1) / W;
+  const int t0 = wt0 + wave * sub < wt1 ? wt0 + wave * sub : wt1;
+  const int t1 = t0 + sub < wt1 ? t0 + sub : wt1;
+  Carry s;
+  s.Ar = 0.0; s.Ac = 0.0; s.Pr = 1.0; s.Pc = 1.0;
+  s.vr_next = 0.f; s.vc_next = 0.f; s.d_next = 0.f;
+  if (t0 < t1) walk_chunk<false, U, false>(a, n, live, t0, t1, s);
+  own[wave][0][lane] = s.Pr;
+  own[wave][1][lane] = s.Ar;
+  own[wave][2][lane] = s.Pc;
+  own[wave][3][lane] = s.Ac;
+  __syncthreads();
+  if (wave == 0 && c > 0) {                            // the map of rows [wt0, wt1): needed by the chunks before it
+    double Pr = 1.0, Qr = 0.0, Pc = 1.0, Qc = 0.0;
+    for (int w = W - 1; w >= 0; --w) {
+      Qr = own[w][1][lane] + own[w][0][lane] * Qr;  Pr = own[w][0][lane] * Pr;
+      Qc = own[w][3][lane] + own[w][2][lane] * Qc;  Pc = own[w][2][lane] * Pc;
+    }
+    double* m = maps + (size_t)(tile * C + c) * 256;
+    m[lane] = Pr; m[64 + lane] = Qr; m[128 + lane] = Pc; m[192 + lane] = Qc;
+    __hip_atomic_store(&flags[tile * C + c], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // wave-wide release: after every lane's stores
+  }
+  for (int j = c + 1 + wave; j < C; j += W) {
+    while (__hip_atomic_load(&flags[tile * C + j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(1);
+    const double* m = maps + (size_t)(tile * C + j) * 256;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ext[j - c - 1][k][lane] = m[k * 64 + lane];
+  }
+  __syncthreads();
+  double Ar = 0.0, Ac = 0.0;
+  for (int j = C - 1; j > c; --j) {
+    Ar = ext[j - c - 1][1][lane] + ext[j - c - 1][0][lane] * Ar;
+    Ac = ext[j - c - 1][3][lane] + ext[j - c - 1][2][lane] * Ac;
+  }
+  for (int w = W - 1; w > wave; --w) {
+    Ar = own[w][1][lane] + own[w][0][lane] * Ar;
+    Ac = own[w][3][lane] + own[w][2][lane] * Ac;
+  }
+  s.Ar = Ar;
+  s.Ac = Ac;
+  if (t0 < t1) walk_chunk<true, U, false>(a, n, live, t0, t1, s);
+}
+
 }  // namespace
 
-extern "C" int icrl_gae_dual_ex(const float* rewards, const float* costs, const float* reward_values,
+extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const float* reward_values,
                                 const float* cost_values, const float* dones, const float* last_v_r,
                                 const float* last_v_c, const uint8_t* last_dones, float* adv_r, float* adv_c,
                                 float* ret_r, float* ret_c, int T, int N, double reward_gamma, double reward_gae_lambda,
-                                double cost_gamma, double cost_gae_lambda, int waves_per_tile, void* stream) {
+                                double cost_gamma, double cost_gae_lambda, int waves_per_tile, void* ws, long long ws_bytes,
+                                void* stream) {
   if (T <= 0 || N <= 0) return fail("icrl_gae_dual: T = %d, N = %d", T, N);
   GaeArgs a{rewards, costs, reward_values, cost_values, dones, last_v_r, last_v_c, last_dones,
             adv_r, adv_c, ret_r, ret_c, T, N,
@@ -212,6 +282,27 @@ extern "C" int icrl_gae_dual_ex(const float* rewards, const float* costs, const 
     while (W > 1 && T / W < 2 * U_DEFAULT) W /= 4;
   }
   hipStream_t s = (hipStream_t)stream;
+  // up to 128 column tiles and a caller-owned workspace: the time axis is split over workgroups too (waves_per_tile 0, or 200 + C
+  // to force C workgroups per tile)
+  if ((waves_per_tile == 0 || waves_per_tile >= 200) && ws != nullptr && tiles * 2 <= 256) {
+    int C = waves_per_tile >= 200 ? waves_per_tile - 200 : T / (SPLIT_W * U_DEFAULT);
+    if (C > SPLIT_CMAX) C = SPLIT_CMAX;
+    // measured (tools/gae_small.py): 1 tile x 16, 4 tiles x 8 (T = 1024) / x 4 (T = 512), 8 tiles x 4 are the fastest splits:
+    // about 32 workgroups for the small shapes; more only adds hops to the fold
+    const int wg_cap = waves_per_tile >= 200 || tiles > 16 ? 256 : 32;
+    while (C > 1 && tiles * C > wg_cap) --C;
+    const long long need = (long long)tiles * C * (256 * 8 + 4);
+    if (C >= 2 && ws_bytes >= need) {
+      static std::atomic<unsigned> launches{0};
+      unsigned tag = ++launches;
+      if (tag == 0) tag = ++launches;                  // 0 = the workspace's initial contents
+      double* maps = (double*)ws;
+      unsigned* flags = (unsigned*)(maps + (size_t)tiles * C * 256);
+      hipLaunchKernelGGL(gae_dual_split_kernel, dim3(tiles * C), dim3(64 * SPLIT_W), 0, s, a, C, tag, maps, flags);
+      return (int)hipGetLastError();
+    }
+    if (waves_per_tile >= 200) return fail("icrl_gae_dual_ws: split %d needs 2..%d workgroups per tile and %lld B of workspace (%lld given)", waves_per_tile - 200, SPLIT_CMAX, need, ws_bytes);
+  }
   // one wave per 64-env tile streams T rows; with >= 1024 tiles, 4 neighbouring tiles share a workgroup (1 KB contiguous per
   // row and array, the 4 waves start together) and 16 rows x 5 arrays are in flight per wave: +5..8 % of HBM rate measured.
   // waves_per_tile codes 101 / 105 / 106 force those shapes for tools/gae_variants.py.
@@ -223,6 +314,16 @@ extern "C" int icrl_gae_dual_ex(const float* rewards, const float* costs, const 
   else if (shape == 16) hipLaunchKernelGGL((gae_dual_kernel<16, 8, false>), dim3(tiles), dim3(1024), 0, s, a);
   else return fail("icrl_gae_dual_ex: waves_per_tile = %d (0 = automatic, 1, 4, 16 or a shape code 101 / 105 / 106)", waves_per_tile);
   return (int)hipGetLastError();
+}
+
+extern "C" int icrl_gae_dual_ex(const float* rewards, const float* costs, const float* reward_values,
+                                const float* cost_values, const float* dones, const float* last_v_r,
+                                const float* last_v_c, const uint8_t* last_dones, float* adv_r, float* adv_c,
+                                float* ret_r, float* ret_c, int T, int N, double reward_gamma, double reward_gae_lambda,
+                                double cost_gamma, double cost_gae_lambda, int waves_per_tile, void* stream) {
+  return icrl_gae_dual_ws(rewards, costs, reward_values, cost_values, dones, last_v_r, last_v_c, last_dones, adv_r,
+                          adv_c, ret_r, ret_c, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda,
+                          waves_per_tile, nullptr, 0, stream);
 }
 
 extern "C" int icrl_gae_dual(const float* rewards, const float* costs, const float* reward_values,

@@ -35,7 +35,7 @@ class BufferT(C.Structure):
                 ("observations", vp), ("new_observations", vp), ("orig_observations", vp), ("new_orig_observations", vp),
                 ("actions", vp), ("dones", vp), ("log_probs", vp), ("rewards", vp), ("reward_values", vp), ("costs", vp),
                 ("orig_costs", vp), ("cost_values", vp), ("reward_advantages", vp), ("reward_returns", vp),
-                ("cost_advantages", vp), ("cost_returns", vp)]
+                ("cost_advantages", vp), ("cost_returns", vp), ("gae_ws", vp), ("gae_ws_bytes", C.c_longlong)]
 
 
 class AgentT(C.Structure):
@@ -63,3 +63,5 @@ def p(t):
         return None
     assert t.is_contiguous()
     return t.data_ptr()
+
+GAE_WS_BYTES = 256 * (256 * 8 + 4)       # ICRL_GAE_WS_BYTES

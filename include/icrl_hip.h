@@ -98,7 +98,10 @@ typedef struct {
   float* actions;                                                                      /* [T,N,act_store] */
   float *dones, *log_probs, *rewards, *reward_values, *costs, *orig_costs, *cost_values;
   float *reward_advantages, *reward_returns, *cost_advantages, *cost_returns; /* [T,N] */
+  void* gae_ws;             /* optional workspace of the GAE launch (see icrl_gae_dual_ws): device memory, zeroed once when */
+  long long gae_ws_bytes;   /* allocated, afterwards written by GAE launches only.  NULL: one workgroup per column tile */
 } icrl_buffer_t;
+#define ICRL_GAE_WS_BYTES (256 * (256 * 8 + 4))
 
 /* What OnPolicyWithCostAlgorithm carries between steps (common/on_policy_algorithm.py:367-416, base_class.py:346-353)
  * plus per-step scratch. */
@@ -172,6 +175,16 @@ int icrl_gae_dual_ex(const float* rewards, const float* costs, const float* rewa
                      float* adv_r, float* adv_c, float* ret_r, float* ret_c,
                      int T, int N, double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
                      int waves_per_tile, void* stream);
+
+/* The same scan with a caller-owned workspace (ICRL_GAE_WS_BYTES always suffices; zeroed once at allocation and written by
+ * these launches only): for up to 128 column tiles the time axis is additionally split over up to 16 workgroups per tile, a
+ * two-level scan over affine maps (the BASELINE-size launch, 64 envs x 2048 rows, walks 16 rows per wave instead of 128).
+ * waves_per_tile as above, or 200 + C to force C workgroups per tile.  ws == NULL: identical to icrl_gae_dual_ex. */
+int icrl_gae_dual_ws(const float* rewards, const float* costs, const float* reward_values, const float* cost_values,
+                     const float* dones, const float* last_v_r, const float* last_v_c, const uint8_t* last_dones,
+                     float* adv_r, float* adv_c, float* ret_r, float* ret_c,
+                     int T, int N, double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
+                     int waves_per_tile, void* ws, long long ws_bytes, void* stream);
 
 /* Write the transposed ([in][out]) weight copies the rollout-time kernels read coalesced.  Call after every change of
  * `params` (policy: after train(); cost net: after ConstraintNet.train / load). */

@@ -123,8 +123,16 @@ def test_numpy_stream_position_after_train(tk):
     numpy stream's."""
     N, T, E = 8, 32, 4
     agent = _agent("hc", N, T, batch_size=64, n_epochs=E, target_kl=tk)
-    agent._setup_learn(N * T)
-    agent.collect_rollouts(agent.env, None, agent.rollout_buffer, T, "cost")
+    rng = np.random.RandomState(3)
+    obs = rng.randn(T, N, 18).astype(np.float32)
+    op = o_nets.TwoCriticPolicy(18, 6); op.load_state_dict(agent.policy.state_dict())
+    with torch.no_grad():
+        a, vr, vc, lp = op.forward(torch.as_tensor(obs.reshape(-1, 18)))
+    _fill(agent, dict(observations=obs, actions=a.numpy().reshape(T, N, 6), log_probs=lp.numpy().reshape(T, N),
+                      reward_values=vr.numpy().reshape(T, N), cost_values=vc.numpy().reshape(T, N),
+                      reward_advantages=rng.randn(T, N).astype(np.float32), cost_advantages=rng.rand(T, N).astype(np.float32),
+                      reward_returns=rng.randn(T, N).astype(np.float32), cost_returns=rng.rand(T, N).astype(np.float32),
+                      orig_costs=rng.rand(T, N).astype(np.float32)))
     np.random.seed(1234)
     agent.train()
     from icrl_amd import logger
