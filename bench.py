@@ -186,11 +186,14 @@ def main():
             traffic = int(pmc["traffic_bytes"])
     roofline = dict(kernel="gae_dual_kernel", bound="hbm", achieved=round(sweep["achieved"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(sweep["achieved"] / HBM_PEAK_GBS, 4), traffic=traffic,
+                    traffic_source=(f"not measured in this run: PMC passes of the same launch shape committed as profiles/{os.path.basename(pmc_path)} "
+                                    "(FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc passes)") if traffic is not None else None,
                     at=f"T={sweep['T']}, N={sweep['envs']} envs: {sweep['bytes'] / 1e9:.2f} GB algorithmic (36 B/transition), "
                        f"{sweep['us']:.0f} us/launch — far beyond the 256 MB Infinity Cache, 2 workgroups per CU",
                     in_loop=dict(achieved=round(gae_ach, 1), frac=round(gae_ach / HBM_PEAK_GBS, 5), us_per_launch=round(float(np.mean(gae_us)), 1),
                                  launches=len(gae_us), bytes_per_launch=gae_bytes,
-                                 note="config-size launch (4.7 MB, cache-resident, launch/latency-bound)"))
+                                 note="the launch the loop itself makes (4.7 MB, cache-resident, latency-bound): two-level scan, "
+                                      "time axis split over 16 workgroups x 8 waves (gae_dual_split_kernel)"))
     # ---- the PPO kernel: flops of the 8 GEMMs per optimiser step x 3 nets, from the events around icrl_ppo_lag_train
     tr_ms = [e0.elapsed_time(e1) for e0, e1, _ in st["agent"].train_events]
     tr_steps = [n for _, _, n in st["agent"].train_events]
@@ -198,13 +201,13 @@ def main():
     flops_step = 3 * 2 * B * (O * H + H * H) * 3 + 2 * B * H * (A + 2) * 3      # fwd + 2x bwd of the three MLPs (+ heads)
     us_per_step = 1e3 * float(np.sum(tr_ms)) / max(1, int(np.sum(tr_steps)))
     ppo_tflops = flops_step / (us_per_step * 1e-6) / 1e12
-    roofline_ppo = dict(kernel="ppo_train_rows_kernel", bound="mfma", achieved=round(ppo_tflops, 4), peak=round(F32_MFMA_PEAK_TFLOPS * 3 / 256, 3),
+    roofline_ppo = dict(kernel="ppo_train_pairs_kernel", bound="mfma", achieved=round(ppo_tflops, 4), peak=round(F32_MFMA_PEAK_TFLOPS * 3 / 256, 3),
                         unit="TFLOP/s", frac=round(ppo_tflops / (F32_MFMA_PEAK_TFLOPS * 3 / 256), 4),
                         chip_peak=F32_MFMA_PEAK_TFLOPS, frac_chip=round(ppo_tflops / F32_MFMA_PEAK_TFLOPS, 5),
                         us_per_optimizer_step=round(us_per_step, 2), optimizer_steps=int(np.sum(tr_steps)),
                         note="dependent optimiser steps of the reference algorithm: 3 workgroups (one per MLP) = 3 of 256 CUs; "
-                             "peak = fp32 MFMA rate of those 3 CUs; the padded 16x16x4 MFMA work actually issued is 304 instructions "
-                             "per wave and step = 9.7k of the ~27k cycles of a step")
+                             "peak = fp32 MFMA rate of those 3 CUs; the padded 16x16x4 MFMA work actually issued is 2 x 148 instructions "
+                             "per SIMD and step = 9.5k of the ~22k cycles of a step (SQ counters: profiles/r02_train_pmc.md)")
     out = dict(metric="env-steps/sec (ICRL outer loop, HCWithPos-v0)", value=round(env_steps / dt, 1), unit="env-steps/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * dt / a.steps, 2), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",

@@ -951,7 +951,11 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
     }
   }
 #ifdef ICRL_FINE_PROF
-  if (tid == 0 && prof && role == 0)
+#ifndef ICRL_FINE_TID
+#define ICRL_FINE_TID 0
+#define ICRL_FINE_ROLE 0
+#endif
+  if (tid == ICRL_FINE_TID && prof && role == ICRL_FINE_ROLE)
     for (int k = 0; k < 20; ++k) a.stats[12 + k] = (float)((double)fph[k] / (double)(a.n_steps > 0 ? a.n_steps : 1));
 #endif
   if (tid == 0 && prof) {

@@ -1,6 +1,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+from icrl_amd import _lib as _l
+if os.environ.get("ICRL_LIB"):
+    _l.LIB_PATH = os.path.abspath(os.environ["ICRL_LIB"])       # tools only: a variant build (e.g. -DICRL_FINE_PROF)
 from icrl_amd.ppo_lag import PPOLagrangian
 from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
 from icrl_amd.constraint_net import ConstraintNet
