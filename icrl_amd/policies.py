@@ -4,7 +4,7 @@ ref: stable_baselines3/common/policies.py:598-779 (ActorTwoCriticsPolicy), commo
      common/distributions.py:114-192,249-298 (DiagGaussian / Categorical), icrl/utils.py:636-655 (get_net_arch).
 
 Scope: the two-critics MLP policy every BASELINE config uses — three separate tanh MLPs (pi / vf / cvf) with two hidden
-layers each (<= 64 wide), no shared trunk, DiagGaussian (Box) or Categorical (Discrete) head.  Parameter initialisation
+layers each (<= 64 wide, per branch; narrower layers are stored zero-padded to 64), no shared trunk, DiagGaussian (Box) or Categorical (Discrete) head.  Parameter initialisation
 runs on the host with torch-CPU exactly like the reference (same construction / orthogonal-init order, so the same seed
 gives the same weights); after that the flat buffer lives on the device and only kernels touch it.
 """
@@ -18,6 +18,7 @@ from . import _lib, spaces
 from .structs import PolicyT, p
 
 BRANCHES = ("policy_net", "value_net", "cost_value_net")
+HW = 64        # width the kernels are built for (HD in csrc/ppo_common.h, MAX_H in csrc/common.h)
 
 
 def state_dict_names(discrete, n_hidden=2):
@@ -41,16 +42,23 @@ class ActorTwoCriticsPolicy:
         if net_arch is None:
             net_arch = [dict(pi=[64, 64], vf=[64, 64], cvf=[64, 64])]
         arch = net_arch[-1] if isinstance(net_arch[-1], dict) else None
-        if arch is None or len(net_arch) != 1 or not (arch.get("pi") == arch.get("vf") == arch.get("cvf")) \
-                or len(arch["pi"]) != 2 or max(arch["pi"]) > 64:
-            raise NotImplementedError("icrl_amd supports net_arch=[dict(pi=[h1,h2], vf=[h1,h2], cvf=[h1,h2])] with h<=64 "
-                                      f"(every BASELINE config); got {net_arch}")
-        self.h1, self.h2 = int(arch["pi"][0]), int(arch["pi"][1])
+        if arch is None or len(net_arch) != 1 or any(len(arch.get(k, ())) != 2 or max(arch[k]) > HW or min(arch[k]) < 1
+                                                     for k in ("pi", "vf", "cvf")):
+            raise NotImplementedError("icrl_amd supports net_arch=[dict(pi=[h1,h2], vf=[h1,h2], cvf=[h1,h2])]: three separate "
+                                      f"two-layer MLPs, every width 1..{HW}, no shared trunk (the kernels are built for {HW}-wide "
+                                      f"layers; narrower ones run zero-padded); got {net_arch}")
+        # logical widths per branch (-pl / -rvl / -cvl, ref: icrl/utils.py:636-655).  The device buffers are always HW wide: a
+        # narrower layer is stored zero-padded.  Padding units have zero weights in and out and a zero bias, so they output
+        # tanh(0) = 0 exactly, receive a zero gradient and keep zero Adam moments: every real parameter sees exactly the
+        # arithmetic of the unpadded network (only zeros are added to its dot products).
+        self.widths = {b: (int(arch[k][0]), int(arch[k][1])) for b, k in zip(BRANCHES, ("pi", "vf", "cvf"))}
+        self.h1 = self.h2 = HW
         self.optimizer_kwargs = dict(eps=1e-5) if optimizer_kwargs is None else dict(optimizer_kwargs)  # ref: policies.py:357-361
         self.lr_schedule = lr_schedule
         sd = self._init_host(log_std_init, ortho_init)
-        self.shapes = OrderedDict((k, tuple(v.shape)) for k, v in sd.items())
-        flat = torch.cat([v.reshape(-1) for v in sd.values()]).float()
+        self.logical_shapes = OrderedDict((k, tuple(v.shape)) for k, v in sd.items())
+        self.shapes = OrderedDict((k, self._physical_shape(k, shp)) for k, shp in self.logical_shapes.items())
+        flat = torch.cat([self._pad(k, v).reshape(-1) for k, v in sd.items()]).float()
         self.n_params = flat.numel()
         self.params = flat.to(self.device).contiguous()
         self.params_t = torch.empty_like(self.params)
@@ -60,16 +68,44 @@ class ActorTwoCriticsPolicy:
         self.adam_step = 0
         self.prepare()
 
+    def _physical_shape(self, name, shp):
+        if name == "log_std":
+            return shp
+        if name.startswith("mlp_extractor."):
+            first = name.split(".")[2] == "0"
+            return ((HW, self.obs_dim if first else HW) if name.endswith("weight") else (HW,))
+        return (shp[0], HW) if name.endswith("weight") else shp          # heads: [outputs, last hidden]
+
+    def _pad(self, name, t):
+        """logical tensor -> device layout (zeros beyond the logical widths)."""
+        t = torch.as_tensor(np.asarray(t), dtype=torch.float32) if not torch.is_tensor(t) else t.detach().float().cpu()
+        assert tuple(t.shape) == self.logical_shapes[name], (name, tuple(t.shape), self.logical_shapes[name])
+        if self.shapes[name] == self.logical_shapes[name]:
+            return t
+        out = torch.zeros(self.shapes[name])
+        out[tuple(slice(0, n) for n in t.shape)] = t
+        return out
+
+    def _split(self, flat, pad=False):
+        """flat device-layout vector -> OrderedDict of logical tensors (the padding is dropped)."""
+        out, off = OrderedDict(), 0
+        for k, shp in self.shapes.items():
+            n = int(np.prod(shp))
+            out[k] = flat[off:off + n].reshape(shp)[tuple(slice(0, m) for m in self.logical_shapes[k])].clone()
+            off += n
+        return out
+
     def _init_host(self, log_std_init, ortho_init):
         """construction + init order of ActorTwoCriticsPolicy._build (ref: policies.py:648-714, torch_layers.py:208-226)."""
         Lin = torch.nn.Linear
         lins = {b: [] for b in BRANCHES}
-        last = self.obs_dim
-        for h in (self.h1, self.h2):
+        last = {b: self.obs_dim for b in BRANCHES}
+        for k in range(2):
             for b in BRANCHES:
-                lins[b].append(Lin(last, h))
-            last = h
-        heads = OrderedDict(action_net=Lin(last, self.act_dim), value_net=Lin(last, 1), cost_value_net=Lin(last, 1))
+                lins[b].append(Lin(last[b], self.widths[b][k]))
+                last[b] = self.widths[b][k]
+        heads = OrderedDict(action_net=Lin(last["policy_net"], self.act_dim), value_net=Lin(last["value_net"], 1),
+                            cost_value_net=Lin(last["cost_value_net"], 1))
         if ortho_init:
             for b in BRANCHES:
                 for lin in lins[b]:
@@ -98,17 +134,10 @@ class ActorTwoCriticsPolicy:
 
     # ---- state dict (reference names; ref: expert_data/*/files/best_model.zip:policy.pth) --------------------------
     def state_dict(self):
-        out, off = OrderedDict(), 0
-        flat = self.params.detach().cpu()
-        for k, shp in self.shapes.items():
-            n = int(np.prod(shp))
-            out[k] = flat[off:off + n].reshape(shp).clone()
-            off += n
-        return out
+        return self._split(self.params.detach().cpu())
 
     def load_state_dict(self, sd):
-        flat = torch.cat([torch.as_tensor(np.asarray(sd[k]), dtype=torch.float32).reshape(-1) if not torch.is_tensor(sd[k])
-                          else sd[k].detach().float().reshape(-1).cpu() for k in self.shapes])
+        flat = torch.cat([self._pad(k, sd[k]).reshape(-1) for k in self.shapes])
         assert flat.numel() == self.n_params
         self.params.copy_(flat.to(self.device))
         self.prepare()
@@ -116,13 +145,8 @@ class ActorTwoCriticsPolicy:
     def optimizer_state_dict(self, lr=None, eps=1e-5):
         """policy.optimizer.state_dict() in torch.optim.Adam's own layout (what SB3 stores as policy.optimizer.pth):
         parameters numbered in state_dict order, per-parameter step / exp_avg / exp_avg_sq."""
-        state, off = {}, 0
-        m, v = self.exp_avg.detach().cpu(), self.exp_avg_sq.detach().cpu()
-        for i, (k, shp) in enumerate(self.shapes.items()):
-            n = int(np.prod(shp))
-            state[i] = dict(step=torch.tensor(float(self.adam_step)), exp_avg=m[off:off + n].reshape(shp).clone(),
-                            exp_avg_sq=v[off:off + n].reshape(shp).clone())
-            off += n
+        m, v = self._split(self.exp_avg.detach().cpu()), self._split(self.exp_avg_sq.detach().cpu())
+        state = {i: dict(step=torch.tensor(float(self.adam_step)), exp_avg=m[k], exp_avg_sq=v[k]) for i, k in enumerate(self.shapes)}
         group = dict(lr=lr, betas=(0.9, 0.999), eps=eps, weight_decay=0, amsgrad=False, params=list(range(len(self.shapes))))
         return dict(state=state if self.adam_step > 0 else {}, param_groups=[group])
 
@@ -135,8 +159,8 @@ class ActorTwoCriticsPolicy:
         # reference wrote (expert_data/*/files/best_model.zip); both follow policy.parameters() = state_dict order
         keys = [k for g in osd.get("param_groups", []) for k in g["params"]] or sorted(state)
         assert len(keys) == len(self.shapes), "optimizer state does not match the policy's parameter list"
-        m = torch.cat([state[k]["exp_avg"].detach().float().reshape(-1) for k in keys])
-        v = torch.cat([state[k]["exp_avg_sq"].detach().float().reshape(-1) for k in keys])
+        m = torch.cat([self._pad(name, state[k]["exp_avg"]).reshape(-1) for name, k in zip(self.shapes, keys)])
+        v = torch.cat([self._pad(name, state[k]["exp_avg_sq"]).reshape(-1) for name, k in zip(self.shapes, keys)])
         assert m.numel() == self.exp_avg.numel()
         self.exp_avg.copy_(m.to(self.device)); self.exp_avg_sq.copy_(v.to(self.device))
         self.adam_step = int(float(state[keys[0]]["step"]))

@@ -247,9 +247,15 @@ def _make_ref_agent(n_envs, kind, seed, cn_hidden, **kw):
     return agent, env, cn
 
 
-def g4_ppo_minibatch():
-    print("G4 PPO-Lagrangian minibatch step + train()")
-    agent, env, cn = _make_ref_agent(4, "hc", 0, [20])
+def g13_widths():
+    """g4 with network widths other than 64 and different per branch (-pl / -rvl / -cvl, icrl/utils.py:636-655)."""
+    g4_ppo_minibatch("g13_widths", dict(pi=[32, 48], vf=[64, 32], cvf=[16, 64]))
+
+
+def g4_ppo_minibatch(name="g4_ppo_minibatch", arch=None):
+    print("G4 PPO-Lagrangian minibatch step + train()" + ("" if arch is None else f" {arch}"))
+    kw = {} if arch is None else dict(policy_kwargs=dict(net_arch=[dict(arch)]))
+    agent, env, cn = _make_ref_agent(4, "hc", 0, [20], **kw)
     pol = agent.policy
     sd0 = _sd_np(pol.state_dict())
     rng = np.random.RandomState(5)
@@ -260,7 +266,8 @@ def g4_ppo_minibatch():
     ret_r, ret_c = th.tensor(rng.randn(B), dtype=th.float32), th.tensor(rng.randn(B), dtype=th.float32)
     nu, clip = 0.731, 0.2
     # oracle policy with the same weights
-    op = o_nets.TwoCriticPolicy(18, 6); op.load_state_dict(pol.state_dict())
+    hidden = (64, 64) if arch is None else dict(policy_net=arch["pi"], value_net=arch["vf"], cost_value_net=arch["cvf"])
+    op = o_nets.TwoCriticPolicy(18, 6, hidden=hidden); op.load_state_dict(pol.state_dict())
     oopt = th.optim.Adam(op.parameters(), lr=3e-4, eps=1e-5)
     out = {}
     for step in range(3):                                # three consecutive steps on the same batch (Adam state evolves)
@@ -295,7 +302,7 @@ def g4_ppo_minibatch():
         out.update({f"s{step}/grad/{k}": v for k, v in grads.items()})
         out.update(_sd_np(pol.state_dict(), f"s{step}/after/"))
     print("  oracle == reference bit-for-bit (loss terms, grads, params after 3 Adam steps)")
-    save("g4_ppo_minibatch", obs=obs.numpy(), act=act.numpy(), old_lp=old_lp.numpy(), adv_r=adv_r.numpy(),
+    save(name, obs=obs.numpy(), act=act.numpy(), old_lp=old_lp.numpy(), adv_r=adv_r.numpy(),
          adv_c=adv_c.numpy(), ret_r=ret_r.numpy(), ret_c=ret_c.numpy(), nu=nu, clip=clip, lr=3e-4,
          **{f"w0/{k}": v for k, v in sd0.items()}, **out)
 
@@ -905,8 +912,8 @@ def fixtures_expert():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11", "g12", "g13"]
     table = dict(g1=g1_gae, g2=g2_cost_function, g3=g3_vecnormalize, g4=g4_ppo_minibatch, g5=g5_dual,
-                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g12=g12_gail, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
+                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g12=g12_gail, g13=g13_widths, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
     for w in which:
         table[w]()

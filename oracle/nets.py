@@ -31,18 +31,21 @@ class TwoCriticPolicy:
     BRANCHES = ("policy_net", "value_net", "cost_value_net")
 
     def __init__(self, obs_dim, act_dim, hidden=(64, 64), discrete=False, log_std_init=0.0, ortho_init=True):
-        self.obs_dim, self.act_dim, self.hidden, self.discrete = obs_dim, act_dim, tuple(hidden), discrete
+        # hidden: one (h1, h2) for the three branches, or a dict branch -> (h1, h2) (net_arch pi / vf / cvf, icrl/utils.py:636-655)
+        widths = {b: tuple(hidden[b]) for b in self.BRANCHES} if isinstance(hidden, dict) else {b: tuple(hidden) for b in self.BRANCHES}
+        self.obs_dim, self.act_dim, self.discrete = obs_dim, act_dim, discrete
+        self.hidden = widths[self.BRANCHES[0]]
         # construction order mirrors MlpExtractor's zip_longest loop (ref: torch_layers.py:208-226):
         # layer k of pi, vf, cvf are created back to back, so the torch RNG stream matches.
         lins = {b: [] for b in self.BRANCHES}
-        last = obs_dim
-        for h in self.hidden:
+        last = {b: obs_dim for b in self.BRANCHES}
+        for k in range(len(self.hidden)):
             for b in self.BRANCHES:
-                lins[b].append(th.nn.Linear(last, h))
-            last = h
-        action_net = th.nn.Linear(last, act_dim)
-        value_net = th.nn.Linear(last, 1)
-        cost_value_net = th.nn.Linear(last, 1)
+                lins[b].append(th.nn.Linear(last[b], widths[b][k]))
+                last[b] = widths[b][k]
+        action_net = th.nn.Linear(last["policy_net"], act_dim)
+        value_net = th.nn.Linear(last["value_net"], 1)
+        cost_value_net = th.nn.Linear(last["cost_value_net"], 1)
         if ortho_init:  # ref: policies.py:697-711 — gains sqrt(2) / 0.01 / 1 / 1, biases zero
             for b in self.BRANCHES:
                 for lin in lins[b]:

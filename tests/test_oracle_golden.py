@@ -73,9 +73,14 @@ def test_g3_vecnormalize_stream(golden):
         assert st.obs_rms.count == g["obs_count"][t] and st.cost_rms.count == g["cost_count"][t]
 
 
-def test_g4_ppo_minibatch(golden):
-    g = golden("g4_ppo_minibatch")
-    pol = o_nets.TwoCriticPolicy(18, 6)
+G13_WIDTHS = dict(policy_net=(32, 48), value_net=(64, 32), cost_value_net=(16, 64))      # oracle/gen_golden.py: g13_widths
+
+
+@pytest.mark.parametrize("name,hidden", [("g4_ppo_minibatch", (64, 64)), ("g13_widths", G13_WIDTHS)])
+def test_g4_ppo_minibatch(golden, name, hidden):
+    """3 optimiser steps of the reference's own policy / optimizer objects; g13: widths other than 64, different per branch."""
+    g = golden(name)
+    pol = o_nets.TwoCriticPolicy(18, 6, hidden=hidden)
     pol.load_state_dict(_sub(g, "w0/"))
     opt = th.optim.Adam(pol.parameters(), lr=float(g["lr"]), eps=1e-5)
     t = lambda k: th.as_tensor(g[k])

@@ -29,17 +29,28 @@ def _fill(agent, buf):
     rb.full = True
 
 
-def test_three_steps_on_one_batch_golden(golden):
-    """tests/golden/g4: the reference's own policy/optimizer objects stepped 3x on one 64-row batch."""
-    g = golden("g4_ppo_minibatch")
-    agent = _agent("hc", 1, 64, batch_size=64, n_epochs=3, target_kl=None, learning_rate=float(g["lr"]))
+G13_ARCH = dict(pi=[32, 48], vf=[64, 32], cvf=[16, 64])          # oracle/gen_golden.py: g13_widths
+
+
+@pytest.mark.parametrize("name,arch", [("g4_ppo_minibatch", None), ("g13_widths", G13_ARCH)])
+def test_three_steps_on_one_batch_golden(golden, name, arch):
+    """tests/golden/g4: the reference's own policy/optimizer objects stepped 3x on one 64-row batch.  g13: the same with
+    -pl 32 48 -rvl 64 32 -cvl 16 64 (narrower layers run zero-padded to the kernels' 64; state dicts keep the logical shapes)."""
+    g = golden(name)
+    kw = {} if arch is None else dict(policy_kwargs=dict(net_arch=[dict(arch)]))
+    agent = _agent("hc", 1, 64, batch_size=64, n_epochs=3, target_kl=None, learning_rate=float(g["lr"]), **kw)
     agent.policy.load_state_dict(_sub(g, "w0/"))
+    assert {k: tuple(v.shape) for k, v in agent.policy.state_dict().items()} == {k: g["w0/" + k].shape for k in agent.policy.shapes}
     z = np.zeros(64, np.float32)
     _fill(agent, dict(observations=g["obs"], actions=g["act"], log_probs=g["old_lp"], reward_advantages=g["adv_r"],
                       cost_advantages=g["adv_c"], reward_returns=g["ret_r"], cost_returns=g["ret_c"], reward_values=z,
                       cost_values=z, orig_costs=z))
     agent.dual.log_nu = np.float32(np.log(np.exp(float(g["nu"])) - 1))       # softplus^-1(nu)
     assert abs(agent.dual.nu().item() - float(g["nu"])) < 1e-6
+    v_r, v_c, lp, _ = agent.policy.evaluate_actions(g["obs"], g["act"])        # the rollout-side forward on the same weights
+    assert np.allclose(v_r.cpu().numpy().ravel(), g["s0/v_r"], rtol=1e-5, atol=2e-6)
+    assert np.allclose(v_c.cpu().numpy().ravel(), g["s0/v_c"], rtol=1e-5, atol=2e-6)
+    assert np.allclose(lp.cpu().numpy(), g["s0/log_prob"], rtol=1e-5, atol=2e-5)
     ident = np.tile(np.arange(64), (3, 1))
     agent.train(perms=ident)
     sd = agent.policy.state_dict()
@@ -57,6 +68,18 @@ def test_three_steps_on_one_batch_golden(golden):
     assert abs(lg["train/approx_kl"] - float(g["s2/approx_kl"])) < 1e-5
     assert abs(lg["train/clip_fraction"] - np.mean([g[f"s{s}/clip_fraction"] for s in range(3)])) < 1e-6
     assert agent.policy.adam_step == 3
+    if arch is not None:           # the padding stayed exactly zero (weights and both Adam moments)
+        pol = agent.policy
+        for flat in (pol.params, pol.exp_avg, pol.exp_avg_sq):
+            off, flat = 0, flat.cpu()
+            for k, shp in pol.shapes.items():
+                n = int(np.prod(shp))
+                full = flat[off:off + n].reshape(shp).clone()
+                full[tuple(slice(0, m) for m in pol.logical_shapes[k])] = 0
+                assert float(full.abs().max()) == 0.0, k
+                off += n
+        osd = pol.optimizer_state_dict(lr=3e-4)
+        assert tuple(osd["state"][1]["exp_avg"].shape) == g["w0/mlp_extractor.policy_net.0.weight"].shape
 
 
 ADAM_DEV_BOUND = 5e-4      # 3 x the largest deviation measured on MI355X (1.7e-4 x lr x steps; absolute: <= 9e-8, ~1 ulp)
