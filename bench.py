@@ -48,7 +48,8 @@ def config2(n_iters_total, seed, rank, world):
 
 
 def gae_sweep_point(N=131072, T=2048, reps=20):
-    """same kernel, working set 9.7 GB >> 256 MB Infinity Cache: the HBM-streaming regime (2 workgroups per CU)."""
+    """the same entry point at 131 072 envs: working set 9.7 GB >> 256 MB Infinity Cache, the HBM-streaming regime (the library
+    picks the four-columns-per-lane streaming shape from 65 536 envs on; bit-exact like the one-column scan)."""
     from icrl_amd import _lib
     L = _lib.lib()
     dev = torch.device("cuda")
@@ -184,12 +185,13 @@ def main():
             pmc = json.load(f)
         if pmc["T"] == sweep["T"] and pmc["N"] == sweep["envs"]:
             traffic = int(pmc["traffic_bytes"])
-    roofline = dict(kernel="gae_dual_kernel", bound="hbm", achieved=round(sweep["achieved"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
+    roofline = dict(kernel="gae_dual_x4_kernel", bound="hbm", achieved=round(sweep["achieved"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(sweep["achieved"] / HBM_PEAK_GBS, 4), traffic=traffic,
                     traffic_source=(f"not measured in this run: PMC passes of the same launch shape committed as profiles/{os.path.basename(pmc_path)} "
                                     "(FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc passes)") if traffic is not None else None,
                     at=f"T={sweep['T']}, N={sweep['envs']} envs: {sweep['bytes'] / 1e9:.2f} GB algorithmic (36 B/transition), "
-                       f"{sweep['us']:.0f} us/launch — far beyond the 256 MB Infinity Cache, 2 workgroups per CU",
+                       f"{sweep['us']:.0f} us/launch — far beyond the 256 MB Infinity Cache; four columns per lane (16-byte accesses), "
+                       f"{sweep['envs'] // 256} one-wave workgroups",
                     in_loop=dict(achieved=round(gae_ach, 1), frac=round(gae_ach / HBM_PEAK_GBS, 5), us_per_launch=round(float(np.mean(gae_us)), 1),
                                  launches=len(gae_us), bytes_per_launch=gae_bytes,
                                  note="the launch the loop itself makes (4.7 MB, cache-resident, latency-bound): two-level scan, "

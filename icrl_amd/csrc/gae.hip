@@ -261,6 +261,113 @@ __global__ void __launch_bounds__(64 * SPLIT_W) gae_dual_split_kernel(GaeArgs a,
   if (t0 < t1) walk_chunk<true, U, false>(a, n, live, t0, t1, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// streaming shape with FOUR adjacent columns per lane: every load / store is a 16-byte dwordx4 (1 KB per wave-instruction and
+// array instead of 256 B: a quarter of the memory instructions for the same bytes).  Same sequential per-column recurrence as the
+// one-column kernel (bit-exact).  Needs N % 4 == 0 (rows stay 16-byte aligned).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int U>
+struct Batch4 {
+  f4 r[U], c[U], vr[U], vc[U], d[U];
+};
+
+__device__ __forceinline__ f4 ldg4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f4*>(p)); }
+__device__ __forceinline__ void stg4(float* p, f4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f4*>(p)); }
+
+template <int U>
+__device__ __forceinline__ void load_batch4(const GaeArgs& a, unsigned n, int t_top, Batch4<U>& b) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    int t = t_top - u;
+    t = t < 0 ? 0 : t;
+    const size_t row = (size_t)t * a.N;
+    b.r[u] = ldg4(a.r + row + n);
+    b.c[u] = ldg4(a.c + row + n);
+    b.vr[u] = ldg4(a.vr + row + n);
+    b.vc[u] = ldg4(a.vc + row + n);
+    b.d[u] = ldg4(a.d + row + n);
+  }
+}
+
+struct Carry4 {
+  double Ar[4], Ac[4];
+  f4 vr_next, vc_next, d_next;
+};
+
+template <int U>
+__device__ __forceinline__ void run_batch4(const GaeArgs& a, unsigned n, int t_top, const Batch4<U>& b, Carry4& s) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int t = t_top - u;
+    if (t >= 0) {
+      f4 fr, fc, rr, rc;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float nnt = 1.0f - s.d_next[k];
+        const float gvr = (a.g_r * s.vr_next[k]) * nnt;      // ref: buffers.py:535-537 — float32 delta, float64 accumulate
+        const float gvc = (a.g_c * s.vc_next[k]) * nnt;
+        const float dr = (b.r[u][k] + gvr) - b.vr[u][k];
+        const float dc = (b.c[u][k] + gvc) - b.vc[u][k];
+        const float cr = a.gl_r * nnt;
+        const float cc = a.gl_c * nnt;
+        s.Ar[k] = (double)dr + (double)cr * s.Ar[k];
+        s.Ac[k] = (double)dc + (double)cc * s.Ac[k];
+        fr[k] = (float)s.Ar[k]; fc[k] = (float)s.Ac[k];
+        rr[k] = fr[k] + b.vr[u][k]; rc[k] = fc[k] + b.vc[u][k];
+      }
+      const size_t row = (size_t)t * a.N;
+      stg4(a.ar + row + n, fr);
+      stg4(a.ac + row + n, fc);
+      stg4(a.rr + row + n, rr);
+      stg4(a.rc + row + n, rc);
+      s.vr_next = b.vr[u];
+      s.vc_next = b.vc[u];
+      s.d_next = b.d[u];
+    }
+  }
+}
+
+template <int U, int G>
+__global__ void __launch_bounds__(64 * G) gae_dual_x4_kernel(GaeArgs a) {
+  const unsigned n = 4u * (blockIdx.x * 64 * G + threadIdx.x);
+  if (n >= (unsigned)a.N) return;                      // N % 4 == 0: a lane's four columns are all inside or all outside
+  Carry4 s;
+  int t = a.T - 1;
+  {  // t = T-1: bootstrap from the last values; `1.0 - last_dones(bool)` is float64 in the reference (buffers.py:530-531)
+    const size_t off = (size_t)t * a.N + n;
+    const f4 rew = ldg4(a.r + off), cost = ldg4(a.c + off), vr = ldg4(a.vr + off), vc = ldg4(a.vc + off), d = ldg4(a.d + off);
+    f4 fr, fc, rr, rc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double nnt = 1.0 - (a.ld[n + k] ? 1.0 : 0.0);
+      const float gvr = a.g_r * a.lvr[n + k];
+      const float gvc = a.g_c * a.lvc[n + k];
+      s.Ar[k] = ((double)rew[k] + (double)gvr * nnt) - (double)vr[k];
+      s.Ac[k] = ((double)cost[k] + (double)gvc * nnt) - (double)vc[k];
+      fr[k] = (float)s.Ar[k]; fc[k] = (float)s.Ac[k];
+      rr[k] = fr[k] + vr[k]; rc[k] = fc[k] + vc[k];
+    }
+    stg4(a.ar + off, fr); stg4(a.ac + off, fc); stg4(a.rr + off, rr); stg4(a.rc + off, rc);
+    s.vr_next = vr; s.vc_next = vc; s.d_next = d;
+    --t;
+  }
+  if (t < 0) return;
+  Batch4<U> b0, b1;
+  load_batch4<U>(a, n, t, b0);
+  while (true) {
+    if (t - U >= 0) load_batch4<U>(a, n, t - U, b1);
+    run_batch4<U>(a, n, t, b0, s);
+    t -= U;
+    if (t < 0) break;
+    if (t - U >= 0) load_batch4<U>(a, n, t - U, b0);
+    run_batch4<U>(a, n, t, b1, s);
+    t -= U;
+    if (t < 0) break;
+  }
+}
+
 }  // namespace
 
 extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const float* reward_values,
@@ -306,13 +413,24 @@ extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const 
   // one wave per 64-env tile streams T rows; with >= 1024 tiles, 4 neighbouring tiles share a workgroup (1 KB contiguous per
   // row and array, the 4 waves start together) and 16 rows x 5 arrays are in flight per wave: +5..8 % of HBM rate measured.
   // waves_per_tile codes 101 / 105 / 106 force those shapes for tools/gae_variants.py.
-  int shape = waves_per_tile >= 100 ? waves_per_tile : (W == 1 ? (tiles >= 1024 ? 106 : 101) : W);
+  // >= 1024 tiles and N % 4 == 0: four columns per lane (dwordx4), one wave per workgroup, 4 rows x 5 arrays x 1 KB in flight twice:
+  // 6.3 TB/s at 131 072 envs against 5.9 for shape 106 (tools/gae_variants.py); below 1024 tiles there are too few such waves.
+  int shape = waves_per_tile >= 100 ? waves_per_tile : (W == 1 ? (tiles >= 1024 ? (N % 4 == 0 ? 111 : 106) : 101) : W);
   if (shape == 101) hipLaunchKernelGGL((gae_dual_kernel<1, 8, true>), dim3(tiles), dim3(64), 0, s, a);
   else if (shape == 105) hipLaunchKernelGGL((gae_dual_kernel<1, 8, true, 4>), dim3((tiles + 3) / 4), dim3(256), 0, s, a);
   else if (shape == 106) hipLaunchKernelGGL((gae_dual_kernel<1, 16, true, 4>), dim3((tiles + 3) / 4), dim3(256), 0, s, a);
+  else if (shape >= 107 && shape <= 112 && N % 4 == 0) {     // four columns per lane: 107 / 108 / 109 = U 2 / 4 / 8 with 4 waves, 110 / 111 / 112 with 1 wave
+    const int lanes = (N / 4 + 63) / 64;                     // waves of 256 columns
+    if (shape == 107) hipLaunchKernelGGL((gae_dual_x4_kernel<2, 4>), dim3((lanes + 3) / 4), dim3(256), 0, s, a);
+    else if (shape == 108) hipLaunchKernelGGL((gae_dual_x4_kernel<4, 4>), dim3((lanes + 3) / 4), dim3(256), 0, s, a);
+    else if (shape == 109) hipLaunchKernelGGL((gae_dual_x4_kernel<8, 4>), dim3((lanes + 3) / 4), dim3(256), 0, s, a);
+    else if (shape == 110) hipLaunchKernelGGL((gae_dual_x4_kernel<2, 1>), dim3(lanes), dim3(64), 0, s, a);
+    else if (shape == 111) hipLaunchKernelGGL((gae_dual_x4_kernel<4, 1>), dim3(lanes), dim3(64), 0, s, a);
+    else hipLaunchKernelGGL((gae_dual_x4_kernel<8, 1>), dim3(lanes), dim3(64), 0, s, a);
+  }
   else if (shape == 4) hipLaunchKernelGGL((gae_dual_kernel<4, 8, false>), dim3(tiles), dim3(256), 0, s, a);
   else if (shape == 16) hipLaunchKernelGGL((gae_dual_kernel<16, 8, false>), dim3(tiles), dim3(1024), 0, s, a);
-  else return fail("icrl_gae_dual_ex: waves_per_tile = %d (0 = automatic, 1, 4, 16 or a shape code 101 / 105 / 106)", waves_per_tile);
+  else return fail("icrl_gae_dual_ex: waves_per_tile = %d (0 = automatic, 1, 4, 16 or a shape code 101 / 105 / 106, 107..112 with N %% 4 == 0)", waves_per_tile);
   return (int)hipGetLastError();
 }
 

@@ -169,7 +169,9 @@ int icrl_gae_dual(const float* rewards, const float* costs, const float* reward_
                   void* stream);
 
 /* Same kernel with the launch shape forced (roofline sweep): waves_per_tile in {1,4,16}; 0 = library heuristic;
- * 101 / 105 / 106 = one-wave-per-tile shapes with 1 / 4 / 4 tiles per workgroup and 8 / 8 / 16 rows in flight. */
+ * 101 / 105 / 106 = one-wave-per-tile shapes with 1 / 4 / 4 tiles per workgroup and 8 / 8 / 16 rows in flight;
+ * 107..112 = four columns per lane (16-byte accesses; N % 4 == 0): 2 / 4 / 8 rows in flight with 4 waves (107-109) or 1 wave
+ * (110-112) per workgroup.  All 1xx shapes are bit-exact replicas of the sequential scan. */
 int icrl_gae_dual_ex(const float* rewards, const float* costs, const float* reward_values, const float* cost_values,
                      const float* dones, const float* last_v_r, const float* last_v_c, const uint8_t* last_dones,
                      float* adv_r, float* adv_c, float* ret_r, float* ret_c,

@@ -31,21 +31,25 @@ def _ulp_diff(a, b):
 
 
 @pytest.mark.parametrize("case", ["t8n3", "t2000n1", "t256n16", "t1n4", "t64n5"])
-@pytest.mark.parametrize("W", [0, 1, 4, 16])
+@pytest.mark.parametrize("W", [0, 1, 4, 16, 106, 108, 111])
 def test_gae_golden(golden, case, W):
     g = golden("g1_gae")
     arrs = {k.split("/")[1]: g[k] for k in g.files if k.startswith(case + "/")}
+    if W > 106 and arrs["rewards"].shape[1] % 4:
+        pytest.skip("four-columns-per-lane shapes need N % 4 == 0")
     adv_r, adv_c, ret_r, ret_c = _run(arrs, arrs["params"], W)
     for got, key in ((adv_r, "reward_advantages"), (adv_c, "cost_advantages"), (ret_r, "reward_returns"), (ret_c, "cost_returns")):
-        if W == 1:
+        if W == 1 or W > 100:
             assert np.array_equal(got, arrs[key]), key          # sequential scan: bit-exact with the reference
         else:
             # time-chunked scan re-associates float64 products: <= 1 ulp of float32 (rtol 1.2e-7), in practice exact
             assert np.allclose(got, arrs[key], rtol=2e-7, atol=1e-7), key
 
 
-@pytest.mark.parametrize("T,N", [(2048, 64), (2048, 256), (500, 1000), (37, 4097), (2048, 4096)])
+@pytest.mark.parametrize("T,N", [(2048, 64), (2048, 256), (500, 1000), (37, 4097), (2048, 4096), (33, 65536), (9, 65540), (5, 65538)])
 def test_gae_vs_oracle_random(T, N):
+    """incl. the streaming shapes the heuristic picks from 65 536 envs on: four columns per lane (N % 4 == 0, with a ragged last
+    wave at 65 540) and one column per lane (65 538); both bit-exact."""
     rng = np.random.RandomState(T + N)
     arrs = dict(rewards=rng.randn(T, N), costs=rng.rand(T, N), reward_values=rng.randn(T, N), cost_values=rng.randn(T, N),
                 dones=(rng.rand(T, N) < 0.002), last_v_r=rng.randn(N), last_v_c=rng.randn(N), last_dones=rng.rand(N) < 0.2)
@@ -56,7 +60,7 @@ def test_gae_vs_oracle_random(T, N):
     for W in (0, 1):
         adv_r, adv_c, ret_r, ret_c = _run(arrs, params, W)
         for got, key in ((adv_r, "reward_advantages"), (adv_c, "cost_advantages"), (ret_r, "reward_returns"), (ret_c, "cost_returns")):
-            if W == 1:
+            if W == 1 or N >= 65536:
                 assert np.array_equal(got, o[key]), (key, W)
             else:
                 assert np.allclose(got, o[key], rtol=2e-7, atol=1e-7), (key, W)

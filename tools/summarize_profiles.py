@@ -50,7 +50,7 @@ def gae_pmc(tag, T=2048, N=131072):
             print("no counter csv for", name); return
         vals, keep = [], []
         for r in csv.DictReader(open(src)):
-            if "gae_dual_kernel" in r["Kernel_Name"] and r["Counter_Name"] == name:
+            if "gae_dual" in r["Kernel_Name"] and r["Counter_Name"] == name:
                 vals.append(float(r["Counter_Value"])); keep.append(r)
         out[name] = vals
         with open(os.path.join(ROOT, "profiles", f"{tag}_gae_pmc_{'fetch' if key == 'f' else 'write'}.csv"), "w") as f:
