@@ -41,6 +41,8 @@ SIGNATURES = {
     "icrl_cn_train_work_floats": [c_int, c_int, c_int, c_int],
     "icrl_cn_train": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "icrl_debug_rollout_profile": [c_void_p],
+    "icrl_debug_rollout_profile_wide": [c_void_p],
+    "icrl_debug_rollout_trace_wide": [c_void_p, c_int],
     "icrl_cn_train_minibatch": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p],
 }

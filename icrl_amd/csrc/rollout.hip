@@ -18,6 +18,9 @@
 //
 // Weights are read from the transposed copies ([in][out]) written by *_prepare so that the 64 lanes of a wave
 // (one lane per output unit) load 256 contiguous bytes per input index.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace icrl {
@@ -68,17 +71,28 @@ struct ActShared {
 // W2^T of network w; lanes < A of wave 0 own a column of the action head, the value waves one head weight per lane.
 // All loads are issued back to back (one memory latency for the whole network instead of one per input index); a
 // persistent kernel loads them ONCE for all its steps.
-template <int OCT>
-struct PolRegs {
-  float w1[16 * OCT];
-  float w2[MAX_H];
+// ONE register image per wave for both roles: a wave is either a policy wave (pi / vf / cvf) or the cost-net wave, never both,
+// but the compiler cannot know that and would keep two full weight sets live in every wave (at AntWall widths 263 + 232
+// values: 468 registers spilled to scratch, the cost wave alone 50 k cycles per step).  The two roles' arrays of equal type
+// share storage through anonymous unions (same element type: plain aliases, no type punning).
+template <int OCT, int CIT>
+struct WaveRegs {
+  static constexpr int NA = 16 * (OCT > CIT ? OCT : CIT);
+  union { float w1[NA]; float c0[NA]; };          // policy: W1 column of hidden unit `lane` (16 OCT used) | cost net: W0 column (16 CIT)
+  union { float w2[MAX_H]; float c1[MAX_H]; };    // second layer column
   float wh[MAX_H];   // wave 0: head column of action `lane`; waves 1/2: wh[0] = value-head weight of hidden unit `lane`
-  float b1, b2, bh, ls;
+  union { float b1; float cb0; };
+  union { float b2; float cb1; };
+  union { float bh; float cbo; };
+  union { float ls; float co; };
   float sd, lsd, i2v;   // Gaussian head constants of action `lane`: exp(log_std), log(exp(log_std)), 1 / (2 sd^2) denominators
+  int sel[(16 * (CIT > 0 ? CIT : 1) + WAVE - 1) / WAVE];   // cost net: select_dim entries this lane prepares
 };
+template <int OCT> using PolRegs = WaveRegs<OCT, 0>;
+template <int CIT> using CnRegs = WaveRegs<0, CIT>;
 
-template <int OCT>
-__device__ __forceinline__ void load_pol_regs(const PolLayout& L, const float* __restrict__ PT, PolRegs<OCT>& R) {
+template <int OCT, class Regs>
+__device__ __forceinline__ void load_pol_regs(const PolLayout& L, const float* __restrict__ PT, Regs& R) {
   const int lane = threadIdx.x & 63;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int j1 = lane < L.H1 ? lane : 0, j2 = lane < L.H2 ? lane : 0;
@@ -107,8 +121,8 @@ __device__ __forceinline__ void load_pol_regs(const PolLayout& L, const float* _
 
 // three tanh MLPs + heads for the observation in sh.x.  Must be called by all threads of the workgroup (waves >= 3 only
 // take part in the barriers).
-template <int OCT>
-__device__ __forceinline__ void policy_forward_block(const PolLayout& L, const PolRegs<OCT>& R, ActShared& sh,
+template <int OCT, class Regs>
+__device__ __forceinline__ void policy_forward_block(const PolLayout& L, const Regs& R, ActShared& sh,
                                                      const float* noise_row, int deterministic,
                                                      const float* alow, const float* ahigh,
                                                      const float* given = nullptr /* evaluate_actions: actions to score */) {
@@ -202,36 +216,28 @@ __device__ __forceinline__ void policy_forward_block(const PolLayout& L, const P
   }
 }
 
-// cost-net weights of one lane (lane j <-> hidden unit j), loaded with independent loads before they are needed
-template <int CIT>
-struct CnRegs {
-  float w0[16 * CIT];
-  float w1[MAX_H];
-  float wo, b0, b1, bo;
-  int sel[(16 * CIT + WAVE - 1) / WAVE];   // select_dim entries this lane prepares
-};
-
-template <int CIT>
-__device__ __forceinline__ void load_cn_regs(const icrl_costnet_t& cn, const CnLayout& L, CnRegs<CIT>& R) {
+// cost-net weights of one lane (lane j <-> hidden unit j), loaded with independent loads before they are needed (WaveRegs c0 / c1 / ...)
+template <int CIT, class Regs>
+__device__ __forceinline__ void load_cn_regs(const icrl_costnet_t& cn, const CnLayout& L, Regs& R) {
   const int lane = threadIdx.x & 63;
   const float* PT = cn.params_t;
   const int j1 = lane < L.H1 ? lane : 0, j2 = lane < L.H2 ? lane : 0;
 #pragma unroll
-  for (int k = 0; k < 16 * CIT; ++k) R.w0[k] = k < L.in ? PT[L.W0 + k * L.H1 + j1] : 0.f;
+  for (int k = 0; k < 16 * CIT; ++k) R.c0[k] = k < L.in ? PT[L.W0 + k * L.H1 + j1] : 0.f;
 #pragma unroll
-  for (int k = 0; k < MAX_H; ++k) R.w1[k] = (L.nh == 2 && k < L.H1) ? PT[L.W1 + k * L.H2 + j2] : 0.f;
-  R.b0 = PT[L.b0 + j1];
-  R.b1 = L.nh == 2 ? PT[L.b1 + j2] : 0.f;
-  R.wo = PT[L.Wo + j2];
-  R.bo = PT[L.bo];
+  for (int k = 0; k < MAX_H; ++k) R.c1[k] = (L.nh == 2 && k < L.H1) ? PT[L.W1 + k * L.H2 + j2] : 0.f;
+  R.cb0 = PT[L.b0 + j1];
+  R.cb1 = L.nh == 2 ? PT[L.b1 + j2] : 0.f;
+  R.co = PT[L.Wo + j2];
+  R.cbo = PT[L.bo];
 #pragma unroll
   for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) { const int idx = lane + i * WAVE; R.sel[i] = idx < L.in ? cn.select_dim[idx] : -1; }
 }
 
 // cost = 1 - sigmoid(ReLU-MLP(prepare(obs, acs))); called by ONE wave. obs_row: float64 raw obs (LDS or global),
 // acs_row: float32 actions.  cx: >= 16*CIT floats (16-byte aligned), ch: [2][MAX_H].  Returns the cost in every lane.
-template <int CIT>
-__device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, const CnLayout& L, const CnRegs<CIT>& R,
+template <int CIT, class Regs>
+__device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, const CnLayout& L, const Regs& R,
                                                    const double* obs_row, const float* acs_row, float* cx, float (*ch)[MAX_H],
                                                    int mode = 0 /* 0: cost = 1 - zeta; 1: zeta; 2: log(zeta + eps) */) {
   const int lane = threadIdx.x & 63;
@@ -265,8 +271,8 @@ __device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, con
     for (int i = 0; i < 4 * CIT; ++i) xs[i] = *reinterpret_cast<const f32x4*>(&cx[4 * i]);
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16 * CIT; ++k) acc = fmaf(R.w0[k], xs[k >> 2][k & 3], acc);
-    ch[0][lane] = lane < L.H1 ? fmaxf(acc + R.b0, 0.f) : 0.f;
+    for (int k = 0; k < 16 * CIT; ++k) acc = fmaf(R.c0[k], xs[k >> 2][k & 3], acc);
+    ch[0][lane] = lane < L.H1 ? fmaxf(acc + R.cb0, 0.f) : 0.f;
   }
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -277,14 +283,14 @@ __device__ __forceinline__ float cost_forward_wave(const icrl_costnet_t& cn, con
     for (int i = 0; i < MAX_H / 4; ++i) hs[i] = *reinterpret_cast<const f32x4*>(&ch[0][4 * i]);
     float acc = 0.f;
 #pragma unroll
-    for (int k = 0; k < MAX_H; ++k) acc = fmaf(R.w1[k], hs[k >> 2][k & 3], acc);
-    ch[1][lane] = lane < L.H2 ? fmaxf(acc + R.b1, 0.f) : 0.f;
+    for (int k = 0; k < MAX_H; ++k) acc = fmaf(R.c1[k], hs[k >> 2][k & 3], acc);
+    ch[1][lane] = lane < L.H2 ? fmaxf(acc + R.cb1, 0.f) : 0.f;
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_s_waitcnt(0xC07F);
     last = 1;
   }
-  float part = lane < L.H2 ? R.wo * ch[last][lane] : 0.f;
-  const float z = wave_sum_fast(part) + R.bo;
+  float part = lane < L.H2 ? R.co * ch[last][lane] : 0.f;
+  const float z = wave_sum_fast(part) + R.cbo;
   const float zeta = 1.f / (1.f + expf(-z));
   if (mode == 1) return zeta;
   if (mode == 2) return logf(zeta + (float)cn.eps);
@@ -421,8 +427,8 @@ struct ActStepArgs {
 template <int OCT, int CIT>
 __global__ void __launch_bounds__(256) act_step_kernel(ActStepArgs a, int t) {
   __shared__ ActShared sh;
-  PolRegs<OCT> R;
-  CnRegs<CIT> C;
+  WaveRegs<OCT, CIT> R;                // one image: policy weights in waves 0..2, cost-net weights in wave 3
+  WaveRegs<OCT, CIT>& C = R;
   load_pol_regs<OCT>(a.pl, a.PT, R);   // every weight load of the step is in flight before anything waits
   if (threadIdx.x >= 192 && a.has_cn) load_cn_regs<CIT>(a.cn, a.cl, C);   // wave 3 = cost net
   const int n = blockIdx.x;
@@ -862,7 +868,10 @@ __global__ void __launch_bounds__(1024) norm_step_small_kernel(NormStepArgs a) {
 // dynamics matrix and the replicated statistics are loaded once for the whole rollout.
 // =================================================================================================================
 // diagnostic: cycles per phase of workgroup 0 of the last persistent rollout (policy+env | barrier | statistics), steps
+constexpr int NORM_MAX_N_TRACE = 1024;
 __device__ unsigned long long g_rollout_prof[8];
+__device__ unsigned long long g_rollout_prof_wide[16];
+__device__ unsigned long long g_wide_trace[NORM_MAX_N_TRACE * 4];   // per workgroup, one step: s_memrealtime at phase-A end / gather end / publish / statistics read     // rollout_wide_kernel: [0..7] wave 0, [8..15] wave 1 (owner) of the profiled workgroup
 __device__ __forceinline__ unsigned long long prof_now() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -947,8 +956,8 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
   __shared__ int last_done_s;
   const ActStepArgs& a = p.act;
   const icrl_norm_t& nm = p.nm;
-  PolRegs<OCT> R;
-  CnRegs<CIT> C;
+  WaveRegs<OCT, CIT> R;                // one image: policy weights in waves 0..2, cost-net weights in wave 3
+  WaveRegs<OCT, CIT>& C = R;
   load_pol_regs<OCT>(a.pl, a.PT, R);
   if (threadIdx.x >= 192 && a.has_cn) load_cn_regs<CIT>(a.cn, a.cl, C);
   const int n = blockIdx.x;
@@ -1191,6 +1200,7 @@ struct WideArgs {
   ActStepArgs act;
   icrl_norm_t nm;
   int T, G;                    // steps; grid size (workgroup g serves envs g, g + G, ...)
+  int prof;                    // diagnostic phase timers of workgroup `prof - 1` (do_gae bit 2: workgroup 0; bit 3: the last one)
   unsigned long long* xg;      // [2][N][2 obs + 4] env granules {step tag | 32 payload bits}, zeroed before the launch
   unsigned long long* sg;      // [2][4 obs + 4] statistics granules, zeroed before the launch
 };
@@ -1207,8 +1217,8 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
   __shared__ int tep_s[WIDE_E], last_done_s[WIDE_E], done_s[WIDE_E], done_all[NORM_MAX_N];
   const ActStepArgs& a = p.act;
   const icrl_norm_t& nm = p.nm;
-  PolRegs<OCT> R;
-  CnRegs<CIT> C;
+  WaveRegs<OCT, CIT> R;                // one image: policy weights in waves 0..2, cost-net weights in wave 3
+  WaveRegs<OCT, CIT>& C = R;
   load_pol_regs<OCT>(a.pl, a.PT, R);
   if (threadIdx.x >= 192 && a.has_cn) load_cn_regs<CIT>(a.cn, a.cl, C);
   const int g = blockIdx.x, G = p.G;
@@ -1249,6 +1259,8 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
   }
   int spin_limit = 1 << 22;
   __syncthreads();
+  const bool prof = p.prof != 0 && g == p.prof - 1;
+  unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, tl = prof ? prof_now() : 0ull;
   for (int t = 0; t < T; ++t) {
     const int par = t & 1;
     const unsigned gtag = (unsigned)(t + 1);
@@ -1306,6 +1318,9 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
         }
       }
     }
+    if (prof) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }     // policy + env + rows (this wave's part)
+    const bool trace = p.prof != 0 && t == T / 2 && lane == 0;
+    if (trace && w == 0) g_wide_trace[4 * g + 0] = __builtin_amdgcn_s_memrealtime();
     // ---------------- phase B1: the owners (wave 1) gather their statistic from all envs and publish it ----------------
     if (w == 1 && (own_col >= 0 || own_ret || own_cost)) {
       const unsigned long long* xb = p.xg + (size_t)par * N * GX;
@@ -1355,6 +1370,8 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xC07F);
+      if (prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }   // owner: gather (wait for all envs)
+      if (trace) g_wide_trace[4 * g + 1] = __builtin_amdgcn_s_memrealtime();
       double bm, bv;
       if (own_col >= 0) {
         column_moments_contig(colbuf, N, bm, bv);                   // every lane computes the same chain (numpy's axis-0 order)
@@ -1381,6 +1398,8 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
       }
       if (own_col < 0)      // returns of finished episodes restart at 0 (vec_normalize.py:99, 241)
         for (int i = lane; i < N; i += WAVE) retbuf[i] = done_all[i] ? 0.0 : colbuf[i];
+      if (prof) { const unsigned long long tn_ = prof_now(); pc2 += tn_ - tl; tl = tn_; }   // owner: moments + merge + publish
+      if (trace) g_wide_trace[4 * g + 2] = __builtin_amdgcn_s_memrealtime();
     }
     // ---------------- phase B2: everybody reads the statistics granules, then normalises its own envs ----------------
     {
@@ -1407,6 +1426,8 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
       }
     }
     __syncthreads();
+    if (prof) { const unsigned long long tn_ = prof_now(); pc3 += tn_ - tl; tl = tn_; }     // statistics granules arrived
+    if (trace && w == 0) g_wide_trace[4 * g + 3] = __builtin_amdgcn_s_memrealtime();
     for (int e = 0; e < E; ++e) {
       const int n = g + e * G;
       const size_t tn = (size_t)t * N + n;
@@ -1432,6 +1453,11 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
     }
     if (pf) noise_s[par ^ 1][pe][pk] = noise_next;
     __syncthreads();
+    if (prof) { const unsigned long long tn_ = prof_now(); pc4 += tn_ - tl; tl = tn_; }     // normalise + rows
+  }
+  if (prof && (tid == 0 || tid == 64)) {      // wave 0: policy wave's view; wave 1: the owner's
+    unsigned long long* o = g_rollout_prof_wide + (tid == 64 ? 8 : 0);
+    o[0] = pc0; o[1] = pc1; o[2] = pc2; o[3] = pc3; o[4] = pc4; o[5] = (unsigned long long)T;
   }
   if (spin_limit == 1 && a.ag.status != nullptr && (tid & 63) == 0) atomicOr(a.ag.status, 1);
   // ---- leave the agent / wrapper / normaliser state exactly where the per-step path leaves it
@@ -1788,6 +1814,13 @@ extern "C" int icrl_vecnorm_step(const icrl_norm_t* nm, const double* raw_obs, c
   return (int)hipGetLastError();
 }
 
+extern "C" int icrl_debug_rollout_profile_wide(unsigned long long* out16) {
+  return (int)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_rollout_prof_wide), sizeof(unsigned long long) * 16);
+}
+extern "C" int icrl_debug_rollout_trace_wide(unsigned long long* out, int n_workgroups) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_trace), sizeof(unsigned long long) * 4 * (size_t)(n_workgroups < NORM_MAX_N_TRACE ? n_workgroups : NORM_MAX_N_TRACE));
+}
+
 extern "C" int icrl_debug_rollout_profile(unsigned long long* out4) {
   return (int)hipMemcpyFromSymbol(out4, HIP_SYMBOL(g_rollout_prof), sizeof(unsigned long long) * 8);
 }
@@ -1838,9 +1871,10 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
       const size_t need = 16 * (size_t)N * GX + 16 * GS + 256;
       void* ws = (ag->xch_ws != nullptr && (size_t)ag->xch_ws_bytes >= need) ? ag->xch_ws
                  : ((size_t)T * N * sizeof(float) >= need ? (void*)buf->reward_advantages : nullptr);
+      if (getenv("ICRL_DEBUG")) fprintf(stderr, "icrl_rollout_collect: wide persistent kernel N=%d obs=%d: %d workgroup(s) per CU x %d CUs -> E=%d envs per workgroup, grid %d\n", N, O, per_cu, cus, E, G);
       if (E <= WIDE_E && G >= O + 2 && ws != nullptr) {
         WideArgs p;
-        p.act = a; p.nm = *nm; p.T = T; p.G = G;
+        p.act = a; p.nm = *nm; p.T = T; p.G = G; p.prof = (do_gae & 4) ? 1 : ((do_gae & 8) ? G : 0);
         p.xg = reinterpret_cast<unsigned long long*>(ws);
         p.sg = p.xg + 2 * (size_t)N * GX;
         hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);

@@ -168,7 +168,7 @@ class PPOLagrangian:
                     p(self._ag["xch_ws"]), self._ag["xch_ws"].numel() * 8)
         b = _lib.byref
         timed = getattr(self, "gae_events", None) is not None
-        flags = int(not timed) | (2 if getattr(self, "rollout_kernel", "auto") == "steps" else 0) | (4 if getattr(self, "profile_phases", 0) else 0)
+        flags = int(not timed) | (2 if getattr(self, "rollout_kernel", "auto") == "steps" else 0) | ((4 if getattr(self, "_wide_prof_flag", 1) == 1 else 8) if getattr(self, "profile_phases", 0) else 0)
         from .seed_batch import budgeted
         with budgeted(0 if flags & 2 else self.n_envs):      # persistent launch: one CU per environment (several runs on one GPU)
             _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn) if cn is not None else None, b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),

@@ -314,6 +314,12 @@ int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, i
 /* Diagnostic: cycles per phase of workgroup 0 of the last persistent rollout that ran with do_gae bit 2 set
  * (out8: policy+env, barrier, tail, steps, exchange load, statistics, normalise, 0). */
 int icrl_debug_rollout_profile(unsigned long long* out8);
+/* the same for the many-environment persistent kernel: 5 phase sums + T of wave 0 ([0..7]) and of the owner wave ([8..15]) of
+ * workgroup 0 (do_gae bit 2) or of the last workgroup, which owns no statistic (do_gae bit 3). */
+int icrl_debug_rollout_profile_wide(unsigned long long* out16);
+/* per workgroup of that kernel, step T/2 of a profiled launch: 100 MHz timestamps at the end of its env phase, of its owner's
+ * gather, of its owner's publish (0 when it owns no statistic) and when it had read all statistics: out[4 * n_workgroups]. */
+int icrl_debug_rollout_trace_wide(unsigned long long* out, int n_workgroups);
 
 /* Minibatch mode of ConstraintNet.train (`--cn_batch_size`; icrl/constraint_net.py:181-206 with get() :300-316): per
  * iteration the importance weights / early-stop test on ALL nominal rows as above, then one optimiser step per batch of

@@ -21,6 +21,32 @@ def run(kind, N, T, broken=False):
         torch.cuda.synchronize(); dt = time.time() - t0
         agent.check_rollout_status()
         print(f"{kind}{'-broken' if broken else ''} N={N} T={T} {mode:5s}: {1e3 * dt:8.2f} ms = {1e6 * dt / T:7.2f} us/step = {N * T / dt / 1e6:6.2f} M env-steps/s")
+    if N > 128 and os.environ.get("PHASES"):          # phase timers of the many-environment persistent kernel (cycles per step)
+        import ctypes
+        from icrl_amd import _lib
+        agent.rollout_kernel = "auto"
+        for flag, who in ((1, "workgroup 0 (env + column owner)"), (2, "last workgroup (env only)")):
+            agent.profile_phases = 1
+            agent._wide_prof_flag = flag
+            agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost")
+            torch.cuda.synchronize()
+            out = (ctypes.c_ulonglong * 16)()
+            _lib.lib().icrl_debug_rollout_profile_wide(out)
+            names = ("policy+env+rows", "owner gather", "owner moments+publish", "statistics wait", "normalise+rows")
+            for base, wave in ((0, "wave 0"), (8, "wave 1")):
+                Tn = max(1, out[base + 5])
+                print(f"   {who}, {wave}: " + ", ".join(f"{n} {out[base + k] / Tn:.0f}" for k, n in enumerate(names)) + f"  (sum {sum(out[base:base + 5]) / Tn:.0f} cycles/step)")
+        G = min(N, 256)
+        tr = (ctypes.c_ulonglong * (4 * G))()
+        _lib.lib().icrl_debug_rollout_trace_wide(tr, G)
+        tr = np.array(list(tr), dtype=np.float64).reshape(G, 4)
+        t0 = tr[:, 0].min()
+        us = lambda x: (x - t0) / 100.0
+        owners = tr[:, 2] > 0
+        print(f"   one step, us after the first workgroup left its env phase: env phase ends {us(tr[:, 0]).min():.1f}..{us(tr[:, 0]).max():.1f}; "
+              f"owners' gathers end {us(tr[owners, 1]).min():.1f}..{us(tr[owners, 1]).max():.1f}; publishes {us(tr[owners, 2]).min():.1f}..{us(tr[owners, 2]).max():.1f} "
+              f"(latest: workgroups {np.argsort(-tr[:, 2])[:4].tolist()}, {np.sort(us(tr[:, 2]))[-4:][::-1].round(1).tolist()}); statistics read {us(tr[:, 3]).min():.1f}..{us(tr[:, 3]).max():.1f}")
+        agent.profile_phases = 0
 
 for cfg in (("hc", 64, 2048), ("hc", 256, 1024), ("ant", 256, 512), ("ant", 512, 256, True)):
     run(*cfg)
