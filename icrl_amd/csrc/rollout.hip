@@ -675,6 +675,31 @@ __global__ void __launch_bounds__(1024) norm_step_kernel(NormStepArgs a) {
 // registers with ONE round of global loads, the three statistics are computed concurrently by different waves
 // (observation columns: threads < O; reward return: wave 15; cost return: wave 14 — for N <= 128 numpy's pairwise sum is a
 // single 8-accumulator leaf, which 8 lanes reproduce exactly), one barrier, then everything is normalised from LDS.
+// numpy's pairwise sum for n in {128, 256, 512, 1024} (leaves of exactly 128, a balanced tree above them), evaluated by one
+// wave: lane 8 L + k owns accumulator k of leaf L (a 16-add chain instead of n adds in every lane); the xor butterflies
+// reproduce the leaf's ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and the recursion's left + right (float64 addition is commutative
+// bit for bit, so only the association matters).  Result in every lane.  Other n: np_pairwise_sum (common.h).
+__device__ __forceinline__ double np_pairwise_sum_wave(const double* a, int n) {
+  const int leaves = n >> 7;
+  if ((n & 127) != 0 || (leaves & (leaves - 1)) != 0 || leaves > 8) return np_pairwise_sum(a, n);
+  const int lane = threadIdx.x & 63;
+  const int L = lane >> 3, k = lane & 7;
+  const double* p = a + 128 * (L < leaves ? L : 0) + k;
+  double v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = p[8 * i];
+  double r = v[0];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) r += v[i];
+  r += __shfl_xor(r, 1, 64);
+  r += __shfl_xor(r, 2, 64);
+  r += __shfl_xor(r, 4, 64);
+  if (leaves >= 2) r += __shfl_xor(r, 8, 64);
+  if (leaves >= 4) r += __shfl_xor(r, 16, 64);
+  if (leaves >= 8) r += __shfl_xor(r, 32, 64);
+  return __shfl(r, 0, 64);
+}
+
 __device__ __forceinline__ double np_leaf_sum_wave(const double* a, int n) {
   // numpy pairwise sum of n <= 128 contiguous doubles, evaluated by one wave; result valid in every lane
   const int lane = threadIdx.x & 63;
@@ -740,19 +765,32 @@ __device__ __forceinline__ void column_moments(const double* col, int stride, in
 // the same moments for a column stored CONTIGUOUSLY (persistent rollout: the exchanged observations are transposed into LDS), so
 // every read is a ds_read with an immediate offset from one running base; the column is padded with >= 32 readable entries.
 __device__ __forceinline__ void column_moments_contig(const double* col, int N, double& bm, double& bv) {
+  // One dependent float64 add per row is the floor (numpy's axis-0 order is a single chain); everything else stays off that
+  // chain: rows are fetched 16 at a time one batch ahead, and only the last, partial block of 32 carries the `row < N` selects
+  // (a select per row on the chain costs more than the add itself).
   double va[16], vb[16];
   double sum = 0.0;
+  const int NF = N & ~31;              // rows in full blocks of 32
 #pragma unroll
   for (int k = 0; k < 16; ++k) va[k] = col[k];
-  for (int r0 = 0; r0 < N; r0 += 32) {
+  int r0 = 0;
+  for (; r0 < NF; r0 += 32) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) vb[k] = col[r0 + 16 + k];
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) if (r0 + k < N) sum += va[k];
+    for (int k = 0; k < 16; ++k) sum += va[k];
 #pragma unroll
     for (int k = 0; k < 16; ++k) va[k] = col[r0 + 32 + k];
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sum += vb[k];
+  }
+  if (r0 < N) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) vb[k] = col[r0 + 16 + k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (r0 + k < N) sum += va[k];
 #pragma unroll
     for (int k = 0; k < 16; ++k) if (r0 + 16 + k < N) sum += vb[k];
   }
@@ -760,19 +798,31 @@ __device__ __forceinline__ void column_moments_contig(const double* col, int N, 
   double sq = 0.0;
 #pragma unroll
   for (int k = 0; k < 16; ++k) va[k] = col[k];
-  for (int r0 = 0; r0 < N; r0 += 32) {
+  for (r0 = 0; r0 < NF; r0 += 32) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) vb[k] = col[r0 + 16 + k];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const double d = va[k] - bm; va[k] = d * d; }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) if (r0 + k < N) sq += va[k];
+    for (int k = 0; k < 16; ++k) sq += va[k];
 #pragma unroll
     for (int k = 0; k < 16; ++k) va[k] = col[r0 + 32 + k];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const double d = vb[k] - bm; vb[k] = d * d; }
     __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sq += vb[k];
+  }
+  if (r0 < N) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) vb[k] = col[r0 + 16 + k];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const double d = va[k] - bm; va[k] = d * d; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const double d = vb[k] - bm; vb[k] = d * d; }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) if (r0 + k < N) sq += va[k];
 #pragma unroll
     for (int k = 0; k < 16; ++k) if (r0 + 16 + k < N) sq += vb[k];
   }
@@ -1376,11 +1426,11 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
       if (own_col >= 0) {
         column_moments_contig(colbuf, N, bm, bv);                   // every lane computes the same chain (numpy's axis-0 order)
       } else {
-        bm = np_pairwise_sum(colbuf, N) / (double)N;                // numpy's 1-D pairwise order
+        bm = np_pairwise_sum_wave(colbuf, N) / (double)N;           // numpy's 1-D pairwise order
         for (int i = lane; i < N; i += WAVE) { const double d = colbuf[i] - bm; dev2buf[i] = d * d; }
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);
-        bv = np_pairwise_sum(dev2buf, N) / (double)N;
+        bv = np_pairwise_sum_wave(dev2buf, N) / (double)N;
       }
       chan_merge(o_mean, o_var, o_cnt, bm, bv, (double)N);
       o_cnt = (double)N + o_cnt;
