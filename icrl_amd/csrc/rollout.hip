@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
   if (w == 2) { st_m = nm.cost_stats[0]; st_v = nm.cost_stats[1]; st_c = nm.cost_stats[2]; }
   float noise_reg = (tid < NA) ? a.noise[(size_t)n * NA + tid] : 0.f;
   double fin_rew = 0.0; float fin_cost = 0.f; int fin_done = 0;
-  unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, tl = p.prof ? prof_now() : 0ull;
+  unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, pc_rounds = 0, tl = p.prof ? prof_now() : 0ull;
   int spin_limit = 1 << 22;
   for (int t = 0; t < T; ++t) {
     const int par = t & 1;
@@ -1102,6 +1102,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
       }
     }
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }
+    if (p.prof && t == T / 2 && lane == 0) g_wide_trace[4 * n + w] = __builtin_amdgcn_s_memrealtime();   // per wave: end of its phase-A part
     if (GRAN) {
       // poll this thread's granules of ALL envs until every one carries this step's tag, then scatter the payload words
       const unsigned long long* xg = p.xg + (size_t)par * N * G;
@@ -1110,12 +1111,15 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
 #pragma unroll
       for (int k = 0; k < GRAN_MAX; ++k) g[k] = (k * 256 + tid < total) ? gload(xg + k * 256 + tid) : ((unsigned long long)gtag << 32);
       bool ok = false;
+      int rounds = 0;
       for (int spins = 0; spins < spin_limit && !ok; ++spins) {
         ok = true;
 #pragma unroll
         for (int k = 0; k < GRAN_MAX; ++k)
           if ((unsigned)(g[k] >> 32) != gtag) { g[k] = gload(xg + k * 256 + tid); ok = false; }
+        ++rounds;
       }
+      if (p.prof && tid == 0) { pc_rounds += (unsigned long long)rounds; }
       if (!ok) spin_limit = 1;      // a peer never showed up (a workgroup was not resident): stop waiting ~2 s per step; reported below
       unsigned* cw = reinterpret_cast<unsigned*>(chunk);
 #pragma unroll
@@ -1210,7 +1214,7 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
     }
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc2 += tn_ - tl; tl = tn_; }
   }
-  if (p.prof && n == 0 && tid == 0) { g_rollout_prof[0] = pc0; g_rollout_prof[1] = pc1; g_rollout_prof[2] = pc2; g_rollout_prof[3] = (unsigned long long)T; g_rollout_prof[4] = pc3; g_rollout_prof[5] = pc4; g_rollout_prof[6] = pc5; }
+  if (p.prof && n == 0 && tid == 0) { g_rollout_prof[0] = pc0; g_rollout_prof[1] = pc1; g_rollout_prof[2] = pc2; g_rollout_prof[3] = (unsigned long long)T; g_rollout_prof[4] = pc3; g_rollout_prof[5] = pc4; g_rollout_prof[6] = pc5; g_rollout_prof[7] = pc_rounds; }
   // a timed-out exchange means stale granules went into the statistics and the buffer: tell the host (it raises)
   if (spin_limit == 1 && a.ag.status != nullptr && (tid & 63) == 0) atomicOr(a.ag.status, 1);
   // ---- leave the agent / wrapper state exactly where the per-step path leaves it

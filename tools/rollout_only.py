@@ -21,6 +21,23 @@ def run(kind, N, T, broken=False):
         torch.cuda.synchronize(); dt = time.time() - t0
         agent.check_rollout_status()
         print(f"{kind}{'-broken' if broken else ''} N={N} T={T} {mode:5s}: {1e3 * dt:8.2f} ms = {1e6 * dt / T:7.2f} us/step = {N * T / dt / 1e6:6.2f} M env-steps/s")
+    if N <= 128 and os.environ.get("PHASES"):         # phase timers of the one-workgroup-per-env persistent kernel (workgroup 0, thread 0)
+        import ctypes
+        from icrl_amd import _lib
+        agent.rollout_kernel = "auto"; agent.profile_phases = 1
+        agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost")
+        torch.cuda.synchronize()
+        out = (ctypes.c_ulonglong * 8)()
+        _lib.lib().icrl_debug_rollout_profile(out)
+        Tn = max(1, out[3])
+        names = {0: "policy+env+publish", 1: "granule wait", 4: "statistics A", 5: "statistics B", 6: "normalise", 2: "rest"}
+        print("   cycles/step: " + ", ".join(f"{v} {out[k] / Tn:.0f}" for k, v in names.items()) + f"  (sum {sum(out[k] for k in names) / Tn:.0f}); poll rounds of thread 0 per step {out[7] / Tn:.1f}")
+        tr = (ctypes.c_ulonglong * (4 * N))()
+        _lib.lib().icrl_debug_rollout_trace_wide(tr, N)
+        tr = (np.array(list(tr), dtype=np.float64).reshape(N, 4) - min(tr)) / 100.0
+        print("   one step, end of each wave's env-phase part, us after the first (min / median / max over workgroups): " +
+              ", ".join(f"wave {k}: {tr[:, k].min():.2f} / {np.median(tr[:, k]):.2f} / {tr[:, k].max():.2f}" for k in range(4)))
+        agent.profile_phases = 0
     if N > 128 and os.environ.get("PHASES"):          # phase timers of the many-environment persistent kernel (cycles per step)
         import ctypes
         from icrl_amd import _lib
