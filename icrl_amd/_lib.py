@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libicrl_hip.so")
 
 _lib = None
+PPO_SPLIT_BYTES = 2 * 3 * 2 * (4 * 8 + 23 + 5) * 256 * 8      # ICRL_PPO_SPLIT_BYTES
 CU_BUDGET = None      # admission control for persistent launches when several runs share the GPU (seed_batch.py)
 
 c_void_p, c_int, c_double, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_float

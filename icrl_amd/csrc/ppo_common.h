@@ -28,8 +28,9 @@ struct TrainArgs {
   u64* xch;
   unsigned t_magic;   // floor(2^32 / T): fast division of a flat index by T
   const struct PlanStep* plan_steps;     // rows kernel: per optimiser step (+2 zero entries)
-  const struct PlanChunk* plan_chunks;   // rows kernel: per 64-row chunk (+5 zero entries)
+  const struct PlanChunk* plan_chunks;   // rows kernel: per 64-row chunk (+5 zero entries); two entries per step in split mode
   int n_steps;
+  u64* gx;                               // split mode (two workgroups per network): partial-gradient granules, ICRL_PPO_SPLIT_BYTES
 };
 
 // the schedule of a launch, tabulated once by ppo_plan_kernel so that the persistent kernel carries no epoch / minibatch /
@@ -92,7 +93,7 @@ struct Cursor {
 };
 
 // ppo_train_rows.hip: row-owning-wave kernel (nt1 = ceil(obs / 16) <= 8), one wave per SIMD
-int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, hipStream_t s);
+int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hipStream_t s);
 // ppo_train_pairs.hip: wave-pair kernel, two waves per SIMD (nt1 rounded up to an even tile count)
 int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s);
 

@@ -874,7 +874,7 @@ __global__ void ppo_perm_offsets_kernel(const int* __restrict__ perms, long long
 }
 
 __global__ void ppo_plan_kernel(const int* adam_t, int n_steps, int n_mb, int n_total, int B, double lr, double b1, double b2,
-                                PlanStep* steps, PlanChunk* chunks) {
+                                PlanStep* steps, PlanChunk* chunks, int two_per_step) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_steps + 2) return;
   if (i >= n_steps) { steps[i] = PlanStep{0.f, 0.f, 0, 0}; return; }
@@ -887,6 +887,12 @@ __global__ void ppo_plan_kernel(const int* adam_t, int n_steps, int n_mb, int n_
   const double t = (double)(adam_t[0] + i + 1);
   steps[i] = PlanStep{(float)(lr / (1.0 - pow(b1, t))), (float)(1.0 / sqrt(1.0 - pow(b2, t))),
                       nb | ((mb == 0) << 8) | ((mb == n_mb - 1) << 9) | (e << 10), e * n_total + p};
+  if (two_per_step) {      // two workgroups per network: chunk c of step i at 2 i + c, an absent second chunk as 0 rows
+    for (int c = 0; c < 2; ++c) chunks[2 * i + c] = c < nch ? PlanChunk{e * n_total + p + RB * c, nb - RB * c < RB ? nb - RB * c : RB} : PlanChunk{0, 0};
+    if (i == n_steps - 1)
+      for (int c = 0; c < 10; ++c) chunks[2 * n_steps + c] = PlanChunk{0, 0};
+    return;
+  }
   for (int c = 0; c < nch; ++c) chunks[g0 + c] = PlanChunk{e * n_total + p + RB * c, nb - RB * c < RB ? nb - RB * c : RB};
   if (i == n_steps - 1)
     for (int c = 0; c < 5; ++c) chunks[g0 + nch + c] = PlanChunk{0, 0};
@@ -924,7 +930,7 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
   a.params = pol->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.buf = *buf; a.perms = perms; a.nu = nu; a.hp = *hp; a.stats = stats; a.xch = (u64*)sync_ws;
   a.t_magic = buf->T == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned long long)buf->T);
-  a.plan_steps = nullptr; a.plan_chunks = nullptr; a.n_steps = 0;
+  a.plan_steps = nullptr; a.plan_chunks = nullptr; a.n_steps = 0; a.gx = nullptr;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(sync_ws, 0, 512, s);      // granule slots: 2 step parities x (3 roles x 8 waves, padded to 32) x 8 B
   if (e != hipSuccess) return (int)e;
@@ -947,10 +953,20 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
       hipLaunchKernelGGL(ppo_perm_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perms, n, buf->T, buf->N, offs);
       a.perms = offs;
     }
+    // obs <= 64: wave pairs; wider (AntWall 113: dz1^T must share h2^T's LDS, two chunks per minibatch) the row-owning waves,
+    // with TWO workgroups per network when a minibatch has two chunks (each computes one, partial gradients exchanged;
+    // hp._pad & 8 keeps one workgroup per network)
+    const bool rows = (hp->_pad & 4) || nt1 > 4;
+    const bool split = rows && hp->batch_size > RB && !(hp->_pad & 8);
     hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
-                       n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks);
-    // obs <= 64: wave pairs; wider (AntWall 113: dz1^T must share h2^T's LDS, two chunks per minibatch) the row-owning waves
-    if ((hp->_pad & 4) || nt1 > 4) return launch_train_rows(a, nt1, pol->discrete != 0, s);
+                       n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks, (int)split);
+    if (split) {
+      const size_t off = (768 + 32 * (size_t)n_steps + 4 * (size_t)hp->n_epochs * n_total + 255) / 256 * 256;      // behind the permutation offsets
+      a.gx = reinterpret_cast<u64*>((char*)sync_ws + off);
+      e = hipMemsetAsync(a.gx, 0, ICRL_PPO_SPLIT_BYTES, s);
+      if (e != hipSuccess) return (int)e;
+    }
+    if (rows) return launch_train_rows(a, nt1, pol->discrete != 0, split, s);
     return launch_train_pairs(a, nt1, pol->discrete != 0, s);
   }
   if (pol->discrete) {

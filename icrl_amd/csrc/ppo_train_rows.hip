@@ -69,13 +69,19 @@ struct SmemR {  // offsets in floats (multiples of 4)
 // that need pointers: keeps ~30 scalar registers out of the loop-carried state (the SGPR file spills otherwise)
 #define KARGS() ([]() { const TrainArgs* k_ = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(k_)); return k_; }())
 
-template <int NT1, bool DISC>
+// SPLIT: TWO workgroups per network (grid 6).  A minibatch of more than 64 rows is two chunks; workgroup (role, half) runs
+// the forward / backward / weight-gradient GEMMs of chunk `half` only, the two halves then exchange their partial gradients
+// (every gradient register as a {step tag | float} granule, same protocol as the norm exchange) and each forms
+// own + partner — float addition is commutative bit for bit, so both halves hold identical gradients, run the identical norm /
+// Adam arithmetic on identical weights and stay replicas of each other.  One more hop per step for half of the GEMM work.
+template <int NT1, bool DISC, bool SPLIT>
 __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   using S = SmemR<NT1>;
   constexpr int SX = S::SX;
   constexpr int XR = (S::O16 + 3) / 4;  // floats of an X row each of the 4 threads of a row stages
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int role = blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
+  const int role = SPLIT ? (int)blockIdx.x % 3 : (int)blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
+  const int half = SPLIT ? (int)blockIdx.x / 3 : 0;                // SPLIT: which 64-row chunk of every minibatch this workgroup computes
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   };
   auto ld_chunk = [&](int g) -> int2 {
     asm volatile("" : "+v"(g));
-    return *reinterpret_cast<const int2*>(plan_chunks + g);
+    return *reinterpret_cast<const int2*>(plan_chunks + (SPLIT ? 2 * g + half : g));   // SPLIT: the plan holds two entries per step
   };
   auto chunk_idx = [&](const int2& c) -> int { return gb_row < c.y ? perms[c.x + gb_row] : -1; };      // {perm_base, rows}
   auto stat_idx = [&](const int4& p) -> int {       // row stid of that step's minibatch (policy role); p.z = nb_flags, p.w = perm_base
@@ -352,9 +358,10 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     sidx_next = stat_idx(ps_nx2);        // ... and the indices of the one after (step st + 2; its plan entry came a step ago)
     float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f, mb_s4 = 0.f;  // bookkeeping lane: minibatch sums of the loss statistics
 
-    const int n_chunks = (nb + RB - 1) / RB;
+    const int n_chunks = SPLIT ? 1 : (nb + RB - 1) / RB;
     for (int ch = 0; ch < n_chunks; ++ch, ++g_chunk) {
-      const int nrows = (nb - ch * RB) < RB ? (nb - ch * RB) : RB;
+      const int first = SPLIT ? half * RB : ch * RB;        // SPLIT: a half without rows (ragged last minibatch) runs on zero rows
+      const int nrows = nb - first < 0 ? 0 : ((nb - first) < RB ? (nb - first) : RB);
       if (ch > 0) {  // chunk 0 of a step was committed during the previous step's granule wait (or the prologue); the
         // chunk-end barrier below separates this from the previous chunk's readers, and the forward reads only this wave's
         // own rows, which this wave's threads stage
@@ -698,6 +705,99 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       STAMP(3)   // weight gradients
     }  // chunks
 
+    if (SPLIT) {
+      // ---- partial gradients of this half <-> the other half of the same network.  Slot of element k of thread tid:
+      // gx[parity][role][half][k][tid]; KG gradient elements per thread + 5 loss-statistic sums of the book-keeping thread.
+      // Gradient registers are published and summed in place, four at a time (no staging copy: the kernel has no registers to
+      // spare at AntWall widths), the next group's loads in flight while this one is checked.
+      constexpr int KG = 4 * NT1 + 23, NGRP = NT1 + 6;       // groups: W1 tiles, 4 W2 tiles, head, {b1, b2, extra, -}
+      const size_t blk = (size_t)(KG + 5) * TH4;
+      u64* const mine = KARGS()->gx + ((size_t)((step & 1) * 3 + role) * 2 + half) * blk + tid;
+      const u64* const theirs = KARGS()->gx + ((size_t)((step & 1) * 3 + role) * 2 + (1 - half)) * blk + tid;
+      const u64 tg = (u64)step << 32;
+      f32x4 gsc = f32x4{gb1r, gb2r, gex, 0.f};
+      auto grp = [&](int g) -> f32x4& { return g < NT1 ? gW1r[g] : (g < NT1 + 4 ? gW2r[g - NT1] : (g == NT1 + 4 ? gWhr : gsc)); };
+#pragma unroll
+      for (int g = 0; g < NGRP; ++g) {
+        const f32x4 v = grp(g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (4 * g + i < KG)
+            __hip_atomic_store(mine + (size_t)(4 * g + i) * TH4, tg | (u64)__float_as_uint(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (book) {
+        const float ms[5] = {mb_s0, mb_s1, mb_s2, mb_s3, mb_s4};
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+          __hip_atomic_store(mine + (size_t)(KG + k) * TH4, tg | (u64)__float_as_uint(ms[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // Fast pass, straight-line on purpose (any loop or branch between a load and its use makes the compiler wait for ALL
+      // outstanding loads): DEP groups in flight, a group is added where all four of its granules carry this step's tag; the
+      // rest is remembered per lane and fetched by the polling loop below.  (Measured: the exchange is throughput-bound, not
+      // latency-bound — ~14 k granules stored and ~14 k loaded per workgroup and step at about one 8-byte granule per cycle and
+      // CU; waiting before the first pass changes nothing.)
+      bool timed_out = false;
+      constexpr int DEP = 4;
+      u64 ring[DEP][4];
+      unsigned pend = 0;
+      auto issue = [&](u64 (&b)[4], int g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          b[i] = (4 * g + i < KG) ? __hip_atomic_load(theirs + (size_t)(4 * g + i) * TH4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tg;
+      };
+      auto arrived = [&](const u64 (&b)[4]) -> bool {
+        return (unsigned)(b[0] >> 32) == step && (unsigned)(b[1] >> 32) == step && (unsigned)(b[2] >> 32) == step && (unsigned)(b[3] >> 32) == step;
+      };
+#pragma unroll
+      for (int g = 0; g < DEP; ++g) issue(ring[g], g);
+#pragma unroll
+      for (int g = 0; g < NGRP; ++g) {
+        u64 (&c)[4] = ring[g % DEP];
+        const bool ok = arrived(c);
+        f32x4& v = grp(g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ok ? v[i] + __uint_as_float((unsigned)c[i]) : v[i];   // own + partner (commutative: both halves agree)
+        pend |= ok ? 0u : (1u << g);
+        if (g + DEP < NGRP) issue(c, g + DEP);
+      }
+      if (__any(pend != 0u)) {
+#pragma unroll
+        for (int g = 0; g < NGRP; ++g) {
+          if (!__any((pend >> g) & 1u)) continue;
+          const bool mine_pending = (pend >> g) & 1u;
+          u64 c[4] = {0, 0, 0, 0};
+          bool ok = !mine_pending;
+          for (int spins = 0; spins < (1 << 22) && !timed_out; ++spins) {
+            if (!ok) { issue(c, g); ok = arrived(c); }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (spins + 1 == (1 << 22)) timed_out = true;
+          }
+          if (mine_pending && ok) {
+            f32x4& v = grp(g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] += __uint_as_float((unsigned)c[i]);
+          }
+        }
+      }
+      gb1r = gsc[0]; gb2r = gsc[1]; gex = gsc[2];
+      if (book) {
+        float ms[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+          u64 v = 0;
+          for (int spins = 0; spins < (1 << 22) && !timed_out; ++spins) {
+            v = __hip_atomic_load(theirs + (size_t)(KG + k) * TH4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == step) break;
+            if (spins + 1 == (1 << 22)) timed_out = true;
+          }
+          ms[k] = __uint_as_float((unsigned)v);
+        }
+        mb_s0 += ms[0]; mb_s1 += ms[1]; mb_s2 += ms[2]; mb_s3 += ms[3]; mb_s4 += ms[4];
+      }
+      if (timed_out) sm[S::MISC + 13] = 1.f;       // reported through the status word like a timed-out norm exchange
+    }
+
     // entropy term of the Gaussian policy loss: d(ent_coef * -mean(H)) / d log_std = -ent_coef
     if (!DISC && role == 0 && w == 1 && r < A) gex += -ent_coef;
 
@@ -733,7 +833,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
         }
       }
       const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
-      __hip_atomic_store(a.xch + (step & 1) * 16 + role * 4 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
+      __hip_atomic_store(a.xch + half * 32 + (step & 1) * 16 + role * 4 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
       if (book) {
         ++steps_done;
@@ -764,7 +864,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       u64 v = 0;
       int spins = 0;
       bool ok = false;
-      const u64* const slot = a.xch + (step & 1) * 16 + tid;
+      const u64* const slot = a.xch + half * 32 + (step & 1) * 16 + tid;     // (the three networks of the same half)
       while (spins < (1 << 24)) {
         v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; break; }
@@ -836,8 +936,8 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
 
   __syncthreads();
   // ---- write back weights, moments, statistics.  The pointers / offsets are re-read from the kernel-argument segment here
-  // instead of being kept in scalar registers across the whole optimisation loop.
-  {
+  // instead of being kept in scalar registers across the whole optimisation loop.  SPLIT: the two halves are replicas; half 0 writes.
+  if (!SPLIT || half == 0) {
   const TrainArgs* ka = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(ka));
   const TrainArgs& a = *ka;
@@ -902,20 +1002,25 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   }
 }
 
-template <int NT1, bool DISC>
+template <int NT1, bool DISC, bool SPLIT>
 static int launch_rows(const TrainArgs& a, hipStream_t s) {
   static_assert(SmemR<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
   const size_t bytes = (size_t)SmemR<NT1>::TOTAL * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_kernel<NT1, DISC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_kernel<NT1, DISC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((ppo_train_rows_kernel<NT1, DISC>), dim3(3), dim3(TH4), bytes, s, a);
+  hipLaunchKernelGGL((ppo_train_rows_kernel<NT1, DISC, SPLIT>), dim3(SPLIT ? 6 : 3), dim3(TH4), bytes, s, a);
   return (int)hipGetLastError();
 }
 
-int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, hipStream_t s) {
-  if (nt1 <= 2) return discrete ? launch_rows<2, true>(a, s) : launch_rows<2, false>(a, s);
-  if (nt1 <= 4) return discrete ? launch_rows<4, true>(a, s) : launch_rows<4, false>(a, s);
-  if (nt1 <= 8) return discrete ? launch_rows<8, true>(a, s) : launch_rows<8, false>(a, s);
+int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hipStream_t s) {
+  if (split) {       // two workgroups per network (a.gx set, the chunk plan holds two entries per step)
+    if (nt1 <= 4) return discrete ? launch_rows<4, true, true>(a, s) : launch_rows<4, false, true>(a, s);
+    if (nt1 <= 8) return discrete ? launch_rows<8, true, true>(a, s) : launch_rows<8, false, true>(a, s);
+    return fail("update (row-owning waves): obs_dim tiles %d > 8", nt1);
+  }
+  if (nt1 <= 2) return discrete ? launch_rows<2, true, false>(a, s) : launch_rows<2, false, false>(a, s);
+  if (nt1 <= 4) return discrete ? launch_rows<4, true, false>(a, s) : launch_rows<4, false, false>(a, s);
+  if (nt1 <= 8) return discrete ? launch_rows<8, true, false>(a, s) : launch_rows<8, false, false>(a, s);
   return fail("update (row-owning waves): obs_dim tiles %d > 8", nt1);
 }
 

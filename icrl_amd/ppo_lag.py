@@ -392,11 +392,11 @@ class PPOLagrangian:
         current_penalty = float(self.dual.nu().item())
         if not hasattr(self, "_train_ws"):
             self._train_ws = dict(nu=torch.zeros(1, device=dev), stats=torch.zeros(32 + self.n_epochs, device=dev),
-                                  sync=torch.zeros(96 + 4 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2, dtype=torch.int64, device=dev), t=torch.zeros(1, dtype=torch.int32, device=dev))
+                                  sync=torch.zeros(96 + 4 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2 + 32 + _lib.PPO_SPLIT_BYTES // 8, dtype=torch.int64, device=dev), t=torch.zeros(1, dtype=torch.int32, device=dev))
         ws = self._train_ws
         ws["nu"].fill_(current_penalty)
         ws["t"].fill_(pol.adam_step)
-        hp = PpoHyperT(int(self.batch_size), int(self.n_epochs), int(self.target_kl is not None), int(getattr(self, "profile_phases", 0)) | {"tiles": 2, "rows": 4}.get(getattr(self, "train_kernel", "auto"), 0), clip_range, float(self.ent_coef),
+        hp = PpoHyperT(int(self.batch_size), int(self.n_epochs), int(self.target_kl is not None), int(getattr(self, "profile_phases", 0)) | {"tiles": 2, "rows": 4, "rows1": 12}.get(getattr(self, "train_kernel", "auto"), 0), clip_range, float(self.ent_coef),
                        float(self.reward_vf_coef), float(self.cost_vf_coef), float(self.max_grad_norm),
                        float(self.target_kl or 0.0), crv, ccv, lr, 0.9, 0.999, float(pol.optimizer_kwargs.get("eps", 1e-8)))
         ps, bs = pol.struct(), rb.struct()
@@ -406,7 +406,7 @@ class PPOLagrangian:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
         from .seed_batch import budgeted
-        with budgeted(3):                                    # three persistent workgroups, a CU each
+        with budgeted(6 if int(self.batch_size) > 64 else 3):   # persistent workgroups, a CU each (two per network when a minibatch is two chunks)
             _lib.check(_lib.lib().icrl_ppo_lag_train(b(ps), p(pol.exp_avg), p(pol.exp_avg_sq), p(ws["t"]), b(bs), p(perms), p(ws["nu"]),
                                                      b(hp), p(ws["stats"]), p(ws["sync"]), _lib.current_stream()), "icrl_ppo_lag_train")
         if ev is not None:

@@ -138,8 +138,9 @@ typedef struct {
   float lr, adam_beta1, adam_beta2, adam_eps;
 } icrl_cn_hyper_t;
 
+#define ICRL_PPO_SPLIT_BYTES (2 * 3 * 2 * (4 * 8 + 23 + 5) * 256 * 8) /* partial-gradient granules: 2 step parities x 3 networks x 2 halves */
 #define ICRL_PPO_SYNC_BYTES(n_epochs, n_minibatches, n_rows) \
-  (768 + 32 * (size_t)(n_epochs) * (size_t)(n_minibatches) + 4 * (size_t)(n_epochs) * (size_t)(n_rows))
+  (768 + 32 * (size_t)(n_epochs) * (size_t)(n_minibatches) + 4 * (size_t)(n_epochs) * (size_t)(n_rows) + 256 + ICRL_PPO_SPLIT_BYTES)
 #define ICRL_CN_METRICS 24 /* floats per iteration in the metrics array of icrl_cn_train */
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -284,7 +285,9 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
  *            (zeroed by the call) + the schedule tables the call fills (per optimiser step: minibatch rows, Adam bias
  *            corrections; per 64-row chunk: permutation offset; the permutations mapped to storage offsets).
  *   hp->_pad: bit 0 = write per-phase cycle counts to stats[12..31] (diagnostic); kernel selection (default: wave pairs, two
- *            waves per SIMD): bit 2 = row-owning waves (one wave per SIMD), bit 1 = the column-split tiles kernel. */
+ *            waves per SIMD; obs > 64: row-owning waves): bit 2 = row-owning waves (one wave per SIMD), bit 1 = the column-split
+ *            tiles kernel; the row-owning kernel runs TWO workgroups per network when batch_size > 64 (each computes one 64-row
+ *            chunk of a minibatch, partial gradients exchanged as granules) unless bit 3 is set. */
 int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                        const icrl_buffer_t* buf, const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp,
                        float* stats, void* sync_ws, void* stream);

@@ -98,11 +98,13 @@ def _oracle_train(agent_sd, buf, perms, kind, nu, **h):
                                              ("hc", 16, 32, 64, 6, 0.002), ("hc", 4, 8, 16, 2, None),
                                              ("hc", 5, 40, 128, 2, None),      # 200 rows: minibatches of 128 and 72 = chunks 64 + 64, 64 + 8
                                              ("ant", 3, 50, 100, 2, None)])    # 150 rows: minibatches of 100 and 50 = chunks 64 + 36, 50
-def test_train_vs_oracle(kind, N, T, B, E, tk):
+def test_train_vs_oracle(kind, N, T, B, E, tk, one_workgroup_per_network=False):
     rng = np.random.RandomState(N * T)
     od, ad = (18, 6) if kind == "hc" else (113, 8)
     lr = 3e-4 if kind == "hc" else 3e-5
     agent = _agent(kind, N, T, batch_size=B, n_epochs=E, target_kl=tk, learning_rate=lr, clip_range=0.2)
+    if one_workgroup_per_network:
+        agent.train_kernel = "rows1"
     sd0 = agent.policy.state_dict()
     obs = rng.randn(T, N, od).astype(np.float32)
     # old log-probs from the current policy on sampled actions so that ratios start near 1 (as in a real rollout)
@@ -167,3 +169,11 @@ def test_numpy_stream_position_after_train(tk):
     for _ in range(executed):
         np.random.permutation(N * T)
     assert after == np.random.randint(1 << 30)
+
+
+@pytest.mark.parametrize("N,T,B", [(24, 16, 128), (3, 50, 100)])
+def test_two_chunk_minibatches_on_one_workgroup_per_network(N, T, B):
+    """AntWall shapes with batch_size > 64: by default two workgroups per network each compute one 64-row chunk and exchange
+    partial gradients (covered by test_train_vs_oracle above); hp._pad bit 3 keeps the sequential two-chunk loop of a single
+    workgroup — same tolerances against the oracle."""
+    test_train_vs_oracle("ant", N, T, B, 2, None, one_workgroup_per_network=True)

@@ -29,7 +29,7 @@ for variant in variants:
     torch.cuda.synchronize()
     e0, e1, n = agent.train_events[-1]
     print(kind, variant, "us/step", round(1e3 * e0.elapsed_time(e1) / n, 3), "steps", n)
-for variant in sorted(set(variants)):
+for variant in sorted(set(v for v in variants if v != "rows1")):
     agent.train_kernel = variant
     agent.profile_phases = 1
     agent.train()
