@@ -331,6 +331,7 @@ __device__ __forceinline__ void run_batch4(const GaeArgs& a, unsigned n, int t_t
 
 template <int U, int G>
 __global__ void __launch_bounds__(64 * G) gae_dual_x4_kernel(GaeArgs a) {
+  // (an XCD-aware blockIdx -> column-range mapping was measured: no difference, every byte is touched once)
   const unsigned n = 4u * (blockIdx.x * 64 * G + threadIdx.x);
   if (n >= (unsigned)a.N) return;                      // N % 4 == 0: a lane's four columns are all inside or all outside
   Carry4 s;
@@ -413,9 +414,10 @@ extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const 
   // one wave per 64-env tile streams T rows; with >= 1024 tiles, 4 neighbouring tiles share a workgroup (1 KB contiguous per
   // row and array, the 4 waves start together) and 16 rows x 5 arrays are in flight per wave: +5..8 % of HBM rate measured.
   // waves_per_tile codes 101 / 105 / 106 force those shapes for tools/gae_variants.py.
-  // >= 1024 tiles and N % 4 == 0: four columns per lane (dwordx4), one wave per workgroup, 4 rows x 5 arrays x 1 KB in flight twice:
-  // 6.3 TB/s at 131 072 envs against 5.9 for shape 106 (tools/gae_variants.py); below 1024 tiles there are too few such waves.
-  int shape = waves_per_tile >= 100 ? waves_per_tile : (W == 1 ? (tiles >= 1024 ? (N % 4 == 0 ? 111 : 106) : 101) : W);
+  // >= 2048 tiles and N % 4 == 0: four columns per lane (dwordx4), one wave per workgroup, 4 rows x 5 arrays x 1 KB in flight twice:
+  // 6.25-6.3 TB/s at 131 072 envs against 5.9-6.0 for shape 106 (tools/gae_variants.py); at 65 536 envs there is only one such
+  // wave per CU and shape 106 is faster (6.0-6.1 against 5.4-5.7).
+  int shape = waves_per_tile >= 100 ? waves_per_tile : (W == 1 ? (tiles >= 1024 ? (tiles >= 2048 && N % 4 == 0 ? 111 : 106) : 101) : W);
   if (shape == 101) hipLaunchKernelGGL((gae_dual_kernel<1, 8, true>), dim3(tiles), dim3(64), 0, s, a);
   else if (shape == 105) hipLaunchKernelGGL((gae_dual_kernel<1, 8, true, 4>), dim3((tiles + 3) / 4), dim3(256), 0, s, a);
   else if (shape == 106) hipLaunchKernelGGL((gae_dual_kernel<1, 16, true, 4>), dim3((tiles + 3) / 4), dim3(256), 0, s, a);
@@ -428,6 +430,7 @@ extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const 
     else if (shape == 111) hipLaunchKernelGGL((gae_dual_x4_kernel<4, 1>), dim3(lanes), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((gae_dual_x4_kernel<8, 1>), dim3(lanes), dim3(64), 0, s, a);
   }
+
   else if (shape == 4) hipLaunchKernelGGL((gae_dual_kernel<4, 8, false>), dim3(tiles), dim3(256), 0, s, a);
   else if (shape == 16) hipLaunchKernelGGL((gae_dual_kernel<16, 8, false>), dim3(tiles), dim3(1024), 0, s, a);
   else return fail("icrl_gae_dual_ex: waves_per_tile = %d (0 = automatic, 1, 4, 16 or a shape code 101 / 105 / 106, 107..112 with N %% 4 == 0)", waves_per_tile);
