@@ -366,7 +366,10 @@ class PPOLagrangian:
         drawing once an epoch early-stops), see train()."""
         if self.streams is not None or callable(self.permutation):
             draw = self.streams.permutation if self.streams is not None else self.permutation
-            perms = np.stack([np.asarray(draw(e, n)) for e in range(self.n_epochs)])
+            perms = [draw(e, n) for e in range(self.n_epochs)]
+            if torch.is_tensor(perms[0]):             # device-side streams (icrl_amd/streams.py): no host work, no upload
+                return torch.stack(perms).to(device=self.device, dtype=torch.int32).contiguous(), None
+            perms = np.stack([np.asarray(q) for q in perms])
             return torch.as_tensor(perms.astype(np.int32), device=self.device).contiguous(), None
         if self.permutation == "device":
             return torch.stack([torch.randperm(n, device=self.device) for _ in range(self.n_epochs)]).to(torch.int32).contiguous(), None

@@ -4,8 +4,12 @@ By default a run draws from the process-wide generators exactly like the referen
 minibatch permutations, common/utils.py:23-39).  When several independent runs share one process (icrl_amd/seed_batch.py)
 each needs generators of its own, otherwise the runs' draws interleave and no run is reproducible: PrivateStreams answers the
 `streams` protocol of PPOLagrangian / icrl.outer_iteration (rollout_noise, permutation, consumed, sample_noise, eval_noise —
-the protocol the parity tests use for teacher forcing, oracle/streams.py) from a private device generator and a private numpy
-RandomState seeded with the run's seed.
+the protocol the parity tests use for teacher forcing, oracle/streams.py) from a private device generator seeded with the run's seed.
+
+Minibatch permutations are drawn ON THE DEVICE here (torch.randperm with the private generator) instead of with
+np.random.permutation: 20 permutations of 131 072 entries per outer iteration cost ~20 ms of host time each way, and with dozens
+of runs in one process the host threads serialise on them (measured: 32 runs spent 1.3 of 1.46 s per iteration there).  Any
+uniformly random permutation is a valid minibatch order (ref: buffers.py:596); parity tests force the order anyway.
 """
 import numpy as np
 import torch
@@ -16,7 +20,8 @@ class PrivateStreams:
         self.device, self.discrete = torch.device(device), discrete
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(int(seed))
-        self.np = np.random.RandomState(int(seed))
+        self.perm_gen = torch.Generator(device=self.device)      # its own generator: the number of executed epochs (early stop)
+        self.perm_gen.manual_seed(int(seed) + 0x5eed)            # must not shift the action-noise stream
 
     def _draw(self, *shape):
         if self.discrete:
@@ -27,7 +32,7 @@ class PrivateStreams:
         return self._draw(T, N, A)
 
     def permutation(self, epoch, n):
-        return self.np.permutation(n)
+        return torch.randperm(n, device=self.device, generator=self.perm_gen)
 
     def consumed(self, executed_epochs):
         pass
