@@ -275,6 +275,71 @@ __global__ void k_pingpong(unsigned long long* flag, unsigned long long* cyc, in
   cyc[me] = t1 - t0;
 }
 
+
+// bulk exchange between two workgroups (256 threads each): every thread publishes K values and reads the partner's K.
+// MODE 0: 8-byte granules {step tag | float}, one agent-scope relaxed atomic store / load per value.
+// MODE 1: 16-byte self-validating records {tag, a, b, tag}: two values per store / load (sc0 sc1 dwordx4), both tags checked.
+template <int MODE, int K>
+__global__ void k_bulk(unsigned long long* buf, unsigned long long* cyc, int iters, float* sink) {
+  const int tid = threadIdx.x, wg = blockIdx.x;
+  typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+  float acc = 0.f;
+  unsigned long long t0 = 0;
+  for (int it = 1; it <= iters; ++it) {
+    if (it == 2) t0 = __builtin_amdgcn_s_memtime();
+    const unsigned tag = (unsigned)it;
+    const size_t par = (size_t)(it & 1) * 2;
+    if (MODE == 0) {
+      unsigned long long* mine = buf + (par + wg) * (size_t)(K * 256) + tid;
+      const unsigned long long* theirs = buf + (par + (1 - wg)) * (size_t)(K * 256) + tid;
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        __hip_atomic_store(mine + (size_t)k * 256, ((unsigned long long)tag << 32) | (unsigned)__float_as_uint((float)(k + it)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // all K loads in flight together, one wait, then the tags; repeated until every granule carries this exchange's tag
+      unsigned long long v[K];
+      bool ok = false;
+      for (int rounds = 0; rounds < (1 << 20) && !ok; ++rounds) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) v[k] = __hip_atomic_load(theirs + (size_t)k * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < K; ++k) ok = ok && (unsigned)(v[k] >> 32) == tag;
+        ok = __all(ok);
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) acc += __uint_as_float((unsigned)v[k]);
+    } else {
+      u4* mine = reinterpret_cast<u4*>(buf) + (par + wg) * (size_t)(K / 2 * 256) + tid;
+      const u4* theirs = reinterpret_cast<const u4*>(buf) + (par + (1 - wg)) * (size_t)(K / 2 * 256) + tid;
+#pragma unroll
+      for (int k = 0; k < K / 2; ++k) {
+        u4 v = {tag, __float_as_uint((float)(2 * k + it)), __float_as_uint((float)(2 * k + 1 + it)), tag};
+        u4* p = mine + (size_t)k * 256;
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" :: "v"(p), "v"(v) : "memory");
+      }
+      u4 v[K / 2];
+      bool ok = false;
+      for (int rounds = 0; rounds < (1 << 20) && !ok; ++rounds) {
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) {
+          const u4* p = theirs + (size_t)k * 256;
+          asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v[k]) : "v"(p) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < K / 2; ++k) { asm volatile("" : "+v"(v[k])); ok = ok && v[k][0] == tag && v[k][3] == tag; }
+        ok = __all(ok);
+      }
+#pragma unroll
+      for (int k = 0; k < K / 2; ++k) acc += __uint_as_float(v[k][1]) + __uint_as_float(v[k][2]);
+    }
+    __syncthreads();
+  }
+  if (tid == 0 && wg == 0) cyc[0] = __builtin_amdgcn_s_memtime() - t0;
+  if (acc == 12345.f) sink[0] = acc;
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main() {
   float* out; unsigned long long* cyc; unsigned long long* flag;
@@ -319,6 +384,23 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0); hipLaunchKernelGGL(k_mfma<4>, dim3(1), dim3(64), 0, 0, out, cyc, 20000); hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h.data(), cyc, 64, hipMemcpyDeviceToHost);
+  {
+    unsigned long long* bulk;
+    CK(hipMalloc(&bulk, 4 * 32 * 256 * 8 * 2));
+    const int bi = 2000;
+    auto run = [&](auto kern, const char* name, int K) {
+      hipMemset(bulk, 0, 4 * 32 * 256 * 8 * 2);
+      hipLaunchKernelGGL(kern, dim3(2), dim3(256), 0, 0, bulk, cyc, bi, out);
+      hipDeviceSynchronize(); hipMemcpy(h.data(), cyc, 64, hipMemcpyDeviceToHost);
+      printf("%-60s %8.1f cycles per exchange (%d values per thread each way)\n", name, (double)h[0] / (bi - 1), K);
+    };
+    run(k_bulk<0, 8>, "bulk exchange, 8-byte granules, 8 per thread", 8);
+    run(k_bulk<0, 16>, "bulk exchange, 8-byte granules, 16 per thread", 16);
+    run(k_bulk<0, 32>, "bulk exchange, 8-byte granules, 32 per thread", 32);
+    run(k_bulk<1, 8>, "bulk exchange, 16-byte records (2 values), 8 per thread", 8);
+    run(k_bulk<1, 16>, "bulk exchange, 16-byte records (2 values), 16 per thread", 16);
+    run(k_bulk<1, 32>, "bulk exchange, 16-byte records (2 values), 32 per thread", 32);
+  }
   printf("s_memtime ticks per us: %.1f  (ticks %llu over %.3f ms)\n", (double)h[0] / (ms * 1e3), h[0], ms);
   return 0;
 }
