@@ -452,34 +452,38 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
         issue_rows(idx_now);
       }
       FSTAMP(1)   // row prefetch issue
-      pair_signal(); pair_wait();    // (P1) the pair's columns of h1^T are complete
+      pair_signal();                 // (P1) this wave's columns of h1^T are complete
       FSTAMP(2)   // S1
       {
+        // the own half of K (h1c, registers) needs nobody: its MFMAs run before the wait for the partner's half
+        f32x4 z[2], awp[2][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * fh + tt;
+          // (operand tiles addressed, never indexed, by the runtime half fh: a runtime-indexed register array goes to scratch)
+          const float* pa = sm + S::W2 + (16 * t + r) * SH + 4 * q;
+          f32x4 awo[2];
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj) { awo[jj] = lds128(pa + 32 * fh + 16 * jj); awp[tt][jj] = lds128(pa + 32 * (1 - fh) + 16 * jj); }
+          z[tt] = lds128(sm + S::B2 + 16 * t + 4 * q);
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[tt] = MFMA_F32(awo[jj][e], h1c[jj][e], z[tt]);
+        }
+        pair_wait();                 // the partner's columns of h1^T are complete
         float hpart[2][4];                  // the partner's half of h1 as B operand: features 16 js + 4 q + e, js = 2 (1 - fh) + jj
         const float* ph1 = sm + S::H1T + (4 * q) * ST + b + 32 * (1 - fh) * ST;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
           for (int e = 0; e < 4; ++e) hpart[jj][e] = ph1[(16 * jj + e) * ST];
-        f32x4 z[2];
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const int t = 2 * fh + tt;
-          // (operand tiles addressed, never indexed, by the runtime half fh: a runtime-indexed register array goes to scratch)
-          const float* pa = sm + S::W2 + (16 * t + r) * SH + 4 * q;
-          f32x4 awo[2], awp[2];
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj) { awo[jj] = lds128(pa + 32 * fh + 16 * jj); awp[jj] = lds128(pa + 32 * (1 - fh) + 16 * jj); }
-          z[tt] = lds128(sm + S::B2 + 16 * t + 4 * q);
-#pragma unroll
-          for (int jj = 0; jj < 2; ++jj)      // own half of K first (registers), then the partner's
-#pragma unroll
-            for (int e = 0; e < 4; ++e) z[tt] = MFMA_F32(awo[jj][e], h1c[jj][e], z[tt]);
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) z[tt] = MFMA_F32(awp[jj][e], hpart[jj][e], z[tt]);
-        }
+            for (int e = 0; e < 4; ++e) z[tt] = MFMA_F32(awp[tt][jj][e], hpart[jj][e], z[tt]);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -628,9 +632,36 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
         }
       }
       FSTAMP(7)   // dH2
-      pair_signal(); pair_wait();  // (P4) the pair's columns of dz2^T complete
+      pair_signal();               // (P4) this wave's columns of dz2^T complete
       FSTAMP(8)   // S4
-      {  // dH1^T = W2^T . dz2^T: A = W2T[k = 16 t + r][j = 16 js + 4 q + e]; the partner's half of dz2 from the image
+      {  // dH1^T = W2^T . dz2^T: A = W2T[k = 16 t + r][j = 16 js + 4 q + e]; own half of K (dz2c, registers) before the wait for
+         // the partner's half, which comes from the image
+        f32x4 acc[2], awp[2][2];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * fh + tt;
+          f32x4 awo[2];
+          if (S::W2TC) {
+            const float* pa = sm + S::W2T + (16 * t + r) * SH + 4 * q;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) { awo[jj] = lds128(pa + 32 * fh + 16 * jj); awp[tt][jj] = lds128(pa + 32 * (1 - fh) + 16 * jj); }
+          } else {
+            const float* pa = sm + S::W2 + (4 * q) * SH + 16 * t + r;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                awo[jj][e] = pa[(32 * fh + 16 * jj + e) * SH];
+                awp[tt][jj][e] = pa[(32 * (1 - fh) + 16 * jj + e) * SH];
+              }
+          }
+          acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[tt] = MFMA_F32(awo[jj][e], dz2c[jj][e], acc[tt]);
+        }
+        pair_wait();               // the partner's columns of dz2^T complete
         float dp[2][4];
         const float* pz = sm + S::DZ2T + (4 * q) * ST + b + 32 * (1 - fh) * ST;
 #pragma unroll
@@ -639,33 +670,12 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
           for (int e = 0; e < 4; ++e) dp[jj][e] = pz[(16 * jj + e) * ST];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-          const int t = 2 * fh + tt;
-          f32x4 awo[2], awp[2];
-          if (S::W2TC) {
-            const float* pa = sm + S::W2T + (16 * t + r) * SH + 4 * q;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj) { awo[jj] = lds128(pa + 32 * fh + 16 * jj); awp[jj] = lds128(pa + 32 * (1 - fh) + 16 * jj); }
-          } else {
-            const float* pa = sm + S::W2 + (4 * q) * SH + 16 * t + r;
-#pragma unroll
-            for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                awo[jj][e] = pa[(32 * fh + 16 * jj + e) * SH];
-                awp[jj][e] = pa[(32 * (1 - fh) + 16 * jj + e) * SH];
-              }
-          }
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = MFMA_F32(awo[jj][e], dz2c[jj][e], acc);
+            for (int e = 0; e < 4; ++e) acc[tt] = MFMA_F32(awp[tt][jj][e], dp[jj][e], acc[tt]);
 #pragma unroll
-          for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc = MFMA_F32(awp[jj][e], dp[jj][e], acc);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) dz1c[tt][i] = fmaf(-(h1c[tt][i] * h1c[tt][i]), acc[i], acc[i]);
+          for (int i = 0; i < 4; ++i) dz1c[tt][i] = fmaf(-(h1c[tt][i] * h1c[tt][i]), acc[tt][i], acc[tt][i]);
         }
       }
 #pragma unroll
