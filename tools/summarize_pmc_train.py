@@ -16,7 +16,14 @@ QUAD = {"SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "
         "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 waves = {}
-for f in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_train_{tag}_*", "**", "*counter_collection.csv"), recursive=True)):
+# one file per pass directory (pmc_train_<tag>_a / _b): gpurun merges every call's files into gpurun_out/, take the newest of each
+_passes = []
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_train_{tag}_*"))):
+    if os.path.isdir(d):
+        hits = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
+        if hits:
+            _passes.append(hits[-1])
+for f in _passes:
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def find(pattern):
-    hits = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True))
+    # gpurun merges every call's files into gpurun_out/ (file names carry the profiled process id): take the newest
+    hits = sorted(glob.glob(os.path.join(ROOT, "gpurun_out", pattern), recursive=True), key=os.path.getmtime)
     return hits[-1] if hits else None
 
 
