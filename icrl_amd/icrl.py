@@ -164,6 +164,7 @@ def outer_iteration(st, itr):
     if config.save_dir and itr % config.save_every == 0 and rank == 0:
         path = os.path.join(config.save_dir, f"models/icrl_{itr}_itrs")
         os.makedirs(path, exist_ok=True)
+        nominal_agent.save(os.path.join(path, "nominal_agent"))                              # SB3-style archive (ref: icrl.py:259)
         torch.save(nominal_agent.policy.state_dict(), os.path.join(path, "nominal_agent_policy.pth"))
         constraint_net.save(os.path.join(path, "cn.pt"))
         train_env.save(os.path.join(path, f"{itr}_train_env_stats.pkl"))

@@ -311,9 +311,12 @@ class PPOLagrangian:
         None (prediction / evaluate_actions only).  Entries the reference stored as cloud-pickled objects are not un-pickled:
         spaces are rebuilt from their printable fields, the schedules from `learning_rate` / `kwargs` (clip_range defaults to
         0.2 unless passed)."""
-        import io, zipfile
+        import io, os, zipfile
         from .utils import parse_sb3_data
-        with zipfile.ZipFile(str(path)) as z:
+        path = str(path)
+        if not os.path.exists(path) and os.path.exists(path + ".zip"):      # save_util.open_path appends the suffix (save_util.py:215-229)
+            path += ".zip"
+        with zipfile.ZipFile(path) as z:
             data = parse_sb3_data(z.read("data"))
         if "observation_dim" in data and "observation_space" not in data:      # archive written by save() of this build
             o, a = int(data["observation_dim"]), int(data["action_dim"])

@@ -262,3 +262,32 @@ def test_cpg_pid_lagrangian_and_callback_cadence(tmp_path):
     assert hist[0]["nu"] == 1.0 and np.allclose(got, nus, rtol=0, atol=1e-5), (got, nus)
     assert len(set(np.round(nus, 6))) > 1                     # the controller moved the multiplier
 
+
+
+def test_run_policy_entry_point(tmp_path):
+    """ref: icrl/run_policy.py — train a few iterations with --save_dir, then `run_policy -ii` loads best_nominal_model.zip +
+    train_env_stats.pkl from the run directory and writes per-episode rollout files the expert loader reads back."""
+    from icrl_amd import icrl as I, run_policy as RP, utils
+    expert = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden/expert_hc.npz")
+    save_dir = str(tmp_path / "run")
+    I.main(["icrl", "-er", "2", "-ep", expert, "-tk", "0.01", "-cl", "20", "-bi", "2", "-ft", "512", "-ni", "2", "-tei", "HCWithPos-v0",
+            "-eei", "HCWithPosTest-v0", "-clr", "0.05", "-crc", "0.5", "-psis", "-nt", "8", "--n_steps", "64", "-ne", "2", "-s", "0", "-v", "0",
+            "--save_dir", save_dir])
+    assert os.path.exists(os.path.join(save_dir, "best_nominal_model.zip")) and os.path.exists(os.path.join(save_dir, "config.json"))
+    assert os.path.exists(os.path.join(save_dir, "models/icrl_0_itrs/nominal_agent.zip"))
+    paths = RP.main(["run_policy", "-l", save_dir, "-ii", "-nr", "2", "-e", "HCWithPos-v0"])
+    assert [os.path.basename(p) for p in paths] == ["0.pkl", "1.pkl"]
+    import pickle
+    for pth in paths:                      # the reference's per-episode layout (icrl/run_policy.py:84-98)
+        with open(pth, "rb") as fh:
+            d = pickle.load(fh)
+        assert d["save_scheme"] == "not_airl" and d["observations"].dtype == np.float64 and d["actions"].dtype == np.float32
+        assert d["observations"].shape == (1000, 18) and d["actions"].shape == (1000, 6) and int(d["lengths"][0]) == 1000
+    # ... and as expert data of a new run: <dir>/files/EXPERT/rollouts/{i}.pkl is what load_expert_data walks (icrl/icrl.py:25-43)
+    exp_dir = str(tmp_path / "expert")
+    os.makedirs(os.path.join(exp_dir, "files/EXPERT"))
+    os.rename(os.path.join(save_dir, "run_policy", "rollouts"), os.path.join(exp_dir, "files/EXPERT/rollouts"))
+    (obs, acs), mean_reward = utils.load_expert_data(exp_dir, 2)
+    assert obs.shape == (2000, 18) and acs.shape == (2000, 6) and np.isfinite(mean_reward)
+    paths = RP.main(["run_policy", "-l", save_dir, "-ii", "-li", "0", "-nr", "1", "-e", "HCWithPos-v0", "-s", "itr0"])
+    assert len(paths) == 1
