@@ -154,6 +154,8 @@ def main(argv=None):
     config["rank"], config["world_size"] = rank, world
     if config["save_dir"]:
         os.makedirs(config["save_dir"], exist_ok=True)
+        with open(os.path.join(config["save_dir"], "config.json"), "w") as fh:      # what run_policy reads back (W&B keeps it in the reference)
+            json.dump({k: v for k, v in config.items()}, fh, indent=2, default=str)
     cpg(types.SimpleNamespace(**config))
     if rank == 0:
         print("Time taken: %05.2f hours" % ((time.time() - start) / 3600))

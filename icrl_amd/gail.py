@@ -10,6 +10,7 @@ the cost term, so the same update kernel computes it; the idle cost critic recei
 (tests/golden/g12_gail.npz pins this against the reference's own PPO).
 """
 import argparse
+import json
 import os
 import sys
 import time
@@ -140,6 +141,8 @@ def main(argv=None):
     config["rank"], config["world_size"] = rank, world
     if config["save_dir"]:
         os.makedirs(config["save_dir"], exist_ok=True)
+        with open(os.path.join(config["save_dir"], "config.json"), "w") as fh:      # what run_policy reads back (W&B keeps it in the reference)
+            json.dump({k: v for k, v in config.items()}, fh, indent=2, default=str)
     gail(types.SimpleNamespace(**config))
     if rank == 0:
         print("Time taken: %05.2f hours" % ((time.time() - start) / 3600))
