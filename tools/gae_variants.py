@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from icrl_amd import _lib
 L = _lib.lib(); dev = torch.device("cuda:0"); T = 2048
-for N in (65536, 131072):
+for N in tuple(int(x) for x in os.environ.get('NS', '65536,131072').split(',')):
     ins = [torch.randn(T, N, device=dev) for _ in range(4)] + [(torch.rand(T, N, device=dev) < 0.001).float()]
     lv = [torch.randn(N, device=dev) for _ in range(2)]; ld = torch.zeros(N, dtype=torch.uint8, device=dev)
     outs = [torch.empty(T, N, device=dev) for _ in range(4)]
