@@ -127,6 +127,37 @@ def test_icrl_hc_three_iterations_vs_port(golden):
     assert len(set(np.round(nus, 4))) == 3          # the multiplier actually moves between iterations
 
 
+def test_icrl_antwall_two_iterations_vs_port(golden):
+    """BASELINE configs[2] (AntWall ICRL, the reference's README.md:50 flags: constraint net [40, 40], batch 128 = two 64-row
+    chunks -> two workgroups per network in the update kernel, clip_range 0.4, lambdas 0.9, lr 3e-5, nu0 0.1) on N = 8 envs,
+    T = 128: HIP icrl() vs the CPU port over 2 outer iterations with the same noise / permutation streams."""
+    from icrl_amd.icrl import build_parser, setup, outer_iteration
+    expert = os.path.join(HERE, "golden/expert_ant.npz")
+    argv = ["icrl", "-ep", expert, "--expert_agent_path", expert, "-er", "2", "-cl", "40", "40", "-clr", "0.005", "-aclr", "0.9", "-crc", "0.6",
+            "-bi", "5", "-ft", "2000", "-ni", "2", "-tei", "AntWall-v0", "-eei", "AntWallTest-v0", "--batch_size", "128",
+            "--reward_gae_lambda", "0.9", "--cost_gae_lambda", "0.9", "--n_epochs", "4", "--learning_rate", "3e-5", "--clip_range", "0.4",
+            "-piv", "0.1", "-plr", "0.05", "-psis", "-tk", "0.02", "-ctkno", "2.5", "-nt", "8", "--n_steps", "128", "-s", "5", "-v", "0"]
+    cfg = vars(build_parser().parse_args(argv))
+    cfg.update(rank=0, world_size=1, streams=SeededStreams(23))
+    st = setup(types.SimpleNamespace(**cfg))
+    init = dict(policy={k: v.numpy().copy() for k, v in st["agent"].policy.state_dict().items()},
+                cn={k: v.numpy().copy() for k, v in st["constraint_net"].state_dict().items()})
+    ex = golden("expert_ant")
+    port_cfg = {k: cfg[k] for k in o_loop.PORT_DEFAULTS if k in cfg}
+    om, steps, _, objs = o_loop.icrl_port(port_cfg, ex["observations"][:1000], ex["actions"][:1000], _sub(ex, "policy/"),
+                                          streams=SeededStreams(23), init=init)
+    keys = sorted(k for k in om[0] if k not in ("forward/std",))
+    worst = {}
+    for it in range(2):
+        m = outer_iteration(st, it)
+        for k, v in _compare(it, m, om[it], [k for k in keys if k in m], False, 1000).items():
+            worst[k] = max(worst.get(k, 0.0), v)
+        assert abs(m["forward/std"] - om[it]["forward/std"]) < 1e-5
+    assert st["timesteps"] == steps == 2 * 2048
+    print("worst absolute deviation from the CPU port over 2 outer iterations (AntWall):",
+          {k: float(f"{v:.3g}") for k, v in sorted(worst.items()) if v > 0})
+
+
 @pytest.mark.parametrize("env_id,N,T,B,epochs", [("HCWithPos-v0", 256, 16, 64, 2), ("AntWallBroken-v0", 512, 8, 128, 2)])
 def test_learn_at_per_gpu_shard_shapes_vs_port(env_id, N, T, B, epochs):
     """BASELINE configs[3] / configs[4] at the shape ONE GPU sees (2048 / 8 = 256 HC envs; 4096 / 8 = 512 AntWallBroken envs with
