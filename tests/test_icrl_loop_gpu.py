@@ -291,3 +291,24 @@ def test_run_policy_entry_point(tmp_path):
     assert obs.shape == (2000, 18) and acs.shape == (2000, 6) and np.isfinite(mean_reward)
     paths = RP.main(["run_policy", "-l", save_dir, "-ii", "-li", "0", "-nr", "1", "-e", "HCWithPos-v0", "-s", "itr0"])
     assert len(paths) == 1
+
+
+@pytest.mark.parametrize("extra", [["--warmup_timesteps", "256"], ["--reset_policy"], ["--cn_normalize"], ["-nis"],
+                                   ["--train_gail_lambda", "-nis"], ["--cn_batch_size", "64"], ["-dno", "-dnr", "-dnc"],
+                                   ["-pl", "32", "48", "-rvl", "64", "32", "-cvl", "16", "64"]])
+def test_icrl_entry_point_optional_branches(extra):
+    """the optional branches of the outer loop the README configurations do not take (icrl/icrl.py:103-117 warm-up with a null cost,
+    :201-203 policy reset, constraint-net input normalisation, no importance sampling, the binary-classifier loss, minibatched
+    constraint-net updates, no env normalisation, narrower networks): two outer iterations run and log finite metrics."""
+    from icrl_amd import icrl as I
+    expert = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden/expert_hc.npz")
+    argv = ["icrl", "-er", "2", "-ep", expert, "-tk", "0.01", "-cl", "20", "-bi", "3", "-ft", "512", "-ni", "2", "-tei", "HCWithPos-v0",
+            "-eei", "HCWithPosTest-v0", "-clr", "0.05", "-crc", "0.5", "-psis", "-nt", "8", "--n_steps", "64", "-ne", "2", "-s", "0", "-v", "0"] + extra
+    cfg = vars(I.build_parser().parse_args(argv))
+    cfg.update(rank=0, world_size=1)
+    import types
+    metrics, agent, cn, env = I.icrl(types.SimpleNamespace(**cfg), log=None)
+    assert len(metrics) == 2
+    for m in metrics:
+        for k in ("forward/nu", "forward/average_cost", "true/reward", "true/cost", "backward/cn_loss"):
+            assert k in m and np.isfinite(float(m[k])), (extra, k, m.get(k))
