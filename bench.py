@@ -1,6 +1,6 @@
 """bench.py — env-steps/s of the ICRL outer loop (HCWithPos-v0 shapes, synthetic env) on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config {1,3}] [--mode {shards,seeds}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is ONE outer ICRL iteration of BASELINE.json configs[1] (README.md:38 flags of the reference):
@@ -8,6 +8,13 @@ A "step" is ONE outer ICRL iteration of BASELINE.json configs[1] (README.md:38 f
 2048 minibatches of 64), nominal sampling (10 episodes), constraint-net update (10 iterations, 10 000 nominal + 5 000
 expert rows), evaluation (10 episodes on the Test env) and both KL metrics.  Nothing is skipped inside the timed region.
 Weak scaling: every rank owns its own 64 envs; one all-reduce of parameters / moments per outer iteration.
+`value` includes the reference's target-KL early stops (ppo_lag.py:293-297): later outer iterations stop their epoch loops early, so
+env-steps/s moves with the iteration count; `us_per_optimizer_step` (roofline_ppo) is the invariant, `optimizer_steps_per_iteration`
+and `early_stop_fraction` say how much of the 2 x 20 480 steps an iteration executed.
+  --config 3       BASELINE configs[3]'s per-GPU shard instead (HCWithPos, 2048 envs over 8 GPUs = 256 envs per GPU)
+  --mode seeds     north_star's other fan-out: rank r runs an independent ICRL run with seed s + r, NO collective; value = sum over ranks
+With one GPU the line also carries `configs2`: BASELINE configs[2] (AntWall-v0, 256 envs, constraint net [40, 40], batch 128, 20
+epochs; README.md:50 flags) timed the same way — extra, never `value`.
 
 The JSON line also carries
   roofline      the dual-GAE kernel (the kernel BASELINE.json's metric names): algorithmic 36 B/transition / live event timing
@@ -36,15 +43,106 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~
 F32_MFMA_PEAK_TFLOPS = 157.3   # whole chip, 256 CUs
 
 
-def config2(n_iters_total, seed, rank, world):
+def _cfg(argv, rank, world):
     from icrl_amd.icrl import build_parser
-    argv = ["icrl", "-er", "10", "-ep", os.path.join(ROOT, "tests/golden/expert_hc.npz"), "-tk", "0.01", "-cl", "20", "-bi", "10",
-            "-ft", "2e5", "-ni", "30", "-tei", "HCWithPos-v0", "-eei", "HCWithPosTest-v0", "-clr", "0.05", "-aclr", "0.9",
-            "-crc", "0.5", "-psis", "-ctkno", "2.5", "-nt", "64", "-s", str(seed), "-v", "0",
-            "--expert_agent_path", os.path.join(ROOT, "tests/golden/expert_hc.npz")]
     cfg = vars(build_parser().parse_args(argv))
     cfg.update(rank=rank, world_size=world, save_dir=None)
     return types.SimpleNamespace(**cfg)
+
+
+def config2(n_iters_total, seed, rank, world, envs=64):
+    """BASELINE configs[1] (README.md:38 flags of the reference); envs = 256: the per-GPU shard of configs[3]."""
+    ex = os.path.join(ROOT, "tests/golden/expert_hc.npz")
+    return _cfg(["icrl", "-er", "10", "-ep", ex, "-tk", "0.01", "-cl", "20", "-bi", "10",
+                 "-ft", "2e5", "-ni", "30", "-tei", "HCWithPos-v0", "-eei", "HCWithPosTest-v0", "-clr", "0.05", "-aclr", "0.9",
+                 "-crc", "0.5", "-psis", "-ctkno", "2.5", "-nt", str(envs), "-s", str(seed), "-v", "0", "--expert_agent_path", ex], rank, world)
+
+
+def antwall_expert_path():
+    """configs[2] uses 45 expert rollouts of 500 steps (22 500 x 121); the committed fixture holds 5.  Synthetic data of the full
+    shape: the fixture's rollouts repeated 9 times with a deterministic perturbation, written once per process under /tmp."""
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f"icrl_bench_expert_ant_{os.getpid()}.npz")
+    if not os.path.exists(path):
+        d = np.load(os.path.join(ROOT, "tests/golden/expert_ant.npz"))
+        rng = np.random.RandomState(45)
+        obs = np.concatenate([d["observations"] + 0.01 * rng.randn(*d["observations"].shape) for _ in range(9)])
+        acs = np.concatenate([np.clip(d["actions"] + 0.01 * rng.randn(*d["actions"].shape).astype(np.float32), -1, 1) for _ in range(9)])
+        extra = {k: d[k] for k in d.files if k.startswith("policy/")}
+        np.savez(path, observations=obs, actions=acs.astype(np.float32), rewards=np.tile(d["rewards"], 9), lengths=np.tile(d["lengths"], 9), **extra)
+    return path
+
+
+def config_antwall(seed, rank, world, envs=256):
+    """BASELINE configs[2] exactly as README.md:50 gives it: AntWall-v0, 256 envs, n_steps 2048, batch 128, 20 epochs, lr 3e-5,
+    clip 0.4, lambdas 0.9, nu0 0.1, nu-lr 0.05, target_kl 0.02, constraint net [40, 40], 45 expert / nominal rollouts."""
+    ex = antwall_expert_path()
+    return _cfg(["icrl", "-ep", ex, "--expert_agent_path", ex, "-er", "45", "-cl", "40", "40", "-clr", "0.005", "-aclr", "0.9", "-crc", "0.6",
+                 "-bi", "5", "-ft", "2e5", "-ni", "20", "-tei", "AntWall-v0", "-eei", "AntWallTest-v0", "--batch_size", "128",
+                 "--reward_gae_lambda", "0.9", "--cost_gae_lambda", "0.9", "--n_epochs", "20", "--learning_rate", "3e-5", "--clip_range", "0.4",
+                 "-piv", "0.1", "-plr", "0.05", "-psis", "-tk", "0.02", "-ctkno", "2.5", "-nt", str(envs), "-s", str(seed), "-v", "0"], rank, world)
+
+
+def update_flops(O, A, H, B):
+    """fp32 flops of ONE optimiser step, the ALGORITHMIC count: per network forward 2 B (O H + H H + H n),
+    backward 2 B (O H [dW1] + 2 H H [dH1, dW2] + 2 H n [dH2, dWh]); n = A for the policy head, 1 for the critics; no d/dx of layer 1."""
+    net = lambda n: 2 * B * (2 * O * H + 3 * H * H + 3 * H * n)
+    return net(A) + 2 * net(1)
+
+
+def timed_iterations(cfg, warmup, steps, world=1):
+    """setup + `warmup` untimed + `steps` timed outer iterations of icrl_amd.icrl (identical calls to icrl()); returns the state,
+    wall seconds and env steps of the timed part."""
+    import torch.distributed as dist
+    from icrl_amd import icrl as I
+    st = I.setup(cfg)
+    for it in range(warmup):
+        I.outer_iteration(st, it)
+    st["agent"].gae_events = []
+    st["agent"].train_events = []
+    st["rollout_events"] = []
+    st["agent"].rollout_events = st["rollout_events"]
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    steps0 = st["timesteps"]
+    for it in range(warmup, warmup + steps):
+        I.outer_iteration(st, it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    return st, time.time() - t0, st["timesteps"] - steps0
+
+
+def update_summary(st, cfg):
+    tr_ms = [e0.elapsed_time(e1) for e0, e1, _ in st["agent"].train_events]
+    tr_steps = [n for _, _, n in st["agent"].train_events]
+    n_mb = -(-cfg.n_steps * cfg.num_threads // cfg.batch_size)
+    full = len(tr_steps) * cfg.n_epochs * n_mb
+    us = 1e3 * float(np.sum(tr_ms)) / max(1, int(np.sum(tr_steps)))
+    ro = [e0.elapsed_time(e1) for e0, e1 in st["agent"].rollout_events]
+    return dict(us_per_optimizer_step=us, optimizer_steps=int(np.sum(tr_steps)), full_steps=full,
+                us_per_rollout_step=(1e3 * float(np.mean(ro)) / cfg.n_steps) if ro else None)
+
+
+def configs2_leg(seed, steps=2, warmup=1):
+    """EXTRA, never the headline value: BASELINE configs[2] on this GPU, `steps` timed outer iterations."""
+    cfg = config_antwall(seed, 0, 1)
+    st, dt, env_steps = timed_iterations(cfg, warmup, steps)
+    u = update_summary(st, cfg)
+    fl = update_flops(113, 8, 64, cfg.batch_size)
+    tf = fl / (u["us_per_optimizer_step"] * 1e-6) / 1e12
+    out = dict(workload="AntWall-v0 ICRL (BASELINE configs[2], README.md:50 flags): 256 envs, n_steps 2048, batch 128, 20 epochs, "
+                        "constraint net [40, 40], 45 nominal + 10 eval episodes, 5 backward iterations on 22 500 + 22 500 rows of width 121",
+               value=round(env_steps / dt, 1), unit="env-steps/s", steps=steps, warmup=warmup, ms_per_step=round(1e3 * dt / steps, 2),
+               us_per_optimizer_step=round(u["us_per_optimizer_step"], 2), us_per_rollout_step=None if u["us_per_rollout_step"] is None else round(u["us_per_rollout_step"], 2),
+               optimizer_steps_per_iteration=round(u["optimizer_steps"] / steps, 1), early_stop_fraction=round(1.0 - u["optimizer_steps"] / max(1, u["full_steps"]), 4),
+               update_kernel="ppo_train_rows_kernel (two workgroups per network: 6 CUs)", rollout_kernel="rollout_wide_kernel",
+               update_tflops=round(tf, 4), update_frac_of_6cu_fp32_mfma_peak=round(tf / (F32_MFMA_PEAK_TFLOPS * 6 / 256), 4))
+    del st
+    torch.cuda.empty_cache()
+    return out
 
 
 def gae_sweep_point(N=131072, T=2048, reps=20):
@@ -127,8 +225,11 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--config", type=int, default=1, choices=(1, 3), help="BASELINE configs[] index of the headline workload: 1 = 64 envs per GPU, 3 = 256 envs per GPU")
+    ap.add_argument("--mode", default="shards", choices=("shards", "seeds"), help="shards: env shards + one all-reduce per outer iteration; seeds: independent runs, no collective")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_seed_batch", action="store_true")
+    ap.add_argument("--no_configs2", action="store_true")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -138,28 +239,14 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
 
-    from icrl_amd import icrl as I, logger, utils
-    from icrl_amd.vec_env import sync_envs_normalization
-    cfg = config2(a.steps + a.warmup, a.seed, rank, world)
+    envs = 64 if a.config == 1 else 256
+    if a.mode == "seeds":      # independent runs: every rank is a 1-rank job with its own seed; the only collectives are the timing ones below
+        cfg = config2(a.steps + a.warmup, a.seed + rank, 0, 1, envs)
+    else:
+        cfg = config2(a.steps + a.warmup, a.seed, rank, world, envs)
 
     # ---- the outer loop, one iteration at a time (identical calls to icrl_amd.icrl.icrl; see that function)
-    st = I.setup(cfg)
-    for it in range(a.warmup):
-        I.outer_iteration(st, it)
-    st["agent"].gae_events = []
-    st["agent"].train_events = []
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.time()
-    steps0 = st["timesteps"]
-    for it in range(a.warmup, a.warmup + a.steps):
-        I.outer_iteration(st, it)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.time() - t0
-    env_steps = st["timesteps"] - steps0
+    st, dt, env_steps = timed_iterations(cfg, a.warmup, a.steps, world)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=D.reduce_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -194,32 +281,40 @@ def main():
                        f"{sweep['envs'] // 256} one-wave workgroups",
                     in_loop=dict(achieved=round(gae_ach, 1), frac=round(gae_ach / HBM_PEAK_GBS, 5), us_per_launch=round(float(np.mean(gae_us)), 1),
                                  launches=len(gae_us), bytes_per_launch=gae_bytes,
-                                 note="the launch the loop itself makes (4.7 MB, cache-resident, latency-bound): two-level scan, "
-                                      "time axis split over 16 workgroups x 8 waves (gae_dual_split_kernel)"))
-    # ---- the PPO kernel: flops of the 8 GEMMs per optimiser step x 3 nets, from the events around icrl_ppo_lag_train
-    tr_ms = [e0.elapsed_time(e1) for e0, e1, _ in st["agent"].train_events]
-    tr_steps = [n for _, _, n in st["agent"].train_events]
-    O, A, H, B = 18, 6, 64, cfg.batch_size
-    flops_step = 3 * 2 * B * (O * H + H * H) * 3 + 2 * B * H * (A + 2) * 3      # fwd + 2x bwd of the three MLPs (+ heads)
-    us_per_step = 1e3 * float(np.sum(tr_ms)) / max(1, int(np.sum(tr_steps)))
+                                 note="the launch the loop itself makes (cache-resident, latency-bound): two-level scan, "
+                                      "time axis split over workgroups x 8 waves (gae_dual_split_kernel)"))
+    # ---- the PPO kernel: algorithmic flops per optimiser step (update_flops) / the events around icrl_ppo_lag_train
+    u = update_summary(st, cfg)
+    B = cfg.batch_size
+    flops_step = update_flops(18, 6, 64, B)
+    us_per_step = u["us_per_optimizer_step"]
     ppo_tflops = flops_step / (us_per_step * 1e-6) / 1e12
     roofline_ppo = dict(kernel="ppo_train_pairs_kernel", bound="mfma", achieved=round(ppo_tflops, 4), peak=round(F32_MFMA_PEAK_TFLOPS * 3 / 256, 3),
                         unit="TFLOP/s", frac=round(ppo_tflops / (F32_MFMA_PEAK_TFLOPS * 3 / 256), 4),
                         chip_peak=F32_MFMA_PEAK_TFLOPS, frac_chip=round(ppo_tflops / F32_MFMA_PEAK_TFLOPS, 5),
-                        us_per_optimizer_step=round(us_per_step, 2), optimizer_steps=int(np.sum(tr_steps)),
+                        us_per_optimizer_step=round(us_per_step, 2), optimizer_steps=u["optimizer_steps"], flops_per_step=flops_step,
+                        us_per_rollout_step=None if u["us_per_rollout_step"] is None else round(u["us_per_rollout_step"], 2),
                         note="dependent optimiser steps of the reference algorithm: 3 workgroups (one per MLP) = 3 of 256 CUs; "
-                             "peak = fp32 MFMA rate of those 3 CUs; the padded 16x16x4 MFMA work actually issued is 2 x 148 instructions "
-                             "per SIMD and step = 9.5k of the ~22k cycles of a step (SQ counters: profiles/r02_train_pmc.md)")
+                             "peak = fp32 MFMA rate of those 3 CUs; flops_per_step is the algorithmic count (DESIGN.md section 5), the "
+                             "padded 16x16x4 MFMA work actually issued is 2 x 152 instructions per SIMD and step (SQ counters: profiles/)")
+    par = (f"env-shards x{world}, 1 all-reduce / outer iteration" if a.mode == "shards" else f"independent seeds x{world}, no collective")
     out = dict(metric="env-steps/sec (ICRL outer loop, HCWithPos-v0)", value=round(env_steps / dt, 1), unit="env-steps/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * dt / a.steps, 2), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload="HCWithPos-v0 ICRL (BASELINE configs[1]): 64 vectorised envs per GPU, n_steps 2048, "
-                                    "forward_timesteps 2e5 (2 rollouts + 2 PPO-Lag updates of 10 epochs x 2048 minibatches of 64), "
-                                    "10 nominal + 10 eval episodes, constraint net [20] x 10 backward iterations, target_kl 0.01",
+               config=dict(workload=f"HCWithPos-v0 ICRL (BASELINE configs[{a.config}]" + ("" if a.config == 1 else ": 2048 envs sharded 8 ways = 256 per GPU") +
+                                    f"): {N} vectorised envs per GPU, n_steps 2048, forward_timesteps 2e5 ({-(-cfg.forward_timesteps // (N * T))} rollout(s) + "
+                                    f"PPO-Lag update(s) of 10 epochs x {N * T // B} minibatches of 64, target_kl 0.01 early stops INCLUDED: value moves with the "
+                                    "iteration count, us_per_optimizer_step does not), 10 nominal + 10 eval episodes, constraint net [20] x 10 backward iterations",
                            envs_per_gpu=N, n_steps=T, batch_size=B, n_epochs=cfg.n_epochs, forward_timesteps=cfg.forward_timesteps,
-                           parallelism=f"env-shards x{world}, 1 all-reduce / outer iteration"),
+                           baseline_config=a.config, mode=a.mode, parallelism=par),
+               optimizer_steps_per_iteration=round(u["optimizer_steps"] / a.steps, 1),
+               early_stop_fraction=round(1.0 - u["optimizer_steps"] / max(1, u["full_steps"]), 4),
                roofline=roofline, roofline_ppo=roofline_ppo)
     out["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline()      # reported at N = 1 only
+    del st
+    torch.cuda.empty_cache()
+    if world == 1 and not a.no_configs2:
+        out["configs2"] = configs2_leg(a.seed)
     if world == 1 and not a.no_seed_batch:
         out["seed_batch"] = seed_batch_leg()
     print(json.dumps(out))

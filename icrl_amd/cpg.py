@@ -62,7 +62,18 @@ def cpg(config, log=print):
     elif config.cn_path is None:
         cost_function = get_true_cost_function(config.eval_env_id)
     elif config.load_gail:
-        raise NotImplementedError("--load_gail: the GAIL discriminator baseline is outside the ICRL hot path")
+        # ref: icrl/cpg.py:54-83 — the cost is the discriminator's output D itself (apply_log=False); numpy in / numpy out like the
+        # reference's callable, so it runs through VecCostWrapper's callable branch and the per-step rollout loop
+        from .gail_utils import GailDiscriminator
+        action_low, action_high = None, None
+        if isinstance(train_env.action_space, spaces.Box):
+            action_low, action_high = train_env.action_space.low, train_env.action_space.high
+        gail = GailDiscriminator.load(config.cn_path, obs_dim=obs_dim, acs_dim=acs_dim, is_discrete=is_discrete,
+                                      obs_select_dim=config.cn_obs_select_dim, acs_select_dim=config.cn_acs_select_dim,
+                                      clip_obs=None, obs_mean=None, obs_var=None, action_low=action_low, action_high=action_high)
+
+        def cost_function(obs, acs):
+            return gail.reward_function(obs, acs, apply_log=False).cpu().numpy()
     else:
         constraint_net = ConstraintNet.load(config.cn_path, obs_dim=obs_dim, acs_dim=acs_dim, is_discrete=is_discrete,
                                             obs_select_dim=config.cn_obs_select_dim, acs_select_dim=config.cn_acs_select_dim,

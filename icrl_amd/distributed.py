@@ -125,17 +125,18 @@ class Scalars:
             setattr(o, a, int(np.rint(v)))
 
 
-def allreduce_state(avg_tensors, rms_list, rms_prev_sums, world, group=None, scalars=None):
+def allreduce_state(avg_tensors, rms_list, rms_prev_sums, world, group=None, scalars=None, force_collective=False):
     """avg_tensors: tensors to average in place; rms_list: running-moment objects (device-resident or host objects with
     .mean/.var/.count/.assign); rms_prev_sums: their S at the last synchronisation; scalars: optional Scalars.
-    ONE all-reduce.  Returns the new common S list (float64 tensors)."""
+    ONE all-reduce.  Returns the new common S list (float64 tensors).  force_collective: issue the all-reduce at world size 1 too
+    (tests/test_multirank_gpu.py exercises the RCCL branch — device-side float64 SUM, no host round trip — on a 1-GPU box)."""
     dev = avg_tensors[0].device if avg_tensors else torch.device("cpu")
     sums = [_rms_sums(r, dev) for r in rms_list]
     parts = [t.detach().reshape(-1).double() for t in avg_tensors]
     if scalars is not None and len(scalars):
         parts.append(scalars.pack(dev))
     buf = torch.cat(parts + sums)
-    if world > 1:
+    if world > 1 or (force_collective and dist.is_initialized()):
         if buf.device.type == "cuda" and reduce_device() == "cpu":
             host = buf.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)

@@ -170,11 +170,18 @@ class PPOLagrangian:
         timed = getattr(self, "gae_events", None) is not None
         flags = int(not timed) | (2 if getattr(self, "rollout_kernel", "auto") == "steps" else 0) | ((4 if getattr(self, "_wide_prof_flag", 1) == 1 else 8) if getattr(self, "profile_phases", 0) else 0)
         from .seed_batch import budgeted
+        rev = None
+        if getattr(self, "rollout_events", None) is not None:      # bench.py: events around the rollout launch on its stream
+            rev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            rev[0].record()
         with budgeted(0 if flags & 2 else self.n_envs):      # persistent launch: one CU per environment (several runs on one GPU)
             _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn) if cn is not None else None, b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
                                                           float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
                                                           float(self.cost_gae_lambda), flags, _lib.current_stream()),
                        "icrl_rollout_collect")
+        if rev is not None:
+            rev[1].record()
+            self.rollout_events.append(rev)
         if timed:   # bench.py: the same GAE launch, bracketed by events on the stream it runs on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -295,6 +302,15 @@ class PPOLagrangian:
                                                "target_kl", "n_envs", "num_timesteps", "_n_updates", "seed")}
         data.update(policy_class="ActorTwoCriticsPolicy", observation_dim=int(self.policy.obs_dim), action_dim=int(self.policy.act_dim),
                     discrete=bool(self.policy.discrete), adam_step=int(self.policy.adam_step))
+        # everything a continued training run needs (the reference pickles self.__dict__, base_class.py:647-692): schedules are
+        # stored by their current value, the network widths as policy_kwargs
+        num = lambda v: None if v is None else float(v(1.0) if callable(v) else v)
+        data.update(learning_rate=num(self.learning_rate), clip_range=num(self.clip_range), clip_range_reward_vf=num(self.clip_range_reward_vf),
+                    clip_range_cost_vf=num(self.clip_range_cost_vf), algo_type=self.algo_type, budget=float(self.budget),
+                    penalty_initial_value=float(self.penalty_initial_value), penalty_learning_rate=float(self.penalty_learning_rate),
+                    penalty_min_value=self.penalty_min_value, update_penalty_after=self.update_penalty_after, pid_kwargs=self.pid_kwargs,
+                    policy_kwargs=dict(net_arch=[dict(pi=list(self.policy.widths["policy_net"]), vf=list(self.policy.widths["value_net"]),
+                                                      cvf=list(self.policy.widths["cost_value_net"]))]))
         with zipfile.ZipFile(path, "w") as z:
             z.writestr("data", json.dumps(data, default=lambda o: str(o)))
             z.writestr("policy.pth", blob(self.policy.state_dict()))
@@ -318,6 +334,12 @@ class PPOLagrangian:
             path += ".zip"
         with zipfile.ZipFile(path) as z:
             data = parse_sb3_data(z.read("data"))
+            sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=False)
+        # network widths (-pl / -rvl / -cvl): read off the stored tensors, whoever wrote the archive
+        if any(k.startswith("mlp_extractor.shared_net") for k in sd):
+            raise NotImplementedError("archives with a shared trunk (-sl) are outside this build (policies.py)")
+        w = lambda b: [int(sd[f"mlp_extractor.{b}.0.weight"].shape[0]), int(sd[f"mlp_extractor.{b}.2.weight"].shape[0])]
+        net_arch = [dict(pi=w("policy_net"), vf=w("value_net"), cvf=w("cost_value_net"))]
         if "observation_dim" in data and "observation_space" not in data:      # archive written by save() of this build
             o, a = int(data["observation_dim"]), int(data["action_dim"])
             data["observation_space"] = spaces.Box(-np.inf, np.inf, (o,), np.float64)
@@ -338,6 +360,7 @@ class PPOLagrangian:
         for k in ("clip_range", "lr_schedule"):          # stored as pickled closures by the reference
             if callable(getattr(model, k, None)) is False and not isinstance(getattr(model, k, None), (int, float)):
                 setattr(model, k, 0.2 if k == "clip_range" else None)
+        model.policy_kwargs = dict(net_arch=net_arch)
         model.__dict__.update(kwargs)
         model._setup_model()
         model.load_parameters(path, dual=False)

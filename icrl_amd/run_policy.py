@@ -60,6 +60,10 @@ def run_policy(args):
     with open(os.path.join(load_dir, "config.json")) as fh:
         config = types.SimpleNamespace(**json.load(fh))
     save_dir = os.path.join(load_dir, args.save_dir)
+    # the directory is deleted first (del_and_make, icrl/utils.py): only ever a proper sub-directory of the run directory
+    real_load, real_save = os.path.realpath(load_dir), os.path.realpath(save_dir)
+    if real_save == real_load or not real_save.startswith(real_load + os.sep):
+        raise ValueError(f"--save_dir {args.save_dir!r} must name a sub-directory of the run directory {load_dir!r}")
     shutil.rmtree(save_dir, ignore_errors=True)
     os.makedirs(save_dir)
     env_id = args.env_id or config.eval_env_id

@@ -191,12 +191,24 @@ class _RefObject:
 
 class _RefUnpickler(pickle.Unpickler):
     """reads pickles written by the reference (train_env_stats.pkl = a pickled VecNormalizeWithCost, vec_normalize.py:42-64)
-    without importing stable_baselines3 / gym: their classes become attribute bags, numpy / builtins load normally."""
+    without importing stable_baselines3 / gym: their classes become attribute bags.  Only the exact (module, name) pairs a numpy /
+    container payload needs are resolved to real objects — nothing callable with side effects (no builtins.eval / getattr /
+    __import__, no numpy.load ...); every other global becomes an inert _RefObject subclass."""
 
-    SAFE = ("numpy", "builtins", "collections", "copyreg", "_codecs")
+    ALLOWED = {
+        ("numpy", "ndarray"), ("numpy", "dtype"), ("numpy", "float64"), ("numpy", "float32"), ("numpy", "int64"), ("numpy", "int32"),
+        ("numpy", "bool_"), ("numpy.core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"),
+        ("numpy._core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "scalar"),
+        ("numpy.core.numeric", "_frombuffer"), ("numpy._core.numeric", "_frombuffer"),
+        ("collections", "OrderedDict"), ("collections", "deque"), ("collections", "defaultdict"),
+        ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "slice"), ("builtins", "complex"), ("builtins", "bytearray"),
+        ("builtins", "list"), ("builtins", "dict"), ("builtins", "tuple"), ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"),
+        ("builtins", "str"), ("builtins", "bytes"), ("builtins", "object"),
+        ("copyreg", "_reconstructor"), ("_codecs", "encode"),
+    }
 
     def find_class(self, module, name):
-        if module.split(".")[0] in self.SAFE:
+        if (module, name) in self.ALLOWED:
             return super().find_class(module, name)
         return type(name, (_RefObject,), {"__module__": module})
 

@@ -1,0 +1,129 @@
+"""GPU: parity at the size the bench quotes (BASELINE configs[1]) and at configs[2]'s widths — long dependent chains.
+
+The other oracle tests stop at <= 960 dependent optimiser steps; bench.py's `value` is measured on 20 480 dependent steps per
+train() (64 envs x 2048 rows, 10 epochs x 2048 minibatches of 64).  Here the HIP path and the CPU port (oracle.loop.PortAgent,
+pinned to the reference by g4 / g9 / g13) run ONE forward step of an outer iteration at exactly that size on the same
+SeededStreams — 2 rollouts + 2 train() calls, README.md:38 flags — and the drift of everything the reference logs is measured
+after 20 480 and 40 960 dependent steps (ref: stable_baselines3/ppo_lag/ppo_lag.py:196-299, common/buffers.py:493-541).
+
+What holds (asserted) and what was measured on MI355X (printed by the test, recorded in DESIGN.md section 2):
+  * the target-KL early-stop decision of every epoch is the same on both sides (`early_stop_epoch` equal); the per-epoch mean
+    approx-KL values differ by fp32 rounding order only and are not within 2 % of the 1.5 x target_kl threshold when a decision
+    is taken, so the decision is not at the mercy of summation order here; if an epoch ever sits that close the test says so
+    instead of failing on a coin flip;
+  * nu (the Lagrange multiplier trajectory) within 1e-5 absolute after each train();
+  * parameters within ADAM_DEV_BOUND x lr x steps of the port's (the per-step rate the short tests use, tests/test_ppo_train_gpu.py).
+"""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loop as o_loop, nets as o_nets
+from oracle.streams import SeededStreams
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+ADAM_DEV_BOUND = 5e-4      # same rate as tests/test_ppo_train_gpu.py: |dp| <= 5e-4 x lr x steps + 2e-7
+
+
+def _pair(env_id, kind, N, T, od, ad, cn_layers, seed, **kw):
+    from icrl_amd import utils
+    from icrl_amd.constraint_net import ConstraintNet
+    from icrl_amd.ppo_lag import PPOLagrangian
+    env = utils.make_train_env(env_id, None, True, seed, N, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    lo = -np.ones(ad, np.float32)
+    torch.manual_seed(seed + 1)
+    cn = ConstraintNet(od, ad, cn_layers, None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
+    ocn = o_nets.CostNet(od, ad, cn_layers, False, None, None, 20, lo, -lo)
+    ocn.load_state_dict(cn.state_dict())
+    env.set_cost_function(cn.cost_function)
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=seed, streams=SeededStreams(77), **kw)
+    stack = o_loop.make_stack(N, kind, seed); stack.cost_fn = ocn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=T, seed=seed, **kw)
+    port.policy.load_state_dict(agent.policy.state_dict())
+    return agent, port, env
+
+
+def _forward_step(agent, port, env, n_rollouts, lr, target_kl):
+    """learn() of both sides, rollout by rollout, with a comparison after every train()."""
+    from icrl_amd import logger
+    T, N = agent.n_steps, agent.n_envs
+    streams = SeededStreams(77)
+    agent._setup_learn(n_rollouts * N * T)
+    port.num_timesteps = 0
+    port._last_obs = port.stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = port.stack.old_obs.copy()
+    rows, t_port = [], 0.0
+    for k in range(n_rollouts):
+        agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost")
+        agent.train()
+        lg = dict(logger.Logger.CURRENT.name_to_value)
+        t0 = time.time()
+        b = port.collect_rollouts(streams.rollout_noise(T, N, port.act_dim))
+        out = port.train(lambda e: streams.permutation(e, T * N))
+        streams.consumed(min(int(out["train/early_stop_epoch"]) + 1, agent.n_epochs))
+        t_port += time.time() - t0
+        steps = agent.policy.adam_step
+        worst_abs, worst_rate = 0.0, 0.0
+        for name, v in agent.policy.state_dict().items():
+            d = float(np.abs(v.numpy() - port.policy.params[name].detach().numpy()).max())
+            worst_abs = max(worst_abs, d)
+        worst_rate = worst_abs / (lr * steps)
+        rb = agent.rollout_buffer
+        buf_dev = {f: float(np.abs(getattr(rb, f).cpu().numpy().reshape(getattr(b, f).shape) - getattr(b, f)).max())
+                   for f in ("rewards", "costs", "orig_costs", "log_probs", "reward_values", "reward_advantages", "cost_advantages")}
+        kls_hip = np.asarray(agent.epoch_kls, np.float64)
+        kls_port = np.asarray(out.get("epoch_kls", []), np.float64)
+        rows.append(dict(rollout=k, steps=steps, nu=(lg["train/nu"], out["train/nu"]), average_cost=(lg["train/average_cost"], out["train/average_cost"]),
+                         early_stop_epoch=(lg["train/early_stop_epoch"], out["train/early_stop_epoch"]),
+                         pg_loss=(lg["train/policy_gradient_loss"], out["train/policy_gradient_loss"]),
+                         rv_loss=(lg["train/reward_value_loss"], out["train/reward_value_loss"]),
+                         cv_loss=(lg["train/cost_value_loss"], out["train/cost_value_loss"]),
+                         approx_kl=(lg["train/approx_kl"], out["train/approx_kl"]),
+                         clip_fraction=(lg["train/clip_fraction"], out["train/clip_fraction"]),
+                         param_dev=worst_abs, param_rate=worst_rate, buffer_dev=buf_dev, kls_hip=kls_hip, kls_port=kls_port))
+        r = rows[-1]
+        print(f"[full-size] after train() #{k + 1}: {steps} dependent optimiser steps; nu {r['nu'][0]:.9f} vs {r['nu'][1]:.9f} (d {abs(r['nu'][0] - r['nu'][1]):.2e}); "
+              f"average_cost d {abs(r['average_cost'][0] - r['average_cost'][1]):.2e}; early_stop_epoch {r['early_stop_epoch']}; "
+              f"losses d pg {abs(r['pg_loss'][0] - r['pg_loss'][1]):.2e} rv {abs(r['rv_loss'][0] - r['rv_loss'][1]):.2e} cv {abs(r['cv_loss'][0] - r['cv_loss'][1]):.2e}; "
+              f"approx_kl d {abs(r['approx_kl'][0] - r['approx_kl'][1]):.2e}; clip_fraction d {abs(r['clip_fraction'][0] - r['clip_fraction'][1]):.2e}; "
+              f"max |d param| {worst_abs:.3e} = {worst_rate:.2e} x lr x steps; buffer of this rollout: "
+              + ", ".join(f"{f} {v:.1e}" for f, v in buf_dev.items()))
+        # ---- what must hold
+        ee_h, ee_p = int(r["early_stop_epoch"][0]), int(r["early_stop_epoch"][1])
+        if ee_h != ee_p and target_kl is not None:
+            # a decision within fp32 rounding of the threshold would be a coin flip, not a bug: say which epoch and how close
+            thr = 1.5 * target_kl
+            e = min(ee_h, ee_p)
+            close = abs(kls_hip[e] - thr) / thr if e < len(kls_hip) else float("nan")
+            assert close < 2e-3, f"early stop differs (HIP {ee_h}, port {ee_p}) and epoch {e}'s mean KL {kls_hip[e]} is not at the threshold {thr}"
+            pytest.skip(f"epoch {e}: mean approx-KL {kls_hip[e]:.7f} sits within {close:.1e} of the 1.5 x target_kl threshold; the decision flips with summation order")
+        assert abs(r["nu"][0] - r["nu"][1]) <= 1e-5, r["nu"]
+        assert abs(r["average_cost"][0] - r["average_cost"][1]) <= 1e-5 + 1e-4 * abs(r["average_cost"][1])
+        assert worst_abs <= ADAM_DEV_BOUND * lr * steps + 2e-7, (worst_abs, steps)
+        for key in ("pg_loss", "rv_loss", "cv_loss"):
+            assert abs(r[key][0] - r[key][1]) <= 1e-5 + 2e-4 * abs(r[key][1]), (key, r[key])
+    print(f"[full-size] CPU port: {t_port:.1f} s for {n_rollouts} x ({N} x {T} env steps + train())")
+    return rows
+
+
+def test_configs1_forward_step_full_size():
+    """BASELINE configs[1] exactly as bench.py runs it: HCWithPos, 64 envs x 2048 steps, batch 64, 10 epochs, target_kl 0.01,
+    lr 3e-4 — 2 rollouts + 2 train() = up to 40 960 dependent optimiser steps."""
+    agent, port, env = _pair("HCWithPos-v0", "hc", 64, 2048, 18, 6, [20], 0, batch_size=64, n_epochs=10, target_kl=0.01,
+                             penalty_learning_rate=0.1)
+    rows = _forward_step(agent, port, env, 2, 3e-4, 0.01)
+    assert rows[0]["steps"] > 2048            # at least one whole epoch ran at full size
+
+
+def test_configs2_widths_long_chain():
+    """BASELINE configs[2] flags (README.md:50: AntWall, constraint net [40, 40], batch 128 -> the two-workgroup update, 20 epochs,
+    lr 3e-5, clip 0.4, lambdas 0.9, nu0 0.1, nu-lr 0.05, target_kl 0.02) at 256 envs x 128 steps: up to 20 x 256 = 5 120 dependent
+    steps per train(), 2 rollouts."""
+    agent, port, env = _pair("AntWall-v0", "ant", 256, 128, 113, 8, [40, 40], 3, batch_size=128, n_epochs=20, target_kl=0.02,
+                             learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9, cost_gae_lambda=0.9,
+                             penalty_initial_value=0.1, penalty_learning_rate=0.05)
+    _forward_step(agent, port, env, 2, 3e-5, 0.02)

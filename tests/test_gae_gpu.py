@@ -48,9 +48,10 @@ def test_gae_golden(golden, case, W):
             assert np.allclose(got, arrs[key], rtol=2e-7, atol=1e-7), key
 
 
-@pytest.mark.parametrize("T,N", [(2048, 64), (2048, 256), (500, 1000), (37, 4097), (2048, 4096), (33, 65536), (9, 131076), (5, 131074)])
+@pytest.mark.parametrize("T,N", [(2048, 64), (2048, 256), (500, 1000), (37, 4097), (2048, 4096), (33, 65536), (9, 131076), (5, 131074), (256, 131072)])
 def test_gae_vs_oracle_random(T, N):
-    """incl. the streaming shapes the heuristic picks: one column per lane from 65 536 envs on, four columns per lane from 131 072
+    """(256, 131 072): the launch shape bench.py's roofline is quoted on (gae_dual_x4_kernel<4,1>, 512 one-wave workgroups, 64 batches of
+    the double-buffered 4-row loop per column).  incl. the streaming shapes the heuristic picks: one column per lane from 65 536 envs on, four columns per lane from 131 072
     on when N % 4 == 0 (131 076: a ragged last wave; 131 074: falls back to one column per lane); all bit-exact."""
     rng = np.random.RandomState(T + N)
     arrs = dict(rewards=rng.randn(T, N), costs=rng.rand(T, N), reward_values=rng.randn(T, N), cost_values=rng.randn(T, N),

@@ -115,3 +115,33 @@ def test_gail_entry_point_short_run(tmp_path):
     again = GailDiscriminator.load(str(tmp_path / "gail_discriminator.pt"))
     for k, v in disc.state_dict().items():
         assert torch.equal(again.state_dict()[k], v), k
+
+
+def test_cpg_load_gail_cost_is_the_reference_discriminator(golden, tmp_path):
+    """`cpg --load_gail -cp <gail_discriminator.pt>` (ref: icrl/cpg.py:54-83): the env cost is D(prev raw obs, clipped action) of
+    the loaded discriminator, apply_log=False.  Fixture: g12's discriminator as the REFERENCE left it after two rollouts (d1/*),
+    written in the reference's save layout; the costs of the last rollout are recomputed with the oracle's torch-CPU copy."""
+    from icrl_amd.cpg import build_parser, cpg
+    from icrl_amd.gail_utils import GailDiscriminator
+    from oracle import gail as o_gail
+    g = golden("g12_gail")
+    disc = GailDiscriminator(18, 6, [20], None, lambda x: 0.0, None, None, False, clip_obs=20, eps=1e-5)
+    disc.load_state_dict(_sub(g, "d1/"))
+    path = str(tmp_path / "gail_discriminator.pt")
+    disc.save(path)
+    N, T = 4, 64
+    argv = ["cpg", "--cn_path", path, "--load_gail", "-tei", "HCWithPos-v0", "-eei", "HCWithPosTest-v0", "-t", str(2 * N * T), "-nt", str(N),
+            "--n_steps", str(T), "-ne", "2", "-s", "2", "-v", "0", "--eval_every_rollouts", "2"]
+    cfg = vars(build_parser().parse_args(argv)); cfg.update(rank=0, world_size=1, save_dir=None)
+    model, hist = cpg(types.SimpleNamespace(**cfg), log=None)
+    assert model.num_timesteps == 2 * N * T
+    rb = model.rollout_buffer
+    od = o_gail.make_disc(18, 6, [20])
+    od.load_state_dict(_sub(g, "d1/"))
+    prev_obs = rb.orig_observations.cpu().numpy().astype(np.float64)            # raw observation BEFORE each step (float32-rounded in the buffer)
+    clipped = np.clip(rb.actions.cpu().numpy(), -1.0, 1.0)
+    ref = o_gail.disc_reward(od, prev_obs, clipped, apply_log=False)
+    got = rb.orig_costs.cpu().numpy()
+    assert got.shape == ref.shape == (T, N)
+    assert np.allclose(got, ref, rtol=2e-5, atol=2e-6), np.abs(got - ref).max()
+    assert 0.0 < got.min() and got.max() < 1.0 and got.std() > 0

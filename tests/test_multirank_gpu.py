@@ -93,3 +93,25 @@ def test_state_identical_across_ranks_after_two_outer_iterations(two_ranks):
     assert not np.array_equal(r0["B_logged_nu"], r1["B_logged_nu"])
     # merged observation count = initial 1e-4 + both shards' samples: 2 iterations x (reset excluded) 2 rollouts x 64 x 16 envs
     assert abs(r0["B_obs_rms"][-1] - (1e-4 + 2 * 2 * 64 * 16)) < 1e-6
+
+
+def test_rccl_allreduce_state_one_rank(tmp_path):
+    """the `nccl` (RCCL) branch of the per-iteration collective on real hardware: a fresh child process with a 1-rank nccl process
+    group runs distributed.allreduce_state with the collective forced — RCCL loads, a float64 SUM of the ~33 k-element flat buffer runs
+    on the device (no host round trip), and at world size 1 it is the identity."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = tmp_path / "nccl1.npz"
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("ICRL_DIST_BACKEND", None)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "helpers/nccl_one_rank_child.py"), str(out)], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert p.returncode == 0, p.stdout.decode(errors="replace")[-3000:]
+    r = np.load(out)
+    assert str(r["seen_device"]) == "cuda" and str(r["seen_dtype"]) == "torch.float64"
+    assert int(r["seen_numel"]) == 2 * 16654 + 5 + (1 + 2 * 18)
+    assert bool(r["same_params"]) and bool(r["same_m"])
+    assert float(r["mean_dev"]) < 1e-12 and float(r["var_dev"]) < 1e-10 and abs(float(r["count"]) - 1234.5) < 1e-9
+    assert np.array_equal(r["x"], np.arange(8) + 0.125)
+    assert np.allclose(r["scal"], [0.5, 0.1, 0.2, 3, 100])
+    print("RCCL version:", r["rccl"])

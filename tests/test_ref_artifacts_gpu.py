@@ -94,3 +94,35 @@ def test_compute_kl_vs_oracle(golden):
     assert abs(fwd + rev) < 1e-4 * max(1.0, abs(o_fwd))               # the two are negatives of each other by construction
     one = utils.compute_kl(agent, d_obs, d_acs)
     assert abs(one - o_loop.compute_kl(op, obs, acs)) < 1e-4 * max(1.0, abs(one))
+
+
+def test_agent_save_load_round_trip_with_narrow_widths(tmp_path):
+    """an agent built with -pl 32 16 -rvl 64 32 -cvl 16 64 and non-default hyper-parameters survives save() -> load():
+    widths (read off policy.pth), weights, Adam state and the hyper-parameters a continued run needs; continued training works."""
+    from icrl_amd import utils
+    from icrl_amd.ppo_lag import PPOLagrangian
+    arch = [dict(pi=[32, 16], vf=[64, 32], cvf=[16, 64])]
+    env = utils.make_train_env("HCWithPos-v0", None, True, 0, 4, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    from icrl_amd.constraint_net import ConstraintNet
+    lo = -np.ones(6, np.float32)
+    cn = ConstraintNet(18, 6, [20], None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
+    env.set_cost_function(cn.cost_function)
+    kw = dict(n_steps=32, batch_size=32, n_epochs=2, learning_rate=1e-4, clip_range=0.3, budget=0.05, penalty_initial_value=0.5,
+              penalty_learning_rate=0.02, target_kl=0.03)
+    a = PPOLagrangian("TwoCriticsMlpPolicy", env, seed=3, policy_kwargs=dict(net_arch=arch), **kw)
+    a.learn(2 * 4 * 32)
+    path = a.save(str(tmp_path / "agent"))
+    b = PPOLagrangian.load(path, env=env)
+    assert b.policy.widths == a.policy.widths == dict(policy_net=(32, 16), value_net=(64, 32), cost_value_net=(16, 64))
+    assert torch.equal(b.policy.params, a.policy.params) and torch.equal(b.policy.exp_avg, a.policy.exp_avg)
+    assert torch.equal(b.policy.exp_avg_sq, a.policy.exp_avg_sq) and b.policy.adam_step == a.policy.adam_step
+    for k, v in kw.items():
+        got = getattr(b, k)
+        assert (got(1.0) if callable(got) else got) == v, (k, got, v)
+    assert b.algo_type == "lagrangian" and b.num_timesteps == a.num_timesteps and b._n_updates == a._n_updates
+    assert abs(b.dual.nu().item() - 0.5) < 1e-6            # the reference's nu-reset quirk: back at penalty_initial_value
+    b.learn(4 * 32)                                        # continued training runs with the restored widths
+    assert np.isfinite(b.policy.params.cpu().numpy()).all()
+    # the reference's own archive (64-64 everywhere) still loads through the width inference
+    c = PPOLagrangian.load(os.path.join(ART, "hc_best_model.zip"))
+    assert c.policy.widths == dict(policy_net=(64, 64), value_net=(64, 64), cost_value_net=(64, 64))
