@@ -29,10 +29,6 @@ import sys
 import time
 import types
 
-# the seed-batch leg runs up to 32 independent ICRL runs on 32 HIP streams: ROCm multiplexes streams onto 4 hardware queues unless
-# told otherwise (measured: aggregate throughput saturates at 4 runs); must be set before the runtime initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
-
 import numpy as np
 import torch
 
@@ -170,22 +166,23 @@ def gae_sweep_point(N=131072, T=2048, reps=20):
     return dict(envs=N, T=T, bytes=T * N * 36, us=ms * 1e3, achieved=T * N * 36 / (ms * 1e-3) / 1e9)
 
 
-def seed_batch_leg(sizes=(8, 32)):
-    """EXTRA, not the headline value: S independent runs of the same workload (seeds 100 ..) sharing the GPU, each on its own
-    HIP stream / host thread (icrl_amd/seed_batch.py; every run bit-identical to its solo run, tests/test_seed_batch_gpu.py).
-    One warm-up iteration, then 2 timed iterations of every run."""
+def seed_batch_leg(sizes=(8, 32, 64)):
+    """EXTRA, not the headline value: S independent runs of the same workload (seeds 100 ..) sharing the GPU INSIDE the launches
+    (icrl_amd/seed_batch.py: one host thread, every phase one launch with grid.y = run; every run bit-identical to its solo run,
+    tests/test_seed_batch_gpu.py).  One warm-up iteration, then 2 timed iterations of every run."""
     from icrl_amd import seed_batch as SB
     res = {}
     for S in sizes:
-        states = SB.setup_runs([config2(4, 100 + s_, 0, 1) for s_ in range(S)])
-        SB.run_iterations(states, 0, 1)                       # warm-up
-        steps0 = sum(st["timesteps"] for st in states)
-        _, dt = SB.run_iterations(states, 1, 2)
-        res[str(S)] = round((sum(st["timesteps"] for st in states) - steps0) / dt, 1)
-        del states
+        sb = SB.SeedBatch([config2(4, 100 + s_, 0, 1) for s_ in range(S)])
+        sb.run(0, 1)                                          # warm-up
+        steps0 = sum(st["timesteps"] for st in sb.states)
+        _, dt = sb.run(1, 2)
+        res[str(S)] = round((sum(st["timesteps"] for st in sb.states) - steps0) / dt, 1)
+        del sb
         torch.cuda.empty_cache()
     return dict(aggregate_env_steps_per_s=res, unit="env-steps/s", note="S independent ICRL runs (seeds) of the same workload on one "
-                "MI355X, one HIP stream + host thread per run, 2 timed outer iterations each; not the headline value")
+                "MI355X in lock-step from one host thread: rollouts of all runs = one launch of grid (64, S), updates = one launch of "
+                "3 S persistent workgroups, 2 timed outer iterations each; not the headline value")
 
 
 def cpu_baseline():

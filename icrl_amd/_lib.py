@@ -11,7 +11,6 @@ LIB_PATH = os.path.join(_HERE, "lib", "libicrl_hip.so")
 
 _lib = None
 PPO_SPLIT_BYTES = 2 * 3 * 2 * (4 * 8 + 23 + 5) * 256 * 8      # ICRL_PPO_SPLIT_BYTES
-CU_BUDGET = None      # admission control for persistent launches when several runs share the GPU (seed_batch.py)
 
 c_void_p, c_int, c_double, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_float
 
@@ -46,7 +45,14 @@ SIGNATURES = {
     "icrl_debug_rollout_trace_wide": [c_void_p, c_int],
     "icrl_cn_train_minibatch": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p],
+    # batched forms (several independent runs in one launch, run = blockIdx.y): n_runs, jobs[n_runs], ..., args_ws, bytes, stream
+    "icrl_rollout_collect_batch": [c_int, c_void_p, c_void_p, c_void_p] + [c_double] * 4 + [c_int, c_void_p, ctypes.c_longlong, c_void_p],
+    "icrl_gae_dual_batch": [c_int, c_void_p, c_int, c_int] + [c_double] * 4 + [c_void_p, ctypes.c_longlong, c_void_p],
+    "icrl_sample_episodes_batch": [c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p, ctypes.c_longlong, c_void_p],
+    "icrl_cn_train_batch": [c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p],
+    "icrl_ppo_lag_train_batch": [c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p],
 }
+BATCH_ARGS_BYTES = 1024      # ICRL_BATCH_ARGS_BYTES
 RESTYPES = {"icrl_cn_train_work_floats": ctypes.c_size_t, "icrl_last_error": ctypes.c_char_p, "icrl_clear_error": None}
 
 

@@ -154,6 +154,13 @@ class ConstraintNet:
         """ref: constraint_net.py:137-229.  `perms` ([iterations, min(Nn, Ne)], minibatch mode only) replaces the
         np.random.permutation draws of get() (:300-316); by default they are drawn from numpy's global generator, which is
         afterwards left where the reference would have left it (it stops drawing once an iteration early-stops)."""
+        job = self._train_begin(iterations, nominal_obs, nominal_acs, episode_lengths, obs_mean, obs_var, current_progress_remaining, perms)
+        self._train_launch(job)
+        return self._train_end(job)
+
+    # train() in three pieces (several runs sharing a GPU put their launches into one grid: icrl_amd/seed_batch.py)
+    def _train_begin(self, iterations, nominal_obs, nominal_acs, episode_lengths, obs_mean=None, obs_var=None,
+                     current_progress_remaining=1, perms=None):
         self._update_learning_rate(current_progress_remaining)
         self.current_obs_mean, self.current_obs_var = obs_mean, obs_var
         self._refresh_consts()
@@ -179,26 +186,37 @@ class ConstraintNet:
         hp = CnHyperT(iters, int(self.importance_sampling), int(self.per_step_importance_sampling), int(bool(self.train_gail_lambda)),
                       float(self.regularizer_coeff), float(self.eps), float(self.target_kl_old_new), float(self.target_kl_new_old),
                       float(self.lr), 0.9, 0.999, float(self.optimizer_kwargs.get("eps", 1e-8)))
-        s = self.struct()
-        rng_state = None
-        if self.batch_size is None:
-            _lib.check(L.icrl_cn_train(_lib.byref(s), p(self.exp_avg), p(self.exp_avg_sq), p(t_dev), p(nominal), p(expert),
-                                       nominal.shape[0], expert.shape[0], p(d_off), p(d_rowep), len(lengths), _lib.byref(hp),
-                                       p(work), p(metrics), _lib.current_stream()), "icrl_cn_train")
-        else:
+        job = dict(s=self.struct(), hp=hp, nominal=nominal, expert=expert, d_off=d_off, d_rowep=d_rowep, n_ep=len(lengths), work=work,
+                   metrics=metrics, t_dev=t_dev, iters=iters, rng_state=None, d_perms=None)
+        if self.batch_size is not None:
             size = min(nominal.shape[0], expert.shape[0])
             if perms is None:
-                rng_state = np.random.get_state()
+                job["rng_state"] = np.random.get_state()
                 perms = np.stack([np.random.permutation(size) for _ in range(max(iters, 1))])
-            d_perms = torch.as_tensor(np.asarray(perms)[:max(iters, 1)].astype(np.int32), device=dev).contiguous()
-            assert d_perms.shape == (max(iters, 1), size), "perms must be [iterations, min(n_nominal, n_expert)]"
-            _lib.check(L.icrl_cn_train_minibatch(_lib.byref(s), p(self.exp_avg), p(self.exp_avg_sq), p(t_dev), p(nominal), p(expert),
-                                                 nominal.shape[0], expert.shape[0], p(d_off), p(d_rowep), len(lengths),
-                                                 _lib.byref(hp), p(d_perms), int(self.batch_size), p(work), p(metrics),
+            if torch.is_tensor(perms):
+                job["d_perms"] = perms[:max(iters, 1)].to(device=dev, dtype=torch.int32).contiguous()
+            else:
+                job["d_perms"] = torch.as_tensor(np.asarray(perms)[:max(iters, 1)].astype(np.int32), device=dev).contiguous()
+            assert job["d_perms"].shape == (max(iters, 1), size), "perms must be [iterations, min(n_nominal, n_expert)]"
+        return job
+
+    def _train_launch(self, job):
+        L, nominal, expert = _lib.lib(), job["nominal"], job["expert"]
+        if self.batch_size is None:
+            _lib.check(L.icrl_cn_train(_lib.byref(job["s"]), p(self.exp_avg), p(self.exp_avg_sq), p(job["t_dev"]), p(nominal), p(expert),
+                                       nominal.shape[0], expert.shape[0], p(job["d_off"]), p(job["d_rowep"]), job["n_ep"], _lib.byref(job["hp"]),
+                                       p(job["work"]), p(job["metrics"]), _lib.current_stream()), "icrl_cn_train")
+        else:
+            _lib.check(L.icrl_cn_train_minibatch(_lib.byref(job["s"]), p(self.exp_avg), p(self.exp_avg_sq), p(job["t_dev"]), p(nominal), p(expert),
+                                                 nominal.shape[0], expert.shape[0], p(job["d_off"]), p(job["d_rowep"]), job["n_ep"],
+                                                 _lib.byref(job["hp"]), p(job["d_perms"]), int(self.batch_size), p(job["work"]), p(job["metrics"]),
                                                  _lib.current_stream()), "icrl_cn_train_minibatch")
+
+    def _train_end(self, job, metrics_host=None, adam_step_host=None):
+        iters, nominal, expert, rng_state = job["iters"], job["nominal"], job["expert"], job["rng_state"]
         self.prepare()
-        m = metrics.cpu().numpy()          # the only host sync of the backward step
-        self.adam_step = int(t_dev.item())
+        m = job["metrics"].cpu().numpy() if metrics_host is None else np.asarray(metrics_host, np.float32)          # the only host sync of the backward step
+        self.adam_step = int(job["t_dev"].item()) if adam_step_host is None else int(adam_step_host)
         stopped = np.nonzero(m[:iters, 0] != 0)[0]
         early_stop_itr = int(stopped[0]) if len(stopped) else iters
         if rng_state is not None and early_stop_itr < iters:      # rewind to the reference's consumption of the stream

@@ -120,7 +120,7 @@ __device__ __forceinline__ void cn_block_forward(const CnDims& d, float* sm, con
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(CN_TH) cn_forward_kernel(CnTrainArgs a, int itr) {
+__device__ __forceinline__ void cn_forward_body(const CnTrainArgs& a, int itr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   if (a.scal[SC_STOPPED] != 0.f) return;
   const CnDims& d = a.d;
@@ -170,7 +170,7 @@ __device__ __forceinline__ float wave_prod(float v) {
   return v;
 }
 
-__global__ void __launch_bounds__(1024) cn_finalize_kernel(CnTrainArgs a, int itr) {
+__device__ __forceinline__ void cn_finalize_body(const CnTrainArgs& a, int itr) {
   __shared__ float red[2][CN_NPART];
   if (a.scal[SC_STOPPED] != 0.f) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -353,7 +353,7 @@ __global__ void __launch_bounds__(64) cn_mb_finalize_kernel(CnTrainArgs a, int i
 }
 
 template <bool MB>
-__global__ void __launch_bounds__(CN_TH) cn_backward_kernel(CnTrainArgs a, int itr) {
+__device__ __forceinline__ void cn_backward_body(const CnTrainArgs& a, int itr) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   if (a.scal[SC_STOPPED] != 0.f) return;
   const CnDims& d = a.d;
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(CN_TH) cn_backward_kernel(CnTrainArgs a, int i
   }
 }
 
-__global__ void __launch_bounds__(256) cn_adam_kernel(CnTrainArgs a, int itr, int upd) {
+__device__ __forceinline__ void cn_adam_body(const CnTrainArgs& a, int itr, int upd) {
   if (a.scal[SC_STOPPED] != 0.f) return;
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int nb = a.nb_n + a.nb_e;
@@ -456,8 +456,41 @@ __global__ void __launch_bounds__(256) cn_adam_kernel(CnTrainArgs a, int itr, in
   if (p == 0) { a.metrics[(size_t)itr * ICRL_CN_METRICS + 17] = 1.f; a.scal[SC_ITER] = (float)(upd + 1); }
 }
 
+// ---- the kernels proper: single-run forms (arguments by value) and batched forms (several independent constraint nets of one
+// shape in one launch: run = blockIdx.y, argument blocks in device memory; grids are sized for the largest run, surplus workgroups
+// of smaller runs leave at once)
+__global__ void __launch_bounds__(CN_TH) cn_forward_kernel(CnTrainArgs a, int itr) { cn_forward_body(a, itr); }
+__global__ void __launch_bounds__(1024) cn_finalize_kernel(CnTrainArgs a, int itr) { cn_finalize_body(a, itr); }
+template <bool MB>
+__global__ void __launch_bounds__(CN_TH) cn_backward_kernel(CnTrainArgs a, int itr) { cn_backward_body<MB>(a, itr); }
+__global__ void __launch_bounds__(256) cn_adam_kernel(CnTrainArgs a, int itr, int upd) { cn_adam_body(a, itr, upd); }
 __global__ void cn_commit_kernel(CnTrainArgs a) {
   // advance the optimiser step counter by the number of executed updates
+  if (threadIdx.x == 0 && blockIdx.x == 0) a.adam_t[0] += (int)a.scal[SC_ITER];
+}
+
+__global__ void __launch_bounds__(CN_TH) cn_forward_batch_kernel(const CnTrainArgs* __restrict__ runs, int itr) {
+  const CnTrainArgs a = runs[blockIdx.y];
+  if ((int)blockIdx.x >= a.nb_n + a.nb_e || itr >= a.hp.iterations) return;
+  cn_forward_body(a, itr);
+}
+__global__ void __launch_bounds__(1024) cn_finalize_batch_kernel(const CnTrainArgs* __restrict__ runs, int itr) {
+  const CnTrainArgs a = runs[blockIdx.y];
+  if (itr >= a.hp.iterations) return;
+  cn_finalize_body(a, itr);
+}
+__global__ void __launch_bounds__(CN_TH) cn_backward_batch_kernel(const CnTrainArgs* __restrict__ runs, int itr) {
+  const CnTrainArgs a = runs[blockIdx.y];
+  if ((int)blockIdx.x >= a.nb_n + a.nb_e || itr >= a.hp.iterations) return;
+  cn_backward_body<false>(a, itr);
+}
+__global__ void __launch_bounds__(256) cn_adam_batch_kernel(const CnTrainArgs* __restrict__ runs, int itr) {
+  const CnTrainArgs a = runs[blockIdx.y];
+  if (itr >= a.hp.iterations) return;
+  cn_adam_body(a, itr, itr);
+}
+__global__ void cn_commit_batch_kernel(const CnTrainArgs* __restrict__ runs) {
+  const CnTrainArgs a = runs[blockIdx.y];
   if (threadIdx.x == 0 && blockIdx.x == 0) a.adam_t[0] += (int)a.scal[SC_ITER];
 }
 
@@ -514,19 +547,19 @@ extern "C" int icrl_cn_prepare(const icrl_costnet_t* cn, const double* obs, cons
   return (int)hipGetLastError();
 }
 
-extern "C" int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
-                             const float* nominal, const float* expert, int Nn, int Ne, const int32_t* ep_offsets,
-                             const int32_t* row_episode, int n_ep, const icrl_cn_hyper_t* hp, float* work, float* metrics,
-                             void* stream) {
+// argument checks + argument block of one full-batch train() call; *lds = dynamic LDS bytes of the forward / backward kernels
+static int make_cn_train_args(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const float* nominal,
+                              const float* expert, int Nn, int Ne, const int32_t* ep_offsets, const int32_t* row_episode, int n_ep,
+                              const icrl_cn_hyper_t* hp, float* work, float* metrics, CnTrainArgs& a, size_t* lds_out) {
   if (Nn <= 0 || Ne <= 0 || n_ep <= 0 || hp->iterations < 0 || cn->n_hidden < 1 || cn->n_hidden > 2)
     return fail("icrl_cn_train: needs nominal rows (%d), expert rows (%d), episodes (%d) > 0, iterations (%d) >= 0 and 1 or 2 hidden layers (%d)",
                 Nn, Ne, n_ep, hp->iterations, cn->n_hidden);
-  CnTrainArgs a;
   a.d = make_cn_dims(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
   if (a.d.n_params != cn->n_params)
     return fail("constraint net: n_params = %d but in_dim %d / hidden (%d, %d) x %d layers need %d", cn->n_params, cn->in_dim, cn->h1, cn->h2, cn->n_hidden, a.d.n_params);
   const size_t lds = (size_t)a.d.total * sizeof(float);
   if (lds > 160 * 1024) return fail("constraint net update: %zu B of LDS needed for in_dim %d / hidden (%d, %d), 160 KB available", lds, cn->in_dim, cn->h1, cn->h2);
+  *lds_out = lds;
   a.params = cn->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.nominal = nominal; a.expert = expert; a.Nn = Nn; a.Ne = Ne; a.n_ep = n_ep;
   a.nb_n = (Nn + CN_ROWS - 1) / CN_ROWS; a.nb_e = (Ne + CN_ROWS - 1) / CN_ROWS;
@@ -536,6 +569,18 @@ extern "C" int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* ex
   a.start_preds = work + offs[0]; a.preds_n = work + offs[1]; a.preds_e = work + offs[2]; a.part = work + offs[3];
   a.ep_prod = work + offs[4]; a.ep_slog = work + offs[5]; a.normed = work + offs[6]; a.scal = work + offs[7];
   a.gpart = work + offs[8]; a.metrics = metrics; a.mb_idx = nullptr; a.mb_n = 0;
+  return 0;
+}
+
+extern "C" int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
+                             const float* nominal, const float* expert, int Nn, int Ne, const int32_t* ep_offsets,
+                             const int32_t* row_episode, int n_ep, const icrl_cn_hyper_t* hp, float* work, float* metrics,
+                             void* stream) {
+  CnTrainArgs a;
+  size_t lds = 0;
+  const int bad = make_cn_train_args(cn, exp_avg, exp_avg_sq, adam_step, nominal, expert, Nn, Ne, ep_offsets, row_episode, n_ep, hp, work,
+                                     metrics, a, &lds);
+  if (bad) return bad;
   hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(a.scal, 0, SC_COUNT * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
@@ -555,6 +600,50 @@ extern "C" int icrl_cn_train(const icrl_costnet_t* cn, float* exp_avg, float* ex
     hipLaunchKernelGGL(cn_adam_kernel, dim3((cn->n_params + 255) / 256), dim3(256), 0, s, a, itr, itr);
   }
   hipLaunchKernelGGL(cn_commit_kernel, dim3(1), dim3(64), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_cn_train_batch(int n_runs, const icrl_cn_train_job_t* jobs, void* args_ws, long long args_ws_bytes, void* stream) {
+  static_assert(sizeof(CnTrainArgs) <= ICRL_BATCH_ARGS_BYTES, "ICRL_BATCH_ARGS_BYTES");
+  if (n_runs < 1 || n_runs > 65535) return fail("icrl_cn_train_batch: n_runs = %d (1..65535)", n_runs);
+  if (args_ws == nullptr || args_ws_bytes < (long long)n_runs * ICRL_BATCH_ARGS_BYTES)
+    return fail("icrl_cn_train_batch: args_ws holds %lld B, %d runs need %lld", args_ws_bytes, n_runs, (long long)n_runs * ICRL_BATCH_ARGS_BYTES);
+  hipStream_t s = (hipStream_t)stream;
+  CnTrainArgs* d_args = (CnTrainArgs*)args_ws;
+  size_t lds0 = 0;
+  int nb_max = 0, iters_max = 0, np0 = 0;
+  for (int r = 0; r < n_runs; ++r) {
+    const icrl_cn_train_job_t& j = jobs[r];
+    CnTrainArgs a;
+    size_t lds = 0;
+    const int bad = make_cn_train_args(j.cn, j.exp_avg, j.exp_avg_sq, j.adam_step, j.nominal, j.expert, j.Nn, j.Ne, j.ep_offsets,
+                                       j.row_episode, j.n_ep, j.hp, j.work, j.metrics, a, &lds);
+    if (bad) return bad;
+    if (r == 0) { lds0 = lds; np0 = a.d.n_params; }
+    else if (lds != lds0 || a.d.n_params != np0)
+      return fail("icrl_cn_train_batch: run %d's network shape differs from run 0's (the runs of a batch share one grid)", r);
+    nb_max = a.nb_n + a.nb_e > nb_max ? a.nb_n + a.nb_e : nb_max;
+    iters_max = j.hp->iterations > iters_max ? j.hp->iterations : iters_max;
+    hipError_t e = hipMemsetAsync(a.scal, 0, SC_COUNT * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    if (j.hp->iterations > 0) {
+      e = hipMemsetAsync(j.metrics, 0, (size_t)j.hp->iterations * ICRL_CN_METRICS * sizeof(float), s);
+      if (e != hipSuccess) return (int)e;
+    }
+    const int pe = put_args(a, d_args + r, s);
+    if (pe) return pe;
+  }
+  hipError_t e = hipFuncSetAttribute((const void*)cn_forward_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+  if (e != hipSuccess) return (int)e;
+  e = hipFuncSetAttribute((const void*)cn_backward_batch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds0);
+  if (e != hipSuccess) return (int)e;
+  for (int itr = 0; itr < iters_max; ++itr) {
+    hipLaunchKernelGGL(cn_forward_batch_kernel, dim3(nb_max, n_runs), dim3(CN_TH), lds0, s, d_args, itr);
+    hipLaunchKernelGGL(cn_finalize_batch_kernel, dim3(1, n_runs), dim3(1024), 0, s, d_args, itr);
+    hipLaunchKernelGGL(cn_backward_batch_kernel, dim3(nb_max, n_runs), dim3(CN_TH), lds0, s, d_args, itr);
+    hipLaunchKernelGGL(cn_adam_batch_kernel, dim3((np0 + 255) / 256, n_runs), dim3(256), 0, s, d_args, itr);
+  }
+  hipLaunchKernelGGL(cn_commit_batch_kernel, dim3(1, n_runs), dim3(64), 0, s, d_args);
   return (int)hipGetLastError();
 }
 

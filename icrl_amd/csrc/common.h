@@ -13,8 +13,28 @@ constexpr int MAX_ACT = 16;    // act_dim limit (HC 6, Ant 8)
 constexpr int MAX_H = 64;      // hidden width limit of policy / cost nets
 constexpr int MAX_CN_IN = 160; // cost-net input limit (Ant: 121)
 
+// gae.hip: the batched dual-GAE launch behind icrl_rollout_collect_batch (jobs' buffers / agent state name the arrays)
+int icrl_gae_dual_batch_impl(int n_runs, const icrl_rollout_job_t* jobs, double reward_gamma, double reward_gae_lambda, double cost_gamma,
+                             double cost_gae_lambda, void* args_ws, void* stream);
+
 // argument rejection: formats the reason into the calling thread's icrl_last_error() text, returns hipErrorInvalidValue
 int fail(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// argument blocks of a BATCHED launch (several independent runs in one grid, run = blockIdx.y): the kernels read block
+// blockIdx.y of an array in device memory.  Each block gets there through one tiny launch that carries it by value — stream-ordered
+// like everything else, no host staging buffer whose lifetime would have to outlive the call, no hidden synchronisation.
+// ---------------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ void put_args_kernel(T v, T* dst) {
+  if (threadIdx.x == 0) *dst = v;
+}
+template <class T>
+inline int put_args(const T& v, T* dst, hipStream_t s) {
+  static_assert(sizeof(T) <= 3584, "argument block must fit the kernel-argument segment");
+  hipLaunchKernelGGL(put_args_kernel<T>, dim3(1), dim3(64), 0, s, v, dst);
+  return (int)hipGetLastError();
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // counter-based random stream of the synthetic env (spec: oracle/synth_env.py u24())

@@ -25,9 +25,8 @@
 
 #include <atomic>
 
-#include "../../include/icrl_hip.h"
+#include "common.h"
 
-namespace icrl { int fail(const char* fmt, ...) __attribute__((format(printf, 1, 2))); }   // errors.hip
 using icrl::fail;
 
 namespace {
@@ -205,7 +204,7 @@ __global__ void __launch_bounds__(64 * W * G) gae_dual_kernel(GaeArgs a) {
 constexpr int SPLIT_W = 8;         // waves per workgroup
 constexpr int SPLIT_CMAX = 16;     // workgroups per column tile
 
-__global__ void __launch_bounds__(64 * SPLIT_W) gae_dual_split_kernel(GaeArgs a, int C, unsigned tag, double* maps, unsigned* flags) {
+__device__ __forceinline__ void gae_dual_split_body(const GaeArgs& a, int C, unsigned tag, double* maps, unsigned* flags) {
   constexpr int W = SPLIT_W, U = U_DEFAULT;
   __shared__ double own[W][4][64];
   __shared__ double ext[SPLIT_CMAX - 1][4][64];
@@ -259,6 +258,21 @@ __global__ void __launch_bounds__(64 * SPLIT_W) gae_dual_split_kernel(GaeArgs a,
   s.Ar = Ar;
   s.Ac = Ac;
   if (t0 < t1) walk_chunk<true, U, false>(a, n, live, t0, t1, s);
+}
+
+__global__ void __launch_bounds__(64 * SPLIT_W) gae_dual_split_kernel(GaeArgs a, int C, unsigned tag, double* maps, unsigned* flags) {
+  gae_dual_split_body(a, C, tag, maps, flags);
+}
+
+// several independent [T,N] rollouts of one shape in ONE launch: grid (tiles * C, n_runs), run = blockIdx.y
+struct GaeRun {
+  GaeArgs a;
+  double* maps;
+  unsigned* flags;
+};
+__global__ void __launch_bounds__(64 * SPLIT_W) gae_dual_split_batch_kernel(const GaeRun* __restrict__ runs, int C, unsigned tag) {
+  const GaeRun r = runs[blockIdx.y];
+  gae_dual_split_body(r.a, C, tag, r.maps, r.flags);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -371,6 +385,14 @@ __global__ void __launch_bounds__(64 * G) gae_dual_x4_kernel(GaeArgs a) {
 
 }  // namespace
 
+// every split launch tags its workspace flags with a process-wide counter value, so nothing is cleared between launches
+static unsigned next_split_tag() {
+  static std::atomic<unsigned> launches{0};
+  unsigned tag = ++launches;
+  if (tag == 0) tag = ++launches;                  // 0 = the workspace's initial contents
+  return tag;
+}
+
 extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const float* reward_values,
                                 const float* cost_values, const float* dones, const float* last_v_r,
                                 const float* last_v_c, const uint8_t* last_dones, float* adv_r, float* adv_c,
@@ -401,9 +423,7 @@ extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const 
     while (C > 1 && tiles * C > wg_cap) --C;
     const long long need = (long long)tiles * C * (256 * 8 + 4);
     if (C >= 2 && ws_bytes >= need) {
-      static std::atomic<unsigned> launches{0};
-      unsigned tag = ++launches;
-      if (tag == 0) tag = ++launches;                  // 0 = the workspace's initial contents
+      const unsigned tag = next_split_tag();
       double* maps = (double*)ws;
       unsigned* flags = (unsigned*)(maps + (size_t)tiles * C * 256);
       hipLaunchKernelGGL(gae_dual_split_kernel, dim3(tiles * C), dim3(64 * SPLIT_W), 0, s, a, C, tag, maps, flags);
@@ -458,3 +478,64 @@ extern "C" int icrl_gae_dual(const float* rewards, const float* costs, const flo
 }
 
 extern "C" int icrl_abi_version(void) { return 100; }
+
+// icrl_gae_dual_ws for n_runs rollouts of one shape in ONE launch (the loop-size launches of several runs sharing a GPU): the
+// two-level scan over workgroups, every run with its own workspace.  Shapes the split scan does not serve (> 128 column tiles, T too
+// short to split, a run without workspace) are issued as n_runs single launches.
+extern "C" int icrl_gae_dual_batch(int n_runs, const icrl_gae_job_t* jobs, int T, int N, double reward_gamma, double reward_gae_lambda,
+                                   double cost_gamma, double cost_gae_lambda, void* args_ws, long long args_ws_bytes, void* stream) {
+  static_assert(sizeof(GaeRun) <= ICRL_BATCH_ARGS_BYTES, "ICRL_BATCH_ARGS_BYTES");
+  if (n_runs < 1 || n_runs > 65535) return fail("icrl_gae_dual_batch: n_runs = %d (1..65535)", n_runs);
+  if (T <= 0 || N <= 0) return fail("icrl_gae_dual_batch: T = %d, N = %d", T, N);
+  hipStream_t s = (hipStream_t)stream;
+  const int tiles = (N + 63) / 64;
+  int C = T / (SPLIT_W * U_DEFAULT);
+  if (C > SPLIT_CMAX) C = SPLIT_CMAX;
+  const int wg_cap = tiles > 16 ? 256 : 32;          // the single-launch heuristic of icrl_gae_dual_ws (same C, same results)
+  while (C > 1 && tiles * C > wg_cap) --C;
+  const long long need = (long long)tiles * C * (256 * 8 + 4);
+  bool split = tiles * 2 <= 256 && C >= 2 && args_ws != nullptr && args_ws_bytes >= (long long)n_runs * ICRL_BATCH_ARGS_BYTES;
+  for (int r = 0; r < n_runs && split; ++r) split = jobs[r].ws != nullptr && jobs[r].ws_bytes >= need;
+  if (!split) {
+    for (int r = 0; r < n_runs; ++r) {
+      const icrl_gae_job_t& j = jobs[r];
+      const int e = icrl_gae_dual_ws(j.rewards, j.costs, j.reward_values, j.cost_values, j.dones, j.last_v_r, j.last_v_c, j.last_dones,
+                                     j.adv_r, j.adv_c, j.ret_r, j.ret_c, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, 0,
+                                     j.ws, j.ws_bytes, stream);
+      if (e) return e;
+    }
+    return 0;
+  }
+  GaeRun* d_runs = (GaeRun*)args_ws;
+  for (int r = 0; r < n_runs; ++r) {
+    const icrl_gae_job_t& j = jobs[r];
+    GaeRun g;
+    g.a = GaeArgs{j.rewards, j.costs, j.reward_values, j.cost_values, j.dones, j.last_v_r, j.last_v_c, j.last_dones,
+                  j.adv_r, j.adv_c, j.ret_r, j.ret_c, T, N,
+                  (float)reward_gamma, (float)(reward_gamma * reward_gae_lambda), (float)cost_gamma, (float)(cost_gamma * cost_gae_lambda)};
+    g.maps = (double*)j.ws;
+    g.flags = (unsigned*)(g.maps + (size_t)tiles * C * 256);
+    const int e = icrl::put_args(g, d_runs + r, s);
+    if (e) return e;
+  }
+  hipLaunchKernelGGL(gae_dual_split_batch_kernel, dim3(tiles * C, n_runs), dim3(64 * SPLIT_W), 0, s, d_runs, C, next_split_tag());
+  return (int)hipGetLastError();
+}
+
+namespace icrl {
+int icrl_gae_dual_batch_impl(int n_runs, const icrl_rollout_job_t* jobs, double reward_gamma, double reward_gae_lambda, double cost_gamma,
+                             double cost_gae_lambda, void* args_ws, void* stream) {
+  icrl_gae_job_t stack_jobs[64];
+  icrl_gae_job_t* gj = n_runs <= 64 ? stack_jobs : new icrl_gae_job_t[n_runs];
+  for (int r = 0; r < n_runs; ++r) {
+    const icrl_buffer_t* b = jobs[r].buf;
+    const icrl_agent_t* ag = jobs[r].ag;
+    gj[r] = icrl_gae_job_t{b->rewards, b->costs, b->reward_values, b->cost_values, b->dones, ag->last_v_r, ag->last_v_c, ag->last_dones,
+                           b->reward_advantages, b->cost_advantages, b->reward_returns, b->cost_returns, b->gae_ws, b->gae_ws_bytes};
+  }
+  const int e = icrl_gae_dual_batch(n_runs, gj, jobs[0].buf->T, jobs[0].buf->N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda,
+                                    args_ws, (long long)n_runs * ICRL_BATCH_ARGS_BYTES, stream);
+  if (gj != stack_jobs) delete[] gj;
+  return e;
+}
+}  // namespace icrl

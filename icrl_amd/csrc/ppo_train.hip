@@ -912,65 +912,78 @@ static int launch_train(const TrainArgs& a, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
-                                  const icrl_buffer_t* buf, const int32_t* perms, const float* nu,
-                                  const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, void* stream) {
+// argument checks + the pre-kernels (granule / statistics reset, permutation offsets, schedule tables) of ONE run; fills `a` and
+// reports which persistent kernel runs it: 0 wave pairs, 1 row-owning waves, 2 row-owning waves with two workgroups per network,
+// 3 column-split tiles.  < 0: refused (return value of fail()) or a HIP error, in *err.
+static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
+                         const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws,
+                         hipStream_t s, TrainArgs& a, int* err) {
+  auto bad = [&](int e) { *err = e; return -1; };
   if (pol->h1 != HD || pol->h2 != HD)
-    return fail("icrl_ppo_lag_train: hidden widths (%d, %d); the update kernels are built for %d x %d (the reference's default net_arch)", pol->h1, pol->h2, HD, HD);
+    return bad(fail("icrl_ppo_lag_train: hidden widths (%d, %d); the update kernels are built for %d x %d (the reference's default net_arch)", pol->h1, pol->h2, HD, HD));
   if (pol->obs_dim < 1 || pol->obs_dim > 128 || pol->act_dim < 1 || pol->act_dim > 16)
-    return fail("icrl_ppo_lag_train: obs_dim %d (1..128) / act_dim %d (1..16)", pol->obs_dim, pol->act_dim);
+    return bad(fail("icrl_ppo_lag_train: obs_dim %d (1..128) / act_dim %d (1..16)", pol->obs_dim, pol->act_dim));
   if (hp->batch_size < 2 || hp->batch_size > MAXB || hp->n_epochs < 1)
-    return fail("icrl_ppo_lag_train: batch_size %d (2..%d: one minibatch = at most two 64-row chunks of one workgroup), n_epochs %d (>= 1)", hp->batch_size, MAXB, hp->n_epochs);
+    return bad(fail("icrl_ppo_lag_train: batch_size %d (2..%d: one minibatch = at most two 64-row chunks of one workgroup), n_epochs %d (>= 1)", hp->batch_size, MAXB, hp->n_epochs));
   if (buf->obs_dim != pol->obs_dim || buf->T < 1)
-    return fail("icrl_ppo_lag_train: buffer obs_dim %d vs policy %d, T = %d", buf->obs_dim, pol->obs_dim, buf->T);
+    return bad(fail("icrl_ppo_lag_train: buffer obs_dim %d vs policy %d, T = %d", buf->obs_dim, pol->obs_dim, buf->T));
   if ((long long)buf->T * buf->N >= (1ll << 31) || (long long)buf->T * buf->N * (pol->obs_dim > 16 ? pol->obs_dim : 16) >= (1ll << 30))
-    return fail("icrl_ppo_lag_train: %d x %d transitions x obs_dim %d overflow the kernel's 32-bit element offsets (limit 2^30 floats per plane)", buf->T, buf->N, pol->obs_dim);
-  TrainArgs a;
+    return bad(fail("icrl_ppo_lag_train: %d x %d transitions x obs_dim %d overflow the kernel's 32-bit element offsets (limit 2^30 floats per plane)", buf->T, buf->N, pol->obs_dim));
+  if (pol->discrete && buf->act_store != 1) return bad(fail("icrl_ppo_lag_train: discrete policy needs act_store = 1 (action index), got %d", buf->act_store));
   a.L = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);
   a.params = pol->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.buf = *buf; a.perms = perms; a.nu = nu; a.hp = *hp; a.stats = stats; a.xch = (u64*)sync_ws;
   a.t_magic = buf->T == 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned long long)buf->T);
   a.plan_steps = nullptr; a.plan_chunks = nullptr; a.n_steps = 0; a.gx = nullptr;
-  hipStream_t s = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(sync_ws, 0, 512, s);      // granule slots: 2 step parities x (3 roles x 8 waves, padded to 32) x 8 B
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) return bad((int)e);
   e = hipMemsetAsync(stats, 0, (32 + hp->n_epochs) * sizeof(float), s);
-  if (e != hipSuccess) return (int)e;
+  if (e != hipSuccess) return bad((int)e);
   const int nt1 = (pol->obs_dim + 15) / 16;
   // default: wave pairs (two waves per SIMD, 6 barriers per step); hp._pad & 4: row-owning waves (one wave per SIMD, 3 barriers
   // per step; 5 when obs > 64); hp._pad & 2: the column-split tiles kernel
-  if (nt1 <= 8 && !(hp->_pad & 2)) {
-    const int n_total = buf->T * buf->N;
-    const int n_mb = (n_total + hp->batch_size - 1) / hp->batch_size;
-    const long long n_steps = (long long)hp->n_epochs * n_mb;
-    if (n_steps >= (1ll << 21)) return fail("icrl_ppo_lag_train: %lld optimiser steps per call, limit 2^21", n_steps);      // epoch index lives in the upper bits of nb_flags
-    PlanStep* steps = reinterpret_cast<PlanStep*>((char*)sync_ws + 512);
-    PlanChunk* chunks = reinterpret_cast<PlanChunk*>(steps + n_steps + 2);
-    a.plan_steps = steps; a.plan_chunks = chunks; a.n_steps = (int)n_steps;
-    {
-      int* offs = reinterpret_cast<int*>((char*)sync_ws + 768 + 32 * (size_t)n_steps);       // after the plan tables
-      const long long n = (long long)hp->n_epochs * n_total;
-      hipLaunchKernelGGL(ppo_perm_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perms, n, buf->T, buf->N, offs);
-      a.perms = offs;
-    }
-    // obs <= 64: wave pairs; wider (AntWall 113: dz1^T must share h2^T's LDS, two chunks per minibatch) the row-owning waves,
-    // with TWO workgroups per network when a minibatch has two chunks (each computes one, partial gradients exchanged;
-    // hp._pad & 8 keeps one workgroup per network)
-    const bool rows = (hp->_pad & 4) || nt1 > 4;
-    const bool split = rows && hp->batch_size > RB && !(hp->_pad & 8);
-    hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
-                       n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks, (int)split);
-    if (split) {
-      const size_t off = (768 + 32 * (size_t)n_steps + 4 * (size_t)hp->n_epochs * n_total + 255) / 256 * 256;      // behind the permutation offsets
-      a.gx = reinterpret_cast<u64*>((char*)sync_ws + off);
-      e = hipMemsetAsync(a.gx, 0, ICRL_PPO_SPLIT_BYTES, s);
-      if (e != hipSuccess) return (int)e;
-    }
-    if (rows) return launch_train_rows(a, nt1, pol->discrete != 0, split, s);
-    return launch_train_pairs(a, nt1, pol->discrete != 0, s);
+  if (nt1 > 8 || (hp->_pad & 2)) return 3;
+  const int n_total = buf->T * buf->N;
+  const int n_mb = (n_total + hp->batch_size - 1) / hp->batch_size;
+  const long long n_steps = (long long)hp->n_epochs * n_mb;
+  if (n_steps >= (1ll << 21)) return bad(fail("icrl_ppo_lag_train: %lld optimiser steps per call, limit 2^21", n_steps));      // epoch index lives in the upper bits of nb_flags
+  PlanStep* steps = reinterpret_cast<PlanStep*>((char*)sync_ws + 512);
+  PlanChunk* chunks = reinterpret_cast<PlanChunk*>(steps + n_steps + 2);
+  a.plan_steps = steps; a.plan_chunks = chunks; a.n_steps = (int)n_steps;
+  {
+    int* offs = reinterpret_cast<int*>((char*)sync_ws + 768 + 32 * (size_t)n_steps);       // after the plan tables
+    const long long n = (long long)hp->n_epochs * n_total;
+    hipLaunchKernelGGL(ppo_perm_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perms, n, buf->T, buf->N, offs);
+    a.perms = offs;
   }
+  // obs <= 64: wave pairs; wider (AntWall 113: dz1^T must share h2^T's LDS, two chunks per minibatch) the row-owning waves,
+  // with TWO workgroups per network when a minibatch has two chunks (each computes one, partial gradients exchanged;
+  // hp._pad & 8 keeps one workgroup per network)
+  const bool rows = (hp->_pad & 4) || nt1 > 4;
+  const bool split = rows && hp->batch_size > RB && !(hp->_pad & 8);
+  hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
+                     n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks, (int)split);
+  if (split) {
+    const size_t off = (768 + 32 * (size_t)n_steps + 4 * (size_t)hp->n_epochs * n_total + 255) / 256 * 256;      // behind the permutation offsets
+    a.gx = reinterpret_cast<u64*>((char*)sync_ws + off);
+    e = hipMemsetAsync(a.gx, 0, ICRL_PPO_SPLIT_BYTES, s);
+    if (e != hipSuccess) return bad((int)e);
+  }
+  return rows ? (split ? 2 : 1) : 0;
+}
+
+extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
+                                  const icrl_buffer_t* buf, const int32_t* perms, const float* nu,
+                                  const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, void* stream) {
+  TrainArgs a;
+  hipStream_t s = (hipStream_t)stream;
+  int err = 0;
+  const int kind = prepare_train(pol, exp_avg, exp_avg_sq, adam_step, buf, perms, nu, hp, stats, sync_ws, s, a, &err);
+  if (kind < 0) return err;
+  const int nt1 = (pol->obs_dim + 15) / 16;
+  if (kind == 0) return launch_train_pairs(a, nt1, pol->discrete != 0, s);
+  if (kind <= 2) return launch_train_rows(a, nt1, pol->discrete != 0, kind == 2, s);
   if (pol->discrete) {
-    if (buf->act_store != 1) return fail("icrl_ppo_lag_train: discrete policy needs act_store = 1 (action index), got %d", buf->act_store);
     if (nt1 <= 2) return launch_train<2, true>(a, s);
     if (nt1 <= 4) return launch_train<4, true>(a, s);
     return launch_train<8, true>(a, s);
@@ -978,4 +991,35 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
   if (nt1 <= 2) return launch_train<2, false>(a, s);
   if (nt1 <= 4) return launch_train<4, false>(a, s);
   return launch_train<8, false>(a, s);
+}
+
+extern "C" int icrl_ppo_lag_train_batch(int n_runs, const icrl_ppo_train_job_t* jobs, void* args_ws, long long args_ws_bytes,
+                                        void* stream) {
+  if (n_runs < 1 || n_runs > 65535) return fail("icrl_ppo_lag_train_batch: n_runs = %d (1..65535)", n_runs);
+  if (args_ws == nullptr || args_ws_bytes < (long long)n_runs * (long long)sizeof(TrainArgs))
+    return fail("icrl_ppo_lag_train_batch: args_ws holds %lld B, %d runs need %lld (ICRL_BATCH_ARGS_BYTES each)", args_ws_bytes, n_runs,
+                (long long)n_runs * (long long)sizeof(TrainArgs));
+  static_assert(sizeof(TrainArgs) <= ICRL_BATCH_ARGS_BYTES, "ICRL_BATCH_ARGS_BYTES");
+  hipStream_t s = (hipStream_t)stream;
+  TrainArgs* d_args = (TrainArgs*)args_ws;
+  int kind0 = -1;
+  const icrl_ppo_train_job_t& j0 = jobs[0];
+  for (int r = 0; r < n_runs; ++r) {
+    const icrl_ppo_train_job_t& j = jobs[r];
+    if (j.pol->obs_dim != j0.pol->obs_dim || j.pol->act_dim != j0.pol->act_dim || j.pol->discrete != j0.pol->discrete ||
+        j.hp->batch_size != j0.hp->batch_size || j.hp->n_epochs != j0.hp->n_epochs || j.hp->_pad != j0.hp->_pad ||
+        j.buf->T != j0.buf->T || j.buf->N != j0.buf->N || j.buf->act_store != j0.buf->act_store)
+      return fail("icrl_ppo_lag_train_batch: run %d differs from run 0 in a shape (obs / act / discrete / batch_size / n_epochs / T / N): the runs of a batch share one grid", r);
+    TrainArgs a;
+    int err = 0;
+    const int kind = prepare_train(j.pol, j.exp_avg, j.exp_avg_sq, j.adam_step, j.buf, j.perms, j.nu, j.hp, j.stats, j.sync_ws, s, a, &err);
+    if (kind < 0) return err;
+    if (kind == 3) return fail("icrl_ppo_lag_train_batch: the column-split tiles kernel (hp->_pad & 2) has no batched form");
+    if (r == 0) kind0 = kind;
+    const int e = put_args(a, d_args + r, s);
+    if (e != 0) return e;
+  }
+  const int nt1 = (j0.pol->obs_dim + 15) / 16;
+  if (kind0 == 0) return launch_train_pairs_batch(d_args, n_runs, nt1, j0.pol->discrete != 0, s);
+  return launch_train_rows_batch(d_args, n_runs, nt1, j0.pol->discrete != 0, kind0 == 2, s);
 }

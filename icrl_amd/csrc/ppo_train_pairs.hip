@@ -86,10 +86,13 @@ struct SmemP {  // offsets in floats (multiples of 4); same images as SmemR in p
 #define FSTAMP(k)
 #endif
 
-#define KARGS() ([]() { const TrainArgs* k_ = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(k_)); return k_; }())
+// re-read a rarely used argument from the launch's argument block instead of keeping it in a register for the whole loop
+#define KARGS() ([&]() { const TrainArgs* k_ = ka; asm volatile("" : "+s"(k_)); return k_; }())
 
+// The whole update of ONE run: `a` are its arguments, `ka` points at the same block in memory (the kernel-argument segment of a
+// single-run launch, element blockIdx.y of the device-side argument array of a batched launch).
 template <int NT1, bool DISC>
-__global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
+__device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const TrainArgs* const ka) {
   using S = SmemP<NT1>;
   constexpr int SX = S::SX;
   constexpr int NW1 = NT1 / 2;          // observation column tiles of dW1 per wave
@@ -247,6 +250,8 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
   const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
   const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
   const float ent_coef = a.hp.ent_coef;
+  const float max_grad_norm = a.hp.max_grad_norm, adam_epsf = a.hp.adam_eps, adam_b2f = a.hp.adam_beta2;
+  u64* const xch = a.xch;
 
   // ---------------------------------------------------------------------------------------------------------------
   // row stream (see ppo_train_rows.hip): `perms` holds storage offsets; rows of chunk g + 1 are prefetched into registers
@@ -811,7 +816,7 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
         }
       }
       const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
-      __hip_atomic_store(a.xch + (step & 1) * 32 + role * 8 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
+      __hip_atomic_store(xch + (step & 1) * 32 + role * 8 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
       // this workgroup reads its OWN eight partials from LDS (same floats, same summation order as everybody else's view of
       // them): the role that publishes last — the policy, the critical path — does not wait for its own stores to come back
@@ -851,7 +856,7 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
       u64 v = 0;
       int spins = 0;
       bool ok = false;
-      const u64* const slot = a.xch + (step & 1) * 32 + tid;
+      const u64* const slot = xch + (step & 1) * 32 + tid;
       while (spins < (1 << 24)) {
         v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; break; }
@@ -877,15 +882,15 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
       if (fl[1] != 0.f) { status = 1; stop = true; }
     }
     total = __builtin_amdgcn_sqrtf(total);
-    float coef = a.hp.max_grad_norm * __builtin_amdgcn_rcpf(total + 1e-6f);
+    float coef = max_grad_norm * __builtin_amdgcn_rcpf(total + 1e-6f);
     coef = coef > 1.f ? 1.f : coef;
     read_stats(nb_next > 0 ? nb_next : 2);
 
     // ================= Adam (torch.optim.Adam, single-tensor form) on the wave's own elements =================
     {
       const float step_size = ps.step_size, inv_bc2_sqrt = ps.inv_bc2_sqrt;
-      const float epsf = a.hp.adam_eps;
-      const float omw1 = 1.f - w1, b2f_ = a.hp.adam_beta2;
+      const float epsf = adam_epsf;
+      const float omw1 = 1.f - w1, b2f_ = adam_b2f;
       const float cw1 = coef * w1, c2w2 = (coef * coef) * w2;
       auto adam4 = [&](const f32x4& g, f32x4& m, f32x4& v, f32x4& p) {   // stage by stage: four independent chains
         f32x4 d;
@@ -921,9 +926,9 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
   __syncthreads();
   // ---- write back weights, moments, statistics
   {
-  const TrainArgs* ka = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(ka));
-  const TrainArgs& a = *ka;
+  const TrainArgs* kw = ka;
+  asm volatile("" : "+s"(kw));
+  const TrainArgs& a = *kw;
   const PolLayout& L = a.L;
   const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
   const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
@@ -993,6 +998,33 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
     }
   }
   }
+}
+
+template <int NT1, bool DISC>
+__global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
+  ppo_train_pairs_body<NT1, DISC>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
+// several independent runs in ONE launch: grid (3, n_runs), run = blockIdx.y; the argument blocks live in device memory
+template <int NT1, bool DISC>
+__global__ void __launch_bounds__(TH8) ppo_train_pairs_batch_kernel(const TrainArgs* __restrict__ runs) {
+  const TrainArgs* const ka = runs + blockIdx.y;
+  ppo_train_pairs_body<NT1, DISC>(*ka, ka);
+}
+
+template <int NT1, bool DISC>
+static int launch_pairs_batch(const TrainArgs* d_args, int n_runs, hipStream_t s) {
+  const size_t bytes = (size_t)SmemP<NT1>::TOTAL * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_batch_kernel<NT1, DISC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((ppo_train_pairs_batch_kernel<NT1, DISC>), dim3(3, n_runs), dim3(TH8), bytes, s, d_args);
+  return (int)hipGetLastError();
+}
+
+int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int nt1, bool discrete, hipStream_t s) {
+  if (nt1 <= 2) return discrete ? launch_pairs_batch<2, true>(d_args, n_runs, s) : launch_pairs_batch<2, false>(d_args, n_runs, s);
+  if (nt1 <= 4) return discrete ? launch_pairs_batch<4, true>(d_args, n_runs, s) : launch_pairs_batch<4, false>(d_args, n_runs, s);
+  return fail("update (wave pairs): obs_dim tiles %d > 4", nt1);
 }
 
 template <int NT1, bool DISC>

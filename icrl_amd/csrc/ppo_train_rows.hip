@@ -67,15 +67,16 @@ struct SmemR {  // offsets in floats (multiples of 4)
 
 // the kernel arguments, re-read from the kernel-argument segment (scalar loads, scalar-cache resident) at the few places
 // that need pointers: keeps ~30 scalar registers out of the loop-carried state (the SGPR file spills otherwise)
-#define KARGS() ([]() { const TrainArgs* k_ = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(); asm volatile("" : "+s"(k_)); return k_; }())
+#define KARGS() ([&]() { const TrainArgs* k_ = ka; asm volatile("" : "+s"(k_)); return k_; }())
 
 // SPLIT: TWO workgroups per network (grid 6).  A minibatch of more than 64 rows is two chunks; workgroup (role, half) runs
 // the forward / backward / weight-gradient GEMMs of chunk `half` only, the two halves then exchange their partial gradients
 // (every gradient register as a {step tag | float} granule, same protocol as the norm exchange) and each forms
 // own + partner — float addition is commutative bit for bit, so both halves hold identical gradients, run the identical norm /
 // Adam arithmetic on identical weights and stay replicas of each other.  One more hop per step for half of the GEMM work.
+// the whole update of ONE run (see ppo_train_pairs_body): `ka` = the same argument block in memory
 template <int NT1, bool DISC, bool SPLIT>
-__global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
+__device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const TrainArgs* const ka) {
   using S = SmemR<NT1>;
   constexpr int SX = S::SX;
   constexpr int XR = (S::O16 + 3) / 4;  // floats of an X row each of the 4 threads of a row stages
@@ -216,6 +217,8 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
   const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
   const float ent_coef = a.hp.ent_coef;
+  const float max_grad_norm = a.hp.max_grad_norm, adam_epsf = a.hp.adam_eps, adam_b2f = a.hp.adam_beta2;
+  u64* const xch = a.xch;
 
   // ---------------------------------------------------------------------------------------------------------------
   // row stream: rows of chunk g+1 are prefetched into registers while chunk g is processed, their permutation indices two
@@ -833,7 +836,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
         }
       }
       const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
-      __hip_atomic_store(a.xch + half * 32 + (step & 1) * 16 + role * 4 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
+      __hip_atomic_store(xch + half * 32 + (step & 1) * 16 + role * 4 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
       if (book) {
         ++steps_done;
@@ -864,7 +867,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       u64 v = 0;
       int spins = 0;
       bool ok = false;
-      const u64* const slot = a.xch + half * 32 + (step & 1) * 16 + tid;     // (the three networks of the same half)
+      const u64* const slot = xch + half * 32 + (step & 1) * 16 + tid;     // (the three networks of the same half)
       while (spins < (1 << 24)) {
         v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; break; }
@@ -885,15 +888,15 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
       if (fl[1] != 0.f) { status = 1; stop = true; }
     }
     total = __builtin_amdgcn_sqrtf(total);
-    float coef = a.hp.max_grad_norm * __builtin_amdgcn_rcpf(total + 1e-6f);
+    float coef = max_grad_norm * __builtin_amdgcn_rcpf(total + 1e-6f);
     coef = coef > 1.f ? 1.f : coef;
     read_stats(nb_next > 0 ? nb_next : 2);
 
     // ================= Adam (torch.optim.Adam, single-tensor form) on register-resident weights and moments =================
     {   // unconditional: after a timed-out exchange (status != 0) the launch ends with the status word set and the host raises
       const float step_size = ps.step_size, inv_bc2_sqrt = ps.inv_bc2_sqrt;
-      const float epsf = a.hp.adam_eps;
-      const float omw1 = 1.f - w1, b2f_ = a.hp.adam_beta2;
+      const float epsf = adam_epsf;
+      const float omw1 = 1.f - w1, b2f_ = adam_b2f;
       const float cw1 = coef * w1, c2w2 = (coef * coef) * w2;
       // four elements at a time, stage by stage (independent chains keep the transcendental unit and the FMA pipe busy; one
       // wave per SIMD has nobody else to cover a dependent v_sqrt -> v_rcp chain)
@@ -938,9 +941,9 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
   // ---- write back weights, moments, statistics.  The pointers / offsets are re-read from the kernel-argument segment here
   // instead of being kept in scalar registers across the whole optimisation loop.  SPLIT: the two halves are replicas; half 0 writes.
   if (!SPLIT || half == 0) {
-  const TrainArgs* ka = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-  asm volatile("" : "+s"(ka));
-  const TrainArgs& a = *ka;
+  const TrainArgs* kw = ka;
+  asm volatile("" : "+s"(kw));
+  const TrainArgs& a = *kw;
   const PolLayout& L = a.L;
   const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
   const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
@@ -1000,6 +1003,39 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
     }
   }
   }
+}
+
+template <int NT1, bool DISC, bool SPLIT>
+__global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
+  ppo_train_rows_body<NT1, DISC, SPLIT>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+}
+
+// several independent runs in ONE launch: grid (3 or 6, n_runs), run = blockIdx.y
+template <int NT1, bool DISC, bool SPLIT>
+__global__ void __launch_bounds__(TH4) ppo_train_rows_batch_kernel(const TrainArgs* __restrict__ runs) {
+  const TrainArgs* const ka = runs + blockIdx.y;
+  ppo_train_rows_body<NT1, DISC, SPLIT>(*ka, ka);
+}
+
+template <int NT1, bool DISC, bool SPLIT>
+static int launch_rows_batch(const TrainArgs* d_args, int n_runs, hipStream_t s) {
+  const size_t bytes = (size_t)SmemR<NT1>::TOTAL * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_batch_kernel<NT1, DISC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL((ppo_train_rows_batch_kernel<NT1, DISC, SPLIT>), dim3(SPLIT ? 6 : 3, n_runs), dim3(TH4), bytes, s, d_args);
+  return (int)hipGetLastError();
+}
+
+int launch_train_rows_batch(const TrainArgs* d_args, int n_runs, int nt1, bool discrete, bool split, hipStream_t s) {
+  if (split) {
+    if (nt1 <= 4) return discrete ? launch_rows_batch<4, true, true>(d_args, n_runs, s) : launch_rows_batch<4, false, true>(d_args, n_runs, s);
+    if (nt1 <= 8) return discrete ? launch_rows_batch<8, true, true>(d_args, n_runs, s) : launch_rows_batch<8, false, true>(d_args, n_runs, s);
+    return fail("update (row-owning waves): obs_dim tiles %d > 8", nt1);
+  }
+  if (nt1 <= 2) return discrete ? launch_rows_batch<2, true, false>(d_args, n_runs, s) : launch_rows_batch<2, false, false>(d_args, n_runs, s);
+  if (nt1 <= 4) return discrete ? launch_rows_batch<4, true, false>(d_args, n_runs, s) : launch_rows_batch<4, false, false>(d_args, n_runs, s);
+  if (nt1 <= 8) return discrete ? launch_rows_batch<8, true, false>(d_args, n_runs, s) : launch_rows_batch<8, false, false>(d_args, n_runs, s);
+  return fail("update (row-owning waves): obs_dim tiles %d > 8", nt1);
 }
 
 template <int NT1, bool DISC, bool SPLIT>

@@ -994,7 +994,7 @@ constexpr int GRAN_MAX = 12;    // granules a thread polls per step in granule m
 // flag: cdna_hip_programming.md Guideline 16).  Consumers poll the granules themselves, so a step costs ONE trip through the
 // memory system after the slowest producer instead of three (drain stores -> raise flag -> see flag -> fetch data).
 template <int OCT, int CIT, bool GRAN>
-__global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) {
+__device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
   __shared__ ActShared sh;
   __shared__ double chunk[NORM_CHUNK + 64 * MAX_OBS];     // raw observations of the step, TRANSPOSED: [obs][NP], NP = N + 64
   __shared__ double vec[2][128], dev2[2][128], ret_s[128], cret_s[128], rawr_s[128];
@@ -1232,6 +1232,26 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
     if (lane == 0 && w == 2 && has_cost) { nm.cost_stats[0] = st_m; nm.cost_stats[1] = st_v; nm.cost_stats[2] = st_c; }
     if (tid < N) { nm.ret[tid] = ret_s[tid]; if (has_cost) nm.cost_ret[tid] = cret_s[tid]; }
   }
+}
+
+template <int OCT, int CIT, bool GRAN>
+__global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) {
+  rollout_persistent_body<OCT, CIT, GRAN>(p);
+}
+
+// several independent runs in ONE launch: grid (N, n_runs), run = blockIdx.y, argument blocks in device memory.  Workgroups are
+// dispatched x-fastest, so a run's N workgroups become resident together and the oldest run of the grid is always complete: runs
+// whose workgroups do not fit yet simply start when earlier runs have finished (the exchange waits are bounded by seconds).
+template <int OCT, int CIT, bool GRAN>
+__global__ void __launch_bounds__(256) rollout_persistent_batch_kernel(const PersistArgs* __restrict__ runs) {
+  __shared__ PersistArgs p;
+  {
+    const unsigned* src = reinterpret_cast<const unsigned*>(runs + blockIdx.y);
+    unsigned* dst = reinterpret_cast<unsigned*>(&p);
+    for (unsigned i = threadIdx.x; i < sizeof(PersistArgs) / 4; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  rollout_persistent_body<OCT, CIT, GRAN>(p);
 }
 
 // =================================================================================================================
@@ -1646,7 +1666,7 @@ struct SampleArgs {
 };
 
 template <int OCT>
-__global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
+__device__ __forceinline__ void sample_episodes_body(const SampleArgs& a) {
   __shared__ ActShared sh;
   PolRegs<OCT> R;
   load_pol_regs<OCT>(a.pl, a.PT, R);    // once for every step of every episode of this stream
@@ -1724,6 +1744,24 @@ __global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
   }
 }
 
+template <int OCT>
+__global__ void __launch_bounds__(192) sample_episodes_kernel(SampleArgs a) {
+  sample_episodes_body<OCT>(a);
+}
+
+// several runs' streams in ONE launch: grid (n_streams, n_runs), run = blockIdx.y (streams of different runs never interact)
+template <int OCT>
+__global__ void __launch_bounds__(192) sample_episodes_batch_kernel(const SampleArgs* __restrict__ runs) {
+  __shared__ SampleArgs a;
+  {
+    const unsigned* src = reinterpret_cast<const unsigned*>(runs + blockIdx.y);
+    unsigned* dst = reinterpret_cast<unsigned*>(&a);
+    for (unsigned i = threadIdx.x; i < sizeof(SampleArgs) / 4; i += 192) dst[i] = src[i];
+  }
+  __syncthreads();
+  sample_episodes_body<OCT>(a);
+}
+
 static bool dims_ok(int O, int A, int H1, int H2) {
   return O > 0 && O <= MAX_OBS && A > 0 && A <= MAX_ACT && H1 > 0 && H1 <= MAX_H && H2 > 0 && H2 <= MAX_H;
 }
@@ -1792,23 +1830,60 @@ extern "C" int icrl_policy_evaluate(const icrl_policy_t* p, const double* obs, c
   return (int)hipGetLastError();
 }
 
-extern "C" int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const float* noise,
-                                    const float* action_low, const float* action_high, int episodes_per_stream,
-                                    int rows_per_stream, int deterministic, int do_reset, double* orig_obs, double* obs,
-                                    float* actions, double* ep_rewards, int32_t* ep_lengths, void* stream) {
+static int make_sample_args(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const float* noise,
+                            const float* action_low, const float* action_high, int episodes_per_stream, int rows_per_stream,
+                            int deterministic, int do_reset, double* orig_obs, double* obs, float* actions, double* ep_rewards,
+                            int32_t* ep_lengths, SampleArgs& a) {
   if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2)) return bad_dims("icrl_sample_episodes", pol->obs_dim, pol->act_dim, pol->h1, pol->h2);
   if (env->obs_dim != pol->obs_dim || nm->training)
     return fail("icrl_sample_episodes: env obs_dim %d vs policy %d; the normaliser must be frozen (training = %d)", env->obs_dim, pol->obs_dim, nm->training);
   if (episodes_per_stream * env->max_steps > rows_per_stream)
     return fail("icrl_sample_episodes: %d episodes x %d steps do not fit %d rows per stream", episodes_per_stream, env->max_steps, rows_per_stream);
-  SampleArgs a;
   a.env = *env; a.nm = *nm; a.pl = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);
   a.PT = pol->params_t; a.noise = noise; a.alow = action_low; a.ahigh = action_high;
   a.episodes_per_stream = episodes_per_stream; a.rows_per_stream = rows_per_stream; a.deterministic = deterministic;
   a.do_reset = do_reset; a.orig_obs = orig_obs; a.obs = obs; a.actions = actions; a.ep_rewards = ep_rewards; a.ep_lengths = ep_lengths;
   a.pt_in_lds = 0;
+  return 0;
+}
+
+extern "C" int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const float* noise,
+                                    const float* action_low, const float* action_high, int episodes_per_stream,
+                                    int rows_per_stream, int deterministic, int do_reset, double* orig_obs, double* obs,
+                                    float* actions, double* ep_rewards, int32_t* ep_lengths, void* stream) {
+  SampleArgs a;
+  const int bad = make_sample_args(env, nm, pol, noise, action_low, action_high, episodes_per_stream, rows_per_stream, deterministic,
+                                   do_reset, orig_obs, obs, actions, ep_rewards, ep_lengths, a);
+  if (bad) return bad;
   if (a.pl.O <= 32) hipLaunchKernelGGL(sample_episodes_kernel<2>, dim3(env->n_envs), dim3(192), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(sample_episodes_kernel<8>, dim3(env->n_envs), dim3(192), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_sample_episodes_batch(int n_runs, const icrl_sample_job_t* jobs, const float* action_low, const float* action_high,
+                                          int episodes_per_stream, int rows_per_stream, int deterministic, int do_reset,
+                                          void* args_ws, long long args_ws_bytes, void* stream) {
+  static_assert(sizeof(SampleArgs) <= ICRL_BATCH_ARGS_BYTES, "ICRL_BATCH_ARGS_BYTES");
+  if (n_runs < 1 || n_runs > 65535) return fail("icrl_sample_episodes_batch: n_runs = %d (1..65535)", n_runs);
+  if (args_ws == nullptr || args_ws_bytes < (long long)n_runs * ICRL_BATCH_ARGS_BYTES)
+    return fail("icrl_sample_episodes_batch: args_ws holds %lld B, %d runs need %lld", args_ws_bytes, n_runs, (long long)n_runs * ICRL_BATCH_ARGS_BYTES);
+  hipStream_t s = (hipStream_t)stream;
+  SampleArgs* d_args = (SampleArgs*)args_ws;
+  const icrl_sample_job_t& j0 = jobs[0];
+  for (int r = 0; r < n_runs; ++r) {
+    const icrl_sample_job_t& j = jobs[r];
+    if (j.env->n_envs != j0.env->n_envs || j.env->obs_dim != j0.env->obs_dim || j.pol->act_dim != j0.pol->act_dim ||
+        j.pol->discrete != j0.pol->discrete || j.env->max_steps != j0.env->max_steps)
+      return fail("icrl_sample_episodes_batch: run %d differs from run 0 in a shape (streams / obs / act / discrete / max_steps)", r);
+    SampleArgs a;
+    const int bad = make_sample_args(j.env, j.nm, j.pol, j.noise, action_low, action_high, episodes_per_stream, rows_per_stream,
+                                     deterministic, do_reset, j.orig_obs, j.obs, j.actions, j.ep_rewards, j.ep_lengths, a);
+    if (bad) return bad;
+    const int e = put_args(a, d_args + r, s);
+    if (e) return e;
+  }
+  if (j0.pol->obs_dim <= 32) hipLaunchKernelGGL(sample_episodes_batch_kernel<2>, dim3(j0.env->n_envs, n_runs), dim3(192), 0, s, d_args);
+  else hipLaunchKernelGGL(sample_episodes_batch_kernel<8>, dim3(j0.env->n_envs, n_runs), dim3(192), 0, s, d_args);
   return (int)hipGetLastError();
 }
 
@@ -2000,6 +2075,78 @@ per_step:
                        ag->last_v_c, ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns,
                        buf->cost_returns, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, 0, buf->gae_ws,
                           buf->gae_ws_bytes, stream);
+}
+
+// icrl_rollout_collect for n_runs runs: ONE persistent launch of grid (N, n_runs) + ONE batched dual-GAE launch.  Only the
+// one-workgroup-per-env persistent kernel has a batched form (N <= 128 and N x obs <= 4096: BASELINE configs[1]); other shapes
+// are refused (the caller then issues the single-run calls).
+extern "C" int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* jobs, const float* action_low, const float* action_high,
+                                          double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
+                                          int do_gae, void* args_ws, long long args_ws_bytes, void* stream) {
+  static_assert(sizeof(PersistArgs) <= ICRL_BATCH_ARGS_BYTES, "ICRL_BATCH_ARGS_BYTES");
+  if (n_runs < 1 || n_runs > 65535) return fail("icrl_rollout_collect_batch: n_runs = %d (1..65535)", n_runs);
+  if (args_ws == nullptr || args_ws_bytes < (long long)n_runs * ICRL_BATCH_ARGS_BYTES)
+    return fail("icrl_rollout_collect_batch: args_ws holds %lld B, %d runs need %lld", args_ws_bytes, n_runs, (long long)n_runs * ICRL_BATCH_ARGS_BYTES);
+  hipStream_t s = (hipStream_t)stream;
+  const icrl_rollout_job_t& j0 = jobs[0];
+  const int N = j0.env->n_envs, O = j0.env->obs_dim, T = j0.buf->T;
+  const bool has_cn = j0.cn != nullptr;
+  if (!(N <= 128 && N * O <= NORM_CHUNK && O * j0.env->act_dim <= MAX_OBS * MAX_ACT && T >= 1))
+    return fail("icrl_rollout_collect_batch: %d envs x obs %d: only the one-workgroup-per-env persistent kernel (<= 128 envs, envs x obs <= %d) has a batched form", N, O, NORM_CHUNK);
+  const int G = 2 * O + 4;
+  const bool gran = (size_t)N * G <= (size_t)256 * GRAN_MAX;
+  const size_t need = (size_t)16 * N * O + (size_t)16 * N + (size_t)8 * N + (size_t)8 * N + 1024 + (gran ? (size_t)16 * N * G : 0);
+  PersistArgs* d_args = (PersistArgs*)args_ws;
+  for (int r = 0; r < n_runs; ++r) {
+    const icrl_rollout_job_t& j = jobs[r];
+    if (j.env->n_envs != N || j.env->obs_dim != O || j.env->act_dim != j0.env->act_dim || j.buf->T != T || j.buf->N != N ||
+        j.pol->obs_dim != O || j.pol->act_dim != j0.pol->act_dim || j.pol->discrete != j0.pol->discrete || (j.cn != nullptr) != has_cn ||
+        (has_cn && (j.cn->in_dim != j0.cn->in_dim || j.cn->n_hidden != j0.cn->n_hidden)))
+      return fail("icrl_rollout_collect_batch: run %d differs from run 0 in a shape (envs / obs / act / T / discrete / constraint net)", r);
+    if (!dims_ok(j.pol->obs_dim, j.pol->act_dim, j.pol->h1, j.pol->h2)) return bad_dims("icrl_rollout_collect_batch", j.pol->obs_dim, j.pol->act_dim, j.pol->h1, j.pol->h2);
+    if (j.buf->obs_dim != O) return fail("icrl_rollout_collect_batch: run %d: buffer obs_dim %d vs env %d", r, j.buf->obs_dim, O);
+    if (j.cn != nullptr && !cn_ok(j.cn)) return bad_cn("icrl_rollout_collect_batch", j.cn);
+    char* ws = (j.ag->xch_ws != nullptr && (size_t)j.ag->xch_ws_bytes >= need) ? reinterpret_cast<char*>(j.ag->xch_ws)
+               : ((size_t)T * N * sizeof(float) >= need ? reinterpret_cast<char*>(j.buf->reward_advantages) : nullptr);
+    if (ws == nullptr) return fail("icrl_rollout_collect_batch: run %d: exchange workspace of %zu B needed (icrl_agent_t.xch_ws, ICRL_ROLLOUT_WS_BYTES)", r, need);
+    PersistArgs p;
+    ActStepArgs& a = p.act;
+    a.env = *j.env; a.buf = *j.buf; a.ag = *j.ag;
+    a.pl = make_pol_layout(j.pol->obs_dim, j.pol->act_dim, j.pol->h1, j.pol->h2, j.pol->discrete);
+    a.PT = j.pol->params_t; a.noise = j.noise; a.alow = action_low; a.ahigh = action_high;
+    a.has_cn = j.cn != nullptr;
+    if (j.cn) { a.cn = *j.cn; a.cl = make_cn_layout(j.cn->in_dim, j.cn->n_hidden, j.cn->h1, j.cn->h2); }
+    p.nm = *j.nm; p.T = T; p.prof = 0;
+    char* base = ws;
+    p.xch_obs = reinterpret_cast<double*>(base); base += (size_t)16 * N * O;
+    p.xch_rew = reinterpret_cast<double*>(base); base += (size_t)16 * N;
+    p.xch_cost = reinterpret_cast<float*>(base); base += (size_t)8 * N;
+    p.xch_done = reinterpret_cast<unsigned*>(base); base += ((size_t)8 * N + 255) / 256 * 256;
+    p.counter = reinterpret_cast<unsigned*>(base); base += 512;
+    p.xg = reinterpret_cast<unsigned long long*>(base);
+    p.g_magic = (unsigned)((1ull << 32) / (unsigned long long)G);
+    hipError_t e = hipMemsetAsync(p.counter, 0, 512 + (gran ? (size_t)16 * N * G : 0), s);
+    if (e != hipSuccess) return (int)e;
+    const int pe = put_args(p, d_args + r, s);
+    if (pe) return pe;
+  }
+  const bool small = O <= 32 && (!has_cn || j0.cn->in_dim <= 32);
+  auto go = [&](auto kernel) -> int {
+    if (!persistent_fits(kernel, N)) return fail("icrl_rollout_collect_batch: the %d workgroups of one run do not fit the device", N);
+    hipLaunchKernelGGL(kernel, dim3(N, n_runs), dim3(256), 0, s, d_args);
+    return (int)hipGetLastError();
+  };
+  int err;
+  if (small && gran) err = go(rollout_persistent_batch_kernel<2, 2, true>);
+  else if (small) err = go(rollout_persistent_batch_kernel<2, 2, false>);
+  else if (gran) err = go(rollout_persistent_batch_kernel<8, 10, true>);
+  else err = go(rollout_persistent_batch_kernel<8, 10, false>);
+  if (err || !(do_gae & 1)) return err;
+  // dual GAE of every run in one launch; its argument blocks go behind the rollout's in args_ws (both launches are in flight together)
+  if (args_ws_bytes < 2ll * n_runs * ICRL_BATCH_ARGS_BYTES)
+    return fail("icrl_rollout_collect_batch: args_ws needs 2 x n_runs x ICRL_BATCH_ARGS_BYTES = %lld B when the GAE launch is included", 2ll * n_runs * ICRL_BATCH_ARGS_BYTES);
+  return icrl_gae_dual_batch_impl(n_runs, jobs, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda,
+                                  (char*)args_ws + (size_t)n_runs * ICRL_BATCH_ARGS_BYTES, stream);
 }
 
 extern "C" int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol,

@@ -142,8 +142,11 @@ def outer_iteration(st, itr):
     mean, var = None, None
     if config.cn_normalize:
         mean, var = sampling_env.obs_rms.mean, sampling_env.obs_rms.var
+    cn_perms = None       # minibatch mode with run-private streams: the permutations of get() come from them (seed batches)
+    if constraint_net.batch_size is not None and streams is not None and hasattr(streams, "cn_permutations"):
+        cn_perms = streams.cn_permutations(config.backward_iters, min(int(orig_observations.shape[0]), int(np.asarray(constraint_net.expert_obs).shape[0])))
     backward_metrics = constraint_net.train(config.backward_iters, orig_observations, actions, lengths, mean, var,
-                                            current_progress_remaining)
+                                            current_progress_remaining, perms=cn_perms)
     train_env.set_cost_function(constraint_net.cost_function)
     # ---- the single collective of the iteration
     synchronise(st)

@@ -111,7 +111,7 @@ class PPOLagrangian:
                         last_v_r=torch.zeros(N, device=dev), last_v_c=torch.zeros(N, device=dev),
                         act_clipped=torch.zeros(N, A, device=dev), status=torch.zeros(1, dtype=torch.int32, device=dev),
                         # exchange workspace of the persistent rollout: ICRL_ROLLOUT_WS_BYTES(N, obs)
-                        xch_ws=torch.zeros((16 * N * (2 * self.observation_space.shape[0] + 4) + 16 * (4 * self.observation_space.shape[0] + 4) + 1024) // 8 + 1,
+                        xch_ws=torch.zeros((48 * N * self.observation_space.shape[0] + 96 * N + 64 * self.observation_space.shape[0] + 2048) // 8 + 1,
                                            dtype=torch.int64, device=dev))
         if isinstance(self.action_space, spaces.Box):
             self._alow = torch.as_tensor(self.action_space.low, device=dev).float().contiguous()
@@ -152,13 +152,25 @@ class PPOLagrangian:
     def collect_rollouts(self, env, callback, rollout_buffer, n_rollout_steps, cost_function="cost", noise=None):
         """ref: on_policy_algorithm.py:340-421."""
         assert self._last_obs is not None, "No previous observation was provided"
-        chain = self._fused_chain()
-        if chain is None or not isinstance(cost_function, str) or n_rollout_steps != rollout_buffer.buffer_size:
+        if not self._fused_rollout_ok(cost_function, n_rollout_steps, rollout_buffer):
             return self._collect_rollouts_stepped(env, callback, rollout_buffer, n_rollout_steps, cost_function, noise)
-        rollout_buffer.reset()
+        job = self._rollout_begin(callback, rollout_buffer, n_rollout_steps, noise)
+        self._rollout_launch(job)
+        return self._rollout_end(job, env, callback, rollout_buffer, n_rollout_steps)
+
+    def _fused_rollout_ok(self, cost_function, n_rollout_steps, rollout_buffer):
+        return self._fused_chain() is not None and isinstance(cost_function, str) and n_rollout_steps == rollout_buffer.buffer_size
+
+    # The fused rollout in three pieces, so that several runs sharing a GPU (icrl_amd/seed_batch.py) can put their launches into
+    # ONE grid: _rollout_begin (host state + descriptors), the launch (single: _rollout_launch; batched: seed_batch), _rollout_end.
+    def _rollout_begin(self, callback, rollout_buffer, n_rollout_steps, noise=None, zero_buffer=True):
+        if zero_buffer:
+            rollout_buffer.reset()
+        else:            # the launch overwrites every row of all 16 arrays: the zeroing is invisible
+            rollout_buffer.pos, rollout_buffer.full, rollout_buffer.generator_ready = 0, False, False
         if callback is not None:
             callback.on_rollout_start()
-        nenv, cw, senv = chain
+        nenv, cw, senv = self._fused_chain()
         if noise is None:
             noise = self._draw_action_noise(n_rollout_steps)
         e, nm, pol, buf = senv.struct(), nenv.struct(), self.policy.struct(), rollout_buffer.struct()
@@ -166,29 +178,35 @@ class PPOLagrangian:
         ag = AgentT(p(self._last_obs), p(self._ag["last_dones"]), p(self._ag["raw_rew"]), p(self._ag["raw_cost"]), p(self._ag["dones"]),
                     p(self._ag["last_v_r"]), p(self._ag["last_v_c"]), p(self._ag["act_clipped"]), p(self._ag["status"]),
                     p(self._ag["xch_ws"]), self._ag["xch_ws"].numel() * 8)
-        b = _lib.byref
         timed = getattr(self, "gae_events", None) is not None
         flags = int(not timed) | (2 if getattr(self, "rollout_kernel", "auto") == "steps" else 0) | ((4 if getattr(self, "_wide_prof_flag", 1) == 1 else 8) if getattr(self, "profile_phases", 0) else 0)
-        from .seed_batch import budgeted
+        return dict(env=e, nm=nm, pol=pol, cn=cn, buf=buf, ag=ag, noise=noise, flags=flags, timed=timed, chain=(nenv, cw, senv))
+
+    def _rollout_launch(self, job):
+        b = _lib.byref
         rev = None
         if getattr(self, "rollout_events", None) is not None:      # bench.py: events around the rollout launch on its stream
             rev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             rev[0].record()
-        with budgeted(0 if flags & 2 else self.n_envs):      # persistent launch: one CU per environment (several runs on one GPU)
-            _lib.check(_lib.lib().icrl_rollout_collect_ex(b(e), b(nm), b(pol), b(cn) if cn is not None else None, b(buf), b(ag), p(noise), p(self._alow), p(self._ahigh),
-                                                          float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
-                                                          float(self.cost_gae_lambda), flags, _lib.current_stream()),
-                       "icrl_rollout_collect")
+        cn = job["cn"]
+        _lib.check(_lib.lib().icrl_rollout_collect_ex(b(job["env"]), b(job["nm"]), b(job["pol"]), b(cn) if cn is not None else None, b(job["buf"]), b(job["ag"]),
+                                                      p(job["noise"]), p(self._alow), p(self._ahigh),
+                                                      float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
+                                                      float(self.cost_gae_lambda), job["flags"], _lib.current_stream()),
+                   "icrl_rollout_collect")
         if rev is not None:
             rev[1].record()
             self.rollout_events.append(rev)
-        if timed:   # bench.py: the same GAE launch, bracketed by events on the stream it runs on
+
+    def _rollout_end(self, job, env, callback, rollout_buffer, n_rollout_steps):
+        nenv, cw, senv = job["chain"]
+        if job["timed"]:   # bench.py: the same GAE launch, bracketed by events on the stream it runs on
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             rollout_buffer.compute_returns_and_advantage(self._ag["last_v_r"], self._ag["last_v_c"], self._ag["last_dones"])
             e1.record()
             self.gae_events.append((e0, e1))
-        self._keepalive = (noise,)
+        self._keepalive = (job["noise"],)
         rollout_buffer.pos, rollout_buffer.full = n_rollout_steps, True
         self.num_timesteps += env.num_envs * n_rollout_steps
         # wrapper-visible "last step" state, as the reference leaves it
@@ -407,6 +425,12 @@ class PPOLagrangian:
 
     def train(self, perms=None):
         """ref: ppo_lag.py:177-338."""
+        job = self._train_begin(perms)
+        self._train_launch(job)
+        self._train_end(job)
+
+    # train() in three pieces (see _rollout_begin): descriptors, the launch (single here, batched in seed_batch.py), read-back + logs
+    def _train_begin(self, perms=None):
         lr = float(self.lr_schedule(self._current_progress_remaining))
         clip_range = float(self.clip_range(self._current_progress_remaining))
         crv = -1.0 if self.clip_range_reward_vf is None else float(self.clip_range_reward_vf(self._current_progress_remaining))
@@ -428,28 +452,50 @@ class PPOLagrangian:
         hp = PpoHyperT(int(self.batch_size), int(self.n_epochs), int(self.target_kl is not None), int(getattr(self, "profile_phases", 0)) | {"tiles": 2, "rows": 4, "rows1": 12}.get(getattr(self, "train_kernel", "auto"), 0), clip_range, float(self.ent_coef),
                        float(self.reward_vf_coef), float(self.cost_vf_coef), float(self.max_grad_norm),
                        float(self.target_kl or 0.0), crv, ccv, lr, 0.9, 0.999, float(pol.optimizer_kwargs.get("eps", 1e-8)))
-        ps, bs = pol.struct(), rb.struct()
-        b = _lib.byref
+        return dict(ps=pol.struct(), bs=rb.struct(), hp=hp, perms=perms, rng_state=rng_state, injected=injected, clip_range=clip_range)
+
+    def _train_launch(self, job):
+        pol, ws, b = self.policy, self._train_ws, _lib.byref
         ev = None
         if getattr(self, "train_events", None) is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record()
-        from .seed_batch import budgeted
-        with budgeted(6 if int(self.batch_size) > 64 else 3):   # persistent workgroups, a CU each (two per network when a minibatch is two chunks)
-            _lib.check(_lib.lib().icrl_ppo_lag_train(b(ps), p(pol.exp_avg), p(pol.exp_avg_sq), p(ws["t"]), b(bs), p(perms), p(ws["nu"]),
-                                                     b(hp), p(ws["stats"]), p(ws["sync"]), _lib.current_stream()), "icrl_ppo_lag_train")
+        _lib.check(_lib.lib().icrl_ppo_lag_train(b(job["ps"]), p(pol.exp_avg), p(pol.exp_avg_sq), p(ws["t"]), b(job["bs"]), p(job["perms"]), p(ws["nu"]),
+                                                 b(job["hp"]), p(ws["stats"]), p(ws["sync"]), _lib.current_stream()), "icrl_ppo_lag_train")
         if ev is not None:
             ev[1].record()
+        job["ev"] = ev
+
+    def train_readback(self):
+        """device tensor with everything _train_end reads back: [32 + n_epochs statistics | adam step | mean / sum of orig_costs |
+        mean reward / cost advantages | mean std | rollout status] — stacked over runs by seed_batch.py (one copy for all runs)."""
+        rb, pol, ws = self.rollout_buffer, self.policy, self._train_ws
+        std = torch.exp(pol.log_std).mean() if pol.log_std is not None else torch.zeros((), device=self.device)
+        tail = torch.stack([rb.orig_costs.mean(), rb.orig_costs.sum(), rb.reward_advantages.mean(), rb.cost_advantages.mean(), std])
+        return torch.cat([ws["stats"].double(), ws["t"].double(), tail.double(), self._ag["status"].double()])
+
+    def _train_end(self, job, host=None):
+        """host: this run's row of train_readback() already on the host (numpy float64; float32 values survive the round trip
+        exactly), or None: read here."""
+        rb, pol, ws = self.rollout_buffer, self.policy, self._train_ws
+        rng_state, injected, clip_range, ev = job["rng_state"], job["injected"], job["clip_range"], job.get("ev")
         pol.prepare()                                   # refresh the transposed copy for the next rollout
         self._n_updates += self.n_epochs
         # ---- the scalars the reference logs (one device->host read per train())
-        average_cost_t = rb.orig_costs.mean()
-        total_cost_t = rb.orig_costs.sum()
-        st = ws["stats"].cpu().numpy()
+        ns = 32 + self.n_epochs
+        if host is None:
+            average_cost_t = rb.orig_costs.mean()
+            total_cost_t = rb.orig_costs.sum()
+        st = ws["stats"].cpu().numpy() if host is None else np.asarray(host[:ns], np.float32)
         if st[11] != 0:
             raise RuntimeError("icrl_ppo_lag_train: inter-workgroup exchange timed out")
-        self.check_rollout_status()
-        pol.adam_step = int(ws["t"].item())
+        if host is None:
+            self.check_rollout_status()
+        elif host[ns + 6] != 0:
+            self._ag["status"].zero_()
+            raise RuntimeError("icrl_rollout_collect: inter-workgroup exchange timed out (a workgroup of the persistent "
+                               "rollout was not resident); rollout buffer and normaliser statistics are invalid")
+        pol.adam_step = int(ws["t"].item()) if host is None else int(host[ns])
         steps = max(int(st[1]), 1)
         if ev is not None:
             self.train_events.append((ev[0], ev[1], steps))
@@ -458,7 +504,11 @@ class PPOLagrangian:
             self.streams.consumed(min(early_stop_epoch + 1, self.n_epochs))
         if rng_state is not None:       # leave np.random where the reference would: one permutation per executed epoch
             np.random.set_state(rng_state[min(early_stop_epoch + 1, self.n_epochs) - 1])
-        average_cost = float(average_cost_t.item())
+        if host is None:
+            average_cost, total_cost = float(average_cost_t.item()), float(total_cost_t.item())
+            mean_ra, mean_ca = float(rb.reward_advantages.mean().item()), float(rb.cost_advantages.mean().item())
+        else:
+            average_cost, total_cost, mean_ra, mean_ca = (float(x) for x in host[ns + 1:ns + 5])
         if self.update_penalty_after is None or ((self._n_updates / self.n_epochs) % self.update_penalty_after == 0):
             self.dual.update_parameter(np.float32(average_cost))
         logger.record("train/entropy_loss", st[2] / steps)
@@ -468,15 +518,15 @@ class PPOLagrangian:
         logger.record("train/approx_kl", float(st[7]))
         logger.record("train/clip_fraction", st[6] / steps)
         logger.record("train/loss", float(st[8] + self.reward_vf_coef * st[9] + self.cost_vf_coef * st[10]))
-        logger.record("train/mean_reward_advantages", float(rb.reward_advantages.mean().item()))
-        logger.record("train/mean_cost_advantages", float(rb.cost_advantages.mean().item()))
+        logger.record("train/mean_reward_advantages", mean_ra)
+        logger.record("train/mean_cost_advantages", mean_ca)
         logger.record("train/nu", self.dual.nu().item())
         logger.record("train/nu_loss", self.dual.loss.item())
         logger.record("train/average_cost", average_cost)
-        logger.record("train/total_cost", float(total_cost_t.item()))
+        logger.record("train/total_cost", total_cost)
         logger.record("train/early_stop_epoch", early_stop_epoch)
         if pol.log_std is not None:
-            logger.record("train/std", float(torch.exp(pol.log_std).mean().item()))
+            logger.record("train/std", float(torch.exp(pol.log_std).mean().item()) if host is None else float(host[ns + 5]))
         logger.record("train/n_updates", self._n_updates)
         logger.record("train/clip_range", clip_range)
         self.epoch_kls = st[32:32 + self.n_epochs].copy()

@@ -37,6 +37,11 @@ class PrivateStreams:
     def consumed(self, executed_epochs):
         pass
 
+    def cn_permutations(self, iterations, size):
+        """the np.random.permutation draws of ConstraintNet.get() in minibatch mode (`--cn_batch_size`, constraint_net.py:300-316):
+        [iterations, size] from this run's own generator (the process-wide numpy generator would interleave the runs' draws)."""
+        return torch.stack([torch.randperm(size, device=self.device, generator=self.perm_gen) for _ in range(max(int(iterations), 1))])
+
     def sample_noise(self, rows, A):
         return self._draw(rows, A)
 

@@ -57,6 +57,34 @@ class CnHyperT(C.Structure):
                 ("lr", C.c_float), ("adam_beta1", C.c_float), ("adam_beta2", C.c_float), ("adam_eps", C.c_float)]
 
 
+# ---- job descriptors of the batched entry points: pointers to the per-run descriptors above (host memory) + device pointers
+class RolloutJobT(C.Structure):
+    _fields_ = [("env", vp), ("nm", vp), ("pol", vp), ("cn", vp), ("buf", vp), ("ag", vp), ("noise", vp)]
+
+
+class GaeJobT(C.Structure):
+    _fields_ = [(k, vp) for k in ("rewards", "costs", "reward_values", "cost_values", "dones", "last_v_r", "last_v_c", "last_dones",
+                                  "adv_r", "adv_c", "ret_r", "ret_c", "ws")] + [("ws_bytes", C.c_longlong)]
+
+
+class SampleJobT(C.Structure):
+    _fields_ = [(k, vp) for k in ("env", "nm", "pol", "noise", "orig_obs", "obs", "actions", "ep_rewards", "ep_lengths")]
+
+
+class CnTrainJobT(C.Structure):
+    _fields_ = [("cn", vp), ("exp_avg", vp), ("exp_avg_sq", vp), ("adam_step", vp), ("nominal", vp), ("expert", vp), ("Nn", i32), ("Ne", i32),
+                ("ep_offsets", vp), ("row_episode", vp), ("n_ep", i32), ("_pad", i32), ("hp", vp), ("work", vp), ("metrics", vp)]
+
+
+class PpoTrainJobT(C.Structure):
+    _fields_ = [(k, vp) for k in ("pol", "exp_avg", "exp_avg_sq", "adam_step", "buf", "perms", "nu", "hp", "stats", "sync_ws")]
+
+
+def addr(struct):
+    """host address of a ctypes struct (for the pointer fields of a job descriptor); the struct must outlive the call."""
+    return C.addressof(struct) if struct is not None else None
+
+
 def p(t):
     """device pointer of a contiguous tensor (or None -> NULL)."""
     if t is None:

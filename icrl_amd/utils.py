@@ -61,71 +61,109 @@ def get_net_arch(config):
 SPECULATIVE_EPISODES = True
 
 
-def _run_episodes(agent, env, n_episodes, deterministic, noise, parallel):
+class EpisodeRun:
     """`n_episodes` sequential episodes of a 1-env loop (icrl/utils.py:323-357, evaluation.py:10-67) as ONE persistent launch.
     Episodes are independent once their position in the env's random stream is known, and that position is the number of
     steps taken before them: with fixed-length episodes it is known up front and the episodes run as parallel streams.  When
     episodes may end early (the "Test" envs, CLGW) they are first run SPECULATIVELY as parallel full-length streams; if
     every episode did run to the time limit the result is exactly the sequential one, otherwise the call is repeated
-    sequentially (same noise, same start state)."""
-    assert env.num_envs == 1, "You must pass only one environment when using this function"
-    senv = env.unwrapped
-    pol, dev = agent.policy, senv.device
-    max_steps, O = senv.max_steps, senv.obs_dim
-    A = 1 if pol.discrete else pol.act_dim
-    fixed_len = not senv.wall_terminate
-    rows = n_episodes * max_steps
-    if noise is None and not deterministic:
-        noise = torch.rand(rows, device=dev) if pol.discrete else torch.randn(rows, A, device=dev)
-    if noise is not None:
-        noise = torch.as_tensor(noise, device=dev).float().reshape(rows, -1).contiguous()
-    base = int(senv.step_count[0].item()) & 0xFFFFFFFF
-    was_training = env.training
-    env.training = False
-    nm, ps = env.struct(), pol.struct()
-    env.training = was_training
-    lo = hi = None
-    if not pol.discrete:
-        lo = torch.as_tensor(pol.action_space.low, device=dev).float().contiguous()
-        hi = torch.as_tensor(pol.action_space.high, device=dev).float().contiguous()
-    b = _lib.byref
+    sequentially (same noise, same start state).
 
-    def launch(n_streams):
-        eps_per = n_episodes // n_streams
-        rows_per = eps_per * max_steps
+    In pieces, so that several runs sharing a GPU can put their launches into one grid (icrl_amd/seed_batch.py):
+    prepare(n_streams) builds the descriptors, launch() is the single-run launch, finish(lengths) checks the speculation and
+    leaves the env where the sequential loop would have left it (returns False when the sequential repeat is needed)."""
+
+    def __init__(self, agent, env, n_episodes, deterministic, noise, parallel):
+        assert env.num_envs == 1, "You must pass only one environment when using this function"
+        self.env, self.senv = env, env.unwrapped
+        senv = self.senv
+        self.pol, self.dev = agent.policy, senv.device
+        pol, dev = self.pol, self.dev
+        self.n_episodes, self.deterministic = n_episodes, deterministic
+        self.max_steps, self.O = senv.max_steps, senv.obs_dim
+        self.A = 1 if pol.discrete else pol.act_dim
+        self.fixed_len = not senv.wall_terminate
+        self.rows = n_episodes * self.max_steps
+        if noise is None and not deterministic:
+            noise = torch.rand(self.rows, device=dev) if pol.discrete else torch.randn(self.rows, self.A, device=dev)
+        if noise is not None:
+            noise = torch.as_tensor(noise, device=dev).float().reshape(self.rows, -1).contiguous()
+        self.noise = noise
+        self.base = None           # position of the env's random stream (read on first use: one small device->host copy)
+        was_training = env.training
+        env.training = False
+        self.nm, self.ps = env.struct(), pol.struct()
+        env.training = was_training
+        self.lo = self.hi = None
+        if not pol.discrete:
+            self.lo = torch.as_tensor(pol.action_space.low, device=dev).float().contiguous()
+            self.hi = torch.as_tensor(pol.action_space.high, device=dev).float().contiguous()
+        # parallel=False keeps fixed-length episodes sequential (a test hook); early-ending envs are tried speculatively unless
+        # SPECULATIVE_EPISODES is switched off
+        self.n_streams = 1 if (n_episodes == 1 or (self.fixed_len and not parallel) or (not self.fixed_len and not SPECULATIVE_EPISODES)) else n_episodes
+
+    def prepare(self, n_streams=None, base=None):
+        senv, dev, O, A = self.senv, self.dev, self.O, self.A
+        if n_streams is not None:
+            self.n_streams = n_streams
+        n_streams = self.n_streams
+        if base is not None:
+            self.base = int(base) & 0xFFFFFFFF
+        if self.base is None:
+            self.base = int(senv.step_count[0].item()) & 0xFFFFFFFF
+        self.eps_per = self.n_episodes // n_streams
+        self.rows_per = self.eps_per * self.max_steps
         # per-stream copies of the env's random-stream position: stream e starts where the sequential loop would be
-        sc = ((base + np.arange(n_streams, dtype=np.int64) * max_steps) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
-        st = dict(s=senv.s.repeat(n_streams, 1).contiguous(), t_ep=senv.t_ep.repeat(n_streams).contiguous(),
-                  step_count=torch.as_tensor(sc, device=dev), key=senv.key.repeat(n_streams).contiguous())
-        e = EnvT(n_streams, O, senv.act_dim, max_steps, senv.reward_form, int(senv.wall_terminate), int(senv.broken), 0,
-                 p(senv.B), p(st["s"]), p(st["t_ep"]), p(st["step_count"]), p(st["key"]))
-        out = dict(orig_obs=torch.empty(rows, O, dtype=torch.float64, device=dev), obs=torch.empty(rows, O, dtype=torch.float64, device=dev),
-                   actions=torch.empty(rows, A, device=dev), ep_rewards=torch.empty(n_episodes, dtype=torch.float64, device=dev),
-                   ep_lengths=torch.empty(n_episodes, dtype=torch.int32, device=dev))
+        sc = ((self.base + np.arange(n_streams, dtype=np.int64) * self.max_steps) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        self.st = dict(s=senv.s.repeat(n_streams, 1).contiguous(), t_ep=senv.t_ep.repeat(n_streams).contiguous(),
+                       step_count=torch.as_tensor(sc, device=dev), key=senv.key.repeat(n_streams).contiguous())
+        st = self.st
+        self.e = EnvT(n_streams, O, senv.act_dim, self.max_steps, senv.reward_form, int(senv.wall_terminate), int(senv.broken), 0,
+                      p(senv.B), p(st["s"]), p(st["t_ep"]), p(st["step_count"]), p(st["key"]))
+        rows, n_episodes = self.rows, self.n_episodes
+        self.out = dict(orig_obs=torch.empty(rows, O, dtype=torch.float64, device=dev), obs=torch.empty(rows, O, dtype=torch.float64, device=dev),
+                        actions=torch.empty(rows, A, device=dev), ep_rewards=torch.empty(n_episodes, dtype=torch.float64, device=dev),
+                        ep_lengths=torch.empty(n_episodes, dtype=torch.int32, device=dev))
+        return self
+
+    def launch(self):
         # streams > 0 of the parallel mode start from a reset as well: in the sequential loop their first state is the
         # auto-reset draw made at exactly this counter value
-        _lib.check(_lib.lib().icrl_sample_episodes(b(e), b(nm), b(ps), p(noise), p(lo), p(hi), eps_per, rows_per, int(deterministic), 1,
-                                                   p(out["orig_obs"]), p(out["obs"]), p(out["actions"]), p(out["ep_rewards"]),
-                                                   p(out["ep_lengths"]), _lib.current_stream()), "icrl_sample_episodes")
-        return out, st, out["ep_lengths"].cpu().numpy().astype(np.int64)
+        b, out = _lib.byref, self.out
+        _lib.check(_lib.lib().icrl_sample_episodes(b(self.e), b(self.nm), b(self.ps), p(self.noise), p(self.lo), p(self.hi), self.eps_per, self.rows_per,
+                                                   int(self.deterministic), 1, p(out["orig_obs"]), p(out["obs"]), p(out["actions"]),
+                                                   p(out["ep_rewards"]), p(out["ep_lengths"]), _lib.current_stream()), "icrl_sample_episodes")
 
-    # parallel=False keeps fixed-length episodes sequential (a test hook); early-ending envs are tried speculatively unless
-    # SPECULATIVE_EPISODES is switched off
-    n_streams = 1 if (n_episodes == 1 or (fixed_len and not parallel) or (not fixed_len and not SPECULATIVE_EPISODES)) else n_episodes
-    out, st, lengths = launch(n_streams)
-    if n_streams > 1 and not fixed_len and not np.all(lengths == max_steps):
-        n_streams = 1                                  # an episode ended early: its successors' stream positions were wrong
-        out, st, lengths = launch(1)
-    # leave the env where the sequential loop would have left it
-    total = int(lengths.sum())
-    senv.step_count.fill_(int(np.uint32((base + total) & 0xFFFFFFFF).view(np.int32)))
-    senv.s.copy_(st["s"][-1:]); senv.t_ep.zero_()
-    env.old_obs = senv.s
-    if n_streams == 1:
-        keep = torch.arange(total, device=dev)
-    else:
-        keep = torch.arange(rows, device=dev)        # full-length episodes: every row is used
-    return out, lengths, keep
+    def finish(self, lengths=None):
+        """lengths: ep_lengths already on the host, or None (read here).  False: an episode ended early under speculation (its
+        successors' stream positions were wrong) — prepare(1), launch() and finish() again."""
+        if lengths is None:
+            lengths = self.out["ep_lengths"].cpu().numpy()
+        lengths = np.asarray(lengths).astype(np.int64)
+        if self.n_streams > 1 and not self.fixed_len and not np.all(lengths == self.max_steps):
+            return False
+        senv, env, dev = self.senv, self.env, self.dev
+        # leave the env where the sequential loop would have left it
+        total = int(lengths.sum())
+        senv.step_count.fill_(int(np.uint32((self.base + total) & 0xFFFFFFFF).view(np.int32)))
+        senv.s.copy_(self.st["s"][-1:]); senv.t_ep.zero_()
+        env.old_obs = senv.s
+        self.lengths = lengths
+        self.keep = None if (self.n_streams > 1 or total == self.rows) else total      # full-length episodes: every row is used
+        return True
+
+    def rows_of(self, name):
+        x = self.out[name]
+        return x if self.keep is None else x[:self.keep]
+
+
+def _run_episodes(agent, env, n_episodes, deterministic, noise, parallel):
+    run = EpisodeRun(agent, env, n_episodes, deterministic, noise, parallel).prepare()
+    run.launch()
+    if not run.finish():
+        run.prepare(1).launch()
+        assert run.finish()
+    return run
 
 
 def sample_from_agent(agent, env, rollouts, noise=None, parallel=True):
@@ -133,17 +171,25 @@ def sample_from_agent(agent, env, rollouts, noise=None, parallel=True):
     device tensors [sum(lengths), ...] holding the observation AFTER each step next to the (clipped) action of that step;
     rewards / lengths are numpy arrays per episode.  With parallel=True the `rollouts` fixed-length episodes of the 1-env loop
     run as independent streams whose random-stream counters are offset exactly as the sequential loop would advance them."""
-    out, lengths, keep = _run_episodes(agent, env, rollouts, False, noise, parallel)
-    return (out["orig_obs"][keep], out["obs"][keep], out["actions"][keep], out["ep_rewards"].cpu().numpy(), lengths)
+    return sample_result(_run_episodes(agent, env, rollouts, False, noise, parallel))
+
+
+def sample_result(run, ep_rewards=None):
+    return (run.rows_of("orig_obs"), run.rows_of("obs"), run.rows_of("actions"),
+            run.out["ep_rewards"].cpu().numpy() if ep_rewards is None else np.asarray(ep_rewards), run.lengths)
 
 
 def evaluate_policy(model, env, n_eval_episodes=10, deterministic=True, render=False, callback=None, reward_threshold=None,
                     return_episode_rewards=False, noise=None):
     """ref: stable_baselines3/common/evaluation.py:10-67 (sequential episodes on one env)."""
-    out, lengths, _ = _run_episodes(model, env, n_eval_episodes, deterministic, noise, parallel=False)
-    ep_rewards = out["ep_rewards"].cpu().numpy()
+    run = _run_episodes(model, env, n_eval_episodes, deterministic, noise, parallel=False)
+    return evaluate_result(run, None, reward_threshold, return_episode_rewards)
+
+
+def evaluate_result(run, ep_rewards=None, reward_threshold=None, return_episode_rewards=False):
+    ep_rewards = run.out["ep_rewards"].cpu().numpy() if ep_rewards is None else np.asarray(ep_rewards)
     if return_episode_rewards:
-        return list(ep_rewards), list(lengths)
+        return list(ep_rewards), list(run.lengths)
     mean_reward, std_reward = float(np.mean(ep_rewards)), float(np.std(ep_rewards))
     if reward_threshold is not None:
         assert mean_reward > reward_threshold

@@ -117,10 +117,10 @@ typedef struct {
   int* status;           /* [1] or NULL: the persistent rollout ORs bit 0 into it when an inter-workgroup exchange timed out
                           * (a workgroup was not resident); the buffer contents are then invalid and the caller must raise */
   void* xch_ws;          /* optional exchange workspace of the persistent rollout (device memory, any contents) ... */
-  long long xch_ws_bytes;/* ... and its size; >= ICRL_ROLLOUT_WS_BYTES(N, obs) always suffices.  NULL / too small: the not yet
+  long long xch_ws_bytes;/* ... and its size; >= ICRL_ROLLOUT_WS_BYTES(N, obs) suffices for both persistent kernels.  NULL / too small: the not yet
                           * computed reward_advantages plane of the buffer is used when T is large enough, else per-step launches */
 } icrl_agent_t;
-#define ICRL_ROLLOUT_WS_BYTES(n_envs, obs_dim) (16 * (size_t)(n_envs) * (2 * (size_t)(obs_dim) + 4) + 16 * (4 * (size_t)(obs_dim) + 4) + 1024)
+#define ICRL_ROLLOUT_WS_BYTES(n_envs, obs_dim) (48 * (size_t)(n_envs) * (size_t)(obs_dim) + 96 * (size_t)(n_envs) + 64 * (size_t)(obs_dim) + 2048)
 
 /* PPO-Lagrangian update hyper-parameters (stable_baselines3/ppo_lag/ppo_lag.py:67-103,177-196; Adam eps 1e-5 from
  * common/policies.py:357-361). */
@@ -291,6 +291,92 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
 int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                        const icrl_buffer_t* buf, const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp,
                        float* stats, void* sync_ws, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Batched forms: several INDEPENDENT runs (seeds) of identical shape in ONE launch, run = blockIdx.y
+ * ------------------------------------------------------------------------------------------------------------------
+ * One run of BASELINE configs[1] occupies 3 CUs during its update and 64 during a rollout; the reference runs seeds as separate
+ * processes (README.md:14-21, one `python run_me.py` per seed).  Here n_runs runs share one grid: every *_batch entry point takes
+ * an array of n_runs job descriptors in HOST memory (same fields as the arguments of the single-run entry point it mirrors),
+ * requires all runs to agree in every shape that decides the grid (refused otherwise), and computes for each run exactly what
+ * the single-run call computes (bit-identical: tests/test_seed_batch_gpu.py).
+ *   args_ws: device scratch of >= n_runs * ICRL_BATCH_ARGS_BYTES bytes, any contents; it receives the per-run argument blocks
+ *            (written on `stream` before the launch) and must not be reused by another call before this one has completed. */
+#define ICRL_BATCH_ARGS_BYTES 1024
+
+/* icrl_rollout_collect_ex for n_runs runs: ONE persistent launch of grid (n_envs, n_runs) + ONE batched dual-GAE launch (do_gae
+ * bit 0).  Batched form exists for the one-workgroup-per-env persistent kernel only (n_envs <= 128, n_envs x obs_dim <= 4096:
+ * BASELINE configs[1]); every run needs its exchange workspace (icrl_agent_t.xch_ws) or T * N * 4 >= ICRL_ROLLOUT_WS_BYTES.
+ * args_ws: 2 x n_runs x ICRL_BATCH_ARGS_BYTES (rollout + GAE argument blocks). */
+typedef struct {
+  const icrl_env_t* env;
+  const icrl_norm_t* nm;
+  const icrl_policy_t* pol;
+  const icrl_costnet_t* cn;     /* NULL in every run or in none */
+  const icrl_buffer_t* buf;
+  const icrl_agent_t* ag;
+  const float* noise;           /* [T, N, act] */
+} icrl_rollout_job_t;
+int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* jobs, const float* action_low, const float* action_high,
+                               double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
+                               int do_gae, void* args_ws, long long args_ws_bytes, void* stream);
+
+/* icrl_gae_dual_ws for n_runs [T,N] rollouts of one shape: ONE launch of the two-level scan, grid (tiles * C, n_runs), every run
+ * with its own workspace; shapes the split scan does not serve are issued as n_runs single launches. */
+typedef struct {
+  const float *rewards, *costs, *reward_values, *cost_values, *dones, *last_v_r, *last_v_c;
+  const uint8_t* last_dones;
+  float *adv_r, *adv_c, *ret_r, *ret_c;
+  void* ws;
+  long long ws_bytes;
+} icrl_gae_job_t;
+int icrl_gae_dual_batch(int n_runs, const icrl_gae_job_t* jobs, int T, int N, double reward_gamma, double reward_gae_lambda,
+                        double cost_gamma, double cost_gae_lambda, void* args_ws, long long args_ws_bytes, void* stream);
+
+/* icrl_sample_episodes for n_runs runs: grid (n_streams, n_runs); every run has its own env streams, frozen normaliser, policy,
+ * noise and outputs; the shape arguments are common. */
+typedef struct {
+  const icrl_env_t* env;
+  const icrl_norm_t* nm;
+  const icrl_policy_t* pol;
+  const float* noise;
+  double *orig_obs, *obs;
+  float* actions;
+  double* ep_rewards;
+  int32_t* ep_lengths;
+} icrl_sample_job_t;
+int icrl_sample_episodes_batch(int n_runs, const icrl_sample_job_t* jobs, const float* action_low, const float* action_high,
+                               int episodes_per_stream, int rows_per_stream, int deterministic, int do_reset,
+                               void* args_ws, long long args_ws_bytes, void* stream);
+
+/* icrl_cn_train (full-batch mode) for n_runs constraint nets of one architecture: the four launches of an iteration carry all runs
+ * (grid.y = run; row counts may differ between runs: grids are sized for the largest, iteration counts likewise). */
+typedef struct {
+  const icrl_costnet_t* cn;
+  float *exp_avg, *exp_avg_sq;
+  int32_t* adam_step;
+  const float *nominal, *expert;
+  int32_t Nn, Ne;
+  const int32_t *ep_offsets, *row_episode;
+  int32_t n_ep, _pad;
+  const icrl_cn_hyper_t* hp;
+  float *work, *metrics;
+} icrl_cn_train_job_t;
+int icrl_cn_train_batch(int n_runs, const icrl_cn_train_job_t* jobs, void* args_ws, long long args_ws_bytes, void* stream);
+
+/* icrl_ppo_lag_train for n_runs runs: grid (3 | 6, n_runs) persistent workgroups. */
+typedef struct {
+  const icrl_policy_t* pol;
+  float *exp_avg, *exp_avg_sq;
+  int32_t* adam_step;
+  const icrl_buffer_t* buf;
+  const int32_t* perms;
+  const float* nu;
+  const icrl_ppo_hyper_t* hp;
+  float* stats;
+  void* sync_ws;
+} icrl_ppo_train_job_t;
+int icrl_ppo_lag_train_batch(int n_runs, const icrl_ppo_train_job_t* jobs, void* args_ws, long long args_ws_bytes, void* stream);
 
 /* ConstraintNet.prepare_data (icrl/constraint_net.py:258-270): out[n,:] = float32(concat(clip(normalise(obs)), clip(one-hot?
  * acs))[select_dim]).  obs [N,obs] float64, acs [N,acs] float32 (class index when discrete), out [N,in_dim] float32. */

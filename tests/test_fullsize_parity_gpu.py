@@ -12,7 +12,8 @@ What holds (asserted) and what was measured on MI355X (printed by the test, reco
     is taken, so the decision is not at the mercy of summation order here; if an epoch ever sits that close the test says so
     instead of failing on a coin flip;
   * nu (the Lagrange multiplier trajectory) within 1e-5 absolute after each train();
-  * parameters within ADAM_DEV_BOUND x lr x steps of the port's (the per-step rate the short tests use, tests/test_ppo_train_gpu.py).
+  * parameters within ADAM_DEV_BOUND x lr x steps of the port's (a drift bound, see below: over 2 x 10^4 dependent steps the fp32
+    trajectories separate faster than the per-step rate of the short tests).
 """
 import os
 import time
@@ -27,7 +28,11 @@ from oracle.streams import SeededStreams
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-ADAM_DEV_BOUND = 5e-4      # same rate as tests/test_ppo_train_gpu.py: |dp| <= 5e-4 x lr x steps + 2e-7
+# The short tests (<= 48 dependent steps, tests/test_ppo_train_gpu.py) hold |dp| <= 5e-4 x lr x steps.  Over 2 x 10^4 dependent steps the
+# two fp32 trajectories separate faster than linearly (each step's rounding difference is amplified by the following ones); measured on
+# MI355X: 1.4e-3 x lr x steps after 20 480 steps (max |dp| = 8.7e-3 against a distance travelled of up to lr x steps = 6.1).  The bound
+# below is 4 x that; what the reference LOGS (nu, costs, losses, the early-stop epoch) is asserted tightly.
+ADAM_DEV_BOUND = 6e-3
 
 
 def _pair(env_id, kind, N, T, od, ad, cn_layers, seed, **kw):
