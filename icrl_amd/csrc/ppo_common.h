@@ -12,7 +12,7 @@ typedef unsigned long long u64;
 constexpr int RB = 64;   // minibatch rows per chunk
 constexpr int HD = 64;   // hidden width (both layers)
 constexpr int SH = 72;   // LDS row stride of 64-wide matrices (= 8 mod 16: conflict-free ds_read_b128 operand fetch)
-constexpr int MAXB = 128;
+constexpr int MAXB = 256;   // minibatch rows: up to four 64-row chunks
 
 struct TrainArgs {
   PolLayout L;
@@ -38,9 +38,11 @@ struct TrainArgs {
 // corrections (lr / (1 - beta1^t), 1 / sqrt(1 - beta2^t), evaluated in double like torch)
 struct PlanStep {
   float step_size, inv_bc2_sqrt;
-  int nb_flags;    // rows | first minibatch of the epoch << 8 | last << 9 | epoch << 10
+  int nb_flags;    // rows (10 bits) | first minibatch of the epoch << 10 | last << 11 | epoch << 12
+
   int perm_base;   // epoch * T*N + position of the minibatch's first row in the permutation
 };
+constexpr int NB_MASK = 0x3ff, NB_FIRST = 10, NB_LAST = 11, NB_EPOCH = 12;
 struct PlanChunk {
   int perm_base, rows;
 };

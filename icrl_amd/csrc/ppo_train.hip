@@ -886,7 +886,7 @@ __global__ void ppo_plan_kernel(const int* adam_t, int n_steps, int n_mb, int n_
   const int g0 = e * cpe + mb * cpm, nch = (nb + RB - 1) / RB;
   const double t = (double)(adam_t[0] + i + 1);
   steps[i] = PlanStep{(float)(lr / (1.0 - pow(b1, t))), (float)(1.0 / sqrt(1.0 - pow(b2, t))),
-                      nb | ((mb == 0) << 8) | ((mb == n_mb - 1) << 9) | (e << 10), e * n_total + p};
+                      nb | ((mb == 0) << NB_FIRST) | ((mb == n_mb - 1) << NB_LAST) | (e << NB_EPOCH), e * n_total + p};
   if (two_per_step) {      // two workgroups per network: chunk c of step i at 2 i + c, an absent second chunk as 0 rows
     for (int c = 0; c < 2; ++c) chunks[2 * i + c] = c < nch ? PlanChunk{e * n_total + p + RB * c, nb - RB * c < RB ? nb - RB * c : RB} : PlanChunk{0, 0};
     if (i == n_steps - 1)
@@ -924,7 +924,10 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   if (pol->obs_dim < 1 || pol->obs_dim > 128 || pol->act_dim < 1 || pol->act_dim > 16)
     return bad(fail("icrl_ppo_lag_train: obs_dim %d (1..128) / act_dim %d (1..16)", pol->obs_dim, pol->act_dim));
   if (hp->batch_size < 2 || hp->batch_size > MAXB || hp->n_epochs < 1)
-    return bad(fail("icrl_ppo_lag_train: batch_size %d (2..%d: one minibatch = at most two 64-row chunks of one workgroup), n_epochs %d (>= 1)", hp->batch_size, MAXB, hp->n_epochs));
+    return bad(fail("icrl_ppo_lag_train: batch_size %d (2..%d: one minibatch = at most four 64-row chunks of one workgroup), n_epochs %d (>= 1)", hp->batch_size, MAXB, hp->n_epochs));
+  if (hp->n_epochs >= (1 << 19)) return bad(fail("icrl_ppo_lag_train: n_epochs %d, limit 2^19", hp->n_epochs));
+  if (hp->batch_size > 128 && (hp->_pad & 2))
+    return bad(fail("icrl_ppo_lag_train: batch_size %d: the column-split tiles kernel (hp->_pad & 2) stops at 128 rows", hp->batch_size));
   if (buf->obs_dim != pol->obs_dim || buf->T < 1)
     return bad(fail("icrl_ppo_lag_train: buffer obs_dim %d vs policy %d, T = %d", buf->obs_dim, pol->obs_dim, buf->T));
   if ((long long)buf->T * buf->N >= (1ll << 31) || (long long)buf->T * buf->N * (pol->obs_dim > 16 ? pol->obs_dim : 16) >= (1ll << 30))
@@ -942,7 +945,10 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   const int nt1 = (pol->obs_dim + 15) / 16;
   // default: wave pairs (two waves per SIMD, 6 barriers per step); hp._pad & 4: row-owning waves (one wave per SIMD, 3 barriers
   // per step; 5 when obs > 64); hp._pad & 2: the column-split tiles kernel
-  if (nt1 > 8 || (hp->_pad & 2)) return 3;
+  if (nt1 > 8 || (hp->_pad & 2)) {
+    if (hp->batch_size > 128) return bad(fail("icrl_ppo_lag_train: batch_size %d with obs_dim %d: the column-split tiles kernel stops at 128 rows", hp->batch_size, pol->obs_dim));
+    return 3;
+  }
   const int n_total = buf->T * buf->N;
   const int n_mb = (n_total + hp->batch_size - 1) / hp->batch_size;
   const long long n_steps = (long long)hp->n_epochs * n_mb;
@@ -960,7 +966,7 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   // with TWO workgroups per network when a minibatch has two chunks (each computes one, partial gradients exchanged;
   // hp._pad & 8 keeps one workgroup per network)
   const bool rows = (hp->_pad & 4) || nt1 > 4;
-  const bool split = rows && hp->batch_size > RB && !(hp->_pad & 8);
+  const bool split = rows && hp->batch_size > RB && hp->batch_size <= 2 * RB && !(hp->_pad & 8);     // (three or four chunks: one workgroup walks them)
   hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
                      n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks, (int)split);
   if (split) {

@@ -258,7 +258,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   // while chunk g is processed.  The 16 rows of tile rt are staged by the 128 threads of the wave pair (rt, *): 8 per row.
   // ---------------------------------------------------------------------------------------------------------------
   const int gb_row = 16 * rt + (lane >> 2), gpart = (lane & 3) + 4 * fh;
-  const int stid = tid - 64;      // advantage statistics: row stid of the minibatch lives in waves 1 (and 2)
+  const int stid = tid - 64;      // advantage statistics: row stid of the minibatch lives in waves 1 .. 4 (<= 256 rows)
   auto ld_step = [&](int i) -> int4 {
     asm volatile("" : "+v"(i));
     return *reinterpret_cast<const int4*>(plan_steps + i);
@@ -274,7 +274,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   // simply re-read its first row; they are masked where it matters (`valid`, stats_partials).
   auto chunk_idx = [&](const int2& c) -> int { return perms[c.x + (gb_row < c.y ? gb_row : 0)]; };      // {perm_base, rows}
   auto stat_idx = [&](const int4& p) -> int {
-    const int nbp = p.z & 0xff;
+    const int nbp = p.z & NB_MASK;
     return perms[p.w + ((stid >= 0 && stid < nbp) ? stid : 0)];
   };
   // Rows beyond the minibatch (idx < 0) and observation components beyond obs are fetched from a clamped, always valid address
@@ -309,18 +309,25 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     sar = p_s1[off];
     sac = p_s2[off];
   };
+  const bool big_mb = a.hp.batch_size > 128;     // minibatches of 129..256 rows: waves 3 and 4 hold statistics rows too
   auto stats_partials = [&](int nb) {
-    if (role != 0 || (w != 1 && w != 2)) return;
+    if (role != 0 || w == 0 || w > (big_mb ? 4 : 2)) return;
     const bool in = stid < nb;
     const float s_r = wave_sum_fast(in ? sar : 0.f), s_c = wave_sum_fast(in ? sac : 0.f), s_rr = wave_sum_fast(in ? sar * sar : 0.f);
-    if (lane == 0) { sm[S::MISC + 13 + 3 * w] = s_r; sm[S::MISC + 14 + 3 * w] = s_c; sm[S::MISC + 15 + 3 * w] = s_rr; }
+    if (lane == 0) { sm[S::MISC + 3 * (w - 1)] = s_r; sm[S::MISC + 3 * (w - 1) + 1] = s_c; sm[S::MISC + 3 * (w - 1) + 2] = s_rr; }
   };
   float mean_r = 0.f, istd_r = 1.f, mean_c = 0.f;
   auto read_stats = [&](int nb) {
     if (role != 0) return;
-    const float s_r = sm[S::MISC + 16] + sm[S::MISC + 19];
-    const float s_c = sm[S::MISC + 17] + sm[S::MISC + 20];
-    const float s_rr = sm[S::MISC + 18] + sm[S::MISC + 21];
+    // MISC[0..11]: (sum A_r, sum A_c, sum A_r^2) of waves 1..4; waves 3, 4 leave zeros for minibatches of <= 128 rows
+    float s_r = sm[S::MISC + 0] + sm[S::MISC + 3];
+    float s_c = sm[S::MISC + 1] + sm[S::MISC + 4];
+    float s_rr = sm[S::MISC + 2] + sm[S::MISC + 5];
+    if (big_mb) {
+      s_r += sm[S::MISC + 6] + sm[S::MISC + 9];
+      s_c += sm[S::MISC + 7] + sm[S::MISC + 10];
+      s_rr += sm[S::MISC + 8] + sm[S::MISC + 11];
+    }
     const float inv = __builtin_amdgcn_rcpf((float)nb);
     mean_r = s_r * inv;
     mean_c = s_c * inv;
@@ -374,9 +381,9 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   refresh_gauss();
   int xcur = S::XT0;
   commit_rows(xcur);
-  stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & 0xff);
+  stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
   __syncthreads();
-  read_stats(__builtin_amdgcn_readfirstlane(ps_next.z) & 0xff);
+  read_stats(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
   const float inv_n_mb = 1.f / (float)((T * N + a.hp.batch_size - 1) / a.hp.batch_size);
 
   const bool prof = (a.hp._pad & 1) != 0;
@@ -396,7 +403,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     ps.perm_base = 0;
     ps_next = ps_nx2; ps_nx2 = ps_nx3;
     ps_nx3 = ld_step(st + 3 < n_steps + 2 ? st + 3 : n_steps + 1);
-    const int nb = ps.nb_flags & 0xff;
+    const int nb = ps.nb_flags & NB_MASK;
     const float inv_nb = __builtin_amdgcn_rcpf((float)nb);
     const float c_mean_r = mean_r, c_mean_c = mean_c, c_istd_r = istd_r;
     const float cpol_nb = inv_nb * __builtin_amdgcn_rcpf(1.f + nu);
@@ -804,10 +811,10 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     if (lane == 0) {
       bool want_stop = false;
       float mean_kl = 0.f;
-      const bool last_mb = (ps.nb_flags >> 9) & 1;
-      const int epoch = ps.nb_flags >> 10;
+      const bool last_mb = (ps.nb_flags >> NB_LAST) & 1;
+      const int epoch = ps.nb_flags >> NB_EPOCH;
       if (book && role == 0) {   // the early-stop decision rides on the granule of the policy workgroup's wave 3
-        if ((ps.nb_flags >> 8) & 1) kl_sum = 0.f;
+        if ((ps.nb_flags >> NB_FIRST) & 1) kl_sum = 0.f;
         kl_sum += mb_s3 * inv_nb;
         if (last_mb) {
           mean_kl = kl_sum * inv_n_mb;
@@ -847,8 +854,8 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     FSTAMP(14)  // norm + publish
     // ---- while the granules travel: stage the next minibatch (rows -> the other X^T buffer, advantage statistics)
     const int xnext = S::XDB ? (xcur == S::XT0 ? S::XT1 : S::XT0) : xcur;
+    const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK;
     commit_rows(xnext);
-    const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & 0xff;
     stats_partials(nb_next);
     xcur = xnext;
     FSTAMP(15)  // staging

@@ -248,7 +248,12 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
   };
   auto chunk_idx = [&](const int2& c) -> int { return gb_row < c.y ? perms[c.x + gb_row] : -1; };      // {perm_base, rows}
   auto stat_idx = [&](const int4& p) -> int {       // row stid of that step's minibatch (policy role); p.z = nb_flags, p.w = perm_base
-    return (role == 0 && stid >= 0 && stid < (p.z & 0xff)) ? perms[p.w + stid] : -1;
+    return (role == 0 && stid >= 0 && stid < (p.z & NB_MASK)) ? perms[p.w + stid] : -1;
+  };
+  // minibatches of 193..256 rows (one workgroup walks four chunks): the 192 statistics threads take a second row, stid + 192
+  const bool big_mb = !SPLIT && a.hp.batch_size > 192;
+  auto stat_idx2 = [&](const int4& p) -> int {
+    return (role == 0 && stid >= 0 && stid + 192 < (p.z & NB_MASK)) ? perms[p.w + stid + 192] : -1;
   };
   float px[XR], pact[4], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
   bool pvalid = false;
@@ -278,25 +283,35 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
     if (gpart == 0) { sm[S::OLP + gb_row] = pvalid ? psc0 : 0.f; sm[S::ADR + gb_row] = pvalid ? psc1 : 0.f; sm[S::ADC + gb_row] = pvalid ? psc2 : 0.f; }
   };
   // advantage statistics of a minibatch (policy role): thread 64 + i, i < nb (<= 128: waves 1 and 2) holds row i's (A_r, A_c)
-  float sar = 0.f, sac = 0.f;
+  float sar = 0.f, sac = 0.f, sar2 = 0.f, sac2 = 0.f;
   auto issue_stats = [&](int idx) {
     const unsigned off = idx >= 0 ? (unsigned)idx : 0u;     // rows beyond the minibatch are masked in stats_partials
     sar = p_s1[off];                                       // (only the policy role uses them)
     sac = p_s2[off];
   };
-  // per-wave partial sums (waves 1, 2) into MISC[16..21]; combined by everybody after the next barrier (fixed order)
+  auto issue_stats2 = [&](int idx) {
+    const unsigned off = idx >= 0 ? (unsigned)idx : 0u;
+    sar2 = p_s1[off];
+    sac2 = p_s2[off];
+  };
+  // per-wave partial sums into MISC[32..40] (waves 1, 2; wave 3 as well when a minibatch has more than 128 rows); combined by
+  // everybody after the next barrier (fixed order)
+  const bool wide_mb = !SPLIT && a.hp.batch_size > 128;
   auto stats_partials = [&](int nb) {
-    if (role != 0 || w == 0 || w == 3) return;
-    const bool in = stid < nb;
-    const float s_r = wave_sum_fast(in ? sar : 0.f), s_c = wave_sum_fast(in ? sac : 0.f), s_rr = wave_sum_fast(in ? sar * sar : 0.f);
-    if (lane == 0) { sm[S::MISC + 13 + 3 * w] = s_r; sm[S::MISC + 14 + 3 * w] = s_c; sm[S::MISC + 15 + 3 * w] = s_rr; }
+    if (role != 0 || w == 0 || (w == 3 && !wide_mb)) return;
+    const bool in = stid < nb, in2 = big_mb && stid + 192 < nb;
+    const float v_r = (in ? sar : 0.f) + (in2 ? sar2 : 0.f), v_c = (in ? sac : 0.f) + (in2 ? sac2 : 0.f);
+    const float v_rr = (in ? sar * sar : 0.f) + (in2 ? sar2 * sar2 : 0.f);
+    const float s_r = wave_sum_fast(v_r), s_c = wave_sum_fast(v_c), s_rr = wave_sum_fast(v_rr);
+    if (lane == 0) { sm[S::MISC + 29 + 3 * w] = s_r; sm[S::MISC + 30 + 3 * w] = s_c; sm[S::MISC + 31 + 3 * w] = s_rr; }
   };
   float mean_r = 0.f, istd_r = 1.f, mean_c = 0.f;
   auto read_stats = [&](int nb) {
     if (role != 0) return;
-    const float s_r = sm[S::MISC + 16] + sm[S::MISC + 19];
-    const float s_c = sm[S::MISC + 17] + sm[S::MISC + 20];
-    const float s_rr = sm[S::MISC + 18] + sm[S::MISC + 21];
+    float s_r = sm[S::MISC + 32] + sm[S::MISC + 35];
+    float s_c = sm[S::MISC + 33] + sm[S::MISC + 36];
+    float s_rr = sm[S::MISC + 34] + sm[S::MISC + 37];
+    if (wide_mb) { s_r += sm[S::MISC + 38]; s_c += sm[S::MISC + 39]; s_rr += sm[S::MISC + 40]; }
     const float inv = __builtin_amdgcn_rcpf((float)nb);
     mean_r = s_r * inv;
     mean_c = s_c * inv;
@@ -331,12 +346,14 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
   int4 ps_next = ld_step(0), ps_nx2 = ld_step(1), ps_nx3 = ld_step(2);   // steps st, st + 1, st + 2 at the loop top
   issue_stats(stat_idx(ps_next));
   int sidx_next = stat_idx(ps_nx2);
+  int sidx2_next = -1;
+  if (big_mb) { issue_stats2(stat_idx2(ps_next)); sidx2_next = stat_idx2(ps_nx2); }
   refresh_gauss();
   int xcur = S::XT0;                    // X^T buffer of the chunk being processed
   commit_rows(xcur);
-  stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & 0xff);
+  stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
   __syncthreads();
-  read_stats(__builtin_amdgcn_readfirstlane(ps_next.z) & 0xff);
+  read_stats(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
   const float inv_n_mb = 1.f / (float)((T * N + a.hp.batch_size - 1) / a.hp.batch_size);
 
   const bool prof = (a.hp._pad & 1) != 0;
@@ -353,12 +370,13 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
     ps.perm_base = 0;
     ps_next = ps_nx2; ps_nx2 = ps_nx3;
     ps_nx3 = ld_step(st + 3 < n_steps + 2 ? st + 3 : n_steps + 1);     // (the table carries two zero entries at its end)
-    const int nb = ps.nb_flags & 0xff;
+    const int nb = ps.nb_flags & NB_MASK;
     const float inv_nb = __builtin_amdgcn_rcpf((float)nb);
     const float c_mean_r = mean_r, c_mean_c = mean_c, c_istd_r = istd_r;   // statistics of THIS minibatch
     const float cpol_nb = inv_nb * __builtin_amdgcn_rcpf(1.f + nu);
     issue_stats(sidx_next);              // advantages of the NEXT minibatch's rows (indices loaded a step ago) ...
     sidx_next = stat_idx(ps_nx2);        // ... and the indices of the one after (step st + 2; its plan entry came a step ago)
+    if (big_mb) { issue_stats2(sidx2_next); sidx2_next = stat_idx2(ps_nx2); }
     float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f, mb_s4 = 0.f;  // bookkeeping lane: minibatch sums of the loss statistics
 
     const int n_chunks = SPLIT ? 1 : (nb + RB - 1) / RB;
@@ -824,10 +842,10 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
     if (lane == 0) {
       bool want_stop = false;
       float mean_kl = 0.f;
-      const bool last_mb = (ps.nb_flags >> 9) & 1;
-      const int epoch = ps.nb_flags >> 10;
+      const bool last_mb = (ps.nb_flags >> NB_LAST) & 1;
+      const int epoch = ps.nb_flags >> NB_EPOCH;
       if (book && role == 0) {   // the early-stop decision rides on the granule of the policy workgroup's wave 3
-        if ((ps.nb_flags >> 8) & 1) kl_sum = 0.f;
+        if ((ps.nb_flags >> NB_FIRST) & 1) kl_sum = 0.f;
         kl_sum += mb_s3 * inv_nb;
         if (last_mb) {
           mean_kl = kl_sum * inv_n_mb;
@@ -860,7 +878,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
     // ---- while the granules travel: stage the next minibatch (rows -> the other X^T buffer, advantage statistics)
     const int xnext = S::XDB ? (xcur == S::XT0 ? S::XT1 : S::XT0) : xcur;
     commit_rows(xnext);
-    const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & 0xff;
+    const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK;
     stats_partials(nb_next);
     xcur = xnext;
     if (tid < 12) {

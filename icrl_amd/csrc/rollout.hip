@@ -993,14 +993,20 @@ constexpr int GRAN_MAX = 12;    // granules a thread polls per step in granule m
 // GRAN: every exchanged 32-bit half-word travels in its own 8-byte granule together with the step number (the datum is the
 // flag: cdna_hip_programming.md Guideline 16).  Consumers poll the granules themselves, so a step costs ONE trip through the
 // memory system after the slowest producer instead of three (drain stores -> raise flag -> see flag -> fetch data).
+// dynamic LDS of the persistent rollout: the transposed observation block [obs][N + 64] and the dynamics matrix [obs][act], sized
+// for the launch's shapes (HC x 64: 19 KB instead of the 114 KB of the largest admissible shape, so that several workgroups —
+// several runs of a batched launch — share a CU)
+static inline size_t persist_dyn_lds(int N, int O, int A) { return ((size_t)O * (size_t)(N + 64) + (size_t)O * (size_t)A) * sizeof(double); }
+
 template <int OCT, int CIT, bool GRAN>
 __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ ActShared sh;
-  __shared__ double chunk[NORM_CHUNK + 64 * MAX_OBS];     // raw observations of the step, TRANSPOSED: [obs][NP], NP = N + 64
+  double* const chunk = dyn_lds;                          // raw observations of the step, TRANSPOSED: [obs][NP], NP = N + 64
+  double* const Bl = dyn_lds + p.act.pl.O * (p.act.env.n_envs + 64);
   __shared__ double vec[2][128], dev2[2][128], ret_s[128], cret_s[128], rawr_s[128];
   __shared__ float rawc_s[128];
   __shared__ double dens[2];
-  __shared__ double Bl[MAX_OBS * MAX_ACT];
   __shared__ float noise_s[MAX_ACT], alow_s[MAX_ACT], ahigh_s[MAX_ACT];     // action box: read every step, kept out of global memory
   __shared__ int done_s[128];
   __shared__ int last_done_s;
@@ -1018,7 +1024,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
   const int NA = a.pl.discrete ? 1 : A;       // noise values per env step
   const int NP = N + 64;                      // padded column length of the transposed observation block
   const int G = 2 * O + 4;                    // granules per env and step: obs halves, reward halves, cost, done
-  for (int i = tid; i < NORM_CHUNK + 64 * MAX_OBS; i += 256) chunk[i] = 0.0;
+  for (int i = tid; i < O * NP; i += 256) chunk[i] = 0.0;
   const bool has_cost = a.has_cn != 0;
   const uint32_t e_key = a.env.key[n];
   uint32_t e_ctr = a.env.step_count[n];
@@ -1242,8 +1248,9 @@ __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) 
 // several independent runs in ONE launch: grid (N, n_runs), run = blockIdx.y, argument blocks in device memory.  Workgroups are
 // dispatched x-fastest, so a run's N workgroups become resident together and the oldest run of the grid is always complete: runs
 // whose workgroups do not fit yet simply start when earlier runs have finished (the exchange waits are bounded by seconds).
-template <int OCT, int CIT, bool GRAN>
-__global__ void __launch_bounds__(256) rollout_persistent_batch_kernel(const PersistArgs* __restrict__ runs) {
+// MINW: waves per SIMD the register allocation must leave room for (= workgroups per CU: each workgroup has one wave per SIMD)
+template <int OCT, int CIT, bool GRAN, int MINW>
+__global__ void __launch_bounds__(256, MINW) rollout_persistent_batch_kernel(const PersistArgs* __restrict__ runs) {
   __shared__ PersistArgs p;
   {
     const unsigned* src = reinterpret_cast<const unsigned*>(runs + blockIdx.y);
@@ -1551,6 +1558,407 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
   }
   if (w == 1 && (own_ret || own_cost))
     for (int i = lane; i < N; i += WAVE) { if (own_ret) nm.ret[i] = retbuf[i]; else nm.cost_ret[i] = retbuf[i]; }
+}
+
+// =================================================================================================================
+// persistent rollout with SEVERAL environments per workgroup, evaluated INTERLEAVED (throughput form)
+// =================================================================================================================
+// Same contract and bit-identical results as rollout_persistent_kernel / rollout_wide_kernel (every per-env operation is the
+// same instruction sequence: k-ascending fmaf chains with the weights of `lane` in registers, the same tanh, the same float64
+// env step, numpy-ordered statistics), different use of the machine.  Those kernels give one environment a workgroup (or walk
+// a workgroup's environments one after the other): an env step is then a 7-8 k cycle chain of dependent latencies.  Here workgroup
+// g of a run serves E environments g, g + G, ... and runs every layer for all of them at once: the lane that owns hidden unit j
+// keeps ONE weight in a register per input and feeds it to E independent accumulator chains, the inputs come from LDS as
+// broadcast reads.  E environments cost little more than one, so a run needs G = N / E workgroups instead of N, all runs of a
+// batched launch (icrl_rollout_collect_batch, run = blockIdx.y) are resident together, and the exchange shrinks with G:
+//   phase A   layers 1, 2, heads for E envs (waves pi | vf | cvf); env steps spread over waves 0..2, cost net on wave 3;
+//             raw obs / reward / cost / done published as self-validating granules (as in the other two kernels)
+//   phase B1  statistic s (observation column, ret_rms, cost_rms) is owned by wave s / G of workgroup s % G: up to four
+//             owners per workgroup work side by side (gather 2 N granules, numpy-ordered moments, merge, publish)
+//   phase B2  every workgroup reads the 4 obs + 4 statistics granules and normalises its E envs
+constexpr int MULTI_OP = 128;     // padded per-env row of the LDS state arrays (>= MAX_OBS)
+
+template <int E>
+struct MultiShared {
+  alignas(16) float x[E][MULTI_OP];          // normalised observation (policy input), pad = 0
+  alignas(16) double s_old[E][MULTI_OP];
+  alignas(16) double s_new[E][MULTI_OP];
+  alignas(16) double olast[E][MULTI_OP];     // normalised observation in float64 (== _last_obs)
+  alignas(16) float h[3][E][MAX_H];
+  alignas(16) float g[3][E][MAX_H];
+  alignas(16) float cx[MAX_CN_IN];
+  alignas(16) float ch[2][MAX_H];
+  float act_raw[E][MAX_ACT], act_clip[E][MAX_ACT], scal[E][4];
+  float noise[2][E][MAX_ACT], alow[MAX_ACT], ahigh[MAX_ACT], cost[E];
+  double rew[E], mean[MAX_OBS], var[MAX_OBS], dens[2];
+  unsigned ctr[E], key[E];
+  int tep[E], last_done[E], done[E];
+};
+
+static inline size_t multi_dyn_lds(int N, int O, int A, int owners) {
+  // dynamics matrix | per owner wave: column buffer (N + 64) | ret / cost owners: previous returns [2][N] | done flags [2][N] bytes
+  return ((size_t)O * A + (size_t)owners * (size_t)(N + 64) + 2 * (size_t)N) * sizeof(double) + 2 * (size_t)((N + 15) / 16 * 16);
+}
+
+// E independent k-ascending fmaf chains (one per environment) against ONE register-resident weight vector W (named directly:
+// handing the register image to a function by address sends it to scratch): inputs X0[e * STRIDE + 0 .. 4 NK4) come from LDS as
+// 16-byte broadcast reads, one group of four inputs at a time.  The compiler fence between the groups keeps the reads of later
+// groups from being issued up front (E x 4 NK4 live registers next to the weights: hundreds of spills); per environment the
+// operation order is the plain chain acc = fmaf(w[k], x[k], acc), k = 0, 1, ...  EB environments are interleaved at a time (a
+// workgroup's E environments go through in E / EB passes of a run-time loop): the weights already take most of the register file.
+#define ICRL_MULTI_CHAINS(W, X0, STRIDE, NK4, ACC)                                                      \
+  {                                                                                                     \
+    _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_) ACC[e_] = 0.f;                                    \
+    _Pragma("unroll") for (int k4_ = 0; k4_ < (NK4); ++k4_) {                                           \
+      f32x4 xv_[EB];                                                                                    \
+      _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_)                                                 \
+        xv_[e_] = *reinterpret_cast<const f32x4*>((X0) + e_ * (STRIDE) + 4 * k4_);                      \
+      _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_) {                                               \
+        ACC[e_] = fmaf(W[4 * k4_ + 0], xv_[e_][0], ACC[e_]);                                            \
+        ACC[e_] = fmaf(W[4 * k4_ + 1], xv_[e_][1], ACC[e_]);                                            \
+        ACC[e_] = fmaf(W[4 * k4_ + 2], xv_[e_][2], ACC[e_]);                                            \
+        ACC[e_] = fmaf(W[4 * k4_ + 3], xv_[e_][3], ACC[e_]);                                            \
+      }                                                                                                 \
+    }                                                                                                   \
+  }
+
+template <int OCT, int CIT, int E>
+__device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
+  constexpr int EB = OCT <= 2 ? 4 : 2;       // environments interleaved at a time
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+  __shared__ MultiShared<E> sh;
+  const ActStepArgs& a = p.act;
+  const icrl_norm_t& nm = p.nm;
+  WaveRegs<OCT, CIT> R;                // policy weights in waves 0..2, cost-net weights in wave 3
+  WaveRegs<OCT, CIT>& C = R;
+  load_pol_regs<OCT>(a.pl, a.PT, R);
+  if (threadIdx.x >= 192 && a.has_cn) load_cn_regs<CIT>(a.cn, a.cl, C);
+  const int g = blockIdx.x, G = p.G;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs, T = p.T;
+  const int AS = a.buf.act_store;
+  const int GX = 2 * O + 4, GS = 4 * O + 4;
+  const int Eg = (N - g + G - 1) / G;                // envs of this workgroup (1 .. E)
+  const bool has_cost = a.has_cn != 0;
+  const bool has_box = a.alow != nullptr && a.ahigh != nullptr;
+  const int n_stats = O + (has_cost ? 2 : 1);
+  const int owners = (n_stats + G - 1) / G;          // owner waves per workgroup (<= 4: checked by the launcher)
+  double* const Bl = dyn_lds;
+  double* const colbuf = Bl + O * a.env.act_dim + (size_t)w * (N + 64);      // this wave's column buffer (owner waves only)
+  double* const retbufs = Bl + O * a.env.act_dim + (size_t)owners * (N + 64);
+  unsigned char* const done_bufs = reinterpret_cast<unsigned char*>(retbufs + 2 * (size_t)N);
+  icrl_env_t env = a.env;
+  for (int i = tid; i < O * a.env.act_dim; i += 256) Bl[i] = a.env.B[i];
+  env.B = Bl;
+  if (tid < MAX_ACT) { sh.alow[tid] = (has_box && tid < A) ? a.alow[tid] : 0.f; sh.ahigh[tid] = (has_box && tid < A) ? a.ahigh[tid] : 0.f; }
+  for (int idx = tid; idx < E * MULTI_OP; idx += 256) {
+    const int e = idx / MULTI_OP, i = idx % MULTI_OP;
+    const bool live = e < Eg && i < O;
+    const int n = g + e * G;
+    const double lo = live ? a.ag.last_obs[(size_t)n * O + i] : 0.0;
+    sh.x[e][i] = (float)lo;
+    sh.olast[e][i] = lo;
+    sh.s_old[e][i] = live ? a.env.s[(size_t)n * O + i] : 0.0;
+    sh.s_new[e][i] = 0.0;
+  }
+  if (tid < E) {
+    const int e = tid, n = g + (e < Eg ? e : 0) * G;
+    sh.ctr[e] = a.env.step_count[n]; sh.tep[e] = a.env.t_ep[n]; sh.last_done[e] = a.ag.last_dones[n]; sh.key[e] = a.env.key[n];
+    sh.rew[e] = 0.0; sh.cost[e] = 0.f; sh.done[e] = 0;
+  }
+  // the statistic this WAVE owns (if any): sid = g + w * G
+  const int sid = g + w * G;
+  const bool owner = w < owners && sid < n_stats;
+  const int own_col = (owner && sid < O) ? sid : -1;
+  const bool own_ret = owner && sid == O, own_cost = owner && has_cost && sid == O + 1;
+  double* const retbuf = retbufs + (own_cost ? (size_t)N : 0);
+  unsigned char* const done_all = done_bufs + (own_cost ? (size_t)((N + 15) / 16 * 16) : 0);
+  double o_mean = 0.0, o_var = 1.0, o_cnt = 0.0;
+  if (own_col >= 0) { o_mean = nm.obs_mean[own_col]; o_var = nm.obs_var[own_col]; o_cnt = nm.obs_count[0]; }
+  if (own_ret) { o_mean = nm.ret_stats[0]; o_var = nm.ret_stats[1]; o_cnt = nm.ret_stats[2]; }
+  if (own_cost) { o_mean = nm.cost_stats[0]; o_var = nm.cost_stats[1]; o_cnt = nm.cost_stats[2]; }
+  if (own_ret || own_cost)
+    for (int i = lane; i < N; i += WAVE) retbuf[i] = own_ret ? nm.ret[i] : nm.cost_ret[i];
+  const int NA = A;                                  // (continuous actions only: the launcher keeps discrete policies elsewhere)
+  if (tid < E * MAX_ACT) {
+    const int e = tid / MAX_ACT, k = tid % MAX_ACT;
+    sh.noise[0][e][k] = (e < Eg && k < NA) ? a.noise[((size_t)(g + e * G)) * NA + k] : 0.f;
+  }
+  int spin_limit = 1 << 22;
+  __syncthreads();
+  for (int t = 0; t < T; ++t) {
+    const int par = t & 1;
+    const unsigned gtag = (unsigned)(t + 1);
+    float noise_next = 0.f;
+    const int pe = tid / MAX_ACT, pk = tid % MAX_ACT;
+    const bool pf = tid < E * MAX_ACT && pe < Eg && pk < NA && t + 1 < T;
+    if (pf) noise_next = a.noise[((size_t)(t + 1) * N + g + pe * G) * NA + pk];
+    // ---------------- phase A: the three MLPs, EB envs interleaved at a time ----------------
+    if (w < 3) {
+      for (int eb = 0; eb < E; eb += EB) {
+        float acc[EB];
+        ICRL_MULTI_CHAINS(R.w1, &sh.x[eb][0], MULTI_OP, 4 * OCT, acc)
+#pragma unroll
+        for (int e = 0; e < EB; ++e) sh.h[w][eb + e][lane] = lane < a.pl.H1 ? fast_tanh(acc[e] + R.b1) : 0.f;
+      }
+    }
+    __syncthreads();
+    if (w < 3) {
+      for (int eb = 0; eb < E; eb += EB) {
+        float acc[EB];
+        ICRL_MULTI_CHAINS(R.w2, &sh.h[w][eb][0], MAX_H, MAX_H / 4, acc)
+#pragma unroll
+        for (int e = 0; e < EB; ++e) sh.g[w][eb + e][lane] = lane < a.pl.H2 ? fast_tanh(acc[e] + R.b2) : 0.f;
+      }
+    }
+    __syncthreads();
+    if (w == 0) {                       // action head + Gaussian sample / log-prob of every env (lane = action index)
+      for (int eb = 0; eb < E; eb += EB) {
+        float acc[EB];
+        ICRL_MULTI_CHAINS(R.wh, &sh.g[0][eb][0], MAX_H, MAX_H / 4, acc)
+#pragma unroll
+        for (int ee = 0; ee < EB; ++ee) {
+          const int e = eb + ee;
+          const float mean = acc[ee] + R.bh;
+          float lp = 0.f;
+          if (lane < A) {
+            const float act = mean + sh.noise[par][e][lane] * R.sd;       // Normal.rsample: loc + eps * scale
+            const float diff = act - mean;
+            lp = -(diff * diff) / R.i2v - R.lsd - LOG_SQRT_2PI_F;
+            sh.act_raw[e][lane] = act;
+            float c = act;
+            if (has_box) c = fminf(fmaxf(act, sh.alow[lane]), sh.ahigh[lane]);
+            sh.act_clip[e][lane] = c;
+          }
+          lp = wave_sum_fast(lp);
+          if (lane == 0) sh.scal[e][2] = lp;
+        }
+      }
+    } else if (w < 3) {                 // value heads
+      for (int e = 0; e < E; ++e) {
+        float part = lane < a.pl.H2 ? R.wh[0] * sh.g[w][e][lane] : 0.f;
+        part = wave_sum_fast(part);
+        if (lane == 0) sh.scal[e][w - 1] = part + R.bh;
+      }
+    }
+    __syncthreads();
+    // ---------------- env steps (waves 0..2: env e on wave e % 3), cost net (wave 3), buffer rows ----------------
+    if (w < 3) {
+      for (int e = w; e < Eg; e += 3) {
+        const int n = g + e * G;
+        const size_t tn = (size_t)t * N + n;
+        unsigned long long* xg = p.xg + ((size_t)par * N + n) * GX;
+        // rows that depend on the pre-step state only
+        float* ob = a.buf.observations + tn * O;
+        float* oob = a.buf.orig_observations + tn * O;
+        for (int i = lane; i < O; i += WAVE) { ob[i] = sh.x[e][i]; oob[i] = (float)sh.s_old[e][i]; }
+        if (lane < AS) a.buf.actions[tn * AS + lane] = sh.act_raw[e][lane];
+        if (lane < A) a.ag.act_clipped[(size_t)n * A + lane] = sh.act_clip[e][lane];
+        if (lane == 0) {
+          a.buf.dones[tn] = (float)sh.last_done[e];
+          a.buf.reward_values[tn] = sh.scal[e][0];
+          a.buf.cost_values[tn] = sh.scal[e][1];
+          a.buf.log_probs[tn] = sh.scal[e][2];
+          a.ag.last_v_r[n] = sh.scal[e][0];
+          a.ag.last_v_c[n] = sh.scal[e][1];
+        }
+        double rew; int done;
+        uint32_t e_ctr = sh.ctr[e];
+        int e_tep = sh.tep[e];
+        env_step_wave(env, n, sh.s_old[e], sh.act_clip[e], sh.key[e], e_ctr, e_tep, sh.s_new[e], rew, done);
+        float* nob = a.buf.new_orig_observations + tn * O;
+        for (int i = lane; i < O; i += WAVE) {
+          const double v = sh.s_new[e][i];
+          nob[i] = (float)v;
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+          gstore(xg + 2 * i, gtag, (unsigned)bits); gstore(xg + 2 * i + 1, gtag, (unsigned)(bits >> 32));
+        }
+        if (lane == 0) {
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(rew);
+          gstore(xg + 2 * O, gtag, (unsigned)bits); gstore(xg + 2 * O + 1, gtag, (unsigned)(bits >> 32));
+          gstore(xg + 2 * O + 3, gtag, (unsigned)done);
+          sh.ctr[e] = e_ctr; sh.tep[e] = e_tep; sh.rew[e] = rew; sh.done[e] = done;
+        }
+      }
+    } else {
+      for (int e = 0; e < Eg; ++e) {
+        const int n = g + e * G;
+        const size_t tn = (size_t)t * N + n;
+        float cost = 0.f;
+        if (a.has_cn) cost = cost_forward_wave<CIT>(a.cn, a.cl, C, sh.s_old[e], sh.act_clip[e], sh.cx, sh.ch);
+        if (lane == 0) {
+          gstore(p.xg + ((size_t)par * N + n) * GX + 2 * O + 2, gtag, __float_as_uint(cost));
+          a.buf.orig_costs[tn] = cost;
+          sh.cost[e] = cost;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    // ---------------- phase B1: owner waves gather their statistic from all envs and publish it ----------------
+    if (own_col >= 0 || own_ret || own_cost) {
+      const unsigned long long* xb = p.xg + (size_t)par * N * GX;
+      const int slot = own_col >= 0 ? 2 * own_col : (own_ret ? 2 * O : 2 * O + 2);
+      const bool wide = !own_cost;                                   // two granules (a float64) per env, or one (the float32 cost)
+      for (int i0 = 0; i0 < N; i0 += 4 * WAVE) {
+        unsigned long long g0[4], g1[4], g2[4];
+        bool ok[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { g0[k] = g1[k] = g2[k] = 0; ok[k] = i0 + k * WAVE + lane >= N; }
+        for (int spins = 0; spins < spin_limit; ++spins) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int i = i0 + k * WAVE + lane;
+            if (!ok[k]) {
+              g0[k] = gload(xb + (size_t)i * GX + slot);
+              g1[k] = wide ? gload(xb + (size_t)i * GX + slot + 1) : g0[k];
+              g2[k] = own_col >= 0 ? g0[k] : gload(xb + (size_t)i * GX + 2 * O + 3);      // done flag (return owners)
+            }
+          }
+          bool all = true;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) ok[k] = (unsigned)(g0[k] >> 32) == gtag && (unsigned)(g1[k] >> 32) == gtag && (unsigned)(g2[k] >> 32) == gtag;
+            all = all && ok[k];
+          }
+          if (__all(all)) break;
+          if (spins + 1 == spin_limit) spin_limit = 1;
+          __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int i = i0 + k * WAVE + lane;
+          if (i < N) {
+            double v;
+            if (wide) v = __longlong_as_double((long long)(((unsigned long long)(unsigned)g1[k] << 32) | (unsigned long long)(unsigned)g0[k]));
+            else v = (double)__uint_as_float((unsigned)g0[k]);
+            if (own_col >= 0) colbuf[i] = v;
+            else {
+              colbuf[i] = retbuf[i] * (own_ret ? nm.reward_gamma : nm.cost_gamma) + v;     // vec_normalize.py:102, 245
+              done_all[i] = (unsigned char)(unsigned)g2[k];
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      double bm, bv;
+      if (own_col >= 0) {
+        column_moments_contig(colbuf, N, bm, bv);                   // every lane computes the same chain (numpy's axis-0 order)
+      } else {
+        bm = np_pairwise_sum_wave(colbuf, N) / (double)N;           // numpy's 1-D pairwise order
+        // returns of finished episodes restart at 0 (vec_normalize.py:99, 241); then the squared deviations in place
+        for (int i = lane; i < N; i += WAVE) { const double c = colbuf[i]; retbuf[i] = done_all[i] ? 0.0 : c; const double d = c - bm; colbuf[i] = d * d; }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        bv = np_pairwise_sum_wave(colbuf, N) / (double)N;
+      }
+      chan_merge(o_mean, o_var, o_cnt, bm, bv, (double)N);
+      o_cnt = (double)N + o_cnt;
+      unsigned long long* sb = p.sg + (size_t)par * GS;
+      if (lane == 0) {
+        if (own_col >= 0) {
+          const unsigned long long mb = (unsigned long long)__double_as_longlong(o_mean), vb = (unsigned long long)__double_as_longlong(o_var);
+          gstore(sb + 4 * own_col, gtag, (unsigned)mb); gstore(sb + 4 * own_col + 1, gtag, (unsigned)(mb >> 32));
+          gstore(sb + 4 * own_col + 2, gtag, (unsigned)vb); gstore(sb + 4 * own_col + 3, gtag, (unsigned)(vb >> 32));
+        } else {
+          const unsigned long long db = (unsigned long long)__double_as_longlong(sqrt(o_var + nm.epsilon));
+          const int k = 4 * O + (own_ret ? 0 : 2);
+          gstore(sb + k, gtag, (unsigned)db); gstore(sb + k + 1, gtag, (unsigned)(db >> 32));
+        }
+      }
+    }
+    // ---------------- phase B2: everybody reads the statistics granules, then normalises its envs ----------------
+    {
+      const unsigned long long* sb = p.sg + (size_t)par * GS;
+      const int total = has_cost ? GS : GS - 2;
+      unsigned* ms = reinterpret_cast<unsigned*>(sh.mean);
+      unsigned* vs = reinterpret_cast<unsigned*>(sh.var);
+      unsigned* ds = reinterpret_cast<unsigned*>(sh.dens);
+      for (int i0 = 0; i0 < total; i0 += 256) {
+        const int i = i0 + tid;
+        unsigned long long gv = (unsigned long long)gtag << 32;
+        bool ok = i >= total;
+        for (int spins = 0; spins < spin_limit && !ok; ++spins) {
+          gv = gload(sb + i);
+          ok = (unsigned)(gv >> 32) == gtag;
+          if (!ok) __builtin_amdgcn_s_sleep(1);
+        }
+        if (!ok) spin_limit = 1;
+        if (i < total) {
+          const unsigned pay = (unsigned)gv;
+          if (i < 4 * O) { const int j = i >> 2, h = i & 3; if (h < 2) ms[2 * j + h] = pay; else vs[2 * j + (h - 2)] = pay; }
+          else ds[i - 4 * O] = pay;
+        }
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < Eg * MULTI_OP; idx += 256) {
+      const int e = idx / MULTI_OP, i = idx % MULTI_OP;
+      if (i < O) {
+        const size_t tn = (size_t)t * N + g + e * G;
+        const double raw = sh.s_new[e][i];
+        double o = raw;
+        if (nm.norm_obs) o = fmin(fmax((o - sh.mean[i]) / sqrt(sh.var[i] + nm.epsilon), -nm.clip_obs), nm.clip_obs);
+        sh.olast[e][i] = o;
+        sh.x[e][i] = (float)o;
+        a.buf.new_observations[tn * O + i] = (float)o;
+        sh.s_old[e][i] = raw;
+      }
+    }
+    if (tid < Eg) {
+      const int e = tid;
+      const size_t tn = (size_t)t * N + g + e * G;
+      double r = sh.rew[e];
+      if (nm.norm_reward) r = fmin(fmax(r / sh.dens[0], -nm.clip_reward), nm.clip_reward);
+      a.buf.rewards[tn] = (float)r;
+      if (has_cost) {
+        double c = (double)sh.cost[e];
+        if (nm.norm_cost) c = fmin(fmax(c / sh.dens[1], -nm.clip_cost), nm.clip_cost);
+        a.buf.costs[tn] = (float)c;
+      }
+      sh.last_done[e] = sh.done[e];
+    }
+    if (pf) sh.noise[par ^ 1][pe][pk] = noise_next;
+    __syncthreads();
+  }
+  if (spin_limit == 1 && a.ag.status != nullptr && (tid & 63) == 0) atomicOr(a.ag.status, 1);
+  // ---- leave the agent / wrapper / normaliser state exactly where the per-step path leaves it
+  for (int idx = tid; idx < Eg * MULTI_OP; idx += 256) {
+    const int e = idx / MULTI_OP, i = idx % MULTI_OP;
+    if (i < O) a.ag.last_obs[(size_t)(g + e * G) * O + i] = sh.olast[e][i];
+  }
+  if (tid < Eg) {
+    const int e = tid, n = g + e * G;
+    a.ag.last_dones[n] = (uint8_t)sh.last_done[e];
+    a.ag.raw_rew[n] = sh.rew[e]; a.ag.dones[n] = (uint8_t)sh.done[e];
+    if (has_cost) a.ag.raw_cost[n] = sh.cost[e];
+  }
+  if (lane == 0) {
+    if (own_col >= 0) { nm.obs_mean[own_col] = o_mean; nm.obs_var[own_col] = o_var; if (own_col == 0) nm.obs_count[0] = o_cnt; }
+    if (own_ret) { nm.ret_stats[0] = o_mean; nm.ret_stats[1] = o_var; nm.ret_stats[2] = o_cnt; }
+    if (own_cost) { nm.cost_stats[0] = o_mean; nm.cost_stats[1] = o_var; nm.cost_stats[2] = o_cnt; }
+  }
+  if (own_ret || own_cost)
+    for (int i = lane; i < N; i += WAVE) { if (own_ret) nm.ret[i] = retbuf[i]; else nm.cost_ret[i] = retbuf[i]; }
+}
+
+template <int OCT, int CIT, int E>
+__global__ void __launch_bounds__(256) rollout_multi_kernel(WideArgs p) {
+  rollout_multi_body<OCT, CIT, E>(p);
+}
+
+// several independent runs in ONE launch: grid (G, n_runs), run = blockIdx.y
+template <int OCT, int CIT, int E>
+__global__ void __launch_bounds__(256) rollout_multi_batch_kernel(const WideArgs* __restrict__ runs) {
+  __shared__ WideArgs p;
+  {
+    const unsigned* src = reinterpret_cast<const unsigned*>(runs + blockIdx.y);
+    unsigned* dst = reinterpret_cast<unsigned*>(&p);
+    for (unsigned i = threadIdx.x; i < sizeof(WideArgs) / 4; i += 256) dst[i] = src[i];
+  }
+  __syncthreads();
+  rollout_multi_body<OCT, CIT, E>(p);
 }
 
 // VecNormalizeWithCost.reset (vec_normalize.py:148-157, 270-278)
@@ -1958,12 +2366,41 @@ extern "C" int icrl_debug_rollout_profile(unsigned long long* out4) {
 // how many blocks of this kernel one CU takes.  The answer is advisory (MI355X_MICROARCH.md: it can read one high for
 // SGPR-heavy kernels), hence the bounded spins + status word as the backstop.
 template <typename K>
-static bool persistent_fits(K kernel, int blocks) {
+static bool persistent_fits(K kernel, int blocks, size_t dyn_lds = 0) {
   int dev = 0, cus = 0, per_cu = 0;
   if (hipGetDevice(&dev) != hipSuccess) return false;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0) != hipSuccess) return false;
+  if (dyn_lds > 48 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn_lds) != hipSuccess) return false;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, dyn_lds) != hipSuccess) return false;
+  if (getenv("ICRL_DEBUG")) fprintf(stderr, "icrl: persistent kernel: %d workgroup(s) per CU x %d CUs (%zu B dynamic LDS), %d needed\n", per_cu, cus, dyn_lds, blocks);
   return (long long)per_cu * cus >= blocks;
+}
+
+// multi-env kernel: E envs per workgroup, G = ceil(N / E) workgroups per run, at most four statistics owners per workgroup
+static bool multi_shape(int N, int n_stats, int* E, int* G) {
+  const int gmin = (n_stats + 3) / 4;
+  const int per = N / gmin;
+  if (per >= 8) *E = 8; else if (per >= 4) *E = 4; else return false;
+  *G = (N + *E - 1) / *E;
+  return *G >= gmin;
+}
+
+template <int OCT, int CIT, int E>
+static int launch_multi_e(const WideArgs* one, const WideArgs* d_args, int n_runs, int G, size_t dyn, hipStream_t s) {
+  if (one != nullptr) {
+    if (!persistent_fits(rollout_multi_kernel<OCT, CIT, E>, G, dyn)) return -1;
+    hipLaunchKernelGGL((rollout_multi_kernel<OCT, CIT, E>), dim3(G), dim3(256), dyn, s, *one);
+  } else {
+    if (!persistent_fits(rollout_multi_batch_kernel<OCT, CIT, E>, G, dyn)) return -1;
+    hipLaunchKernelGGL((rollout_multi_batch_kernel<OCT, CIT, E>), dim3(G, n_runs), dim3(256), dyn, s, d_args);
+  }
+  return (int)hipGetLastError();
+}
+
+// one: single-run launch (argument block by value) | d_args: n_runs blocks in device memory.  -1: does not fit the device
+static int launch_multi(bool small, int E, const WideArgs* one, const WideArgs* d_args, int n_runs, int G, size_t dyn, hipStream_t s) {
+  if (small) return E == 8 ? launch_multi_e<2, 2, 8>(one, d_args, n_runs, G, dyn, s) : launch_multi_e<2, 2, 4>(one, d_args, n_runs, G, dyn, s);
+  return E == 8 ? launch_multi_e<8, 10, 8>(one, d_args, n_runs, G, dyn, s) : launch_multi_e<8, 10, 4>(one, d_args, n_runs, G, dyn, s);
 }
 
 extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol,
@@ -1986,8 +2423,34 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
   a.PT = pol->params_t; a.noise = noise; a.alow = action_low; a.ahigh = action_high;
   a.has_cn = cn != nullptr;
   if (cn) { a.cn = *cn; a.cl = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2); }
+  // several environments per workgroup, interleaved (rollout_multi_kernel): do_gae bit 5
+  if ((do_gae & 32) && !(do_gae & 2) && nm->training && !pol->discrete && N <= NORM_MAX_N && T >= 1) {
+    int E = 0, G = 0;
+    const int n_stats = O + (cn ? 2 : 1);
+    const size_t GX = 2 * (size_t)O + 4, GS = 4 * (size_t)O + 4;
+    const size_t need = 16 * (size_t)N * GX + 16 * GS + 256;
+    void* ws = (ag->xch_ws != nullptr && (size_t)ag->xch_ws_bytes >= need) ? ag->xch_ws
+               : ((size_t)T * N * sizeof(float) >= need ? (void*)buf->reward_advantages : nullptr);
+    if (multi_shape(N, n_stats, &E, &G) && ws != nullptr) {
+      WideArgs p;
+      p.act = a; p.nm = *nm; p.T = T; p.G = G; p.prof = 0;
+      p.xg = reinterpret_cast<unsigned long long*>(ws);
+      p.sg = p.xg + 2 * (size_t)N * GX;
+      hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
+      if (e != hipSuccess) return (int)e;
+      const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
+      const int err = launch_multi(small, E, &p, nullptr, 1, G, multi_dyn_lds(N, O, env->act_dim, (n_stats + G - 1) / G), s);
+      if (err >= 0) {
+        if (err || !(do_gae & 1)) return err;
+        return icrl_gae_dual_ws(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
+                                ag->last_v_c, ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns,
+                                buf->cost_returns, T, N, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, 0, buf->gae_ws,
+                                buf->gae_ws_bytes, stream);
+      }
+    }
+  }
   // many environments: persistent launch with the statistics partitioned by observation column (rollout_wide_kernel)
-  if (!(do_gae & 2) && nm->training && (N > 128 || N * O > NORM_CHUNK) && N <= NORM_MAX_N && O * env->act_dim <= MAX_OBS * MAX_ACT && T >= 1) {
+  if (!(do_gae & 2) && nm->training && (N > 128 || N * O > NORM_CHUNK || (do_gae & 16)) && N <= NORM_MAX_N && O * env->act_dim <= MAX_OBS * MAX_ACT && T >= 1) {
     const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
     const void* kfn = small ? (const void*)rollout_wide_kernel<2, 2> : (const void*)rollout_wide_kernel<8, 10>;
     int dev = 0, cus = 0, per_cu = 0;
@@ -2041,9 +2504,10 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
       hipError_t e = hipMemsetAsync(p.counter, 0, 512 + (gran ? (size_t)16 * N * G : 0), s);
       if (e != hipSuccess) return (int)e;
       const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
+      const size_t dyn = persist_dyn_lds(N, O, env->act_dim);
       auto go = [&](auto kernel) -> bool {
-        if (!persistent_fits(kernel, N)) return false;
-        hipLaunchKernelGGL(kernel, dim3(N), dim3(256), 0, s, p);
+        if (!persistent_fits(kernel, N, dyn)) return false;
+        hipLaunchKernelGGL(kernel, dim3(N), dim3(256), dyn, s, p);
         return true;
       };
       bool launched;
@@ -2091,8 +2555,59 @@ extern "C" int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* 
   const icrl_rollout_job_t& j0 = jobs[0];
   const int N = j0.env->n_envs, O = j0.env->obs_dim, T = j0.buf->T;
   const bool has_cn = j0.cn != nullptr;
+  // ---- preferred: several envs per workgroup, interleaved (G = N / E workgroups per run: all runs resident together)
+  {
+    int E = 0, G = 0;
+    const int n_stats = O + (has_cn ? 2 : 1);
+    static const bool no_multi = getenv("ICRL_BATCH_NO_MULTI") != nullptr;      // tools: the one-workgroup-per-env kernel instead
+    if (!no_multi && !j0.pol->discrete && j0.nm->training && N <= NORM_MAX_N && T >= 1 && multi_shape(N, n_stats, &E, &G)) {
+      static_assert(sizeof(WideArgs) <= ICRL_BATCH_ARGS_BYTES, "ICRL_BATCH_ARGS_BYTES");
+      const size_t GX = 2 * (size_t)O + 4, GS = 4 * (size_t)O + 4;
+      const size_t need = 16 * (size_t)N * GX + 16 * GS + 256;
+      WideArgs* d_args = (WideArgs*)args_ws;
+      bool ok = true;
+      for (int r = 0; r < n_runs && ok; ++r) {
+        const icrl_rollout_job_t& j = jobs[r];
+        if (j.env->n_envs != N || j.env->obs_dim != O || j.env->act_dim != j0.env->act_dim || j.buf->T != T || j.buf->N != N ||
+            j.pol->obs_dim != O || j.pol->act_dim != j0.pol->act_dim || j.pol->discrete != j0.pol->discrete || (j.cn != nullptr) != has_cn ||
+            (has_cn && (j.cn->in_dim != j0.cn->in_dim || j.cn->n_hidden != j0.cn->n_hidden)) || j.nm->training != j0.nm->training)
+          return fail("icrl_rollout_collect_batch: run %d differs from run 0 in a shape (envs / obs / act / T / discrete / constraint net)", r);
+        if (!dims_ok(j.pol->obs_dim, j.pol->act_dim, j.pol->h1, j.pol->h2)) return bad_dims("icrl_rollout_collect_batch", j.pol->obs_dim, j.pol->act_dim, j.pol->h1, j.pol->h2);
+        if (j.buf->obs_dim != O) return fail("icrl_rollout_collect_batch: run %d: buffer obs_dim %d vs env %d", r, j.buf->obs_dim, O);
+        if (j.cn != nullptr && !cn_ok(j.cn)) return bad_cn("icrl_rollout_collect_batch", j.cn);
+        void* ws = (j.ag->xch_ws != nullptr && (size_t)j.ag->xch_ws_bytes >= need) ? j.ag->xch_ws
+                   : ((size_t)T * N * sizeof(float) >= need ? (void*)j.buf->reward_advantages : nullptr);
+        if (ws == nullptr) { ok = false; break; }
+        WideArgs p;
+        ActStepArgs& a = p.act;
+        a.env = *j.env; a.buf = *j.buf; a.ag = *j.ag;
+        a.pl = make_pol_layout(j.pol->obs_dim, j.pol->act_dim, j.pol->h1, j.pol->h2, j.pol->discrete);
+        a.PT = j.pol->params_t; a.noise = j.noise; a.alow = action_low; a.ahigh = action_high;
+        a.has_cn = j.cn != nullptr;
+        if (j.cn) { a.cn = *j.cn; a.cl = make_cn_layout(j.cn->in_dim, j.cn->n_hidden, j.cn->h1, j.cn->h2); }
+        p.nm = *j.nm; p.T = T; p.G = G; p.prof = 0;
+        p.xg = reinterpret_cast<unsigned long long*>(ws);
+        p.sg = p.xg + 2 * (size_t)N * GX;
+        hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
+        if (e != hipSuccess) return (int)e;
+        const int pe = put_args(p, d_args + r, s);
+        if (pe) return pe;
+      }
+      if (ok) {
+        const bool small = O <= 32 && (!has_cn || j0.cn->in_dim <= 32);
+        const int err = launch_multi(small, E, nullptr, d_args, n_runs, G, multi_dyn_lds(N, O, j0.env->act_dim, (n_stats + G - 1) / G), s);
+        if (err >= 0) {
+          if (err || !(do_gae & 1)) return err;
+          if (args_ws_bytes < 2ll * n_runs * ICRL_BATCH_ARGS_BYTES)
+            return fail("icrl_rollout_collect_batch: args_ws needs 2 x n_runs x ICRL_BATCH_ARGS_BYTES = %lld B when the GAE launch is included", 2ll * n_runs * ICRL_BATCH_ARGS_BYTES);
+          return icrl_gae_dual_batch_impl(n_runs, jobs, reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda,
+                                          (char*)args_ws + (size_t)n_runs * ICRL_BATCH_ARGS_BYTES, stream);
+        }
+      }
+    }
+  }
   if (!(N <= 128 && N * O <= NORM_CHUNK && O * j0.env->act_dim <= MAX_OBS * MAX_ACT && T >= 1))
-    return fail("icrl_rollout_collect_batch: %d envs x obs %d: only the one-workgroup-per-env persistent kernel (<= 128 envs, envs x obs <= %d) has a batched form", N, O, NORM_CHUNK);
+    return fail("icrl_rollout_collect_batch: %d envs x obs %d: no batched form for this shape (multi-env kernel: continuous actions, training statistics, >= 4 envs per statistics-owner group; one workgroup per env: <= 128 envs, envs x obs <= %d)", N, O, NORM_CHUNK);
   const int G = 2 * O + 4;
   const bool gran = (size_t)N * G <= (size_t)256 * GRAN_MAX;
   const size_t need = (size_t)16 * N * O + (size_t)16 * N + (size_t)8 * N + (size_t)8 * N + 1024 + (gran ? (size_t)16 * N * G : 0);
@@ -2131,16 +2646,20 @@ extern "C" int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* 
     if (pe) return pe;
   }
   const bool small = O <= 32 && (!has_cn || j0.cn->in_dim <= 32);
+  const size_t dyn = persist_dyn_lds(N, O, j0.env->act_dim);
   auto go = [&](auto kernel) -> int {
-    if (!persistent_fits(kernel, N)) return fail("icrl_rollout_collect_batch: the %d workgroups of one run do not fit the device", N);
-    hipLaunchKernelGGL(kernel, dim3(N, n_runs), dim3(256), 0, s, d_args);
+    if (!persistent_fits(kernel, N, dyn)) return fail("icrl_rollout_collect_batch: the %d workgroups of one run do not fit the device", N);
+    hipLaunchKernelGGL(kernel, dim3(N, n_runs), dim3(256), dyn, s, d_args);
     return (int)hipGetLastError();
   };
+  // registers: the narrow (HC-width) kernel leaves room for several workgroups per CU, so that several runs of the grid are resident
+  // together; ICRL_ROLLOUT_MINW (tools) picks the allocation
+  static const int minw = getenv("ICRL_ROLLOUT_MINW") ? atoi(getenv("ICRL_ROLLOUT_MINW")) : 2;
   int err;
-  if (small && gran) err = go(rollout_persistent_batch_kernel<2, 2, true>);
-  else if (small) err = go(rollout_persistent_batch_kernel<2, 2, false>);
-  else if (gran) err = go(rollout_persistent_batch_kernel<8, 10, true>);
-  else err = go(rollout_persistent_batch_kernel<8, 10, false>);
+  if (small && gran) err = minw >= 3 ? go(rollout_persistent_batch_kernel<2, 2, true, 3>) : (minw == 2 ? go(rollout_persistent_batch_kernel<2, 2, true, 2>) : go(rollout_persistent_batch_kernel<2, 2, true, 1>));
+  else if (small) err = go(rollout_persistent_batch_kernel<2, 2, false, 2>);
+  else if (gran) err = go(rollout_persistent_batch_kernel<8, 10, true, 1>);
+  else err = go(rollout_persistent_batch_kernel<8, 10, false, 1>);
   if (err || !(do_gae & 1)) return err;
   // dual GAE of every run in one launch; its argument blocks go behind the rollout's in args_ws (both launches are in flight together)
   if (args_ws_bytes < 2ll * n_runs * ICRL_BATCH_ARGS_BYTES)

@@ -179,7 +179,7 @@ class PPOLagrangian:
                     p(self._ag["last_v_r"]), p(self._ag["last_v_c"]), p(self._ag["act_clipped"]), p(self._ag["status"]),
                     p(self._ag["xch_ws"]), self._ag["xch_ws"].numel() * 8)
         timed = getattr(self, "gae_events", None) is not None
-        flags = int(not timed) | (2 if getattr(self, "rollout_kernel", "auto") == "steps" else 0) | ((4 if getattr(self, "_wide_prof_flag", 1) == 1 else 8) if getattr(self, "profile_phases", 0) else 0)
+        flags = int(not timed) | {"steps": 2, "wide": 16, "multi": 32}.get(getattr(self, "rollout_kernel", "auto"), 0) | ((4 if getattr(self, "_wide_prof_flag", 1) == 1 else 8) if getattr(self, "profile_phases", 0) else 0)
         return dict(env=e, nm=nm, pol=pol, cn=cn, buf=buf, ag=ag, noise=noise, flags=flags, timed=timed, chain=(nenv, cw, senv))
 
     def _rollout_launch(self, job):

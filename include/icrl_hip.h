@@ -15,6 +15,18 @@
  *     stable_baselines3/common/buffers.py:468-491).
  *   - structs are plain C, passed by pointer to HOST memory (they hold device pointers + scalars) and are
  *     only read during the call.
+ *
+ * Co-residency precondition of the PERSISTENT launches (icrl_rollout_collect[_ex|_batch], icrl_ppo_lag_train[_batch]): the
+ * workgroups of ONE run wait for each other inside the launch (granule exchange), so they must all be resident at the same
+ * time: n_envs workgroups of 256 threads for the rollout (<= 128 envs; the many-environment kernel sizes its grid to what
+ * hipOccupancyMaxActiveBlocksPerMultiprocessor reports), 3 (6 when a minibatch is two chunks at obs_dim > 64) workgroups for
+ * the update, each filling a CU's LDS.  These are ordinary launches, not cooperative ones: the library checks the occupancy
+ * the runtime reports for an otherwise idle device, and nothing else.  Whatever else occupies CUs for long at the same time —
+ * another stream of this process, or ANOTHER PROCESS on the same GPU, which no host-side check of this process can see — can
+ * keep a workgroup of a run from being scheduled; its peers then spin (bounded: ~2 s per exchange, s_sleep between polls), the
+ * launch ends with icrl_agent_t.status bit 0 / stats[11] set and the host raises — buffers and statistics of that call are
+ * invalid, nothing hangs.  Runs of one *_batch grid do not wait for each other: a run whose workgroups do not fit yet starts
+ * when earlier runs of the grid have finished (dispatch is in grid order).
  */
 #ifndef ICRL_HIP_H
 #define ICRL_HIP_H

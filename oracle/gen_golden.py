@@ -252,14 +252,18 @@ def g13_widths():
     g4_ppo_minibatch("g13_widths", dict(pi=[32, 48], vf=[64, 32], cvf=[16, 64]))
 
 
-def g4_ppo_minibatch(name="g4_ppo_minibatch", arch=None):
-    print("G4 PPO-Lagrangian minibatch step + train()" + ("" if arch is None else f" {arch}"))
+def g14_batch256():
+    """a 256-row minibatch (four 64-row chunks of the update kernels) through the reference's own policy / optimizer objects."""
+    g4_ppo_minibatch("g14_batch256", None, B=256)
+
+
+def g4_ppo_minibatch(name="g4_ppo_minibatch", arch=None, B=64):
+    print("G4 PPO-Lagrangian minibatch step + train()" + ("" if arch is None else f" {arch}") + ("" if B == 64 else f" batch {B}"))
     kw = {} if arch is None else dict(policy_kwargs=dict(net_arch=[dict(arch)]))
     agent, env, cn = _make_ref_agent(4, "hc", 0, [20], **kw)
     pol = agent.policy
     sd0 = _sd_np(pol.state_dict())
-    rng = np.random.RandomState(5)
-    B = 64
+    rng = np.random.RandomState(5 if B == 64 else 500 + B)
     obs = th.tensor(rng.randn(B, 18), dtype=th.float32); act = th.tensor(rng.randn(B, 6), dtype=th.float32)
     old_lp = th.tensor(-8 + rng.randn(B) * 0.3, dtype=th.float32)
     adv_r, adv_c = th.tensor(rng.randn(B), dtype=th.float32), th.tensor(rng.rand(B), dtype=th.float32)
@@ -912,8 +916,8 @@ def fixtures_expert():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11", "g12", "g13", "g14"]
     table = dict(g1=g1_gae, g2=g2_cost_function, g3=g3_vecnormalize, g4=g4_ppo_minibatch, g5=g5_dual,
-                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g12=g12_gail, g13=g13_widths, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
+                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g12=g12_gail, g13=g13_widths, g14=g14_batch256, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
     for w in which:
         table[w]()

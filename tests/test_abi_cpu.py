@@ -48,10 +48,10 @@ def test_refused_arguments_carry_a_reason():
     err = L.icrl_gae_dual(*([None] * 12), 0, 5, 0.99, 0.95, 0.99, 0.95, None)
     with pytest.raises(ValueError, match="T = 0, N = 5"):
         _lib.check(err, "icrl_gae_dual")
-    hp = S.PpoHyperT(256, 2, 0, 0)
+    hp = S.PpoHyperT(512, 2, 0, 0)
     pol = S.PolicyT(18, 6, 64, 64, 0, 1, None, None)
     err = L.icrl_ppo_lag_train(ctypes.byref(pol), None, None, None, ctypes.byref(buf), None, None, ctypes.byref(hp), None, None, None)
-    with pytest.raises(ValueError, match="batch_size 256"):
+    with pytest.raises(ValueError, match="batch_size 512"):
         _lib.check(err, "icrl_ppo_lag_train")
 
 

@@ -29,9 +29,11 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 # The short tests (<= 48 dependent steps, tests/test_ppo_train_gpu.py) hold |dp| <= 5e-4 x lr x steps.  Over 2 x 10^4 dependent steps the
-# two fp32 trajectories separate faster than linearly (each step's rounding difference is amplified by the following ones); measured on
-# MI355X: 1.4e-3 x lr x steps after 20 480 steps (max |dp| = 8.7e-3 against a distance travelled of up to lr x steps = 6.1).  The bound
-# below is 4 x that; what the reference LOGS (nu, costs, losses, the early-stop epoch) is asserted tightly.
+# two fp32 trajectories separate faster than linearly (Adam turns a rounding-size difference in a near-zero gradient into an lr-size
+# difference in the update); measured on MI355X (two boxes): max |dp| = 0.9-1.1e-2 = 1.4-1.8e-3 x lr x steps after 20 480 steps
+# (distance travelled up to lr x steps = 6.1), 1.3e-2 = 1.0e-3 x lr x steps after 40 960.  What the reference LOGS moved by: nu 0 / 1.2e-7,
+# average_cost 1.2e-7 / 1.0e-4, losses <= 1.5e-6 / 2.8e-5, approx_kl 3e-5, clip_fraction 2.5e-4, early_stop_epoch equal.  The second
+# rollout (collected with the drifted parameters) differs per element by up to 3e-2 (values), 2e-3 (costs).
 ADAM_DEV_BOUND = 6e-3
 
 
@@ -57,6 +59,7 @@ def _forward_step(agent, port, env, n_rollouts, lr, target_kl):
     """learn() of both sides, rollout by rollout, with a comparison after every train()."""
     from icrl_amd import logger
     T, N = agent.n_steps, agent.n_envs
+    torch.set_num_threads(1)          # the port's 64-row MLP steps are fastest on one thread (bench.py: cpu_baseline)
     streams = SeededStreams(77)
     agent._setup_learn(n_rollouts * N * T)
     port.num_timesteps = 0
@@ -107,7 +110,8 @@ def _forward_step(agent, port, env, n_rollouts, lr, target_kl):
             assert close < 2e-3, f"early stop differs (HIP {ee_h}, port {ee_p}) and epoch {e}'s mean KL {kls_hip[e]} is not at the threshold {thr}"
             pytest.skip(f"epoch {e}: mean approx-KL {kls_hip[e]:.7f} sits within {close:.1e} of the 1.5 x target_kl threshold; the decision flips with summation order")
         assert abs(r["nu"][0] - r["nu"][1]) <= 1e-5, r["nu"]
-        assert abs(r["average_cost"][0] - r["average_cost"][1]) <= 1e-5 + 1e-4 * abs(r["average_cost"][1])
+        # (the SECOND rollout is collected with parameters that already differ by ~1e-2: its mean cost moves by ~1e-4)
+        assert abs(r["average_cost"][0] - r["average_cost"][1]) <= 1e-5 + 5e-4 * abs(r["average_cost"][1])
         assert worst_abs <= ADAM_DEV_BOUND * lr * steps + 2e-7, (worst_abs, steps)
         for key in ("pg_loss", "rv_loss", "cv_loss"):
             assert abs(r[key][0] - r[key][1]) <= 1e-5 + 2e-4 * abs(r[key][1]), (key, r[key])

@@ -32,16 +32,18 @@ def _fill(agent, buf):
 G13_ARCH = dict(pi=[32, 48], vf=[64, 32], cvf=[16, 64])          # oracle/gen_golden.py: g13_widths
 
 
-@pytest.mark.parametrize("name,arch", [("g4_ppo_minibatch", None), ("g13_widths", G13_ARCH)])
+@pytest.mark.parametrize("name,arch", [("g4_ppo_minibatch", None), ("g13_widths", G13_ARCH), ("g14_batch256", None)])
 def test_three_steps_on_one_batch_golden(golden, name, arch):
     """tests/golden/g4: the reference's own policy/optimizer objects stepped 3x on one 64-row batch.  g13: the same with
-    -pl 32 48 -rvl 64 32 -cvl 16 64 (narrower layers run zero-padded to the kernels' 64; state dicts keep the logical shapes)."""
+    -pl 32 48 -rvl 64 32 -cvl 16 64 (narrower layers run zero-padded to the kernels' 64; state dicts keep the logical shapes).
+    g14: one 256-row batch (four chunks per minibatch)."""
     g = golden(name)
+    B = int(g["obs"].shape[0])
     kw = {} if arch is None else dict(policy_kwargs=dict(net_arch=[dict(arch)]))
-    agent = _agent("hc", 1, 64, batch_size=64, n_epochs=3, target_kl=None, learning_rate=float(g["lr"]), **kw)
+    agent = _agent("hc", 1, B, batch_size=B, n_epochs=3, target_kl=None, learning_rate=float(g["lr"]), **kw)
     agent.policy.load_state_dict(_sub(g, "w0/"))
     assert {k: tuple(v.shape) for k, v in agent.policy.state_dict().items()} == {k: g["w0/" + k].shape for k in agent.policy.shapes}
-    z = np.zeros(64, np.float32)
+    z = np.zeros(B, np.float32)
     _fill(agent, dict(observations=g["obs"], actions=g["act"], log_probs=g["old_lp"], reward_advantages=g["adv_r"],
                       cost_advantages=g["adv_c"], reward_returns=g["ret_r"], cost_returns=g["ret_c"], reward_values=z,
                       cost_values=z, orig_costs=z))
@@ -51,7 +53,7 @@ def test_three_steps_on_one_batch_golden(golden, name, arch):
     assert np.allclose(v_r.cpu().numpy().ravel(), g["s0/v_r"], rtol=1e-5, atol=2e-6)
     assert np.allclose(v_c.cpu().numpy().ravel(), g["s0/v_c"], rtol=1e-5, atol=2e-6)
     assert np.allclose(lp.cpu().numpy(), g["s0/log_prob"], rtol=1e-5, atol=2e-5)
-    ident = np.tile(np.arange(64), (3, 1))
+    ident = np.tile(np.arange(B), (3, 1))
     agent.train(perms=ident)
     sd = agent.policy.state_dict()
     worst = 0.0
@@ -97,7 +99,13 @@ def _oracle_train(agent_sd, buf, perms, kind, nu, **h):
 @pytest.mark.parametrize("kind,N,T,B,E,tk", [("hc", 8, 32, 64, 3, None), ("hc", 5, 40, 64, 2, None), ("ant", 24, 16, 128, 2, None),
                                              ("hc", 16, 32, 64, 6, 0.002), ("hc", 4, 8, 16, 2, None),
                                              ("hc", 5, 40, 128, 2, None),      # 200 rows: minibatches of 128 and 72 = chunks 64 + 64, 64 + 8
-                                             ("ant", 3, 50, 100, 2, None)])    # 150 rows: minibatches of 100 and 50 = chunks 64 + 36, 50
+                                             ("ant", 3, 50, 100, 2, None),     # 150 rows: minibatches of 100 and 50 = chunks 64 + 36, 50
+                                             # batch sizes above 128 (buffers.py:594-612 slices any size): one workgroup per network walks
+                                             # up to four 64-row chunks; advantage statistics over up to 256 rows
+                                             ("hc", 8, 64, 256, 2, None),      # 512 rows: minibatches of 256 = 4 chunks (wave pairs)
+                                             ("hc", 5, 60, 200, 2, None),      # 300 rows: 200 (64 + 64 + 64 + 8) and 100 (64 + 36)
+                                             ("ant", 4, 80, 256, 2, None),     # 320 rows: 256 and 64 (row-owning waves, obs 113)
+                                             ("ant", 3, 70, 160, 2, None)])    # 210 rows: 160 (3 chunks) and 50
 def test_train_vs_oracle(kind, N, T, B, E, tk, one_workgroup_per_network=False):
     rng = np.random.RandomState(N * T)
     od, ad = (18, 6) if kind == "hc" else (113, 8)

@@ -339,7 +339,7 @@ def test_analytic_env_cost_through_cost_wrapper():
 # shards of BASELINE configs[3], [2] and [4].
 @pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("hc", 7, 33), ("hc", 128, 20), ("hc", 256, 40), ("hc", 130, 24), ("ant", 256, 12),
                                       ("antbroken", 512, 10), ("hc", 1000, 6)])
-def test_persistent_rollout_equals_per_step_launches(kind, N, T):
+def test_persistent_rollout_equals_per_step_launches(kind, N, T, kernel="auto"):
     """the one-launch rollout (device-wide exchange per step inside the kernel) against the launch pair per
     step: every buffer plane, the normaliser state and the agent's carry-over state are bit-identical, across two
     consecutive rollouts and across episode ends."""
@@ -348,6 +348,7 @@ def test_persistent_rollout_equals_per_step_launches(kind, N, T):
     limit = 1000 if ekind == "hc" else 500
     (a_p, e_p, _), (a_s, e_s, _) = _pair_of_agents(N, T, 13, ekind, broken=kind == "antbroken")
     a_s.rollout_kernel = "steps"
+    a_p.rollout_kernel = kernel
     noise = torch.as_tensor(np.random.RandomState(8).randn(2, T, N, ad).astype(np.float32), device="cuda")
     a_p._setup_learn(2 * N * T); a_s._setup_learn(2 * N * T)
     for env in (e_p, e_s):
@@ -369,3 +370,12 @@ def test_persistent_rollout_equals_per_step_launches(kind, N, T):
     assert torch.equal(e_p.unwrapped.s, e_s.unwrapped.s) and torch.equal(e_p.unwrapped.t_ep, e_s.unwrapped.t_ep)
     for k in ("raw_rew", "raw_cost", "dones", "last_v_r", "last_v_c", "act_clipped"):
         assert torch.equal(a_p._ag[k], a_s._ag[k]), k
+
+
+# rollout_multi_kernel: E = 4 or 8 envs per workgroup evaluated interleaved, statistics owners on all four waves.  hc 64 = the
+# shape of a seed batch's runs (8 workgroups x 8 envs), hc 20 / 37 = ragged last workgroups (E = 4), hc 300 / ant 256 / antbroken 512 =
+# the many-environment shapes (ant: 29+ workgroups needed for the 115 statistics)
+@pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("hc", 20, 33), ("hc", 37, 21), ("hc", 128, 20), ("hc", 300, 12), ("ant", 256, 12),
+                                      ("antbroken", 512, 10), ("hc", 1000, 6)])
+def test_multi_env_rollout_equals_per_step_launches(kind, N, T):
+    test_persistent_rollout_equals_per_step_launches(kind, N, T, kernel="multi")

@@ -14,7 +14,7 @@ def run(kind, N, T, broken=False):
     env.set_cost_function(cn.cost_function)
     agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, batch_size=64, seed=0)
     agent._setup_learn(N * T)
-    for mode in ("auto", "steps", "auto", "steps"):
+    for mode in os.environ.get("MODES", "auto,steps,auto,steps").split(","):
         agent.rollout_kernel = mode
         torch.cuda.synchronize(); t0 = time.time()
         agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost")
@@ -65,5 +65,6 @@ def run(kind, N, T, broken=False):
               f"(latest: workgroups {np.argsort(-tr[:, 2])[:4].tolist()}, {np.sort(us(tr[:, 2]))[-4:][::-1].round(1).tolist()}); statistics read {us(tr[:, 3]).min():.1f}..{us(tr[:, 3]).max():.1f}")
         agent.profile_phases = 0
 
-for cfg in (("hc", 64, 2048), ("hc", 256, 1024), ("ant", 256, 512), ("ant", 512, 256, True)):
-    run(*cfg)
+CFGS = dict(hc64=("hc", 64, 2048), hc256=("hc", 256, 1024), ant256=("ant", 256, 512), antb512=("ant", 512, 256, True), hc128=("hc", 128, 1024), hc16=("hc", 16, 2048))
+for name in os.environ.get("CFGS", "hc64,hc256,ant256,antb512").split(","):
+    run(*CFGS[name])

@@ -11,14 +11,16 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
-STEPS = 4096
+kind = sys.argv[2] if len(sys.argv) > 2 else "hc"           # "ant": tools/train_only.py with KIND=ant (64 envs x 512 rows, batch 128)
+STEPS = 4096 if kind == "hc" else 512
+suffix = "" if kind == "hc" else "_antwall"
 QUAD = {"SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
         "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 waves = {}
 # one file per pass directory (pmc_train_<tag>_a / _b): gpurun merges every call's files into gpurun_out/, take the newest of each
 _passes = []
-for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_train_{tag}_*"))):
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_train_{tag}{suffix}_[ab]"))):
     if os.path.isdir(d):
         hits = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
         if hits:
@@ -31,16 +33,20 @@ for f in _passes:
             continue
         name = k.split("<")[0].split("::")[-1].replace("void ", "")
         per[(name, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
-        waves[name] = int(r["Workgroup_Size"]) // 64 * 3
+        waves[name] = int(r["Workgroup_Size"]) // 64 * int(r["Grid_Size"]) // int(r["Workgroup_Size"])
     for (name, _), c in per.items():
         for cn, v in c.items():
             agg[name][cn].append(v)
-lines = [f"# SQ counters of the PPO-Lagrangian update kernels ({tag}) — HCWithPos shapes, batch 64, per WAVE and optimiser step",
+shape = "HCWithPos shapes, batch 64" if kind == "hc" else "AntWall shapes (obs 113, act 8), batch 128 = two 64-row chunks"
+lines = [f"# SQ counters of the PPO-Lagrangian update kernels ({tag}) — {shape}, per WAVE and optimiser step",
          "", "command: `bash tools/pmc_train.sh <tag>` on the GPU box = two `rocprofv3 --pmc <8 SQ counters> --kernel-trace` passes over "
-         "`tools/train_only.py` (VARIANTS=rows,auto: the row-owning kernel with one wave per SIMD, 12 waves, and the wave-pair kernel with two, "
-         "24 waves; 4096 optimiser steps per launch); raw csv: gpurun_out/pmc_train_<tag>_{a,b} (scratch).  Values below = median over the "
-         "launches / waves of the kernel / 4096; cycle-type counters converted from quad-cycles to shader cycles.", ""]
+         "`tools/train_only.py` (HC: VARIANTS=rows,auto = the row-owning kernel with one wave per SIMD, 12 waves, and the wave-pair kernel with two, "
+         "24 waves, 4096 optimiser steps per launch; KIND=ant: VARIANTS=rows1,auto = one workgroup per network walking both chunks, 12 waves, and "
+         "the default two workgroups per network, 24 waves, 512 steps per launch); raw csv: gpurun_out/pmc_train_<tag>_{a,b} (scratch).  Values "
+         f"below = median over the launches / waves of the kernel / {STEPS}; cycle-type counters converted from quad-cycles to shader cycles.", ""]
 names = sorted(agg)
+if kind != "hc":      # the same kernel symbol runs with 3 and with 6 workgroups: keep them apart by wave count
+    pass
 cols = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_SALU",
         "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_SMEM",
         "SQ_INSTS_VMEM_RD"]
@@ -60,5 +66,5 @@ lines += ["", "Reading: SQ_WAVE_CYCLES = ACTIVE_INST_ANY (issuing) + WAIT_INST_A
           "v_mfma_f32_16x16x4_f32 instructions.  With two waves per SIMD each wave issues half the instructions (761 vs 1733 VALU), "
           "and the step shortens by what the two waves overlap; what remains parked (WAIT_ANY) is the exchange hop, the three "
           "workgroup barriers and LDS latency both waves of a SIMD meet at the same time."]
-open(os.path.join(ROOT, "profiles", f"{tag}_train_pmc.md"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(ROOT, "profiles", f"{tag}_train_pmc{suffix}.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))

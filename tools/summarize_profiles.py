@@ -17,26 +17,32 @@ def find(pattern):
     return hits[-1] if hits else None
 
 
-def kernel_stats(tag):
-    src = find(f"prof_{tag}/**/*kernel_stats.csv")
+def kernel_stats(tag, which="bench"):
+    sfx = "" if which == "bench" else "_antwall"
+    src = find(f"prof_{tag}{sfx}/**/*kernel_stats.csv")
     if src is None:
         print("no kernel_stats.csv"); return
     rows = list(csv.DictReader(open(src)))
-    dst = os.path.join(ROOT, "profiles", f"{tag}_bench_kernel_stats")
+    dst = os.path.join(ROOT, "profiles", f"{tag}_{which}_kernel_stats")
     with open(dst + ".csv", "w") as f:
         f.write(open(src).read())
     bench = ""
-    log = os.path.join(ROOT, "gpurun_out", f"prof_{tag}.log")
+    log = os.path.join(ROOT, "gpurun_out", f"prof_{tag}{sfx}.log")
     if os.path.exists(log):
         for line in open(log):
-            if line.startswith("{\"metric\""):
+            if line.startswith("{\"metric\"") or line.startswith("{\"workload\""):
                 j = json.loads(line)
-                bench = f"bench line of that (profiled) run: {j['value']:.0f} env-steps/s, {j['ms_per_step']:.0f} ms per outer iteration"
+                bench = (f"line of that (profiled) run: {j['value']:.0f} env-steps/s, {j['ms_per_step']:.0f} ms per outer iteration" +
+                         (f", {j['us_per_optimizer_step']} us per optimiser step, {j['us_per_rollout_step']} us per rollout step" if which != "bench" else ""))
+    head = (f"# rocprofv3 --kernel-trace --stats — bench.py --steps 2 --warmup 1 ({tag})\n\n"
+            "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag> -- python3 bench.py --steps 2 "
+            "--warmup 1 --no_cpu_baseline --no_seed_batch --no_configs2` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 131 072)\n\n"
+            if which == "bench" else
+            f"# rocprofv3 --kernel-trace --stats — BASELINE configs[2] (AntWall-v0, 256 envs, batch 128, [40, 40]) ({tag})\n\n"
+            "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag>_antwall -- python3 tools/antwall_iter.py` "
+            "(= bench.py's configs2 leg: 1 warm-up + 2 timed outer iterations)\n\n")
     with open(dst + ".md", "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats — bench.py --steps 2 --warmup 1 ({tag})\n\n"
-                "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag> -- python3 bench.py --steps 2 "
-                "--warmup 1 --no_cpu_baseline` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 131 072)\n\n"
-                f"{bench}\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        f.write(head + f"{bench}\n\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
         for r in rows[:24]:
             name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
             f.write(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
@@ -81,4 +87,5 @@ def gae_pmc(tag, T=2048, N=131072):
 if __name__ == "__main__":
     tag = sys.argv[1]
     kernel_stats(tag)
+    kernel_stats(tag, "antwall")
     gae_pmc(tag)
