@@ -27,7 +27,7 @@ SIGNATURES = {
     "icrl_costnet_prepare": [c_void_p, c_void_p],
     "icrl_policy_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8,
     "icrl_policy_evaluate": [c_void_p, c_void_p, c_void_p, c_int] + [c_void_p] * 5,
-    "icrl_sample_episodes": [c_void_p] * 6 + [c_int] * 4 + [c_void_p] * 6,
+    "icrl_sample_episodes": [c_void_p] * 6 + [c_int] * 4 + [c_void_p, c_int] + [c_void_p] * 6,
     "icrl_cost_mlp_forward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "icrl_disc_reward": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p],
     "icrl_synth_env_reset": [c_void_p, c_void_p],

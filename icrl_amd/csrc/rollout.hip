@@ -513,7 +513,8 @@ __device__ __forceinline__ void chan_merge(double& mean, double& var, double cou
 // <= 128 elements, sums each block with 8 strided accumulators + a fixed combine tree + sequential tail, and adds the
 // block results back up the recursion.  Blocks and accumulators are independent, so (block, accumulator) pairs map to
 // threads; only the tiny combine runs on one thread.
-constexpr int NORM_MAX_N = 1024;                 // envs handled by the single-workgroup normaliser
+constexpr int NORM_MAX_N = 4096;                 // envs handled by the single-workgroup normaliser (and per GPU)
+constexpr int WIDE_MAX_N = 1024;                 // rollout_wide_kernel's static buffers; beyond: rollout_multi_kernel
 constexpr int NORM_MAX_LEAVES = NORM_MAX_N / 64 + 2;
 constexpr int NORM_CHUNK = 4096;                 // doubles of raw obs staged in LDS per pass
 
@@ -1290,12 +1291,12 @@ template <int OCT, int CIT>
 __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
   __shared__ ActShared sh[WIDE_E];
   __shared__ double Bl[MAX_OBS * MAX_ACT];
-  __shared__ double colbuf[NORM_MAX_N + 64], dev2buf[NORM_MAX_N], retbuf[NORM_MAX_N];
+  __shared__ double colbuf[WIDE_MAX_N + 64], dev2buf[WIDE_MAX_N], retbuf[WIDE_MAX_N];
   __shared__ double mean_s[MAX_OBS], var_s[MAX_OBS], dens_s[2];
   __shared__ double olast[WIDE_E][MAX_OBS], rew_s[WIDE_E];
   __shared__ float noise_s[2][WIDE_E][MAX_ACT], alow_s[MAX_ACT], ahigh_s[MAX_ACT], cost_s[WIDE_E];
   __shared__ unsigned ctr_s[WIDE_E];
-  __shared__ int tep_s[WIDE_E], last_done_s[WIDE_E], done_s[WIDE_E], done_all[NORM_MAX_N];
+  __shared__ int tep_s[WIDE_E], last_done_s[WIDE_E], done_s[WIDE_E], done_all[WIDE_MAX_N];
   const ActStepArgs& a = p.act;
   const icrl_norm_t& nm = p.nm;
   WaveRegs<OCT, CIT> R;                // one image: policy weights in waves 0..2, cost-net weights in wave 3
@@ -1596,8 +1597,9 @@ struct MultiShared {
 };
 
 static inline size_t multi_dyn_lds(int N, int O, int A, int owners) {
-  // dynamics matrix | per owner wave: column buffer (N + 64) | ret / cost owners: previous returns [2][N] | done flags [2][N] bytes
-  return ((size_t)O * A + (size_t)owners * (size_t)(N + 64) + 2 * (size_t)N) * sizeof(double) + 2 * (size_t)((N + 15) / 16 * 16);
+  // dynamics matrix | per owner wave: column buffer (N + 64) | ret / cost owners: done flags [2][N] bytes.  (The discounted returns of
+  // the previous step stay in nm.ret / nm.cost_ret: only their owner wave touches them during the launch.)
+  return ((size_t)O * A + (size_t)owners * (size_t)(N + 64)) * sizeof(double) + 2 * (size_t)((N + 15) / 16 * 16);
 }
 
 // E independent k-ascending fmaf chains (one per environment) against ONE register-resident weight vector W (named directly:
@@ -1608,19 +1610,81 @@ static inline size_t multi_dyn_lds(int N, int O, int A, int owners) {
 // workgroup's E environments go through in E / EB passes of a run-time loop): the weights already take most of the register file.
 #define ICRL_MULTI_CHAINS(W, X0, STRIDE, NK4, ACC)                                                      \
   {                                                                                                     \
-    _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_) ACC[e_] = 0.f;                                    \
+    f32x4 xc_[EB], xn_[EB];   /* inputs of the current group and, already in flight, of the next one */ \
+    _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_) {                                                 \
+      ACC[e_] = 0.f;                                                                                    \
+      xc_[e_] = *reinterpret_cast<const f32x4*>((X0) + e_ * (STRIDE));                                  \
+      xn_[e_] = xc_[e_];                                                                                \
+    }                                                                                                   \
     _Pragma("unroll") for (int k4_ = 0; k4_ < (NK4); ++k4_) {                                           \
-      f32x4 xv_[EB];                                                                                    \
-      _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_)                                                 \
-        xv_[e_] = *reinterpret_cast<const f32x4*>((X0) + e_ * (STRIDE) + 4 * k4_);                      \
-      _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_) {                                               \
-        ACC[e_] = fmaf(W[4 * k4_ + 0], xv_[e_][0], ACC[e_]);                                            \
-        ACC[e_] = fmaf(W[4 * k4_ + 1], xv_[e_][1], ACC[e_]);                                            \
-        ACC[e_] = fmaf(W[4 * k4_ + 2], xv_[e_][2], ACC[e_]);                                            \
-        ACC[e_] = fmaf(W[4 * k4_ + 3], xv_[e_][3], ACC[e_]);                                            \
+      if (k4_ + 1 < (NK4)) {                                                                            \
+        _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_)                                               \
+          xn_[e_] = *reinterpret_cast<const f32x4*>((X0) + e_ * (STRIDE) + 4 * (k4_ + 1));              \
       }                                                                                                 \
+      _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_) {                                               \
+        ACC[e_] = fmaf(W[4 * k4_ + 0], xc_[e_][0], ACC[e_]);                                            \
+        ACC[e_] = fmaf(W[4 * k4_ + 1], xc_[e_][1], ACC[e_]);                                            \
+        ACC[e_] = fmaf(W[4 * k4_ + 2], xc_[e_][2], ACC[e_]);                                            \
+        ACC[e_] = fmaf(W[4 * k4_ + 3], xc_[e_][3], ACC[e_]);                                            \
+      }                                                                                                 \
+      _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_) xc_[e_] = xn_[e_];                              \
     }                                                                                                   \
   }
+
+// synthetic env step of up to THREE environments at once by one wave (obs_dim <= 21): lane 21 s + i handles component i of the env in
+// slot s.  em / n / mine are PER-LANE: the env's slot in the workgroup's LDS state, its index in the run, and whether the lane has an
+// env at all.  The per-component arithmetic, the reward and the auto-reset draw are env_step_wave's, operation for operation; only
+// the lanes they run on differ.  Leaves s_new, ctr, tep, rew, done of every handled env in `sh`.
+template <int E>
+__device__ __noinline__ void env_step_wave3(const icrl_env_t& e, MultiShared<E>& sh, int em, int n, bool mine, int ci, int slot) {
+  const int O = e.obs_dim, A = e.act_dim;
+  const bool live = mine && ci < O;
+  double a[MAX_ACT];
+  double sq = 0.0;
+#pragma unroll
+  for (int j = 0; j < MAX_ACT; ++j) {
+    a[j] = 0.0;
+    if (j < A) {
+      a[j] = (double)sh.act_clip[em][j];
+      if (e.broken && j >= 4) a[j] = 0.0;
+      sq = sq + a[j] * a[j];
+    }
+  }
+  const uint32_t ky = sh.key[em], ct = sh.ctr[em];
+  const int i = ci < O ? ci : 0;
+  double ns = 0.0;
+  {
+    double acc = 0.99 * sh.s_old[em][i];
+    const double* Bi = e.B + (size_t)i * A;
+#pragma unroll
+    for (int j = 0; j < MAX_ACT; ++j)
+      if (j < A) acc = acc + Bi[j] * a[j];
+    const double eps = (unit_uniform(ky, ct, (uint32_t)i) - 0.5) * 3.4641016151377544;
+    ns = acc + 0.01 * eps;
+  }
+  const int base = 21 * (slot < 3 ? slot : 0);
+  const double n0 = __shfl(ns, base, 64);
+  const double n1 = __shfl(ns, base + 1, 64);
+  double rw;
+  if (e.reward_form == 0) rw = fabs(n0 - sh.s_old[em][0]) / 0.05 - 0.1 * sq;
+  else rw = (sqrt(n0 * n0 + n1 * n1) + 1.0) - 0.5 * sq;
+  int d = 0;
+  if (e.wall_terminate && n0 <= -3.0) { rw = 0.0; d = 1; }
+  const int tep = sh.tep[em] + 1;
+  if (tep >= e.max_steps) d = 1;
+  __builtin_amdgcn_wave_barrier();           // every lane has read ctr / tep / s_old before lane 0 of a slot replaces them
+  if (live) {
+    double v = ns;
+    if (d) v = env_reset_value(e, ky, ct + 1u, i);   // auto-reset draw
+    e.s[(size_t)n * O + i] = v;
+    sh.s_new[em][i] = v;
+  }
+  if (mine && ci == 0) {
+    const int tnew = d ? 0 : tep;
+    sh.tep[em] = tnew; sh.ctr[em] = ct + 1u; sh.rew[em] = rw; sh.done[em] = d;
+    e.t_ep[n] = tnew; e.step_count[n] = ct + 1u;
+  }
+}
 
 template <int OCT, int CIT, int E>
 __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
@@ -1646,8 +1710,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   const int owners = (n_stats + G - 1) / G;          // owner waves per workgroup (<= 4: checked by the launcher)
   double* const Bl = dyn_lds;
   double* const colbuf = Bl + O * a.env.act_dim + (size_t)w * (N + 64);      // this wave's column buffer (owner waves only)
-  double* const retbufs = Bl + O * a.env.act_dim + (size_t)owners * (N + 64);
-  unsigned char* const done_bufs = reinterpret_cast<unsigned char*>(retbufs + 2 * (size_t)N);
+  unsigned char* const done_bufs = reinterpret_cast<unsigned char*>(Bl + O * a.env.act_dim + (size_t)owners * (N + 64));
   icrl_env_t env = a.env;
   for (int i = tid; i < O * a.env.act_dim; i += 256) Bl[i] = a.env.B[i];
   env.B = Bl;
@@ -1672,14 +1735,12 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   const bool owner = w < owners && sid < n_stats;
   const int own_col = (owner && sid < O) ? sid : -1;
   const bool own_ret = owner && sid == O, own_cost = owner && has_cost && sid == O + 1;
-  double* const retbuf = retbufs + (own_cost ? (size_t)N : 0);
+  double* const retbuf = own_cost ? nm.cost_ret : nm.ret;           // [N] in global memory: this wave is its only user during the launch
   unsigned char* const done_all = done_bufs + (own_cost ? (size_t)((N + 15) / 16 * 16) : 0);
   double o_mean = 0.0, o_var = 1.0, o_cnt = 0.0;
   if (own_col >= 0) { o_mean = nm.obs_mean[own_col]; o_var = nm.obs_var[own_col]; o_cnt = nm.obs_count[0]; }
   if (own_ret) { o_mean = nm.ret_stats[0]; o_var = nm.ret_stats[1]; o_cnt = nm.ret_stats[2]; }
   if (own_cost) { o_mean = nm.cost_stats[0]; o_var = nm.cost_stats[1]; o_cnt = nm.cost_stats[2]; }
-  if (own_ret || own_cost)
-    for (int i = lane; i < N; i += WAVE) retbuf[i] = own_ret ? nm.ret[i] : nm.cost_ret[i];
   const int NA = A;                                  // (continuous actions only: the launcher keeps discrete policies elsewhere)
   if (tid < E * MAX_ACT) {
     const int e = tid / MAX_ACT, k = tid % MAX_ACT;
@@ -1687,6 +1748,8 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   }
   int spin_limit = 1 << 22;
   __syncthreads();
+  const bool prof = p.prof != 0 && g == p.prof - 1 && blockIdx.y == 0;
+  unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, tl = prof ? prof_now() : 0ull;
   for (int t = 0; t < T; ++t) {
     const int par = t & 1;
     const unsigned gtag = (unsigned)(t + 1);
@@ -1743,8 +1806,49 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       }
     }
     __syncthreads();
-    // ---------------- env steps (waves 0..2: env e on wave e % 3), cost net (wave 3), buffer rows ----------------
-    if (w < 3) {
+    if (prof) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }     // the three MLPs + heads
+    // ---------------- env steps (waves 0..2), cost net (wave 3), buffer rows ----------------
+    if (OCT <= 2 && w < 3 && O <= 21 && env.reward_form < 2) {
+      // narrow observations: THREE envs per pass, lane 21 s + i = component i of slot s (env 3 q + s; triple q on wave q % 3)
+      const int slot = lane / 21, ci = lane - 21 * slot;
+      for (int q = w; 3 * q < Eg; q += 3) {
+        const int e = 3 * q + slot;
+        const bool mine = slot < 3 && e < Eg;
+        const int em = mine ? e : 3 * q;
+        const int n = g + em * G;
+        const size_t tn = (size_t)t * N + n;
+        unsigned long long* xg = p.xg + ((size_t)par * N + n) * GX;
+        if (mine) {       // rows that depend on the pre-step state only
+          if (ci < O) { a.buf.observations[tn * O + ci] = sh.x[em][ci]; a.buf.orig_observations[tn * O + ci] = (float)sh.s_old[em][ci]; }
+          if (ci < AS) a.buf.actions[tn * AS + ci] = sh.act_raw[em][ci];
+          if (ci < A) a.ag.act_clipped[(size_t)n * A + ci] = sh.act_clip[em][ci];
+          if (ci == 0) {
+            a.buf.dones[tn] = (float)sh.last_done[em];
+            a.buf.reward_values[tn] = sh.scal[em][0];
+            a.buf.cost_values[tn] = sh.scal[em][1];
+            a.buf.log_probs[tn] = sh.scal[em][2];
+            a.ag.last_v_r[n] = sh.scal[em][0];
+            a.ag.last_v_c[n] = sh.scal[em][1];
+          }
+        }
+        env_step_wave3<E>(env, sh, em, n, mine, ci, slot);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // the wave's LDS writes (s_new, rew, done) are visible to its own reads
+        if (mine) {
+          if (ci < O) {
+            const double v = sh.s_new[em][ci];
+            a.buf.new_orig_observations[tn * O + ci] = (float)v;
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+            gstore(xg + 2 * ci, gtag, (unsigned)bits); gstore(xg + 2 * ci + 1, gtag, (unsigned)(bits >> 32));
+          }
+          if (ci == 0) {
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.rew[em]);
+            gstore(xg + 2 * O, gtag, (unsigned)bits); gstore(xg + 2 * O + 1, gtag, (unsigned)(bits >> 32));
+            gstore(xg + 2 * O + 3, gtag, (unsigned)sh.done[em]);
+          }
+        }
+      }
+    } else if (w < 3) {
       for (int e = w; e < Eg; e += 3) {
         const int n = g + e * G;
         const size_t tn = (size_t)t * N + n;
@@ -1795,6 +1899,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         __builtin_amdgcn_wave_barrier();
       }
     }
+    if (prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }     // env steps / cost net + rows (this wave's part)
     // ---------------- phase B1: owner waves gather their statistic from all envs and publish it ----------------
     if (own_col >= 0 || own_ret || own_cost) {
       const unsigned long long* xb = p.xg + (size_t)par * N * GX;
@@ -1805,6 +1910,11 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         bool ok[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) { g0[k] = g1[k] = g2[k] = 0; ok[k] = i0 + k * WAVE + lane >= N; }
+        double rprev[4] = {0.0, 0.0, 0.0, 0.0};      // previous discounted returns (return owners): in flight while the granules are polled
+        if (own_col < 0) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { const int i = i0 + k * WAVE + lane; if (i < N) rprev[k] = retbuf[i]; }
+        }
         for (int spins = 0; spins < spin_limit; ++spins) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -1834,7 +1944,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
             else v = (double)__uint_as_float((unsigned)g0[k]);
             if (own_col >= 0) colbuf[i] = v;
             else {
-              colbuf[i] = retbuf[i] * (own_ret ? nm.reward_gamma : nm.cost_gamma) + v;     // vec_normalize.py:102, 245
+              colbuf[i] = rprev[k] * (own_ret ? nm.reward_gamma : nm.cost_gamma) + v;      // vec_normalize.py:102, 245
               done_all[i] = (unsigned char)(unsigned)g2[k];
             }
           }
@@ -1868,6 +1978,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         }
       }
     }
+    if (prof) { const unsigned long long tn_ = prof_now(); pc2 += tn_ - tl; tl = tn_; }     // owner: gather + moments + publish
     // ---------------- phase B2: everybody reads the statistics granules, then normalises its envs ----------------
     {
       const unsigned long long* sb = p.sg + (size_t)par * GS;
@@ -1893,6 +2004,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       }
     }
     __syncthreads();
+    if (prof) { const unsigned long long tn_ = prof_now(); pc3 += tn_ - tl; tl = tn_; }     // statistics granules arrived (+ barrier)
     for (int idx = tid; idx < Eg * MULTI_OP; idx += 256) {
       const int e = idx / MULTI_OP, i = idx % MULTI_OP;
       if (i < O) {
@@ -1921,6 +2033,11 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     }
     if (pf) sh.noise[par ^ 1][pe][pk] = noise_next;
     __syncthreads();
+    if (prof) { const unsigned long long tn_ = prof_now(); pc4 += tn_ - tl; tl = tn_; }     // normalise + rows
+  }
+  if (prof && (tid == 0 || tid == 192)) {      // wave 0: a policy / env wave's view; wave 3: the cost wave's
+    unsigned long long* o = g_rollout_prof_wide + (tid == 192 ? 8 : 0);
+    o[0] = pc0; o[1] = pc1; o[2] = pc2; o[3] = pc3; o[4] = pc4; o[5] = (unsigned long long)T;
   }
   if (spin_limit == 1 && a.ag.status != nullptr && (tid & 63) == 0) atomicOr(a.ag.status, 1);
   // ---- leave the agent / wrapper / normaliser state exactly where the per-step path leaves it
@@ -1939,8 +2056,6 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     if (own_ret) { nm.ret_stats[0] = o_mean; nm.ret_stats[1] = o_var; nm.ret_stats[2] = o_cnt; }
     if (own_cost) { nm.cost_stats[0] = o_mean; nm.cost_stats[1] = o_var; nm.cost_stats[2] = o_cnt; }
   }
-  if (own_ret || own_cost)
-    for (int i = lane; i < N; i += WAVE) { if (own_ret) nm.ret[i] = retbuf[i]; else nm.cost_ret[i] = retbuf[i]; }
 }
 
 template <int OCT, int CIT, int E>
@@ -2066,6 +2181,8 @@ struct SampleArgs {
   const float* alow;
   const float* ahigh;
   int episodes_per_stream, rows_per_stream, deterministic, do_reset;
+  const int* stream_row0;  // [n_streams] first row (noise in, outputs out) of every stream, or NULL: stream * rows_per_stream
+  int total_rows;          // rows of the noise / output arrays (only read with stream_row0)
   double* orig_obs;        // [n_streams*rows_per_stream, obs] raw observation AFTER each step
   double* obs;             // same, normalised
   float* actions;          // [.., act_store] clipped action that produced it
@@ -2105,8 +2222,8 @@ __device__ __forceinline__ void sample_episodes_body(const SampleArgs& a) {
   }
   if (a.do_reset) e_tep = 0;
   __syncthreads();
-  size_t row = (size_t)n * a.rows_per_stream;
-  const size_t row_end = row + a.rows_per_stream;
+  size_t row = a.stream_row0 != nullptr ? (size_t)a.stream_row0[n] : (size_t)n * a.rows_per_stream;
+  const size_t row_end = a.stream_row0 != nullptr ? (size_t)a.total_rows : row + a.rows_per_stream;
   float noise_reg = (a.noise != nullptr && tid < AS) ? a.noise[row * AS + tid] : 0.f;   // noise of the first step
   for (int ep = 0; ep < a.episodes_per_stream; ++ep) {
     double ep_rew = 0.0;
@@ -2127,14 +2244,15 @@ __device__ __forceinline__ void sample_episodes_body(const SampleArgs& a) {
       policy_forward_block<OCT>(a.pl, R, sh, a.noise ? noise_s : nullptr, a.deterministic || a.noise == nullptr,
                                 has_box ? alow_s : nullptr, has_box ? ahigh_s : nullptr);
       __syncthreads();
+      const bool in_rows = row < row_end;      // (a stream whose speculative start row was too late can run off the arrays)
       if (w == 0) {
         double rew; int done;
         env_step_wave(env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
         if (lane == 0) { s_done = done; s_rew = rew; }
-        if (lane < AS) a.actions[row * AS + lane] = sh.act_clip[lane];
+        if (lane < AS && in_rows) a.actions[row * AS + lane] = sh.act_clip[lane];
       }
       __syncthreads();
-      if (tid < O) {
+      if (tid < O && in_rows) {
         const double raw = sh.s_new[tid];
         double o = raw;
         if (a.nm.norm_obs) o = fmin(fmax((raw - n_mean) / n_den, -a.nm.clip_obs), a.nm.clip_obs);
@@ -2240,13 +2358,15 @@ extern "C" int icrl_policy_evaluate(const icrl_policy_t* p, const double* obs, c
 
 static int make_sample_args(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const float* noise,
                             const float* action_low, const float* action_high, int episodes_per_stream, int rows_per_stream,
-                            int deterministic, int do_reset, double* orig_obs, double* obs, float* actions, double* ep_rewards,
-                            int32_t* ep_lengths, SampleArgs& a) {
+                            int deterministic, int do_reset, const int32_t* stream_row0, int total_rows, double* orig_obs, double* obs,
+                            float* actions, double* ep_rewards, int32_t* ep_lengths, SampleArgs& a) {
   if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2)) return bad_dims("icrl_sample_episodes", pol->obs_dim, pol->act_dim, pol->h1, pol->h2);
   if (env->obs_dim != pol->obs_dim || nm->training)
     return fail("icrl_sample_episodes: env obs_dim %d vs policy %d; the normaliser must be frozen (training = %d)", env->obs_dim, pol->obs_dim, nm->training);
   if (episodes_per_stream * env->max_steps > rows_per_stream)
     return fail("icrl_sample_episodes: %d episodes x %d steps do not fit %d rows per stream", episodes_per_stream, env->max_steps, rows_per_stream);
+  if (stream_row0 != nullptr && total_rows < 1) return fail("icrl_sample_episodes: stream_row0 given with total_rows = %d", total_rows);
+  a.stream_row0 = stream_row0; a.total_rows = total_rows;
   a.env = *env; a.nm = *nm; a.pl = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);
   a.PT = pol->params_t; a.noise = noise; a.alow = action_low; a.ahigh = action_high;
   a.episodes_per_stream = episodes_per_stream; a.rows_per_stream = rows_per_stream; a.deterministic = deterministic;
@@ -2257,11 +2377,12 @@ static int make_sample_args(const icrl_env_t* env, const icrl_norm_t* nm, const 
 
 extern "C" int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const float* noise,
                                     const float* action_low, const float* action_high, int episodes_per_stream,
-                                    int rows_per_stream, int deterministic, int do_reset, double* orig_obs, double* obs,
-                                    float* actions, double* ep_rewards, int32_t* ep_lengths, void* stream) {
+                                    int rows_per_stream, int deterministic, int do_reset, const int32_t* stream_row0, int total_rows,
+                                    double* orig_obs, double* obs, float* actions, double* ep_rewards, int32_t* ep_lengths,
+                                    void* stream) {
   SampleArgs a;
   const int bad = make_sample_args(env, nm, pol, noise, action_low, action_high, episodes_per_stream, rows_per_stream, deterministic,
-                                   do_reset, orig_obs, obs, actions, ep_rewards, ep_lengths, a);
+                                   do_reset, stream_row0, total_rows, orig_obs, obs, actions, ep_rewards, ep_lengths, a);
   if (bad) return bad;
   if (a.pl.O <= 32) hipLaunchKernelGGL(sample_episodes_kernel<2>, dim3(env->n_envs), dim3(192), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(sample_episodes_kernel<8>, dim3(env->n_envs), dim3(192), 0, (hipStream_t)stream, a);
@@ -2285,7 +2406,8 @@ extern "C" int icrl_sample_episodes_batch(int n_runs, const icrl_sample_job_t* j
       return fail("icrl_sample_episodes_batch: run %d differs from run 0 in a shape (streams / obs / act / discrete / max_steps)", r);
     SampleArgs a;
     const int bad = make_sample_args(j.env, j.nm, j.pol, j.noise, action_low, action_high, episodes_per_stream, rows_per_stream,
-                                     deterministic, do_reset, j.orig_obs, j.obs, j.actions, j.ep_rewards, j.ep_lengths, a);
+                                     deterministic, do_reset, j.stream_row0, j.total_rows, j.orig_obs, j.obs, j.actions, j.ep_rewards,
+                                     j.ep_lengths, a);
     if (bad) return bad;
     const int e = put_args(a, d_args + r, s);
     if (e) return e;
@@ -2380,7 +2502,10 @@ static bool persistent_fits(K kernel, int blocks, size_t dyn_lds = 0) {
 static bool multi_shape(int N, int n_stats, int* E, int* G) {
   const int gmin = (n_stats + 3) / 4;
   const int per = N / gmin;
-  if (per >= 8) *E = 8; else if (per >= 4) *E = 4; else return false;
+  if (per >= 16 && N > 8 * 256) *E = 16;        // more than 2048 envs: 16 per workgroup keep the grid at <= 256 workgroups
+  else if (per >= 8) *E = 8;
+  else if (per >= 4) *E = 4;
+  else return false;
   *G = (N + *E - 1) / *E;
   return *G >= gmin;
 }
@@ -2399,8 +2524,10 @@ static int launch_multi_e(const WideArgs* one, const WideArgs* d_args, int n_run
 
 // one: single-run launch (argument block by value) | d_args: n_runs blocks in device memory.  -1: does not fit the device
 static int launch_multi(bool small, int E, const WideArgs* one, const WideArgs* d_args, int n_runs, int G, size_t dyn, hipStream_t s) {
-  if (small) return E == 8 ? launch_multi_e<2, 2, 8>(one, d_args, n_runs, G, dyn, s) : launch_multi_e<2, 2, 4>(one, d_args, n_runs, G, dyn, s);
-  return E == 8 ? launch_multi_e<8, 10, 8>(one, d_args, n_runs, G, dyn, s) : launch_multi_e<8, 10, 4>(one, d_args, n_runs, G, dyn, s);
+  if (small) return E == 16 ? launch_multi_e<2, 2, 16>(one, d_args, n_runs, G, dyn, s)
+                    : (E == 8 ? launch_multi_e<2, 2, 8>(one, d_args, n_runs, G, dyn, s) : launch_multi_e<2, 2, 4>(one, d_args, n_runs, G, dyn, s));
+  return E == 16 ? launch_multi_e<8, 10, 16>(one, d_args, n_runs, G, dyn, s)
+         : (E == 8 ? launch_multi_e<8, 10, 8>(one, d_args, n_runs, G, dyn, s) : launch_multi_e<8, 10, 4>(one, d_args, n_runs, G, dyn, s));
 }
 
 extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol,
@@ -2424,7 +2551,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
   a.has_cn = cn != nullptr;
   if (cn) { a.cn = *cn; a.cl = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2); }
   // several environments per workgroup, interleaved (rollout_multi_kernel): do_gae bit 5
-  if ((do_gae & 32) && !(do_gae & 2) && nm->training && !pol->discrete && N <= NORM_MAX_N && T >= 1) {
+  if (((do_gae & 32) || N > WIDE_MAX_N) && !(do_gae & 2) && nm->training && !pol->discrete && N <= NORM_MAX_N && T >= 1) {
     int E = 0, G = 0;
     const int n_stats = O + (cn ? 2 : 1);
     const size_t GX = 2 * (size_t)O + 4, GS = 4 * (size_t)O + 4;
@@ -2433,7 +2560,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
                : ((size_t)T * N * sizeof(float) >= need ? (void*)buf->reward_advantages : nullptr);
     if (multi_shape(N, n_stats, &E, &G) && ws != nullptr) {
       WideArgs p;
-      p.act = a; p.nm = *nm; p.T = T; p.G = G; p.prof = 0;
+      p.act = a; p.nm = *nm; p.T = T; p.G = G; p.prof = (do_gae & 4) ? 1 : ((do_gae & 8) ? G : 0);
       p.xg = reinterpret_cast<unsigned long long*>(ws);
       p.sg = p.xg + 2 * (size_t)N * GX;
       hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
@@ -2450,7 +2577,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
     }
   }
   // many environments: persistent launch with the statistics partitioned by observation column (rollout_wide_kernel)
-  if (!(do_gae & 2) && nm->training && (N > 128 || N * O > NORM_CHUNK || (do_gae & 16)) && N <= NORM_MAX_N && O * env->act_dim <= MAX_OBS * MAX_ACT && T >= 1) {
+  if (!(do_gae & 2) && nm->training && (N > 128 || N * O > NORM_CHUNK || (do_gae & 16)) && N <= WIDE_MAX_N && O * env->act_dim <= MAX_OBS * MAX_ACT && T >= 1) {
     const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
     const void* kfn = small ? (const void*)rollout_wide_kernel<2, 2> : (const void*)rollout_wide_kernel<8, 10>;
     int dev = 0, cus = 0, per_cu = 0;

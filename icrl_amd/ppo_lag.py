@@ -408,6 +408,8 @@ class PPOLagrangian:
         """[n_epochs, n] int32 on the device.  "numpy": np.random.permutation per epoch — the reference's stream
         (ref: buffers.py:596); the generator is rewound afterwards to what the reference would have consumed (it stops
         drawing once an epoch early-stops), see train()."""
+        if self.streams is not None and hasattr(self.streams, "permutations"):      # one batched device-side draw for all epochs
+            return self.streams.permutations(self.n_epochs, n).to(device=self.device, dtype=torch.int32).contiguous(), None
         if self.streams is not None or callable(self.permutation):
             draw = self.streams.permutation if self.streams is not None else self.permutation
             perms = [draw(e, n) for e in range(self.n_epochs)]

@@ -125,8 +125,8 @@ class SeedBatch:
 
     def _launch_episodes(self, runs):
         r0 = runs[0]
-        arr = _jobs(SampleJobT, [(addr(r.e), addr(r.nm), addr(r.ps), p(r.noise), p(r.out["orig_obs"]), p(r.out["obs"]), p(r.out["actions"]),
-                                  p(r.out["ep_rewards"]), p(r.out["ep_lengths"])) for r in runs])
+        arr = _jobs(SampleJobT, [(addr(r.e), addr(r.nm), addr(r.ps), p(r.noise), p(r.row0), r.rows, 0, p(r.out["orig_obs"]), p(r.out["obs"]),
+                                  p(r.out["actions"]), p(r.out["ep_rewards"]), p(r.out["ep_lengths"])) for r in runs])
         ws, nbytes = self._ws()
         _lib.check(_lib.lib().icrl_sample_episodes_batch(len(runs), arr, p(r0.lo), p(r0.hi), r0.eps_per, r0.rows_per, int(r0.deterministic), 1,
                                                          ws, nbytes, _lib.current_stream()), "icrl_sample_episodes_batch")
@@ -196,8 +196,8 @@ class SeedBatch:
             for i, r, h in zip(todo, sub, host):
                 if r.finish(h[:n_episodes]):
                     rewards[i] = h[n_episodes:].copy()
-                else:
-                    r.prepare(1)
+                else:           # an episode ended early: the run repeats with the positions the measured lengths imply
+                    r.prepare()
                     again.append(i)
             todo = again
         return runs, rewards

@@ -34,6 +34,13 @@ class PrivateStreams:
     def permutation(self, epoch, n):
         return torch.randperm(n, device=self.device, generator=self.perm_gen)
 
+    def permutations(self, n_epochs, n):
+        """all epochs' permutations of one train() call in ONE batched draw: [n_epochs, n] = the sort order of n_epochs x n float64
+        uniforms (no ties in practice: 2^53 values).  torch.randperm per epoch is a sort per call — with dozens of runs in a batch
+        the draws of one update phase were 20+ ms of device time between the rollout and the update launch."""
+        keys = torch.rand(n_epochs, n, dtype=torch.float64, device=self.device, generator=self.perm_gen)
+        return torch.argsort(keys, dim=1).to(torch.int32)
+
     def consumed(self, executed_epochs):
         pass
 

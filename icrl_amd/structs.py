@@ -68,7 +68,8 @@ class GaeJobT(C.Structure):
 
 
 class SampleJobT(C.Structure):
-    _fields_ = [(k, vp) for k in ("env", "nm", "pol", "noise", "orig_obs", "obs", "actions", "ep_rewards", "ep_lengths")]
+    _fields_ = ([(k, vp) for k in ("env", "nm", "pol", "noise", "stream_row0")] + [("total_rows", i32), ("_pad", i32)] +
+                [(k, vp) for k in ("orig_obs", "obs", "actions", "ep_rewards", "ep_lengths")])
 
 
 class CnTrainJobT(C.Structure):

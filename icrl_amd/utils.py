@@ -62,16 +62,20 @@ SPECULATIVE_EPISODES = True
 
 
 class EpisodeRun:
-    """`n_episodes` sequential episodes of a 1-env loop (icrl/utils.py:323-357, evaluation.py:10-67) as ONE persistent launch.
-    Episodes are independent once their position in the env's random stream is known, and that position is the number of
-    steps taken before them: with fixed-length episodes it is known up front and the episodes run as parallel streams.  When
-    episodes may end early (the "Test" envs, CLGW) they are first run SPECULATIVELY as parallel full-length streams; if
-    every episode did run to the time limit the result is exactly the sequential one, otherwise the call is repeated
-    sequentially (same noise, same start state).
+    """`n_episodes` sequential episodes of a 1-env loop (icrl/utils.py:323-357, evaluation.py:10-67) as ONE persistent launch of
+    parallel streams, one per episode.  An episode is determined by where it starts in the loop: its start row = the number of
+    steps taken before it, which is also its position in the env's random stream and in the action-noise array.  With
+    fixed-length episodes the positions are known up front.  When episodes may end early (the "Test" envs, CLGW) the positions
+    are GUESSED (every earlier episode runs to the time limit), all episodes run, and the guess is replaced by what the measured
+    lengths imply until the two agree: episode 0 is always right, so every pass fixes at least one more episode — in practice
+    one or two passes; after MAX_PASSES the episodes run sequentially in one stream.  The rows of a converged pass are exactly
+    the sequential loop's.
 
     In pieces, so that several runs sharing a GPU can put their launches into one grid (icrl_amd/seed_batch.py):
-    prepare(n_streams) builds the descriptors, launch() is the single-run launch, finish(lengths) checks the speculation and
-    leaves the env where the sequential loop would have left it (returns False when the sequential repeat is needed)."""
+    prepare() builds the descriptors, launch() is the single-run launch, finish(lengths) checks the positions and leaves the env
+    where the sequential loop would have left it (returns False when another pass is needed: prepare() again, launch(), ...)."""
+
+    MAX_PASSES = 4
 
     def __init__(self, agent, env, n_episodes, deterministic, noise, parallel):
         assert env.num_envs == 1, "You must pass only one environment when using this function"
@@ -101,11 +105,14 @@ class EpisodeRun:
         # parallel=False keeps fixed-length episodes sequential (a test hook); early-ending envs are tried speculatively unless
         # SPECULATIVE_EPISODES is switched off
         self.n_streams = 1 if (n_episodes == 1 or (self.fixed_len and not parallel) or (not self.fixed_len and not SPECULATIVE_EPISODES)) else n_episodes
+        self.starts = np.arange(self.n_streams, dtype=np.int64) * self.max_steps      # start row of every stream (first guess)
+        self.passes = 0
 
     def prepare(self, n_streams=None, base=None):
         senv, dev, O, A = self.senv, self.dev, self.O, self.A
-        if n_streams is not None:
+        if n_streams is not None and n_streams != self.n_streams:
             self.n_streams = n_streams
+            self.starts = np.arange(n_streams, dtype=np.int64) * self.max_steps
         n_streams = self.n_streams
         if base is not None:
             self.base = int(base) & 0xFFFFFFFF
@@ -114,16 +121,18 @@ class EpisodeRun:
         self.eps_per = self.n_episodes // n_streams
         self.rows_per = self.eps_per * self.max_steps
         # per-stream copies of the env's random-stream position: stream e starts where the sequential loop would be
-        sc = ((self.base + np.arange(n_streams, dtype=np.int64) * self.max_steps) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+        sc = ((self.base + self.starts) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
         self.st = dict(s=senv.s.repeat(n_streams, 1).contiguous(), t_ep=senv.t_ep.repeat(n_streams).contiguous(),
                        step_count=torch.as_tensor(sc, device=dev), key=senv.key.repeat(n_streams).contiguous())
         st = self.st
         self.e = EnvT(n_streams, O, senv.act_dim, self.max_steps, senv.reward_form, int(senv.wall_terminate), int(senv.broken), 0,
                       p(senv.B), p(st["s"]), p(st["t_ep"]), p(st["step_count"]), p(st["key"]))
+        self.row0 = torch.as_tensor(self.starts.astype(np.int32), device=dev) if n_streams > 1 else None
         rows, n_episodes = self.rows, self.n_episodes
         self.out = dict(orig_obs=torch.empty(rows, O, dtype=torch.float64, device=dev), obs=torch.empty(rows, O, dtype=torch.float64, device=dev),
                         actions=torch.empty(rows, A, device=dev), ep_rewards=torch.empty(n_episodes, dtype=torch.float64, device=dev),
                         ep_lengths=torch.empty(n_episodes, dtype=torch.int32, device=dev))
+        self.passes += 1
         return self
 
     def launch(self):
@@ -131,17 +140,25 @@ class EpisodeRun:
         # auto-reset draw made at exactly this counter value
         b, out = _lib.byref, self.out
         _lib.check(_lib.lib().icrl_sample_episodes(b(self.e), b(self.nm), b(self.ps), p(self.noise), p(self.lo), p(self.hi), self.eps_per, self.rows_per,
-                                                   int(self.deterministic), 1, p(out["orig_obs"]), p(out["obs"]), p(out["actions"]),
-                                                   p(out["ep_rewards"]), p(out["ep_lengths"]), _lib.current_stream()), "icrl_sample_episodes")
+                                                   int(self.deterministic), 1, p(self.row0), self.rows, p(out["orig_obs"]), p(out["obs"]),
+                                                   p(out["actions"]), p(out["ep_rewards"]), p(out["ep_lengths"]), _lib.current_stream()),
+                   "icrl_sample_episodes")
 
     def finish(self, lengths=None):
-        """lengths: ep_lengths already on the host, or None (read here).  False: an episode ended early under speculation (its
-        successors' stream positions were wrong) — prepare(1), launch() and finish() again."""
+        """lengths: ep_lengths already on the host, or None (read here).  False: an episode ended early, so its successors started
+        at the wrong position — the positions the measured lengths imply are installed: prepare(), launch() and finish() again."""
         if lengths is None:
             lengths = self.out["ep_lengths"].cpu().numpy()
         lengths = np.asarray(lengths).astype(np.int64)
-        if self.n_streams > 1 and not self.fixed_len and not np.all(lengths == self.max_steps):
-            return False
+        if self.n_streams > 1:
+            implied = np.concatenate([[0], np.cumsum(lengths)[:-1]])
+            if not np.array_equal(implied, self.starts):
+                if self.passes >= self.MAX_PASSES:
+                    self.n_streams = 1
+                    self.starts = np.zeros(1, np.int64)
+                else:
+                    self.starts = implied
+                return False
         senv, env, dev = self.senv, self.env, self.dev
         # leave the env where the sequential loop would have left it
         total = int(lengths.sum())
@@ -149,7 +166,7 @@ class EpisodeRun:
         senv.s.copy_(self.st["s"][-1:]); senv.t_ep.zero_()
         env.old_obs = senv.s
         self.lengths = lengths
-        self.keep = None if (self.n_streams > 1 or total == self.rows) else total      # full-length episodes: every row is used
+        self.keep = None if total == self.rows else total      # rows are those of the sequential loop: the first `total`
         return True
 
     def rows_of(self, name):
@@ -160,9 +177,8 @@ class EpisodeRun:
 def _run_episodes(agent, env, n_episodes, deterministic, noise, parallel):
     run = EpisodeRun(agent, env, n_episodes, deterministic, noise, parallel).prepare()
     run.launch()
-    if not run.finish():
-        run.prepare(1).launch()
-        assert run.finish()
+    while not run.finish():
+        run.prepare().launch()
     return run
 
 

@@ -160,7 +160,7 @@ typedef struct {
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* ABI version (major*100+minor). */
-int icrl_abi_version(void);
+int icrl_abi_version(void);   /* 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
 
 /* Every entry point returns a hipError_t.  When it is hipErrorInvalidValue because the arguments are outside what the
  * kernels were built for (env count, widths, batch size ...; the reference's Python raises ValueError / AssertionError with a
@@ -237,11 +237,16 @@ int icrl_policy_evaluate(const icrl_policy_t* pol, const double* obs, const floa
  * Row k of a stream records the observation AFTER step k (raw in orig_obs, normalised in obs) next to the clipped action
  * of step k — the (s_{t+1}, a_t) pairing of the reference — at rows [stream*rows_per_stream + k].  noise: standard normals
  * [n_streams*rows_per_stream, act] (NULL or deterministic != 0: mode of the distribution).  do_reset: draw the initial
- * state first (VecEnv.reset).  Per-episode un-normalised reward sums and lengths go to ep_rewards / ep_lengths. */
+ * state first (VecEnv.reset).  Per-episode un-normalised reward sums and lengths go to ep_rewards / ep_lengths.
+ * stream_row0 ([n_streams] int32 on the device, or NULL): first row of every stream in the noise and output arrays instead of
+ * stream * rows_per_stream, total_rows = rows of those arrays.  This is how episodes of a sequential 1-env loop that may end
+ * early (the "Test" envs) run as parallel streams: the host guesses every episode's position in the loop (its start row = the
+ * steps taken before it, which is also its position in the env's random stream, env->step_count), runs all of them, and
+ * repeats with the positions the measured lengths imply until they agree; rows are then exactly the sequential loop's. */
 int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const float* noise,
                          const float* action_low, const float* action_high, int episodes_per_stream, int rows_per_stream,
-                         int deterministic, int do_reset, double* orig_obs, double* obs, float* actions,
-                         double* ep_rewards, int32_t* ep_lengths, void* stream);
+                         int deterministic, int do_reset, const int32_t* stream_row0, int total_rows, double* orig_obs,
+                         double* obs, float* actions, double* ep_rewards, int32_t* ep_lengths, void* stream);
 
 /* ConstraintNet.cost_function (icrl/constraint_net.py:121-130): cost[n] = 1 - zeta(prepare(obs[n], acs[n])).
  * obs [N,obs] float64, acs [N,acs] float32 (class index in acs[n,0] when discrete). */
@@ -352,6 +357,8 @@ typedef struct {
   const icrl_norm_t* nm;
   const icrl_policy_t* pol;
   const float* noise;
+  const int32_t* stream_row0;   /* or NULL (see icrl_sample_episodes) */
+  int32_t total_rows, _pad;
   double *orig_obs, *obs;
   float* actions;
   double* ep_rewards;

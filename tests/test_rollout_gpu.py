@@ -88,7 +88,7 @@ def test_vecnormalize_stream_golden(golden):
         assert np.array_equal(env.get_original_cost().cpu().numpy(), g["costs"][t])
 
 
-@pytest.mark.parametrize("N", [1, 8, 127, 128, 129, 300, 1000])
+@pytest.mark.parametrize("N", [1, 8, 127, 128, 129, 300, 1000, 2048, 3000, 4096])
 def test_vecnormalize_numpy_reduction_order(N):
     from icrl_amd.vec_env import HipSynthVecEnv, VecNormalizeWithCost, VecCostWrapper
     rng = np.random.RandomState(N)
@@ -376,6 +376,9 @@ def test_persistent_rollout_equals_per_step_launches(kind, N, T, kernel="auto"):
 # shape of a seed batch's runs (8 workgroups x 8 envs), hc 20 / 37 = ragged last workgroups (E = 4), hc 300 / ant 256 / antbroken 512 =
 # the many-environment shapes (ant: 29+ workgroups needed for the 115 statistics)
 @pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("hc", 20, 33), ("hc", 37, 21), ("hc", 128, 20), ("hc", 300, 12), ("ant", 256, 12),
-                                      ("antbroken", 512, 10), ("hc", 1000, 6)])
+                                      ("antbroken", 512, 10), ("hc", 1000, 6),
+                                      # beyond 1024 envs per GPU (BASELINE configs[3] / configs[4] whole on ONE GPU): 8 / 16 envs per
+                                      # workgroup, 256 workgroups; the per-step normaliser handles up to 4096 envs as well
+                                      ("hc", 2048, 5), ("antbroken", 4096, 3)])
 def test_multi_env_rollout_equals_per_step_launches(kind, N, T):
     test_persistent_rollout_equals_per_step_launches(kind, N, T, kernel="multi")

@@ -38,6 +38,23 @@ def run(kind, N, T, broken=False):
         print("   one step, end of each wave's env-phase part, us after the first (min / median / max over workgroups): " +
               ", ".join(f"wave {k}: {tr[:, k].min():.2f} / {np.median(tr[:, k]):.2f} / {tr[:, k].max():.2f}" for k in range(4)))
         agent.profile_phases = 0
+    if os.environ.get("PHASES_MULTI"):        # phase timers of the multi-env kernel (cycles per step; wave 0 and the cost wave)
+        import ctypes
+        from icrl_amd import _lib
+        agent.rollout_kernel = "multi"
+        for flag, who in ((1, "workgroup 0"), (2, "last workgroup")):
+            agent.profile_phases = 1
+            agent._wide_prof_flag = flag
+            agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost")
+            torch.cuda.synchronize()
+            out = (ctypes.c_ulonglong * 16)()
+            _lib.lib().icrl_debug_rollout_profile_wide(out)
+            names = ("MLPs+heads", "env steps / cost net + rows", "owner gather+moments+publish", "statistics wait", "normalise+rows")
+            for base, wave in ((0, "wave 0"), (8, "wave 3 (cost)")):
+                Tn = max(1, out[base + 5])
+                print(f"   multi, {who}, {wave}: " + ", ".join(f"{n} {out[base + k] / Tn:.0f}" for k, n in enumerate(names)) + f"  (sum {sum(out[base:base + 5]) / Tn:.0f} cycles/step)")
+        agent.profile_phases = 0
+        agent.rollout_kernel = "auto"
     if N > 128 and os.environ.get("PHASES"):          # phase timers of the many-environment persistent kernel (cycles per step)
         import ctypes
         from icrl_amd import _lib
