@@ -227,6 +227,7 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_seed_batch", action="store_true")
     ap.add_argument("--no_configs2", action="store_true")
+    ap.add_argument("--envs_per_gpu", type=int, default=None, help="override the env count per GPU (e.g. 2048: BASELINE configs[3] whole on one GPU)")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -236,7 +237,7 @@ def main():
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
 
-    envs = 64 if a.config == 1 else 256
+    envs = a.envs_per_gpu or (64 if a.config == 1 else 256)
     if a.mode == "seeds":      # independent runs: every rank is a 1-rank job with its own seed; the only collectives are the timing ones below
         cfg = config2(a.steps + a.warmup, a.seed + rank, 0, 1, envs)
     else:

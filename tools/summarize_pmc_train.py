@@ -32,6 +32,8 @@ for f in _passes:
         if "ppo_train_" not in k or "perm" in k or "plan" in k:
             continue
         name = k.split("<")[0].split("::")[-1].replace("void ", "")
+        if kind != "hc":      # the SPLIT template argument tells the two launch shapes of the row-owning kernel apart
+            name = k.split("(")[0].split("::")[-1].replace("void ", "")
         per[(name, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
         waves[name] = int(r["Workgroup_Size"]) // 64 * int(r["Grid_Size"]) // int(r["Workgroup_Size"])
     for (name, _), c in per.items():
@@ -61,6 +63,14 @@ for c in cols:
         med = sorted(v)[len(v) // 2] / waves[n] / STEPS * (4 if c in QUAD else 1)
         row.append(f"{med:,.0f}")
     lines.append(f"| {c}{' (cycles)' if c in QUAD else ''} | " + " | ".join(row) + " |")
+if kind != "hc":
+    lines += ["", "`ppo_train_rows_kernel<8, false, true>` = the default at batch 128: TWO workgroups per network (24 waves on 6 CUs), each computes one 64-row "
+              "chunk of a minibatch and the partial gradients are exchanged as granules; `<8, false, false>` = one workgroup per network walking both "
+              "chunks (hp._pad & 8).  Per wave and step the split kernel issues about half the MFMAs (1 936 / 4 = 484 vs the single workgroup's) and "
+              "spends the difference parked (SQ_WAIT_ANY) in the gradient exchange."]
+    open(os.path.join(ROOT, "profiles", f"{tag}_train_pmc{suffix}.md"), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    raise SystemExit(0)
 lines += ["", "Reading: SQ_WAVE_CYCLES = ACTIVE_INST_ANY (issuing) + WAIT_INST_ANY (issue stalled: here the shared fp32 MFMA / VALU pipe, "
           "304 MFMAs x 32 cycles = 9.7 k cycles per SIMD and step) + WAIT_ANY (parked at s_waitcnt / s_barrier).  MFMA_MOPS_F32 / 4 = "
           "v_mfma_f32_16x16x4_f32 instructions.  With two waves per SIMD each wave issues half the instructions (761 vs 1733 VALU), "
