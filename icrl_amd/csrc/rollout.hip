@@ -2690,7 +2690,7 @@ extern "C" int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* 
     static const bool no_multi = getenv("ICRL_BATCH_NO_MULTI") != nullptr;      // tools: the one-workgroup-per-env kernel instead
     // (few small runs: one workgroup per env keeps every env's step at its latency floor and all of them fit the chip at once)
     int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
     const bool few = (long long)n_runs * N <= cus && N <= 128 && N * O <= NORM_CHUNK;
     if (!no_multi && !few && !j0.pol->discrete && j0.nm->training && N <= NORM_MAX_N && T >= 1 && multi_shape(N, n_stats, &E, &G)) {
       static_assert(sizeof(WideArgs) <= ICRL_BATCH_ARGS_BYTES, "ICRL_BATCH_ARGS_BYTES");
