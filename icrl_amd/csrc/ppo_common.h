@@ -100,7 +100,7 @@ int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hi
 int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s);
 // batched forms: n_runs argument blocks in DEVICE memory, grid.y = run
 int launch_train_rows_batch(const TrainArgs* d_args, int n_runs, int nt1, bool discrete, bool split, hipStream_t s);
-int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int nt1, bool discrete, hipStream_t s);
+int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, hipStream_t s);
 
 
 }  // namespace icrl

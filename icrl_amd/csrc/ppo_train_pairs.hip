@@ -91,7 +91,10 @@ struct SmemP {  // offsets in floats (multiples of 4); same images as SmemR in p
 
 // The whole update of ONE run: `a` are its arguments, `ka` points at the same block in memory (the kernel-argument segment of a
 // single-run launch, element blockIdx.y of the device-side argument array of a batched launch).
-template <int NT1, bool DISC>
+// OBS > 0: the observation width is known at compile time (the widths of the BASELINE configs get their own instantiation): layer-1
+// MFMAs whose four k values are all padding (k = 16 js + 4 q + e >= obs for every q, i.e. 16 js + e >= obs) are not issued — at
+// obs 18 six of eight per tile remain, at obs 1 (LapGridWorld) one.  OBS == 0: every k step runs against the zero pad weights.
+template <int NT1, bool DISC, int OBS = 0>
 __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const TrainArgs* const ka) {
   using S = SmemP<NT1>;
   constexpr int SX = S::SX;
@@ -430,7 +433,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 #pragma unroll
         for (int js = 0; js < NT1; ++js)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) bx[js][e] = pb[(16 * js + e) * ST];
+          for (int e = 0; e < 4; ++e) bx[js][e] = (OBS == 0 || 16 * js + e < OBS) ? pb[(16 * js + e) * ST] : 0.f;
         f32x4 z[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
@@ -443,7 +446,8 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 #pragma unroll
           for (int js = 0; js < NT1; ++js)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) z[tt] = MFMA_F32(aw[js][e], bx[js][e], z[tt]);     // (k >= obs: zero weights)
+            for (int e = 0; e < 4; ++e)
+              if (OBS == 0 || 16 * js + e < OBS) z[tt] = MFMA_F32(aw[js][e], bx[js][e], z[tt]);     // (k >= obs: zero weights)
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
@@ -1007,48 +1011,51 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   }
 }
 
-template <int NT1, bool DISC>
+template <int NT1, bool DISC, int OBS>
 __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
-  ppo_train_pairs_body<NT1, DISC>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+  ppo_train_pairs_body<NT1, DISC, OBS>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 // several independent runs in ONE launch: grid (3, n_runs), run = blockIdx.y; the argument blocks live in device memory
-template <int NT1, bool DISC>
+template <int NT1, bool DISC, int OBS>
 __global__ void __launch_bounds__(TH8) ppo_train_pairs_batch_kernel(const TrainArgs* __restrict__ runs) {
   const TrainArgs* const ka = runs + blockIdx.y;
-  ppo_train_pairs_body<NT1, DISC>(*ka, ka);
+  ppo_train_pairs_body<NT1, DISC, OBS>(*ka, ka);
 }
 
-template <int NT1, bool DISC>
-static int launch_pairs_batch(const TrainArgs* d_args, int n_runs, hipStream_t s) {
+// one: single-run launch (argument block by value) | d_args: n_runs blocks in device memory
+template <int NT1, bool DISC, int OBS>
+static int launch_pairs(const TrainArgs* one, const TrainArgs* d_args, int n_runs, hipStream_t s) {
+  static_assert(SmemP<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
   const size_t bytes = (size_t)SmemP<NT1>::TOTAL * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_batch_kernel<NT1, DISC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((ppo_train_pairs_batch_kernel<NT1, DISC>), dim3(3, n_runs), dim3(TH8), bytes, s, d_args);
+  if (one != nullptr) {
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((ppo_train_pairs_kernel<NT1, DISC, OBS>), dim3(3), dim3(TH8), bytes, s, *one);
+  } else {
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_batch_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((ppo_train_pairs_batch_kernel<NT1, DISC, OBS>), dim3(3, n_runs), dim3(TH8), bytes, s, d_args);
+  }
   return (int)hipGetLastError();
 }
 
-int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int nt1, bool discrete, hipStream_t s) {
-  if (nt1 <= 2) return discrete ? launch_pairs_batch<2, true>(d_args, n_runs, s) : launch_pairs_batch<2, false>(d_args, n_runs, s);
-  if (nt1 <= 4) return discrete ? launch_pairs_batch<4, true>(d_args, n_runs, s) : launch_pairs_batch<4, false>(d_args, n_runs, s);
+static int dispatch_pairs(const TrainArgs* one, const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, hipStream_t s) {
+  if (nt1 <= 2) {
+    if (!discrete && obs == 18) return launch_pairs<2, false, 18>(one, d_args, n_runs, s);      // HCWithPos (BASELINE configs[1], [3])
+    if (discrete && obs == 1) return launch_pairs<2, true, 1>(one, d_args, n_runs, s);          // LapGridWorld (configs[0])
+    return discrete ? launch_pairs<2, true, 0>(one, d_args, n_runs, s) : launch_pairs<2, false, 0>(one, d_args, n_runs, s);
+  }
+  if (nt1 <= 4) return discrete ? launch_pairs<4, true, 0>(one, d_args, n_runs, s) : launch_pairs<4, false, 0>(one, d_args, n_runs, s);
   return fail("update (wave pairs): obs_dim tiles %d > 4", nt1);
 }
 
-template <int NT1, bool DISC>
-static int launch_pairs(const TrainArgs& a, hipStream_t s) {
-  static_assert(SmemP<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
-
-  const size_t bytes = (size_t)SmemP<NT1>::TOTAL * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_kernel<NT1, DISC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((ppo_train_pairs_kernel<NT1, DISC>), dim3(3), dim3(TH8), bytes, s, a);
-  return (int)hipGetLastError();
+int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, hipStream_t s) {
+  return dispatch_pairs(nullptr, d_args, n_runs, obs, nt1, discrete, s);
 }
 
 int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s) {
-  if (nt1 <= 2) return discrete ? launch_pairs<2, true>(a, s) : launch_pairs<2, false>(a, s);
-  if (nt1 <= 4) return discrete ? launch_pairs<4, true>(a, s) : launch_pairs<4, false>(a, s);
-  return fail("update (wave pairs): obs_dim tiles %d > 4", nt1);
+  return dispatch_pairs(&a, nullptr, 1, a.L.O, nt1, discrete, s);
 }
 
 }  // namespace icrl
