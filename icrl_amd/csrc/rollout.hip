@@ -1578,23 +1578,122 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
 //             owners per workgroup work side by side (gather 2 N granules, numpy-ordered moments, merge, publish)
 //   phase B2  every workgroup reads the 4 obs + 4 statistics granules and normalises its E envs
 constexpr int MULTI_OP = 128;     // padded per-env row of the LDS state arrays (>= MAX_OBS)
+// rows that feed the MFMA B operand (lane (r, q) reads element 4 ks + q of row r): a row stride of 4 mod 32 floats spreads the 64
+// lanes of a read over all banks (two lanes per bank: the minimum); strides of 64 / 128 would put 16 lanes on one bank
+constexpr int MULTI_XS = MULTI_OP + 4;
+constexpr int MULTI_HS = MAX_H + 4;
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-template <int E>
+template <int E, int CIT>
 struct MultiShared {
-  alignas(16) float x[E][MULTI_OP];          // normalised observation (policy input), pad = 0
+  alignas(16) float x[E][MULTI_XS];          // normalised observation (policy input), pad = 0
   alignas(16) double s_old[E][MULTI_OP];
   alignas(16) double s_new[E][MULTI_OP];
   alignas(16) double olast[E][MULTI_OP];     // normalised observation in float64 (== _last_obs)
-  alignas(16) float h[3][E][MAX_H];
-  alignas(16) float g[3][E][MAX_H];
-  alignas(16) float cx[MAX_CN_IN];
-  alignas(16) float ch[2][MAX_H];
-  float act_raw[E][MAX_ACT], act_clip[E][MAX_ACT], scal[E][4];
-  float noise[2][E][MAX_ACT], alow[MAX_ACT], ahigh[MAX_ACT], cost[E];
+  alignas(16) float h[4][E][MULTI_HS];       // per wave (pi | vf | cvf | cost net): the layer output it turns into its next B operand
+  alignas(16) float cx[E][16 * CIT + 4];     // cost-net inputs of every env
+  alignas(16) float act_raw[E][MAX_ACT];
+  alignas(16) float act_clip[E][MAX_ACT];
+  alignas(16) float noise[2][E][MAX_ACT];
+  alignas(16) float alow[MAX_ACT];
+  alignas(16) float ahigh[MAX_ACT];
+  float scal[E][4], cost[E];
   double rew[E], mean[MAX_OBS], var[MAX_OBS], dens[2];
   unsigned ctr[E], key[E];
   int tep[E], last_done[E], done[E];
 };
+
+// Register image of one wave of the multi-env kernel: the weights as MFMA A operands.  v_mfma_f32_16x16x4_f32 accumulates its four
+// products one after the other in k order with the rounding of fmaf (tools/ubench: a chain of them equals the chain
+// acc = fmaf(w[k], x[k], acc), k ascending, bit for bit in 51 200 of 51 200 outputs), so Z^T[unit][env] = W . X^T evaluated as
+// 16-unit x 16-env tiles gives every (unit, env) exactly the value of the per-environment fmaf chains of the other rollout kernels.
+// Lane (r = lane % 16, q = lane / 16): A operand of tile t, k step ks = W[unit 16 t + r][k = 4 ks + q]; the tile's result registers
+// i = 0..3 hold unit 16 t + 4 q + i of env r.
+template <int OCT, int CIT>
+struct TileRegs {
+  static constexpr int K1 = 4 * (OCT > CIT ? OCT : CIT);
+  float w1[4][K1];        // first layer (policy nets: 4 OCT k steps used | cost net: 4 CIT)
+  float w2[4][16];        // second layer
+  float wh[16];           // wave 0: Wa[action r][k = 4 ks + q] at [ks] | waves 1..3: output weight of unit 16 t + 4 q + i at [4 t + i]
+  float b1[16], b2[16];   // bias of unit 16 t + 4 q + i at [4 t + i]
+  float bh[4];            // wave 0: bias of action 4 q + i | waves 1..3: bh[0] = output bias
+  float sd[4], lsd[4], i2v[4];   // wave 0: Gaussian head constants of action 4 q + i (same expressions as load_pol_regs)
+  int sel[(16 * (CIT > 0 ? CIT : 1) + WAVE - 1) / WAVE];   // cost net: select_dim entries this lane prepares
+};
+
+template <int OCT, int CIT>
+__device__ __forceinline__ void load_pol_tiles(const PolLayout& L, const float* __restrict__ PT, TileRegs<OCT, CIT>& R) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int net = w < 3 ? w : 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ju = 16 * t + r;
+#pragma unroll
+    for (int ks = 0; ks < 4 * OCT; ++ks) { const int k = 4 * ks + q; R.w1[t][ks] = (ju < L.H1 && k < L.O) ? PT[L.W1[net] + k * L.H1 + ju] : 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) { const int k = 4 * ks + q; R.w2[t][ks] = (ju < L.H2 && k < L.H1) ? PT[L.W2[net] + k * L.H2 + ju] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * t + 4 * q + i;
+      R.b1[4 * t + i] = j < L.H1 ? PT[L.b1[net] + j] : 0.f;
+      R.b2[4 * t + i] = j < L.H2 ? PT[L.b2[net] + j] : 0.f;
+      R.wh[4 * t + i] = (w != 0 && j < L.H2) ? PT[(w == 1 ? L.Wv : L.Wc) + j] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { R.bh[i] = 0.f; R.sd[i] = 1.f; R.lsd[i] = 0.f; R.i2v[i] = 2.f; }
+  if (w == 0) {
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) { const int k = 4 * ks + q; R.wh[ks] = (r < L.A && k < L.H2) ? PT[L.Wa + k * L.A + r] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int a = 4 * q + i < L.A ? 4 * q + i : 0;
+      R.bh[i] = PT[L.ba + a];
+      const float ls = L.discrete ? 0.f : PT[L.log_std + a];
+      R.sd[i] = expf(ls); R.lsd[i] = logf(R.sd[i]); R.i2v[i] = 2.f * (R.sd[i] * R.sd[i]);
+    }
+  } else {
+    R.bh[0] = PT[w == 1 ? L.bv : L.bc];
+  }
+}
+
+template <int OCT, int CIT>
+__device__ __forceinline__ void load_cn_tiles(const icrl_costnet_t& cn, const CnLayout& L, TileRegs<OCT, CIT>& R) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  const float* PT = cn.params_t;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int ju = 16 * t + r;
+#pragma unroll
+    for (int ks = 0; ks < 4 * CIT; ++ks) { const int k = 4 * ks + q; R.w1[t][ks] = (ju < L.H1 && k < L.in) ? PT[L.W0 + k * L.H1 + ju] : 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) { const int k = 4 * ks + q; R.w2[t][ks] = (L.nh == 2 && ju < L.H2 && k < L.H1) ? PT[L.W1 + k * L.H2 + ju] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = 16 * t + 4 * q + i;
+      R.b1[4 * t + i] = j < L.H1 ? PT[L.b0 + j] : 0.f;
+      R.b2[4 * t + i] = (L.nh == 2 && j < L.H2) ? PT[L.b1 + j] : 0.f;
+      R.wh[4 * t + i] = j < L.H2 ? PT[L.Wo + j] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { R.bh[i] = 0.f; R.sd[i] = 1.f; R.lsd[i] = 0.f; R.i2v[i] = 2.f; }
+  R.bh[0] = PT[L.bo];
+#pragma unroll
+  for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) { const int idx = lane + i * WAVE; R.sel[i] = idx < L.in ? cn.select_dim[idx] : -1; }
+}
+
+// wave_sum_fast's association for a value that lives as [tile t][i] = element 16 t + 4 q + i of env r: element c + 16 m sits in
+// lane c + 16 m there, here c = 4 q + i and m = t.  wave_sum_fast: u[c] = (v[c] + v[c + 32]) + (v[c + 16] + v[c + 48]), then the
+// 16 u's as ((u0 + u1) + (u2 + u3)) quads, quads pairwise, halves.  Returns the sum of env r in all four q lanes.
+__device__ __forceinline__ float tile_sum64(const f32x4 (&v)[4]) {
+  float u[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = (v[0][i] + v[2][i]) + (v[1][i] + v[3][i]);
+  const float quad = (u[0] + u[1]) + (u[2] + u[3]);
+  return xor32_sum(xor16_sum(quad));
+}
 
 static inline size_t multi_dyn_lds(int N, int O, int A, int owners) {
   // dynamics matrix | per owner wave: column buffer (N + 64) | ret / cost owners: done flags [2][N] bytes.  (The discounted returns of
@@ -1602,41 +1701,12 @@ static inline size_t multi_dyn_lds(int N, int O, int A, int owners) {
   return ((size_t)O * A + (size_t)owners * (size_t)(N + 64)) * sizeof(double) + 2 * (size_t)((N + 15) / 16 * 16);
 }
 
-// E independent k-ascending fmaf chains (one per environment) against ONE register-resident weight vector W (named directly:
-// handing the register image to a function by address sends it to scratch): inputs X0[e * STRIDE + 0 .. 4 NK4) come from LDS as
-// 16-byte broadcast reads, one group of four inputs at a time.  The compiler fence between the groups keeps the reads of later
-// groups from being issued up front (E x 4 NK4 live registers next to the weights: hundreds of spills); per environment the
-// operation order is the plain chain acc = fmaf(w[k], x[k], acc), k = 0, 1, ...  EB environments are interleaved at a time (a
-// workgroup's E environments go through in E / EB passes of a run-time loop): the weights already take most of the register file.
-#define ICRL_MULTI_CHAINS(W, X0, STRIDE, NK4, ACC)                                                      \
-  {                                                                                                     \
-    f32x4 xc_[EB], xn_[EB];   /* inputs of the current group and, already in flight, of the next one */ \
-    _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_) {                                                 \
-      ACC[e_] = 0.f;                                                                                    \
-      xc_[e_] = *reinterpret_cast<const f32x4*>((X0) + e_ * (STRIDE));                                  \
-      xn_[e_] = xc_[e_];                                                                                \
-    }                                                                                                   \
-    _Pragma("unroll") for (int k4_ = 0; k4_ < (NK4); ++k4_) {                                           \
-      if (k4_ + 1 < (NK4)) {                                                                            \
-        _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_)                                               \
-          xn_[e_] = *reinterpret_cast<const f32x4*>((X0) + e_ * (STRIDE) + 4 * (k4_ + 1));              \
-      }                                                                                                 \
-      _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_) {                                               \
-        ACC[e_] = fmaf(W[4 * k4_ + 0], xc_[e_][0], ACC[e_]);                                            \
-        ACC[e_] = fmaf(W[4 * k4_ + 1], xc_[e_][1], ACC[e_]);                                            \
-        ACC[e_] = fmaf(W[4 * k4_ + 2], xc_[e_][2], ACC[e_]);                                            \
-        ACC[e_] = fmaf(W[4 * k4_ + 3], xc_[e_][3], ACC[e_]);                                            \
-      }                                                                                                 \
-      _Pragma("unroll") for (int e_ = 0; e_ < EB; ++e_) xc_[e_] = xn_[e_];                              \
-    }                                                                                                   \
-  }
-
 // synthetic env step of up to THREE environments at once by one wave (obs_dim <= 21): lane 21 s + i handles component i of the env in
 // slot s.  em / n / mine are PER-LANE: the env's slot in the workgroup's LDS state, its index in the run, and whether the lane has an
 // env at all.  The per-component arithmetic, the reward and the auto-reset draw are env_step_wave's, operation for operation; only
 // the lanes they run on differ.  Leaves s_new, ctr, tep, rew, done of every handled env in `sh`.
-template <int E>
-__device__ __noinline__ void env_step_wave3(const icrl_env_t& e, MultiShared<E>& sh, int em, int n, bool mine, int ci, int slot) {
+template <int E, int CIT>
+__device__ __noinline__ void env_step_wave3(const icrl_env_t& e, MultiShared<E, CIT>& sh, int em, int n, bool mine, int ci, int slot) {
   const int O = e.obs_dim, A = e.act_dim;
   const bool live = mine && ci < O;
   double a[MAX_ACT];
@@ -1688,15 +1758,13 @@ __device__ __noinline__ void env_step_wave3(const icrl_env_t& e, MultiShared<E>&
 
 template <int OCT, int CIT, int E>
 __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
-  constexpr int EB = OCT <= 2 ? 4 : 2;       // environments interleaved at a time
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
-  __shared__ MultiShared<E> sh;
+  __shared__ MultiShared<E, CIT> sh;
   const ActStepArgs& a = p.act;
   const icrl_norm_t& nm = p.nm;
-  WaveRegs<OCT, CIT> R;                // policy weights in waves 0..2, cost-net weights in wave 3
-  WaveRegs<OCT, CIT>& C = R;
-  load_pol_regs<OCT>(a.pl, a.PT, R);
-  if (threadIdx.x >= 192 && a.has_cn) load_cn_regs<CIT>(a.cn, a.cl, C);
+  TileRegs<OCT, CIT> R;                // waves 0..2: policy / value / cost-value net, wave 3: cost net — as MFMA A operands
+  if (threadIdx.x >= 192 && a.has_cn) load_cn_tiles<OCT, CIT>(a.cn, a.cl, R);
+  else load_pol_tiles<OCT, CIT>(a.pl, a.PT, R);
   const int g = blockIdx.x, G = p.G;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1746,6 +1814,9 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     const int e = tid / MAX_ACT, k = tid % MAX_ACT;
     sh.noise[0][e][k] = (e < Eg && k < NA) ? a.noise[((size_t)(g + e * G)) * NA + k] : 0.f;
   }
+  const int r16 = lane & 15, q4 = lane >> 4;          // MFMA lane coordinates: env row r16, k / unit quarter q4
+  const int er = r16 < E ? r16 : E - 1;               // rows beyond E replicate the last env's row (their results are not used)
+  const int nk1 = (O + 3) / 4, nkc = a.has_cn ? (a.cl.in + 3) / 4 : 0;
   int spin_limit = 1 << 22;
   __syncthreads();
   const bool prof = p.prof != 0 && g == p.prof - 1 && blockIdx.y == 0;
@@ -1757,52 +1828,98 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     const int pe = tid / MAX_ACT, pk = tid % MAX_ACT;
     const bool pf = tid < E * MAX_ACT && pe < Eg && pk < NA && t + 1 < T;
     if (pf) noise_next = a.noise[((size_t)(t + 1) * N + g + pe * G) * NA + pk];
-    // ---------------- phase A: the three MLPs, EB envs interleaved at a time ----------------
+    // ---------------- phase A: the three MLPs for all E envs at once, as MFMA tiles (TileRegs) ----------------
+    // A wave consumes only its own network's activations: the hand-over between layers (result layout [unit 16 t + 4 q + i][env r]
+    // -> B operand layout [k = 4 ks + q][env r]) goes through the wave's own LDS rows, no workgroup barrier until the heads are done.
     if (w < 3) {
-      for (int eb = 0; eb < E; eb += EB) {
-        float acc[EB];
-        ICRL_MULTI_CHAINS(R.w1, &sh.x[eb][0], MULTI_OP, 4 * OCT, acc)
+      f32x4 z[4];
+      float bop[16];
 #pragma unroll
-        for (int e = 0; e < EB; ++e) sh.h[w][eb + e][lane] = lane < a.pl.H1 ? fast_tanh(acc[e] + R.b1) : 0.f;
-      }
-    }
-    __syncthreads();
-    if (w < 3) {
-      for (int eb = 0; eb < E; eb += EB) {
-        float acc[EB];
-        ICRL_MULTI_CHAINS(R.w2, &sh.h[w][eb][0], MAX_H, MAX_H / 4, acc)
+      for (int t = 0; t < 4; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        const float* xb = &sh.x[er][q4];
 #pragma unroll
-        for (int e = 0; e < EB; ++e) sh.g[w][eb + e][lane] = lane < a.pl.H2 ? fast_tanh(acc[e] + R.b2) : 0.f;
-      }
-    }
-    __syncthreads();
-    if (w == 0) {                       // action head + Gaussian sample / log-prob of every env (lane = action index)
-      for (int eb = 0; eb < E; eb += EB) {
-        float acc[EB];
-        ICRL_MULTI_CHAINS(R.wh, &sh.g[0][eb][0], MAX_H, MAX_H / 4, acc)
+        for (int ks = 0; ks < 4 * OCT; ++ks) {
+          if (ks < nk1) {               // (k steps that only meet padding — zero weights — are not issued)
+            const float b = xb[4 * ks];
 #pragma unroll
-        for (int ee = 0; ee < EB; ++ee) {
-          const int e = eb + ee;
-          const float mean = acc[ee] + R.bh;
-          float lp = 0.f;
-          if (lane < A) {
-            const float act = mean + sh.noise[par][e][lane] * R.sd;       // Normal.rsample: loc + eps * scale
-            const float diff = act - mean;
-            lp = -(diff * diff) / R.i2v - R.lsd - LOG_SQRT_2PI_F;
-            sh.act_raw[e][lane] = act;
-            float c = act;
-            if (has_box) c = fminf(fmaxf(act, sh.alow[lane]), sh.ahigh[lane]);
-            sh.act_clip[e][lane] = c;
+            for (int t = 0; t < 4; ++t) z[t] = MFMA16(R.w1[t][ks], b, z[t]);
           }
-          lp = wave_sum_fast(lp);
-          if (lane == 0) sh.scal[e][2] = lp;
         }
       }
-    } else if (w < 3) {                 // value heads
-      for (int e = 0; e < E; ++e) {
-        float part = lane < a.pl.H2 ? R.wh[0] * sh.g[w][e][lane] : 0.f;
-        part = wave_sum_fast(part);
-        if (lane == 0) sh.scal[e][w - 1] = part + R.bh;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H1 ? fast_tanh(z[t][i] + R.b1[4 * t + i]) : 0.f;
+      if (r16 < E) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&sh.h[w][r16][16 * t + 4 * q4]) = z[t];
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      {
+        const float* hb = &sh.h[w][er][q4];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) bop[ks] = hb[4 * ks];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) z[t] = MFMA16(R.w2[t][ks], bop[ks], z[t]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H2 ? fast_tanh(z[t][i] + R.b2[4 * t + i]) : 0.f;
+      if (w == 0) {                     // action head + Gaussian sample / log-prob of every env: lane (r, q) holds actions 4 q + i of env r
+        __builtin_amdgcn_wave_barrier();        // (every lane's reads of h are consumed: the MFMAs above used them)
+        if (r16 < E) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&sh.h[0][r16][16 * t + 4 * q4]) = z[t];
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        {
+          const float* hb = &sh.h[0][er][q4];
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) bop[ks] = hb[4 * ks];
+        }
+        f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) m = MFMA16(R.wh[ks], bop[ks], m);
+        const f32x4 nz = *reinterpret_cast<const f32x4*>(&sh.noise[par][er][4 * q4]);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&sh.alow[4 * q4]);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(&sh.ahigh[4 * q4]);
+        f32x4 araw, aclip;
+        float u[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float mean = m[i] + R.bh[i];
+          float lp = 0.f, act = 0.f, c = 0.f;
+          if (4 * q4 + i < A) {
+            act = mean + nz[i] * R.sd[i];                 // Normal.rsample: loc + eps * scale
+            const float diff = act - mean;
+            lp = -(diff * diff) / R.i2v[i] - R.lsd[i] - LOG_SQRT_2PI_F;
+            c = act;
+            if (has_box) c = fminf(fmaxf(act, lo[i]), hi[i]);
+          }
+          araw[i] = act; aclip[i] = c;
+          u[i] = (lp + 0.f) + (0.f + 0.f);                // wave_sum_fast over lane = action: lanes 16.. hold 0
+        }
+        const float lp_env = xor32_sum(xor16_sum((u[0] + u[1]) + (u[2] + u[3])));
+        if (r16 < E) {
+          *reinterpret_cast<f32x4*>(&sh.act_raw[r16][4 * q4]) = araw;
+          *reinterpret_cast<f32x4*>(&sh.act_clip[r16][4 * q4]) = aclip;
+          if (q4 == 0) sh.scal[r16][2] = lp_env;
+        }
+      } else {                          // value heads: products with the output weights, summed in wave_sum_fast's order
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H2 ? R.wh[4 * t + i] * z[t][i] : 0.f;
+        const float v = tile_sum64(z) + R.bh[0];
+        if (r16 < E && q4 == 0) sh.scal[r16][w - 1] = v;
       }
     }
     __syncthreads();
@@ -1831,7 +1948,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
             a.ag.last_v_c[n] = sh.scal[em][1];
           }
         }
-        env_step_wave3<E>(env, sh, em, n, mine, ci, slot);
+        env_step_wave3<E, CIT>(env, sh, em, n, mine, ci, slot);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);      // the wave's LDS writes (s_new, rew, done) are visible to its own reads
         if (mine) {
@@ -1885,18 +2002,101 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
           sh.ctr[e] = e_ctr; sh.tep[e] = e_tep; sh.rew[e] = rew; sh.done[e] = done;
         }
       }
-    } else {
+    } else if (a.has_cn) {
+      // cost net of all E envs at once (wave 3): prepare() per env into cx, then the ReLU layers as MFMA tiles
       for (int e = 0; e < Eg; ++e) {
-        const int n = g + e * G;
-        const size_t tn = (size_t)t * N + n;
-        float cost = 0.f;
-        if (a.has_cn) cost = cost_forward_wave<CIT>(a.cn, a.cl, C, sh.s_old[e], sh.act_clip[e], sh.cx, sh.ch);
-        if (lane == 0) {
-          gstore(p.xg + ((size_t)par * N + n) * GX + 2 * O + 2, gtag, __float_as_uint(cost));
-          a.buf.orig_costs[tn] = cost;
-          sh.cost[e] = cost;
+#pragma unroll
+        for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) {
+          const int idx = lane + i * WAVE;
+          const int sel = R.sel[i];
+          float v = 0.f;
+          if (sel >= 0) {
+            if (sel < a.cn.obs_dim) {
+              double o = sh.s_old[e][sel];
+              if (a.cn.obs_mean != nullptr && a.cn.obs_var != nullptr) o = (o - a.cn.obs_mean[sel]) / sqrt(a.cn.obs_var[sel] + a.cn.eps);
+              if (a.cn.clip_obs >= 0.0) o = fmin(fmax(o, -a.cn.clip_obs), a.cn.clip_obs);
+              v = (float)o;
+            } else {
+              const int ai = sel - a.cn.obs_dim;
+              float x;
+              if (a.cn.is_discrete) x = ((int)sh.act_clip[e][0] == ai) ? 1.f : 0.f;
+              else x = sh.act_clip[e][ai];
+              if (a.cn.action_low != nullptr && a.cn.action_high != nullptr) x = fminf(fmaxf(x, a.cn.action_low[ai]), a.cn.action_high[ai]);
+              v = x;
+            }
+          }
+          if (idx < 16 * CIT) sh.cx[e][idx] = v;       // pad entries are written as 0
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      const int erc = r16 < Eg ? r16 : Eg - 1;          // (rows beyond the workgroup's envs replicate the last one)
+      f32x4 z[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        const float* xb = &sh.cx[erc][q4];
+#pragma unroll
+        for (int ks = 0; ks < 4 * CIT; ++ks) {
+          if (ks < nkc) {
+            const float b = xb[4 * ks];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (16 * t < a.cl.H1) z[t] = MFMA16(R.w1[t][ks], b, z[t]);
+          }
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H1 ? fmaxf(z[t][i] + R.b1[4 * t + i], 0.f) : 0.f;
+      if (a.cl.nh == 2) {
+        if (r16 < E) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&sh.h[3][r16][16 * t + 4 * q4]) = z[t];
         }
         __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        float bop[16];
+        {
+          const float* hb = &sh.h[3][er][q4];
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) bop[ks] = hb[4 * ks];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          if (4 * ks < a.cl.H1) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+              if (16 * t < a.cl.H2) z[t] = MFMA16(R.w2[t][ks], bop[ks], z[t]);
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H2 ? fmaxf(z[t][i] + R.b2[4 * t + i], 0.f) : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H2 ? R.wh[4 * t + i] * z[t][i] : 0.f;
+      const float zz = tile_sum64(z) + R.bh[0];
+      const float zeta = 1.f / (1.f + expf(-zz));
+      const float cost = 1.f - zeta;
+      if (q4 == 0 && r16 < Eg) {
+        const int n = g + r16 * G;
+        gstore(p.xg + ((size_t)par * N + n) * GX + 2 * O + 2, gtag, __float_as_uint(cost));
+        a.buf.orig_costs[(size_t)t * N + n] = cost;
+        sh.cost[r16] = cost;
+      }
+    } else {
+      if (lane < Eg) {
+        const int n = g + lane * G;
+        gstore(p.xg + ((size_t)par * N + n) * GX + 2 * O + 2, gtag, __float_as_uint(0.f));
+        a.buf.orig_costs[(size_t)t * N + n] = 0.f;
+        sh.cost[lane] = 0.f;
       }
     }
     if (prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }     // env steps / cost net + rows (this wave's part)

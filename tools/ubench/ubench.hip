@@ -20,6 +20,23 @@ __device__ __forceinline__ float fast_tanh2(float x) {   // 1 - 2 / (exp2(c x) +
   return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
 }
 
+// Is a chain of fp32 16x16x4 MFMAs bit-identical to the sequential chain acc = fmaf(a[k], b[k], acc), k ascending?  A is 16 x K,
+// B is K x 16 (K = 64); mismatching output elements are counted.  scale mixes magnitudes so that rounding differs between orders.
+__global__ void k_mfma_vs_fma(const float* A, const float* B, int K, int* mismatches, float* worst) {
+  const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
+  f32x4 acc = f32x4{0, 0, 0, 0};
+  for (int k0 = 0; k0 < K; k0 += 4) acc = MFMA(A[r * K + k0 + q], B[(k0 + q) * 16 + r], acc);
+  int bad = 0; float wdev = 0.f;
+  for (int i = 0; i < 4; ++i) {
+    const int row = 4 * q + i, col = r;
+    float ref = 0.f;
+    for (int k = 0; k < K; ++k) ref = fmaf(A[row * K + k], B[k * 16 + col], ref);
+    if (__float_as_uint(ref) != __float_as_uint(acc[i])) { ++bad; wdev = fmaxf(wdev, fabsf(ref - acc[i])); }
+  }
+  atomicAdd(mismatches, bad);
+  atomicMax(reinterpret_cast<unsigned*>(worst), __float_as_uint(wdev));
+}
+
 template <int CHAINS>
 __global__ void k_mfma(float* out, unsigned long long* cyc, int iters) {
   f32x4 acc[CHAINS];
@@ -248,6 +265,59 @@ __global__ void k_lds32(float* out, unsigned long long* cyc, int iters) {
   if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
 }
 
+// v_fmac_f32: CH independent accumulator chains of 64 terms each, weights in registers; MODE 0 = activations in registers,
+// 1 = activations fetched by broadcast ds_read_b128 (every lane the same address, the rollout kernels' pattern), prefetched one
+// group ahead, 2 = the same without prefetch (load, wait, use)
+template <int CH, int MODE>
+__global__ void k_fmac(float* out, unsigned long long* cyc, int iters) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  for (int i = threadIdx.x; i < 4096; i += blockDim.x) sm[i] = 1e-3f * (i & 31);
+  __syncthreads();
+  float w[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) w[k] = 1e-3f * (threadIdx.x + k);
+  float acc[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) acc[c] = c;
+  unsigned long long t0 = now();
+  for (int i = 0; i < iters; ++i) {
+    if (MODE == 0) {
+#pragma unroll
+      for (int k = 0; k < 64; ++k)
+#pragma unroll
+        for (int c = 0; c < CH; ++c) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[c]) : "v"(w[k]), "v"(w[(k + c + 1) & 63]));
+    } else {
+      f32x4 cur[CH], nxt[CH];
+      const float* base = sm + (i & 7) * 64 * CH;
+#pragma unroll
+      for (int c = 0; c < CH; ++c) cur[c] = *reinterpret_cast<const f32x4*>(base + c * 64);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        if (MODE == 1 && j < 15) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) nxt[c] = *reinterpret_cast<const f32x4*>(base + c * 64 + 4 * (j + 1));
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int c = 0; c < CH; ++c) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(acc[c]) : "v"(cur[c][e]), "v"(w[4 * j + e]));
+        if (MODE == 2 && j < 15) {
+#pragma unroll
+          for (int c = 0; c < CH; ++c) nxt[c] = *reinterpret_cast<const f32x4*>(base + c * 64 + 4 * (j + 1));
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) cur[c] = nxt[c];
+      }
+    }
+  }
+  unsigned long long t1 = now();
+  float s = 0;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) s += acc[c];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 __global__ void k_barrier(float* out, unsigned long long* cyc, int iters) {
   unsigned long long t0 = now();
   for (int i = 0; i < iters; ++i) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -373,6 +443,35 @@ int main() {
   hipLaunchKernelGGL((k_lds32<64, 72>), dim3(1), dim3(256), 72 * 64 * 4, 0, out, cyc, it); rd("64 x ds_read_b32 transposed stride 72, 4 waves", it);
   hipLaunchKernelGGL((k_lds32<64, 68>), dim3(1), dim3(256), 72 * 64 * 4, 0, out, cyc, it); rd("64 x ds_read_b32 transposed stride 68, 4 waves", it);
   hipLaunchKernelGGL((k_lds32<16, 72>), dim3(1), dim3(256), 72 * 64 * 4, 0, out, cyc, it); rd("16 x ds_read_b32 transposed stride 72, 4 waves", it);
+  hipLaunchKernelGGL((k_fmac<1, 0>), dim3(1), dim3(64), 16384, 0, out, cyc, it); rd("v_fmac, 1 dependent chain, registers, per fmac", it * 64.0);
+  hipLaunchKernelGGL((k_fmac<2, 0>), dim3(1), dim3(64), 16384, 0, out, cyc, it); rd("v_fmac, 2 chains, registers, per fmac", it * 128.0);
+  hipLaunchKernelGGL((k_fmac<4, 0>), dim3(1), dim3(64), 16384, 0, out, cyc, it); rd("v_fmac, 4 chains, registers, per fmac", it * 256.0);
+  hipLaunchKernelGGL((k_fmac<4, 0>), dim3(1), dim3(256), 16384, 0, out, cyc, it); rd("v_fmac, 4 chains, registers, 4 waves, per fmac/wave", it * 256.0);
+  hipLaunchKernelGGL((k_fmac<4, 1>), dim3(1), dim3(64), 16384, 0, out, cyc, it); rd("v_fmac, 4 chains, broadcast b128 prefetched, 1 wave", it * 256.0);
+  hipLaunchKernelGGL((k_fmac<4, 1>), dim3(1), dim3(256), 16384, 0, out, cyc, it); rd("v_fmac, 4 chains, broadcast b128 prefetched, 4 waves", it * 256.0);
+  hipLaunchKernelGGL((k_fmac<4, 2>), dim3(1), dim3(256), 16384, 0, out, cyc, it); rd("v_fmac, 4 chains, broadcast b128 not prefetched, 4 waves", it * 256.0);
+  hipLaunchKernelGGL((k_fmac<2, 1>), dim3(1), dim3(256), 16384, 0, out, cyc, it); rd("v_fmac, 2 chains, broadcast b128 prefetched, 4 waves", it * 128.0);
+  hipLaunchKernelGGL((k_fmac<1, 1>), dim3(1), dim3(256), 16384, 0, out, cyc, it); rd("v_fmac, 1 chain, broadcast b128 prefetched, 4 waves", it * 64.0);
+  for (int blocks : {1, 8, 64, 256, 1024}) {   // does the rate hold when the whole chip runs the same chains (clock under load)?
+    char nm[96]; snprintf(nm, sizeof nm, "v_fmac, 4 chains, broadcast b128, 4 waves, %d workgroups", blocks);
+    hipLaunchKernelGGL((k_fmac<4, 1>), dim3(blocks), dim3(256), 16384, 0, out, cyc, 20 * it); rd(nm, 20 * it * 256.0);
+  }
+  { // bit-identity of MFMA accumulation with the fmaf chain
+    const int K = 64; std::vector<float> hA(16 * K), hB(K * 16);
+    unsigned st = 12345u; auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) & 0xffff) / 32768.f - 1.f; };
+    float *dA, *dB, *dw; int* dm; CK(hipMalloc(&dA, hA.size() * 4)); CK(hipMalloc(&dB, hB.size() * 4)); CK(hipMalloc(&dm, 4)); CK(hipMalloc(&dw, 4));
+    int total = 0, trials = 200; float worst = 0.f;
+    for (int tr = 0; tr < trials; ++tr) {
+      for (auto& v : hA) { v = rnd(); if (tr & 1) v *= (rnd() > 0.5f ? 1e3f : 1e-3f); }
+      for (auto& v : hB) v = rnd();
+      hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice); hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
+      hipMemset(dm, 0, 4); hipMemset(dw, 0, 4);
+      hipLaunchKernelGGL(k_mfma_vs_fma, dim3(1), dim3(64), 0, 0, dA, dB, K, dm, dw);
+      int m; float w; hipMemcpy(&m, dm, 4, hipMemcpyDeviceToHost); hipMemcpy(&w, dw, 4, hipMemcpyDeviceToHost);
+      total += m; worst = w > worst ? w : worst;
+    }
+    printf("mfma 16x16x4 f32 chain vs sequential fmaf chain (K = 64): %d of %d outputs differ bitwise (worst |d| %.3e)\n", total, trials * 256, worst);
+  }
   hipLaunchKernelGGL(k_barrier, dim3(1), dim3(256), 0, 0, out, cyc, it); rd("s_barrier, 4 waves", it);
   hipLaunchKernelGGL(k_barrier, dim3(1), dim3(512), 0, 0, out, cyc, it); rd("s_barrier, 8 waves", it);
   hipLaunchKernelGGL(k_pingpong, dim3(2), dim3(64), 0, 0, flag, cyc, it, 1); rd("granule round trip, workgroups 0 and 1 (different XCDs)", it);
@@ -384,6 +483,7 @@ int main() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0); hipLaunchKernelGGL(k_mfma<4>, dim3(1), dim3(64), 0, 0, out, cyc, 20000); hipEventRecord(e1); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1); hipMemcpy(h.data(), cyc, 64, hipMemcpyDeviceToHost);
+  const unsigned long long clock_ticks = h[0];
   {
     unsigned long long* bulk;
     CK(hipMalloc(&bulk, 4 * 32 * 256 * 8 * 2));
@@ -401,6 +501,6 @@ int main() {
     run(k_bulk<1, 16>, "bulk exchange, 16-byte records (2 values), 16 per thread", 16);
     run(k_bulk<1, 32>, "bulk exchange, 16-byte records (2 values), 32 per thread", 32);
   }
-  printf("s_memtime ticks per us: %.1f  (ticks %llu over %.3f ms)\n", (double)h[0] / (ms * 1e3), h[0], ms);
+  printf("s_memtime ticks per us: %.1f  (ticks %llu over %.3f ms)\n", (double)clock_ticks / (ms * 1e3), clock_ticks, ms);
   return 0;
 }
