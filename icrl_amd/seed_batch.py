@@ -261,6 +261,12 @@ class SeedBatch:
             s_ = getattr(st["config"], "streams", None)
             enoise.append(None if s_ is None else s_.eval_noise(10 * st["eval_env"].unwrapped.max_steps, A))
         eruns, erewards = self._episodes([st["eval_env"] for st in sts], 10, False, enoise, False)
+        for i, (st, a) in enumerate(zip(sts, agents)):          # the KL metrics stay on the device until the one copy below
+            if st["expert_agent"] is not None:
+                orig_obs, obs, acts, rews, lengths = samples[i]
+                fkl = utils.compute_kl_device(a, st["d_expert_obs"], st["d_expert_acs"], st["expert_agent"])
+                rkl = utils.compute_kl_device(st["expert_agent"], orig_obs, acts, a)
+                tail[i] = torch.cat([tail[i], torch.stack([fkl, rkl]).double()])
         tail_h = self._to_host(tail)
         out = []
         for i, (st, a) in enumerate(zip(sts, agents)):
@@ -271,8 +277,7 @@ class SeedBatch:
             average_true_reward, std_true_reward = utils.evaluate_result(eruns[i], erewards[i])
             forward_kl = reverse_kl = float("nan")
             if st["expert_agent"] is not None:
-                forward_kl = utils.compute_kl(a, st["d_expert_obs"], st["d_expert_acs"], st["expert_agent"])
-                reverse_kl = utils.compute_kl(st["expert_agent"], orig_obs, acts, a)
+                forward_kl, reverse_kl = float(tail_h[i][2]), float(tail_h[i][3])
             best = st["best"]
             if config.save_dir and itr % config.save_every == 0:
                 path = os.path.join(config.save_dir, f"models/icrl_{itr}_itrs")

@@ -216,10 +216,16 @@ def compute_kl(agent_2, observations, actions, agent_1=None):
     """ref: icrl/utils.py:421-437; observations are fed un-normalised, as the reference does.  QUIRK kept: the reference
     takes element [1] of evaluate_actions(), which for the two-critics policy is the cost value (policies.py:752-767 returns
     values, cost_values, log_prob, entropy), so the logged "KL" is mean(V_c^{agent_1} - V_c^{agent_2})."""
+    return float(compute_kl_device(agent_2, observations, actions, agent_1).item())
+
+
+def compute_kl_device(agent_2, observations, actions, agent_1=None):
+    """compute_kl without the device->host copy: the float32 scalar stays on the device (callers that log many runs at once fetch
+    all of them with one copy, icrl_amd/seed_batch.py)."""
     kl = -agent_2.policy.evaluate_actions(observations, actions)[1].reshape(-1)
     if agent_1 is not None:
         kl = kl + agent_1.policy.evaluate_actions(observations, actions)[1].reshape(-1)
-    return float((kl.sum() / kl.shape[0]).item())
+    return kl.sum() / kl.shape[0]
 
 
 # ---- on-disk artefacts -------------------------------------------------------------------------------------------------------
