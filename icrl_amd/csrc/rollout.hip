@@ -1583,6 +1583,9 @@ constexpr int MULTI_OP = 128;     // padded per-env row of the LDS state arrays 
 constexpr int MULTI_XS = MULTI_OP + 4;
 constexpr int MULTI_HS = MAX_H + 4;
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// per-wave constants read back as 16-byte rows where they are used (they would cost 84 registers per lane next to the weights):
+// by unit j: b1 | b2 | output weight (value / cost-value / cost net);  by action a (wave 0): bias | exp(log_std) | log(sd) | 2 sd^2;  [CST_BO]: output bias
+constexpr int CST_B1 = 0, CST_B2 = 64, CST_WO = 128, CST_BA = 192, CST_SD = 208, CST_LSD = 224, CST_I2V = 240, CST_BO = 256, MULTI_CST = 260;
 
 template <int E, int CIT>
 struct MultiShared {
@@ -1592,6 +1595,7 @@ struct MultiShared {
   alignas(16) double olast[E][MULTI_OP];     // normalised observation in float64 (== _last_obs)
   alignas(16) float h[4][E][MULTI_HS];       // per wave (pi | vf | cvf | cost net): the layer output it turns into its next B operand
   alignas(16) float cx[E][16 * CIT + 4];     // cost-net inputs of every env
+  alignas(16) float cst[4][MULTI_CST];       // per wave: biases / output weights by unit, Gaussian head constants by action (TileRegs)
   alignas(16) float act_raw[E][MAX_ACT];
   alignas(16) float act_clip[E][MAX_ACT];
   alignas(16) float noise[2][E][MAX_ACT];
@@ -1614,15 +1618,12 @@ struct TileRegs {
   static constexpr int K1 = 4 * (OCT > CIT ? OCT : CIT);
   float w1[4][K1];        // first layer (policy nets: 4 OCT k steps used | cost net: 4 CIT)
   float w2[4][16];        // second layer
-  float wh[16];           // wave 0: Wa[action r][k = 4 ks + q] at [ks] | waves 1..3: output weight of unit 16 t + 4 q + i at [4 t + i]
-  float b1[16], b2[16];   // bias of unit 16 t + 4 q + i at [4 t + i]
-  float bh[4];            // wave 0: bias of action 4 q + i | waves 1..3: bh[0] = output bias
-  float sd[4], lsd[4], i2v[4];   // wave 0: Gaussian head constants of action 4 q + i (same expressions as load_pol_regs)
+  float wh[16];           // wave 0: Wa[action r][k = 4 ks + q] at [ks] (the other per-unit / per-action constants: MultiShared::cst)
   int sel[(16 * (CIT > 0 ? CIT : 1) + WAVE - 1) / WAVE];   // cost net: select_dim entries this lane prepares
 };
 
 template <int OCT, int CIT>
-__device__ __forceinline__ void load_pol_tiles(const PolLayout& L, const float* __restrict__ PT, TileRegs<OCT, CIT>& R) {
+__device__ __forceinline__ void load_pol_tiles(const PolLayout& L, const float* __restrict__ PT, TileRegs<OCT, CIT>& R, float* cst) {
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int net = w < 3 ? w : 0;
@@ -1633,33 +1634,28 @@ __device__ __forceinline__ void load_pol_tiles(const PolLayout& L, const float* 
     for (int ks = 0; ks < 4 * OCT; ++ks) { const int k = 4 * ks + q; R.w1[t][ks] = (ju < L.H1 && k < L.O) ? PT[L.W1[net] + k * L.H1 + ju] : 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) { const int k = 4 * ks + q; R.w2[t][ks] = (ju < L.H2 && k < L.H1) ? PT[L.W2[net] + k * L.H2 + ju] : 0.f; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 16 * t + 4 * q + i;
-      R.b1[4 * t + i] = j < L.H1 ? PT[L.b1[net] + j] : 0.f;
-      R.b2[4 * t + i] = j < L.H2 ? PT[L.b2[net] + j] : 0.f;
-      R.wh[4 * t + i] = (w != 0 && j < L.H2) ? PT[(w == 1 ? L.Wv : L.Wc) + j] : 0.f;
-    }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { R.bh[i] = 0.f; R.sd[i] = 1.f; R.lsd[i] = 0.f; R.i2v[i] = 2.f; }
-  if (w == 0) {
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) { const int k = 4 * ks + q; R.wh[ks] = (r < L.A && k < L.H2) ? PT[L.Wa + k * L.A + r] : 0.f; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int a = 4 * q + i < L.A ? 4 * q + i : 0;
-      R.bh[i] = PT[L.ba + a];
-      const float ls = L.discrete ? 0.f : PT[L.log_std + a];
-      R.sd[i] = expf(ls); R.lsd[i] = logf(R.sd[i]); R.i2v[i] = 2.f * (R.sd[i] * R.sd[i]);
+  for (int ks = 0; ks < 16; ++ks) { const int k = 4 * ks + q; R.wh[ks] = (w == 0 && r < L.A && k < L.H2) ? PT[L.Wa + k * L.A + r] : 0.f; }
+  {
+    const int j = lane;
+    cst[CST_B1 + j] = j < L.H1 ? PT[L.b1[net] + j] : 0.f;
+    cst[CST_B2 + j] = j < L.H2 ? PT[L.b2[net] + j] : 0.f;
+    cst[CST_WO + j] = (w != 0 && j < L.H2) ? PT[(w == 1 ? L.Wv : L.Wc) + j] : 0.f;
+    if (j < 16) {
+      // constants of the whole rollout: evaluated once here instead of once per env step (same expressions as load_pol_regs)
+      const int a = j < L.A ? j : 0;
+      const float ls = (w == 0 && !L.discrete) ? PT[L.log_std + a] : 0.f;
+      const float sd = expf(ls);
+      cst[CST_BA + j] = w == 0 ? PT[L.ba + a] : 0.f;
+      cst[CST_SD + j] = sd; cst[CST_LSD + j] = logf(sd); cst[CST_I2V + j] = 2.f * (sd * sd);
     }
-  } else {
-    R.bh[0] = PT[w == 1 ? L.bv : L.bc];
+    if (j == 0) cst[CST_BO] = w == 0 ? 0.f : PT[w == 1 ? L.bv : L.bc];
   }
 }
 
 template <int OCT, int CIT>
-__device__ __forceinline__ void load_cn_tiles(const icrl_costnet_t& cn, const CnLayout& L, TileRegs<OCT, CIT>& R) {
+__device__ __forceinline__ void load_cn_tiles(const icrl_costnet_t& cn, const CnLayout& L, TileRegs<OCT, CIT>& R, float* cst) {
   const int lane = threadIdx.x & 63, r = lane & 15, q = lane >> 4;
   const float* PT = cn.params_t;
 #pragma unroll
@@ -1669,17 +1665,16 @@ __device__ __forceinline__ void load_cn_tiles(const icrl_costnet_t& cn, const Cn
     for (int ks = 0; ks < 4 * CIT; ++ks) { const int k = 4 * ks + q; R.w1[t][ks] = (ju < L.H1 && k < L.in) ? PT[L.W0 + k * L.H1 + ju] : 0.f; }
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) { const int k = 4 * ks + q; R.w2[t][ks] = (L.nh == 2 && ju < L.H2 && k < L.H1) ? PT[L.W1 + k * L.H2 + ju] : 0.f; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 16 * t + 4 * q + i;
-      R.b1[4 * t + i] = j < L.H1 ? PT[L.b0 + j] : 0.f;
-      R.b2[4 * t + i] = (L.nh == 2 && j < L.H2) ? PT[L.b1 + j] : 0.f;
-      R.wh[4 * t + i] = j < L.H2 ? PT[L.Wo + j] : 0.f;
-    }
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { R.bh[i] = 0.f; R.sd[i] = 1.f; R.lsd[i] = 0.f; R.i2v[i] = 2.f; }
-  R.bh[0] = PT[L.bo];
+  for (int ks = 0; ks < 16; ++ks) R.wh[ks] = 0.f;
+  {
+    const int j = lane;
+    cst[CST_B1 + j] = j < L.H1 ? PT[L.b0 + j] : 0.f;
+    cst[CST_B2 + j] = (L.nh == 2 && j < L.H2) ? PT[L.b1 + j] : 0.f;
+    cst[CST_WO + j] = j < L.H2 ? PT[L.Wo + j] : 0.f;
+    if (j == 0) cst[CST_BO] = PT[L.bo];
+  }
 #pragma unroll
   for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) { const int idx = lane + i * WAVE; R.sel[i] = idx < L.in ? cn.select_dim[idx] : -1; }
 }
@@ -1763,8 +1758,8 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   const ActStepArgs& a = p.act;
   const icrl_norm_t& nm = p.nm;
   TileRegs<OCT, CIT> R;                // waves 0..2: policy / value / cost-value net, wave 3: cost net — as MFMA A operands
-  if (threadIdx.x >= 192 && a.has_cn) load_cn_tiles<OCT, CIT>(a.cn, a.cl, R);
-  else load_pol_tiles<OCT, CIT>(a.pl, a.PT, R);
+  if (threadIdx.x >= 192 && a.has_cn) load_cn_tiles<OCT, CIT>(a.cn, a.cl, R, sh.cst[3]);
+  else load_pol_tiles<OCT, CIT>(a.pl, a.PT, R, sh.cst[threadIdx.x >> 6]);
   const int g = blockIdx.x, G = p.G;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1832,10 +1827,11 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     // A wave consumes only its own network's activations: the hand-over between layers (result layout [unit 16 t + 4 q + i][env r]
     // -> B operand layout [k = 4 ks + q][env r]) goes through the wave's own LDS rows, no workgroup barrier until the heads are done.
     if (w < 3) {
-      f32x4 z[4];
+      f32x4 z[4], cb[4];
       float bop[16];
+      const float* const cw = &sh.cst[w][4 * q4];       // this lane's slice of the wave's constants: + CST_x + 16 t
 #pragma unroll
-      for (int t = 0; t < 4; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 4; ++t) { z[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[t] = *reinterpret_cast<const f32x4*>(cw + CST_B1 + 16 * t); }
       {
         const float* xb = &sh.x[er][q4];
 #pragma unroll
@@ -1850,7 +1846,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H1 ? fast_tanh(z[t][i] + R.b1[4 * t + i]) : 0.f;
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H1 ? fast_tanh(z[t][i] + cb[t][i]) : 0.f;
       if (r16 < E) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&sh.h[w][r16][16 * t + 4 * q4]) = z[t];
@@ -1863,7 +1859,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         for (int ks = 0; ks < 16; ++ks) bop[ks] = hb[4 * ks];
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 4; ++t) { z[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[t] = *reinterpret_cast<const f32x4*>(cw + CST_B2 + 16 * t); }
 #pragma unroll
       for (int ks = 0; ks < 16; ++ks)
 #pragma unroll
@@ -1871,7 +1867,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H2 ? fast_tanh(z[t][i] + R.b2[4 * t + i]) : 0.f;
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H2 ? fast_tanh(z[t][i] + cb[t][i]) : 0.f;
       if (w == 0) {                     // action head + Gaussian sample / log-prob of every env: lane (r, q) holds actions 4 q + i of env r
         __builtin_amdgcn_wave_barrier();        // (every lane's reads of h are consumed: the MFMAs above used them)
         if (r16 < E) {
@@ -1891,16 +1887,18 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         const f32x4 nz = *reinterpret_cast<const f32x4*>(&sh.noise[par][er][4 * q4]);
         const f32x4 lo = *reinterpret_cast<const f32x4*>(&sh.alow[4 * q4]);
         const f32x4 hi = *reinterpret_cast<const f32x4*>(&sh.ahigh[4 * q4]);
+        const f32x4 hb_ = *reinterpret_cast<const f32x4*>(cw + CST_BA), sd_ = *reinterpret_cast<const f32x4*>(cw + CST_SD);
+        const f32x4 lsd_ = *reinterpret_cast<const f32x4*>(cw + CST_LSD), i2v_ = *reinterpret_cast<const f32x4*>(cw + CST_I2V);
         f32x4 araw, aclip;
         float u[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          const float mean = m[i] + R.bh[i];
+          const float mean = m[i] + hb_[i];
           float lp = 0.f, act = 0.f, c = 0.f;
           if (4 * q4 + i < A) {
-            act = mean + nz[i] * R.sd[i];                 // Normal.rsample: loc + eps * scale
+            act = mean + nz[i] * sd_[i];                  // Normal.rsample: loc + eps * scale
             const float diff = act - mean;
-            lp = -(diff * diff) / R.i2v[i] - R.lsd[i] - LOG_SQRT_2PI_F;
+            lp = -(diff * diff) / i2v_[i] - lsd_[i] - LOG_SQRT_2PI_F;
             c = act;
             if (has_box) c = fminf(fmaxf(act, lo[i]), hi[i]);
           }
@@ -1915,10 +1913,12 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         }
       } else {                          // value heads: products with the output weights, summed in wave_sum_fast's order
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < 4; ++t) {
+          const f32x4 wo = *reinterpret_cast<const f32x4*>(cw + CST_WO + 16 * t);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H2 ? R.wh[4 * t + i] * z[t][i] : 0.f;
-        const float v = tile_sum64(z) + R.bh[0];
+          for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H2 ? wo[i] * z[t][i] : 0.f;
+        }
+        const float v = tile_sum64(z) + sh.cst[w][CST_BO];
         if (r16 < E && q4 == 0) sh.scal[r16][w - 1] = v;
       }
     }
@@ -2031,9 +2031,10 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xC07F);
       const int erc = r16 < Eg ? r16 : Eg - 1;          // (rows beyond the workgroup's envs replicate the last one)
-      f32x4 z[4];
+      f32x4 z[4], cb[4];
+      const float* const cw = &sh.cst[3][4 * q4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < 4; ++t) { z[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[t] = *reinterpret_cast<const f32x4*>(cw + CST_B1 + 16 * t); }
       {
         const float* xb = &sh.cx[erc][q4];
 #pragma unroll
@@ -2049,7 +2050,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H1 ? fmaxf(z[t][i] + R.b1[4 * t + i], 0.f) : 0.f;
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H1 ? fmaxf(z[t][i] + cb[t][i], 0.f) : 0.f;
       if (a.cl.nh == 2) {
         if (r16 < E) {
 #pragma unroll
@@ -2064,7 +2065,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
           for (int ks = 0; ks < 16; ++ks) bop[ks] = hb[4 * ks];
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) z[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 4; ++t) { z[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[t] = *reinterpret_cast<const f32x4*>(cw + CST_B2 + 16 * t); }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
           if (4 * ks < a.cl.H1) {
@@ -2076,13 +2077,15 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H2 ? fmaxf(z[t][i] + R.b2[4 * t + i], 0.f) : 0.f;
+          for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H2 ? fmaxf(z[t][i] + cb[t][i], 0.f) : 0.f;
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 wo = *reinterpret_cast<const f32x4*>(cw + CST_WO + 16 * t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H2 ? R.wh[4 * t + i] * z[t][i] : 0.f;
-      const float zz = tile_sum64(z) + R.bh[0];
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H2 ? wo[i] * z[t][i] : 0.f;
+      }
+      const float zz = tile_sum64(z) + sh.cst[3][CST_BO];
       const float zeta = 1.f / (1.f + expf(-zz));
       const float cost = 1.f - zeta;
       if (q4 == 0 && r16 < Eg) {
@@ -2723,7 +2726,11 @@ static int launch_multi_e(const WideArgs* one, const WideArgs* d_args, int n_run
 }
 
 // one: single-run launch (argument block by value) | d_args: n_runs blocks in device memory.  -1: does not fit the device
-static int launch_multi(bool small, int E, const WideArgs* one, const WideArgs* d_args, int n_runs, int G, size_t dyn, hipStream_t s) {
+static int launch_multi(bool small, bool cn128, int E, const WideArgs* one, const WideArgs* d_args, int n_runs, int G, size_t dyn, hipStream_t s) {
+  // cn128: the cost net reads <= 128 inputs (AntWall: 121) — 32 instead of 40 first-layer k steps in the register image
+  if (!small && cn128)
+    return E == 16 ? launch_multi_e<8, 8, 16>(one, d_args, n_runs, G, dyn, s)
+           : (E == 8 ? launch_multi_e<8, 8, 8>(one, d_args, n_runs, G, dyn, s) : launch_multi_e<8, 8, 4>(one, d_args, n_runs, G, dyn, s));
   if (small) return E == 16 ? launch_multi_e<2, 2, 16>(one, d_args, n_runs, G, dyn, s)
                     : (E == 8 ? launch_multi_e<2, 2, 8>(one, d_args, n_runs, G, dyn, s) : launch_multi_e<2, 2, 4>(one, d_args, n_runs, G, dyn, s));
   return E == 16 ? launch_multi_e<8, 10, 16>(one, d_args, n_runs, G, dyn, s)
@@ -2766,7 +2773,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
       hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
       if (e != hipSuccess) return (int)e;
       const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
-      const int err = launch_multi(small, E, &p, nullptr, 1, G, multi_dyn_lds(N, O, env->act_dim, (n_stats + G - 1) / G), s);
+      const int err = launch_multi(small, !cn || cn->in_dim <= 128, E, &p, nullptr, 1, G, multi_dyn_lds(N, O, env->act_dim, (n_stats + G - 1) / G), s);
       if (err >= 0) {
         if (err || !(do_gae & 1)) return err;
         return icrl_gae_dual_ws(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
@@ -2927,7 +2934,7 @@ extern "C" int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* 
       }
       if (ok) {
         const bool small = O <= 32 && (!has_cn || j0.cn->in_dim <= 32);
-        const int err = launch_multi(small, E, nullptr, d_args, n_runs, G, multi_dyn_lds(N, O, j0.env->act_dim, (n_stats + G - 1) / G), s);
+        const int err = launch_multi(small, !has_cn || j0.cn->in_dim <= 128, E, nullptr, d_args, n_runs, G, multi_dyn_lds(N, O, j0.env->act_dim, (n_stats + G - 1) / G), s);
         if (err >= 0) {
           if (err || !(do_gae & 1)) return err;
           if (args_ws_bytes < 2ll * n_runs * ICRL_BATCH_ARGS_BYTES)
