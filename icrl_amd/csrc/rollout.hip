@@ -2208,9 +2208,9 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     }
     __syncthreads();
     if (prof) { const unsigned long long tn_ = prof_now(); pc3 += tn_ - tl; tl = tn_; }     // statistics granules arrived (+ barrier)
-    for (int idx = tid; idx < Eg * MULTI_OP; idx += 256) {
-      const int e = idx / MULTI_OP, i = idx % MULTI_OP;
-      if (i < O) {
+    for (int idx = tid; idx < Eg * O; idx += 256) {      // (env, component) pairs spread over all threads: one float64 sqrt + division each
+      const int e = idx / O, i = idx - e * O;
+      {
         const size_t tn = (size_t)t * N + g + e * G;
         const double raw = sh.s_new[e][i];
         double o = raw;
