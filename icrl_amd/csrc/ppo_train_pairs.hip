@@ -134,16 +134,16 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   const int O = a.L.O, A = a.L.A;
   const int n_out = role == 0 ? A : 1;
   const int T = a.buf.T, N = a.buf.N;
-  const float nu = a.nu[0];
+  const float nu = as_global(a.nu)[0];
   const int n_steps = a.n_steps;
-  const PlanStep* __restrict__ const plan_steps = a.plan_steps;
-  const PlanChunk* __restrict__ const plan_chunks = a.plan_chunks;
-  const int* __restrict__ const perms = a.perms;
-  const float* const p_s0 = role == 0 ? a.buf.log_probs : (role == 1 ? a.buf.reward_values : a.buf.cost_values);
-  const float* const p_s1 = role == 0 ? a.buf.reward_advantages : (role == 1 ? a.buf.reward_returns : a.buf.cost_returns);
-  const float* const p_s2 = a.buf.cost_advantages;
-  const float* const p_obs = a.buf.observations;
-  const float* const p_act = a.buf.actions;
+  const PlanStep* __restrict__ const plan_steps = as_global(a.plan_steps);
+  const PlanChunk* __restrict__ const plan_chunks = as_global(a.plan_chunks);
+  const int* __restrict__ const perms = as_global(a.perms);
+  const float* const p_s0 = as_global(role == 0 ? a.buf.log_probs : (role == 1 ? a.buf.reward_values : a.buf.cost_values));
+  const float* const p_s1 = as_global(role == 0 ? a.buf.reward_advantages : (role == 1 ? a.buf.reward_returns : a.buf.cost_returns));
+  const float* const p_s2 = as_global(a.buf.cost_advantages);
+  const float* const p_obs = as_global(a.buf.observations);
+  const float* const p_act = as_global(a.buf.actions);
   const int AS = a.buf.act_store;
 
   // ---- Adam ownership of wave (jt = rt, kh = fh): element (row j = 16 jt + 4 q + i, column k = 16 c + r) of
@@ -254,7 +254,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
   const float ent_coef = a.hp.ent_coef;
   const float max_grad_norm = a.hp.max_grad_norm, adam_epsf = a.hp.adam_eps, adam_b2f = a.hp.adam_beta2;
-  u64* const xch = a.xch;
+  u64* const xch = as_global(a.xch);
 
   // ---------------------------------------------------------------------------------------------------------------
   // row stream (see ppo_train_rows.hip): `perms` holds storage offsets; rows of chunk g + 1 are prefetched into registers
@@ -1019,7 +1019,7 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
 // several independent runs in ONE launch: grid (3, n_runs), run = blockIdx.y; the argument blocks live in device memory
 template <int NT1, bool DISC, int OBS>
 __global__ void __launch_bounds__(TH8) ppo_train_pairs_batch_kernel(const TrainArgs* __restrict__ runs) {
-  const TrainArgs* const ka = runs + blockIdx.y;
+  const TrainArgs* const ka = as_global(runs + blockIdx.y);
   ppo_train_pairs_body<NT1, DISC, OBS>(*ka, ka);
 }
 

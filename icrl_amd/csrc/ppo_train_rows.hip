@@ -90,18 +90,18 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
   const int O = a.L.O, A = a.L.A;
   const int n_out = role == 0 ? A : 1;
   const int T = a.buf.T, N = a.buf.N;
-  const float nu = a.nu[0];
+  const float nu = as_global(a.nu)[0];
   const int n_steps = a.n_steps;
-  const PlanStep* __restrict__ const plan_steps = a.plan_steps;
-  const PlanChunk* __restrict__ const plan_chunks = a.plan_chunks;
-  const int* __restrict__ const perms = a.perms;
+  const PlanStep* __restrict__ const plan_steps = as_global(a.plan_steps);
+  const PlanChunk* __restrict__ const plan_chunks = as_global(a.plan_chunks);
+  const int* __restrict__ const perms = as_global(a.perms);
   // per-row side data of this role, selected once:
   //   policy: old log-prob, reward advantage, cost advantage;  critics: old value, return, (unused)
-  const float* const p_s0 = role == 0 ? a.buf.log_probs : (role == 1 ? a.buf.reward_values : a.buf.cost_values);
-  const float* const p_s1 = role == 0 ? a.buf.reward_advantages : (role == 1 ? a.buf.reward_returns : a.buf.cost_returns);
-  const float* const p_s2 = a.buf.cost_advantages;
-  const float* const p_obs = a.buf.observations;
-  const float* const p_act = a.buf.actions;
+  const float* const p_s0 = as_global(role == 0 ? a.buf.log_probs : (role == 1 ? a.buf.reward_values : a.buf.cost_values));
+  const float* const p_s1 = as_global(role == 0 ? a.buf.reward_advantages : (role == 1 ? a.buf.reward_returns : a.buf.cost_returns));
+  const float* const p_s2 = as_global(a.buf.cost_advantages);
+  const float* const p_obs = as_global(a.buf.observations);
+  const float* const p_act = as_global(a.buf.actions);
   const int AS = a.buf.act_store;
 
   // wave w owns W1 / W2 rows 16w..16w+15 (element j = 16w + 4q + i, k = 16c + r) and head-weight columns 16w..16w+15
@@ -218,7 +218,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
   const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
   const float ent_coef = a.hp.ent_coef;
   const float max_grad_norm = a.hp.max_grad_norm, adam_epsf = a.hp.adam_eps, adam_b2f = a.hp.adam_beta2;
-  u64* const xch = a.xch;
+  u64* const xch = as_global(a.xch);
 
   // ---------------------------------------------------------------------------------------------------------------
   // row stream: rows of chunk g+1 are prefetched into registers while chunk g is processed, their permutation indices two
@@ -733,8 +733,8 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
       // spare at AntWall widths), the next group's loads in flight while this one is checked.
       constexpr int KG = 4 * NT1 + 23, NGRP = NT1 + 6;       // groups: W1 tiles, 4 W2 tiles, head, {b1, b2, extra, -}
       const size_t blk = (size_t)(KG + 5) * TH4;
-      u64* const mine = KARGS()->gx + ((size_t)((step & 1) * 3 + role) * 2 + half) * blk + tid;
-      const u64* const theirs = KARGS()->gx + ((size_t)((step & 1) * 3 + role) * 2 + (1 - half)) * blk + tid;
+      u64* const mine = as_global(KARGS()->gx) + ((size_t)((step & 1) * 3 + role) * 2 + half) * blk + tid;
+      const u64* const theirs = as_global(KARGS()->gx) + ((size_t)((step & 1) * 3 + role) * 2 + (1 - half)) * blk + tid;
       const u64 tg = (u64)step << 32;
       f32x4 gsc = f32x4{gb1r, gb2r, gex, 0.f};
       auto grp = [&](int g) -> f32x4& { return g < NT1 ? gW1r[g] : (g < NT1 + 4 ? gW2r[g - NT1] : (g == NT1 + 4 ? gWhr : gsc)); };
@@ -1031,7 +1031,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
 // several independent runs in ONE launch: grid (3 or 6, n_runs), run = blockIdx.y
 template <int NT1, bool DISC, bool SPLIT>
 __global__ void __launch_bounds__(TH4) ppo_train_rows_batch_kernel(const TrainArgs* __restrict__ runs) {
-  const TrainArgs* const ka = runs + blockIdx.y;
+  const TrainArgs* const ka = as_global(runs + blockIdx.y);
   ppo_train_rows_body<NT1, DISC, SPLIT>(*ka, ka);
 }
 

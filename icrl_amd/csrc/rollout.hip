@@ -1012,7 +1012,14 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
   __shared__ int done_s[128];
   __shared__ int last_done_s;
   const ActStepArgs& a = p.act;
-  const icrl_norm_t& nm = p.nm;
+  // private copies of the structs whose pointers the step loop goes through, every pointer marked as a global-memory pointer
+  // (common.h: as_global — in a batched launch the block comes from LDS / memory and the accesses would be flat_* otherwise)
+  icrl_norm_t nm = p.nm; globalize(nm);
+  icrl_buffer_t buf = a.buf; globalize(buf);
+  icrl_agent_t ag = a.ag; globalize(ag);
+  icrl_costnet_t cnet = a.cn; globalize(cnet);
+  unsigned long long* const xg_all = as_global(p.xg);
+  const float* const noise_g = as_global(a.noise);
   WaveRegs<OCT, CIT> R;                // one image: policy weights in waves 0..2, cost-net weights in wave 3
   WaveRegs<OCT, CIT>& C = R;
   load_pol_regs<OCT>(a.pl, a.PT, R);
@@ -1021,7 +1028,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs, T = p.T;
-  const int AS = a.buf.act_store;
+  const int AS = buf.act_store;
   const int NA = a.pl.discrete ? 1 : A;       // noise values per env step
   const int NP = N + 64;                      // padded column length of the transposed observation block
   const int G = 2 * O + 4;                    // granules per env and step: obs halves, reward halves, cost, done
@@ -1030,24 +1037,24 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
   const uint32_t e_key = a.env.key[n];
   uint32_t e_ctr = a.env.step_count[n];
   int e_tep = a.env.t_ep[n];
-  icrl_env_t env = a.env;
+  icrl_env_t env = a.env; globalize(env);
   for (int i = tid; i < O * a.env.act_dim; i += 256) Bl[i] = a.env.B[i];
   env.B = Bl;
   const bool has_box = a.alow != nullptr && a.ahigh != nullptr;
   if (tid < MAX_ACT) { alow_s[tid] = (has_box && tid < A) ? a.alow[tid] : 0.f; ahigh_s[tid] = (has_box && tid < A) ? a.ahigh[tid] : 0.f; }
   for (int i = tid; i < MAX_OBS; i += 256) {
-    sh.x[i] = i < O ? (float)a.ag.last_obs[(size_t)n * O + i] : 0.f;
+    sh.x[i] = i < O ? (float)ag.last_obs[(size_t)n * O + i] : 0.f;
     if (i < O) sh.s_old[i] = a.env.s[(size_t)n * O + i];
   }
   if (tid < N) { ret_s[tid] = nm.ret[tid]; cret_s[tid] = nm.cost_ret[tid]; }
-  if (tid == 0) last_done_s = a.ag.last_dones[n];
+  if (tid == 0) last_done_s = ag.last_dones[n];
   // replicated running statistics: observation columns in threads < O, ret_rms in wave 3, cost_rms in wave 2
   double o_mean = 0.0, o_var = 1.0, o_cnt = 0.0, o_last = 0.0;
-  if (tid < O) { o_mean = nm.obs_mean[tid]; o_var = nm.obs_var[tid]; o_cnt = nm.obs_count[0]; o_last = a.ag.last_obs[(size_t)n * O + tid]; }
+  if (tid < O) { o_mean = nm.obs_mean[tid]; o_var = nm.obs_var[tid]; o_cnt = nm.obs_count[0]; o_last = ag.last_obs[(size_t)n * O + tid]; }
   double st_m = 0.0, st_v = 1.0, st_c = 0.0;
   if (w == 3) { st_m = nm.ret_stats[0]; st_v = nm.ret_stats[1]; st_c = nm.ret_stats[2]; }
   if (w == 2) { st_m = nm.cost_stats[0]; st_v = nm.cost_stats[1]; st_c = nm.cost_stats[2]; }
-  float noise_reg = (tid < NA) ? a.noise[(size_t)n * NA + tid] : 0.f;
+  float noise_reg = (tid < NA) ? noise_g[(size_t)n * NA + tid] : 0.f;
   double fin_rew = 0.0; float fin_cost = 0.f; int fin_done = 0;
   unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, pc_rounds = 0, tl = p.prof ? prof_now() : 0ull;
   int spin_limit = 1 << 22;
@@ -1057,7 +1064,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
     const unsigned gtag = (unsigned)(t + 1);
     if (tid < NA) {
       noise_s[tid] = noise_reg;
-      if (t + 1 < T) noise_reg = a.noise[((size_t)(t + 1) * N + n) * NA + tid];     // lands during this step
+      if (t + 1 < T) noise_reg = noise_g[((size_t)(t + 1) * N + n) * NA + tid];     // lands during this step
     }
     __syncthreads();
     // ---------------- phase A: kernel A's work for env n ----------------
@@ -1066,9 +1073,9 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
     if (w == 0) {
       double rew; int done;
       env_step_wave(env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
-      float* nob = a.buf.new_orig_observations + tn * O;
+      float* nob = buf.new_orig_observations + tn * O;
       if (GRAN) {
-        unsigned long long* xg = p.xg + ((size_t)par * N + n) * G;
+        unsigned long long* xg = xg_all + ((size_t)par * N + n) * G;
         for (int i = lane; i < O; i += WAVE) {
           const double v = sh.s_new[i];
           nob[i] = (float)v;
@@ -1081,38 +1088,38 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
           gstore(xg + 2 * O + 3, gtag, (unsigned)done);
         }
       } else {
-        double* xo = p.xch_obs + ((size_t)par * N + n) * O;
+        double* xo = as_global(p.xch_obs) + ((size_t)par * N + n) * O;
         for (int i = lane; i < O; i += WAVE) { const double v = sh.s_new[i]; nob[i] = (float)v; xstore(xo + i, v); }
-        if (lane == 0) { xstore(p.xch_rew + par * N + n, rew); xstore(p.xch_done + par * N + n, (unsigned)done); }
+        if (lane == 0) { xstore(as_global(p.xch_rew) + par * N + n, rew); xstore(as_global(p.xch_done) + par * N + n, (unsigned)done); }
       }
     } else if (w == 3) {
       float cost = 0.f;
-      if (a.has_cn) cost = cost_forward_wave<CIT>(a.cn, a.cl, C, sh.s_old, sh.act_clip, sh.cx, sh.ch);
+      if (a.has_cn) cost = cost_forward_wave<CIT>(cnet, a.cl, C, sh.s_old, sh.act_clip, sh.cx, sh.ch);
       if (lane == 0) {
-        if (GRAN) gstore(p.xg + ((size_t)par * N + n) * G + 2 * O + 2, gtag, __float_as_uint(cost));
-        else xstore(p.xch_cost + par * N + n, cost);
-        a.buf.orig_costs[tn] = cost;
+        if (GRAN) gstore(xg_all + ((size_t)par * N + n) * G + 2 * O + 2, gtag, __float_as_uint(cost));
+        else xstore(as_global(p.xch_cost) + par * N + n, cost);
+        buf.orig_costs[tn] = cost;
       }
     } else if (w == 2) {
-      float* ob = a.buf.observations + tn * O;
-      float* oob = a.buf.orig_observations + tn * O;
+      float* ob = buf.observations + tn * O;
+      float* oob = buf.orig_observations + tn * O;
       for (int i = lane; i < O; i += WAVE) { ob[i] = sh.x[i]; oob[i] = (float)sh.s_old[i]; }
-      if (lane < AS) a.buf.actions[tn * AS + lane] = sh.act_raw[lane];
-      if (lane < A && !a.pl.discrete) a.ag.act_clipped[(size_t)n * A + lane] = sh.act_clip[lane];
+      if (lane < AS) buf.actions[tn * AS + lane] = sh.act_raw[lane];
+      if (lane < A && !a.pl.discrete) ag.act_clipped[(size_t)n * A + lane] = sh.act_clip[lane];
       if (lane == 0) {
-        a.buf.dones[tn] = (float)last_done_s;
-        a.buf.reward_values[tn] = sh.scal[0];
-        a.buf.cost_values[tn] = sh.scal[1];
-        a.buf.log_probs[tn] = sh.scal[2];
-        a.ag.last_v_r[n] = sh.scal[0];
-        a.ag.last_v_c[n] = sh.scal[1];
+        buf.dones[tn] = (float)last_done_s;
+        buf.reward_values[tn] = sh.scal[0];
+        buf.cost_values[tn] = sh.scal[1];
+        buf.log_probs[tn] = sh.scal[2];
+        ag.last_v_r[n] = sh.scal[0];
+        ag.last_v_c[n] = sh.scal[1];
       }
     }
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }
     if (p.prof && t == T / 2 && lane == 0) g_wide_trace[4 * n + w] = __builtin_amdgcn_s_memrealtime();   // per wave: end of its phase-A part
     if (GRAN) {
       // poll this thread's granules of ALL envs until every one carries this step's tag, then scatter the payload words
-      const unsigned long long* xg = p.xg + (size_t)par * N * G;
+      const unsigned long long* xg = xg_all + (size_t)par * N * G;
       const int total = N * G;
       unsigned long long g[GRAN_MAX];
 #pragma unroll
@@ -1145,20 +1152,20 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
       }
       __syncthreads();
     } else {
-      grid_barrier(p.counter, N, n, (unsigned)(t + 1), spin_limit);
+      grid_barrier(as_global(p.counter), N, n, (unsigned)(t + 1), spin_limit);
     }
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }
     // ---------------- phase B: kernel B's statistics, replicated; normalise own env ----------------
     {
       if (!GRAN) {
-        const double* xo = p.xch_obs + (size_t)par * N * O;
+        const double* xo = as_global(p.xch_obs) + (size_t)par * N * O;
         for (int i = tid; i < N * O; i += 256) { const int rr = i / O, j = i - rr * O; chunk[j * NP + rr] = xload(xo + i); }
       }
       if (tid < N) {
         if (!GRAN) {
-          rawr_s[tid] = xload(p.xch_rew + par * N + tid);
-          rawc_s[tid] = has_cost ? xload(p.xch_cost + par * N + tid) : 0.f;
-          done_s[tid] = (int)xload(p.xch_done + par * N + tid);
+          rawr_s[tid] = xload(as_global(p.xch_rew) + par * N + tid);
+          rawc_s[tid] = has_cost ? xload(as_global(p.xch_cost) + par * N + tid) : 0.f;
+          done_s[tid] = (int)xload(as_global(p.xch_done) + par * N + tid);
         }
         const double rr = rawr_s[tid];
         const float rc = rawc_s[tid];
@@ -1198,7 +1205,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
       if (nm.norm_obs) o = fmin(fmax((o - o_mean) / sqrt(o_var + nm.epsilon), -nm.clip_obs), nm.clip_obs);
       o_last = o;
       sh.x[tid] = (float)o;
-      a.buf.new_observations[tn * O + tid] = (float)o;
+      buf.new_observations[tn * O + tid] = (float)o;
       sh.s_old[tid] = sh.s_new[tid];
     }
     __syncthreads();
@@ -1211,11 +1218,11 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
       double r = rawr_s[n];
       fin_rew = r; fin_cost = rawc_s[n]; fin_done = done_s[n];
       if (nm.norm_reward) r = fmin(fmax(r / dens[0], -nm.clip_reward), nm.clip_reward);
-      a.buf.rewards[tn] = (float)r;
+      buf.rewards[tn] = (float)r;
       if (has_cost) {
         double c = (double)rawc_s[n];
         if (nm.norm_cost) c = fmin(fmax(c / dens[1], -nm.clip_cost), nm.clip_cost);
-        a.buf.costs[tn] = (float)c;
+        buf.costs[tn] = (float)c;
       }
       last_done_s = done_s[n];
     }
@@ -1223,14 +1230,14 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
   }
   if (p.prof && n == 0 && tid == 0) { g_rollout_prof[0] = pc0; g_rollout_prof[1] = pc1; g_rollout_prof[2] = pc2; g_rollout_prof[3] = (unsigned long long)T; g_rollout_prof[4] = pc3; g_rollout_prof[5] = pc4; g_rollout_prof[6] = pc5; g_rollout_prof[7] = pc_rounds; }
   // a timed-out exchange means stale granules went into the statistics and the buffer: tell the host (it raises)
-  if (spin_limit == 1 && a.ag.status != nullptr && (tid & 63) == 0) atomicOr(a.ag.status, 1);
+  if (spin_limit == 1 && ag.status != nullptr && (tid & 63) == 0) atomicOr(ag.status, 1);
   // ---- leave the agent / wrapper state exactly where the per-step path leaves it
   __syncthreads();
-  if (tid < O) a.ag.last_obs[(size_t)n * O + tid] = o_last;
+  if (tid < O) ag.last_obs[(size_t)n * O + tid] = o_last;
   if (tid == 0) {
-    a.ag.last_dones[n] = (uint8_t)last_done_s;
-    a.ag.raw_rew[n] = fin_rew; a.ag.dones[n] = (uint8_t)fin_done;
-    if (has_cost) a.ag.raw_cost[n] = fin_cost;
+    ag.last_dones[n] = (uint8_t)last_done_s;
+    ag.raw_rew[n] = fin_rew; ag.dones[n] = (uint8_t)fin_done;
+    if (has_cost) ag.raw_cost[n] = fin_cost;
   }
   if (n == 0) {
     if (tid < O) { nm.obs_mean[tid] = o_mean; nm.obs_var[tid] = o_var; }
@@ -1741,13 +1748,13 @@ __device__ __noinline__ void env_step_wave3(const icrl_env_t& e, MultiShared<E, 
   if (live) {
     double v = ns;
     if (d) v = env_reset_value(e, ky, ct + 1u, i);   // auto-reset draw
-    e.s[(size_t)n * O + i] = v;
+    as_global(e.s)[(size_t)n * O + i] = v;
     sh.s_new[em][i] = v;
   }
   if (mine && ci == 0) {
     const int tnew = d ? 0 : tep;
     sh.tep[em] = tnew; sh.ctr[em] = ct + 1u; sh.rew[em] = rw; sh.done[em] = d;
-    e.t_ep[n] = tnew; e.step_count[n] = ct + 1u;
+    as_global(e.t_ep)[n] = tnew; as_global(e.step_count)[n] = ct + 1u;
   }
 }
 
@@ -1756,7 +1763,15 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ MultiShared<E, CIT> sh;
   const ActStepArgs& a = p.act;
-  const icrl_norm_t& nm = p.nm;
+  // private copies of the structs whose pointers the step loop goes through, every pointer marked as a global-memory pointer
+  // (common.h: as_global — in a batched launch the block comes from memory and the accesses would be flat_* otherwise)
+  icrl_norm_t nm = p.nm; globalize(nm);
+  icrl_buffer_t buf = a.buf; globalize(buf);
+  icrl_agent_t ag = a.ag; globalize(ag);
+  icrl_costnet_t cnet = a.cn; globalize(cnet);
+  unsigned long long* const xg_all = as_global(p.xg);      // granules of every env, both parities
+  unsigned long long* const sg_all = as_global(p.sg);      // statistics granules
+  const float* const noise_g = as_global(a.noise);
   TileRegs<OCT, CIT> R;                // waves 0..2: policy / value / cost-value net, wave 3: cost net — as MFMA A operands
   if (threadIdx.x >= 192 && a.has_cn) load_cn_tiles<OCT, CIT>(a.cn, a.cl, R, sh.cst[3]);
   else load_pol_tiles<OCT, CIT>(a.pl, a.PT, R, sh.cst[threadIdx.x >> 6]);
@@ -1764,7 +1779,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs, T = p.T;
-  const int AS = a.buf.act_store;
+  const int AS = buf.act_store;
   const int GX = 2 * O + 4, GS = 4 * O + 4;
   const int Eg = (N - g + G - 1) / G;                // envs of this workgroup (1 .. E)
   const bool has_cost = a.has_cn != 0;
@@ -1774,7 +1789,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   double* const Bl = dyn_lds;
   double* const colbuf = Bl + O * a.env.act_dim + (size_t)w * (N + 64);      // this wave's column buffer (owner waves only)
   unsigned char* const done_bufs = reinterpret_cast<unsigned char*>(Bl + O * a.env.act_dim + (size_t)owners * (N + 64));
-  icrl_env_t env = a.env;
+  icrl_env_t env = a.env; globalize(env);
   for (int i = tid; i < O * a.env.act_dim; i += 256) Bl[i] = a.env.B[i];
   env.B = Bl;
   if (tid < MAX_ACT) { sh.alow[tid] = (has_box && tid < A) ? a.alow[tid] : 0.f; sh.ahigh[tid] = (has_box && tid < A) ? a.ahigh[tid] : 0.f; }
@@ -1782,7 +1797,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     const int e = idx / MULTI_OP, i = idx % MULTI_OP;
     const bool live = e < Eg && i < O;
     const int n = g + e * G;
-    const double lo = live ? a.ag.last_obs[(size_t)n * O + i] : 0.0;
+    const double lo = live ? ag.last_obs[(size_t)n * O + i] : 0.0;
     sh.x[e][i] = (float)lo;
     sh.olast[e][i] = lo;
     sh.s_old[e][i] = live ? a.env.s[(size_t)n * O + i] : 0.0;
@@ -1790,7 +1805,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   }
   if (tid < E) {
     const int e = tid, n = g + (e < Eg ? e : 0) * G;
-    sh.ctr[e] = a.env.step_count[n]; sh.tep[e] = a.env.t_ep[n]; sh.last_done[e] = a.ag.last_dones[n]; sh.key[e] = a.env.key[n];
+    sh.ctr[e] = a.env.step_count[n]; sh.tep[e] = a.env.t_ep[n]; sh.last_done[e] = ag.last_dones[n]; sh.key[e] = a.env.key[n];
     sh.rew[e] = 0.0; sh.cost[e] = 0.f; sh.done[e] = 0;
   }
   // the statistic this WAVE owns (if any): sid = g + w * G
@@ -1807,7 +1822,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   const int NA = A;                                  // (continuous actions only: the launcher keeps discrete policies elsewhere)
   if (tid < E * MAX_ACT) {
     const int e = tid / MAX_ACT, k = tid % MAX_ACT;
-    sh.noise[0][e][k] = (e < Eg && k < NA) ? a.noise[((size_t)(g + e * G)) * NA + k] : 0.f;
+    sh.noise[0][e][k] = (e < Eg && k < NA) ? noise_g[((size_t)(g + e * G)) * NA + k] : 0.f;
   }
   const int r16 = lane & 15, q4 = lane >> 4;          // MFMA lane coordinates: env row r16, k / unit quarter q4
   const int er = r16 < E ? r16 : E - 1;               // rows beyond E replicate the last env's row (their results are not used)
@@ -1822,7 +1837,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     float noise_next = 0.f;
     const int pe = tid / MAX_ACT, pk = tid % MAX_ACT;
     const bool pf = tid < E * MAX_ACT && pe < Eg && pk < NA && t + 1 < T;
-    if (pf) noise_next = a.noise[((size_t)(t + 1) * N + g + pe * G) * NA + pk];
+    if (pf) noise_next = noise_g[((size_t)(t + 1) * N + g + pe * G) * NA + pk];
     // ---------------- phase A: the three MLPs for all E envs at once, as MFMA tiles (TileRegs) ----------------
     // A wave consumes only its own network's activations: the hand-over between layers (result layout [unit 16 t + 4 q + i][env r]
     // -> B operand layout [k = 4 ks + q][env r]) goes through the wave's own LDS rows, no workgroup barrier until the heads are done.
@@ -1934,18 +1949,18 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         const int em = mine ? e : 3 * q;
         const int n = g + em * G;
         const size_t tn = (size_t)t * N + n;
-        unsigned long long* xg = p.xg + ((size_t)par * N + n) * GX;
+        unsigned long long* xg = xg_all + ((size_t)par * N + n) * GX;
         if (mine) {       // rows that depend on the pre-step state only
-          if (ci < O) { a.buf.observations[tn * O + ci] = sh.x[em][ci]; a.buf.orig_observations[tn * O + ci] = (float)sh.s_old[em][ci]; }
-          if (ci < AS) a.buf.actions[tn * AS + ci] = sh.act_raw[em][ci];
-          if (ci < A) a.ag.act_clipped[(size_t)n * A + ci] = sh.act_clip[em][ci];
+          if (ci < O) { buf.observations[tn * O + ci] = sh.x[em][ci]; buf.orig_observations[tn * O + ci] = (float)sh.s_old[em][ci]; }
+          if (ci < AS) buf.actions[tn * AS + ci] = sh.act_raw[em][ci];
+          if (ci < A) ag.act_clipped[(size_t)n * A + ci] = sh.act_clip[em][ci];
           if (ci == 0) {
-            a.buf.dones[tn] = (float)sh.last_done[em];
-            a.buf.reward_values[tn] = sh.scal[em][0];
-            a.buf.cost_values[tn] = sh.scal[em][1];
-            a.buf.log_probs[tn] = sh.scal[em][2];
-            a.ag.last_v_r[n] = sh.scal[em][0];
-            a.ag.last_v_c[n] = sh.scal[em][1];
+            buf.dones[tn] = (float)sh.last_done[em];
+            buf.reward_values[tn] = sh.scal[em][0];
+            buf.cost_values[tn] = sh.scal[em][1];
+            buf.log_probs[tn] = sh.scal[em][2];
+            ag.last_v_r[n] = sh.scal[em][0];
+            ag.last_v_c[n] = sh.scal[em][1];
           }
         }
         env_step_wave3<E, CIT>(env, sh, em, n, mine, ci, slot);
@@ -1954,7 +1969,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         if (mine) {
           if (ci < O) {
             const double v = sh.s_new[em][ci];
-            a.buf.new_orig_observations[tn * O + ci] = (float)v;
+            buf.new_orig_observations[tn * O + ci] = (float)v;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
             gstore(xg + 2 * ci, gtag, (unsigned)bits); gstore(xg + 2 * ci + 1, gtag, (unsigned)(bits >> 32));
           }
@@ -1969,26 +1984,26 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       for (int e = w; e < Eg; e += 3) {
         const int n = g + e * G;
         const size_t tn = (size_t)t * N + n;
-        unsigned long long* xg = p.xg + ((size_t)par * N + n) * GX;
+        unsigned long long* xg = xg_all + ((size_t)par * N + n) * GX;
         // rows that depend on the pre-step state only
-        float* ob = a.buf.observations + tn * O;
-        float* oob = a.buf.orig_observations + tn * O;
+        float* ob = buf.observations + tn * O;
+        float* oob = buf.orig_observations + tn * O;
         for (int i = lane; i < O; i += WAVE) { ob[i] = sh.x[e][i]; oob[i] = (float)sh.s_old[e][i]; }
-        if (lane < AS) a.buf.actions[tn * AS + lane] = sh.act_raw[e][lane];
-        if (lane < A) a.ag.act_clipped[(size_t)n * A + lane] = sh.act_clip[e][lane];
+        if (lane < AS) buf.actions[tn * AS + lane] = sh.act_raw[e][lane];
+        if (lane < A) ag.act_clipped[(size_t)n * A + lane] = sh.act_clip[e][lane];
         if (lane == 0) {
-          a.buf.dones[tn] = (float)sh.last_done[e];
-          a.buf.reward_values[tn] = sh.scal[e][0];
-          a.buf.cost_values[tn] = sh.scal[e][1];
-          a.buf.log_probs[tn] = sh.scal[e][2];
-          a.ag.last_v_r[n] = sh.scal[e][0];
-          a.ag.last_v_c[n] = sh.scal[e][1];
+          buf.dones[tn] = (float)sh.last_done[e];
+          buf.reward_values[tn] = sh.scal[e][0];
+          buf.cost_values[tn] = sh.scal[e][1];
+          buf.log_probs[tn] = sh.scal[e][2];
+          ag.last_v_r[n] = sh.scal[e][0];
+          ag.last_v_c[n] = sh.scal[e][1];
         }
         double rew; int done;
         uint32_t e_ctr = sh.ctr[e];
         int e_tep = sh.tep[e];
         env_step_wave(env, n, sh.s_old[e], sh.act_clip[e], sh.key[e], e_ctr, e_tep, sh.s_new[e], rew, done);
-        float* nob = a.buf.new_orig_observations + tn * O;
+        float* nob = buf.new_orig_observations + tn * O;
         for (int i = lane; i < O; i += WAVE) {
           const double v = sh.s_new[e][i];
           nob[i] = (float)v;
@@ -2011,17 +2026,17 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
           const int sel = R.sel[i];
           float v = 0.f;
           if (sel >= 0) {
-            if (sel < a.cn.obs_dim) {
+            if (sel < cnet.obs_dim) {
               double o = sh.s_old[e][sel];
-              if (a.cn.obs_mean != nullptr && a.cn.obs_var != nullptr) o = (o - a.cn.obs_mean[sel]) / sqrt(a.cn.obs_var[sel] + a.cn.eps);
-              if (a.cn.clip_obs >= 0.0) o = fmin(fmax(o, -a.cn.clip_obs), a.cn.clip_obs);
+              if (cnet.obs_mean != nullptr && cnet.obs_var != nullptr) o = (o - cnet.obs_mean[sel]) / sqrt(cnet.obs_var[sel] + cnet.eps);
+              if (cnet.clip_obs >= 0.0) o = fmin(fmax(o, -cnet.clip_obs), cnet.clip_obs);
               v = (float)o;
             } else {
-              const int ai = sel - a.cn.obs_dim;
+              const int ai = sel - cnet.obs_dim;
               float x;
-              if (a.cn.is_discrete) x = ((int)sh.act_clip[e][0] == ai) ? 1.f : 0.f;
+              if (cnet.is_discrete) x = ((int)sh.act_clip[e][0] == ai) ? 1.f : 0.f;
               else x = sh.act_clip[e][ai];
-              if (a.cn.action_low != nullptr && a.cn.action_high != nullptr) x = fminf(fmaxf(x, a.cn.action_low[ai]), a.cn.action_high[ai]);
+              if (cnet.action_low != nullptr && cnet.action_high != nullptr) x = fminf(fmaxf(x, cnet.action_low[ai]), cnet.action_high[ai]);
               v = x;
             }
           }
@@ -2090,22 +2105,22 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       const float cost = 1.f - zeta;
       if (q4 == 0 && r16 < Eg) {
         const int n = g + r16 * G;
-        gstore(p.xg + ((size_t)par * N + n) * GX + 2 * O + 2, gtag, __float_as_uint(cost));
-        a.buf.orig_costs[(size_t)t * N + n] = cost;
+        gstore(xg_all + ((size_t)par * N + n) * GX + 2 * O + 2, gtag, __float_as_uint(cost));
+        buf.orig_costs[(size_t)t * N + n] = cost;
         sh.cost[r16] = cost;
       }
     } else {
       if (lane < Eg) {
         const int n = g + lane * G;
-        gstore(p.xg + ((size_t)par * N + n) * GX + 2 * O + 2, gtag, __float_as_uint(0.f));
-        a.buf.orig_costs[(size_t)t * N + n] = 0.f;
+        gstore(xg_all + ((size_t)par * N + n) * GX + 2 * O + 2, gtag, __float_as_uint(0.f));
+        buf.orig_costs[(size_t)t * N + n] = 0.f;
         sh.cost[lane] = 0.f;
       }
     }
     if (prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }     // env steps / cost net + rows (this wave's part)
     // ---------------- phase B1: owner waves gather their statistic from all envs and publish it ----------------
     if (own_col >= 0 || own_ret || own_cost) {
-      const unsigned long long* xb = p.xg + (size_t)par * N * GX;
+      const unsigned long long* xb = xg_all + (size_t)par * N * GX;
       const int slot = own_col >= 0 ? 2 * own_col : (own_ret ? 2 * O : 2 * O + 2);
       const bool wide = !own_cost;                                   // two granules (a float64) per env, or one (the float32 cost)
       for (int i0 = 0; i0 < N; i0 += 4 * WAVE) {
@@ -2168,7 +2183,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       }
       chan_merge(o_mean, o_var, o_cnt, bm, bv, (double)N);
       o_cnt = (double)N + o_cnt;
-      unsigned long long* sb = p.sg + (size_t)par * GS;
+      unsigned long long* sb = sg_all + (size_t)par * GS;
       if (lane == 0) {
         if (own_col >= 0) {
           const unsigned long long mb = (unsigned long long)__double_as_longlong(o_mean), vb = (unsigned long long)__double_as_longlong(o_var);
@@ -2184,7 +2199,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     if (prof) { const unsigned long long tn_ = prof_now(); pc2 += tn_ - tl; tl = tn_; }     // owner: gather + moments + publish
     // ---------------- phase B2: everybody reads the statistics granules, then normalises its envs ----------------
     {
-      const unsigned long long* sb = p.sg + (size_t)par * GS;
+      const unsigned long long* sb = sg_all + (size_t)par * GS;
       const int total = has_cost ? GS : GS - 2;
       unsigned* ms = reinterpret_cast<unsigned*>(sh.mean);
       unsigned* vs = reinterpret_cast<unsigned*>(sh.var);
@@ -2217,7 +2232,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         if (nm.norm_obs) o = fmin(fmax((o - sh.mean[i]) / sqrt(sh.var[i] + nm.epsilon), -nm.clip_obs), nm.clip_obs);
         sh.olast[e][i] = o;
         sh.x[e][i] = (float)o;
-        a.buf.new_observations[tn * O + i] = (float)o;
+        buf.new_observations[tn * O + i] = (float)o;
         sh.s_old[e][i] = raw;
       }
     }
@@ -2226,11 +2241,11 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       const size_t tn = (size_t)t * N + g + e * G;
       double r = sh.rew[e];
       if (nm.norm_reward) r = fmin(fmax(r / sh.dens[0], -nm.clip_reward), nm.clip_reward);
-      a.buf.rewards[tn] = (float)r;
+      buf.rewards[tn] = (float)r;
       if (has_cost) {
         double c = (double)sh.cost[e];
         if (nm.norm_cost) c = fmin(fmax(c / sh.dens[1], -nm.clip_cost), nm.clip_cost);
-        a.buf.costs[tn] = (float)c;
+        buf.costs[tn] = (float)c;
       }
       sh.last_done[e] = sh.done[e];
     }
@@ -2242,17 +2257,17 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     unsigned long long* o = g_rollout_prof_wide + (tid == 192 ? 8 : 0);
     o[0] = pc0; o[1] = pc1; o[2] = pc2; o[3] = pc3; o[4] = pc4; o[5] = (unsigned long long)T;
   }
-  if (spin_limit == 1 && a.ag.status != nullptr && (tid & 63) == 0) atomicOr(a.ag.status, 1);
+  if (spin_limit == 1 && ag.status != nullptr && (tid & 63) == 0) atomicOr(ag.status, 1);
   // ---- leave the agent / wrapper / normaliser state exactly where the per-step path leaves it
   for (int idx = tid; idx < Eg * MULTI_OP; idx += 256) {
     const int e = idx / MULTI_OP, i = idx % MULTI_OP;
-    if (i < O) a.ag.last_obs[(size_t)(g + e * G) * O + i] = sh.olast[e][i];
+    if (i < O) ag.last_obs[(size_t)(g + e * G) * O + i] = sh.olast[e][i];
   }
   if (tid < Eg) {
     const int e = tid, n = g + e * G;
-    a.ag.last_dones[n] = (uint8_t)sh.last_done[e];
-    a.ag.raw_rew[n] = sh.rew[e]; a.ag.dones[n] = (uint8_t)sh.done[e];
-    if (has_cost) a.ag.raw_cost[n] = sh.cost[e];
+    ag.last_dones[n] = (uint8_t)sh.last_done[e];
+    ag.raw_rew[n] = sh.rew[e]; ag.dones[n] = (uint8_t)sh.done[e];
+    if (has_cost) ag.raw_cost[n] = sh.cost[e];
   }
   if (lane == 0) {
     if (own_col >= 0) { nm.obs_mean[own_col] = o_mean; nm.obs_var[own_col] = o_var; if (own_col == 0) nm.obs_count[0] = o_cnt; }
@@ -2406,7 +2421,14 @@ __device__ __forceinline__ void sample_episodes_body(const SampleArgs& a) {
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int O = a.pl.O, A = a.pl.A;
   const int AS = a.pl.discrete ? 1 : A;
-  icrl_env_t env = a.env;
+  icrl_env_t env = a.env; globalize(env);
+  // what the step loop reads of the argument block, once (a batched launch keeps the block in LDS; pointers: common.h as_global)
+  const float* const noise_g = as_global(a.noise);
+  float* const actions_g = as_global(a.actions);
+  double* const orig_obs_g = as_global(a.orig_obs);
+  double* const obs_g = as_global(a.obs);
+  const int norm_obs = a.nm.norm_obs, deterministic = a.deterministic;
+  const double clip_obs = a.nm.clip_obs;
   for (int i = tid; i < O * a.env.act_dim; i += 192) Bl[i] = a.env.B[i];
   env.B = Bl;
   const bool has_box = a.alow != nullptr && a.ahigh != nullptr;
@@ -2427,7 +2449,7 @@ __device__ __forceinline__ void sample_episodes_body(const SampleArgs& a) {
   __syncthreads();
   size_t row = a.stream_row0 != nullptr ? (size_t)a.stream_row0[n] : (size_t)n * a.rows_per_stream;
   const size_t row_end = a.stream_row0 != nullptr ? (size_t)a.total_rows : row + a.rows_per_stream;
-  float noise_reg = (a.noise != nullptr && tid < AS) ? a.noise[row * AS + tid] : 0.f;   // noise of the first step
+  float noise_reg = (noise_g != nullptr && tid < AS) ? noise_g[row * AS + tid] : 0.f;   // noise of the first step
   for (int ep = 0; ep < a.episodes_per_stream; ++ep) {
     double ep_rew = 0.0;
     int ep_len = 0;
@@ -2435,16 +2457,16 @@ __device__ __forceinline__ void sample_episodes_body(const SampleArgs& a) {
       if (tid < O) {
         const double raw = sh.s_new[tid];
         double o = raw;
-        if (a.nm.norm_obs) o = fmin(fmax((raw - n_mean) / n_den, -a.nm.clip_obs), a.nm.clip_obs);
+        if (norm_obs) o = fmin(fmax((raw - n_mean) / n_den, -clip_obs), clip_obs);
         sh.s_old[tid] = raw;
         sh.x[tid] = (float)o;
       }
-      if (a.noise != nullptr && tid < AS) {
+      if (noise_g != nullptr && tid < AS) {
         noise_s[tid] = noise_reg;
-        if (row + 1 < row_end) noise_reg = a.noise[(row + 1) * AS + tid];      // next step's noise lands during this step
+        if (row + 1 < row_end) noise_reg = noise_g[(row + 1) * AS + tid];      // next step's noise lands during this step
       }
       __syncthreads();
-      policy_forward_block<OCT>(a.pl, R, sh, a.noise ? noise_s : nullptr, a.deterministic || a.noise == nullptr,
+      policy_forward_block<OCT>(a.pl, R, sh, noise_g ? noise_s : nullptr, deterministic || noise_g == nullptr,
                                 has_box ? alow_s : nullptr, has_box ? ahigh_s : nullptr);
       __syncthreads();
       const bool in_rows = row < row_end;      // (a stream whose speculative start row was too late can run off the arrays)
@@ -2452,15 +2474,15 @@ __device__ __forceinline__ void sample_episodes_body(const SampleArgs& a) {
         double rew; int done;
         env_step_wave(env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
         if (lane == 0) { s_done = done; s_rew = rew; }
-        if (lane < AS && in_rows) a.actions[row * AS + lane] = sh.act_clip[lane];
+        if (lane < AS && in_rows) actions_g[row * AS + lane] = sh.act_clip[lane];
       }
       __syncthreads();
       if (tid < O && in_rows) {
         const double raw = sh.s_new[tid];
         double o = raw;
-        if (a.nm.norm_obs) o = fmin(fmax((raw - n_mean) / n_den, -a.nm.clip_obs), a.nm.clip_obs);
-        a.orig_obs[row * O + tid] = raw;
-        a.obs[row * O + tid] = o;
+        if (norm_obs) o = fmin(fmax((raw - n_mean) / n_den, -clip_obs), clip_obs);
+        orig_obs_g[row * O + tid] = raw;
+        obs_g[row * O + tid] = o;
       }
       ep_rew += s_rew;     // episode_reward += reward (un-normalised: norm_reward is False on sampling / eval envs)
       ++ep_len;

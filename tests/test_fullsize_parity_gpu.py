@@ -55,11 +55,20 @@ def _pair(env_id, kind, N, T, od, ad, cn_layers, seed, **kw):
     return agent, port, env
 
 
+@pytest.fixture(autouse=True)
+def _one_cpu_thread():
+    """the port's 64-row MLP steps are fastest on one thread (bench.py: cpu_baseline); restored afterwards — the thread count
+    changes the rounding of torch's CPU initialisers (orthogonal_: LAPACK QR), which other tests compare across processes."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
+
+
 def _forward_step(agent, port, env, n_rollouts, lr, target_kl):
     """learn() of both sides, rollout by rollout, with a comparison after every train()."""
     from icrl_amd import logger
     T, N = agent.n_steps, agent.n_envs
-    torch.set_num_threads(1)          # the port's 64-row MLP steps are fastest on one thread (bench.py: cpu_baseline)
     streams = SeededStreams(77)
     agent._setup_learn(n_rollouts * N * T)
     port.num_timesteps = 0

@@ -39,5 +39,20 @@ for S in [int(x) for x in os.environ.get("SEEDS", "1,8,16,32,64").split(",")]:
         res = dict(rollout_begin=t1 - t0, rollout=t2 - t1, train_begin=t3 - t2, train=t4 - t3, train_end=t5 - t4)
     steps = int(host[0][1])
     print(f"S={S:3d}: " + ", ".join(f"{k} {1e3 * v:7.1f} ms" for k, v in res.items()) + f"; update {1e6 * res['train'] / steps:6.2f} us/step ({steps} steps), rollout {1e6 * res['rollout'] / 2048:6.2f} us/step", flush=True)
+    if S == 1:      # the same run through the single-run entry points (argument blocks by value): is the batched form as fast?
+        a = agents[0]
+        for rep in range(2):
+            t0 = sync()
+            j = a._rollout_begin(None, a.rollout_buffer, a.n_steps, None, zero_buffer=False)
+            a._rollout_launch(j)
+            t1 = sync()
+            a._rollout_end(j, a.env, None, a.rollout_buffer, a.n_steps)
+            tj = a._train_begin(None)
+            t2 = sync()
+            a._train_launch(tj)
+            t3 = sync()
+            h = a.train_readback().cpu().numpy().reshape(-1)
+            a._train_end(tj, host=h)
+        print(f"      solo entry points: rollout {1e6 * (t1 - t0) / 2048:6.2f} us/step, update {1e6 * (t3 - t2) / int(h[1]):6.2f} us/step ({int(h[1])} steps)", flush=True)
     del sb, sts, agents
     torch.cuda.empty_cache()
