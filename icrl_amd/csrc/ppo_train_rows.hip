@@ -75,8 +75,11 @@ struct SmemR {  // offsets in floats (multiples of 4)
 // own + partner — float addition is commutative bit for bit, so both halves hold identical gradients, run the identical norm /
 // Adam arithmetic on identical weights and stay replicas of each other.  One more hop per step for half of the GEMM work.
 // the whole update of ONE run (see ppo_train_pairs_body): `ka` = the same argument block in memory
-template <int NT1, bool DISC, bool SPLIT>
+// BATCH: the argument block was read from memory (batched launch): its pointers are marked as global-memory pointers (common.h:
+// as_global).  The single-run kernel's by-value pointers already are, and at AntWall widths the extra scalar traffic costs it 6 %.
+template <int NT1, bool DISC, bool SPLIT, bool BATCH>
 __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const TrainArgs* const ka) {
+#define GP(x) (BATCH ? as_global(x) : (x))
   using S = SmemR<NT1>;
   constexpr int SX = S::SX;
   constexpr int XR = (S::O16 + 3) / 4;  // floats of an X row each of the 4 threads of a row stages
@@ -90,18 +93,18 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
   const int O = a.L.O, A = a.L.A;
   const int n_out = role == 0 ? A : 1;
   const int T = a.buf.T, N = a.buf.N;
-  const float nu = as_global(a.nu)[0];
+  const float nu = GP(a.nu)[0];
   const int n_steps = a.n_steps;
-  const PlanStep* __restrict__ const plan_steps = as_global(a.plan_steps);
-  const PlanChunk* __restrict__ const plan_chunks = as_global(a.plan_chunks);
-  const int* __restrict__ const perms = as_global(a.perms);
+  const PlanStep* __restrict__ const plan_steps = GP(a.plan_steps);
+  const PlanChunk* __restrict__ const plan_chunks = GP(a.plan_chunks);
+  const int* __restrict__ const perms = GP(a.perms);
   // per-row side data of this role, selected once:
   //   policy: old log-prob, reward advantage, cost advantage;  critics: old value, return, (unused)
-  const float* const p_s0 = as_global(role == 0 ? a.buf.log_probs : (role == 1 ? a.buf.reward_values : a.buf.cost_values));
-  const float* const p_s1 = as_global(role == 0 ? a.buf.reward_advantages : (role == 1 ? a.buf.reward_returns : a.buf.cost_returns));
-  const float* const p_s2 = as_global(a.buf.cost_advantages);
-  const float* const p_obs = as_global(a.buf.observations);
-  const float* const p_act = as_global(a.buf.actions);
+  const float* const p_s0 = GP(role == 0 ? a.buf.log_probs : (role == 1 ? a.buf.reward_values : a.buf.cost_values));
+  const float* const p_s1 = GP(role == 0 ? a.buf.reward_advantages : (role == 1 ? a.buf.reward_returns : a.buf.cost_returns));
+  const float* const p_s2 = GP(a.buf.cost_advantages);
+  const float* const p_obs = GP(a.buf.observations);
+  const float* const p_act = GP(a.buf.actions);
   const int AS = a.buf.act_store;
 
   // wave w owns W1 / W2 rows 16w..16w+15 (element j = 16w + 4q + i, k = 16c + r) and head-weight columns 16w..16w+15
@@ -218,7 +221,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
   const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
   const float ent_coef = a.hp.ent_coef;
   const float max_grad_norm = a.hp.max_grad_norm, adam_epsf = a.hp.adam_eps, adam_b2f = a.hp.adam_beta2;
-  u64* const xch = as_global(a.xch);
+  u64* const xch = GP(a.xch);
 
   // ---------------------------------------------------------------------------------------------------------------
   // row stream: rows of chunk g+1 are prefetched into registers while chunk g is processed, their permutation indices two
@@ -733,8 +736,8 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
       // spare at AntWall widths), the next group's loads in flight while this one is checked.
       constexpr int KG = 4 * NT1 + 23, NGRP = NT1 + 6;       // groups: W1 tiles, 4 W2 tiles, head, {b1, b2, extra, -}
       const size_t blk = (size_t)(KG + 5) * TH4;
-      u64* const mine = as_global(KARGS()->gx) + ((size_t)((step & 1) * 3 + role) * 2 + half) * blk + tid;
-      const u64* const theirs = as_global(KARGS()->gx) + ((size_t)((step & 1) * 3 + role) * 2 + (1 - half)) * blk + tid;
+      u64* const mine = GP(KARGS()->gx) + ((size_t)((step & 1) * 3 + role) * 2 + half) * blk + tid;
+      const u64* const theirs = GP(KARGS()->gx) + ((size_t)((step & 1) * 3 + role) * 2 + (1 - half)) * blk + tid;
       const u64 tg = (u64)step << 32;
       f32x4 gsc = f32x4{gb1r, gb2r, gex, 0.f};
       auto grp = [&](int g) -> f32x4& { return g < NT1 ? gW1r[g] : (g < NT1 + 4 ? gW2r[g - NT1] : (g == NT1 + 4 ? gWhr : gsc)); };
@@ -1025,14 +1028,14 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
 
 template <int NT1, bool DISC, bool SPLIT>
 __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
-  ppo_train_rows_body<NT1, DISC, SPLIT>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+  ppo_train_rows_body<NT1, DISC, SPLIT, false>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr());
 }
 
 // several independent runs in ONE launch: grid (3 or 6, n_runs), run = blockIdx.y
 template <int NT1, bool DISC, bool SPLIT>
 __global__ void __launch_bounds__(TH4) ppo_train_rows_batch_kernel(const TrainArgs* __restrict__ runs) {
   const TrainArgs* const ka = as_global(runs + blockIdx.y);
-  ppo_train_rows_body<NT1, DISC, SPLIT>(*ka, ka);
+  ppo_train_rows_body<NT1, DISC, SPLIT, true>(*ka, ka);
 }
 
 template <int NT1, bool DISC, bool SPLIT>
