@@ -1626,7 +1626,10 @@ struct TileRegs {
   float w1[4][K1];        // first layer (policy nets: 4 OCT k steps used | cost net: 4 CIT)
   float w2[4][16];        // second layer
   float wh[16];           // wave 0: Wa[action r][k = 4 ks + q] at [ks] (the other per-unit / per-action constants: MultiShared::cst)
-  int sel[(16 * (CIT > 0 ? CIT : 1) + WAVE - 1) / WAVE];   // cost net: select_dim entries this lane prepares
+  static constexpr int NSEL = (16 * (CIT > 0 ? CIT : 1) + WAVE - 1) / WAVE;
+  int sel[NSEL];          // cost net: select_dim entries this lane prepares ...
+  float plo[NSEL], phi[NSEL];        // ... their action bounds (ConstraintNet.clip_actions) ...
+  double pmean[NSEL], pden[NSEL];    // ... and observation statistics (--cn_normalize: mean, sqrt(var + eps)): constants of the rollout
 };
 
 template <int OCT, int CIT>
@@ -1683,7 +1686,18 @@ __device__ __forceinline__ void load_cn_tiles(const icrl_costnet_t& cn, const Cn
     if (j == 0) cst[CST_BO] = PT[L.bo];
   }
 #pragma unroll
-  for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) { const int idx = lane + i * WAVE; R.sel[i] = idx < L.in ? cn.select_dim[idx] : -1; }
+  for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) {
+    const int idx = lane + i * WAVE;
+    const int sel = idx < L.in ? cn.select_dim[idx] : -1;
+    R.sel[i] = sel;
+    R.plo[i] = 0.f; R.phi[i] = 0.f; R.pmean[i] = 0.0; R.pden[i] = 1.0;
+    if (sel >= 0 && sel < cn.obs_dim) {
+      if (cn.obs_mean != nullptr && cn.obs_var != nullptr) { R.pmean[i] = cn.obs_mean[sel]; R.pden[i] = sqrt(cn.obs_var[sel] + cn.eps); }
+    } else if (sel >= 0) {
+      const int ai = sel - cn.obs_dim;
+      if (cn.action_low != nullptr && cn.action_high != nullptr) { R.plo[i] = cn.action_low[ai]; R.phi[i] = cn.action_high[ai]; }
+    }
+  }
 }
 
 // wave_sum_fast's association for a value that lives as [tile t][i] = element 16 t + 4 q + i of env r: element c + 16 m sits in
@@ -1708,8 +1722,16 @@ static inline size_t multi_dyn_lds(int N, int O, int A, int owners) {
 // env at all.  The per-component arithmetic, the reward and the auto-reset draw are env_step_wave's, operation for operation; only
 // the lanes they run on differ.  Leaves s_new, ctr, tep, rew, done of every handled env in `sh`.
 template <int E, int CIT>
-__device__ __noinline__ void env_step_wave3(const icrl_env_t& e, MultiShared<E, CIT>& sh, int em, int n, bool mine, int ci, int slot) {
-  const int O = e.obs_dim, A = e.act_dim;
+__device__ __noinline__ void env_step_wave3(int O, int A, int flags, int max_steps, const double __attribute__((address_space(3)))* B,
+                                            double* s_all, int32_t* t_ep_all, uint32_t* step_count_all,
+                                            MultiShared<E, CIT> __attribute__((address_space(3)))* shp,
+                                            int em, int n, bool mine, int ci, int slot) {
+  // (not inlined — inlined, the kernel spills; so everything comes in by value: the env's few scalars (flags = broken | reward_form << 1
+  // | wall_terminate << 8), the workgroup's LDS state and the LDS copy of the dynamics matrix as LDS-address-space pointers, the env
+  // arrays as global pointers — through a struct reference every access would be a flat_* instruction)
+  MultiShared<E, CIT> __attribute__((address_space(3)))& sh = *shp;
+  const bool broken = flags & 1, wall_terminate = (flags >> 8) & 1;
+  const int reward_form = (flags >> 1) & 127;
   const bool live = mine && ci < O;
   double a[MAX_ACT];
   double sq = 0.0;
@@ -1718,7 +1740,7 @@ __device__ __noinline__ void env_step_wave3(const icrl_env_t& e, MultiShared<E, 
     a[j] = 0.0;
     if (j < A) {
       a[j] = (double)sh.act_clip[em][j];
-      if (e.broken && j >= 4) a[j] = 0.0;
+      if (broken && j >= 4) a[j] = 0.0;
       sq = sq + a[j] * a[j];
     }
   }
@@ -1727,7 +1749,7 @@ __device__ __noinline__ void env_step_wave3(const icrl_env_t& e, MultiShared<E, 
   double ns = 0.0;
   {
     double acc = 0.99 * sh.s_old[em][i];
-    const double* Bi = e.B + (size_t)i * A;
+    const double __attribute__((address_space(3)))* Bi = B + (size_t)i * A;
 #pragma unroll
     for (int j = 0; j < MAX_ACT; ++j)
       if (j < A) acc = acc + Bi[j] * a[j];
@@ -1738,23 +1760,23 @@ __device__ __noinline__ void env_step_wave3(const icrl_env_t& e, MultiShared<E, 
   const double n0 = __shfl(ns, base, 64);
   const double n1 = __shfl(ns, base + 1, 64);
   double rw;
-  if (e.reward_form == 0) rw = fabs(n0 - sh.s_old[em][0]) / 0.05 - 0.1 * sq;
+  if (reward_form == 0) rw = fabs(n0 - sh.s_old[em][0]) / 0.05 - 0.1 * sq;
   else rw = (sqrt(n0 * n0 + n1 * n1) + 1.0) - 0.5 * sq;
   int d = 0;
-  if (e.wall_terminate && n0 <= -3.0) { rw = 0.0; d = 1; }
+  if (wall_terminate && n0 <= -3.0) { rw = 0.0; d = 1; }
   const int tep = sh.tep[em] + 1;
-  if (tep >= e.max_steps) d = 1;
+  if (tep >= max_steps) d = 1;
   __builtin_amdgcn_wave_barrier();           // every lane has read ctr / tep / s_old before lane 0 of a slot replaces them
   if (live) {
     double v = ns;
-    if (d) v = env_reset_value(e, ky, ct + 1u, i);   // auto-reset draw
-    as_global(e.s)[(size_t)n * O + i] = v;
+    if (d) v = reward_form >= 2 ? -1.0 : (unit_uniform(ky, ct + 1u, (uint32_t)(O + i)) - 0.5) * 0.2;   // auto-reset draw (env_reset_value)
+    as_global(s_all)[(size_t)n * O + i] = v;
     sh.s_new[em][i] = v;
   }
   if (mine && ci == 0) {
     const int tnew = d ? 0 : tep;
     sh.tep[em] = tnew; sh.ctr[em] = ct + 1u; sh.rew[em] = rw; sh.done[em] = d;
-    as_global(e.t_ep)[n] = tnew; as_global(e.step_count)[n] = ct + 1u;
+    as_global(t_ep_all)[n] = tnew; as_global(step_count_all)[n] = ct + 1u;
   }
 }
 
@@ -1792,6 +1814,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   icrl_env_t env = a.env; globalize(env);
   for (int i = tid; i < O * a.env.act_dim; i += 256) Bl[i] = a.env.B[i];
   env.B = Bl;
+  const int env_flags = (env.broken ? 1 : 0) | (env.reward_form << 1) | (env.wall_terminate ? 256 : 0);
   if (tid < MAX_ACT) { sh.alow[tid] = (has_box && tid < A) ? a.alow[tid] : 0.f; sh.ahigh[tid] = (has_box && tid < A) ? a.ahigh[tid] : 0.f; }
   for (int idx = tid; idx < E * MULTI_OP; idx += 256) {
     const int e = idx / MULTI_OP, i = idx % MULTI_OP;
@@ -1827,10 +1850,14 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   const int r16 = lane & 15, q4 = lane >> 4;          // MFMA lane coordinates: env row r16, k / unit quarter q4
   const int er = r16 < E ? r16 : E - 1;               // rows beyond E replicate the last env's row (their results are not used)
   const int nk1 = (O + 3) / 4, nkc = a.has_cn ? (a.cl.in + 3) / 4 : 0;
+  const int pH1 = a.pl.H1, pH2 = a.pl.H2, cH1 = a.cl.H1, cH2 = a.cl.H2, cnh = a.cl.nh;      // (read once: the block may live in LDS)
+  const bool cn_norm = a.has_cn && cnet.obs_mean != nullptr && cnet.obs_var != nullptr;
+  const bool cn_box = a.has_cn && cnet.action_low != nullptr && cnet.action_high != nullptr;
+  const double cn_clip = cnet.clip_obs;
   int spin_limit = 1 << 22;
   __syncthreads();
   const bool prof = p.prof != 0 && g == p.prof - 1 && blockIdx.y == 0;
-  unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, tl = prof ? prof_now() : 0ull;
+  unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pcA = 0, pcB = 0, tl = prof ? prof_now() : 0ull;
   for (int t = 0; t < T; ++t) {
     const int par = t & 1;
     const unsigned gtag = (unsigned)(t + 1);
@@ -1849,19 +1876,21 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       for (int t = 0; t < 4; ++t) { z[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[t] = *reinterpret_cast<const f32x4*>(cw + CST_B1 + 16 * t); }
       {
         const float* xb = &sh.x[er][q4];
+        float bx[4 * OCT];              // every B operand of the layer in flight before the first MFMA (pad columns are zero)
+#pragma unroll
+        for (int ks = 0; ks < 4 * OCT; ++ks) bx[ks] = xb[4 * ks];
 #pragma unroll
         for (int ks = 0; ks < 4 * OCT; ++ks) {
           if (ks < nk1) {               // (k steps that only meet padding — zero weights — are not issued)
-            const float b = xb[4 * ks];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) z[t] = MFMA16(R.w1[t][ks], b, z[t]);
+            for (int t = 0; t < 4; ++t) z[t] = MFMA16(R.w1[t][ks], bx[ks], z[t]);
           }
         }
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H1 ? fast_tanh(z[t][i] + cb[t][i]) : 0.f;
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < pH1 ? fast_tanh(z[t][i] + cb[t][i]) : 0.f;
       if (r16 < E) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&sh.h[w][r16][16 * t + 4 * q4]) = z[t];
@@ -1882,7 +1911,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H2 ? fast_tanh(z[t][i] + cb[t][i]) : 0.f;
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < pH2 ? fast_tanh(z[t][i] + cb[t][i]) : 0.f;
       if (w == 0) {                     // action head + Gaussian sample / log-prob of every env: lane (r, q) holds actions 4 q + i of env r
         __builtin_amdgcn_wave_barrier();        // (every lane's reads of h are consumed: the MFMAs above used them)
         if (r16 < E) {
@@ -1931,7 +1960,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         for (int t = 0; t < 4; ++t) {
           const f32x4 wo = *reinterpret_cast<const f32x4*>(cw + CST_WO + 16 * t);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.pl.H2 ? wo[i] * z[t][i] : 0.f;
+          for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < pH2 ? wo[i] * z[t][i] : 0.f;
         }
         const float v = tile_sum64(z) + sh.cst[w][CST_BO];
         if (r16 < E && q4 == 0) sh.scal[r16][w - 1] = v;
@@ -1963,7 +1992,8 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
             ag.last_v_c[n] = sh.scal[em][1];
           }
         }
-        env_step_wave3<E, CIT>(env, sh, em, n, mine, ci, slot);
+        env_step_wave3<E, CIT>(O, env.act_dim, env_flags, env.max_steps, (const double __attribute__((address_space(3)))*)Bl, env.s, env.t_ep, env.step_count,
+                               (MultiShared<E, CIT> __attribute__((address_space(3)))*)&sh, em, n, mine, ci, slot);
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_s_waitcnt(0xC07F);      // the wave's LDS writes (s_new, rew, done) are visible to its own reads
         if (mine) {
@@ -2017,34 +2047,41 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
           sh.ctr[e] = e_ctr; sh.tep[e] = e_tep; sh.rew[e] = rew; sh.done[e] = done;
         }
       }
-    } else if (a.has_cn) {
+    } else if (has_cost) {
       // cost net of all E envs at once (wave 3): prepare() per env into cx, then the ReLU layers as MFMA tiles
-      for (int e = 0; e < Eg; ++e) {
 #pragma unroll
-        for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) {
-          const int idx = lane + i * WAVE;
-          const int sel = R.sel[i];
+      for (int i = 0; i < (16 * CIT + WAVE - 1) / WAVE; ++i) {
+        // this lane's input component idx = lane + 64 i of EVERY env: the loads of all envs first (no branch between them), then the
+        // arithmetic of prepare() — operation for operation cost_forward_wave's
+        const int idx = lane + i * WAVE;
+        const int sel = R.sel[i];
+        const bool is_obs = sel >= 0 && sel < cnet.obs_dim, is_act = sel >= cnet.obs_dim;
+        const int so = is_obs ? sel : 0, sa = is_act ? sel - cnet.obs_dim : 0;
+        double ov[E];
+        float av[E], a0[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) { ov[e] = sh.s_old[e][so]; av[e] = sh.act_clip[e][sa]; a0[e] = sh.act_clip[e][0]; }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
           float v = 0.f;
-          if (sel >= 0) {
-            if (sel < cnet.obs_dim) {
-              double o = sh.s_old[e][sel];
-              if (cnet.obs_mean != nullptr && cnet.obs_var != nullptr) o = (o - cnet.obs_mean[sel]) / sqrt(cnet.obs_var[sel] + cnet.eps);
-              if (cnet.clip_obs >= 0.0) o = fmin(fmax(o, -cnet.clip_obs), cnet.clip_obs);
-              v = (float)o;
-            } else {
-              const int ai = sel - cnet.obs_dim;
-              float x;
-              if (cnet.is_discrete) x = ((int)sh.act_clip[e][0] == ai) ? 1.f : 0.f;
-              else x = sh.act_clip[e][ai];
-              if (cnet.action_low != nullptr && cnet.action_high != nullptr) x = fminf(fmaxf(x, cnet.action_low[ai]), cnet.action_high[ai]);
-              v = x;
-            }
+          if (is_obs) {
+            double o = ov[e];
+            if (cn_norm) o = (o - R.pmean[i]) / R.pden[i];
+            if (cn_clip >= 0.0) o = fmin(fmax(o, -cn_clip), cn_clip);
+            v = (float)o;
+          } else if (is_act) {
+            float x;
+            if (cnet.is_discrete) x = ((int)a0[e] == sa) ? 1.f : 0.f;
+            else x = av[e];
+            if (cn_box) x = fminf(fmaxf(x, R.plo[i]), R.phi[i]);
+            v = x;
           }
           if (idx < 16 * CIT) sh.cx[e][idx] = v;       // pad entries are written as 0
         }
       }
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_s_waitcnt(0xC07F);
+      if (prof) pcA += prof_now() - tl;                 // (cost wave: inputs prepared)
       const int erc = r16 < Eg ? r16 : Eg - 1;          // (rows beyond the workgroup's envs replicate the last one)
       f32x4 z[4], cb[4];
       const float* const cw = &sh.cst[3][4 * q4];
@@ -2052,21 +2089,23 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       for (int t = 0; t < 4; ++t) { z[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[t] = *reinterpret_cast<const f32x4*>(cw + CST_B1 + 16 * t); }
       {
         const float* xb = &sh.cx[erc][q4];
+        float bx[4 * CIT];
+#pragma unroll
+        for (int ks = 0; ks < 4 * CIT; ++ks) bx[ks] = xb[4 * ks];
 #pragma unroll
         for (int ks = 0; ks < 4 * CIT; ++ks) {
           if (ks < nkc) {
-            const float b = xb[4 * ks];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              if (16 * t < a.cl.H1) z[t] = MFMA16(R.w1[t][ks], b, z[t]);
+              if (16 * t < cH1) z[t] = MFMA16(R.w1[t][ks], bx[ks], z[t]);
           }
         }
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H1 ? fmaxf(z[t][i] + cb[t][i], 0.f) : 0.f;
-      if (a.cl.nh == 2) {
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < cH1 ? fmaxf(z[t][i] + cb[t][i], 0.f) : 0.f;
+      if (cnh == 2) {
         if (r16 < E) {
 #pragma unroll
           for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&sh.h[3][r16][16 * t + 4 * q4]) = z[t];
@@ -2083,23 +2122,24 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         for (int t = 0; t < 4; ++t) { z[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[t] = *reinterpret_cast<const f32x4*>(cw + CST_B2 + 16 * t); }
 #pragma unroll
         for (int ks = 0; ks < 16; ++ks) {
-          if (4 * ks < a.cl.H1) {
+          if (4 * ks < cH1) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
-              if (16 * t < a.cl.H2) z[t] = MFMA16(R.w2[t][ks], bop[ks], z[t]);
+              if (16 * t < cH2) z[t] = MFMA16(R.w2[t][ks], bop[ks], z[t]);
           }
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H2 ? fmaxf(z[t][i] + cb[t][i], 0.f) : 0.f;
+          for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < cH2 ? fmaxf(z[t][i] + cb[t][i], 0.f) : 0.f;
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const f32x4 wo = *reinterpret_cast<const f32x4*>(cw + CST_WO + 16 * t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < a.cl.H2 ? wo[i] * z[t][i] : 0.f;
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < cH2 ? wo[i] * z[t][i] : 0.f;
       }
+      if (prof) pcB += prof_now() - tl;                 // (cost wave: hidden layers done)
       const float zz = tile_sum64(z) + sh.cst[3][CST_BO];
       const float zeta = 1.f / (1.f + expf(-zz));
       const float cost = 1.f - zeta;
@@ -2255,7 +2295,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   }
   if (prof && (tid == 0 || tid == 192)) {      // wave 0: a policy / env wave's view; wave 3: the cost wave's
     unsigned long long* o = g_rollout_prof_wide + (tid == 192 ? 8 : 0);
-    o[0] = pc0; o[1] = pc1; o[2] = pc2; o[3] = pc3; o[4] = pc4; o[5] = (unsigned long long)T;
+    o[0] = pc0; o[1] = pc1; o[2] = pc2; o[3] = pc3; o[4] = pc4; o[5] = (unsigned long long)T; o[6] = pcA; o[7] = pcB;
   }
   if (spin_limit == 1 && ag.status != nullptr && (tid & 63) == 0) atomicOr(ag.status, 1);
   // ---- leave the agent / wrapper / normaliser state exactly where the per-step path leaves it

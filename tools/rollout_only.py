@@ -52,7 +52,7 @@ def run(kind, N, T, broken=False):
             names = ("MLPs+heads", "env steps / cost net + rows", "owner gather+moments+publish", "statistics wait", "normalise+rows")
             for base, wave in ((0, "wave 0"), (8, "wave 3 (cost)")):
                 Tn = max(1, out[base + 5])
-                print(f"   multi, {who}, {wave}: " + ", ".join(f"{n} {out[base + k] / Tn:.0f}" for k, n in enumerate(names)) + f"  (sum {sum(out[base:base + 5]) / Tn:.0f} cycles/step)")
+                print(f"   multi, {who}, {wave}: " + ", ".join(f"{n} {out[base + k] / Tn:.0f}" for k, n in enumerate(names)) + f"  (sum {sum(out[base:base + 5]) / Tn:.0f} cycles/step" + (f"; cost wave: inputs prepared after {out[base + 6] / Tn:.0f}, hidden layers after {out[base + 7] / Tn:.0f}" if base else "") + ")")
         agent.profile_phases = 0
         agent.rollout_kernel = "auto"
     if N > 128 and os.environ.get("PHASES"):          # phase timers of the many-environment persistent kernel (cycles per step)
