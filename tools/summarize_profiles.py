@@ -49,6 +49,30 @@ def kernel_stats(tag, which="bench"):
     print("wrote", dst + ".md")
 
 
+def seed_batch_stats(tag):
+    """kernel table of a lock-step batch of 32 runs (tools/profile_seed_batch.sh)."""
+    src = find(f"prof_{tag}_seeds/**/*kernel_stats.csv")
+    if src is None:
+        return
+    rows = list(csv.DictReader(open(src)))
+    dst = os.path.join(ROOT, "profiles", f"{tag}_seed_batch_kernel_stats")
+    with open(dst + ".csv", "w") as f:
+        f.write(open(src).read())
+    line = ""
+    log = os.path.join(ROOT, "gpurun_out", f"prof_{tag}_seeds.log")
+    if os.path.exists(log):
+        line = "".join(l for l in open(log) if l.startswith("S="))
+    with open(dst + ".md", "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats — 32 independent ICRL runs (BASELINE configs[1] each) in lock-step on one MI355X ({tag})\n\n"
+                "command: `SEEDS=32 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag>_seeds -- python3 tools/seed_batch_bench.py` "
+                "(set-up + 1 warm-up + 2 timed outer iterations of every run; every `*_batch_kernel` launch carries all 32 runs, run = blockIdx.y)\n\n"
+                f"the (profiled) run: {line}\n| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|\n")
+        for r in rows[:20]:
+            name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
+            f.write(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+    print("wrote", dst + ".md")
+
+
 def gae_pmc(tag, T=2048, N=131072):
     out = {}
     for name, key in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
@@ -88,4 +112,5 @@ if __name__ == "__main__":
     tag = sys.argv[1]
     kernel_stats(tag)
     kernel_stats(tag, "antwall")
+    seed_batch_stats(tag)
     gae_pmc(tag)
