@@ -236,7 +236,7 @@ def test_fused_rollout_vs_port(kind, N, T):
     assert env.obs_rms.count == stack.norm.obs_rms.count
 
 
-def _pair_of_agents(N, T, seed, kind="hc", broken=False):
+def _pair_of_agents(N, T, seed, kind="hc", broken=False, cn_kwargs=None):
     from icrl_amd.ppo_lag import PPOLagrangian
     from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
     from icrl_amd.constraint_net import ConstraintNet
@@ -247,7 +247,8 @@ def _pair_of_agents(N, T, seed, kind="hc", broken=False):
     for _ in range(2):
         torch.manual_seed(seed)
         env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, kind, seed, broken=broken)))
-        cn = ConstraintNet(od, ad, hid, None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
+        kw = dict(clip_obs=20, action_low=lo, action_high=-lo) if cn_kwargs is None else cn_kwargs
+        cn = ConstraintNet(od, ad, hid, None, lambda x: 0.05, None, None, False, 0.5, **kw)
         env.set_cost_function(cn.cost_function)
         out.append((PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=seed), env, cn))
     out[1][2].load_state_dict(out[0][2].state_dict())
@@ -339,14 +340,14 @@ def test_analytic_env_cost_through_cost_wrapper():
 # shards of BASELINE configs[3], [2] and [4].
 @pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("hc", 7, 33), ("hc", 128, 20), ("hc", 256, 40), ("hc", 130, 24), ("ant", 256, 12),
                                       ("antbroken", 512, 10), ("hc", 1000, 6)])
-def test_persistent_rollout_equals_per_step_launches(kind, N, T, kernel="auto"):
+def test_persistent_rollout_equals_per_step_launches(kind, N, T, kernel="auto", cn_kwargs=None):
     """the one-launch rollout (device-wide exchange per step inside the kernel) against the launch pair per
     step: every buffer plane, the normaliser state and the agent's carry-over state are bit-identical, across two
     consecutive rollouts and across episode ends."""
     ekind = "ant" if kind == "antbroken" else kind
     ad = 6 if ekind == "hc" else 8
     limit = 1000 if ekind == "hc" else 500
-    (a_p, e_p, _), (a_s, e_s, _) = _pair_of_agents(N, T, 13, ekind, broken=kind == "antbroken")
+    (a_p, e_p, _), (a_s, e_s, _) = _pair_of_agents(N, T, 13, ekind, broken=kind == "antbroken", cn_kwargs=cn_kwargs)
     a_s.rollout_kernel = "steps"
     a_p.rollout_kernel = kernel
     noise = torch.as_tensor(np.random.RandomState(8).randn(2, T, N, ad).astype(np.float32), device="cuda")
@@ -382,3 +383,15 @@ def test_persistent_rollout_equals_per_step_launches(kind, N, T, kernel="auto"):
                                       ("hc", 2048, 5), ("antbroken", 4096, 3)])
 def test_multi_env_rollout_equals_per_step_launches(kind, N, T):
     test_persistent_rollout_equals_per_step_launches(kind, N, T, kernel="multi")
+
+
+@pytest.mark.parametrize("kernel", ["multi", "auto"])
+@pytest.mark.parametrize("kind,N,T", [("hc", 64, 40), ("ant", 128, 10)])
+def test_rollout_kernels_with_a_normalising_unclipped_constraint_net(kind, N, T, kernel):
+    """the other branches of ConstraintNet.prepare_data inside the fused rollouts: --cn_normalize statistics (mean / var per
+    observation column; the multi-env kernel keeps mean and sqrt(var + eps) of its input columns in registers), no observation
+    clipping, no action bounds (what ConstraintNet.load builds, constraint_net.py:394-399)."""
+    od = 18 if kind == "hc" else 113
+    rng = np.random.RandomState(4)
+    kw = dict(clip_obs=None, initial_obs_mean=rng.randn(od) * 0.1, initial_obs_var=rng.rand(od) + 0.5)
+    test_persistent_rollout_equals_per_step_launches(kind, N, T, kernel=kernel, cn_kwargs=kw)
