@@ -181,7 +181,7 @@ def seed_batch_leg(sizes=(8, 32, 64)):
         del sb
         torch.cuda.empty_cache()
     return dict(aggregate_env_steps_per_s=res, unit="env-steps/s", note="S independent ICRL runs (seeds) of the same workload on one "
-                "MI355X in lock-step from one host thread: rollouts of all runs = one launch of grid (64, S), updates = one launch of "
+                "MI355X in lock-step from one host thread: rollouts of all runs = one launch of 8 S persistent workgroups (8 envs each, the MLPs as fp32 MFMA tiles), updates = one launch of "
                 "3 S persistent workgroups, 2 timed outer iterations each; not the headline value")
 
 

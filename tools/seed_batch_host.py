@@ -10,6 +10,7 @@ S = int(os.environ.get("SEEDS", "32"))
 sb = SB.SeedBatch([bench.config2(4, seed, 0, 1) for seed in range(S)])
 sb.run(0, 2)
 acc = {}
+calls = {}
 def wrap(obj, name, label=None):
     fn = getattr(obj, name)
     label = label or f"{getattr(obj, '__name__', obj)}.{name}"
@@ -19,6 +20,7 @@ def wrap(obj, name, label=None):
             return fn(*a, **k)
         finally:
             acc[label] = acc.get(label, 0.0) + time.perf_counter() - t0
+            calls[label] = calls.get(label, 0) + 1
     setattr(obj, name, w)
 A = ppo_lag.PPOLagrangian
 for n in ("_setup_learn", "_rollout_begin", "_rollout_end", "_train_begin", "_train_end", "train_readback", "_draw_permutations"):
@@ -45,5 +47,6 @@ torch.cuda.synchronize(); t0 = time.perf_counter()
 sb.run(2, 2)
 tot = time.perf_counter() - t0
 print(f"S={S}: {1e3 * tot / 2:.1f} ms per iteration")
+print("  calls per iteration:", {k: c / 2 for k, c in calls.items() if k.startswith("batch._launch") or k.startswith("EpisodeRun")})
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     print(f"  {k:38s} {1e3 * v / 2:8.2f} ms")
