@@ -410,6 +410,25 @@ __global__ void k_bulk(unsigned long long* buf, unsigned long long* cyc, int ite
   if (acc == 12345.f) sink[0] = acc;
 }
 
+// per-XCD speed: one wave per workgroup runs the same dependent MFMA chain; wall time from the constant-rate counter (s_memrealtime,
+// 100 MHz) next to the shader-clock count (s_memtime) and the XCD the workgroup landed on
+__global__ void k_xcd_speed(unsigned long long* out, int iters) {
+  f32x4 acc = f32x4{0, 0, 0, 0};
+  float a = threadIdx.x * 0.001f, b = threadIdx.x * 0.002f;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), c0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = MFMA(a, b, acc);
+  }
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime(), c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID, 0, 4)" : "=s"(xcc));
+    out[4 * blockIdx.x + 0] = xcc; out[4 * blockIdx.x + 1] = r1 - r0; out[4 * blockIdx.x + 2] = c1 - c0;
+    out[4 * blockIdx.x + 3] = (unsigned long long)(acc[0] == 12345.f);
+  }
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main() {
   float* out; unsigned long long* cyc; unsigned long long* flag;
@@ -471,6 +490,19 @@ int main() {
       total += m; worst = w > worst ? w : worst;
     }
     printf("mfma 16x16x4 f32 chain vs sequential fmaf chain (K = 64): %d of %d outputs differ bitwise (worst |d| %.3e)\n", total, trials * 256, worst);
+  }
+  { // do the XCDs run at the same speed?
+    unsigned long long* xo; CK(hipMalloc(&xo, 64 * 4 * 8));
+    for (int rep = 0; rep < 3; ++rep) {
+      hipLaunchKernelGGL(k_xcd_speed, dim3(64), dim3(64), 0, 0, xo, 20000);
+      std::vector<unsigned long long> hx(64 * 4); hipDeviceSynchronize(); hipMemcpy(hx.data(), xo, hx.size() * 8, hipMemcpyDeviceToHost);
+      double best[8], worst[8]; int cnt[8];
+      for (int x = 0; x < 8; ++x) { best[x] = 1e30; worst[x] = 0; cnt[x] = 0; }
+      for (int b = 0; b < 64; ++b) { const int x = (int)hx[4 * b] & 7; const double us = hx[4 * b + 1] / 100.0; if (us < best[x]) best[x] = us; if (us > worst[x]) worst[x] = us; ++cnt[x]; }
+      printf("320 k dependent MFMAs (10.24 M shader cycles), 64 workgroups, wall us by XCD (min..max of its workgroups):");
+      for (int x = 0; x < 8; ++x) printf("  xcd%d[%d] %.0f..%.0f", x, cnt[x], best[x], worst[x]);
+      printf("\n");
+    }
   }
   hipLaunchKernelGGL(k_barrier, dim3(1), dim3(256), 0, 0, out, cyc, it); rd("s_barrier, 4 waves", it);
   hipLaunchKernelGGL(k_barrier, dim3(1), dim3(512), 0, 0, out, cyc, it); rd("s_barrier, 8 waves", it);
