@@ -2389,6 +2389,138 @@ __global__ void __launch_bounds__(192) policy_forward_kernel(PolLayout pl, const
   }
 }
 
+// The same forward for MANY rows (policy.evaluate_actions over the nominal / expert samples of the KL metrics, forward over a batch):
+// 16 rows per workgroup pass as fp32 MFMA tiles, exactly as rollout_multi_kernel evaluates 16 environments — every (unit, row) gets the
+// value of policy_forward_block's fmaf chain (TileRegs), the heads and the log-probability / entropy sums are taken in
+// wave_sum_fast's association.  Continuous actions only.  Waves: pi | vf | cvf; a workgroup walks tiles blockIdx.x, + gridDim.x, ...
+template <int OCT>
+__global__ void __launch_bounds__(192) policy_rows_kernel(PolLayout pl, const float* __restrict__ PT, const double* __restrict__ obs,
+                                                          const float* __restrict__ noise, int deterministic, const float* __restrict__ alow,
+                                                          const float* __restrict__ ahigh, float* actions, float* act_clipped, float* v_r,
+                                                          float* v_c, float* log_prob, const float* __restrict__ given, float* entropy, int N) {
+  constexpr int XS = 16 * OCT + 4;                       // row strides of 4 mod 32 floats: conflict-free B-operand reads
+  __shared__ __attribute__((aligned(16))) float x[16][XS];
+  __shared__ __attribute__((aligned(16))) float hbuf[3][16][MULTI_HS];
+  __shared__ __attribute__((aligned(16))) float cst[3][MULTI_CST];
+  TileRegs<OCT, 1> R;
+  load_pol_tiles<OCT, 1>(pl, PT, R, cst[threadIdx.x >> 6]);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int O = pl.O, A = pl.A, H1 = pl.H1, H2 = pl.H2;
+  const int nk1 = (O + 3) / 4;
+  const bool has_box = alow != nullptr && ahigh != nullptr;
+  const bool sample = given == nullptr && !deterministic && noise != nullptr;
+  for (int i = tid; i < 16 * XS; i += 192) (&x[0][0])[i] = 0.f;          // pad columns stay zero
+  const int n_tiles = (N + 15) / 16;
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int n0 = 16 * tile;
+    const int rows = N - n0 < 16 ? N - n0 : 16;
+    __syncthreads();                                      // the previous tile's x is consumed (first pass: the zero fill, cst)
+    for (int i = tid; i < rows * O; i += 192) { const int rr = i / O, k = i - rr * O; x[rr][k] = (float)obs[(size_t)(n0 + rr) * O + k]; }
+    __syncthreads();
+    const int er = r16 < rows ? r16 : rows - 1;           // rows beyond the tile replicate its last row (their results are not stored)
+    f32x4 z[4], cb[4];
+    float bop[16];
+    const float* const cw = &cst[w][4 * q4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { z[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[t] = *reinterpret_cast<const f32x4*>(cw + CST_B1 + 16 * t); }
+    {
+      const float* xb = &x[er][q4];
+      float bx[4 * OCT];
+#pragma unroll
+      for (int ks = 0; ks < 4 * OCT; ++ks) bx[ks] = xb[4 * ks];
+#pragma unroll
+      for (int ks = 0; ks < 4 * OCT; ++ks) {
+        if (ks < nk1) {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) z[t] = MFMA16(R.w1[t][ks], bx[ks], z[t]);
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < H1 ? fast_tanh(z[t][i] + cb[t][i]) : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&hbuf[w][r16][16 * t + 4 * q4]) = z[t];
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    {
+      const float* hb = &hbuf[w][r16][q4];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) bop[ks] = hb[4 * ks];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { z[t] = f32x4{0.f, 0.f, 0.f, 0.f}; cb[t] = *reinterpret_cast<const f32x4*>(cw + CST_B2 + 16 * t); }
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) z[t] = MFMA16(R.w2[t][ks], bop[ks], z[t]);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < H2 ? fast_tanh(z[t][i] + cb[t][i]) : 0.f;
+    const int n = n0 + r16;
+    const bool live = r16 < rows;
+    if (w == 0) {
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int t = 0; t < 4; ++t) *reinterpret_cast<f32x4*>(&hbuf[0][r16][16 * t + 4 * q4]) = z[t];
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      {
+        const float* hb = &hbuf[0][r16][q4];
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) bop[ks] = hb[4 * ks];
+      }
+      f32x4 m = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) m = MFMA16(R.wh[ks], bop[ks], m);
+      const f32x4 hb_ = *reinterpret_cast<const f32x4*>(cw + CST_BA), sd_ = *reinterpret_cast<const f32x4*>(cw + CST_SD);
+      const f32x4 lsd_ = *reinterpret_cast<const f32x4*>(cw + CST_LSD), i2v_ = *reinterpret_cast<const f32x4*>(cw + CST_I2V);
+      float u[4], ue[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ai = 4 * q4 + i;
+        const float mean = m[i] + hb_[i];
+        float lp = 0.f, entl = 0.f;
+        if (ai < A) {
+          const size_t at = (size_t)(live ? n : n0) * A + ai;
+          float act = mean;
+          if (given != nullptr) act = given[at];
+          else if (sample) act = mean + noise[at] * sd_[i];             // Normal.rsample: loc + eps * scale
+          const float diff = act - mean;
+          lp = -(diff * diff) / i2v_[i] - lsd_[i] - LOG_SQRT_2PI_F;
+          entl = HALF_LOG_2PI_PLUS_HALF_F + lsd_[i];
+          if (live) {
+            if (actions) actions[at] = act;
+            if (act_clipped) act_clipped[at] = has_box ? fminf(fmaxf(act, alow[ai]), ahigh[ai]) : act;
+          }
+        }
+        u[i] = (lp + 0.f) + (0.f + 0.f);                 // wave_sum_fast over lane = action: lanes 16.. hold 0
+        ue[i] = (entl + 0.f) + (0.f + 0.f);
+      }
+      const float lp_row = xor32_sum(xor16_sum((u[0] + u[1]) + (u[2] + u[3])));
+      const float ent_row = xor32_sum(xor16_sum((ue[0] + ue[1]) + (ue[2] + ue[3])));
+      if (live && q4 == 0) {
+        if (log_prob) log_prob[n] = lp_row;
+        if (entropy) entropy[n] = ent_row;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const f32x4 wo = *reinterpret_cast<const f32x4*>(cw + CST_WO + 16 * t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[t][i] = 16 * t + 4 * q4 + i < H2 ? wo[i] * z[t][i] : 0.f;
+      }
+      const float v = tile_sum64(z) + cst[w][CST_BO];
+      float* const dst = w == 1 ? v_r : v_c;
+      if (live && q4 == 0 && dst) dst[n] = v;
+    }
+  }
+}
+
 template <int CIT>
 __global__ void __launch_bounds__(64) cost_forward_kernel(icrl_costnet_t cn, CnLayout cl, const double* obs,
                                                           const float* acs, int N, float* cost, int mode = 0) {
@@ -2553,6 +2685,9 @@ __global__ void __launch_bounds__(192) sample_episodes_batch_kernel(const Sample
   sample_episodes_body<OCT>(a);
 }
 
+// rows from which icrl_policy_forward / icrl_policy_evaluate take the 16-rows-per-pass MFMA kernel (below: one workgroup per row)
+constexpr int ROWS_KERNEL_MIN = 64;
+
 static bool dims_ok(int O, int A, int H1, int H2) {
   return O > 0 && O <= MAX_OBS && A > 0 && A <= MAX_ACT && H1 > 0 && H1 <= MAX_H && H2 > 0 && H2 <= MAX_H;
 }
@@ -2594,6 +2729,16 @@ extern "C" int icrl_policy_forward(const icrl_policy_t* p, const double* obs, co
   if (N <= 0) return fail("policy forward / evaluate: N = %d rows", N);
   if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("policy forward / evaluate", p->obs_dim, p->act_dim, p->h1, p->h2);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
+  if (N >= ROWS_KERNEL_MIN && !p->discrete) {
+    const int grid = (N + 15) / 16 < 1024 ? (N + 15) / 16 : 1024;
+    if (L.O <= 32)
+      hipLaunchKernelGGL(policy_rows_kernel<2>, dim3(grid), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, noise, deterministic,
+                         action_low, action_high, actions, act_clipped, v_r, v_c, log_prob, (const float*)nullptr, (float*)nullptr, N);
+    else
+      hipLaunchKernelGGL(policy_rows_kernel<8>, dim3(grid), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, noise, deterministic,
+                         action_low, action_high, actions, act_clipped, v_r, v_c, log_prob, (const float*)nullptr, (float*)nullptr, N);
+    return (int)hipGetLastError();
+  }
   if (L.O <= 32)
     hipLaunchKernelGGL(policy_forward_kernel<2>, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, noise,
                        deterministic, action_low, action_high, actions, act_clipped, v_r, v_c, log_prob,
@@ -2610,6 +2755,16 @@ extern "C" int icrl_policy_evaluate(const icrl_policy_t* p, const double* obs, c
   if (N <= 0) return fail("policy forward / evaluate: N = %d rows", N);
   if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("policy forward / evaluate", p->obs_dim, p->act_dim, p->h1, p->h2);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
+  if (N >= ROWS_KERNEL_MIN && !p->discrete) {
+    const int grid = (N + 15) / 16 < 1024 ? (N + 15) / 16 : 1024;
+    if (L.O <= 32)
+      hipLaunchKernelGGL(policy_rows_kernel<2>, dim3(grid), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, (const float*)nullptr, 1,
+                         (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, v_r, v_c, log_prob, actions, entropy, N);
+    else
+      hipLaunchKernelGGL(policy_rows_kernel<8>, dim3(grid), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs, (const float*)nullptr, 1,
+                         (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, v_r, v_c, log_prob, actions, entropy, N);
+    return (int)hipGetLastError();
+  }
   if (L.O <= 32)
     hipLaunchKernelGGL(policy_forward_kernel<2>, dim3(N), dim3(192), 0, (hipStream_t)stream, L, p->params_t, obs,
                        (const float*)nullptr, 1, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr,

@@ -88,6 +88,39 @@ def test_policy_evaluate_actions(golden):
     assert np.allclose(ent.cpu().numpy(), oent.numpy(), rtol=1e-5, atol=1e-5)
 
 
+@pytest.mark.parametrize("kind,n", [("hc", 257), ("hc", 1000), ("ant", 333), ("narrow", 100)])
+def test_policy_rows_kernel_equals_one_workgroup_per_row(kind, n):
+    """icrl_policy_forward / icrl_policy_evaluate over >= 64 rows run 16 rows per workgroup pass as fp32 MFMA tiles
+    (policy_rows_kernel); below, one workgroup per row with per-lane fmaf chains.  Same values bit for bit: evaluate / forward
+    the rows at once, and in chunks of 50."""
+    from icrl_amd.policies import ActorTwoCriticsPolicy
+    from icrl_amd import spaces
+    od, ad = (113, 8) if kind == "ant" else (18, 6)
+    torch.manual_seed(3)
+    kw = dict(net_arch=[dict(pi=[40, 24], vf=[64, 20], cvf=[16, 64])]) if kind == "narrow" else {}
+    pol = ActorTwoCriticsPolicy(spaces.Box(-np.inf, np.inf, (od,), np.float64), spaces.Box(-1, 1, (ad,), np.float32), **kw)
+    rng = np.random.RandomState(5)
+    obs = rng.randn(n, od) * 2.0
+    act = rng.randn(n, ad).astype(np.float32)
+    noise = rng.randn(n, ad).astype(np.float32)
+    whole = [t.cpu().numpy() for t in pol.evaluate_actions(obs, act)]
+    parts = [pol.evaluate_actions(obs[i:i + 50], act[i:i + 50]) for i in range(0, n, 50)]
+    for k, name in enumerate(("reward_values", "cost_values", "log_prob", "entropy")):
+        ref = np.concatenate([pt[k].cpu().numpy() for pt in parts])
+        assert np.array_equal(whole[k], ref), (name, np.abs(whole[k] - ref).max())
+    for det in (False, True):
+        a, vr, vc, lp = pol.forward(obs, deterministic=det, noise=noise)
+        cl = pol.last_clipped
+        got = [t.cpu().numpy() for t in (a, vr, vc, lp, cl)]
+        ref = [[], [], [], [], []]
+        for i in range(0, n, 50):
+            a2, vr2, vc2, lp2 = pol.forward(obs[i:i + 50], deterministic=det, noise=noise[i:i + 50])
+            for lst, t in zip(ref, (a2, vr2, vc2, lp2, pol.last_clipped)):
+                lst.append(t.cpu().numpy())
+        for g_, r_, name in zip(got, ref, ("actions", "reward_values", "cost_values", "log_prob", "clipped")):
+            assert np.array_equal(g_, np.concatenate(r_)), (det, name)
+
+
 @pytest.mark.parametrize("case", ["mb_psis", "mb_episode", "mb_nois", "mb_gail"])
 def test_cn_train_minibatch_golden(golden, case):
     """`--cn_batch_size` mode against the REFERENCE's train() with the recorded permutations (tests/golden/g7)."""
