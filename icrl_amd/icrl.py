@@ -124,7 +124,10 @@ def outer_iteration(st, itr):
     config, rank, world = st["config"], st["rank"], st["world"]
     train_env, sampling_env, eval_env, constraint_net = st["train_env"], st["sampling_env"], st["eval_env"], st["constraint_net"]
     if config.reset_policy and itr != 0:
+        old_agent = st["agent"]
         st["agent"] = st["create_nominal_agent"]()
+        if hasattr(old_agent, "_train_ws"):         # same shapes: the update workspace (and where it was found to be fastest) carries over
+            st["agent"]._train_ws = old_agent._train_ws
     nominal_agent = st["agent"]
     current_progress_remaining = 1 - float(itr) / float(config.n_iters)
     # ---- forward step

@@ -446,8 +446,11 @@ class PPOLagrangian:
             perms = torch.as_tensor(np.asarray(perms).astype(np.int32), device=dev).contiguous()
         current_penalty = float(self.dual.nu().item())
         if not hasattr(self, "_train_ws"):
-            self._train_ws = dict(nu=torch.zeros(1, device=dev), stats=torch.zeros(32 + self.n_epochs, device=dev),
-                                  sync=torch.zeros(96 + 4 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2 + 32 + _lib.PPO_SPLIT_BYTES // 8, dtype=torch.int64, device=dev), t=torch.zeros(1, dtype=torch.int32, device=dev))
+            n_words = 96 + 4 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2 + 32 + _lib.PPO_SPLIT_BYTES // 8
+            # the workspace lives in an arena with room for SYNC_CANDIDATES positions 1 MB apart: see _tune_sync_placement
+            arena = torch.zeros(n_words + (self.SYNC_CANDIDATES - 1) * (1 << 17), dtype=torch.int64, device=dev)
+            self._train_ws = dict(nu=torch.zeros(1, device=dev), stats=torch.zeros(32 + self.n_epochs, device=dev), sync=arena[:n_words],
+                                  sync_arena=arena, sync_words=n_words, sync_tuned=False, t=torch.zeros(1, dtype=torch.int32, device=dev))
         ws = self._train_ws
         ws["nu"].fill_(current_penalty)
         ws["t"].fill_(pol.adam_step)
@@ -456,8 +459,54 @@ class PPOLagrangian:
                        float(self.target_kl or 0.0), crv, ccv, lr, 0.9, 0.999, float(pol.optimizer_kwargs.get("eps", 1e-8)))
         return dict(ps=pol.struct(), bs=rb.struct(), hp=hp, perms=perms, rng_state=rng_state, injected=injected, clip_range=clip_range)
 
+    # The three workgroups of an update exchange one granule per optimiser step through the first 512 bytes of the `sync` workspace, and
+    # how fast that hop is depends on where those bytes lie in device memory: moving the workspace by 2 MB switches the step between
+    # 8.87-8.90 us and 9.04-9.14 us on MI355X (period 4 MB inside one allocation, sub-structure at 512 KB; across allocations the
+    # virtual address does not tell — tools/sync_placement.py).  Which position is the near one is not knowable up front, so the first
+    # train() of an agent times a short update (one epoch over <= 16 384 rows of the rollout it is about to train on, identity
+    # permutation, parameters and moments restored afterwards) at SYNC_CANDIDATES positions 1 MB apart and keeps the fastest.
+    SYNC_CANDIDATES = 4
+    tune_sync_placement = True
+
+    def _tune_sync_placement(self, job):
+        ws, pol, rb = self._train_ws, self.policy, self.rollout_buffer
+        ws["sync_tuned"] = True
+        N, B = rb.n_envs, int(self.batch_size)
+        Tc = min(rb.buffer_size, max(1, 16384 // N))
+        if not self.tune_sync_placement or Tc * N < 64 * B:       # too few optimiser steps to time a 3 % difference
+            return
+        from .structs import BufferT, PpoHyperT
+        b = _lib.byref
+        bs = BufferT.from_buffer_copy(job["bs"]); bs.T = Tc
+        hp = PpoHyperT.from_buffer_copy(job["hp"]); hp.n_epochs = 1; hp.use_target_kl = 0; hp._pad = hp._pad & ~1
+        perm = torch.arange(Tc * N, dtype=torch.int32, device=self.device)
+        keep = [t.clone() for t in (pol.params, pol.exp_avg, pol.exp_avg_sq, ws["t"], ws["stats"])]
+        arena, n_words = ws["sync_arena"], ws["sync_words"]
+        best = (None, 0)
+        for rep_ in range(2):
+            for c in range(self.SYNC_CANDIDATES):
+                view = arena[c * (1 << 17):c * (1 << 17) + n_words]
+                for dst, src in zip((pol.params, pol.exp_avg, pol.exp_avg_sq, ws["t"]), keep):
+                    dst.copy_(src)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(_lib.lib().icrl_ppo_lag_train(b(job["ps"]), p(pol.exp_avg), p(pol.exp_avg_sq), p(ws["t"]), b(bs), p(perm), p(ws["nu"]),
+                                                         b(hp), p(ws["stats"]), p(view), _lib.current_stream()), "icrl_ppo_lag_train")
+                e1.record(); e1.synchronize()
+                ms = e0.elapsed_time(e1)
+                if rep_ == 1 and (best[0] is None or ms < best[0]):     # (the first round warms the code and the rows up)
+                    best = (ms, c)
+        for dst, src in zip((pol.params, pol.exp_avg, pol.exp_avg_sq, ws["t"], ws["stats"]), keep):
+            dst.copy_(src)
+        c = best[1]
+        arena.zero_()
+        ws["sync"] = arena[c * (1 << 17):c * (1 << 17) + n_words]
+        ws["sync_position"] = c
+
     def _train_launch(self, job):
         pol, ws, b = self.policy, self._train_ws, _lib.byref
+        if not ws["sync_tuned"]:
+            self._tune_sync_placement(job)
         ev = None
         if getattr(self, "train_events", None) is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))

@@ -117,6 +117,8 @@ class SeedBatch:
         rows = []
         for a, j in zip(agents, jobs):
             ws = a._train_ws
+            if not ws["sync_tuned"]:          # first update of the run: where its exchange workspace is fastest (PPOLagrangian._tune_sync_placement)
+                a._tune_sync_placement(j)
             rows.append((addr(j["ps"]), p(a.policy.exp_avg), p(a.policy.exp_avg_sq), p(ws["t"]), addr(j["bs"]), p(j["perms"]), p(ws["nu"]), addr(j["hp"]),
                          p(ws["stats"]), p(ws["sync"])))
         arr = _jobs(PpoTrainJobT, rows)
@@ -211,7 +213,10 @@ class SeedBatch:
         for st in sts:
             if st["config"].reset_policy and itr != 0:
                 with _as_run(st):
+                    old_agent = st["agent"]
                     st["agent"] = st["create_nominal_agent"]()
+                    if hasattr(old_agent, "_train_ws"):
+                        st["agent"]._train_ws = old_agent._train_ws
         agents = [st["agent"] for st in sts]
         progress = 1 - float(itr) / float(cfg0.n_iters)
         # ---- forward step
