@@ -185,3 +185,29 @@ def test_two_chunk_minibatches_on_one_workgroup_per_network(N, T, B):
     partial gradients (covered by test_train_vs_oracle above); hp._pad bit 3 keeps the sequential two-chunk loop of a single
     workgroup — same tolerances against the oracle."""
     test_train_vs_oracle("ant", N, T, B, 2, None, one_workgroup_per_network=True)
+
+
+@pytest.mark.parametrize("kind,N,T,B", [("hc", 64, 256, 64), ("ant", 64, 256, 128)])
+def test_sync_placement_tuning_leaves_no_trace(kind, N, T, B):
+    """the first train() times short updates at several positions of the exchange workspace (PPOLagrangian._tune_sync_placement)
+    and restores parameters, moments and the step counter: the update that follows is bit-identical to an untuned agent's, and
+    a position was chosen."""
+    od, ad = (18, 6) if kind == "hc" else (113, 8)
+    rng = np.random.RandomState(3)
+    obs = rng.randn(T, N, od).astype(np.float32)
+    buf = dict(observations=obs, actions=rng.randn(T, N, ad).astype(np.float32) * 0.5, log_probs=rng.randn(T, N).astype(np.float32) - 6,
+               reward_values=rng.randn(T, N).astype(np.float32), cost_values=rng.rand(T, N).astype(np.float32),
+               reward_advantages=rng.randn(T, N).astype(np.float32) * 2, cost_advantages=rng.rand(T, N).astype(np.float32),
+               reward_returns=rng.randn(T, N).astype(np.float32), cost_returns=rng.rand(T, N).astype(np.float32),
+               orig_costs=rng.rand(T, N).astype(np.float32))
+    perms = np.stack([np.random.RandomState(7 + e).permutation(N * T) for e in range(2)])
+    out = []
+    for tune in (True, False):
+        a = _agent(kind, N, T, batch_size=B, n_epochs=2, target_kl=None)
+        a.tune_sync_placement = tune
+        _fill(a, buf)
+        a.train(perms=perms)
+        out.append((a.policy.params.cpu().numpy().copy(), a.policy.exp_avg_sq.cpu().numpy().copy(), a.policy.adam_step,
+                    a._train_ws.get("sync_position")))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    assert out[0][3] in range(4) and out[1][3] is None
