@@ -46,6 +46,9 @@ def kernel_stats(tag, which="bench"):
         for r in rows[:24]:
             name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
             f.write(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
+        f.write("\nThe update kernel's calls include the 8 short launches (one epoch over 16 384 rows = 256 steps, ~2.3 ms each at HC) with which the first "
+                "`train()` of an agent finds the fastest position of its exchange workspace (`PPOLagrangian._tune_sync_placement`); the other calls are "
+                "the updates proper — their duration is `total - 8 x 2.3 ms` over `calls - 8` launches (HC: ~182 ms per 20 480 steps = 8.9 us per step).\n")
     print("wrote", dst + ".md")
 
 
