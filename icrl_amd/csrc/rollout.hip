@@ -989,7 +989,8 @@ __device__ __forceinline__ void grid_barrier(unsigned* flags, int N, int n, unsi
   __syncthreads();
 }
 
-constexpr int GRAN_MAX = 12;    // granules a thread polls per step in granule mode (N (2 obs + 4) <= 256 * GRAN_MAX)
+constexpr int GRAN_MAX = 12;    // 8-byte words of exchange area per thread in record mode (N (2 obs + 4) <= 256 * GRAN_MAX) ...
+constexpr int REC_MAX = GRAN_MAX / 2;   // ... = 16-byte records a thread polls per step
 
 // GRAN: every exchanged 32-bit half-word travels in its own 8-byte granule together with the step number (the datum is the
 // flag: cdna_hip_programming.md Guideline 16).  Consumers poll the granules themselves, so a step costs ONE trip through the
@@ -1031,7 +1032,16 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
   const int AS = buf.act_store;
   const int NA = a.pl.discrete ? 1 : A;       // noise values per env step
   const int NP = N + 64;                      // padded column length of the transposed observation block
-  const int G = 2 * O + 4;                    // granules per env and step: obs halves, reward halves, cost, done
+  const int G = 2 * O + 4;                    // 8-byte words per env and step of the exchange area
+  // Exchange records (GRAN): 16 bytes {tag, lo, hi, tag} — a float64 with this step's tag at both ends (a torn 16-byte access shows an
+  // old tag in one half).  Per env: obs_dim observation records, one reward record (the done flag in the top bit of its second tag), one
+  // cost record = R16 = obs_dim + 2 records = the same G x 8 bytes as one 8-byte {tag, word} granule per 32-bit word, but HALF the
+  // memory instructions: 64 workgroups x 2560 granule loads per step ran into the chip's rate of uncached loads (~62 G/s).
+  const int R16 = O + 2;
+  typedef unsigned int rec_u4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xg_all, 0, 2 * N * G * 8, 0x00020000);
+  auto rstore = [&](int byte_off, rec_u4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, xrs, byte_off, 0, 16); };     // sc1
+  auto rload = [&](int byte_off) -> rec_u4 { return __builtin_amdgcn_raw_buffer_load_b128(xrs, byte_off, 0, 16); };
   for (int i = tid; i < O * NP; i += 256) chunk[i] = 0.0;
   const bool has_cost = a.has_cn != 0;
   const uint32_t e_key = a.env.key[n];
@@ -1075,17 +1085,16 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
       env_step_wave(env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
       float* nob = buf.new_orig_observations + tn * O;
       if (GRAN) {
-        unsigned long long* xg = xg_all + ((size_t)par * N + n) * G;
+        const int rec0 = ((par * N + n) * R16) * 16;       // byte offset of this env's records of this parity
         for (int i = lane; i < O; i += WAVE) {
           const double v = sh.s_new[i];
           nob[i] = (float)v;
           const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-          gstore(xg + 2 * i, gtag, (unsigned)bits); gstore(xg + 2 * i + 1, gtag, (unsigned)(bits >> 32));
+          rstore(rec0 + 16 * i, rec_u4{gtag, (unsigned)bits, (unsigned)(bits >> 32), gtag});
         }
-        if (lane == 0) {
+        if (lane == 0) {       // reward record: the done flag rides in the top bit of its second tag
           const unsigned long long bits = (unsigned long long)__double_as_longlong(rew);
-          gstore(xg + 2 * O, gtag, (unsigned)bits); gstore(xg + 2 * O + 1, gtag, (unsigned)(bits >> 32));
-          gstore(xg + 2 * O + 3, gtag, (unsigned)done);
+          rstore(rec0 + 16 * O, rec_u4{gtag, (unsigned)bits, (unsigned)(bits >> 32), gtag | (done ? 0x80000000u : 0u)});
         }
       } else {
         double* xo = as_global(p.xch_obs) + ((size_t)par * N + n) * O;
@@ -1096,7 +1105,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
       float cost = 0.f;
       if (a.has_cn) cost = cost_forward_wave<CIT>(cnet, a.cl, C, sh.s_old, sh.act_clip, sh.cx, sh.ch);
       if (lane == 0) {
-        if (GRAN) gstore(xg_all + ((size_t)par * N + n) * G + 2 * O + 2, gtag, __float_as_uint(cost));
+        if (GRAN) rstore(((par * N + n) * R16 + O + 1) * 16, rec_u4{gtag, __float_as_uint(cost), 0u, gtag});
         else xstore(as_global(p.xch_cost) + par * N + n, cost);
         buf.orig_costs[tn] = cost;
       }
@@ -1118,36 +1127,34 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
     if (p.prof) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }
     if (p.prof && t == T / 2 && lane == 0) g_wide_trace[4 * n + w] = __builtin_amdgcn_s_memrealtime();   // per wave: end of its phase-A part
     if (GRAN) {
-      // poll this thread's granules of ALL envs until every one carries this step's tag, then scatter the payload words
-      const unsigned long long* xg = xg_all + (size_t)par * N * G;
-      const int total = N * G;
-      unsigned long long g[GRAN_MAX];
+      // poll this thread's records of ALL envs until every one carries this step's tag at both ends, then scatter the payloads
+      const int rbase = par * N * R16 * 16;
+      const int total = N * R16;
+      rec_u4 g[REC_MAX];
 #pragma unroll
-      for (int k = 0; k < GRAN_MAX; ++k) g[k] = (k * 256 + tid < total) ? gload(xg + k * 256 + tid) : ((unsigned long long)gtag << 32);
+      for (int k = 0; k < REC_MAX; ++k) g[k] = (k * 256 + tid < total) ? rload(rbase + (k * 256 + tid) * 16) : rec_u4{gtag, 0u, 0u, gtag};
       bool ok = false;
       int rounds = 0;
       for (int spins = 0; spins < spin_limit && !ok; ++spins) {
         ok = true;
 #pragma unroll
-        for (int k = 0; k < GRAN_MAX; ++k)
-          if ((unsigned)(g[k] >> 32) != gtag) { g[k] = gload(xg + k * 256 + tid); ok = false; }
+        for (int k = 0; k < REC_MAX; ++k)
+          if (g[k][0] != gtag || (g[k][3] & 0x7fffffffu) != gtag) { g[k] = rload(rbase + (k * 256 + tid) * 16); ok = false; }
         ++rounds;
       }
       if (p.prof && tid == 0) { pc_rounds += (unsigned long long)rounds; }
       if (!ok) spin_limit = 1;      // a peer never showed up (a workgroup was not resident): stop waiting ~2 s per step; reported below
-      unsigned* cw = reinterpret_cast<unsigned*>(chunk);
 #pragma unroll
-      for (int k = 0; k < GRAN_MAX; ++k) {
+      for (int k = 0; k < REC_MAX; ++k) {
         const int idx = k * 256 + tid;
         if (idx < total) {
           unsigned rr = __umulhi((unsigned)idx, p.g_magic);
-          int slot = idx - (int)rr * G;
-          if (slot >= G) { slot -= G; ++rr; }
-          const unsigned pay = (unsigned)g[k];
-          if (slot < 2 * O) cw[2 * ((slot >> 1) * NP + (int)rr) + (slot & 1)] = pay;
-          else if (slot < 2 * O + 2) reinterpret_cast<unsigned*>(rawr_s)[2 * rr + (slot - 2 * O)] = pay;
-          else if (slot == 2 * O + 2) rawc_s[rr] = has_cost ? __uint_as_float(pay) : 0.f;
-          else done_s[rr] = (int)pay;
+          int slot = idx - (int)rr * R16;
+          if (slot >= R16) { slot -= R16; ++rr; }
+          const double v = __longlong_as_double((long long)(((unsigned long long)g[k][2] << 32) | (unsigned long long)g[k][1]));
+          if (slot < O) chunk[slot * NP + (int)rr] = v;
+          else if (slot == O) { rawr_s[rr] = v; done_s[rr] = (int)(g[k][3] >> 31); }
+          else rawc_s[rr] = has_cost ? __uint_as_float(g[k][1]) : 0.f;
         }
       }
       __syncthreads();
@@ -3052,7 +3059,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
       p.xch_done = reinterpret_cast<unsigned*>(base); base += ((size_t)8 * N + 255) / 256 * 256;
       p.counter = reinterpret_cast<unsigned*>(base); base += 512;
       p.xg = reinterpret_cast<unsigned long long*>(base);
-      p.g_magic = (unsigned)((1ull << 32) / (unsigned long long)G);
+      p.g_magic = (unsigned)((1ull << 32) / (unsigned long long)(G / 2));      // index split by the records per env (obs + 2)
       hipError_t e = hipMemsetAsync(p.counter, 0, 512 + (gran ? (size_t)16 * N * G : 0), s);
       if (e != hipSuccess) return (int)e;
       const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
@@ -3195,7 +3202,7 @@ extern "C" int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* 
     p.xch_done = reinterpret_cast<unsigned*>(base); base += ((size_t)8 * N + 255) / 256 * 256;
     p.counter = reinterpret_cast<unsigned*>(base); base += 512;
     p.xg = reinterpret_cast<unsigned long long*>(base);
-    p.g_magic = (unsigned)((1ull << 32) / (unsigned long long)G);
+    p.g_magic = (unsigned)((1ull << 32) / (unsigned long long)(G / 2));      // records per env
     hipError_t e = hipMemsetAsync(p.counter, 0, 512 + (gran ? (size_t)16 * N * G : 0), s);
     if (e != hipSuccess) return (int)e;
     const int pe = put_args(p, d_args + r, s);
