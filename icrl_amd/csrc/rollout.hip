@@ -1324,6 +1324,15 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
   const int AS = a.buf.act_store;
   const int NA = a.pl.discrete ? 1 : A;
   const int GX = 2 * O + 4, GS = 4 * O + 4;
+  // Exchange records: 16 bytes {tag, lo, hi, tag} instead of two 8-byte {tag, word} granules per float64 (same bytes, half the memory
+  // instructions; the done flag rides in the top bit of the reward record's second tag).  Per env R16 = obs + 2 records (obs columns,
+  // reward, cost); statistics: (mean, var) per column, then the ret / cost denominators.
+  const int R16 = O + 2;
+  typedef unsigned int rec_u4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(p.xg, 0, 2 * N * GX * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(p.sg, 0, 2 * GS * 8, 0x00020000);
+  auto rstore = [](const __amdgpu_buffer_rsrc_t& rs, int byte_off, rec_u4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16); };   // sc1
+  auto rload = [](const __amdgpu_buffer_rsrc_t& rs, int byte_off) -> rec_u4 { return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16); };
   const int E = (N - g + G - 1) / G;                 // envs of this workgroup (>= 1: G <= N)
   const bool has_cost = a.has_cn != 0;
   const bool has_box = a.alow != nullptr && a.ahigh != nullptr;
@@ -1371,7 +1380,7 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
       const size_t tn = (size_t)t * N + n;
       policy_forward_block<OCT>(a.pl, R, sh[e], noise_s[par][e], 0, has_box ? alow_s : nullptr, has_box ? ahigh_s : nullptr);
       __syncthreads();
-      unsigned long long* xg = p.xg + ((size_t)par * N + n) * GX;
+      const int xrec = (par * N + n) * R16 * 16;      // byte offset of the env's records of this parity
       if (w == 0) {
         double rew; int done;
         uint32_t e_ctr = ctr_s[e];
@@ -1382,19 +1391,18 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
           const double v = sh[e].s_new[i];
           nob[i] = (float)v;
           const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-          gstore(xg + 2 * i, gtag, (unsigned)bits); gstore(xg + 2 * i + 1, gtag, (unsigned)(bits >> 32));
+          rstore(xrs, xrec + 16 * i, rec_u4{gtag, (unsigned)bits, (unsigned)(bits >> 32), gtag});
         }
         if (lane == 0) {
           const unsigned long long bits = (unsigned long long)__double_as_longlong(rew);
-          gstore(xg + 2 * O, gtag, (unsigned)bits); gstore(xg + 2 * O + 1, gtag, (unsigned)(bits >> 32));
-          gstore(xg + 2 * O + 3, gtag, (unsigned)done);
+          rstore(xrs, xrec + 16 * O, rec_u4{gtag, (unsigned)bits, (unsigned)(bits >> 32), gtag | (done ? 0x80000000u : 0u)});
           ctr_s[e] = e_ctr; tep_s[e] = e_tep; rew_s[e] = rew; done_s[e] = done;
         }
       } else if (w == 3) {
         float cost = 0.f;
         if (a.has_cn) cost = cost_forward_wave<CIT>(a.cn, a.cl, C, sh[e].s_old, sh[e].act_clip, sh[e].cx, sh[e].ch);
         if (lane == 0) {
-          gstore(xg + 2 * O + 2, gtag, __float_as_uint(cost));
+          rstore(xrs, xrec + 16 * (O + 1), rec_u4{gtag, __float_as_uint(cost), 0u, gtag});
           a.buf.orig_costs[tn] = cost;
           cost_s[e] = cost;
         }
@@ -1419,30 +1427,26 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
     if (trace && w == 0) g_wide_trace[4 * g + 0] = __builtin_amdgcn_s_memrealtime();
     // ---------------- phase B1: the owners (wave 1) gather their statistic from all envs and publish it ----------------
     if (w == 1 && (own_col >= 0 || own_ret || own_cost)) {
-      const unsigned long long* xb = p.xg + (size_t)par * N * GX;
-      const int slot = own_col >= 0 ? 2 * own_col : (own_ret ? 2 * O : 2 * O + 2);
-      const bool wide = !own_cost;                                   // two granules (a float64) per env, or one (the float32 cost)
+      const int slot = own_col >= 0 ? own_col : (own_ret ? O : O + 1);      // the record of every env this owner gathers
+      const bool wide = !own_cost;                                   // a float64 in the record, or the float32 cost
+      const int gbase = par * N * R16 * 16;
       // four blocks of 64 envs per polling round: all their loads are in flight together (one trip through the memory system
       // per round instead of one per block)
       for (int i0 = 0; i0 < N; i0 += 4 * WAVE) {
-        unsigned long long g0[4], g1[4], g2[4];
+        rec_u4 g0[4], gd[4];          // gd: the reward record of the env — the cost owner takes the done flag from its tag
         bool ok[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { g0[k] = g1[k] = g2[k] = 0; ok[k] = i0 + k * WAVE + lane >= N; }
+        for (int k = 0; k < 4; ++k) { g0[k] = gd[k] = rec_u4{0u, 0u, 0u, 0u}; ok[k] = i0 + k * WAVE + lane >= N; }
         for (int spins = 0; spins < spin_limit; ++spins) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int i = i0 + k * WAVE + lane;
-            if (!ok[k]) {
-              g0[k] = gload(xb + (size_t)i * GX + slot);
-              g1[k] = wide ? gload(xb + (size_t)i * GX + slot + 1) : g0[k];
-              g2[k] = own_col >= 0 ? g0[k] : gload(xb + (size_t)i * GX + 2 * O + 3);      // done flag (return owners)
-            }
+            if (!ok[k]) { g0[k] = rload(xrs, gbase + (i * R16 + slot) * 16); gd[k] = own_cost ? rload(xrs, gbase + (i * R16 + O) * 16) : g0[k]; }
           }
           bool all = true;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            if (!ok[k]) ok[k] = (unsigned)(g0[k] >> 32) == gtag && (unsigned)(g1[k] >> 32) == gtag && (unsigned)(g2[k] >> 32) == gtag;
+            if (!ok[k]) ok[k] = g0[k][0] == gtag && (g0[k][3] & 0x7fffffffu) == gtag && gd[k][0] == gtag && (gd[k][3] & 0x7fffffffu) == gtag;
             all = all && ok[k];
           }
           if (__all(all)) break;
@@ -1453,13 +1457,13 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
           const int i = i0 + k * WAVE + lane;
           if (i < N) {
             double v;
-            if (wide) v = __longlong_as_double((long long)(((unsigned long long)(unsigned)g1[k] << 32) | (unsigned long long)(unsigned)g0[k]));
-            else v = (double)__uint_as_float((unsigned)g0[k]);
+            if (wide) v = __longlong_as_double((long long)(((unsigned long long)g0[k][2] << 32) | (unsigned long long)g0[k][1]));
+            else v = (double)__uint_as_float(g0[k][1]);
             if (own_col >= 0) colbuf[i] = v;
             else {
               const double ret = retbuf[i] * (own_ret ? nm.reward_gamma : nm.cost_gamma) + v;     // vec_normalize.py:102, 245
               colbuf[i] = ret;
-              done_all[i] = (int)(unsigned)g2[k];
+              done_all[i] = (int)(gd[k][3] >> 31);
             }
           }
         }
@@ -1480,16 +1484,15 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
       }
       chan_merge(o_mean, o_var, o_cnt, bm, bv, (double)N);
       o_cnt = (double)N + o_cnt;
-      unsigned long long* sb = p.sg + (size_t)par * GS;
+      const int sbase = par * (GS / 2) * 16;          // statistics records of this parity: (mean, var) per column, then the two denominators
       if (lane == 0) {
         if (own_col >= 0) {
           const unsigned long long mb = (unsigned long long)__double_as_longlong(o_mean), vb = (unsigned long long)__double_as_longlong(o_var);
-          gstore(sb + 4 * own_col, gtag, (unsigned)mb); gstore(sb + 4 * own_col + 1, gtag, (unsigned)(mb >> 32));
-          gstore(sb + 4 * own_col + 2, gtag, (unsigned)vb); gstore(sb + 4 * own_col + 3, gtag, (unsigned)(vb >> 32));
+          rstore(srs, sbase + 32 * own_col, rec_u4{gtag, (unsigned)mb, (unsigned)(mb >> 32), gtag});
+          rstore(srs, sbase + 32 * own_col + 16, rec_u4{gtag, (unsigned)vb, (unsigned)(vb >> 32), gtag});
         } else {
           const unsigned long long db = (unsigned long long)__double_as_longlong(sqrt(o_var + nm.epsilon));
-          const int k = 4 * O + (own_ret ? 0 : 2);
-          gstore(sb + k, gtag, (unsigned)db); gstore(sb + k + 1, gtag, (unsigned)(db >> 32));
+          rstore(srs, sbase + (2 * O + (own_ret ? 0 : 1)) * 16, rec_u4{gtag, (unsigned)db, (unsigned)(db >> 32), gtag});
         }
       }
       if (own_col < 0)      // returns of finished episodes restart at 0 (vec_normalize.py:99, 241)
@@ -1499,25 +1502,22 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
     }
     // ---------------- phase B2: everybody reads the statistics granules, then normalises its own envs ----------------
     {
-      const unsigned long long* sb = p.sg + (size_t)par * GS;
-      const int total = has_cost ? GS : GS - 2;
-      unsigned* ms = reinterpret_cast<unsigned*>(mean_s);
-      unsigned* vs = reinterpret_cast<unsigned*>(var_s);
-      unsigned* ds = reinterpret_cast<unsigned*>(dens_s);
+      const int sbase = par * (GS / 2) * 16;
+      const int total = has_cost ? GS / 2 : GS / 2 - 1;              // records: (mean, var) per column, ret denominator, cost denominator
       for (int i0 = 0; i0 < total; i0 += 256) {
         const int i = i0 + tid;
-        unsigned long long gv = (unsigned long long)gtag << 32;
+        rec_u4 gv = rec_u4{gtag, 0u, 0u, gtag};
         bool ok = i >= total;
         for (int spins = 0; spins < spin_limit && !ok; ++spins) {
-          gv = gload(sb + i);
-          ok = (unsigned)(gv >> 32) == gtag;
+          gv = rload(srs, sbase + i * 16);
+          ok = gv[0] == gtag && gv[3] == gtag;
           if (!ok) __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) spin_limit = 1;
         if (i < total) {
-          const unsigned pay = (unsigned)gv;
-          if (i < 4 * O) { const int j = i >> 2, h = i & 3; if (h < 2) ms[2 * j + h] = pay; else vs[2 * j + (h - 2)] = pay; }
-          else ds[i - 4 * O] = pay;
+          const double v = __longlong_as_double((long long)(((unsigned long long)gv[2] << 32) | (unsigned long long)gv[1]));
+          if (i < 2 * O) { if (i & 1) var_s[i >> 1] = v; else mean_s[i >> 1] = v; }
+          else dens_s[i - 2 * O] = v;
         }
       }
     }
@@ -1810,6 +1810,15 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs, T = p.T;
   const int AS = buf.act_store;
   const int GX = 2 * O + 4, GS = 4 * O + 4;
+  // Exchange records: 16 bytes {tag, lo, hi, tag} instead of two 8-byte {tag, word} granules per float64 (same bytes, half the memory
+  // instructions; the done flag rides in the top bit of the reward record's second tag).  Per env R16 = obs + 2 records (obs columns,
+  // reward, cost); statistics: (mean, var) per column, then the ret / cost denominators.
+  const int R16 = O + 2;
+  typedef unsigned int rec_u4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xg_all, 0, 2 * N * GX * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(sg_all, 0, 2 * GS * 8, 0x00020000);
+  auto rstore = [](const __amdgpu_buffer_rsrc_t& rs, int byte_off, rec_u4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16); };   // sc1
+  auto rload = [](const __amdgpu_buffer_rsrc_t& rs, int byte_off) -> rec_u4 { return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16); };
   const int Eg = (N - g + G - 1) / G;                // envs of this workgroup (1 .. E)
   const bool has_cost = a.has_cn != 0;
   const bool has_box = a.alow != nullptr && a.ahigh != nullptr;
@@ -1985,7 +1994,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
         const int em = mine ? e : 3 * q;
         const int n = g + em * G;
         const size_t tn = (size_t)t * N + n;
-        unsigned long long* xg = xg_all + ((size_t)par * N + n) * GX;
+        const int xrec = (par * N + n) * R16 * 16;      // byte offset of the env's records of this parity
         if (mine) {       // rows that depend on the pre-step state only
           if (ci < O) { buf.observations[tn * O + ci] = sh.x[em][ci]; buf.orig_observations[tn * O + ci] = (float)sh.s_old[em][ci]; }
           if (ci < AS) buf.actions[tn * AS + ci] = sh.act_raw[em][ci];
@@ -2008,12 +2017,11 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
             const double v = sh.s_new[em][ci];
             buf.new_orig_observations[tn * O + ci] = (float)v;
             const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-            gstore(xg + 2 * ci, gtag, (unsigned)bits); gstore(xg + 2 * ci + 1, gtag, (unsigned)(bits >> 32));
+            rstore(xrs, xrec + 16 * ci, rec_u4{gtag, (unsigned)bits, (unsigned)(bits >> 32), gtag});
           }
           if (ci == 0) {
             const unsigned long long bits = (unsigned long long)__double_as_longlong(sh.rew[em]);
-            gstore(xg + 2 * O, gtag, (unsigned)bits); gstore(xg + 2 * O + 1, gtag, (unsigned)(bits >> 32));
-            gstore(xg + 2 * O + 3, gtag, (unsigned)sh.done[em]);
+            rstore(xrs, xrec + 16 * O, rec_u4{gtag, (unsigned)bits, (unsigned)(bits >> 32), gtag | (sh.done[em] ? 0x80000000u : 0u)});
           }
         }
       }
@@ -2021,7 +2029,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       for (int e = w; e < Eg; e += 3) {
         const int n = g + e * G;
         const size_t tn = (size_t)t * N + n;
-        unsigned long long* xg = xg_all + ((size_t)par * N + n) * GX;
+        const int xrec = (par * N + n) * R16 * 16;      // byte offset of the env's records of this parity
         // rows that depend on the pre-step state only
         float* ob = buf.observations + tn * O;
         float* oob = buf.orig_observations + tn * O;
@@ -2045,12 +2053,11 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
           const double v = sh.s_new[e][i];
           nob[i] = (float)v;
           const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-          gstore(xg + 2 * i, gtag, (unsigned)bits); gstore(xg + 2 * i + 1, gtag, (unsigned)(bits >> 32));
+          rstore(xrs, xrec + 16 * i, rec_u4{gtag, (unsigned)bits, (unsigned)(bits >> 32), gtag});
         }
         if (lane == 0) {
           const unsigned long long bits = (unsigned long long)__double_as_longlong(rew);
-          gstore(xg + 2 * O, gtag, (unsigned)bits); gstore(xg + 2 * O + 1, gtag, (unsigned)(bits >> 32));
-          gstore(xg + 2 * O + 3, gtag, (unsigned)done);
+          rstore(xrs, xrec + 16 * O, rec_u4{gtag, (unsigned)bits, (unsigned)(bits >> 32), gtag | (done ? 0x80000000u : 0u)});
           sh.ctr[e] = e_ctr; sh.tep[e] = e_tep; sh.rew[e] = rew; sh.done[e] = done;
         }
       }
@@ -2152,14 +2159,14 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       const float cost = 1.f - zeta;
       if (q4 == 0 && r16 < Eg) {
         const int n = g + r16 * G;
-        gstore(xg_all + ((size_t)par * N + n) * GX + 2 * O + 2, gtag, __float_as_uint(cost));
+        rstore(xrs, ((par * N + n) * R16 + O + 1) * 16, rec_u4{gtag, __float_as_uint(cost), 0u, gtag});
         buf.orig_costs[(size_t)t * N + n] = cost;
         sh.cost[r16] = cost;
       }
     } else {
       if (lane < Eg) {
         const int n = g + lane * G;
-        gstore(xg_all + ((size_t)par * N + n) * GX + 2 * O + 2, gtag, __float_as_uint(0.f));
+        rstore(xrs, ((par * N + n) * R16 + O + 1) * 16, rec_u4{gtag, __float_as_uint(0.f), 0u, gtag});
         buf.orig_costs[(size_t)t * N + n] = 0.f;
         sh.cost[lane] = 0.f;
       }
@@ -2167,14 +2174,14 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
     if (prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }     // env steps / cost net + rows (this wave's part)
     // ---------------- phase B1: owner waves gather their statistic from all envs and publish it ----------------
     if (own_col >= 0 || own_ret || own_cost) {
-      const unsigned long long* xb = xg_all + (size_t)par * N * GX;
-      const int slot = own_col >= 0 ? 2 * own_col : (own_ret ? 2 * O : 2 * O + 2);
-      const bool wide = !own_cost;                                   // two granules (a float64) per env, or one (the float32 cost)
+      const int slot = own_col >= 0 ? own_col : (own_ret ? O : O + 1);      // the record of every env this owner gathers
+      const bool wide = !own_cost;                                   // a float64 in the record, or the float32 cost
+      const int gbase = par * N * R16 * 16;
       for (int i0 = 0; i0 < N; i0 += 4 * WAVE) {
-        unsigned long long g0[4], g1[4], g2[4];
+        rec_u4 g0[4], gd[4];          // gd: the reward record of the env — the cost owner takes the done flag from its tag
         bool ok[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { g0[k] = g1[k] = g2[k] = 0; ok[k] = i0 + k * WAVE + lane >= N; }
+        for (int k = 0; k < 4; ++k) { g0[k] = gd[k] = rec_u4{0u, 0u, 0u, 0u}; ok[k] = i0 + k * WAVE + lane >= N; }
         double rprev[4] = {0.0, 0.0, 0.0, 0.0};      // previous discounted returns (return owners): in flight while the granules are polled
         if (own_col < 0) {
 #pragma unroll
@@ -2184,16 +2191,12 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int i = i0 + k * WAVE + lane;
-            if (!ok[k]) {
-              g0[k] = gload(xb + (size_t)i * GX + slot);
-              g1[k] = wide ? gload(xb + (size_t)i * GX + slot + 1) : g0[k];
-              g2[k] = own_col >= 0 ? g0[k] : gload(xb + (size_t)i * GX + 2 * O + 3);      // done flag (return owners)
-            }
+            if (!ok[k]) { g0[k] = rload(xrs, gbase + (i * R16 + slot) * 16); gd[k] = own_cost ? rload(xrs, gbase + (i * R16 + O) * 16) : g0[k]; }
           }
           bool all = true;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            if (!ok[k]) ok[k] = (unsigned)(g0[k] >> 32) == gtag && (unsigned)(g1[k] >> 32) == gtag && (unsigned)(g2[k] >> 32) == gtag;
+            if (!ok[k]) ok[k] = g0[k][0] == gtag && (g0[k][3] & 0x7fffffffu) == gtag && gd[k][0] == gtag && (gd[k][3] & 0x7fffffffu) == gtag;
             all = all && ok[k];
           }
           if (__all(all)) break;
@@ -2205,12 +2208,12 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
           const int i = i0 + k * WAVE + lane;
           if (i < N) {
             double v;
-            if (wide) v = __longlong_as_double((long long)(((unsigned long long)(unsigned)g1[k] << 32) | (unsigned long long)(unsigned)g0[k]));
-            else v = (double)__uint_as_float((unsigned)g0[k]);
+            if (wide) v = __longlong_as_double((long long)(((unsigned long long)g0[k][2] << 32) | (unsigned long long)g0[k][1]));
+            else v = (double)__uint_as_float(g0[k][1]);
             if (own_col >= 0) colbuf[i] = v;
             else {
               colbuf[i] = rprev[k] * (own_ret ? nm.reward_gamma : nm.cost_gamma) + v;      // vec_normalize.py:102, 245
-              done_all[i] = (unsigned char)(unsigned)g2[k];
+              done_all[i] = (unsigned char)(gd[k][3] >> 31);
             }
           }
         }
@@ -2230,41 +2233,37 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
       }
       chan_merge(o_mean, o_var, o_cnt, bm, bv, (double)N);
       o_cnt = (double)N + o_cnt;
-      unsigned long long* sb = sg_all + (size_t)par * GS;
+      const int sbase = par * (GS / 2) * 16;          // statistics records of this parity: (mean, var) per column, then the two denominators
       if (lane == 0) {
         if (own_col >= 0) {
           const unsigned long long mb = (unsigned long long)__double_as_longlong(o_mean), vb = (unsigned long long)__double_as_longlong(o_var);
-          gstore(sb + 4 * own_col, gtag, (unsigned)mb); gstore(sb + 4 * own_col + 1, gtag, (unsigned)(mb >> 32));
-          gstore(sb + 4 * own_col + 2, gtag, (unsigned)vb); gstore(sb + 4 * own_col + 3, gtag, (unsigned)(vb >> 32));
+          rstore(srs, sbase + 32 * own_col, rec_u4{gtag, (unsigned)mb, (unsigned)(mb >> 32), gtag});
+          rstore(srs, sbase + 32 * own_col + 16, rec_u4{gtag, (unsigned)vb, (unsigned)(vb >> 32), gtag});
         } else {
           const unsigned long long db = (unsigned long long)__double_as_longlong(sqrt(o_var + nm.epsilon));
-          const int k = 4 * O + (own_ret ? 0 : 2);
-          gstore(sb + k, gtag, (unsigned)db); gstore(sb + k + 1, gtag, (unsigned)(db >> 32));
+          rstore(srs, sbase + (2 * O + (own_ret ? 0 : 1)) * 16, rec_u4{gtag, (unsigned)db, (unsigned)(db >> 32), gtag});
         }
       }
     }
     if (prof) { const unsigned long long tn_ = prof_now(); pc2 += tn_ - tl; tl = tn_; }     // owner: gather + moments + publish
     // ---------------- phase B2: everybody reads the statistics granules, then normalises its envs ----------------
     {
-      const unsigned long long* sb = sg_all + (size_t)par * GS;
-      const int total = has_cost ? GS : GS - 2;
-      unsigned* ms = reinterpret_cast<unsigned*>(sh.mean);
-      unsigned* vs = reinterpret_cast<unsigned*>(sh.var);
-      unsigned* ds = reinterpret_cast<unsigned*>(sh.dens);
+      const int sbase = par * (GS / 2) * 16;
+      const int total = has_cost ? GS / 2 : GS / 2 - 1;              // records: (mean, var) per column, ret denominator, cost denominator
       for (int i0 = 0; i0 < total; i0 += 256) {
         const int i = i0 + tid;
-        unsigned long long gv = (unsigned long long)gtag << 32;
+        rec_u4 gv = rec_u4{gtag, 0u, 0u, gtag};
         bool ok = i >= total;
         for (int spins = 0; spins < spin_limit && !ok; ++spins) {
-          gv = gload(sb + i);
-          ok = (unsigned)(gv >> 32) == gtag;
+          gv = rload(srs, sbase + i * 16);
+          ok = gv[0] == gtag && gv[3] == gtag;
           if (!ok) __builtin_amdgcn_s_sleep(1);
         }
         if (!ok) spin_limit = 1;
         if (i < total) {
-          const unsigned pay = (unsigned)gv;
-          if (i < 4 * O) { const int j = i >> 2, h = i & 3; if (h < 2) ms[2 * j + h] = pay; else vs[2 * j + (h - 2)] = pay; }
-          else ds[i - 4 * O] = pay;
+          const double v = __longlong_as_double((long long)(((unsigned long long)gv[2] << 32) | (unsigned long long)gv[1]));
+          if (i < 2 * O) { if (i & 1) sh.var[i >> 1] = v; else sh.mean[i >> 1] = v; }
+          else sh.dens[i - 2 * O] = v;
         }
       }
     }
