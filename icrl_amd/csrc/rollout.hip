@@ -992,9 +992,11 @@ __device__ __forceinline__ void grid_barrier(unsigned* flags, int N, int n, unsi
 constexpr int GRAN_MAX = 12;    // 8-byte words of exchange area per thread in record mode (N (2 obs + 4) <= 256 * GRAN_MAX) ...
 constexpr int REC_MAX = GRAN_MAX / 2;   // ... = 16-byte records a thread polls per step
 
-// GRAN: every exchanged 32-bit half-word travels in its own 8-byte granule together with the step number (the datum is the
-// flag: cdna_hip_programming.md Guideline 16).  Consumers poll the granules themselves, so a step costs ONE trip through the
-// memory system after the slowest producer instead of three (drain stores -> raise flag -> see flag -> fetch data).
+// GRAN: every exchanged float64 travels in its own 16-byte record with the step number at both ends (the datum is the flag:
+// cdna_hip_programming.md Guideline 16; a torn access shows an old tag in one half).  Consumers poll the records themselves, so a
+// step costs ONE trip through the memory system after the slowest producer instead of three (drain stores -> raise flag -> see
+// flag -> fetch data).  (Until the end of round 3: one 8-byte {tag, 32 bits} granule per half-word — twice the memory
+// instructions, and the all-to-all read of 64 workgroups ran into the chip's rate of uncached loads.)
 // dynamic LDS of the persistent rollout: the transposed observation block [obs][N + 64] and the dynamics matrix [obs][act], sized
 // for the launch's shapes (HC x 64: 19 KB instead of the 114 KB of the largest admissible shape, so that several workgroups —
 // several runs of a batched launch — share a CU)
@@ -1579,15 +1581,15 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
 // persistent rollout with SEVERAL environments per workgroup, evaluated INTERLEAVED (throughput form)
 // =================================================================================================================
 // Same contract and bit-identical results as rollout_persistent_kernel / rollout_wide_kernel (every per-env operation is the
-// same instruction sequence: k-ascending fmaf chains with the weights of `lane` in registers, the same tanh, the same float64
-// env step, numpy-ordered statistics), different use of the machine.  Those kernels give one environment a workgroup (or walk
-// a workgroup's environments one after the other): an env step is then a 7-8 k cycle chain of dependent latencies.  Here workgroup
-// g of a run serves E environments g, g + G, ... and runs every layer for all of them at once: the lane that owns hidden unit j
-// keeps ONE weight in a register per input and feeds it to E independent accumulator chains, the inputs come from LDS as
-// broadcast reads.  E environments cost little more than one, so a run needs G = N / E workgroups instead of N, all runs of a
+// same arithmetic: the k-ascending fmaf chains of the other kernels, evaluated here as fp32 MFMA tiles — TileRegs below —, the same
+// tanh, the same float64 env step, numpy-ordered statistics), different use of the machine.  Those kernels give one environment a
+// workgroup (or walk a workgroup's environments one after the other): an env step is then a 7-8 k cycle chain of dependent
+// latencies.  Here workgroup g of a run serves E environments g, g + G, ... and runs every layer for all of them at once (16 units
+// x 16 envs per MFMA, the weights register-resident as A operands, the activations read from LDS as B operands).  E environments
+// cost little more than one, so a run needs G = N / E workgroups instead of N, all runs of a
 // batched launch (icrl_rollout_collect_batch, run = blockIdx.y) are resident together, and the exchange shrinks with G:
 //   phase A   layers 1, 2, heads for E envs (waves pi | vf | cvf); env steps spread over waves 0..2, cost net on wave 3;
-//             raw obs / reward / cost / done published as self-validating granules (as in the other two kernels)
+//             raw obs / reward / cost / done published as self-validating 16-byte records (as in the other two kernels)
 //   phase B1  statistic s (observation column, ret_rms, cost_rms) is owned by wave s / G of workgroup s % G: up to four
 //             owners per workgroup work side by side (gather 2 N granules, numpy-ordered moments, merge, publish)
 //   phase B2  every workgroup reads the 4 obs + 4 statistics granules and normalises its E envs
