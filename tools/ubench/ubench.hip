@@ -491,6 +491,15 @@ int main() {
     }
     printf("mfma 16x16x4 f32 chain vs sequential fmaf chain (K = 64): %d of %d outputs differ bitwise (worst |d| %.3e)\n", total, trials * 256, worst);
   }
+  { // does the clock hold when every SIMD of every CU issues fp32 MFMAs for tens of milliseconds? (wall time of the same chain)
+    unsigned long long* xo2; CK(hipMalloc(&xo2, 1024 * 4 * 4 * 8));
+    for (int blocks : {3, 96, 192, 256}) {
+      hipLaunchKernelGGL(k_xcd_speed, dim3(blocks), dim3(256), 0, 0, xo2, 200000);
+      std::vector<unsigned long long> hx(4 * blocks); hipDeviceSynchronize(); hipMemcpy(hx.data(), xo2, hx.size() * 8, hipMemcpyDeviceToHost);
+      double mx = 0, mn = 1e30; for (int b = 0; b < blocks; ++b) { const double us = hx[4 * b + 1] / 100.0; mx = us > mx ? us : mx; mn = us < mn ? us : mn; }
+      printf("3.2 M dependent MFMAs per wave, %3d workgroups x 4 waves (one per SIMD): wall %.0f .. %.0f us per workgroup (102.4 M shader cycles = %.0f us at 2.4 GHz)\n", blocks, mn, mx, 102.4e6 / 2400.0);
+    }
+  }
   { // do the XCDs run at the same speed?
     unsigned long long* xo; CK(hipMalloc(&xo, 64 * 4 * 8));
     for (int rep = 0; rep < 3; ++rep) {
