@@ -142,6 +142,15 @@ class SeedBatch:
         ws, nbytes = self._ws()
         _lib.check(_lib.lib().icrl_cn_train_batch(len(jobs), arr, ws, nbytes, _lib.current_stream()), "icrl_cn_train_batch")
 
+    def _prefetch_permutations(self, agents):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        self._side.wait_stream(torch.cuda.current_stream())        # (the generator's device state is ordered with earlier draws)
+        for a in agents:
+            s_ = a.streams
+            if s_ is not None and hasattr(s_, "prefetch_permutations"):
+                s_.prefetch_permutations(a.n_epochs, a.rollout_buffer.buffer_size * a.rollout_buffer.n_envs, self._side)
+
     # ---- phases ----------------------------------------------------------------------------------------------------------------
     def _learn(self, total_timesteps):
         """PPOLagrangian.learn(total_timesteps, cost_function="cost") of every run (ref: on_policy_algorithm.py:430-492), rollouts
@@ -171,6 +180,12 @@ class SeedBatch:
                     logger.record("time/total_timesteps", a.num_timesteps)
                     tjobs.append(a._train_begin(None))
             self._launch_trains(agents, tjobs)
+            # while the updates run (3 S CUs busy, the host idle): the permutations of the NEXT update, on a side stream — their sorts
+            # were ~5 ms of device time + ~7 ms of launches per update phase at S = 32, in front of the update launch.  Not across the end
+            # of the forward step when the constraint net draws minibatch permutations from the same generator in between.
+            more = agents[0].num_timesteps < totals[0]
+            if more or sts[0]["constraint_net"].batch_size is None:
+                self._prefetch_permutations(agents)
             host = self._to_host([a.train_readback() for a in agents])          # waits for the update of every run
             for st, a, j, h in zip(sts, agents, tjobs, host):
                 with _as_run(st):

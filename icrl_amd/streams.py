@@ -38,8 +38,29 @@ class PrivateStreams:
         """all epochs' permutations of one train() call in ONE batched draw: [n_epochs, n] = the sort order of n_epochs x n float64
         uniforms (no ties in practice: 2^53 values).  torch.randperm per epoch is a sort per call — with dozens of runs in a batch
         the draws of one update phase were 20+ ms of device time between the rollout and the update launch."""
+        pre = getattr(self, "_prefetched", None)
+        if pre is not None:
+            self._prefetched = None
+            if pre[0] == (n_epochs, n):             # drawn ahead on a side stream (prefetch_permutations): the same draw, earlier
+                torch.cuda.current_stream().wait_event(pre[2])
+                pre[1].record_stream(torch.cuda.current_stream())
+                return pre[1]
+            raise RuntimeError("PrivateStreams: permutations were prefetched for another shape")      # (would desynchronise the stream)
         keys = torch.rand(n_epochs, n, dtype=torch.float64, device=self.device, generator=self.perm_gen)
         return torch.argsort(keys, dim=1).to(torch.int32)
+
+    def prefetch_permutations(self, n_epochs, n, stream):
+        """draw the NEXT permutations() call's result now, on `stream` — e.g. while an update occupies 3 CUs and the host waits for
+        it.  The draw consumes the permutation generator exactly as the later call would have (nothing else may draw from it in
+        between: the caller's business), so the values are the same; only when the sorts run changes."""
+        if getattr(self, "_prefetched", None) is not None:
+            return
+        with torch.cuda.stream(stream):
+            keys = torch.rand(n_epochs, n, dtype=torch.float64, device=self.device, generator=self.perm_gen)
+            perms = torch.argsort(keys, dim=1).to(torch.int32)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self._prefetched = ((n_epochs, n), perms, ev)
 
     def consumed(self, executed_epochs):
         pass
@@ -47,6 +68,7 @@ class PrivateStreams:
     def cn_permutations(self, iterations, size):
         """the np.random.permutation draws of ConstraintNet.get() in minibatch mode (`--cn_batch_size`, constraint_net.py:300-316):
         [iterations, size] from this run's own generator (the process-wide numpy generator would interleave the runs' draws)."""
+        assert getattr(self, "_prefetched", None) is None, "update permutations were drawn ahead across a constraint-net draw"
         return torch.stack([torch.randperm(size, device=self.device, generator=self.perm_gen) for _ in range(max(int(iterations), 1))])
 
     def sample_noise(self, rows, A):
