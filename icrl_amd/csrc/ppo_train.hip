@@ -957,7 +957,9 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   PlanChunk* chunks = reinterpret_cast<PlanChunk*>(steps + n_steps + 2);
   a.plan_steps = steps; a.plan_chunks = chunks; a.n_steps = (int)n_steps;
   {
-    int* offs = reinterpret_cast<int*>((char*)sync_ws + 768 + 32 * (size_t)n_steps);       // after the plan tables
+    // after the plan tables: 16 B per step (+2 entries) and 8 B per chunk (<= 4 chunks per step at batch_size 256, +10 entries):
+    // 512 + 16 (n + 2) + 8 (4 n + 10) <= 768 + 48 n  (ICRL_PPO_PLAN_BYTES)
+    int* offs = reinterpret_cast<int*>((char*)sync_ws + ICRL_PPO_PLAN_BYTES(n_steps));
     const long long n = (long long)hp->n_epochs * n_total;
     hipLaunchKernelGGL(ppo_perm_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perms, n, buf->T, buf->N, offs);
     a.perms = offs;
@@ -970,7 +972,7 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
                      n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks, (int)split);
   if (split) {
-    const size_t off = (768 + 32 * (size_t)n_steps + 4 * (size_t)hp->n_epochs * n_total + 255) / 256 * 256;      // behind the permutation offsets
+    const size_t off = (ICRL_PPO_PLAN_BYTES(n_steps) + 4 * (size_t)hp->n_epochs * n_total + 255) / 256 * 256;      // behind the permutation offsets
     a.gx = reinterpret_cast<u64*>((char*)sync_ws + off);
     e = hipMemsetAsync(a.gx, 0, ICRL_PPO_SPLIT_BYTES, s);
     if (e != hipSuccess) return bad((int)e);

@@ -27,6 +27,17 @@
 // Built with -ffp-contract=off; FMA is used only where written (fmaf / MFMA).
 #include "ppo_common.h"
 
+// A/B switches (tools/build_variant.sh): the defaults are what ships
+#ifndef ICRL_EARLY_POLL
+#define ICRL_EARLY_POLL 0
+#endif
+#ifndef ICRL_STATIC_LDS
+#define ICRL_STATIC_LDS 1
+#endif
+#ifndef ICRL_BOOK_WAVE
+#define ICRL_BOOK_WAVE 7
+#endif
+
 namespace icrl {
 
 constexpr int TH8 = 512;   // 8 waves, two per SIMD (<= 256 registers each)
@@ -102,7 +113,14 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   constexpr int XR = (S::O16 + 7) / 8;  // floats of an X row each of the 8 threads of a row stages
   static_assert(NT1 % 2 == 0, "the two waves of a pair split the observation tiles");
   static_assert(!S::DZ1A, "wide observations (dz1^T sharing h2^T's storage) stay on the row-owning kernel");
+#if ICRL_STATIC_LDS
+  // a STATIC array: its address is the compile-time constant 0, so every image offset folds into an instruction's immediate or one
+  // literal move.  With `extern __shared__` the base is a symbol the optimiser cannot fold: it hoisted ~40 "base + offset" sums out of
+  // the step loop into scalar registers, spilled them to VGPR lanes and read them back (107 v_readlane + s_nop + v_mov per step)
+  __shared__ __attribute__((aligned(16))) float sm[S::TOTAL];
+#else
   extern __shared__ __attribute__((aligned(16))) float sm[];
+#endif
   const int role = blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -368,7 +386,10 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   auto pair_signal = [&]() { (void)pflag; (void)pphase; (void)partner; lds_barrier(); };
   auto pair_wait = [&]() {};
 #endif
-  const bool book = tid == 192;      // wave 3 lane 0 keeps the running statistics of the role
+  // lane 0 of wave ICRL_BOOK_WAVE keeps the running statistics of the role.  A HIGH wave (fh == 1): those have no head-weight
+  // gradient to form and reach the norm barrier ~1 k cycles before the low waves, which is about what the book-keeping costs
+  // (per-wave timers: on wave 3 it made that wave the last one at the barrier by ~750 cycles)
+  const bool book = tid == 64 * ICRL_BOOK_WAVE;
   // Its running sums live in LDS (MISC + 56..61) and are advanced with ds_add_f32, which needs no answer: as loop-carried registers of
   // one lane they were spilled to scratch at the 256-register limit (two scratch reloads + three stores per optimiser step on the
   // book-keeping wave; in-loop scratch instructions 12 -> 3; measured 8.91-8.93 against 8.94-8.95 us per step on the same box).  One
@@ -824,7 +845,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       float mean_kl = 0.f;
       const bool last_mb = (ps.nb_flags >> NB_LAST) & 1;
       const int epoch = ps.nb_flags >> NB_EPOCH;
-      if (book && role == 0) {   // the early-stop decision rides on the granule of the policy workgroup's wave 3
+      if (book && role == 0) {   // the early-stop decision rides on the granule of the policy workgroup's book-keeping wave
         if ((ps.nb_flags >> NB_FIRST) & 1) *acc_kl = 0.f;
         lds_add(acc_kl, mb_s3 * inv_nb);
         if (last_mb) {
@@ -866,23 +887,35 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     // ---- while the granules travel: stage the next minibatch (rows -> the other X^T buffer, advantage statistics)
     const int xnext = S::XDB ? (xcur == S::XT0 ? S::XT1 : S::XT0) : xcur;
     const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK;
+    // granule (role rr, wave ww) = slot 8 rr + ww; a workgroup polls the other two roles' sixteen.  The FIRST look is issued before
+    // the staging and read behind it: the policy workgroup publishes last, so the critics' granules are in memory by now and the
+    // look's trip through the memory system (~0.9 k cycles) runs under the staging instead of behind it.
+    const bool poller = tid < 24 && (!ICRL_OWN_LDS || (tid >> 3) != role);
+    const u64* const slot = xch + (step & 1) * 32 + (tid < 24 ? tid : 0);
+#if ICRL_EARLY_POLL
+    u64 v_first = 0;
+    if (poller) v_first = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     commit_rows(xnext);
     stats_partials(nb_next);
     xcur = xnext;
     FSTAMP(15)  // staging
-    if (tid < 24 && (!ICRL_OWN_LDS || (tid >> 3) != role)) {     // granule (role rr, wave ww) = slot 8 rr + ww; the other two roles' sixteen
+    if (poller) {
       u64 v = 0;
       int spins = 0;
       bool ok = false;
-      const u64* const slot = xch + (step & 1) * 32 + tid;
-      while (spins < (1 << 24)) {
+#if ICRL_EARLY_POLL
+      v = v_first;
+      ok = (unsigned)((v >> 32) & 0x7fffffffu) == step;
+#endif
+      while (!ok && spins < (1 << 24)) {
         v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; break; }
         __builtin_amdgcn_s_sleep(1);
         ++spins;
       }
       sm[S::MISC + 24 + tid] = __uint_as_float((unsigned)(v & 0xffffffffu));
-      if (tid == 3) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;     // granule 3 = (policy, wave 3) carries the stop flag
+      if (tid == ICRL_BOOK_WAVE) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;     // the granule of the policy's book-keeping wave carries the stop flag
       if (!ok) sm[S::MISC + 13] = 1.f;
     }
     lds_barrier();   // (S6) norm partials, next minibatch and its statistics visible
@@ -984,11 +1017,8 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     }
   }
 #ifdef ICRL_FINE_PROF
-#ifndef ICRL_FINE_TID
-#define ICRL_FINE_TID 0
-#define ICRL_FINE_ROLE 0
-#endif
-  if (tid == ICRL_FINE_TID && prof && role == ICRL_FINE_ROLE)
+  // which wave reports: hp._pad bits 8..10 = wave, bits 12..13 = role (tools/train_only.py FINE=1)
+  if (tid == 64 * ((a.hp._pad >> 8) & 7) && prof && role == ((a.hp._pad >> 12) & 3))
     for (int k = 0; k < 20; ++k) a.stats[12 + k] = (float)((double)fph[k] / (double)(a.n_steps > 0 ? a.n_steps : 1));
 #endif
   if (tid == 0 && prof) {
@@ -1034,7 +1064,7 @@ __global__ void __launch_bounds__(TH8) ppo_train_pairs_batch_kernel(const TrainA
 template <int NT1, bool DISC, int OBS>
 static int launch_pairs(const TrainArgs* one, const TrainArgs* d_args, int n_runs, hipStream_t s) {
   static_assert(SmemP<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
-  const size_t bytes = (size_t)SmemP<NT1>::TOTAL * sizeof(float);
+  const size_t bytes = ICRL_STATIC_LDS ? 0 : (size_t)SmemP<NT1>::TOTAL * sizeof(float);
   if (one != nullptr) {
     hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;

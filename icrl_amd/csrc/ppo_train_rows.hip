@@ -25,6 +25,13 @@
 // Built with -ffp-contract=off; FMA is used only where written (fmaf / MFMA).
 #include "ppo_common.h"
 
+// static LDS array instead of `extern __shared__` (ppo_train_pairs.hip: -1.6 % there).  Measured here: at AntWall widths 30.5 us per
+// step against 24.0 (scratch instructions 336 -> 424: the folded offsets let the optimiser hoist more than the register file holds),
+// at HC widths 10.1-10.3 against 10.2-10.5 — off.
+#ifndef ICRL_ROWS_STATIC_LDS
+#define ICRL_ROWS_STATIC_LDS 0
+#endif
+
 namespace icrl {
 
 constexpr int TH4 = 256;   // 4 waves, one per SIMD (up to 512 VGPRs each)
@@ -83,7 +90,11 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
   using S = SmemR<NT1>;
   constexpr int SX = S::SX;
   constexpr int XR = (S::O16 + 3) / 4;  // floats of an X row each of the 4 threads of a row stages
+#if ICRL_ROWS_STATIC_LDS
+  __shared__ __attribute__((aligned(16))) float sm[S::TOTAL];   // static: offsets fold into immediates (see ppo_train_pairs.hip)
+#else
   extern __shared__ __attribute__((aligned(16))) float sm[];
+#endif
   const int role = SPLIT ? (int)blockIdx.x % 3 : (int)blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
   const int half = SPLIT ? (int)blockIdx.x / 3 : 0;                // SPLIT: which 64-row chunk of every minibatch this workgroup computes
   const int tid = threadIdx.x;
@@ -1040,7 +1051,7 @@ __global__ void __launch_bounds__(TH4) ppo_train_rows_batch_kernel(const TrainAr
 
 template <int NT1, bool DISC, bool SPLIT>
 static int launch_rows_batch(const TrainArgs* d_args, int n_runs, hipStream_t s) {
-  const size_t bytes = (size_t)SmemR<NT1>::TOTAL * sizeof(float);
+  const size_t bytes = ICRL_ROWS_STATIC_LDS ? 0 : (size_t)SmemR<NT1>::TOTAL * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_batch_kernel<NT1, DISC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((ppo_train_rows_batch_kernel<NT1, DISC, SPLIT>), dim3(SPLIT ? 6 : 3, n_runs), dim3(TH4), bytes, s, d_args);
@@ -1062,7 +1073,7 @@ int launch_train_rows_batch(const TrainArgs* d_args, int n_runs, int nt1, bool d
 template <int NT1, bool DISC, bool SPLIT>
 static int launch_rows(const TrainArgs& a, hipStream_t s) {
   static_assert(SmemR<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
-  const size_t bytes = (size_t)SmemR<NT1>::TOTAL * sizeof(float);
+  const size_t bytes = ICRL_ROWS_STATIC_LDS ? 0 : (size_t)SmemR<NT1>::TOTAL * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_kernel<NT1, DISC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL((ppo_train_rows_kernel<NT1, DISC, SPLIT>), dim3(SPLIT ? 6 : 3), dim3(TH4), bytes, s, a);

@@ -446,7 +446,7 @@ class PPOLagrangian:
             perms = torch.as_tensor(np.asarray(perms).astype(np.int32), device=dev).contiguous()
         current_penalty = float(self.dual.nu().item())
         if not hasattr(self, "_train_ws"):
-            n_words = 96 + 4 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2 + 32 + _lib.PPO_SPLIT_BYTES // 8
+            n_words = 96 + 6 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2 + 32 + _lib.PPO_SPLIT_BYTES // 8
             # the workspace lives in an arena with room for SYNC_CANDIDATES positions 1 MB apart: see _tune_sync_placement
             arena = torch.zeros(n_words + (self.SYNC_CANDIDATES - 1) * (1 << 17), dtype=torch.int64, device=dev)
             self._train_ws = dict(nu=torch.zeros(1, device=dev), stats=torch.zeros(32 + self.n_epochs, device=dev), sync=arena[:n_words],

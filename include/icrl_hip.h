@@ -151,8 +151,10 @@ typedef struct {
 } icrl_cn_hyper_t;
 
 #define ICRL_PPO_SPLIT_BYTES (2 * 3 * 2 * (4 * 8 + 23 + 5) * 256 * 8) /* partial-gradient granules: 2 step parities x 3 networks x 2 halves */
+/* granule slots (512 B) + the schedule tables: 16 B per optimiser step and 8 B per 64-row chunk (up to four per step) */
+#define ICRL_PPO_PLAN_BYTES(n_steps) (768 + 48 * (size_t)(n_steps))
 #define ICRL_PPO_SYNC_BYTES(n_epochs, n_minibatches, n_rows) \
-  (768 + 32 * (size_t)(n_epochs) * (size_t)(n_minibatches) + 4 * (size_t)(n_epochs) * (size_t)(n_rows) + 256 + ICRL_PPO_SPLIT_BYTES)
+  (ICRL_PPO_PLAN_BYTES((size_t)(n_epochs) * (size_t)(n_minibatches)) + 4 * (size_t)(n_epochs) * (size_t)(n_rows) + 256 + ICRL_PPO_SPLIT_BYTES)
 #define ICRL_CN_METRICS 24 /* floats per iteration in the metrics array of icrl_cn_train */
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -105,7 +105,11 @@ def _oracle_train(agent_sd, buf, perms, kind, nu, **h):
                                              ("hc", 8, 64, 256, 2, None),      # 512 rows: minibatches of 256 = 4 chunks (wave pairs)
                                              ("hc", 5, 60, 200, 2, None),      # 300 rows: 200 (64 + 64 + 64 + 8) and 100 (64 + 36)
                                              ("ant", 4, 80, 256, 2, None),     # 320 rows: 256 and 64 (row-owning waves, obs 113)
-                                             ("ant", 3, 70, 160, 2, None)])    # 210 rows: 160 (3 chunks) and 50
+                                             ("ant", 3, 70, 160, 2, None),     # 210 rows: 160 (3 chunks) and 50
+                                             # many steps at > 2 chunks per step: the schedule tables (16 B per step + 8 B per chunk)
+                                             # must not reach the permutation offsets behind them (ICRL_PPO_PLAN_BYTES)
+                                             ("hc", 8, 512, 256, 2, None),     # 32 steps x 4 chunks
+                                             ("hc", 8, 256, 192, 3, None)])    # 33 steps x 3 chunks
 def test_train_vs_oracle(kind, N, T, B, E, tk, one_workgroup_per_network=False):
     rng = np.random.RandomState(N * T)
     od, ad = (18, 6) if kind == "hc" else (113, 8)

@@ -17,7 +17,9 @@ suffix = "" if kind == "hc" else "_antwall"
 QUAD = {"SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
         "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-waves = {}
+waves, dur = {}, {}
+kept, dropped = collections.Counter(), collections.Counter()
+clocks, us_step = collections.defaultdict(list), collections.defaultdict(list)
 # one file per pass directory (pmc_train_<tag>_a / _b): gpurun merges every call's files into gpurun_out/, take the newest of each
 _passes = []
 for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_train_{tag}{suffix}_[ab]"))):
@@ -35,17 +37,35 @@ for f in _passes:
         if kind != "hc":      # the SPLIT template argument tells the two launch shapes of the row-owning kernel apart
             name = k.split("(")[0].split("::")[-1].replace("void ", "")
         per[(name, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        dur[(name, r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
         waves[name] = int(r["Workgroup_Size"]) // 64 * int(r["Grid_Size"]) // int(r["Workgroup_Size"])
-    for (name, _), c in per.items():
+    # Only the FULL launches (STEPS optimiser steps) count: every process also makes 8 short calibration launches of the same kernel
+    # (PPOLagrangian._tune_sync_placement: 256 steps each at HC), and a median over all launches divided by STEPS would describe those
+    # (round 3's tables did: 1 376 "cycles per wave-step" for a kernel that takes 21 334).  A full launch is one that lasts at least
+    # half as long as the kernel's longest.
+    longest = collections.defaultdict(float)
+    for (name, d_), t in dur.items():
+        longest[name] = max(longest[name], t)
+    for (name, d_), c in per.items():
+        if dur[(name, d_)] < 0.5 * longest[name]:
+            dropped[name] += 1
+            continue
+        kept[name] += 1
         for cn, v in c.items():
             agg[name][cn].append(v)
+        if "SQ_WAVE_CYCLES" in c:      # cross-check: wave cycles per wave must be the launch's duration at a plausible shader clock
+            ghz = c["SQ_WAVE_CYCLES"] * 4 / waves[name] / dur[(name, d_)] * 1e-9
+            assert 1.2 < ghz < 2.7, f"{name} dispatch {d_}: SQ_WAVE_CYCLES x 4 / waves / duration = {ghz:.2f} GHz — not a shader clock"
+            clocks[name].append(ghz)
+            us_step[name].append(dur[(name, d_)] / STEPS * 1e6)
 shape = "HCWithPos shapes, batch 64" if kind == "hc" else "AntWall shapes (obs 113, act 8), batch 128 = two 64-row chunks"
 lines = [f"# SQ counters of the PPO-Lagrangian update kernels ({tag}) — {shape}, per WAVE and optimiser step",
          "", "command: `bash tools/pmc_train.sh <tag>` on the GPU box = two `rocprofv3 --pmc <8 SQ counters> --kernel-trace` passes over "
          "`tools/train_only.py` (HC: VARIANTS=rows,auto = the row-owning kernel with one wave per SIMD, 12 waves, and the wave-pair kernel with two, "
          "24 waves, 4096 optimiser steps per launch; KIND=ant: VARIANTS=rows1,auto = one workgroup per network walking both chunks, 12 waves, and "
          "the default two workgroups per network, 24 waves, 512 steps per launch); raw csv: gpurun_out/pmc_train_<tag>_{a,b} (scratch).  Values "
-         f"below = median over the launches / waves of the kernel / {STEPS}; cycle-type counters converted from quad-cycles to shader cycles.", ""]
+         f"below = median over the FULL launches ({STEPS} optimiser steps; the short sync-placement calibration launches every process makes are dropped by duration) "
+         f"/ waves of the kernel / {STEPS}; cycle-type counters converted from quad-cycles to shader cycles.", ""]
 names = sorted(agg)
 if kind != "hc":      # the same kernel symbol runs with 3 and with 6 workgroups: keep them apart by wave count
     pass
@@ -54,6 +74,9 @@ cols = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY
         "SQ_INSTS_VMEM_RD"]
 lines.append("| counter | " + " | ".join(f"`{n}` ({waves[n]} waves)" for n in names) + " |")
 lines.append("|---|" + "---|" * len(names))
+lines.append("| full launches used (calibration launches dropped) | " + " | ".join(f"{kept[n]} ({dropped[n]})" for n in names) + " |")
+lines.append("| us per optimiser step (dispatch timestamps, profiled) | " + " | ".join(f"{sorted(us_step[n])[len(us_step[n]) // 2]:.2f}" if us_step[n] else "-" for n in names) + " |")
+lines.append("| implied shader clock, GHz (WAVE_CYCLES x 4 / waves / duration) | " + " | ".join(f"{sorted(clocks[n])[len(clocks[n]) // 2]:.2f}" if clocks[n] else "-" for n in names) + " |")
 for c in cols:
     row = []
     for n in names:

@@ -38,7 +38,13 @@ for variant in sorted(set(v for v in variants if v != "rows1")):
     print(variant, "cycles/step per phase fwd|loss|bwd|wgrad|norm|wait|adam (role 0 | 1):", np.round(st[12:19]), np.round(st[19:26]))
 agent.profile_phases = 0
 if os.environ.get("FINE"):
+    # per-wave phase timers of a -DICRL_FINE_PROF build (tools/build_variant.sh fine -DICRL_FINE_PROF; ICRL_LIB=...): FINE=1 all
+    # eight waves of the policy workgroup, FINE=<role> those of another role
     names = ["L1", "prefetch", "S1", "L2", "head", "S3", "loss", "dH2", "S4", "dH1", "dW2", "dWh", "S5", "dW1", "norm", "staging", "poll+S6", "Adam", "S7", "-"]
-    agent.train_kernel = "auto"; agent.profile_phases = 1; agent.train(); torch.cuda.synchronize()
-    st = agent._train_ws["stats"].cpu().numpy()
-    print("fine (policy wg, wave 0):", " ".join(f"{n}={v:.0f}" for n, v in zip(names, st[12:32])), " total", st[12:32].sum())
+    frole = int(os.environ["FINE"]) if os.environ["FINE"] in "012" else 0
+    agent.train_kernel = "auto"
+    print("role", frole, "wave " + " ".join(f"{n:>7s}" for n in names[:19]) + "   total")
+    for wv in range(8):
+        agent.profile_phases = 1 | (wv << 8) | (frole << 12); agent.train(); torch.cuda.synchronize()
+        st = agent._train_ws["stats"].cpu().numpy()
+        print(f"        {wv}    " + " ".join(f"{v:7.0f}" for v in st[12:31]), f"  {st[12:32].sum():.0f}")
