@@ -37,8 +37,32 @@
 #ifndef ICRL_BOOK_WAVE
 #define ICRL_BOOK_WAVE 7
 #endif
+#ifndef ICRL_L1_TAILQ
+#define ICRL_L1_TAILQ 1
+#endif
+#ifndef ICRL_LEAN_GATHER
+#define ICRL_LEAN_GATHER 1
+#endif
+#ifndef ICRL_STATS_WAVE0
+#define ICRL_STATS_WAVE0 4
+#endif
+#ifndef ICRL_L1_AHEAD
+#define ICRL_L1_AHEAD 0
+#endif
+
+// Timing diagnostics (tools/diag_train.sh; WRONG RESULTS, never the shipped build): -DICRL_DIAG=<bits> removes one component of the
+// step so that its marginal cost on the critical path can be read off the step time:
+//   1 barrier S5 | 2 barrier S6 | 4 barrier S7 | 8 pair hand-offs | 16 tanh | 32 Adam arithmetic | 64 loss tail | 128 row prefetch + staging
+//   256 gradient norm (partial sums, publish, poll) | 512 advantage statistics | 1024 book-keeping lane
+#ifndef ICRL_DIAG
+#define ICRL_DIAG 0
+#endif
 
 namespace icrl {
+
+#if ICRL_DIAG & 16
+#define fast_tanh(x) ((x) * 0.5f)
+#endif
 
 constexpr int TH8 = 512;   // 8 waves, two per SIMD (<= 256 registers each)
 constexpr int ST = 72;     // row stride of the [feature][row] matrices (64 rows + 8: conflict-free ds_read_b128)
@@ -279,7 +303,11 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   // while chunk g is processed.  The 16 rows of tile rt are staged by the 128 threads of the wave pair (rt, *): 8 per row.
   // ---------------------------------------------------------------------------------------------------------------
   const int gb_row = 16 * rt + (lane >> 2), gpart = (lane & 3) + 4 * fh;
-  const int stid = tid - 64;      // advantage statistics: row stid of the minibatch lives in waves 1 .. 4 (<= 256 rows)
+  // advantage statistics: row stid of the minibatch lives in waves SW0 .. SW0 + 3 (<= 256 rows).  The HIGH waves (4..7): they reach the
+  // norm barrier ~1 k cycles ahead of the low waves (no head-weight gradient), and the three wave sums cost ~400 cycles — on waves 1, 2
+  // they made those two the last at the barrier
+  constexpr int SW0 = ICRL_STATS_WAVE0;
+  const int stid = tid - 64 * SW0;
   auto ld_step = [&](int i) -> int4 {
     asm volatile("" : "+v"(i));
     return *reinterpret_cast<const int4*>(plan_steps + i);
@@ -302,8 +330,42 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   // and staged as they are: a row b >= nrows contributes nothing (its d loss / d output is forced to 0 by `valid`), and the
   // k >= obs columns of X only ever meet the zero pad columns of W1 (the dW1 step below keeps those at zero).  So the staging
   // path carries no masks and no branches; offsets are 32-bit element indices (the C ABI checks T * N * obs < 2^30).
+#if ICRL_LEAN_GATHER
+  // Lean form: (i) with the observation width known at compile time only the pieces that hold real components are fetched and
+  // staged (obs 18: 3 of 4 per thread; the X^T rows k >= obs keep the zeros of the start), (ii) the second action piece only when
+  // there are more than 8 actions, (iii) ONE of the three per-row scalars per thread — thread gpart of a row fetches scalar gpart
+  // (old log-prob / value | advantage / return | cost advantage) through its own pointer and stores it at its own address, threads
+  // 3..7 re-read the third and park it in a scratch word.  9 -> 5 loads and 9 -> 5 stores per thread and step at HC shapes.
+  constexpr int XRL = OBS > 0 ? (OBS + 7) / 8 : XR;
+  float px[XR], pact[2] = {0.f, 0.f}, psc = 0.f;
+  const float* const p_sc = gpart == 0 ? p_s0 : (gpart == 1 ? p_s1 : p_s2);
+  const int sc_dst = gpart == 0 ? S::OLP + gb_row : (gpart == 1 ? S::ADR + gb_row : (gpart == 2 ? S::ADC + gb_row : S::MISC + 62));
+  const bool two_act = AS > 8;
+  auto issue_rows = [&](int idx) {
+    if (ICRL_DIAG & 128) return;
+    const unsigned off = idx >= 0 ? (unsigned)idx : 0u;
+    const unsigned ob = off * (unsigned)O;
+#pragma unroll
+    for (int i = 0; i < XRL; ++i) { const int k = gpart + 8 * i; px[i] = p_obs[ob + (unsigned)(k < O ? k : O - 1)]; }
+    const unsigned ab = off * (unsigned)AS;      // (the critics fetch the action bytes too: a load is cheaper than a branch in the load stream)
+    pact[0] = p_act[ab + (unsigned)(gpart < AS ? gpart : AS - 1)];
+    if (two_act) pact[1] = p_act[ab + (unsigned)(gpart + 8 < AS ? gpart + 8 : AS - 1)];
+    psc = p_sc[off];
+  };
+  auto commit_rows = [&](int xbase) {
+    if (ICRL_DIAG & 128) return;
+#pragma unroll
+    for (int i = 0; i < XRL; ++i) { const int k = gpart + 8 * i; if (OBS > 0 ? k < OBS : k < S::O16) sm[xbase + k * ST + gb_row] = px[i]; }
+    if (role == 0) {
+      sm[S::ACT + gb_row * SA + gpart] = gpart < AS ? pact[0] : 0.f;                           // pad actions are 0
+      if (two_act) sm[S::ACT + gb_row * SA + gpart + 8] = gpart + 8 < AS ? pact[1] : 0.f;      // (<= 8 actions: columns 8.. keep the zeros of the start)
+    }
+    sm[sc_dst] = psc;
+  };
+#else
   float px[XR], pact[2], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
   auto issue_rows = [&](int idx) {
+    if (ICRL_DIAG & 128) return;
     const unsigned off = idx >= 0 ? (unsigned)idx : 0u;
     const unsigned ob = off * (unsigned)O;
 #pragma unroll
@@ -316,6 +378,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     psc0 = p_s0[off]; psc1 = p_s1[off]; psc2 = p_s2[off];
   };
   auto commit_rows = [&](int xbase) {
+    if (ICRL_DIAG & 128) return;
 #pragma unroll
     for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; if (k < S::O16) sm[xbase + k * ST + gb_row] = px[i]; }
     if (role == 0) {
@@ -324,23 +387,25 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     }
     if (gpart == 0) { sm[S::OLP + gb_row] = psc0; sm[S::ADR + gb_row] = psc1; sm[S::ADC + gb_row] = psc2; }
   };
+#endif
   float sar = 0.f, sac = 0.f;
   auto issue_stats = [&](int idx) {
     const unsigned off = idx >= 0 ? (unsigned)idx : 0u;
     sar = p_s1[off];
     sac = p_s2[off];
   };
-  const bool big_mb = a.hp.batch_size > 128;     // minibatches of 129..256 rows: waves 3 and 4 hold statistics rows too
+  const bool big_mb = a.hp.batch_size > 128;     // minibatches of 129..256 rows: all four statistics waves hold rows
   auto stats_partials = [&](int nb) {
-    if (role != 0 || w == 0 || w > (big_mb ? 4 : 2)) return;
+    if (ICRL_DIAG & 512) return;
+    if (role != 0 || w < SW0 || w > SW0 + (big_mb ? 3 : 1)) return;
     const bool in = stid < nb;
     const float s_r = wave_sum_fast(in ? sar : 0.f), s_c = wave_sum_fast(in ? sac : 0.f), s_rr = wave_sum_fast(in ? sar * sar : 0.f);
-    if (lane == 0) { sm[S::MISC + 3 * (w - 1)] = s_r; sm[S::MISC + 3 * (w - 1) + 1] = s_c; sm[S::MISC + 3 * (w - 1) + 2] = s_rr; }
+    if (lane == 0) { sm[S::MISC + 3 * (w - SW0)] = s_r; sm[S::MISC + 3 * (w - SW0) + 1] = s_c; sm[S::MISC + 3 * (w - SW0) + 2] = s_rr; }
   };
   float mean_r = 0.f, istd_r = 1.f, mean_c = 0.f;
   auto read_stats = [&](int nb) {
     if (role != 0) return;
-    // MISC[0..11]: (sum A_r, sum A_c, sum A_r^2) of waves 1..4; waves 3, 4 leave zeros for minibatches of <= 128 rows
+    // MISC[0..11]: (sum A_r, sum A_c, sum A_r^2) of the four statistics waves; the last two leave zeros for minibatches of <= 128 rows
     float s_r = sm[S::MISC + 0] + sm[S::MISC + 3];
     float s_c = sm[S::MISC + 1] + sm[S::MISC + 4];
     float s_rr = sm[S::MISC + 2] + sm[S::MISC + 5];
@@ -372,7 +437,10 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   // ever exchanges data with its partner before the dz1 barrier, so the other pairs need not be there yet.
   int* const pflag = reinterpret_cast<int*>(sm + S::MISC + 48);      // [8] one word per wave
   int pphase = 0;
-#if ICRL_PAIR_FLAGS
+#if ICRL_DIAG & 8
+  auto pair_signal = [&]() { (void)pflag; (void)pphase; (void)partner; };
+  auto pair_wait = [&]() {};
+#elif ICRL_PAIR_FLAGS
   auto pair_signal = [&]() {
     ++pphase;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -389,7 +457,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   // lane 0 of wave ICRL_BOOK_WAVE keeps the running statistics of the role.  A HIGH wave (fh == 1): those have no head-weight
   // gradient to form and reach the norm barrier ~1 k cycles before the low waves, which is about what the book-keeping costs
   // (per-wave timers: on wave 3 it made that wave the last one at the barrier by ~750 cycles)
-  const bool book = tid == 64 * ICRL_BOOK_WAVE;
+  const bool book = !(ICRL_DIAG & 1024) && tid == 64 * ICRL_BOOK_WAVE;
   // Its running sums live in LDS (MISC + 56..61) and are advanced with ds_add_f32, which needs no answer: as loop-carried registers of
   // one lane they were spilled to scratch at the 256-register limit (two scratch reloads + three stores per optimiser step on the
   // book-keeping wave; in-loop scratch instructions 12 -> 3; measured 8.91-8.93 against 8.94-8.95 us per step on the same box).  One
@@ -416,6 +484,56 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   __syncthreads();
   read_stats(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
   const float inv_n_mb = 1.f / (float)((T * N + a.hp.batch_size - 1) / a.hp.batch_size);
+
+  // ---- layer 1 of the chunk staged at `xbase`: own feature tiles t = 2 fh + tt -> h1c (registers) and the h1^T image
+  const int b = 16 * rt + r;            // this lane's row of the chunk (all four q lanes share it)
+  float* const pt = sm + (4 * q) * ST + b;     // + image + (16 t + i) ST: element [feature 16 t + 4 q + i][row b]
+  f32x4 h1c[2];
+  // TAILQ: the last K group holds 1..4 real observation components (obs 18: k = 16, 17).  An MFMA covers k = 16 js + 4 q + e for its
+  // four lane groups q, so that group used to take one MFMA per component, each with three idle lane groups; here ONE MFMA takes the
+  // components along q (k = 16 js + q): same products in the same order (the others are zeros), one MFMA and one operand fetch less
+  // per component and tile.
+  constexpr int JT = OBS / 16;
+  constexpr bool TAILQ = ICRL_L1_TAILQ && OBS > 0 && OBS % 16 >= 1 && OBS % 16 <= 4 && JT < NT1;
+  auto l1_forward = [&](int xbase) {
+    float bx[NT1][4];                   // x[row b][k = 16 js + 4 q + e]
+    const float* pb = sm + xbase + (4 * q) * ST + b;
+#pragma unroll
+    for (int js = 0; js < NT1; ++js)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bx[js][e] = ((OBS == 0 || 16 * js + e < OBS) && !(TAILQ && js == JT)) ? pb[(16 * js + e) * ST] : 0.f;
+    const float bt = TAILQ ? sm[xbase + (16 * JT + q) * ST + b] : 0.f;      // x[row b][k = 16 JT + q]
+    f32x4 z[2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+      const int t = 2 * fh + tt;
+      const float* pa = sm + S::W1 + (16 * t + r) * SX + 4 * q;
+      f32x4 aw[NT1];
+#pragma unroll
+      for (int js = 0; js < NT1; ++js)
+        if (!(TAILQ && js >= JT)) aw[js] = lds128(pa + 16 * js);
+      const float at = TAILQ ? sm[S::W1 + (16 * t + r) * SX + 16 * JT + q] : 0.f;
+      z[tt] = lds128(sm + S::B1 + 16 * t + 4 * q);      // the bias is the accumulator's initial value
+#pragma unroll
+      for (int js = 0; js < NT1; ++js)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if ((OBS == 0 || 16 * js + e < OBS) && !(TAILQ && js >= JT)) z[tt] = MFMA_F32(aw[js][e], bx[js][e], z[tt]);     // (k >= obs: zero weights)
+      if (TAILQ) z[tt] = MFMA_F32(at, bt, z[tt]);
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) h1c[tt][i] = fast_tanh(z[tt][i]);
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pt[S::H1T + (16 * (2 * fh + tt) + i) * ST] = h1c[tt][i];
+  };
+#if ICRL_L1_AHEAD
+  l1_forward(xcur);       // layer 1 of the first minibatch; from here on every step ends with layer 1 of the next one
+  lds_barrier();
+#endif
 
   const bool prof = (a.hp._pad & 1) != 0;
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -450,42 +568,14 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
         commit_rows(xcur);
         lds_barrier();                      // a row is staged by threads of both waves of its pair
       }
-      const int b = 16 * rt + r;            // this lane's row of the chunk (all four q lanes share it)
       const bool valid = b < nrows;
-      float* const pt = sm + (4 * q) * ST + b;     // + image + (16 t + i) ST: element [feature 16 t + 4 q + i][row b]
       // ================= forward =================
-      f32x4 h1c[2], h2c[2], outc;           // own feature tiles t = 2 fh + tt
-      {
-        float bx[NT1][4];                   // x[row b][k = 16 js + 4 q + e]
-        const float* pb = sm + xcur + (4 * q) * ST + b;
-#pragma unroll
-        for (int js = 0; js < NT1; ++js)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bx[js][e] = (OBS == 0 || 16 * js + e < OBS) ? pb[(16 * js + e) * ST] : 0.f;
-        f32x4 z[2];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const int t = 2 * fh + tt;
-          const float* pa = sm + S::W1 + (16 * t + r) * SX + 4 * q;
-          f32x4 aw[NT1];
-#pragma unroll
-          for (int js = 0; js < NT1; ++js) aw[js] = lds128(pa + 16 * js);
-          z[tt] = lds128(sm + S::B1 + 16 * t + 4 * q);      // the bias is the accumulator's initial value
-#pragma unroll
-          for (int js = 0; js < NT1; ++js)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (OBS == 0 || 16 * js + e < OBS) z[tt] = MFMA_F32(aw[js][e], bx[js][e], z[tt]);     // (k >= obs: zero weights)
-        }
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) h1c[tt][i] = fast_tanh(z[tt][i]);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) pt[S::H1T + (16 * (2 * fh + tt) + i) * ST] = h1c[tt][i];
-      }
+      f32x4 h2c[2], outc;                   // own feature tiles t = 2 fh + tt
+#if ICRL_L1_AHEAD
+      if (ch > 0) l1_forward(xcur);         // (chunk 0: computed at the end of the previous step, under its Adam)
+#else
+      l1_forward(xcur);
+#endif
       FSTAMP(0)   // L1
       // prefetch the next chunk's rows (random 72-byte pieces of the rollout buffer: several microseconds away)
       {
@@ -496,7 +586,11 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
         issue_rows(idx_now);
       }
       FSTAMP(1)   // row prefetch issue
+#if ICRL_L1_AHEAD
+      if (ch > 0) pair_signal();     // (P1) this wave's columns of h1^T are complete (chunk 0: the S7 barrier said so)
+#else
       pair_signal();                 // (P1) this wave's columns of h1^T are complete
+#endif
       FSTAMP(2)   // S1
       {
         // the own half of K (h1c, registers) needs nobody: its MFMAs run before the wait for the partner's half
@@ -515,7 +609,11 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 #pragma unroll
             for (int e = 0; e < 4; ++e) z[tt] = MFMA_F32(awo[jj][e], h1c[jj][e], z[tt]);
         }
+#if ICRL_L1_AHEAD
+        if (ch > 0) pair_wait();     // the partner's columns of h1^T are complete
+#else
         pair_wait();                 // the partner's columns of h1^T are complete
+#endif
         float hpart[2][4];                  // the partner's half of h1 as B operand: features 16 js + 4 q + e, js = 2 (1 - fh) + jj
         const float* ph1 = sm + S::H1T + (4 * q) * ST + b + 32 * (1 - fh) * ST;
 #pragma unroll
@@ -560,7 +658,10 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       STAMP(0)   // forward
       // ============ loss + d loss / d head output (both waves of a pair: identical values) ============
       f32x4 dout = f32x4{0.f, 0.f, 0.f, 0.f};
-      {
+      if (ICRL_DIAG & 64) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dout[i] = outc[i] * 1e-6f;
+      } else {
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
         if (role == 0) {
           float lp = 0.f, ent = 0.f;
@@ -734,7 +835,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
         gW2r[0] = gW2r[1] = gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
         gb1r = 0.f; gb2r = 0.f; gex = 0.f;
       }
-      lds_barrier();  // (S5) every pair's columns of h1^T, h2^T, dz1^T, dz2^T, dOut^T (and the loss partials) are complete
+      if (!(ICRL_DIAG & 1)) lds_barrier();  // (S5) every pair's columns of h1^T, h2^T, dz1^T, dz2^T, dOut^T (and the loss partials) are complete
       FSTAMP(12)  // S5
       // ================= weight gradients (K = the 64 rows) =================
       {  // dW2 rows 16 rt.., column tiles 2 fh, 2 fh + 1
@@ -825,6 +926,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 
     // ================= global gradient norm: this wave's partial sum of squares -> its own 8-byte granule =================
     float ss = 0.f;
+    if (ICRL_DIAG & 256) ss = 1.f + gW1r[0][0] * 1e-9f; else {
 #pragma unroll
     for (int cc = 0; cc < NW1; ++cc)
 #pragma unroll
@@ -840,6 +942,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       ss += q == 0 ? sb : 0.f;
     }
     ss = wave_sum_fast(ss);
+    }
     if (lane == 0) {
       bool want_stop = false;
       float mean_kl = 0.f;
@@ -908,6 +1011,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       v = v_first;
       ok = (unsigned)((v >> 32) & 0x7fffffffu) == step;
 #endif
+      if (ICRL_DIAG & 256) ok = true;
       while (!ok && spins < (1 << 24)) {
         v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; break; }
@@ -918,7 +1022,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       if (tid == ICRL_BOOK_WAVE) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;     // the granule of the policy's book-keeping wave carries the stop flag
       if (!ok) sm[S::MISC + 13] = 1.f;
     }
-    lds_barrier();   // (S6) norm partials, next minibatch and its statistics visible
+    if (!(ICRL_DIAG & 2)) lds_barrier();   // (S6) norm partials, next minibatch and its statistics visible
     STAMP(5)   // staging + granule wait
     FSTAMP(16)  // poll + S6
     float total = 0.f;
@@ -944,6 +1048,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       const float omw1 = 1.f - w1, b2f_ = adam_b2f;
       const float cw1 = coef * w1, c2w2 = (coef * coef) * w2;
       auto adam4 = [&](const f32x4& g, f32x4& m, f32x4& v, f32x4& p) {   // stage by stage: four independent chains
+        if (ICRL_DIAG & 32) { p[0] += g[0] * step_size; return; }
         f32x4 d;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { m[i] = fmaf(cw1, g[i], omw1 * m[i]); v[i] = fmaf(c2w2, g[i] * g[i], b2f_ * v[i]); }
@@ -953,23 +1058,38 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
         for (int i = 0; i < 4; ++i) p[i] = fmaf(-step_size, m[i] * __builtin_amdgcn_rcpf(d[i]), p[i]);
       };
       // pad elements (k >= obs, o >= n_out) have g = m = v = p = 0 and stay 0: no masks needed
+      // Part 1: what layer 1 reads (W1, b1; the low waves' bias block carries b2 and the head bias / log_std along)
 #pragma unroll
       for (int cc = 0; cc < NW1; ++cc) { f32x4 p_ = load_own_w1(cc); adam4(gW1r[cc], mW1[cc], vW1[cc], p_); store_w1(cc, p_); }
-#pragma unroll
-      for (int cc = 0; cc < 2; ++cc) { f32x4 p_ = load_own_w2(cc); adam4(gW2r[cc], mW2[cc], vW2[cc], p_); store_w2(cc, p_); }
       if (low) {
-        { f32x4 p_ = load_own_wh(); adam4(gWhr, mWh, vWh, p_); store_wh(p_); }
         f32x4 g_ = f32x4{gb1r, gb2r, ex_g >= 0 ? gex : 0.f, 0.f}, p_ = f32x4{sm[S::B1 + jb], sm[S::B2 + jb], sm[ex_s], 0.f};
         f32x4 m_ = f32x4{mb1, mb2, mex, 0.f}, v_ = f32x4{vb1, vb2, vex, 0.f};
         adam4(g_, m_, v_, p_);     // identical arithmetic in the four q lanes, lane q == 0 stores
         mb1 = m_[0]; mb2 = m_[1]; mex = m_[2]; vb1 = v_[0]; vb2 = v_[1]; vex = v_[2];
         if (q == 0) { sm[S::B1 + jb] = p_[0]; sm[S::B2 + jb] = p_[1]; sm[ex_s] = p_[2]; }
-        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the log_std store has landed before refresh_gauss re-reads it
-        refresh_gauss();
       }
+      // Part 2: W2, head weights, the Gaussian head's constants
+      auto adam_rest = [&]() {
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) { f32x4 p_ = load_own_w2(cc); adam4(gW2r[cc], mW2[cc], vW2[cc], p_); store_w2(cc, p_); }
+        if (low) {
+          { f32x4 p_ = load_own_wh(); adam4(gWhr, mWh, vWh, p_); store_wh(p_); }
+          __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the log_std store has landed before refresh_gauss re-reads it
+          refresh_gauss();
+        }
+      };
+#if ICRL_L1_AHEAD
+      // Layer 1 of the NEXT minibatch (staged above) needs W1 and b1 only: the two waves of a SIMD run it and the rest of Adam in
+      // opposite orders, so one wave's MFMAs / LDS latencies meet the other's VALU work instead of its twin
+      lds_barrier();   // (S7a) W1, b1 visible
+      FSTAMP(19)
+      if (low) { l1_forward(xcur); adam_rest(); } else { adam_rest(); l1_forward(xcur); }
+#else
+      adam_rest();
+#endif
     }
     FSTAMP(17)  // Adam
-    lds_barrier();   // (S7) updated weights visible
+    if (!(ICRL_DIAG & 4)) lds_barrier();   // (S7) updated weights visible
     STAMP(6)   // Adam
     FSTAMP(18)  // S7
   }  // optimiser steps

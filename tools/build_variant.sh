@@ -10,7 +10,8 @@ mkdir -p $R/icrl_amd/lib/var
 cd $R/icrl_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
 for f in ppo_train_pairs ppo_train_rows; do
-  /opt/rocm/bin/hipcc $FLAGS "$@" -c $f.hip -o ../lib/var/${f}_$name.o &
+  extra=""; [ $f = ppo_train_pairs ] && [ -z "$SLP" ] && extra="-fno-slp-vectorize"      # as in the Makefile (SLP=1: with the vectoriser)
+  /opt/rocm/bin/hipcc $FLAGS $extra "$@" -c $f.hip -o ../lib/var/${f}_$name.o &
 done
 wait
 objs=""

@@ -15,14 +15,14 @@ kind = sys.argv[2] if len(sys.argv) > 2 else "hc"           # "ant": tools/train
 STEPS = 4096 if kind == "hc" else 512
 suffix = "" if kind == "hc" else "_antwall"
 QUAD = {"SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU",
-        "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA"}
+        "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC", "SQ_BUSY_CU_CYCLES"}
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 waves, dur = {}, {}
 kept, dropped = collections.Counter(), collections.Counter()
 clocks, us_step = collections.defaultdict(list), collections.defaultdict(list)
 # one file per pass directory (pmc_train_<tag>_a / _b): gpurun merges every call's files into gpurun_out/, take the newest of each
 _passes = []
-for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_train_{tag}{suffix}_[ab]"))):
+for d in sorted(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_train_{tag}{suffix}_[abc]"))):
     if os.path.isdir(d):
         hits = sorted(glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
         if hits:
@@ -71,7 +71,8 @@ if kind != "hc":      # the same kernel symbol runs with 3 and with 6 workgroups
     pass
 cols = ["SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_INSTS_VALU", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_SALU",
         "SQ_INSTS_LDS", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_SCA", "SQ_WAIT_INST_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_INSTS_SMEM",
-        "SQ_INSTS_VMEM_RD"]
+        "SQ_INSTS_VMEM_RD", "SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_VALU_MFMA_COEXEC_CYCLES", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_FMA_F32",
+        "SQ_INSTS_BRANCH", "SQ_ACTIVE_INST_MISC", "SQ_BUSY_CU_CYCLES"]
 lines.append("| counter | " + " | ".join(f"`{n}` ({waves[n]} waves)" for n in names) + " |")
 lines.append("|---|" + "---|" * len(names))
 lines.append("| full launches used (calibration launches dropped) | " + " | ".join(f"{kept[n]} ({dropped[n]})" for n in names) + " |")

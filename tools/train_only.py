@@ -40,11 +40,11 @@ agent.profile_phases = 0
 if os.environ.get("FINE"):
     # per-wave phase timers of a -DICRL_FINE_PROF build (tools/build_variant.sh fine -DICRL_FINE_PROF; ICRL_LIB=...): FINE=1 all
     # eight waves of the policy workgroup, FINE=<role> those of another role
-    names = ["L1", "prefetch", "S1", "L2", "head", "S3", "loss", "dH2", "S4", "dH1", "dW2", "dWh", "S5", "dW1", "norm", "staging", "poll+S6", "Adam", "S7", "-"]
+    names = ["L1", "prefetch", "S1", "L2", "head", "S3", "loss", "dH2", "S4", "dH1", "dW2", "dWh", "S5", "dW1", "norm", "staging", "poll+S6", "Adam", "S7", "S7a"]
     frole = int(os.environ["FINE"]) if os.environ["FINE"] in "012" else 0
     agent.train_kernel = "auto"
-    print("role", frole, "wave " + " ".join(f"{n:>7s}" for n in names[:19]) + "   total")
+    print("role", frole, "wave " + " ".join(f"{n:>7s}" for n in names[:20]) + "   total")
     for wv in range(8):
         agent.profile_phases = 1 | (wv << 8) | (frole << 12); agent.train(); torch.cuda.synchronize()
         st = agent._train_ws["stats"].cpu().numpy()
-        print(f"        {wv}    " + " ".join(f"{v:7.0f}" for v in st[12:31]), f"  {st[12:32].sum():.0f}")
+        print(f"        {wv}    " + " ".join(f"{v:7.0f}" for v in st[12:32]), f"  {st[12:32].sum():.0f}")
