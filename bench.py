@@ -1,6 +1,6 @@
 """bench.py — env-steps/s of the ICRL outer loop (HCWithPos-v0 shapes, synthetic env) on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps K --warmup W [--config {1,3}] [--mode {shards,seeds}]
+    python bench.py --gpus 1 --steps K --warmup W [--config {1,3,4}] [--mode {shards,seeds}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is ONE outer ICRL iteration of BASELINE.json configs[1] (README.md:38 flags of the reference):
@@ -11,10 +11,15 @@ Weak scaling: every rank owns its own 64 envs; one all-reduce of parameters / mo
 `value` includes the reference's target-KL early stops (ppo_lag.py:293-297): later outer iterations stop their epoch loops early, so
 env-steps/s moves with the iteration count; `us_per_optimizer_step` (roofline_ppo) is the invariant, `optimizer_steps_per_iteration`
 and `early_stop_fraction` say how much of the 2 x 20 480 steps an iteration executed.
-  --config 3       BASELINE configs[3]'s per-GPU shard instead (HCWithPos, 2048 envs over 8 GPUs = 256 envs per GPU)
+  --config 1       (default at --gpus 1) BASELINE configs[1]: 64 envs per GPU
+  --config 3       (default at --gpus > 1) BASELINE configs[3]'s per-GPU shard: HCWithPos, 2048 envs over 8 GPUs = 256 envs per GPU
+  --config 4       BASELINE configs[4]: AntWall -> AntBroken constraint transfer (cpg, README.md:78 flags of the reference): frozen cost
+                   net, 4096 envs over 8 GPUs = 512 envs per GPU; a "step" = one rollout (512 x 2048 env steps) + PPO-Lagrangian update of
+                   learn(), value = env-steps/s of learn(); ranks all-reduce once per rollout + update
   --mode seeds     north_star's other fan-out: rank r runs an independent ICRL run with seed s + r, NO collective; value = sum over ranks
-With one GPU the line also carries `configs2`: BASELINE configs[2] (AntWall-v0, 256 envs, constraint net [40, 40], batch 128, 20
-epochs; README.md:50 flags) timed the same way — extra, never `value`.
+With one GPU the line also carries, as extras that are never `value`: `configs2` (BASELINE configs[2]: AntWall-v0, 256 envs, constraint
+net [40, 40], batch 128, 20 epochs; README.md:50 flags), `configs3_one_gpu` (configs[3]'s 2048 envs whole on this GPU) and `configs4`
+(configs[4]'s 512-env shard), each timed the same way.
 
 The JSON line also carries
   roofline      the dual-GAE kernel (the kernel BASELINE.json's metric names): algorithmic 36 B/transition / live event timing
@@ -122,6 +127,94 @@ def update_summary(st, cfg):
                 us_per_rollout_step=(1e3 * float(np.mean(ro)) / cfg.n_steps) if ro else None)
 
 
+def no_early_stop(env_steps, dt, u):
+    """env-steps/s the same iterations would give with every epoch of every train() executed (target_kl never stopping a loop):
+    the executed optimiser steps are replaced by the full count at the measured time per step, everything else as timed."""
+    t_update = u["optimizer_steps"] * u["us_per_optimizer_step"] * 1e-6
+    return env_steps / (dt - t_update + u["full_steps"] * u["us_per_optimizer_step"] * 1e-6)
+
+
+def configs3_one_gpu_leg(seed, steps=1, warmup=1):
+    """EXTRA: BASELINE configs[3]'s 2048 HCWithPos envs WHOLE on this GPU (rollout_multi_kernel, 10 epochs x 65 536 minibatches)."""
+    cfg = config2(steps + warmup, seed, 0, 1, 2048)
+    st, dt, env_steps = timed_iterations(cfg, warmup, steps)
+    u = update_summary(st, cfg)
+    out = dict(workload="HCWithPos-v0 ICRL, BASELINE configs[3]'s 2048 envs on ONE GPU: 1 rollout of 2048 x 2048 + PPO-Lag update of 10 epochs x "
+                        "65 536 minibatches of 64 per outer iteration", value=round(env_steps / dt, 1), unit="env-steps/s", steps=steps, warmup=warmup,
+               ms_per_step=round(1e3 * dt / steps, 2), us_per_optimizer_step=round(u["us_per_optimizer_step"], 2),
+               us_per_rollout_step=None if u["us_per_rollout_step"] is None else round(u["us_per_rollout_step"], 2),
+               optimizer_steps_per_iteration=round(u["optimizer_steps"] / steps, 1), early_stop_fraction=round(1.0 - u["optimizer_steps"] / max(1, u["full_steps"]), 4),
+               value_no_early_stop=round(no_early_stop(env_steps, dt, u), 1))
+    del st
+    torch.cuda.empty_cache()
+    return out
+
+
+def config_cpg(seed, rank, world, envs=512):
+    """BASELINE configs[4] exactly as README.md:78 gives it (AntWallBroken-v0, frozen constraint net through ConstraintNet.load,
+    batch 128, 20 epochs, lr 3e-5, clip 0.4, reward lambda 0.9, -plr 1.0, -tk 0.01); 4096 envs over 8 GPUs = 512 per GPU."""
+    from icrl_amd.cpg import build_parser
+    cfg = vars(build_parser().parse_args(["cpg", "--cn_path", os.path.join(ROOT, "tests/golden/cn_antbroken.npz"), "-tei", "AntWallBroken-v0",
+                                          "-eei", "AntWallBrokenTest-v0", "-tk", "0.01", "--batch_size", "128", "--reward_gae_lambda", "0.9",
+                                          "--n_epochs", "20", "--learning_rate", "3e-5", "--clip_range", "0.4", "-t", "2e6", "-plr", "1.0",
+                                          "-nt", str(envs), "-s", str(seed), "-v", "0"]))
+    cfg.update(rank=rank, world_size=world, save_dir=None)
+    return types.SimpleNamespace(**cfg)
+
+
+def timed_cpg(cfg, warmup, steps, world=1):
+    """cpg (icrl_amd/cpg.py): setup, one untimed learn() of `warmup` rollouts + updates, one timed learn() of `steps` (the
+    reference's cpg is a single learn() call, icrl/cpg.py:203; learn() resets the envs and its step count on every call)."""
+    import torch.distributed as dist
+    from icrl_amd import cpg as C
+    model, cb, learn_cost, _ = C.setup(cfg, log=None)
+    per = cfg.num_threads * cfg.n_steps
+    if warmup > 0:
+        model.learn(total_timesteps=warmup * per, cost_function=learn_cost, callback=cb)
+    model.gae_events, model.train_events, model.rollout_events = [], [], []
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    model.learn(total_timesteps=steps * per, cost_function=learn_cost, callback=cb)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    return model, time.time() - t0, float(model.num_timesteps)
+
+
+def cpg_summary(model, cfg, dt, env_steps, steps, warmup):
+    st = dict(agent=model)
+    u = update_summary(st, cfg)
+    fl = update_flops(113, 8, 64, cfg.batch_size)
+    tf = fl / (u["us_per_optimizer_step"] * 1e-6) / 1e12
+    return u, dict(us_per_optimizer_step=round(u["us_per_optimizer_step"], 2),
+                   us_per_rollout_step=None if u["us_per_rollout_step"] is None else round(u["us_per_rollout_step"], 2),
+                   optimizer_steps_per_iteration=round(u["optimizer_steps"] / steps, 1),
+                   early_stop_fraction=round(1.0 - u["optimizer_steps"] / max(1, u["full_steps"]), 4),
+                   value_no_early_stop=round(no_early_stop(env_steps, dt, u), 1),
+                   update_kernel="ppo_train_rows_kernel (two workgroups per network: 6 CUs)", rollout_kernel="rollout_wide_kernel",
+                   update_tflops=round(tf, 4), update_frac_of_6cu_fp32_mfma_peak=round(tf / (F32_MFMA_PEAK_TFLOPS * 6 / 256), 4))
+
+
+CPG_WORKLOAD = ("AntWall -> AntBroken constraint transfer (cpg, BASELINE configs[4], README.md:78 flags): AntWallBroken-v0, frozen constraint net "
+                "(ConstraintNet.load of the AntBroken checkpoint), {n} envs per GPU, n_steps 2048, batch 128, 20 epochs, lr 3e-5, clip 0.4, "
+                "-plr 1.0, target_kl 0.01 early stops INCLUDED; a step = one rollout + PPO-Lagrangian update of learn() with its "
+                "callbacks (5 evaluation episodes per rollout)")
+
+
+def configs4_leg(seed, steps=1, warmup=1):
+    """EXTRA: BASELINE configs[4]'s per-GPU shard (512 envs) on this GPU."""
+    cfg = config_cpg(seed, 0, 1)
+    model, dt, env_steps = timed_cpg(cfg, warmup, steps)
+    _, extra = cpg_summary(model, cfg, dt, env_steps, steps, warmup)
+    out = dict(workload=CPG_WORKLOAD.format(n=cfg.num_threads), value=round(env_steps / dt, 1), unit="env-steps/s", steps=steps, warmup=warmup,
+               ms_per_step=round(1e3 * dt / steps, 2), **extra)
+    del model
+    torch.cuda.empty_cache()
+    return out
+
+
 def configs2_leg(seed, steps=2, warmup=1):
     """EXTRA, never the headline value: BASELINE configs[2] on this GPU, `steps` timed outer iterations."""
     cfg = config_antwall(seed, 0, 1)
@@ -134,6 +227,7 @@ def configs2_leg(seed, steps=2, warmup=1):
                value=round(env_steps / dt, 1), unit="env-steps/s", steps=steps, warmup=warmup, ms_per_step=round(1e3 * dt / steps, 2),
                us_per_optimizer_step=round(u["us_per_optimizer_step"], 2), us_per_rollout_step=None if u["us_per_rollout_step"] is None else round(u["us_per_rollout_step"], 2),
                optimizer_steps_per_iteration=round(u["optimizer_steps"] / steps, 1), early_stop_fraction=round(1.0 - u["optimizer_steps"] / max(1, u["full_steps"]), 4),
+               value_no_early_stop=round(no_early_stop(env_steps, dt, u), 1),
                update_kernel="ppo_train_rows_kernel (two workgroups per network: 6 CUs)", rollout_kernel="rollout_wide_kernel",
                update_tflops=round(tf, 4), update_frac_of_6cu_fp32_mfma_peak=round(tf / (F32_MFMA_PEAK_TFLOPS * 6 / 256), 4))
     del st
@@ -164,6 +258,30 @@ def gae_sweep_point(N=131072, T=2048, reps=20):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     return dict(envs=N, T=T, bytes=T * N * 36, us=ms * 1e3, achieved=T * N * 36 / (ms * 1e-3) / 1e9)
+
+
+def gae_roofline(sweep, in_loop):
+    """the `roofline` object: the dual-GAE kernel at the HBM-streaming launch shape, timed live with events on the launch stream;
+    `traffic` from the committed PMC passes of the same launch shape (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc passes)."""
+    import glob
+    traffic = None
+    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gae_pmc.json")))      # latest round's passes
+    pmc_path = pmc_files[-1] if pmc_files else ""
+    if os.path.exists(pmc_path):
+        with open(pmc_path) as f:
+            pmc = json.load(f)
+        if pmc["T"] == sweep["T"] and pmc["N"] == sweep["envs"]:
+            traffic = int(pmc["traffic_bytes"])
+    r = dict(kernel="gae_dual_x4_kernel", bound="hbm", achieved=round(sweep["achieved"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
+             frac=round(sweep["achieved"] / HBM_PEAK_GBS, 4), traffic=traffic,
+             traffic_source=(f"not measured in this run: PMC passes of the same launch shape committed as profiles/{os.path.basename(pmc_path)} "
+                             "(FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc passes)") if traffic is not None else None,
+             at=f"T={sweep['T']}, N={sweep['envs']} envs: {sweep['bytes'] / 1e9:.2f} GB algorithmic (36 B/transition), "
+                f"{sweep['us']:.0f} us/launch — far beyond the 256 MB Infinity Cache; four columns per lane (16-byte accesses), "
+                f"{sweep['envs'] // 256} one-wave workgroups")
+    if in_loop is not None:
+        r["in_loop"] = in_loop
+    return r
 
 
 def seed_batch_leg(sizes=(8, 32, 64)):
@@ -222,11 +340,15 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--config", type=int, default=1, choices=(1, 3), help="BASELINE configs[] index of the headline workload: 1 = 64 envs per GPU, 3 = 256 envs per GPU")
+    ap.add_argument("--config", type=int, default=None, choices=(1, 3, 4),
+                    help="BASELINE configs[] index of the headline workload: 1 = 64 HCWithPos envs per GPU (default on one GPU), 3 = 256 per GPU = "
+                         "2048 over 8 GPUs (default with --gpus > 1), 4 = the AntWall -> AntBroken transfer, 512 envs per GPU")
     ap.add_argument("--mode", default="shards", choices=("shards", "seeds"), help="shards: env shards + one all-reduce per outer iteration; seeds: independent runs, no collective")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--no_seed_batch", action="store_true")
     ap.add_argument("--no_configs2", action="store_true")
+    ap.add_argument("--no_configs3", action="store_true")
+    ap.add_argument("--no_configs4", action="store_true")
     ap.add_argument("--envs_per_gpu", type=int, default=None, help="override the env count per GPU (e.g. 2048: BASELINE configs[3] whole on one GPU)")
     a = ap.parse_args()
 
@@ -236,8 +358,40 @@ def main():
     if world == 1 and a.gpus > 1:
         raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", 0)) % torch.cuda.device_count())
+    # the multi-GPU default is a BASELINE config too: configs[3] = 2048 envs over 8 GPUs = 256 per GPU (64 per GPU x 8 would be none)
+    config_id = a.config if a.config is not None else (1 if world == 1 else 3)
 
-    envs = a.envs_per_gpu or (64 if a.config == 1 else 256)
+    def reduce_over_ranks(dt, env_steps):
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=D.reduce_device())
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            s_ = torch.tensor([env_steps], dtype=torch.float64, device=D.reduce_device())
+            dist.all_reduce(s_, op=dist.ReduceOp.SUM)
+            return float(t.item()), float(s_.item())
+        return dt, env_steps
+
+    if config_id == 4:
+        # ---- BASELINE configs[4]: one learn() of `steps` rollouts + updates per rank, all-reduce once per rollout + update
+        seeds = a.mode == "seeds"
+        cfg = config_cpg(a.seed + (rank if seeds else 0), 0 if seeds else rank, 1 if seeds else world, a.envs_per_gpu or 512)
+        model, dt, env_steps = timed_cpg(cfg, a.warmup, a.steps, world)
+        dt, env_steps = reduce_over_ranks(dt, env_steps)
+        if rank != 0:
+            return
+        u, extra = cpg_summary(model, cfg, dt, env_steps, a.steps, a.warmup)
+        sweep = gae_sweep_point()
+        par = (f"env-shards x{world}, 1 all-reduce / rollout + update" if not seeds else f"independent seeds x{world}, no collective")
+        out = dict(metric="env-steps/sec (cpg learn(), AntWallBroken-v0)", value=round(env_steps / dt, 1), unit="env-steps/s", n_gpus=world,
+                   steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * dt / a.steps, 2), higher_is_better=True, scaling="weak",
+                   vs_baseline=None, dtype="f32", data="synthetic",
+                   config=dict(workload=CPG_WORKLOAD.format(n=cfg.num_threads), envs_per_gpu=cfg.num_threads, n_steps=cfg.n_steps,
+                               batch_size=cfg.batch_size, n_epochs=cfg.n_epochs, baseline_config=4, mode=a.mode, parallelism=par),
+                   roofline=gae_roofline(sweep, None), **extra)
+        out["cpu_baseline"] = None
+        print(json.dumps(out))
+        return
+
+    envs = a.envs_per_gpu or (64 if config_id == 1 else 256)
     if a.mode == "seeds":      # independent runs: every rank is a 1-rank job with its own seed; the only collectives are the timing ones below
         cfg = config2(a.steps + a.warmup, a.seed + rank, 0, 1, envs)
     else:
@@ -245,13 +399,7 @@ def main():
 
     # ---- the outer loop, one iteration at a time (identical calls to icrl_amd.icrl.icrl; see that function)
     st, dt, env_steps = timed_iterations(cfg, a.warmup, a.steps, world)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=D.reduce_device())
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        s = torch.tensor([env_steps], dtype=torch.float64, device=D.reduce_device())
-        dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        env_steps = float(s.item())
+    dt, env_steps = reduce_over_ranks(dt, env_steps)
     if rank != 0:
         return
 
@@ -261,26 +409,10 @@ def main():
     gae_bytes = T * N * 36
     gae_ach = gae_bytes / (np.mean(gae_us) * 1e-6) / 1e9
     sweep = gae_sweep_point()
-    traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE), same shape
-    import glob
-    pmc_files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*gae_pmc.json")))      # latest round's passes
-    pmc_path = pmc_files[-1] if pmc_files else ""
-    if os.path.exists(pmc_path):
-        with open(pmc_path) as f:
-            pmc = json.load(f)
-        if pmc["T"] == sweep["T"] and pmc["N"] == sweep["envs"]:
-            traffic = int(pmc["traffic_bytes"])
-    roofline = dict(kernel="gae_dual_x4_kernel", bound="hbm", achieved=round(sweep["achieved"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(sweep["achieved"] / HBM_PEAK_GBS, 4), traffic=traffic,
-                    traffic_source=(f"not measured in this run: PMC passes of the same launch shape committed as profiles/{os.path.basename(pmc_path)} "
-                                    "(FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc passes)") if traffic is not None else None,
-                    at=f"T={sweep['T']}, N={sweep['envs']} envs: {sweep['bytes'] / 1e9:.2f} GB algorithmic (36 B/transition), "
-                       f"{sweep['us']:.0f} us/launch — far beyond the 256 MB Infinity Cache; four columns per lane (16-byte accesses), "
-                       f"{sweep['envs'] // 256} one-wave workgroups",
-                    in_loop=dict(achieved=round(gae_ach, 1), frac=round(gae_ach / HBM_PEAK_GBS, 5), us_per_launch=round(float(np.mean(gae_us)), 1),
-                                 launches=len(gae_us), bytes_per_launch=gae_bytes,
-                                 note="the launch the loop itself makes (cache-resident, latency-bound): two-level scan, "
-                                      "time axis split over workgroups x 8 waves (gae_dual_split_kernel)"))
+    roofline = gae_roofline(sweep, dict(achieved=round(gae_ach, 1), frac=round(gae_ach / HBM_PEAK_GBS, 5), us_per_launch=round(float(np.mean(gae_us)), 1),
+                                        launches=len(gae_us), bytes_per_launch=gae_bytes,
+                                        note="the launch the loop itself makes (cache-resident, latency-bound): two-level scan, "
+                                             "time axis split over workgroups x 8 waves (gae_dual_split_kernel)"))
     # ---- the PPO kernel: algorithmic flops per optimiser step (update_flops) / the events around icrl_ppo_lag_train
     u = update_summary(st, cfg)
     B = cfg.batch_size
@@ -299,20 +431,25 @@ def main():
     out = dict(metric="env-steps/sec (ICRL outer loop, HCWithPos-v0)", value=round(env_steps / dt, 1), unit="env-steps/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * dt / a.steps, 2), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload=f"HCWithPos-v0 ICRL (BASELINE configs[{a.config}]" + ("" if a.config == 1 else ": 2048 envs sharded 8 ways = 256 per GPU") +
+               config=dict(workload=f"HCWithPos-v0 ICRL (BASELINE configs[{config_id}]" + ("" if config_id == 1 else ": 2048 envs sharded 8 ways = 256 per GPU") +
                                     f"): {N} vectorised envs per GPU, n_steps 2048, forward_timesteps 2e5 ({-(-cfg.forward_timesteps // (N * T))} rollout(s) + "
                                     f"PPO-Lag update(s) of 10 epochs x {N * T // B} minibatches of 64, target_kl 0.01 early stops INCLUDED: value moves with the "
                                     "iteration count, us_per_optimizer_step does not), 10 nominal + 10 eval episodes, constraint net [20] x 10 backward iterations",
                            envs_per_gpu=N, n_steps=T, batch_size=B, n_epochs=cfg.n_epochs, forward_timesteps=cfg.forward_timesteps,
-                           baseline_config=a.config, mode=a.mode, parallelism=par),
+                           baseline_config=config_id, mode=a.mode, parallelism=par),
                optimizer_steps_per_iteration=round(u["optimizer_steps"] / a.steps, 1),
                early_stop_fraction=round(1.0 - u["optimizer_steps"] / max(1, u["full_steps"]), 4),
+               value_no_early_stop=round(no_early_stop(env_steps / world, dt, u) * world, 1),      # (rank 0's step counts stand for every rank's)
                roofline=roofline, roofline_ppo=roofline_ppo)
     out["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline()      # reported at N = 1 only
     del st
     torch.cuda.empty_cache()
     if world == 1 and not a.no_configs2:
         out["configs2"] = configs2_leg(a.seed)
+    if world == 1 and not a.no_configs3 and config_id == 1 and a.envs_per_gpu is None:
+        out["configs3_one_gpu"] = configs3_one_gpu_leg(a.seed)
+    if world == 1 and not a.no_configs4:
+        out["configs4"] = configs4_leg(a.seed)
     if world == 1 and not a.no_seed_batch:
         out["seed_batch"] = seed_batch_leg()
     print(json.dumps(out))

@@ -222,3 +222,40 @@ class AdjustedRewardCallback(BaseCallback):
             rec["true_cost"] = float(c.double().mean().item()) if hasattr(c, "double") else float(np.mean(c))
             logger.record("eval/true_cost", rec["true_cost"])
         self.history.append(rec)
+
+
+class RankSyncCallback(BaseCallback):
+    """Multi-GPU cpg (ours; the reference has no multi-device mode): rank r steps its own env shard and runs
+    its own PPO epochs; before every rollout but the first, and once more when learn() ends, ONE flat float64 all-reduce
+    (icrl_amd/distributed.py: allreduce_state, RCCL over xGMI) averages policy parameters / Adam moments / the dual variable,
+    agrees on the step counters and merges the three running-moment sets exactly — the same message as an outer ICRL iteration's,
+    without the constraint net (frozen here)."""
+
+    def __init__(self, train_env, world):
+        super().__init__()
+        self.train_env, self.world, self.rollouts = train_env, world, 0
+
+    def _on_training_start(self):
+        from . import distributed as D
+        env = self.train_env
+        self.rms_list = [r for r in (getattr(env, "obs_rms", None), getattr(env, "ret_rms", None), getattr(env, "cost_rms", None)) if r is not None]
+        self.rms_prev = [D._rms_sums(r, "cpu").numpy() for r in self.rms_list]
+        self.rollouts = 0
+
+    def synchronise(self):
+        from . import distributed as D
+        pol, dual = self.model.policy, self.model.dual
+        if hasattr(dual, "log_nu"):
+            scal = D.Scalars(avg=[(dual, "log_nu"), (dual, "m"), (dual, "v")], counters=[(pol, "adam_step"), (dual, "t")])
+        else:
+            scal = D.Scalars(avg=[(dual, "pid_i"), (dual, "cost_penalty"), (dual, "_delta_p"), (dual, "_cost_delta")], counters=[(pol, "adam_step")])
+        self.rms_prev = D.allreduce_state([pol.params, pol.exp_avg, pol.exp_avg_sq], self.rms_list, self.rms_prev, self.world, scalars=scal)
+        pol.prepare()
+
+    def _on_rollout_start(self):
+        if self.rollouts > 0:
+            self.synchronise()
+        self.rollouts += 1
+
+    def _on_training_end(self):
+        self.synchronise()

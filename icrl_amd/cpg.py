@@ -42,9 +42,11 @@ class _History(callbacks.BaseCallback):
             self.log(json.dumps(rec))
 
 
-def cpg(config, log=print):
+def setup(config, log=print):
+    """everything of cpg() up to the learn() call: (model, callback, cost argument of learn(), history callback).  bench.py times
+    learn() calls on the result; cpg() below is setup + one learn()."""
     logger.configure()          # a fresh scalar log per run (the reference configures its logger in learn())
-    rank = getattr(config, "rank", 0)
+    rank, world = getattr(config, "rank", 0), getattr(config, "world_size", 1)
     dev = config.device if str(config.device).startswith("cuda") else "cuda"
     train_env = utils.make_train_env(env_id=config.train_env_id, save_dir=config.save_dir, use_cost_wrapper=True,
                                      base_seed=config.seed, num_threads=config.num_threads,
@@ -99,6 +101,8 @@ def cpg(config, log=print):
         policy_kwargs=dict(net_arch=utils.get_net_arch(config)),
         action_noise=getattr(config, "action_noise", "device"), permutation=getattr(config, "permutation", "numpy"),
         streams=getattr(config, "streams", None))
+    if world > 1:      # all ranks hold the same initial networks (same seed); from here on rank r draws its own noise / permutations
+        D.decorrelate_streams(config.seed, rank)
     # ref: icrl/cpg.py:160-176
     hist = _History(log if (config.verbose > 0 and rank == 0) else None)
     eval_every = int(config.eval_every) if not getattr(config, "eval_every_rollouts", 0) else int(config.eval_every_rollouts) * int(config.n_steps)
@@ -108,9 +112,17 @@ def cpg(config, log=print):
            callbacks.AdjustedRewardCallback(get_true_cost_function(config.eval_env_id)), hist]
     if config.save_dir and rank == 0:
         cbs.insert(0, callbacks.CheckpointCallback(int(config.save_every), os.path.join(config.save_dir, "models"), verbose=0))
+    if world > 1:      # env shards (BASELINE configs[4]: 4096 envs over 8 GPUs): one all-reduce per rollout + update
+        cbs.insert(0, callbacks.RankSyncCallback(train_env, world))
     cb = callbacks.CallbackList(cbs)
     # ref: icrl/cpg.py:201-203 — `-cis None` hands the callable itself to learn() (costs evaluated outside the env chain)
     learn_cost = config.cost_info_str if config.cost_info_str is not None else cost_function
+    return model, cb, learn_cost, hist
+
+
+def cpg(config, log=print):
+    rank = getattr(config, "rank", 0)
+    model, cb, learn_cost, hist = setup(config, log)
     model.learn(total_timesteps=int(config.timesteps), cost_function=learn_cost, callback=cb)
     if config.save_dir and rank == 0:
         torch.save(model.policy.state_dict(), os.path.join(config.save_dir, "final_model_policy.pth"))
@@ -162,6 +174,7 @@ def main(argv=None):
     if config["seed"] is None:
         config["seed"] = int(np.random.randint(0, 100))
     rank, world = D.init_from_env()
+    config["seed"] = D.broadcast_seed(config["seed"], rank, world)     # every rank builds the same initial networks
     config["rank"], config["world_size"] = rank, world
     if config["save_dir"]:
         os.makedirs(config["save_dir"], exist_ok=True)

@@ -40,8 +40,9 @@
 #ifndef ICRL_L1_TAILQ
 #define ICRL_L1_TAILQ 1
 #endif
-#ifndef ICRL_LEAN_GATHER
-#define ICRL_LEAN_GATHER 1
+// head outputs along the lane groups (see `out_of`): the dH2 GEMM then needs ceil(n_out / 4) of its 4 MFMAs per tile
+#ifndef ICRL_HEAD_PERM
+#define ICRL_HEAD_PERM 1
 #endif
 #ifndef ICRL_STATS_WAVE0
 #define ICRL_STATS_WAVE0 4
@@ -175,6 +176,16 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   const int r = lane & 15, q = lane >> 4;
   const int O = a.L.O, A = a.L.A;
   const int n_out = role == 0 ? A : 1;
+  // Where a head output sits in the 16-wide M / K index of the head GEMMs ("position").  An MFMA's C layout gives lane (r, q) the
+  // positions 4 q + i (i = 0..3), and as a K index MFMA e covers the positions 4 q + e of its four lane groups.  With output o at
+  // position p = 4 (o % 4) + o / 4 (a 4 x 4 transpose, its own inverse) lane (r, q) holds the outputs o = 4 i + q, and MFMA e of
+  // dH2 = Wh^T . dOut covers the outputs 4 e .. 4 e + 3: the MFMAs with 4 e >= n_out multiply zeros and are not issued (6 actions:
+  // 2 of 4; a critic: 1 of 4).  Every head image (WH, WHT, BH, LS, GAU, ACT, DOT, PLS) is indexed by position; only the places
+  // that meet a real output index (parameter load / write-back, masks against n_out, the staged action columns) go through
+  // out_of / pos_of.
+  auto out_of = [&](int i) { return ICRL_HEAD_PERM ? 4 * i + q : 4 * q + i; };      // output of this lane's C-layout element i
+  auto pos_of = [](int o) { return ICRL_HEAD_PERM ? 4 * (o & 3) + (o >> 2) : o; };   // position of output o (and back)
+  const int ro = pos_of(r);                                                          // the output at position r
   const int T = a.buf.T, N = a.buf.N;
   const float nu = as_global(a.nu)[0];
   const int n_steps = a.n_steps;
@@ -270,7 +281,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       f32x4 pv;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int o = 4 * q + i, j = 16 * rt + r;
+        const int o = out_of(i), j = 16 * rt + r;
         pv[i] = o < n_out ? a.params[gWh + o * HD + j] : 0.f;
         mWh[i] = o < n_out ? a.exp_avg[gWh + o * HD + j] : 0.f;
         vWh[i] = o < n_out ? a.exp_avg_sq[gWh + o * HD + j] : 0.f;
@@ -278,8 +289,8 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       store_wh(pv);
       mb1 = a.exp_avg[gb1 + jb]; vb1 = a.exp_avg_sq[gb1 + jb];
       mb2 = a.exp_avg[gb2 + jb]; vb2 = a.exp_avg_sq[gb2 + jb];
-      if (w == 0 && r < n_out) { ex_g = gbh + r; ex_s = S::BH + r; }
-      if (w == LS_WAVE && !DISC && role == 0 && r < A) { ex_g = L.log_std + r; ex_s = S::LS + r; }
+      if (w == 0 && ro < n_out) { ex_g = gbh + ro; ex_s = S::BH + r; }      // lane r: the entry at POSITION r
+      if (w == LS_WAVE && !DISC && role == 0 && ro < A) { ex_g = L.log_std + ro; ex_s = S::LS + r; }
       if (ex_g >= 0) { mex = a.exp_avg[ex_g]; vex = a.exp_avg_sq[ex_g]; }
       if (q == 0) {
         sm[S::B1 + jb] = a.params[gb1 + jb]; sm[S::B2 + jb] = a.params[gb2 + jb];
@@ -330,7 +341,6 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   // and staged as they are: a row b >= nrows contributes nothing (its d loss / d output is forced to 0 by `valid`), and the
   // k >= obs columns of X only ever meet the zero pad columns of W1 (the dW1 step below keeps those at zero).  So the staging
   // path carries no masks and no branches; offsets are 32-bit element indices (the C ABI checks T * N * obs < 2^30).
-#if ICRL_LEAN_GATHER
   // Lean form: (i) with the observation width known at compile time only the pieces that hold real components are fetched and
   // staged (obs 18: 3 of 4 per thread; the X^T rows k >= obs keep the zeros of the start), (ii) the second action piece only when
   // there are more than 8 actions, (iii) ONE of the three per-row scalars per thread — thread gpart of a row fetches scalar gpart
@@ -357,37 +367,11 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 #pragma unroll
     for (int i = 0; i < XRL; ++i) { const int k = gpart + 8 * i; if (OBS > 0 ? k < OBS : k < S::O16) sm[xbase + k * ST + gb_row] = px[i]; }
     if (role == 0) {
-      sm[S::ACT + gb_row * SA + gpart] = gpart < AS ? pact[0] : 0.f;                           // pad actions are 0
-      if (two_act) sm[S::ACT + gb_row * SA + gpart + 8] = gpart + 8 < AS ? pact[1] : 0.f;      // (<= 8 actions: columns 8.. keep the zeros of the start)
+      sm[S::ACT + gb_row * SA + pos_of(gpart)] = gpart < AS ? pact[0] : 0.f;                           // pad actions are 0
+      if (two_act) sm[S::ACT + gb_row * SA + pos_of(gpart + 8)] = gpart + 8 < AS ? pact[1] : 0.f;      // (<= 8 actions: those columns keep the zeros of the start)
     }
     sm[sc_dst] = psc;
   };
-#else
-  float px[XR], pact[2], psc0 = 0.f, psc1 = 0.f, psc2 = 0.f;
-  auto issue_rows = [&](int idx) {
-    if (ICRL_DIAG & 128) return;
-    const unsigned off = idx >= 0 ? (unsigned)idx : 0u;
-    const unsigned ob = off * (unsigned)O;
-#pragma unroll
-    for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; px[i] = p_obs[ob + (unsigned)(k < O ? k : O - 1)]; }
-    {   // (the critics fetch the action bytes too: two loads are cheaper than a branch in the middle of the load stream)
-      const unsigned ab = off * (unsigned)AS;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; pact[i] = p_act[ab + (unsigned)(k < AS ? k : AS - 1)]; }
-    }
-    psc0 = p_s0[off]; psc1 = p_s1[off]; psc2 = p_s2[off];
-  };
-  auto commit_rows = [&](int xbase) {
-    if (ICRL_DIAG & 128) return;
-#pragma unroll
-    for (int i = 0; i < XR; ++i) { const int k = gpart + 8 * i; if (k < S::O16) sm[xbase + k * ST + gb_row] = px[i]; }
-    if (role == 0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) { const int k = gpart + 8 * i; sm[S::ACT + gb_row * SA + k] = k < AS ? pact[i] : 0.f; }   // pad actions are 0
-    }
-    if (gpart == 0) { sm[S::OLP + gb_row] = psc0; sm[S::ADR + gb_row] = psc1; sm[S::ADC + gb_row] = psc2; }
-  };
-#endif
   float sar = 0.f, sac = 0.f;
   auto issue_stats = [&](int idx) {
     const unsigned off = idx >= 0 ? (unsigned)idx : 0u;
@@ -425,10 +409,10 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       const float wex = sm[S::LS + r];
       const float sd = __expf(wex);
       const float iv = __builtin_amdgcn_rcpf(sd * sd);
-      sm[S::GAU + r] = r < A ? iv : 0.f;
-      sm[S::GAU + 16 + r] = r < A ? 0.5f * iv : 0.f;
-      sm[S::GAU + 32 + r] = r < A ? wex + LOG_SQRT_2PI_F : 0.f;
-      const float ent = row_sum(r < A ? HALF_LOG_2PI_PLUS_HALF_F + wex : 0.f);
+      sm[S::GAU + r] = ro < A ? iv : 0.f;
+      sm[S::GAU + 16 + r] = ro < A ? 0.5f * iv : 0.f;
+      sm[S::GAU + 32 + r] = ro < A ? wex + LOG_SQRT_2PI_F : 0.f;
+      const float ent = row_sum(ro < A ? HALF_LOG_2PI_PLUS_HALF_F + wex : 0.f);
       if (r == 0) sm[S::MISC + 22] = ent;
     }
   };
@@ -664,23 +648,24 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       } else {
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
         if (role == 0) {
+          const int ngp = ICRL_HEAD_PERM ? (A + 3) >> 2 : 4;      // groups of four outputs that hold real ones
           float lp = 0.f, ent = 0.f;
           f32x4 g1 = f32x4{0.f, 0.f, 0.f, 0.f}, g2 = f32x4{0.f, 0.f, 0.f, 0.f};
           if (DISC) {
             float lg[4], zmax = -INFINITY;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { lg[i] = (4 * q + i < A) ? outc[i] : -INFINITY; zmax = fmaxf(zmax, lg[i]); }
+            for (int i = 0; i < 4; ++i) { lg[i] = (out_of(i) < A) ? outc[i] : -INFINITY; zmax = fmaxf(zmax, lg[i]); }
             zmax = xor16_max(xor32_max(zmax));
             float se = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) se += (4 * q + i < A) ? expf(lg[i] - zmax) : 0.f;
+            for (int i = 0; i < 4; ++i) se += (out_of(i) < A) ? expf(lg[i] - zmax) : 0.f;
             se = quad_rows_sum(se);
             const float lse = zmax + logf(se);
             const int act = (int)sm[S::ACT + b * SA];
             float pr[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int k = 4 * q + i;
+              const int k = out_of(i);
               lg[i] = k < A ? lg[i] - lse : 0.f;
               pr[i] = k < A ? expf(lg[i]) : 0.f;
               lp += (k == act) ? lg[i] : 0.f;
@@ -690,20 +675,22 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
             ent = quad_rows_sum(ent);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              const int k = 4 * q + i;
+              const int k = out_of(i);
               g1[i] = k < A ? ((k == act ? 1.f : 0.f) - pr[i]) : 0.f;
               g2[i] = k < A ? pr[i] * (lg[i] + ent) : 0.f;
             }
           } else {
             const f32x4 actv = lds128(sm + S::ACT + b * SA + 4 * q);
             const f32x4 iv = lds128(sm + S::GAU + 4 * q), hiv = lds128(sm + S::GAU + 16 + 4 * q), lsd = lds128(sm + S::GAU + 32 + 4 * q);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            // elements i with 4 i >= A are head padding in every lane group (out_of): all their terms are zeros, skipped
+            auto elem = [&](int i) {
               const float dd = actv[i] - outc[i];
               lp += -(dd * dd) * hiv[i] - lsd[i];
               g1[i] = dd * iv[i];
-              g2[i] = (4 * q + i < A) ? (dd * dd) * iv[i] - 1.f : 0.f;
-            }
+              g2[i] = (out_of(i) < A) ? (dd * dd) * iv[i] - 1.f : 0.f;
+            };
+            elem(0);
+            if (ngp > 1) { elem(1); if (ngp > 2) { elem(2); elem(3); } }
             lp = quad_rows_sum(lp);
           }
           const float old_lp = sm[S::OLP + b];
@@ -720,9 +707,10 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 #pragma unroll
             for (int i = 0; i < 4; ++i) dout[i] = dlp * g1[i] + dent * g2[i];
           } else {
-            f32x4 t;       // d log_std: sum over this tile's 16 rows, per output o = 4q + i
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { dout[i] = dlp * g1[i]; t[i] = row_sum(dlp * g2[i]); }
+            f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};       // d log_std: sum over this tile's 16 rows, per element i (output out_of(i))
+            auto dls = [&](int i) { dout[i] = dlp * g1[i]; t[i] = row_sum(dlp * g2[i]); };
+            dls(0);
+            if (ngp > 1) { dls(1); if (ngp > 2) { dls(2); dls(3); } }
             if (low && r == 0) *reinterpret_cast<f32x4*>(sm + S::PLS + 16 * rt + 4 * q) = t;
           }
           const bool cnt = valid && q == 0;
@@ -753,21 +741,34 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       FSTAMP(6)   // partial read + loss
       // ================= backward of the activations =================
       f32x4 dz2c[2], dz1c[2];
-      {  // dH2^T = Wh^T . dOut^T for the own feature tiles: A = WHT[j = 16 t + r][o = 4 q + e] (K = 16 outputs)
+      {  // dH2^T = Wh^T . dOut^T for the own feature tiles: A = WHT[j = 16 t + r][position 4 q + e] (K = 16 head positions);
+         // MFMA e covers the outputs 4 e .. 4 e + 3 (out_of): those with 4 e >= n_out would multiply zeros
+        const int ng = ICRL_HEAD_PERM ? (n_out + 3) >> 2 : 4;
+        f32x4 aw[2], acc[2];
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           const int t = 2 * fh + tt;
-          f32x4 aw;
-          if (S::WHTC) aw = lds128(sm + S::WHT + (16 * t + r) * SA + 4 * q);
+          if (S::WHTC) aw[tt] = lds128(sm + S::WHT + (16 * t + r) * SA + 4 * q);
           else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) aw[e] = sm[S::WH + (4 * q + e) * SH + 16 * t + r];
+            for (int e = 0; e < 4; ++e) aw[tt][e] = sm[S::WH + (4 * q + e) * SH + 16 * t + r];
           }
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[e], dout[e], acc);
+        for (int tt = 0; tt < 2; ++tt) acc[tt] = MFMA_F32(aw[tt][0], dout[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
+        if (ng > 1) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) dz2c[tt][i] = fmaf(-(h2c[tt][i] * h2c[tt][i]), acc[i], acc[i]);   // acc (1 - h2^2)
+          for (int tt = 0; tt < 2; ++tt) acc[tt] = MFMA_F32(aw[tt][1], dout[1], acc[tt]);
+          if (ng > 2) {
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) { acc[tt] = MFMA_F32(aw[tt][2], dout[2], acc[tt]); acc[tt] = MFMA_F32(aw[tt][3], dout[3], acc[tt]); }
+          }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          const int t = 2 * fh + tt;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dz2c[tt][i] = fmaf(-(h2c[tt][i] * h2c[tt][i]), acc[tt][i], acc[tt][i]);   // acc (1 - h2^2)
 #pragma unroll
           for (int i = 0; i < 4; ++i) pt[S::DZ2T + (16 * t + i) * ST] = dz2c[tt][i];
         }
@@ -922,7 +923,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     }  // chunks
 
     // entropy term of the Gaussian policy loss: d(ent_coef * -mean(H)) / d log_std = -ent_coef
-    if (!DISC && role == 0 && w == LS_WAVE && r < A) gex += -ent_coef;
+    if (!DISC && role == 0 && w == LS_WAVE && ro < A) gex += -ent_coef;
 
     // ================= global gradient norm: this wave's partial sum of squares -> its own 8-byte granule =================
     float ss = 0.f;
@@ -1127,7 +1128,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     const f32x4 pv = load_own_wh();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int o = 4 * q + i, j = 16 * rt + r;
+      const int o = out_of(i), j = 16 * rt + r;
       if (o < n_out) { a.params[gWh + o * HD + j] = pv[i]; a.exp_avg[gWh + o * HD + j] = mWh[i]; a.exp_avg_sq[gWh + o * HD + j] = vWh[i]; }
     }
     if (q == 0) {

@@ -352,11 +352,18 @@ class PPOLagrangian:
             path += ".zip"
         with zipfile.ZipFile(path) as z:
             data = parse_sb3_data(z.read("data"))
-            sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=False)
+            # a state dict of tensors: weights_only refuses anything else (an archive is untrusted input; the `data` entry next to it
+            # goes through the allow-list unpickler of utils.parse_sb3_data for the same reason)
+            sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
         # network widths (-pl / -rvl / -cvl): read off the stored tensors, whoever wrote the archive
         if any(k.startswith("mlp_extractor.shared_net") for k in sd):
             raise NotImplementedError("archives with a shared trunk (-sl) are outside this build (policies.py)")
-        w = lambda b: [int(sd[f"mlp_extractor.{b}.0.weight"].shape[0]), int(sd[f"mlp_extractor.{b}.2.weight"].shape[0])]
+        def w(b):      # the Linear layers of a branch sit at even indices of its Sequential (torch_layers.py:208-226)
+            idx = sorted(int(k.split(".")[2]) for k in sd if k.startswith(f"mlp_extractor.{b}.") and k.endswith(".weight"))
+            if idx != [0, 2]:
+                raise NotImplementedError(f"archive: {len(idx)} hidden layers in mlp_extractor.{b} (Linear layers at {idx}); this build's policies "
+                                          "have exactly two per branch (policies.py)")
+            return [int(sd[f"mlp_extractor.{b}.{i}.weight"].shape[0]) for i in idx]
         net_arch = [dict(pi=w("policy_net"), vf=w("value_net"), cvf=w("cost_value_net"))]
         if "observation_dim" in data and "observation_space" not in data:      # archive written by save() of this build
             o, a = int(data["observation_dim"]), int(data["action_dim"])

@@ -81,11 +81,16 @@ class SeedBatch:
         c0 = self.states[0]["config"]
         for st in self.states[1:]:
             c = st["config"]
+            # everything a batched launch takes from run 0 only: the grids' shapes, and the discounting of the batched GAE
+            # (icrl_rollout_collect_batch takes the four gamma / lambda values as scalars)
             same = ("train_env_id", "eval_env_id", "num_threads", "n_steps", "batch_size", "n_epochs", "forward_timesteps", "expert_rollouts",
-                    "backward_iters", "cn_batch_size", "cn_layers", "n_iters")
+                    "backward_iters", "cn_batch_size", "cn_layers", "n_iters", "reward_gamma", "reward_gae_lambda", "cost_gamma", "cost_gae_lambda")
             diff = [k for k in same if getattr(c, k) != getattr(c0, k)]
             if diff:
                 raise ValueError(f"seed batch: the runs of a batch share every grid; they differ in {diff}")
+        if any(st.get("world", 1) > 1 for st in self.states):
+            # outer_iteration() below has no per-iteration all-reduce and no rank-0 guard on the saves: a seed batch is a one-rank matter
+            raise ValueError("seed batch: the runs of a batch live on ONE rank (launch the batch per GPU; world_size > 1 states would skip the collective)")
         S = len(self.states)
         self.dev = self.states[0]["agent"].device
         self.args_ws = torch.empty(2 * S * _lib.BATCH_ARGS_BYTES, dtype=torch.uint8, device=self.dev)
@@ -142,10 +147,16 @@ class SeedBatch:
         ws, nbytes = self._ws()
         _lib.check(_lib.lib().icrl_cn_train_batch(len(jobs), arr, ws, nbytes, _lib.current_stream()), "icrl_cn_train_batch")
 
-    def _prefetch_permutations(self, agents):
+    def _prefetch_permutations(self, agents, after=None):
+        """`after`: an event recorded on the main stream BEFORE the update launch — the side stream waits for that point only, so the
+        sorts run beside the update kernels (3 S busy CUs) instead of behind them.  (The draws' order is the host's call order: the
+        Philox offset of the generator advances on the host.)"""
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream()
-        self._side.wait_stream(torch.cuda.current_stream())        # (the generator's device state is ordered with earlier draws)
+        if after is not None:
+            self._side.wait_event(after)
+        else:
+            self._side.wait_stream(torch.cuda.current_stream())
         for a in agents:
             s_ = a.streams
             if s_ is not None and hasattr(s_, "prefetch_permutations"):
@@ -179,13 +190,15 @@ class SeedBatch:
                     logger.record("time/iterations", iteration)
                     logger.record("time/total_timesteps", a.num_timesteps)
                     tjobs.append(a._train_begin(None))
+            before_update = torch.cuda.Event()
+            before_update.record()
             self._launch_trains(agents, tjobs)
             # while the updates run (3 S CUs busy, the host idle): the permutations of the NEXT update, on a side stream — their sorts
             # were ~5 ms of device time + ~7 ms of launches per update phase at S = 32, in front of the update launch.  Not across the end
             # of the forward step when the constraint net draws minibatch permutations from the same generator in between.
             more = agents[0].num_timesteps < totals[0]
             if more or sts[0]["constraint_net"].batch_size is None:
-                self._prefetch_permutations(agents)
+                self._prefetch_permutations(agents, after=before_update)
             host = self._to_host([a.train_readback() for a in agents])          # waits for the update of every run
             for st, a, j, h in zip(sts, agents, tjobs, host):
                 with _as_run(st):

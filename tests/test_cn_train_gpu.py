@@ -171,3 +171,36 @@ def test_cn_train_minibatch_default_stream_matches_oracle():
     for k, v in cn.state_dict().items():
         ref = orc.params[k].detach().numpy()
         assert np.allclose(v.numpy(), ref, rtol=3e-3, atol=3e-4), (k, np.abs(v.numpy() - ref).max())
+
+
+@pytest.mark.parametrize("kind,n", [("hc", 64), ("hc", 1000), ("ant", 333), ("narrow", 200)])
+def test_policy_rows_kernel_vs_oracle(kind, n):
+    """policy_rows_kernel (>= 64 rows: 16 rows per workgroup pass as fp32 MFMA tiles; the KL metrics' evaluate_actions and batched
+    predict) against the oracle's ActorTwoCriticsPolicy.evaluate_actions / forward directly (policies.py:716-731, 752-767;
+    distributions.py:143-171) — not only against the one-workgroup-per-row kernel."""
+    from icrl_amd.policies import ActorTwoCriticsPolicy
+    from icrl_amd import spaces
+    from oracle import nets as o_nets
+    od, ad = (113, 8) if kind == "ant" else (18, 6)
+    torch.manual_seed(11)
+    arch = dict(pi=[40, 24], vf=[64, 20], cvf=[16, 64]) if kind == "narrow" else None
+    kw = dict(net_arch=[arch]) if arch else {}
+    pol = ActorTwoCriticsPolicy(spaces.Box(-np.inf, np.inf, (od,), np.float64), spaces.Box(-1, 1, (ad,), np.float32), **kw)
+    op = o_nets.TwoCriticPolicy(od, ad, **({"hidden": dict(policy_net=arch["pi"], value_net=arch["vf"], cost_value_net=arch["cvf"])} if arch else {}))
+    op.load_state_dict(pol.state_dict())
+    rng = np.random.RandomState(9)
+    obs = (rng.randn(n, od) * 2.0).astype(np.float32)
+    act = rng.randn(n, ad).astype(np.float32)
+    noise = rng.randn(n, ad).astype(np.float32)
+    vr, vc, lp, ent = [t.cpu().numpy().reshape(-1) for t in pol.evaluate_actions(obs, act)]
+    with torch.no_grad():
+        o_vr, o_vc, o_lp, o_ent = op.evaluate_actions(torch.as_tensor(obs), torch.as_tensor(act))
+    for name, got, ref in (("reward_values", vr, o_vr), ("cost_values", vc, o_vc), ("log_prob", lp, o_lp), ("entropy", ent, o_ent)):
+        ref = ref.numpy().reshape(-1)
+        assert np.allclose(got, ref, rtol=1e-5, atol=2e-6), (name, np.abs(got - ref).max())
+    a, fvr, fvc, flp = [t.cpu().numpy() for t in pol.forward(obs, deterministic=False, noise=noise)]
+    with torch.no_grad():
+        o_a, o_fvr, o_fvc, o_flp = op.forward(torch.as_tensor(obs), noise=torch.as_tensor(noise))
+    for name, got, ref in (("actions", a, o_a), ("reward_values", fvr, o_fvr), ("cost_values", fvc, o_fvc), ("log_prob", flp, o_flp)):
+        ref = ref.numpy().reshape(got.shape)
+        assert np.allclose(got, ref, rtol=1e-5, atol=2e-6), (name, np.abs(got - ref).max())

@@ -78,3 +78,45 @@ def test_single_rank_is_identity():
     t = torch.arange(4.0)
     D.allreduce_state([t], [rms], [D.moments_to_sums(*before)], 1)
     assert torch.equal(t, torch.arange(4.0)) and np.allclose(rms.mean, before[0]) and np.allclose(rms.var, before[1])
+
+
+def _worker8(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from icrl_amd import distributed as D
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rms = HostRms(4)
+    common = np.random.RandomState(11).randn(500, 4) * 3 + 50          # a long shared history, mean far from 0: the merge subtracts
+    rms.update(common)                                                 # (G - 1) x its sums, so cancellation would show here
+    rms.count = rms.count * 2000.0                                     # as if ~1e6 samples had been seen (configs[3]: 256 envs x 2048 rows x rollouts)
+    prev = [D.moments_to_sums(rms.mean, rms.var, rms.count)]
+    shard = np.random.RandomState(200 + rank).randn(131072 // 8, 4) * (1 + 0.1 * rank) + 50 + 0.01 * rank
+    rms.update(shard)
+    p = torch.full((3,), float(rank))
+    D.allreduce_state([p], [rms], prev, world)
+    out[rank] = (p.numpy().copy(), rms.mean.copy(), rms.var.copy(), rms.count, shard)
+    dist.destroy_process_group()
+
+
+def test_allreduce_state_world8_merge_is_exact_at_large_counts():
+    """the shape the driver's 8-GPU run has: G = 8 streams sharing a history of ~1e6 samples; S_global = sum_g S_g - (G - 1) S_prev
+    must reproduce the moments of ONE stream that saw the history and then all eight shards (variance to 1e-10 relative)."""
+    G = 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker8, args=(G, port, out), nprocs=G, join=True)
+    ref = HostRms(4)
+    ref.update(np.random.RandomState(11).randn(500, 4) * 3 + 50)
+    ref.count = ref.count * 2000.0
+    for r in range(G):
+        ref.update(out[r][4])
+    for r in range(G):
+        p, mean, var, count, _ = out[r]
+        assert np.allclose(p, np.mean(np.arange(G)))
+        assert np.array_equal(mean, out[0][1]) and np.array_equal(var, out[0][2]) and count == out[0][3]      # identical on every rank
+        assert abs(count - ref.count) <= 1e-9 * ref.count
+        assert np.allclose(mean, ref.mean, rtol=1e-12, atol=0), np.abs(mean - ref.mean).max()
+        assert np.allclose(var, ref.var, rtol=1e-10, atol=0), np.abs(var / ref.var - 1).max()

@@ -28,13 +28,23 @@ from oracle.streams import SeededStreams
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-# The short tests (<= 48 dependent steps, tests/test_ppo_train_gpu.py) hold |dp| <= 5e-4 x lr x steps.  Over 2 x 10^4 dependent steps the
-# two fp32 trajectories separate faster than linearly (Adam turns a rounding-size difference in a near-zero gradient into an lr-size
-# difference in the update); measured on MI355X (two boxes): max |dp| = 0.9-1.1e-2 = 1.4-1.8e-3 x lr x steps after 20 480 steps
-# (distance travelled up to lr x steps = 6.1), 1.3e-2 = 1.0e-3 x lr x steps after 40 960.  What the reference LOGS moved by: nu 0 / 1.2e-7,
-# average_cost 1.2e-7 / 1.0e-4, losses <= 1.5e-6 / 2.8e-5, approx_kl 3e-5, clip_fraction 2.5e-4, early_stop_epoch equal.  The second
-# rollout (collected with the drifted parameters) differs per element by up to 3e-2 (values), 2e-3 (costs).
-ADAM_DEV_BOUND = 6e-3
+# CALIBRATED bounds (round 4).  The short tests (<= 48 dependent steps, tests/test_ppo_train_gpu.py) hold |dp| <= 5e-4 x lr x steps; over
+# 2 x 10^4 dependent steps two fp32 executions of the SAME algorithm separate faster than that (Adam turns a rounding-size difference
+# in a near-zero gradient into an lr-size difference in the update).  How fast is measured, not fitted: tools/calibrate_drift.py runs the
+# CPU port against ITSELF through this test's schedule with a rounding-size disturbance (every initial parameter moved by one float32
+# ulp up / down, the critics' only, 8 torch threads instead of 1) — profiles/r04_drift_calibration.md:
+#                                port vs disturbed port (4 runs)                 HIP vs port (MI355X, round 4)
+#   max |dp| after 20 480 steps  6.5-7.7e-3 = 1.1-1.3e-3 x lr x steps             7.0e-3 = 1.1e-3 x lr x steps
+#   max |dp| after 40 960 steps  1.3-1.6e-2 = 1.1-1.3e-3 x lr x steps             1.3-2.2e-2 = 1.0-1.8e-3 x lr x steps
+#   nu                           0 | <= 4.8e-7                                     0 | 3.6e-7
+#   average_cost                 0 | 1.9-4.5e-4 (rollout 2 is collected with the drifted parameters)   1.2e-7 | 1.0-3.4e-4
+#   losses pg / rv / cv          <= 1.1e-6 | <= 1.0e-5 / 9.6e-5 / 8.9e-5           <= 6.9e-7 | 7.9e-6 / 2.6e-5 / 6.4e-5
+#   early_stop_epoch             equal                                             equal
+# Each bound below is 2 x the largest port-vs-port figure (first | second train()).
+ADAM_DEV_BOUND = 2.6e-3                      # x lr x steps: 2 x 1.3e-3
+NU_BOUND = 1e-6                              # 2 x 4.8e-7
+AVERAGE_COST_BOUND = (1e-6, 9e-4)            # (0 measured: the floor of one float32 mean) | 2 x 4.5e-4
+LOSS_BOUND = (2.5e-6, 2e-4)                  # 2 x 1.1e-6 | 2 x 9.6e-5
 
 
 def _pair(env_id, kind, N, T, od, ad, cn_layers, seed, **kw):
@@ -65,7 +75,7 @@ def _one_cpu_thread():
     torch.set_num_threads(n)
 
 
-def _forward_step(agent, port, env, n_rollouts, lr, target_kl):
+def _forward_step(agent, port, env, n_rollouts, lr, target_kl, calibrated=False):
     """learn() of both sides, rollout by rollout, with a comparison after every train()."""
     from icrl_amd import logger
     T, N = agent.n_steps, agent.n_envs
@@ -118,12 +128,13 @@ def _forward_step(agent, port, env, n_rollouts, lr, target_kl):
             close = abs(kls_hip[e] - thr) / thr if e < len(kls_hip) else float("nan")
             assert close < 2e-3, f"early stop differs (HIP {ee_h}, port {ee_p}) and epoch {e}'s mean KL {kls_hip[e]} is not at the threshold {thr}"
             pytest.skip(f"epoch {e}: mean approx-KL {kls_hip[e]:.7f} sits within {close:.1e} of the 1.5 x target_kl threshold; the decision flips with summation order")
-        assert abs(r["nu"][0] - r["nu"][1]) <= 1e-5, r["nu"]
-        # (the SECOND rollout is collected with parameters that already differ by ~1e-2: its mean cost moves by ~1e-4)
-        assert abs(r["average_cost"][0] - r["average_cost"][1]) <= 1e-5 + 5e-4 * abs(r["average_cost"][1])
-        assert worst_abs <= ADAM_DEV_BOUND * lr * steps + 2e-7, (worst_abs, steps)
+        cal = calibrated
+        assert abs(r["nu"][0] - r["nu"][1]) <= (NU_BOUND if cal else 1e-5), r["nu"]
+        # (the SECOND rollout is collected with parameters that already differ by ~1e-2: its mean cost moves by a few 1e-4)
+        assert abs(r["average_cost"][0] - r["average_cost"][1]) <= (AVERAGE_COST_BOUND[min(k, 1)] if cal else 1e-5 + 5e-4 * abs(r["average_cost"][1]))
+        assert worst_abs <= (ADAM_DEV_BOUND if cal else 6e-3) * lr * steps + 2e-7, (worst_abs, steps)
         for key in ("pg_loss", "rv_loss", "cv_loss"):
-            assert abs(r[key][0] - r[key][1]) <= 5e-5 + 5e-4 * abs(r[key][1]), (key, r[key])      # measured: <= 2.8e-5 (cv, second train())
+            assert abs(r[key][0] - r[key][1]) <= (LOSS_BOUND[min(k, 1)] if cal else 5e-5 + 5e-4 * abs(r[key][1])), (key, r[key])
     print(f"[full-size] CPU port: {t_port:.1f} s for {n_rollouts} x ({N} x {T} env steps + train())")
     return rows
 
@@ -133,14 +144,15 @@ def test_configs1_forward_step_full_size():
     lr 3e-4 — 2 rollouts + 2 train() = up to 40 960 dependent optimiser steps."""
     agent, port, env = _pair("HCWithPos-v0", "hc", 64, 2048, 18, 6, [20], 0, batch_size=64, n_epochs=10, target_kl=0.01,
                              penalty_learning_rate=0.1)
-    rows = _forward_step(agent, port, env, 2, 3e-4, 0.01)
+    rows = _forward_step(agent, port, env, 2, 3e-4, 0.01, calibrated=True)
     assert rows[0]["steps"] > 2048            # at least one whole epoch ran at full size
 
 
 def test_configs2_widths_long_chain():
     """BASELINE configs[2] flags (README.md:50: AntWall, constraint net [40, 40], batch 128 -> the two-workgroup update, 20 epochs,
     lr 3e-5, clip 0.4, lambdas 0.9, nu0 0.1, nu-lr 0.05, target_kl 0.02) at 256 envs x 128 steps: up to 20 x 256 = 5 120 dependent
-    steps per train(), 2 rollouts."""
+    steps per train(), 2 rollouts.  (Bounds: the uncalibrated ones of round 3 — 6e-3 x lr x steps, measured 1e-3; the calibration run of
+    profiles/r04_drift_calibration.md is for configs[1]'s schedule.)"""
     agent, port, env = _pair("AntWall-v0", "ant", 256, 128, 113, 8, [40, 40], 3, batch_size=128, n_epochs=20, target_kl=0.02,
                              learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9, cost_gae_lambda=0.9,
                              penalty_initial_value=0.1, penalty_learning_rate=0.05)

@@ -178,8 +178,13 @@ def test_fused_rollout_vs_reference_golden(golden):
 # ant 96 / hc 256 / antbroken 512: per-step launches (generic normaliser kernel); the others: persistent kernel.
 # hc 256 = the per-GPU shard of BASELINE configs[3] (2048 envs / 8), antbroken 512 = that of configs[4] (4096 envs / 8) with the
 # reference's committed AntBroken constraint net loaded through the (quirky) ConstraintNet.load and action[4:] zeroed.
-@pytest.mark.parametrize("kind,N,T", [("hc", 64, 300), ("ant", 96, 40), ("ant", 32, 60), ("hc", 256, 40), ("antbroken", 512, 12)])
-def test_fused_rollout_vs_port(kind, N, T):
+# kernel "multi": rollout_multi_kernel (MFMA tiles, several envs per workgroup: every seed-batch rollout and any run with more than 1024
+# envs) forced at shapes the other kernels normally serve, so that it is compared with the ORACLE directly and not only with the
+# per-step launches (on_policy_algorithm.py:340-421, policies.py:716-731).
+@pytest.mark.parametrize("kind,N,T,kernel", [("hc", 64, 300, "auto"), ("ant", 96, 40, "auto"), ("ant", 32, 60, "auto"), ("hc", 256, 40, "auto"),
+                                             ("antbroken", 512, 12, "auto"), ("hc", 64, 300, "multi"), ("antbroken", 512, 12, "multi"),
+                                             ("ant", 96, 40, "multi")])
+def test_fused_rollout_vs_port(kind, N, T, kernel):
     """same comparison at HC / Ant shapes with freshly initialised nets; also crosses episode ends (hc T=300 < 1000: none,
     so the env is pre-stepped to t_ep = 900 first)."""
     import os
@@ -204,6 +209,7 @@ def test_fused_rollout_vs_port(kind, N, T):
         cn.load_state_dict(ocn.state_dict())
     env.set_cost_function(cn.cost_function)
     agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=7)   # learn() re-seeds the env with the agent seed
+    agent.rollout_kernel = kernel
     stack = o_loop.make_stack(N, ekind, 7, broken=broken); stack.cost_fn = ocn.cost_function
     port = o_loop.PortAgent(stack, n_steps=T, seed=7)
     port.policy.load_state_dict(agent.policy.state_dict())        # same seed gives the same init; make it explicit anyway

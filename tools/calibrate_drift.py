@@ -1,0 +1,88 @@
+"""CPU only: how far do two runs of the SAME algorithm drift apart over the full-size forward step of BASELINE configs[1]?
+
+The full-size parity test (tests/test_fullsize_parity_gpu.py) compares the HIP path with the CPU port after 20 480 and 40 960 dependent
+optimiser steps.  Its bounds must not be fitted to what the HIP path happened to show: this tool runs the PORT against ITSELF through the
+same schedule (64 envs x 2048 steps, 10 epochs x 2048 minibatches of 64, target_kl 0.01, SeededStreams(77), seed 0) with a rounding-size
+disturbance, and reports the same quantities the test asserts on.  Any correct fp32 implementation that differs from the port in
+summation order is such a disturbance, so these numbers are the floor a HIP-vs-port bound can be held to.
+
+    python tools/calibrate_drift.py run <variant> <out.json>     variant: base | ulp / ulpm (every initial parameter moved to the next float32 above / below) | ulpc (the critics' only)
+                                                                          | ulp1 (ONE parameter moved by one ulp) | threads8
+    python tools/calibrate_drift.py compare base.json other.json ...
+"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+
+def run(variant, out_path):
+    from oracle import loop as o_loop, nets as o_nets
+    from oracle.streams import SeededStreams
+    torch.set_num_threads(8 if variant == "threads8" else 1)
+    N, T, od, ad, seed = 64, 2048, 18, 6, 0
+    lo = -np.ones(ad, np.float32)
+    torch.manual_seed(seed + 1)
+    ocn = o_nets.CostNet(od, ad, [20], False, None, None, 20, lo, -lo)
+    stack = o_loop.make_stack(N, "hc", seed); stack.cost_fn = ocn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=T, seed=seed, batch_size=64, n_epochs=10, target_kl=0.01, penalty_learning_rate=0.1)
+    with torch.no_grad():
+        if variant == "ulp":
+            for p in port.policy.parameters():
+                p.copy_(torch.nextafter(p, torch.full_like(p, float("inf"))))
+        elif variant == "ulpm":       # every parameter to the next float32 below
+            for p in port.policy.parameters():
+                p.copy_(torch.nextafter(p, torch.full_like(p, float("-inf"))))
+        elif variant == "ulpc":       # the critics' parameters only (the policy network starts identical)
+            for n, p in port.policy.params.items():
+                if "value" in n or "vf" in n:
+                    p.copy_(torch.nextafter(p, torch.full_like(p, float("inf"))))
+        elif variant == "ulp1":
+            p = next(iter(port.policy.parameters()))
+            p.view(-1)[0] = torch.nextafter(p.view(-1)[0], torch.tensor(float("inf")))
+    streams = SeededStreams(77)
+    port.num_timesteps = 0
+    port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
+    res, t0 = [], time.time()
+    for k in range(2):
+        b = port.collect_rollouts(streams.rollout_noise(T, N, port.act_dim))
+        out = port.train(lambda e: streams.permutation(e, T * N))
+        streams.consumed(min(int(out["train/early_stop_epoch"]) + 1, 10))
+        res.append(dict(
+            scalars={k_: float(out[k_]) for k_ in ("train/nu", "train/average_cost", "train/early_stop_epoch", "train/policy_gradient_loss",
+                                                   "train/reward_value_loss", "train/cost_value_loss", "train/approx_kl", "train/clip_fraction")},
+            epoch_kls=[float(x) for x in out.get("epoch_kls", [])],
+            params={n: v.detach().numpy().ravel().tolist() for n, v in port.policy.params.items()},
+            buffer={f: getattr(b, f).astype(np.float64).ravel()[::17].tolist() for f in ("rewards", "costs", "reward_values", "reward_advantages", "cost_advantages", "log_probs")}))
+        print(variant, "train", k + 1, "done", round(time.time() - t0, 1), "s", flush=True)
+    json.dump(res, open(out_path, "w"))
+
+
+def compare(base_path, others):
+    base = json.load(open(base_path))
+    lr = 3e-4
+    print("| disturbance | after | nu | average_cost | losses pg / rv / cv | approx_kl | clip_fraction | early_stop_epoch | max abs parameter difference | buffer (sampled) values / advantages |")
+    print("|---|---|---|---|---|---|---|---|---|---|")
+    for path in others:
+        o = json.load(open(path))
+        for k in range(2):
+            a, b = base[k], o[k]
+            d = lambda key: abs(a["scalars"][key] - b["scalars"][key])
+            dp = max(float(np.abs(np.asarray(a["params"][n]) - np.asarray(b["params"][n])).max()) for n in a["params"])
+            steps = 20480 * (k + 1)
+            db = {f: float(np.abs(np.asarray(a["buffer"][f]) - np.asarray(b["buffer"][f])).max()) for f in a["buffer"]}
+            print(f"| {os.path.basename(path).replace('.json', '')} | {steps} steps | {d('train/nu'):.1e} | {d('train/average_cost'):.1e} | "
+                  f"{d('train/policy_gradient_loss'):.1e} / {d('train/reward_value_loss'):.1e} / {d('train/cost_value_loss'):.1e} | {d('train/approx_kl'):.1e} | "
+                  f"{d('train/clip_fraction'):.1e} | {int(a['scalars']['train/early_stop_epoch'])}, {int(b['scalars']['train/early_stop_epoch'])} | "
+                  f"{dp:.2e} = {dp / (lr * steps):.1e} x lr x steps | {db['reward_values']:.1e} / {db['reward_advantages']:.1e} |")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(sys.argv[2], sys.argv[3])
+    else:
+        compare(sys.argv[2], sys.argv[3:])
