@@ -6,7 +6,7 @@
 tag=$1
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_seed_batch --no_configs2 > $R/gpurun_out/prof_$tag.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_seed_batch --no_configs2 --no_configs3 --no_configs4 > $R/gpurun_out/prof_$tag.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_f -- python3 $R/tools/gae_once.py > $R/gpurun_out/pmc_${tag}_f.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_w -- python3 $R/tools/gae_once.py > $R/gpurun_out/pmc_${tag}_w.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_antwall -- python3 $R/tools/antwall_iter.py > $R/gpurun_out/prof_${tag}_antwall.log 2>&1
@@ -17,5 +17,6 @@ timeout 300 python3 tools/rollout_only.py > gpurun_out/rollout_$tag.log 2>&1
 timeout 300 python3 tools/train_only.py > gpurun_out/train_$tag.log 2>&1
 KIND=ant timeout 300 python3 tools/train_only.py >> gpurun_out/train_$tag.log 2>&1
 timeout 600 python3 tools/seed_batch_bench.py > gpurun_out/seeds_$tag.log 2>&1
+bash tools/profile_seed_batch.sh $tag > /dev/null 2>&1
 find $R/gpurun_out -name "*.db" -delete
 du -sh $R/gpurun_out

@@ -26,7 +26,7 @@ def kernel_stats(tag, which="bench"):
     dst = os.path.join(ROOT, "profiles", f"{tag}_{which}_kernel_stats")
     with open(dst + ".csv", "w") as f:
         f.write(open(src).read())
-    bench = ""
+    bench, agree = "", ""
     log = os.path.join(ROOT, "gpurun_out", f"prof_{tag}{sfx}.log")
     if os.path.exists(log):
         for line in open(log):
@@ -34,9 +34,29 @@ def kernel_stats(tag, which="bench"):
                 j = json.loads(line)
                 bench = (f"line of that (profiled) run: {j['value']:.0f} env-steps/s, {j['ms_per_step']:.0f} ms per outer iteration" +
                          (f", {j['us_per_optimizer_step']} us per optimiser step, {j['us_per_rollout_step']} us per rollout step" if which != "bench" else ""))
+                if which == "bench" and "roofline" in j:
+                    # the SAME process printed the line and was traced: its live event timing and the trace's average must agree
+                    gae = [r for r in rows if "gae_dual_x4" in r["Name"]]
+                    if gae:
+                        avg_us = float(gae[0]["AverageNs"]) / 1e3
+                        prof_frac = 2048 * 131072 * 36 / (avg_us * 1e-6) / 8e12
+                        agree = (f"GAE roofline of the SAME run: the line says `roofline.achieved` {j['roofline']['achieved']} GB/s = {j['roofline']['frac']} of 8 TB/s "
+                                 f"(HIP events inside bench.py); this trace's `gae_dual_x4_kernel` average is {avg_us:.1f} us = {2048 * 131072 * 36 / (avg_us * 1e-6) / 1e9:.0f} GB/s = "
+                                 f"{prof_frac:.3f} ({100 * (prof_frac / j['roofline']['frac'] - 1):+.1f} %; the trace's average includes the 5 warm-up launches of the sweep).  "
+                                 f"Update kernel: the line says {j['roofline_ppo']['us_per_optimizer_step']} us per optimiser step.")
+    # full launches of the update kernel (the first train() of a process also makes 8 short calibration launches: drop by duration)
+    upd = ""
+    tr = find(f"prof_{tag}{sfx}/**/*kernel_trace.csv")
+    if tr is not None:
+        d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in csv.DictReader(open(tr)) if "ppo_train_" in r["Kernel_Name"] and "perm" not in r["Kernel_Name"] and "plan" not in r["Kernel_Name"]]
+        if d:
+            full = [x for x in d if x >= 0.5 * max(d)]
+            upd = (f"The update kernel's calls include {len(d) - len(full)} short calibration launches (`PPOLagrangian._tune_sync_placement`: the first `train()` of an agent "
+                   f"times one epoch over <= 16 384 rows at four positions of its exchange workspace, twice); the {len(full)} updates proper last "
+                   f"{sum(full) / len(full):.2f} ms each on average (from the kernel trace's timestamps).")
     head = (f"# rocprofv3 --kernel-trace --stats — bench.py --steps 2 --warmup 1 ({tag})\n\n"
             "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag> -- python3 bench.py --steps 2 "
-            "--warmup 1 --no_cpu_baseline --no_seed_batch --no_configs2` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 131 072)\n\n"
+            "--warmup 1 --no_cpu_baseline --no_seed_batch --no_configs2 --no_configs3 --no_configs4` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 131 072)\n\n"
             if which == "bench" else
             f"# rocprofv3 --kernel-trace --stats — BASELINE configs[2] (AntWall-v0, 256 envs, batch 128, [40, 40]) ({tag})\n\n"
             "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag>_antwall -- python3 tools/antwall_iter.py` "
@@ -46,9 +66,7 @@ def kernel_stats(tag, which="bench"):
         for r in rows[:24]:
             name = r["Name"].replace("(anonymous namespace)::", "").split("(")[0][-70:]
             f.write(f"| `{name}` | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.2f} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |\n")
-        f.write("\nThe update kernel's calls include the 8 short launches (one epoch over 16 384 rows = 256 steps, ~2.3 ms each at HC) with which the first "
-                "`train()` of an agent finds the fastest position of its exchange workspace (`PPOLagrangian._tune_sync_placement`); the other calls are "
-                "the updates proper — their duration is `total - 8 x 2.3 ms` over `calls - 8` launches (HC: ~182 ms per 20 480 steps = 8.9 us per step).\n")
+        f.write("\n" + upd + "\n" + ("\n" + agree + "\n" if agree else ""))
     print("wrote", dst + ".md")
 
 
