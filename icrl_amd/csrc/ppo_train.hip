@@ -980,11 +980,35 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   return rows ? (split ? 2 : 1) : 0;
 }
 
+// shapes the persistent kernels refuse (hidden widths above 64, minibatches above 256 rows): the generic-shape path of generic.hip,
+// four plain launches per optimiser step.  Its scratch lies behind the regular workspace: sync_ws must then hold
+// ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(batch_size, h, n_params) bytes.
+static int train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
+                         const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, hipStream_t s) {
+  if (hp->batch_size < 2 || hp->n_epochs < 1) return fail("icrl_ppo_lag_train: batch_size %d (>= 2), n_epochs %d (>= 1)", hp->batch_size, hp->n_epochs);
+  if (buf->obs_dim != pol->obs_dim || buf->T < 1) return fail("icrl_ppo_lag_train: buffer obs_dim %d vs policy %d, T = %d", buf->obs_dim, pol->obs_dim, buf->T);
+  if ((long long)buf->T * buf->N * (pol->obs_dim > 16 ? pol->obs_dim : 16) >= (1ll << 31))
+    return fail("icrl_ppo_lag_train: %d x %d transitions x obs_dim %d overflow 32-bit element offsets", buf->T, buf->N, pol->obs_dim);
+  if (pol->discrete && buf->act_store != 1) return fail("icrl_ppo_lag_train: discrete policy needs act_store = 1 (action index), got %d", buf->act_store);
+  const int n_total = buf->T * buf->N;
+  const int n_mb = (n_total + hp->batch_size - 1) / hp->batch_size;
+  const long long n_steps = (long long)hp->n_epochs * n_mb;
+  hipError_t e = hipMemsetAsync(stats, 0, (32 + hp->n_epochs) * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  int* offs = reinterpret_cast<int*>((char*)sync_ws + ICRL_PPO_PLAN_BYTES(n_steps));
+  const long long n = (long long)hp->n_epochs * n_total;
+  hipLaunchKernelGGL(ppo_perm_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perms, n, buf->T, buf->N, offs);
+  char* scratch = (char*)sync_ws + ICRL_PPO_SYNC_BYTES(hp->n_epochs, n_mb, n_total);
+  return launch_train_generic(pol, exp_avg, exp_avg_sq, adam_step, buf, offs, nu, hp, stats, scratch, s);
+}
+
 extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                                   const icrl_buffer_t* buf, const int32_t* perms, const float* nu,
                                   const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, void* stream) {
   TrainArgs a;
   hipStream_t s = (hipStream_t)stream;
+  if (policy_is_wide(pol) || hp->batch_size > MAXB)
+    return train_generic(pol, exp_avg, exp_avg_sq, adam_step, buf, perms, nu, hp, stats, sync_ws, s);
   int err = 0;
   const int kind = prepare_train(pol, exp_avg, exp_avg_sq, adam_step, buf, perms, nu, hp, stats, sync_ws, s, a, &err);
   if (kind < 0) return err;

@@ -2704,7 +2704,8 @@ static bool cn_ok(const icrl_costnet_t* cn) {
          (cn->n_hidden == 2 && cn->h2 > 0 && cn->h2 <= MAX_H)) && cn->obs_dim <= MAX_OBS && cn->acs_dim <= MAX_ACT;
 }
 static int bad_dims(const char* who, int O, int A, int H1, int H2) {
-  return fail("%s: policy obs_dim %d (1..%d), act_dim %d (1..%d), hidden (%d, %d) (1..%d each)", who, O, MAX_OBS, A, MAX_ACT, H1, H2, MAX_H);
+  return fail("%s: policy obs_dim %d (1..%d), act_dim %d (1..%d), hidden (%d, %d) (1..%d each; wider policies run through the generic-shape "
+              "entry points: icrl_policy_forward / icrl_policy_evaluate / icrl_ppo_lag_train and the per-step rollout)", who, O, MAX_OBS, A, MAX_ACT, H1, H2, MAX_H);
 }
 static int bad_cn(const char* who, const icrl_costnet_t* cn) {
   return fail("%s: constraint net in_dim %d (1..%d), %d hidden layers (1 or 2) of (%d, %d) (1..%d), obs_dim %d (<= %d), acs_dim %d (<= %d)", who,
@@ -2716,7 +2717,7 @@ static int bad_cn(const char* who, const icrl_costnet_t* cn) {
 using namespace icrl;
 
 extern "C" int icrl_policy_prepare(const icrl_policy_t* p, void* stream) {
-  if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("icrl_policy_prepare", p->obs_dim, p->act_dim, p->h1, p->h2);
+  if (!policy_is_wide(p) && !dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("icrl_policy_prepare", p->obs_dim, p->act_dim, p->h1, p->h2);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
   if (L.n != p->n_params) return fail("icrl_policy_prepare: n_params = %d, the layout needs %d", p->n_params, L.n);
   hipLaunchKernelGGL(policy_transpose_kernel, dim3((L.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, p->params, p->params_t);
@@ -2735,6 +2736,9 @@ extern "C" int icrl_policy_forward(const icrl_policy_t* p, const double* obs, co
                                    const float* action_low, const float* action_high, float* actions, float* act_clipped,
                                    float* v_r, float* v_c, float* log_prob, void* stream) {
   if (N <= 0) return fail("policy forward / evaluate: N = %d rows", N);
+  if (policy_is_wide(p))      // hidden widths above 64: the generic-shape kernel (generic.hip)
+    return launch_policy_generic(p, obs, noise, N, deterministic, action_low, action_high, actions, act_clipped, v_r, v_c, log_prob, nullptr, nullptr,
+                                 (hipStream_t)stream);
   if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("policy forward / evaluate", p->obs_dim, p->act_dim, p->h1, p->h2);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
   if (N >= ROWS_KERNEL_MIN && !p->discrete) {
@@ -2761,6 +2765,8 @@ extern "C" int icrl_policy_forward(const icrl_policy_t* p, const double* obs, co
 extern "C" int icrl_policy_evaluate(const icrl_policy_t* p, const double* obs, const float* actions, int N, float* v_r,
                                     float* v_c, float* log_prob, float* entropy, void* stream) {
   if (N <= 0) return fail("policy forward / evaluate: N = %d rows", N);
+  if (policy_is_wide(p))
+    return launch_policy_generic(p, obs, nullptr, N, 1, nullptr, nullptr, nullptr, nullptr, v_r, v_c, log_prob, actions, entropy, (hipStream_t)stream);
   if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("policy forward / evaluate", p->obs_dim, p->act_dim, p->h1, p->h2);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
   if (N >= ROWS_KERNEL_MIN && !p->discrete) {

@@ -18,7 +18,8 @@ from . import _lib, spaces
 from .structs import PolicyT, p
 
 BRANCHES = ("policy_net", "value_net", "cost_value_net")
-HW = 64        # width the kernels are built for (HD in csrc/ppo_common.h, MAX_H in csrc/common.h)
+HW = 64        # width the fast kernels are built for (HD in csrc/ppo_common.h, MAX_H in csrc/common.h)
+HW_MAX = 256   # widest layer of the generic-shape path (csrc/generic.hip: GEN_MAX_H)
 
 
 def state_dict_names(discrete, n_hidden=2):
@@ -42,17 +43,21 @@ class ActorTwoCriticsPolicy:
         if net_arch is None:
             net_arch = [dict(pi=[64, 64], vf=[64, 64], cvf=[64, 64])]
         arch = net_arch[-1] if isinstance(net_arch[-1], dict) else None
-        if arch is None or len(net_arch) != 1 or any(len(arch.get(k, ())) != 2 or max(arch[k]) > HW or min(arch[k]) < 1
+        if arch is None or len(net_arch) != 1 or any(len(arch.get(k, ())) != 2 or max(arch[k]) > HW_MAX or min(arch[k]) < 1
                                                      for k in ("pi", "vf", "cvf")):
             raise NotImplementedError("icrl_amd supports net_arch=[dict(pi=[h1,h2], vf=[h1,h2], cvf=[h1,h2])]: three separate "
-                                      f"two-layer MLPs, every width 1..{HW}, no shared trunk (the kernels are built for {HW}-wide "
-                                      f"layers; narrower ones run zero-padded); got {net_arch}")
-        # logical widths per branch (-pl / -rvl / -cvl, ref: icrl/utils.py:636-655).  The device buffers are always HW wide: a
-        # narrower layer is stored zero-padded.  Padding units have zero weights in and out and a zero bias, so they output
+                                      f"two-layer MLPs, every width 1..{HW_MAX}, no shared trunk (up to {HW} wide on the persistent kernels, "
+                                      f"wider on the generic-shape path; narrower layers run zero-padded); got {net_arch}")
+        # logical widths per branch (-pl / -rvl / -cvl, ref: icrl/utils.py:636-655).  The device buffers are `hw` wide — 64 when every
+        # layer fits the fast kernels, else the widest layer rounded up to a multiple of 64 (the generic-shape path, csrc/generic.hip) —
+        # and a narrower layer is stored zero-padded.  Padding units have zero weights in and out and a zero bias, so they output
         # tanh(0) = 0 exactly, receive a zero gradient and keep zero Adam moments: every real parameter sees exactly the
         # arithmetic of the unpadded network (only zeros are added to its dot products).
         self.widths = {b: (int(arch[k][0]), int(arch[k][1])) for b, k in zip(BRANCHES, ("pi", "vf", "cvf"))}
-        self.h1 = self.h2 = HW
+        widest = max(max(w) for w in self.widths.values())
+        self.hw = HW if widest <= HW else -(-widest // 64) * 64
+        self.wide = self.hw > HW          # the persistent rollout / sampling / update kernels do not serve this policy
+        self.h1 = self.h2 = self.hw
         self.optimizer_kwargs = dict(eps=1e-5) if optimizer_kwargs is None else dict(optimizer_kwargs)  # ref: policies.py:357-361
         self.lr_schedule = lr_schedule
         sd = self._init_host(log_std_init, ortho_init)
@@ -73,8 +78,8 @@ class ActorTwoCriticsPolicy:
             return shp
         if name.startswith("mlp_extractor."):
             first = name.split(".")[2] == "0"
-            return ((HW, self.obs_dim if first else HW) if name.endswith("weight") else (HW,))
-        return (shp[0], HW) if name.endswith("weight") else shp          # heads: [outputs, last hidden]
+            return ((self.hw, self.obs_dim if first else self.hw) if name.endswith("weight") else (self.hw,))
+        return (shp[0], self.hw) if name.endswith("weight") else shp          # heads: [outputs, last hidden]
 
     def _pad(self, name, t):
         """logical tensor -> device layout (zeros beyond the logical widths)."""

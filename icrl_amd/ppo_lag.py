@@ -122,7 +122,7 @@ class PPOLagrangian:
     # ---- env-chain introspection: is this the device-native stack the fused rollout handles? ---------------------------
     def _fused_chain(self):
         env = self.env
-        if not isinstance(env, VecNormalizeWithCost):
+        if not isinstance(env, VecNormalizeWithCost) or self.policy.wide:      # (hidden widths above 64: per-step path, generic-shape kernels)
             return None
         cw = env.venv
         if isinstance(cw, HipSynthVecEnv):           # no cost wrapper in the chain (the GAIL baseline, icrl/gail.py:50-59): costs are 0
@@ -240,6 +240,8 @@ class PPOLagrangian:
         is_box = isinstance(self.action_space, spaces.Box)
         norm_env = env if isinstance(env, VecNormalizeWithCost) else None
         v_r = v_c = dones = None
+        if noise is None and self.streams is not None:      # teacher-forced streams serve this path like the fused one
+            noise = self._draw_action_noise(n_rollout_steps)
         for t in range(n_rollout_steps):
             actions, v_r, v_c, log_probs = self.policy.forward(self._last_obs, noise=None if noise is None else noise[t])
             clipped = self.policy.last_clipped if is_box else actions
@@ -454,6 +456,10 @@ class PPOLagrangian:
         current_penalty = float(self.dual.nu().item())
         if not hasattr(self, "_train_ws"):
             n_words = 96 + 6 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2 + 32 + _lib.PPO_SPLIT_BYTES // 8
+            self._generic_update = pol.wide or int(self.batch_size) > 256      # shapes of the generic-shape path (csrc/generic.hip)
+            if self._generic_update:      # its scratch lies behind the regular workspace: ICRL_PPO_GENERIC_BYTES(batch_size, h, n_params)
+                B_, n_ = int(self.batch_size), pol.n_params
+                n_words += (64 + B_ * (24 + 1 + 16 + 3 * (4 * pol.hw + 16)) + n_ + (n_ + 255) // 256 + 64 + 1) // 2 + 8
             # the workspace lives in an arena with room for SYNC_CANDIDATES positions 1 MB apart: see _tune_sync_placement
             arena = torch.zeros(n_words + (self.SYNC_CANDIDATES - 1) * (1 << 17), dtype=torch.int64, device=dev)
             self._train_ws = dict(nu=torch.zeros(1, device=dev), stats=torch.zeros(32 + self.n_epochs, device=dev), sync=arena[:n_words],
@@ -480,7 +486,7 @@ class PPOLagrangian:
         ws["sync_tuned"] = True
         N, B = rb.n_envs, int(self.batch_size)
         Tc = min(rb.buffer_size, max(1, 16384 // N))
-        if not self.tune_sync_placement or Tc * N < 64 * B:       # too few optimiser steps to time a 3 % difference
+        if not self.tune_sync_placement or Tc * N < 64 * B or getattr(self, "_generic_update", False):       # too few optimiser steps to time a 3 % difference
             return
         from .structs import BufferT, PpoHyperT
         b = _lib.byref

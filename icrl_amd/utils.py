@@ -174,7 +174,53 @@ class EpisodeRun:
         return x if self.keep is None else x[:self.keep]
 
 
+class SteppedEpisodeRun:
+    """EpisodeRun's results from the reference's own loop (icrl/utils.py:323-357, evaluation.py:10-67) over the per-step env chain —
+    policy.forward + env.step, one launch sequence and one host read of `done` per step — for the policies the persistent sampler
+    does not serve (hidden widths above 64: generic-shape forward kernel).  The env is reset before the first episode only; the later
+    ones start from the auto-reset observation, like the sequential loop the sampler kernel reproduces."""
+
+    def __init__(self, agent, env, n_episodes, deterministic, noise):
+        assert env.num_envs == 1, "You must pass only one environment when using this function"
+        pol, senv = agent.policy, env.unwrapped
+        dev, max_steps = senv.device, senv.max_steps
+        A = 1 if pol.discrete else pol.act_dim
+        rows = n_episodes * max_steps
+        if noise is None and not deterministic:
+            noise = torch.rand(rows, device=dev) if pol.discrete else torch.randn(rows, A, device=dev)
+        if noise is not None:
+            noise = torch.as_tensor(noise, device=dev).float().reshape(rows, -1).contiguous()
+        was_training = env.training
+        env.training = False
+        try:
+            orig, obs_l, acts, ep_rewards, lengths = [], [], [], [], []
+            k, obs = 0, env.reset()
+            for _ in range(n_episodes):
+                done, ep_r, ep_l = False, 0.0, 0
+                while not done:
+                    actions, _, _, _ = pol.forward(obs, deterministic=deterministic, noise=None if noise is None else noise[k:k + 1])
+                    clipped = actions if pol.discrete else pol.last_clipped
+                    k += 1
+                    obs, r, d, _ = env.step(clipped)
+                    orig.append(env.get_original_obs().reshape(1, -1).double().clone()); obs_l.append(obs.reshape(1, -1).double().clone())
+                    acts.append(clipped.reshape(1, -1).float().clone())
+                    ep_r += float(torch.as_tensor(r).reshape(-1)[0].item()); ep_l += 1
+                    done = bool(torch.as_tensor(d).reshape(-1)[0].item())
+                ep_rewards.append(ep_r); lengths.append(ep_l)
+        finally:
+            env.training = was_training
+        self.out = dict(orig_obs=torch.cat(orig), obs=torch.cat(obs_l), actions=torch.cat(acts),
+                        ep_rewards=torch.as_tensor(np.asarray(ep_rewards, np.float64), device=dev),
+                        ep_lengths=torch.as_tensor(np.asarray(lengths, np.int32), device=dev))
+        self.lengths, self.keep = np.asarray(lengths, np.int64), None
+
+    def rows_of(self, name):
+        return self.out[name]
+
+
 def _run_episodes(agent, env, n_episodes, deterministic, noise, parallel):
+    if agent.policy.wide:
+        return SteppedEpisodeRun(agent, env, n_episodes, deterministic, noise)
     run = EpisodeRun(agent, env, n_episodes, deterministic, noise, parallel).prepare()
     run.launch()
     while not run.finish():

@@ -155,6 +155,10 @@ typedef struct {
 #define ICRL_PPO_PLAN_BYTES(n_steps) (768 + 48 * (size_t)(n_steps))
 #define ICRL_PPO_SYNC_BYTES(n_epochs, n_minibatches, n_rows) \
   (ICRL_PPO_PLAN_BYTES((size_t)(n_epochs) * (size_t)(n_minibatches)) + 4 * (size_t)(n_epochs) * (size_t)(n_rows) + 256 + ICRL_PPO_SPLIT_BYTES)
+/* generic-shape update (hidden widths above 64 — `h` = the padded common width, a multiple of 64 up to 256 — or batch_size above 256):
+ * its scratch lies BEHIND the regular workspace, sync_ws then holds ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(...) bytes */
+#define ICRL_PPO_GENERIC_BYTES(batch_size, h, n_params) \
+  (4 * (64 + (size_t)(batch_size) * (24 + 1 + 16 + 3 * (4 * (size_t)(h) + 16)) + (size_t)(n_params) + ((size_t)(n_params) + 255) / 256 + 64))
 #define ICRL_CN_METRICS 24 /* floats per iteration in the metrics array of icrl_cn_train */
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -306,7 +310,11 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
  *   hp->_pad: bit 0 = write per-phase cycle counts to stats[12..31] (diagnostic); kernel selection (default: wave pairs, two
  *            waves per SIMD; obs > 64: row-owning waves): bit 2 = row-owning waves (one wave per SIMD), bit 1 = the column-split
  *            tiles kernel; the row-owning kernel runs TWO workgroups per network when batch_size > 64 (each computes one 64-row
- *            chunk of a minibatch, partial gradients exchanged as granules) unless bit 3 is set. */
+ *            chunk of a minibatch, partial gradients exchanged as granules) unless bit 3 is set.
+ * Shapes outside the persistent kernels — a policy stored with hidden width h1 = h2 > 64 (a multiple of 64 up to 256: the reference's
+ * -pl / -rvl / -cvl flags take any width, icrl/utils.py:636-655) or batch_size > 256 (buffers.py:594-612 slices any size) — run
+ * through the generic-shape path (csrc/generic.hip): four plain launches per optimiser step, same statistics layout, no hp->_pad
+ * options; sync_ws must then hold ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(batch_size, h1, n_params) bytes. */
 int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                        const icrl_buffer_t* buf, const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp,
                        float* stats, void* sync_ws, void* stream);

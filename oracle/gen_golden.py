@@ -252,6 +252,16 @@ def g13_widths():
     g4_ppo_minibatch("g13_widths", dict(pi=[32, 48], vf=[64, 32], cvf=[16, 64]))
 
 
+def g15_wide():
+    """g4 with layers wider than 64 (the generic-shape path of the build: csrc/generic.hip), different per branch."""
+    g4_ppo_minibatch("g15_wide", dict(pi=[128, 128], vf=[96, 128], cvf=[128, 80]))
+
+
+def g16_batch512():
+    """g4 on ONE 512-row batch (batch sizes above 256: generic-shape path)."""
+    g4_ppo_minibatch("g16_batch512", None, B=512)
+
+
 def g14_batch256():
     """a 256-row minibatch (four 64-row chunks of the update kernels) through the reference's own policy / optimizer objects."""
     g4_ppo_minibatch("g14_batch256", None, B=256)
@@ -916,8 +926,8 @@ def fixtures_expert():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11", "g12", "g13", "g14"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11", "g12", "g13", "g14", "g15", "g16"]
     table = dict(g1=g1_gae, g2=g2_cost_function, g3=g3_vecnormalize, g4=g4_ppo_minibatch, g5=g5_dual,
-                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g12=g12_gail, g13=g13_widths, g14=g14_batch256, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
+                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g12=g12_gail, g13=g13_widths, g14=g14_batch256, g15=g15_wide, g16=g16_batch512, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
     for w in which:
         table[w]()

@@ -281,7 +281,8 @@ PORT_DEFAULTS = dict(   # the reference's flag names and parser defaults (icrl/i
     no_importance_sampling=False, per_step_importance_sampling=False, cn_target_kl_old_new=10, cn_target_kl_new_old=10,
     cn_batch_size=None, train_gail_lambda=False, cn_normalize=False, backward_iters=10, forward_timesteps=1000000, n_iters=100,
     expert_rollouts=20, clip_obs=20, cn_eps=1e-5, dont_normalize_obs=False, dont_normalize_reward=False,
-    dont_normalize_cost=False, warmup_timesteps=None, reset_policy=False, factored=False)
+    dont_normalize_cost=False, warmup_timesteps=None, reset_policy=False, factored=False,
+    policy_layers=(64, 64), reward_vf_layers=(64, 64), cost_vf_layers=(64, 64))      # -pl / -rvl / -cvl (icrl/utils.py:636-655)
 
 
 def true_cost(eval_env_id, orig_obs, acts):
@@ -317,7 +318,9 @@ def icrl_port(cfg, expert_obs, expert_acs, expert_policy_sd=None, n_iters=None, 
                       cost_gae_lambda=c["cost_gae_lambda"], clip_range=c["clip_range"], ent_coef=c["ent_coef"],
                       reward_vf_coef=c["reward_vf_coef"], cost_vf_coef=c["cost_vf_coef"], max_grad_norm=c["max_grad_norm"],
                       target_kl=c["target_kl"], penalty_initial_value=c["penalty_initial_value"],
-                      penalty_learning_rate=c["penalty_learning_rate"], budget=c["budget"], seed=c["seed"], discrete=discrete)
+                      penalty_learning_rate=c["penalty_learning_rate"], budget=c["budget"], seed=c["seed"], discrete=discrete,
+                      hidden=dict(policy_net=tuple(c["policy_layers"]), value_net=tuple(c["reward_vf_layers"]),
+                                  cost_value_net=tuple(c["cost_vf_layers"])))
     # NB the reference builds the constraint net BEFORE the agent (icrl.py:88-117 vs :139-178) but the agent's constructor
     # re-seeds every generator (common/utils.py:23-39), so the construction order only matters for the net's own draw.
     cn = CostNet(env.obs_dim, env.act_dim, c["cn_layers"], discrete, None, None, c["clip_obs"],

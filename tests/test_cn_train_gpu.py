@@ -173,7 +173,7 @@ def test_cn_train_minibatch_default_stream_matches_oracle():
         assert np.allclose(v.numpy(), ref, rtol=3e-3, atol=3e-4), (k, np.abs(v.numpy() - ref).max())
 
 
-@pytest.mark.parametrize("kind,n", [("hc", 64), ("hc", 1000), ("ant", 333), ("narrow", 200)])
+@pytest.mark.parametrize("kind,n", [("hc", 64), ("hc", 1000), ("ant", 333), ("narrow", 200), ("wide", 40), ("wide", 300)])
 def test_policy_rows_kernel_vs_oracle(kind, n):
     """policy_rows_kernel (>= 64 rows: 16 rows per workgroup pass as fp32 MFMA tiles; the KL metrics' evaluate_actions and batched
     predict) against the oracle's ActorTwoCriticsPolicy.evaluate_actions / forward directly (policies.py:716-731, 752-767;
@@ -184,8 +184,11 @@ def test_policy_rows_kernel_vs_oracle(kind, n):
     od, ad = (113, 8) if kind == "ant" else (18, 6)
     torch.manual_seed(11)
     arch = dict(pi=[40, 24], vf=[64, 20], cvf=[16, 64]) if kind == "narrow" else None
+    if kind == "wide":      # layers above 64: policy_generic_kernel (csrc/generic.hip)
+        arch = dict(pi=[128, 100], vf=[72, 128], cvf=[200, 256])
     kw = dict(net_arch=[arch]) if arch else {}
     pol = ActorTwoCriticsPolicy(spaces.Box(-np.inf, np.inf, (od,), np.float64), spaces.Box(-1, 1, (ad,), np.float32), **kw)
+    assert pol.wide == (kind == "wide")
     op = o_nets.TwoCriticPolicy(od, ad, **({"hidden": dict(policy_net=arch["pi"], value_net=arch["vf"], cost_value_net=arch["cvf"])} if arch else {}))
     op.load_state_dict(pol.state_dict())
     rng = np.random.RandomState(9)

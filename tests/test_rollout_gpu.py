@@ -183,7 +183,10 @@ def test_fused_rollout_vs_reference_golden(golden):
 # per-step launches (on_policy_algorithm.py:340-421, policies.py:716-731).
 @pytest.mark.parametrize("kind,N,T,kernel", [("hc", 64, 300, "auto"), ("ant", 96, 40, "auto"), ("ant", 32, 60, "auto"), ("hc", 256, 40, "auto"),
                                              ("antbroken", 512, 12, "auto"), ("hc", 64, 300, "multi"), ("antbroken", 512, 12, "multi"),
-                                             ("ant", 96, 40, "multi")])
+                                             ("ant", 96, 40, "multi"),
+                                             # a policy with layers above 64 (-pl 128 96 -rvl 80 128 -cvl 128 128, icrl/utils.py:636-655): the
+                                             # per-step loop over the fine-grained entry points with the generic-shape forward kernel
+                                             ("hc", 16, 120, "wide-policy"), ("ant", 8, 30, "wide-policy")])
 def test_fused_rollout_vs_port(kind, N, T, kernel):
     """same comparison at HC / Ant shapes with freshly initialised nets; also crosses episode ends (hc T=300 < 1000: none,
     so the env is pre-stepped to t_ep = 900 first)."""
@@ -208,10 +211,15 @@ def test_fused_rollout_vs_port(kind, N, T, kernel):
         cn = ConstraintNet(od, ad, hid, None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
         cn.load_state_dict(ocn.state_dict())
     env.set_cost_function(cn.cost_function)
-    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=7)   # learn() re-seeds the env with the agent seed
-    agent.rollout_kernel = kernel
+    wide = kernel == "wide-policy"
+    akw = dict(policy_kwargs=dict(net_arch=[dict(pi=[128, 96], vf=[80, 128], cvf=[128, 128])])) if wide else {}
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=7, **akw)   # learn() re-seeds the env with the agent seed
+    if wide:
+        assert agent.policy.wide and agent._fused_chain() is None
+    else:
+        agent.rollout_kernel = kernel
     stack = o_loop.make_stack(N, ekind, 7, broken=broken); stack.cost_fn = ocn.cost_function
-    port = o_loop.PortAgent(stack, n_steps=T, seed=7)
+    port = o_loop.PortAgent(stack, n_steps=T, seed=7, **(dict(hidden=dict(policy_net=(128, 96), value_net=(80, 128), cost_value_net=(128, 128))) if wide else {}))
     port.policy.load_state_dict(agent.policy.state_dict())        # same seed gives the same init; make it explicit anyway
     near_end = {"hc": 1000 - T // 3, "antbroken": 500 - T // 3}.get(kind)      # cross an episode end inside the rollout
     rng = np.random.RandomState(2)
