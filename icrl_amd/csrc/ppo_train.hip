@@ -986,6 +986,10 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
 static int train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
                          const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, hipStream_t s) {
   if (hp->batch_size < 2 || hp->n_epochs < 1) return fail("icrl_ppo_lag_train: batch_size %d (>= 2), n_epochs %d (>= 1)", hp->batch_size, hp->n_epochs);
+  if (pol->h1 != pol->h2 || pol->h1 % 64 != 0 || pol->h1 > 256 || pol->obs_dim < 1 || pol->obs_dim > 1024 || pol->act_dim < 1 || pol->act_dim > 16)
+    return fail("icrl_ppo_lag_train: hidden widths (%d, %d), obs_dim %d, act_dim %d: the persistent kernels are built for %d x %d (narrower layers stored "
+                "zero-padded), obs <= 128, act <= 16; the generic-shape path for a common padded width that is a multiple of 64 up to 256, obs <= 1024",
+                pol->h1, pol->h2, pol->obs_dim, pol->act_dim, HD, HD);
   if (buf->obs_dim != pol->obs_dim || buf->T < 1) return fail("icrl_ppo_lag_train: buffer obs_dim %d vs policy %d, T = %d", buf->obs_dim, pol->obs_dim, buf->T);
   if ((long long)buf->T * buf->N * (pol->obs_dim > 16 ? pol->obs_dim : 16) >= (1ll << 31))
     return fail("icrl_ppo_lag_train: %d x %d transitions x obs_dim %d overflow 32-bit element offsets", buf->T, buf->N, pol->obs_dim);

@@ -48,10 +48,16 @@ def test_refused_arguments_carry_a_reason():
     err = L.icrl_gae_dual(*([None] * 12), 0, 5, 0.99, 0.95, 0.99, 0.95, None)
     with pytest.raises(ValueError, match="T = 0, N = 5"):
         _lib.check(err, "icrl_gae_dual")
+    # batch sizes above 256 and layers above 64 are served (generic-shape path); what it refuses says so
     hp = S.PpoHyperT(512, 2, 0, 0)
-    pol = S.PolicyT(18, 6, 64, 64, 0, 1, None, None)
+    pol = S.PolicyT(18, 6, 320, 320, 0, 1, None, None)
     err = L.icrl_ppo_lag_train(ctypes.byref(pol), None, None, None, ctypes.byref(buf), None, None, ctypes.byref(hp), None, None, None)
-    with pytest.raises(ValueError, match="batch_size 512"):
+    with pytest.raises(ValueError, match=r"hidden widths \(320, 320\).*multiple of 64 up to 256"):
+        _lib.check(err, "icrl_ppo_lag_train")
+    hp = S.PpoHyperT(1, 2, 0, 0)
+    pol = S.PolicyT(18, 6, 128, 128, 0, 1, None, None)
+    err = L.icrl_ppo_lag_train(ctypes.byref(pol), None, None, None, ctypes.byref(buf), None, None, ctypes.byref(hp), None, None, None)
+    with pytest.raises(ValueError, match="batch_size 1"):
         _lib.check(err, "icrl_ppo_lag_train")
 
 
