@@ -216,7 +216,10 @@ int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream);
  * `noise` uniforms when discrete; deterministic: mean / argmax), log-prob, both values.
  * obs: [N,obs] float64 (cast to float32 like preprocess_obs, preprocessing.py:61).  noise: [N,act] standard normals
  * ([N] uniforms when discrete) or NULL when deterministic.  actions: [N,act_store] unclipped; act_clipped: [N,act]
- * clipped to [low,high] (on_policy_algorithm.py:381-382; NULL low/high: no clipping).  Any output may be NULL. */
+ * clipped to [low,high] (on_policy_algorithm.py:381-382; NULL low/high: no clipping).  Any output may be NULL.
+ * Policies stored with h1 = h2 > 64 (a multiple of 64 up to 256; obs up to 1024) run the generic-shape kernel here and in
+ * icrl_policy_evaluate; the fused entry points (icrl_rollout_collect*, icrl_sample_episodes*) refuse them with a message — their
+ * rollouts use the per-step entry points (icrl_policy_forward, icrl_synth_env_step, icrl_cost_mlp_forward, icrl_vecnorm_step). */
 int icrl_policy_forward(const icrl_policy_t* pol, const double* obs, const float* noise, int N, int deterministic,
                         const float* action_low, const float* action_high,
                         float* actions, float* act_clipped, float* v_r, float* v_c, float* log_prob, void* stream);

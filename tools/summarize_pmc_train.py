@@ -95,10 +95,9 @@ if kind != "hc":
     open(os.path.join(ROOT, "profiles", f"{tag}_train_pmc{suffix}.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
     raise SystemExit(0)
-lines += ["", "Reading: SQ_WAVE_CYCLES = ACTIVE_INST_ANY (issuing) + WAIT_INST_ANY (issue stalled: here the shared fp32 MFMA / VALU pipe, "
-          "304 MFMAs x 32 cycles = 9.7 k cycles per SIMD and step) + WAIT_ANY (parked at s_waitcnt / s_barrier).  MFMA_MOPS_F32 / 4 = "
-          "v_mfma_f32_16x16x4_f32 instructions.  With two waves per SIMD each wave issues half the instructions (761 vs 1733 VALU), "
-          "and the step shortens by what the two waves overlap; what remains parked (WAIT_ANY) is the exchange hop, the three "
-          "workgroup barriers and LDS latency both waves of a SIMD meet at the same time."]
+lines += ["", "Reading: SQ_WAVE_CYCLES = ACTIVE_INST_ANY (issuing) + WAIT_INST_ANY (issue stalled: here the SIMD's one fp32 lane array, which the fp32 MFMA "
+          "occupies alone: SQ_VALU_MFMA_COEXEC_CYCLES = 0, MFMA_BUSY = 32 cycles x SQ_INSTS_MFMA) + WAIT_ANY (parked at s_waitcnt / s_barrier).  "
+          "With two waves per SIMD each wave issues about half the instructions of the one-wave kernel, and the step shortens by what one wave's waits "
+          "hide of the other's issue; what remains parked is the norm hop, the three workgroup barriers and LDS latency both waves of a SIMD meet at the same time."]
 open(os.path.join(ROOT, "profiles", f"{tag}_train_pmc{suffix}.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
