@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/icrl_hip.h"
 
@@ -77,6 +78,23 @@ __device__ __forceinline__ void globalize(icrl_agent_t& g) {
 __device__ __forceinline__ void globalize(icrl_costnet_t& c) {
   c.select_dim = as_global(c.select_dim); c.action_low = as_global(c.action_low); c.action_high = as_global(c.action_high);
   c.obs_mean = as_global(c.obs_mean); c.obs_var = as_global(c.obs_var); c.params = as_global(c.params); c.params_t = as_global(c.params_t);
+}
+
+// SINGLE-RUN persistent launches (their workgroups spin on each other's records / granules): a cooperative launch, so that the runtime
+// itself refuses a grid that cannot be co-resident (hipErrorCooperativeLaunchTooLarge) instead of the kernel timing out on its bounded
+// spins.  The host-side occupancy arithmetic (persistent_fits) stays in front of it — the guide (MI355X_MICROARCH.md, Correctness
+// boundaries) reports the cooperative path accepting an over-size grid at some SGPR counts — and the status word stays behind it.
+// The BATCHED grids are intentionally not co-resident across runs (a run that does not fit yet starts when earlier ones finish) and
+// keep the plain launch.  ICRL_PLAIN_LAUNCH=1 in the environment: plain launches (A/B).
+template <class K, class A>
+inline hipError_t launch_coresident(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t s, A& arg) {
+  static const bool plain = getenv("ICRL_PLAIN_LAUNCH") != nullptr;
+  if (plain) {
+    hipLaunchKernelGGL(kernel, grid, block, dyn_lds, s, arg);
+    return hipGetLastError();
+  }
+  void* params[] = {(void*)&arg};
+  return hipLaunchCooperativeKernel((const void*)kernel, grid, block, params, (unsigned)dyn_lds, s);
 }
 
 template <class T>

@@ -908,8 +908,8 @@ static int launch_train(const TrainArgs& a, hipStream_t s) {
   const size_t bytes = (size_t)Smem<NT1>::TOTAL * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)ppo_train_kernel<NT1, DISC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((ppo_train_kernel<NT1, DISC>), dim3(3), dim3(TH), bytes, s, a);
-  return (int)hipGetLastError();
+  TrainArgs arg = a;
+  return (int)launch_coresident(ppo_train_kernel<NT1, DISC>, dim3(3), dim3(TH), bytes, s, arg);
 }
 
 // argument checks + the pre-kernels (granule / statistics reset, permutation offsets, schedule tables) of ONE run; fills `a` and

@@ -37,6 +37,23 @@
 #ifndef ICRL_BOOK_WAVE
 #define ICRL_BOOK_WAVE 7
 #endif
+#ifndef ICRL_W1_TAIL
+#define ICRL_W1_TAIL 0
+#endif
+// weight-gradient GEMMs: ALL operand tiles of a GEMM fetched before its first MFMA (a scheduling barrier; left alone the compiler fetches
+// one K step at a time and waits for the LDS in front of every group of four dependent MFMAs).  Measured: 8.53 vs 8.53 us — the other
+// wave of the SIMD already covers those waits; off.
+#ifndef ICRL_OPERANDS_FIRST
+#define ICRL_OPERANDS_FIRST 0
+#endif
+#if ICRL_OPERANDS_FIRST
+#define OPERANDS_FIRST() __builtin_amdgcn_sched_barrier(0)
+#else
+#define OPERANDS_FIRST()
+#endif
+#ifndef ICRL_W1_TAIL_MOVE_HEAD
+#define ICRL_W1_TAIL_MOVE_HEAD 0
+#endif
 #ifndef ICRL_L1_TAILQ
 #define ICRL_L1_TAILQ 1
 #endif
@@ -166,11 +183,11 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 #endif
 #if ICRL_PAIR_ADJ
   const int rt = w >> 1, fh = w & 1;       // row tile, feature half (= jt, kh in the weight-gradient phase)
-  constexpr int LS_WAVE = 2;               // the low wave (fh == 0) that owns log_std (wave 0 owns the head bias)
+
   const int partner = w ^ 1;
 #else
   const int rt = w & 3, fh = w >> 2;
-  constexpr int LS_WAVE = 1;
+
   const int partner = w ^ 4;
 #endif
   const int r = lane & 15, q = lane >> 4;
@@ -208,7 +225,23 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   const int jb = 16 * rt + r;
   float mb1 = 0.f, vb1 = 0.f, mb2 = 0.f, vb2 = 0.f, mex = 0.f, vex = 0.f, gb1r = 0.f, gb2r = 0.f, gex = 0.f;
   int ex_g = -1, ex_s = S::MISC + 63;
-  const bool low = fh == 0;     // wave-uniform: owns the head column block, the biases and the extra entries
+  const bool low = fh == 0;     // wave-uniform: owns b1 / b2 (and, without TAILW, the head column block and the extra entries)
+  // TAILW (obs 17 / 18: the second observation tile holds one or two real columns) — MEASURED AND REJECTED, off by default.  That tile is a full
+  // 16 x 16 x 64 GEMM of the high waves (16 MFMAs for <= 2 useful columns) and a full Adam block.  With TAILW the tail columns are per-row
+  // vectors like the biases: d W1[j][16 + c] = sum_rows dz1^T[j][row] x^T[16 + c][row] as 16 FMAs per lane and column + the quad-row sum,
+  // owned (q-replicated, lane q == 0 stores) by the high wave of row block rt: 16 MFMAs less on the SIMD's pipe per step.  8.48 us per
+  // step against 8.42 — the ~45 VALU / LDS instructions cost the late (high) wave more than the 16 MFMAs did.  ICRL_W1_TAIL_MOVE_HEAD
+  // additionally moves the head (dWh GEMM, its Adam block, head bias, log_std) to the high waves so that both waves of a pair carry 48
+  // weight-gradient MFMAs and 4 Adam blocks (64 / 48 and 5 / 3 otherwise): 8.84 us — the high wave of a pair loses the issue arbitration
+  // to the older low wave, so the uneven split IS the balanced one (per-wave timers: the high waves then reach the norm barrier 1.8 k
+  // cycles after the low waves instead of 1 k before them).
+  constexpr bool TAILW = ICRL_W1_TAIL && OBS > 0 && NT1 == 2 && OBS / 16 == 1 && (OBS % 16 == 1 || OBS % 16 == 2);
+  constexpr int NTAIL = TAILW ? OBS % 16 : 0;
+  const bool own_wh = (TAILW && ICRL_W1_TAIL_MOVE_HEAD) ? !low : low;          // head column block, head bias / log_std
+  auto wave_of = [](int rt_, int fh_) { return ICRL_PAIR_ADJ ? 2 * rt_ + fh_ : rt_ + 4 * fh_; };
+  const int W_BH = wave_of(0, (TAILW && ICRL_W1_TAIL_MOVE_HEAD) ? 1 : 0), W_LS = wave_of(1, (TAILW && ICRL_W1_TAIL_MOVE_HEAD) ? 1 : 0);       // the waves that own the head bias / log_std
+  float mt[2] = {0.f, 0.f}, vt[2] = {0.f, 0.f}, gt[2] = {0.f, 0.f};                     // tail columns' moments / gradients (high waves)
+  const bool own_w1_tile = !(TAILW && !low);       // this wave owns an observation tile of W1 (TAILW: the low waves' tile 0 only)
   auto w1_addr = [&](int cc, int i) { return S::W1 + (16 * rt + 4 * q + i) * SX + 16 * (NW1 * fh + cc) + r; };
   auto w2_addr = [&](int cc, int i) { return S::W2 + (16 * rt + 4 * q + i) * SH + 16 * (2 * fh + cc) + r; };
   auto store_w1 = [&](int cc, const f32x4& v) {
@@ -258,11 +291,20 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int j = 16 * rt + 4 * q + i, k = 16 * (NW1 * fh + cc) + r;
-        pv[i] = k < O ? a.params[gW1 + j * O + k] : 0.f;
-        mW1[cc][i] = k < O ? a.exp_avg[gW1 + j * O + k] : 0.f;
-        vW1[cc][i] = k < O ? a.exp_avg_sq[gW1 + j * O + k] : 0.f;
+        const bool mine = own_w1_tile && k < O;
+        pv[i] = mine ? a.params[gW1 + j * O + k] : 0.f;
+        mW1[cc][i] = mine ? a.exp_avg[gW1 + j * O + k] : 0.f;
+        vW1[cc][i] = mine ? a.exp_avg_sq[gW1 + j * O + k] : 0.f;
       }
-      store_w1(cc, pv);
+      if (own_w1_tile) store_w1(cc, pv);
+    }
+    if (TAILW && !low) {
+#pragma unroll
+      for (int c = 0; c < NTAIL; ++c) {
+        const int e = gW1 + jb * O + 16 + c;
+        mt[c] = a.exp_avg[e]; vt[c] = a.exp_avg_sq[e];
+        if (q == 0) sm[S::W1 + jb * SX + 16 + c] = a.params[e];
+      }
     }
 #pragma unroll
     for (int cc = 0; cc < 2; ++cc) {
@@ -277,7 +319,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       store_w2(cc, pv);
     }
     mWh = vWh = gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (low) {
+    if (own_wh) {
       f32x4 pv;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -287,15 +329,15 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
         vWh[i] = o < n_out ? a.exp_avg_sq[gWh + o * HD + j] : 0.f;
       }
       store_wh(pv);
+      if (w == W_BH && ro < n_out) { ex_g = gbh + ro; ex_s = S::BH + r; }      // lane r: the entry at POSITION r
+      if (w == W_LS && !DISC && role == 0 && ro < A) { ex_g = L.log_std + ro; ex_s = S::LS + r; }
+      if (ex_g >= 0) { mex = a.exp_avg[ex_g]; vex = a.exp_avg_sq[ex_g]; }
+      if (q == 0) sm[ex_s] = ex_g >= 0 ? a.params[ex_g] : 0.f;        // lanes without an extra entry hit a scratch word
+    }
+    if (low) {
       mb1 = a.exp_avg[gb1 + jb]; vb1 = a.exp_avg_sq[gb1 + jb];
       mb2 = a.exp_avg[gb2 + jb]; vb2 = a.exp_avg_sq[gb2 + jb];
-      if (w == 0 && ro < n_out) { ex_g = gbh + ro; ex_s = S::BH + r; }      // lane r: the entry at POSITION r
-      if (w == LS_WAVE && !DISC && role == 0 && ro < A) { ex_g = L.log_std + ro; ex_s = S::LS + r; }
-      if (ex_g >= 0) { mex = a.exp_avg[ex_g]; vex = a.exp_avg_sq[ex_g]; }
-      if (q == 0) {
-        sm[S::B1 + jb] = a.params[gb1 + jb]; sm[S::B2 + jb] = a.params[gb2 + jb];
-        sm[ex_s] = ex_g >= 0 ? a.params[ex_g] : 0.f;        // lanes without an extra entry hit a scratch word
-      }
+      if (q == 0) { sm[S::B1 + jb] = a.params[gb1 + jb]; sm[S::B2 + jb] = a.params[gb2 + jb]; }
     }
   }
 
@@ -405,7 +447,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     istd_r = __builtin_amdgcn_rcpf(__builtin_amdgcn_sqrtf(var) + 1e-8f);
   };
   auto refresh_gauss = [&]() {   // wave 1, lanes q == 0 own log_std r: derived constants of the Gaussian head
-    if (!DISC && role == 0 && w == LS_WAVE && q == 0) {
+    if (!DISC && role == 0 && w == W_LS && q == 0) {
       const float wex = sm[S::LS + r];
       const float sd = __expf(wex);
       const float iv = __builtin_amdgcn_rcpf(sd * sd);
@@ -834,7 +876,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 #pragma unroll
         for (int cc = 0; cc < NW1; ++cc) gW1r[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
         gW2r[0] = gW2r[1] = gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
-        gb1r = 0.f; gb2r = 0.f; gex = 0.f;
+        gb1r = 0.f; gb2r = 0.f; gex = 0.f; gt[0] = gt[1] = 0.f;
       }
       if (!(ICRL_DIAG & 1)) lds_barrier();  // (S5) every pair's columns of h1^T, h2^T, dz1^T, dz2^T, dOut^T (and the loss partials) are complete
       FSTAMP(12)  // S5
@@ -850,6 +892,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
           f32x4 bh[4];
 #pragma unroll
           for (int js = 0; js < 4; ++js) bh[js] = lds128(pb + 16 * js);
+          OPERANDS_FIRST();
 #pragma unroll
           for (int js = 0; js < 4; ++js)
 #pragma unroll
@@ -863,12 +906,13 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
         }
       }
       FSTAMP(10)  // dW2
-      if (low) {   // dWh columns 16 rt..: A = dOut^T[o = r][rows], B = h2^T[j = 16 rt + r][rows]
+      if (own_wh) {   // dWh columns 16 rt..: A = dOut^T[o = r][rows], B = h2^T[j = 16 rt + r][rows]
         f32x4 ao[4], bh[4];
         const float* pa = sm + S::DOT + r * ST + 4 * q;
         const float* pb = sm + S::H2T + (16 * rt + r) * ST + 4 * q;
 #pragma unroll
         for (int js = 0; js < 4; ++js) { ao[js] = lds128(pa + 16 * js); bh[js] = lds128(pb + 16 * js); }
+        OPERANDS_FIRST();
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int js = 0; js < 4; ++js)
@@ -882,7 +926,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
         s = quad_rows_sum(s);
         // log_std's wave (Gaussian policy): d log_std r = sum of the four per-tile partials
         const float sl = (sm[S::PLS + r] + sm[S::PLS + 16 + r]) + (sm[S::PLS + 32 + r] + sm[S::PLS + 48 + r]);
-        gex += w == 0 ? s : ((!DISC && role == 0 && w == LS_WAVE) ? sl : 0.f);
+        gex += w == W_BH ? s : ((!DISC && role == 0 && w == W_LS) ? sl : 0.f);
       }
       FSTAMP(11)  // dWh
       {  // dW1 rows 16 rt.., observation tiles NW1 fh ..
@@ -890,12 +934,28 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
         const float* pa = sm + S::DZ1T + (16 * rt + r) * ST + 4 * q;
 #pragma unroll
         for (int js = 0; js < 4; ++js) az[js] = lds128(pa + 16 * js);
+        if (TAILW && !low) {      // the tail columns k = 16 + c as dot products over this lane's 16 rows, summed over the lane groups
+#pragma unroll
+          for (int c = 0; c < NTAIL; ++c) {
+            const float* px_ = sm + xcur + (16 + c) * ST + 4 * q;      // x^T[16 + c][rows 16 js + 4 q + e] (the same for every r)
+            float s_ = 0.f;
+#pragma unroll
+            for (int js = 0; js < 4; ++js) {
+              const f32x4 xr = lds128(px_ + 16 * js);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) s_ = fmaf(az[js][e], xr[e], s_);
+            }
+            gt[c] += quad_rows_sum(s_);
+          }
+        }
 #pragma unroll
         for (int cc = 0; cc < NW1; ++cc) {
+          if (!own_w1_tile) break;
           const float* pb = sm + xcur + (16 * (NW1 * fh + cc) + r) * ST + 4 * q;     // x^T[k][rows 16 js + 4 q + e]
           f32x4 bx[4];
 #pragma unroll
           for (int js = 0; js < 4; ++js) bx[js] = lds128(pb + 16 * js);
+          OPERANDS_FIRST();
 #pragma unroll
           for (int js = 0; js < 4; ++js)
 #pragma unroll
@@ -923,7 +983,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     }  // chunks
 
     // entropy term of the Gaussian policy loss: d(ent_coef * -mean(H)) / d log_std = -ent_coef
-    if (!DISC && role == 0 && w == LS_WAVE && ro < A) gex += -ent_coef;
+    if (!DISC && role == 0 && w == W_LS && ro < A) gex += -ent_coef;
 
     // ================= global gradient norm: this wave's partial sum of squares -> its own 8-byte granule =================
     float ss = 0.f;
@@ -936,10 +996,15 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     for (int cc = 0; cc < 2; ++cc)
 #pragma unroll
       for (int i = 0; i < 4; ++i) ss = fmaf(gW2r[cc][i], gW2r[cc][i], ss);
-    if (low) {
+    {
+      float sb = 0.f;      // per-row entries (replicated over the lane groups: counted on q == 0)
+      if (own_wh) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) ss = fmaf(gWhr[i], gWhr[i], ss);
-      const float sb = fmaf(gb1r, gb1r, gb2r * gb2r) + (ex_g >= 0 ? gex * gex : 0.f);
+        for (int i = 0; i < 4; ++i) ss = fmaf(gWhr[i], gWhr[i], ss);
+        sb = ex_g >= 0 ? gex * gex : 0.f;
+      }
+      if (low) sb = fmaf(gb1r, gb1r, gb2r * gb2r) + sb;
+      if (TAILW && !low) sb = fmaf(gt[0], gt[0], gt[1] * gt[1]) + sb;
       ss += q == 0 ? sb : 0.f;
     }
     ss = wave_sum_fast(ss);
@@ -1060,9 +1125,27 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       };
       // pad elements (k >= obs, o >= n_out) have g = m = v = p = 0 and stay 0: no masks needed
       // Part 1: what layer 1 reads (W1, b1; the low waves' bias block carries b2 and the head bias / log_std along)
+      if (own_w1_tile) {
 #pragma unroll
-      for (int cc = 0; cc < NW1; ++cc) { f32x4 p_ = load_own_w1(cc); adam4(gW1r[cc], mW1[cc], vW1[cc], p_); store_w1(cc, p_); }
-      if (low) {
+        for (int cc = 0; cc < NW1; ++cc) { f32x4 p_ = load_own_w1(cc); adam4(gW1r[cc], mW1[cc], vW1[cc], p_); store_w1(cc, p_); }
+      }
+      if (TAILW) {      // per-row entries, lane q == 0 stores — low: {b1, b2}, high: {tail column 0, tail column 1}; the head bias | log_std rides with its owner
+        const bool exo = own_wh && ex_g >= 0;
+        if (low) {
+          f32x4 g_ = f32x4{gb1r, gb2r, exo ? gex : 0.f, 0.f}, p_ = f32x4{sm[S::B1 + jb], sm[S::B2 + jb], own_wh ? sm[ex_s] : 0.f, 0.f};
+          f32x4 m_ = f32x4{mb1, mb2, mex, 0.f}, v_ = f32x4{vb1, vb2, vex, 0.f};
+          adam4(g_, m_, v_, p_);
+          mb1 = m_[0]; mb2 = m_[1]; mex = m_[2]; vb1 = v_[0]; vb2 = v_[1]; vex = v_[2];
+          if (q == 0) { sm[S::B1 + jb] = p_[0]; sm[S::B2 + jb] = p_[1]; if (own_wh) sm[ex_s] = p_[2]; }
+        } else {
+          float* const pw = sm + S::W1 + jb * SX + 16;
+          f32x4 g_ = f32x4{gt[0], gt[1], exo ? gex : 0.f, 0.f}, p_ = f32x4{pw[0], NTAIL > 1 ? pw[1] : 0.f, own_wh ? sm[ex_s] : 0.f, 0.f};
+          f32x4 m_ = f32x4{mt[0], mt[1], mex, 0.f}, v_ = f32x4{vt[0], vt[1], vex, 0.f};
+          adam4(g_, m_, v_, p_);
+          mt[0] = m_[0]; mt[1] = m_[1]; mex = m_[2]; vt[0] = v_[0]; vt[1] = v_[1]; vex = v_[2];
+          if (q == 0) { pw[0] = p_[0]; if (NTAIL > 1) pw[1] = p_[1]; if (own_wh) sm[ex_s] = p_[2]; }
+        }
+      } else if (low) {
         f32x4 g_ = f32x4{gb1r, gb2r, ex_g >= 0 ? gex : 0.f, 0.f}, p_ = f32x4{sm[S::B1 + jb], sm[S::B2 + jb], sm[ex_s], 0.f};
         f32x4 m_ = f32x4{mb1, mb2, mex, 0.f}, v_ = f32x4{vb1, vb2, vex, 0.f};
         adam4(g_, m_, v_, p_);     // identical arithmetic in the four q lanes, lane q == 0 stores
@@ -1073,7 +1156,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       auto adam_rest = [&]() {
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) { f32x4 p_ = load_own_w2(cc); adam4(gW2r[cc], mW2[cc], vW2[cc], p_); store_w2(cc, p_); }
-        if (low) {
+        if (own_wh) {
           { f32x4 p_ = load_own_wh(); adam4(gWhr, mWh, vWh, p_); store_wh(p_); }
           __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the log_std store has landed before refresh_gauss re-reads it
           refresh_gauss();
@@ -1104,13 +1187,21 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   const PolLayout& L = a.L;
   const int gW1 = L.W1[role], gb1 = L.b1[role], gW2 = L.W2[role], gb2 = L.b2[role];
   const int gWh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
+  if (own_w1_tile) {
 #pragma unroll
-  for (int cc = 0; cc < NW1; ++cc) {
-    const f32x4 pv = load_own_w1(cc);
+    for (int cc = 0; cc < NW1; ++cc) {
+      const f32x4 pv = load_own_w1(cc);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int j = 16 * rt + 4 * q + i, k = 16 * (NW1 * fh + cc) + r;
-      if (k < O) { a.params[gW1 + j * O + k] = pv[i]; a.exp_avg[gW1 + j * O + k] = mW1[cc][i]; a.exp_avg_sq[gW1 + j * O + k] = vW1[cc][i]; }
+      for (int i = 0; i < 4; ++i) {
+        const int j = 16 * rt + 4 * q + i, k = 16 * (NW1 * fh + cc) + r;
+        if (k < O) { a.params[gW1 + j * O + k] = pv[i]; a.exp_avg[gW1 + j * O + k] = mW1[cc][i]; a.exp_avg_sq[gW1 + j * O + k] = vW1[cc][i]; }
+      }
+    }
+  } else if (q == 0) {
+#pragma unroll
+    for (int c = 0; c < NTAIL; ++c) {
+      const int e = gW1 + jb * O + 16 + c;
+      a.params[e] = sm[S::W1 + jb * SX + 16 + c]; a.exp_avg[e] = mt[c]; a.exp_avg_sq[e] = vt[c];
     }
   }
 #pragma unroll
@@ -1124,18 +1215,18 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       a.exp_avg_sq[gW2 + j * HD + k] = vW2[cc][i];
     }
   }
-  if (low) {
+  if (own_wh) {
     const f32x4 pv = load_own_wh();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int o = out_of(i), j = 16 * rt + r;
       if (o < n_out) { a.params[gWh + o * HD + j] = pv[i]; a.exp_avg[gWh + o * HD + j] = mWh[i]; a.exp_avg_sq[gWh + o * HD + j] = vWh[i]; }
     }
-    if (q == 0) {
-      a.params[gb1 + jb] = sm[S::B1 + jb]; a.exp_avg[gb1 + jb] = mb1; a.exp_avg_sq[gb1 + jb] = vb1;
-      a.params[gb2 + jb] = sm[S::B2 + jb]; a.exp_avg[gb2 + jb] = mb2; a.exp_avg_sq[gb2 + jb] = vb2;
-      if (ex_g >= 0) { a.params[ex_g] = sm[ex_s]; a.exp_avg[ex_g] = mex; a.exp_avg_sq[ex_g] = vex; }
-    }
+    if (q == 0 && ex_g >= 0) { a.params[ex_g] = sm[ex_s]; a.exp_avg[ex_g] = mex; a.exp_avg_sq[ex_g] = vex; }
+  }
+  if (low && q == 0) {
+    a.params[gb1 + jb] = sm[S::B1 + jb]; a.exp_avg[gb1 + jb] = mb1; a.exp_avg_sq[gb1 + jb] = vb1;
+    a.params[gb2 + jb] = sm[S::B2 + jb]; a.exp_avg[gb2 + jb] = mb2; a.exp_avg_sq[gb2 + jb] = vb2;
   }
 #ifdef ICRL_FINE_PROF
   // which wave reports: hp._pad bits 8..10 = wave, bits 12..13 = role (tools/train_only.py FINE=1)
@@ -1189,7 +1280,8 @@ static int launch_pairs(const TrainArgs* one, const TrainArgs* d_args, int n_run
   if (one != nullptr) {
     hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((ppo_train_pairs_kernel<NT1, DISC, OBS>), dim3(3), dim3(TH8), bytes, s, *one);
+    TrainArgs arg = *one;
+    return (int)launch_coresident(ppo_train_pairs_kernel<NT1, DISC, OBS>, dim3(3), dim3(TH8), bytes, s, arg);
   } else {
     hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_batch_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;

@@ -1076,8 +1076,8 @@ static int launch_rows(const TrainArgs& a, hipStream_t s) {
   const size_t bytes = ICRL_ROWS_STATIC_LDS ? 0 : (size_t)SmemR<NT1>::TOTAL * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_kernel<NT1, DISC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((ppo_train_rows_kernel<NT1, DISC, SPLIT>), dim3(SPLIT ? 6 : 3), dim3(TH4), bytes, s, a);
-  return (int)hipGetLastError();
+  TrainArgs arg = a;
+  return (int)launch_coresident(ppo_train_rows_kernel<NT1, DISC, SPLIT>, dim3(SPLIT ? 6 : 3), dim3(TH4), bytes, s, arg);
 }
 
 int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hipStream_t s) {

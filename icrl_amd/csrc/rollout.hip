@@ -2948,7 +2948,10 @@ template <int OCT, int CIT, int E>
 static int launch_multi_e(const WideArgs* one, const WideArgs* d_args, int n_runs, int G, size_t dyn, hipStream_t s) {
   if (one != nullptr) {
     if (!persistent_fits(rollout_multi_kernel<OCT, CIT, E>, G, dyn)) return -1;
-    hipLaunchKernelGGL((rollout_multi_kernel<OCT, CIT, E>), dim3(G), dim3(256), dyn, s, *one);
+    WideArgs arg = *one;
+    const hipError_t e = launch_coresident(rollout_multi_kernel<OCT, CIT, E>, dim3(G), dim3(256), dyn, s, arg);
+    if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return -1; }
+    return (int)e;
   } else {
     if (!persistent_fits(rollout_multi_batch_kernel<OCT, CIT, E>, G, dyn)) return -1;
     hipLaunchKernelGGL((rollout_multi_batch_kernel<OCT, CIT, E>), dim3(G, n_runs), dim3(256), dyn, s, d_args);
@@ -3037,9 +3040,9 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
         p.sg = p.xg + 2 * (size_t)N * GX;
         hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
         if (e != hipSuccess) return (int)e;
-        if (small) hipLaunchKernelGGL((rollout_wide_kernel<2, 2>), dim3(G), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((rollout_wide_kernel<8, 10>), dim3(G), dim3(256), 0, s, p);
-        int err = (int)hipGetLastError();
+        int err = (int)(small ? launch_coresident(rollout_wide_kernel<2, 2>, dim3(G), dim3(256), 0, s, p)
+                              : launch_coresident(rollout_wide_kernel<8, 10>, dim3(G), dim3(256), 0, s, p));
+        if (err == (int)hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); goto per_step; }
         if (err || !(do_gae & 1)) return err;
         return icrl_gae_dual_ws(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
                              ag->last_v_c, ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns,
@@ -3071,9 +3074,12 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
       if (e != hipSuccess) return (int)e;
       const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
       const size_t dyn = persist_dyn_lds(N, O, env->act_dim);
+      int coop_err = 0;
       auto go = [&](auto kernel) -> bool {
         if (!persistent_fits(kernel, N, dyn)) return false;
-        hipLaunchKernelGGL(kernel, dim3(N), dim3(256), dyn, s, p);
+        const hipError_t e_ = launch_coresident(kernel, dim3(N), dim3(256), dyn, s, p);
+        if (e_ == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return false; }
+        coop_err = (int)e_;
         return true;
       };
       bool launched;
@@ -3081,7 +3087,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
       else if (small) launched = go(rollout_persistent_kernel<2, 2, false>);
       else if (gran) launched = go(rollout_persistent_kernel<8, 10, true>);
       else launched = go(rollout_persistent_kernel<8, 10, false>);
-      int err = (int)hipGetLastError();
+      int err = coop_err != 0 ? coop_err : (int)hipGetLastError();
       if (!launched) goto per_step;
       if (err || !(do_gae & 1)) return err;
       return icrl_gae_dual_ws(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
