@@ -28,6 +28,12 @@
 // static LDS array instead of `extern __shared__` (ppo_train_pairs.hip: -1.6 % there).  Measured here: at AntWall widths 30.5 us per
 // step against 24.0 (scratch instructions 336 -> 424: the folded offsets let the optimiser hoist more than the register file holds),
 // at HC widths 10.1-10.3 against 10.2-10.5 — off.
+#ifndef ICRL_EARLY_PUBLISH
+#define ICRL_EARLY_PUBLISH 1
+#endif
+#ifndef ICRL_EARLY_RECV
+#define ICRL_EARLY_RECV 0
+#endif
 #ifndef ICRL_ROWS_STATIC_LDS
 #define ICRL_ROWS_STATIC_LDS 0
 #endif
@@ -84,6 +90,25 @@ struct SmemR {  // offsets in floats (multiples of 4)
 // the whole update of ONE run (see ppo_train_pairs_body): `ka` = the same argument block in memory
 // BATCH: the argument block was read from memory (batched launch): its pointers are marked as global-memory pointers (common.h:
 // as_global).  The single-run kernel's by-value pointers already are, and at AntWall widths the extra scalar traffic costs it 6 %.
+// SPLIT exchange: which gradient group (0 .. NT1-1: W1 tiles, NT1 .. NT1+3: W2 tiles, NT1+4: head, NT1+5: {b1, b2, extra}) is fetched
+// during dW1 tile c — the W2 tiles and the head first (published before dW1 started), then the W1 tiles published five tiles ago
+__host__ __device__ constexpr int early_group_of(int nt1, int c) { return c < 5 ? nt1 + c : c - 5; }
+template <int NT1>
+struct RemGroups {      // the groups the final pass still has to fetch
+  int v[NT1 + 6];
+  int n;
+  static constexpr RemGroups make(bool early) {
+    RemGroups r{};
+    r.n = 0;
+    for (int g = 0; g < NT1 + 6; ++g) {
+      bool e = false;
+      for (int c = 0; c < NT1; ++c) e = e || (early && early_group_of(NT1, c) == g);
+      if (!e) r.v[r.n++] = g;
+    }
+    return r;
+  }
+};
+
 template <int NT1, bool DISC, bool SPLIT, bool BATCH>
 __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const TrainArgs* const ka) {
 #define GP(x) (BATCH ? as_global(x) : (x))
@@ -394,6 +419,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
     float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f, mb_s4 = 0.f;  // bookkeeping lane: minibatch sums of the loss statistics
 
     const int n_chunks = SPLIT ? 1 : (nb + RB - 1) / RB;
+    unsigned pend = 0;      // SPLIT: gradient groups of the other half that had not arrived when they were looked at
     for (int ch = 0; ch < n_chunks; ++ch, ++g_chunk) {
       const int first = SPLIT ? half * RB : ch * RB;        // SPLIT: a half without rows (ragged last minibatch) runs on zero rows
       const int nrows = nb - first < 0 ? 0 : ((nb - first) < RB ? (nb - first) : RB);
@@ -655,6 +681,35 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
         gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
         gb1r = 0.f; gb2r = 0.f; gex = 0.f;
       }
+      // SPLIT + ICRL_EARLY_PUBLISH: a gradient register group goes out to the other half as soon as its GEMM is done — one GEMM late, so that
+      // the store does not wait for the MFMA chain that produces it — instead of all 55 granules per thread behind the last GEMM:
+      // the exchange is throughput-bound (~1 granule per cycle and CU), and the memory pipe runs beside the MFMAs of the next tiles.
+      constexpr int KG_ = 4 * NT1 + 23;
+      u64* const mine_e = SPLIT ? GP(KARGS()->gx) + ((size_t)((step & 1) * 3 + role) * 2 + half) * ((size_t)(KG_ + 5) * TH4) + tid : nullptr;
+      auto publish4 = [&](int g, const f32x4& v) {
+        if (!(SPLIT && ICRL_EARLY_PUBLISH)) return;
+        const u64 tg_ = (u64)step << 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          __hip_atomic_store(mine_e + (size_t)(4 * g + i) * TH4, tg_ | (u64)__float_as_uint(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      // ICRL_EARLY_RECV (measured and rejected: 24.0 us per step against 22.5 with the early publish alone — a group that is looked at
+      // inside the MFMA stream stalls it when it is late, and the in-order vmcnt makes every look wait for the stores issued since;
+      // off): the partner's groups fetched the same way — during dW1 tile c the granules of group early_group(c) (which
+      // the partner published several tiles ago) are loaded, one tile later they are checked and added to the own (already
+      // published) partial; a group that has not arrived is left to the polling pass below (`pend`).
+      const u64* const theirs_e = SPLIT ? GP(KARGS()->gx) + ((size_t)((step & 1) * 3 + role) * 2 + (1 - half)) * ((size_t)(KG_ + 5) * TH4) + tid : nullptr;
+      u64 eb[4] = {0, 0, 0, 0};
+      auto early_issue = [&](int g) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) eb[i] = __hip_atomic_load(theirs_e + (size_t)(4 * g + i) * TH4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      auto early_take = [&](int g, f32x4& v) {
+        const bool ok = (unsigned)(eb[0] >> 32) == step && (unsigned)(eb[1] >> 32) == step && (unsigned)(eb[2] >> 32) == step && (unsigned)(eb[3] >> 32) == step;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = ok ? v[i] + __uint_as_float((unsigned)eb[i]) : v[i];
+        pend |= ok ? 0u : (1u << g);
+      };
       // ================= weight gradients: rows 16w.. of dW2 / dW1, columns 16w.. of dWh; K = the 64 rows =================
       {
         f32x4 az[4];   // dz2^T[j = 16w + r][rows 16 js + 4q + e]
@@ -671,6 +726,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
           for (int js = 0; js < 4; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e) gW2r[t] = MFMA_F32(az[js][e], bh[js][e], gW2r[t]);
+          if (t > 0) publish4(NT1 + t - 1, gW2r[t - 1]);
         }
         float s = 0.f;     // d b2[16w + r] = sum over the rows
 #pragma unroll
@@ -690,6 +746,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[js] = MFMA_F32(ao[js][e], bh[js][e], acc[js]);
         }
+        publish4(NT1 + 3, gW2r[3]);
 #pragma unroll
         for (int i = 0; i < 4; ++i) gWhr[i] += (acc[0][i] + acc[1][i]) + (acc[2][i] + acc[3][i]);
         float s = 0.f;      // head bias (wave 0 keeps it): row sums of dOut^T
@@ -723,11 +780,21 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
           for (int js = 0; js < 4; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e) gW1r[c] = MFMA_F32(az[js][e], bx[js][e], gW1r[c]);
+          if (c == 0) publish4(NT1 + 4, gWhr); else publish4(c - 1, gW1r[c - 1]);
+          if (SPLIT && ICRL_EARLY_PUBLISH && ICRL_EARLY_RECV) {
+            if (c > 0) { const int gp = early_group_of(NT1, c - 1); early_take(gp, gp < NT1 ? gW1r[gp < NT1 ? gp : 0] : (gp < NT1 + 4 ? gW2r[gp - NT1 < 4 && gp >= NT1 ? gp - NT1 : 0] : gWhr)); }
+            early_issue(early_group_of(NT1, c));
+          }
+        }
+        if (SPLIT && ICRL_EARLY_PUBLISH && ICRL_EARLY_RECV) {
+          const int gp = early_group_of(NT1, NT1 - 1);
+          early_take(gp, gp < NT1 ? gW1r[gp < NT1 ? gp : 0] : (gp < NT1 + 4 ? gW2r[gp - NT1 < 4 && gp >= NT1 ? gp - NT1 : 0] : gWhr));
         }
         float s = 0.f;
 #pragma unroll
         for (int js = 0; js < 4; ++js) s += (az[js][0] + az[js][1]) + (az[js][2] + az[js][3]);
         gb1r += quad_rows_sum(s);
+        publish4(NT1 - 1, gW1r[NT1 - 1]);
       }
       if (book) {
         mb_s0 += (sm[S::PST + 0] + sm[S::PST + 8]) + (sm[S::PST + 16] + sm[S::PST + 24]);
@@ -754,6 +821,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
       auto grp = [&](int g) -> f32x4& { return g < NT1 ? gW1r[g] : (g < NT1 + 4 ? gW2r[g - NT1] : (g == NT1 + 4 ? gWhr : gsc)); };
 #pragma unroll
       for (int g = 0; g < NGRP; ++g) {
+        if (ICRL_EARLY_PUBLISH && g < NT1 + 5) continue;      // (already out, group by group, behind their GEMMs)
         const f32x4 v = grp(g);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -774,7 +842,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
       bool timed_out = false;
       constexpr int DEP = 4;
       u64 ring[DEP][4];
-      unsigned pend = 0;
+      constexpr RemGroups<NT1> REM = RemGroups<NT1>::make(SPLIT && ICRL_EARLY_PUBLISH && ICRL_EARLY_RECV);
       auto issue = [&](u64 (&b)[4], int g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -784,16 +852,18 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
         return (unsigned)(b[0] >> 32) == step && (unsigned)(b[1] >> 32) == step && (unsigned)(b[2] >> 32) == step && (unsigned)(b[3] >> 32) == step;
       };
 #pragma unroll
-      for (int g = 0; g < DEP; ++g) issue(ring[g], g);
+      for (int k = 0; k < DEP; ++k)
+        if (k < REM.n) issue(ring[k], REM.v[k]);
 #pragma unroll
-      for (int g = 0; g < NGRP; ++g) {
-        u64 (&c)[4] = ring[g % DEP];
+      for (int k = 0; k < REM.n; ++k) {
+        const int g = REM.v[k];
+        u64 (&c)[4] = ring[k % DEP];
         const bool ok = arrived(c);
         f32x4& v = grp(g);
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = ok ? v[i] + __uint_as_float((unsigned)c[i]) : v[i];   // own + partner (commutative: both halves agree)
         pend |= ok ? 0u : (1u << g);
-        if (g + DEP < NGRP) issue(c, g + DEP);
+        if (k + DEP < REM.n) issue(c, REM.v[k + DEP]);
       }
       if (__any(pend != 0u)) {
 #pragma unroll
