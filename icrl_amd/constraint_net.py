@@ -58,8 +58,12 @@ class ConstraintNet:
     def _build(self):
         """ref: constraint_net.py:101-116 — create_mlp(input, 1, hidden) with ReLU + Sigmoid; host init, device storage."""
         hs = list(self.hidden_sizes)
-        if not (1 <= len(hs) <= 2) or max(hs) > 64:
-            raise NotImplementedError(f"icrl_amd ConstraintNet supports 1-2 hidden layers of <= 64 units, got {hs}")
+        if not (1 <= len(hs) <= 2) or max(hs) > 128 or min(hs) < 1:
+            raise NotImplementedError(f"icrl_amd ConstraintNet supports 1-2 hidden layers of 1..128 units (up to 64 inside the fused rollout, "
+                                      f"wider through the per-step path), got {hs}")
+        # a hidden layer above 64 units: the one-wave-per-row cost kernels (inside the fused rollout) do not hold it; cost_function and
+        # train() then run 64 rows per workgroup with the weights read from device memory (csrc/cn_train.hip: cn_cost_rows_kernel, wglobal)
+        self.wide = max(hs) > 64
         sd, last, k = OrderedDict(), self.input_dims, 0
         for h in hs + [1]:
             lin = torch.nn.Linear(last, h)

@@ -25,17 +25,22 @@ constexpr int CN_NPART = 16;   // statistics per block
 struct CnDims {
   int D, nh, H1, H2, HL;       // input, hidden layers, widths, width of the last hidden layer
   int W0, b0, W1, b1, Wo, bo, n_params;
+  int wglobal;                 // 1: the weights stay in device memory (wide nets: the 64-row activation images alone fill the LDS)
   // LDS offsets (floats)
   int sW, sX, sH1, sH2, sD1, sD2, sZ, total;
 };
+
+constexpr int CN_LDS_FLOATS = 160 * 1024 / 4;
 
 __host__ __device__ inline CnDims make_cn_dims(int D, int nh, int H1, int H2) {
   CnDims d;
   CnLayout L = make_cn_layout(D, nh, H1, H2);
   d.D = D; d.nh = nh; d.H1 = H1; d.H2 = (nh == 2 ? H2 : 0); d.HL = L.H2;
   d.W0 = L.W0; d.b0 = L.b0; d.W1 = L.W1; d.b1 = L.b1; d.Wo = L.Wo; d.bo = L.bo; d.n_params = L.n;
+  const int act = CN_ROWS * (D + 1) + 2 * CN_ROWS * (H1 + 1) + (nh == 2 ? 2 * CN_ROWS * (H2 + 1) : 0) + 2 * CN_ROWS;
+  d.wglobal = (L.n + act > CN_LDS_FLOATS) ? 1 : 0;      // the reference's widths (<= 64) keep their weights in LDS as before
   int off = 0;
-  d.sW = off; off += L.n;
+  d.sW = off; off += d.wglobal ? 0 : L.n;
   d.sX = off; off += CN_ROWS * (D + 1);
   d.sH1 = off; off += CN_ROWS * (H1 + 1);
   d.sH2 = off; off += (nh == 2 ? CN_ROWS * (H2 + 1) : 0);
@@ -75,12 +80,12 @@ struct CnTrainArgs {
   int mb_n;            // ... and their number; nb_n == nb_e == ceil(mb_n / 64) in the arguments of those launches
 };
 
+__device__ __forceinline__ void cn_block_mlp(const CnDims& d, float* sm, const float* params);
+
 // block-level forward of CN_ROWS rows starting at row0 of `src` ([n, D]); leaves x, h1, (h2) in LDS, zeta in sm[sZ + row]
 __device__ __forceinline__ void cn_block_forward(const CnDims& d, float* sm, const float* params, const float* src, int row0,
                                                  int n_rows_total, const int* gather = nullptr) {
   const int tid = threadIdx.x;
-  const int row = tid & 63, part = __builtin_amdgcn_readfirstlane(tid >> 6);
-  for (int i = tid; i < d.n_params; i += CN_TH) sm[d.sW + i] = params[i];
   const int D = d.D;
   for (int i = tid; i < CN_ROWS * D; i += CN_TH) {
     const int rr = i / D, k = i % D;
@@ -88,8 +93,18 @@ __device__ __forceinline__ void cn_block_forward(const CnDims& d, float* sm, con
     if (row0 + rr < n_rows_total) v = src[(size_t)(gather ? gather[row0 + rr] : row0 + rr) * D + k];
     sm[d.sX + rr * (D + 1) + k] = v;
   }
+  cn_block_mlp(d, sm, params);
+}
+
+// the ReLU-MLP + sigmoid of the CN_ROWS input rows already in sm[sX] (a barrier is taken first); leaves h1, (h2) in LDS, zeta in sm[sZ + row]
+__device__ __forceinline__ void cn_block_mlp(const CnDims& d, float* sm, const float* params) {
+  const int tid = threadIdx.x;
+  const int row = tid & 63, part = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int D = d.D;
+  if (!d.wglobal)
+    for (int i = tid; i < d.n_params; i += CN_TH) sm[d.sW + i] = params[i];
   __syncthreads();
-  const float* W = sm + d.sW;
+  const float* W = d.wglobal ? params : sm + d.sW;
   const float* x = sm + d.sX + row * (D + 1);
   float* h1 = sm + d.sH1 + row * (d.H1 + 1);
   for (int j = part; j < d.H1; j += 4) {
@@ -364,7 +379,7 @@ __device__ __forceinline__ void cn_backward_body(const CnTrainArgs& a, int itr) 
   const float cnt_n = (float)(MB ? a.mb_n : a.Nn), cnt_e = (float)(MB ? a.mb_n : a.Ne);
   cn_block_forward(d, sm, a.params, nominal ? a.nominal : a.expert, row0, n_tot, MB ? a.mb_idx : nullptr);
   const int row = tid & 63, part = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const float* W = sm + d.sW;
+  const float* W = d.wglobal ? a.params : sm + d.sW;
   // ---- d loss / d logit
   if (part == 0) {
     const int g = row0 + row;
@@ -514,6 +529,50 @@ __global__ void __launch_bounds__(64) cn_prepare_kernel(icrl_costnet_t cn, const
     }
     out[(size_t)n * cn.in_dim + i] = v;
   }
+}
+
+// ConstraintNet.cost_function / the GAIL discriminator's reward for nets the one-wave-per-row kernel of rollout.hip does not hold
+// (a hidden layer above 64 units): 64 rows per workgroup, prepare_data (constraint_net.py:258-299) straight into the LDS input image,
+// then the block MLP of the update kernels.  mode 0: cost = 1 - zeta; 1: zeta; 2: log(zeta + eps).
+__global__ void __launch_bounds__(CN_TH) cn_cost_rows_kernel(icrl_costnet_t cn, CnDims d, const double* obs, const float* acs, int N, float* out, int mode) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int tid = threadIdx.x, row0 = blockIdx.x * CN_ROWS, D = d.D;
+  const int AS = cn.is_discrete ? 1 : cn.acs_dim;
+  for (int i = tid; i < CN_ROWS * D; i += CN_TH) {
+    const int rr = i / D, k = i % D, n = row0 + rr;
+    float v = 0.f;
+    if (n < N) {
+      const int sel = cn.select_dim[k];
+      if (sel < cn.obs_dim) {
+        double o = obs[(size_t)n * cn.obs_dim + sel];
+        if (cn.obs_mean != nullptr && cn.obs_var != nullptr) o = (o - cn.obs_mean[sel]) / sqrt(cn.obs_var[sel] + cn.eps);
+        if (cn.clip_obs >= 0.0) o = fmin(fmax(o, -cn.clip_obs), cn.clip_obs);
+        v = (float)o;
+      } else {
+        const int kk = sel - cn.obs_dim;
+        float x = cn.is_discrete ? (((int)acs[(size_t)n * AS] == kk) ? 1.f : 0.f) : acs[(size_t)n * AS + kk];
+        if (cn.action_low != nullptr && cn.action_high != nullptr) x = fminf(fmaxf(x, cn.action_low[kk]), cn.action_high[kk]);
+        v = x;
+      }
+    }
+    sm[d.sX + rr * (D + 1) + k] = v;
+  }
+  cn_block_mlp(d, sm, cn.params);
+  if (tid < CN_ROWS && row0 + tid < N) {
+    const float zeta = sm[d.sZ + tid];
+    out[row0 + tid] = mode == 1 ? zeta : (mode == 2 ? logf(zeta + (float)cn.eps) : 1.f - zeta);
+  }
+}
+
+int launch_cn_cost_rows(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, int mode, hipStream_t s) {
+  if (cn->n_hidden < 1 || cn->n_hidden > 2 || cn->in_dim < 1) return fail("cost forward: %d hidden layers (1 or 2), in_dim %d", cn->n_hidden, cn->in_dim);
+  const CnDims d = make_cn_dims(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
+  const size_t lds = (size_t)d.total * sizeof(float);
+  if (lds > 160 * 1024) return fail("cost forward: %zu B of LDS needed for in_dim %d / hidden (%d, %d), 160 KB available", lds, cn->in_dim, cn->h1, cn->h2);
+  hipError_t e = hipFuncSetAttribute((const void*)cn_cost_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(cn_cost_rows_kernel, dim3((N + CN_ROWS - 1) / CN_ROWS), dim3(CN_TH), lds, s, *cn, d, obs, acs, N, out, mode);
+  return (int)hipGetLastError();
 }
 
 static void cn_work_layout(int n_params, int Nn, int Ne, int n_ep, size_t* offs /* 9 */, size_t* total) {

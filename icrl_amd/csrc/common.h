@@ -27,6 +27,9 @@ int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
                          const int* perm_off, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* scratch, hipStream_t s);
 long long generic_train_bytes(int batch_size, int hp, int n_params);
 inline bool policy_is_wide(const icrl_policy_t* p) { return p->h1 > MAX_H || p->h2 > MAX_H; }
+// cn_train.hip: cost / discriminator forward of a constraint net with a hidden layer above MAX_H units (64 rows per workgroup)
+int launch_cn_cost_rows(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, int mode, hipStream_t s);
+inline bool costnet_is_wide(const icrl_costnet_t* cn) { return cn->h1 > MAX_H || (cn->n_hidden == 2 && cn->h2 > MAX_H); }
 
 // argument rejection: formats the reason into the calling thread's icrl_last_error() text, returns hipErrorInvalidValue
 int fail(const char* fmt, ...) __attribute__((format(printf, 1, 2)));

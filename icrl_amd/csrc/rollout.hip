@@ -2708,7 +2708,7 @@ static int bad_dims(const char* who, int O, int A, int H1, int H2) {
               "entry points: icrl_policy_forward / icrl_policy_evaluate / icrl_ppo_lag_train and the per-step rollout)", who, O, MAX_OBS, A, MAX_ACT, H1, H2, MAX_H);
 }
 static int bad_cn(const char* who, const icrl_costnet_t* cn) {
-  return fail("%s: constraint net in_dim %d (1..%d), %d hidden layers (1 or 2) of (%d, %d) (1..%d), obs_dim %d (<= %d), acs_dim %d (<= %d)", who,
+  return fail("%s: constraint net in_dim %d (1..%d), %d hidden layers (1 or 2) of (%d, %d) (1..%d; wider nets: icrl_cost_mlp_forward / icrl_disc_reward / icrl_cn_train and the per-step rollout), obs_dim %d (<= %d), acs_dim %d (<= %d)", who,
               cn->in_dim, MAX_CN_IN, cn->n_hidden, cn->h1, cn->h2, MAX_H, cn->obs_dim, MAX_OBS, cn->acs_dim, MAX_ACT);
 }
 
@@ -2725,7 +2725,7 @@ extern "C" int icrl_policy_prepare(const icrl_policy_t* p, void* stream) {
 }
 
 extern "C" int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream) {
-  if (!cn_ok(cn)) return bad_cn("icrl_costnet_prepare", cn);
+  if (!costnet_is_wide(cn) && !cn_ok(cn)) return bad_cn("icrl_costnet_prepare", cn);
   CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
   if (L.n != cn->n_params) return fail("icrl_costnet_prepare: n_params = %d, the layout needs %d", cn->n_params, L.n);
   hipLaunchKernelGGL(costnet_transpose_kernel, dim3((L.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, cn->params, cn->params_t);
@@ -2854,6 +2854,7 @@ extern "C" int icrl_sample_episodes_batch(int n_runs, const icrl_sample_job_t* j
 extern "C" int icrl_cost_mlp_forward(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* cost,
                                      void* stream) {
   if (N <= 0) return fail("cost forward: N = %d rows", N);
+  if (costnet_is_wide(cn)) return launch_cn_cost_rows(cn, obs, acs, N, cost, 0, (hipStream_t)stream);
   if (!cn_ok(cn)) return bad_cn("cost forward", cn);
   CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
   if (cn->in_dim <= 32) hipLaunchKernelGGL(cost_forward_kernel<2>, dim3(N), dim3(64), 0, (hipStream_t)stream, *cn, L, obs, acs, N, cost, 0);
@@ -2864,6 +2865,7 @@ extern "C" int icrl_cost_mlp_forward(const icrl_costnet_t* cn, const double* obs
 extern "C" int icrl_disc_reward(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, int apply_log,
                                 void* stream) {
   if (N <= 0) return fail("cost forward: N = %d rows", N);
+  if (costnet_is_wide(cn)) return launch_cn_cost_rows(cn, obs, acs, N, out, apply_log ? 2 : 1, (hipStream_t)stream);
   if (!cn_ok(cn)) return bad_cn("cost forward", cn);
   CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
   const int mode = apply_log ? 2 : 1;

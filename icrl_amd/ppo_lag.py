@@ -129,6 +129,8 @@ class PPOLagrangian:
             return env, None, cw
         if not isinstance(cw, VecCostWrapper) or not isinstance(cw.venv, HipSynthVecEnv) or cw.constraint_net() is None:
             return None
+        if getattr(cw.constraint_net(), "wide", False):      # (a constraint net with a layer above 64 units: per-step path)
+            return None
         return env, cw, cw.venv
 
     # ---- noise / permutation streams -------------------------------------------------------------------------------------

@@ -88,7 +88,7 @@ class SeedBatch:
             diff = [k for k in same if getattr(c, k) != getattr(c0, k)]
             if diff:
                 raise ValueError(f"seed batch: the runs of a batch share every grid; they differ in {diff}")
-        if any(st["agent"].policy.wide or int(st["agent"].batch_size) > 256 for st in self.states):
+        if any(st["agent"].policy.wide or int(st["agent"].batch_size) > 256 or getattr(st["constraint_net"], "wide", False) for st in self.states):
             raise ValueError("seed batch: hidden widths above 64 / batch sizes above 256 run on the generic-shape path, which has no batched form")
         if any(st.get("world", 1) > 1 for st in self.states):
             # outer_iteration() below has no per-iteration all-reduce and no rank-0 guard on the saves: a seed batch is a one-rank matter

@@ -86,7 +86,8 @@ typedef struct {
 } icrl_policy_t;
 
 /* ConstraintNet zeta_theta (icrl/constraint_net.py:14-130,258-299): ReLU MLP + sigmoid over
- * concat(clip(obs), clip(acs))[select_dim]; cost = 1 - zeta.  n_hidden in {1,2}.  params flat in state_dict order:
+ * concat(clip(obs), clip(acs))[select_dim]; cost = 1 - zeta.  n_hidden in {1,2}; hidden widths up to 64 inside the fused rollouts,
+ * up to 128 through icrl_cost_mlp_forward / icrl_disc_reward / icrl_cn_train* (64 rows per workgroup).  params flat in state_dict order:
  * W0[h1,in] b0[h1] (W1[h2,h1] b1[h2]) Wo[1,h] bo[1]. */
 typedef struct {
   int32_t obs_dim, acs_dim, in_dim, n_hidden, h1, h2;

@@ -43,7 +43,11 @@ def test_cn_train_golden(golden, case):
 
 
 @pytest.mark.parametrize("kind,hidden,psis,Nn,Ne,eplen", [("hc", [20], True, 3000, 1500, 1000), ("ant", [40, 40], True, 1500, 900, 500),
-                                                          ("hc", [20], False, 400, 300, 100)])
+                                                          ("hc", [20], False, 400, 300, 100),
+                                                          # layers above 64 units (-cl 128 128 / -cl 100: create_mlp takes any width,
+                                                          # torch_layers.py:93-126): weights read from device memory, 64 rows per workgroup
+                                                          ("hc", [128, 128], True, 3000, 1500, 1000), ("ant", [128, 96], True, 1500, 900, 500),
+                                                          ("hc", [100], False, 400, 300, 100)])
 def test_cn_train_vs_oracle(kind, hidden, psis, Nn, Ne, eplen):
     from icrl_amd.constraint_net import ConstraintNet
     rng = np.random.RandomState(Nn)
@@ -58,8 +62,10 @@ def test_cn_train_vs_oracle(kind, hidden, psis, Nn, Ne, eplen):
                        per_step_importance_sampling=psis, target_kl_old_new=10, target_kl_new_old=2.5)
     cn.load_state_dict(orc.state_dict())
     opt = torch.optim.Adam(orc.parameters(), lr=0.01, eps=1e-5)
+    ref_cost = orc.cost_function(nom_obs[:777], nom_acs[:777])      # on the initial weights (wide nets: cn_cost_rows_kernel)
     om = o_cn.cn_train(orc, opt, 5, orc.prepare(nom_obs, nom_acs), orc.prepare(exp_obs, exp_acs), lengths, reg_coeff=0.6,
                        per_step=psis, target_kl_old_new=10, target_kl_new_old=2.5, factored=True)
+    assert np.allclose(cn.cost_function(nom_obs[:777], nom_acs[:777].astype(np.float32)), ref_cost, rtol=2e-5, atol=2e-6)
     m = cn.train(5, nom_obs, nom_acs, lengths)
     assert np.array_equal(cn.prepare_data(nom_obs, nom_acs).cpu().numpy(), orc.prepare(nom_obs, nom_acs).numpy())
     assert m["backward/early_stop_itr"] == om["backward/early_stop_itr"]

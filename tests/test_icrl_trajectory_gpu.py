@@ -155,6 +155,31 @@ def test_icrl_hc_wide_policy_two_iterations_vs_port(golden):
     assert st["timesteps"] == steps == 2 * 2048
 
 
+def test_icrl_hc_wide_constraint_net_two_iterations_vs_port(golden):
+    """`-cl 128 128`: a constraint net with layers above 64 units — its cost inside per-step rollouts (the fused rollout's cost wave holds
+    64 units), cost_function and train() 64 rows per workgroup with the weights in device memory — through the unchanged outer loop."""
+    from icrl_amd.icrl import build_parser, setup, outer_iteration
+    expert = os.path.join(HERE, "golden/expert_hc.npz")
+    argv = ["icrl", "-er", "2", "-ep", expert, "--expert_agent_path", expert, "-tk", "0.01", "-cl", "128", "128", "-bi", "10", "-ft", "2000",
+            "-ni", "2", "-tei", "HCWithPos-v0", "-eei", "HCWithPosTest-v0", "-clr", "0.01", "-aclr", "0.9", "-crc", "0.5", "-psis",
+            "-ctkno", "2.5", "-nt", "8", "--n_steps", "128", "-s", "3", "-v", "0"]
+    cfg = vars(build_parser().parse_args(argv))
+    cfg.update(rank=0, world_size=1, streams=SeededStreams(13))
+    st = setup(types.SimpleNamespace(**cfg))
+    assert st["constraint_net"].wide and st["agent"]._fused_chain() is None
+    init = dict(policy={k: v.numpy().copy() for k, v in st["agent"].policy.state_dict().items()},
+                cn={k: v.numpy().copy() for k, v in st["constraint_net"].state_dict().items()})
+    ex = golden("expert_hc")
+    port_cfg = {k: cfg[k] for k in o_loop.PORT_DEFAULTS if k in cfg}
+    om, steps, _, objs = o_loop.icrl_port(port_cfg, ex["observations"][:1000], ex["actions"][:1000], _sub(ex, "policy/"),
+                                          streams=SeededStreams(13), init=init)
+    keys = sorted(k for k in om[0] if k not in ("forward/std",))
+    for it in range(2):
+        m = outer_iteration(st, it)
+        _compare(it, m, om[it], [k for k in keys if k in m], False, 2000)
+    assert st["timesteps"] == steps == 2 * 2048
+
+
 def test_icrl_antwall_two_iterations_vs_port(golden):
     """BASELINE configs[2] (AntWall ICRL, the reference's README.md:50 flags: constraint net [40, 40], batch 128 = two 64-row
     chunks -> two workgroups per network in the update kernel, clip_range 0.4, lambdas 0.9, lr 3e-5, nu0 0.1) on N = 8 envs,
