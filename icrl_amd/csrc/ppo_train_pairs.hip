@@ -51,6 +51,12 @@
 #else
 #define OPERANDS_FIRST()
 #endif
+#ifndef ICRL_HIGH_PRIO
+#define ICRL_HIGH_PRIO 0
+#endif
+#ifndef ICRL_LOW_PRIO
+#define ICRL_LOW_PRIO 0
+#endif
 #ifndef ICRL_W1_TAIL_MOVE_HEAD
 #define ICRL_W1_TAIL_MOVE_HEAD 0
 #endif
@@ -561,6 +567,11 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   lds_barrier();
 #endif
 
+#if ICRL_HIGH_PRIO
+  if (fh == 1) __builtin_amdgcn_s_setprio(ICRL_HIGH_PRIO);      // (A/B: the younger wave of a pair loses the issue arbitration to the older one)
+#elif ICRL_LOW_PRIO
+  if (fh == 0) __builtin_amdgcn_s_setprio(ICRL_LOW_PRIO);
+#endif
   const bool prof = (a.hp._pad & 1) != 0;
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef ICRL_FINE_PROF
