@@ -1,7 +1,8 @@
 """Child process of tests/test_multirank_gpu.py: ONE rank of a 2-rank run (gloo transport, both ranks on GPU 0).
 Phase A: one sharded rollout without observation normalisation + the collective -> the merged running moments must equal
          those of one process that stepped the union of the shards (checked by the parent).
-Phase B: icrl setup() + 2 outer_iteration()s with the per-iteration collective; dumps what must agree across ranks."""
+Phase B: icrl setup() + 2 outer_iteration()s with the per-iteration collective; dumps what must agree across ranks.
+Phase C: cpg (BASELINE configs[4]'s flags at toy sizes) — learn() of 3 rollouts + updates with callbacks.RankSyncCallback."""
 import os
 import sys
 import types
@@ -73,6 +74,21 @@ def main():
                B_steps=np.array([pol.adam_step, cnet.adam_step]), B_logged_nu=np.array(nus), B_timesteps=np.array([st["timesteps"]]))
     for name, r in zip(("obs", "ret", "cost"), st["rms_list"]):
         out[f"B_{name}_rms"] = np.concatenate([np.atleast_1d(r.mean), np.atleast_1d(r.var), [r.count]])
+    # ---------------- phase C
+    from icrl_amd import cpg as C
+    cargv = ["cpg", "--cn_path", os.path.join(ROOT, "tests/golden/cn_antbroken.npz"), "-tei", "AntWallBroken-v0", "-eei", "AntWallBrokenTest-v0",
+             "-tk", "0.01", "--batch_size", "128", "--reward_gae_lambda", "0.9", "--n_epochs", "3", "--learning_rate", "3e-5", "--clip_range", "0.4",
+             "-t", str(3 * 16 * 64), "-plr", "1.0", "-nt", "16", "--n_steps", "64", "-s", "4", "-v", "0", "--eval_every_rollouts", "100"]
+    ccfg = vars(C.build_parser().parse_args(cargv))
+    ccfg.update(rank=rank, world_size=world, save_dir=None)
+    model, hist = C.cpg(types.SimpleNamespace(**ccfg), log=None)
+    cpol, cdual, cenv = model.policy, model.dual, model.env
+    out.update(C_params=cpol.params.cpu().numpy(), C_exp_avg=cpol.exp_avg.cpu().numpy(), C_exp_avg_sq=cpol.exp_avg_sq.cpu().numpy(),
+               C_dual=np.array([cdual.log_nu, cdual.m, cdual.v, cdual.t], np.float64), C_steps=np.array([cpol.adam_step]),
+               C_keys=cenv.unwrapped.key.cpu().numpy(), C_timesteps=np.array([model.num_timesteps]),
+               C_first_obs=model.rollout_buffer.orig_observations[0].cpu().numpy())
+    for name, r in zip(("obs", "ret", "cost"), (cenv.obs_rms, cenv.ret_rms, cenv.cost_rms)):
+        out[f"C_{name}_rms"] = np.concatenate([np.atleast_1d(r.mean), np.atleast_1d(r.var), [r.count]])
     np.savez(out_path, **out)
     import torch.distributed as dist
     dist.barrier()

@@ -127,7 +127,11 @@ def _forward_step(agent, port, env, n_rollouts, lr, target_kl, calibrated=False)
             e = min(ee_h, ee_p)
             close = abs(kls_hip[e] - thr) / thr if e < len(kls_hip) else float("nan")
             assert close < 2e-3, f"early stop differs (HIP {ee_h}, port {ee_p}) and epoch {e}'s mean KL {kls_hip[e]} is not at the threshold {thr}"
-            pytest.skip(f"epoch {e}: mean approx-KL {kls_hip[e]:.7f} sits within {close:.1e} of the 1.5 x target_kl threshold; the decision flips with summation order")
+            # not a skip (invisible in a -q pass count): the run up to here was compared, the rest of it has legitimately diverged
+            import warnings
+            warnings.warn(f"full-size parity: epoch {e}'s mean approx-KL {kls_hip[e]:.7f} sits within {close:.1e} of the 1.5 x target_kl threshold; "
+                          f"the early-stop decision flipped with summation order (HIP {ee_h}, port {ee_p}); comparison stops after train() #{k + 1}")
+            return rows
         cal = calibrated
         assert abs(r["nu"][0] - r["nu"][1]) <= (NU_BOUND if cal else 1e-5), r["nu"]
         # (the SECOND rollout is collected with parameters that already differ by ~1e-2: its mean cost moves by a few 1e-4)

@@ -95,6 +95,20 @@ def test_state_identical_across_ranks_after_two_outer_iterations(two_ranks):
     assert abs(r0["B_obs_rms"][-1] - (1e-4 + 2 * 2 * 64 * 16)) < 1e-6
 
 
+def test_cpg_ranks_agree_after_learn(two_ranks):
+    """BASELINE configs[4]'s path (cpg, frozen constraint net) on two ranks: own env shards and noise, ONE all-reduce per rollout + update
+    (callbacks.RankSyncCallback) and one when learn() ends — parameters, Adam moments, the dual variable, the step counters and the three
+    running-moment sets are then identical on both ranks, and the merged observation count is both shards' samples."""
+    r0, r1 = two_ranks
+    assert list(r0["C_keys"]) == [4 + i for i in range(16)] and list(r1["C_keys"]) == [4 + 16 + i for i in range(16)]
+    assert not np.array_equal(r0["C_first_obs"], r1["C_first_obs"])
+    for k in ("C_params", "C_exp_avg", "C_exp_avg_sq", "C_dual", "C_steps", "C_obs_rms", "C_ret_rms", "C_cost_rms"):
+        assert np.array_equal(r0[k], r1[k]), k
+    assert np.all(np.isfinite(r0["C_params"])) and r0["C_steps"][0] > 0 and r0["C_dual"][3] == 3
+    assert r0["C_timesteps"][0] == 3 * 16 * 64
+    assert abs(r0["C_obs_rms"][-1] - (1e-4 + 3 * 64 * 32)) < 1e-6      # 3 rollouts x 64 steps x (16 + 16) envs (the reset is not counted)
+
+
 def test_rccl_allreduce_state_one_rank(tmp_path):
     """the `nccl` (RCCL) branch of the per-iteration collective on real hardware: a fresh child process with a 1-rank nccl process
     group runs distributed.allreduce_state with the collective forced — RCCL loads, a float64 SUM of the ~33 k-element flat buffer runs
