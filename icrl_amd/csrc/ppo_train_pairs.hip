@@ -68,7 +68,7 @@
 #define ICRL_HEAD_PERM 1
 #endif
 #ifndef ICRL_STATS_WAVE0
-#define ICRL_STATS_WAVE0 4
+#define ICRL_STATS_WAVE0 1
 #endif
 #ifndef ICRL_L1_AHEAD
 #define ICRL_L1_AHEAD 0
@@ -362,9 +362,9 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   // while chunk g is processed.  The 16 rows of tile rt are staged by the 128 threads of the wave pair (rt, *): 8 per row.
   // ---------------------------------------------------------------------------------------------------------------
   const int gb_row = 16 * rt + (lane >> 2), gpart = (lane & 3) + 4 * fh;
-  // advantage statistics: row stid of the minibatch lives in waves SW0 .. SW0 + 3 (<= 256 rows).  The HIGH waves (4..7): they reach the
-  // norm barrier ~1 k cycles ahead of the low waves (no head-weight gradient), and the three wave sums cost ~400 cycles — on waves 1, 2
-  // they made those two the last at the barrier
+  // advantage statistics: row stid of the minibatch lives in waves SW0 .. SW0 + 3 (<= 256 rows).  SW0 = 1 (low waves 1, 2 at <= 128 rows):
+  // measured 8.40 us per step against 8.45 with the statistics on the high waves 4, 5 — the younger wave of a pair already trails its
+  // partner through every phase; extra work belongs on the leading one (wave 0 polls the granules, so the rows start at wave 1).
   constexpr int SW0 = ICRL_STATS_WAVE0;
   const int stid = tid - 64 * SW0;
   auto ld_step = [&](int i) -> int4 {
