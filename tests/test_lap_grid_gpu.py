@@ -92,8 +92,10 @@ def test_learn_matches_reference_golden(golden):
     assert abs(lg["train/approx_kl"] - g["log/approx_kl"].item()) < 2e-5
 
 
-@pytest.mark.parametrize("O,A,N,T,B,E,ent", [(18, 5, 8, 32, 64, 3, 0.01), (1, 2, 4, 40, 64, 2, 0.0), (40, 16, 8, 16, 128, 2, 0.05)])
-def test_categorical_update_vs_oracle(O, A, N, T, B, E, ent):
+@pytest.mark.parametrize("O,A,N,T,B,E,ent,wide", [(18, 5, 8, 32, 64, 3, 0.01, False), (1, 2, 4, 40, 64, 2, 0.0, False), (40, 16, 8, 16, 128, 2, 0.05, False),
+                                                  # the Categorical branch of the generic-shape path (csrc/generic.hip): layers above 64 / a 320-row batch
+                                                  (18, 5, 8, 32, 64, 3, 0.01, True), (1, 2, 8, 80, 320, 2, 0.02, False)])
+def test_categorical_update_vs_oracle(O, A, N, T, B, E, ent, wide):
     """the Categorical branch of the update kernel at other widths (up to 16 classes) against the oracle epoch loop."""
     from icrl_amd import logger, spaces
     from icrl_amd.ppo_lag import PPOLagrangian
@@ -103,15 +105,27 @@ def test_categorical_update_vs_oracle(O, A, N, T, B, E, ent):
     senv.observation_space = spaces.Box(-np.inf, np.inf, (O,), np.float64)
     senv.action_space = spaces.Discrete(A)
     env = VecNormalizeWithCost(VecCostWrapper(senv))
-    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=0, batch_size=B, n_epochs=E, target_kl=None, ent_coef=ent)
+    akw = dict(policy_kwargs=dict(net_arch=[dict(pi=[128, 72], vf=[100, 128], cvf=[128, 128])])) if wide else {}
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=0, batch_size=B, n_epochs=E, target_kl=None, ent_coef=ent, **akw)
     sd0 = agent.policy.state_dict()
-    assert "log_std" not in sd0
-    op = o_nets.TwoCriticPolicy(O, A, discrete=True)
+    assert "log_std" not in sd0 and agent.policy.wide == wide
+    okw = dict(hidden=dict(policy_net=(128, 72), value_net=(100, 128), cost_value_net=(128, 128))) if wide else {}
+    op = o_nets.TwoCriticPolicy(O, A, discrete=True, **okw)
     op.load_state_dict(sd0)
     obs = rng.randn(T, N, O).astype(np.float32)
     with torch.no_grad():
         a, vr, vc, lp = op.forward(torch.as_tensor(obs.reshape(-1, O)), noise=torch.as_tensor(rng.rand(T * N).astype(np.float32)))
     assert len(np.unique(a.numpy())) == A or A > 8
+    # the rollout-side forward / evaluate_actions of the same policy (wide: policy_generic_kernel's Categorical branch) vs the oracle
+    unif = rng.rand(T * N).astype(np.float32)
+    with torch.no_grad():
+        o_a, o_vr, o_vc, o_lp = op.forward(torch.as_tensor(obs.reshape(-1, O)), noise=torch.as_tensor(unif))
+        e_vr, e_vc, e_lp, e_ent = op.evaluate_actions(torch.as_tensor(obs.reshape(-1, O)), a)
+    h_a, h_vr, h_vc, h_lp = agent.policy.forward(obs.reshape(-1, O), noise=unif)
+    assert np.array_equal(h_a.cpu().numpy().ravel().astype(np.int64), o_a.numpy().ravel())
+    assert np.allclose(h_lp.cpu().numpy(), o_lp.numpy(), rtol=1e-5, atol=2e-6) and np.allclose(h_vr.cpu().numpy().ravel(), o_vr.numpy().ravel(), rtol=1e-5, atol=2e-6)
+    g_vr, g_vc, g_lp, g_ent = agent.policy.evaluate_actions(obs.reshape(-1, O), a.numpy().reshape(-1, 1).astype(np.float32))
+    assert np.allclose(g_lp.cpu().numpy(), e_lp.numpy(), rtol=1e-5, atol=2e-6) and np.allclose(g_ent.cpu().numpy(), e_ent.numpy(), rtol=1e-5, atol=2e-6)
     buf = dict(observations=obs, actions=a.numpy().reshape(T, N, 1).astype(np.float32), log_probs=lp.numpy().reshape(T, N),
                reward_values=vr.numpy().reshape(T, N), cost_values=vc.numpy().reshape(T, N),
                reward_advantages=rng.randn(T, N).astype(np.float32) * 2, cost_advantages=rng.rand(T, N).astype(np.float32),
