@@ -51,6 +51,12 @@
 #else
 #define OPERANDS_FIRST()
 #endif
+#ifndef ICRL_EARLY_COMMIT
+#define ICRL_EARLY_COMMIT 0
+#endif
+#ifndef ICRL_LOW_GATHER
+#define ICRL_LOW_GATHER 0
+#endif
 #ifndef ICRL_HIGH_PRIO
 #define ICRL_HIGH_PRIO 0
 #endif
@@ -158,6 +164,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   using S = SmemP<NT1>;
   constexpr int SX = S::SX;
   constexpr int NW1 = NT1 / 2;          // observation column tiles of dW1 per wave
+  constexpr bool EARLY_COMMIT = ICRL_EARLY_COMMIT && S::XDB;      // needs the second X^T buffer
   constexpr int XR = (S::O16 + 7) / 8;  // floats of an X row each of the 8 threads of a row stages
   static_assert(NT1 % 2 == 0, "the two waves of a pair split the observation tiles");
   static_assert(!S::DZ1A, "wide observations (dz1^T sharing h2^T's storage) stay on the row-owning kernel");
@@ -361,7 +368,14 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   // row stream (see ppo_train_rows.hip): `perms` holds storage offsets; rows of chunk g + 1 are prefetched into registers
   // while chunk g is processed.  The 16 rows of tile rt are staged by the 128 threads of the wave pair (rt, *): 8 per row.
   // ---------------------------------------------------------------------------------------------------------------
-  const int gb_row = 16 * rt + (lane >> 2), gpart = (lane & 3) + 4 * fh;
+  // ICRL_LOW_GATHER (measured and rejected: 8.60 us per step against 8.49; off): the LOW wave of a pair fetches and stages all 16 rows of
+  // the tile (4 threads per row) and the high wave none — in the forward the high wave is the late one of the pair (the low wave waits
+  // ~1 k cycles for it behind the head partials) and the issue of the row fetches sits on its path; but the low wave then carries all of
+  // the staging at the end of the step, where IT is the late one
+  constexpr bool LOWG = ICRL_LOW_GATHER;
+  constexpr int GP = LOWG ? 4 : 8;       // threads per row
+  const int gb_row = 16 * rt + (lane >> 2), gpart = LOWG ? (lane & 3) : (lane & 3) + 4 * fh;
+  const bool gather = !LOWG || fh == 0;  // wave-uniform
   // advantage statistics: row stid of the minibatch lives in waves SW0 .. SW0 + 3 (<= 256 rows).  SW0 = 1 (low waves 1, 2 at <= 128 rows):
   // measured 8.40 us per step against 8.45 with the statistics on the high waves 4, 5 — the younger wave of a pair already trails its
   // partner through every phase; extra work belongs on the leading one (wave 0 polls the granules, so the rows start at wave 1).
@@ -394,29 +408,34 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   // there are more than 8 actions, (iii) ONE of the three per-row scalars per thread — thread gpart of a row fetches scalar gpart
   // (old log-prob / value | advantage / return | cost advantage) through its own pointer and stores it at its own address, threads
   // 3..7 re-read the third and park it in a scratch word.  9 -> 5 loads and 9 -> 5 stores per thread and step at HC shapes.
-  constexpr int XRL = OBS > 0 ? (OBS + 7) / 8 : XR;
-  float px[XR], pact[2] = {0.f, 0.f}, psc = 0.f;
+  constexpr int XRG = (S::O16 + GP - 1) / GP;
+  constexpr int XRL = OBS > 0 ? (OBS + GP - 1) / GP : XRG;
+  constexpr int NACT = 16 / GP;
+  float px[XRG], pact[NACT], psc = 0.f;
+#pragma unroll
+  for (int i = 0; i < NACT; ++i) pact[i] = 0.f;
   const float* const p_sc = gpart == 0 ? p_s0 : (gpart == 1 ? p_s1 : p_s2);
   const int sc_dst = gpart == 0 ? S::OLP + gb_row : (gpart == 1 ? S::ADR + gb_row : (gpart == 2 ? S::ADC + gb_row : S::MISC + 62));
-  const bool two_act = AS > 8;
   auto issue_rows = [&](int idx) {
-    if (ICRL_DIAG & 128) return;
+    if ((ICRL_DIAG & 128) || !gather) return;
     const unsigned off = idx >= 0 ? (unsigned)idx : 0u;
     const unsigned ob = off * (unsigned)O;
 #pragma unroll
-    for (int i = 0; i < XRL; ++i) { const int k = gpart + 8 * i; px[i] = p_obs[ob + (unsigned)(k < O ? k : O - 1)]; }
+    for (int i = 0; i < XRL; ++i) { const int k = gpart + GP * i; px[i] = p_obs[ob + (unsigned)(k < O ? k : O - 1)]; }
     const unsigned ab = off * (unsigned)AS;      // (the critics fetch the action bytes too: a load is cheaper than a branch in the load stream)
-    pact[0] = p_act[ab + (unsigned)(gpart < AS ? gpart : AS - 1)];
-    if (two_act) pact[1] = p_act[ab + (unsigned)(gpart + 8 < AS ? gpart + 8 : AS - 1)];
+#pragma unroll
+    for (int i = 0; i < NACT; ++i)
+      if (i == 0 || AS > GP * i) { const int k = gpart + GP * i; pact[i] = p_act[ab + (unsigned)(k < AS ? k : AS - 1)]; }
     psc = p_sc[off];
   };
   auto commit_rows = [&](int xbase) {
-    if (ICRL_DIAG & 128) return;
+    if ((ICRL_DIAG & 128) || !gather) return;
 #pragma unroll
-    for (int i = 0; i < XRL; ++i) { const int k = gpart + 8 * i; if (OBS > 0 ? k < OBS : k < S::O16) sm[xbase + k * ST + gb_row] = px[i]; }
+    for (int i = 0; i < XRL; ++i) { const int k = gpart + GP * i; if (OBS > 0 ? k < OBS : k < S::O16) sm[xbase + k * ST + gb_row] = px[i]; }
     if (role == 0) {
-      sm[S::ACT + gb_row * SA + pos_of(gpart)] = gpart < AS ? pact[0] : 0.f;                           // pad actions are 0
-      if (two_act) sm[S::ACT + gb_row * SA + pos_of(gpart + 8)] = gpart + 8 < AS ? pact[1] : 0.f;      // (<= 8 actions: those columns keep the zeros of the start)
+#pragma unroll
+      for (int i = 0; i < NACT; ++i)      // pad actions are 0; pieces beyond the action count are not written: those columns keep the zeros of the start
+        if (i == 0 || AS > GP * i) { const int k = gpart + GP * i; sm[S::ACT + gb_row * SA + pos_of(k)] = k < AS ? pact[i] : 0.f; }
     }
     sm[sc_dst] = psc;
   };
@@ -602,8 +621,10 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
       const int nrows = (nb - ch * RB) < RB ? (nb - ch * RB) : RB;
       if (ch > 0) {
         if (S::XDB) xcur = xcur == S::XT0 ? S::XT1 : S::XT0;
-        commit_rows(xcur);
-        lds_barrier();                      // a row is staged by threads of both waves of its pair
+        if (!EARLY_COMMIT) {
+          commit_rows(xcur);
+          lds_barrier();                    // a row is staged by threads of both waves of its pair
+        }                                   // (EARLY_COMMIT: staged in front of the previous chunk's dz1 barrier, S5 and the chunk-end barrier passed since)
       }
       const bool valid = b < nrows;
       // ================= forward =================
@@ -883,6 +904,15 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
         for (int i = 0; i < 4; ++i) pt[S::DZ1T + (16 * (2 * fh + tt) + i) * ST] = dz1c[tt][i];
       STAMP(2)   // activation backward
       FSTAMP(9)   // dH1 + dz1 store
+      if (EARLY_COMMIT) {
+        // ICRL_EARLY_COMMIT (measured and rejected: 8.81 us per step against 8.46; off — the dz1 barrier waits for the HIGH waves, and the
+        // staging lands on their path).  The prefetched rows (the next chunk's, or the next minibatch's first chunk) are staged HERE, in front of the dz1 barrier, instead of
+        // behind the norm publish: the other X^T buffer is free during the whole chunk, the per-row action / scalar images belong to this
+        // pair alone and its loss tail is over (the partner's dz2 hand-off has been passed).  At the end of the step the low waves are the
+        // critical ones (they carry dWh) and the staging sat on their path; here it sits where they wait for the dz1 barrier.
+        commit_rows(xcur == S::XT0 ? S::XT1 : S::XT0);
+        if (ch + 1 == n_chunks) stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
+      }
       if (ch == 0) {   // gradient accumulators start their life here
 #pragma unroll
         for (int cc = 0; cc < NW1; ++cc) gW1r[cc] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1076,8 +1106,10 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
     u64 v_first = 0;
     if (poller) v_first = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
-    commit_rows(xnext);
-    stats_partials(nb_next);
+    if (!EARLY_COMMIT) {
+      commit_rows(xnext);
+      stats_partials(nb_next);
+    }
     xcur = xnext;
     FSTAMP(15)  // staging
     if (poller) {
