@@ -2938,7 +2938,9 @@ static bool persistent_fits(K kernel, int blocks, size_t dyn_lds = 0) {
 static bool multi_shape(int N, int n_stats, int* E, int* G) {
   const int gmin = (n_stats + 3) / 4;
   const int per = N / gmin;
-  if (per >= 16 && N > 8 * 256) *E = 16;        // more than 2048 envs: 16 per workgroup keep the grid at <= 256 workgroups
+  const char* force = getenv("ICRL_MULTI_E");      // tools only: force the envs per workgroup (4 | 8 | 16)
+  if (force != nullptr && (atoi(force) == 4 || atoi(force) == 8 || atoi(force) == 16) && per >= atoi(force)) *E = atoi(force);
+  else if (per >= 16 && N > 8 * 256) *E = 16;        // more than 2048 envs: 16 per workgroup keep the grid at <= 256 workgroups
   else if (per >= 8) *E = 8;
   else if (per >= 4) *E = 4;
   else return false;
