@@ -20,8 +20,9 @@
  * workgroups of ONE run wait for each other inside the launch (granule exchange), so they must all be resident at the same
  * time: n_envs workgroups of 256 threads for the rollout (<= 128 envs; the many-environment kernel sizes its grid to what
  * hipOccupancyMaxActiveBlocksPerMultiprocessor reports), 3 (6 when a minibatch is two chunks at obs_dim > 64) workgroups for
- * the update, each filling a CU's LDS.  These are ordinary launches, not cooperative ones: the library checks the occupancy
- * the runtime reports for an otherwise idle device, and nothing else.  Whatever else occupies CUs for long at the same time —
+ * the update, each filling a CU's LDS.  The SINGLE-RUN entry points issue these grids with hipLaunchCooperativeKernel (round 4): the
+ * runtime refuses a grid it cannot make co-resident (the rollout then falls back to per-step launches), after the library's own
+ * check of the occupancy the runtime reports; the *_batch grids are ordinary launches.  Whatever else occupies CUs for long at the same time —
  * another stream of this process, or ANOTHER PROCESS on the same GPU, which no host-side check of this process can see — can
  * keep a workgroup of a run from being scheduled; its peers then spin (bounded: ~2 s per exchange, s_sleep between polls), the
  * launch ends with icrl_agent_t.status bit 0 / stats[11] set and the host raises — buffers and statistics of that call are
