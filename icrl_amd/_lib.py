@@ -37,6 +37,7 @@ SIGNATURES = {
     "icrl_rollout_collect": [c_void_p] * 9 + [c_double] * 4 + [c_void_p],
     "icrl_rollout_collect_ex": [c_void_p] * 9 + [c_double] * 4 + [c_int, c_void_p],
     "icrl_ppo_lag_train": [c_void_p] * 11,
+    "icrl_ppo_generic_row_floats": [c_void_p],
     "icrl_cn_prepare": [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "icrl_cn_train_work_floats": [c_int, c_int, c_int, c_int],
     "icrl_cn_train": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p],

@@ -18,15 +18,16 @@ constexpr int MAX_CN_IN = 160; // cost-net input limit (Ant: 121)
 int icrl_gae_dual_batch_impl(int n_runs, const icrl_rollout_job_t* jobs, double reward_gamma, double reward_gae_lambda, double cost_gamma,
                              double cost_gae_lambda, void* args_ws, void* stream);
 
-// generic.hip: the generic-shape path (hidden widths above MAX_H up to 256, any batch size) behind icrl_policy_forward /
-// icrl_policy_evaluate / icrl_ppo_lag_train
+// generic.hip: the generic-shape path (hidden widths above MAX_H up to 256, any MlpExtractor architecture given by icrl_policy_t.arch,
+// any batch size) behind icrl_policy_forward / icrl_policy_evaluate / icrl_ppo_lag_train
 int launch_policy_generic(const icrl_policy_t* p, const double* obs, const float* noise, int N, int deterministic, const float* alow,
                           const float* ahigh, float* actions, float* act_clipped, float* v_r, float* v_c, float* log_prob,
                           const float* given, float* entropy, hipStream_t s);
 int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
                          const int* perm_off, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* scratch, hipStream_t s);
-long long generic_train_bytes(int batch_size, int hp, int n_params);
-inline bool policy_is_wide(const icrl_policy_t* p) { return p->h1 > MAX_H || p->h2 > MAX_H; }
+int generic_row_floats(const icrl_policy_t* pol);
+int policy_generic_check(const icrl_policy_t* p, const char* who);      // 0, or the fail() code of an architecture the path refuses
+inline bool policy_is_wide(const icrl_policy_t* p) { return p->arch != nullptr || p->h1 > MAX_H || p->h2 > MAX_H; }
 // cn_train.hip: cost / discriminator forward of a constraint net with a hidden layer above MAX_H units (64 rows per workgroup)
 int launch_cn_cost_rows(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, int mode, hipStream_t s);
 inline bool costnet_is_wide(const icrl_costnet_t* cn) { return cn->h1 > MAX_H || (cn->n_hidden == 2 && cn->h2 > MAX_H); }

@@ -477,7 +477,7 @@ extern "C" int icrl_gae_dual(const float* rewards, const float* costs, const flo
                           stream);
 }
 
-extern "C" int icrl_abi_version(void) { return 101; }
+extern "C" int icrl_abi_version(void) { return 102; }
 
 // icrl_gae_dual_ws for n_runs rollouts of one shape in ONE launch (the loop-size launches of several runs sharing a GPU): the
 // two-level scan over workgroups, every run with its own workspace.  Shapes the split scan does not serve (> 128 column tiles, T too

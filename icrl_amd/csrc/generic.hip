@@ -1,12 +1,17 @@
 // Generic-shape path of the policy kernels — gfx950.
 //
-// The fast kernels (rollout.hip, ppo_train_*.hip) are built around 64-wide hidden layers, minibatches of at most 256 rows and one
-// lane per hidden unit.  The reference accepts any `-pl / -rvl / -cvl` widths and any batch size (icrl/utils.py:636-655,
-// stable_baselines3/common/torch_layers.py:129-254, common/buffers.py:594-612); this file serves what the fast kernels refuse:
-// two-layer branches up to 256 units (stored padded to a common width HP = a multiple of 64; pad units have zero weights and
-// biases, output tanh(0) = 0 and receive zero gradients, exactly like the narrow widths of the fast kernels) and minibatches of
-// any size.  Plain kernels, one thread per hidden unit / per parameter, sequential fmaf chains, several launches per optimiser
-// step — correct and deterministic, not latency-tuned: every BASELINE config runs on the fast kernels.
+// The fast kernels (rollout.hip, ppo_train_*.hip) are built around three separate two-layer branches of 64-wide hidden layers,
+// minibatches of at most 256 rows and one lane per hidden unit.  The reference accepts any `-sl / -pl / -rvl / -cvl` layer lists and
+// any batch size (icrl/utils.py:636-655, stable_baselines3/common/torch_layers.py:129-254, common/buffers.py:594-612); this file
+// serves what the fast kernels refuse, from ONE table of layers (GenNet):
+//   * two-layer branches up to 256 units in the classic layout (icrl_policy_t.arch == NULL; stored padded to a common width h1 = h2 =
+//     a multiple of 64: pad units have zero weights and biases, output tanh(0) = 0 and receive zero gradients, exactly like the narrow
+//     widths of the fast kernels),
+//   * any MlpExtractor architecture (icrl_policy_t.arch != NULL): a shared trunk of 0..4 layers, then 0..4 layers per branch, every
+//     width 1..256, natural (unpadded) parameter layout in the reference's state_dict order,
+//   * minibatches of any size.
+// Plain kernels, one thread per hidden unit / per parameter, sequential fmaf chains, several launches per optimiser step — correct
+// and deterministic, not latency-tuned: every BASELINE config runs on the fast kernels.
 //
 //   icrl_policy_forward / icrl_policy_evaluate      -> policy_generic_kernel            (policies.py:716-731, 752-767)
 //   icrl_ppo_lag_train                              -> per optimiser step: gen_stats | gen_forward_backward | gen_wgrad | gen_adam
@@ -16,7 +21,90 @@
 
 namespace icrl {
 
-constexpr int GEN_MAX_H = 256;
+constexpr int GEN_MAX_H = 256;                               // widest layer
+constexpr int GEN_MAX_DEPTH = 4;                             // layers of the shared trunk / of one branch
+constexpr int GEN_MAX_LAYERS = 4 * GEN_MAX_DEPTH + 3;        // trunk + three branches + three heads
+constexpr int GEN_MAX_STAGES = 2 * GEN_MAX_DEPTH + 1;
+constexpr int GEN_MAX_ROW = 4 * GEN_MAX_DEPTH * GEN_MAX_H + MAX_ACT + 2;      // outputs of every layer of one row
+
+// One Linear (+ tanh) of the network.  Layers are numbered in execution order; a layer reads the observation (in_buf = -1) or the
+// output of an earlier layer, and writes act_off .. act_off + out_dim of the row's activation record.  The layers of one stage
+// are independent and run side by side, one per slot (slot = threadIdx.x / W; the trunk on slot 0, branch r on slot r).
+struct GenLayer { int in_dim, out_dim, w_off, b_off, in_buf, act_off, slot, tanh; };
+
+struct GenNet {
+  int O, A, discrete, log_std, n;          // log_std: parameter offset (-1 when discrete); n: parameter count
+  int n_layers, n_stages, row_floats, W;   // W: threads per slot = the widest layer rounded up to 64
+  int stage_begin[GEN_MAX_STAGES + 1];
+  int head[3];                             // layer indices of action_net / value_net / cost_value_net (the last stage)
+  GenLayer layer[GEN_MAX_LAYERS];
+};
+
+// icrl_policy_t -> GenNet.  Runs on the host (arch is host memory).  Returns 0 or the fail() code.
+static int make_gen_net(const icrl_policy_t* p, GenNet* out, const char* who) {
+  GenNet& g = *out;
+  const int O = p->obs_dim, A = p->act_dim;
+  if (O < 1 || O > 1024 || A < 1 || A > MAX_ACT) return fail("%s (generic path): obs_dim %d (1..1024), act_dim %d (1..%d)", who, O, A, MAX_ACT);
+  int n_sh = 0, sh[GEN_MAX_DEPTH], n_br[3], br[3][GEN_MAX_DEPTH];
+  if (p->arch == nullptr) {      // classic layout: three two-layer branches, widths padded to h1 = h2
+    if (p->h1 != p->h2 || p->h1 % 64 != 0 || p->h1 < 64 || p->h1 > GEN_MAX_H)
+      return fail("%s (generic path): padded hidden width %d x %d (equal, a multiple of 64, <= %d)", who, p->h1, p->h2, GEN_MAX_H);
+    for (int r = 0; r < 3; ++r) { n_br[r] = 2; br[r][0] = p->h1; br[r][1] = p->h2; }
+  } else {
+    const int32_t* a = p->arch;
+    n_sh = *a++;
+    if (n_sh < 0 || n_sh > GEN_MAX_DEPTH) return fail("%s: %d shared layers (0..%d)", who, n_sh, GEN_MAX_DEPTH);
+    for (int i = 0; i < n_sh; ++i) sh[i] = *a++;
+    for (int r = 0; r < 3; ++r) {
+      n_br[r] = *a++;
+      if (n_br[r] < 0 || n_br[r] > GEN_MAX_DEPTH) return fail("%s: %d layers in branch %d (0..%d)", who, n_br[r], r, GEN_MAX_DEPTH);
+      for (int i = 0; i < n_br[r]; ++i) br[r][i] = *a++;
+    }
+    for (int i = 0; i < n_sh; ++i) if (sh[i] < 1 || sh[i] > GEN_MAX_H) return fail("%s: shared layer %d has %d units (1..%d)", who, i, sh[i], GEN_MAX_H);
+    for (int r = 0; r < 3; ++r)
+      for (int i = 0; i < n_br[r]; ++i) if (br[r][i] < 1 || br[r][i] > GEN_MAX_H) return fail("%s: layer %d of branch %d has %d units (1..%d)", who, i, r, br[r][i], GEN_MAX_H);
+  }
+  g.O = O; g.A = A; g.discrete = p->discrete != 0;
+  int off = 0, nl = 0, ns = 0, act = 0, widest = 64;
+  if (g.discrete) g.log_std = -1; else { g.log_std = 0; off += A; }
+  auto add = [&](int in_dim, int out_dim, int in_buf, int slot, int tanh, int w_off) {
+    GenLayer& l = g.layer[nl];
+    l.in_dim = in_dim; l.out_dim = out_dim; l.w_off = w_off; l.b_off = w_off + in_dim * out_dim; l.in_buf = in_buf; l.act_off = act; l.slot = slot; l.tanh = tanh;
+    act += out_dim;
+    if (out_dim > widest) widest = out_dim;
+    return nl++;
+  };
+  // parameter order = the reference's state_dict: trunk, policy_net, value_net, cost_value_net (every layer W then b), then the heads
+  int last = -1, last_dim = O;
+  for (int i = 0; i < n_sh; ++i) {
+    g.stage_begin[ns++] = nl;
+    last = add(last_dim, sh[i], last, 0, 1, off);
+    off += last_dim * sh[i] + sh[i];
+    last_dim = sh[i];
+  }
+  int w_off[3][GEN_MAX_DEPTH], max_depth = 0;
+  for (int r = 0; r < 3; ++r) {
+    int d_in = last_dim;
+    for (int i = 0; i < n_br[r]; ++i) { w_off[r][i] = off; off += d_in * br[r][i] + br[r][i]; d_in = br[r][i]; }
+    if (n_br[r] > max_depth) max_depth = n_br[r];
+  }
+  int tip[3] = {last, last, last}, tip_dim[3] = {last_dim, last_dim, last_dim};
+  for (int d = 0; d < max_depth; ++d) {
+    g.stage_begin[ns++] = nl;
+    for (int r = 0; r < 3; ++r)
+      if (d < n_br[r]) { tip[r] = add(tip_dim[r], br[r][d], tip[r], r, 1, w_off[r][d]); tip_dim[r] = br[r][d]; }
+  }
+  g.stage_begin[ns++] = nl;
+  for (int r = 0; r < 3; ++r) {
+    const int n_out = r == 0 ? A : 1;
+    g.head[r] = add(tip_dim[r], n_out, tip[r], r, 0, off);
+    off += tip_dim[r] * n_out + n_out;
+  }
+  g.stage_begin[ns] = nl;
+  g.n = off; g.n_layers = nl; g.n_stages = ns; g.row_floats = act; g.W = (widest + 63) / 64 * 64;
+  if (p->n_params != g.n) return fail("%s: n_params = %d, the architecture needs %d", who, p->n_params, g.n);
+  return 0;
+}
 
 struct GenCtl {      // first 64 floats of the generic scratch, zeroed at the start of a train() launch sequence
   float mean_r, istd_r, mean_c;
@@ -26,8 +114,7 @@ struct GenCtl {      // first 64 floats of the generic scratch, zeroed at the st
 };
 
 struct GenArgs {
-  PolLayout L;
-  int HP, B;                 // padded hidden width (= L.H1 = L.H2), batch_size
+  int B;                     // batch_size
   float* params; float* exp_avg; float* exp_avg_sq;
   const int* adam_t;
   icrl_buffer_t buf;
@@ -39,70 +126,65 @@ struct GenArgs {
   int n_total, n_mb;
 };
 
-// scratch layout in floats
+// scratch layout in floats (RF = GenNet.row_floats): control | per-row loss terms | row -> storage offset | log_std gradient terms |
+// activations [B][RF] | pre-activation gradients [B][RF] | gradient [n] | per-block partial squared norms
 __host__ __device__ inline size_t gen_off_rowstat() { return 64; }
 __host__ __device__ inline size_t gen_off_rowidx(int B) { return gen_off_rowstat() + (size_t)3 * B * 8; }
 __host__ __device__ inline size_t gen_off_g2(int B) { return gen_off_rowidx(B) + (size_t)B; }
-__host__ __device__ inline size_t gen_off_act(int B, int role, int HP) { return gen_off_g2(B) + (size_t)B * 16 + (size_t)role * B * (4 * HP + 16); }
-__host__ __device__ inline size_t gen_off_grad(int B, int HP) { return gen_off_act(B, 3, HP); }
-__host__ __device__ inline size_t gen_off_part(int B, int HP, int n_params) { return gen_off_grad(B, HP) + (size_t)n_params; }
-__host__ __device__ inline size_t gen_floats(int B, int HP, int n_params) { return gen_off_part(B, HP, n_params) + (size_t)(n_params + 255) / 256 + 64; }
+__host__ __device__ inline size_t gen_off_act(int B) { return gen_off_g2(B) + (size_t)B * 16; }
+__host__ __device__ inline size_t gen_off_dz(int B, int RF) { return gen_off_act(B) + (size_t)B * RF; }
+__host__ __device__ inline size_t gen_off_grad(int B, int RF) { return gen_off_dz(B, RF) + (size_t)B * RF; }
+__host__ __device__ inline size_t gen_off_part(int B, int RF, int n_params) { return gen_off_grad(B, RF) + (size_t)n_params; }
+__host__ __device__ inline size_t gen_floats(int B, int RF, int n_params) { return gen_off_part(B, RF, n_params) + (size_t)(n_params + 255) / 256 + 64; }
 
 // ---------------------------------------------------------------------------------------------------------------
-// forward of ONE row through the three branches: thread (role, j) = hidden unit j of branch role.  blockDim = 3 * HP.
+// forward of ONE row: thread (slot, j) = unit j of the layer its slot runs in the current stage.  blockDim = 3 * W.
 // ---------------------------------------------------------------------------------------------------------------
 struct GenFwdShared {
   float x[1024];
-  float h1[3][GEN_MAX_H], h2[3][GEN_MAX_H];
-  float out[MAX_ACT];
-  float scal[4];
+  float act[GEN_MAX_ROW];
 };
 
-__device__ __forceinline__ void gen_mlp_forward(const PolLayout& L, const float* __restrict__ P, GenFwdShared& sh, int role, int j) {
-  const int O = L.O, H1 = L.H1, H2 = L.H2;
-  {
-    const float* w = P + L.W1[role] + (size_t)j * O;
-    float z = P[L.b1[role] + j];
-    for (int k = 0; k < O; ++k) z = fmaf(w[k], sh.x[k], z);
-    sh.h1[role][j] = fast_tanh(z);
+__device__ __forceinline__ int gen_my_layer(const GenNet& net, int stage, int slot) {
+  for (int l = net.stage_begin[stage]; l < net.stage_begin[stage + 1]; ++l)
+    if (net.layer[l].slot == slot) return l;
+  return -1;
+}
+
+__device__ __forceinline__ void gen_mlp_forward(const GenNet& net, const float* __restrict__ P, const float* x, float* act, int slot, int j) {
+  for (int s = 0; s < net.n_stages; ++s) {
+    const int l = gen_my_layer(net, s, slot);
+    if (l >= 0 && j < net.layer[l].out_dim) {
+      const GenLayer& y = net.layer[l];
+      const float* w = P + y.w_off + (size_t)j * y.in_dim;
+      const float* in = y.in_buf < 0 ? x : act + net.layer[y.in_buf].act_off;
+      float z = P[y.b_off + j];
+      for (int k = 0; k < y.in_dim; ++k) z = fmaf(w[k], in[k], z);
+      act[y.act_off + j] = y.tanh ? fast_tanh(z) : z;
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  {
-    const float* w = P + L.W2[role] + (size_t)j * H1;
-    float z = P[L.b2[role] + j];
-    for (int k = 0; k < H1; ++k) z = fmaf(w[k], sh.h1[role][k], z);
-    sh.h2[role][j] = fast_tanh(z);
-  }
-  __syncthreads();
-  const int n_out = role == 0 ? L.A : 1;
-  if (j < n_out) {
-    const int Wh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc), bh = role == 0 ? L.ba : (role == 1 ? L.bv : L.bc);
-    const float* w = P + Wh + (size_t)j * H2;
-    float z = P[bh + j];
-    for (int k = 0; k < H2; ++k) z = fmaf(w[k], sh.h2[role][k], z);
-    if (role == 0) sh.out[j] = z; else sh.scal[role - 1] = z;
-  }
-  __syncthreads();
 }
 
 // policies.py:716-731 (forward: sample / deterministic, clip, log-prob) and :752-767 (evaluate_actions: `given` actions, entropy)
-__global__ void __launch_bounds__(3 * GEN_MAX_H) policy_generic_kernel(PolLayout L, const float* __restrict__ P, const double* __restrict__ obs,
+__global__ void __launch_bounds__(3 * GEN_MAX_H) policy_generic_kernel(GenNet net, const float* __restrict__ P, const double* __restrict__ obs,
                                                                         const float* __restrict__ noise, int deterministic, const float* alow,
                                                                         const float* ahigh, float* actions, float* act_clipped, float* v_r,
                                                                         float* v_c, float* log_prob, const float* __restrict__ given,
                                                                         float* entropy) {
   __shared__ GenFwdShared sh;
-  const int HP = L.H1, tid = threadIdx.x, role = tid / HP, j = tid - role * HP;
+  const int tid = threadIdx.x, slot = tid / net.W, j = tid - slot * net.W;
   const size_t n = blockIdx.x;
-  for (int i = tid; i < L.O; i += blockDim.x) sh.x[i] = (float)obs[n * L.O + i];
+  for (int i = tid; i < net.O; i += blockDim.x) sh.x[i] = (float)obs[n * net.O + i];
   __syncthreads();
-  gen_mlp_forward(L, P, sh, role, j);
+  gen_mlp_forward(net, P, sh.x, sh.act, slot, j);
   if (tid == 0) {
-    const int A = L.A, AS = L.discrete ? 1 : A;
+    const int A = net.A, AS = net.discrete ? 1 : A;
+    const float* out = sh.act + net.layer[net.head[0]].act_off;
     float lp = 0.f, ent = 0.f;
-    if (!L.discrete) {
+    if (!net.discrete) {
       for (int o = 0; o < A; ++o) {
-        const float ls = P[L.log_std + o], sd = __expf(ls), mean = sh.out[o];
+        const float ls = P[net.log_std + o], sd = __expf(ls), mean = out[o];
         float act = mean;
         if (given != nullptr) act = given[n * AS + o];
         else if (!deterministic && noise != nullptr) act = mean + noise[n * AS + o] * sd;      // Normal.rsample: loc + eps * scale
@@ -114,29 +196,29 @@ __global__ void __launch_bounds__(3 * GEN_MAX_H) policy_generic_kernel(PolLayout
       }
     } else {      // Categorical(logits): log-softmax, inverse-CDF sample on the injected uniform (spec: oracle/nets.py forward)
       float m = -INFINITY;
-      for (int o = 0; o < A; ++o) m = fmaxf(m, sh.out[o]);
+      for (int o = 0; o < A; ++o) m = fmaxf(m, out[o]);
       float se = 0.f;
-      for (int o = 0; o < A; ++o) se += expf(sh.out[o] - m);
+      for (int o = 0; o < A; ++o) se += expf(out[o] - m);
       const float lse = m + logf(se);
       int action = 0;
       if (given != nullptr) action = (int)given[n];
       else if (deterministic || noise == nullptr) {
         float best = -1.f;
-        for (int o = 0; o < A; ++o) { const float p = expf(sh.out[o] - lse); if (p > best) { best = p; action = o; } }
+        for (int o = 0; o < A; ++o) { const float p = expf(out[o] - lse); if (p > best) { best = p; action = o; } }
       } else {
         const float u = noise[n];
         float cdf = 0.f;
         int cnt = 0;
-        for (int o = 0; o < A; ++o) { cdf += expf(sh.out[o] - lse); cnt += (u >= cdf) ? 1 : 0; }
+        for (int o = 0; o < A; ++o) { cdf += expf(out[o] - lse); cnt += (u >= cdf) ? 1 : 0; }
         action = cnt < A - 1 ? cnt : A - 1;
       }
-      lp = sh.out[action] - lse;
-      for (int o = 0; o < A; ++o) { const float lg = sh.out[o] - lse; ent -= lg * expf(lg); }
+      lp = out[action] - lse;
+      for (int o = 0; o < A; ++o) { const float lg = out[o] - lse; ent -= lg * expf(lg); }
       if (actions) actions[n] = (float)action;
       if (act_clipped) act_clipped[n] = (float)action;
     }
-    if (v_r) v_r[n] = sh.scal[0];
-    if (v_c) v_c[n] = sh.scal[1];
+    if (v_r) v_r[n] = sh.act[net.layer[net.head[1]].act_off];
+    if (v_c) v_c[n] = sh.act[net.layer[net.head[2]].act_off];
     if (log_prob) log_prob[n] = lp;
     if (entropy) entropy[n] = ent;
   }
@@ -145,13 +227,16 @@ __global__ void __launch_bounds__(3 * GEN_MAX_H) policy_generic_kernel(PolLayout
 int launch_policy_generic(const icrl_policy_t* p, const double* obs, const float* noise, int N, int deterministic, const float* alow,
                           const float* ahigh, float* actions, float* act_clipped, float* v_r, float* v_c, float* log_prob,
                           const float* given, float* entropy, hipStream_t s) {
-  if (p->h1 != p->h2 || p->h1 % 64 != 0 || p->h1 > GEN_MAX_H || p->obs_dim < 1 || p->obs_dim > 1024 || p->act_dim < 1 || p->act_dim > MAX_ACT)
-    return fail("policy forward / evaluate (generic path): obs_dim %d (1..1024), act_dim %d (1..%d), padded hidden width %d x %d (equal, a multiple "
-                "of 64, <= %d)", p->obs_dim, p->act_dim, MAX_ACT, p->h1, p->h2, GEN_MAX_H);
-  PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
-  hipLaunchKernelGGL(policy_generic_kernel, dim3(N), dim3(3 * p->h1), 0, s, L, p->params, obs, noise, deterministic, alow, ahigh, actions,
+  GenNet net;
+  if (int e = make_gen_net(p, &net, "policy forward / evaluate")) return e;
+  hipLaunchKernelGGL(policy_generic_kernel, dim3(N), dim3(3 * net.W), 0, s, net, p->params, obs, noise, deterministic, alow, ahigh, actions,
                      act_clipped, v_r, v_c, log_prob, given, entropy);
   return (int)hipGetLastError();
+}
+
+int policy_generic_check(const icrl_policy_t* p, const char* who) {
+  GenNet net;
+  return make_gen_net(p, &net, who);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -185,37 +270,33 @@ __global__ void __launch_bounds__(256) gen_stats_kernel(GenArgs a, int perm_base
   if (threadIdx.x == 0) { ctl->mean_r = mean_r; ctl->mean_c = mean_c; ctl->istd_r = 1.f / (sqrtf(var) + 1e-8f); }
 }
 
-// forward, loss and activation backward of ONE minibatch row through ONE branch: grid (nb, 3), block HP
-__global__ void __launch_bounds__(GEN_MAX_H) gen_forward_backward_kernel(GenArgs a, int perm_base, int nb) {
+// forward, loss and activation backward of ONE minibatch row through the whole network: grid nb, block 3 * W
+__global__ void __launch_bounds__(3 * GEN_MAX_H) gen_forward_backward_kernel(GenNet net, GenArgs a, int perm_base, int nb) {
   __shared__ GenFwdShared sh;
-  __shared__ float dout[MAX_ACT];
+  __shared__ float dz[GEN_MAX_ROW];      // d loss / d pre-activation of every layer of the row, laid out like sh.act
   const GenCtl* ctl = reinterpret_cast<const GenCtl*>(a.scratch);
   if (ctl->stop) return;
-  const PolLayout& L = a.L;
-  const int HP = a.HP, B = a.B, j = threadIdx.x, row = blockIdx.x, role = blockIdx.y;
+  const int B = a.B, RF = net.row_floats, tid = threadIdx.x, slot = tid / net.W, j = tid - slot * net.W, row = blockIdx.x;
   const float* P = a.params;
   const int idx = a.perm_off[perm_base + row];
-  for (int i = j; i < L.O; i += HP) sh.x[i] = a.buf.observations[(size_t)idx * L.O + i];
+  for (int i = tid; i < net.O; i += blockDim.x) sh.x[i] = a.buf.observations[(size_t)idx * net.O + i];
   __syncthreads();
-  gen_mlp_forward(L, P, sh, role, j);
-  float* act = a.scratch + gen_off_act(B, role, HP);
-  float* H1b = act, *H2b = act + (size_t)B * HP, *DZ1 = act + (size_t)2 * B * HP, *DZ2 = act + (size_t)3 * B * HP, *DOUT = act + (size_t)4 * B * HP;
-  H1b[(size_t)row * HP + j] = sh.h1[role][j];
-  H2b[(size_t)row * HP + j] = sh.h2[role][j];
-  const int n_out = role == 0 ? L.A : 1;
-  if (j == 0) {
+  gen_mlp_forward(net, P, sh.x, sh.act, slot, j);
+  if (j == 0) {      // one thread per slot: the loss terms of its head (pi | vf | cvf)
+    const int role = slot;
+    float* dout = dz + net.layer[net.head[role]].act_off;
     const float nu = a.nu[0], inv_nb = 1.f / (float)nb;
     float* rs = a.scratch + gen_off_rowstat() + ((size_t)role * B + row) * 8;
-    for (int o = 0; o < MAX_ACT; ++o) dout[o] = 0.f;
     if (role == 0) {
       reinterpret_cast<int*>(a.scratch + gen_off_rowidx(B))[row] = idx;
       float* g2row = a.scratch + gen_off_g2(B) + (size_t)row * 16;
-      const int A = L.A;
+      const float* out = sh.act + net.layer[net.head[0]].act_off;
+      const int A = net.A;
       float lp = 0.f, ent = 0.f, g1[MAX_ACT], g2[MAX_ACT];
-      if (!L.discrete) {
+      if (!net.discrete) {
         for (int o = 0; o < A; ++o) {
-          const float ls = P[L.log_std + o], sd = __expf(ls), iv = 1.f / (sd * sd);
-          const float dd = a.buf.actions[(size_t)idx * a.buf.act_store + o] - sh.out[o];
+          const float ls = P[net.log_std + o], sd = __expf(ls), iv = 1.f / (sd * sd);
+          const float dd = a.buf.actions[(size_t)idx * a.buf.act_store + o] - out[o];
           lp += -(dd * dd) * (0.5f * iv) - ls - LOG_SQRT_2PI_F;
           g1[o] = dd * iv;
           g2[o] = (dd * dd) * iv - 1.f;
@@ -223,14 +304,14 @@ __global__ void __launch_bounds__(GEN_MAX_H) gen_forward_backward_kernel(GenArgs
         }
       } else {
         float m = -INFINITY;
-        for (int o = 0; o < A; ++o) m = fmaxf(m, sh.out[o]);
+        for (int o = 0; o < A; ++o) m = fmaxf(m, out[o]);
         float se = 0.f;
-        for (int o = 0; o < A; ++o) se += expf(sh.out[o] - m);
+        for (int o = 0; o < A; ++o) se += expf(out[o] - m);
         const float lse = m + logf(se);
         const int action = (int)a.buf.actions[(size_t)idx * a.buf.act_store];
-        for (int o = 0; o < A; ++o) { const float lg = sh.out[o] - lse; ent -= expf(lg) * lg; }
+        for (int o = 0; o < A; ++o) { const float lg = out[o] - lse; ent -= expf(lg) * lg; }
         for (int o = 0; o < A; ++o) {
-          const float lg = sh.out[o] - lse, pr = expf(lg);
+          const float lg = out[o] - lse, pr = expf(lg);
           if (o == action) lp = lg;
           g1[o] = (o == action ? 1.f : 0.f) - pr;
           g2[o] = pr * (lg + ent);
@@ -244,13 +325,14 @@ __global__ void __launch_bounds__(GEN_MAX_H) gen_forward_backward_kernel(GenArgs
       const float s1 = Ar * ratio, s2 = Ar * fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
       const float gsel = (s1 <= s2) ? Ar : 0.f;
       const float dlp = inv_nb / (1.f + nu) * (-gsel + nu * Ac) * ratio;
+      for (int o = 0; o < 16; ++o) g2row[o] = 0.f;
       for (int o = 0; o < A; ++o) {
-        dout[o] = L.discrete ? dlp * g1[o] + a.hp.ent_coef * inv_nb * g2[o] : dlp * g1[o];
-        g2row[o] = L.discrete ? 0.f : dlp * g2[o];
+        dout[o] = net.discrete ? dlp * g1[o] + a.hp.ent_coef * inv_nb * g2[o] : dlp * g1[o];
+        g2row[o] = net.discrete ? 0.f : dlp * g2[o];
       }
       rs[0] = fminf(s1, s2); rs[1] = Ac * ratio; rs[2] = fabsf(ratio - 1.f) > clip ? 1.f : 0.f; rs[3] = old_lp - lp; rs[4] = ent;
-    } else {
-      const float v = sh.scal[role - 1];
+    } else if (role < 3) {
+      const float v = sh.act[net.layer[net.head[role]].act_off];
       const float R = role == 1 ? a.buf.reward_returns[idx] : a.buf.cost_returns[idx];
       const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
       const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
@@ -267,80 +349,71 @@ __global__ void __launch_bounds__(GEN_MAX_H) gen_forward_backward_kernel(GenArgs
     }
   }
   __syncthreads();
-  if (j < 16) DOUT[(size_t)row * 16 + j] = dout[j];
-  // dH2 = Wh^T dOut, dz2 = dH2 (1 - h2^2); dH1 = W2^T dz2, dz1 = dH1 (1 - h1^2)
-  {
-    const int Wh = role == 0 ? L.Wa : (role == 1 ? L.Wv : L.Wc);
-    float s = 0.f;
-    for (int o = 0; o < n_out; ++o) s = fmaf(P[Wh + (size_t)o * L.H2 + j], dout[o], s);
-    const float h2 = sh.h2[role][j];
-    const float dz2 = fmaf(-(h2 * h2), s, s);
-    DZ2[(size_t)row * HP + j] = dz2;
+  // back through the stages: d h = sum over the layers that read h of W^T dz (in layer order), dz = d h (1 - h^2)
+  for (int s = net.n_stages - 2; s >= 0; --s) {
+    const int l = gen_my_layer(net, s, slot);
+    if (l >= 0 && j < net.layer[l].out_dim) {
+      float t = 0.f;
+      for (int c = l + 1; c < net.n_layers; ++c) {
+        const GenLayer& y = net.layer[c];
+        if (y.in_buf != l) continue;
+        const float* w = P + y.w_off + j;
+        const float* d = dz + y.act_off;
+        for (int i = 0; i < y.out_dim; ++i) t = fmaf(w[(size_t)i * y.in_dim], d[i], t);
+      }
+      const float h = sh.act[net.layer[l].act_off + j];
+      dz[net.layer[l].act_off + j] = fmaf(-(h * h), t, t);
+    }
     __syncthreads();
-    sh.h2[role][j] = dz2;         // (h2 is no longer needed in LDS)
-    __syncthreads();
-    float t = 0.f;
-    for (int k = 0; k < L.H2; ++k) t = fmaf(P[L.W2[role] + (size_t)k * L.H1 + j], sh.h2[role][k], t);
-    const float h1 = sh.h1[role][j];
-    DZ1[(size_t)row * HP + j] = fmaf(-(h1 * h1), t, t);
   }
+  float* ACT = a.scratch + gen_off_act(B) + (size_t)row * RF;
+  float* DZ = a.scratch + gen_off_dz(B, RF) + (size_t)row * RF;
+  for (int i = tid; i < RF; i += blockDim.x) { ACT[i] = sh.act[i]; DZ[i] = dz[i]; }
 }
 
 // one thread per parameter: its gradient = the sum over the minibatch rows, in row order; block partial of the squared norm
-__global__ void __launch_bounds__(256) gen_wgrad_kernel(GenArgs a, int nb) {
+__global__ void __launch_bounds__(256) gen_wgrad_kernel(GenNet net, GenArgs a, int nb) {
   __shared__ float red[256];
   const GenCtl* ctl = reinterpret_cast<const GenCtl*>(a.scratch);
   if (ctl->stop) return;
-  const PolLayout& L = a.L;
-  const int HP = a.HP, B = a.B, O = L.O;
+  const int B = a.B, RF = net.row_floats, O = net.O;
   const int e = blockIdx.x * 256 + threadIdx.x;
   float g = 0.f;
-  if (e < L.n) {
+  if (e < net.n) {
     const int* rowidx = reinterpret_cast<const int*>(a.scratch + gen_off_rowidx(B));
-    if (!L.discrete && e < L.A) {          // log_std: sum_rows dlp (dd^2 / var - 1), and d(ent_coef * -mean H) / d log_std = -ent_coef
+    if (!net.discrete && e < net.A) {          // log_std: sum_rows dlp (dd^2 / var - 1), and d(ent_coef * -mean H) / d log_std = -ent_coef
       const float* g2 = a.scratch + gen_off_g2(B);
       for (int r = 0; r < nb; ++r) g += g2[(size_t)r * 16 + e];
       g += -a.hp.ent_coef;
     } else {
-      int role = -1, kind = 0, off = 0;    // kind 0 W1, 1 b1, 2 W2, 3 b2, 4 head weight, 5 head bias
-      for (int w = 0; w < 3; ++w) {
-        if (e >= L.W1[w] && e < L.b1[w]) { role = w; kind = 0; off = e - L.W1[w]; }
-        else if (e >= L.b1[w] && e < L.W2[w]) { role = w; kind = 1; off = e - L.b1[w]; }
-        else if (e >= L.W2[w] && e < L.b2[w]) { role = w; kind = 2; off = e - L.W2[w]; }
-        else if (e >= L.b2[w] && e < L.b2[w] + L.H2) { role = w; kind = 3; off = e - L.b2[w]; }
+      int l = 0;
+      while (l < net.n_layers - 1 && !(e >= net.layer[l].w_off && e < net.layer[l].b_off + net.layer[l].out_dim)) ++l;
+      const GenLayer& y = net.layer[l];
+      const float* ACT = a.scratch + gen_off_act(B);
+      const float* DZ = a.scratch + gen_off_dz(B, RF) + y.act_off;
+      if (e < y.b_off) {                       // W[j][k]: sum_rows dz[j] * input[k]
+        const int off = e - y.w_off, j = off / y.in_dim, k = off - j * y.in_dim;
+        if (y.in_buf < 0) { for (int r = 0; r < nb; ++r) g = fmaf(DZ[(size_t)r * RF + j], a.buf.observations[(size_t)rowidx[r] * O + k], g); }
+        else { const float* in = ACT + net.layer[y.in_buf].act_off + k; for (int r = 0; r < nb; ++r) g = fmaf(DZ[(size_t)r * RF + j], in[(size_t)r * RF], g); }
+      } else {                                 // b[j]
+        const int j = e - y.b_off;
+        for (int r = 0; r < nb; ++r) g += DZ[(size_t)r * RF + j];
       }
-      if (role < 0) {
-        if (e >= L.Wa && e < L.ba) { role = 0; kind = 4; off = e - L.Wa; }
-        else if (e >= L.ba && e < L.Wv) { role = 0; kind = 5; off = e - L.ba; }
-        else if (e >= L.Wv && e < L.bv) { role = 1; kind = 4; off = e - L.Wv; }
-        else if (e == L.bv) { role = 1; kind = 5; off = 0; }
-        else if (e >= L.Wc && e < L.bc) { role = 2; kind = 4; off = e - L.Wc; }
-        else { role = 2; kind = 5; off = 0; }
-      }
-      const float* act = a.scratch + gen_off_act(B, role, HP);
-      const float* H1b = act, *H2b = act + (size_t)B * HP, *DZ1 = act + (size_t)2 * B * HP, *DZ2 = act + (size_t)3 * B * HP, *DOUT = act + (size_t)4 * B * HP;
-      if (kind == 0) { const int j = off / O, k = off - j * O; for (int r = 0; r < nb; ++r) g = fmaf(DZ1[(size_t)r * HP + j], a.buf.observations[(size_t)rowidx[r] * O + k], g); }
-      else if (kind == 1) { for (int r = 0; r < nb; ++r) g += DZ1[(size_t)r * HP + off]; }
-      else if (kind == 2) { const int j = off / L.H1, k = off - j * L.H1; for (int r = 0; r < nb; ++r) g = fmaf(DZ2[(size_t)r * HP + j], H1b[(size_t)r * HP + k], g); }
-      else if (kind == 3) { for (int r = 0; r < nb; ++r) g += DZ2[(size_t)r * HP + off]; }
-      else if (kind == 4) { const int o = off / L.H2, k = off - o * L.H2; for (int r = 0; r < nb; ++r) g = fmaf(DOUT[(size_t)r * 16 + o], H2b[(size_t)r * HP + k], g); }
-      else { for (int r = 0; r < nb; ++r) g += DOUT[(size_t)r * 16 + off]; }
     }
-    a.scratch[gen_off_grad(B, HP) + e] = g;
+    a.scratch[gen_off_grad(B, RF) + e] = g;
   }
   const float ss = block_sum(g * g, red);
-  if (threadIdx.x == 0) a.scratch[gen_off_part(B, HP, L.n) + blockIdx.x] = ss;
+  if (threadIdx.x == 0) a.scratch[gen_off_part(B, RF, net.n) + blockIdx.x] = ss;
 }
 
 // clip_grad_norm_ + torch.optim.Adam (single-tensor form) on every parameter; block 0 keeps the statistics of the step
-__global__ void __launch_bounds__(256) gen_adam_kernel(GenArgs a, int step, int epoch, int mb, int nb) {
+__global__ void __launch_bounds__(256) gen_adam_kernel(GenArgs a, int n_params, int RF, int step, int epoch, int mb, int nb) {
   __shared__ float coef_s;
   GenCtl* ctl = reinterpret_cast<GenCtl*>(a.scratch);
   if (ctl->stop) return;
-  const PolLayout& L = a.L;
-  const int HP = a.HP, B = a.B, nblk = (L.n + 255) / 256;
+  const int B = a.B, nblk = (n_params + 255) / 256;
   if (threadIdx.x == 0) {
-    const float* part = a.scratch + gen_off_part(B, HP, L.n);
+    const float* part = a.scratch + gen_off_part(B, RF, n_params);
     float total = 0.f;
     for (int i = 0; i < nblk; ++i) total += part[i];          // fixed order: every block forms the same total
     const float c = a.hp.max_grad_norm / (sqrtf(total) + 1e-6f);
@@ -349,11 +422,11 @@ __global__ void __launch_bounds__(256) gen_adam_kernel(GenArgs a, int step, int 
   __syncthreads();
   const float coef = coef_s;
   const int e = blockIdx.x * 256 + threadIdx.x;
-  if (e < L.n) {
+  if (e < n_params) {
     const double t = (double)(a.adam_t[0] + step + 1);
     const float step_size = (float)((double)a.hp.lr / (1.0 - pow((double)a.hp.adam_beta1, t)));
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)a.hp.adam_beta2, t)));
-    const float g = a.scratch[gen_off_grad(B, HP) + e] * coef;
+    const float g = a.scratch[gen_off_grad(B, RF) + e] * coef;
     const float b1 = a.hp.adam_beta1, b2 = a.hp.adam_beta2;
     const float m = fmaf((float)(1.0 - (double)b1), g, b1 * a.exp_avg[e]);
     const float v = fmaf((float)(1.0 - (double)b2), g * g, b2 * a.exp_avg_sq[e]);
@@ -396,26 +469,23 @@ __global__ void gen_finish_kernel(GenArgs a, int* adam_t) {
   adam_t[0] += ctl->steps_done;
 }
 
-long long generic_train_bytes(int batch_size, int hp, int n_params) { return (long long)gen_floats(batch_size, hp, n_params) * 4; }
-static_assert(ICRL_PPO_GENERIC_BYTES(64, 128, 1000) == 4 * (64 + 64 * (24 + 1 + 16 + 3 * (4 * 128 + 16)) + 1000 + 4 + 64), "ICRL_PPO_GENERIC_BYTES");
+static_assert(ICRL_PPO_GENERIC_BYTES(64, 776, 1000) == 4 * (64 + 64 * (24 + 1 + 16 + 2 * 776) + 1000 + 4 + 64), "ICRL_PPO_GENERIC_BYTES");
 
 // perm_off: the permutations already mapped to storage offsets (prepare in ppo_train.hip); scratch: ICRL_PPO_GENERIC_BYTES
 int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
                          const int* perm_off, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* scratch, hipStream_t s) {
-  if (pol->h1 != pol->h2 || pol->h1 % 64 != 0 || pol->h1 > GEN_MAX_H || pol->obs_dim > 1024 || pol->act_dim > MAX_ACT)
-    return fail("icrl_ppo_lag_train (generic path): obs_dim %d (<= 1024), act_dim %d (<= %d), padded hidden width %d x %d (equal, a multiple of 64, "
-                "<= %d)", pol->obs_dim, pol->act_dim, MAX_ACT, pol->h1, pol->h2, GEN_MAX_H);
+  GenNet net;
+  if (int e = make_gen_net(pol, &net, "icrl_ppo_lag_train")) return e;
   GenArgs a;
-  a.L = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);
-  a.HP = pol->h1; a.B = hp->batch_size;
+  a.B = hp->batch_size;
   a.params = pol->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.buf = *buf; a.perm_off = perm_off; a.nu = nu; a.hp = *hp; a.stats = stats; a.scratch = (float*)scratch;
   a.n_total = buf->T * buf->N;
   a.n_mb = (a.n_total + hp->batch_size - 1) / hp->batch_size;
-  if ((size_t)generic_train_bytes(a.B, a.HP, a.L.n) != ICRL_PPO_GENERIC_BYTES(a.B, a.HP, a.L.n)) return fail("generic update: scratch layout and ICRL_PPO_GENERIC_BYTES disagree");
+  if (gen_floats(a.B, net.row_floats, net.n) * 4 != ICRL_PPO_GENERIC_BYTES(a.B, net.row_floats, net.n)) return fail("generic update: scratch layout and ICRL_PPO_GENERIC_BYTES disagree");
   hipError_t e = hipMemsetAsync(scratch, 0, 64 * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
-  const int nblk = (a.L.n + 255) / 256;
+  const int nblk = (net.n + 255) / 256;
   int step = 0;
   for (int ep = 0; ep < hp->n_epochs; ++ep)
     for (int mb = 0; mb < a.n_mb; ++mb, ++step) {
@@ -423,12 +493,19 @@ int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
       const int nb = a.n_total - p0 < hp->batch_size ? a.n_total - p0 : hp->batch_size;
       const int base = ep * a.n_total + p0;
       hipLaunchKernelGGL(gen_stats_kernel, dim3(1), dim3(256), 0, s, a, base, nb);
-      hipLaunchKernelGGL(gen_forward_backward_kernel, dim3(nb, 3), dim3(a.HP), 0, s, a, base, nb);
-      hipLaunchKernelGGL(gen_wgrad_kernel, dim3(nblk), dim3(256), 0, s, a, nb);
-      hipLaunchKernelGGL(gen_adam_kernel, dim3(nblk), dim3(256), 0, s, a, step, ep, mb, nb);
+      hipLaunchKernelGGL(gen_forward_backward_kernel, dim3(nb), dim3(3 * net.W), 0, s, net, a, base, nb);
+      hipLaunchKernelGGL(gen_wgrad_kernel, dim3(nblk), dim3(256), 0, s, net, a, nb);
+      hipLaunchKernelGGL(gen_adam_kernel, dim3(nblk), dim3(256), 0, s, a, net.n, net.row_floats, step, ep, mb, nb);
     }
   hipLaunchKernelGGL(gen_finish_kernel, dim3(1), dim3(1), 0, s, a, adam_step);
   return (int)hipGetLastError();
+}
+
+// floats one row's activation record takes (the `row_floats` argument of ICRL_PPO_GENERIC_BYTES), or -1 (reason in icrl_last_error)
+int generic_row_floats(const icrl_policy_t* pol) {
+  GenNet net;
+  if (make_gen_net(pol, &net, "icrl_ppo_generic_row_floats")) return -1;
+  return net.row_floats;
 }
 
 }  // namespace icrl

@@ -919,8 +919,9 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
                          const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws,
                          hipStream_t s, TrainArgs& a, int* err) {
   auto bad = [&](int e) { *err = e; return -1; };
-  if (pol->h1 != HD || pol->h2 != HD)
-    return bad(fail("icrl_ppo_lag_train: hidden widths (%d, %d); the update kernels are built for %d x %d (the reference's default net_arch)", pol->h1, pol->h2, HD, HD));
+  if (pol->arch != nullptr || pol->h1 != HD || pol->h2 != HD)
+    return bad(fail("icrl_ppo_lag_train: hidden widths (%d, %d)%s; the persistent update kernels are built for %d x %d (the reference's default net_arch)", pol->h1, pol->h2,
+                    pol->arch != nullptr ? " with an `arch` descriptor" : "", HD, HD));
   if (pol->obs_dim < 1 || pol->obs_dim > 128 || pol->act_dim < 1 || pol->act_dim > 16)
     return bad(fail("icrl_ppo_lag_train: obs_dim %d (1..128) / act_dim %d (1..16)", pol->obs_dim, pol->act_dim));
   if (hp->batch_size < 2 || hp->batch_size > MAXB || hp->n_epochs < 1)
@@ -980,13 +981,14 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   return rows ? (split ? 2 : 1) : 0;
 }
 
-// shapes the persistent kernels refuse (hidden widths above 64, minibatches above 256 rows): the generic-shape path of generic.hip,
-// four plain launches per optimiser step.  Its scratch lies behind the regular workspace: sync_ws must then hold
-// ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(batch_size, h, n_params) bytes.
+// shapes the persistent kernels refuse (hidden widths above 64, architectures given by icrl_policy_t.arch, minibatches above 256 rows):
+// the generic-shape path of generic.hip, four plain launches per optimiser step.  Its scratch lies behind the regular workspace:
+// sync_ws must then hold ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(batch_size, row_floats, n_params) bytes.
 static int train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
                          const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, hipStream_t s) {
   if (hp->batch_size < 2 || hp->n_epochs < 1) return fail("icrl_ppo_lag_train: batch_size %d (>= 2), n_epochs %d (>= 1)", hp->batch_size, hp->n_epochs);
-  if (pol->h1 != pol->h2 || pol->h1 % 64 != 0 || pol->h1 > 256 || pol->obs_dim < 1 || pol->obs_dim > 1024 || pol->act_dim < 1 || pol->act_dim > 16)
+  if (pol->arch != nullptr) { if (int e = policy_generic_check(pol, "icrl_ppo_lag_train")) return e; }
+  else if (pol->h1 != pol->h2 || pol->h1 % 64 != 0 || pol->h1 > 256 || pol->obs_dim < 1 || pol->obs_dim > 1024 || pol->act_dim < 1 || pol->act_dim > 16)
     return fail("icrl_ppo_lag_train: hidden widths (%d, %d), obs_dim %d, act_dim %d: the persistent kernels are built for %d x %d (narrower layers stored "
                 "zero-padded), obs <= 128, act <= 16; the generic-shape path for a common padded width that is a multiple of 64 up to 256, obs <= 1024",
                 pol->h1, pol->h2, pol->obs_dim, pol->act_dim, HD, HD);
@@ -1005,6 +1007,8 @@ static int train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   char* scratch = (char*)sync_ws + ICRL_PPO_SYNC_BYTES(hp->n_epochs, n_mb, n_total);
   return launch_train_generic(pol, exp_avg, exp_avg_sq, adam_step, buf, offs, nu, hp, stats, scratch, s);
 }
+
+extern "C" int icrl_ppo_generic_row_floats(const icrl_policy_t* pol) { return generic_row_floats(pol); }
 
 extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                                   const icrl_buffer_t* buf, const int32_t* perms, const float* nu,

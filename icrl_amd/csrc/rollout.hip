@@ -2696,16 +2696,18 @@ __global__ void __launch_bounds__(192) sample_episodes_batch_kernel(const Sample
 // rows from which icrl_policy_forward / icrl_policy_evaluate take the 16-rows-per-pass MFMA kernel (below: one workgroup per row)
 constexpr int ROWS_KERNEL_MIN = 64;
 
-static bool dims_ok(int O, int A, int H1, int H2) {
-  return O > 0 && O <= MAX_OBS && A > 0 && A <= MAX_ACT && H1 > 0 && H1 <= MAX_H && H2 > 0 && H2 <= MAX_H;
+static bool dims_ok(const icrl_policy_t* p) {      // what the fused kernels serve: two hidden layers per branch, no shared trunk
+  return p->arch == nullptr && p->obs_dim > 0 && p->obs_dim <= MAX_OBS && p->act_dim > 0 && p->act_dim <= MAX_ACT && p->h1 > 0 && p->h1 <= MAX_H &&
+         p->h2 > 0 && p->h2 <= MAX_H;
 }
 static bool cn_ok(const icrl_costnet_t* cn) {
   return cn->in_dim > 0 && cn->in_dim <= MAX_CN_IN && cn->h1 > 0 && cn->h1 <= MAX_H && (cn->n_hidden == 1 ||
          (cn->n_hidden == 2 && cn->h2 > 0 && cn->h2 <= MAX_H)) && cn->obs_dim <= MAX_OBS && cn->acs_dim <= MAX_ACT;
 }
-static int bad_dims(const char* who, int O, int A, int H1, int H2) {
-  return fail("%s: policy obs_dim %d (1..%d), act_dim %d (1..%d), hidden (%d, %d) (1..%d each; wider policies run through the generic-shape "
-              "entry points: icrl_policy_forward / icrl_policy_evaluate / icrl_ppo_lag_train and the per-step rollout)", who, O, MAX_OBS, A, MAX_ACT, H1, H2, MAX_H);
+static int bad_dims(const char* who, const icrl_policy_t* p) {
+  return fail("%s: policy obs_dim %d (1..%d), act_dim %d (1..%d), hidden (%d, %d) (1..%d each)%s; wider policies, shared trunks and other depths run "
+              "through the generic-shape entry points: icrl_policy_forward / icrl_policy_evaluate / icrl_ppo_lag_train and the per-step rollout", who,
+              p->obs_dim, MAX_OBS, p->act_dim, MAX_ACT, p->h1, p->h2, MAX_H, p->arch != nullptr ? ", an `arch` descriptor" : "");
 }
 static int bad_cn(const char* who, const icrl_costnet_t* cn) {
   return fail("%s: constraint net in_dim %d (1..%d), %d hidden layers (1 or 2) of (%d, %d) (1..%d; wider nets: icrl_cost_mlp_forward / icrl_disc_reward / icrl_cn_train and the per-step rollout), obs_dim %d (<= %d), acs_dim %d (<= %d)", who,
@@ -2717,7 +2719,8 @@ static int bad_cn(const char* who, const icrl_costnet_t* cn) {
 using namespace icrl;
 
 extern "C" int icrl_policy_prepare(const icrl_policy_t* p, void* stream) {
-  if (!policy_is_wide(p) && !dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("icrl_policy_prepare", p->obs_dim, p->act_dim, p->h1, p->h2);
+  if (p->arch != nullptr) return policy_generic_check(p, "icrl_policy_prepare");      // no transposed copy: the generic path reads `params`
+  if (!policy_is_wide(p) && !dims_ok(p)) return bad_dims("icrl_policy_prepare", p);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
   if (L.n != p->n_params) return fail("icrl_policy_prepare: n_params = %d, the layout needs %d", p->n_params, L.n);
   hipLaunchKernelGGL(policy_transpose_kernel, dim3((L.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, p->params, p->params_t);
@@ -2739,7 +2742,7 @@ extern "C" int icrl_policy_forward(const icrl_policy_t* p, const double* obs, co
   if (policy_is_wide(p))      // hidden widths above 64: the generic-shape kernel (generic.hip)
     return launch_policy_generic(p, obs, noise, N, deterministic, action_low, action_high, actions, act_clipped, v_r, v_c, log_prob, nullptr, nullptr,
                                  (hipStream_t)stream);
-  if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("policy forward / evaluate", p->obs_dim, p->act_dim, p->h1, p->h2);
+  if (!dims_ok(p)) return bad_dims("policy forward / evaluate", p);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
   if (N >= ROWS_KERNEL_MIN && !p->discrete) {
     const int grid = (N + 15) / 16 < 1024 ? (N + 15) / 16 : 1024;
@@ -2767,7 +2770,7 @@ extern "C" int icrl_policy_evaluate(const icrl_policy_t* p, const double* obs, c
   if (N <= 0) return fail("policy forward / evaluate: N = %d rows", N);
   if (policy_is_wide(p))
     return launch_policy_generic(p, obs, nullptr, N, 1, nullptr, nullptr, nullptr, nullptr, v_r, v_c, log_prob, actions, entropy, (hipStream_t)stream);
-  if (!dims_ok(p->obs_dim, p->act_dim, p->h1, p->h2)) return bad_dims("policy forward / evaluate", p->obs_dim, p->act_dim, p->h1, p->h2);
+  if (!dims_ok(p)) return bad_dims("policy forward / evaluate", p);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
   if (N >= ROWS_KERNEL_MIN && !p->discrete) {
     const int grid = (N + 15) / 16 < 1024 ? (N + 15) / 16 : 1024;
@@ -2794,7 +2797,7 @@ static int make_sample_args(const icrl_env_t* env, const icrl_norm_t* nm, const 
                             const float* action_low, const float* action_high, int episodes_per_stream, int rows_per_stream,
                             int deterministic, int do_reset, const int32_t* stream_row0, int total_rows, double* orig_obs, double* obs,
                             float* actions, double* ep_rewards, int32_t* ep_lengths, SampleArgs& a) {
-  if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2)) return bad_dims("icrl_sample_episodes", pol->obs_dim, pol->act_dim, pol->h1, pol->h2);
+  if (!dims_ok(pol)) return bad_dims("icrl_sample_episodes", pol);
   if (env->obs_dim != pol->obs_dim || nm->training)
     return fail("icrl_sample_episodes: env obs_dim %d vs policy %d; the normaliser must be frozen (training = %d)", env->obs_dim, pol->obs_dim, nm->training);
   if (episodes_per_stream * env->max_steps > rows_per_stream)
@@ -2981,7 +2984,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
                                        double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
                                        int do_gae, void* stream) {
   const int N = env->n_envs, O = env->obs_dim, T = buf->T;
-  if (!dims_ok(pol->obs_dim, pol->act_dim, pol->h1, pol->h2)) return bad_dims("icrl_rollout_collect", pol->obs_dim, pol->act_dim, pol->h1, pol->h2);
+  if (!dims_ok(pol)) return bad_dims("icrl_rollout_collect", pol);
   if (pol->obs_dim != O || buf->N != N || buf->obs_dim != O)
     return fail("icrl_rollout_collect: env (%d envs, obs_dim %d) vs policy obs_dim %d vs buffer (%d envs, obs_dim %d)", N, O, pol->obs_dim, buf->N, buf->obs_dim);
   if (cn != nullptr && !cn_ok(cn)) return bad_cn("icrl_rollout_collect", cn);
@@ -3152,7 +3155,7 @@ extern "C" int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* 
             j.pol->obs_dim != O || j.pol->act_dim != j0.pol->act_dim || j.pol->discrete != j0.pol->discrete || (j.cn != nullptr) != has_cn ||
             (has_cn && (j.cn->in_dim != j0.cn->in_dim || j.cn->n_hidden != j0.cn->n_hidden)) || j.nm->training != j0.nm->training)
           return fail("icrl_rollout_collect_batch: run %d differs from run 0 in a shape (envs / obs / act / T / discrete / constraint net)", r);
-        if (!dims_ok(j.pol->obs_dim, j.pol->act_dim, j.pol->h1, j.pol->h2)) return bad_dims("icrl_rollout_collect_batch", j.pol->obs_dim, j.pol->act_dim, j.pol->h1, j.pol->h2);
+        if (!dims_ok(j.pol)) return bad_dims("icrl_rollout_collect_batch", j.pol);
         if (j.buf->obs_dim != O) return fail("icrl_rollout_collect_batch: run %d: buffer obs_dim %d vs env %d", r, j.buf->obs_dim, O);
         if (j.cn != nullptr && !cn_ok(j.cn)) return bad_cn("icrl_rollout_collect_batch", j.cn);
         void* ws = (j.ag->xch_ws != nullptr && (size_t)j.ag->xch_ws_bytes >= need) ? j.ag->xch_ws
@@ -3198,7 +3201,7 @@ extern "C" int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* 
         j.pol->obs_dim != O || j.pol->act_dim != j0.pol->act_dim || j.pol->discrete != j0.pol->discrete || (j.cn != nullptr) != has_cn ||
         (has_cn && (j.cn->in_dim != j0.cn->in_dim || j.cn->n_hidden != j0.cn->n_hidden)))
       return fail("icrl_rollout_collect_batch: run %d differs from run 0 in a shape (envs / obs / act / T / discrete / constraint net)", r);
-    if (!dims_ok(j.pol->obs_dim, j.pol->act_dim, j.pol->h1, j.pol->h2)) return bad_dims("icrl_rollout_collect_batch", j.pol->obs_dim, j.pol->act_dim, j.pol->h1, j.pol->h2);
+    if (!dims_ok(j.pol)) return bad_dims("icrl_rollout_collect_batch", j.pol);
     if (j.buf->obs_dim != O) return fail("icrl_rollout_collect_batch: run %d: buffer obs_dim %d vs env %d", r, j.buf->obs_dim, O);
     if (j.cn != nullptr && !cn_ok(j.cn)) return bad_cn("icrl_rollout_collect_batch", j.cn);
     char* ws = (j.ag->xch_ws != nullptr && (size_t)j.ag->xch_ws_bytes >= need) ? reinterpret_cast<char*>(j.ag->xch_ws)

@@ -3,10 +3,15 @@
 ref: stable_baselines3/common/policies.py:598-779 (ActorTwoCriticsPolicy), common/torch_layers.py:129-254 (MlpExtractor),
      common/distributions.py:114-192,249-298 (DiagGaussian / Categorical), icrl/utils.py:636-655 (get_net_arch).
 
-Scope: the two-critics MLP policy every BASELINE config uses — three separate tanh MLPs (pi / vf / cvf) with two hidden
-layers each (<= 64 wide, per branch; narrower layers are stored zero-padded to 64), no shared trunk, DiagGaussian (Box) or Categorical (Discrete) head.  Parameter initialisation
-runs on the host with torch-CPU exactly like the reference (same construction / orthogonal-init order, so the same seed
-gives the same weights); after that the flat buffer lives on the device and only kernels touch it.
+Scope: the two-critics MLP policy — an optional shared tanh trunk, then three tanh MLPs (pi / vf / cvf) and a DiagGaussian (Box) or
+Categorical (Discrete) head.  Three storage kinds, by architecture:
+  * "fast": no trunk, two hidden layers per branch, every width <= 64 (every BASELINE config) — the persistent kernels; narrower
+    layers are stored zero-padded to 64;
+  * "wide": the same shape with a layer of 65..256 units — generic-shape path, stored zero-padded to a common multiple of 64;
+  * "arch": anything else MlpExtractor builds (`-sl` trunk of up to 4 layers, branches of 0..4 layers, widths 1..256) — generic-shape
+    path, natural unpadded layout, described to the library by an `arch` array (include/icrl_hip.h: icrl_policy_t).
+Parameter initialisation runs on the host with torch-CPU exactly like the reference (same construction / orthogonal-init order, so
+the same seed gives the same weights); after that the flat buffer lives on the device and only kernels touch it.
 """
 import math
 from collections import OrderedDict
@@ -20,12 +25,17 @@ from .structs import PolicyT, p
 BRANCHES = ("policy_net", "value_net", "cost_value_net")
 HW = 64        # width the fast kernels are built for (HD in csrc/ppo_common.h, MAX_H in csrc/common.h)
 HW_MAX = 256   # widest layer of the generic-shape path (csrc/generic.hip: GEN_MAX_H)
+DEPTH_MAX = 4  # layers of the shared trunk / of one branch on the generic-shape path (csrc/generic.hip: GEN_MAX_DEPTH)
 
 
-def state_dict_names(discrete, n_hidden=2):
+def state_dict_names(discrete, n_hidden=2, n_shared=0):
+    """parameter names in the reference's state_dict order; n_hidden: one depth for the three branches or a (pi, vf, cvf) triple."""
+    depths = (n_hidden,) * 3 if isinstance(n_hidden, int) else tuple(n_hidden)
     names = [] if discrete else ["log_std"]
-    for b in BRANCHES:
-        for k in range(n_hidden):
+    for k in range(n_shared):
+        names += [f"mlp_extractor.shared_net.{2 * k}.weight", f"mlp_extractor.shared_net.{2 * k}.bias"]
+    for b, d in zip(BRANCHES, depths):
+        for k in range(d):
             names += [f"mlp_extractor.{b}.{2 * k}.weight", f"mlp_extractor.{b}.{2 * k}.bias"]
     for h in ("action_net", "value_net", "cost_value_net"):
         names += [f"{h}.weight", f"{h}.bias"]
@@ -42,22 +52,34 @@ class ActorTwoCriticsPolicy:
         self.act_dim = int(action_space.n) if self.discrete else int(action_space.shape[0])
         if net_arch is None:
             net_arch = [dict(pi=[64, 64], vf=[64, 64], cvf=[64, 64])]
-        arch = net_arch[-1] if isinstance(net_arch[-1], dict) else None
-        if arch is None or len(net_arch) != 1 or any(len(arch.get(k, ())) != 2 or max(arch[k]) > HW_MAX or min(arch[k]) < 1
-                                                     for k in ("pi", "vf", "cvf")):
-            raise NotImplementedError("icrl_amd supports net_arch=[dict(pi=[h1,h2], vf=[h1,h2], cvf=[h1,h2])]: three separate "
-                                      f"two-layer MLPs, every width 1..{HW_MAX}, no shared trunk (up to {HW} wide on the persistent kernels, "
-                                      f"wider on the generic-shape path; narrower layers run zero-padded); got {net_arch}")
-        # logical widths per branch (-pl / -rvl / -cvl, ref: icrl/utils.py:636-655).  The device buffers are `hw` wide — 64 when every
-        # layer fits the fast kernels, else the widest layer rounded up to a multiple of 64 (the generic-shape path, csrc/generic.hip) —
-        # and a narrower layer is stored zero-padded.  Padding units have zero weights in and out and a zero bias, so they output
-        # tanh(0) = 0 exactly, receive a zero gradient and keep zero Adam moments: every real parameter sees exactly the
-        # arithmetic of the unpadded network (only zeros are added to its dot products).
-        self.widths = {b: (int(arch[k][0]), int(arch[k][1])) for b, k in zip(BRANCHES, ("pi", "vf", "cvf"))}
-        widest = max(max(w) for w in self.widths.values())
-        self.hw = HW if widest <= HW else -(-widest // 64) * 64
-        self.wide = self.hw > HW          # the persistent rollout / sampling / update kernels do not serve this policy
+        # net_arch = [shared widths..., dict(pi=[...], vf=[...], cvf=[...])] (ref: torch_layers.py:129-254, icrl/utils.py:636-655); a list
+        # without the dict is a trunk the three heads read directly
+        n_sh = next((i for i, x in enumerate(net_arch) if isinstance(x, dict)), len(net_arch))
+        arch = net_arch[n_sh] if n_sh < len(net_arch) else {}
+        self.shared = tuple(int(w) for w in net_arch[:n_sh])
+        self.layers = {b: tuple(int(w) for w in (arch.get(k) or ())) for b, k in zip(BRANCHES, ("pi", "vf", "cvf"))}
+        every = list(self.shared) + [w for b in BRANCHES for w in self.layers[b]]
+        if len(self.shared) > DEPTH_MAX or any(len(v) > DEPTH_MAX for v in self.layers.values()) or any(w < 1 or w > HW_MAX for w in every):
+            raise NotImplementedError(f"icrl_amd serves net_arch = [shared..., dict(pi=[...], vf=[...], cvf=[...])] with up to {DEPTH_MAX} shared layers, up to "
+                                      f"{DEPTH_MAX} layers per branch and 1..{HW_MAX} units per layer; got {net_arch}")
+        two = not self.shared and all(len(v) == 2 for v in self.layers.values())
+        # logical widths per branch (-pl / -rvl / -cvl).  "fast" / "wide": the device buffers are `hw` wide — 64 when every layer fits the
+        # fast kernels, else the widest layer rounded up to a multiple of 64 (the generic-shape path, csrc/generic.hip) — and a narrower
+        # layer is stored zero-padded.  Padding units have zero weights in and out and a zero bias, so they output tanh(0) = 0 exactly,
+        # receive a zero gradient and keep zero Adam moments: every real parameter sees exactly the arithmetic of the unpadded network
+        # (only zeros are added to its dot products).  "arch": natural widths, no padding.
+        widest = max(every) if every else 0
+        self.kind = ("fast" if widest <= HW else "wide") if two else "arch"
+        self.widths = {b: self.layers[b] for b in BRANCHES} if two else None
+        self.hw = (HW if widest <= HW else -(-widest // 64) * 64) if two else 0
+        self.wide = self.kind != "fast"   # the persistent rollout / sampling / update kernels do not serve this policy
         self.h1 = self.h2 = self.hw
+        self.arch = None
+        if self.kind == "arch":           # the descriptor icrl_policy_t.arch points at (host memory, kept alive here)
+            desc = [len(self.shared), *self.shared]
+            for b in BRANCHES:
+                desc += [len(self.layers[b]), *self.layers[b]]
+            self.arch = np.ascontiguousarray(desc, dtype=np.int32)
         self.optimizer_kwargs = dict(eps=1e-5) if optimizer_kwargs is None else dict(optimizer_kwargs)  # ref: policies.py:357-361
         self.lr_schedule = lr_schedule
         sd = self._init_host(log_std_init, ortho_init)
@@ -74,7 +96,7 @@ class ActorTwoCriticsPolicy:
         self.prepare()
 
     def _physical_shape(self, name, shp):
-        if name == "log_std":
+        if name == "log_std" or self.kind == "arch":
             return shp
         if name.startswith("mlp_extractor."):
             first = name.split(".")[2] == "0"
@@ -103,23 +125,29 @@ class ActorTwoCriticsPolicy:
     def _init_host(self, log_std_init, ortho_init):
         """construction + init order of ActorTwoCriticsPolicy._build (ref: policies.py:648-714, torch_layers.py:208-226)."""
         Lin = torch.nn.Linear
+        shared, last_sh = [], self.obs_dim
+        for w in self.shared:             # the trunk is built first, then layer k of pi, vf, cvf back to back (zip_longest)
+            shared.append(Lin(last_sh, w)); last_sh = w
         lins = {b: [] for b in BRANCHES}
-        last = {b: self.obs_dim for b in BRANCHES}
-        for k in range(2):
+        last = {b: last_sh for b in BRANCHES}
+        for k in range(max(len(v) for v in self.layers.values())):
             for b in BRANCHES:
-                lins[b].append(Lin(last[b], self.widths[b][k]))
-                last[b] = self.widths[b][k]
+                if k < len(self.layers[b]):
+                    lins[b].append(Lin(last[b], self.layers[b][k]))
+                    last[b] = self.layers[b][k]
         heads = OrderedDict(action_net=Lin(last["policy_net"], self.act_dim), value_net=Lin(last["value_net"], 1),
                             cost_value_net=Lin(last["cost_value_net"], 1))
-        if ortho_init:
-            for b in BRANCHES:
-                for lin in lins[b]:
-                    torch.nn.init.orthogonal_(lin.weight, gain=math.sqrt(2)); lin.bias.data.fill_(0.0)
+        if ortho_init:                    # module.apply order: shared_net, policy_net, value_net, cost_value_net, then the heads
+            for lin in shared + [lin for b in BRANCHES for lin in lins[b]]:
+                torch.nn.init.orthogonal_(lin.weight, gain=math.sqrt(2)); lin.bias.data.fill_(0.0)
             for lin, g in zip(heads.values(), (0.01, 1.0, 1.0)):
                 torch.nn.init.orthogonal_(lin.weight, gain=g); lin.bias.data.fill_(0.0)
         sd = OrderedDict()
         if not self.discrete:
             sd["log_std"] = torch.ones(self.act_dim) * log_std_init
+        for k, lin in enumerate(shared):
+            sd[f"mlp_extractor.shared_net.{2 * k}.weight"] = lin.weight.data
+            sd[f"mlp_extractor.shared_net.{2 * k}.bias"] = lin.bias.data
         for b in BRANCHES:
             for k, lin in enumerate(lins[b]):
                 sd[f"mlp_extractor.{b}.{2 * k}.weight"] = lin.weight.data
@@ -130,7 +158,15 @@ class ActorTwoCriticsPolicy:
 
     # ---- C-ABI descriptor -------------------------------------------------------------------------------------
     def struct(self):
-        return PolicyT(self.obs_dim, self.act_dim, self.h1, self.h2, int(self.discrete), self.n_params, p(self.params), p(self.params_t))
+        return PolicyT(self.obs_dim, self.act_dim, self.h1, self.h2, int(self.discrete), self.n_params, p(self.params), p(self.params_t),
+                       None if self.arch is None else self.arch.ctypes.data)
+
+    @property
+    def row_floats(self):
+        """outputs of every layer of one row: the `row_floats` argument of ICRL_PPO_GENERIC_BYTES (include/icrl_hip.h)."""
+        if self.kind == "arch":
+            return sum(self.shared) + sum(sum(v) for v in self.layers.values()) + self.act_dim + 2
+        return 6 * self.hw + self.act_dim + 2
 
     def prepare(self):
         """refresh the transposed weight copy the rollout kernels read (call after params change)."""

@@ -331,8 +331,8 @@ class PPOLagrangian:
                     clip_range_cost_vf=num(self.clip_range_cost_vf), algo_type=self.algo_type, budget=float(self.budget),
                     penalty_initial_value=float(self.penalty_initial_value), penalty_learning_rate=float(self.penalty_learning_rate),
                     penalty_min_value=self.penalty_min_value, update_penalty_after=self.update_penalty_after, pid_kwargs=self.pid_kwargs,
-                    policy_kwargs=dict(net_arch=[dict(pi=list(self.policy.widths["policy_net"]), vf=list(self.policy.widths["value_net"]),
-                                                      cvf=list(self.policy.widths["cost_value_net"]))]))
+                    policy_kwargs=dict(net_arch=[*self.policy.shared, dict(pi=list(self.policy.layers["policy_net"]), vf=list(self.policy.layers["value_net"]),
+                                                                           cvf=list(self.policy.layers["cost_value_net"]))]))
         with zipfile.ZipFile(path, "w") as z:
             z.writestr("data", json.dumps(data, default=lambda o: str(o)))
             z.writestr("policy.pth", blob(self.policy.state_dict()))
@@ -359,16 +359,13 @@ class PPOLagrangian:
             # a state dict of tensors: weights_only refuses anything else (an archive is untrusted input; the `data` entry next to it
             # goes through the allow-list unpickler of utils.parse_sb3_data for the same reason)
             sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)
-        # network widths (-pl / -rvl / -cvl): read off the stored tensors, whoever wrote the archive
-        if any(k.startswith("mlp_extractor.shared_net") for k in sd):
-            raise NotImplementedError("archives with a shared trunk (-sl) are outside this build (policies.py)")
-        def w(b):      # the Linear layers of a branch sit at even indices of its Sequential (torch_layers.py:208-226)
+        # network widths (-sl / -pl / -rvl / -cvl): read off the stored tensors, whoever wrote the archive
+        def w(b):      # the Linear layers of a Sequential sit at its even indices (torch_layers.py:183-226)
             idx = sorted(int(k.split(".")[2]) for k in sd if k.startswith(f"mlp_extractor.{b}.") and k.endswith(".weight"))
-            if idx != [0, 2]:
-                raise NotImplementedError(f"archive: {len(idx)} hidden layers in mlp_extractor.{b} (Linear layers at {idx}); this build's policies "
-                                          "have exactly two per branch (policies.py)")
+            if idx != list(range(0, 2 * len(idx), 2)):
+                raise NotImplementedError(f"archive: mlp_extractor.{b} has Linear layers at {idx}, not at 0, 2, 4, ... (tanh between them)")
             return [int(sd[f"mlp_extractor.{b}.{i}.weight"].shape[0]) for i in idx]
-        net_arch = [dict(pi=w("policy_net"), vf=w("value_net"), cvf=w("cost_value_net"))]
+        net_arch = [*w("shared_net"), dict(pi=w("policy_net"), vf=w("value_net"), cvf=w("cost_value_net"))]
         if "observation_dim" in data and "observation_space" not in data:      # archive written by save() of this build
             o, a = int(data["observation_dim"]), int(data["action_dim"])
             data["observation_space"] = spaces.Box(-np.inf, np.inf, (o,), np.float64)
@@ -459,9 +456,9 @@ class PPOLagrangian:
         if not hasattr(self, "_train_ws"):
             n_words = 96 + 6 * self.n_epochs * (-(-n // int(self.batch_size))) + (self.n_epochs * n + 1) // 2 + 32 + _lib.PPO_SPLIT_BYTES // 8
             self._generic_update = pol.wide or int(self.batch_size) > 256      # shapes of the generic-shape path (csrc/generic.hip)
-            if self._generic_update:      # its scratch lies behind the regular workspace: ICRL_PPO_GENERIC_BYTES(batch_size, h, n_params)
+            if self._generic_update:      # its scratch lies behind the regular workspace: ICRL_PPO_GENERIC_BYTES(batch_size, row_floats, n_params)
                 B_, n_ = int(self.batch_size), pol.n_params
-                n_words += (64 + B_ * (24 + 1 + 16 + 3 * (4 * pol.hw + 16)) + n_ + (n_ + 255) // 256 + 64 + 1) // 2 + 8
+                n_words += (64 + B_ * (24 + 1 + 16 + 2 * pol.row_floats) + n_ + (n_ + 255) // 256 + 64 + 1) // 2 + 8
             # the workspace lives in an arena with room for SYNC_CANDIDATES positions 1 MB apart: see _tune_sync_placement
             arena = torch.zeros(n_words + (self.SYNC_CANDIDATES - 1) * (1 << 17), dtype=torch.int64, device=dev)
             self._train_ws = dict(nu=torch.zeros(1, device=dev), stats=torch.zeros(32 + self.n_epochs, device=dev), sync=arena[:n_words],

@@ -20,7 +20,7 @@ class NormT(C.Structure):
 
 class PolicyT(C.Structure):
     _fields_ = [("obs_dim", i32), ("act_dim", i32), ("h1", i32), ("h2", i32), ("discrete", i32), ("n_params", i32),
-                ("params", vp), ("params_t", vp)]
+                ("params", vp), ("params_t", vp), ("arch", vp)]      # arch: host int32 array or NULL (include/icrl_hip.h)
 
 
 class CostNetT(C.Structure):

@@ -77,13 +77,21 @@ typedef struct {
 /* ActorTwoCriticsPolicy parameters (stable_baselines3/common/policies.py:598-779): three tanh MLPs obs->h1->h2
  * (pi, vf, cvf), heads h2->act / 1 / 1, state-independent log_std.  `params` is ONE flat float32 buffer in the
  * reference's state_dict order: log_std[A] (absent when discrete), then for pi, vf, cvf: W1[h1,obs] b1[h1] W2[h2,h1]
- * b2[h2], then action_net W[A,h2] b[A], value_net W[1,h2] b[1], cost_value_net W[1,h2] b[1]. */
+ * b2[h2], then action_net W[A,h2] b[A], value_net W[1,h2] b[1], cost_value_net W[1,h2] b[1].
+ *
+ * Any other MlpExtractor architecture (common/torch_layers.py:129-254: `-sl` shared trunk, `-pl / -rvl / -cvl` of any depth) is
+ * described by `arch`, HOST memory: { n_shared, widths..., n_pi, widths..., n_vf, widths..., n_cvf, widths... } with 0..4 layers per
+ * group and 1..256 units per layer (a branch without layers feeds its head from the trunk, or from the observation).  h1 / h2 are then
+ * ignored and `params` holds the natural, unpadded layout in state_dict order: log_std, the trunk's layers (W[out,in] b[out] each),
+ * policy_net's, value_net's, cost_value_net's, then the three heads.  Such a policy is served by icrl_policy_forward,
+ * icrl_policy_evaluate and icrl_ppo_lag_train (generic-shape path); the fused rollout / sampling launches refuse it. */
 typedef struct {
   int32_t obs_dim, act_dim, h1, h2;
   int32_t discrete; /* 1: Categorical over act_dim logits (LGW), 0: DiagGaussian */
   int32_t n_params;
   float* params;     /* [n_params] */
-  float* params_t;   /* [n_params] transposed copy for the rollout kernels (written by icrl_policy_prepare) */
+  float* params_t;   /* [n_params] transposed copy for the rollout kernels (written by icrl_policy_prepare; unused with `arch`) */
+  const int32_t* arch; /* NULL: two hidden layers per branch (h1, h2), no shared trunk */
 } icrl_policy_t;
 
 /* ConstraintNet zeta_theta (icrl/constraint_net.py:14-130,258-299): ReLU MLP + sigmoid over
@@ -157,10 +165,11 @@ typedef struct {
 #define ICRL_PPO_PLAN_BYTES(n_steps) (768 + 48 * (size_t)(n_steps))
 #define ICRL_PPO_SYNC_BYTES(n_epochs, n_minibatches, n_rows) \
   (ICRL_PPO_PLAN_BYTES((size_t)(n_epochs) * (size_t)(n_minibatches)) + 4 * (size_t)(n_epochs) * (size_t)(n_rows) + 256 + ICRL_PPO_SPLIT_BYTES)
-/* generic-shape update (hidden widths above 64 — `h` = the padded common width, a multiple of 64 up to 256 — or batch_size above 256):
- * its scratch lies BEHIND the regular workspace, sync_ws then holds ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(...) bytes */
-#define ICRL_PPO_GENERIC_BYTES(batch_size, h, n_params) \
-  (4 * (64 + (size_t)(batch_size) * (24 + 1 + 16 + 3 * (4 * (size_t)(h) + 16)) + (size_t)(n_params) + ((size_t)(n_params) + 255) / 256 + 64))
+/* generic-shape update (hidden widths above 64, a policy with `arch`, or batch_size above 256): its scratch lies BEHIND the regular
+ * workspace, sync_ws then holds ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(...) bytes.  row_floats = the outputs of every layer
+ * of one row = icrl_ppo_generic_row_floats(pol) (6 h + act_dim + 2 for the padded two-layer layout of common width h) */
+#define ICRL_PPO_GENERIC_BYTES(batch_size, row_floats, n_params) \
+  (4 * (64 + (size_t)(batch_size) * (24 + 1 + 16 + 2 * (size_t)(row_floats)) + (size_t)(n_params) + ((size_t)(n_params) + 255) / 256 + 64))
 #define ICRL_CN_METRICS 24 /* floats per iteration in the metrics array of icrl_cn_train */
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -168,7 +177,7 @@ typedef struct {
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* ABI version (major*100+minor). */
-int icrl_abi_version(void);   /* 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
+int icrl_abi_version(void);   /* 102: icrl_policy_t.arch; 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
 
 /* Every entry point returns a hipError_t.  When it is hipErrorInvalidValue because the arguments are outside what the
  * kernels were built for (env count, widths, batch size ...; the reference's Python raises ValueError / AssertionError with a
@@ -317,12 +326,16 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
  *            tiles kernel; the row-owning kernel runs TWO workgroups per network when batch_size > 64 (each computes one 64-row
  *            chunk of a minibatch, partial gradients exchanged as granules) unless bit 3 is set.
  * Shapes outside the persistent kernels — a policy stored with hidden width h1 = h2 > 64 (a multiple of 64 up to 256: the reference's
- * -pl / -rvl / -cvl flags take any width, icrl/utils.py:636-655) or batch_size > 256 (buffers.py:594-612 slices any size) — run
- * through the generic-shape path (csrc/generic.hip): four plain launches per optimiser step, same statistics layout, no hp->_pad
- * options; sync_ws must then hold ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(batch_size, h1, n_params) bytes. */
+ * -pl / -rvl / -cvl flags take any width, icrl/utils.py:636-655), a policy described by `arch` (shared trunk, other depths) or
+ * batch_size > 256 (buffers.py:594-612 slices any size) — run through the generic-shape path (csrc/generic.hip): four plain launches
+ * per optimiser step, same statistics layout, no hp->_pad options; sync_ws must then hold ICRL_PPO_SYNC_BYTES(...) +
+ * ICRL_PPO_GENERIC_BYTES(batch_size, icrl_ppo_generic_row_floats(pol), n_params) bytes. */
 int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                        const icrl_buffer_t* buf, const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp,
                        float* stats, void* sync_ws, void* stream);
+/* the `row_floats` argument of ICRL_PPO_GENERIC_BYTES for this policy (host arithmetic, no launch), or -1 with the reason in
+ * icrl_last_error() when the generic-shape path does not serve its architecture */
+int icrl_ppo_generic_row_floats(const icrl_policy_t* pol);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Batched forms: several INDEPENDENT runs (seeds) of identical shape in ONE launch, run = blockIdx.y

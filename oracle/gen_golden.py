@@ -257,6 +257,17 @@ def g15_wide():
     g4_ppo_minibatch("g15_wide", dict(pi=[128, 128], vf=[96, 128], cvf=[128, 80]))
 
 
+def g17_trunk():
+    """g4 with a shared trunk and branches of 3 / 1 / 0 layers (-sl 48 -pl 64 32 32 -rvl 40 -cvl; torch_layers.py:129-254): the
+    architectures icrl_policy_t.arch describes (csrc/generic.hip)."""
+    g4_ppo_minibatch("g17_trunk", [48, dict(pi=[64, 32, 32], vf=[40], cvf=[])])
+
+
+def g18_deep():
+    """g4 with branches of 1 / 3 / 4 layers, no trunk (-pl 32 -rvl 64 64 64 -cvl 96 200 64 16)."""
+    g4_ppo_minibatch("g18_deep", [dict(pi=[32], vf=[64, 64, 64], cvf=[96, 200, 64, 16])])
+
+
 def g16_batch512():
     """g4 on ONE 512-row batch (batch sizes above 256: generic-shape path)."""
     g4_ppo_minibatch("g16_batch512", None, B=512)
@@ -269,7 +280,8 @@ def g14_batch256():
 
 def g4_ppo_minibatch(name="g4_ppo_minibatch", arch=None, B=64):
     print("G4 PPO-Lagrangian minibatch step + train()" + ("" if arch is None else f" {arch}") + ("" if B == 64 else f" batch {B}"))
-    kw = {} if arch is None else dict(policy_kwargs=dict(net_arch=[dict(arch)]))
+    net_arch = None if arch is None else ([dict(arch)] if isinstance(arch, dict) else list(arch))      # arch: the dict, or a full net_arch list
+    kw = {} if arch is None else dict(policy_kwargs=dict(net_arch=net_arch))
     agent, env, cn = _make_ref_agent(4, "hc", 0, [20], **kw)
     pol = agent.policy
     sd0 = _sd_np(pol.state_dict())
@@ -280,8 +292,11 @@ def g4_ppo_minibatch(name="g4_ppo_minibatch", arch=None, B=64):
     ret_r, ret_c = th.tensor(rng.randn(B), dtype=th.float32), th.tensor(rng.randn(B), dtype=th.float32)
     nu, clip = 0.731, 0.2
     # oracle policy with the same weights
-    hidden = (64, 64) if arch is None else dict(policy_net=arch["pi"], value_net=arch["vf"], cost_value_net=arch["cvf"])
-    op = o_nets.TwoCriticPolicy(18, 6, hidden=hidden); op.load_state_dict(pol.state_dict())
+    n_sh = 0 if net_arch is None else next(i for i, x in enumerate(net_arch) if isinstance(x, dict))
+    hidden = (64, 64) if arch is None else dict(policy_net=net_arch[n_sh]["pi"], value_net=net_arch[n_sh]["vf"], cost_value_net=net_arch[n_sh]["cvf"])
+    op = o_nets.TwoCriticPolicy(18, 6, hidden=hidden, shared=() if net_arch is None else tuple(net_arch[:n_sh]))
+    assert list(op.params) == list(pol.state_dict())
+    op.load_state_dict(pol.state_dict())
     oopt = th.optim.Adam(op.parameters(), lr=3e-4, eps=1e-5)
     out = {}
     for step in range(3):                                # three consecutive steps on the same batch (Adam state evolves)
@@ -926,8 +941,8 @@ def fixtures_expert():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11", "g12", "g13", "g14", "g15", "g16"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g9", "g10", "expert", "g8", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"]
     table = dict(g1=g1_gae, g2=g2_cost_function, g3=g3_vecnormalize, g4=g4_ppo_minibatch, g5=g5_dual,
-                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g12=g12_gail, g13=g13_widths, g14=g14_batch256, g15=g15_wide, g16=g16_batch512, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
+                 g6=g6_constraint_net_train, g7=g7_constraint_net_minibatch, g8=g8_icrl_lgw, g11=g11_pid, g12=g12_gail, g13=g13_widths, g14=g14_batch256, g15=g15_wide, g16=g16_batch512, g17=g17_trunk, g18=g18_deep, g9=g9_learn_iteration, g10=g10_lap_grid, expert=fixtures_expert)
     for w in which:
         table[w]()

@@ -82,7 +82,7 @@ class PortAgent:
                  reward_gamma=0.99, reward_gae_lambda=0.95, cost_gamma=0.99, cost_gae_lambda=0.95,
                  clip_range=0.2, ent_coef=0.0, reward_vf_coef=0.5, cost_vf_coef=0.5, max_grad_norm=0.5,
                  target_kl=None, penalty_initial_value=1.0, penalty_learning_rate=0.1, budget=0.0,
-                 hidden=(64, 64), seed=0, discrete=False, pid_kwargs=None):
+                 hidden=(64, 64), seed=0, discrete=False, pid_kwargs=None, shared=()):
         self.stack = stack
         env = stack.env
         self.obs_dim, self.act_dim = env.obs_dim, env.act_dim
@@ -93,7 +93,7 @@ class PortAgent:
         # ref: on_policy_algorithm.py:313-316 / common/utils.py:23-39 — seed python/numpy/torch, then build
         import random
         random.seed(seed); np.random.seed(seed); th.manual_seed(seed)
-        self.policy = TwoCriticPolicy(self.obs_dim, self.act_dim, hidden, discrete=discrete)
+        self.policy = TwoCriticPolicy(self.obs_dim, self.act_dim, hidden, discrete=discrete, shared=shared)
         self.optimizer = th.optim.Adam(self.policy.parameters(), lr=learning_rate, eps=1e-5)  # ref: policies.py:357-361
         # ref: ppo_lag.py:147-160 — algo_type "lagrangian" | "pidlagrangian"
         self.dual = PID(**pid_kwargs) if pid_kwargs is not None else Dual(budget, penalty_learning_rate, penalty_initial_value, None)
@@ -282,7 +282,7 @@ PORT_DEFAULTS = dict(   # the reference's flag names and parser defaults (icrl/i
     cn_batch_size=None, train_gail_lambda=False, cn_normalize=False, backward_iters=10, forward_timesteps=1000000, n_iters=100,
     expert_rollouts=20, clip_obs=20, cn_eps=1e-5, dont_normalize_obs=False, dont_normalize_reward=False,
     dont_normalize_cost=False, warmup_timesteps=None, reset_policy=False, factored=False,
-    policy_layers=(64, 64), reward_vf_layers=(64, 64), cost_vf_layers=(64, 64))      # -pl / -rvl / -cvl (icrl/utils.py:636-655)
+    policy_layers=(64, 64), reward_vf_layers=(64, 64), cost_vf_layers=(64, 64), shared_layers=None)      # -pl / -rvl / -cvl / -sl (icrl/utils.py:636-655)
 
 
 def true_cost(eval_env_id, orig_obs, acts):
@@ -320,7 +320,7 @@ def icrl_port(cfg, expert_obs, expert_acs, expert_policy_sd=None, n_iters=None, 
                       target_kl=c["target_kl"], penalty_initial_value=c["penalty_initial_value"],
                       penalty_learning_rate=c["penalty_learning_rate"], budget=c["budget"], seed=c["seed"], discrete=discrete,
                       hidden=dict(policy_net=tuple(c["policy_layers"]), value_net=tuple(c["reward_vf_layers"]),
-                                  cost_value_net=tuple(c["cost_vf_layers"])))
+                                  cost_value_net=tuple(c["cost_vf_layers"])), shared=tuple(c.get("shared_layers") or ()))
     # NB the reference builds the constraint net BEFORE the agent (icrl.py:88-117 vs :139-178) but the agent's constructor
     # re-seeds every generator (common/utils.py:23-39), so the construction order only matters for the net's own draw.
     cn = CostNet(env.obs_dim, env.act_dim, c["cn_layers"], discrete, None, None, c["clip_obs"],

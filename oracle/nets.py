@@ -30,31 +30,39 @@ class TwoCriticPolicy:
 
     BRANCHES = ("policy_net", "value_net", "cost_value_net")
 
-    def __init__(self, obs_dim, act_dim, hidden=(64, 64), discrete=False, log_std_init=0.0, ortho_init=True):
-        # hidden: one (h1, h2) for the three branches, or a dict branch -> (h1, h2) (net_arch pi / vf / cvf, icrl/utils.py:636-655)
+    def __init__(self, obs_dim, act_dim, hidden=(64, 64), discrete=False, log_std_init=0.0, ortho_init=True, shared=()):
+        # hidden: one width list for the three branches, or a dict branch -> width list of any length (net_arch pi / vf / cvf,
+        # icrl/utils.py:636-655); shared: widths of the trunk in front of the branches (-sl)
         widths = {b: tuple(hidden[b]) for b in self.BRANCHES} if isinstance(hidden, dict) else {b: tuple(hidden) for b in self.BRANCHES}
         self.obs_dim, self.act_dim, self.discrete = obs_dim, act_dim, discrete
         self.hidden = widths[self.BRANCHES[0]]
-        # construction order mirrors MlpExtractor's zip_longest loop (ref: torch_layers.py:208-226):
-        # layer k of pi, vf, cvf are created back to back, so the torch RNG stream matches.
+        self.widths, self.shared = widths, tuple(shared)
+        # construction order mirrors MlpExtractor (ref: torch_layers.py:183-226): the trunk first, then layer k of pi, vf, cvf back
+        # to back (zip_longest), so the torch RNG stream matches.
+        trunk, last_sh = [], obs_dim
+        for w in self.shared:
+            trunk.append(th.nn.Linear(last_sh, w)); last_sh = w
         lins = {b: [] for b in self.BRANCHES}
-        last = {b: obs_dim for b in self.BRANCHES}
-        for k in range(len(self.hidden)):
+        last = {b: last_sh for b in self.BRANCHES}
+        for k in range(max(len(v) for v in widths.values())):
             for b in self.BRANCHES:
-                lins[b].append(th.nn.Linear(last[b], widths[b][k]))
-                last[b] = widths[b][k]
+                if k < len(widths[b]):
+                    lins[b].append(th.nn.Linear(last[b], widths[b][k]))
+                    last[b] = widths[b][k]
         action_net = th.nn.Linear(last["policy_net"], act_dim)
         value_net = th.nn.Linear(last["value_net"], 1)
         cost_value_net = th.nn.Linear(last["cost_value_net"], 1)
-        if ortho_init:  # ref: policies.py:697-711 — gains sqrt(2) / 0.01 / 1 / 1, biases zero
-            for b in self.BRANCHES:
-                for lin in lins[b]:
-                    th.nn.init.orthogonal_(lin.weight, gain=math.sqrt(2)); lin.bias.data.fill_(0.0)
+        if ortho_init:  # ref: policies.py:697-711 — gains sqrt(2) / 0.01 / 1 / 1, biases zero; module.apply order
+            for lin in trunk + [lin for b in self.BRANCHES for lin in lins[b]]:
+                th.nn.init.orthogonal_(lin.weight, gain=math.sqrt(2)); lin.bias.data.fill_(0.0)
             for lin, g in ((action_net, 0.01), (value_net, 1.0), (cost_value_net, 1.0)):
                 th.nn.init.orthogonal_(lin.weight, gain=g); lin.bias.data.fill_(0.0)
         p = OrderedDict()
         if not discrete:
             p["log_std"] = th.ones(act_dim) * log_std_init
+        for k, lin in enumerate(trunk):
+            p[f"mlp_extractor.shared_net.{2 * k}.weight"] = lin.weight.data.clone()
+            p[f"mlp_extractor.shared_net.{2 * k}.bias"] = lin.bias.data.clone()
         for b in self.BRANCHES:
             for k, lin in enumerate(lins[b]):
                 p[f"mlp_extractor.{b}.{2 * k}.weight"] = lin.weight.data.clone()
@@ -76,15 +84,16 @@ class TwoCriticPolicy:
         return list(self.params.values())
 
     # -- forward ---------------------------------------------------------------------------
-    def _branch(self, x, b):
-        for k in range(len(self.hidden)):
+    def _branch(self, x, b, depth):
+        for k in range(depth):
             x = th.tanh(F.linear(x, self.params[f"mlp_extractor.{b}.{2 * k}.weight"],
                                  self.params[f"mlp_extractor.{b}.{2 * k}.bias"]))
         return x
 
     def latents(self, obs):
         obs = obs.float()                                   # ref: preprocessing.py:61
-        return tuple(self._branch(obs, b) for b in self.BRANCHES)
+        shared_latent = self._branch(obs, "shared_net", len(self.shared))      # ref: torch_layers.py:245-254
+        return tuple(self._branch(shared_latent, b, len(self.widths[b])) for b in self.BRANCHES)
 
     def heads(self, obs):
         lp, lv, lc = self.latents(obs)

@@ -6,6 +6,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+if os.path.dirname(os.path.abspath(__file__)) not in sys.path:      # tests/helpers is importable as `helpers`
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/icrl_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert L.icrl_abi_version() == 101
+    assert L.icrl_abi_version() == 102
     assert L.icrl_cn_train_work_floats(521, 10000, 5000, 10) > 521 * 235
 
 
@@ -66,7 +66,7 @@ def test_struct_sizes_match_header_layout():
     from icrl_amd import structs as S
     assert ctypes.sizeof(S.EnvT) == 8 * 4 + 5 * 8
     assert ctypes.sizeof(S.NormT) == 4 * 4 + 6 * 8 + 7 * 8
-    assert ctypes.sizeof(S.PolicyT) == 6 * 4 + 2 * 8
+    assert ctypes.sizeof(S.PolicyT) == 6 * 4 + 3 * 8
     assert ctypes.sizeof(S.CostNetT) == 8 * 4 + 8 + 5 * 8 + 8 + 2 * 8
     assert ctypes.sizeof(S.BufferT) == 4 * 4 + 18 * 8
     assert ctypes.sizeof(S.AgentT) == 11 * 8

@@ -179,7 +179,11 @@ def test_cn_train_minibatch_default_stream_matches_oracle():
         assert np.allclose(v.numpy(), ref, rtol=3e-3, atol=3e-4), (k, np.abs(v.numpy() - ref).max())
 
 
-@pytest.mark.parametrize("kind,n", [("hc", 64), ("hc", 1000), ("ant", 333), ("narrow", 200), ("wide", 40), ("wide", 300)])
+from helpers.arches import ARCHES, oracle_arch_kwargs
+
+
+@pytest.mark.parametrize("kind,n", [("hc", 64), ("hc", 1000), ("ant", 333), ("narrow", 200), ("wide", 40), ("wide", 300),
+                                    ("trunk", 150), ("deep", 70), ("trunk-only", 33), ("bare", 20)])
 def test_policy_rows_kernel_vs_oracle(kind, n):
     """policy_rows_kernel (>= 64 rows: 16 rows per workgroup pass as fp32 MFMA tiles; the KL metrics' evaluate_actions and batched
     predict) against the oracle's ActorTwoCriticsPolicy.evaluate_actions / forward directly (policies.py:716-731, 752-767;
@@ -192,10 +196,12 @@ def test_policy_rows_kernel_vs_oracle(kind, n):
     arch = dict(pi=[40, 24], vf=[64, 20], cvf=[16, 64]) if kind == "narrow" else None
     if kind == "wide":      # layers above 64: policy_generic_kernel (csrc/generic.hip)
         arch = dict(pi=[128, 100], vf=[72, 128], cvf=[200, 256])
-    kw = dict(net_arch=[arch]) if arch else {}
+    net_arch = ARCHES.get(kind, [arch] if arch else None)      # (ARCHES: the table-driven generic kernel with an `arch` descriptor)
+    kw = dict(net_arch=net_arch) if net_arch else {}
     pol = ActorTwoCriticsPolicy(spaces.Box(-np.inf, np.inf, (od,), np.float64), spaces.Box(-1, 1, (ad,), np.float32), **kw)
-    assert pol.wide == (kind == "wide")
-    op = o_nets.TwoCriticPolicy(od, ad, **({"hidden": dict(policy_net=arch["pi"], value_net=arch["vf"], cost_value_net=arch["cvf"])} if arch else {}))
+    assert pol.wide == (kind == "wide" or kind in ARCHES) and (pol.kind == "arch") == (kind in ARCHES)
+    op = o_nets.TwoCriticPolicy(od, ad, **(oracle_arch_kwargs(net_arch) if net_arch else {}))
+    assert list(op.params) == list(pol.shapes) and all(tuple(op.params[k].shape) == pol.shapes[k] or pol.kind != "arch" for k in op.params)
     op.load_state_dict(pol.state_dict())
     rng = np.random.RandomState(9)
     obs = (rng.randn(n, od) * 2.0).astype(np.float32)

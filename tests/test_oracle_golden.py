@@ -76,11 +76,16 @@ def test_g3_vecnormalize_stream(golden):
 G13_WIDTHS = dict(policy_net=(32, 48), value_net=(64, 32), cost_value_net=(16, 64))      # oracle/gen_golden.py: g13_widths
 
 
-@pytest.mark.parametrize("name,hidden", [("g4_ppo_minibatch", (64, 64)), ("g13_widths", G13_WIDTHS)])
+G17 = dict(hidden=dict(policy_net=(64, 32, 32), value_net=(40,), cost_value_net=()), shared=(48,))      # gen_golden.py: g17_trunk
+G18 = dict(hidden=dict(policy_net=(32,), value_net=(64, 64, 64), cost_value_net=(96, 200, 64, 16)))     # gen_golden.py: g18_deep
+
+
+@pytest.mark.parametrize("name,hidden", [("g4_ppo_minibatch", (64, 64)), ("g13_widths", G13_WIDTHS), ("g17_trunk", G17), ("g18_deep", G18)])
 def test_g4_ppo_minibatch(golden, name, hidden):
-    """3 optimiser steps of the reference's own policy / optimizer objects; g13: widths other than 64, different per branch."""
+    """3 optimiser steps of the reference's own policy / optimizer objects; g13: widths other than 64, different per branch;
+    g17: a shared trunk and branches of 3 / 1 / 0 layers; g18: branches of 1 / 3 / 4 layers (torch_layers.py:129-254)."""
     g = golden(name)
-    pol = o_nets.TwoCriticPolicy(18, 6, hidden=hidden)
+    pol = o_nets.TwoCriticPolicy(18, 6, **(hidden if isinstance(hidden, dict) and "hidden" in hidden else dict(hidden=hidden)))
     pol.load_state_dict(_sub(g, "w0/"))
     opt = th.optim.Adam(pol.parameters(), lr=float(g["lr"]), eps=1e-5)
     t = lambda k: th.as_tensor(g[k])

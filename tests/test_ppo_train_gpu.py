@@ -31,19 +31,22 @@ def _fill(agent, buf):
 
 G13_ARCH = dict(pi=[32, 48], vf=[64, 32], cvf=[16, 64])          # oracle/gen_golden.py: g13_widths
 G15_ARCH = dict(pi=[128, 128], vf=[96, 128], cvf=[128, 80])      # oracle/gen_golden.py: g15_wide (generic-shape path)
+G17_ARCH = [48, dict(pi=[64, 32, 32], vf=[40], cvf=[])]          # oracle/gen_golden.py: g17_trunk (generic-shape path, `arch` descriptor)
+G18_ARCH = [dict(pi=[32], vf=[64, 64, 64], cvf=[96, 200, 64, 16])]      # oracle/gen_golden.py: g18_deep
 
 
 @pytest.mark.parametrize("name,arch", [("g4_ppo_minibatch", None), ("g13_widths", G13_ARCH), ("g14_batch256", None),
-                                       ("g15_wide", G15_ARCH), ("g16_batch512", None)])
+                                       ("g15_wide", G15_ARCH), ("g16_batch512", None), ("g17_trunk", G17_ARCH), ("g18_deep", G18_ARCH)])
 def test_three_steps_on_one_batch_golden(golden, name, arch):
     """tests/golden/g4: the reference's own policy/optimizer objects stepped 3x on one 64-row batch.  g13: the same with
     -pl 32 48 -rvl 64 32 -cvl 16 64 (narrower layers run zero-padded to the kernels' 64; state dicts keep the logical shapes).
     g14: one 256-row batch (four chunks per minibatch).  g15: -pl 128 128 -rvl 96 128 -cvl 128 80 and g16: one 512-row batch — the
     shapes the persistent kernels do not serve run on the generic-shape path (csrc/generic.hip; icrl/utils.py:636-655,
-    common/buffers.py:594-612)."""
+    common/buffers.py:594-612).  g17: -sl 48 -pl 64 32 32 -rvl 40 -cvl (shared trunk, 3 / 1 / 0 layers) and g18: -pl 32 -rvl 64 64 64
+    -cvl 96 200 64 16 — architectures described by icrl_policy_t.arch (torch_layers.py:129-254)."""
     g = golden(name)
     B = int(g["obs"].shape[0])
-    kw = {} if arch is None else dict(policy_kwargs=dict(net_arch=[dict(arch)]))
+    kw = {} if arch is None else dict(policy_kwargs=dict(net_arch=[dict(arch)] if isinstance(arch, dict) else arch))
     agent = _agent("hc", 1, B, batch_size=B, n_epochs=3, target_kl=None, learning_rate=float(g["lr"]), **kw)
     agent.policy.load_state_dict(_sub(g, "w0/"))
     assert {k: tuple(v.shape) for k, v in agent.policy.state_dict().items()} == {k: g["w0/" + k].shape for k in agent.policy.shapes}
@@ -85,15 +88,15 @@ def test_three_steps_on_one_batch_golden(golden, name, arch):
                 assert float(full.abs().max()) == 0.0, k
                 off += n
         osd = pol.optimizer_state_dict(lr=3e-4)
-        assert tuple(osd["state"][1]["exp_avg"].shape) == g["w0/mlp_extractor.policy_net.0.weight"].shape
+        assert tuple(osd["state"][1]["exp_avg"].shape) == g["w0/" + list(pol.shapes)[1]].shape      # (logical shape of the first weight)
 
 
 ADAM_DEV_BOUND = 5e-4      # 3 x the largest deviation measured on MI355X (1.7e-4 x lr x steps; absolute: <= 9e-8, ~1 ulp)
 
 
-def _oracle_train(agent_sd, buf, perms, kind, nu, hidden=None, **h):
+def _oracle_train(agent_sd, buf, perms, kind, nu, okw=None, **h):
     od, ad = (18, 6) if kind == "hc" else (113, 8)
-    pol = o_nets.TwoCriticPolicy(od, ad, **({} if hidden is None else dict(hidden=hidden)))
+    pol = o_nets.TwoCriticPolicy(od, ad, **(okw or {}))
     pol.load_state_dict(agent_sd)
     opt = torch.optim.Adam(pol.parameters(), lr=h.pop("lr"), eps=1e-5)
     out = o_ppo.ppo_lag_train(pol, opt, buf, perms, nu, **h)
@@ -116,22 +119,26 @@ def _oracle_train(agent_sd, buf, perms, kind, nu, hidden=None, **h):
                                              ("hc", 8, 256, 192, 3, None),     # 33 steps x 3 chunks
                                              # generic-shape path: layers wider than 64 / minibatches above 256 rows
                                              ("hc-wide", 8, 32, 64, 3, None), ("ant-wide", 6, 40, 128, 2, None), ("hc-wide", 16, 32, 64, 6, 0.002),
-                                             ("hc", 8, 128, 512, 3, None), ("hc", 5, 200, 300, 2, None)])      # 1000 rows: 300 + 300 + 300 + 100
+                                             ("hc", 8, 128, 512, 3, None), ("hc", 5, 200, 300, 2, None),      # 1000 rows: 300 + 300 + 300 + 100
+                                             # architectures beyond three two-layer branches (-sl trunk, other depths; torch_layers.py:129-254)
+                                             ("hc-trunk", 8, 32, 64, 3, None), ("ant-deep", 6, 40, 128, 2, None), ("hc-trunk-only", 5, 40, 100, 2, None),
+                                             ("hc-bare", 4, 30, 40, 2, None), ("hc-deep", 16, 32, 64, 6, 0.002), ("ant-trunk", 4, 100, 400, 2, None)])
 def test_train_vs_oracle(kind, N, T, B, E, tk, one_workgroup_per_network=False):
+    from helpers.arches import ARCHES, oracle_arch_kwargs
     rng = np.random.RandomState(N * T)
-    wide = kind.endswith("-wide")
-    kind = kind.split("-")[0]
-    arch = dict(pi=[128, 96], vf=[80, 128], cvf=[128, 128]) if wide else None
+    kind, _, shape = kind.partition("-")
+    net_arch = [dict(pi=[128, 96], vf=[80, 128], cvf=[128, 128])] if shape == "wide" else ARCHES.get(shape)
+    wide = net_arch is not None
     od, ad = (18, 6) if kind == "hc" else (113, 8)
     lr = 3e-4 if kind == "hc" else 3e-5
-    akw = dict(policy_kwargs=dict(net_arch=[dict(arch)])) if wide else {}
+    akw = dict(policy_kwargs=dict(net_arch=net_arch)) if wide else {}
     agent = _agent(kind, N, T, batch_size=B, n_epochs=E, target_kl=tk, learning_rate=lr, clip_range=0.2, **akw)
     if one_workgroup_per_network:
         agent.train_kernel = "rows1"
     sd0 = agent.policy.state_dict()
     obs = rng.randn(T, N, od).astype(np.float32)
     # old log-probs from the current policy on sampled actions so that ratios start near 1 (as in a real rollout)
-    okw = dict(hidden=dict(policy_net=arch["pi"], value_net=arch["vf"], cost_value_net=arch["cvf"])) if wide else {}
+    okw = oracle_arch_kwargs(net_arch) if wide else {}
     op = o_nets.TwoCriticPolicy(od, ad, **okw); op.load_state_dict(sd0)
     with torch.no_grad():
         a, vr, vc, lp = op.forward(torch.as_tensor(obs.reshape(-1, od)))
@@ -144,7 +151,7 @@ def test_train_vs_oracle(kind, N, T, B, E, tk, one_workgroup_per_network=False):
     perms = np.stack([rng.permutation(T * N) for _ in range(E)])
     nu = agent.dual.nu().item()
     agent.train(perms=perms)
-    pol, out = _oracle_train(sd0, buf, perms, kind, nu, lr=lr, batch_size=B, n_epochs=E, clip_range=0.2, target_kl=tk, **({"hidden": okw["hidden"]} if wide else {}))
+    pol, out = _oracle_train(sd0, buf, perms, kind, nu, lr=lr, batch_size=B, n_epochs=E, clip_range=0.2, target_kl=tk, okw=okw)
     from icrl_amd import logger
     lg = logger.Logger.CURRENT.name_to_value
     assert lg["train/early_stop_epoch"] == out["train/early_stop_epoch"]
