@@ -94,9 +94,12 @@ def test_learn_matches_reference_golden(golden):
 
 @pytest.mark.parametrize("O,A,N,T,B,E,ent,wide", [(18, 5, 8, 32, 64, 3, 0.01, False), (1, 2, 4, 40, 64, 2, 0.0, False), (40, 16, 8, 16, 128, 2, 0.05, False),
                                                   # the Categorical branch of the generic-shape path (csrc/generic.hip): layers above 64 / a 320-row batch
-                                                  (18, 5, 8, 32, 64, 3, 0.01, True), (1, 2, 8, 80, 320, 2, 0.02, False)])
+                                                  (18, 5, 8, 32, 64, 3, 0.01, True), (1, 2, 8, 80, 320, 2, 0.02, False),
+                                                  # ... and of a policy with a shared trunk / other depths (icrl_policy_t.arch)
+                                                  (18, 5, 8, 32, 64, 3, 0.01, "trunk"), (7, 3, 4, 50, 100, 2, 0.03, "deep")])
 def test_categorical_update_vs_oracle(O, A, N, T, B, E, ent, wide):
     """the Categorical branch of the update kernel at other widths (up to 16 classes) against the oracle epoch loop."""
+    from helpers.arches import ARCHES, oracle_arch_kwargs
     from icrl_amd import logger, spaces
     from icrl_amd.ppo_lag import PPOLagrangian
     from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
@@ -105,11 +108,12 @@ def test_categorical_update_vs_oracle(O, A, N, T, B, E, ent, wide):
     senv.observation_space = spaces.Box(-np.inf, np.inf, (O,), np.float64)
     senv.action_space = spaces.Discrete(A)
     env = VecNormalizeWithCost(VecCostWrapper(senv))
-    akw = dict(policy_kwargs=dict(net_arch=[dict(pi=[128, 72], vf=[100, 128], cvf=[128, 128])])) if wide else {}
+    net_arch = ARCHES[wide] if isinstance(wide, str) else [dict(pi=[128, 72], vf=[100, 128], cvf=[128, 128])]
+    akw = dict(policy_kwargs=dict(net_arch=net_arch)) if wide else {}
     agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=0, batch_size=B, n_epochs=E, target_kl=None, ent_coef=ent, **akw)
     sd0 = agent.policy.state_dict()
-    assert "log_std" not in sd0 and agent.policy.wide == wide
-    okw = dict(hidden=dict(policy_net=(128, 72), value_net=(100, 128), cost_value_net=(128, 128))) if wide else {}
+    assert "log_std" not in sd0 and agent.policy.wide == bool(wide)
+    okw = oracle_arch_kwargs(net_arch) if wide else {}
     op = o_nets.TwoCriticPolicy(O, A, discrete=True, **okw)
     op.load_state_dict(sd0)
     obs = rng.randn(T, N, O).astype(np.float32)
