@@ -22,33 +22,49 @@ constexpr int CN_ROWS = 64;
 constexpr int CN_TH = 256;
 constexpr int CN_NPART = 16;   // statistics per block
 
+constexpr int CN_MAX_LAYERS = 4;   // hidden layers (icrl_costnet_t: h1 .. h4)
+
 struct CnDims {
-  int D, nh, H1, H2, HL;       // input, hidden layers, widths, width of the last hidden layer
-  int W0, b0, W1, b1, Wo, bo, n_params;
+  int D, nh, H[CN_MAX_LAYERS], HL;     // input, hidden layers, their widths, width of the last hidden layer
+  int W[CN_MAX_LAYERS], b[CN_MAX_LAYERS], Wo, bo, n_params;      // state_dict order: W0 b0 W1 b1 ... Wo bo
   int wglobal;                 // 1: the weights stay in device memory (wide nets: the 64-row activation images alone fill the LDS)
-  // LDS offsets (floats)
-  int sW, sX, sH1, sH2, sD1, sD2, sZ, total;
+  // LDS offsets (floats): weights, input image, one activation image per layer, TWO gradient images used alternately (layer l writes
+  // sD[l & 1]; the parameter gradients of a layer are formed before its image is reused), logits / logit gradients
+  int sW, sX, sH[CN_MAX_LAYERS], sD[2], sZ, total;
 };
 
 constexpr int CN_LDS_FLOATS = 160 * 1024 / 4;
 
-__host__ __device__ inline CnDims make_cn_dims(int D, int nh, int H1, int H2) {
+__host__ __device__ inline CnDims make_cn_dims(int D, int nh, const int* H) {
   CnDims d;
-  CnLayout L = make_cn_layout(D, nh, H1, H2);
-  d.D = D; d.nh = nh; d.H1 = H1; d.H2 = (nh == 2 ? H2 : 0); d.HL = L.H2;
-  d.W0 = L.W0; d.b0 = L.b0; d.W1 = L.W1; d.b1 = L.b1; d.Wo = L.Wo; d.bo = L.bo; d.n_params = L.n;
-  const int act = CN_ROWS * (D + 1) + 2 * CN_ROWS * (H1 + 1) + (nh == 2 ? 2 * CN_ROWS * (H2 + 1) : 0) + 2 * CN_ROWS;
-  d.wglobal = (L.n + act > CN_LDS_FLOATS) ? 1 : 0;      // the reference's widths (<= 64) keep their weights in LDS as before
-  int off = 0;
-  d.sW = off; off += d.wglobal ? 0 : L.n;
+  d.D = D; d.nh = nh;
+  int off = 0, last = D, hmax = 0, hsum = 0;
+  for (int l = 0; l < CN_MAX_LAYERS; ++l) {
+    d.H[l] = l < nh ? H[l] : 0;
+    d.W[l] = off; d.b[l] = off;
+    if (l < nh) { d.b[l] = off + H[l] * last; off = d.b[l] + H[l]; last = H[l]; hsum += H[l] + 1; if (H[l] > hmax) hmax = H[l]; }
+  }
+  d.HL = last;
+  d.Wo = off; off += last;
+  d.bo = off; off += 1;
+  d.n_params = off;
+  const int act = CN_ROWS * (D + 1) + CN_ROWS * hsum + 2 * CN_ROWS * (hmax + 1) + 2 * CN_ROWS;
+  d.wglobal = (d.n_params + act > CN_LDS_FLOATS) ? 1 : 0;      // the reference's widths (<= 64) keep their weights in LDS
+  off = 0;
+  d.sW = off; off += d.wglobal ? 0 : d.n_params;
   d.sX = off; off += CN_ROWS * (D + 1);
-  d.sH1 = off; off += CN_ROWS * (H1 + 1);
-  d.sH2 = off; off += (nh == 2 ? CN_ROWS * (H2 + 1) : 0);
-  d.sD1 = off; off += CN_ROWS * (H1 + 1);
-  d.sD2 = off; off += (nh == 2 ? CN_ROWS * (H2 + 1) : 0);
+  for (int l = 0; l < CN_MAX_LAYERS; ++l) { d.sH[l] = off; off += l < nh ? CN_ROWS * (H[l] + 1) : 0; }
+  d.sD[0] = off; off += CN_ROWS * (hmax + 1);
+  d.sD[1] = off; off += CN_ROWS * (hmax + 1);
   d.sZ = off; off += 2 * CN_ROWS;
   d.total = off;
   return d;
+}
+
+// hidden widths of a descriptor as an array; 0 when the layer count is outside 1..CN_MAX_LAYERS
+__host__ __device__ inline int cn_widths(const icrl_costnet_t& cn, int* H) {
+  H[0] = cn.h1; H[1] = cn.h2; H[2] = cn.h3; H[3] = cn.h4;
+  return cn.n_hidden >= 1 && cn.n_hidden <= CN_MAX_LAYERS;
 }
 
 // scalars shared between the kernels of one train() call (device floats in `work`)
@@ -105,30 +121,22 @@ __device__ __forceinline__ void cn_block_mlp(const CnDims& d, float* sm, const f
     for (int i = tid; i < d.n_params; i += CN_TH) sm[d.sW + i] = params[i];
   __syncthreads();
   const float* W = d.wglobal ? params : sm + d.sW;
-  const float* x = sm + d.sX + row * (D + 1);
-  float* h1 = sm + d.sH1 + row * (d.H1 + 1);
-  for (int j = part; j < d.H1; j += 4) {
-    float acc = 0.f;
-    const float* wr = W + d.W0 + j * D;
-    for (int k = 0; k < D; ++k) acc = fmaf(x[k], wr[k], acc);
-    h1[j] = fmaxf(acc + W[d.b0 + j], 0.f);
-  }
-  __syncthreads();
-  const float* hl = h1;
-  if (d.nh == 2) {
-    float* h2 = sm + d.sH2 + row * (d.H2 + 1);
-    for (int j = part; j < d.H2; j += 4) {
+  const float* in = sm + d.sX + row * (D + 1);
+  int n_in = D;
+  for (int l = 0; l < d.nh; ++l) {
+    float* h = sm + d.sH[l] + row * (d.H[l] + 1);
+    for (int j = part; j < d.H[l]; j += 4) {
       float acc = 0.f;
-      const float* wr = W + d.W1 + j * d.H1;
-      for (int k = 0; k < d.H1; ++k) acc = fmaf(h1[k], wr[k], acc);
-      h2[j] = fmaxf(acc + W[d.b1 + j], 0.f);
+      const float* wr = W + d.W[l] + j * n_in;
+      for (int k = 0; k < n_in; ++k) acc = fmaf(in[k], wr[k], acc);
+      h[j] = fmaxf(acc + W[d.b[l] + j], 0.f);
     }
     __syncthreads();
-    hl = h2;
+    in = h; n_in = d.H[l];
   }
   if (part == 0) {
     float acc = 0.f;
-    for (int j = 0; j < d.HL; ++j) acc = fmaf(hl[j], W[d.Wo + j], acc);
+    for (int j = 0; j < d.HL; ++j) acc = fmaf(in[j], W[d.Wo + j], acc);
     const float z = acc + W[d.bo];
     sm[d.sZ + row] = 1.f / (1.f + expf(-z));
   }
@@ -404,48 +412,47 @@ __device__ __forceinline__ void cn_backward_body(const CnTrainArgs& a, int itr) 
   }
   __syncthreads();
   const float dz = sm[d.sZ + CN_ROWS + row];
-  // ---- back through the last hidden layer (and the first, when there are two)
-  const float* h1 = sm + d.sH1 + row * (d.H1 + 1);
-  float* d1 = sm + d.sD1 + row * (d.H1 + 1);
-  if (d.nh == 2) {
-    const float* h2 = sm + d.sH2 + row * (d.H2 + 1);
-    float* d2 = sm + d.sD2 + row * (d.H2 + 1);
-    for (int j = part; j < d.H2; j += 4) d2[j] = h2[j] > 0.f ? dz * W[d.Wo + j] : 0.f;
-    __syncthreads();
-    for (int k = part; k < d.H1; k += 4) {
-      float acc = 0.f;
-      for (int j = 0; j < d.H2; ++j) acc = fmaf(d2[j], W[d.W1 + j * d.H1 + k], acc);
-      d1[k] = h1[k] > 0.f ? acc : 0.f;
-    }
-  } else {
-    for (int j = part; j < d.H1; j += 4) d1[j] = h1[j] > 0.f ? dz * W[d.Wo + j] : 0.f;
-  }
-  __syncthreads();
-  // ---- per-block parameter gradients: one thread per parameter, rows added in order
   float* gp = a.gpart + (size_t)blk * d.n_params;
-  const int D = d.D;
-  for (int p = tid; p < d.n_params; p += CN_TH) {
-    float acc = 0.f;
-    if (p < d.b0) {                                   // W0[j][k]
-      const int j = p / D, k = p % D;
-      for (int rr = 0; rr < CN_ROWS; ++rr) acc = fmaf(sm[d.sD1 + rr * (d.H1 + 1) + j], sm[d.sX + rr * (D + 1) + k], acc);
-    } else if (p < d.b0 + d.H1) {                     // b0[j]
-      const int j = p - d.b0;
-      for (int rr = 0; rr < CN_ROWS; ++rr) acc += sm[d.sD1 + rr * (d.H1 + 1) + j];
-    } else if (d.nh == 2 && p < d.b1) {               // W1[j][k]
-      const int q = p - d.W1, j = q / d.H1, k = q % d.H1;
-      for (int rr = 0; rr < CN_ROWS; ++rr) acc = fmaf(sm[d.sD2 + rr * (d.H2 + 1) + j], sm[d.sH1 + rr * (d.H1 + 1) + k], acc);
-    } else if (d.nh == 2 && p < d.b1 + d.H2) {        // b1[j]
-      const int j = p - d.b1;
-      for (int rr = 0; rr < CN_ROWS; ++rr) acc += sm[d.sD2 + rr * (d.H2 + 1) + j];
-    } else if (p < d.bo) {                            // Wo[j]
-      const int j = p - d.Wo;
-      const int hb = d.nh == 2 ? d.sH2 : d.sH1, hs = d.HL + 1;
-      for (int rr = 0; rr < CN_ROWS; ++rr) acc = fmaf(sm[d.sZ + CN_ROWS + rr], sm[hb + rr * hs + j], acc);
-    } else {                                          // bo
-      for (int rr = 0; rr < CN_ROWS; ++rr) acc += sm[d.sZ + CN_ROWS + rr];
+  // ---- per-block parameter gradients: one thread per parameter, rows added in order.  Output layer first (logit gradients x last
+  // hidden image), then layer by layer from the top: the layer's pre-activation gradients, then the gradients of its parameters
+  {
+    const int hb = d.sH[d.nh - 1], hs = d.HL + 1;
+    for (int p = tid; p < d.HL + 1; p += CN_TH) {
+      float acc = 0.f;
+      if (p < d.HL) { for (int rr = 0; rr < CN_ROWS; ++rr) acc = fmaf(sm[d.sZ + CN_ROWS + rr], sm[hb + rr * hs + p], acc); }     // Wo[j]
+      else { for (int rr = 0; rr < CN_ROWS; ++rr) acc += sm[d.sZ + CN_ROWS + rr]; }                                            // bo
+      gp[d.Wo + p] = acc;
     }
-    gp[p] = acc;
+  }
+  for (int l = d.nh - 1; l >= 0; --l) {
+    const int Hl = d.H[l];
+    const float* h = sm + d.sH[l] + row * (Hl + 1);
+    float* dl = sm + d.sD[l & 1] + row * (Hl + 1);
+    if (l == d.nh - 1) {
+      for (int j = part; j < Hl; j += 4) dl[j] = h[j] > 0.f ? dz * W[d.Wo + j] : 0.f;
+    } else {
+      const int Hu = d.H[l + 1];
+      const float* du = sm + d.sD[(l + 1) & 1] + row * (Hu + 1);
+      for (int k = part; k < Hl; k += 4) {
+        float acc = 0.f;
+        for (int j = 0; j < Hu; ++j) acc = fmaf(du[j], W[d.W[l + 1] + j * Hl + k], acc);
+        dl[k] = h[k] > 0.f ? acc : 0.f;
+      }
+    }
+    __syncthreads();
+    const int n_in = l == 0 ? d.D : d.H[l - 1];
+    const int ib = l == 0 ? d.sX : d.sH[l - 1], is = n_in + 1, db = d.sD[l & 1], ds = Hl + 1;
+    for (int p = tid; p < Hl * n_in + Hl; p += CN_TH) {
+      float acc = 0.f;
+      if (p < Hl * n_in) {                              // W_l[j][k]
+        const int j = p / n_in, k = p % n_in;
+        for (int rr = 0; rr < CN_ROWS; ++rr) acc = fmaf(sm[db + rr * ds + j], sm[ib + rr * is + k], acc);
+      } else {                                          // b_l[j]
+        const int j = p - Hl * n_in;
+        for (int rr = 0; rr < CN_ROWS; ++rr) acc += sm[db + rr * ds + j];
+      }
+      gp[d.W[l] + p] = acc;
+    }
   }
 }
 
@@ -564,11 +571,27 @@ __global__ void __launch_bounds__(CN_TH) cn_cost_rows_kernel(icrl_costnet_t cn, 
   }
 }
 
+// descriptor -> CnDims + dynamic LDS bytes of the 64-row kernels; refuses (fail()) what they do not hold
+static int cn_dims_checked(const icrl_costnet_t* cn, const char* who, CnDims* d, size_t* lds) {
+  int H[CN_MAX_LAYERS];
+  if (!cn_widths(*cn, H) || cn->in_dim < 1) return fail("%s: %d hidden layers (1..%d), in_dim %d", who, cn->n_hidden, CN_MAX_LAYERS, cn->in_dim);
+  for (int l = 0; l < cn->n_hidden; ++l)
+    if (H[l] < 1) return fail("%s: hidden layer %d has %d units", who, l, H[l]);
+  *d = make_cn_dims(cn->in_dim, cn->n_hidden, H);
+  if (d->n_params != cn->n_params)
+    return fail("%s: n_params = %d but in_dim %d / hidden (%d, %d, %d, %d) x %d layers need %d", who, cn->n_params, cn->in_dim, cn->h1, cn->h2, cn->h3, cn->h4,
+                cn->n_hidden, d->n_params);
+  *lds = (size_t)d->total * sizeof(float);
+  if (*lds > 160 * 1024)
+    return fail("%s: the 64-row activation images of in_dim %d / hidden (%d, %d, %d, %d) x %d layers take %zu B of LDS, 160 KB available (e.g. 2 x 128, 3 x 96, "
+                "4 x 64 units fit)", who, cn->in_dim, cn->h1, cn->h2, cn->h3, cn->h4, cn->n_hidden, *lds);
+  return 0;
+}
+
 int launch_cn_cost_rows(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, int mode, hipStream_t s) {
-  if (cn->n_hidden < 1 || cn->n_hidden > 2 || cn->in_dim < 1) return fail("cost forward: %d hidden layers (1 or 2), in_dim %d", cn->n_hidden, cn->in_dim);
-  const CnDims d = make_cn_dims(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
-  const size_t lds = (size_t)d.total * sizeof(float);
-  if (lds > 160 * 1024) return fail("cost forward: %zu B of LDS needed for in_dim %d / hidden (%d, %d), 160 KB available", lds, cn->in_dim, cn->h1, cn->h2);
+  CnDims d;
+  size_t lds;
+  if (int e = cn_dims_checked(cn, "cost forward", &d, &lds)) return e;
   hipError_t e = hipFuncSetAttribute((const void*)cn_cost_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(cn_cost_rows_kernel, dim3((N + CN_ROWS - 1) / CN_ROWS), dim3(CN_TH), lds, s, *cn, d, obs, acs, N, out, mode);
@@ -610,14 +633,10 @@ extern "C" int icrl_cn_prepare(const icrl_costnet_t* cn, const double* obs, cons
 static int make_cn_train_args(const icrl_costnet_t* cn, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const float* nominal,
                               const float* expert, int Nn, int Ne, const int32_t* ep_offsets, const int32_t* row_episode, int n_ep,
                               const icrl_cn_hyper_t* hp, float* work, float* metrics, CnTrainArgs& a, size_t* lds_out) {
-  if (Nn <= 0 || Ne <= 0 || n_ep <= 0 || hp->iterations < 0 || cn->n_hidden < 1 || cn->n_hidden > 2)
-    return fail("icrl_cn_train: needs nominal rows (%d), expert rows (%d), episodes (%d) > 0, iterations (%d) >= 0 and 1 or 2 hidden layers (%d)",
-                Nn, Ne, n_ep, hp->iterations, cn->n_hidden);
-  a.d = make_cn_dims(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
-  if (a.d.n_params != cn->n_params)
-    return fail("constraint net: n_params = %d but in_dim %d / hidden (%d, %d) x %d layers need %d", cn->n_params, cn->in_dim, cn->h1, cn->h2, cn->n_hidden, a.d.n_params);
-  const size_t lds = (size_t)a.d.total * sizeof(float);
-  if (lds > 160 * 1024) return fail("constraint net update: %zu B of LDS needed for in_dim %d / hidden (%d, %d), 160 KB available", lds, cn->in_dim, cn->h1, cn->h2);
+  if (Nn <= 0 || Ne <= 0 || n_ep <= 0 || hp->iterations < 0)
+    return fail("icrl_cn_train: needs nominal rows (%d), expert rows (%d), episodes (%d) > 0 and iterations (%d) >= 0", Nn, Ne, n_ep, hp->iterations);
+  size_t lds;
+  if (int e = cn_dims_checked(cn, "icrl_cn_train", &a.d, &lds)) return e;
   *lds_out = lds;
   a.params = cn->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.nominal = nominal; a.expert = expert; a.Nn = Nn; a.Ne = Ne; a.n_ep = n_ep;
@@ -711,16 +730,12 @@ extern "C" int icrl_cn_train_minibatch(const icrl_costnet_t* cn, float* exp_avg,
                                        const int32_t* ep_offsets, const int32_t* row_episode, int n_ep,
                                        const icrl_cn_hyper_t* hp, const int32_t* perms, int batch_size, float* work,
                                        float* metrics, void* stream) {
-  if (Nn <= 0 || Ne <= 0 || n_ep <= 0 || hp->iterations < 0 || cn->n_hidden < 1 || cn->n_hidden > 2 || batch_size <= 0 ||
-      perms == nullptr)
-    return fail("icrl_cn_train_minibatch: needs nominal rows (%d), expert rows (%d), episodes (%d), batch_size (%d) > 0, iterations (%d) >= 0, "
-                "1 or 2 hidden layers (%d) and a permutation table", Nn, Ne, n_ep, batch_size, hp->iterations, cn->n_hidden);
+  if (Nn <= 0 || Ne <= 0 || n_ep <= 0 || hp->iterations < 0 || batch_size <= 0 || perms == nullptr)
+    return fail("icrl_cn_train_minibatch: needs nominal rows (%d), expert rows (%d), episodes (%d), batch_size (%d) > 0, iterations (%d) >= 0 "
+                "and a permutation table", Nn, Ne, n_ep, batch_size, hp->iterations);
   CnTrainArgs a;
-  a.d = make_cn_dims(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
-  if (a.d.n_params != cn->n_params)
-    return fail("constraint net: n_params = %d but in_dim %d / hidden (%d, %d) x %d layers need %d", cn->n_params, cn->in_dim, cn->h1, cn->h2, cn->n_hidden, a.d.n_params);
-  const size_t lds = (size_t)a.d.total * sizeof(float);
-  if (lds > 160 * 1024) return fail("constraint net update: %zu B of LDS needed for in_dim %d / hidden (%d, %d), 160 KB available", lds, cn->in_dim, cn->h1, cn->h2);
+  size_t lds;
+  if (int e = cn_dims_checked(cn, "icrl_cn_train_minibatch", &a.d, &lds)) return e;
   a.params = cn->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.nominal = nominal; a.expert = expert; a.Nn = Nn; a.Ne = Ne; a.n_ep = n_ep;
   a.nb_n = (Nn + CN_ROWS - 1) / CN_ROWS; a.nb_e = (Ne + CN_ROWS - 1) / CN_ROWS;

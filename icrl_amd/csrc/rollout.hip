@@ -2710,7 +2710,7 @@ static int bad_dims(const char* who, const icrl_policy_t* p) {
               p->obs_dim, MAX_OBS, p->act_dim, MAX_ACT, p->h1, p->h2, MAX_H, p->arch != nullptr ? ", an `arch` descriptor" : "");
 }
 static int bad_cn(const char* who, const icrl_costnet_t* cn) {
-  return fail("%s: constraint net in_dim %d (1..%d), %d hidden layers (1 or 2) of (%d, %d) (1..%d; wider nets: icrl_cost_mlp_forward / icrl_disc_reward / icrl_cn_train and the per-step rollout), obs_dim %d (<= %d), acs_dim %d (<= %d)", who,
+  return fail("%s: constraint net in_dim %d (1..%d), %d hidden layers (1 or 2) of (%d, %d) (1..%d; wider and deeper nets: icrl_cost_mlp_forward / icrl_disc_reward / icrl_cn_train and the per-step rollout), obs_dim %d (<= %d), acs_dim %d (<= %d)", who,
               cn->in_dim, MAX_CN_IN, cn->n_hidden, cn->h1, cn->h2, MAX_H, cn->obs_dim, MAX_OBS, cn->acs_dim, MAX_ACT);
 }
 
@@ -2728,6 +2728,7 @@ extern "C" int icrl_policy_prepare(const icrl_policy_t* p, void* stream) {
 }
 
 extern "C" int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream) {
+  if (cn->n_hidden > 2) return 0;      // served 64 rows per workgroup from `params` (cn_train.hip): no transposed copy
   if (!costnet_is_wide(cn) && !cn_ok(cn)) return bad_cn("icrl_costnet_prepare", cn);
   CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
   if (L.n != cn->n_params) return fail("icrl_costnet_prepare: n_params = %d, the layout needs %d", cn->n_params, L.n);

@@ -24,7 +24,7 @@ class PolicyT(C.Structure):
 
 
 class CostNetT(C.Structure):
-    _fields_ = [("obs_dim", i32), ("acs_dim", i32), ("in_dim", i32), ("n_hidden", i32), ("h1", i32), ("h2", i32),
+    _fields_ = [("obs_dim", i32), ("acs_dim", i32), ("in_dim", i32), ("n_hidden", i32), ("h1", i32), ("h2", i32), ("h3", i32), ("h4", i32),
                 ("is_discrete", i32), ("n_params", i32),
                 ("clip_obs", f64), ("select_dim", vp), ("action_low", vp), ("action_high", vp), ("obs_mean", vp),
                 ("obs_var", vp), ("eps", f64), ("params", vp), ("params_t", vp)]

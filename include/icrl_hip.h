@@ -95,11 +95,12 @@ typedef struct {
 } icrl_policy_t;
 
 /* ConstraintNet zeta_theta (icrl/constraint_net.py:14-130,258-299): ReLU MLP + sigmoid over
- * concat(clip(obs), clip(acs))[select_dim]; cost = 1 - zeta.  n_hidden in {1,2}; hidden widths up to 64 inside the fused rollouts,
- * up to 128 through icrl_cost_mlp_forward / icrl_disc_reward / icrl_cn_train* (64 rows per workgroup).  params flat in state_dict order:
- * W0[h1,in] b0[h1] (W1[h2,h1] b1[h2]) Wo[1,h] bo[1]. */
+ * concat(clip(obs), clip(acs))[select_dim]; cost = 1 - zeta.  n_hidden hidden layers of h1 .. h4 units (`-cl`, torch_layers.py:93-126):
+ * 1 or 2 layers of up to 64 units inside the fused rollouts; 1..4 layers through icrl_cost_mlp_forward / icrl_disc_reward /
+ * icrl_cn_train* (64 rows per workgroup) as long as the 64-row activation images fit the 160 KB LDS — e.g. 2 x 128, 3 x 96, 4 x 64 units
+ * (refused with the byte count otherwise).  params flat in state_dict order: W0[h1,in] b0[h1] (W1[h2,h1] b1[h2] ...) Wo[1,h] bo[1]. */
 typedef struct {
-  int32_t obs_dim, acs_dim, in_dim, n_hidden, h1, h2;
+  int32_t obs_dim, acs_dim, in_dim, n_hidden, h1, h2, h3, h4;
   int32_t is_discrete;  /* one-hot the action first */
   int32_t n_params;
   double clip_obs;           /* < 0: no clipping (what ConstraintNet.load builds, constraint_net.py:394-399) */

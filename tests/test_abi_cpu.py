@@ -67,7 +67,7 @@ def test_struct_sizes_match_header_layout():
     assert ctypes.sizeof(S.EnvT) == 8 * 4 + 5 * 8
     assert ctypes.sizeof(S.NormT) == 4 * 4 + 6 * 8 + 7 * 8
     assert ctypes.sizeof(S.PolicyT) == 6 * 4 + 3 * 8
-    assert ctypes.sizeof(S.CostNetT) == 8 * 4 + 8 + 5 * 8 + 8 + 2 * 8
+    assert ctypes.sizeof(S.CostNetT) == 10 * 4 + 8 + 5 * 8 + 8 + 2 * 8
     assert ctypes.sizeof(S.BufferT) == 4 * 4 + 18 * 8
     assert ctypes.sizeof(S.AgentT) == 11 * 8
     assert ctypes.sizeof(S.PpoHyperT) == 4 * 4 + 12 * 4

@@ -47,7 +47,11 @@ def test_cn_train_golden(golden, case):
                                                           # layers above 64 units (-cl 128 128 / -cl 100: create_mlp takes any width,
                                                           # torch_layers.py:93-126): weights read from device memory, 64 rows per workgroup
                                                           ("hc", [128, 128], True, 3000, 1500, 1000), ("ant", [128, 96], True, 1500, 900, 500),
-                                                          ("hc", [100], False, 400, 300, 100)])
+                                                          ("hc", [100], False, 400, 300, 100),
+                                                          # more than two hidden layers (-cl 64 64 64 ...): one activation image per layer
+                                                          # and two alternating gradient images in the LDS
+                                                          ("hc", [64, 64, 64], True, 3000, 1500, 1000), ("ant", [64, 48, 64, 32], True, 1500, 900, 500),
+                                                          ("hc", [96, 96, 96], False, 400, 300, 100), ("hc", [24, 20, 16, 12], True, 1000, 640, 500)])
 def test_cn_train_vs_oracle(kind, hidden, psis, Nn, Ne, eplen):
     from icrl_amd.constraint_net import ConstraintNet
     rng = np.random.RandomState(Nn)

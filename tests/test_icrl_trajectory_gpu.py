@@ -205,12 +205,14 @@ def test_icrl_hc_shared_trunk_two_iterations_vs_port(golden):
         assert torch.equal(torch.as_tensor(a0).cpu(), torch.as_tensor(a1).cpu())
 
 
-def test_icrl_hc_wide_constraint_net_two_iterations_vs_port(golden):
+@pytest.mark.parametrize("cl", [["128", "128"], ["48", "32", "24"]])
+def test_icrl_hc_wide_constraint_net_two_iterations_vs_port(golden, cl):
     """`-cl 128 128`: a constraint net with layers above 64 units — its cost inside per-step rollouts (the fused rollout's cost wave holds
-    64 units), cost_function and train() 64 rows per workgroup with the weights in device memory — through the unchanged outer loop."""
+    64 units), cost_function and train() 64 rows per workgroup with the weights in device memory — through the unchanged outer loop.
+    `-cl 48 32 24`: more than two hidden layers (create_mlp takes any depth, torch_layers.py:93-126), same route."""
     from icrl_amd.icrl import build_parser, setup, outer_iteration
     expert = os.path.join(HERE, "golden/expert_hc.npz")
-    argv = ["icrl", "-er", "2", "-ep", expert, "--expert_agent_path", expert, "-tk", "0.01", "-cl", "128", "128", "-bi", "10", "-ft", "2000",
+    argv = ["icrl", "-er", "2", "-ep", expert, "--expert_agent_path", expert, "-tk", "0.01", "-cl", *cl, "-bi", "10", "-ft", "2000",
             "-ni", "2", "-tei", "HCWithPos-v0", "-eei", "HCWithPosTest-v0", "-clr", "0.01", "-aclr", "0.9", "-crc", "0.5", "-psis",
             "-ctkno", "2.5", "-nt", "8", "--n_steps", "128", "-s", "3", "-v", "0"]
     cfg = vars(build_parser().parse_args(argv))
