@@ -16,7 +16,7 @@
 //   icrl_policy_forward / icrl_policy_evaluate      -> policy_generic_kernel            (policies.py:716-731, 752-767)
 //   icrl_ppo_lag_train                              -> per optimiser step: gen_stats | gen_forward_backward | gen_wgrad | gen_adam
 //                                                      (ppo_lag.py:196-299, torch.optim.Adam, clip_grad_norm_)
-// Only `params` is read (never the transposed copy: the update changes the weights between its own launches).
+// The forward reads the weights from `params_t` = the per-layer transposes (icrl_policy_prepare; the update keeps both images current).
 #include "ppo_common.h"
 
 namespace icrl {
@@ -115,7 +115,7 @@ struct GenCtl {      // first 64 floats of the generic scratch, zeroed at the st
 
 struct GenArgs {
   int B;                     // batch_size
-  float* params; float* exp_avg; float* exp_avg_sq;
+  float* params; float* params_t; float* exp_avg; float* exp_avg_sq;      // params_t: kept equal to the transposes of params by gen_adam_kernel
   const int* adam_t;
   icrl_buffer_t buf;
   const int* perm_off;       // [n_epochs * T*N] storage offsets (ppo_perm_offsets_kernel)
@@ -151,23 +151,51 @@ __device__ __forceinline__ int gen_my_layer(const GenNet& net, int stage, int sl
   return -1;
 }
 
-__device__ __forceinline__ void gen_mlp_forward(const GenNet& net, const float* __restrict__ P, const float* x, float* act, int slot, int j) {
+// PT: the per-layer transposes (gen_transpose_kernel): unit j reads Wt[k][j], consecutive units consecutive addresses — the row-major
+// W[j][k] costs one cache line per lane and load.  Same fmaf chain (k ascending from the bias) either way.
+__device__ __forceinline__ void gen_mlp_forward(const GenNet& net, const float* __restrict__ PT, const float* x, float* act, int slot, int j) {
   for (int s = 0; s < net.n_stages; ++s) {
     const int l = gen_my_layer(net, s, slot);
     if (l >= 0 && j < net.layer[l].out_dim) {
       const GenLayer& y = net.layer[l];
-      const float* w = P + y.w_off + (size_t)j * y.in_dim;
+      const float* wt = PT + y.w_off + j;
       const float* in = y.in_buf < 0 ? x : act + net.layer[y.in_buf].act_off;
-      float z = P[y.b_off + j];
-      for (int k = 0; k < y.in_dim; ++k) z = fmaf(w[k], in[k], z);
+      const int n_in = y.in_dim, n_out = y.out_dim;
+      float z = PT[y.b_off + j];
+      int k = 0;
+      for (; k + 8 <= n_in; k += 8) {
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = wt[(size_t)(k + u) * n_out];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) z = fmaf(w[u], in[k + u], z);
+      }
+      for (; k < n_in; ++k) z = fmaf(wt[(size_t)k * n_out], in[k], z);
       act[y.act_off + j] = y.tanh ? fast_tanh(z) : z;
     }
     __syncthreads();
   }
 }
 
+// position of parameter e in the transposed image: weights W[j][k] -> Wt[k][j] inside their layer's block, everything else in place
+__device__ __forceinline__ int gen_transposed_index(const GenNet& net, int e) {
+  for (int l = 0; l < net.n_layers; ++l) {
+    const GenLayer& y = net.layer[l];
+    if (e >= y.w_off && e < y.b_off) {
+      const int off = e - y.w_off, j = off / y.in_dim, k = off - j * y.in_dim;
+      return y.w_off + k * y.out_dim + j;
+    }
+  }
+  return e;
+}
+
+__global__ void __launch_bounds__(256) gen_transpose_kernel(GenNet net, const float* __restrict__ P, float* __restrict__ PT) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e < net.n) PT[gen_transposed_index(net, e)] = P[e];
+}
+
 // policies.py:716-731 (forward: sample / deterministic, clip, log-prob) and :752-767 (evaluate_actions: `given` actions, entropy)
-__global__ void __launch_bounds__(3 * GEN_MAX_H) policy_generic_kernel(GenNet net, const float* __restrict__ P, const double* __restrict__ obs,
+__global__ void __launch_bounds__(3 * GEN_MAX_H) policy_generic_kernel(GenNet net, const float* __restrict__ P, const float* __restrict__ PT, const double* __restrict__ obs,
                                                                         const float* __restrict__ noise, int deterministic, const float* alow,
                                                                         const float* ahigh, float* actions, float* act_clipped, float* v_r,
                                                                         float* v_c, float* log_prob, const float* __restrict__ given,
@@ -177,7 +205,7 @@ __global__ void __launch_bounds__(3 * GEN_MAX_H) policy_generic_kernel(GenNet ne
   const size_t n = blockIdx.x;
   for (int i = tid; i < net.O; i += blockDim.x) sh.x[i] = (float)obs[n * net.O + i];
   __syncthreads();
-  gen_mlp_forward(net, P, sh.x, sh.act, slot, j);
+  gen_mlp_forward(net, PT, sh.x, sh.act, slot, j);
   if (tid == 0) {
     const int A = net.A, AS = net.discrete ? 1 : A;
     const float* out = sh.act + net.layer[net.head[0]].act_off;
@@ -229,7 +257,8 @@ int launch_policy_generic(const icrl_policy_t* p, const double* obs, const float
                           const float* given, float* entropy, hipStream_t s) {
   GenNet net;
   if (int e = make_gen_net(p, &net, "policy forward / evaluate")) return e;
-  hipLaunchKernelGGL(policy_generic_kernel, dim3(N), dim3(3 * net.W), 0, s, net, p->params, obs, noise, deterministic, alow, ahigh, actions,
+  if (p->params_t == nullptr) return fail("policy forward / evaluate (generic path): params_t is NULL (icrl_policy_prepare fills it)");
+  hipLaunchKernelGGL(policy_generic_kernel, dim3(N), dim3(3 * net.W), 0, s, net, p->params, p->params_t, obs, noise, deterministic, alow, ahigh, actions,
                      act_clipped, v_r, v_c, log_prob, given, entropy);
   return (int)hipGetLastError();
 }
@@ -237,6 +266,15 @@ int launch_policy_generic(const icrl_policy_t* p, const double* obs, const float
 int policy_generic_check(const icrl_policy_t* p, const char* who) {
   GenNet net;
   return make_gen_net(p, &net, who);
+}
+
+// icrl_policy_prepare of a generic-path policy: params_t = the per-layer transposes the forward reads
+int launch_generic_transpose(const icrl_policy_t* p, hipStream_t s) {
+  GenNet net;
+  if (int e = make_gen_net(p, &net, "icrl_policy_prepare")) return e;
+  if (p->params_t == nullptr) return fail("icrl_policy_prepare: params_t is NULL");
+  hipLaunchKernelGGL(gen_transpose_kernel, dim3((net.n + 255) / 256), dim3(256), 0, s, net, p->params, p->params_t);
+  return (int)hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -281,7 +319,7 @@ __global__ void __launch_bounds__(3 * GEN_MAX_H) gen_forward_backward_kernel(Gen
   const int idx = a.perm_off[perm_base + row];
   for (int i = tid; i < net.O; i += blockDim.x) sh.x[i] = a.buf.observations[(size_t)idx * net.O + i];
   __syncthreads();
-  gen_mlp_forward(net, P, sh.x, sh.act, slot, j);
+  gen_mlp_forward(net, a.params_t, sh.x, sh.act, slot, j);
   if (j == 0) {      // one thread per slot: the loss terms of its head (pi | vf | cvf)
     const int role = slot;
     float* dout = dz + net.layer[net.head[role]].act_off;
@@ -359,7 +397,16 @@ __global__ void __launch_bounds__(3 * GEN_MAX_H) gen_forward_backward_kernel(Gen
         if (y.in_buf != l) continue;
         const float* w = P + y.w_off + j;
         const float* d = dz + y.act_off;
-        for (int i = 0; i < y.out_dim; ++i) t = fmaf(w[(size_t)i * y.in_dim], d[i], t);
+        const int n_o = y.out_dim, n_i = y.in_dim;
+        int i = 0;
+        for (; i + 8 <= n_o; i += 8) {      // (eight weights in flight before the eight dependent fmas; same chain order)
+          float wv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(i + u) * n_i];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) t = fmaf(wv[u], d[i + u], t);
+        }
+        for (; i < n_o; ++i) t = fmaf(w[(size_t)i * n_i], d[i], t);
       }
       const float h = sh.act[net.layer[l].act_off + j];
       dz[net.layer[l].act_off + j] = fmaf(-(h * h), t, t);
@@ -393,11 +440,40 @@ __global__ void __launch_bounds__(256) gen_wgrad_kernel(GenNet net, GenArgs a, i
       const float* DZ = a.scratch + gen_off_dz(B, RF) + y.act_off;
       if (e < y.b_off) {                       // W[j][k]: sum_rows dz[j] * input[k]
         const int off = e - y.w_off, j = off / y.in_dim, k = off - j * y.in_dim;
-        if (y.in_buf < 0) { for (int r = 0; r < nb; ++r) g = fmaf(DZ[(size_t)r * RF + j], a.buf.observations[(size_t)rowidx[r] * O + k], g); }
-        else { const float* in = ACT + net.layer[y.in_buf].act_off + k; for (int r = 0; r < nb; ++r) g = fmaf(DZ[(size_t)r * RF + j], in[(size_t)r * RF], g); }
+        // (eight rows' operands are fetched before the eight dependent fmas: the chain's order is the row order either way)
+        int r = 0;
+        if (y.in_buf < 0) {
+          const float* ob = a.buf.observations + k;
+          for (; r + 8 <= nb; r += 8) {
+            float d[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { d[u] = DZ[(size_t)(r + u) * RF + j]; x[u] = ob[(size_t)rowidx[r + u] * O]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g = fmaf(d[u], x[u], g);
+          }
+          for (; r < nb; ++r) g = fmaf(DZ[(size_t)r * RF + j], ob[(size_t)rowidx[r] * O], g);
+        } else {
+          const float* in = ACT + net.layer[y.in_buf].act_off + k;
+          for (; r + 8 <= nb; r += 8) {
+            float d[8], x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { d[u] = DZ[(size_t)(r + u) * RF + j]; x[u] = in[(size_t)(r + u) * RF]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) g = fmaf(d[u], x[u], g);
+          }
+          for (; r < nb; ++r) g = fmaf(DZ[(size_t)r * RF + j], in[(size_t)r * RF], g);
+        }
       } else {                                 // b[j]
         const int j = e - y.b_off;
-        for (int r = 0; r < nb; ++r) g += DZ[(size_t)r * RF + j];
+        int r = 0;
+        for (; r + 8 <= nb; r += 8) {
+          float d[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) d[u] = DZ[(size_t)(r + u) * RF + j];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) g += d[u];
+        }
+        for (; r < nb; ++r) g += DZ[(size_t)r * RF + j];
       }
     }
     a.scratch[gen_off_grad(B, RF) + e] = g;
@@ -406,22 +482,23 @@ __global__ void __launch_bounds__(256) gen_wgrad_kernel(GenNet net, GenArgs a, i
   if (threadIdx.x == 0) a.scratch[gen_off_part(B, RF, net.n) + blockIdx.x] = ss;
 }
 
-// clip_grad_norm_ + torch.optim.Adam (single-tensor form) on every parameter; block 0 keeps the statistics of the step
-__global__ void __launch_bounds__(256) gen_adam_kernel(GenArgs a, int n_params, int RF, int step, int epoch, int mb, int nb) {
-  __shared__ float coef_s;
+// clip_grad_norm_ + torch.optim.Adam (single-tensor form) on every parameter (both images: params and its per-layer transposes);
+// block 0 keeps the statistics of the step.  Sums are fixed trees over the block (block_sum): every block forms the same total.
+__global__ void __launch_bounds__(256) gen_adam_kernel(GenNet net, GenArgs a, int step, int epoch, int mb, int nb) {
+  __shared__ float red[256];
   GenCtl* ctl = reinterpret_cast<GenCtl*>(a.scratch);
   if (ctl->stop) return;
-  const int B = a.B, nblk = (n_params + 255) / 256;
-  if (threadIdx.x == 0) {
+  const int B = a.B, RF = net.row_floats, n_params = net.n, nblk = (n_params + 255) / 256, tid = threadIdx.x;
+  float coef;
+  {
     const float* part = a.scratch + gen_off_part(B, RF, n_params);
-    float total = 0.f;
-    for (int i = 0; i < nblk; ++i) total += part[i];          // fixed order: every block forms the same total
+    float p = 0.f;
+    for (int i = tid; i < nblk; i += 256) p += part[i];
+    const float total = block_sum(p, red);
     const float c = a.hp.max_grad_norm / (sqrtf(total) + 1e-6f);
-    coef_s = c > 1.f ? 1.f : c;
+    coef = c > 1.f ? 1.f : c;
   }
-  __syncthreads();
-  const float coef = coef_s;
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.x * 256 + tid;
   if (e < n_params) {
     const double t = (double)(a.adam_t[0] + step + 1);
     const float step_size = (float)((double)a.hp.lr / (1.0 - pow((double)a.hp.adam_beta1, t)));
@@ -431,31 +508,37 @@ __global__ void __launch_bounds__(256) gen_adam_kernel(GenArgs a, int n_params, 
     const float m = fmaf((float)(1.0 - (double)b1), g, b1 * a.exp_avg[e]);
     const float v = fmaf((float)(1.0 - (double)b2), g * g, b2 * a.exp_avg_sq[e]);
     a.exp_avg[e] = m; a.exp_avg_sq[e] = v;
-    a.params[e] = fmaf(-step_size, m / fmaf(sqrtf(v), inv_bc2_sqrt, a.hp.adam_eps), a.params[e]);
+    const float w = fmaf(-step_size, m / fmaf(sqrtf(v), inv_bc2_sqrt, a.hp.adam_eps), a.params[e]);
+    a.params[e] = w;
+    a.params_t[gen_transposed_index(net, e)] = w;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blockIdx.x == 0) {
     const float* rs = a.scratch + gen_off_rowstat();
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, s4 = 0.f, vr = 0.f, vc = 0.f;
-    for (int r = 0; r < nb; ++r) {
-      const float* q = rs + (size_t)r * 8;
-      s0 += q[0]; s1 += q[1]; s2 += q[2]; s3 += q[3]; s4 += q[4];
-      vr += rs[((size_t)B + r) * 8]; vc += rs[((size_t)2 * B + r) * 8];
+    float q[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = tid; r < nb; r += 256) {
+      const float* x = rs + (size_t)r * 8;
+      q[0] += x[0]; q[1] += x[1]; q[2] += x[2]; q[3] += x[3]; q[4] += x[4];
+      q[5] += rs[((size_t)B + r) * 8]; q[6] += rs[((size_t)2 * B + r) * 8];
     }
-    const float inv_nb = 1.f / (float)nb, nu = a.nu[0];
-    const float ent = s4 * inv_nb;        // continuous: every row carries the same sum over log_std
-    const float entropy_loss = -ent;
-    const float pl = (-(s0 * inv_nb) + nu * (s1 * inv_nb)) / (1.f + nu);
-    ctl->acc_ent += entropy_loss; ctl->acc_pg += pl; ctl->acc_cf += s2 * inv_nb;
-    ctl->acc_vl_r += vr * inv_nb; ctl->acc_vl_c += vc * inv_nb;
-    ctl->last_pol = pl + a.hp.ent_coef * entropy_loss; ctl->last_vl_r = vr * inv_nb; ctl->last_vl_c = vc * inv_nb;
-    if (mb == 0) ctl->kl_acc = 0.f;
-    ctl->kl_acc += s3 * inv_nb;
-    ctl->steps_done += 1;
-    if (mb == a.n_mb - 1) {
-      const float mean_kl = ctl->kl_acc / (float)a.n_mb;
-      ctl->mean_kl = mean_kl;
-      a.stats[32 + epoch] = mean_kl;
-      if (a.hp.use_target_kl && mean_kl > 1.5f * a.hp.target_kl) { ctl->stop = 1; ctl->early_stop_epoch = epoch; }
+    for (int i = 0; i < 7; ++i) q[i] = block_sum(q[i], red);
+    if (tid == 0) {
+      const float s0 = q[0], s1 = q[1], s2 = q[2], s3 = q[3], s4 = q[4], vr = q[5], vc = q[6];
+      const float inv_nb = 1.f / (float)nb, nu = a.nu[0];
+      const float ent = s4 * inv_nb;        // continuous: every row carries the same sum over log_std
+      const float entropy_loss = -ent;
+      const float pl = (-(s0 * inv_nb) + nu * (s1 * inv_nb)) / (1.f + nu);
+      ctl->acc_ent += entropy_loss; ctl->acc_pg += pl; ctl->acc_cf += s2 * inv_nb;
+      ctl->acc_vl_r += vr * inv_nb; ctl->acc_vl_c += vc * inv_nb;
+      ctl->last_pol = pl + a.hp.ent_coef * entropy_loss; ctl->last_vl_r = vr * inv_nb; ctl->last_vl_c = vc * inv_nb;
+      if (mb == 0) ctl->kl_acc = 0.f;
+      ctl->kl_acc += s3 * inv_nb;
+      ctl->steps_done += 1;
+      if (mb == a.n_mb - 1) {
+        const float mean_kl = ctl->kl_acc / (float)a.n_mb;
+        ctl->mean_kl = mean_kl;
+        a.stats[32 + epoch] = mean_kl;
+        if (a.hp.use_target_kl && mean_kl > 1.5f * a.hp.target_kl) { ctl->stop = 1; ctl->early_stop_epoch = epoch; }
+      }
     }
   }
 }
@@ -478,7 +561,8 @@ int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   if (int e = make_gen_net(pol, &net, "icrl_ppo_lag_train")) return e;
   GenArgs a;
   a.B = hp->batch_size;
-  a.params = pol->params; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
+  if (pol->params_t == nullptr) return fail("icrl_ppo_lag_train (generic path): params_t is NULL");
+  a.params = pol->params; a.params_t = pol->params_t; a.exp_avg = exp_avg; a.exp_avg_sq = exp_avg_sq; a.adam_t = adam_step;
   a.buf = *buf; a.perm_off = perm_off; a.nu = nu; a.hp = *hp; a.stats = stats; a.scratch = (float*)scratch;
   a.n_total = buf->T * buf->N;
   a.n_mb = (a.n_total + hp->batch_size - 1) / hp->batch_size;
@@ -486,6 +570,7 @@ int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   hipError_t e = hipMemsetAsync(scratch, 0, 64 * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   const int nblk = (net.n + 255) / 256;
+  hipLaunchKernelGGL(gen_transpose_kernel, dim3(nblk), dim3(256), 0, s, net, pol->params, pol->params_t);
   int step = 0;
   for (int ep = 0; ep < hp->n_epochs; ++ep)
     for (int mb = 0; mb < a.n_mb; ++mb, ++step) {
@@ -495,7 +580,7 @@ int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
       hipLaunchKernelGGL(gen_stats_kernel, dim3(1), dim3(256), 0, s, a, base, nb);
       hipLaunchKernelGGL(gen_forward_backward_kernel, dim3(nb), dim3(3 * net.W), 0, s, net, a, base, nb);
       hipLaunchKernelGGL(gen_wgrad_kernel, dim3(nblk), dim3(256), 0, s, net, a, nb);
-      hipLaunchKernelGGL(gen_adam_kernel, dim3(nblk), dim3(256), 0, s, a, net.n, net.row_floats, step, ep, mb, nb);
+      hipLaunchKernelGGL(gen_adam_kernel, dim3(nblk), dim3(256), 0, s, net, a, step, ep, mb, nb);
     }
   hipLaunchKernelGGL(gen_finish_kernel, dim3(1), dim3(1), 0, s, a, adam_step);
   return (int)hipGetLastError();

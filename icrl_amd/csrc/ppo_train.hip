@@ -1005,7 +1005,11 @@ static int train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   const long long n = (long long)hp->n_epochs * n_total;
   hipLaunchKernelGGL(ppo_perm_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perms, n, buf->T, buf->N, offs);
   char* scratch = (char*)sync_ws + ICRL_PPO_SYNC_BYTES(hp->n_epochs, n_mb, n_total);
-  return launch_train_generic(pol, exp_avg, exp_avg_sq, adam_step, buf, offs, nu, hp, stats, scratch, s);
+  const int err = launch_train_generic(pol, exp_avg, exp_avg_sq, adam_step, buf, offs, nu, hp, stats, scratch, s);
+  // the generic kernels keep THEIR transposed image in params_t; a policy the fast forward kernels serve (this call came here for its
+  // batch size) gets the image those kernels read back
+  if (err == 0 && !policy_is_wide(pol)) return icrl_policy_prepare(pol, (void*)s);
+  return err;
 }
 
 extern "C" int icrl_ppo_generic_row_floats(const icrl_policy_t* pol) { return generic_row_floats(pol); }

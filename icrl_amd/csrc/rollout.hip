@@ -476,6 +476,50 @@ __global__ void __launch_bounds__(256) act_step_kernel(ActStepArgs a, int t) {
   }
 }
 
+// act_step_kernel for policies / constraint nets the one-workgroup-per-env image does not hold (generic-shape path): the policy
+// forward (policy_generic_kernel: actions, values, log-probs straight into row t of the buffer, clipped actions into ag.act_clipped)
+// and the cost (cn_cost_rows_kernel: ag.raw_cost) have run as launches of their own on the same stream; this kernel is the rest
+// of the step for env n — env step, the pre-normaliser buffer fields, the values of this forward for the GAE bootstrap.  One wave.
+struct GenStepArgs {
+  icrl_env_t env;
+  icrl_buffer_t buf;
+  icrl_agent_t ag;
+  int has_cn;
+};
+
+__global__ void __launch_bounds__(64) act_step_generic_kernel(GenStepArgs a, int t) {
+  __shared__ double s_old[MAX_OBS], s_new[MAX_OBS];
+  __shared__ float act_clip[MAX_ACT];
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const int O = a.env.obs_dim, N = a.env.n_envs, AS = a.buf.act_store;
+  const uint32_t e_key = a.env.key[n];
+  uint32_t e_ctr = a.env.step_count[n];
+  int e_tep = a.env.t_ep[n];
+  const size_t tn = (size_t)t * N + n;
+  float* ob = a.buf.observations + tn * O;
+  float* oob = a.buf.orig_observations + tn * O;
+  for (int i = lane; i < O; i += WAVE) {
+    const double s = a.env.s[(size_t)n * O + i];
+    s_old[i] = s;
+    oob[i] = (float)s;
+    ob[i] = (float)a.ag.last_obs[(size_t)n * O + i];      // preprocess_obs: .float()
+  }
+  if (lane < AS) act_clip[lane] = a.ag.act_clipped[(size_t)n * AS + lane];
+  __syncthreads();
+  double rew; int done;
+  env_step_wave(a.env, n, s_old, act_clip, e_key, e_ctr, e_tep, s_new, rew, done);
+  float* nob = a.buf.new_orig_observations + tn * O;
+  for (int i = lane; i < O; i += WAVE) nob[i] = (float)s_new[i];
+  if (lane == 0) {
+    a.ag.raw_rew[n] = rew; a.ag.dones[n] = (uint8_t)done;
+    const float cost = a.has_cn ? a.ag.raw_cost[n] : 0.f;
+    a.ag.raw_cost[n] = cost; a.buf.orig_costs[tn] = cost;
+    a.buf.dones[tn] = (float)a.ag.last_dones[n];
+    a.ag.last_v_r[n] = a.buf.reward_values[tn];
+    a.ag.last_v_c[n] = a.buf.cost_values[tn];
+  }
+}
+
 // =================================================================================================================
 // kernel B: VecNormalizeWithCost.step_wait for all envs, one workgroup
 // =================================================================================================================
@@ -2719,8 +2763,8 @@ static int bad_cn(const char* who, const icrl_costnet_t* cn) {
 using namespace icrl;
 
 extern "C" int icrl_policy_prepare(const icrl_policy_t* p, void* stream) {
-  if (p->arch != nullptr) return policy_generic_check(p, "icrl_policy_prepare");      // no transposed copy: the generic path reads `params`
-  if (!policy_is_wide(p) && !dims_ok(p)) return bad_dims("icrl_policy_prepare", p);
+  if (policy_is_wide(p)) return launch_generic_transpose(p, (hipStream_t)stream);      // generic-shape path: per-layer transposes (generic.hip)
+  if (!dims_ok(p)) return bad_dims("icrl_policy_prepare", p);
   PolLayout L = make_pol_layout(p->obs_dim, p->act_dim, p->h1, p->h2, p->discrete);
   if (L.n != p->n_params) return fail("icrl_policy_prepare: n_params = %d, the layout needs %d", p->n_params, L.n);
   hipLaunchKernelGGL(policy_transpose_kernel, dim3((L.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, L, p->params, p->params_t);
@@ -2985,14 +3029,49 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
                                        double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
                                        int do_gae, void* stream) {
   const int N = env->n_envs, O = env->obs_dim, T = buf->T;
-  if (!dims_ok(pol)) return bad_dims("icrl_rollout_collect", pol);
+  const bool generic = policy_is_wide(pol) || (cn != nullptr && costnet_is_wide(cn));      // shapes of the generic-shape path: per-step launches
+  if (!generic && !dims_ok(pol)) return bad_dims("icrl_rollout_collect", pol);
   if (pol->obs_dim != O || buf->N != N || buf->obs_dim != O)
     return fail("icrl_rollout_collect: env (%d envs, obs_dim %d) vs policy obs_dim %d vs buffer (%d envs, obs_dim %d)", N, O, pol->obs_dim, buf->N, buf->obs_dim);
-  if (cn != nullptr && !cn_ok(cn)) return bad_cn("icrl_rollout_collect", cn);
+  if (!generic && cn != nullptr && !cn_ok(cn)) return bad_cn("icrl_rollout_collect", cn);
   if (N > NORM_MAX_N)
     return fail("icrl_rollout_collect: %d envs on one GPU, limit %d (shard the envs over ranks: the float64 normaliser statistics are one "
                 "numpy-ordered chain per column)", N, NORM_MAX_N);
   hipStream_t s = (hipStream_t)stream;
+  if (generic) {
+    // a policy with layers above 64 units / an `arch` descriptor, or a constraint net above 64 units / two layers: the reference's
+    // per-step loop as four launches per step on this stream — policy_generic_kernel (generic.hip), cn_cost_rows_kernel (cn_train.hip),
+    // act_step_generic_kernel, the normaliser — no host work in between
+    if (O > MAX_OBS || env->act_dim > MAX_ACT || T < 1)
+      return fail("icrl_rollout_collect (generic-shape path): obs_dim %d (<= %d), act_dim %d (<= %d), T = %d", O, MAX_OBS, env->act_dim, MAX_ACT, T);
+    if (buf->act_store != (pol->discrete ? 1 : pol->act_dim))
+      return fail("icrl_rollout_collect (generic-shape path): buffer act_store %d vs policy act_dim %d (discrete: 1)", buf->act_store, pol->act_dim);
+    GenStepArgs g;
+    g.env = *env; g.buf = *buf; g.ag = *ag; g.has_cn = cn != nullptr;
+    const int AS = buf->act_store;
+    for (int t = 0; t < T; ++t) {
+      const size_t row = (size_t)t * N;
+      int err = policy_is_wide(pol)
+          ? launch_policy_generic(pol, ag->last_obs, noise ? noise + row * AS : nullptr, N, 0, action_low, action_high, buf->actions + row * AS, ag->act_clipped,
+                                  buf->reward_values + row, buf->cost_values + row, buf->log_probs + row, nullptr, nullptr, s)
+          : icrl_policy_forward(pol, ag->last_obs, noise ? noise + row * AS : nullptr, N, 0, action_low, action_high, buf->actions + row * AS, ag->act_clipped,
+                                buf->reward_values + row, buf->cost_values + row, buf->log_probs + row, stream);
+      if (err) return err;
+      if (cn != nullptr) {
+        err = icrl_cost_mlp_forward(cn, env->s, ag->act_clipped, N, ag->raw_cost, stream);
+        if (err) return err;
+      }
+      hipLaunchKernelGGL(act_step_generic_kernel, dim3(N), dim3(64), 0, s, g, t);
+      NormStepArgs b{*nm, env->s, ag->raw_rew, cn ? ag->raw_cost : nullptr, ag->dones, N, O, ag->last_obs, nullptr, nullptr,
+                     buf->new_observations + row * O, buf->rewards + row, buf->costs + row, ag->last_dones};
+      launch_norm_step(b, s);
+    }
+    const int err = (int)hipGetLastError();
+    if (err || !(do_gae & 1)) return err;
+    return icrl_gae_dual_ws(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r, ag->last_v_c,
+                            ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns, buf->cost_returns, T, N,
+                            reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, 0, buf->gae_ws, buf->gae_ws_bytes, stream);
+  }
   ActStepArgs a;
   a.env = *env; a.buf = *buf; a.ag = *ag;
   a.pl = make_pol_layout(pol->obs_dim, pol->act_dim, pol->h1, pol->h2, pol->discrete);

@@ -122,14 +122,14 @@ class PPOLagrangian:
     # ---- env-chain introspection: is this the device-native stack the fused rollout handles? ---------------------------
     def _fused_chain(self):
         env = self.env
-        if not isinstance(env, VecNormalizeWithCost) or self.policy.wide:      # (hidden widths above 64: per-step path, generic-shape kernels)
+        if not isinstance(env, VecNormalizeWithCost):
             return None
+        # (a policy / constraint net of the generic-shape path — layers above 64 units, shared trunk, other depths — takes the same entry
+        # point; the library then issues the reference's per-step loop as four launches per step, csrc/rollout.hip)
         cw = env.venv
         if isinstance(cw, HipSynthVecEnv):           # no cost wrapper in the chain (the GAIL baseline, icrl/gail.py:50-59): costs are 0
             return env, None, cw
         if not isinstance(cw, VecCostWrapper) or not isinstance(cw.venv, HipSynthVecEnv) or cw.constraint_net() is None:
-            return None
-        if getattr(cw.constraint_net(), "wide", False):      # (a constraint net with a layer above 64 units: per-step path)
             return None
         return env, cw, cw.venv
 

@@ -90,7 +90,7 @@ typedef struct {
   int32_t discrete; /* 1: Categorical over act_dim logits (LGW), 0: DiagGaussian */
   int32_t n_params;
   float* params;     /* [n_params] */
-  float* params_t;   /* [n_params] transposed copy for the rollout kernels (written by icrl_policy_prepare; unused with `arch`) */
+  float* params_t;   /* [n_params] transposed copy for the forward kernels (written by icrl_policy_prepare; icrl_ppo_lag_train keeps it current) */
   const int32_t* arch; /* NULL: two hidden layers per branch (h1, h2), no shared trunk */
 } icrl_policy_t;
 

@@ -218,7 +218,7 @@ def test_icrl_hc_wide_constraint_net_two_iterations_vs_port(golden, cl):
     cfg = vars(build_parser().parse_args(argv))
     cfg.update(rank=0, world_size=1, streams=SeededStreams(13))
     st = setup(types.SimpleNamespace(**cfg))
-    assert st["constraint_net"].wide and st["agent"]._fused_chain() is None
+    assert st["constraint_net"].wide and st["agent"]._fused_chain() is not None
     init = dict(policy={k: v.numpy().copy() for k, v in st["agent"].policy.state_dict().items()},
                 cn={k: v.numpy().copy() for k, v in st["constraint_net"].state_dict().items()})
     ex = golden("expert_hc")

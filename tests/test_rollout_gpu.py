@@ -185,7 +185,7 @@ def test_fused_rollout_vs_reference_golden(golden):
                                              ("antbroken", 512, 12, "auto"), ("hc", 64, 300, "multi"), ("antbroken", 512, 12, "multi"),
                                              ("ant", 96, 40, "multi"),
                                              # a policy with layers above 64 (-pl 128 96 -rvl 80 128 -cvl 128 128, icrl/utils.py:636-655): the
-                                             # per-step loop over the fine-grained entry points with the generic-shape forward kernel
+                                             # per-step launches of icrl_rollout_collect with the generic-shape forward kernel
                                              ("hc", 16, 120, "wide-policy"), ("ant", 8, 30, "wide-policy")])
 def test_fused_rollout_vs_port(kind, N, T, kernel):
     """same comparison at HC / Ant shapes with freshly initialised nets; also crosses episode ends (hc T=300 < 1000: none,
@@ -215,7 +215,7 @@ def test_fused_rollout_vs_port(kind, N, T, kernel):
     akw = dict(policy_kwargs=dict(net_arch=[dict(pi=[128, 96], vf=[80, 128], cvf=[128, 128])])) if wide else {}
     agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=7, **akw)   # learn() re-seeds the env with the agent seed
     if wide:
-        assert agent.policy.wide and agent._fused_chain() is None
+        assert agent.policy.wide and agent._fused_chain() is not None
     else:
         agent.rollout_kernel = kernel
     stack = o_loop.make_stack(N, ekind, 7, broken=broken); stack.cost_fn = ocn.cost_function
@@ -250,13 +250,13 @@ def test_fused_rollout_vs_port(kind, N, T, kernel):
     assert env.obs_rms.count == stack.norm.obs_rms.count
 
 
-def _pair_of_agents(N, T, seed, kind="hc", broken=False, cn_kwargs=None):
+def _pair_of_agents(N, T, seed, kind="hc", broken=False, cn_kwargs=None, hid=None, agent_kwargs=None):
     from icrl_amd.ppo_lag import PPOLagrangian
     from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
     from icrl_amd.constraint_net import ConstraintNet
     out = []
     od, ad = (18, 6) if kind == "hc" else (113, 8)
-    hid = [20] if kind == "hc" else [40, 40]
+    hid = hid or ([20] if kind == "hc" else [40, 40])
     lo = -np.ones(ad, np.float32)
     for _ in range(2):
         torch.manual_seed(seed)
@@ -264,7 +264,7 @@ def _pair_of_agents(N, T, seed, kind="hc", broken=False, cn_kwargs=None):
         kw = dict(clip_obs=20, action_low=lo, action_high=-lo) if cn_kwargs is None else cn_kwargs
         cn = ConstraintNet(od, ad, hid, None, lambda x: 0.05, None, None, False, 0.5, **kw)
         env.set_cost_function(cn.cost_function)
-        out.append((PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=seed), env, cn))
+        out.append((PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=seed, **(agent_kwargs or {})), env, cn))
     out[1][2].load_state_dict(out[0][2].state_dict())
     out[1][0].policy.load_state_dict(out[0][0].policy.state_dict())
     return out
@@ -289,6 +289,31 @@ def test_stepped_rollout_equals_fused_rollout():
             got, ref = getattr(a_s.rollout_buffer, k).cpu().numpy(), getattr(a_f.rollout_buffer, k).cpu().numpy()
             assert np.allclose(got, ref, rtol=2e-5, atol=2e-6), (it, k, np.abs(got - ref).max())
     assert np.allclose(e_s.obs_rms.mean, e_f.obs_rms.mean, rtol=0, atol=1e-12) and abs(e_s.cost_rms.var - e_f.cost_rms.var) < 1e-12
+    assert a_s.num_timesteps == a_f.num_timesteps == 2 * N * T
+
+
+@pytest.mark.parametrize("kind,shape", [("hc", "wide"), ("hc", "trunk"), ("ant", "deep"), ("hc", "wide-cn"), ("ant", "deep-cn"), ("hc", "both")])
+def test_generic_shape_rollout_equals_python_loop(kind, shape):
+    """policies / constraint nets of the generic-shape path (layers above 64 units, shared trunk, other depths): icrl_rollout_collect
+    issues the reference's per-step loop itself — four launches per step, no host work in between (csrc/rollout.hip) — and must
+    leave exactly what the Python loop over the fine-grained entry points leaves (same kernels, same order)."""
+    from helpers.arches import ARCHES
+    N, T = 12, 40
+    net_arch = {"wide": [dict(pi=[128, 96], vf=[80, 128], cvf=[128, 128])], "both": [dict(pi=[128, 96], vf=[80, 128], cvf=[128, 128])]}.get(shape, ARCHES.get(shape))
+    hid = {"wide-cn": [128, 100], "deep-cn": [48, 32, 24], "both": [64, 64, 64]}.get(shape)
+    akw = dict(policy_kwargs=dict(net_arch=net_arch)) if net_arch else None
+    (a_f, e_f, c_f), (a_s, e_s, _) = _pair_of_agents(N, T, 11, kind=kind, hid=hid, agent_kwargs=akw)
+    assert a_f.policy.wide == (net_arch is not None) and c_f.wide == (hid is not None) and a_f._fused_chain() is not None
+    ad = 6 if kind == "hc" else 8
+    noise = torch.as_tensor(np.random.RandomState(3).randn(2, T, N, ad).astype(np.float32), device="cuda")
+    a_f._setup_learn(2 * N * T); a_s._setup_learn(2 * N * T)
+    for it in range(2):
+        a_f.collect_rollouts(e_f, None, a_f.rollout_buffer, T, "cost", noise=noise[it])
+        a_s._collect_rollouts_stepped(e_s, None, a_s.rollout_buffer, T, "cost", noise=noise[it])
+        for k in _BUF_KEYS:
+            got, ref = getattr(a_s.rollout_buffer, k).cpu().numpy(), getattr(a_f.rollout_buffer, k).cpu().numpy()
+            assert np.array_equal(got, ref), (it, k, np.abs(got - ref).max())
+    assert np.array_equal(e_s.obs_rms.mean, e_f.obs_rms.mean) and e_s.cost_rms.var == e_f.cost_rms.var and e_s.ret_rms.var == e_f.ret_rms.var
     assert a_s.num_timesteps == a_f.num_timesteps == 2 * N * T
 
 

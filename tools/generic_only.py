@@ -13,11 +13,15 @@ for name, kw, B in (("-pl 128 128 -rvl 128 128 -cvl 128 128, batch 64", dict(pol
     cn = ConstraintNet(18, 6, [20], None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
     env.set_cost_function(cn.cost_function)
     agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, batch_size=B, n_epochs=2, seed=0, permutation="device", **kw)
-    agent._setup_learn(N * T)
+    agent._setup_learn(3 * N * T)
+    agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost"); torch.cuda.synchronize()      # (first call: module load)
     t0 = time.time()
     agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost")
     torch.cuda.synchronize(); t_roll = time.time() - t0
+    t0 = time.time()
+    agent._collect_rollouts_stepped(env, None, agent.rollout_buffer, T, "cost")
+    torch.cuda.synchronize(); t_py = time.time() - t0
     agent.train(); torch.cuda.synchronize()
     t0 = time.time(); agent.train(); torch.cuda.synchronize(); dt = time.time() - t0
     steps = 2 * (N * T // B)
-    print(f"{name}: rollout {1e6 * t_roll / T:.0f} us per {N}-env step ({'per-step path' if agent.policy.wide else 'fused'}), update {1e6 * dt / steps:.1f} us per optimiser step ({steps} steps)")
+    print(f"{name}: rollout {1e6 * t_roll / T:.0f} us per {N}-env step ({'four launches per step inside icrl_rollout_collect' if agent.policy.wide else 'fused'}; the Python loop over the fine-grained entry points: {1e6 * t_py / T:.0f}), update {1e6 * dt / steps:.1f} us per optimiser step ({steps} steps)")
