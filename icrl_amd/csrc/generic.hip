@@ -18,93 +18,9 @@
 //                                                      (ppo_lag.py:196-299, torch.optim.Adam, clip_grad_norm_)
 // The forward reads the weights from `params_t` = the per-layer transposes (icrl_policy_prepare; the update keeps both images current).
 #include "ppo_common.h"
+#include "generic.h"
 
 namespace icrl {
-
-constexpr int GEN_MAX_H = 256;                               // widest layer
-constexpr int GEN_MAX_DEPTH = 4;                             // layers of the shared trunk / of one branch
-constexpr int GEN_MAX_LAYERS = 4 * GEN_MAX_DEPTH + 3;        // trunk + three branches + three heads
-constexpr int GEN_MAX_STAGES = 2 * GEN_MAX_DEPTH + 1;
-constexpr int GEN_MAX_ROW = 4 * GEN_MAX_DEPTH * GEN_MAX_H + MAX_ACT + 2;      // outputs of every layer of one row
-
-// One Linear (+ tanh) of the network.  Layers are numbered in execution order; a layer reads the observation (in_buf = -1) or the
-// output of an earlier layer, and writes act_off .. act_off + out_dim of the row's activation record.  The layers of one stage
-// are independent and run side by side, one per slot (slot = threadIdx.x / W; the trunk on slot 0, branch r on slot r).
-struct GenLayer { int in_dim, out_dim, w_off, b_off, in_buf, act_off, slot, tanh; };
-
-struct GenNet {
-  int O, A, discrete, log_std, n;          // log_std: parameter offset (-1 when discrete); n: parameter count
-  int n_layers, n_stages, row_floats, W;   // W: threads per slot = the widest layer rounded up to 64
-  int stage_begin[GEN_MAX_STAGES + 1];
-  int head[3];                             // layer indices of action_net / value_net / cost_value_net (the last stage)
-  GenLayer layer[GEN_MAX_LAYERS];
-};
-
-// icrl_policy_t -> GenNet.  Runs on the host (arch is host memory).  Returns 0 or the fail() code.
-static int make_gen_net(const icrl_policy_t* p, GenNet* out, const char* who) {
-  GenNet& g = *out;
-  const int O = p->obs_dim, A = p->act_dim;
-  if (O < 1 || O > 1024 || A < 1 || A > MAX_ACT) return fail("%s (generic path): obs_dim %d (1..1024), act_dim %d (1..%d)", who, O, A, MAX_ACT);
-  int n_sh = 0, sh[GEN_MAX_DEPTH], n_br[3], br[3][GEN_MAX_DEPTH];
-  if (p->arch == nullptr) {      // classic layout: three two-layer branches, widths padded to h1 = h2
-    if (p->h1 != p->h2 || p->h1 % 64 != 0 || p->h1 < 64 || p->h1 > GEN_MAX_H)
-      return fail("%s (generic path): padded hidden width %d x %d (equal, a multiple of 64, <= %d)", who, p->h1, p->h2, GEN_MAX_H);
-    for (int r = 0; r < 3; ++r) { n_br[r] = 2; br[r][0] = p->h1; br[r][1] = p->h2; }
-  } else {
-    const int32_t* a = p->arch;
-    n_sh = *a++;
-    if (n_sh < 0 || n_sh > GEN_MAX_DEPTH) return fail("%s: %d shared layers (0..%d)", who, n_sh, GEN_MAX_DEPTH);
-    for (int i = 0; i < n_sh; ++i) sh[i] = *a++;
-    for (int r = 0; r < 3; ++r) {
-      n_br[r] = *a++;
-      if (n_br[r] < 0 || n_br[r] > GEN_MAX_DEPTH) return fail("%s: %d layers in branch %d (0..%d)", who, n_br[r], r, GEN_MAX_DEPTH);
-      for (int i = 0; i < n_br[r]; ++i) br[r][i] = *a++;
-    }
-    for (int i = 0; i < n_sh; ++i) if (sh[i] < 1 || sh[i] > GEN_MAX_H) return fail("%s: shared layer %d has %d units (1..%d)", who, i, sh[i], GEN_MAX_H);
-    for (int r = 0; r < 3; ++r)
-      for (int i = 0; i < n_br[r]; ++i) if (br[r][i] < 1 || br[r][i] > GEN_MAX_H) return fail("%s: layer %d of branch %d has %d units (1..%d)", who, i, r, br[r][i], GEN_MAX_H);
-  }
-  g.O = O; g.A = A; g.discrete = p->discrete != 0;
-  int off = 0, nl = 0, ns = 0, act = 0, widest = 64;
-  if (g.discrete) g.log_std = -1; else { g.log_std = 0; off += A; }
-  auto add = [&](int in_dim, int out_dim, int in_buf, int slot, int tanh, int w_off) {
-    GenLayer& l = g.layer[nl];
-    l.in_dim = in_dim; l.out_dim = out_dim; l.w_off = w_off; l.b_off = w_off + in_dim * out_dim; l.in_buf = in_buf; l.act_off = act; l.slot = slot; l.tanh = tanh;
-    act += out_dim;
-    if (out_dim > widest) widest = out_dim;
-    return nl++;
-  };
-  // parameter order = the reference's state_dict: trunk, policy_net, value_net, cost_value_net (every layer W then b), then the heads
-  int last = -1, last_dim = O;
-  for (int i = 0; i < n_sh; ++i) {
-    g.stage_begin[ns++] = nl;
-    last = add(last_dim, sh[i], last, 0, 1, off);
-    off += last_dim * sh[i] + sh[i];
-    last_dim = sh[i];
-  }
-  int w_off[3][GEN_MAX_DEPTH], max_depth = 0;
-  for (int r = 0; r < 3; ++r) {
-    int d_in = last_dim;
-    for (int i = 0; i < n_br[r]; ++i) { w_off[r][i] = off; off += d_in * br[r][i] + br[r][i]; d_in = br[r][i]; }
-    if (n_br[r] > max_depth) max_depth = n_br[r];
-  }
-  int tip[3] = {last, last, last}, tip_dim[3] = {last_dim, last_dim, last_dim};
-  for (int d = 0; d < max_depth; ++d) {
-    g.stage_begin[ns++] = nl;
-    for (int r = 0; r < 3; ++r)
-      if (d < n_br[r]) { tip[r] = add(tip_dim[r], br[r][d], tip[r], r, 1, w_off[r][d]); tip_dim[r] = br[r][d]; }
-  }
-  g.stage_begin[ns++] = nl;
-  for (int r = 0; r < 3; ++r) {
-    const int n_out = r == 0 ? A : 1;
-    g.head[r] = add(tip_dim[r], n_out, tip[r], r, 0, off);
-    off += tip_dim[r] * n_out + n_out;
-  }
-  g.stage_begin[ns] = nl;
-  g.n = off; g.n_layers = nl; g.n_stages = ns; g.row_floats = act; g.W = (widest + 63) / 64 * 64;
-  if (p->n_params != g.n) return fail("%s: n_params = %d, the architecture needs %d", who, p->n_params, g.n);
-  return 0;
-}
 
 struct GenCtl {      // first 64 floats of the generic scratch, zeroed at the start of a train() launch sequence
   float mean_r, istd_r, mean_c;
@@ -137,46 +53,6 @@ __host__ __device__ inline size_t gen_off_grad(int B, int RF) { return gen_off_d
 __host__ __device__ inline size_t gen_off_part(int B, int RF, int n_params) { return gen_off_grad(B, RF) + (size_t)n_params; }
 __host__ __device__ inline size_t gen_floats(int B, int RF, int n_params) { return gen_off_part(B, RF, n_params) + (size_t)(n_params + 255) / 256 + 64; }
 
-// ---------------------------------------------------------------------------------------------------------------
-// forward of ONE row: thread (slot, j) = unit j of the layer its slot runs in the current stage.  blockDim = 3 * W.
-// ---------------------------------------------------------------------------------------------------------------
-struct GenFwdShared {
-  float x[1024];
-  float act[GEN_MAX_ROW];
-};
-
-__device__ __forceinline__ int gen_my_layer(const GenNet& net, int stage, int slot) {
-  for (int l = net.stage_begin[stage]; l < net.stage_begin[stage + 1]; ++l)
-    if (net.layer[l].slot == slot) return l;
-  return -1;
-}
-
-// PT: the per-layer transposes (gen_transpose_kernel): unit j reads Wt[k][j], consecutive units consecutive addresses — the row-major
-// W[j][k] costs one cache line per lane and load.  Same fmaf chain (k ascending from the bias) either way.
-__device__ __forceinline__ void gen_mlp_forward(const GenNet& net, const float* __restrict__ PT, const float* x, float* act, int slot, int j) {
-  for (int s = 0; s < net.n_stages; ++s) {
-    const int l = gen_my_layer(net, s, slot);
-    if (l >= 0 && j < net.layer[l].out_dim) {
-      const GenLayer& y = net.layer[l];
-      const float* wt = PT + y.w_off + j;
-      const float* in = y.in_buf < 0 ? x : act + net.layer[y.in_buf].act_off;
-      const int n_in = y.in_dim, n_out = y.out_dim;
-      float z = PT[y.b_off + j];
-      int k = 0;
-      for (; k + 8 <= n_in; k += 8) {
-        float w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = wt[(size_t)(k + u) * n_out];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) z = fmaf(w[u], in[k + u], z);
-      }
-      for (; k < n_in; ++k) z = fmaf(wt[(size_t)k * n_out], in[k], z);
-      act[y.act_off + j] = y.tanh ? fast_tanh(z) : z;
-    }
-    __syncthreads();
-  }
-}
-
 // position of parameter e in the transposed image: weights W[j][k] -> Wt[k][j] inside their layer's block, everything else in place
 __device__ __forceinline__ int gen_transposed_index(const GenNet& net, int e) {
   for (int l = 0; l < net.n_layers; ++l) {
@@ -207,44 +83,10 @@ __global__ void __launch_bounds__(3 * GEN_MAX_H) policy_generic_kernel(GenNet ne
   __syncthreads();
   gen_mlp_forward(net, PT, sh.x, sh.act, slot, j);
   if (tid == 0) {
-    const int A = net.A, AS = net.discrete ? 1 : A;
-    const float* out = sh.act + net.layer[net.head[0]].act_off;
-    float lp = 0.f, ent = 0.f;
-    if (!net.discrete) {
-      for (int o = 0; o < A; ++o) {
-        const float ls = P[net.log_std + o], sd = __expf(ls), mean = out[o];
-        float act = mean;
-        if (given != nullptr) act = given[n * AS + o];
-        else if (!deterministic && noise != nullptr) act = mean + noise[n * AS + o] * sd;      // Normal.rsample: loc + eps * scale
-        const float diff = act - mean;
-        lp += -(diff * diff) / (2.f * sd * sd) - ls - LOG_SQRT_2PI_F;
-        ent += HALF_LOG_2PI_PLUS_HALF_F + ls;
-        if (actions) actions[n * AS + o] = act;
-        if (act_clipped) act_clipped[n * AS + o] = (alow != nullptr && ahigh != nullptr) ? fminf(fmaxf(act, alow[o]), ahigh[o]) : act;
-      }
-    } else {      // Categorical(logits): log-softmax, inverse-CDF sample on the injected uniform (spec: oracle/nets.py forward)
-      float m = -INFINITY;
-      for (int o = 0; o < A; ++o) m = fmaxf(m, out[o]);
-      float se = 0.f;
-      for (int o = 0; o < A; ++o) se += expf(out[o] - m);
-      const float lse = m + logf(se);
-      int action = 0;
-      if (given != nullptr) action = (int)given[n];
-      else if (deterministic || noise == nullptr) {
-        float best = -1.f;
-        for (int o = 0; o < A; ++o) { const float p = expf(out[o] - lse); if (p > best) { best = p; action = o; } }
-      } else {
-        const float u = noise[n];
-        float cdf = 0.f;
-        int cnt = 0;
-        for (int o = 0; o < A; ++o) { cdf += expf(out[o] - lse); cnt += (u >= cdf) ? 1 : 0; }
-        action = cnt < A - 1 ? cnt : A - 1;
-      }
-      lp = out[action] - lse;
-      for (int o = 0; o < A; ++o) { const float lg = out[o] - lse; ent -= lg * expf(lg); }
-      if (actions) actions[n] = (float)action;
-      if (act_clipped) act_clipped[n] = (float)action;
-    }
+    const int AS = net.discrete ? 1 : net.A;
+    float lp, ent;
+    gen_policy_head(net, P, sh.act + net.layer[net.head[0]].act_off, noise ? noise + n * AS : nullptr, deterministic, alow, ahigh,
+                    given ? given + n * AS : nullptr, actions ? actions + n * AS : nullptr, act_clipped ? act_clipped + n * AS : nullptr, lp, ent);
     if (v_r) v_r[n] = sh.act[net.layer[net.head[1]].act_off];
     if (v_c) v_c[n] = sh.act[net.layer[net.head[2]].act_off];
     if (log_prob) log_prob[n] = lp;

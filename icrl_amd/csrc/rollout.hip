@@ -22,6 +22,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "generic.h"
 
 namespace icrl {
 
@@ -2838,6 +2839,106 @@ extern "C" int icrl_policy_evaluate(const icrl_policy_t* p, const double* obs, c
   return (int)hipGetLastError();
 }
 
+// sample_episodes_kernel for the policies of the generic-shape path (layers above 64 units, shared trunk, other depths): the same
+// persistent episode loop, one workgroup per stream, with the table-driven forward of generic.h on the trunk + policy branch (slot 0;
+// the value branches are not needed here) and the weights read from the per-layer transposes every step (L2-resident).
+struct GenSampleArgs {
+  icrl_env_t env;
+  icrl_norm_t nm;
+  const float* P;
+  const float* PT;
+  const float* noise;
+  const float* alow;
+  const float* ahigh;
+  int episodes_per_stream, rows_per_stream, deterministic, do_reset;
+  const int* stream_row0;
+  int total_rows;
+  double* orig_obs;
+  double* obs;
+  float* actions;
+  double* ep_rewards;
+  int* ep_lengths;
+};
+
+__global__ void __launch_bounds__(GEN_MAX_H) sample_episodes_generic_kernel(GenNet net, GenSampleArgs a) {
+  __shared__ float x[MAX_OBS];
+  __shared__ float act[GEN_MAX_ROW];
+  __shared__ double s_old[MAX_OBS], s_new[MAX_OBS], n_mean[MAX_OBS], n_den[MAX_OBS];
+  __shared__ double Bl[MAX_OBS * MAX_ACT];
+  __shared__ float act_raw[MAX_ACT], act_clip[MAX_ACT], noise_s[MAX_ACT], alow_s[MAX_ACT], ahigh_s[MAX_ACT];
+  __shared__ int s_done;
+  __shared__ double s_rew;
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, nt = blockDim.x;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int O = net.O, A = net.A, AS = net.discrete ? 1 : A;
+  icrl_env_t env = a.env;
+  const int norm_obs = a.nm.norm_obs, deterministic = a.deterministic;
+  const double clip_obs = a.nm.clip_obs;
+  for (int i = tid; i < O * a.env.act_dim; i += nt) Bl[i] = a.env.B[i];
+  env.B = Bl;
+  const bool has_box = a.alow != nullptr && a.ahigh != nullptr;
+  if (tid < MAX_ACT) { alow_s[tid] = (has_box && tid < A) ? a.alow[tid] : 0.f; ahigh_s[tid] = (has_box && tid < A) ? a.ahigh[tid] : 0.f; }
+  const uint32_t e_key = a.env.key[n];
+  uint32_t e_ctr = a.env.step_count[n];
+  int e_tep = a.env.t_ep[n];
+  for (int i = tid; i < O; i += nt) {      // frozen normaliser statistics; the state the stream starts from
+    n_mean[i] = a.nm.norm_obs ? a.nm.obs_mean[i] : 0.0;
+    n_den[i] = a.nm.norm_obs ? sqrt(a.nm.obs_var[i] + a.nm.epsilon) : 1.0;
+    double v = a.env.s[(size_t)n * O + i];
+    if (a.do_reset) v = env_reset_value(a.env, e_key, e_ctr, i);
+    s_new[i] = v;
+  }
+  if (a.do_reset) e_tep = 0;
+  __syncthreads();
+  size_t row = a.stream_row0 != nullptr ? (size_t)a.stream_row0[n] : (size_t)n * a.rows_per_stream;
+  const size_t row_end = a.stream_row0 != nullptr ? (size_t)a.total_rows : row + a.rows_per_stream;
+  for (int ep = 0; ep < a.episodes_per_stream; ++ep) {
+    double ep_rew = 0.0;
+    int ep_len = 0;
+    while (true) {
+      for (int i = tid; i < O; i += nt) {
+        const double raw = s_new[i];
+        double o = raw;
+        if (norm_obs) o = fmin(fmax((raw - n_mean[i]) / n_den[i], -clip_obs), clip_obs);
+        s_old[i] = raw;
+        x[i] = (float)o;
+      }
+      const bool in_rows = row < row_end;      // (a stream whose speculative start row was too late can run off the arrays)
+      if (a.noise != nullptr && tid < AS) noise_s[tid] = in_rows ? a.noise[row * AS + tid] : 0.f;
+      __syncthreads();
+      gen_mlp_forward(net, a.PT, x, act, 0, tid);
+      if (tid == 0) {
+        float lp, ent;
+        gen_policy_head(net, a.P, act + net.layer[net.head[0]].act_off, a.noise != nullptr ? noise_s : nullptr, deterministic || a.noise == nullptr,
+                        has_box ? alow_s : nullptr, has_box ? ahigh_s : nullptr, nullptr, act_raw, act_clip, lp, ent);
+      }
+      __syncthreads();
+      if (w == 0) {
+        double rew; int done;
+        env_step_wave(env, n, s_old, act_clip, e_key, e_ctr, e_tep, s_new, rew, done);
+        if (lane == 0) { s_done = done; s_rew = rew; }
+        if (lane < AS && in_rows) a.actions[row * AS + lane] = act_clip[lane];
+      }
+      __syncthreads();
+      if (in_rows)
+        for (int i = tid; i < O; i += nt) {
+          const double raw = s_new[i];
+          double o = raw;
+          if (norm_obs) o = fmin(fmax((raw - n_mean[i]) / n_den[i], -clip_obs), clip_obs);
+          a.orig_obs[row * O + i] = raw;
+          a.obs[row * O + i] = o;
+        }
+      ep_rew += s_rew;     // episode_reward += reward (un-normalised: norm_reward is False on sampling / eval envs)
+      ++ep_len;
+      ++row;
+      const int done = s_done;
+      __syncthreads();
+      if (done) break;
+    }
+    if (tid == 0) { a.ep_rewards[(size_t)n * a.episodes_per_stream + ep] = ep_rew; a.ep_lengths[(size_t)n * a.episodes_per_stream + ep] = ep_len; }
+  }
+}
+
 static int make_sample_args(const icrl_env_t* env, const icrl_norm_t* nm, const icrl_policy_t* pol, const float* noise,
                             const float* action_low, const float* action_high, int episodes_per_stream, int rows_per_stream,
                             int deterministic, int do_reset, const int32_t* stream_row0, int total_rows, double* orig_obs, double* obs,
@@ -2862,6 +2963,20 @@ extern "C" int icrl_sample_episodes(const icrl_env_t* env, const icrl_norm_t* nm
                                     int rows_per_stream, int deterministic, int do_reset, const int32_t* stream_row0, int total_rows,
                                     double* orig_obs, double* obs, float* actions, double* ep_rewards, int32_t* ep_lengths,
                                     void* stream) {
+  if (policy_is_wide(pol)) {      // generic-shape path: the same persistent loop with the table-driven forward
+    GenNet net;
+    if (int e = make_gen_net(pol, &net, "icrl_sample_episodes")) return e;
+    if (env->obs_dim != pol->obs_dim || nm->training || env->obs_dim > MAX_OBS || env->act_dim > MAX_ACT || pol->params_t == nullptr)
+      return fail("icrl_sample_episodes (generic-shape path): env obs_dim %d vs policy %d (<= %d), act_dim %d (<= %d); the normaliser must be frozen "
+                  "(training = %d); params_t %s", env->obs_dim, pol->obs_dim, MAX_OBS, env->act_dim, MAX_ACT, nm->training, pol->params_t ? "set" : "NULL");
+    if (episodes_per_stream * env->max_steps > rows_per_stream)
+      return fail("icrl_sample_episodes: %d episodes x %d steps do not fit %d rows per stream", episodes_per_stream, env->max_steps, rows_per_stream);
+    if (stream_row0 != nullptr && total_rows < 1) return fail("icrl_sample_episodes: stream_row0 given with total_rows = %d", total_rows);
+    GenSampleArgs g{*env, *nm, pol->params, pol->params_t, noise, action_low, action_high, episodes_per_stream, rows_per_stream, deterministic, do_reset,
+                    stream_row0, total_rows, orig_obs, obs, actions, ep_rewards, ep_lengths};
+    hipLaunchKernelGGL(sample_episodes_generic_kernel, dim3(env->n_envs), dim3(net.W), 0, (hipStream_t)stream, net, g);
+    return (int)hipGetLastError();
+  }
   SampleArgs a;
   const int bad = make_sample_args(env, nm, pol, noise, action_low, action_high, episodes_per_stream, rows_per_stream, deterministic,
                                    do_reset, stream_row0, total_rows, orig_obs, obs, actions, ep_rewards, ep_lengths, a);

@@ -176,9 +176,9 @@ class EpisodeRun:
 
 class SteppedEpisodeRun:
     """EpisodeRun's results from the reference's own loop (icrl/utils.py:323-357, evaluation.py:10-67) over the per-step env chain —
-    policy.forward + env.step, one launch sequence and one host read of `done` per step — for the policies the persistent sampler
-    does not serve (hidden widths above 64: generic-shape forward kernel).  The env is reset before the first episode only; the later
-    ones start from the auto-reset observation, like the sequential loop the sampler kernel reproduces."""
+    policy.forward + env.step, one launch sequence and one host read of `done` per step.  Not used by the product path any more (the
+    sampler kernels serve every policy shape); tests run it beside EpisodeRun: same rows, same episode sums.  The env is reset before
+    the first episode only; the later ones start from the auto-reset observation, like the sequential loop the sampler kernel reproduces."""
 
     def __init__(self, agent, env, n_episodes, deterministic, noise):
         assert env.num_envs == 1, "You must pass only one environment when using this function"
@@ -219,8 +219,8 @@ class SteppedEpisodeRun:
 
 
 def _run_episodes(agent, env, n_episodes, deterministic, noise, parallel):
-    if agent.policy.wide:
-        return SteppedEpisodeRun(agent, env, n_episodes, deterministic, noise)
+    # (policies of the generic-shape path take the same launch: icrl_sample_episodes runs its persistent loop with the table-driven
+    # forward, csrc/rollout.hip sample_episodes_generic_kernel; SteppedEpisodeRun is the same loop from the host, kept as the check)
     run = EpisodeRun(agent, env, n_episodes, deterministic, noise, parallel).prepare()
     run.launch()
     while not run.finish():

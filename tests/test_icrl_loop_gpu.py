@@ -70,6 +70,48 @@ def test_evaluate_policy_wall_termination_vs_port():
     assert max(el) < 1000           # the wall was hit
 
 
+@pytest.mark.parametrize("shape,env_id", [("wide", "HCWithPos-v0"), ("trunk", "HCWithPosTest-v0"), ("deep", "AntWallTest-v0"), ("bare", "HCWithPos-v0")])
+def test_generic_shape_sampler_equals_host_loop(shape, env_id):
+    """policies of the generic-shape path (layers above 64 units, shared trunk, other depths) in sample_from_agent / evaluate_policy:
+    icrl_sample_episodes runs its persistent episode loop with the table-driven forward (sample_episodes_generic_kernel) — parallel
+    streams, speculative start rows on the "Test" envs — and must return exactly the rows and episode sums of the reference's loop
+    driven from the host over the fine-grained entry points (utils.SteppedEpisodeRun: policy.forward + env.step, same kernels)."""
+    from helpers.arches import ARCHES
+    from icrl_amd import utils
+    from icrl_amd.ppo_lag import PPOLagrangian
+    ant = env_id.startswith("Ant")
+    od, ad = (113, 8) if ant else (18, 6)
+    net_arch = ARCHES.get(shape, [dict(pi=[128, 96], vf=[80, 128], cvf=[128, 128])])
+    train_env = utils.make_train_env("AntWall-v0" if ant else "HCWithPos-v0", None, True, 3, 4, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", train_env, n_steps=32, seed=3, policy_kwargs=dict(net_arch=net_arch))
+    assert agent.policy.wide
+    if env_id.endswith("Test-v0"):      # drive obs[0] down so that episodes end at the wall, at different lengths
+        sd = agent.policy.state_dict()
+        B0 = np.random.RandomState(1234).randn(od, ad)[0] * 0.05
+        sd["action_net.bias"] = torch.as_tensor(-np.sign(B0) * (2.0 if not ant else 1.0), dtype=torch.float32)
+        agent.policy.load_state_dict(sd)
+    n_ep = 3
+    outs = []
+    for cls in ("kernel", "host"):
+        eenv = utils.make_eval_env(env_id, False, seed=3)
+        ms = eenv.unwrapped.max_steps
+        noise = np.random.RandomState(0).randn(n_ep * ms, ad).astype(np.float32) * 0.3
+        if cls == "kernel":
+            run = utils._run_episodes(agent, eenv, n_ep, False, noise, parallel=True)
+            assert isinstance(run, utils.EpisodeRun)
+        else:
+            run = utils.SteppedEpisodeRun(agent, eenv, n_ep, False, noise)
+        oo, o, a, r, l = utils.sample_result(run)
+        outs.append((oo.cpu().numpy(), o.cpu().numpy(), a.cpu().numpy(), np.asarray(r), np.asarray(l), eenv.unwrapped.step_count.cpu().numpy().copy()))
+    k, h = outs
+    assert np.array_equal(k[4], h[4]), (k[4], h[4])
+    if env_id == "HCWithPosTest-v0":
+        assert k[4].min() < 1000
+    for i, name in enumerate(("orig_obs", "obs", "actions", "ep_rewards")):
+        assert k[i].shape == h[i].shape and np.array_equal(k[i], h[i]), (name, np.abs(k[i] - h[i]).max())
+    assert np.array_equal(k[5], h[5])      # the env's random stream is left where the sequential loop leaves it
+
+
 def test_icrl_entry_point_short_run(tmp_path, golden):
     """`run_me.py icrl`-style flags, 2 outer iterations at a reduced size; checks the metric keys the reference logs."""
     from icrl_amd.icrl import build_parser, icrl
