@@ -84,7 +84,8 @@ typedef struct {
  * group and 1..256 units per layer (a branch without layers feeds its head from the trunk, or from the observation).  h1 / h2 are then
  * ignored and `params` holds the natural, unpadded layout in state_dict order: log_std, the trunk's layers (W[out,in] b[out] each),
  * policy_net's, value_net's, cost_value_net's, then the three heads.  Such a policy is served by icrl_policy_forward,
- * icrl_policy_evaluate and icrl_ppo_lag_train (generic-shape path); the fused rollout / sampling launches refuse it. */
+ * icrl_policy_evaluate, icrl_ppo_lag_train, icrl_rollout_collect(_ex) and icrl_sample_episodes (generic-shape path: plain launches,
+ * per step where the fast path has one persistent launch); the *_batch entry points refuse it. */
 typedef struct {
   int32_t obs_dim, act_dim, h1, h2;
   int32_t discrete; /* 1: Categorical over act_dim logits (LGW), 0: DiagGaussian */
@@ -229,9 +230,11 @@ int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream);
  * obs: [N,obs] float64 (cast to float32 like preprocess_obs, preprocessing.py:61).  noise: [N,act] standard normals
  * ([N] uniforms when discrete) or NULL when deterministic.  actions: [N,act_store] unclipped; act_clipped: [N,act]
  * clipped to [low,high] (on_policy_algorithm.py:381-382; NULL low/high: no clipping).  Any output may be NULL.
- * Policies stored with h1 = h2 > 64 (a multiple of 64 up to 256; obs up to 1024) run the generic-shape kernel here and in
- * icrl_policy_evaluate; the fused entry points (icrl_rollout_collect*, icrl_sample_episodes*) refuse them with a message — their
- * rollouts use the per-step entry points (icrl_policy_forward, icrl_synth_env_step, icrl_cost_mlp_forward, icrl_vecnorm_step). */
+ * Policies stored with h1 = h2 > 64 (a multiple of 64 up to 256; obs up to 1024) or described by `arch` run the generic-shape kernel
+ * here and in icrl_policy_evaluate (it reads the per-layer transposes icrl_policy_prepare leaves in params_t); icrl_rollout_collect(_ex)
+ * then issues the reference's per-step loop itself (policy forward, constraint-net cost, env step, normaliser: four launches per
+ * step, the same for a constraint net above 64 units / two layers) and icrl_sample_episodes runs its episode loop with that forward;
+ * the *_batch entry points refuse such shapes with a message. */
 int icrl_policy_forward(const icrl_policy_t* pol, const double* obs, const float* noise, int N, int deterministic,
                         const float* action_low, const float* action_high,
                         float* actions, float* act_clipped, float* v_r, float* v_c, float* log_prob, void* stream);
