@@ -150,6 +150,33 @@ def configs3_one_gpu_leg(seed, steps=1, warmup=1):
     return out
 
 
+def generic_shape_leg(seed):
+    """EXTRA: the generic-shape path (csrc/generic.hip) — what a user of `-sl / -pl / -rvl / -cvl` with anything but three two-layer
+    branches of <= 64 units gets: HC shapes, 64 envs, `-sl 64 -pl 128 128 -rvl 64 -cvl 64 64 64`, batch 64; one rollout of 256 steps
+    and one update of 2 epochs, timed with events on their stream.  Not a BASELINE config."""
+    from icrl_amd.constraint_net import ConstraintNet
+    from icrl_amd.ppo_lag import PPOLagrangian
+    from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
+    N, T, B, E = 64, 256, 64, 2
+    env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, "hc", seed)))
+    lo = -np.ones(6, np.float32)
+    cn = ConstraintNet(18, 6, [20], None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
+    env.set_cost_function(cn.cost_function)
+    arch = [64, dict(pi=[128, 128], vf=[64], cvf=[64, 64, 64])]
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, batch_size=B, n_epochs=E, seed=seed, permutation="device", target_kl=None,
+                          policy_kwargs=dict(net_arch=arch))
+    agent._setup_learn(3 * N * T)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost"); agent.train()      # warm-up (module load)
+    ev[0].record(); agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost"); ev[1].record()
+    ev[2].record(); agent.train(); ev[3].record()
+    torch.cuda.synchronize()
+    steps = E * (N * T // B)
+    return dict(workload=f"HC shapes, {N} envs, net_arch {arch}, batch {B}: policy_generic / gen_* kernels behind the same entry points",
+                us_per_rollout_step=round(1e3 * ev[0].elapsed_time(ev[1]) / T, 1), us_per_optimizer_step=round(1e3 * ev[2].elapsed_time(ev[3]) / steps, 1),
+                optimizer_steps=steps, rollout_steps=T)
+
+
 def config_cpg(seed, rank, world, envs=512):
     """BASELINE configs[4] exactly as README.md:78 gives it (AntWallBroken-v0, frozen constraint net through ConstraintNet.load,
     batch 128, 20 epochs, lr 3e-5, clip 0.4, reward lambda 0.9, -plr 1.0, -tk 0.01); 4096 envs over 8 GPUs = 512 per GPU."""
@@ -349,6 +376,7 @@ def main():
     ap.add_argument("--no_configs2", action="store_true")
     ap.add_argument("--no_configs3", action="store_true")
     ap.add_argument("--no_configs4", action="store_true")
+    ap.add_argument("--no_generic", action="store_true", help="skip the generic-shape extra (a non-default net_arch at toy size)")
     ap.add_argument("--envs_per_gpu", type=int, default=None, help="override the env count per GPU (e.g. 2048: BASELINE configs[3] whole on one GPU)")
     a = ap.parse_args()
 
@@ -450,6 +478,8 @@ def main():
         out["configs3_one_gpu"] = configs3_one_gpu_leg(a.seed)
     if world == 1 and not a.no_configs4:
         out["configs4"] = configs4_leg(a.seed)
+    if world == 1 and not a.no_generic:
+        out["generic_shape"] = generic_shape_leg(a.seed)
     if world == 1 and not a.no_seed_batch:
         out["seed_batch"] = seed_batch_leg()
     print(json.dumps(out))
