@@ -3159,8 +3159,9 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
     // act_step_generic_kernel, the normaliser — no host work in between
     if (O > MAX_OBS || env->act_dim > MAX_ACT || T < 1)
       return fail("icrl_rollout_collect (generic-shape path): obs_dim %d (<= %d), act_dim %d (<= %d), T = %d", O, MAX_OBS, env->act_dim, MAX_ACT, T);
-    if (buf->act_store != (pol->discrete ? 1 : pol->act_dim))
-      return fail("icrl_rollout_collect (generic-shape path): buffer act_store %d vs policy act_dim %d (discrete: 1)", buf->act_store, pol->act_dim);
+    if (buf->act_store != (pol->discrete ? 1 : pol->act_dim) || (!pol->discrete && env->act_dim != pol->act_dim))
+      return fail("icrl_rollout_collect (generic-shape path): buffer act_store %d / env act_dim %d vs policy act_dim %d (discrete: act_store 1)",
+                  buf->act_store, env->act_dim, pol->act_dim);
     GenStepArgs g;
     g.env = *env; g.buf = *buf; g.ag = *ag; g.has_cn = cn != nullptr;
     const int AS = buf->act_store;

@@ -61,6 +61,36 @@ def test_refused_arguments_carry_a_reason():
         _lib.check(err, "icrl_ppo_lag_train")
 
 
+def test_generic_shape_limits_are_reported():
+    """what the generic-shape path refuses (host arithmetic, before any launch): more than 4 layers per group / 256 units per layer in an
+    `arch` descriptor, constraint nets outside 1..4 hidden layers or beyond the LDS; icrl_ppo_generic_row_floats sizes the scratch."""
+    from icrl_amd import _lib, structs as S
+    L = _lib.lib()
+    def pol(desc, n_params=1):
+        a = np.ascontiguousarray(desc, dtype=np.int32)
+        return S.PolicyT(18, 6, 0, 0, 0, n_params, None, None, a.ctypes.data), a
+    p, keep = pol([1, 48, 3, 64, 32, 32, 1, 40, 0])       # tests/helpers/arches.py "trunk": -sl 48 -pl 64 32 32 -rvl 40 -cvl
+    n = 6 + (18 * 48 + 48) + (48 * 64 + 64) + (64 * 32 + 32) + (32 * 32 + 32) + (48 * 40 + 40) + (32 * 6 + 6) + (40 + 1) + (48 + 1)
+    p.n_params = n
+    assert L.icrl_ppo_generic_row_floats(ctypes.byref(p)) == 48 + 64 + 32 + 32 + 40 + 6 + 2
+    p.n_params = n + 1
+    assert L.icrl_ppo_generic_row_floats(ctypes.byref(p)) == -1
+    assert f"the architecture needs {n}".encode() in L.icrl_last_error()
+    p, keep = pol([5, 8, 8, 8, 8, 8, 0, 0, 0])
+    assert L.icrl_ppo_generic_row_floats(ctypes.byref(p)) == -1 and b"5 shared layers (0..4)" in L.icrl_last_error()
+    p, keep = pol([0, 1, 300, 0, 0])
+    assert L.icrl_ppo_generic_row_floats(ctypes.byref(p)) == -1 and b"300 units (1..256)" in L.icrl_last_error()
+    cn = S.CostNetT(18, 6, 24, 5, 8, 8, 8, 8, 0, 1)
+    err = L.icrl_cost_mlp_forward(ctypes.byref(cn), None, None, 4, None, None)
+    with pytest.raises(ValueError, match=r"5 hidden layers \(1\.\.4\)"):
+        _lib.check(err, "icrl_cost_mlp_forward")
+    n_cn = (24 * 128 + 128) + 3 * (128 * 128 + 128) + 129
+    cn = S.CostNetT(18, 6, 24, 4, 128, 128, 128, 128, 0, n_cn)
+    err = L.icrl_cost_mlp_forward(ctypes.byref(cn), None, None, 4, None, None)
+    with pytest.raises(ValueError, match="B of LDS, 160 KB available"):
+        _lib.check(err, "icrl_cost_mlp_forward")
+
+
 def test_struct_sizes_match_header_layout():
     """natural alignment, no packing: sizes computed by hand from include/icrl_hip.h."""
     from icrl_amd import structs as S
