@@ -58,18 +58,18 @@ class ConstraintNet:
     def _build(self):
         """ref: constraint_net.py:101-116 — create_mlp(input, 1, hidden) with ReLU + Sigmoid; host init, device storage."""
         hs = list(self.hidden_sizes)
-        if not (1 <= len(hs) <= 4) or min(hs) < 1:
-            raise NotImplementedError(f"icrl_amd ConstraintNet supports 1..4 hidden layers (1-2 of up to 64 units inside the fused rollout, wider and "
-                                      f"deeper through the per-step path), got {hs}")
+        if len(hs) > 4 or min(hs, default=1) < 1:
+            raise NotImplementedError(f"icrl_amd ConstraintNet supports 0..4 hidden layers (1-2 of up to 64 units inside the fused rollout, the rest "
+                                      f"through the per-step launches), got {hs}")
         # 64-row activation images of the update / cost kernels (csrc/cn_train.hip: make_cn_dims) must fit the 160 KB LDS
-        lds_floats = 64 * (self.input_dims + 1) + 64 * sum(h + 1 for h in hs) + 2 * 64 * (max(hs) + 1) + 128
+        lds_floats = 64 * (self.input_dims + 1) + 64 * sum(h + 1 for h in hs) + 2 * 64 * (max(hs, default=0) + 1) + 128
         if lds_floats > 160 * 1024 // 4:
             raise NotImplementedError(f"icrl_amd ConstraintNet: hidden layers {hs} on {self.input_dims} inputs need {4 * lds_floats} B of LDS for 64 rows "
                                       "(160 KB available; e.g. 2 x 128, 3 x 96 or 4 x 64 units fit)")
         # a hidden layer above 64 units or more than two of them: the one-wave-per-row cost kernels (inside the fused rollout) do not hold
         # it; cost_function and train() then run 64 rows per workgroup (csrc/cn_train.hip: cn_cost_rows_kernel; weights from device memory
         # when they do not fit next to the activations)
-        self.wide = max(hs) > 64 or len(hs) > 2
+        self.wide = max(hs, default=0) > 64 or len(hs) > 2 or len(hs) == 0
         sd, last, k = OrderedDict(), self.input_dims, 0
         for h in hs + [1]:
             lin = torch.nn.Linear(last, h)

@@ -61,10 +61,10 @@ __host__ __device__ inline CnDims make_cn_dims(int D, int nh, const int* H) {
   return d;
 }
 
-// hidden widths of a descriptor as an array; 0 when the layer count is outside 1..CN_MAX_LAYERS
+// hidden widths of a descriptor as an array; 0 when the layer count is outside 0..CN_MAX_LAYERS (0: the sigmoid of one Linear)
 __host__ __device__ inline int cn_widths(const icrl_costnet_t& cn, int* H) {
   H[0] = cn.h1; H[1] = cn.h2; H[2] = cn.h3; H[3] = cn.h4;
-  return cn.n_hidden >= 1 && cn.n_hidden <= CN_MAX_LAYERS;
+  return cn.n_hidden >= 0 && cn.n_hidden <= CN_MAX_LAYERS;
 }
 
 // scalars shared between the kernels of one train() call (device floats in `work`)
@@ -416,7 +416,7 @@ __device__ __forceinline__ void cn_backward_body(const CnTrainArgs& a, int itr) 
   // ---- per-block parameter gradients: one thread per parameter, rows added in order.  Output layer first (logit gradients x last
   // hidden image), then layer by layer from the top: the layer's pre-activation gradients, then the gradients of its parameters
   {
-    const int hb = d.sH[d.nh - 1], hs = d.HL + 1;
+    const int hb = d.nh > 0 ? d.sH[d.nh - 1] : d.sX, hs = d.HL + 1;      // (no hidden layer: the input image, HL = D)
     for (int p = tid; p < d.HL + 1; p += CN_TH) {
       float acc = 0.f;
       if (p < d.HL) { for (int rr = 0; rr < CN_ROWS; ++rr) acc = fmaf(sm[d.sZ + CN_ROWS + rr], sm[hb + rr * hs + p], acc); }     // Wo[j]
@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(CN_TH) cn_cost_rows_kernel(icrl_costnet_t cn, 
 // descriptor -> CnDims + dynamic LDS bytes of the 64-row kernels; refuses (fail()) what they do not hold
 static int cn_dims_checked(const icrl_costnet_t* cn, const char* who, CnDims* d, size_t* lds) {
   int H[CN_MAX_LAYERS];
-  if (!cn_widths(*cn, H) || cn->in_dim < 1) return fail("%s: %d hidden layers (1..%d), in_dim %d", who, cn->n_hidden, CN_MAX_LAYERS, cn->in_dim);
+  if (!cn_widths(*cn, H) || cn->in_dim < 1) return fail("%s: %d hidden layers (0..%d), in_dim %d", who, cn->n_hidden, CN_MAX_LAYERS, cn->in_dim);
   for (int l = 0; l < cn->n_hidden; ++l)
     if (H[l] < 1) return fail("%s: hidden layer %d has %d units", who, l, H[l]);
   *d = make_cn_dims(cn->in_dim, cn->n_hidden, H);

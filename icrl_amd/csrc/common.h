@@ -31,7 +31,7 @@ int policy_generic_check(const icrl_policy_t* p, const char* who);      // 0, or
 inline bool policy_is_wide(const icrl_policy_t* p) { return p->arch != nullptr || p->h1 > MAX_H || p->h2 > MAX_H; }
 // cn_train.hip: cost / discriminator forward of a constraint net with a hidden layer above MAX_H units or more than two of them (64 rows per workgroup)
 int launch_cn_cost_rows(const icrl_costnet_t* cn, const double* obs, const float* acs, int N, float* out, int mode, hipStream_t s);
-inline bool costnet_is_wide(const icrl_costnet_t* cn) { return cn->n_hidden > 2 || cn->h1 > MAX_H || (cn->n_hidden == 2 && cn->h2 > MAX_H); }
+inline bool costnet_is_wide(const icrl_costnet_t* cn) { return cn->n_hidden > 2 || cn->n_hidden == 0 || cn->h1 > MAX_H || (cn->n_hidden == 2 && cn->h2 > MAX_H); }
 
 // argument rejection: formats the reason into the calling thread's icrl_last_error() text, returns hipErrorInvalidValue
 int fail(const char* fmt, ...) __attribute__((format(printf, 1, 2)));

@@ -2773,7 +2773,7 @@ extern "C" int icrl_policy_prepare(const icrl_policy_t* p, void* stream) {
 }
 
 extern "C" int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream) {
-  if (cn->n_hidden > 2) return 0;      // served 64 rows per workgroup from `params` (cn_train.hip): no transposed copy
+  if (cn->n_hidden > 2 || cn->n_hidden == 0) return 0;      // served 64 rows per workgroup from `params` (cn_train.hip): no transposed copy
   if (!costnet_is_wide(cn) && !cn_ok(cn)) return bad_cn("icrl_costnet_prepare", cn);
   CnLayout L = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2);
   if (L.n != cn->n_params) return fail("icrl_costnet_prepare: n_params = %d, the layout needs %d", cn->n_params, L.n);

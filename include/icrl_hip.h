@@ -97,7 +97,7 @@ typedef struct {
 
 /* ConstraintNet zeta_theta (icrl/constraint_net.py:14-130,258-299): ReLU MLP + sigmoid over
  * concat(clip(obs), clip(acs))[select_dim]; cost = 1 - zeta.  n_hidden hidden layers of h1 .. h4 units (`-cl`, torch_layers.py:93-126):
- * 1 or 2 layers of up to 64 units inside the fused rollouts; 1..4 layers through icrl_cost_mlp_forward / icrl_disc_reward /
+ * 1 or 2 layers of up to 64 units inside the fused rollouts; 0..4 layers through icrl_cost_mlp_forward / icrl_disc_reward /
  * icrl_cn_train* (64 rows per workgroup) as long as the 64-row activation images fit the 160 KB LDS — e.g. 2 x 128, 3 x 96, 4 x 64 units
  * (refused with the byte count otherwise).  params flat in state_dict order: W0[h1,in] b0[h1] (W1[h2,h1] b1[h2] ...) Wo[1,h] bo[1]. */
 typedef struct {

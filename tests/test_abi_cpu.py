@@ -63,7 +63,7 @@ def test_refused_arguments_carry_a_reason():
 
 def test_generic_shape_limits_are_reported():
     """what the generic-shape path refuses (host arithmetic, before any launch): more than 4 layers per group / 256 units per layer in an
-    `arch` descriptor, constraint nets outside 1..4 hidden layers or beyond the LDS; icrl_ppo_generic_row_floats sizes the scratch."""
+    `arch` descriptor, constraint nets outside 0..4 hidden layers or beyond the LDS; icrl_ppo_generic_row_floats sizes the scratch."""
     from icrl_amd import _lib, structs as S
     L = _lib.lib()
     def pol(desc, n_params=1):
@@ -82,7 +82,7 @@ def test_generic_shape_limits_are_reported():
     assert L.icrl_ppo_generic_row_floats(ctypes.byref(p)) == -1 and b"300 units (1..256)" in L.icrl_last_error()
     cn = S.CostNetT(18, 6, 24, 5, 8, 8, 8, 8, 0, 1)
     err = L.icrl_cost_mlp_forward(ctypes.byref(cn), None, None, 4, None, None)
-    with pytest.raises(ValueError, match=r"5 hidden layers \(1\.\.4\)"):
+    with pytest.raises(ValueError, match=r"5 hidden layers \(0\.\.4\)"):
         _lib.check(err, "icrl_cost_mlp_forward")
     n_cn = (24 * 128 + 128) + 3 * (128 * 128 + 128) + 129
     cn = S.CostNetT(18, 6, 24, 4, 128, 128, 128, 128, 0, n_cn)

@@ -51,7 +51,8 @@ def test_cn_train_golden(golden, case):
                                                           # more than two hidden layers (-cl 64 64 64 ...): one activation image per layer
                                                           # and two alternating gradient images in the LDS
                                                           ("hc", [64, 64, 64], True, 3000, 1500, 1000), ("ant", [64, 48, 64, 32], True, 1500, 900, 500),
-                                                          ("hc", [96, 96, 96], False, 400, 300, 100), ("hc", [24, 20, 16, 12], True, 1000, 640, 500)])
+                                                          ("hc", [96, 96, 96], False, 400, 300, 100), ("hc", [24, 20, 16, 12], True, 1000, 640, 500),
+                                                          ("hc", [], True, 1000, 640, 500)])      # `-cl` without widths: sigmoid(Linear)
 def test_cn_train_vs_oracle(kind, hidden, psis, Nn, Ne, eplen):
     from icrl_amd.constraint_net import ConstraintNet
     rng = np.random.RandomState(Nn)
