@@ -21,6 +21,7 @@ the runs of a grid become resident oldest first and a run that does not fit yet 
 phases are not mixed (no update workgroup ever competes with rollout workgroups for a CU), which is why no admission control
 is needed.  Nothing else may occupy the GPU's CUs for long while a batch runs (include/icrl_hip.h: co-residency precondition).
 """
+import os
 import ctypes
 import time
 
@@ -75,6 +76,12 @@ def _jobs(cls, rows):
     return arr
 
 
+# The placement calibration of a run's exchange workspace (8 short update launches, PPOLagrangian._tune_sync_placement) pays for a run
+# that owns the GPU; in a batch the 3 S update workgroups sit on CUs all over the chip and the timed difference disappears — see the
+# measurement next to the switch's use in DESIGN.md section 9.  ICRL_SEED_TUNE=1 restores the per-run calibration.
+TUNE_PLACEMENT_IN_BATCH = os.environ.get("ICRL_SEED_TUNE", "0") == "1"
+
+
 class SeedBatch:
     def __init__(self, configs=None, states=None, on_setup=None):
         self.states = setup_runs(configs, on_setup) if states is None else states
@@ -125,6 +132,8 @@ class SeedBatch:
         for a, j in zip(agents, jobs):
             ws = a._train_ws
             if not ws["sync_tuned"]:          # first update of the run: where its exchange workspace is fastest (PPOLagrangian._tune_sync_placement)
+                if not TUNE_PLACEMENT_IN_BATCH and len(jobs) > 1:
+                    a.tune_sync_placement = False
                 a._tune_sync_placement(j)
             rows.append((addr(j["ps"]), p(a.policy.exp_avg), p(a.policy.exp_avg_sq), p(ws["t"]), addr(j["bs"]), p(j["perms"]), p(ws["nu"]), addr(j["hp"]),
                          p(ws["stats"]), p(ws["sync"])))
