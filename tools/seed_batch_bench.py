@@ -6,12 +6,13 @@ import bench
 from icrl_amd import seed_batch as SB
 
 for S in [int(x) for x in os.environ.get("SEEDS", "1,8,32,64").split(",")]:
-    sb = SB.SeedBatch([bench.config2(4, seed, 0, 1) for seed in range(S)])
+    sb = SB.SeedBatch([bench.config2(4 + int(os.environ.get('ITERS', '2')), seed, 0, 1) for seed in range(S)])
     sb.run(0, 1)
     steps0 = sum(st["timesteps"] for st in sb.states)
-    _, dt = sb.run(1, 2)
+    n_it = int(os.environ.get("ITERS", "2"))
+    _, dt = sb.run(1, n_it)
     steps = sum(st["timesteps"] for st in sb.states) - steps0
-    print(f"S={S:3d}: 2 iterations of every run in {dt:6.2f} s -> {steps / dt / 1e6:7.3f} M env-steps/s aggregate ({steps / dt / S / 1e3:7.1f} k per run)", flush=True)
+    print(f"S={S:3d}: {n_it} iterations of every run in {dt:6.2f} s -> {steps / dt / 1e6:7.3f} M env-steps/s aggregate ({steps / dt / S / 1e3:7.1f} k per run)", flush=True)
     if os.environ.get("PHASES"):       # where one lock-step iteration goes (host clock, synchronised at the phase boundaries)
         import icrl_amd.seed_batch as M
         t = {}
