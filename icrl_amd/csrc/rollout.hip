@@ -3433,7 +3433,12 @@ extern "C" int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* 
   };
   // registers: the narrow (HC-width) kernel leaves room for several workgroups per CU, so that several runs of the grid are resident
   // together; ICRL_ROLLOUT_MINW (tools) picks the allocation
-  static const int minw = getenv("ICRL_ROLLOUT_MINW") ? atoi(getenv("ICRL_ROLLOUT_MINW")) : 2;
+  // (all workgroups of the grid fit one per CU — up to 4 runs of 64 envs: the full register file per workgroup, 17 ms per 2048-step
+  // rollout against 29.6 with the two-per-CU allocation, measured at S = 1 and 4)
+  static const int minw_env = getenv("ICRL_ROLLOUT_MINW") ? atoi(getenv("ICRL_ROLLOUT_MINW")) : 0;
+  int dev_ = 0, cus_ = 256;
+  if (hipGetDevice(&dev_) != hipSuccess || hipDeviceGetAttribute(&cus_, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess) cus_ = 256;
+  const int minw = minw_env > 0 ? minw_env : ((long long)n_runs * N <= cus_ ? 1 : 2);
   int err;
   if (small && gran) err = minw >= 3 ? go(rollout_persistent_batch_kernel<2, 2, true, 3>) : (minw == 2 ? go(rollout_persistent_batch_kernel<2, 2, true, 2>) : go(rollout_persistent_batch_kernel<2, 2, true, 1>));
   else if (small) err = go(rollout_persistent_batch_kernel<2, 2, false, 2>);
