@@ -56,7 +56,7 @@ def kernel_stats(tag, which="bench"):
                    f"{sum(full) / len(full):.2f} ms each on average (from the kernel trace's timestamps).")
     head = (f"# rocprofv3 --kernel-trace --stats — bench.py --steps 2 --warmup 1 ({tag})\n\n"
             "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag> -- python3 bench.py --steps 2 "
-            "--warmup 1 --no_cpu_baseline --no_seed_batch --no_configs2 --no_configs3 --no_configs4` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 131 072)\n\n"
+            "--warmup 1 --no_cpu_baseline --no_seed_batch --no_configs2 --no_configs3 --no_configs4 --no_generic` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 131 072)\n\n"
             if which == "bench" else
             f"# rocprofv3 --kernel-trace --stats — BASELINE configs[2] (AntWall-v0, 256 envs, batch 128, [40, 40]) ({tag})\n\n"
             "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag>_antwall -- python3 tools/antwall_iter.py` "
