@@ -160,7 +160,7 @@ struct SmemP {  // offsets in floats (multiples of 4); same images as SmemR in p
 // MFMAs whose four k values are all padding (k = 16 js + 4 q + e >= obs for every q, i.e. 16 js + e >= obs) are not issued — at
 // obs 18 six of eight per tile remain, at obs 1 (LapGridWorld) one.  OBS == 0: every k step runs against the zero pad weights.
 template <int NT1, bool DISC, int OBS = 0>
-__device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const TrainArgs* const ka) {
+__device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const TrainArgs* const ka, const int role_arg) {
   using S = SmemP<NT1>;
   constexpr int SX = S::SX;
   constexpr int NW1 = NT1 / 2;          // observation column tiles of dW1 per wave
@@ -176,7 +176,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 #else
   extern __shared__ __attribute__((aligned(16))) float sm[];
 #endif
-  const int role = blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
+  const int role = role_arg;  // 0 policy, 1 reward critic, 2 cost critic
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -527,7 +527,9 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   int4 ps_next = ld_step(0), ps_nx2 = ld_step(1), ps_nx3 = ld_step(2);
   issue_stats(stat_idx(ps_next));
   int sidx_next = stat_idx(ps_nx2);
+  if (tid == 0) sm[S::MISC + 14] = run_on_one_xcd(xch, role, 3) ? 1.f : 0.f;
   __syncthreads();                      // initial weights visible (refresh_gauss reads log_std)
+  const bool xcd_local = __builtin_amdgcn_readfirstlane(__float_as_int(sm[S::MISC + 14])) != 0;
   refresh_gauss();
   int xcur = S::XT0;
   commit_rows(xcur);
@@ -1065,8 +1067,9 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
         }
       }
       const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
-      __hip_atomic_store(xch + (step & 1) * 32 + role * 8 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      // (xcd_local: the three workgroups share an XCD — the line stays in its L2 for the others' polls; ppo_common.h)
+      if (xcd_local) __hip_atomic_store(xch + (step & 1) * 32 + role * 8 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else __hip_atomic_store(xch + (step & 1) * 32 + role * 8 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // this workgroup reads its OWN eight partials from LDS (same floats, same summation order as everybody else's view of
       // them): the role that publishes last — the policy, the critical path — does not wait for its own stores to come back
       // through the memory system (~870 cycles)
@@ -1305,14 +1308,19 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 
 template <int NT1, bool DISC, int OBS>
 __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
-  ppo_train_pairs_body<NT1, DISC, OBS>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+  int run, role;
+  if (!packed_slot(3, 1, run, role)) return;
+  ppo_train_pairs_body<NT1, DISC, OBS>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), role);
 }
 
-// several independent runs in ONE launch: grid (3, n_runs), run = blockIdx.y; the argument blocks live in device memory
+// several independent runs in ONE launch: the packed 1-D grid of ppo_common.h (a run's workgroups on one XCD), or grid (3, n_runs) with
+// run = blockIdx.y when that many workgroups are not resident at once; the argument blocks live in device memory
 template <int NT1, bool DISC, int OBS>
-__global__ void __launch_bounds__(TH8) ppo_train_pairs_batch_kernel(const TrainArgs* __restrict__ runs) {
-  const TrainArgs* const ka = as_global(runs + blockIdx.y);
-  ppo_train_pairs_body<NT1, DISC, OBS>(*ka, ka);
+__global__ void __launch_bounds__(TH8) ppo_train_pairs_batch_kernel(const TrainArgs* __restrict__ runs, int n_runs, int packed) {
+  int run = (int)blockIdx.y, role = (int)blockIdx.x;      // run-major layout: grid (3, n_runs)
+  if (packed && !packed_slot(3, n_runs, run, role)) return;
+  const TrainArgs* const ka = as_global(runs + run);
+  ppo_train_pairs_body<NT1, DISC, OBS>(*ka, ka, role);
 }
 
 // one: single-run launch (argument block by value) | d_args: n_runs blocks in device memory
@@ -1324,11 +1332,12 @@ static int launch_pairs(const TrainArgs* one, const TrainArgs* d_args, int n_run
     hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
     TrainArgs arg = *one;
-    return (int)launch_coresident(ppo_train_pairs_kernel<NT1, DISC, OBS>, dim3(3), dim3(TH8), bytes, s, arg);
+    return (int)launch_coresident(ppo_train_pairs_kernel<NT1, DISC, OBS>, dim3(packed_grid(3, 1)), dim3(TH8), bytes, s, arg);
   } else {
     hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_batch_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((ppo_train_pairs_batch_kernel<NT1, DISC, OBS>), dim3(3, n_runs), dim3(TH8), bytes, s, d_args);
+    const int pg = packed_grid(3, n_runs);      // the runs' workgroups on one XCD each (ppo_common.h) when the whole grid is resident at once
+    hipLaunchKernelGGL((ppo_train_pairs_batch_kernel<NT1, DISC, OBS>), pg ? dim3(pg) : dim3(3, n_runs), dim3(TH8), bytes, s, d_args, n_runs, pg ? 1 : 0);
   }
   return (int)hipGetLastError();
 }

@@ -28,6 +28,13 @@
 // static LDS array instead of `extern __shared__` (ppo_train_pairs.hip: -1.6 % there).  Measured here: at AntWall widths 30.5 us per
 // step against 24.0 (scratch instructions 336 -> 424: the folded offsets let the optimiser hoist more than the register file holds),
 // at HC widths 10.1-10.3 against 10.2-10.5 — off.
+// granule store: workgroup scope (`sc0`: the line stays in this XCD's L2) when all workgroups of the run share an XCD, else agent
+// scope (ppo_common.h: XCD placement)
+#define GSTORE(ptr, val)                                                                              \
+  do {                                                                                                \
+    if (xcd_local) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  \
+    else __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                \
+  } while (0)
 #ifndef ICRL_EARLY_PUBLISH
 #define ICRL_EARLY_PUBLISH 1
 #endif
@@ -110,7 +117,7 @@ struct RemGroups {      // the groups the final pass still has to fetch
 };
 
 template <int NT1, bool DISC, bool SPLIT, bool BATCH>
-__device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const TrainArgs* const ka) {
+__device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const TrainArgs* const ka, const int slot_j) {
 #define GP(x) (BATCH ? as_global(x) : (x))
   using S = SmemR<NT1>;
   constexpr int SX = S::SX;
@@ -120,8 +127,8 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
 #else
   extern __shared__ __attribute__((aligned(16))) float sm[];
 #endif
-  const int role = SPLIT ? (int)blockIdx.x % 3 : (int)blockIdx.x;  // 0 policy, 1 reward critic, 2 cost critic
-  const int half = SPLIT ? (int)blockIdx.x / 3 : 0;                // SPLIT: which 64-row chunk of every minibatch this workgroup computes
+  const int role = slot_j % 3;   // 0 policy, 1 reward critic, 2 cost critic
+  const int half = slot_j / 3;   // SPLIT: which 64-row chunk of every minibatch this workgroup computes
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -391,7 +398,9 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
   int xcur = S::XT0;                    // X^T buffer of the chunk being processed
   commit_rows(xcur);
   stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
+  if (tid == 0) sm[S::MISC + 14] = run_on_one_xcd(xch, slot_j, SPLIT ? 6 : 3) ? 1.f : 0.f;
   __syncthreads();
+  const bool xcd_local = __builtin_amdgcn_readfirstlane(__float_as_int(sm[S::MISC + 14])) != 0;
   read_stats(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
   const float inv_n_mb = 1.f / (float)((T * N + a.hp.batch_size - 1) / a.hp.batch_size);
 
@@ -691,7 +700,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
         const u64 tg_ = (u64)step << 32;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-          __hip_atomic_store(mine_e + (size_t)(4 * g + i) * TH4, tg_ | (u64)__float_as_uint(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          GSTORE(mine_e + (size_t)(4 * g + i) * TH4, tg_ | (u64)__float_as_uint(v[i]));
       };
       // ICRL_EARLY_RECV (measured and rejected: 24.0 us per step against 22.5 with the early publish alone — a group that is looked at
       // inside the MFMA stream stalls it when it is late, and the in-order vmcnt makes every look wait for the stores issued since;
@@ -826,13 +835,13 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
 #pragma unroll
         for (int i = 0; i < 4; ++i)
           if (4 * g + i < KG)
-            __hip_atomic_store(mine + (size_t)(4 * g + i) * TH4, tg | (u64)__float_as_uint(v[i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            GSTORE(mine + (size_t)(4 * g + i) * TH4, tg | (u64)__float_as_uint(v[i]));
       }
       if (book) {
         const float ms[5] = {mb_s0, mb_s1, mb_s2, mb_s3, mb_s4};
 #pragma unroll
         for (int k = 0; k < 5; ++k)
-          __hip_atomic_store(mine + (size_t)(KG + k) * TH4, tg | (u64)__float_as_uint(ms[k]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          GSTORE(mine + (size_t)(KG + k) * TH4, tg | (u64)__float_as_uint(ms[k]));
       }
       // Fast pass, straight-line on purpose (any loop or branch between a load and its use makes the compiler wait for ALL
       // outstanding loads): DEP groups in flight, a group is added where all four of its granules carry this step's tag; the
@@ -938,8 +947,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
         }
       }
       const unsigned tag = step | (want_stop ? 0x80000000u : 0u);
-      __hip_atomic_store(xch + half * 32 + (step & 1) * 16 + role * 4 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
+      GSTORE(xch + half * 32 + (step & 1) * 16 + role * 4 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss));
       if (book) {
         ++steps_done;
         if (role == 0) {
@@ -1109,14 +1117,19 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
 
 template <int NT1, bool DISC, bool SPLIT>
 __global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
-  ppo_train_rows_body<NT1, DISC, SPLIT, false>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr());
+  int run, j;
+  if (!packed_slot(SPLIT ? 6 : 3, 1, run, j)) return;
+  ppo_train_rows_body<NT1, DISC, SPLIT, false>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), j);
 }
 
-// several independent runs in ONE launch: grid (3 or 6, n_runs), run = blockIdx.y
+// several independent runs in ONE launch: the packed 1-D grid of ppo_common.h (a run's workgroups on one XCD), or grid (3 or 6, n_runs)
+// with run = blockIdx.y when that many workgroups are not resident at once
 template <int NT1, bool DISC, bool SPLIT>
-__global__ void __launch_bounds__(TH4) ppo_train_rows_batch_kernel(const TrainArgs* __restrict__ runs) {
-  const TrainArgs* const ka = as_global(runs + blockIdx.y);
-  ppo_train_rows_body<NT1, DISC, SPLIT, true>(*ka, ka);
+__global__ void __launch_bounds__(TH4) ppo_train_rows_batch_kernel(const TrainArgs* __restrict__ runs, int n_runs, int packed) {
+  int run = (int)blockIdx.y, j = (int)blockIdx.x;
+  if (packed && !packed_slot(SPLIT ? 6 : 3, n_runs, run, j)) return;
+  const TrainArgs* const ka = as_global(runs + run);
+  ppo_train_rows_body<NT1, DISC, SPLIT, true>(*ka, ka, j);
 }
 
 template <int NT1, bool DISC, bool SPLIT>
@@ -1124,7 +1137,8 @@ static int launch_rows_batch(const TrainArgs* d_args, int n_runs, hipStream_t s)
   const size_t bytes = ICRL_ROWS_STATIC_LDS ? 0 : (size_t)SmemR<NT1>::TOTAL * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_batch_kernel<NT1, DISC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL((ppo_train_rows_batch_kernel<NT1, DISC, SPLIT>), dim3(SPLIT ? 6 : 3, n_runs), dim3(TH4), bytes, s, d_args);
+  const int pg = packed_grid(SPLIT ? 6 : 3, n_runs);
+  hipLaunchKernelGGL((ppo_train_rows_batch_kernel<NT1, DISC, SPLIT>), pg ? dim3(pg) : dim3(SPLIT ? 6 : 3, n_runs), dim3(TH4), bytes, s, d_args, n_runs, pg ? 1 : 0);
   return (int)hipGetLastError();
 }
 
@@ -1147,7 +1161,7 @@ static int launch_rows(const TrainArgs& a, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_kernel<NT1, DISC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
   TrainArgs arg = a;
-  return (int)launch_coresident(ppo_train_rows_kernel<NT1, DISC, SPLIT>, dim3(SPLIT ? 6 : 3), dim3(TH4), bytes, s, arg);
+  return (int)launch_coresident(ppo_train_rows_kernel<NT1, DISC, SPLIT>, dim3(packed_grid(SPLIT ? 6 : 3, 1)), dim3(TH4), bytes, s, arg);
 }
 
 int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hipStream_t s) {
