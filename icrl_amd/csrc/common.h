@@ -207,6 +207,33 @@ __device__ inline double np_pairwise_sum(const double* a, int n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// XCD placement of persistent workgroups that exchange granules (update kernels: ppo_common.h; batched multi-env rollout)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned xcc_id() {
+  unsigned v;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+  return v & 15u;
+}
+// called by ONE thread of workgroup j (of M) of a run; `words`: M zeroed 8-byte words of the run.  True when all M workgroups report
+// the same XCD (bounded wait: a workgroup that does not show up counts as elsewhere)
+__device__ __forceinline__ bool all_on_one_xcd(unsigned long long* words, int stride_words, int j, int M) {
+  const unsigned long long me = 0x100ull | (unsigned long long)xcc_id();
+  __hip_atomic_store(words + (size_t)j * stride_words, me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool same = true;
+  for (int o = 0; o < M; ++o) {
+    if (o == j) continue;
+    unsigned long long v = 0;
+    for (int spins = 0; spins < (1 << 18); ++spins) {
+      v = __hip_atomic_load(words + (size_t)o * stride_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (v != 0) break;
+      __builtin_amdgcn_s_sleep(8);
+    }
+    same = same && v == me;
+  }
+  return same;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // flat parameter layouts
 // ---------------------------------------------------------------------------------------------------------------
 struct PolLayout {

@@ -106,14 +106,9 @@ struct Cursor {
 // uses the `sc0` stores only when all workgroups of its run reported the same one; any other dispatch keeps the agent-scope stores.
 // Every granule carries its step tag, so a poll that is served a stale line retries.
 constexpr int XCD_STRIDE = 8;
-__device__ __forceinline__ unsigned xcc_id() {
-  unsigned v;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-  return v & 15u;
-}
 // spare words of the 64-word norm exchange area (both kernels' layouts leave 28..31 and 60..63 unused; zeroed before every launch)
 __device__ __forceinline__ int xcc_word(int j) { return j < 4 ? 28 + j : 56 + j; }
-// called by ONE thread of workgroup j (of M <= 6) of a run: true when all M report the same XCD (bounded wait: else false)
+// called by ONE thread of workgroup j (of M <= 6) of a run: true when all M report the same XCD (common.h: all_on_one_xcd)
 __device__ __forceinline__ bool run_on_one_xcd(unsigned long long* xch, int j, int M) {
   const unsigned long long me = 0x100ull | (unsigned long long)xcc_id();
   __hip_atomic_store(xch + xcc_word(j), me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1346,6 +1346,7 @@ struct WideArgs {
   int prof;                    // diagnostic phase timers of workgroup `prof - 1` (do_gae bit 2: workgroup 0; bit 3: the last one)
   unsigned long long* xg;      // [2][N][2 obs + 4] env granules {step tag | 32 payload bits}, zeroed before the launch
   unsigned long long* sg;      // [2][4 obs + 4] statistics granules, zeroed before the launch
+  unsigned long long* xcc;     // multi-env kernel, packed batched launches: G zeroed words (the workgroups' XCD ids), else NULL
 };
 
 template <int OCT, int CIT>
@@ -1662,6 +1663,7 @@ struct MultiShared {
   alignas(16) float noise[2][E][MAX_ACT];
   alignas(16) float alow[MAX_ACT];
   alignas(16) float ahigh[MAX_ACT];
+  int xcd_local;                             // all workgroups of this run share this XCD (rollout_multi_body)
   float scal[E][4], cost[E];
   double rew[E], mean[MAX_OBS], var[MAX_OBS], dens[2];
   unsigned ctr[E], key[E];
@@ -1835,7 +1837,7 @@ __device__ __noinline__ void env_step_wave3(int O, int A, int flags, int max_ste
 }
 
 template <int OCT, int CIT, int E>
-__device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
+__device__ __forceinline__ void rollout_multi_body(const WideArgs& p, const int g_arg) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ MultiShared<E, CIT> sh;
   const ActStepArgs& a = p.act;
@@ -1851,7 +1853,7 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   TileRegs<OCT, CIT> R;                // waves 0..2: policy / value / cost-value net, wave 3: cost net — as MFMA A operands
   if (threadIdx.x >= 192 && a.has_cn) load_cn_tiles<OCT, CIT>(a.cn, a.cl, R, sh.cst[3]);
   else load_pol_tiles<OCT, CIT>(a.pl, a.PT, R, sh.cst[threadIdx.x >> 6]);
-  const int g = blockIdx.x, G = p.G;
+  const int g = g_arg, G = p.G;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs, T = p.T;
@@ -1864,7 +1866,14 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   typedef unsigned int rec_u4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xg_all, 0, 2 * N * GX * 8, 0x00020000);
   const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(sg_all, 0, 2 * GS * 8, 0x00020000);
-  auto rstore = [](const __amdgpu_buffer_rsrc_t& rs, int byte_off, rec_u4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16); };   // sc1
+  // record stores: `sc1` (agent scope), or `sc0` when every workgroup of this run sits on this XCD (xcd_local, set below): the line then
+  // stays in the XCD's L2 for the other workgroups' `sc1` loads instead of being dropped (ppo_common.h, "XCD placement"; measured at
+  // HC x 64, 8 envs per workgroup: 12.2 -> 10.7 us per step).  Records carry their step tag at both ends: a stale read retries.
+  bool xcd_local = false;
+  auto rstore = [&](const __amdgpu_buffer_rsrc_t& rs, int byte_off, rec_u4 v) {
+    if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 1);      // sc0
+    else __builtin_amdgcn_raw_buffer_store_b128(v, rs, byte_off, 0, 16);               // sc1
+  };
   auto rload = [](const __amdgpu_buffer_rsrc_t& rs, int byte_off) -> rec_u4 { return __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16); };
   const int Eg = (N - g + G - 1) / G;                // envs of this workgroup (1 .. E)
   const bool has_cost = a.has_cn != 0;
@@ -1918,7 +1927,9 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
   const bool cn_box = a.has_cn && cnet.action_low != nullptr && cnet.action_high != nullptr;
   const double cn_clip = cnet.clip_obs;
   int spin_limit = 1 << 22;
+  if (p.xcc != nullptr && tid == 0) sh.xcd_local = all_on_one_xcd(as_global(p.xcc), 1, g, G) ? 1 : 0;
   __syncthreads();
+  if (p.xcc != nullptr) xcd_local = __builtin_amdgcn_readfirstlane(sh.xcd_local) != 0;
   const bool prof = p.prof != 0 && g == p.prof - 1 && blockIdx.y == 0;
   unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pcA = 0, pcB = 0, tl = prof ? prof_now() : 0ull;
   for (int t = 0; t < T; ++t) {
@@ -2371,20 +2382,27 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p) {
 
 template <int OCT, int CIT, int E>
 __global__ void __launch_bounds__(256) rollout_multi_kernel(WideArgs p) {
-  rollout_multi_body<OCT, CIT, E>(p);
+  rollout_multi_body<OCT, CIT, E>(p, (int)blockIdx.x);
 }
 
 // several independent runs in ONE launch: grid (G, n_runs), run = blockIdx.y
 template <int OCT, int CIT, int E>
-__global__ void __launch_bounds__(256) rollout_multi_batch_kernel(const WideArgs* __restrict__ runs) {
+__global__ void __launch_bounds__(256) rollout_multi_batch_kernel(const WideArgs* __restrict__ runs, int n_runs, int G, int packed) {
   __shared__ WideArgs p;
+  int run = (int)blockIdx.y, g = (int)blockIdx.x;
+  if (packed) {      // the G workgroups of a run on one XCD: workgroups b, b + 8, ... (ppo_common.h, "XCD placement")
+    const int id = (int)blockIdx.x, per = 8 * G;
+    run = (id / per) * 8 + (id & 7);
+    g = (id % per) >> 3;
+    if (run >= n_runs) return;
+  }
   {
-    const unsigned* src = reinterpret_cast<const unsigned*>(runs + blockIdx.y);
+    const unsigned* src = reinterpret_cast<const unsigned*>(runs + run);
     unsigned* dst = reinterpret_cast<unsigned*>(&p);
     for (unsigned i = threadIdx.x; i < sizeof(WideArgs) / 4; i += 256) dst[i] = src[i];
   }
   __syncthreads();
-  rollout_multi_body<OCT, CIT, E>(p);
+  rollout_multi_body<OCT, CIT, E>(p, g);
 }
 
 // VecNormalizeWithCost.reset (vec_normalize.py:148-157, 270-278)
@@ -3121,7 +3139,14 @@ static int launch_multi_e(const WideArgs* one, const WideArgs* d_args, int n_run
     return (int)e;
   } else {
     if (!persistent_fits(rollout_multi_batch_kernel<OCT, CIT, E>, G, dyn)) return -1;
-    hipLaunchKernelGGL((rollout_multi_batch_kernel<OCT, CIT, E>), dim3(G, n_runs), dim3(256), dyn, s, d_args);
+    // packed layout (a run's G workgroups on ONE XCD: workgroups b, b + 8, ...) when every XCD can hold its share of the grid at once
+    // (32 CUs each); otherwise run-major, whose runs become resident oldest first
+    int per_cu = 0;
+    const int groups = (n_runs + 7) / 8;
+    const bool packed = G <= 32 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rollout_multi_batch_kernel<OCT, CIT, E>, 256, dyn) == hipSuccess &&
+                        groups * G <= 32 * per_cu;
+    if (packed) hipLaunchKernelGGL((rollout_multi_batch_kernel<OCT, CIT, E>), dim3(8 * G * ((n_runs + 7) / 8)), dim3(256), dyn, s, d_args, n_runs, G, 1);
+    else hipLaunchKernelGGL((rollout_multi_batch_kernel<OCT, CIT, E>), dim3(G, n_runs), dim3(256), dyn, s, d_args, n_runs, G, 0);
   }
   return (int)hipGetLastError();
 }
@@ -3207,6 +3232,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
       p.act = a; p.nm = *nm; p.T = T; p.G = G; p.prof = (do_gae & 4) ? 1 : ((do_gae & 8) ? G : 0);
       p.xg = reinterpret_cast<unsigned long long*>(ws);
       p.sg = p.xg + 2 * (size_t)N * GX;
+      p.xcc = nullptr;
       hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
       if (e != hipSuccess) return (int)e;
       const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
@@ -3241,6 +3267,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
         p.act = a; p.nm = *nm; p.T = T; p.G = G; p.prof = (do_gae & 4) ? 1 : ((do_gae & 8) ? G : 0);
         p.xg = reinterpret_cast<unsigned long long*>(ws);
         p.sg = p.xg + 2 * (size_t)N * GX;
+        p.xcc = nullptr;
         hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
         if (e != hipSuccess) return (int)e;
         int err = (int)(small ? launch_coresident(rollout_wide_kernel<2, 2>, dim3(G), dim3(256), 0, s, p)
@@ -3367,7 +3394,9 @@ extern "C" int icrl_rollout_collect_batch(int n_runs, const icrl_rollout_job_t* 
         p.nm = *j.nm; p.T = T; p.G = G; p.prof = 0;
         p.xg = reinterpret_cast<unsigned long long*>(ws);
         p.sg = p.xg + 2 * (size_t)N * GX;
-        hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
+        // the workgroups' XCD ids: G words in the 256 spare bytes behind the statistics granules (`need` above)
+        p.xcc = G <= 32 ? p.sg + 2 * GS : nullptr;
+        hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS + (p.xcc ? 256 : 0), s);
         if (e != hipSuccess) return (int)e;
         const int pe = put_args(p, d_args + r, s);
         if (pe) return pe;
