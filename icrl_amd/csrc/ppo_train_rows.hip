@@ -39,7 +39,7 @@
 #define ICRL_EARLY_PUBLISH 1
 #endif
 #ifndef ICRL_EARLY_RECV
-#define ICRL_EARLY_RECV 0
+#define ICRL_EARLY_RECV 1
 #endif
 #ifndef ICRL_ROWS_STATIC_LDS
 #define ICRL_ROWS_STATIC_LDS 0
@@ -702,9 +702,10 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
         for (int i = 0; i < 4; ++i)
           GSTORE(mine_e + (size_t)(4 * g + i) * TH4, tg_ | (u64)__float_as_uint(v[i]));
       };
-      // ICRL_EARLY_RECV (measured and rejected: 24.0 us per step against 22.5 with the early publish alone — a group that is looked at
-      // inside the MFMA stream stalls it when it is late, and the in-order vmcnt makes every look wait for the stores issued since;
-      // off): the partner's groups fetched the same way — during dW1 tile c the granules of group early_group(c) (which
+      // ICRL_EARLY_RECV (on since the exchange is XCD-local: 19.6 us per step against 20.8 with the early publish alone; with agent-scope
+      // stores across XCDs it was 24.0 against 22.5 — a group that is looked at inside the MFMA stream stalls it when it is late, and
+      // the in-order vmcnt makes every look wait for the stores issued since — which is what a launch whose workgroups do NOT share an
+      // XCD still pays): the partner's groups fetched the same way — during dW1 tile c the granules of group early_group(c) (which
       // the partner published several tiles ago) are loaded, one tile later they are checked and added to the own (already
       // published) partial; a group that has not arrived is left to the polling pass below (`pend`).
       const u64* const theirs_e = SPLIT ? GP(KARGS()->gx) + ((size_t)((step & 1) * 3 + role) * 2 + (1 - half)) * ((size_t)(KG_ + 5) * TH4) + tid : nullptr;
