@@ -28,6 +28,12 @@
  * launch ends with icrl_agent_t.status bit 0 / stats[11] set and the host raises — buffers and statistics of that call are
  * invalid, nothing hangs.  Runs of one *_batch grid do not wait for each other: a run whose workgroups do not fit yet starts
  * when earlier runs of the grid have finished (dispatch is in grid order).
+ * XCD placement (speed only): the update launches and the batched multi-env rollout are 1-D grids in which the workgroups of run r sit
+ * at 8 M (r / 8) + r % 8 + 8 j, j < M (M = 3 | 6 | workgroups of the rollout; surplus workgroups of the grid leave at once) — workgroups are
+ * dealt round-robin over the 8 XCDs, so a run then sits on ONE XCD, and granules stored with workgroup scope stay in that XCD's L2 for
+ * the other workgroups' polls.  Nothing relies on it: every workgroup publishes its HW_REG_XCC_ID once per launch and the workgroup-scope
+ * stores are used only where all workgroups of a run reported the same XCD; batched grids too large for every XCD to hold its share at
+ * once (32 CUs) keep the run-major layout (3 | 6 | G, n_runs) and agent-scope stores.
  */
 #ifndef ICRL_HIP_H
 #define ICRL_HIP_H
@@ -415,7 +421,7 @@ typedef struct {
 } icrl_cn_train_job_t;
 int icrl_cn_train_batch(int n_runs, const icrl_cn_train_job_t* jobs, void* args_ws, long long args_ws_bytes, void* stream);
 
-/* icrl_ppo_lag_train for n_runs runs: grid (3 | 6, n_runs) persistent workgroups. */
+/* icrl_ppo_lag_train for n_runs runs: 3 | 6 persistent workgroups per run in one grid (layout: "XCD placement" at the top). */
 typedef struct {
   const icrl_policy_t* pol;
   float *exp_avg, *exp_avg_sq;
