@@ -2381,8 +2381,9 @@ __device__ __forceinline__ void rollout_multi_body(const WideArgs& p, const int 
 }
 
 template <int OCT, int CIT, int E>
-__global__ void __launch_bounds__(256) rollout_multi_kernel(WideArgs p) {
-  rollout_multi_body<OCT, CIT, E>(p, (int)blockIdx.x);
+__global__ void __launch_bounds__(256) rollout_multi_kernel(WideArgs p, int packed) {
+  if (packed && (blockIdx.x & 7)) return;      // the G <= 32 workgroups on one XCD: workgroups 0, 8, 16, ... (ppo_common.h, "XCD placement")
+  rollout_multi_body<OCT, CIT, E>(p, packed ? (int)(blockIdx.x >> 3) : (int)blockIdx.x);
 }
 
 // several independent runs in ONE launch: grid (G, n_runs), run = blockIdx.y
@@ -3134,7 +3135,9 @@ static int launch_multi_e(const WideArgs* one, const WideArgs* d_args, int n_run
   if (one != nullptr) {
     if (!persistent_fits(rollout_multi_kernel<OCT, CIT, E>, G, dyn)) return -1;
     WideArgs arg = *one;
-    const hipError_t e = launch_coresident(rollout_multi_kernel<OCT, CIT, E>, dim3(G), dim3(256), dyn, s, arg);
+    const int packed = arg.xcc != nullptr && G <= 32;
+    void* params[] = {(void*)&arg, (void*)&packed};
+    const hipError_t e = hipLaunchCooperativeKernel((const void*)rollout_multi_kernel<OCT, CIT, E>, dim3(packed ? 8 * (G - 1) + 1 : G), dim3(256), params, (unsigned)dyn, s);
     if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return -1; }
     return (int)e;
   } else {
@@ -3232,8 +3235,8 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
       p.act = a; p.nm = *nm; p.T = T; p.G = G; p.prof = (do_gae & 4) ? 1 : ((do_gae & 8) ? G : 0);
       p.xg = reinterpret_cast<unsigned long long*>(ws);
       p.sg = p.xg + 2 * (size_t)N * GX;
-      p.xcc = nullptr;
-      hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
+      p.xcc = G <= 32 ? p.sg + 2 * GS : nullptr;      // (the workgroups' XCD ids: the 256 spare bytes behind the statistics granules)
+      hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS + (p.xcc ? 256 : 0), s);
       if (e != hipSuccess) return (int)e;
       const bool small = a.pl.O <= 32 && (!cn || cn->in_dim <= 32);
       const int err = launch_multi(small, !cn || cn->in_dim <= 128, E, &p, nullptr, 1, G, multi_dyn_lds(N, O, env->act_dim, (n_stats + G - 1) / G), s);
