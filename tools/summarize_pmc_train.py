@@ -38,7 +38,11 @@ for f in _passes:
             name = k.split("(")[0].split("::")[-1].replace("void ", "")
         per[(name, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
         dur[(name, r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
-        waves[name] = int(r["Workgroup_Size"]) // 64 * int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+        # the WORKING waves: the update launches are 1-D grids of 8 (M - 1) + 1 workgroups of which M = 3 or 6 (the run's, at b, b + 8,
+        # ...: one XCD) do the work and the others leave at once (their cycles are noise in the sums)
+        wgs = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
+        wgs = (wgs - 1) // 8 + 1 if wgs > 6 else wgs
+        waves[name] = int(r["Workgroup_Size"]) // 64 * wgs
     # Only the FULL launches (STEPS optimiser steps) count: every process also makes 8 short calibration launches of the same kernel
     # (PPOLagrangian._tune_sync_placement: 256 steps each at HC), and a median over all launches divided by STEPS would describe those
     # (round 3's tables did: 1 376 "cycles per wave-step" for a kernel that takes 21 334).  A full launch is one that lasts at least
