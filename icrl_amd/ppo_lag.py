@@ -477,8 +477,12 @@ class PPOLagrangian:
     # virtual address does not tell — tools/sync_placement.py).  Which position is the near one is not knowable up front, so the first
     # train() of an agent times a short update (one epoch over <= 16 384 rows of the rollout it is about to train on, identity
     # permutation, parameters and moments restored afterwards) at SYNC_CANDIDATES positions 1 MB apart and keeps the fastest.
+    # OFF since the update's workgroups sit on one XCD and store their granules with workgroup scope (csrc/ppo_common.h, "XCD
+    # placement"): the hop is served by that XCD's L2 and the position of the bytes in device memory no longer shows — measured with /
+    # without the calibration: HC 8.25 / 8.25 us per step, AntWall 19.6 / 19.6.  The mechanism stays for a dispatch that does not give
+    # a run one XCD (the kernels then fall back to agent-scope stores): agent.tune_sync_placement = True.
     SYNC_CANDIDATES = 4
-    tune_sync_placement = True
+    tune_sync_placement = False
 
     def _tune_sync_placement(self, job):
         ws, pol, rb = self._train_ws, self.policy, self.rollout_buffer

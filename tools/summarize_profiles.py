@@ -51,9 +51,9 @@ def kernel_stats(tag, which="bench"):
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in csv.DictReader(open(tr)) if "ppo_train_" in r["Kernel_Name"] and "perm" not in r["Kernel_Name"] and "plan" not in r["Kernel_Name"]]
         if d:
             full = [x for x in d if x >= 0.5 * max(d)]
-            upd = (f"The update kernel's calls include {len(d) - len(full)} short calibration launches (`PPOLagrangian._tune_sync_placement`: the first `train()` of an agent "
-                   f"times one epoch over <= 16 384 rows at four positions of its exchange workspace, twice); the {len(full)} updates proper last "
-                   f"{sum(full) / len(full):.2f} ms each on average (from the kernel trace's timestamps).")
+            cal = (f"The update kernel's calls include {len(d) - len(full)} short calibration launches (`PPOLagrangian._tune_sync_placement`: the first `train()` of an agent "
+                   f"times one epoch over <= 16 384 rows at four positions of its exchange workspace, twice); " if len(d) > len(full) else "")
+            upd = cal + f"the {len(full)} updates proper last {sum(full) / len(full):.2f} ms each on average (from the kernel trace's timestamps)."
     head = (f"# rocprofv3 --kernel-trace --stats — bench.py --steps 2 --warmup 1 ({tag})\n\n"
             "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag> -- python3 bench.py --steps 2 "
             "--warmup 1 --no_cpu_baseline --no_seed_batch --no_configs2 --no_configs3 --no_configs4 --no_generic` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 131 072)\n\n"

@@ -15,6 +15,8 @@ lo = -np.ones(ad, np.float32)
 cn = ConstraintNet(od, ad, [20] if kind == "hc" else [40, 40], None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
 env.set_cost_function(cn.cost_function)
 agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, batch_size=B, n_epochs=int(os.environ.get("EPOCHS", "2")), seed=0, permutation="device")
+if os.environ.get("TUNE") == "0":
+    agent.tune_sync_placement = False       # (A/B: no placement calibration of the exchange workspace)
 agent._setup_learn(N * T)
 agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost")
 torch.cuda.synchronize(); t0 = time.time()
