@@ -101,6 +101,17 @@ inline hipError_t launch_coresident(K kernel, dim3 grid, dim3 block, size_t dyn_
   void* params[] = {(void*)&arg};
   return hipLaunchCooperativeKernel((const void*)kernel, grid, block, params, (unsigned)dyn_lds, s);
 }
+// the same with a second, scalar kernel argument
+template <class K, class A>
+inline hipError_t launch_coresident(K kernel, dim3 grid, dim3 block, size_t dyn_lds, hipStream_t s, A& arg, int arg2) {
+  static const bool plain = getenv("ICRL_PLAIN_LAUNCH") != nullptr;
+  if (plain) {
+    hipLaunchKernelGGL(kernel, grid, block, dyn_lds, s, arg, arg2);
+    return hipGetLastError();
+  }
+  void* params[] = {(void*)&arg, (void*)&arg2};
+  return hipLaunchCooperativeKernel((const void*)kernel, grid, block, params, (unsigned)dyn_lds, s);
+}
 
 template <class T>
 __global__ void put_args_kernel(T v, T* dst) {

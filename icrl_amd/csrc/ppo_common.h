@@ -135,8 +135,9 @@ __device__ __forceinline__ bool packed_slot(int M, int n_runs, int& run, int& j)
 // grid of the packed layout; 0: the runs' workgroups could not all be resident on their XCDs at once (32 CUs each, one workgroup per
 // CU) — the caller then uses the run-major layout, whose runs become resident oldest first
 inline int packed_grid(int M, int n_runs) {
+  static const bool off = getenv("ICRL_NO_XCD_PACK") != nullptr;      // tests / A/B: the run-major layout (agent-scope stores) everywhere
   const int groups = (n_runs + XCD_STRIDE - 1) / XCD_STRIDE;
-  if (groups * M > 30) return 0;
+  if (off || groups * M > 30) return 0;
   return n_runs >= XCD_STRIDE ? groups * XCD_STRIDE * M : XCD_STRIDE * (M - 1) + n_runs;
 }
 

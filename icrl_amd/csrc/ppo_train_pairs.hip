@@ -1307,9 +1307,9 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 }
 
 template <int NT1, bool DISC, int OBS>
-__global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a) {
-  int run, role;
-  if (!packed_slot(3, 1, run, role)) return;
+__global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a, int packed) {
+  int run = 0, role = (int)blockIdx.x;
+  if (packed && !packed_slot(3, 1, run, role)) return;
   ppo_train_pairs_body<NT1, DISC, OBS>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), role);
 }
 
@@ -1332,7 +1332,8 @@ static int launch_pairs(const TrainArgs* one, const TrainArgs* d_args, int n_run
     hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
     TrainArgs arg = *one;
-    return (int)launch_coresident(ppo_train_pairs_kernel<NT1, DISC, OBS>, dim3(packed_grid(3, 1)), dim3(TH8), bytes, s, arg);
+    const int pg = packed_grid(3, 1);
+    return (int)launch_coresident(ppo_train_pairs_kernel<NT1, DISC, OBS>, dim3(pg ? pg : 3), dim3(TH8), bytes, s, arg, pg ? 1 : 0);
   } else {
     hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_batch_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;

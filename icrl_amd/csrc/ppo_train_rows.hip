@@ -1117,9 +1117,9 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
 }
 
 template <int NT1, bool DISC, bool SPLIT>
-__global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a) {
-  int run, j;
-  if (!packed_slot(SPLIT ? 6 : 3, 1, run, j)) return;
+__global__ void __launch_bounds__(TH4) ppo_train_rows_kernel(TrainArgs a, int packed) {
+  int run = 0, j = (int)blockIdx.x;
+  if (packed && !packed_slot(SPLIT ? 6 : 3, 1, run, j)) return;
   ppo_train_rows_body<NT1, DISC, SPLIT, false>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), j);
 }
 
@@ -1162,7 +1162,8 @@ static int launch_rows(const TrainArgs& a, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_kernel<NT1, DISC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
   TrainArgs arg = a;
-  return (int)launch_coresident(ppo_train_rows_kernel<NT1, DISC, SPLIT>, dim3(packed_grid(SPLIT ? 6 : 3, 1)), dim3(TH4), bytes, s, arg);
+  const int pg = packed_grid(SPLIT ? 6 : 3, 1);
+  return (int)launch_coresident(ppo_train_rows_kernel<NT1, DISC, SPLIT>, dim3(pg ? pg : (SPLIT ? 6 : 3)), dim3(TH4), bytes, s, arg, pg ? 1 : 0);
 }
 
 int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hipStream_t s) {

@@ -3135,7 +3135,8 @@ static int launch_multi_e(const WideArgs* one, const WideArgs* d_args, int n_run
   if (one != nullptr) {
     if (!persistent_fits(rollout_multi_kernel<OCT, CIT, E>, G, dyn)) return -1;
     WideArgs arg = *one;
-    const int packed = arg.xcc != nullptr && G <= 32;
+    static const bool no_pack = getenv("ICRL_NO_XCD_PACK") != nullptr;
+    const int packed = !no_pack && arg.xcc != nullptr && G <= 32;
     void* params[] = {(void*)&arg, (void*)&packed};
     const hipError_t e = hipLaunchCooperativeKernel((const void*)rollout_multi_kernel<OCT, CIT, E>, dim3(packed ? 8 * (G - 1) + 1 : G), dim3(256), params, (unsigned)dyn, s);
     if (e == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return -1; }
@@ -3146,7 +3147,8 @@ static int launch_multi_e(const WideArgs* one, const WideArgs* d_args, int n_run
     // (32 CUs each); otherwise run-major, whose runs become resident oldest first
     int per_cu = 0;
     const int groups = (n_runs + 7) / 8;
-    const bool packed = G <= 32 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rollout_multi_batch_kernel<OCT, CIT, E>, 256, dyn) == hipSuccess &&
+    static const bool no_pack_b = getenv("ICRL_NO_XCD_PACK") != nullptr;
+    const bool packed = !no_pack_b && G <= 32 && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, rollout_multi_batch_kernel<OCT, CIT, E>, 256, dyn) == hipSuccess &&
                         groups * G <= 32 * per_cu;
     if (packed) hipLaunchKernelGGL((rollout_multi_batch_kernel<OCT, CIT, E>), dim3(8 * G * ((n_runs + 7) / 8)), dim3(256), dyn, s, d_args, n_runs, G, 1);
     else hipLaunchKernelGGL((rollout_multi_batch_kernel<OCT, CIT, E>), dim3(G, n_runs), dim3(256), dyn, s, d_args, n_runs, G, 0);

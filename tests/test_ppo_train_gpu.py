@@ -1,6 +1,8 @@
 """GPU parity of the persistent PPO-Lagrangian update kernel (icrl_ppo_lag_train) vs the reference (golden g4) and the
 oracle's epoch loop (teacher-forced permutations).  fp32 tolerance: the kernel's MFMA dot products, tanh/exp and Adam
 differ from torch-CPU by rounding order; after k dependent Adam steps parameters agree to ~1e-5 absolute (lr 3e-4)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -208,6 +210,22 @@ def test_two_chunk_minibatches_on_one_workgroup_per_network(N, T, B):
     partial gradients (covered by test_train_vs_oracle above); hp._pad bit 3 keeps the sequential two-chunk loop of a single
     workgroup — same tolerances against the oracle."""
     test_train_vs_oracle("ant", N, T, B, 2, None, one_workgroup_per_network=True)
+
+
+def test_run_major_layout_equals_packed_layout():
+    """the persistent update kernels and the multi-env rollout put a run's workgroups on one XCD (1-D grid: b, b + 8, ...) and store
+    their granules with workgroup scope when every workgroup of the run reports the same XCD; any other dispatch uses the run-major
+    grid and agent-scope stores.  Placement and store scope are speed matters only: ICRL_NO_XCD_PACK=1 forces the second form, and
+    everything an update and a rollout leave must be bit-identical (child process: the switch is read once per process)."""
+    import subprocess, sys
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "helpers", "xcd_layout_child.py")
+    digests = []
+    for extra in ({}, {"ICRL_NO_XCD_PACK": "1"}):
+        env = dict(os.environ, **extra)
+        out = subprocess.run([sys.executable, child], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append([l for l in out.stdout.splitlines() if l.startswith("DIGEST")][-1])
+    assert digests[0] == digests[1]
 
 
 @pytest.mark.parametrize("kind,N,T,B", [("hc", 64, 256, 64), ("ant", 64, 256, 128)])
