@@ -225,7 +225,10 @@ class SeedBatch:
             r.prepare(base=int(b))
         todo = list(range(len(runs)))
         rewards = [None] * len(runs)
+        dbg = os.environ.get("ICRL_SEED_DEBUG")
         while todo:
+            if dbg:
+                torch.cuda.synchronize(); t_dbg = time.time()
             sub = [runs[i] for i in todo]
             if len({r.n_streams for r in sub}) == 1:
                 self._launch_episodes(sub)
@@ -240,6 +243,9 @@ class SeedBatch:
                 else:           # an episode ended early: the run repeats with the positions the measured lengths imply
                     r.prepare()
                     again.append(i)
+            if dbg:
+                torch.cuda.synchronize()
+                print(f"[episodes] pass over {len(todo)} run(s), streams {sorted({r.n_streams for r in sub})}: {1e3 * (time.time() - t_dbg):.1f} ms, {len(again)} to repeat", flush=True)
             todo = again
         return runs, rewards
 
