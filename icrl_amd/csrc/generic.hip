@@ -241,12 +241,12 @@ __global__ void __launch_bounds__(3 * GEN_MAX_H) gen_forward_backward_kernel(Gen
         const float* d = dz + y.act_off;
         const int n_o = y.out_dim, n_i = y.in_dim;
         int i = 0;
-        for (; i + 8 <= n_o; i += 8) {      // (eight weights in flight before the eight dependent fmas; same chain order)
-          float wv[8];
+        for (; i + GEN_AHEAD <= n_o; i += GEN_AHEAD) {      // (GEN_AHEAD weights in flight before their dependent fmas; same chain order)
+          float wv[GEN_AHEAD];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(i + u) * n_i];
+          for (int u = 0; u < GEN_AHEAD; ++u) wv[u] = w[(size_t)(i + u) * n_i];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) t = fmaf(wv[u], d[i + u], t);
+          for (int u = 0; u < GEN_AHEAD; ++u) t = fmaf(wv[u], d[i + u], t);
         }
         for (; i < n_o; ++i) t = fmaf(w[(size_t)i * n_i], d[i], t);
       }
