@@ -19,6 +19,9 @@
 // The forward reads the weights from `params_t` = the per-layer transposes (icrl_policy_prepare; the update keeps both images current).
 #include "ppo_common.h"
 #include "generic.h"
+#ifndef GEN_ROWS_AHEAD
+#define GEN_ROWS_AHEAD 8      // rows whose operands the weight-gradient kernel fetches ahead of their dependent fmas
+#endif
 
 namespace icrl {
 
@@ -286,34 +289,34 @@ __global__ void __launch_bounds__(256) gen_wgrad_kernel(GenNet net, GenArgs a, i
         int r = 0;
         if (y.in_buf < 0) {
           const float* ob = a.buf.observations + k;
-          for (; r + 8 <= nb; r += 8) {
-            float d[8], x[8];
+          for (; r + GEN_ROWS_AHEAD <= nb; r += GEN_ROWS_AHEAD) {
+            float d[GEN_ROWS_AHEAD], x[GEN_ROWS_AHEAD];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { d[u] = DZ[(size_t)(r + u) * RF + j]; x[u] = ob[(size_t)rowidx[r + u] * O]; }
+            for (int u = 0; u < GEN_ROWS_AHEAD; ++u) { d[u] = DZ[(size_t)(r + u) * RF + j]; x[u] = ob[(size_t)rowidx[r + u] * O]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) g = fmaf(d[u], x[u], g);
+            for (int u = 0; u < GEN_ROWS_AHEAD; ++u) g = fmaf(d[u], x[u], g);
           }
           for (; r < nb; ++r) g = fmaf(DZ[(size_t)r * RF + j], ob[(size_t)rowidx[r] * O], g);
         } else {
           const float* in = ACT + net.layer[y.in_buf].act_off + k;
-          for (; r + 8 <= nb; r += 8) {
-            float d[8], x[8];
+          for (; r + GEN_ROWS_AHEAD <= nb; r += GEN_ROWS_AHEAD) {
+            float d[GEN_ROWS_AHEAD], x[GEN_ROWS_AHEAD];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { d[u] = DZ[(size_t)(r + u) * RF + j]; x[u] = in[(size_t)(r + u) * RF]; }
+            for (int u = 0; u < GEN_ROWS_AHEAD; ++u) { d[u] = DZ[(size_t)(r + u) * RF + j]; x[u] = in[(size_t)(r + u) * RF]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) g = fmaf(d[u], x[u], g);
+            for (int u = 0; u < GEN_ROWS_AHEAD; ++u) g = fmaf(d[u], x[u], g);
           }
           for (; r < nb; ++r) g = fmaf(DZ[(size_t)r * RF + j], in[(size_t)r * RF], g);
         }
       } else {                                 // b[j]
         const int j = e - y.b_off;
         int r = 0;
-        for (; r + 8 <= nb; r += 8) {
-          float d[8];
+        for (; r + GEN_ROWS_AHEAD <= nb; r += GEN_ROWS_AHEAD) {
+          float d[GEN_ROWS_AHEAD];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) d[u] = DZ[(size_t)(r + u) * RF + j];
+          for (int u = 0; u < GEN_ROWS_AHEAD; ++u) d[u] = DZ[(size_t)(r + u) * RF + j];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) g += d[u];
+          for (int u = 0; u < GEN_ROWS_AHEAD; ++u) g += d[u];
         }
         for (; r < nb; ++r) g += DZ[(size_t)r * RF + j];
       }
