@@ -343,11 +343,17 @@ __global__ void __launch_bounds__(256) gen_adam_kernel(GenNet net, GenArgs a, in
     const float c = a.hp.max_grad_norm / (sqrtf(total) + 1e-6f);
     coef = c > 1.f ? 1.f : c;
   }
+  // bias corrections in double, once per block (two pow() calls per thread were a third of this kernel's time)
+  __shared__ float bc_s[2];
+  if (tid == 0) {
+    const double t = (double)(a.adam_t[0] + step + 1);
+    bc_s[0] = (float)((double)a.hp.lr / (1.0 - pow((double)a.hp.adam_beta1, t)));
+    bc_s[1] = (float)(1.0 / sqrt(1.0 - pow((double)a.hp.adam_beta2, t)));
+  }
+  __syncthreads();
   const int e = blockIdx.x * 256 + tid;
   if (e < n_params) {
-    const double t = (double)(a.adam_t[0] + step + 1);
-    const float step_size = (float)((double)a.hp.lr / (1.0 - pow((double)a.hp.adam_beta1, t)));
-    const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow((double)a.hp.adam_beta2, t)));
+    const float step_size = bc_s[0], inv_bc2_sqrt = bc_s[1];
     const float g = a.scratch[gen_off_grad(B, RF) + e] * coef;
     const float b1 = a.hp.adam_beta1, b2 = a.hp.adam_beta2;
     const float m = fmaf((float)(1.0 - (double)b1), g, b1 * a.exp_avg[e]);
