@@ -54,7 +54,7 @@ __host__ __device__ inline size_t gen_off_act(int B) { return gen_off_g2(B) + (s
 __host__ __device__ inline size_t gen_off_dz(int B, int RF) { return gen_off_act(B) + (size_t)B * RF; }
 __host__ __device__ inline size_t gen_off_grad(int B, int RF) { return gen_off_dz(B, RF) + (size_t)B * RF; }
 __host__ __device__ inline size_t gen_off_part(int B, int RF, int n_params) { return gen_off_grad(B, RF) + (size_t)n_params; }
-__host__ __device__ inline size_t gen_floats(int B, int RF, int n_params) { return gen_off_part(B, RF, n_params) + (size_t)(n_params + 255) / 256 + 64; }
+__host__ __device__ inline size_t gen_floats(int B, int RF, int n_params) { return gen_off_part(B, RF, n_params) + (size_t)(n_params + 255) / 256 + 1088; }
 
 // position of parameter e in the transposed image: weights W[j][k] -> Wt[k][j] inside their layer's block, everything else in place
 __device__ __forceinline__ int gen_transposed_index(const GenNet& net, int e) {
@@ -327,13 +327,84 @@ __global__ void __launch_bounds__(256) gen_wgrad_kernel(GenNet net, GenArgs a, i
   if (threadIdx.x == 0) a.scratch[gen_off_part(B, RF, net.n) + blockIdx.x] = ss;
 }
 
+// The same gradients by 16 x 16 parameter tiles: workgroup = one tile W[16 jt .., 16 kt ..] of one layer (thread (tj, tk) = one
+// parameter; the threads tk = 0 of the tiles kt = 0 also carry the bias b[16 jt + tj]), the rows' dz and inputs staged through LDS
+// 64 rows at a time — every staged value is read 16 times from LDS instead of once per parameter from L2.  Each parameter still adds
+// its rows in row order (same chain as gen_wgrad_kernel: bit-identical gradients); workgroup 0 does log_std.  Partial squared norms:
+// one per workgroup (a different grouping than gen_wgrad_kernel's 256 consecutive parameters: the clip coefficient can differ in the
+// last bit).
+constexpr int GEN_TILE = 16, GEN_TROWS = 64;
+__host__ __device__ inline int gen_tiles_of(const GenLayer& y) { return ((y.out_dim + GEN_TILE - 1) / GEN_TILE) * ((y.in_dim + GEN_TILE - 1) / GEN_TILE); }
+
+__global__ void __launch_bounds__(256) gen_wgrad_tiled_kernel(GenNet net, GenArgs a, int nb) {
+  __shared__ float red[256];
+  __shared__ float dzs[GEN_TROWS][GEN_TILE + 1], ins[GEN_TROWS][GEN_TILE + 1];
+  const GenCtl* ctl = reinterpret_cast<const GenCtl*>(a.scratch);
+  if (ctl->stop) return;
+  const int B = a.B, RF = net.row_floats, O = net.O, tid = threadIdx.x;
+  float* grad = a.scratch + gen_off_grad(B, RF);
+  float g = 0.f, gb = 0.f;
+  if (blockIdx.x == 0) {      // log_std: sum_rows dlp (dd^2 / var - 1), and d(ent_coef * -mean H) / d log_std = -ent_coef
+    if (!net.discrete && tid < net.A) {
+      const float* g2 = a.scratch + gen_off_g2(B) + tid;
+      int r = 0;
+      for (; r + 16 <= nb; r += 16) {      // (sixteen rows' terms in flight before their dependent adds: one load per iteration made this
+        float v[16];                       // workgroup the kernel's longest at large batches)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = g2[(size_t)(r + u) * 16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) g += v[u];
+      }
+      for (; r < nb; ++r) g += g2[(size_t)r * 16];
+      g += -a.hp.ent_coef;
+      grad[tid] = g;
+    }
+  } else {
+    int t = (int)blockIdx.x - 1, l = 0;
+    while (l < net.n_layers - 1 && t >= gen_tiles_of(net.layer[l])) { t -= gen_tiles_of(net.layer[l]); ++l; }
+    const GenLayer& y = net.layer[l];
+    const int ktiles = (y.in_dim + GEN_TILE - 1) / GEN_TILE, jt = t / ktiles, kt = t - jt * ktiles;
+    const int tj = tid >> 4, tk = tid & 15, j = jt * GEN_TILE + tj, k = kt * GEN_TILE + tk;
+    const int* rowidx = reinterpret_cast<const int*>(a.scratch + gen_off_rowidx(B));
+    const float* ACT = a.scratch + gen_off_act(B);
+    const float* DZ = a.scratch + gen_off_dz(B, RF) + y.act_off;
+    const float* IN = y.in_buf < 0 ? nullptr : ACT + net.layer[y.in_buf].act_off;
+    const bool bias = kt == 0 && tk == 0;
+    for (int r0 = 0; r0 < nb; r0 += GEN_TROWS) {
+      // stage 64 rows x 16 columns of dz (columns 16 jt ..) and of the layer's input (columns 16 kt ..): four values of each per thread, all in flight together
+      for (int i = tid; i < GEN_TROWS * GEN_TILE; i += 256) {
+        const int rr = i >> 4, c = i & 15, r = r0 + rr;
+        float dv = 0.f, xv = 0.f;
+        if (r < nb) {
+          if (jt * GEN_TILE + c < y.out_dim) dv = DZ[(size_t)r * RF + jt * GEN_TILE + c];
+          if (kt * GEN_TILE + c < y.in_dim)
+            xv = IN == nullptr ? a.buf.observations[(size_t)rowidx[r] * O + kt * GEN_TILE + c] : IN[(size_t)r * RF + kt * GEN_TILE + c];
+        }
+        dzs[rr][c] = dv; ins[rr][c] = xv;
+      }
+      __syncthreads();
+      const int nr = nb - r0 < GEN_TROWS ? nb - r0 : GEN_TROWS;
+      for (int rr = 0; rr < nr; ++rr) {
+        const float d = dzs[rr][tj];
+        g = fmaf(d, ins[rr][tk], g);
+        gb += d;
+      }
+      __syncthreads();
+    }
+    if (j < y.out_dim && k < y.in_dim) grad[y.w_off + (size_t)j * y.in_dim + k] = g; else g = 0.f;
+    if (bias && j < y.out_dim) grad[y.b_off + j] = gb; else gb = 0.f;
+  }
+  const float ss = block_sum(fmaf(g, g, gb * gb), red);
+  if (tid == 0) a.scratch[gen_off_part(B, RF, net.n) + blockIdx.x] = ss;
+}
+
 // clip_grad_norm_ + torch.optim.Adam (single-tensor form) on every parameter (both images: params and its per-layer transposes);
 // block 0 keeps the statistics of the step.  Sums are fixed trees over the block (block_sum): every block forms the same total.
-__global__ void __launch_bounds__(256) gen_adam_kernel(GenNet net, GenArgs a, int step, int epoch, int mb, int nb) {
+__global__ void __launch_bounds__(256) gen_adam_kernel(GenNet net, GenArgs a, int n_parts, int step, int epoch, int mb, int nb) {
   __shared__ float red[256];
   GenCtl* ctl = reinterpret_cast<GenCtl*>(a.scratch);
   if (ctl->stop) return;
-  const int B = a.B, RF = net.row_floats, n_params = net.n, nblk = (n_params + 255) / 256, tid = threadIdx.x;
+  const int B = a.B, RF = net.row_floats, n_params = net.n, nblk = n_parts, tid = threadIdx.x;      // n_parts: partial squared norms the gradient kernel left
   float coef;
   {
     const float* part = a.scratch + gen_off_part(B, RF, n_params);
@@ -403,7 +474,7 @@ __global__ void gen_finish_kernel(GenArgs a, int* adam_t) {
   adam_t[0] += ctl->steps_done;
 }
 
-static_assert(ICRL_PPO_GENERIC_BYTES(64, 776, 1000) == 4 * (64 + 64 * (24 + 1 + 16 + 2 * 776) + 1000 + 4 + 64), "ICRL_PPO_GENERIC_BYTES");
+static_assert(ICRL_PPO_GENERIC_BYTES(64, 776, 1000) == 4 * (64 + 64 * (24 + 1 + 16 + 2 * 776) + 1000 + 4 + 1088), "ICRL_PPO_GENERIC_BYTES");
 
 // perm_off: the permutations already mapped to storage offsets (prepare in ppo_train.hip); scratch: ICRL_PPO_GENERIC_BYTES
 int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
@@ -421,6 +492,10 @@ int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   hipError_t e = hipMemsetAsync(scratch, 0, 64 * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   const int nblk = (net.n + 255) / 256;
+  int n_tiles = 1;      // workgroups of gen_wgrad_tiled_kernel: log_std + the 16 x 16 tiles of every layer
+  for (int l = 0; l < net.n_layers; ++l) n_tiles += gen_tiles_of(net.layer[l]);
+  static const bool flat = getenv("ICRL_GEN_WGRAD_FLAT") != nullptr;      // A/B: one thread per parameter straight from L2 (gen_wgrad_kernel)
+  const bool tiled = !flat && n_tiles <= nblk + 1024;                      // (partial-norm slots of the scratch)
   hipLaunchKernelGGL(gen_transpose_kernel, dim3(nblk), dim3(256), 0, s, net, pol->params, pol->params_t);
   int step = 0;
   for (int ep = 0; ep < hp->n_epochs; ++ep)
@@ -430,8 +505,9 @@ int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
       const int base = ep * a.n_total + p0;
       hipLaunchKernelGGL(gen_stats_kernel, dim3(1), dim3(256), 0, s, a, base, nb);
       hipLaunchKernelGGL(gen_forward_backward_kernel, dim3(nb), dim3(3 * net.W), 0, s, net, a, base, nb);
-      hipLaunchKernelGGL(gen_wgrad_kernel, dim3(nblk), dim3(256), 0, s, net, a, nb);
-      hipLaunchKernelGGL(gen_adam_kernel, dim3(nblk), dim3(256), 0, s, net, a, step, ep, mb, nb);
+      if (tiled) hipLaunchKernelGGL(gen_wgrad_tiled_kernel, dim3(n_tiles), dim3(256), 0, s, net, a, nb);
+      else hipLaunchKernelGGL(gen_wgrad_kernel, dim3(nblk), dim3(256), 0, s, net, a, nb);
+      hipLaunchKernelGGL(gen_adam_kernel, dim3(nblk), dim3(256), 0, s, net, a, tiled ? n_tiles : nblk, step, ep, mb, nb);
     }
   hipLaunchKernelGGL(gen_finish_kernel, dim3(1), dim3(1), 0, s, a, adam_step);
   return (int)hipGetLastError();

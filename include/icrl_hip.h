@@ -177,7 +177,7 @@ typedef struct {
  * workspace, sync_ws then holds ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(...) bytes.  row_floats = the outputs of every layer
  * of one row = icrl_ppo_generic_row_floats(pol) (6 h + act_dim + 2 for the padded two-layer layout of common width h) */
 #define ICRL_PPO_GENERIC_BYTES(batch_size, row_floats, n_params) \
-  (4 * (64 + (size_t)(batch_size) * (24 + 1 + 16 + 2 * (size_t)(row_floats)) + (size_t)(n_params) + ((size_t)(n_params) + 255) / 256 + 64))
+  (4 * (64 + (size_t)(batch_size) * (24 + 1 + 16 + 2 * (size_t)(row_floats)) + (size_t)(n_params) + ((size_t)(n_params) + 255) / 256 + 1088))
 #define ICRL_CN_METRICS 24 /* floats per iteration in the metrics array of icrl_cn_train */
 
 /* ------------------------------------------------------------------------------------------------------------------
