@@ -14,7 +14,7 @@
 // and deterministic, not latency-tuned: every BASELINE config runs on the fast kernels.
 //
 //   icrl_policy_forward / icrl_policy_evaluate      -> policy_generic_kernel            (policies.py:716-731, 752-767)
-//   icrl_ppo_lag_train                              -> per optimiser step: gen_stats | gen_forward_backward | gen_wgrad | gen_adam
+//   icrl_ppo_lag_train                              -> per optimiser step: gen_forward_backward | gen_wgrad_tiled | gen_adam (+ the next step's gen_stats)
 //                                                      (ppo_lag.py:196-299, torch.optim.Adam, clip_grad_norm_)
 // The forward reads the weights from `params_t` = the per-layer transposes (icrl_policy_prepare; the update keeps both images current).
 #include "ppo_common.h"
@@ -140,10 +140,8 @@ __device__ __forceinline__ float block_sum(float v, float* red) {      // fixed 
 
 // advantage statistics of the minibatch (ppo_lag.py:219-222: reward advantages standardised with torch's unbiased std, cost
 // advantages centred only)
-__global__ void __launch_bounds__(256) gen_stats_kernel(GenArgs a, int perm_base, int nb) {
-  __shared__ float red[256];
+__device__ __forceinline__ void gen_stats_body(const GenArgs& a, int perm_base, int nb, float* red) {
   GenCtl* ctl = reinterpret_cast<GenCtl*>(a.scratch);
-  if (ctl->stop) return;
   float sr = 0.f, sc = 0.f;
   for (int i = threadIdx.x; i < nb; i += 256) { const int idx = a.perm_off[perm_base + i]; sr += a.buf.reward_advantages[idx]; sc += a.buf.cost_advantages[idx]; }
   const float mean_r = block_sum(sr, red) / (float)nb, mean_c = block_sum(sc, red) / (float)nb;
@@ -151,6 +149,13 @@ __global__ void __launch_bounds__(256) gen_stats_kernel(GenArgs a, int perm_base
   for (int i = threadIdx.x; i < nb; i += 256) { const float d = a.buf.reward_advantages[a.perm_off[perm_base + i]] - mean_r; ss += d * d; }
   const float var = block_sum(ss, red) / (float)(nb - 1);
   if (threadIdx.x == 0) { ctl->mean_r = mean_r; ctl->mean_c = mean_c; ctl->istd_r = 1.f / (sqrtf(var) + 1e-8f); }
+}
+
+// (the first step's; every later step's statistics are formed by the last workgroup of the previous step's gen_adam_kernel)
+__global__ void __launch_bounds__(256) gen_stats_kernel(GenArgs a, int perm_base, int nb) {
+  __shared__ float red[256];
+  if (reinterpret_cast<const GenCtl*>(a.scratch)->stop) return;
+  gen_stats_body(a, perm_base, nb, red);
 }
 
 // forward, loss and activation backward of ONE minibatch row through the whole network: grid nb, block 3 * W
@@ -400,7 +405,7 @@ __global__ void __launch_bounds__(256) gen_wgrad_tiled_kernel(GenNet net, GenArg
 
 // clip_grad_norm_ + torch.optim.Adam (single-tensor form) on every parameter (both images: params and its per-layer transposes);
 // block 0 keeps the statistics of the step.  Sums are fixed trees over the block (block_sum): every block forms the same total.
-__global__ void __launch_bounds__(256) gen_adam_kernel(GenNet net, GenArgs a, int n_parts, int step, int epoch, int mb, int nb) {
+__global__ void __launch_bounds__(256) gen_adam_kernel(GenNet net, GenArgs a, int n_parts, int step, int epoch, int mb, int nb, int next_base, int next_nb) {
   __shared__ float red[256];
   GenCtl* ctl = reinterpret_cast<GenCtl*>(a.scratch);
   if (ctl->stop) return;
@@ -463,6 +468,12 @@ __global__ void __launch_bounds__(256) gen_adam_kernel(GenNet net, GenArgs a, in
       }
     }
   }
+  // the advantage statistics of the NEXT minibatch (read by the next step's forward / backward launch): the last workgroup, behind its
+  // share of the update — one launch less per step.  (The statistics in `ctl` were last read by this step's forward / backward.)
+  if (next_nb > 0 && blockIdx.x == gridDim.x - 1) {
+    __syncthreads();
+    gen_stats_body(a, next_base, next_nb, red);
+  }
 }
 
 __global__ void gen_finish_kernel(GenArgs a, int* adam_t) {
@@ -503,11 +514,15 @@ int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
       const int p0 = mb * hp->batch_size;
       const int nb = a.n_total - p0 < hp->batch_size ? a.n_total - p0 : hp->batch_size;
       const int base = ep * a.n_total + p0;
-      hipLaunchKernelGGL(gen_stats_kernel, dim3(1), dim3(256), 0, s, a, base, nb);
+      if (step == 0) hipLaunchKernelGGL(gen_stats_kernel, dim3(1), dim3(256), 0, s, a, base, nb);
       hipLaunchKernelGGL(gen_forward_backward_kernel, dim3(nb), dim3(3 * net.W), 0, s, net, a, base, nb);
       if (tiled) hipLaunchKernelGGL(gen_wgrad_tiled_kernel, dim3(n_tiles), dim3(256), 0, s, net, a, nb);
       else hipLaunchKernelGGL(gen_wgrad_kernel, dim3(nblk), dim3(256), 0, s, net, a, nb);
-      hipLaunchKernelGGL(gen_adam_kernel, dim3(nblk), dim3(256), 0, s, net, a, tiled ? n_tiles : nblk, step, ep, mb, nb);
+      // (the next step's minibatch: position p0 + batch_size of this epoch, or the start of the next epoch)
+      const bool last = ep == hp->n_epochs - 1 && mb == a.n_mb - 1;
+      const int np0 = mb + 1 < a.n_mb ? p0 + hp->batch_size : 0, nep = mb + 1 < a.n_mb ? ep : ep + 1;
+      const int next_nb = last ? 0 : (a.n_total - np0 < hp->batch_size ? a.n_total - np0 : hp->batch_size);
+      hipLaunchKernelGGL(gen_adam_kernel, dim3(nblk), dim3(256), 0, s, net, a, tiled ? n_tiles : nblk, step, ep, mb, nb, last ? 0 : nep * a.n_total + np0, next_nb);
     }
   hipLaunchKernelGGL(gen_finish_kernel, dim3(1), dim3(1), 0, s, a, adam_step);
   return (int)hipGetLastError();

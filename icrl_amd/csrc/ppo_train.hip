@@ -982,7 +982,7 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
 }
 
 // shapes the persistent kernels refuse (hidden widths above 64, architectures given by icrl_policy_t.arch, minibatches above 256 rows):
-// the generic-shape path of generic.hip, four plain launches per optimiser step.  Its scratch lies behind the regular workspace:
+// the generic-shape path of generic.hip, three plain launches per optimiser step.  Its scratch lies behind the regular workspace:
 // sync_ws must then hold ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(batch_size, row_floats, n_params) bytes.
 static int train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
                          const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws, hipStream_t s) {

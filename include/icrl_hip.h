@@ -337,7 +337,7 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
  *            chunk of a minibatch, partial gradients exchanged as granules) unless bit 3 is set.
  * Shapes outside the persistent kernels — a policy stored with hidden width h1 = h2 > 64 (a multiple of 64 up to 256: the reference's
  * -pl / -rvl / -cvl flags take any width, icrl/utils.py:636-655), a policy described by `arch` (shared trunk, other depths) or
- * batch_size > 256 (buffers.py:594-612 slices any size) — run through the generic-shape path (csrc/generic.hip): four plain launches
+ * batch_size > 256 (buffers.py:594-612 slices any size) — run through the generic-shape path (csrc/generic.hip): three plain launches
  * per optimiser step, same statistics layout, no hp->_pad options; sync_ws must then hold ICRL_PPO_SYNC_BYTES(...) +
  * ICRL_PPO_GENERIC_BYTES(batch_size, icrl_ppo_generic_row_floats(pol), n_params) bytes. */
 int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
