@@ -264,7 +264,10 @@ def configs2_leg(seed, steps=2, warmup=1):
 
 def gae_sweep_point(N=131072, T=2048, reps=20):
     """the same entry point at 131 072 envs: working set 9.7 GB >> 256 MB Infinity Cache, the HBM-streaming regime (the library
-    picks the four-columns-per-lane streaming shape from 65 536 envs on; bit-exact like the one-column scan)."""
+    picks the four-columns-per-lane streaming shape from 65 536 envs on; bit-exact like the one-column scan).  In the same process,
+    on the same stream and buffers, interleaved with the GAE launches: `icrl_debug_stream_ref` mode 0 (the launch shape and the
+    5-loads-4-stores traffic of the GAE kernel without its recurrence: the same 9.66 GB) and mode 1 (a flat float4 copy, 8.59 GB) —
+    what THIS box streams, so that the kernel can be judged apart from the box's HBM rate."""
     from icrl_amd import _lib
     L = _lib.lib()
     dev = torch.device("cuda")
@@ -273,18 +276,31 @@ def gae_sweep_point(N=131072, T=2048, reps=20):
     ld = torch.zeros(N, dtype=torch.uint8, device=dev)
     outs = [torch.empty(T, N, device=dev) for _ in range(4)]
     args = [_lib.ptr(x) for x in (*ins, *lv, ld, *outs)]
+    cargs = [_lib.ptr(x) for x in (*ins, *outs)]
     st = _lib.current_stream()
-    for _ in range(5):
-        L.icrl_gae_dual(*args, T, N, 0.99, 0.95, 0.99, 0.95, st)
+    launch = {"gae": lambda: L.icrl_gae_dual(*args, T, N, 0.99, 0.95, 0.99, 0.95, st),
+              "ref": lambda: L.icrl_debug_stream_ref(*cargs, T, N, 0, st),
+              "copy": lambda: L.icrl_debug_stream_ref(*cargs, T, N, 1, st)}
+    for f in launch.values():
+        for _ in range(3):
+            _lib.check(f(), "gae sweep")
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        L.icrl_gae_dual(*args, T, N, 0.99, 0.95, 0.99, 0.95, st)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    return dict(envs=N, T=T, bytes=T * N * 36, us=ms * 1e3, achieved=T * N * 36 / (ms * 1e-3) / 1e9)
+    ms = {k: [] for k in launch}
+    rounds, per = 4, max(1, reps // 4)
+    for _ in range(rounds):                     # interleaved rounds: a drifting HBM clock hits all three alike
+        for k, f in launch.items():
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(per):
+                f()
+            e1.record()
+            torch.cuda.synchronize()
+            ms[k].append(e0.elapsed_time(e1) / per)
+    t = {k: float(np.mean(v)) for k, v in ms.items()}
+    gbs = lambda nbytes, k: nbytes / (t[k] * 1e-3) / 1e9
+    return dict(envs=N, T=T, bytes=T * N * 36, us=t["gae"] * 1e3, achieved=gbs(T * N * 36, "gae"),
+                ref_gbs=gbs(T * N * 36, "ref"), ref_us=t["ref"] * 1e3, copy_gbs=gbs(T * N * 32, "copy"), copy_us=t["copy"] * 1e3,
+                launches=rounds * per)
 
 
 def gae_roofline(sweep, in_loop):
@@ -306,6 +322,14 @@ def gae_roofline(sweep, in_loop):
              at=f"T={sweep['T']}, N={sweep['envs']} envs: {sweep['bytes'] / 1e9:.2f} GB algorithmic (36 B/transition), "
                 f"{sweep['us']:.0f} us/launch — far beyond the 256 MB Infinity Cache; four columns per lane (16-byte accesses), "
                 f"{sweep['envs'] // 256} one-wave workgroups")
+    # self-normalisation: the same bytes through the same launch shape without the recurrence, and a flat float4 copy, timed
+    # in this process on this stream between the GAE launches (HBM rate differs box to box by more than the kernel does)
+    r.update(copy_gbs=round(sweep["ref_gbs"], 1), frac_of_copy=round(sweep["achieved"] / sweep["ref_gbs"], 4),
+             copy_kernel="stream_ref_x4_kernel<4> (icrl_debug_stream_ref mode 0): grid, 5 non-temporal 16-byte loads + 4 stores per lane and row and "
+                         f"bytes of the GAE launch, no recurrence: {sweep['ref_us']:.0f} us/launch",
+             flat_copy_gbs=round(sweep["copy_gbs"], 1), frac_of_flat_copy=round(sweep["achieved"] / sweep["copy_gbs"], 4),
+             flat_copy_kernel=f"stream_copy_kernel (mode 1): four grid-stride float4 copies, {sweep['T'] * sweep['envs'] * 32 / 1e9:.2f} GB, {sweep['copy_us']:.0f} us",
+             launches_timed=sweep["launches"])
     if in_loop is not None:
         r["in_loop"] = in_loop
     return r
@@ -331,34 +355,39 @@ def seed_batch_leg(sizes=(8, 32, 64)):
 
 
 def cpu_baseline():
-    """oracle CPU port (`oracle.loop.icrl_port`, pinned bit-for-bit to the reference's own icrl() by tests/golden/g8) timed on
-    a BOUNDED sample of the same workload: one whole outer ICRL iteration of configs[1] — forward step (rollouts + PPO-Lagrangian
-    updates), 10 nominal + 10 evaluation episodes, constraint-net update, both KL metrics — with n_steps 256 instead of 2048.
-    The forward step's cost is proportional to n_steps (same work per env step and per minibatch), the rest does not depend on
-    it, so the full-size iteration time is 8 x t_forward + t_rest; value = 2 x 64 x 2048 env steps / that.  Run with the 8 torch
-    intra-op threads the reference's own measurement used, and with 1."""
+    """oracle CPU port (`oracle.loop.icrl_port`, pinned bit-for-bit to the reference's own icrl() by tests/golden/g8) timed on the
+    host: ONE whole outer ICRL iteration of configs[1] at FULL size — 2 rollouts of 64 x 2048 + 2 PPO-Lagrangian updates of
+    10 epochs x 2048 minibatches, 10 nominal + 10 evaluation episodes, constraint-net update, both KL metrics — on 1 torch thread
+    (the faster setting for 64-wide MLPs; measured, no extrapolation; ~45 s).  The 8-thread figure the reference's own measurement
+    used is taken on a bounded sample (n_steps 256, same work per env step and per minibatch) and reported beside it."""
     from oracle import loop as o_loop
     ex = np.load(os.path.join(ROOT, "tests/golden/expert_hc.npz"))
     esd = {k[len("policy/"):]: ex[k] for k in ex.files if k.startswith("policy/")}
-    T, scale = 256, 8
-    cfg = dict(train_env_id="HCWithPos-v0", eval_env_id="HCWithPosTest-v0", num_threads=64, seed=0, n_steps=T, batch_size=64, n_epochs=10,
-               target_kl=0.01, cn_layers=(20,), cn_learning_rate=0.05, anneal_clr_by_factor=0.9, cn_reg_coeff=0.5,
-               per_step_importance_sampling=True, cn_target_kl_new_old=2.5, backward_iters=10, forward_timesteps=2 * 64 * T - 1,
-               n_iters=30, expert_rollouts=10)
-    res = {}
-    for threads in (min(8, os.cpu_count() or 1), 1):
+
+    def run(T, threads):
+        cfg = dict(train_env_id="HCWithPos-v0", eval_env_id="HCWithPosTest-v0", num_threads=64, seed=0, n_steps=T, batch_size=64, n_epochs=10,
+                   target_kl=0.01, cn_layers=(20,), cn_learning_rate=0.05, anneal_clr_by_factor=0.9, cn_reg_coeff=0.5,
+                   per_step_importance_sampling=True, cn_target_kl_new_old=2.5, backward_iters=10, forward_timesteps=2 * 64 * T - 1,
+                   n_iters=30, expert_rollouts=10)
         torch.set_num_threads(threads)
         m, steps, dt, _ = o_loop.icrl_port(cfg, ex["observations"][:5000], ex["actions"][:5000], esd, n_iters=1)
-        full = scale * m[0]["time/forward_s"] + m[0]["time/rest_s"]
-        res[threads] = (scale * steps / full, m[0]["time/forward_s"], m[0]["time/rest_s"], steps)
-    k = max(res, key=lambda n_: res[n_][0])               # the faster of the two thread counts is the baseline (fair to the CPU)
-    kk = max(res)
-    return dict(value=res[k][0], unit="env-steps/s", cores=k, kind="port", value_1_thread=res[1][0], **{f"value_{kk}_threads": res[kk][0]},
-                sample=f"one whole outer ICRL iteration of the same workload with n_steps={T} instead of 2048 ({res[k][3]} env steps of "
-                       f"the forward step: {res[kk][1]:.1f} s on {kk} torch threads / {res[1][1]:.1f} s on 1; sampling + constraint-net update "
-                       f"+ evaluation + KL metrics: {res[kk][2]:.1f} s / {res[1][2]:.1f} s), extrapolated to n_steps 2048 as 8 x forward + rest; "
-                       f"host {os.cpu_count()} logical cores.  In the build container the port's learn() step runs 1.46x the "
-                       f"reference's (BASELINE.md section 2: 1382 vs 944 env-steps/s)")
+        return steps, m[0]["time/forward_s"], m[0]["time/rest_s"]
+
+    steps, fwd, rest = run(2048, 1)
+    value = steps / (fwd + rest)
+    kk = min(8, os.cpu_count() or 1)
+    s8, f8, r8 = run(256, kk)
+    v8 = 8 * s8 / (8 * f8 + r8)
+    ratio = 1382.0 / 944.0      # BASELINE.md section 4: port vs reference, learn() of this shape in the build container
+    return dict(value=value, unit="env-steps/s", cores=1, kind="port", value_1_thread=value,
+                reference_equivalent=value / ratio,
+                reference_equivalent_note="value / 1.46: in the build container the port's learn() of this shape runs 1 382 env-steps/s against the "
+                                          "reference's 944 (BASELINE.md section 4); the reference itself cannot travel to the GPU box",
+                **{f"value_{kk}_threads_sample": v8},
+                sample=f"one whole outer ICRL iteration of the same workload at full size (n_steps 2048: {steps} env steps, 40 960 optimiser "
+                       f"steps before target-KL stops) on 1 torch thread: forward step {fwd:.1f} s + sampling, constraint-net update, "
+                       f"evaluation and KL metrics {rest:.1f} s, measured; the {kk}-thread figure from an n_steps 256 sample "
+                       f"({s8} env steps: {f8:.1f} s + {r8:.1f} s, forward scaled by 8); host {os.cpu_count()} logical cores")
 
 
 def main():

@@ -44,6 +44,7 @@ SIGNATURES = {
     "icrl_debug_rollout_profile": [c_void_p],
     "icrl_debug_rollout_profile_wide": [c_void_p],
     "icrl_debug_rollout_trace_wide": [c_void_p, c_int],
+    "icrl_debug_stream_ref": [c_void_p] * 9 + [c_int, c_int, c_int, c_void_p],
     "icrl_cn_train_minibatch": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p],
     # batched forms (several independent runs in one launch, run = blockIdx.y): n_runs, jobs[n_runs], ..., args_ws, bytes, stream

@@ -383,6 +383,50 @@ __global__ void __launch_bounds__(64 * G) gae_dual_x4_kernel(GaeArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Diagnostic (bench.py: `roofline.copy_gbs`): the memory traffic of gae_dual_x4_kernel<4, 1> WITHOUT its recurrence — the same grid
+// (one wave per 256 columns walking the T rows from the last one down), the same five non-temporal 16-byte loads and four stores
+// per lane and row, U rows in flight twice — so that a bench line can quote the GAE kernel against what the SAME box, process and
+// stream deliver for the same bytes (HBM rate varies box to box more than the kernel does).  mode 1: a flat grid-stride 1:1 copy.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int U>
+__global__ void __launch_bounds__(64) stream_ref_x4_kernel(GaeArgs a) {
+  const unsigned n = 4u * (blockIdx.x * 64 + threadIdx.x);
+  if (n >= (unsigned)a.N) return;
+  auto run = [&](int t_top, const Batch4<U>& b) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t_top - u;
+      if (t >= 0) {
+        const size_t row = (size_t)t * a.N;
+        stg4(a.ar + row + n, b.r[u] + b.d[u]);
+        stg4(a.ac + row + n, b.c[u]);
+        stg4(a.rr + row + n, b.vr[u]);
+        stg4(a.rc + row + n, b.vc[u]);
+      }
+    }
+  };
+  int t = a.T - 1;
+  Batch4<U> b0, b1;
+  load_batch4<U>(a, n, t, b0);
+  while (true) {
+    if (t - U >= 0) load_batch4<U>(a, n, t - U, b1);
+    run(t, b0);
+    t -= U;
+    if (t < 0) break;
+    if (t - U >= 0) load_batch4<U>(a, n, t - U, b0);
+    run(t, b1);
+    t -= U;
+    if (t < 0) break;
+  }
+}
+
+__global__ void __launch_bounds__(256) stream_copy_kernel(const f4* __restrict__ src, f4* __restrict__ dst, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
 }  // namespace
 
 // every split launch tags its workspace flags with a process-wide counter value, so nothing is cleared between launches
@@ -477,7 +521,24 @@ extern "C" int icrl_gae_dual(const float* rewards, const float* costs, const flo
                           stream);
 }
 
-extern "C" int icrl_abi_version(void) { return 102; }
+extern "C" int icrl_debug_stream_ref(const float* in0, const float* in1, const float* in2, const float* in3, const float* in4,
+                                     float* out0, float* out1, float* out2, float* out3, int T, int N, int mode, void* stream) {
+  if (T <= 0 || N <= 0 || N % 4 != 0) return fail("icrl_debug_stream_ref: T = %d, N = %d (N %% 4 == 0)", T, N);
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) {
+    GaeArgs a{in0, in1, in2, in3, in4, nullptr, nullptr, nullptr, out0, out1, out2, out3, T, N, 0.f, 0.f, 0.f, 0.f};
+    hipLaunchKernelGGL((stream_ref_x4_kernel<4>), dim3((N / 4 + 63) / 64), dim3(64), 0, s, a);
+  } else {
+    const float* src[4] = {in0, in1, in2, in3};
+    float* dst[4] = {out0, out1, out2, out3};
+    const size_t n4 = (size_t)T * N / 4;
+    for (int k = 0; k < 4; ++k)
+      hipLaunchKernelGGL(stream_copy_kernel, dim3(256 * 16), dim3(256), 0, s, reinterpret_cast<const f4*>(src[k]), reinterpret_cast<f4*>(dst[k]), n4);
+  }
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_abi_version(void) { return 103; }
 
 // icrl_gae_dual_ws for n_runs rollouts of one shape in ONE launch (the loop-size launches of several runs sharing a GPU): the
 // two-level scan over workgroups, every run with its own workspace.  Shapes the split scan does not serve (> 128 column tiles, T too

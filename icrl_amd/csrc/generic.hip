@@ -27,7 +27,7 @@ namespace icrl {
 
 struct GenCtl {      // first 64 floats of the generic scratch, zeroed at the start of a train() launch sequence
   float mean_r, istd_r, mean_c;
-  int stop, steps_done, early_stop_epoch;
+  int stop, steps_done, early_stop_epoch;      // stop: 0, or 1 + the index of the optimiser step that decided the target-KL early stop
   float kl_acc;
   float acc_ent, acc_pg, acc_cf, acc_vl_r, acc_vl_c, last_pol, last_vl_r, last_vl_c, mean_kl;
 };
@@ -408,7 +408,11 @@ __global__ void __launch_bounds__(256) gen_wgrad_tiled_kernel(GenNet net, GenArg
 __global__ void __launch_bounds__(256) gen_adam_kernel(GenNet net, GenArgs a, int n_parts, int step, int epoch, int mb, int nb, int next_base, int next_nb) {
   __shared__ float red[256];
   GenCtl* ctl = reinterpret_cast<GenCtl*>(a.scratch);
-  if (ctl->stop) return;
+  // The stop word holds 1 + the step that decided it, and only LATER steps leave: workgroup 0 of this very launch may write it below
+  // while other workgroups (or waves of one workgroup) are still being dispatched, and the reference applies the epoch's last
+  // optimizer.step() in full before it breaks (ppo_lag.py:286-297) — a plain flag would let late workgroups skip their share of it.
+  const int stop_at = ctl->stop;
+  if (stop_at != 0 && stop_at <= step) return;
   const int B = a.B, RF = net.row_floats, n_params = net.n, nblk = n_parts, tid = threadIdx.x;      // n_parts: partial squared norms the gradient kernel left
   float coef;
   {
@@ -464,7 +468,7 @@ __global__ void __launch_bounds__(256) gen_adam_kernel(GenNet net, GenArgs a, in
         const float mean_kl = ctl->kl_acc / (float)a.n_mb;
         ctl->mean_kl = mean_kl;
         a.stats[32 + epoch] = mean_kl;
-        if (a.hp.use_target_kl && mean_kl > 1.5f * a.hp.target_kl) { ctl->stop = 1; ctl->early_stop_epoch = epoch; }
+        if (a.hp.use_target_kl && mean_kl > 1.5f * a.hp.target_kl) { ctl->stop = step + 1; ctl->early_stop_epoch = epoch; }
       }
     }
   }

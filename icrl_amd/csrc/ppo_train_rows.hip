@@ -41,6 +41,16 @@
 #ifndef ICRL_ROWS_REC16
 #define ICRL_ROWS_REC16 0
 #endif
+// SPLIT exchange as RAW 16-byte stores + ONE flag per wave (round 5): a gradient group is four floats of a lane — one dwordx4 store, no
+// tags — and when a wave has stored all its groups it drains its stores (s_waitcnt vmcnt(0): a store is acknowledged by the L2 it was
+// written through to) and raises a flag word carrying the step; the same wave of the other half polls that flag and then fetches the
+// groups with L1-bypassing loads.  A quarter of the memory instructions of the tagged granules (14 stores + 14 loads per lane and step
+// instead of 55 + 55) and half their bytes; the exchange was request-rate-bound.  What it gives up is the early receive (nothing can be
+// fetched before the flag).  Both halves still form own + partner, so they stay bit-identical replicas, and the sums are the granule
+// path's sums: results are bit-identical to it.
+#ifndef ICRL_ROWS_RAWX
+#define ICRL_ROWS_RAWX 1
+#endif
 #ifndef ICRL_EARLY_PUBLISH
 #define ICRL_EARLY_PUBLISH 1
 #endif
@@ -435,7 +445,20 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
 
     const int n_chunks = SPLIT ? 1 : (nb + RB - 1) / RB;
     unsigned pend = 0;      // SPLIT: gradient groups of the other half that had not arrived when they were looked at
-#if ICRL_ROWS_REC16
+#if ICRL_ROWS_RAWX
+    typedef unsigned int raw_u4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(SPLIT ? GP(KARGS()->gx) : nullptr, 0, (int)ICRL_PPO_SPLIT_BYTES, 0x00020000);
+    constexpr int XBLK = (4 * NT1 + 23 + 5) * TH4 * 8;          // bytes of one (parity, role, half) block (the granule layout's size)
+    constexpr int XFLAG = (NT1 + 7) * TH4 * 16;                 // NT1 + 6 groups + the book-keeping lane's record, then one flag word per wave (64 B apart)
+    static_assert(XFLAG + 4 * 64 <= XBLK, "raw exchange block");
+    const int xmine = (((int)(step & 1) * 3 + role) * 2 + half) * XBLK, xtheirs = (((int)(step & 1) * 3 + role) * 2 + (1 - half)) * XBLK;
+    auto raw_store = [&](int byte_off, const f32x4& v) {
+      const raw_u4 u = __builtin_bit_cast(raw_u4, v);
+      if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(u, grs, byte_off, 0, 1);      // sc0: stays in this XCD's L2
+      else __builtin_amdgcn_raw_buffer_store_b128(u, grs, byte_off, 0, 16);               // sc1
+    };
+    auto raw_load = [&](int byte_off) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, byte_off, 0, 16)); };
+#elif ICRL_ROWS_REC16
     typedef unsigned int rec_u4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(SPLIT ? GP(KARGS()->gx) : nullptr, 0, (int)ICRL_PPO_SPLIT_BYTES, 0x00020000);
     constexpr int RBLK = (4 * NT1 + 23 + 5) * TH4 * 8;          // bytes of one (parity, role, half) block: (KG + 5) / 2 records per thread
@@ -717,8 +740,18 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
       // the store does not wait for the MFMA chain that produces it — instead of all 55 granules per thread behind the last GEMM:
       // the exchange is throughput-bound (~1 granule per cycle and CU), and the memory pipe runs beside the MFMAs of the next tiles.
       constexpr int KG_ = 4 * NT1 + 23;
+#if !ICRL_ROWS_RAWX
       u64* const mine_e = SPLIT ? GP(KARGS()->gx) + ((size_t)((step & 1) * 3 + role) * 2 + half) * ((size_t)(KG_ + 5) * TH4) + tid : nullptr;
-#if ICRL_ROWS_REC16
+#endif
+      (void)KG_;
+#if ICRL_ROWS_RAWX
+      auto publish4 = [&](int g, const f32x4& v) {
+        if (!(SPLIT && ICRL_EARLY_PUBLISH)) return;
+        raw_store(xmine + (g * TH4 + tid) * 16, v);
+      };
+      auto early_issue = [&](int) {};
+      auto early_take = [&](int, f32x4&) {};
+#elif ICRL_ROWS_REC16
       auto publish4 = [&](int g, const f32x4& v) {
         if (!(SPLIT && ICRL_EARLY_PUBLISH)) return;
         rec_pub(g, v);
@@ -829,12 +862,12 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
 #pragma unroll
             for (int e = 0; e < 4; ++e) gW1r[c] = MFMA_F32(az[js][e], bx[js][e], gW1r[c]);
           if (c == 0) publish4(NT1 + 4, gWhr); else publish4(c - 1, gW1r[c - 1]);
-          if (SPLIT && ICRL_EARLY_PUBLISH && ICRL_EARLY_RECV) {
+          if (SPLIT && ICRL_EARLY_PUBLISH && ICRL_EARLY_RECV && !ICRL_ROWS_RAWX) {
             if (c > 0) { const int gp = early_group_of(NT1, c - 1); early_take(gp, gp < NT1 ? gW1r[gp < NT1 ? gp : 0] : (gp < NT1 + 4 ? gW2r[gp - NT1 < 4 && gp >= NT1 ? gp - NT1 : 0] : gWhr)); }
             early_issue(early_group_of(NT1, c));
           }
         }
-        if (SPLIT && ICRL_EARLY_PUBLISH && ICRL_EARLY_RECV) {
+        if (SPLIT && ICRL_EARLY_PUBLISH && ICRL_EARLY_RECV && !ICRL_ROWS_RAWX) {
           const int gp = early_group_of(NT1, NT1 - 1);
           early_take(gp, gp < NT1 ? gW1r[gp < NT1 ? gp : 0] : (gp < NT1 + 4 ? gW2r[gp - NT1 < 4 && gp >= NT1 ? gp - NT1 : 0] : gWhr));
         }
@@ -867,7 +900,53 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
       const u64 tg = (u64)step << 32;
       f32x4 gsc = f32x4{gb1r, gb2r, gex, 0.f};
       auto grp = [&](int g) -> f32x4& { return g < NT1 ? gW1r[g] : (g < NT1 + 4 ? gW2r[g - NT1] : (g == NT1 + 4 ? gWhr : gsc)); };
-#if ICRL_ROWS_REC16
+#if ICRL_ROWS_RAWX
+      (void)mine; (void)theirs; (void)tg; (void)KG;
+      if (book) gsc[3] = mb_s0;                    // (the book-keeping lane's first loss sum rides in the spare slot of the last group)
+#pragma unroll
+      for (int g = 0; g < NGRP; ++g) {
+        if (ICRL_EARLY_PUBLISH && g < NT1 + 5) continue;      // (already out, group by group, behind their GEMMs)
+        raw_store(xmine + (g * TH4 + tid) * 16, grp(g));
+      }
+      if (book) raw_store(xmine + NGRP * TH4 * 16, f32x4{mb_s1, mb_s2, mb_s3, mb_s4});
+      // every store of this wave has been acknowledged (it is in the L2 the partner reads through, or beyond) -> the wave's flag
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) {
+        if (xcd_local) __builtin_amdgcn_raw_buffer_store_b32(step, grs, xmine + XFLAG + 64 * w, 0, 1);
+        else __builtin_amdgcn_raw_buffer_store_b32(step, grs, xmine + XFLAG + 64 * w, 0, 16);
+      }
+      bool timed_out = false;
+      {
+        unsigned f = 0;
+        int spins = 0;
+        while (true) {
+          f = __builtin_amdgcn_raw_buffer_load_b32(grs, xtheirs + XFLAG + 64 * w, 0, 16);
+          if (f == step) break;
+          if (++spins >= (1 << 22)) { timed_out = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+      asm volatile("" ::: "memory");
+      constexpr int DEP = 7;
+      f32x4 ring[DEP];
+#pragma unroll
+      for (int k = 0; k < DEP; ++k)
+        if (k < NGRP) ring[k] = raw_load(xtheirs + (k * TH4 + tid) * 16);
+#pragma unroll
+      for (int g = 0; g < NGRP; ++g) {
+        f32x4& v = grp(g);
+        const f32x4 c = ring[g % DEP];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] += c[i];                // own + partner (commutative: both halves agree)
+        if (g + DEP < NGRP) ring[g % DEP] = raw_load(xtheirs + ((g + DEP) * TH4 + tid) * 16);
+      }
+      gb1r = gsc[0]; gb2r = gsc[1]; gex = gsc[2];
+      if (book) {
+        mb_s0 = gsc[3];
+        const f32x4 c = raw_load(xtheirs + NGRP * TH4 * 16);
+        mb_s1 += c[0]; mb_s2 += c[1]; mb_s3 += c[2]; mb_s4 += c[3];
+      }
+#elif ICRL_ROWS_REC16
       if (book) gsc[3] = mb_s0;                    // (the book-keeping thread's first loss sum rides in the spare slot of the last group)
 #pragma unroll
       for (int g = 0; g < NGRP; ++g) {

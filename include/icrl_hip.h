@@ -185,7 +185,7 @@ typedef struct {
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* ABI version (major*100+minor). */
-int icrl_abi_version(void);   /* 102: icrl_policy_t.arch; 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
+int icrl_abi_version(void);   /* 103: icrl_debug_stream_ref; 102: icrl_policy_t.arch; 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
 
 /* Every entry point returns a hipError_t.  When it is hipErrorInvalidValue because the arguments are outside what the
  * kernels were built for (env count, widths, batch size ...; the reference's Python raises ValueError / AssertionError with a
@@ -466,6 +466,13 @@ int icrl_debug_rollout_profile_wide(unsigned long long* out16);
 /* per workgroup of that kernel, step T/2 of a profiled launch: 100 MHz timestamps at the end of its env phase, of its owner's
  * gather, of its owner's publish (0 when it owns no statistic) and when it had read all statistics: out[4 * n_workgroups]. */
 int icrl_debug_rollout_trace_wide(unsigned long long* out, int n_workgroups);
+
+/* Diagnostic (bench.py `roofline.copy_gbs`; no reference counterpart): the memory traffic of the streaming dual-GAE launch without
+ * its recurrence.  mode 0: grid, access pattern and bytes of icrl_gae_dual at N >= 131 072 (five [T,N] float arrays read, four written,
+ * 16-byte non-temporal accesses, one wave per 256 columns walking the rows downwards); mode 1: in0..in3 copied to out0..out3 by
+ * four flat grid-stride float4 copies (in4 unused).  N % 4 == 0. */
+int icrl_debug_stream_ref(const float* in0, const float* in1, const float* in2, const float* in3, const float* in4,
+                          float* out0, float* out1, float* out2, float* out3, int T, int N, int mode, void* stream);
 
 /* Minibatch mode of ConstraintNet.train (`--cn_batch_size`; icrl/constraint_net.py:181-206 with get() :300-316): per
  * iteration the importance weights / early-stop test on ALL nominal rows as above, then one optimiser step per batch of

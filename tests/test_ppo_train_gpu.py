@@ -124,7 +124,9 @@ def _oracle_train(agent_sd, buf, perms, kind, nu, okw=None, **h):
                                              ("hc", 8, 128, 512, 3, None), ("hc", 5, 200, 300, 2, None),      # 1000 rows: 300 + 300 + 300 + 100
                                              # architectures beyond three two-layer branches (-sl trunk, other depths; torch_layers.py:129-254)
                                              ("hc-trunk", 8, 32, 64, 3, None), ("ant-deep", 6, 40, 128, 2, None), ("hc-trunk-only", 5, 40, 100, 2, None),
-                                             ("hc-bare", 4, 30, 40, 2, None), ("hc-deep", 16, 32, 64, 6, 0.002), ("ant-trunk", 4, 100, 400, 2, None)])
+                                             ("hc-bare", 4, 30, 40, 2, None), ("hc-deep", 16, 32, 64, 6, 0.002), ("ant-trunk", 4, 100, 400, 2, None),
+                                             # target-KL stop decided inside an Adam launch of ~3 900 workgroups: the epoch's last step is applied in full
+                                             ("hc-huge", 8, 16, 64, 3, 1e-7)])
 def test_train_vs_oracle(kind, N, T, B, E, tk, one_workgroup_per_network=False):
     from helpers.arches import ARCHES, oracle_arch_kwargs
     rng = np.random.RandomState(N * T)

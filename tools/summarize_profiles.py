@@ -42,18 +42,29 @@ def kernel_stats(tag, which="bench"):
                         prof_frac = 2048 * 131072 * 36 / (avg_us * 1e-6) / 8e12
                         agree = (f"GAE roofline of the SAME run: the line says `roofline.achieved` {j['roofline']['achieved']} GB/s = {j['roofline']['frac']} of 8 TB/s "
                                  f"(HIP events inside bench.py); this trace's `gae_dual_x4_kernel` average is {avg_us:.1f} us = {2048 * 131072 * 36 / (avg_us * 1e-6) / 1e9:.0f} GB/s = "
-                                 f"{prof_frac:.3f} ({100 * (prof_frac / j['roofline']['frac'] - 1):+.1f} %; the trace's average includes the 5 warm-up launches of the sweep).  "
+                                 f"{prof_frac:.3f} ({100 * (prof_frac / j['roofline']['frac'] - 1):+.1f} %; the trace also holds the 3 warm-up launches of the sweep).  "
                                  f"Update kernel: the line says {j['roofline_ppo']['us_per_optimizer_step']} us per optimiser step.")
-    # full launches of the update kernel (the first train() of a process also makes 8 short calibration launches: drop by duration)
+    # every launch of the update kernel, from the trace's timestamps, with the optimiser steps it ran at the line's time per step (the
+    # target-KL early stop makes launches of one configuration differ in length: a launch is NOT classified by its duration.  The
+    # placement calibration of rounds 3 / 4 — `PPOLagrangian.tune_sync_placement`, off by default since 0ecb14a — would show as 8
+    # launches of <= 256 steps in front of the first update; it is only mentioned when the run switched it on: ICRL_TUNE_SYNC=1 in the log)
     upd = ""
     tr = find(f"prof_{tag}{sfx}/**/*kernel_trace.csv")
     if tr is not None:
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6 for r in csv.DictReader(open(tr)) if "ppo_train_" in r["Kernel_Name"] and "perm" not in r["Kernel_Name"] and "plan" not in r["Kernel_Name"]]
         if d:
-            full = [x for x in d if x >= 0.5 * max(d)]
-            cal = (f"The update kernel's calls include {len(d) - len(full)} short calibration launches (`PPOLagrangian._tune_sync_placement`: the first `train()` of an agent "
-                   f"times one epoch over <= 16 384 rows at four positions of its exchange workspace, twice); " if len(d) > len(full) else "")
-            upd = cal + f"the {len(full)} updates proper last {sum(full) / len(full):.2f} ms each on average (from the kernel trace's timestamps)."
+            us = None
+            if os.path.exists(log):
+                for line in open(log):
+                    if line.startswith("{\"metric\"") or line.startswith("{\"workload\""):
+                        j = json.loads(line)
+                        us = j.get("us_per_optimizer_step") or j.get("roofline_ppo", {}).get("us_per_optimizer_step")
+            tuned = os.path.exists(log) and any("ICRL_TUNE_SYNC=1" in l for l in open(log))
+            per = ", ".join(f"{x:.2f} ms" + (f" (~{round(x * 1e3 / us)} steps)" if us else "") for x in d)
+            upd = (f"The {len(d)} launches of the update kernel in trace order (warm-up first): {per}" +
+                   (f" — step counts at the line's {us} us per optimiser step; launches of one configuration differ in length where the target-KL test "
+                    "(ppo_lag.py:293-297) ended their epoch loops early." if us else ".") +
+                   (" The short launches in front of the first update are the placement calibration (`tune_sync_placement` was on in this run)." if tuned else ""))
     head = (f"# rocprofv3 --kernel-trace --stats — bench.py --steps 2 --warmup 1 ({tag})\n\n"
             "command: `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_<tag> -- python3 bench.py --steps 2 "
             "--warmup 1 --no_cpu_baseline --no_seed_batch --no_configs2 --no_configs3 --no_configs4 --no_generic` (3 outer iterations traced incl. warm-up, plus the GAE sweep launches at N = 131 072)\n\n"
