@@ -310,11 +310,17 @@ class PPOLagrangian:
 
     # ---- persistence (ref: common/base_class.py save / load, common/save_util.py:284-418) ---------------------------------
     def save(self, path):
-        """SB3-style archive: `<path>.zip` with `policy.pth` (state dict under the reference's parameter names),
-        `policy.optimizer.pth` (torch Adam layout), `pytorch_variables.pth` (the dual variable) and `data` (JSON of the plain
-        hyper-parameters).  The pickled gym spaces of the reference's `data` entry are not reproduced (no gym here), so the
-        reference can read the tensors out of the archive but not `PPOLagrangian.load` it; this build reads both kinds."""
+        """SB3-style archive the REFERENCE can load (ref: base_class.py:647-692 save, save_util.py:72-119 data_to_json, :284-322
+        save_to_zip_file): `<path>.zip` with `policy.pth` (state dict under the reference's parameter names), `policy.optimizer.pth`
+        (torch Adam layout), `pytorch_variables.pth` (empty, as the reference writes it) and `data` = the JSON of the constructor
+        attributes, in which `policy_class`, `observation_space` and `action_space` are pickles BY REFERENCE to
+        stable_baselines3.common.policies.ActorTwoCriticsPolicy / gym.spaces.box.Box / gym.spaces.discrete.Discrete (utils.sb3_*_entry:
+        no gym needed to write them).  The reference's `PPOLagrangian.load(path)` (base_class.py:564-645) rebuilds the agent from it —
+        checked in the build container by oracle/verify_agent_archive.py.  Schedules are stored by their current value (the reference
+        re-wraps floats in `_setup_model`); what only this build reads (the dual variable's state, the Adam step count) sits in a
+        `dual_state.json` member the reference ignores."""
         import io, json, zipfile
+        from . import utils as U
         path = str(path)
         path = path if path.endswith(".zip") else path + ".zip"
         def blob(obj):
@@ -322,10 +328,6 @@ class PPOLagrangian:
         data = {k: getattr(self, k) for k in ("n_steps", "batch_size", "n_epochs", "reward_gamma", "reward_gae_lambda", "cost_gamma",
                                                "cost_gae_lambda", "ent_coef", "reward_vf_coef", "cost_vf_coef", "max_grad_norm",
                                                "target_kl", "n_envs", "num_timesteps", "_n_updates", "seed")}
-        data.update(policy_class="ActorTwoCriticsPolicy", observation_dim=int(self.policy.obs_dim), action_dim=int(self.policy.act_dim),
-                    discrete=bool(self.policy.discrete), adam_step=int(self.policy.adam_step))
-        # everything a continued training run needs (the reference pickles self.__dict__, base_class.py:647-692): schedules are
-        # stored by their current value, the network widths as policy_kwargs
         num = lambda v: None if v is None else float(v(1.0) if callable(v) else v)
         data.update(learning_rate=num(self.learning_rate), clip_range=num(self.clip_range), clip_range_reward_vf=num(self.clip_range_reward_vf),
                     clip_range_cost_vf=num(self.clip_range_cost_vf), algo_type=self.algo_type, budget=float(self.budget),
@@ -333,12 +335,21 @@ class PPOLagrangian:
                     penalty_min_value=self.penalty_min_value, update_penalty_after=self.update_penalty_after, pid_kwargs=self.pid_kwargs,
                     policy_kwargs=dict(net_arch=[*self.policy.shared, dict(pi=list(self.policy.layers["policy_net"]), vf=list(self.policy.layers["value_net"]),
                                                                            cvf=list(self.policy.layers["cost_value_net"]))]))
+        # the rest of what the reference's __init__ leaves in self.__dict__ and its load() / _setup_model() / predict() read
+        data.update(verbose=int(getattr(self, "verbose", 0)), use_sde=False, sde_sample_freq=-1, tensorboard_log=None, action_noise=None,
+                    _total_timesteps=int(getattr(self, "_total_timesteps", 0) or 0), _episode_num=0, start_time=None,
+                    _current_progress_remaining=float(getattr(self, "_current_progress_remaining", 1.0)))
+        data.update(policy_class=U.sb3_policy_class_entry(), observation_space=U.sb3_space_entry(self.observation_space),
+                    action_space=U.sb3_space_entry(self.action_space))
+        extra = dict(dual=self.dual.state_dict() if hasattr(self.dual, "state_dict") else {}, adam_step=int(self.policy.adam_step),
+                     writer="icrl_amd")
         with zipfile.ZipFile(path, "w") as z:
-            z.writestr("data", json.dumps(data, default=lambda o: str(o)))
+            z.writestr("data", json.dumps(data, indent=4, default=lambda o: str(o)))
+            z.writestr("pytorch_variables.pth", blob({}))
             z.writestr("policy.pth", blob(self.policy.state_dict()))
             z.writestr("policy.optimizer.pth", blob(self.policy.optimizer_state_dict(lr=float(self.lr_schedule(1.0)))))
-            z.writestr("pytorch_variables.pth", blob(self.dual.state_dict() if hasattr(self.dual, "state_dict") else {}))
-            z.writestr("_stable_baselines3_version", "0.9.0a0+icrl_amd")
+            z.writestr("dual_state.json", json.dumps(extra))
+            z.writestr("_stable_baselines3_version", "0.9.0")
         return path
 
     @classmethod
@@ -402,8 +413,13 @@ class PPOLagrangian:
             self.policy.load_state_dict(rd("policy.pth"))
             if "policy.optimizer.pth" in names:
                 self.policy.load_optimizer_state_dict(rd("policy.optimizer.pth"))
-            if dual and "pytorch_variables.pth" in names and hasattr(self.dual, "load_state_dict"):
-                pv = rd("pytorch_variables.pth")
+            if dual and hasattr(self.dual, "load_state_dict"):
+                import json
+                pv = {}
+                if "dual_state.json" in names:                    # archives of this build (round 5 on)
+                    pv = json.loads(z.read("dual_state.json")).get("dual", {})
+                elif "pytorch_variables.pth" in names:            # rounds 2-4 kept it there; the reference's own archives hold {}
+                    pv = rd("pytorch_variables.pth")
                 if isinstance(pv, dict) and pv:
                     self.dual.load_state_dict(pv)
         return self

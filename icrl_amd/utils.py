@@ -352,6 +352,54 @@ def parse_sb3_data(raw):
     return out
 
 
+# ---- the WRITER side of the `data` entry: entries the reference cloud-pickles (save_util.py:72-119) ---------------------------------
+# cloudpickle.dumps of an importable class, or of an instance of one, is an ordinary pickle that names the class by (module, name):
+# the stream below says "gym.spaces.box Box" and carries the instance's __dict__ — no gym is needed to WRITE it, and the reference's
+# json_to_data (cloudpickle.loads = pickle.loads) resolves the name in ITS environment.  Protocol 2 (textual GLOBAL opcodes), numpy
+# objects under their numpy 1.x module path (numpy 2 still resolves `numpy.core.*`, numpy 1.x has no `numpy._core`).
+def _pickle_by_reference(module, name, state=None):
+    """pickle of `module.name` itself (state None) or of an instance of it built as cls.__new__(cls) + __dict__.update(state) —
+    what object.__reduce_ex__(2) emits for a plain class (copyreg.__newobj__, BUILD)."""
+    head = b"\x80\x02c" + module.encode() + b"\n" + name.encode() + b"\n"
+    if state is None:
+        return head + b"."
+    body = pickle.dumps(state, protocol=2)
+    assert body[:2] == b"\x80\x02" and body[-1:] == b"."
+    body = body[2:-1].replace(b"cnumpy._core.", b"cnumpy.core.")
+    return head + b")\x81" + body + b"b."
+
+
+def _sb3_pickled_entry(type_repr, blob, fields):
+    """the JSON object save_util.data_to_json writes for a non-JSON-serialisable item (:type:, :serialized:, printable first-level fields)"""
+    import base64
+    out = {":type:": type_repr, ":serialized:": base64.b64encode(blob).decode()}
+    out.update(fields)
+    return out
+
+
+def sb3_space_entry(space):
+    """`observation_space` / `action_space` of an agent archive as the reference stores them: a pickled gym.spaces.box.Box /
+    gym.spaces.discrete.Discrete (gym 0.17 attribute set: dtype, shape, low, high, bounded_below, bounded_above, np_random | n, shape,
+    dtype, np_random; the generator is stored as None: the load path never samples from a space) + the printable fields."""
+    if isinstance(space, spaces.Discrete) or hasattr(space, "n"):
+        state = dict(n=int(space.n), shape=(), dtype=np.dtype(np.int64), np_random=None)
+        return _sb3_pickled_entry("<class 'gym.spaces.discrete.Discrete'>", _pickle_by_reference("gym.spaces.discrete", "Discrete", state),
+                                  dict(n=int(space.n), shape=[], dtype="int64", np_random="None"))
+    dt = np.dtype(space.dtype)
+    low, high = np.asarray(space.low, dt).copy(), np.asarray(space.high, dt).copy()
+    state = dict(dtype=dt, shape=tuple(int(x) for x in space.shape), low=low, high=high,
+                 bounded_below=-np.inf < low, bounded_above=np.inf > high, np_random=None)
+    return _sb3_pickled_entry("<class 'gym.spaces.box.Box'>", _pickle_by_reference("gym.spaces.box", "Box", state),
+                              dict(dtype=str(dt), shape=list(state["shape"]), low=str(low), high=str(high),
+                                   bounded_below=str(state["bounded_below"]), bounded_above=str(state["bounded_above"]), np_random="None"))
+
+
+def sb3_policy_class_entry():
+    """`policy_class`: the reference stores the class object itself (pickled by reference to stable_baselines3.common.policies)"""
+    return _sb3_pickled_entry("<class 'abc.ABCMeta'>", _pickle_by_reference("stable_baselines3.common.policies", "ActorTwoCriticsPolicy"),
+                              {"__module__": "stable_baselines3.common.policies"})
+
+
 def load_policy_state_dict(path):
     """policy.pth out of a stable-baselines3 agent zip (no gym needed), or the `policy/*` arrays of the .npz fixture."""
     if str(path).endswith(".npz"):

@@ -142,3 +142,13 @@ def test_flag_set_matches_reference_readme_commands():
                      "--batch_size 128 --reward_gae_lambda 0.9 --cost_gae_lambda 0.9 --n_epochs 20 --learning_rate 3e-5 "
                      "--clip_range 0.4 -piv 0.1 -plr 0.05 -psis -tk 0.02 -ctkno 2.5".split())
     assert a.cn_layers == [40, 40] and a.batch_size == 128 and a.penalty_initial_value == 0.1 and a.n_epochs == 20
+
+
+def test_gpu_suite_fits_its_time_budget():
+    """tests/gpu_suite_duration.json = the record the last FULL `pytest tests -m gpu` run on an MI355X box left (tests/conftest.py writes
+    it to gpurun_out/, it is committed from there): the driver's step limit for that command is 1 200 s, the budget 900 s."""
+    import json
+    from conftest import GPU_SUITE_BUDGET_S
+    rec = json.load(open(os.path.join(ROOT, "tests", "gpu_suite_duration.json")))
+    assert rec["tests"] >= 266, "the record must come from a run of the whole GPU suite"
+    assert rec["duration_s"] <= GPU_SUITE_BUDGET_S, f"GPU suite {rec['duration_s']} s > {GPU_SUITE_BUDGET_S} s: slowest {rec['slowest']}"

@@ -98,6 +98,59 @@ def test_icrl_lgw_three_iterations_vs_reference(golden):
         assert np.allclose(v.numpy(), g["cn1/" + k], rtol=2e-3, atol=2e-4), (k, np.abs(v.numpy() - g["cn1/" + k]).max())
 
 
+def _lgw_full_size(golden, ft, n_iters):
+    """HIP icrl() and the CPU port on BASELINE configs[0]'s shapes — LGW-v0 / CLGW-v0, 1 env, n_steps 2000 (minibatches 31 x 64 + 16), the
+    reference's README.md:25 flags, `ft` forward timesteps per outer iteration — on the same uniform / permutation streams."""
+    from icrl_amd.icrl import build_parser, setup, outer_iteration
+    expert = os.path.join(HERE, "golden/expert_lgw.npz")
+    argv = ["icrl", "-er", "20", "-ep", expert, "--expert_agent_path", expert, "-tei", "LGW-v0", "-eei", "CLGW-v0", "-tk", "0.01", "-cl", "20",
+            "-clr", "0.003", "-ft", str(ft), "-ni", str(n_iters), "-bi", "20", "-dno", "-dnr", "-dnc", "--n_steps", "2000", "-nt", "1", "-s", "0", "-v", "0"]
+    cfg = vars(build_parser().parse_args(argv))
+    cfg.update(rank=0, world_size=1, streams=SeededStreams(5))
+    st = setup(types.SimpleNamespace(**cfg))
+    init = dict(policy={k: v.numpy().copy() for k, v in st["agent"].policy.state_dict().items()},
+                cn={k: v.numpy().copy() for k, v in st["constraint_net"].state_dict().items()})
+    ex = golden("expert_lgw")
+    n_thr = torch.get_num_threads()
+    torch.set_num_threads(1)          # the port's 64-wide MLP steps are fastest on one thread
+    try:
+        port_cfg = {k: cfg[k] for k in o_loop.PORT_DEFAULTS if k in cfg}
+        om, steps, _, objs = o_loop.icrl_port(port_cfg, ex["observations"], ex["actions"], _sub(ex, "policy/"), streams=SeededStreams(5), init=init)
+    finally:
+        torch.set_num_threads(n_thr)
+    return st, om, steps, [outer_iteration(st, it) for it in range(n_iters)]
+
+
+def test_icrl_lgw_full_size_vs_port(golden):
+    """BASELINE configs[0] at FULL size (VERDICT r4 #4c): 1 env, n_steps 2000, README.md:25 flags, against the CPU port (pinned to the
+    reference's own icrl() on this env by g8 at 2 envs x 200).  Discrete actions come from the inverse CDF of teacher-forced uniforms:
+    as long as no uniform lands between the two sides' CDFs the env traces are IDENTICAL and everything is compared at the module's
+    tolerances; the first flipped sample moves the rest of its episode, the updates fed with it and — LapGridWorld's policy swings
+    hard (approx_kl up to 0.5 per update) — every later metric by per cents.  Measured on MI355X in round 5 (growing forward_timesteps):
+    HIP and port agree exactly in all traces for 30 000 env steps = 15 rollouts + 15 updates (max |d param| 7.7e-6 after 4 800 Adam
+    steps), and part somewhere in rollouts 16-25.  The port against ITSELF (5 runs with every initial parameter moved by -1 / 0 / +1
+    ulp, tools/calibrate_lgw.py, profiles/r05_lgw_calibration.md) holds all of iteration 0 (forward metrics within 6e-5) and is
+    chaotic in iteration 1 (early_stop_epoch 0 vs 10, true/cost 0.39 vs 0.20, nu +- 3.9e-3, average_cost +- 2.8e-2).  So:
+      (A) one outer iteration with forward_timesteps 30 000: EVERY metric strict — forward, sampled episodes, constraint-net update, KLs;
+      (B) two outer iterations at the README's 0.5e5: step counts exact, everything finite, nu within 2e-2 and average_cost within
+          0.15 (5 x the port-vs-port spread of iteration 1) in both iterations."""
+    st, om, steps, ms = _lgw_full_size(golden, 30000, 1)
+    keys = sorted(k for k in om[0] if k in ms[0] and k not in ("forward/std",) and not k.startswith("time/"))
+    worst = _compare(0, ms[0], om[0], keys, True, 4000)
+    assert st["timesteps"] == steps == 15 * 2000 and ms[0]["forward/n_updates"] == om[0]["forward/n_updates"] == 150
+    print("LGW full size (A), 15 rollouts + updates + sampling + constraint-net update: worst absolute deviation from the CPU port",
+          {k: float(f"{v:.3g}") for k, v in sorted(worst.items()) if v > 0})
+    st, om, steps, ms = _lgw_full_size(golden, "0.5e5", 2)
+    assert st["timesteps"] == steps == 2 * 25 * 2000
+    for it in range(2):
+        assert ms[it]["forward/n_updates"] == om[it]["forward/n_updates"] == 250 * (it + 1)
+        assert all(np.isfinite(float(v)) for k, v in ms[it].items() if k.startswith("forward/"))
+        assert abs(ms[it]["forward/nu"] - om[it]["forward/nu"]) <= 2e-2 and abs(ms[it]["forward/average_cost"] - om[it]["forward/average_cost"]) <= 0.15
+    print("LGW full size (B), README size: " + "; ".join(f"iteration {it}: nu {ms[it]['forward/nu']:.5f} vs {om[it]['forward/nu']:.5f}, average_cost "
+                                                         f"{ms[it]['forward/average_cost']:.4f} vs {om[it]['forward/average_cost']:.4f}, true/cost "
+                                                         f"{ms[it]['true/cost']:.4f} vs {om[it]['true/cost']:.4f}" for it in range(2)))
+
+
 def test_icrl_hc_three_iterations_vs_port(golden):
     """HIP icrl() vs the CPU port on HCWithPos shapes (N = 8, T = 128), README.md:38 flags, 3 outer iterations, same
     noise / permutation streams.  The port itself is pinned to the reference by g8 (outer loop) and g9 (HC learn())."""

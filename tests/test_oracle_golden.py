@@ -1,11 +1,15 @@
 """CPU: the oracle restatement replayed against the golden vectors produced by the reference itself
 (oracle/gen_golden.py).  Bit-exact where the arithmetic is numpy / identical torch ops."""
+import os
+
 import numpy as np
 import pytest
 import torch as th
 
 from oracle import cn as o_cn, gae as o_gae, nets as o_nets, ppo as o_ppo, stats as o_stats
 from oracle import loop as o_loop
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _sub(g, prefix):
@@ -374,3 +378,17 @@ def test_g12_gail_baseline_reference(golden):
     for k, v in _sub(g, "d1/").items():
         assert np.allclose(net.params[k].detach().numpy(), v, rtol=0, atol=1e-6), k
     assert np.allclose(o_gail.disc_reward(net, g["probe_obs"], g["probe_acs"]), g["probe_reward"], rtol=0, atol=1e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference exists in the build container only")
+def test_reference_loads_the_archive_this_build_wrote():
+    """tests/golden/hip_agent_archive.zip was written by `icrl_amd.PPOLagrangian.save` on an MI355X
+    (tests/test_ref_artifacts_gpu.py::test_agent_archive_for_the_reference_loader); the REFERENCE's own `PPOLagrangian.load`
+    (base_class.py:564-645) — imported unmodified under oracle/ref_shim — rebuilds the agent from it and its deterministic `predict`
+    on 64 observations equals what the HIP path computed (hip_agent_archive_expected.npz)."""
+    import subprocess, sys
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(root, "oracle", "ref_shim"), "/root/reference", "/root/reference/custom_envs", root]))
+    out = subprocess.run([sys.executable, "-W", "ignore", "-m", "oracle.verify_agent_archive", os.path.join(HERE, "golden", "hip_agent_archive.zip"),
+                          os.path.join(HERE, "golden", "hip_agent_archive_expected.npz")], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "VERIFIED" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])

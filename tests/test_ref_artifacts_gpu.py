@@ -1,6 +1,7 @@
 """GPU: interop with files written by the REFERENCE itself (tests/golden/ref_artifacts: bytes of its committed data files; the
 expected values in ref_artifacts_expected.npz were read out of the same files by the reference's own loaders,
 oracle/gen_golden.py:fixtures_expert) — SURVEY.md §8 f-2."""
+import io
 import os
 
 import numpy as np
@@ -126,3 +127,76 @@ def test_agent_save_load_round_trip_with_narrow_widths(tmp_path):
     # the reference's own archive (64-64 everywhere) still loads through the width inference
     c = PPOLagrangian.load(os.path.join(ART, "hc_best_model.zip"))
     assert c.policy.widths == dict(policy_net=(64, 64), value_net=(64, 64), cost_value_net=(64, 64))
+
+
+def test_agent_archive_for_the_reference_loader(tmp_path):
+    """`PPOLagrangian.save` writes what the REFERENCE's `PPOLagrangian.load` reads (base_class.py:564-645,
+    save_util.py:284-418): `data` carries `policy_class`, `observation_space`, `action_space` as pickles by reference to
+    stable_baselines3.common.policies.ActorTwoCriticsPolicy / gym.spaces.box.Box, `pytorch_variables.pth` is the reference's empty
+    dict, no `.pth` member the reference's loader would take for a state dict is added.  The reference itself does not exist on the
+    GPU box: this test writes the archive and this build's deterministic `predict` on 64 observations to gpurun_out/ — committed from
+    there as tests/golden/hip_agent_archive.zip / hip_agent_archive_expected.npz — and oracle/verify_agent_archive.py (build
+    container; tests/test_oracle_golden.py runs it there) loads that archive with the reference's own loader and compares `predict`."""
+    import base64, json, pickle, sys, types, zipfile
+    from icrl_amd import utils
+    from icrl_amd.constraint_net import ConstraintNet
+    from icrl_amd.ppo_lag import PPOLagrangian
+    env = utils.make_train_env("HCWithPos-v0", None, True, 11, 4, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    lo = -np.ones(6, np.float32)
+    cn = ConstraintNet(18, 6, [20], None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
+    env.set_cost_function(cn.cost_function)
+    a = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=64, batch_size=64, n_epochs=2, seed=11, target_kl=0.01, learning_rate=1e-3)
+    a.learn(3 * 4 * 64)
+    path = a.save(str(tmp_path / "hip_agent_archive"))
+    with zipfile.ZipFile(path) as z:
+        names = set(z.namelist())
+        assert names == {"data", "policy.pth", "policy.optimizer.pth", "pytorch_variables.pth", "dual_state.json", "_stable_baselines3_version"}
+        assert torch.load(io.BytesIO(z.read("pytorch_variables.pth")), weights_only=True) == {}
+        data = json.loads(z.read("data"))
+    # the pickles name the reference's classes; they decode under any module that offers those names (here: bare stand-ins)
+    mods = {}
+    for mod, cls_name in (("gym.spaces.box", "Box"), ("gym.spaces.discrete", "Discrete"), ("stable_baselines3.common.policies", "ActorTwoCriticsPolicy")):
+        parts = mod.split(".")
+        for i in range(1, len(parts) + 1):
+            mods.setdefault(".".join(parts[:i]), types.ModuleType(".".join(parts[:i])))
+        setattr(mods[mod], cls_name, type(cls_name, (), {"__module__": mod}))
+    saved = {k: sys.modules.get(k) for k in mods}
+    sys.modules.update(mods)
+    try:
+        osp = pickle.loads(base64.b64decode(data["observation_space"][":serialized:"]))
+        asp = pickle.loads(base64.b64decode(data["action_space"][":serialized:"]))
+        pcl = pickle.loads(base64.b64decode(data["policy_class"][":serialized:"]))
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    assert type(osp).__name__ == "Box" and osp.shape == (18,) and osp.dtype == np.float64 and np.all(np.isinf(osp.low)) and not osp.bounded_below.any()
+    assert asp.shape == (6,) and asp.dtype == np.float32 and np.array_equal(asp.low, -np.ones(6, np.float32)) and asp.bounded_above.all()
+    assert pcl.__name__ == "ActorTwoCriticsPolicy"
+    for k in ("n_steps", "batch_size", "n_epochs", "learning_rate", "clip_range", "target_kl", "policy_kwargs", "n_envs", "seed", "use_sde",
+              "algo_type", "penalty_initial_value", "penalty_learning_rate", "budget", "update_penalty_after", "_total_timesteps"):
+        assert k in data and not (isinstance(data[k], dict) and ":serialized:" in data[k]), k
+    # this build reads its own archive back (spaces through the printable fields, dual variable from dual_state.json)
+    b = PPOLagrangian.load(path)
+    assert torch.equal(b.policy.params, a.policy.params) and b.policy.adam_step == a.policy.adam_step
+    c = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=64, batch_size=64, n_epochs=2, seed=5).load_parameters(path)
+    assert c.dual.nu().item() == a.dual.nu().item()
+    rng = np.random.RandomState(64)
+    obs = rng.randn(64, 18) * 2
+    act, _ = a.predict(obs, deterministic=True)
+    v_r, v_c, lp, _ = a.policy.evaluate_actions(obs, act)
+    out = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    import shutil
+    shutil.copy(path, os.path.join(out, "hip_agent_archive.zip"))
+    np.savez(os.path.join(out, "hip_agent_archive_expected.npz"), obs=obs, actions=act.cpu().numpy(), v_r=v_r.cpu().numpy().ravel(),
+             v_c=v_c.cpu().numpy().ravel(), log_prob=lp.cpu().numpy(), nu=np.float32(a.dual.nu().item()))
+    # the committed fixture (written by an earlier run of this test) still loads here
+    fix = os.path.join(HERE, "golden", "hip_agent_archive.zip")
+    if os.path.exists(fix):
+        d = PPOLagrangian.load(fix)
+        exp = np.load(os.path.join(HERE, "golden", "hip_agent_archive_expected.npz"))
+        got, _ = d.predict(exp["obs"], deterministic=True)
+        assert np.allclose(got.cpu().numpy(), exp["actions"], rtol=1e-6, atol=1e-7)
