@@ -146,6 +146,8 @@ inline int packed_grid(int M, int n_runs) {
 int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hipStream_t s);
 // ppo_train_pairs.hip: wave-pair kernel, two waves per SIMD (nt1 rounded up to an even tile count)
 int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s);
+// ppo_train_halves.hip: two workgroups per network, wave quads (nt1 <= 2; single-run launches; a.gx set)
+int launch_train_halves(const TrainArgs& a, bool discrete, hipStream_t s);
 // batched forms: n_runs argument blocks in DEVICE memory, grid.y = run
 int launch_train_rows_batch(const TrainArgs* d_args, int n_runs, int nt1, bool discrete, bool split, hipStream_t s);
 int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, hipStream_t s);
