@@ -148,6 +148,8 @@ int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hi
 int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s);
 // ppo_train_halves.hip: two workgroups per network, wave quads (nt1 <= 2; single-run launches; a.gx set)
 int launch_train_halves(const TrainArgs& a, bool discrete, hipStream_t s);
+int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, hipStream_t s);
+constexpr int HALVES_MAX_RUNS = 40;      // batched launches: 6 workgroups per run, 5 groups of 8 runs = 30 workgroups per XCD (packed_grid)
 // batched forms: n_runs argument blocks in DEVICE memory, grid.y = run
 int launch_train_rows_batch(const TrainArgs* d_args, int n_runs, int nt1, bool discrete, bool split, hipStream_t s);
 int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, hipStream_t s);

@@ -914,11 +914,11 @@ static int launch_train(const TrainArgs& a, hipStream_t s) {
 
 // argument checks + the pre-kernels (granule / statistics reset, permutation offsets, schedule tables) of ONE run; fills `a` and
 // reports which persistent kernel runs it: 0 wave pairs, 1 row-owning waves, 2 row-owning waves with two workgroups per network,
-// 3 column-split tiles, 4 wave quads with two workgroups per network (single-run launches at obs <= 32: the batched launches keep one
-// compute unit per network — there the compute units are what runs out).  < 0: refused (return value of fail()) or a HIP error, in *err.
+// 3 column-split tiles, 4 wave quads with two workgroups per network (obs <= 32, launches of up to HALVES_MAX_RUNS runs: beyond that the
+// compute units are what runs out and a run keeps one per network).  < 0: refused (return value of fail()) or a HIP error, in *err.
 static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
                          const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws,
-                         hipStream_t s, TrainArgs& a, int* err, bool single) {
+                         hipStream_t s, TrainArgs& a, int* err, int n_runs) {
   auto bad = [&](int e) { *err = e; return -1; };
   if (pol->arch != nullptr || pol->h1 != HD || pol->h2 != HD)
     return bad(fail("icrl_ppo_lag_train: hidden widths (%d, %d)%s; the persistent update kernels are built for %d x %d (the reference's default net_arch)", pol->h1, pol->h2,
@@ -972,7 +972,7 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   const bool rows = (hp->_pad & 4) || nt1 > 4;
   const bool split = rows && hp->batch_size > RB && hp->batch_size <= 2 * RB && !(hp->_pad & 8);     // (three or four chunks: one workgroup walks them)
   // hp._pad & 16: the wave-pair kernel (one workgroup per network) where the wave-quad kernel would run
-  const bool halves = !rows && single && nt1 <= 2 && !(hp->_pad & 16);
+  const bool halves = !rows && n_runs <= HALVES_MAX_RUNS && nt1 <= 2 && !(hp->_pad & 16);
   hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
                      n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks, (int)split);
   if (split || halves) {
@@ -1025,7 +1025,7 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
   if (policy_is_wide(pol) || hp->batch_size > MAXB)
     return train_generic(pol, exp_avg, exp_avg_sq, adam_step, buf, perms, nu, hp, stats, sync_ws, s);
   int err = 0;
-  const int kind = prepare_train(pol, exp_avg, exp_avg_sq, adam_step, buf, perms, nu, hp, stats, sync_ws, s, a, &err, true);
+  const int kind = prepare_train(pol, exp_avg, exp_avg_sq, adam_step, buf, perms, nu, hp, stats, sync_ws, s, a, &err, 1);
   if (kind < 0) return err;
   const int nt1 = (pol->obs_dim + 15) / 16;
   if (kind == 4) return launch_train_halves(a, pol->discrete != 0, s);
@@ -1060,7 +1060,7 @@ extern "C" int icrl_ppo_lag_train_batch(int n_runs, const icrl_ppo_train_job_t* 
       return fail("icrl_ppo_lag_train_batch: run %d differs from run 0 in a shape (obs / act / discrete / batch_size / n_epochs / T / N): the runs of a batch share one grid", r);
     TrainArgs a;
     int err = 0;
-    const int kind = prepare_train(j.pol, j.exp_avg, j.exp_avg_sq, j.adam_step, j.buf, j.perms, j.nu, j.hp, j.stats, j.sync_ws, s, a, &err, false);
+    const int kind = prepare_train(j.pol, j.exp_avg, j.exp_avg_sq, j.adam_step, j.buf, j.perms, j.nu, j.hp, j.stats, j.sync_ws, s, a, &err, n_runs);
     if (kind < 0) return err;
     if (kind == 3) return fail("icrl_ppo_lag_train_batch: the column-split tiles kernel (hp->_pad & 2) has no batched form");
     if (r == 0) kind0 = kind;
@@ -1068,6 +1068,7 @@ extern "C" int icrl_ppo_lag_train_batch(int n_runs, const icrl_ppo_train_job_t* 
     if (e != 0) return e;
   }
   const int nt1 = (j0.pol->obs_dim + 15) / 16;
+  if (kind0 == 4) return launch_train_halves_batch(d_args, n_runs, j0.pol->obs_dim, j0.pol->discrete != 0, s);
   if (kind0 == 0) return launch_train_pairs_batch(d_args, n_runs, j0.pol->obs_dim, nt1, j0.pol->discrete != 0, s);
   return launch_train_rows_batch(d_args, n_runs, nt1, j0.pol->discrete != 0, kind0 == 2, s);
 }

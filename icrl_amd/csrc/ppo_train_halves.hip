@@ -27,8 +27,20 @@
 // Built with -ffp-contract=off; FMA is used only where written (fmaf / MFMA).
 #include "ppo_common.h"
 
+// (measured, round 5, us per optimiser step on one box: early publish + staging inside the hop 6.91 | early publish 6.89 | neither 6.87 |
+// staging inside the hop alone 6.96 — all inside the run-to-run spread; the plain order ships)
 #ifndef ICRL_HALVES_EARLY_PUBLISH
-#define ICRL_HALVES_EARLY_PUBLISH 1
+#define ICRL_HALVES_EARLY_PUBLISH 0
+#endif
+// the next minibatch is staged (rows -> the other X^T buffer, advantage statistics) between this wave's flag and its first look at the
+// partner's: the exchange hop (~1.5 k cycles) is the longer of the step's two trips through the memory system and has no other
+// independent work to run under; the norm granules of the other networks are then polled without anything in between
+#ifndef ICRL_HALVES_STAGE_IN_HOP
+#define ICRL_HALVES_STAGE_IN_HOP 0
+#endif
+// A/B: the four waves of a quad on four SIMDs (rt2 = w >> 2) instead of two and two (rt2 = w & 1)
+#ifndef ICRL_HALVES_QUAD_SPREAD
+#define ICRL_HALVES_QUAD_SPREAD 0
 #endif
 
 namespace icrl {
@@ -78,8 +90,11 @@ struct SmemH {  // offsets in floats (multiples of 4)
 
 #define KARGS() ([&]() { const TrainArgs* k_ = ka; asm volatile("" : "+s"(k_)); return k_; }())
 
-template <int NT1, bool DISC, int OBS = 0>
+// BATCH: the argument block was read from memory (batched launch): its pointers are marked as global-memory pointers (common.h:
+// as_global; a pointer a kernel LOADS has no known address space and every access through it is a flat_load / flat_store)
+template <int NT1, bool DISC, int OBS, bool BATCH>
 __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const TrainArgs* const ka, const int slot_j) {
+#define GPH(x) (BATCH ? as_global(x) : (x))
   using S = SmemH<NT1>;
   constexpr int SX = S::SX;
   static_assert(NT1 == 2, "one observation tile per weight-gradient wave half");
@@ -89,7 +104,13 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if ICRL_HALVES_QUAD_SPREAD
+  const int rt2 = w >> 2, fq = w & 3;
+  const int qp0 = w ^ 1, qp1 = w ^ 2, qp2 = w ^ 3;
+#else
   const int rt2 = w & 1, fq = w >> 1;      // forward / activation backward: row tile, feature tile
+  const int qp0 = w ^ 2, qp1 = w ^ 4, qp2 = w ^ 6;      // the other three waves of the quad
+#endif
   const int jt = w & 3, kh = w >> 2;       // weight gradients / Adam: parameter row block, column half
   const int r = lane & 15, q = lane >> 4;
   const int O = a.L.O, A = a.L.A;
@@ -99,16 +120,16 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   auto pos_of = [](int o) { return 4 * (o & 3) + (o >> 2); };
   const int ro = pos_of(r);
   const int T = a.buf.T, N = a.buf.N;
-  const float nu = a.nu[0];
+  const float nu = GPH(a.nu)[0];
   const int n_steps = a.n_steps;
-  const PlanStep* __restrict__ const plan_steps = a.plan_steps;
-  const PlanChunk* __restrict__ const plan_chunks = a.plan_chunks;
-  const int* __restrict__ const perms = a.perms;
-  const float* const p_s0 = role == 0 ? a.buf.log_probs : (role == 1 ? a.buf.reward_values : a.buf.cost_values);
-  const float* const p_s1 = role == 0 ? a.buf.reward_advantages : (role == 1 ? a.buf.reward_returns : a.buf.cost_returns);
-  const float* const p_s2 = a.buf.cost_advantages;
-  const float* const p_obs = a.buf.observations;
-  const float* const p_act = a.buf.actions;
+  const PlanStep* __restrict__ const plan_steps = GPH(a.plan_steps);
+  const PlanChunk* __restrict__ const plan_chunks = GPH(a.plan_chunks);
+  const int* __restrict__ const perms = GPH(a.perms);
+  const float* const p_s0 = GPH(role == 0 ? a.buf.log_probs : (role == 1 ? a.buf.reward_values : a.buf.cost_values));
+  const float* const p_s1 = GPH(role == 0 ? a.buf.reward_advantages : (role == 1 ? a.buf.reward_returns : a.buf.cost_returns));
+  const float* const p_s2 = GPH(a.buf.cost_advantages);
+  const float* const p_obs = GPH(a.buf.observations);
+  const float* const p_act = GPH(a.buf.actions);
   const int AS = a.buf.act_store;
 
   // ---- Adam ownership of wave (jt, kh): element (row j = 16 jt + 4 q + i, column k = 16 c + r) of W2 for c in {2 kh, 2 kh + 1}, of W1
@@ -204,8 +225,9 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
   const float ent_coef = a.hp.ent_coef;
   const float max_grad_norm = a.hp.max_grad_norm, adam_epsf = a.hp.adam_eps, adam_b2f = a.hp.adam_beta2;
-  u64* const xch0 = a.xch;                                                                         // XCD words of all six workgroups, half 0's norm granules
-  u64* const nx = half == 0 ? a.xch : reinterpret_cast<u64*>(reinterpret_cast<char*>(a.gx) + ICRL_PPO_SPLIT_BYTES - 512);      // this half's norm granules
+  u64* const xch0 = GPH(a.xch);                                                                    // XCD words of all six workgroups, half 0's norm granules
+  u64* const gxp = GPH(a.gx);
+  u64* const nx = half == 0 ? xch0 : reinterpret_cast<u64*>(reinterpret_cast<char*>(gxp) + ICRL_PPO_SPLIT_BYTES - 512);      // this half's norm granules
 
   // ---- row stream: the 32 rows of this half are staged by the 512 threads, 16 per row (see ppo_train_pairs.hip for the rules the
   // index / row loads follow: unconditional, clamped, untouched until consumed)
@@ -297,9 +319,9 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   };
   auto quad_wait = [&]() {
     while (true) {
-      const int f0 = __hip_atomic_load(pflag + (w ^ 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const int f1 = __hip_atomic_load(pflag + (w ^ 4), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      const int f2 = __hip_atomic_load(pflag + (w ^ 6), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int f0 = __hip_atomic_load(pflag + qp0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int f1 = __hip_atomic_load(pflag + qp1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      const int f2 = __hip_atomic_load(pflag + qp2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const int f = f0 < f1 ? (f0 < f2 ? f0 : f2) : (f1 < f2 ? f1 : f2);
       if (f >= pphase) break;
       __builtin_amdgcn_s_sleep(0);
@@ -340,7 +362,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   // ---- the exchange of the partial gradients: raw 16-byte stores (sc0: the line stays in this XCD's L2 for the partner's L1-bypassing
   // loads; sc1 when the six workgroups do not share an XCD), one flag word per wave behind s_waitcnt vmcnt(0)
   typedef unsigned int raw_u4 __attribute__((ext_vector_type(4)));
-  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(a.gx, 0, (int)ICRL_PPO_SPLIT_BYTES, 0x00020000);
+  const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(gxp, 0, (int)ICRL_PPO_SPLIT_BYTES, 0x00020000);
   auto raw_store = [&](int byte_off, const f32x4& v) {
     const raw_u4 u = __builtin_bit_cast(raw_u4, v);
     if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(u, grs, byte_off, 0, 1);
@@ -696,6 +718,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         if (xcd_local) __builtin_amdgcn_raw_buffer_store_b32(step, grs, xmine + HX_FLAG + 64 * w, 0, 1);
         else __builtin_amdgcn_raw_buffer_store_b32(step, grs, xmine + HX_FLAG + 64 * w, 0, 16);
       }
+      if (ICRL_HALVES_STAGE_IN_HOP) {
+        commit_rows(xcur == S::XT0 ? S::XT1 : S::XT0);
+        stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
+      }
       bool timed_out = false;
       {
         int spins = 0;
@@ -784,8 +810,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK;
     const bool poller = tid < 24 && (tid >> 3) != role;
     const u64* const slot = nx + (step & 1) * 32 + (tid < 24 ? tid : 0);
-    commit_rows(xnext);
-    stats_partials(nb_next);
+    if (!ICRL_HALVES_STAGE_IN_HOP) {
+      commit_rows(xnext);
+      stats_partials(nb_next);
+    }
     xcur = xnext;
     if (poller) {
       u64 v = 0;
@@ -923,23 +951,40 @@ template <int NT1, bool DISC, int OBS>
 __global__ void __launch_bounds__(THH) ppo_train_halves_kernel(TrainArgs a, int packed) {
   int run = 0, j = (int)blockIdx.x;
   if (packed && !packed_slot(6, 1, run, j)) return;
-  ppo_train_halves_body<NT1, DISC, OBS>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), j);
+  ppo_train_halves_body<NT1, DISC, OBS, false>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), j);
+}
+
+// several independent runs in ONE launch: the packed 1-D grid of ppo_common.h (a run's six workgroups on one XCD), or grid (6, n_runs)
+// with run = blockIdx.y when that many workgroups are not resident on their XCDs at once; the argument blocks live in device memory
+template <int NT1, bool DISC, int OBS>
+__global__ void __launch_bounds__(THH) ppo_train_halves_batch_kernel(const TrainArgs* __restrict__ runs, int n_runs, int packed) {
+  int run = (int)blockIdx.y, j = (int)blockIdx.x;
+  if (packed && !packed_slot(6, n_runs, run, j)) return;
+  const TrainArgs* const ka = as_global(runs + run);
+  ppo_train_halves_body<NT1, DISC, OBS, true>(*ka, ka, j);
 }
 
 template <int NT1, bool DISC, int OBS>
-static int launch_halves(const TrainArgs& a, hipStream_t s) {
+static int launch_halves(const TrainArgs* one, const TrainArgs* d_args, int n_runs, hipStream_t s) {
   static_assert(SmemH<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
-  TrainArgs arg = a;
-  const int pg = packed_grid(6, 1);
-  return (int)launch_coresident(ppo_train_halves_kernel<NT1, DISC, OBS>, dim3(pg ? pg : 6), dim3(THH), 0, s, arg, pg ? 1 : 0);
+  if (one != nullptr) {
+    TrainArgs arg = *one;
+    const int pg = packed_grid(6, 1);
+    return (int)launch_coresident(ppo_train_halves_kernel<NT1, DISC, OBS>, dim3(pg ? pg : 6), dim3(THH), 0, s, arg, pg ? 1 : 0);
+  }
+  const int pg = packed_grid(6, n_runs);
+  hipLaunchKernelGGL((ppo_train_halves_batch_kernel<NT1, DISC, OBS>), pg ? dim3(pg) : dim3(6, n_runs), dim3(THH), 0, s, d_args, n_runs, pg ? 1 : 0);
+  return (int)hipGetLastError();
+}
+
+static int dispatch_halves(const TrainArgs* one, const TrainArgs* d_args, int n_runs, int obs, bool discrete, hipStream_t s) {
+  if (!discrete && obs == 18) return launch_halves<2, false, 18>(one, d_args, n_runs, s);      // HCWithPos (BASELINE configs[1], [3])
+  if (discrete && obs == 1) return launch_halves<2, true, 1>(one, d_args, n_runs, s);          // LapGridWorld (configs[0])
+  return discrete ? launch_halves<2, true, 0>(one, d_args, n_runs, s) : launch_halves<2, false, 0>(one, d_args, n_runs, s);
 }
 
 // obs <= 32 (nt1 <= 2), a.gx set and zeroed (prepare_train)
-int launch_train_halves(const TrainArgs& a, bool discrete, hipStream_t s) {
-  const int obs = a.L.O;
-  if (!discrete && obs == 18) return launch_halves<2, false, 18>(a, s);      // HCWithPos (BASELINE configs[1], [3])
-  if (discrete && obs == 1) return launch_halves<2, true, 1>(a, s);          // LapGridWorld (configs[0])
-  return discrete ? launch_halves<2, true, 0>(a, s) : launch_halves<2, false, 0>(a, s);
-}
+int launch_train_halves(const TrainArgs& a, bool discrete, hipStream_t s) { return dispatch_halves(&a, nullptr, 1, a.L.O, discrete, s); }
+int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, hipStream_t s) { return dispatch_halves(nullptr, d_args, n_runs, obs, discrete, s); }
 
 }  // namespace icrl

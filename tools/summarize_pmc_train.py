@@ -65,8 +65,8 @@ for f in _passes:
 shape = "HCWithPos shapes, batch 64" if kind == "hc" else "AntWall shapes (obs 113, act 8), batch 128 = two 64-row chunks"
 lines = [f"# SQ counters of the PPO-Lagrangian update kernels ({tag}) — {shape}, per WAVE and optimiser step",
          "", "command: `bash tools/pmc_train.sh <tag>` on the GPU box = two `rocprofv3 --pmc <8 SQ counters> --kernel-trace` passes over "
-         "`tools/train_only.py` (HC: VARIANTS=rows,auto = the row-owning kernel with one wave per SIMD, 12 waves, and the wave-pair kernel with two, "
-         "24 waves, 4096 optimiser steps per launch; KIND=ant: VARIANTS=rows1,auto = one workgroup per network walking both chunks, 12 waves, and "
+         "`tools/train_only.py` (HC: VARIANTS=pairs,auto = the wave-pair kernel, one workgroup per network, 24 waves on 3 CUs, and the wave-quad kernel "
+         "of round 5, two workgroups per network, 48 waves on 6 CUs, 4096 optimiser steps per launch; until round 4 the columns were the row-owning and the wave-pair kernel; KIND=ant: VARIANTS=rows1,auto = one workgroup per network walking both chunks, 12 waves, and "
          "the default two workgroups per network, 24 waves, 512 steps per launch); raw csv: gpurun_out/pmc_train_<tag>_{a,b} (scratch).  Values "
          f"below = median over the FULL launches ({STEPS} optimiser steps; the short sync-placement calibration launches every process makes are dropped by duration) "
          f"/ waves of the kernel / {STEPS}; cycle-type counters converted from quad-cycles to shader cycles.", ""]
@@ -101,7 +101,8 @@ if kind != "hc":
     raise SystemExit(0)
 lines += ["", "Reading: SQ_WAVE_CYCLES = ACTIVE_INST_ANY (issuing) + WAIT_INST_ANY (issue stalled: here the SIMD's one fp32 lane array, which the fp32 MFMA "
           "occupies alone: SQ_VALU_MFMA_COEXEC_CYCLES = 0, MFMA_BUSY = 32 cycles x SQ_INSTS_MFMA) + WAIT_ANY (parked at s_waitcnt / s_barrier).  "
-          "With two waves per SIMD each wave issues about half the instructions of the one-wave kernel, and the step shortens by what one wave's waits "
-          "hide of the other's issue; what remains parked is the norm hop, the three workgroup barriers and LDS latency both waves of a SIMD meet at the same time."]
+          "`ppo_train_halves_kernel` (two workgroups per network, 32 rows each): per wave about half the MFMAs of the pair kernel's waves "
+          "(each SIMD's fp32 pipe is busy 2 x that), the VALU work of the loss tail and of Adam is NOT halved (both halves run them on their replicas); "
+          "what it adds is parked time in the raw 16-byte gradient exchange (one trip through the XCD's L2 per step)."]
 open(os.path.join(ROOT, "profiles", f"{tag}_train_pmc{suffix}.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
