@@ -45,6 +45,12 @@ SIGNATURES = {
     "icrl_debug_rollout_profile_wide": [c_void_p],
     "icrl_debug_rollout_trace_wide": [c_void_p, c_int],
     "icrl_debug_stream_ref": [c_void_p] * 9 + [c_int, c_int, c_int, c_void_p],
+    # fine-grained pieces of the update for a host that keeps torch MLPs (csrc/fine.hip)
+    "icrl_minibatch_gather": [c_void_p, c_void_p, c_int] + [c_void_p] * 10,
+    "icrl_adv_stats": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
+    "icrl_ppo_lag_loss_fwd_bwd": [c_void_p] * 13 + [c_int] + [c_void_p] * 6,
+    "icrl_clip_adam_step": [c_void_p] * 5 + [ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p],
+    "icrl_dual_step": [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p],
     "icrl_cn_train_minibatch": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p],
     # batched forms (several independent runs in one launch, run = blockIdx.y): n_runs, jobs[n_runs], ..., args_ws, bytes, stream

@@ -165,7 +165,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   constexpr int SX = S::SX;
   constexpr int NW1 = NT1 / 2;          // observation column tiles of dW1 per wave
   constexpr bool EARLY_COMMIT = ICRL_EARLY_COMMIT && S::XDB;      // needs the second X^T buffer
-  constexpr int XR = (S::O16 + 7) / 8;  // floats of an X row each of the 8 threads of a row stages
+  constexpr int XR = (S::O16 + 7) / 8; (void)XR;  // floats of an X row each of the 8 threads of a row stages
   static_assert(NT1 % 2 == 0, "the two waves of a pair split the observation tiles");
   static_assert(!S::DZ1A, "wide observations (dz1^T sharing h2^T's storage) stay on the row-owning kernel");
 #if ICRL_STATIC_LDS

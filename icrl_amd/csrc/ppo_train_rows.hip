@@ -444,7 +444,7 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
     float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f, mb_s4 = 0.f;  // bookkeeping lane: minibatch sums of the loss statistics
 
     const int n_chunks = SPLIT ? 1 : (nb + RB - 1) / RB;
-    unsigned pend = 0;      // SPLIT: gradient groups of the other half that had not arrived when they were looked at
+    unsigned pend = 0; (void)pend;      // SPLIT: gradient groups of the other half that had not arrived when they were looked at
 #if ICRL_ROWS_RAWX
     typedef unsigned int raw_u4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t grs = __builtin_amdgcn_make_buffer_rsrc(SPLIT ? GP(KARGS()->gx) : nullptr, 0, (int)ICRL_PPO_SPLIT_BYTES, 0x00020000);

@@ -185,7 +185,7 @@ typedef struct {
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* ABI version (major*100+minor). */
-int icrl_abi_version(void);   /* 103: icrl_debug_stream_ref; 102: icrl_policy_t.arch; 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
+int icrl_abi_version(void);   /* 104: the fine-grained update entry points (csrc/fine.hip); 103: icrl_debug_stream_ref; 102: icrl_policy_t.arch; 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
 
 /* Every entry point returns a hipError_t.  When it is hipErrorInvalidValue because the arguments are outside what the
  * kernels were built for (env count, widths, batch size ...; the reference's Python raises ValueError / AssertionError with a
@@ -466,6 +466,45 @@ int icrl_debug_rollout_profile_wide(unsigned long long* out16);
 /* per workgroup of that kernel, step T/2 of a profiled launch: 100 MHz timestamps at the end of its env phase, of its owner's
  * gather, of its owner's publish (0 when it owns no statistic) and when it had read all statistics: out[4 * n_workgroups]. */
 int icrl_debug_rollout_trace_wide(unsigned long long* out, int n_workgroups);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fine-grained pieces of the update, for a host that keeps its MLPs in torch (csrc/fine.hip)
+ * ------------------------------------------------------------------------------------------------------------------
+ * icrl_ppo_lag_train runs the whole of PPOLagrangian.train() in one launch.  A maintainer who keeps `policy.evaluate_actions` and
+ * autograd in torch can bind these instead, one call site at a time (INTEGRATION.md section 5 shows the loop):
+ *   rollout_buffer.get(batch_size)         stable_baselines3/common/buffers.py:594-627  -> icrl_minibatch_gather
+ *   advantage normalisation                ppo_lag/ppo_lag.py:219-222                   -> icrl_adv_stats
+ *   loss terms + their gradients           ppo_lag/ppo_lag.py:224-281                   -> icrl_ppo_lag_loss_fwd_bwd
+ *   clip_grad_norm_ + optimizer.step()     ppo_lag/ppo_lag.py:283-288                   -> icrl_clip_adam_step
+ *   dual.update_parameter(average_cost)    common/dual_variable.py:47-57                -> icrl_dual_step
+ * Launch-bound by construction (a minibatch is 64..512 rows); the fused persistent kernels are the fast path. */
+
+/* flat_idx[n]: env-major indices (i = env * T + t, buffers.py:53-65) -> the rows of the [T, N] buffer: obs [n, obs_dim], actions
+ * [n, act_store], and per-row scalars [n]; any output but obs may be NULL. */
+int icrl_minibatch_gather(const icrl_buffer_t* buf, const int32_t* flat_idx, int n, float* obs, float* actions, float* old_log_prob,
+                          float* adv_r, float* adv_c, float* ret_r, float* ret_c, float* old_v_r, float* old_v_c, void* stream);
+/* out4 = {mean(adv_r), 1 / (std(adv_r) + 1e-8) with torch's unbiased std, mean(adv_c), std(adv_r)}; n >= 2. */
+int icrl_adv_stats(const float* adv_r, const float* adv_c, int n, float* out4, void* stream);
+/* The PPO-Lagrangian loss of ONE minibatch on the networks' outputs (all [n] float32; adv_r / adv_c RAW: they are normalised /
+ * centred inside as ppo_lag.py:219-222 does): terms8 = {loss, policy_loss, reward_value_loss, cost_value_loss, entropy_loss,
+ * approx_kl, clip_fraction, 0}; d_log_prob / d_v_r / d_v_c / d_entropy = d loss / d that output, what loss.backward() would send
+ * into `log_prob.backward(...)` etc.  old_v_r / old_v_c NULL: no value clipping; entropy NULL: the reference's -mean(-log_prob)
+ * estimate (its gradient then goes into d_log_prob; d_entropy is not written).  nu: device pointer.  2 <= n <= 65536. */
+int icrl_ppo_lag_loss_fwd_bwd(const float* log_prob, const float* old_log_prob, const float* adv_r, const float* adv_c, const float* v_r,
+                              const float* v_c, const float* ret_r, const float* ret_c, const float* old_v_r, const float* old_v_c,
+                              const float* entropy, const float* nu, const icrl_ppo_hyper_t* hp, int n, float* terms8, float* d_log_prob,
+                              float* d_v_r, float* d_v_c, float* d_entropy, void* stream);
+/* torch.nn.utils.clip_grad_norm_(max_grad_norm) followed by torch.optim.Adam.step() on ONE flat parameter buffer (hp: lr, betas, eps,
+ * max_grad_norm; bias corrections in double from *adam_step + 1, which is then incremented on the device).  work: 256 floats of
+ * scratch; out2 (may be NULL) = {total norm, clip coefficient}. */
+int icrl_clip_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, long long n,
+                        const icrl_ppo_hyper_t* hp, float* work, float* out2, void* stream);
+/* DualVariable.update_parameter on the device: state4 = {log_nu, exp_avg, exp_avg_sq, nu} (nu = softplus(log_nu) is rewritten, so
+ * state4 + 3 can be the `nu` argument of the update), *adam_step its Adam step count; cost from cost_dev[0] when not NULL, else
+ * cost_host; clamp_log_nu = the clamp floor in log_nu space (the reference's double inverse softplus, dual_variable.py:19-29);
+ * loss_out (may be NULL) = -nu * (cost - budget). */
+int icrl_dual_step(float* state4, int32_t* adam_step, const float* cost_dev, float cost_host, float budget, float learning_rate,
+                   float clamp_log_nu, float* loss_out, void* stream);
 
 /* Diagnostic (bench.py `roofline.copy_gbs`; no reference counterpart): the memory traffic of the streaming dual-GAE launch without
  * its recurrence.  mode 0: grid, access pattern and bytes of icrl_gae_dual at N >= 131 072 (five [T,N] float arrays read, four written,

@@ -1,0 +1,147 @@
+"""GPU: the fine-grained entry points of the update (csrc/fine.hip) driven the way a maintainer of the
+reference would bind them — the MLPs and autograd stay in torch (here: the oracle's torch policy on the CPU standing in for
+`policy.evaluate_actions`), the library computes the loss terms and d loss / d outputs, then clip_grad_norm_ + Adam on the flat
+parameter buffer — against the reference's own numbers (tests/golden/g4: its policy / optimizer objects stepped 3 x on one batch)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets as o_nets, ppo as o_ppo
+
+pytestmark = pytest.mark.gpu
+
+
+def _sub(g, prefix):
+    return {k[len(prefix):]: g[k] for k in g.files if k.startswith(prefix)}
+
+
+def _dev(x, dtype=torch.float32):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).cuda().contiguous()
+
+
+def test_loss_fwd_bwd_and_clip_adam_reproduce_the_reference_steps(golden):
+    """ppo_lag.py:216-288 with the network in torch and everything else in the library: three consecutive optimiser steps."""
+    from icrl_amd import _lib, structs as S
+    L = _lib.lib()
+    g = golden("g4_ppo_minibatch")
+    B = int(g["obs"].shape[0])
+    pol = o_nets.TwoCriticPolicy(18, 6)
+    pol.load_state_dict(_sub(g, "w0/"))
+    names = list(pol.params)
+    sizes = [int(pol.params[k].numel()) for k in names]
+    n = sum(sizes)
+    flat = _dev(np.concatenate([pol.params[k].detach().numpy().ravel() for k in names]))
+    m, v = torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    work, out2, terms = torch.zeros(256, device="cuda"), torch.zeros(2, device="cuda"), torch.zeros(8, device="cuda")
+    hp = S.PpoHyperT(B, 1, 0, 0)
+    hp.clip_range, hp.ent_coef, hp.reward_vf_coef, hp.cost_vf_coef, hp.max_grad_norm = float(g["clip"]), 0.0, 0.5, 0.5, 0.5
+    hp.clip_range_reward_vf = hp.clip_range_cost_vf = -1.0
+    hp.lr, hp.adam_beta1, hp.adam_beta2, hp.adam_eps = float(g["lr"]), 0.9, 0.999, 1e-5
+    nu = _dev(np.float32([float(g["nu"])]))
+    dev = {k: _dev(g[k]) for k in ("old_lp", "adv_r", "adv_c", "ret_r", "ret_c")}
+    obs, act = torch.as_tensor(g["obs"]), torch.as_tensor(g["act"])
+    st = _lib.current_stream()
+    for s in range(3):
+        # ---- the host's part: forward through ITS networks (torch, autograd on)
+        for k in names:
+            pol.params[k].grad = None
+        v_r, v_c, lp, ent = pol.evaluate_actions(obs, act)
+        v_r, v_c = v_r.flatten(), v_c.flatten()
+        ent_t = ent if ent is not None and ent.dim() > 0 else None
+        # ---- the library's part 1: loss terms + d loss / d outputs
+        d_lp, d_vr, d_vc, d_en = (torch.empty(B, device="cuda") for _ in range(4))
+        o_lp, o_vr, o_vc = _dev(lp.detach().numpy()), _dev(v_r.detach().numpy()), _dev(v_c.detach().numpy())      # (kept alive across the call)
+        o_en = _dev(ent_t.detach().numpy()) if ent_t is not None else None
+        args = [_lib.ptr(o_lp), _lib.ptr(dev["old_lp"]), _lib.ptr(dev["adv_r"]), _lib.ptr(dev["adv_c"]),
+                _lib.ptr(o_vr), _lib.ptr(o_vc), _lib.ptr(dev["ret_r"]), _lib.ptr(dev["ret_c"]), None, None,
+                _lib.ptr(o_en), _lib.ptr(nu), ctypes.byref(hp), B, _lib.ptr(terms),
+                _lib.ptr(d_lp), _lib.ptr(d_vr), _lib.ptr(d_vc), _lib.ptr(d_en) if ent_t is not None else None, st]
+        _lib.check(L.icrl_ppo_lag_loss_fwd_bwd(*args), "icrl_ppo_lag_loss_fwd_bwd")
+        t = terms.cpu().numpy()
+        for i, key in enumerate(("loss", "policy_loss", "rvl", "cvl", "entropy_loss", "approx_kl", "clip_fraction")):
+            ref = float(g[f"s{s}/{key}"])
+            assert abs(t[i] - ref) <= 2e-6 + 2e-5 * abs(ref), (s, key, t[i], ref)
+        # ---- the host's part: backward through its networks from the library's output gradients
+        outs, grads = [lp, v_r, v_c], [d_lp.cpu(), d_vr.cpu(), d_vc.cpu()]
+        if ent_t is not None:
+            outs.append(ent_t); grads.append(d_en.cpu())
+        torch.autograd.backward(outs, grads)
+        for k in names:
+            ref = g[f"s{s}/grad/{k}"]
+            got = pol.params[k].grad.numpy()
+            assert np.allclose(got, ref, rtol=2e-4, atol=2e-7), (s, k, np.abs(got - ref).max())
+        # ---- the library's part 2: clip_grad_norm_ + Adam on the flat buffer
+        gflat = _dev(np.concatenate([pol.params[k].grad.numpy().ravel() for k in names]))
+        _lib.check(L.icrl_clip_adam_step(_lib.ptr(flat), _lib.ptr(gflat), _lib.ptr(m), _lib.ptr(v), _lib.ptr(step), n, ctypes.byref(hp), _lib.ptr(work),
+                                         _lib.ptr(out2), st), "icrl_clip_adam_step")
+        assert abs(out2[0].item() - float(g[f"s{s}/grad_norm"])) <= 1e-5 * max(1.0, float(g[f"s{s}/grad_norm"]))
+        new = flat.cpu().numpy()
+        off = 0
+        with torch.no_grad():
+            for k, sz in zip(names, sizes):
+                got = new[off:off + sz].reshape(pol.params[k].shape)
+                ref = g[f"s{s}/after/{k}"]
+                assert np.allclose(got, ref, rtol=1e-5, atol=3e-7), (s, k, np.abs(got - ref).max())
+                pol.params[k].copy_(torch.as_tensor(got))
+                off += sz
+    assert int(step.item()) == 3
+
+
+def test_minibatch_gather_and_adv_stats():
+    """buffers.py:53-65,594-627: flat env-major indices -> rows of the [T, N] buffer; ppo_lag.py:219-222 statistics."""
+    from icrl_amd import _lib, spaces
+    from icrl_amd.buffers import RolloutBufferWithCost
+    L = _lib.lib()
+    T, N, od, ad, n = 40, 7, 18, 6, 100
+    rb = RolloutBufferWithCost(T, spaces.Box(-np.inf, np.inf, (od,), np.float64), spaces.Box(-1, 1, (ad,), np.float32), "cuda", n_envs=N)
+    rng = np.random.RandomState(1)
+    ref = {}
+    for k in ("observations", "actions", "log_probs", "reward_advantages", "cost_advantages", "reward_returns", "cost_returns", "reward_values", "cost_values"):
+        a = rng.randn(*getattr(rb, k).shape).astype(np.float32)
+        getattr(rb, k).copy_(torch.as_tensor(a))
+        ref[k] = o_ppo.env_major(a.reshape(T, N, -1))
+    idx = rng.permutation(T * N)[:n].astype(np.int32)
+    outs = dict(obs=torch.empty(n, od, device="cuda"), act=torch.empty(n, ad, device="cuda"))
+    for k in ("lp", "ar", "ac", "rr", "rc", "vr", "vc"):
+        outs[k] = torch.empty(n, device="cuda")
+    s = rb.struct()
+    d_idx = _dev(idx, torch.int32)
+    _lib.check(L.icrl_minibatch_gather(ctypes.byref(s), _lib.ptr(d_idx), n, *[_lib.ptr(outs[k]) for k in ("obs", "act", "lp", "ar", "ac", "rr", "rc", "vr", "vc")],
+                                       _lib.current_stream()), "icrl_minibatch_gather")
+    pairs = dict(obs="observations", act="actions", lp="log_probs", ar="reward_advantages", ac="cost_advantages", rr="reward_returns", rc="cost_returns",
+                 vr="reward_values", vc="cost_values")
+    for k, name in pairs.items():
+        assert np.array_equal(outs[k].cpu().numpy().reshape(n, -1), ref[name][idx].reshape(n, -1)), k
+    out4 = torch.zeros(4, device="cuda")
+    _lib.check(L.icrl_adv_stats(_lib.ptr(outs["ar"]), _lib.ptr(outs["ac"]), n, _lib.ptr(out4), _lib.current_stream()), "icrl_adv_stats")
+    ar, ac = torch.as_tensor(ref["reward_advantages"][idx].ravel()), torch.as_tensor(ref["cost_advantages"][idx].ravel())
+    exp = [ar.mean().item(), 1.0 / (ar.std().item() + 1e-8), ac.mean().item(), ar.std().item()]
+    assert np.allclose(out4.cpu().numpy(), exp, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", "abcd")
+def test_dual_step_follows_the_reference_trajectories(golden, case):
+    """dual_variable.py:9-57 on the device against the reference's own nu trajectories (tests/golden/g5: 200 costs each, incl. the
+    clamp-floor case); float32 arithmetic with libm's expf / log1pf instead of torch's: 2e-6 relative."""
+    from icrl_amd import _lib
+    from icrl_amd.dual_variable import DualVariable, _inv_softplus_floor
+    L = _lib.lib()
+    g = _sub(golden("g5_dual"), case + "/")
+    nu0, lr, budget = (float(x) for x in g["params"])
+    host = DualVariable(budget, lr, nu0, None)
+    state = _dev(np.float32([host.log_nu, 0, 0, host.nu().item()]))
+    t = torch.zeros(1, dtype=torch.int32, device="cuda")
+    loss = torch.zeros(1, device="cuda")
+    clamp = float(np.float32(_inv_softplus_floor(host.clamp_at)))
+    traj = []
+    for c in g["costs"]:
+        _lib.check(L.icrl_dual_step(_lib.ptr(state), _lib.ptr(t), None, float(c), budget, lr, clamp, _lib.ptr(loss), _lib.current_stream()), "icrl_dual_step")
+        traj.append(torch.cat([state[3:4], loss, state[0:1]]).clone())
+    got = torch.stack(traj).cpu().numpy()
+    assert int(t.item()) == len(g["costs"])
+    assert np.allclose(got[:, 0], g["traj"][:, 0], rtol=2e-6, atol=1e-7), np.abs(got[:, 0] - g["traj"][:, 0]).max()      # nu
+    assert np.allclose(got[:, 2], g["traj"][:, 2], rtol=2e-6, atol=2e-7)                                                   # log_nu
+    assert np.allclose(got[:, 1], g["traj"][:, 1], rtol=2e-5, atol=1e-7)                                                   # loss = -nu (cost - budget)
