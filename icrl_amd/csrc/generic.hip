@@ -473,7 +473,8 @@ __global__ void __launch_bounds__(256) gen_adam_kernel(GenNet net, GenArgs a, in
     }
   }
   // the advantage statistics of the NEXT minibatch (read by the next step's forward / backward launch): the last workgroup, behind its
-  // share of the update — one launch less per step.  (The statistics in `ctl` were last read by this step's forward / backward.)
+  // share of the update — one launch less per step.  (The statistics in `ctl` were last read by this step's forward / backward.)  This
+  // workgroup runs whenever the next step will: a launch only leaves early for a stop decided by an EARLIER launch (stop_at above).
   if (next_nb > 0 && blockIdx.x == gridDim.x - 1) {
     __syncthreads();
     gen_stats_body(a, next_base, next_nb, red);

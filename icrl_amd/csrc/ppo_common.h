@@ -132,15 +132,39 @@ __device__ __forceinline__ bool packed_slot(int M, int n_runs, int& run, int& j)
   j = (id % per) / XCD_STRIDE;
   return run < n_runs;
 }
-// grid of the packed layout; 0: the runs' workgroups could not all be resident on their XCDs at once (32 CUs each, one workgroup per
-// CU) — the caller then uses the run-major layout, whose runs become resident oldest first
+// grid of the packed layout; 0: the runs' workgroups could not all be resident on their XCDs at once (one workgroup per CU, two CUs
+// of every XCD left to whatever else is in flight — the side-stream permutation sorts of a seed batch are short kernels that come and
+// go: they can delay a workgroup's dispatch, they cannot hold a CU against it, and the spins are bounded in seconds) — the caller then
+// uses the run-major layout, whose runs become resident oldest first
 inline int packed_grid(int M, int n_runs) {
   static const bool off = getenv("ICRL_NO_XCD_PACK") != nullptr;      // tests / A/B: the run-major layout (agent-scope stores) everywhere
+  static const int cus_per_xcd = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < XCD_STRIDE) return 32;
+    return cus / XCD_STRIDE;
+  }();
   const int groups = (n_runs + XCD_STRIDE - 1) / XCD_STRIDE;
-  if (off || groups * M > 30) return 0;
+  if (off || groups * M > cus_per_xcd - 2) return 0;
   return n_runs >= XCD_STRIDE ? groups * XCD_STRIDE * M : XCD_STRIDE * (M - 1) + n_runs;
 }
+// a single-run update launch: the packed 1-D grid as a cooperative launch; a device or partition that refuses it
+// (hipErrorCooperativeLaunchTooLarge: 8 (M - 1) + 1 workgroups of which M work) gets the plain M-workgroup grid
+template <class K>
+inline int launch_update_single(K kernel, int M, dim3 block, size_t dyn_lds, hipStream_t s, TrainArgs& arg) {
+  const int pg = packed_grid(M, 1);
+  hipError_t e = launch_coresident(kernel, dim3(pg ? pg : M), block, dyn_lds, s, arg, pg ? 1 : 0);
+  if (e == hipErrorCooperativeLaunchTooLarge && pg) {
+    (void)hipGetLastError();
+    e = launch_coresident(kernel, dim3(M), block, dyn_lds, s, arg, 0);
+  }
+  return (int)e;
+}
 
+// The `sc0` granule / raw stores rest on gfx942 / gfx950 behaviour (write-through L1, one L2 per XCD that every CU of the XCD reads
+// through, checked per launch by run_on_one_xcd): not a property of the HIP memory model.  This library is built for gfx950 only.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "libicrl_hip: the XCD-local exchange of the persistent kernels is written for gfx950 (CDNA4) / gfx942"
+#endif
 
 // ppo_train_rows.hip: row-owning-wave kernel (nt1 = ceil(obs / 16) <= 8), one wave per SIMD
 int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hipStream_t s);

@@ -969,8 +969,7 @@ static int launch_halves(const TrainArgs* one, const TrainArgs* d_args, int n_ru
   static_assert(SmemH<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
   if (one != nullptr) {
     TrainArgs arg = *one;
-    const int pg = packed_grid(6, 1);
-    return (int)launch_coresident(ppo_train_halves_kernel<NT1, DISC, OBS>, dim3(pg ? pg : 6), dim3(THH), 0, s, arg, pg ? 1 : 0);
+    return launch_update_single(ppo_train_halves_kernel<NT1, DISC, OBS>, 6, dim3(THH), 0, s, arg);
   }
   const int pg = packed_grid(6, n_runs);
   hipLaunchKernelGGL((ppo_train_halves_batch_kernel<NT1, DISC, OBS>), pg ? dim3(pg) : dim3(6, n_runs), dim3(THH), 0, s, d_args, n_runs, pg ? 1 : 0);

@@ -1332,8 +1332,7 @@ static int launch_pairs(const TrainArgs* one, const TrainArgs* d_args, int n_run
     hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
     TrainArgs arg = *one;
-    const int pg = packed_grid(3, 1);
-    return (int)launch_coresident(ppo_train_pairs_kernel<NT1, DISC, OBS>, dim3(pg ? pg : 3), dim3(TH8), bytes, s, arg, pg ? 1 : 0);
+    return launch_update_single(ppo_train_pairs_kernel<NT1, DISC, OBS>, 3, dim3(TH8), bytes, s, arg);
   } else {
     hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_batch_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;

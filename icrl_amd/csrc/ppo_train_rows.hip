@@ -1340,8 +1340,7 @@ static int launch_rows(const TrainArgs& a, hipStream_t s) {
   hipError_t e = hipFuncSetAttribute((const void*)ppo_train_rows_kernel<NT1, DISC, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
   TrainArgs arg = a;
-  const int pg = packed_grid(SPLIT ? 6 : 3, 1);
-  return (int)launch_coresident(ppo_train_rows_kernel<NT1, DISC, SPLIT>, dim3(pg ? pg : (SPLIT ? 6 : 3)), dim3(TH4), bytes, s, arg, pg ? 1 : 0);
+  return launch_update_single(ppo_train_rows_kernel<NT1, DISC, SPLIT>, SPLIT ? 6 : 3, dim3(TH4), bytes, s, arg);
 }
 
 int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hipStream_t s) {
