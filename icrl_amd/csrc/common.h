@@ -24,7 +24,7 @@ int launch_policy_generic(const icrl_policy_t* p, const double* obs, const float
                           const float* ahigh, float* actions, float* act_clipped, float* v_r, float* v_c, float* log_prob,
                           const float* given, float* entropy, hipStream_t s);
 int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
-                         const int* perm_off, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* scratch, hipStream_t s);
+                         const int* perm_off, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* scratch, void* sync_ws, hipStream_t s);
 int generic_row_floats(const icrl_policy_t* pol);
 int launch_generic_transpose(const icrl_policy_t* p, hipStream_t s);       // icrl_policy_prepare of a generic-path policy
 int policy_generic_check(const icrl_policy_t* p, const char* who);      // 0, or the fail() code of an architecture the path refuses

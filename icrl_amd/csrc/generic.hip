@@ -490,11 +490,519 @@ __global__ void gen_finish_kernel(GenArgs a, int* adam_t) {
   adam_t[0] += ctl->steps_done;
 }
 
-static_assert(ICRL_PPO_GENERIC_BYTES(64, 776, 1000) == 4 * (64 + 64 * (24 + 1 + 16 + 2 * 776) + 1000 + 4 + 1088), "ICRL_PPO_GENERIC_BYTES");
+// =====================================================================================================================
+// ONE persistent launch per train() (round 5): the same GenNet table, the update as fp32 MFMA tiles.
+// =====================================================================================================================
+// grid = G = ceil(batch_size / 16) workgroups of 8 waves; workgroup g takes rows 16 g .. 16 g + 15 of EVERY minibatch through the whole
+// network — activations and pre-activation gradients of its 16 rows live in LDS, row-major and padded per layer to 16 units; every GEMM
+// is a chain of v_mfma_f32_16x16x4_f32 whose A operand (weights: `params` row-major for the forward and the weight gradients' layout,
+// the per-layer transposes `params_t` for the backward) is streamed from L2 and whose B operand is one ds_read_b128 of the row image;
+// the 16 x 16 tiles of a stage are dealt round-robin to the waves — then writes its PARTIAL weight gradients (K = its 16 rows: four
+// MFMAs per parameter tile) to `part[g]`.  Across workgroups, per optimiser step: grid barrier | workgroup g sums the partials of ITS
+// parameter slice over the tiles in tile order (deterministic), leaves the gradient and its squared norm | grid barrier | every
+// workgroup forms the same total norm and runs clip + Adam on its slice (both parameter images) | grid barrier.  Data that crosses
+// workgroups (partials, parameters, norms, loss sums) is written and read with agent-scope relaxed atomics (sc1: no stale L1 / non-local L2
+// line), a barrier arrival is preceded by s_waitcnt vmcnt(0); no fences.  Every workgroup accumulates the SAME logged sums and takes
+// the same target-KL decision from them, so nothing has to be broadcast.
+// Shapes this form does not serve (more than GENP_MAX_TILES row tiles, more than GENP_MAX_PARAMS parameters, rows that do not fit the
+// LDS) keep the three-launches-per-step form below.
+constexpr int GENP_TH = 512;
+constexpr int GENP_MAX_TILES = 32;            // batch_size <= 512
+constexpr int GENP_MIN_TILES = 16;            // the default from this many row tiles on (batch_size > 240): below, the launch-per-phase form is faster (measured)
+constexpr int GENP_MAX_PARAMS = 131072;
+constexpr int GENP_MAX_RS = 1096;             // floats per LDS row: 2 images x 16 rows x RS x 4 B <= 140 KB
+
+struct GenPersist {
+  int RS, OB, G, H, slice;                    // LDS row stride | observation width padded to 16 | row-tile workgroups | all workgroups (G + helpers of the reduce / Adam phases) | parameters per workgroup there
+  int poff[GEN_MAX_LAYERS];                   // padded offset of each layer's output inside a row (the observation sits at 0)
+  const PlanStep* plan;                       // per optimiser step: Adam's bias corrections, rows, flags, permutation base
+  int n_steps;
+  float* part; float* grad; float* norm; float* stat; unsigned* bar; int* tidx;      // [G][n] | [n] | [G] | [G][8] | barrier counter | [n] position of a parameter in params_t
+};
+
+// loads: agent scope (sc1: the L1 is bypassed; served by the XCD's L2 when the line is there).  stores: agent scope (sc1: written through, the
+// line is DROPPED from the L2 — every later load pays the fabric, ~2 us) unless all workgroups of the launch share one XCD (`local`,
+// checked at run time: HW_REG_XCC_ID of every workgroup), then workgroup scope (sc0: the line stays in the one L2 all of them read through)
+__device__ __forceinline__ float ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <bool LOCAL>
+__device__ __forceinline__ void st_x(float* p, float v) {
+  if (LOCAL) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Shared read-mostly data (parameters, partial gradients) goes through buffer resources with the sc1 cache policy — L1 bypassed,
+// served by the XCD's L2 — as plain (non-atomic) loads: a chain of relaxed ATOMIC loads is issued one at a time (each waited for
+// before the next: 16 trips to the L2 per K chunk, measured 6 k cycles per chunk), buffer loads are scheduled freely, and an offset
+// beyond the resource returns 0, which is the mask of the padded tiles.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t genp_rsrc(const float* p, size_t n_floats) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(n_floats * 4), 0x00020000);
+}
+// cache policy of the loads: sc1 (agent scope) is only served by the L2 for a line that is DIRTY there — anything else goes to the fabric
+// (~6 k cycles measured) —; when all workgroups share an XCD (`local`) sc0 is enough: the L1 is bypassed and the one L2 everybody
+// writes through serves every resident line (~700 cycles)
+template <bool LOCAL>
+__device__ __forceinline__ float genp_ld(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {      // (the policy is an immediate of the instruction: a compile-time choice)
+  if (LOCAL) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 1));
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 16));
+}
+constexpr unsigned GENP_OOB = 0x80000000u;      // an offset outside every resource (they hold <= 16 MB), with room for the constant offsets added to it: the load returns 0, the store is dropped
+
+// acc[i] (unit 16 t + 4 q + i, row r) += sum_k A[16 t + r][k] B[r][k]:  A[m][k] = W[w_off + m * ldk + k] (zero outside nM x nK),
+// B = the LDS row image at `brow` (= image + r * RS + the input's padded offset).  K in chunks of 64 (16 weights per lane), the next
+// chunk's loads in flight under this chunk's MFMAs.
+template <bool LOCAL>
+__device__ __forceinline__ f32x4 genp_gemm(f32x4 acc, __amdgpu_buffer_rsrc_t rs, int w_off, int t, int ldk, int nM, int nK, const float* brow, int r, int q) {
+  // Masking without a branch in the load stream (a select between two LOADS becomes divergent control flow with a wait in every arm —
+  // measured 10 k cycles per tile): a row m >= nM starts at an offset outside the resource, so all its loads return 0; columns
+  // k >= nK need no mask at all — the B operand's pad columns are zeros (every tile is stored 16 wide with its rows masked like this),
+  // the weights read there are some other finite parameters, or 0 past the end of the resource.
+  const int m = 16 * t + r;
+  const unsigned base = m < nM ? 4u * (unsigned)(w_off + m * ldk + 4 * q) : GENP_OOB;
+  auto fetch = [&](int k0, float (&a)[16]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[4 * c + e] = genp_ld<LOCAL>(rs, base + 4u * (unsigned)(k0 + 16 * c + e));
+  };
+  float cur[16], nxt[16];
+  fetch(0, cur);
+  for (int k0 = 0; k0 < nK; k0 += 64) {
+    const bool more = k0 + 64 < nK;
+    if (more) fetch(k0 + 64, nxt);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (k0 + 16 * c < nK) {
+        const f32x4 b = lds128(brow + k0 + 16 * c + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = MFMA_F32(cur[4 * c + e], b[e], acc);
+      }
+    }
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
+    }
+  }
+  return acc;
+}
+
+template <bool LOCAL>
+__device__ __forceinline__ void genp_grid_barrier(unsigned* bar, unsigned target) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (LOCAL) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (atomics execute in the L2: the one all workgroups share)
+    else __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+  }
+  __syncthreads();
+}
+
+// fixed tree over the 8 waves of the workgroup (wave sums by DPP, then the eight in order): every workgroup forms the same value
+__device__ __forceinline__ float genp_block_sum(float v, float* red8) {
+  v = wave_sum_fast(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red8[w] = v;
+  __syncthreads();
+  return ((red8[0] + red8[1]) + (red8[2] + red8[3])) + ((red8[4] + red8[5]) + (red8[6] + red8[7]));
+}
+
+// the body for one store / load policy (LOCAL: every workgroup of the launch sits on the same XCD)
+template <bool LOCAL>
+__device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, const GenPersist& pp, const int g, float* const sm, unsigned bar_n) {
+  constexpr bool local = LOCAL;
+  const int RS = pp.RS, G = pp.G, H = pp.H;
+  const bool tile_wg = g < G;                  // workgroups G .. H-1 only help with the reduce / Adam phases
+  float* const ACT = sm;                       // [16][RS] observation + every layer's output
+  float* const DZ = sm + 16 * RS;              // [16][RS] d loss / d pre-activation
+  float* const G2 = DZ + 16 * RS;              // [16][16] log_std gradient terms of the rows
+  float* const RST = G2 + 256;                 // [3][16][8] per-row loss terms
+  float* const RED = RST + 384;                // [16] reduction scratch
+  int* const RIDX = reinterpret_cast<int*>(RED + 16);      // [16] storage offsets of the rows
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+  const int n = net.n, O = net.O, A = net.A;
+  const __amdgpu_buffer_rsrc_t rsP = genp_rsrc(a.params, (size_t)n), rsPT = genp_rsrc(a.params_t, (size_t)n), rsPart = genp_rsrc(pp.part, (size_t)G * n);
+  const int lo = g * pp.slice, hi = (lo + pp.slice < n) ? lo + pp.slice : n;      // this workgroup's parameter slice
+  // replicated logged state (identical in every workgroup)
+  float acc_ent = 0.f, acc_pg = 0.f, acc_cf = 0.f, acc_vr = 0.f, acc_vc = 0.f, last_pol = 0.f, last_vr = 0.f, last_vc = 0.f, kl_acc = 0.f, mean_kl = 0.f;
+  int steps_done = 0, early_stop_epoch = a.hp.n_epochs;
+  const float nu = a.nu[0];
+  bool stop = false;
+  const bool prof = (a.hp._pad & 1) != 0 && g == 0;       // phase timers of workgroup 0, thread 0 (tools/generic_only.py PROF=1): stats[12..21]
+  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = prof ? stamp() : 0ull;
+#define GSTAMP(k) if (prof) { const unsigned long long now_ = stamp(); ph[k] += now_ - t_last; t_last = now_; }
+  for (int st = 0; st < pp.n_steps && !stop; ++st) {
+    const PlanStep ps = pp.plan[st];
+    const int nb = ps.nb_flags & NB_MASK, epoch = ps.nb_flags >> NB_EPOCH;
+    const bool first_mb = (ps.nb_flags >> NB_FIRST) & 1, last_mb = (ps.nb_flags >> NB_LAST) & 1;
+    const float inv_nb = 1.f / (float)nb;
+    if (tile_wg) {
+    // ---- rows of this tile -> LDS; advantage statistics of the whole minibatch (every workgroup, identically)
+    if (tid < 16) {
+      const int row = 16 * g + tid;
+      RIDX[tid] = a.perm_off[ps.perm_base + (row < nb ? row : 0)];
+    }
+    float sr = 0.f, sc = 0.f, srr = 0.f;
+    for (int i = tid; i < nb; i += GENP_TH) {
+      const int idx = a.perm_off[ps.perm_base + i];
+      const float ar = a.buf.reward_advantages[idx];
+      sr += ar; sc += a.buf.cost_advantages[idx]; srr += ar * ar;
+    }
+    __syncthreads();
+    for (int i = tid; i < 16 * pp.OB; i += GENP_TH) {
+      const int rr = i / pp.OB, k = i - rr * pp.OB;
+      ACT[rr * RS + k] = k < O ? a.buf.observations[(size_t)RIDX[rr] * O + k] : 0.f;
+    }
+    sr = genp_block_sum(sr, RED); sc = genp_block_sum(sc, RED); srr = genp_block_sum(srr, RED);
+    const float mean_r = sr * inv_nb, mean_c = sc * inv_nb;
+    const float istd_r = 1.f / (sqrtf(fmaxf(srr - sr * mean_r, 0.f) / (float)(nb - 1)) + 1e-8f);
+    __syncthreads();
+    GSTAMP(0)   // rows + advantage statistics
+    // ================= forward, stage by stage =================
+    for (int s = 0; s < net.n_stages; ++s) {
+      int item = 0;
+      for (int l = net.stage_begin[s]; l < net.stage_begin[s + 1]; ++l) {
+        const GenLayer& y = net.layer[l];
+        const int in_off = y.in_buf < 0 ? 0 : pp.poff[y.in_buf];
+        for (int t = 0; t < (y.out_dim + 15) / 16; ++t, ++item) {
+          if ((item & 7) != w) continue;
+          f32x4 acc;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const int j = 16 * t + 4 * q + i; acc[i] = genp_ld<LOCAL>(rsP, j < y.out_dim ? 4u * (unsigned)(y.b_off + j) : GENP_OOB); }
+          acc = genp_gemm<LOCAL>(acc, rsP, y.w_off, t, y.in_dim, y.out_dim, y.in_dim, ACT + r * RS + in_off, r, q);
+          if (y.tanh) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = fast_tanh(acc[i]);
+          }
+          *reinterpret_cast<f32x4*>(ACT + r * RS + pp.poff[l] + 16 * t + 4 * q) = acc;
+        }
+      }
+      __syncthreads();
+    }
+    GSTAMP(1)   // forward
+    // ================= loss terms of the three heads: thread (role, row) =================
+    if (tid < 48) {
+      const int role = tid >> 4, row = tid & 15;
+      const bool valid = 16 * g + row < nb;
+      const int idx = RIDX[row];
+      float* dout = DZ + row * RS + pp.poff[net.head[role]];
+      const float* out = ACT + row * RS + pp.poff[net.head[role]];
+      float* rs = RST + (role * 16 + row) * 8;
+      if (role == 0) {
+        float lp = 0.f, ent = 0.f, g1[MAX_ACT], g2[MAX_ACT];
+        if (!net.discrete) {
+          for (int o = 0; o < A; ++o) {
+            const float ls = genp_ld<LOCAL>(rsP, 4u * (unsigned)(net.log_std + o)), sd = __expf(ls), iv = 1.f / (sd * sd);
+            const float dd = a.buf.actions[(size_t)idx * a.buf.act_store + o] - out[o];
+            lp += -(dd * dd) * (0.5f * iv) - ls - LOG_SQRT_2PI_F;
+            g1[o] = dd * iv;
+            g2[o] = (dd * dd) * iv - 1.f;
+            ent += HALF_LOG_2PI_PLUS_HALF_F + ls;
+          }
+        } else {
+          float m = -INFINITY;
+          for (int o = 0; o < A; ++o) m = fmaxf(m, out[o]);
+          float se = 0.f;
+          for (int o = 0; o < A; ++o) se += expf(out[o] - m);
+          const float lse = m + logf(se);
+          const int action = (int)a.buf.actions[(size_t)idx * a.buf.act_store];
+          for (int o = 0; o < A; ++o) { const float lg = out[o] - lse; ent -= expf(lg) * lg; }
+          for (int o = 0; o < A; ++o) {
+            const float lg = out[o] - lse, pr = expf(lg);
+            if (o == action) lp = lg;
+            g1[o] = (o == action ? 1.f : 0.f) - pr;
+            g2[o] = pr * (lg + ent);
+          }
+        }
+        const float old_lp = a.buf.log_probs[idx];
+        const float ratio = __expf(lp - old_lp);
+        const float Ar = (a.buf.reward_advantages[idx] - mean_r) * istd_r;
+        const float Ac = a.buf.cost_advantages[idx] - mean_c;
+        const float clip = a.hp.clip_range;
+        const float s1 = Ar * ratio, s2 = Ar * fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+        const float gsel = (s1 <= s2) ? Ar : 0.f;
+        const float dlp = valid ? inv_nb / (1.f + nu) * (-gsel + nu * Ac) * ratio : 0.f;
+        const float dent = valid ? a.hp.ent_coef * inv_nb : 0.f;
+        for (int o = 0; o < 16; ++o) G2[row * 16 + o] = 0.f;
+        for (int o = 0; o < A; ++o) {
+          dout[o] = net.discrete ? dlp * g1[o] + dent * g2[o] : dlp * g1[o];
+          G2[row * 16 + o] = net.discrete ? 0.f : dlp * g2[o];
+        }
+        rs[0] = valid ? fminf(s1, s2) : 0.f; rs[1] = valid ? Ac * ratio : 0.f; rs[2] = (valid && fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
+        rs[3] = valid ? old_lp - lp : 0.f; rs[4] = valid ? ent : 0.f;
+      } else {
+        const float v = out[0];
+        const float R = role == 1 ? a.buf.reward_returns[idx] : a.buf.cost_returns[idx];
+        const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
+        const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
+        float vp = v, pass = 1.f;
+        if (vclip >= 0.f) {
+          const float old = role == 1 ? a.buf.reward_values[idx] : a.buf.cost_values[idx];
+          const float dv = v - old;
+          vp = old + fminf(fmaxf(dv, -vclip), vclip);
+          pass = (dv >= -vclip && dv <= vclip) ? 1.f : 0.f;
+        }
+        const float e = vp - R;
+        dout[0] = valid ? vcoef * 2.f * e * inv_nb * pass : 0.f;
+        rs[0] = valid ? e * e : 0.f;
+      }
+    }
+    __syncthreads();
+    GSTAMP(2)   // loss
+    // ================= backward of the activations, stage by stage: d h = sum over the layers that read h of W^T dz (layer order) =================
+    for (int s = net.n_stages - 2; s >= 0; --s) {
+      int item = 0;
+      for (int l = net.stage_begin[s]; l < net.stage_begin[s + 1]; ++l) {
+        const GenLayer& y = net.layer[l];
+        for (int t = 0; t < (y.out_dim + 15) / 16; ++t, ++item) {
+          if ((item & 7) != w) continue;
+          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int c = l + 1; c < net.n_layers; ++c) {
+            const GenLayer& z = net.layer[c];
+            if (z.in_buf != l) continue;
+            acc = genp_gemm<LOCAL>(acc, rsPT, z.w_off, t, z.out_dim, z.in_dim, z.out_dim, DZ + r * RS + pp.poff[c], r, q);      // A[k][j] = Wt[k * out + j]
+          }
+          const f32x4 h = lds128(ACT + r * RS + pp.poff[l] + 16 * t + 4 * q);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] = fmaf(-(h[i] * h[i]), acc[i], acc[i]);
+          *reinterpret_cast<f32x4*>(DZ + r * RS + pp.poff[l] + 16 * t + 4 * q) = acc;
+        }
+      }
+      __syncthreads();
+    }
+    GSTAMP(3)   // backward
+    // ================= partial weight gradients of this tile's 16 rows -> part[g] =================
+    float* const mypart = pp.part + (size_t)g * n;
+    {
+      int item = 0;
+      for (int l = 0; l < net.n_layers; ++l) {
+        const GenLayer& y = net.layer[l];
+        const int in_off = y.in_buf < 0 ? 0 : pp.poff[y.in_buf];
+        for (int jt = 0; jt < (y.out_dim + 15) / 16; ++jt, ++item) {
+          if ((item & 7) != w) continue;
+          float az[4];      // dz[row 4 q + e][unit 16 jt + r]
+#pragma unroll
+          for (int e = 0; e < 4; ++e) az[e] = DZ[(4 * q + e) * RS + pp.poff[l] + 16 * jt + r];
+          unsigned jrow[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const int j = 16 * jt + 4 * q + i; jrow[i] = j < y.out_dim ? 4u * (unsigned)(g * n + y.w_off + j * y.in_dim) : GENP_OOB / 2; }
+          for (int kt = 0; kt < (y.in_dim + 15) / 16; ++kt) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = MFMA_F32(az[e], ACT[(4 * q + e) * RS + in_off + 16 * kt + r], acc);
+            // (an element outside the layer: row or column offset outside the resource — two halves of GENP_OOB, so that one or both
+            // of them push the sum out of range without wrapping — and the store is dropped; no branch in the store stream)
+            const unsigned koff = 16 * kt + r < y.in_dim ? 4u * (unsigned)(16 * kt + r) : GENP_OOB / 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const unsigned off = jrow[i] + koff;
+              if (LOCAL) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i]), rsPart, (int)off, 0, 1);
+              else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i]), rsPart, (int)off, 0, 16);
+            }
+          }
+          // bias: the sum over the 16 rows (lanes r = unit, q = row group): rows 4 q .. 4 q + 3, then over q
+          const float sb = quad_rows_sum((az[0] + az[1]) + (az[2] + az[3]));
+          if (q == 0 && 16 * jt + r < y.out_dim) st_x<LOCAL>(mypart + y.b_off + 16 * jt + r, sb);
+        }
+      }
+      if (!net.discrete && tid < A) {
+        float sl = 0.f;
+        for (int rr = 0; rr < 16; ++rr) sl += G2[rr * 16 + tid];
+        st_x<LOCAL>(mypart + net.log_std + tid, sl);
+      }
+      if (tid < 8) {      // this tile's loss sums: policy terms 0..4, reward / cost value errors 5, 6
+        float v = 0.f;
+        if (tid < 5) for (int rr = 0; rr < 16; ++rr) v += RST[rr * 8 + tid];
+        else if (tid < 7) for (int rr = 0; rr < 16; ++rr) v += RST[((tid - 4) * 16 + rr) * 8];
+        st_x<LOCAL>(pp.stat + g * 8 + tid, v);
+      }
+    }
+    }      // tile_wg
+    GSTAMP(4)   // weight gradients
+    bar_n += H; genp_grid_barrier<LOCAL>(pp.bar, bar_n);           // (A) every tile's partials are in memory
+    GSTAMP(5)   // barrier A
+    // ================= this workgroup's parameter slice: sum over the tiles in tile order, squared norm =================
+    float ss = 0.f;
+    for (int e0 = lo + 4 * tid; e0 < hi; e0 += 4 * GENP_TH) {      // four consecutive elements per thread: G 16-byte loads in flight
+      f32x4 gs = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < G; t += 4) {
+        f32x4 pv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const unsigned off = t + u < G ? 4u * (unsigned)((t + u) * n + e0) : GENP_OOB;
+          pv[u] = __builtin_bit_cast(f32x4, LOCAL ? __builtin_amdgcn_raw_buffer_load_b128(rsPart, (int)off, 0, 1) : __builtin_amdgcn_raw_buffer_load_b128(rsPart, (int)off, 0, 16));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gs[i] += pv[u][i];      // tile order (absent tiles read 0)
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int e = e0 + i;
+        if (e < hi) {
+          if (!net.discrete && e >= net.log_std && e < net.log_std + A) gs[i] += -a.hp.ent_coef;      // d(ent_coef * -mean H) / d log_std
+          pp.grad[e] = gs[i];
+          ss = fmaf(gs[i], gs[i], ss);
+        }
+      }
+    }
+    ss = genp_block_sum(ss, RED);
+    if (tid == 0) st_x<LOCAL>(pp.norm + g, ss);
+    GSTAMP(6)   // reduce + norm
+    bar_n += H; genp_grid_barrier<LOCAL>(pp.bar, bar_n);           // (B) every slice's squared norm is in memory
+    GSTAMP(7)   // barrier B
+    float total = 0.f, q7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    {   // every tile's loss sums and every slice's squared norm: fetched side by side (one value per thread; a chain of relaxed atomic
+        // loads, or a loop of dependent buffer loads, is one L2 round trip per value: 26 k cycles at 32 tiles), summed in tile order from LDS
+      const __amdgpu_buffer_rsrc_t rsX = genp_rsrc(pp.stat, 512);      // [stat G x 8 | norm H]
+      __syncthreads();
+      if (tid < 8 * G) RST[tid] = genp_ld<LOCAL>(rsX, 4u * (unsigned)tid);
+      else if (tid >= 256 && tid < 256 + H) RST[tid] = genp_ld<LOCAL>(rsX, 4u * (unsigned)tid);
+      __syncthreads();
+      for (int t = 0; t < H; ++t) total += RST[256 + t];
+      for (int t = 0; t < G; ++t) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) q7[k] += RST[t * 8 + k];
+      }
+    }
+    const float cc = a.hp.max_grad_norm / (sqrtf(total) + 1e-6f), coef = cc > 1.f ? 1.f : cc;
+    {
+      const float b1 = a.hp.adam_beta1, b2 = a.hp.adam_beta2, w1 = (float)(1.0 - (double)b1), w2 = (float)(1.0 - (double)b2);
+      for (int e0 = lo + 4 * tid; e0 < hi; e0 += 4 * GENP_TH) {
+        float gv[4], mv[4], vv[4], pw[4];
+        int ti[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int ec = e0 + u < hi ? e0 + u : lo;
+          gv[u] = pp.grad[ec]; mv[u] = a.exp_avg[ec]; vv[u] = a.exp_avg_sq[ec]; pw[u] = genp_ld<LOCAL>(rsP, 4u * (unsigned)ec); ti[u] = pp.tidx[ec];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e0 + u;
+          if (e < hi) {
+            const float gc = gv[u] * coef;
+            const float m = fmaf(w1, gc, b1 * mv[u]);
+            const float v = fmaf(w2, gc * gc, b2 * vv[u]);
+            a.exp_avg[e] = m; a.exp_avg_sq[e] = v;
+            const float nw = fmaf(-ps.step_size, m / fmaf(sqrtf(v), ps.inv_bc2_sqrt, a.hp.adam_eps), pw[u]);
+            st_x<LOCAL>(a.params + e, nw);
+            st_x<LOCAL>(a.params_t + ti[u], nw);
+          }
+        }
+      }
+    }
+    {   // logged sums (every workgroup, identically; workgroup 0 writes them out at the end)
+      const float ent = q7[4] * inv_nb, entropy_loss = -ent;
+      const float pl = (-(q7[0] * inv_nb) + nu * (q7[1] * inv_nb)) / (1.f + nu);
+      acc_ent += entropy_loss; acc_pg += pl; acc_cf += q7[2] * inv_nb;
+      acc_vr += q7[5] * inv_nb; acc_vc += q7[6] * inv_nb;
+      last_pol = pl + a.hp.ent_coef * entropy_loss; last_vr = q7[5] * inv_nb; last_vc = q7[6] * inv_nb;
+      if (first_mb) kl_acc = 0.f;
+      kl_acc += q7[3] * inv_nb;
+      ++steps_done;
+      if (last_mb) {
+        mean_kl = kl_acc / (float)a.n_mb;
+        if (g == 0 && tid == 0) a.stats[32 + epoch] = mean_kl;
+        if (a.hp.use_target_kl && mean_kl > 1.5f * a.hp.target_kl) { stop = true; early_stop_epoch = epoch; }
+      }
+    }
+    GSTAMP(8)   // Adam + logged sums
+    bar_n += H; genp_grid_barrier<LOCAL>(pp.bar, bar_n);           // (C) the updated parameters are in memory
+    GSTAMP(9)   // barrier C
+  }
+  if (prof && tid == 0) a.stats[22] = local ? 1.f : 0.f;
+  if (prof && tid == 0)
+    for (int k = 0; k < 10; ++k) a.stats[12 + k] = (float)((double)ph[k] / (double)(steps_done > 0 ? steps_done : 1));
+  if (g == 0 && tid == 0) {
+    a.stats[0] = (float)early_stop_epoch;
+    a.stats[1] = (float)steps_done;
+    a.stats[2] = acc_ent; a.stats[3] = acc_pg; a.stats[4] = acc_vr; a.stats[5] = acc_vc; a.stats[6] = acc_cf;
+    a.stats[7] = mean_kl; a.stats[8] = last_pol; a.stats[9] = last_vr; a.stats[10] = last_vc; a.stats[11] = 0.f;
+    const_cast<int*>(a.adam_t)[0] += steps_done;
+  }
+}
+
+__global__ void __launch_bounds__(GENP_TH) gen_train_persistent_kernel(GenNet net, GenArgs a, GenPersist pp, int packed) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  // packed: a 1-D grid of 8 (G - 1) + 1 workgroups of which every eighth works — workgroups are dealt round-robin over the 8 XCDs, so
+  // the G working ones land on ONE (ppo_common.h: XCD placement); the others leave at once
+  if (packed && (blockIdx.x & (XCD_STRIDE - 1)) != 0) return;
+  const int H = pp.H, g = packed ? (int)blockIdx.x / XCD_STRIDE : (int)blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < 32 * pp.RS + 256 + 384 + 32; i += GENP_TH) sm[i] = 0.f;
+  for (int e = g * pp.slice + tid; e < g * pp.slice + pp.slice && e < net.n; e += GENP_TH) pp.tidx[e] = gen_transposed_index(net, e);      // (read back by the same thread)
+  __syncthreads();
+  // do all workgroups share an XCD?  (every workgroup publishes its XCC id in its norm slot, one barrier, everybody compares)
+  unsigned bar_n = 0;
+  if (tid == 0) __hip_atomic_store(pp.norm + g, __uint_as_float(0x100u | xcc_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bar_n += H; genp_grid_barrier<false>(pp.bar, bar_n);
+  bool local = true;
+  for (int t = 0; t < H; ++t) local = local && __float_as_uint(ld_sc1(pp.norm + t)) == (0x100u | xcc_id());
+  local = __builtin_amdgcn_readfirstlane((int)local) != 0;
+  bar_n += H; genp_grid_barrier<false>(pp.bar, bar_n);      // (the slots are reused by the first step's norms)
+  if (local) genp_body<true>(net, a, pp, g, sm, bar_n);
+  else genp_body<false>(net, a, pp, g, sm, bar_n);
+}
+
+static_assert(ICRL_PPO_GENERIC_BYTES(64, 776, 1000) == 4 * (64 + 64 * (24 + 1 + 16 + 2 * 776) + 1000 + 4 + 1088 + 5 * 1000 + 1024), "ICRL_PPO_GENERIC_BYTES");
+static_assert(ICRL_PPO_GENERIC_BYTES(1024, 776, 1000) == 4 * (64 + 1024 * (24 + 1 + 16 + 2 * 776) + 1000 + 4 + 1088), "ICRL_PPO_GENERIC_BYTES");
+
+// the schedule table of ppo_train.hip (per optimiser step: Adam's bias corrections in double, rows, flags, permutation base)
+__global__ void ppo_plan_kernel(const int* adam_t, int n_steps, int n_mb, int n_total, int B, double lr, double b1, double b2, PlanStep* steps,
+                                PlanChunk* chunks, int two_per_step);
+
+// the persistent form, when the shape allows it: 0 launched | < 0 not eligible (the caller uses the launch-per-phase form) | > 0 error
+static int launch_train_generic_persistent(const GenNet& net, GenArgs& a, const icrl_ppo_hyper_t* hp, int32_t* adam_step, void* sync_ws, hipStream_t s) {
+  // WHERE IT IS THE DEFAULT IS MEASURED (round 5, MI355X, tools/generic_only.py): a 64-row minibatch is FOUR row tiles, i.e. four compute
+  // units walking every stage of the network one after the other (three 16 x 16 tiles per wave and stage, each a 32-MFMA chain behind an
+  // L2 round trip), where the launch-per-phase form spreads the same rows over 64 compute units: -pl 128 128 -rvl 128 128 -cvl 128 128 at
+  // batch 64: 56 us per optimiser step against 45 (per step of workgroup 0, cycles: rows + statistics 4.9 k | forward 29.2 k | loss 6.0 k |
+  // backward 24.6 k | weight gradients 36.4 k | barrier 2.0 k | reduce 2.6 k | barrier 2.7 k | Adam + logged sums 13.5 k | barrier 8.4 k);
+  // with 32 row tiles (default widths, batch 512) the same phases take 15.2 | 11.6 | 17.3 k and the step 48 us against 64.  So: the default
+  // from GENP_MIN_TILES row tiles on; ICRL_GEN_PERSISTENT=1 / ICRL_GEN_LAUNCHES=1 force one form (tests run both).
+  static const bool on = getenv("ICRL_GEN_PERSISTENT") != nullptr, off = getenv("ICRL_GEN_LAUNCHES") != nullptr;
+  const int B = hp->batch_size, G = (B + 15) / 16, n = net.n;
+  if (off || (!on && G < GENP_MIN_TILES) || G > GENP_MAX_TILES || n > GENP_MAX_PARAMS || B > NB_MASK) return -1;
+  GenPersist pp;
+  pp.OB = (net.O + 15) / 16 * 16;
+  int off_ = pp.OB;
+  for (int l = 0; l < net.n_layers; ++l) { pp.poff[l] = off_; off_ += (net.layer[l].out_dim + 15) / 16 * 16; }
+  pp.RS = off_ + ((8 - off_ % 32) + 32) % 32;      // = 8 mod 32: conflict-free ds_read_b128 of a row image
+  if (pp.RS > GENP_MAX_RS) return -1;
+  const long long n_steps = (long long)hp->n_epochs * a.n_mb;
+  if (n_steps >= (1ll << 21)) return -1;
+  // helpers for the reduce / Adam phases: ~2048 parameters per workgroup, all workgroups on one XCD when that fits (<= its CUs)
+  int H = (n + 2047) / 2048;
+  H = H < G ? G : (H > 30 ? (G > 30 ? G : 30) : H);
+  pp.G = G; pp.H = H; pp.slice = ((n + H - 1) / H + 3) / 4 * 4;
+  PlanStep* steps = reinterpret_cast<PlanStep*>((char*)sync_ws + 512);
+  hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, a.n_mb, a.n_total, B,
+                     (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, (PlanChunk*)nullptr, 0);
+  pp.plan = steps; pp.n_steps = (int)n_steps;
+  float* extra = a.scratch + gen_floats(B, net.row_floats, n);      // behind the launch-per-phase layout: [stat G x 8 | norm G | part G x n]
+  pp.stat = extra; pp.norm = extra + 256; pp.tidx = reinterpret_cast<int*>(extra + 512); pp.part = extra + 512 + n;
+  pp.grad = a.scratch + gen_off_grad(B, net.row_floats);
+  pp.bar = reinterpret_cast<unsigned*>(a.scratch + 60);           // (the first 64 floats are zeroed by the caller)
+  const size_t lds = (size_t)(32 * pp.RS + 256 + 384 + 32) * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)gen_train_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gen_transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, s, net, a.params, a.params_t);
+  GenNet net_ = net; GenArgs a_ = a;
+  static const bool nopack = getenv("ICRL_NO_XCD_PACK") != nullptr;
+  int packed = nopack ? 0 : 1;
+  void* params[] = {(void*)&net_, (void*)&a_, (void*)&pp, (void*)&packed};
+  e = hipLaunchCooperativeKernel((const void*)gen_train_persistent_kernel, dim3(packed ? XCD_STRIDE * (H - 1) + 1 : H), dim3(GENP_TH), params, (unsigned)lds, s);
+  if (e == hipErrorCooperativeLaunchTooLarge && packed) {      // (a partition that cannot hold the sparse grid: the dense one, agent-scope stores)
+    (void)hipGetLastError();
+    packed = 0;
+    e = hipLaunchCooperativeKernel((const void*)gen_train_persistent_kernel, dim3(H), dim3(GENP_TH), params, (unsigned)lds, s);
+  }
+  return (int)e;
+}
 
 // perm_off: the permutations already mapped to storage offsets (prepare in ppo_train.hip); scratch: ICRL_PPO_GENERIC_BYTES
 int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
-                         const int* perm_off, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* scratch, hipStream_t s) {
+                         const int* perm_off, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* scratch, void* sync_ws, hipStream_t s) {
   GenNet net;
   if (int e = make_gen_net(pol, &net, "icrl_ppo_lag_train")) return e;
   GenArgs a;
@@ -504,9 +1012,13 @@ int launch_train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   a.buf = *buf; a.perm_off = perm_off; a.nu = nu; a.hp = *hp; a.stats = stats; a.scratch = (float*)scratch;
   a.n_total = buf->T * buf->N;
   a.n_mb = (a.n_total + hp->batch_size - 1) / hp->batch_size;
-  if (gen_floats(a.B, net.row_floats, net.n) * 4 != ICRL_PPO_GENERIC_BYTES(a.B, net.row_floats, net.n)) return fail("generic update: scratch layout and ICRL_PPO_GENERIC_BYTES disagree");
+  if ((gen_floats(a.B, net.row_floats, net.n) + ICRL_PPO_GENERIC_PERSIST_FLOATS(a.B, net.n)) * 4 != ICRL_PPO_GENERIC_BYTES(a.B, net.row_floats, net.n)) return fail("generic update: scratch layout and ICRL_PPO_GENERIC_BYTES disagree");
   hipError_t e = hipMemsetAsync(scratch, 0, 64 * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
+  {
+    const int pe = launch_train_generic_persistent(net, a, hp, adam_step, sync_ws, s);
+    if (pe >= 0) return pe;
+  }
   const int nblk = (net.n + 255) / 256;
   int n_tiles = 1;      // workgroups of gen_wgrad_tiled_kernel: log_std + the 16 x 16 tiles of every layer
   for (int l = 0; l < net.n_layers; ++l) n_tiles += gen_tiles_of(net.layer[l]);

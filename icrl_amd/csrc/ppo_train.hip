@@ -887,6 +887,7 @@ __global__ void ppo_plan_kernel(const int* adam_t, int n_steps, int n_mb, int n_
   const double t = (double)(adam_t[0] + i + 1);
   steps[i] = PlanStep{(float)(lr / (1.0 - pow(b1, t))), (float)(1.0 / sqrt(1.0 - pow(b2, t))),
                       nb | ((mb == 0) << NB_FIRST) | ((mb == n_mb - 1) << NB_LAST) | (e << NB_EPOCH), e * n_total + p};
+  if (chunks == nullptr) return;      // (the generic-shape path reads the step table only)
   if (two_per_step) {      // two workgroups per network: chunk c of step i at 2 i + c, an absent second chunk as 0 rows
     for (int c = 0; c < 2; ++c) chunks[2 * i + c] = c < nch ? PlanChunk{e * n_total + p + RB * c, nb - RB * c < RB ? nb - RB * c : RB} : PlanChunk{0, 0};
     if (i == n_steps - 1)
@@ -1008,7 +1009,7 @@ static int train_generic(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   const long long n = (long long)hp->n_epochs * n_total;
   hipLaunchKernelGGL(ppo_perm_offsets_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, perms, n, buf->T, buf->N, offs);
   char* scratch = (char*)sync_ws + ICRL_PPO_SYNC_BYTES(hp->n_epochs, n_mb, n_total);
-  const int err = launch_train_generic(pol, exp_avg, exp_avg_sq, adam_step, buf, offs, nu, hp, stats, scratch, s);
+  const int err = launch_train_generic(pol, exp_avg, exp_avg_sq, adam_step, buf, offs, nu, hp, stats, scratch, sync_ws, s);
   // the generic kernels keep THEIR transposed image in params_t; a policy the fast forward kernels serve (this call came here for its
   // batch size) gets the image those kernels read back
   if (err == 0 && !policy_is_wide(pol)) return icrl_policy_prepare(pol, (void*)s);

@@ -474,7 +474,8 @@ class PPOLagrangian:
             self._generic_update = pol.wide or int(self.batch_size) > 256      # shapes of the generic-shape path (csrc/generic.hip)
             if self._generic_update:      # its scratch lies behind the regular workspace: ICRL_PPO_GENERIC_BYTES(batch_size, row_floats, n_params)
                 B_, n_ = int(self.batch_size), pol.n_params
-                n_words += (64 + B_ * (24 + 1 + 16 + 2 * pol.row_floats) + n_ + (n_ + 255) // 256 + 1088 + 1) // 2 + 8
+                persist = ((B_ + 15) // 16 + 1) * n_ + 1024 if (B_ + 15) // 16 <= 32 and n_ <= 131072 else 0      # ICRL_PPO_GENERIC_PERSIST_FLOATS
+                n_words += (64 + B_ * (24 + 1 + 16 + 2 * pol.row_floats) + n_ + (n_ + 255) // 256 + 1088 + persist + 1) // 2 + 8
             # the workspace lives in an arena with room for SYNC_CANDIDATES positions 1 MB apart: see _tune_sync_placement
             arena = torch.zeros(n_words + (self.SYNC_CANDIDATES - 1) * (1 << 17), dtype=torch.int64, device=dev)
             self._train_ws = dict(nu=torch.zeros(1, device=dev), stats=torch.zeros(32 + self.n_epochs, device=dev), sync=arena[:n_words],

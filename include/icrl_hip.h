@@ -177,7 +177,11 @@ typedef struct {
  * workspace, sync_ws then holds ICRL_PPO_SYNC_BYTES(...) + ICRL_PPO_GENERIC_BYTES(...) bytes.  row_floats = the outputs of every layer
  * of one row = icrl_ppo_generic_row_floats(pol) (6 h + act_dim + 2 for the padded two-layer layout of common width h) */
 #define ICRL_PPO_GENERIC_BYTES(batch_size, row_floats, n_params) \
-  (4 * (64 + (size_t)(batch_size) * (24 + 1 + 16 + 2 * (size_t)(row_floats)) + (size_t)(n_params) + ((size_t)(n_params) + 255) / 256 + 1088))
+  (4 * (64 + (size_t)(batch_size) * (24 + 1 + 16 + 2 * (size_t)(row_floats)) + (size_t)(n_params) + ((size_t)(n_params) + 255) / 256 + 1088 + \
+        ICRL_PPO_GENERIC_PERSIST_FLOATS(batch_size, n_params)))
+/* the one-launch form of the generic-shape update (up to 32 row tiles of 16 rows, up to 131 072 parameters): per-tile partial gradients */
+#define ICRL_PPO_GENERIC_PERSIST_FLOATS(batch_size, n_params) \
+  ((((batch_size) + 15) / 16 <= 32 && (n_params) <= 131072) ? (size_t)(((batch_size) + 15) / 16 + 1) * (size_t)(n_params) + 1024 : (size_t)0)
 #define ICRL_CN_METRICS 24 /* floats per iteration in the metrics array of icrl_cn_train */
 
 /* ------------------------------------------------------------------------------------------------------------------

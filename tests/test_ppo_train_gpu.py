@@ -254,3 +254,16 @@ def test_sync_placement_tuning_leaves_no_trace(kind, N, T, B):
                     a._train_ws.get("sync_position")))
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
     assert out[0][3] in range(4) and out[1][3] is None
+
+
+def test_generic_shape_update_as_one_persistent_launch():
+    """ICRL_GEN_PERSISTENT=1: the generic-shape update as ONE cooperative launch per train() (csrc/generic.hip: row-tile workgroups, fp32 MFMA
+    tiles, three grid barriers per optimiser step) — measured slower than the three launches per step at the sizes of this suite and
+    therefore not the default — stays correct: the golden and oracle cases of the generic-shape path pass under it
+    (child process: the switch is read once per process)."""
+    import subprocess, sys
+    env = dict(os.environ, ICRL_GEN_PERSISTENT="1")
+    sel = "g15 or g16 or g17 or g18 or hc-wide or hc-trunk or ant-deep or hc-bare or hc-8-128-512 or hc-5-200-300"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:]

@@ -6,7 +6,8 @@ from icrl_amd.ppo_lag import PPOLagrangian
 from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCost
 from icrl_amd.constraint_net import ConstraintNet
 for name, kw, B in (("-pl 128 128 -rvl 128 128 -cvl 128 128, batch 64", dict(policy_kwargs=dict(net_arch=[dict(pi=[128, 128], vf=[128, 128], cvf=[128, 128])])), 64),
-                    ("default widths, batch 512", {}, 512)):
+                    ("default widths, batch 256", {}, 256), ("default widths, batch 512", {}, 512),
+                    ("-pl 128 128 -rvl 128 128 -cvl 128 128, batch 512", dict(policy_kwargs=dict(net_arch=[dict(pi=[128, 128], vf=[128, 128], cvf=[128, 128])])), 512)):
     N, T = 64, 256
     env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, "hc", 0)))
     lo = -np.ones(6, np.float32)
@@ -24,4 +25,8 @@ for name, kw, B in (("-pl 128 128 -rvl 128 128 -cvl 128 128, batch 64", dict(pol
     agent.train(); torch.cuda.synchronize()
     t0 = time.time(); agent.train(); torch.cuda.synchronize(); dt = time.time() - t0
     steps = 2 * (N * T // B)
+    if os.environ.get("PROF"):
+        agent.profile_phases = 1; agent.train(); torch.cuda.synchronize(); agent.profile_phases = 0
+        st_ = agent._train_ws["stats"].cpu().numpy()
+        print("   cycles per step of workgroup 0: rows+stats | fwd | loss | bwd | wgrad | barrier A | reduce | barrier B | adam | barrier C:", np.round(st_[12:22]), "one XCD:", bool(st_[22]))
     print(f"{name}: rollout {1e6 * t_roll / T:.0f} us per {N}-env step ({'four launches per step inside icrl_rollout_collect' if agent.policy.wide else 'fused'}; the Python loop over the fine-grained entry points: {1e6 * t_py / T:.0f}), update {1e6 * dt / steps:.1f} us per optimiser step ({steps} steps)")
