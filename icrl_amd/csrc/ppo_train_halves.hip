@@ -38,6 +38,12 @@
 #ifndef ICRL_HALVES_STAGE_IN_HOP
 #define ICRL_HALVES_STAGE_IN_HOP 0
 #endif
+// the first look at the other networks' norm granules is ISSUED before the staging of the next minibatch and read behind it: its trip to
+// the L2 runs under the staging (6.84 -> 6.76 us per step, three alternating runs on one box; the pair kernel's same switch measured nothing
+// in round 4, when the granules still crossed the fabric)
+#ifndef ICRL_HALVES_EARLY_POLL
+#define ICRL_HALVES_EARLY_POLL 1
+#endif
 // A/B: the four waves of a quad on four SIMDs (rt2 = w >> 2) instead of two and two (rt2 = w & 1)
 #ifndef ICRL_HALVES_QUAD_SPREAD
 #define ICRL_HALVES_QUAD_SPREAD 0
@@ -810,6 +816,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK;
     const bool poller = tid < 24 && (tid >> 3) != role;
     const u64* const slot = nx + (step & 1) * 32 + (tid < 24 ? tid : 0);
+#if ICRL_HALVES_EARLY_POLL
+    u64 v_first = 0;
+    if (poller) v_first = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     if (!ICRL_HALVES_STAGE_IN_HOP) {
       commit_rows(xnext);
       stats_partials(nb_next);
@@ -819,6 +829,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       u64 v = 0;
       int spins = 0;
       bool ok = false;
+#if ICRL_HALVES_EARLY_POLL
+      v = v_first;
+      ok = (unsigned)((v >> 32) & 0x7fffffffu) == step;
+#endif
       while (!ok && spins < (1 << 24)) {
         v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; break; }

@@ -60,6 +60,10 @@
 #ifndef ICRL_ROWS_STATIC_LDS
 #define ICRL_ROWS_STATIC_LDS 0
 #endif
+// the first look at the other networks' norm granules issued before the staging of the next minibatch, read behind it (ppo_train_halves.hip)
+#ifndef ICRL_ROWS_EARLY_POLL
+#define ICRL_ROWS_EARLY_POLL 0
+#endif
 
 namespace icrl {
 
@@ -1148,6 +1152,10 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
     STAMP(4)   // gradient norm + publish
     // ---- while the granules travel: stage the next minibatch (rows -> the other X^T buffer, advantage statistics)
     const int xnext = S::XDB ? (xcur == S::XT0 ? S::XT1 : S::XT0) : xcur;
+#if ICRL_ROWS_EARLY_POLL
+    u64 v_first = 0;
+    if (tid < 12) v_first = __hip_atomic_load(xch + half * 32 + (step & 1) * 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
     commit_rows(xnext);
     const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK;
     stats_partials(nb_next);
@@ -1157,6 +1165,10 @@ __device__ __forceinline__ void ppo_train_rows_body(const TrainArgs& a, const Tr
       int spins = 0;
       bool ok = false;
       const u64* const slot = xch + half * 32 + (step & 1) * 16 + tid;     // (the three networks of the same half)
+#if ICRL_ROWS_EARLY_POLL
+      v = v_first;
+      if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; spins = 1 << 24; }
+#endif
       while (spins < (1 << 24)) {
         v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((unsigned)((v >> 32) & 0x7fffffffu) == step) { ok = true; break; }
