@@ -449,14 +449,90 @@ class PPOLagrangian:
             states.append(np.random.get_state())             # generator state after e + 1 epochs' draws
         return torch.as_tensor(perms, device=self.device).contiguous(), states
 
+    # Rollouts of this many rows or more: the reference's per-epoch np.random.permutation (buffers.py:596; 2-8 ms per epoch of host
+    # time at 0.5-1 M rows, 20 epochs in the AntWall configurations) is drawn EPOCH BY EPOCH beside the running update instead of all
+    # epochs up front — see _train_epochwise.  Below it the draws hide under the asynchronous rollout launch anyway.
+    LAZY_PERM_ROWS = 262144
+
     def train(self, perms=None):
         """ref: ppo_lag.py:177-338."""
+        rb = self.rollout_buffer
+        if (perms is None and self.streams is None and not callable(self.permutation) and self.permutation != "device" and self.n_epochs > 1
+                and rb.buffer_size * rb.n_envs >= self.LAZY_PERM_ROWS):
+            return self._train_epochwise()
         job = self._train_begin(perms)
         self._train_launch(job)
         self._train_end(job)
 
+    def _train_epochwise(self):
+        """train() as one launch PER EPOCH, the next epoch's permutation drawn on the host while the current epoch runs on the device.
+        The reference draws np.random.permutation inside its epoch loop and stops drawing when the target-KL test ends the loop
+        (ppo_lag.py:203-299); drawing all n_epochs permutations before a single launch costs n_epochs x (2-8 ms) of host time at
+        0.5-1 M rows — 55 ms of a 162 ms outer iteration of BASELINE configs[2], 165 of 358 ms of configs[4], nearly all of it for
+        epochs the early stop never runs.  Here: draw(0), launch(0); then for every further epoch draw(e) beside the running epoch
+        e - 1, wait for that epoch's statistics, stop if it stopped, launch(e).  At most ONE permutation is drawn in vain, and the
+        generator is put back to where the reference leaves it.  Same permutations, same minibatches, same arithmetic: parameters,
+        moments and step counter are bit-identical to the single launch (they round-trip through device memory in fp32 between
+        launches); the logged SUMS are added up per epoch on the host instead of in one fp32 chain (~1e-7 relative)."""
+        rb, pol, dev = self.rollout_buffer, self.policy, self.device
+        n, E = rb.buffer_size * rb.n_envs, self.n_epochs
+        if getattr(self, "_lazy_perm", None) is None or tuple(self._lazy_perm.shape) != (E, n):
+            self._lazy_perm = torch.empty((E, n), dtype=torch.int32, device=dev)
+            self._lazy_pin = torch.empty((2, n), dtype=torch.int32).pin_memory()
+            self._lazy_stats = torch.empty((E, 33), dtype=torch.float32).pin_memory()
+        job = self._train_begin(device_perms=self._lazy_perm)
+        ws, b = self._train_ws, _lib.byref
+        if not ws["sync_tuned"]:
+            ws["sync_tuned"] = True          # (the placement calibration times whole updates: not for this form)
+        hp = PpoHyperT.from_buffer_copy(job["hp"]); hp.n_epochs = 1
+        states, events = [], []
+
+        def draw(e):
+            self._lazy_pin[e % 2].numpy()[:] = np.random.permutation(n)
+            states.append(np.random.get_state())                       # generator state after e + 1 draws
+            self._lazy_perm[e].copy_(self._lazy_pin[e % 2], non_blocking=True)
+
+        def launch(e):
+            _lib.check(_lib.lib().icrl_ppo_lag_train(b(job["ps"]), p(pol.exp_avg), p(pol.exp_avg_sq), p(ws["t"]), b(job["bs"]), p(self._lazy_perm[e]), p(ws["nu"]),
+                                                     b(hp), p(ws["stats"]), p(ws["sync"]), _lib.current_stream()), "icrl_ppo_lag_train")
+            self._lazy_stats[e].copy_(ws["stats"][:33], non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(); events.append(ev)
+
+        ev = None
+        if getattr(self, "train_events", None) is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        draw(0); launch(0)
+        executed = 1
+        for e in range(1, E):
+            draw(e)                                                    # (host work beside the running epoch e - 1)
+            events[e - 1].synchronize()
+            if self._lazy_stats[e - 1, 0].item() == 0 or self._lazy_stats[e - 1, 11].item() != 0:      # that epoch ended the loop (target KL) | exchange timed out
+                break
+            launch(e)
+            executed += 1
+        events[-1].synchronize()
+        if ev is not None:
+            ev[1].record()
+        job["ev"] = ev
+        # ---- one statistics row as the single launch would have left it
+        per = self._lazy_stats[:executed].numpy().astype(np.float32)
+        st = np.zeros(32 + E, np.float32)
+        stopped = per[-1, 0] == 0
+        st[0] = executed - 1 if stopped else E                        # early_stop_epoch
+        st[1] = per[:, 1].sum()                                        # optimiser steps
+        for k in (2, 3, 4, 5, 6):
+            st[k] = np.float32(per[:, k].astype(np.float64).sum())     # sums over the steps: entropy, policy, value, cost-value losses, clip fraction
+        st[7:11] = per[-1, 7:11]                                       # mean KL of the last executed epoch, the last minibatch's loss terms
+        st[11] = per[:, 11].max()
+        st[32:32 + executed] = per[:, 32]
+        tail = self.train_readback().cpu().numpy()
+        host = np.concatenate([st.astype(np.float64), tail[32 + E:]])
+        job["rng_state"] = states + [states[-1]] * (E - len(states))  # (indexable by executed epochs like the single launch's list)
+        self._train_end(job, host=host)
+
     # train() in three pieces (see _rollout_begin): descriptors, the launch (single here, batched in seed_batch.py), read-back + logs
-    def _train_begin(self, perms=None):
+    def _train_begin(self, perms=None, device_perms=None):
         lr = float(self.lr_schedule(self._current_progress_remaining))
         clip_range = float(self.clip_range(self._current_progress_remaining))
         crv = -1.0 if self.clip_range_reward_vf is None else float(self.clip_range_reward_vf(self._current_progress_remaining))
@@ -464,7 +540,9 @@ class PPOLagrangian:
         rb, pol, dev = self.rollout_buffer, self.policy, self.device
         n = rb.buffer_size * rb.n_envs
         rng_state, injected = None, perms is not None
-        if perms is None:
+        if device_perms is not None:              # (_train_epochwise fills this [n_epochs, n] device tensor epoch by epoch)
+            perms = device_perms
+        elif perms is None:
             perms, rng_state = self._draw_permutations(n)
         else:
             perms = torch.as_tensor(np.asarray(perms).astype(np.int32), device=dev).contiguous()

@@ -267,3 +267,45 @@ def test_generic_shape_update_as_one_persistent_launch():
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:]
+
+
+@pytest.mark.parametrize("tk", [None, 1e-6, 0.02])
+def test_epochwise_update_equals_single_launch(tk):
+    """PPOLagrangian._train_epochwise (rollouts of >= LAZY_PERM_ROWS rows: one launch per epoch, the next epoch's np.random.permutation
+    drawn beside the running epoch; ref: ppo_lag.py:203-299, buffers.py:596) against the single launch on the same buffer and generator
+    state: parameters, Adam moments and step counter bit-identical, the same epochs executed, np.random left where the reference
+    leaves it, the logged means equal to float32 rounding of their sums."""
+    from icrl_amd import logger
+    N, T, E = 8, 64, 5
+    rng = np.random.RandomState(5)
+    obs = rng.randn(T, N, 18).astype(np.float32)
+    out = []
+    for lazy_rows in (1 << 30, 1):
+        agent = _agent("hc", N, T, batch_size=64, n_epochs=E, target_kl=tk, learning_rate=1e-3)
+        agent.LAZY_PERM_ROWS = lazy_rows
+        op = o_nets.TwoCriticPolicy(18, 6); op.load_state_dict(agent.policy.state_dict())
+        with torch.no_grad():
+            a, vr, vc, lp = op.forward(torch.as_tensor(obs.reshape(-1, 18)))
+        r2 = np.random.RandomState(6)
+        _fill(agent, dict(observations=obs, actions=a.numpy().reshape(T, N, 6), log_probs=lp.numpy().reshape(T, N),
+                          reward_values=vr.numpy().reshape(T, N), cost_values=vc.numpy().reshape(T, N),
+                          reward_advantages=r2.randn(T, N).astype(np.float32), cost_advantages=r2.rand(T, N).astype(np.float32),
+                          reward_returns=r2.randn(T, N).astype(np.float32), cost_returns=r2.rand(T, N).astype(np.float32),
+                          orig_costs=r2.rand(T, N).astype(np.float32)))
+        np.random.seed(4321)
+        agent.train()
+        lg = dict(logger.Logger.CURRENT.name_to_value)
+        out.append(dict(params=agent.policy.params.clone(), m=agent.policy.exp_avg.clone(), v=agent.policy.exp_avg_sq.clone(), t=agent.policy.adam_step,
+                        after=np.random.randint(1 << 30), lg=lg, kls=np.asarray(agent.epoch_kls).copy(), nu=agent.dual.nu().item()))
+    a_, b_ = out
+    assert torch.equal(a_["params"], b_["params"]) and torch.equal(a_["m"], b_["m"]) and torch.equal(a_["v"], b_["v"]) and a_["t"] == b_["t"] > 0
+    assert a_["after"] == b_["after"] and a_["nu"] == b_["nu"]
+    assert a_["lg"]["train/early_stop_epoch"] == b_["lg"]["train/early_stop_epoch"]
+    if tk == 1e-6:
+        assert a_["lg"]["train/early_stop_epoch"] < E - 1          # (the loop did end early: the epoch-wise form stopped launching)
+    n_exec = int(min(a_["lg"]["train/early_stop_epoch"] + 1, E))
+    assert np.array_equal(a_["kls"][:n_exec], b_["kls"][:n_exec])
+    for key in ("train/approx_kl", "train/loss"):
+        assert a_["lg"][key] == b_["lg"][key], key
+    for key in ("train/entropy_loss", "train/policy_gradient_loss", "train/reward_value_loss", "train/cost_value_loss", "train/clip_fraction"):
+        assert abs(a_["lg"][key] - b_["lg"][key]) <= 1e-6 * max(1.0, abs(a_["lg"][key])), (key, a_["lg"][key], b_["lg"][key])
