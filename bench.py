@@ -262,7 +262,7 @@ def configs2_leg(seed, steps=2, warmup=1):
     return out
 
 
-def gae_sweep_point(N=131072, T=2048, reps=20):
+def gae_sweep_point(N=131072, T=2048, reps=48):
     """the same entry point at 131 072 envs: working set 9.7 GB >> 256 MB Infinity Cache, the HBM-streaming regime (the library
     picks the four-columns-per-lane streaming shape from 65 536 envs on; bit-exact like the one-column scan).  In the same process,
     on the same stream and buffers, interleaved with the GAE launches: `icrl_debug_stream_ref` mode 0 (the launch shape and the
@@ -286,7 +286,7 @@ def gae_sweep_point(N=131072, T=2048, reps=20):
             _lib.check(f(), "gae sweep")
     torch.cuda.synchronize()
     ms = {k: [] for k in launch}
-    rounds, per = 4, max(1, reps // 4)
+    rounds, per = 6, max(1, reps // 6)
     for _ in range(rounds):                     # interleaved rounds: a drifting HBM clock hits all three alike
         for k, f in launch.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -296,11 +296,11 @@ def gae_sweep_point(N=131072, T=2048, reps=20):
             e1.record()
             torch.cuda.synchronize()
             ms[k].append(e0.elapsed_time(e1) / per)
-    t = {k: float(np.mean(v)) for k, v in ms.items()}
+    t = {k: float(np.median(v)) for k, v in ms.items()}      # (median over the rounds: one disturbed round of one kernel would move a mean by 5-20 %)
     gbs = lambda nbytes, k: nbytes / (t[k] * 1e-3) / 1e9
     return dict(envs=N, T=T, bytes=T * N * 36, us=t["gae"] * 1e3, achieved=gbs(T * N * 36, "gae"),
                 ref_gbs=gbs(T * N * 36, "ref"), ref_us=t["ref"] * 1e3, copy_gbs=gbs(T * N * 32, "copy"), copy_us=t["copy"] * 1e3,
-                launches=rounds * per)
+                launches=rounds * per, spread={k: [round(min(v) * 1e3), round(max(v) * 1e3)] for k, v in ms.items()})
 
 
 def gae_roofline(sweep, in_loop):
@@ -329,7 +329,7 @@ def gae_roofline(sweep, in_loop):
                          f"bytes of the GAE launch, no recurrence: {sweep['ref_us']:.0f} us/launch",
              flat_copy_gbs=round(sweep["copy_gbs"], 1), frac_of_flat_copy=round(sweep["achieved"] / sweep["copy_gbs"], 4),
              flat_copy_kernel=f"stream_copy_kernel (mode 1): four grid-stride float4 copies, {sweep['T'] * sweep['envs'] * 32 / 1e9:.2f} GB, {sweep['copy_us']:.0f} us",
-             launches_timed=sweep["launches"])
+             launches_timed=sweep["launches"], us_min_max_per_round=sweep["spread"])
     if in_loop is not None:
         r["in_loop"] = in_loop
     return r

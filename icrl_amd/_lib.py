@@ -51,6 +51,9 @@ SIGNATURES = {
     "icrl_ppo_lag_loss_fwd_bwd": [c_void_p] * 13 + [c_int] + [c_void_p] * 6,
     "icrl_clip_adam_step": [c_void_p] * 5 + [ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p],
     "icrl_dual_step": [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p],
+    "icrl_buffer_add": [c_void_p, c_int] + [c_void_p] * 13,
+    "icrl_is_weights": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
+    "icrl_cn_loss_fwd_bwd": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
     "icrl_cn_train_minibatch": [c_void_p] * 6 + [c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                 c_void_p, c_void_p],
     # batched forms (several independent runs in one launch, run = blockIdx.y): n_runs, jobs[n_runs], ..., args_ws, bytes, stream

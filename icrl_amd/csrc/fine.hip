@@ -9,6 +9,9 @@
 //   clip_grad_norm_ + optimizer.step()        ppo_lag.py:283-288      -> icrl_clip_adam_step     (one flat buffer: torch's clip coefficient and
 //                                                                        single-tensor Adam, bias corrections in double)
 //   dual.update_parameter(average_cost)       dual_variable.py:47-57  -> icrl_dual_step          (nu stays on the device)
+//   rollout_buffer.add(...)                   buffers.py:554-592      -> icrl_buffer_add         (one step's arrays -> row t)
+//   compute_is_weights                        constraint_net.py:231-256 -> icrl_is_weights       (episode products, both KLs, weights)
+//   the constraint-net loss + its gradients   constraint_net.py:188-202 -> icrl_cn_loss_fwd_bwd  (on the network's outputs)
 // Same conventions as the rest of the library: caller-owned device buffers, a stream, hipError_t as int, no allocation, no sync.
 // Plain kernels (a minibatch is 64..512 rows; these calls are launch-bound by construction — the fused persistent kernels are the
 // fast path); every reduction is a fixed tree over one block, so results do not depend on the launch.
@@ -173,6 +176,118 @@ __global__ void dual_step_kernel(float* st, int* t_p, const float* cost_p, float
   st[3] = nx > 20.f ? nx : log1pf(expf(nx));
 }
 
+
+// RolloutBufferWithCost.add (buffers.py:554-592): one step's arrays of all envs -> row t of the [T, N] planes (float64 -> float32 like the
+// reference's np.array(x).copy() into float32 storage).  One thread per (env, component).
+__global__ void __launch_bounds__(256) buffer_add_kernel(icrl_buffer_t b, int t, const double* obs, const double* orig_obs, const double* new_obs,
+                                                         const double* new_orig_obs, const float* action, const double* reward, const double* cost,
+                                                         const float* orig_cost, const uint8_t* done, const float* reward_value, const float* cost_value,
+                                                         const float* log_prob) {
+  const int i = blockIdx.x * 256 + threadIdx.x, N = b.N, O = b.obs_dim, AS = b.act_store;
+  const size_t row = (size_t)t * N;
+  if (i < N * O) {
+    b.observations[row * O + i] = (float)obs[i]; b.orig_observations[row * O + i] = (float)orig_obs[i];
+    b.new_observations[row * O + i] = (float)new_obs[i]; b.new_orig_observations[row * O + i] = (float)new_orig_obs[i];
+  }
+  if (i < N * AS) b.actions[row * AS + i] = action[i];
+  if (i < N) {
+    b.rewards[row + i] = (float)reward[i]; b.costs[row + i] = (float)cost[i]; b.orig_costs[row + i] = orig_cost[i];
+    b.dones[row + i] = (float)done[i]; b.reward_values[row + i] = reward_value[i]; b.cost_values[row + i] = cost_value[i];
+    b.log_probs[row + i] = log_prob[i];
+  }
+}
+
+// ConstraintNet.compute_is_weights (constraint_net.py:231-256) on the predictions of the start-of-call and of the current network:
+// per-episode float32 products of (new + eps) / (old + eps) — they overflow to inf / nan for long episodes exactly like the reference's —,
+// weights per step (ratio / mean ratio) or per episode (n_ep prod / (sum prod + eps), repeated over the episode's rows), both KLs.
+// One workgroup; one wave per episode for the products (lane-strided, wave_prod: the association differs from torch.prod's by rounding).
+__device__ __forceinline__ float wave_prod_f(float v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v *= __shfl_xor(v, m, 64);
+  return v;
+}
+__global__ void __launch_bounds__(1024) is_weights_kernel(const float* __restrict__ old_p, const float* __restrict__ new_p, int N, const int* __restrict__ ep_off,
+                                                          int n_ep, float eps, int per_step, float* w, float* ep_prod, float* out4) {
+  __shared__ float red[16];
+  __shared__ float sh[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int e = wv; e < n_ep; e += 16) {
+    float pr = 1.f;
+    for (int i = ep_off[e] + lane; i < ep_off[e + 1]; i += 64) pr *= (new_p[i] + eps) / (old_p[i] + eps);
+    pr = wave_prod_f(pr);
+    if (lane == 0) ep_prod[e] = pr;
+  }
+  float sr = 0.f;
+  for (int i = tid; i < N; i += 1024) sr += (new_p[i] + eps) / (old_p[i] + eps);
+  sr = wave_sum_fast(sr);
+  if (lane == 0) red[wv] = sr;
+  __syncthreads();
+  if (tid == 0) {
+    float sum_p = 0.f, tot = 0.f;
+    for (int e = 0; e < n_ep; ++e) sum_p += ep_prod[e];
+    for (int k = 0; k < 16; ++k) tot += red[k];
+    const float pm = sum_p / (float)n_ep;
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = 0; e < n_ep; ++e) {
+      const float lp = logf(ep_prod[e] + eps);
+      s1 += -lp;
+      s2 += (ep_prod[e] - pm) * lp / (pm + eps);
+    }
+    out4[0] = s1 / (float)n_ep; out4[1] = s2 / (float)n_ep; out4[2] = tot / (float)N; out4[3] = sum_p;
+    sh[0] = tot / (float)N; sh[1] = sum_p;
+  }
+  __syncthreads();
+  if (per_step) {
+    const float mr = sh[0];
+    for (int i = tid; i < N; i += 1024) w[i] = ((new_p[i] + eps) / (old_p[i] + eps)) / mr;
+  } else {
+    for (int e = wv; e < n_ep; e += 16) {
+      const float nw = (float)n_ep * ep_prod[e] / (sh[1] + eps);
+      for (int i = ep_off[e] + lane; i < ep_off[e + 1]; i += 64) w[i] = nw;
+    }
+  }
+}
+
+// The constraint-net loss on the network's OUTPUTS (constraint_net.py:188-202) and d loss / d those outputs.  terms6 = {loss, expert_loss,
+// nominal_loss, regularizer, mean(log(nominal + eps)), 0}.  mode bit 0: GAIL's BCE form; bit 1: the per-step broadcast quirk
+// (weights [B,1,1] x log zeta [B,1] -> [B,B,1]: nominal_loss = mean(w) * mean(log zeta_N)).  w NULL: no importance sampling (ones).
+__global__ void __launch_bounds__(256) cn_loss_fwd_bwd_kernel(const float* __restrict__ nom, const float* __restrict__ exp_, const float* __restrict__ w, int Bn, int Be,
+                                                              float reg_coeff, float eps, int mode, float* terms, float* d_nom, float* d_exp) {
+  __shared__ float red[256];
+  const bool gail = mode & 1, factored = (mode & 2) && w != nullptr;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f;      // sum w log n | sum log n | sum w | sum (1 - n) | expert term | sum (1 - e)
+  for (int i = threadIdx.x; i < Bn; i += 256) {
+    const float n_ = nom[i], wi = w ? w[i] : 1.f;
+    const float ln = gail ? -fmaxf(logf(1.f - n_), -100.f) : logf(n_ + eps);      // (torch BCELoss clamps its logs at -100)
+    a0 += wi * ln; a1 += ln; a2 += wi; a3 += 1.f - n_;
+  }
+  for (int i = threadIdx.x; i < Be; i += 256) {
+    const float e_ = exp_[i];
+    a4 += gail ? -fmaxf(logf(e_), -100.f) : logf(e_ + eps);
+    a5 += 1.f - e_;
+  }
+  a0 = block_sum_256(a0, red); a1 = block_sum_256(a1, red); a2 = block_sum_256(a2, red); a3 = block_sum_256(a3, red);
+  a4 = block_sum_256(a4, red); a5 = block_sum_256(a5, red);
+  const float inv_n = 1.f / (float)Bn, inv_e = 1.f / (float)Be, mean_w = a2 * inv_n;
+  if (threadIdx.x == 0) {
+    if (gail) {
+      const float nl = a1 * inv_n, el = a4 * inv_e;
+      terms[0] = nl + el; terms[1] = el; terms[2] = nl; terms[3] = 0.f; terms[4] = 0.f; terms[5] = 0.f;
+    } else {
+      const float el = a4 * inv_e, nl = factored ? mean_w * (a1 * inv_n) : a0 * inv_n, reg = reg_coeff * (a5 * inv_e + a3 * inv_n);
+      terms[0] = (-el + nl) + reg; terms[1] = el; terms[2] = nl; terms[3] = reg; terms[4] = a1 * inv_n; terms[5] = 0.f;
+    }
+  }
+  for (int i = threadIdx.x; i < Bn; i += 256) {
+    const float n_ = nom[i], wi = factored ? mean_w : (w ? w[i] : 1.f);
+    d_nom[i] = gail ? (logf(1.f - n_) > -100.f ? inv_n / (1.f - n_) : 0.f) : wi * inv_n / (n_ + eps) - reg_coeff * inv_n;
+  }
+  for (int i = threadIdx.x; i < Be; i += 256) {
+    const float e_ = exp_[i];
+    d_exp[i] = gail ? (logf(e_) > -100.f ? -inv_e / e_ : 0.f) : -inv_e / (e_ + eps) - reg_coeff * inv_e;
+  }
+}
+
 }  // namespace
 }  // namespace icrl
 
@@ -219,5 +334,32 @@ extern "C" int icrl_dual_step(float* state4, int32_t* adam_step, const float* co
                               float clamp_log_nu, float* loss_out, void* stream) {
   if (!state4 || !adam_step) return fail("icrl_dual_step: NULL state");
   hipLaunchKernelGGL(dual_step_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, state4, adam_step, cost_dev, cost_host, budget, learning_rate, clamp_log_nu, loss_out);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_buffer_add(const icrl_buffer_t* buf, int t, const double* obs, const double* orig_obs, const double* new_obs, const double* new_orig_obs,
+                               const float* action, const double* reward, const double* cost, const float* orig_cost, const uint8_t* done,
+                               const float* reward_value, const float* cost_value, const float* log_prob, void* stream) {
+  if (buf == nullptr || t < 0 || t >= buf->T) return fail("icrl_buffer_add: t = %d outside the buffer's %d steps", t, buf ? buf->T : 0);
+  if (!obs || !orig_obs || !new_obs || !new_orig_obs || !action || !reward || !cost || !orig_cost || !done || !reward_value || !cost_value || !log_prob)
+    return fail("icrl_buffer_add: NULL argument");
+  const int m = buf->N * (buf->obs_dim > buf->act_store ? buf->obs_dim : buf->act_store);
+  hipLaunchKernelGGL(buffer_add_kernel, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream, *buf, t, obs, orig_obs, new_obs, new_orig_obs, action, reward, cost,
+                     orig_cost, done, reward_value, cost_value, log_prob);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_is_weights(const float* preds_old, const float* preds_new, int N, const int32_t* ep_offsets, int n_ep, float eps, int per_step,
+                               float* weights, float* ep_prod, float* out4, void* stream) {
+  if (N < 1 || n_ep < 1 || !preds_old || !preds_new || !ep_offsets || !weights || !ep_prod || !out4) return fail("icrl_is_weights: N = %d, n_ep = %d, NULL argument", N, n_ep);
+  hipLaunchKernelGGL(is_weights_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, preds_old, preds_new, N, ep_offsets, n_ep, eps, per_step, weights, ep_prod, out4);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_cn_loss_fwd_bwd(const float* nominal_preds, const float* expert_preds, const float* is_weights, int Bn, int Be, float reg_coeff, float eps,
+                                    int mode, float* terms6, float* d_nominal, float* d_expert, void* stream) {
+  if (Bn < 1 || Be < 1 || !nominal_preds || !expert_preds || !terms6 || !d_nominal || !d_expert) return fail("icrl_cn_loss_fwd_bwd: Bn = %d, Be = %d, NULL argument", Bn, Be);
+  hipLaunchKernelGGL(cn_loss_fwd_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, nominal_preds, expert_preds, is_weights, Bn, Be, reg_coeff, eps, mode, terms6,
+                     d_nominal, d_expert);
   return (int)hipGetLastError();
 }

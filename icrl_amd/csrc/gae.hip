@@ -538,7 +538,7 @@ extern "C" int icrl_debug_stream_ref(const float* in0, const float* in1, const f
   return (int)hipGetLastError();
 }
 
-extern "C" int icrl_abi_version(void) { return 104; }
+extern "C" int icrl_abi_version(void) { return 105; }
 
 // icrl_gae_dual_ws for n_runs rollouts of one shape in ONE launch (the loop-size launches of several runs sharing a GPU): the
 // two-level scan over workgroups, every run with its own workspace.  Shapes the split scan does not serve (> 128 column tiles, T too

@@ -189,7 +189,7 @@ typedef struct {
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* ABI version (major*100+minor). */
-int icrl_abi_version(void);   /* 104: the fine-grained update entry points (csrc/fine.hip); 103: icrl_debug_stream_ref; 102: icrl_policy_t.arch; 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
+int icrl_abi_version(void);   /* 105: icrl_buffer_add, icrl_is_weights, icrl_cn_loss_fwd_bwd; 104: the fine-grained update entry points (csrc/fine.hip); 103: icrl_debug_stream_ref; 102: icrl_policy_t.arch; 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
 
 /* Every entry point returns a hipError_t.  When it is hipErrorInvalidValue because the arguments are outside what the
  * kernels were built for (env count, widths, batch size ...; the reference's Python raises ValueError / AssertionError with a
@@ -481,6 +481,8 @@ int icrl_debug_rollout_trace_wide(unsigned long long* out, int n_workgroups);
  *   loss terms + their gradients           ppo_lag/ppo_lag.py:224-281                   -> icrl_ppo_lag_loss_fwd_bwd
  *   clip_grad_norm_ + optimizer.step()     ppo_lag/ppo_lag.py:283-288                   -> icrl_clip_adam_step
  *   dual.update_parameter(average_cost)    common/dual_variable.py:47-57                -> icrl_dual_step
+ *   rollout_buffer.add(...)                common/buffers.py:554-592                    -> icrl_buffer_add
+ *   compute_is_weights / the cn loss       icrl/constraint_net.py:231-256, 188-202      -> icrl_is_weights, icrl_cn_loss_fwd_bwd
  * Launch-bound by construction (a minibatch is 64..512 rows); the fused persistent kernels are the fast path. */
 
 /* flat_idx[n]: env-major indices (i = env * T + t, buffers.py:53-65) -> the rows of the [T, N] buffer: obs [n, obs_dim], actions
@@ -509,6 +511,24 @@ int icrl_clip_adam_step(float* params, const float* grads, float* exp_avg, float
  * loss_out (may be NULL) = -nu * (cost - budget). */
 int icrl_dual_step(float* state4, int32_t* adam_step, const float* cost_dev, float cost_host, float budget, float learning_rate,
                    float clamp_log_nu, float* loss_out, void* stream);
+
+/* RolloutBufferWithCost.add (stable_baselines3/common/buffers.py:554-592): one step's arrays of all N envs (observations float64
+ * [N, obs_dim] x 4, action float32 [N, act_store], reward / cost float64 [N], the rest float32 / uint8 [N]) -> row t of the buffer. */
+int icrl_buffer_add(const icrl_buffer_t* buf, int t, const double* obs, const double* orig_obs, const double* new_obs, const double* new_orig_obs,
+                    const float* action, const double* reward, const double* cost, const float* orig_cost, const uint8_t* done,
+                    const float* reward_value, const float* cost_value, const float* log_prob, void* stream);
+/* ConstraintNet.compute_is_weights (icrl/constraint_net.py:231-256): preds_old / preds_new [N] = zeta of the start-of-call and of the current
+ * network on the nominal rows, episodes = rows ep_offsets[e] .. ep_offsets[e + 1] (n_ep + 1 offsets); weights [N] per step (ratio / mean
+ * ratio) or per episode (repeated over its rows); ep_prod [n_ep] scratch / output (float32 products, overflowing like the reference's);
+ * out4 = {kl_old_new, kl_new_old, mean ratio, sum of the products}. */
+int icrl_is_weights(const float* preds_old, const float* preds_new, int N, const int32_t* ep_offsets, int n_ep, float eps, int per_step,
+                    float* weights, float* ep_prod, float* out4, void* stream);
+/* The constraint-net loss of one (mini)batch on the network's outputs (icrl/constraint_net.py:188-202): terms6 = {loss, expert_loss,
+ * nominal_loss, regularizer, mean(log(nominal + eps)), 0}; d_nominal / d_expert = d loss / d prediction (for preds.backward(...)).
+ * is_weights NULL: ones.  mode bit 0: the GAIL discriminator's BCE (gail_utils.py); bit 1: the per-step broadcast quirk of the
+ * reference (nominal_loss = mean(w) * mean(log zeta)). */
+int icrl_cn_loss_fwd_bwd(const float* nominal_preds, const float* expert_preds, const float* is_weights, int Bn, int Be, float reg_coeff, float eps,
+                         int mode, float* terms6, float* d_nominal, float* d_expert, void* stream);
 
 /* Diagnostic (bench.py `roofline.copy_gbs`; no reference counterpart): the memory traffic of the streaming dual-GAE launch without
  * its recurrence.  mode 0: grid, access pattern and bytes of icrl_gae_dual at N >= 131 072 (five [T,N] float arrays read, four written,

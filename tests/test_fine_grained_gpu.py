@@ -145,3 +145,81 @@ def test_dual_step_follows_the_reference_trajectories(golden, case):
     assert np.allclose(got[:, 0], g["traj"][:, 0], rtol=2e-6, atol=1e-7), np.abs(got[:, 0] - g["traj"][:, 0]).max()      # nu
     assert np.allclose(got[:, 2], g["traj"][:, 2], rtol=2e-6, atol=2e-7)                                                   # log_nu
     assert np.allclose(got[:, 1], g["traj"][:, 1], rtol=2e-5, atol=1e-7)                                                   # loss = -nu (cost - budget)
+
+
+def test_buffer_add_writes_row_t():
+    """buffers.py:554-592: one step's arrays -> row t of every plane (float64 observations / rewards stored as float32)."""
+    from icrl_amd import _lib, spaces
+    from icrl_amd.buffers import RolloutBufferWithCost
+    L = _lib.lib()
+    T, N, od, ad, t = 6, 5, 18, 6, 3
+    rb = RolloutBufferWithCost(T, spaces.Box(-np.inf, np.inf, (od,), np.float64), spaces.Box(-1, 1, (ad,), np.float32), "cuda", n_envs=N)
+    rng = np.random.RandomState(2)
+    host = dict(obs=rng.randn(N, od), orig_obs=rng.randn(N, od), new_obs=rng.randn(N, od), new_orig_obs=rng.randn(N, od), action=rng.randn(N, ad).astype(np.float32),
+                reward=rng.randn(N), cost=rng.rand(N), orig_cost=rng.rand(N).astype(np.float32), done=(rng.rand(N) < 0.5).astype(np.uint8),
+                reward_value=rng.randn(N).astype(np.float32), cost_value=rng.randn(N).astype(np.float32), log_prob=rng.randn(N).astype(np.float32))
+    dev = {k: torch.as_tensor(v).cuda().contiguous() for k, v in host.items()}
+    s = rb.struct()
+    order = ("obs", "orig_obs", "new_obs", "new_orig_obs", "action", "reward", "cost", "orig_cost", "done", "reward_value", "cost_value", "log_prob")
+    _lib.check(L.icrl_buffer_add(ctypes.byref(s), t, *[_lib.ptr(dev[k]) for k in order], _lib.current_stream()), "icrl_buffer_add")
+    planes = dict(obs="observations", orig_obs="orig_observations", new_obs="new_observations", new_orig_obs="new_orig_observations", action="actions",
+                  reward="rewards", cost="costs", orig_cost="orig_costs", done="dones", reward_value="reward_values", cost_value="cost_values", log_prob="log_probs")
+    for k, name in planes.items():
+        got = getattr(rb, name).cpu().numpy()
+        assert np.array_equal(got[t].reshape(N, -1), host[k].astype(np.float32).reshape(N, -1)), k
+        assert not got[:t].any() and not got[t + 1:].any(), k          # only row t was touched
+    assert L.icrl_buffer_add(ctypes.byref(s), T, *[_lib.ptr(dev[k]) for k in order], _lib.current_stream()) == 1       # refused: t outside the buffer
+    L.icrl_clear_error()
+
+
+@pytest.mark.parametrize("per_step", [False, True])
+def test_is_weights_vs_oracle(per_step):
+    """constraint_net.py:231-256 against the oracle restatement (pinned to the reference by g6): ragged episodes."""
+    from icrl_amd import _lib
+    from oracle import cn as o_cn
+    L = _lib.lib()
+    rng = np.random.RandomState(3)
+    lengths = [7, 40, 1, 23, 64, 12, 33]
+    N = sum(lengths)
+    old = torch.as_tensor(rng.uniform(0.2, 0.9, (N, 1)).astype(np.float32))
+    new = (old + torch.as_tensor(rng.uniform(-0.02, 0.02, (N, 1)).astype(np.float32))).clamp(0.01, 0.99)
+    w_ref, kl_on, kl_no = o_cn.is_weights_and_kls(old.clone(), new.clone(), lengths, 1e-5, per_step)
+    offs = torch.as_tensor(np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)).cuda()
+    d_old, d_new = old.flatten().cuda().contiguous(), new.flatten().cuda().contiguous()
+    w, prod, out4 = torch.zeros(N, device="cuda"), torch.zeros(len(lengths), device="cuda"), torch.zeros(4, device="cuda")
+    _lib.check(L.icrl_is_weights(_lib.ptr(d_old), _lib.ptr(d_new), N, _lib.ptr(offs), len(lengths), 1e-5, int(per_step), _lib.ptr(w), _lib.ptr(prod), _lib.ptr(out4),
+                                 _lib.current_stream()), "icrl_is_weights")
+    assert np.allclose(w.cpu().numpy(), w_ref.numpy().ravel(), rtol=2e-5, atol=1e-7)
+    o = out4.cpu().numpy()
+    assert abs(o[0] - kl_on.item()) <= 2e-5 * max(1.0, abs(kl_on.item())) and abs(o[1] - kl_no.item()) <= 2e-5 * max(1.0, abs(kl_no.item())) + 1e-6
+
+
+@pytest.mark.parametrize("mode,weights", [(0, True), (0, False), (2, True), (1, False)])
+def test_cn_loss_fwd_bwd_vs_autograd(mode, weights):
+    """constraint_net.py:188-202 (and gail_utils.py's BCE) on the network's outputs: loss terms and d loss / d prediction against torch
+    autograd of the oracle's expressions.  mode 2: the per-step broadcast quirk (nominal_loss = mean(w) * mean(log zeta))."""
+    from icrl_amd import _lib
+    from oracle import cn as o_cn
+    L = _lib.lib()
+    rng = np.random.RandomState(4)
+    Bn, Be, reg, eps = 300, 170, 0.5, 1e-5
+    nom = torch.as_tensor(rng.uniform(0.05, 0.95, (Bn, 1)).astype(np.float32)).requires_grad_(True)
+    exp = torch.as_tensor(rng.uniform(0.05, 0.95, (Be, 1)).astype(np.float32)).requires_grad_(True)
+    w = torch.as_tensor(rng.uniform(0.5, 1.5, Bn).astype(np.float32)) if weights else torch.ones(Bn)
+
+    class _Net:                       # the oracle's cn_loss evaluates net.forward(batch): hand it the leaf predictions
+        def forward(self, x):
+            return x
+    is_batch = w[..., None, None] if mode == 2 else w[..., None]
+    loss, e_l, n_l, r_l, _, _ = o_cn.cn_loss(_Net(), nom, exp, is_batch, reg, eps, gail=bool(mode & 1), factored=(mode == 2))
+    loss.backward()
+    d_nom, d_exp, terms = torch.zeros(Bn, device="cuda"), torch.zeros(Be, device="cuda"), torch.zeros(6, device="cuda")
+    dn, de = nom.detach().flatten().cuda().contiguous(), exp.detach().flatten().cuda().contiguous()
+    dw = w.cuda().contiguous() if weights else None
+    _lib.check(L.icrl_cn_loss_fwd_bwd(_lib.ptr(dn), _lib.ptr(de), _lib.ptr(dw), Bn, Be, reg, eps, mode, _lib.ptr(terms), _lib.ptr(d_nom), _lib.ptr(d_exp),
+                                      _lib.current_stream()), "icrl_cn_loss_fwd_bwd")
+    t = terms.cpu().numpy()
+    for got, ref in zip(t[:4], (loss.item(), e_l.item(), n_l.item(), float(r_l))):
+        assert abs(got - ref) <= 2e-6 + 2e-5 * abs(ref), (t, loss.item(), e_l.item(), n_l.item(), float(r_l))
+    assert np.allclose(d_nom.cpu().numpy(), nom.grad.numpy().ravel(), rtol=2e-5, atol=1e-8)
+    assert np.allclose(d_exp.cpu().numpy(), exp.grad.numpy().ravel(), rtol=2e-5, atol=1e-8)
