@@ -22,6 +22,7 @@ struct GenLayer { int in_dim, out_dim, w_off, b_off, in_buf, act_off, slot, tanh
 struct GenNet {
   int O, A, discrete, log_std, n;          // log_std: parameter offset (-1 when discrete); n: parameter count
   int n_layers, n_stages, row_floats, W;   // W: threads per slot = the widest layer rounded up to 64
+  int n_shared;                            // layers 0 .. n_shared-1 form the shared trunk (one per stage)
   int stage_begin[GEN_MAX_STAGES + 1];
   int head[3];                             // layer indices of action_net / value_net / cost_value_net (the last stage)
   GenLayer layer[GEN_MAX_LAYERS];
@@ -88,7 +89,7 @@ static inline int make_gen_net(const icrl_policy_t* p, GenNet* out, const char* 
     off += tip_dim[r] * n_out + n_out;
   }
   g.stage_begin[ns] = nl;
-  g.n = off; g.n_layers = nl; g.n_stages = ns; g.row_floats = act; g.W = (widest + 63) / 64 * 64;
+  g.n = off; g.n_layers = nl; g.n_stages = ns; g.row_floats = act; g.W = (widest + 63) / 64 * 64; g.n_shared = n_sh;
   if (p->n_params != g.n) return fail("%s: n_params = %d, the architecture needs %d", who, p->n_params, g.n);
   return 0;
 }

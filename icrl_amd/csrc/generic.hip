@@ -493,32 +493,144 @@ __global__ void gen_finish_kernel(GenArgs a, int* adam_t) {
 // =====================================================================================================================
 // ONE persistent launch per train() (round 5): the same GenNet table, the update as fp32 MFMA tiles.
 // =====================================================================================================================
-// grid = G = ceil(batch_size / 16) workgroups of 8 waves; workgroup g takes rows 16 g .. 16 g + 15 of EVERY minibatch through the whole
-// network — activations and pre-activation gradients of its 16 rows live in LDS, row-major and padded per layer to 16 units; every GEMM
-// is a chain of v_mfma_f32_16x16x4_f32 whose A operand (weights: `params` row-major for the forward and the weight gradients' layout,
-// the per-layer transposes `params_t` for the backward) is streamed from L2 and whose B operand is one ds_read_b128 of the row image;
-// the 16 x 16 tiles of a stage are dealt round-robin to the waves — then writes its PARTIAL weight gradients (K = its 16 rows: four
-// MFMAs per parameter tile) to `part[g]`.  Across workgroups, per optimiser step: grid barrier | workgroup g sums the partials of ITS
-// parameter slice over the tiles in tile order (deterministic), leaves the gradient and its squared norm | grid barrier | every
-// workgroup forms the same total norm and runs clip + Adam on its slice (both parameter images) | grid barrier.  Data that crosses
-// workgroups (partials, parameters, norms, loss sums) is written and read with agent-scope relaxed atomics (sc1: no stale L1 / non-local L2
-// line), a barrier arrival is preceded by s_waitcnt vmcnt(0); no fences.  Every workgroup accumulates the SAME logged sums and takes
-// the same target-KL decision from them, so nothing has to be broadcast.
+// Workgroups of 8 waves, all on ONE XCD (<= 30 of its 32 compute units).  A TILE workgroup (g, b) takes rows 16 g .. 16 g + 15 of every
+// minibatch through the layers of branch b (NBR = 3: policy / value / cost-value workgroups per row tile, every one of them also runs
+// the shared trunk forward; chosen while 3 G <= 30) or through the whole table (NBR = 1).  Activations and pre-activation gradients of
+// its 16 rows live in LDS, row-major, every layer padded to 16 units; every GEMM is a chain of v_mfma_f32_16x16x4_f32:
+//   forward    Z^T tile (16 units x 16 rows): A = 16 weight rows streamed from the XCD's L2 (one tile's whole K per wave, the NEXT tile
+//              of the wave's work list — also across stages — in flight under this tile's MFMAs), B = ds_read_b128 of the row image;
+//   backward   d h (16 rows x 64 units per item): A = ds_read_b128 of the consumers' d z, B = the consumers' weights read in their
+//              NATURAL layout — one 16-byte load serves four output tiles whose columns are interleaved (unit 64 T + 4 r + i belongs to
+//              tile i), so no transposed parameter image is needed; the consumers' units are split over the waves (K split), partial
+//              sums meet in an LDS scratch;
+//   gradients  d W^T tiles (16 inputs x 16 units, K = the 16 rows), four input tiles per item, 16-byte stores into part[g].
+// A trunk under NBR = 3: the three workgroups of a row tile leave their branch's share of d h(trunk) in memory, the trunk's owner (the
+// branch with the fewest parameters) sums them in branch order and walks the trunk backward.
+// Across workgroups, per optimiser step: grid barrier | every workgroup (tile workgroups and helpers, ~2 048 parameters each) sums its
+// parameter slice over the row tiles in tile order and leaves its squared norm | grid barrier | clip + Adam on the slice | grid barrier.
+// The rows of the NEXT minibatch (observations, the per-row record of the loss, the advantage statistics) are fetched under the
+// barriers.  Data that crosses workgroups is written with sc0 (workgroup scope: stays in the one L2 all of them read through) and read
+// with sc0 buffer loads (L1 bypassed) when the run-time XCC check finds every workgroup on one XCD, else with agent scope (sc1);
+// a barrier arrival is preceded by s_waitcnt vmcnt(0); no fences.  Every workgroup accumulates the SAME logged sums and takes the same
+// target-KL decision from them, so nothing has to be broadcast.  `params_t` is rebuilt once, after the launch.
 // Shapes this form does not serve (more than GENP_MAX_TILES row tiles, more than GENP_MAX_PARAMS parameters, rows that do not fit the
 // LDS) keep the three-launches-per-step form below.
 constexpr int GENP_TH = 512;
 constexpr int GENP_MAX_TILES = 32;            // batch_size <= 512
-constexpr int GENP_MIN_TILES = 16;            // the default from this many row tiles on (batch_size > 240): below, the launch-per-phase form is faster (measured)
 constexpr int GENP_MAX_PARAMS = 131072;
-constexpr int GENP_MAX_RS = 1096;             // floats per LDS row: 2 images x 16 rows x RS x 4 B <= 140 KB
+constexpr int GENP_MAX_RS = 904;              // floats per LDS row: 2 images x 16 rows x RS x 4 B + what follows them <= 160 KB
+constexpr int GENP_SCR = 8192;                // floats of the K-split scratch: parts x 16 rows x 64-unit groups, parts x groups <= 8
+constexpr int GENP_FLIST = 64;                // forward items per wave
+constexpr int GENP_BLIST = 128;               // backward items per wave
+constexpr int GENP_REC = 24;                  // a row's record of the loss: actions [16] | old log-prob | adv r | adv c | return r | return c | value r | value c
+constexpr int GENP_MAX_WGS = 30;
+// ints of the tables: rows [16] | next rows [16] | FLN [8] | BLN [8] | SP [16] | SWD [16] | STL [16][4] | WL [32] | misc [16] | LT [32][8] | FL | BL
+constexpr int GENP_I_FLN = 32, GENP_I_BLN = 40, GENP_I_SP = 48, GENP_I_SWD = 64, GENP_I_STL = 80, GENP_I_WL = 144, GENP_I_MISC = 176, GENP_I_LT = 192,
+              GENP_I_FL = GENP_I_LT + 256, GENP_I_BL = GENP_I_FL + 8 * GENP_FLIST, GENP_INTS = GENP_I_BL + 8 * GENP_BLIST;
+constexpr int GENP_FLOATS = GENP_SCR + 256 + 512 + 32 + 16 * GENP_REC + 16 + 16 + GENP_INTS;      // LDS beyond the two row images
+static_assert((32 * GENP_MAX_RS + GENP_FLOATS) * 4 <= 160 * 1024, "LDS of the persistent generic-shape update");
 
 struct GenPersist {
-  int RS, OB, G, H, slice;                    // LDS row stride | observation width padded to 16 | row-tile workgroups | all workgroups (G + helpers of the reduce / Adam phases) | parameters per workgroup there
+  int RS, OB, G, H, slice, NBR, owner, WTP;   // LDS row stride | observation width padded to 16 | row tiles | all workgroups | parameters per workgroup in the reduce / Adam phases | branches per row tile | trunk owner | padded width of the trunk's last layer
   int poff[GEN_MAX_LAYERS];                   // padded offset of each layer's output inside a row (the observation sits at 0)
-  const PlanStep* plan;                       // per optimiser step: Adam's bias corrections, rows, flags, permutation base
+  const PlanStep* plan;                       // per optimiser step: Adam's bias corrections, rows, flags, permutation base (+ 2 zero entries)
   int n_steps;
-  float* part; float* grad; float* norm; float* stat; unsigned* bar; int* tidx;      // [G][n] | [n] | [G] | [G][8] | barrier counter | [n] position of a parameter in params_t
+  float* part; float* grad; float* norm; float* stat; unsigned* bar; float* xt; unsigned* xflag;      // [G][n] | [n] | [H] | [G][8] | barrier counter | [G][3][16][WTP] | [G][3]
 };
+
+// The tables of one tile workgroup (LDS on the device, filled once by one thread — the step loop never indexes the kernel arguments;
+// the host builds them per branch to check that they fit).
+//   LT[l] = {in_dim, out_dim, w_off, b_off, in_col, out_col, flags, scol}: in_col / out_col = columns of the layer's input / output in a row image,
+//           flags = tanh | backward role << 1 (0 none, 1 whole, 2 a share of the trunk's gradient, 3 share + the sum), scol = first scratch column
+//   FL      forward items of a wave:  l | 16-unit tile << 5 | 128-wide K slab << 9 | last slab << 12 | stage << 13
+//   BL      backward items of a wave: consumer layer | first unit / 16 << 5 | two chunks << 9 | l << 10 | 64-unit group << 15 | part << 17 | stage << 20 |
+//           last of its (l, group, part) << 24 | no chunk at all << 25        (a chunk = 16 units of ONE consumer of l)
+//   SP / SWD per stage: K-split parts (0: no scratch, straight into the image) / scratch row width;  STL[s] = the layers of stage s with a role (-1 ends)
+//   WL      the layers whose weight gradients are formed here (-1 ends);  MISC = {head columns 0..2, stages, trunk's last layer}
+struct GenpTables { int* LT; int* FL; int* FLN; int* BL; int* BLN; int* SP; int* SWD; int* STL; int* WL; int* MISC; };
+__host__ __device__ inline GenpTables genp_tables(int* iw) {
+  GenpTables T;
+  T.FLN = iw + GENP_I_FLN; T.BLN = iw + GENP_I_BLN; T.SP = iw + GENP_I_SP; T.SWD = iw + GENP_I_SWD; T.STL = iw + GENP_I_STL; T.WL = iw + GENP_I_WL;
+  T.MISC = iw + GENP_I_MISC; T.LT = iw + GENP_I_LT; T.FL = iw + GENP_I_FL; T.BL = iw + GENP_I_BL;
+  return T;
+}
+__host__ __device__ inline bool genp_build(const GenNet& net, const int* poff, int NBR, int b, int owner, const GenpTables& T) {
+  const int nsh = net.n_shared, NL = net.n_layers, NS = net.n_stages;
+  bool ok = true;
+  int wown[GEN_MAX_LAYERS], nwl = 0;
+  for (int l = 0; l < NL; ++l) {
+    const GenLayer& y = net.layer[l];
+    wown[l] = (NBR == 1 || (l < nsh ? b == owner : y.slot == b)) ? 1 : 0;
+    int* row = T.LT + 8 * l;
+    row[0] = y.in_dim; row[1] = y.out_dim; row[2] = y.w_off; row[3] = y.b_off; row[4] = y.in_buf < 0 ? 0 : poff[y.in_buf]; row[5] = poff[l];
+    row[6] = y.tanh ? 1 : 0; row[7] = 0;
+    if (wown[l]) T.WL[nwl++] = l;
+  }
+  T.WL[nwl] = -1;
+  for (int r = 0; r < 3; ++r) T.MISC[r] = poff[net.head[r]];
+  T.MISC[3] = NS; T.MISC[4] = nsh - 1;
+  for (int w = 0; w < 8; ++w) { T.FLN[w] = 0; T.BLN[w] = 0; }
+  int rr = 0;
+  for (int s = 0; s < NS; ++s)
+    for (int l = net.stage_begin[s]; l < net.stage_begin[s + 1]; ++l) {
+      if (!(NBR == 1 || l < nsh || net.layer[l].slot == b)) continue;
+      const int nt = (net.layer[l].out_dim + 15) / 16, nkb = (net.layer[l].in_dim + 127) / 128;
+      for (int t = 0; t < nt; ++t, ++rr)
+        for (int kb = 0; kb < nkb; ++kb) {
+          const int w = rr & 7;
+          if (T.FLN[w] >= GENP_FLIST) { ok = false; continue; }
+          T.FL[w * GENP_FLIST + T.FLN[w]++] = l | t << 5 | kb << 9 | (kb == nkb - 1 ? 1 : 0) << 12 | s << 13;
+        }
+    }
+  rr = 0;
+  for (int s = 0; s < 16; ++s) { T.SP[s] = 1; T.SWD[s] = 0; for (int i = 0; i < 4; ++i) T.STL[4 * s + i] = -1; }
+  for (int s = NS - 2; s >= 0; --s) {
+    int nsup = 0, nst = 0;
+    for (int l = net.stage_begin[s]; l < net.stage_begin[s + 1]; ++l) {
+      int role;
+      if (NBR == 1) role = 1;
+      else if (l >= nsh) role = net.layer[l].slot == b ? 1 : 0;
+      else if (l == nsh - 1) role = b == owner ? 3 : 2;
+      else role = b == owner ? 1 : 0;
+      T.LT[8 * l + 6] |= role << 1;
+      if (role) { T.LT[8 * l + 7] = 64 * nsup; nsup += (net.layer[l].out_dim + 63) / 64; T.STL[4 * s + nst++] = l; }
+    }
+    int P = 1;
+    if (nsup > 8) P = 0; else if (nsup > 0) { while (2 * P * nsup <= 8) P *= 2; }
+    T.SP[s] = P; T.SWD[s] = 64 * nsup;
+    for (int i = 0; i < nst; ++i) {
+      const int l = T.STL[4 * s + i];
+      // the chain of chunks over the consumers of l whose d z is here, in layer order
+      int total = 0;
+      for (int c = l + 1; c < NL; ++c) if (net.layer[c].in_buf == l && wown[c]) total += (net.layer[c].out_dim + 15) / 16;
+      const int PP = P > 0 ? P : 1, cpp = (total + PP - 1) / PP;
+      for (int TT = 0; TT < (net.layer[l].out_dim + 63) / 64; ++TT)
+        for (int p = 0; p < PP; ++p, ++rr) {
+          const int w = rr & 7, c0 = p * cpp < total ? p * cpp : total, c1 = c0 + cpp < total ? c0 + cpp : total;
+          const int common = l << 10 | TT << 15 | p << 17 | s << 20;
+          if (c0 == c1) {
+            if (T.BLN[w] >= GENP_BLIST) { ok = false; continue; }
+            T.BL[w * GENP_BLIST + T.BLN[w]++] = common | 1 << 24 | 1 << 25;
+            continue;
+          }
+          int ci = 0;
+          for (int c = l + 1; c < NL; ++c) {
+            if (!(net.layer[c].in_buf == l && wown[c])) continue;
+            const int nch = (net.layer[c].out_dim + 15) / 16;
+            for (int jc = 0; jc < nch; ++jc, ++ci) {
+              if (ci < c0 || ci >= c1) continue;
+              const bool two = jc + 1 < nch && ci + 1 < c1;      // (two chunks of the same consumer in one item)
+              const bool last = ci + (two ? 2 : 1) >= c1;
+              if (T.BLN[w] >= GENP_BLIST) ok = false;
+              else T.BL[w * GENP_BLIST + T.BLN[w]++] = common | c | jc << 5 | (two ? 1 : 0) << 9 | (last ? 1 : 0) << 24;
+              if (two) { ++jc; ++ci; }
+            }
+          }
+        }
+    }
+  }
+  return ok;
+}
 
 // loads: agent scope (sc1: the L1 is bypassed; served by the XCD's L2 when the line is there).  stores: agent scope (sc1: written through, the
 // line is DROPPED from the L2 — every later load pays the fabric, ~2 us) unless all workgroups of the launch share one XCD (`local`,
@@ -530,173 +642,289 @@ __device__ __forceinline__ void st_x(float* p, float v) {
   else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Shared read-mostly data (parameters, partial gradients) goes through buffer resources with the sc1 cache policy — L1 bypassed,
-// served by the XCD's L2 — as plain (non-atomic) loads: a chain of relaxed ATOMIC loads is issued one at a time (each waited for
-// before the next: 16 trips to the L2 per K chunk, measured 6 k cycles per chunk), buffer loads are scheduled freely, and an offset
-// beyond the resource returns 0, which is the mask of the padded tiles.
+// Shared read-mostly data (parameters, partial gradients) goes through buffer resources as plain (non-atomic) loads with a cache policy:
+// a chain of relaxed ATOMIC loads is issued one at a time (each waited for before the next: 16 trips to the L2 per K chunk, measured
+// 6 k cycles per chunk), buffer loads are scheduled freely; an offset beyond the resource returns 0 (checked per dword, also inside a
+// 16-byte access) and a store there is dropped — the mask of the padded tiles, without a branch in the load / store stream (a select
+// between two LOADS becomes divergent control flow with a wait in every arm: measured 10 k cycles per tile).
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t genp_rsrc(const float* p, size_t n_floats) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)(n_floats * 4), 0x00020000);
 }
 // cache policy of the loads: sc1 (agent scope) is only served by the L2 for a line that is DIRTY there — anything else goes to the fabric
 // (~6 k cycles measured) —; when all workgroups share an XCD (`local`) sc0 is enough: the L1 is bypassed and the one L2 everybody
 // writes through serves every resident line (~700 cycles)
+#ifndef GENP_LD_AUX
+#define GENP_LD_AUX 16      // cache policy of the loads when every workgroup shares an XCD: 16 = sc1, 1 = sc0
+#endif
 template <bool LOCAL>
 __device__ __forceinline__ float genp_ld(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {      // (the policy is an immediate of the instruction: a compile-time choice)
-  if (LOCAL) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 1));
+  if (LOCAL) return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, GENP_LD_AUX));
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)byte_off, 0, 16));
+}
+template <bool LOCAL>
+__device__ __forceinline__ f32x4 genp_ld4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off) {     // (dword alignment is enough)
+  if (LOCAL) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, GENP_LD_AUX));
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)byte_off, 0, 16));
+}
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+template <bool LOCAL>
+__device__ __forceinline__ void genp_st4(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, f32x4 v) {
+  if (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)byte_off, 0, 1);
+  else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)byte_off, 0, 16);
+}
+template <bool LOCAL>
+__device__ __forceinline__ void genp_st1(__amdgpu_buffer_rsrc_t rs, unsigned byte_off, float v) {
+  if (LOCAL) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)byte_off, 0, 1);
+  else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs, (int)byte_off, 0, 16);
 }
 constexpr unsigned GENP_OOB = 0x80000000u;      // an offset outside every resource (they hold <= 16 MB), with room for the constant offsets added to it: the load returns 0, the store is dropped
 
-// acc[i] (unit 16 t + 4 q + i, row r) += sum_k A[16 t + r][k] B[r][k]:  A[m][k] = W[w_off + m * ldk + k] (zero outside nM x nK),
-// B = the LDS row image at `brow` (= image + r * RS + the input's padded offset).  K in chunks of 64 (16 weights per lane), the next
-// chunk's loads in flight under this chunk's MFMAs.
+// grid barrier in two halves (work that needs nothing from the other workgroups goes between them)
 template <bool LOCAL>
-__device__ __forceinline__ f32x4 genp_gemm(f32x4 acc, __amdgpu_buffer_rsrc_t rs, int w_off, int t, int ldk, int nM, int nK, const float* brow, int r, int q) {
-  // Masking without a branch in the load stream (a select between two LOADS becomes divergent control flow with a wait in every arm —
-  // measured 10 k cycles per tile): a row m >= nM starts at an offset outside the resource, so all its loads return 0; columns
-  // k >= nK need no mask at all — the B operand's pad columns are zeros (every tile is stored 16 wide with its rows masked like this),
-  // the weights read there are some other finite parameters, or 0 past the end of the resource.
-  const int m = 16 * t + r;
-  const unsigned base = m < nM ? 4u * (unsigned)(w_off + m * ldk + 4 * q) : GENP_OOB;
-  auto fetch = [&](int k0, float (&a)[16]) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) a[4 * c + e] = genp_ld<LOCAL>(rs, base + 4u * (unsigned)(k0 + 16 * c + e));
-  };
-  float cur[16], nxt[16];
-  fetch(0, cur);
-  for (int k0 = 0; k0 < nK; k0 += 64) {
-    const bool more = k0 + 64 < nK;
-    if (more) fetch(k0 + 64, nxt);
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      if (k0 + 16 * c < nK) {
-        const f32x4 b = lds128(brow + k0 + 16 * c + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc = MFMA_F32(cur[4 * c + e], b[e], acc);
-      }
-    }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) cur[i] = nxt[i];
-    }
-  }
-  return acc;
-}
-
-template <bool LOCAL>
-__device__ __forceinline__ void genp_grid_barrier(unsigned* bar, unsigned target) {
+__device__ __forceinline__ void genp_arrive(unsigned* bar) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
     if (LOCAL) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);      // (atomics execute in the L2: the one all workgroups share)
     else __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
   }
+}
+// (the L1 is invalidated behind every wait: an sc0 load is a workgroup-scope load — it MAY be served by the compute unit's L1, and was, with
+// the previous step's parameters, once a network was small enough to stay there: measured, test hc-bare)
+__device__ __forceinline__ void genp_wait(unsigned* bar, unsigned target) {
+  if (threadIdx.x == 0)
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
   __syncthreads();
 }
+template <bool LOCAL>
+__device__ __forceinline__ void genp_grid_barrier(unsigned* bar, unsigned target) { genp_arrive<LOCAL>(bar); genp_wait(bar, target); }
 
-// fixed tree over the 8 waves of the workgroup (wave sums by DPP, then the eight in order): every workgroup forms the same value
+// three sums over the workgroup at once: fixed tree (wave sums by DPP, then the eight in order): every workgroup forms the same values
+__device__ __forceinline__ void genp_block_sum3(float& a, float& b, float& c, float* red24) {
+  a = wave_sum_fast(a); b = wave_sum_fast(b); c = wave_sum_fast(c);
+  const int w = threadIdx.x >> 6;
+  lds_barrier();
+  if ((threadIdx.x & 63) == 0) { red24[w] = a; red24[8 + w] = b; red24[16 + w] = c; }
+  lds_barrier();
+  a = ((red24[0] + red24[1]) + (red24[2] + red24[3])) + ((red24[4] + red24[5]) + (red24[6] + red24[7]));
+  b = ((red24[8] + red24[9]) + (red24[10] + red24[11])) + ((red24[12] + red24[13]) + (red24[14] + red24[15]));
+  c = ((red24[16] + red24[17]) + (red24[18] + red24[19])) + ((red24[20] + red24[21]) + (red24[22] + red24[23]));
+}
 __device__ __forceinline__ float genp_block_sum(float v, float* red8) {
   v = wave_sum_fast(v);
   const int w = threadIdx.x >> 6;
-  __syncthreads();
+  lds_barrier();
   if ((threadIdx.x & 63) == 0) red8[w] = v;
-  __syncthreads();
+  lds_barrier();
   return ((red8[0] + red8[1]) + (red8[2] + red8[3])) + ((red8[4] + red8[5]) + (red8[6] + red8[7]));
 }
 
 // the body for one store / load policy (LOCAL: every workgroup of the launch sits on the same XCD)
 template <bool LOCAL>
-__device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, const GenPersist& pp, const int g, float* const sm, unsigned bar_n) {
-  constexpr bool local = LOCAL;
-  const int RS = pp.RS, G = pp.G, H = pp.H;
-  const bool tile_wg = g < G;                  // workgroups G .. H-1 only help with the reduce / Adam phases
+__device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, const GenPersist& pp, const int wg, float* const sm, unsigned bar_n) {
+  const int RS = pp.RS, G = pp.G, H = pp.H, NBR = pp.NBR;
+  const bool tile_wg = wg < G * NBR;           // the other workgroups only help with the reduce / Adam phases
+  const int g = tile_wg ? wg / NBR : 0, b = tile_wg ? wg - g * NBR : 0;
   float* const ACT = sm;                       // [16][RS] observation + every layer's output
   float* const DZ = sm + 16 * RS;              // [16][RS] d loss / d pre-activation
-  float* const G2 = DZ + 16 * RS;              // [16][16] log_std gradient terms of the rows
-  float* const RST = G2 + 256;                 // [3][16][8] per-row loss terms
-  float* const RED = RST + 384;                // [16] reduction scratch
-  int* const RIDX = reinterpret_cast<int*>(RED + 16);      // [16] storage offsets of the rows
+  float* const SCR = DZ + 16 * RS;             // K-split partial sums of the backward pass
+  float* const G2 = SCR + GENP_SCR;            // [16][16] log_std gradient terms of the rows
+  float* const RST = G2 + 256;                 // [3][16][8] per-row loss terms; the tiles' sums and the slices' norms in the Adam phase
+  float* const RED = RST + 512;                // [32] reduction scratch
+  float* const REC = RED + 32;                 // [16][GENP_REC] the rows' records
+  float* const ADV = REC + 16 * GENP_REC;      // [16] the minibatch's advantage sums
+  float* const LS = ADV + 16;                  // [16] log_std
+  int* const IW = reinterpret_cast<int*>(LS + 16);
+  int* const RIDX = IW;                        // [16] storage offsets of the rows
+  int* const RIDXN = IW + 16;                  // [16] ... of the next minibatch's rows
+  const GenpTables T = genp_tables(IW);
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
-  const int n = net.n, O = net.O, A = net.A;
-  const __amdgpu_buffer_rsrc_t rsP = genp_rsrc(a.params, (size_t)n), rsPT = genp_rsrc(a.params_t, (size_t)n), rsPart = genp_rsrc(pp.part, (size_t)G * n);
-  const int lo = g * pp.slice, hi = (lo + pp.slice < n) ? lo + pp.slice : n;      // this workgroup's parameter slice
+  const int n = net.n, O = net.O, A = net.A, OB = pp.OB;
+  const bool discrete = net.discrete != 0;
+  const __amdgpu_buffer_rsrc_t rsP = genp_rsrc(a.params, (size_t)n), rsPart = genp_rsrc(pp.part, (size_t)G * n);
+  const __amdgpu_buffer_rsrc_t rsXT = genp_rsrc(pp.xt, (size_t)G * 3 * 16 * (pp.WTP > 0 ? pp.WTP : 1));
+  const int lo = wg * pp.slice, hi = (lo + pp.slice < n) ? lo + pp.slice : n;      // this workgroup's parameter slice
+  const int role_mask = NBR == 1 ? 7 : 1 << b;      // the heads (0 policy, 1 value, 2 cost value) whose loss this workgroup forms
+  const bool role0 = (role_mask & 1) != 0;
+  if (tile_wg && tid == 0) genp_build(net, pp.poff, NBR, b, pp.owner, T);
+  __syncthreads();
+  const int n_stages = T.MISC[3], trunk_last = T.MISC[4];
+#define SU(x) __builtin_amdgcn_readfirstlane(x)      // a workgroup-uniform value read from LDS, back into a scalar register
   // replicated logged state (identical in every workgroup)
   float acc_ent = 0.f, acc_pg = 0.f, acc_cf = 0.f, acc_vr = 0.f, acc_vc = 0.f, last_pol = 0.f, last_vr = 0.f, last_vc = 0.f, kl_acc = 0.f, mean_kl = 0.f;
   int steps_done = 0, early_stop_epoch = a.hp.n_epochs;
   const float nu = a.nu[0];
   bool stop = false;
-  const bool prof = (a.hp._pad & 1) != 0 && g == 0;       // phase timers of workgroup 0, thread 0 (tools/generic_only.py PROF=1): stats[12..21]
+  const bool prof = (a.hp._pad & 1) != 0 && wg == 0;       // phase timers of workgroup 0, thread 0 (tools/generic_only.py PROF=1): stats[12..21]
   unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = prof ? stamp() : 0ull;
 #define GSTAMP(k) if (prof) { const unsigned long long now_ = stamp(); ph[k] += now_ - t_last; t_last = now_; }
+
+  // ---- the rows of a minibatch: fetched in two round trips (row offsets, then what they address) into registers, committed to LDS later
+  int nx_idx = -1, nx_ridx = 0;
+  float nx_ar = 0.f, nx_ac = 0.f, nx_obs[4] = {0.f, 0.f, 0.f, 0.f}, nx_rec = 0.f;
+  auto rows_issue1 = [&](const PlanStep& pn) {
+    const int nbn = pn.nb_flags & NB_MASK;
+    nx_idx = -1;
+    if (nbn == 0) return;
+    if (role0 && tid < nbn) nx_idx = a.perm_off[pn.perm_base + tid];
+    if (tid < 16) nx_ridx = a.perm_off[pn.perm_base + (16 * g + tid < nbn ? 16 * g + tid : 0)];
+  };
+  auto rows_issue2 = [&](const PlanStep& pn) {
+    const int nbn = pn.nb_flags & NB_MASK;
+    if (nbn == 0) return;
+    if (tid < 16) RIDXN[tid] = nx_ridx;
+    lds_barrier();
+    nx_ar = 0.f; nx_ac = 0.f;
+    if (nx_idx >= 0) { nx_ar = a.buf.reward_advantages[nx_idx]; nx_ac = a.buf.cost_advantages[nx_idx]; }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + GENP_TH * u;
+      nx_obs[u] = 0.f;
+      if (e < 16 * OB) {
+        const int rr = e / OB, k = e - rr * OB;
+        if (k < O) nx_obs[u] = a.buf.observations[(size_t)RIDXN[rr] * O + k];
+      }
+    }
+    if (tid < 16 * GENP_REC) {
+      const int rr = tid / GENP_REC, f = tid - rr * GENP_REC, idx = RIDXN[rr];
+      float v = 0.f;
+      if (f < 16) { if (f < a.buf.act_store) v = a.buf.actions[(size_t)idx * a.buf.act_store + f]; }
+      else if (f == 16) v = a.buf.log_probs[idx];
+      else if (f == 17) v = a.buf.reward_advantages[idx];
+      else if (f == 18) v = a.buf.cost_advantages[idx];
+      else if (f == 19) v = a.buf.reward_returns[idx];
+      else if (f == 20) v = a.buf.cost_returns[idx];
+      else if (f == 21) v = a.buf.reward_values[idx];
+      else if (f == 22) v = a.buf.cost_values[idx];
+      nx_rec = v;
+    }
+  };
+  auto rows_commit = [&](const PlanStep& pn) {
+    const int nbn = pn.nb_flags & NB_MASK;
+    if (nbn == 0) return;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = tid + GENP_TH * u;
+      if (e < 16 * OB) { const int rr = e / OB, k = e - rr * OB; ACT[rr * RS + k] = nx_obs[u]; }
+    }
+    for (int e = tid + 4 * GENP_TH; e < 16 * OB; e += GENP_TH) {      // (observations wider than 128: the rest, not prefetched)
+      const int rr = e / OB, k = e - rr * OB;
+      ACT[rr * RS + k] = k < O ? a.buf.observations[(size_t)RIDXN[rr] * O + k] : 0.f;
+    }
+    if (tid < 16 * GENP_REC) REC[tid] = nx_rec;
+    if (tid < 16) RIDX[tid] = RIDXN[tid];
+    float sr = nx_ar, sc = nx_ac, srr = nx_ar * nx_ar;
+    genp_block_sum3(sr, sc, srr, RED);
+    if (tid == 0) { ADV[0] = sr; ADV[1] = sc; ADV[2] = srr; }
+    lds_barrier();
+  };
+  if (tile_wg) {
+    const PlanStep p0 = pp.plan[0];
+    rows_issue1(p0); rows_issue2(p0); rows_commit(p0);
+  }
+
   for (int st = 0; st < pp.n_steps && !stop; ++st) {
-    const PlanStep ps = pp.plan[st];
+    const PlanStep ps = pp.plan[st], pn = pp.plan[st + 1];
     const int nb = ps.nb_flags & NB_MASK, epoch = ps.nb_flags >> NB_EPOCH;
     const bool first_mb = (ps.nb_flags >> NB_FIRST) & 1, last_mb = (ps.nb_flags >> NB_LAST) & 1;
     const float inv_nb = 1.f / (float)nb;
     if (tile_wg) {
-    // ---- rows of this tile -> LDS; advantage statistics of the whole minibatch (every workgroup, identically)
-    if (tid < 16) {
-      const int row = 16 * g + tid;
-      RIDX[tid] = a.perm_off[ps.perm_base + (row < nb ? row : 0)];
-    }
-    float sr = 0.f, sc = 0.f, srr = 0.f;
-    for (int i = tid; i < nb; i += GENP_TH) {
-      const int idx = a.perm_off[ps.perm_base + i];
-      const float ar = a.buf.reward_advantages[idx];
-      sr += ar; sc += a.buf.cost_advantages[idx]; srr += ar * ar;
-    }
-    __syncthreads();
-    for (int i = tid; i < 16 * pp.OB; i += GENP_TH) {
-      const int rr = i / pp.OB, k = i - rr * pp.OB;
-      ACT[rr * RS + k] = k < O ? a.buf.observations[(size_t)RIDX[rr] * O + k] : 0.f;
-    }
-    sr = genp_block_sum(sr, RED); sc = genp_block_sum(sc, RED); srr = genp_block_sum(srr, RED);
+    float ls_reg = 0.f;
+    if (!discrete && role0 && tid < A) ls_reg = genp_ld<LOCAL>(rsP, 4u * (unsigned)(net.log_std + tid));
+    const float sr = ADV[0], sc = ADV[1], srr = ADV[2];
     const float mean_r = sr * inv_nb, mean_c = sc * inv_nb;
     const float istd_r = 1.f / (sqrtf(fmaxf(srr - sr * mean_r, 0.f) / (float)(nb - 1)) + 1e-8f);
-    __syncthreads();
     GSTAMP(0)   // rows + advantage statistics
-    // ================= forward, stage by stage =================
-    for (int s = 0; s < net.n_stages; ++s) {
-      int item = 0;
-      for (int l = net.stage_begin[s]; l < net.stage_begin[s + 1]; ++l) {
-        const GenLayer& y = net.layer[l];
-        const int in_off = y.in_buf < 0 ? 0 : pp.poff[y.in_buf];
-        for (int t = 0; t < (y.out_dim + 15) / 16; ++t, ++item) {
-          if ((item & 7) != w) continue;
-          f32x4 acc;
+    f32x4 X0[8];
+    // ================= forward: the wave's tiles in list order, the next tile's weights in flight under this tile's MFMAs =================
+    {
+      const int fn = SU(T.FLN[w]);
+      const int* fl = T.FL + w * GENP_FLIST;
+      struct FD { int it, in_dim, out_dim, w_off, b_off, in_col, out_col, tanh; };
+      auto f_decode = [&](int idx) -> FD {
+        FD d;
+        d.it = SU(fl[idx]);
+        const int* row = T.LT + 8 * (d.it & 31);
+        d.in_dim = SU(row[0]); d.out_dim = SU(row[1]); d.w_off = SU(row[2]); d.b_off = SU(row[3]); d.in_col = SU(row[4]); d.out_col = SU(row[5]); d.tanh = SU(row[6]) & 1;
+        return d;
+      };
+      // ONE register image of a tile's weights: chunk c of the NEXT item is loaded into X[c] right after this item's MFMAs have read
+      // it — every load is issued about one item ahead of its use, also across the stage barriers (the weights do not change inside a step)
+      f32x4 Bv = f32x4{0.f, 0.f, 0.f, 0.f}, acc = Bv;
+      auto f_row = [&](const FD& d) -> unsigned {      // byte offset of this lane's 4 weights of chunk 0
+        const int t = (d.it >> 5) & 15, kb = (d.it >> 9) & 7, m = 16 * t + r;
+        return m < d.out_dim ? 4u * (unsigned)(d.w_off + m * d.in_dim + 128 * kb + 4 * q) : GENP_OOB;
+      };
+      auto f_bias = [&](const FD& d) -> f32x4 {
+        const int t = (d.it >> 5) & 15;
+        return genp_ld4<LOCAL>(rsP, 16 * t + 4 * q < d.out_dim ? 4u * (unsigned)(d.b_off + 16 * t + 4 * q) : GENP_OOB);
+      };
+      int fi = 0;
+      FD d, nd;
+      d.it = -1; nd.it = -1;
+      if (fn > 0) {
+        d = f_decode(0);
+        const unsigned base = f_row(d);
+        const int kk = d.in_dim - 128 * ((d.it >> 9) & 7);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { const int j = 16 * t + 4 * q + i; acc[i] = genp_ld<LOCAL>(rsP, j < y.out_dim ? 4u * (unsigned)(y.b_off + j) : GENP_OOB); }
-          acc = genp_gemm<LOCAL>(acc, rsP, y.w_off, t, y.in_dim, y.out_dim, y.in_dim, ACT + r * RS + in_off, r, q);
-          if (y.tanh) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = fast_tanh(acc[i]);
-          }
-          *reinterpret_cast<f32x4*>(ACT + r * RS + pp.poff[l] + 16 * t + 4 * q) = acc;
-        }
+        for (int c = 0; c < 8; ++c)
+          if (16 * c < kk) X0[c] = genp_ld4<LOCAL>(rsP, base + 64u * (unsigned)c);
+        if (((d.it >> 9) & 7) == 0) Bv = f_bias(d);
       }
-      __syncthreads();
+      for (int s = 0; s < n_stages; ++s) {
+        while (fi < fn && (d.it >> 13) == s) {
+          const bool more = fi + 1 < fn;
+          unsigned nbase = GENP_OOB;
+          int nkk = 0;
+          if (more) { nd = f_decode(fi + 1); nbase = f_row(nd); nkk = nd.in_dim - 128 * ((nd.it >> 9) & 7); }
+          const int t = (d.it >> 5) & 15, kb = (d.it >> 9) & 7, lastk = (d.it >> 12) & 1, kk = d.in_dim - 128 * kb;
+          if (kb == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = 16 * t + 4 * q + i < d.out_dim ? Bv[i] : 0.f;
+          }
+          if (more && ((nd.it >> 9) & 7) == 0) Bv = f_bias(nd);
+          const float* brow = ACT + r * RS + d.in_col + 128 * kb + 4 * q;
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            if (16 * c < kk) {
+              const f32x4 bv = lds128(brow + 16 * c);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc = MFMA_F32(X0[c][e], bv[e], acc);
+            }
+            if (16 * c < nkk) X0[c] = genp_ld4<LOCAL>(rsP, nbase + 64u * (unsigned)c);
+          }
+          if (lastk) {
+            if (d.tanh) {
+#pragma unroll
+              for (int i = 0; i < 4; ++i) acc[i] = fast_tanh(acc[i]);
+            }
+            *reinterpret_cast<f32x4*>(ACT + r * RS + d.out_col + 16 * t + 4 * q) = acc;
+          }
+          d = nd; ++fi;
+          if (fi >= fn) d.it = -1;
+        }
+        lds_barrier();
+      }
     }
+    if (tid < A) LS[tid] = ls_reg;
+    lds_barrier();
     GSTAMP(1)   // forward
-    // ================= loss terms of the three heads: thread (role, row) =================
-    if (tid < 48) {
+    // ================= loss terms of the heads this workgroup owns: thread (role, row) =================
+    if (tid < 48 && ((role_mask >> (tid >> 4)) & 1)) {
       const int role = tid >> 4, row = tid & 15;
       const bool valid = 16 * g + row < nb;
-      const int idx = RIDX[row];
-      float* dout = DZ + row * RS + pp.poff[net.head[role]];
-      const float* out = ACT + row * RS + pp.poff[net.head[role]];
+      const float* rec = REC + row * GENP_REC;
+      const int hcol = T.MISC[role];
+      float* dout = DZ + row * RS + hcol;
+      const float* out = ACT + row * RS + hcol;
       float* rs = RST + (role * 16 + row) * 8;
       if (role == 0) {
-        float lp = 0.f, ent = 0.f, g1[MAX_ACT], g2[MAX_ACT];
-        if (!net.discrete) {
+        const float old_lp = rec[16];
+        float lp = 0.f, ent = 0.f, lse = 0.f;
+        if (!discrete) {
           for (int o = 0; o < A; ++o) {
-            const float ls = genp_ld<LOCAL>(rsP, 4u * (unsigned)(net.log_std + o)), sd = __expf(ls), iv = 1.f / (sd * sd);
-            const float dd = a.buf.actions[(size_t)idx * a.buf.act_store + o] - out[o];
+            const float ls = LS[o], dd = rec[o] - out[o], sd = __expf(ls), iv = 1.f / (sd * sd);
             lp += -(dd * dd) * (0.5f * iv) - ls - LOG_SQRT_2PI_F;
-            g1[o] = dd * iv;
-            g2[o] = (dd * dd) * iv - 1.f;
             ent += HALF_LOG_2PI_PLUS_HALF_F + ls;
           }
         } else {
@@ -704,40 +932,46 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
           for (int o = 0; o < A; ++o) m = fmaxf(m, out[o]);
           float se = 0.f;
           for (int o = 0; o < A; ++o) se += expf(out[o] - m);
-          const float lse = m + logf(se);
-          const int action = (int)a.buf.actions[(size_t)idx * a.buf.act_store];
-          for (int o = 0; o < A; ++o) { const float lg = out[o] - lse; ent -= expf(lg) * lg; }
-          for (int o = 0; o < A; ++o) {
-            const float lg = out[o] - lse, pr = expf(lg);
-            if (o == action) lp = lg;
-            g1[o] = (o == action ? 1.f : 0.f) - pr;
-            g2[o] = pr * (lg + ent);
-          }
+          lse = m + logf(se);
+          const int action = (int)rec[0];
+          for (int o = 0; o < A; ++o) { const float lg = out[o] - lse; ent -= expf(lg) * lg; if (o == action) lp = lg; }
         }
-        const float old_lp = a.buf.log_probs[idx];
         const float ratio = __expf(lp - old_lp);
-        const float Ar = (a.buf.reward_advantages[idx] - mean_r) * istd_r;
-        const float Ac = a.buf.cost_advantages[idx] - mean_c;
+        const float Ar = (rec[17] - mean_r) * istd_r;
+        const float Ac = rec[18] - mean_c;
         const float clip = a.hp.clip_range;
         const float s1 = Ar * ratio, s2 = Ar * fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
         const float gsel = (s1 <= s2) ? Ar : 0.f;
         const float dlp = valid ? inv_nb / (1.f + nu) * (-gsel + nu * Ac) * ratio : 0.f;
         const float dent = valid ? a.hp.ent_coef * inv_nb : 0.f;
-        for (int o = 0; o < 16; ++o) G2[row * 16 + o] = 0.f;
-        for (int o = 0; o < A; ++o) {
-          dout[o] = net.discrete ? dlp * g1[o] + dent * g2[o] : dlp * g1[o];
-          G2[row * 16 + o] = net.discrete ? 0.f : dlp * g2[o];
+        // (the per-output terms again, now that d loss / d log-prob is known: no per-thread arrays)
+        if (!discrete) {
+          for (int o = 0; o < 16; ++o) {
+            float d1v = 0.f, d2v = 0.f;
+            if (o < A) {
+              const float ls = LS[o], dd = rec[o] - out[o], sd = __expf(ls), iv = 1.f / (sd * sd);
+              d1v = dlp * (dd * iv); d2v = dlp * ((dd * dd) * iv - 1.f);
+            }
+            if (o < A) dout[o] = d1v;
+            G2[row * 16 + o] = d2v;
+          }
+        } else {
+          const int action = (int)rec[0];
+          for (int o = 0; o < 16; ++o) {
+            if (o < A) { const float lg = out[o] - lse, pr = expf(lg); dout[o] = dlp * ((o == action ? 1.f : 0.f) - pr) + dent * (pr * (lg + ent)); }
+            G2[row * 16 + o] = 0.f;
+          }
         }
         rs[0] = valid ? fminf(s1, s2) : 0.f; rs[1] = valid ? Ac * ratio : 0.f; rs[2] = (valid && fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
         rs[3] = valid ? old_lp - lp : 0.f; rs[4] = valid ? ent : 0.f;
       } else {
         const float v = out[0];
-        const float R = role == 1 ? a.buf.reward_returns[idx] : a.buf.cost_returns[idx];
+        const float R = role == 1 ? rec[19] : rec[20];
         const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
         const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
         float vp = v, pass = 1.f;
         if (vclip >= 0.f) {
-          const float old = role == 1 ? a.buf.reward_values[idx] : a.buf.cost_values[idx];
+          const float old = role == 1 ? rec[21] : rec[22];
           const float dv = v - old;
           vp = old + fminf(fmaxf(dv, -vclip), vclip);
           pass = (dv >= -vclip && dv <= vclip) ? 1.f : 0.f;
@@ -747,79 +981,213 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
         rs[0] = valid ? e * e : 0.f;
       }
     }
-    __syncthreads();
+    lds_barrier();
     GSTAMP(2)   // loss
     // ================= backward of the activations, stage by stage: d h = sum over the layers that read h of W^T dz (layer order) =================
-    for (int s = net.n_stages - 2; s >= 0; --s) {
-      int item = 0;
-      for (int l = net.stage_begin[s]; l < net.stage_begin[s + 1]; ++l) {
-        const GenLayer& y = net.layer[l];
-        for (int t = 0; t < (y.out_dim + 15) / 16; ++t, ++item) {
-          if ((item & 7) != w) continue;
-          f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-          for (int c = l + 1; c < net.n_layers; ++c) {
-            const GenLayer& z = net.layer[c];
-            if (z.in_buf != l) continue;
-            acc = genp_gemm<LOCAL>(acc, rsPT, z.w_off, t, z.out_dim, z.in_dim, z.out_dim, DZ + r * RS + pp.poff[c], r, q);      // A[k][j] = Wt[k * out + j]
-          }
-          const f32x4 h = lds128(ACT + r * RS + pp.poff[l] + 16 * t + 4 * q);
+    {
+      const int bn = SU(T.BLN[w]);
+      const int* bl = T.BL + w * GENP_BLIST;
+      f32x4 acc[4];
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[i] = fmaf(-(h[i] * h[i]), acc[i], acc[i]);
-          *reinterpret_cast<f32x4*>(DZ + r * RS + pp.poff[l] + 16 * t + 4 * q) = acc;
+      for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      struct BD { int it, nl, c_out, c_woff, c_col; };      // the item, the width of l (= the consumer's row stride), the consumer's units / weights / d z column
+      auto b_decode = [&](int idx) -> BD {
+        BD d;
+        d.it = SU(bl[idx]);
+        const int* row = T.LT + 8 * (d.it & 31);
+        d.nl = SU(row[0]); d.c_out = SU(row[1]); d.c_woff = SU(row[2]); d.c_col = SU(row[5]);
+        return d;
+      };
+      auto b_load = [&](const BD& d, int u, int e) -> f32x4 {      // the consumer's weights [unit j0 + 16 u + 4 q + e][64 T + 4 r ..]
+        const int TT = (d.it >> 15) & 3, j = 16 * ((d.it >> 5) & 15) + 16 * u + 4 * q + e;
+        return genp_ld4<LOCAL>(rsP, j < d.c_out ? 4u * (unsigned)(d.c_woff + j * d.nl + 64 * TT + 4 * r) : GENP_OOB);
+      };
+      auto b_chunks = [&](const BD& d) -> int { return ((d.it >> 25) & 1) ? 0 : 1 + ((d.it >> 9) & 1); };
+      auto b_flush = [&](const BD& d) {      // acc[i][ii] = d h[row 4 q + ii][unit 64 T + 4 r + i] of this part
+        const int l = (d.it >> 10) & 31, TT = (d.it >> 15) & 3, p = (d.it >> 17) & 7, s = (d.it >> 20) & 15;
+        const int* row = T.LT + 8 * l;
+        const int nl = SU(row[1]), lcol = SU(row[5]), scol = SU(row[7]), k = 64 * TT + 4 * r;
+        if (SU(T.SP[s]) == 0) {      // straight into the image
+          if (k < (nl + 15) / 16 * 16) {
+#pragma unroll
+            for (int ii = 0; ii < 4; ++ii) {
+              const int rw = 4 * q + ii;
+              const f32x4 h = lds128(ACT + rw * RS + lcol + k);
+              f32x4 v;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) v[i] = k + i < nl ? fmaf(-(h[i] * h[i]), acc[i][ii], acc[i][ii]) : 0.f;
+              *reinterpret_cast<f32x4*>(DZ + rw * RS + lcol + k) = v;
+            }
+          }
+        } else {
+          const int SW = SU(T.SWD[s]);
+#pragma unroll
+          for (int ii = 0; ii < 4; ++ii)
+            *reinterpret_cast<f32x4*>(SCR + (p * 16 + 4 * q + ii) * SW + scol + k) = f32x4{acc[0][ii], acc[1][ii], acc[2][ii], acc[3][ii]};
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      };
+      int bi = 0;
+      BD d, nd;
+      d.it = -1; nd.it = -1;
+      if (bn > 0) {
+        d = b_decode(0);
+        const int nch = b_chunks(d);
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+          if (u < nch) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) X0[4 * u + e] = b_load(d, u, e);
+          }
+      }
+      for (int s = n_stages - 2; s >= 0; --s) {
+        const int P = SU(T.SP[s]), SW = SU(T.SWD[s]);
+        if (SW == 0) continue;
+        while (bi < bn && ((d.it >> 20) & 15) == s) {
+          const bool more = bi + 1 < bn;
+          int nnch = 0;
+          if (more) { nd = b_decode(bi + 1); nnch = b_chunks(nd); }
+          const int nch = b_chunks(d), j0 = 16 * ((d.it >> 5) & 15);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            if (u < nch) {
+              const f32x4 dzv = lds128(DZ + r * RS + d.c_col + j0 + 16 * u + 4 * q);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = MFMA_F32(dzv[e], X0[4 * u + e][i], acc[i]);
+            }
+            if (u < nnch) {      // (the next item's weights, into the registers this chunk has just been read from)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) X0[4 * u + e] = b_load(nd, u, e);
+            }
+          }
+          if ((d.it >> 24) & 1) b_flush(d);
+          d = nd; ++bi;
+          if (bi >= bn) d.it = -1;
+        }
+        lds_barrier();
+        if (P != 0) {      // the parts' sums: x (1 - h^2) into the image, or (a trunk under three branch workgroups) this branch's share to memory
+          for (int si = 0; si < 3; ++si) {
+            const int l = SU(T.STL[4 * s + si]);
+            if (l < 0) break;
+            const int* row = T.LT + 8 * l;
+            const int nl = SU(row[1]), lcol = SU(row[5]), role = (SU(row[6]) >> 1) & 3, scol = SU(row[7]), np4 = (nl + 15) / 16 * 4;      // quads of a padded row
+            for (int idx = tid; idx < 16 * np4; idx += GENP_TH) {
+              const int rw = idx / np4, k = 4 * (idx - rw * np4);
+              f32x4 v = lds128(SCR + rw * SW + scol + k);
+              for (int p = 1; p < P; ++p) {
+                const f32x4 x = lds128(SCR + (p * 16 + rw) * SW + scol + k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] += x[i];
+              }
+              if (role == 1) {
+                const f32x4 h = lds128(ACT + rw * RS + lcol + k);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = k + i < nl ? fmaf(-(h[i] * h[i]), v[i], v[i]) : 0.f;
+                *reinterpret_cast<f32x4*>(DZ + rw * RS + lcol + k) = v;
+              } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = k + i < nl ? v[i] : 0.f;
+                genp_st4<LOCAL>(rsXT, 4u * (unsigned)(((g * 3 + b) * 16 + rw) * pp.WTP + k), v);
+              }
+            }
+          }
+          if (NBR == 3 && trunk_last >= 0 && SU(T.STL[4 * s]) == trunk_last) {      // the three shares of d h(trunk) meet
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+              if (LOCAL) __hip_atomic_store(pp.xflag + g * 3 + b, (unsigned)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              else __hip_atomic_store(pp.xflag + g * 3 + b, (unsigned)(st + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const int* row = T.LT + 8 * trunk_last;
+            if (((SU(row[6]) >> 1) & 3) == 3) {
+              if (tid < 3)
+                while (__hip_atomic_load(pp.xflag + g * 3 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(st + 1)) __builtin_amdgcn_s_sleep(1);
+              __syncthreads();
+                          const int nl = SU(row[1]), lcol = SU(row[5]), WT = pp.WTP;
+              for (int idx = tid; idx < 4 * WT; idx += GENP_TH) {
+                const int rw = idx / (WT / 4), k = 4 * (idx - rw * (WT / 4));
+                const f32x4 x0 = genp_ld4<LOCAL>(rsXT, 4u * (unsigned)(((g * 3 + 0) * 16 + rw) * WT + k));
+                const f32x4 x1 = genp_ld4<LOCAL>(rsXT, 4u * (unsigned)(((g * 3 + 1) * 16 + rw) * WT + k));
+                const f32x4 x2 = genp_ld4<LOCAL>(rsXT, 4u * (unsigned)(((g * 3 + 2) * 16 + rw) * WT + k));
+                const f32x4 h = lds128(ACT + rw * RS + lcol + k);
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float sum = (x0[i] + x1[i]) + x2[i]; v[i] = k + i < nl ? fmaf(-(h[i] * h[i]), sum, sum) : 0.f; }
+                *reinterpret_cast<f32x4*>(DZ + rw * RS + lcol + k) = v;
+              }
+            }
+          }
+          lds_barrier();
         }
       }
-      __syncthreads();
     }
     GSTAMP(3)   // backward
     // ================= partial weight gradients of this tile's 16 rows -> part[g] =================
     float* const mypart = pp.part + (size_t)g * n;
     {
-      int item = 0;
-      for (int l = 0; l < net.n_layers; ++l) {
-        const GenLayer& y = net.layer[l];
-        const int in_off = y.in_buf < 0 ? 0 : pp.poff[y.in_buf];
-        for (int jt = 0; jt < (y.out_dim + 15) / 16; ++jt, ++item) {
-          if ((item & 7) != w) continue;
-          float az[4];      // dz[row 4 q + e][unit 16 jt + r]
+      int base = 0;
+      for (int wi = 0; wi < GEN_MAX_LAYERS; ++wi) {
+        const int l = SU(T.WL[wi]);
+        if (l < 0) break;
+        const int* row = T.LT + 8 * l;
+        const int in_dim = SU(row[0]), out_dim = SU(row[1]), w_off = SU(row[2]), b_off = SU(row[3]), in_col = SU(row[4]), out_col = SU(row[5]);
+        const int nkg = (in_dim + 63) / 64, cnt = (out_dim + 15) / 16 * nkg;
+        for (int idx = (w - base) & 7; idx < cnt; idx += 8) {
+          const int jt = idx / nkg, kg = idx - jt * nkg;
+          float az[4];      // d z[row 4 e + q][unit 16 jt + r]
 #pragma unroll
-          for (int e = 0; e < 4; ++e) az[e] = DZ[(4 * q + e) * RS + pp.poff[l] + 16 * jt + r];
-          unsigned jrow[4];
+          for (int e = 0; e < 4; ++e) az[e] = DZ[(4 * e + q) * RS + out_col + 16 * jt + r];
+          f32x4 acc[4];     // acc[u][i] = d W[unit 16 jt + r][input 16 (4 kg + u) + 4 q + i]
 #pragma unroll
-          for (int i = 0; i < 4; ++i) { const int j = 16 * jt + 4 * q + i; jrow[i] = j < y.out_dim ? 4u * (unsigned)(g * n + y.w_off + j * y.in_dim) : GENP_OOB / 2; }
-          for (int kt = 0; kt < (y.in_dim + 15) / 16; ++kt) {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int u = 0; u < 4; ++u) {
+            acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (16 * (4 * kg + u) < in_dim) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc = MFMA_F32(az[e], ACT[(4 * q + e) * RS + in_off + 16 * kt + r], acc);
-            // (an element outside the layer: row or column offset outside the resource — two halves of GENP_OOB, so that one or both
-            // of them push the sum out of range without wrapping — and the store is dropped; no branch in the store stream)
-            const unsigned koff = 16 * kt + r < y.in_dim ? 4u * (unsigned)(16 * kt + r) : GENP_OOB / 2;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const unsigned off = jrow[i] + koff;
-              if (LOCAL) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i]), rsPart, (int)off, 0, 1);
-              else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i]), rsPart, (int)off, 0, 16);
+              for (int e = 0; e < 4; ++e) acc[u] = MFMA_F32(ACT[(4 * e + q) * RS + in_col + 16 * (4 * kg + u) + r], az[e], acc[u]);
             }
           }
-          // bias: the sum over the 16 rows (lanes r = unit, q = row group): rows 4 q .. 4 q + 3, then over q
-          const float sb = quad_rows_sum((az[0] + az[1]) + (az[2] + az[3]));
-          if (q == 0 && 16 * jt + r < y.out_dim) st_x<LOCAL>(mypart + y.b_off + 16 * jt + r, sb);
+          // (an element outside the layer: row or column offset outside the resource — two halves of GENP_OOB, so that one or both
+          // of them push the sum out of range without wrapping — and the store is dropped; no branch in the store stream)
+          const int j = 16 * jt + r;
+          const unsigned jrow = j < out_dim ? 4u * (unsigned)(g * n + w_off + j * in_dim) : GENP_OOB / 2;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int kt = 4 * kg + u, k = 16 * kt + 4 * q;
+            if (16 * kt < in_dim) {
+              if ((in_dim & 3) == 0 || 16 * kt + 16 <= in_dim) genp_st4<LOCAL>(rsPart, jrow + (k < in_dim ? 4u * (unsigned)k : GENP_OOB / 2), acc[u]);
+              else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) genp_st1<LOCAL>(rsPart, jrow + (k + i < in_dim ? 4u * (unsigned)(k + i) : GENP_OOB / 2), acc[u][i]);
+              }
+            }
+          }
+          if (kg == 0) {      // bias: the sum over the 16 rows (lanes r = unit, q, e = row 4 e + q)
+            const float sb = quad_rows_sum((az[0] + az[1]) + (az[2] + az[3]));
+            if (q == 0 && j < out_dim) st_x<LOCAL>(mypart + b_off + j, sb);
+          }
         }
+        base += cnt;
       }
-      if (!net.discrete && tid < A) {
+      if (!discrete && role0 && tid < A) {
         float sl = 0.f;
         for (int rr = 0; rr < 16; ++rr) sl += G2[rr * 16 + tid];
         st_x<LOCAL>(mypart + net.log_std + tid, sl);
       }
-      if (tid < 8) {      // this tile's loss sums: policy terms 0..4, reward / cost value errors 5, 6
+      if (tid < 7 && ((role_mask >> (tid < 5 ? 0 : tid - 4)) & 1)) {      // this tile's loss sums: policy terms 0..4, reward / cost value errors 5, 6
         float v = 0.f;
         if (tid < 5) for (int rr = 0; rr < 16; ++rr) v += RST[rr * 8 + tid];
-        else if (tid < 7) for (int rr = 0; rr < 16; ++rr) v += RST[((tid - 4) * 16 + rr) * 8];
+        else for (int rr = 0; rr < 16; ++rr) v += RST[((tid - 4) * 16 + rr) * 8];
         st_x<LOCAL>(pp.stat + g * 8 + tid, v);
       }
     }
     }      // tile_wg
     GSTAMP(4)   // weight gradients
-    bar_n += H; genp_grid_barrier<LOCAL>(pp.bar, bar_n);           // (A) every tile's partials are in memory
+    bar_n += H; genp_arrive<LOCAL>(pp.bar);
+    if (tile_wg) rows_issue1(pn);      // (the next minibatch's rows, under the barriers: first round trip — the row offsets)
+    genp_wait(pp.bar, bar_n);          // (A) every tile's partials are in memory
     GSTAMP(5)   // barrier A
     // ================= this workgroup's parameter slice: sum over the tiles in tile order, squared norm =================
     float ss = 0.f;
@@ -828,10 +1196,7 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
       for (int t = 0; t < G; t += 4) {
         f32x4 pv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const unsigned off = t + u < G ? 4u * (unsigned)((t + u) * n + e0) : GENP_OOB;
-          pv[u] = __builtin_bit_cast(f32x4, LOCAL ? __builtin_amdgcn_raw_buffer_load_b128(rsPart, (int)off, 0, 1) : __builtin_amdgcn_raw_buffer_load_b128(rsPart, (int)off, 0, 16));
-        }
+        for (int u = 0; u < 4; ++u) pv[u] = genp_ld4<LOCAL>(rsPart, t + u < G ? 4u * (unsigned)((t + u) * n + e0) : GENP_OOB);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
@@ -841,42 +1206,43 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
       for (int i = 0; i < 4; ++i) {
         const int e = e0 + i;
         if (e < hi) {
-          if (!net.discrete && e >= net.log_std && e < net.log_std + A) gs[i] += -a.hp.ent_coef;      // d(ent_coef * -mean H) / d log_std
+          if (!discrete && e >= net.log_std && e < net.log_std + A) gs[i] += -a.hp.ent_coef;      // d(ent_coef * -mean H) / d log_std
           pp.grad[e] = gs[i];
           ss = fmaf(gs[i], gs[i], ss);
         }
       }
     }
     ss = genp_block_sum(ss, RED);
-    if (tid == 0) st_x<LOCAL>(pp.norm + g, ss);
+    if (tid == 0) st_x<LOCAL>(pp.norm + wg, ss);
     GSTAMP(6)   // reduce + norm
-    bar_n += H; genp_grid_barrier<LOCAL>(pp.bar, bar_n);           // (B) every slice's squared norm is in memory
+    bar_n += H; genp_arrive<LOCAL>(pp.bar);
+    if (tile_wg) rows_issue2(pn);      // (second round trip: what the offsets address)
+    genp_wait(pp.bar, bar_n);          // (B) every slice's squared norm is in memory
     GSTAMP(7)   // barrier B
     float total = 0.f, q7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    {   // every tile's loss sums and every slice's squared norm: fetched side by side (one value per thread; a chain of relaxed atomic
-        // loads, or a loop of dependent buffer loads, is one L2 round trip per value: 26 k cycles at 32 tiles), summed in tile order from LDS
+    {   // every tile's loss sums and every slice's squared norm fetched side by side (one value per thread), summed by fixed trees
       const __amdgpu_buffer_rsrc_t rsX = genp_rsrc(pp.stat, 512);      // [stat G x 8 | norm H]
-      __syncthreads();
-      if (tid < 8 * G) RST[tid] = genp_ld<LOCAL>(rsX, 4u * (unsigned)tid);
-      else if (tid >= 256 && tid < 256 + H) RST[tid] = genp_ld<LOCAL>(rsX, 4u * (unsigned)tid);
-      __syncthreads();
-      for (int t = 0; t < H; ++t) total += RST[256 + t];
-      for (int t = 0; t < G; ++t) {
-#pragma unroll
-        for (int k = 0; k < 7; ++k) q7[k] += RST[t * 8 + k];
-      }
-    }
-    const float cc = a.hp.max_grad_norm / (sqrtf(total) + 1e-6f), coef = cc > 1.f ? 1.f : cc;
-    {
+      float sv = 0.f;
+      if (tid < 8 * G || (tid >= 256 && tid < 256 + H)) sv = genp_ld<LOCAL>(rsX, 4u * (unsigned)tid);
+      // Adam's operands of the slice travel with them
       const float b1 = a.hp.adam_beta1, b2 = a.hp.adam_beta2, w1 = (float)(1.0 - (double)b1), w2 = (float)(1.0 - (double)b2);
-      for (int e0 = lo + 4 * tid; e0 < hi; e0 += 4 * GENP_TH) {
-        float gv[4], mv[4], vv[4], pw[4];
-        int ti[4];
+      const int e0 = lo + 4 * tid;
+      float gv[4], mv[4], vv[4];
+      f32x4 pw = f32x4{0.f, 0.f, 0.f, 0.f};
+      const bool mine = e0 < hi;
+      if (mine) {
+        pw = genp_ld4<LOCAL>(rsP, 4u * (unsigned)e0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int ec = e0 + u < hi ? e0 + u : lo;
-          gv[u] = pp.grad[ec]; mv[u] = a.exp_avg[ec]; vv[u] = a.exp_avg_sq[ec]; pw[u] = genp_ld<LOCAL>(rsP, 4u * (unsigned)ec); ti[u] = pp.tidx[ec];
-        }
+        for (int u = 0; u < 4; ++u) { const int ec = e0 + u < hi ? e0 + u : lo; gv[u] = pp.grad[ec]; mv[u] = a.exp_avg[ec]; vv[u] = a.exp_avg_sq[ec]; }
+      }
+      lds_barrier();
+      RST[tid] = sv;
+      lds_barrier();
+      total = wave_sum_fast(lane < H ? RST[256 + lane] : 0.f);
+#pragma unroll
+      for (int k = 0; k < 7; ++k) q7[k] = wave_sum_fast(lane < G ? RST[lane * 8 + k] : 0.f);
+      const float cc = a.hp.max_grad_norm / (sqrtf(total) + 1e-6f), coef = cc > 1.f ? 1.f : cc;
+      if (mine) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int e = e0 + u;
@@ -885,9 +1251,20 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
             const float m = fmaf(w1, gc, b1 * mv[u]);
             const float v = fmaf(w2, gc * gc, b2 * vv[u]);
             a.exp_avg[e] = m; a.exp_avg_sq[e] = v;
-            const float nw = fmaf(-ps.step_size, m / fmaf(sqrtf(v), ps.inv_bc2_sqrt, a.hp.adam_eps), pw[u]);
-            st_x<LOCAL>(a.params + e, nw);
-            st_x<LOCAL>(a.params_t + ti[u], nw);
+            st_x<LOCAL>(a.params + e, fmaf(-ps.step_size, m / fmaf(sqrtf(v), ps.inv_bc2_sqrt, a.hp.adam_eps), pw[u]));
+          }
+        }
+      }
+      for (int e1 = e0 + 4 * GENP_TH; e1 < hi; e1 += 4 * GENP_TH) {      // (slices above 2 048 parameters: the rest)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = e1 + u;
+          if (e < hi) {
+            const float gc = pp.grad[e] * coef;
+            const float m = fmaf(w1, gc, b1 * a.exp_avg[e]);
+            const float v = fmaf(w2, gc * gc, b2 * a.exp_avg_sq[e]);
+            a.exp_avg[e] = m; a.exp_avg_sq[e] = v;
+            st_x<LOCAL>(a.params + e, fmaf(-ps.step_size, m / fmaf(sqrtf(v), ps.inv_bc2_sqrt, a.hp.adam_eps), genp_ld<LOCAL>(rsP, 4u * (unsigned)e)));
           }
         }
       }
@@ -903,18 +1280,20 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
       ++steps_done;
       if (last_mb) {
         mean_kl = kl_acc / (float)a.n_mb;
-        if (g == 0 && tid == 0) a.stats[32 + epoch] = mean_kl;
+        if (wg == 0 && tid == 0) a.stats[32 + epoch] = mean_kl;
         if (a.hp.use_target_kl && mean_kl > 1.5f * a.hp.target_kl) { stop = true; early_stop_epoch = epoch; }
       }
     }
     GSTAMP(8)   // Adam + logged sums
-    bar_n += H; genp_grid_barrier<LOCAL>(pp.bar, bar_n);           // (C) the updated parameters are in memory
+    bar_n += H; genp_arrive<LOCAL>(pp.bar);
+    if (tile_wg) rows_commit(pn);      // (into the image)
+    genp_wait(pp.bar, bar_n);          // (C) the updated parameters are in memory
     GSTAMP(9)   // barrier C
   }
-  if (prof && tid == 0) a.stats[22] = local ? 1.f : 0.f;
+  if (prof && tid == 0) a.stats[22] = LOCAL ? 1.f : 0.f;
   if (prof && tid == 0)
     for (int k = 0; k < 10; ++k) a.stats[12 + k] = (float)((double)ph[k] / (double)(steps_done > 0 ? steps_done : 1));
-  if (g == 0 && tid == 0) {
+  if (wg == 0 && tid == 0) {
     a.stats[0] = (float)early_stop_epoch;
     a.stats[1] = (float)steps_done;
     a.stats[2] = acc_ent; a.stats[3] = acc_pg; a.stats[4] = acc_vr; a.stats[5] = acc_vc; a.stats[6] = acc_cf;
@@ -925,23 +1304,23 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
 
 __global__ void __launch_bounds__(GENP_TH) gen_train_persistent_kernel(GenNet net, GenArgs a, GenPersist pp, int packed) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  // packed: a 1-D grid of 8 (G - 1) + 1 workgroups of which every eighth works — workgroups are dealt round-robin over the 8 XCDs, so
-  // the G working ones land on ONE (ppo_common.h: XCD placement); the others leave at once
+  // packed: a 1-D grid of 8 (H - 1) + 1 workgroups of which every eighth works — workgroups are dealt round-robin over the 8 XCDs, so
+  // the H working ones land on ONE (ppo_common.h: XCD placement); the others leave at once
   if (packed && (blockIdx.x & (XCD_STRIDE - 1)) != 0) return;
-  const int H = pp.H, g = packed ? (int)blockIdx.x / XCD_STRIDE : (int)blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < 32 * pp.RS + 256 + 384 + 32; i += GENP_TH) sm[i] = 0.f;
-  for (int e = g * pp.slice + tid; e < g * pp.slice + pp.slice && e < net.n; e += GENP_TH) pp.tidx[e] = gen_transposed_index(net, e);      // (read back by the same thread)
+  const int H = pp.H, wg = packed ? (int)blockIdx.x / XCD_STRIDE : (int)blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < 32 * pp.RS + GENP_FLOATS; i += GENP_TH) sm[i] = 0.f;
+  if (tid < 3 && wg < pp.G) pp.xflag[wg * 3 + tid] = 0u;
   __syncthreads();
   // do all workgroups share an XCD?  (every workgroup publishes its XCC id in its norm slot, one barrier, everybody compares)
   unsigned bar_n = 0;
-  if (tid == 0) __hip_atomic_store(pp.norm + g, __uint_as_float(0x100u | xcc_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(pp.norm + wg, __uint_as_float(0x100u | xcc_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bar_n += H; genp_grid_barrier<false>(pp.bar, bar_n);
   bool local = true;
   for (int t = 0; t < H; ++t) local = local && __float_as_uint(ld_sc1(pp.norm + t)) == (0x100u | xcc_id());
   local = __builtin_amdgcn_readfirstlane((int)local) != 0;
   bar_n += H; genp_grid_barrier<false>(pp.bar, bar_n);      // (the slots are reused by the first step's norms)
-  if (local) genp_body<true>(net, a, pp, g, sm, bar_n);
-  else genp_body<false>(net, a, pp, g, sm, bar_n);
+  if (local) genp_body<true>(net, a, pp, wg, sm, bar_n);
+  else genp_body<false>(net, a, pp, wg, sm, bar_n);
 }
 
 static_assert(ICRL_PPO_GENERIC_BYTES(64, 776, 1000) == 4 * (64 + 64 * (24 + 1 + 16 + 2 * 776) + 1000 + 4 + 1088 + 5 * 1000 + 1024), "ICRL_PPO_GENERIC_BYTES");
@@ -953,40 +1332,49 @@ __global__ void ppo_plan_kernel(const int* adam_t, int n_steps, int n_mb, int n_
 
 // the persistent form, when the shape allows it: 0 launched | < 0 not eligible (the caller uses the launch-per-phase form) | > 0 error
 static int launch_train_generic_persistent(const GenNet& net, GenArgs& a, const icrl_ppo_hyper_t* hp, int32_t* adam_step, void* sync_ws, hipStream_t s) {
-  // WHERE IT IS THE DEFAULT IS MEASURED (round 5, MI355X, tools/generic_only.py): a 64-row minibatch is FOUR row tiles, i.e. four compute
-  // units walking every stage of the network one after the other (three 16 x 16 tiles per wave and stage, each a 32-MFMA chain behind an
-  // L2 round trip), where the launch-per-phase form spreads the same rows over 64 compute units: -pl 128 128 -rvl 128 128 -cvl 128 128 at
-  // batch 64: 56 us per optimiser step against 45 (per step of workgroup 0, cycles: rows + statistics 4.9 k | forward 29.2 k | loss 6.0 k |
-  // backward 24.6 k | weight gradients 36.4 k | barrier 2.0 k | reduce 2.6 k | barrier 2.7 k | Adam + logged sums 13.5 k | barrier 8.4 k);
-  // with 32 row tiles (default widths, batch 512) the same phases take 15.2 | 11.6 | 17.3 k and the step 48 us against 64.  So: the default
-  // from GENP_MIN_TILES row tiles on; ICRL_GEN_PERSISTENT=1 / ICRL_GEN_LAUNCHES=1 force one form (tests run both).
   static const bool on = getenv("ICRL_GEN_PERSISTENT") != nullptr, off = getenv("ICRL_GEN_LAUNCHES") != nullptr;
+  static const char* nbr_env = getenv("ICRL_GEN_BRANCH_WGS");      // A/B: "1" keeps one workgroup per row tile
   const int B = hp->batch_size, G = (B + 15) / 16, n = net.n;
-  if (off || (!on && G < GENP_MIN_TILES) || G > GENP_MAX_TILES || n > GENP_MAX_PARAMS || B > NB_MASK) return -1;
+  if (off || G > GENP_MAX_TILES || n > GENP_MAX_PARAMS || B > NB_MASK) return -1;
+  (void)on;
   GenPersist pp;
   pp.OB = (net.O + 15) / 16 * 16;
+  const long long n_steps = (long long)hp->n_epochs * a.n_mb;
+  if (n_steps >= (1ll << 21)) return -1;
+  // three workgroups per row tile (one per branch) while they fit one XCD; a trunk then needs room for the exchanged shares of its gradient
+  pp.WTP = net.n_shared > 0 ? (net.layer[net.n_shared - 1].out_dim + 15) / 16 * 16 : 0;
+  pp.NBR = (3 * G <= GENP_MAX_WGS && !(nbr_env && nbr_env[0] == '1') && (size_t)G * 48 * pp.WTP <= (size_t)n) ? 3 : 1;
+  {   // the trunk's owner: the branch with the fewest parameters of its own
+    int cnt[3] = {0, 0, 0};
+    for (int l = net.n_shared; l < net.n_layers; ++l) cnt[net.layer[l].slot] += net.layer[l].in_dim * net.layer[l].out_dim;
+    pp.owner = cnt[1] <= cnt[0] && cnt[1] <= cnt[2] ? 1 : (cnt[2] <= cnt[0] ? 2 : 0);
+  }
   int off_ = pp.OB;
   for (int l = 0; l < net.n_layers; ++l) { pp.poff[l] = off_; off_ += (net.layer[l].out_dim + 15) / 16 * 16; }
   pp.RS = off_ + ((8 - off_ % 32) + 32) % 32;      // = 8 mod 32: conflict-free ds_read_b128 of a row image
   if (pp.RS > GENP_MAX_RS) return -1;
-  const long long n_steps = (long long)hp->n_epochs * a.n_mb;
-  if (n_steps >= (1ll << 21)) return -1;
-  // helpers for the reduce / Adam phases: ~2048 parameters per workgroup, all workgroups on one XCD when that fits (<= its CUs)
+  {   // do the work lists fit?
+    int ibuf[GENP_INTS];
+    const GenpTables T = genp_tables(ibuf);
+    for (int b = 0; b < pp.NBR; ++b)
+      if (!genp_build(net, pp.poff, pp.NBR, b, pp.owner, T)) return -1;
+  }
+  // helpers for the reduce / Adam phases: ~2048 parameters per workgroup, all workgroups on one XCD (<= its CUs)
   int H = (n + 2047) / 2048;
-  H = H < G ? G : (H > 30 ? (G > 30 ? G : 30) : H);
+  const int tiles = G * pp.NBR;
+  H = H < tiles ? tiles : (H > GENP_MAX_WGS ? (tiles > GENP_MAX_WGS ? tiles : GENP_MAX_WGS) : H);
   pp.G = G; pp.H = H; pp.slice = ((n + H - 1) / H + 3) / 4 * 4;
   PlanStep* steps = reinterpret_cast<PlanStep*>((char*)sync_ws + 512);
   hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, a.n_mb, a.n_total, B,
                      (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, (PlanChunk*)nullptr, 0);
   pp.plan = steps; pp.n_steps = (int)n_steps;
-  float* extra = a.scratch + gen_floats(B, net.row_floats, n);      // behind the launch-per-phase layout: [stat G x 8 | norm G | part G x n]
-  pp.stat = extra; pp.norm = extra + 256; pp.tidx = reinterpret_cast<int*>(extra + 512); pp.part = extra + 512 + n;
+  float* extra = a.scratch + gen_floats(B, net.row_floats, n);      // behind the launch-per-phase layout: [stat 256 | norm 256 | flags 512 | trunk shares n | part G x n]
+  pp.stat = extra; pp.norm = extra + 256; pp.xflag = reinterpret_cast<unsigned*>(extra + 512); pp.xt = extra + 1024; pp.part = extra + 1024 + n;
   pp.grad = a.scratch + gen_off_grad(B, net.row_floats);
   pp.bar = reinterpret_cast<unsigned*>(a.scratch + 60);           // (the first 64 floats are zeroed by the caller)
-  const size_t lds = (size_t)(32 * pp.RS + 256 + 384 + 32) * sizeof(float);
+  const size_t lds = (size_t)(32 * pp.RS + GENP_FLOATS) * sizeof(float);
   hipError_t e = hipFuncSetAttribute((const void*)gen_train_persistent_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(gen_transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, s, net, a.params, a.params_t);
   GenNet net_ = net; GenArgs a_ = a;
   static const bool nopack = getenv("ICRL_NO_XCD_PACK") != nullptr;
   int packed = nopack ? 0 : 1;
@@ -997,7 +1385,9 @@ static int launch_train_generic_persistent(const GenNet& net, GenArgs& a, const 
     packed = 0;
     e = hipLaunchCooperativeKernel((const void*)gen_train_persistent_kernel, dim3(H), dim3(GENP_TH), params, (unsigned)lds, s);
   }
-  return (int)e;
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(gen_transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, s, net, a.params, a.params_t);      // the forward / sampling kernels read params_t
+  return (int)hipGetLastError();
 }
 
 // perm_off: the permutations already mapped to storage offsets (prepare in ppo_train.hip); scratch: ICRL_PPO_GENERIC_BYTES

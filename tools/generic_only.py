@@ -7,7 +7,8 @@ from icrl_amd.vec_env import HipSynthVecEnv, VecCostWrapper, VecNormalizeWithCos
 from icrl_amd.constraint_net import ConstraintNet
 for name, kw, B in (("-pl 128 128 -rvl 128 128 -cvl 128 128, batch 64", dict(policy_kwargs=dict(net_arch=[dict(pi=[128, 128], vf=[128, 128], cvf=[128, 128])])), 64),
                     ("default widths, batch 256", {}, 256), ("default widths, batch 512", {}, 512),
-                    ("-pl 128 128 -rvl 128 128 -cvl 128 128, batch 512", dict(policy_kwargs=dict(net_arch=[dict(pi=[128, 128], vf=[128, 128], cvf=[128, 128])])), 512)):
+                    ("-pl 128 128 -rvl 128 128 -cvl 128 128, batch 512", dict(policy_kwargs=dict(net_arch=[dict(pi=[128, 128], vf=[128, 128], cvf=[128, 128])])), 512),
+                    ("-sl 64 -pl 128 128 -rvl 64 -cvl 64 64 64, batch 64", dict(policy_kwargs=dict(net_arch=[64, dict(pi=[128, 128], vf=[64], cvf=[64, 64, 64])])), 64))[slice(*[int(x) for x in os.environ.get("ONLY", "0,5").split(",")])]:
     N, T = 64, 256
     env = VecNormalizeWithCost(VecCostWrapper(HipSynthVecEnv(N, "hc", 0)))
     lo = -np.ones(6, np.float32)
