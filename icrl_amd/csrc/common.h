@@ -191,6 +191,13 @@ __device__ __forceinline__ float row_sum(float v) {     // sum over the 16 lanes
   v += ICRL_DPP_F32(v, 0x140);   // row_mirror
   return v;
 }
+__device__ __forceinline__ float row_max(float v) {     // max over the 16 lanes of the lane's row, in every lane
+  v = fmaxf(v, ICRL_DPP_F32(v, 0xB1));
+  v = fmaxf(v, ICRL_DPP_F32(v, 0x4E));
+  v = fmaxf(v, ICRL_DPP_F32(v, 0x141));
+  v = fmaxf(v, ICRL_DPP_F32(v, 0x140));
+  return v;
+}
 __device__ __forceinline__ float quad_rows_sum(float v) { return xor16_sum(xor32_sum(v)); }   // over the 4 lanes lane % 16
 __device__ __forceinline__ float wave_sum_fast(float v) { return row_sum(quad_rows_sum(v)); }
 

@@ -527,7 +527,7 @@ constexpr int GENP_MAX_WGS = 30;
 // ints of the tables: rows [16] | next rows [16] | FLN [8] | BLN [8] | SP [16] | SWD [16] | STL [16][4] | WL [32] | misc [16] | LT [32][8] | FL | BL
 constexpr int GENP_I_FLN = 32, GENP_I_BLN = 40, GENP_I_SP = 48, GENP_I_SWD = 64, GENP_I_STL = 80, GENP_I_WL = 144, GENP_I_MISC = 176, GENP_I_LT = 192,
               GENP_I_FL = GENP_I_LT + 256, GENP_I_BL = GENP_I_FL + 8 * GENP_FLIST, GENP_INTS = GENP_I_BL + 8 * GENP_BLIST;
-constexpr int GENP_FLOATS = GENP_SCR + 256 + 512 + 32 + 16 * GENP_REC + 16 + 16 + GENP_INTS;      // LDS beyond the two row images
+constexpr int GENP_FLOATS = GENP_SCR + 256 + 512 + 32 + 16 * GENP_REC + 16 + 16 + GENP_INTS + 32;      // LDS beyond the two row images (the last 32: phase timers)
 static_assert((32 * GENP_MAX_RS + GENP_FLOATS) * 4 <= 160 * 1024, "LDS of the persistent generic-shape update");
 
 struct GenPersist {
@@ -756,8 +756,16 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
   const float nu = a.nu[0];
   bool stop = false;
   const bool prof = (a.hp._pad & 1) != 0 && wg == 0;       // phase timers of workgroup 0, thread 0 (tools/generic_only.py PROF=1): stats[12..21]
-  unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = prof ? stamp() : 0ull;
-#define GSTAMP(k) if (prof) { const unsigned long long now_ = stamp(); ph[k] += now_ - t_last; t_last = now_; }
+  unsigned long long* const PH = reinterpret_cast<unsigned long long*>(IW + GENP_INTS);      // [16] cycles per phase (in LDS: 34 scalar registers otherwise); 10..15: parts of the phases before them (stats[23..28])
+  unsigned long long t_last = prof ? stamp() : 0ull;
+#ifdef GENP_X_STAGES
+#define GSUB(k)
+#define GSTAGE(k) GSTAMP(k)
+#else
+#define GSUB(k) GSTAMP(k)
+#define GSTAGE(k)
+#endif
+#define GSTAMP(k) if (prof) { const unsigned long long now_ = stamp(); if (tid == 0) PH[k] += now_ - t_last; t_last = now_; }
 
   // ---- the rows of a minibatch: fetched in two round trips (row offsets, then what they address) into registers, committed to LDS later
   int nx_idx = -1, nx_ridx = 0;
@@ -769,34 +777,31 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
     if (role0 && tid < nbn) nx_idx = a.perm_off[pn.perm_base + tid];
     if (tid < 16) nx_ridx = a.perm_off[pn.perm_base + (16 * g + tid < nbn ? 16 * g + tid : 0)];
   };
-  auto rows_issue2 = [&](const PlanStep& pn) {
-    const int nbn = pn.nb_flags & NB_MASK;
-    if (nbn == 0) return;
+  // (the loads of the second trip are UNCONDITIONAL — a lane with nothing to fetch re-reads element 0 — so that their number is static and
+  // the compiler can wait for the loads issued before them with vmcnt(7) instead of vmcnt(0))
+  auto rows_issue2 = [&]() {
     if (tid < 16) RIDXN[tid] = nx_ridx;
     lds_barrier();
-    nx_ar = 0.f; nx_ac = 0.f;
-    if (nx_idx >= 0) { nx_ar = a.buf.reward_advantages[nx_idx]; nx_ac = a.buf.cost_advantages[nx_idx]; }
+    const int ia = nx_idx >= 0 ? nx_idx : 0;
+    nx_ar = a.buf.reward_advantages[ia]; nx_ac = a.buf.cost_advantages[ia];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int e = tid + GENP_TH * u;
-      nx_obs[u] = 0.f;
-      if (e < 16 * OB) {
-        const int rr = e / OB, k = e - rr * OB;
-        if (k < O) nx_obs[u] = a.buf.observations[(size_t)RIDXN[rr] * O + k];
-      }
+      const int e = tid + GENP_TH * u, ec = e < 16 * OB ? e : 0;
+      const int rr = ec / OB, k = ec - rr * OB;
+      nx_obs[u] = a.buf.observations[(size_t)RIDXN[rr] * O + (k < O ? k : 0)];
     }
-    if (tid < 16 * GENP_REC) {
-      const int rr = tid / GENP_REC, f = tid - rr * GENP_REC, idx = RIDXN[rr];
-      float v = 0.f;
-      if (f < 16) { if (f < a.buf.act_store) v = a.buf.actions[(size_t)idx * a.buf.act_store + f]; }
-      else if (f == 16) v = a.buf.log_probs[idx];
-      else if (f == 17) v = a.buf.reward_advantages[idx];
-      else if (f == 18) v = a.buf.cost_advantages[idx];
-      else if (f == 19) v = a.buf.reward_returns[idx];
-      else if (f == 20) v = a.buf.cost_returns[idx];
-      else if (f == 21) v = a.buf.reward_values[idx];
-      else if (f == 22) v = a.buf.cost_values[idx];
-      nx_rec = v;
+    {
+      const int tc = tid < 16 * GENP_REC ? tid : 0;
+      const int rr = tc / GENP_REC, f = tc - rr * GENP_REC, idx = RIDXN[rr];
+      const float* ptr = a.buf.actions + (size_t)idx * a.buf.act_store + (f < a.buf.act_store ? f : 0);
+      if (f == 16) ptr = a.buf.log_probs + idx;
+      if (f == 17) ptr = a.buf.reward_advantages + idx;
+      if (f == 18) ptr = a.buf.cost_advantages + idx;
+      if (f == 19) ptr = a.buf.reward_returns + idx;
+      if (f == 20) ptr = a.buf.cost_returns + idx;
+      if (f == 21) ptr = a.buf.reward_values + idx;
+      if (f == 22) ptr = a.buf.cost_values + idx;
+      nx_rec = *ptr;
     }
   };
   auto rows_commit = [&](const PlanStep& pn) {
@@ -805,22 +810,25 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + GENP_TH * u;
-      if (e < 16 * OB) { const int rr = e / OB, k = e - rr * OB; ACT[rr * RS + k] = nx_obs[u]; }
+      if (e < 16 * OB) { const int rr = e / OB, k = e - rr * OB; ACT[rr * RS + k] = k < O ? nx_obs[u] : 0.f; }
     }
     for (int e = tid + 4 * GENP_TH; e < 16 * OB; e += GENP_TH) {      // (observations wider than 128: the rest, not prefetched)
       const int rr = e / OB, k = e - rr * OB;
       ACT[rr * RS + k] = k < O ? a.buf.observations[(size_t)RIDXN[rr] * O + k] : 0.f;
     }
-    if (tid < 16 * GENP_REC) REC[tid] = nx_rec;
+    if (tid < 16 * GENP_REC) {
+      const int f = tid % GENP_REC;
+      REC[tid] = (f < a.buf.act_store || (f >= 16 && f < 23)) ? nx_rec : 0.f;
+    }
     if (tid < 16) RIDX[tid] = RIDXN[tid];
-    float sr = nx_ar, sc = nx_ac, srr = nx_ar * nx_ar;
+    float sr = nx_idx >= 0 ? nx_ar : 0.f, sc = nx_idx >= 0 ? nx_ac : 0.f, srr = sr * sr;
     genp_block_sum3(sr, sc, srr, RED);
     if (tid == 0) { ADV[0] = sr; ADV[1] = sc; ADV[2] = srr; }
     lds_barrier();
   };
   if (tile_wg) {
     const PlanStep p0 = pp.plan[0];
-    rows_issue1(p0); rows_issue2(p0); rows_commit(p0);
+    rows_issue1(p0); rows_issue2(); rows_commit(p0);
   }
 
   for (int st = 0; st < pp.n_steps && !stop; ++st) {
@@ -851,38 +859,42 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
       // ONE register image of a tile's weights: chunk c of the NEXT item is loaded into X[c] right after this item's MFMAs have read
       // it — every load is issued about one item ahead of its use, also across the stage barriers (the weights do not change inside a step)
       f32x4 Bv = f32x4{0.f, 0.f, 0.f, 0.f}, acc = Bv;
+      // (every load of the loop is UNCONDITIONAL — an absent chunk reads at an offset outside the resource — so that the number of loads
+      // in flight is the same on every path and the compiler waits with vmcnt(8) instead of vmcnt(0): a load under a branch made it
+      // wait for the prefetch it had just issued, a full L2 round trip per chunk)
       auto f_row = [&](const FD& d) -> unsigned {      // byte offset of this lane's 4 weights of chunk 0
         const int t = (d.it >> 5) & 15, kb = (d.it >> 9) & 7, m = 16 * t + r;
-        return m < d.out_dim ? 4u * (unsigned)(d.w_off + m * d.in_dim + 128 * kb + 4 * q) : GENP_OOB;
+        return (d.it >= 0 && m < d.out_dim) ? 4u * (unsigned)(d.w_off + m * d.in_dim + 128 * kb + 4 * q) : GENP_OOB;
       };
-      auto f_bias = [&](const FD& d) -> f32x4 {
+      auto f_bias = [&](const FD& d) -> f32x4 {      // (only the first K slab of a tile starts from the bias)
         const int t = (d.it >> 5) & 15;
-        return genp_ld4<LOCAL>(rsP, 16 * t + 4 * q < d.out_dim ? 4u * (unsigned)(d.b_off + 16 * t + 4 * q) : GENP_OOB);
+        return genp_ld4<LOCAL>(rsP, (d.it >= 0 && ((d.it >> 9) & 7) == 0 && 16 * t + 4 * q < d.out_dim) ? 4u * (unsigned)(d.b_off + 16 * t + 4 * q) : GENP_OOB);
       };
       int fi = 0;
       FD d, nd;
-      d.it = -1; nd.it = -1;
-      if (fn > 0) {
-        d = f_decode(0);
+      d.it = -1; d.in_dim = 0; d.out_dim = 0; d.w_off = 0; d.b_off = 0; d.in_col = 0; d.out_col = 0; d.tanh = 0;
+      nd = d;
+      if (fn > 0) d = f_decode(0);
+      {
         const unsigned base = f_row(d);
-        const int kk = d.in_dim - 128 * ((d.it >> 9) & 7);
+        const int kk = d.it >= 0 ? d.in_dim - 128 * ((d.it >> 9) & 7) : 0;
+        Bv = f_bias(d);
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (16 * c < kk) X0[c] = genp_ld4<LOCAL>(rsP, base + 64u * (unsigned)c);
-        if (((d.it >> 9) & 7) == 0) Bv = f_bias(d);
+        for (int c = 0; c < 8; ++c) X0[c] = genp_ld4<LOCAL>(rsP, 16 * c < kk ? base + 64u * (unsigned)c : GENP_OOB);
       }
       for (int s = 0; s < n_stages; ++s) {
         while (fi < fn && (d.it >> 13) == s) {
           const bool more = fi + 1 < fn;
-          unsigned nbase = GENP_OOB;
-          int nkk = 0;
-          if (more) { nd = f_decode(fi + 1); nbase = f_row(nd); nkk = nd.in_dim - 128 * ((nd.it >> 9) & 7); }
+          nd.it = -1;
+          if (more) nd = f_decode(fi + 1);
+          const unsigned nbase = f_row(nd);
+          const int nkk = more ? nd.in_dim - 128 * ((nd.it >> 9) & 7) : 0;
           const int t = (d.it >> 5) & 15, kb = (d.it >> 9) & 7, lastk = (d.it >> 12) & 1, kk = d.in_dim - 128 * kb;
           if (kb == 0) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = 16 * t + 4 * q + i < d.out_dim ? Bv[i] : 0.f;
           }
-          if (more && ((nd.it >> 9) & 7) == 0) Bv = f_bias(nd);
+          Bv = f_bias(nd);
           const float* brow = ACT + r * RS + d.in_col + 128 * kb + 4 * q;
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
@@ -891,7 +903,7 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
 #pragma unroll
               for (int e = 0; e < 4; ++e) acc = MFMA_F32(X0[c][e], bv[e], acc);
             }
-            if (16 * c < nkk) X0[c] = genp_ld4<LOCAL>(rsP, nbase + 64u * (unsigned)c);
+            X0[c] = genp_ld4<LOCAL>(rsP, 16 * c < nkk ? nbase + 64u * (unsigned)c : GENP_OOB);
           }
           if (lastk) {
             if (d.tanh) {
@@ -904,82 +916,71 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
           if (fi >= fn) d.it = -1;
         }
         lds_barrier();
+        if (s < 3) { GSTAGE(10 + s) }
       }
     }
     if (tid < A) LS[tid] = ls_reg;
     lds_barrier();
     GSTAMP(1)   // forward
-    // ================= loss terms of the heads this workgroup owns: thread (role, row) =================
-    if (tid < 48 && ((role_mask >> (tid >> 4)) & 1)) {
-      const int role = tid >> 4, row = tid & 15;
+    // ================= loss terms of the heads this workgroup owns =================
+    // policy: waves 0..3, lane (o = lane % 16, row = 4 w + lane / 16) — the sums over the outputs by DPP over the 16 lanes of a row;
+    // value / cost value: waves 4 / 5, lane = row
+    if (w < 4 && role0) {
+      const int o = r, row = 4 * w + q;
+      const bool valid = 16 * g + row < nb, on = o < A;
+      const float* rec = REC + row * GENP_REC;
+      const int hcol = T.MISC[0];
+      const float out = ACT[row * RS + hcol + o];      // (pad columns of the head are zeros)
+      const float old_lp = rec[16];
+      float lp, ent, g1, g2;      // log-prob and entropy of the row (in every lane), this output's d lp / d mean (or logit), d lp / d log_std
+      if (!discrete) {
+        const float ls = on ? LS[o] : 0.f, dd = rec[o & 15] - out, sd = __expf(ls), iv = 1.f / (sd * sd);
+        lp = row_sum(on ? -(dd * dd) * (0.5f * iv) - ls - LOG_SQRT_2PI_F : 0.f);
+        ent = row_sum(on ? HALF_LOG_2PI_PLUS_HALF_F + ls : 0.f);
+        g1 = dd * iv; g2 = (dd * dd) * iv - 1.f;
+      } else {
+        const float m = row_max(on ? out : -INFINITY);
+        const float lse = m + logf(row_sum(on ? expf(out - m) : 0.f));
+        const int action = (int)rec[0];
+        const float lg = out - lse, pr = expf(lg);
+        ent = -row_sum(on ? pr * lg : 0.f);
+        lp = row_sum(o == action ? lg : 0.f);
+        g1 = (o == action ? 1.f : 0.f) - pr; g2 = pr * (lg + ent);
+      }
+      const float ratio = __expf(lp - old_lp);
+      const float Ar = (rec[17] - mean_r) * istd_r;
+      const float Ac = rec[18] - mean_c;
+      const float clip = a.hp.clip_range;
+      const float s1 = Ar * ratio, s2 = Ar * fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
+      const float gsel = (s1 <= s2) ? Ar : 0.f;
+      const float dlp = valid ? inv_nb / (1.f + nu) * (-gsel + nu * Ac) * ratio : 0.f;
+      const float dent = valid ? a.hp.ent_coef * inv_nb : 0.f;
+      if (on) DZ[row * RS + hcol + o] = discrete ? dlp * g1 + dent * g2 : dlp * g1;
+      G2[row * 16 + o] = (on && !discrete) ? dlp * g2 : 0.f;
+      if (o == 0) {
+        float* rs = RST + row * 8;
+        rs[0] = valid ? fminf(s1, s2) : 0.f; rs[1] = valid ? Ac * ratio : 0.f; rs[2] = (valid && fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
+        rs[3] = valid ? old_lp - lp : 0.f; rs[4] = valid ? ent : 0.f;
+      }
+    } else if ((w == 4 || w == 5) && lane < 16 && ((role_mask >> (w - 3)) & 1)) {
+      const int role = w - 3, row = lane;
       const bool valid = 16 * g + row < nb;
       const float* rec = REC + row * GENP_REC;
       const int hcol = T.MISC[role];
-      float* dout = DZ + row * RS + hcol;
-      const float* out = ACT + row * RS + hcol;
-      float* rs = RST + (role * 16 + row) * 8;
-      if (role == 0) {
-        const float old_lp = rec[16];
-        float lp = 0.f, ent = 0.f, lse = 0.f;
-        if (!discrete) {
-          for (int o = 0; o < A; ++o) {
-            const float ls = LS[o], dd = rec[o] - out[o], sd = __expf(ls), iv = 1.f / (sd * sd);
-            lp += -(dd * dd) * (0.5f * iv) - ls - LOG_SQRT_2PI_F;
-            ent += HALF_LOG_2PI_PLUS_HALF_F + ls;
-          }
-        } else {
-          float m = -INFINITY;
-          for (int o = 0; o < A; ++o) m = fmaxf(m, out[o]);
-          float se = 0.f;
-          for (int o = 0; o < A; ++o) se += expf(out[o] - m);
-          lse = m + logf(se);
-          const int action = (int)rec[0];
-          for (int o = 0; o < A; ++o) { const float lg = out[o] - lse; ent -= expf(lg) * lg; if (o == action) lp = lg; }
-        }
-        const float ratio = __expf(lp - old_lp);
-        const float Ar = (rec[17] - mean_r) * istd_r;
-        const float Ac = rec[18] - mean_c;
-        const float clip = a.hp.clip_range;
-        const float s1 = Ar * ratio, s2 = Ar * fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
-        const float gsel = (s1 <= s2) ? Ar : 0.f;
-        const float dlp = valid ? inv_nb / (1.f + nu) * (-gsel + nu * Ac) * ratio : 0.f;
-        const float dent = valid ? a.hp.ent_coef * inv_nb : 0.f;
-        // (the per-output terms again, now that d loss / d log-prob is known: no per-thread arrays)
-        if (!discrete) {
-          for (int o = 0; o < 16; ++o) {
-            float d1v = 0.f, d2v = 0.f;
-            if (o < A) {
-              const float ls = LS[o], dd = rec[o] - out[o], sd = __expf(ls), iv = 1.f / (sd * sd);
-              d1v = dlp * (dd * iv); d2v = dlp * ((dd * dd) * iv - 1.f);
-            }
-            if (o < A) dout[o] = d1v;
-            G2[row * 16 + o] = d2v;
-          }
-        } else {
-          const int action = (int)rec[0];
-          for (int o = 0; o < 16; ++o) {
-            if (o < A) { const float lg = out[o] - lse, pr = expf(lg); dout[o] = dlp * ((o == action ? 1.f : 0.f) - pr) + dent * (pr * (lg + ent)); }
-            G2[row * 16 + o] = 0.f;
-          }
-        }
-        rs[0] = valid ? fminf(s1, s2) : 0.f; rs[1] = valid ? Ac * ratio : 0.f; rs[2] = (valid && fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
-        rs[3] = valid ? old_lp - lp : 0.f; rs[4] = valid ? ent : 0.f;
-      } else {
-        const float v = out[0];
-        const float R = role == 1 ? rec[19] : rec[20];
-        const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
-        const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
-        float vp = v, pass = 1.f;
-        if (vclip >= 0.f) {
-          const float old = role == 1 ? rec[21] : rec[22];
-          const float dv = v - old;
-          vp = old + fminf(fmaxf(dv, -vclip), vclip);
-          pass = (dv >= -vclip && dv <= vclip) ? 1.f : 0.f;
-        }
-        const float e = vp - R;
-        dout[0] = valid ? vcoef * 2.f * e * inv_nb * pass : 0.f;
-        rs[0] = valid ? e * e : 0.f;
+      const float v = ACT[row * RS + hcol];
+      const float R = role == 1 ? rec[19] : rec[20];
+      const float vclip = role == 1 ? a.hp.clip_range_reward_vf : a.hp.clip_range_cost_vf;
+      const float vcoef = role == 1 ? a.hp.reward_vf_coef : a.hp.cost_vf_coef;
+      float vp = v, pass = 1.f;
+      if (vclip >= 0.f) {
+        const float old = role == 1 ? rec[21] : rec[22];
+        const float dv = v - old;
+        vp = old + fminf(fmaxf(dv, -vclip), vclip);
+        pass = (dv >= -vclip && dv <= vclip) ? 1.f : 0.f;
       }
+      const float e = vp - R;
+      DZ[row * RS + hcol] = valid ? vcoef * 2.f * e * inv_nb * pass : 0.f;
+      RST[(role * 16 + row) * 8] = valid ? e * e : 0.f;
     }
     lds_barrier();
     GSTAMP(2)   // loss
@@ -998,9 +999,10 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
         d.nl = SU(row[0]); d.c_out = SU(row[1]); d.c_woff = SU(row[2]); d.c_col = SU(row[5]);
         return d;
       };
-      auto b_load = [&](const BD& d, int u, int e) -> f32x4 {      // the consumer's weights [unit j0 + 16 u + 4 q + e][64 T + 4 r ..]
+      auto b_load = [&](const BD& d, int u, int e) -> f32x4 {      // the consumer's weights [unit j0 + 16 u + 4 q + e][64 T + 4 r ..]; an absent chunk: outside the resource
         const int TT = (d.it >> 15) & 3, j = 16 * ((d.it >> 5) & 15) + 16 * u + 4 * q + e;
-        return genp_ld4<LOCAL>(rsP, j < d.c_out ? 4u * (unsigned)(d.c_woff + j * d.nl + 64 * TT + 4 * r) : GENP_OOB);
+        const bool there = d.it >= 0 && !((d.it >> 25) & 1) && u <= ((d.it >> 9) & 1);
+        return genp_ld4<LOCAL>(rsP, (there && j < d.c_out) ? 4u * (unsigned)(d.c_woff + j * d.nl + 64 * TT + 4 * r) : GENP_OOB);
       };
       auto b_chunks = [&](const BD& d) -> int { return ((d.it >> 25) & 1) ? 0 : 1 + ((d.it >> 9) & 1); };
       auto b_flush = [&](const BD& d) {      // acc[i][ii] = d h[row 4 q + ii][unit 64 T + 4 r + i] of this part
@@ -1030,24 +1032,19 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
       };
       int bi = 0;
       BD d, nd;
-      d.it = -1; nd.it = -1;
-      if (bn > 0) {
-        d = b_decode(0);
-        const int nch = b_chunks(d);
+      d.it = -1; d.nl = 0; d.c_out = 0; d.c_woff = 0; d.c_col = 0;
+      nd = d;
+      if (bn > 0) d = b_decode(0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
-          if (u < nch) {
+      for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) X0[4 * u + e] = b_load(d, u, e);
-          }
-      }
+        for (int e = 0; e < 4; ++e) X0[4 * u + e] = b_load(d, u, e);
       for (int s = n_stages - 2; s >= 0; --s) {
         const int P = SU(T.SP[s]), SW = SU(T.SWD[s]);
         if (SW == 0) continue;
         while (bi < bn && ((d.it >> 20) & 15) == s) {
-          const bool more = bi + 1 < bn;
-          int nnch = 0;
-          if (more) { nd = b_decode(bi + 1); nnch = b_chunks(nd); }
+          nd.it = -1;
+          if (bi + 1 < bn) nd = b_decode(bi + 1);
           const int nch = b_chunks(d), j0 = 16 * ((d.it >> 5) & 15);
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
@@ -1058,10 +1055,9 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = MFMA_F32(dzv[e], X0[4 * u + e][i], acc[i]);
             }
-            if (u < nnch) {      // (the next item's weights, into the registers this chunk has just been read from)
+            // (the next item's weights, into the registers this chunk has just been read from; unconditional: see the forward pass)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) X0[4 * u + e] = b_load(nd, u, e);
-            }
+            for (int e = 0; e < 4; ++e) X0[4 * u + e] = b_load(nd, u, e);
           }
           if ((d.it >> 24) & 1) b_flush(d);
           d = nd; ++bi;
@@ -1141,18 +1137,34 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
 #pragma unroll
           for (int e = 0; e < 4; ++e) az[e] = DZ[(4 * e + q) * RS + out_col + 16 * jt + r];
           f32x4 acc[4];     // acc[u][i] = d W[unit 16 jt + r][input 16 (4 kg + u) + 4 q + i]
+          float ax[4][4];   // the layer's input [row 4 e + q][16 (4 kg + u) + r]: all sixteen reads ahead of the MFMAs (an absent tile re-reads the last one)
+          const int kt_last = (in_dim - 1) / 16;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int kt = 4 * kg + u < kt_last ? 4 * kg + u : kt_last;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ax[u][e] = ACT[(4 * e + q) * RS + in_col + 16 * kt + r];
+          }
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (16 * (4 * kg + u) < in_dim) {
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[u] = MFMA_F32(ACT[(4 * e + q) * RS + in_col + 16 * (4 * kg + u) + r], az[e], acc[u]);
+#ifdef GENP_X_NOMF
+              for (int e = 0; e < 4; ++e) acc[u][e] = ax[u][e] * az[e];
+#else
+              for (int e = 0; e < 4; ++e) acc[u] = MFMA_F32(ax[u][e], az[e], acc[u]);
+#endif
             }
           }
           // (an element outside the layer: row or column offset outside the resource — two halves of GENP_OOB, so that one or both
           // of them push the sum out of range without wrapping — and the store is dropped; no branch in the store stream)
           const int j = 16 * jt + r;
+#ifdef GENP_X_NOST
+          const unsigned jrow = GENP_OOB / 2;
+#else
           const unsigned jrow = j < out_dim ? 4u * (unsigned)(g * n + w_off + j * in_dim) : GENP_OOB / 2;
+#endif
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int kt = 4 * kg + u, k = 16 * kt + 4 * q;
@@ -1171,89 +1183,92 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
         }
         base += cnt;
       }
-      if (!discrete && role0 && tid < A) {
-        float sl = 0.f;
-        for (int rr = 0; rr < 16; ++rr) sl += G2[rr * 16 + tid];
-        st_x<LOCAL>(mypart + net.log_std + tid, sl);
+      if (w == 6 && !discrete && role0) {      // log_std: sum over the 16 rows — lane (o, q): rows 4 q .. 4 q + 3, then over q
+        const float sl = quad_rows_sum((G2[(4 * q) * 16 + r] + G2[(4 * q + 1) * 16 + r]) + (G2[(4 * q + 2) * 16 + r] + G2[(4 * q + 3) * 16 + r]));
+        if (q == 0 && r < A) st_x<LOCAL>(mypart + net.log_std + r, sl);
       }
-      if (tid < 7 && ((role_mask >> (tid < 5 ? 0 : tid - 4)) & 1)) {      // this tile's loss sums: policy terms 0..4, reward / cost value errors 5, 6
-        float v = 0.f;
-        if (tid < 5) for (int rr = 0; rr < 16; ++rr) v += RST[rr * 8 + tid];
-        else for (int rr = 0; rr < 16; ++rr) v += RST[((tid - 4) * 16 + rr) * 8];
-        st_x<LOCAL>(pp.stat + g * 8 + tid, v);
+      if (w == 7) {      // this tile's loss sums: policy terms 0..4, reward / cost value errors 5, 6 — lane (row, q): terms q and q + 4
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const int k = q + 4 * h2, role = k < 5 ? 0 : k - 4;
+          const float v = row_sum(k < 7 ? RST[(role * 16 + r) * 8 + (k < 5 ? k : 0)] : 0.f);
+          if (r == 0 && k < 7 && ((role_mask >> role) & 1)) st_x<LOCAL>(pp.stat + g * 8 + k, v);
+        }
       }
     }
     }      // tile_wg
     GSTAMP(4)   // weight gradients
     bar_n += H; genp_arrive<LOCAL>(pp.bar);
+    GSUB(14)  // (arrival at A)
     if (tile_wg) rows_issue1(pn);      // (the next minibatch's rows, under the barriers: first round trip — the row offsets)
     genp_wait(pp.bar, bar_n);          // (A) every tile's partials are in memory
     GSTAMP(5)   // barrier A
     // ================= this workgroup's parameter slice: sum over the tiles in tile order, squared norm =================
+    // (elements lo + 4 tid .. + 3 stay in registers until Adam; a slice above 2 048 parameters walks the rest through `grad`)
     float ss = 0.f;
-    for (int e0 = lo + 4 * tid; e0 < hi; e0 += 4 * GENP_TH) {      // four consecutive elements per thread: G 16-byte loads in flight
+    const int e0 = lo + 4 * tid;
+    const unsigned eo = e0 < hi ? 4u * (unsigned)e0 : GENP_OOB;
+    f32x4 g0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto slice_sum = [&](int eb) -> f32x4 {      // four consecutive elements: G 16-byte loads in flight, summed in tile order (absent tiles read 0)
       f32x4 gs = f32x4{0.f, 0.f, 0.f, 0.f};
       for (int t = 0; t < G; t += 4) {
         f32x4 pv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) pv[u] = genp_ld4<LOCAL>(rsPart, t + u < G ? 4u * (unsigned)((t + u) * n + e0) : GENP_OOB);
+        for (int u = 0; u < 4; ++u) pv[u] = genp_ld4<LOCAL>(rsPart, (t + u < G && eb < hi) ? 4u * (unsigned)((t + u) * n + eb) : GENP_OOB);
 #pragma unroll
         for (int u = 0; u < 4; ++u)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) gs[i] += pv[u][i];      // tile order (absent tiles read 0)
+          for (int i = 0; i < 4; ++i) gs[i] += pv[u][i];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int e = e0 + i;
-        if (e < hi) {
-          if (!discrete && e >= net.log_std && e < net.log_std + A) gs[i] += -a.hp.ent_coef;      // d(ent_coef * -mean H) / d log_std
-          pp.grad[e] = gs[i];
-          ss = fmaf(gs[i], gs[i], ss);
-        }
+        const int e = eb + i;
+        if (!discrete && e >= net.log_std && e < net.log_std + A) gs[i] += -a.hp.ent_coef;      // d(ent_coef * -mean H) / d log_std
+        if (e >= hi) gs[i] = 0.f;
+        ss = fmaf(gs[i], gs[i], ss);
       }
+      return gs;
+    };
+    g0 = slice_sum(e0);
+    for (int e1 = e0 + 4 * GENP_TH; e1 < hi; e1 += 4 * GENP_TH) {
+      const f32x4 gs = slice_sum(e1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) if (e1 + i < hi) pp.grad[e1 + i] = gs[i];
     }
     ss = genp_block_sum(ss, RED);
     if (tid == 0) st_x<LOCAL>(pp.norm + wg, ss);
     GSTAMP(6)   // reduce + norm
     bar_n += H; genp_arrive<LOCAL>(pp.bar);
-    if (tile_wg) rows_issue2(pn);      // (second round trip: what the offsets address)
+    GSUB(10)  // (arrival at B)
     genp_wait(pp.bar, bar_n);          // (B) every slice's squared norm is in memory
     GSTAMP(7)   // barrier B
     float total = 0.f, q7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    {   // every tile's loss sums and every slice's squared norm fetched side by side (one value per thread), summed by fixed trees
+    {   // every tile's loss sums and every slice's squared norm fetched side by side (one value per thread), summed by fixed trees;
+        // Adam's operands of the slice travel with them, and BEHIND them the second round trip of the next minibatch's rows (loads come back in order)
       const __amdgpu_buffer_rsrc_t rsX = genp_rsrc(pp.stat, 512);      // [stat G x 8 | norm H]
-      float sv = 0.f;
-      if (tid < 8 * G || (tid >= 256 && tid < 256 + H)) sv = genp_ld<LOCAL>(rsX, 4u * (unsigned)tid);
-      // Adam's operands of the slice travel with them
+      const __amdgpu_buffer_rsrc_t rsM = genp_rsrc(a.exp_avg, (size_t)n), rsV = genp_rsrc(a.exp_avg_sq, (size_t)n);
+      const float sv = genp_ld<LOCAL>(rsX, (tid < 8 * G || (tid >= 256 && tid < 256 + H)) ? 4u * (unsigned)tid : GENP_OOB);
+      const f32x4 pw = genp_ld4<LOCAL>(rsP, eo), mv = genp_ld4<LOCAL>(rsM, eo), vv = genp_ld4<LOCAL>(rsV, eo);
+      if (tile_wg) rows_issue2();
       const float b1 = a.hp.adam_beta1, b2 = a.hp.adam_beta2, w1 = (float)(1.0 - (double)b1), w2 = (float)(1.0 - (double)b2);
-      const int e0 = lo + 4 * tid;
-      float gv[4], mv[4], vv[4];
-      f32x4 pw = f32x4{0.f, 0.f, 0.f, 0.f};
-      const bool mine = e0 < hi;
-      if (mine) {
-        pw = genp_ld4<LOCAL>(rsP, 4u * (unsigned)e0);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int ec = e0 + u < hi ? e0 + u : lo; gv[u] = pp.grad[ec]; mv[u] = a.exp_avg[ec]; vv[u] = a.exp_avg_sq[ec]; }
-      }
       lds_barrier();
       RST[tid] = sv;
       lds_barrier();
       total = wave_sum_fast(lane < H ? RST[256 + lane] : 0.f);
 #pragma unroll
       for (int k = 0; k < 7; ++k) q7[k] = wave_sum_fast(lane < G ? RST[lane * 8 + k] : 0.f);
+      GSUB(11)  // (the sums and the slice's operands are here)
       const float cc = a.hp.max_grad_norm / (sqrtf(total) + 1e-6f), coef = cc > 1.f ? 1.f : cc;
-      if (mine) {
+      {
+        f32x4 nm, nv, nw;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int e = e0 + u;
-          if (e < hi) {
-            const float gc = gv[u] * coef;
-            const float m = fmaf(w1, gc, b1 * mv[u]);
-            const float v = fmaf(w2, gc * gc, b2 * vv[u]);
-            a.exp_avg[e] = m; a.exp_avg_sq[e] = v;
-            st_x<LOCAL>(a.params + e, fmaf(-ps.step_size, m / fmaf(sqrtf(v), ps.inv_bc2_sqrt, a.hp.adam_eps), pw[u]));
-          }
+          const float gc = g0[u] * coef;
+          nm[u] = fmaf(w1, gc, b1 * mv[u]);
+          nv[u] = fmaf(w2, gc * gc, b2 * vv[u]);
+          nw[u] = fmaf(-ps.step_size, nm[u] / fmaf(sqrtf(nv[u]), ps.inv_bc2_sqrt, a.hp.adam_eps), pw[u]);
         }
+        genp_st4<LOCAL>(rsM, eo, nm); genp_st4<LOCAL>(rsV, eo, nv); genp_st4<LOCAL>(rsP, eo, nw);      // (dwords beyond n are dropped)
       }
       for (int e1 = e0 + 4 * GENP_TH; e1 < hi; e1 += 4 * GENP_TH) {      // (slices above 2 048 parameters: the rest)
 #pragma unroll
@@ -1286,13 +1301,15 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
     }
     GSTAMP(8)   // Adam + logged sums
     bar_n += H; genp_arrive<LOCAL>(pp.bar);
+    GSUB(12)  // (arrival at C)
     if (tile_wg) rows_commit(pn);      // (into the image)
+    GSUB(13)  // (the rows in the image)
     genp_wait(pp.bar, bar_n);          // (C) the updated parameters are in memory
     GSTAMP(9)   // barrier C
   }
   if (prof && tid == 0) a.stats[22] = LOCAL ? 1.f : 0.f;
   if (prof && tid == 0)
-    for (int k = 0; k < 10; ++k) a.stats[12 + k] = (float)((double)ph[k] / (double)(steps_done > 0 ? steps_done : 1));
+    for (int k = 0; k < 16; ++k) a.stats[(k < 10 ? 12 : 13) + k] = (float)((double)PH[k] / (double)(steps_done > 0 ? steps_done : 1));
   if (wg == 0 && tid == 0) {
     a.stats[0] = (float)early_stop_epoch;
     a.stats[1] = (float)steps_done;
