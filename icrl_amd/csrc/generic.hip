@@ -769,6 +769,7 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
 
   // ---- the rows of a minibatch: fetched in two round trips (row offsets, then what they address) into registers, committed to LDS later
   int nx_idx = -1, nx_ridx = 0;
+  const int ob_e = tid < 16 * OB ? tid : 0, ob_rr = ob_e / OB, ob_k = ob_e - ob_rr * OB;
   float nx_ar = 0.f, nx_ac = 0.f, nx_obs[4] = {0.f, 0.f, 0.f, 0.f}, nx_rec = 0.f;
   auto rows_issue1 = [&](const PlanStep& pn) {
     const int nbn = pn.nb_flags & NB_MASK;
@@ -784,8 +785,9 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
     lds_barrier();
     const int ia = nx_idx >= 0 ? nx_idx : 0;
     nx_ar = a.buf.reward_advantages[ia]; nx_ac = a.buf.cost_advantages[ia];
+    nx_obs[0] = a.buf.observations[(size_t)RIDXN[ob_rr] * O + (ob_k < O ? ob_k : 0)];      // (element tid of the 16 x OB block: row / column found once, before the loop)
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 1; u < 4; ++u) {
       const int e = tid + GENP_TH * u, ec = e < 16 * OB ? e : 0;
       const int rr = ec / OB, k = ec - rr * OB;
       nx_obs[u] = a.buf.observations[(size_t)RIDXN[rr] * O + (k < O ? k : 0)];
@@ -807,10 +809,13 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
   auto rows_commit = [&](const PlanStep& pn) {
     const int nbn = pn.nb_flags & NB_MASK;
     if (nbn == 0) return;
+    if (tid < 16 * OB) ACT[ob_rr * RS + ob_k] = ob_k < O ? nx_obs[0] : 0.f;
+    if (16 * OB > GENP_TH) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = tid + GENP_TH * u;
-      if (e < 16 * OB) { const int rr = e / OB, k = e - rr * OB; ACT[rr * RS + k] = k < O ? nx_obs[u] : 0.f; }
+      for (int u = 1; u < 4; ++u) {
+        const int e = tid + GENP_TH * u;
+        if (e < 16 * OB) { const int rr = e / OB, k = e - rr * OB; ACT[rr * RS + k] = k < O ? nx_obs[u] : 0.f; }
+      }
     }
     for (int e = tid + 4 * GENP_TH; e < 16 * OB; e += GENP_TH) {      // (observations wider than 128: the rest, not prefetched)
       const int rr = e / OB, k = e - rr * OB;
@@ -1124,65 +1129,59 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
     // ================= partial weight gradients of this tile's 16 rows -> part[g] =================
     float* const mypart = pp.part + (size_t)g * n;
     {
+      // item = 16 units (jt) of a layer, dealt round-robin to the waves; inside, the layer's inputs 64 at a time (four 16 x 16 tiles, K = the
+      // 16 rows): d W^T tile = A (inputs x rows, from the ACT image) x B (rows x units, from the DZ image) -> lane (unit r, q) holds inputs
+      // 4 q .. 4 q + 3 of its unit: ONE 16-byte store per tile.  The per-item work outside the MFMAs is kept to pointer increments (the
+      // kernel spends 4 cycles per vector instruction and nothing overlaps an MFMA of the same SIMD).
+      const int lane_act = q * RS + r;      // row q (+ 4 e), column r of a tile
       int base = 0;
       for (int wi = 0; wi < GEN_MAX_LAYERS; ++wi) {
         const int l = SU(T.WL[wi]);
         if (l < 0) break;
         const int* row = T.LT + 8 * l;
         const int in_dim = SU(row[0]), out_dim = SU(row[1]), w_off = SU(row[2]), b_off = SU(row[3]), in_col = SU(row[4]), out_col = SU(row[5]);
-        const int nkg = (in_dim + 63) / 64, cnt = (out_dim + 15) / 16 * nkg;
-        for (int idx = (w - base) & 7; idx < cnt; idx += 8) {
-          const int jt = idx / nkg, kg = idx - jt * nkg;
+        const int nj = (out_dim + 15) / 16, nkt = (in_dim + 15) / 16, nfull = (in_dim & 3) == 0 ? nkt : in_dim / 16;      // tiles a 16-byte store serves (the last one too when rows are whole quads)
+        for (int jt = (w - base) & 7; jt < nj; jt += 8) {
           float az[4];      // d z[row 4 e + q][unit 16 jt + r]
 #pragma unroll
-          for (int e = 0; e < 4; ++e) az[e] = DZ[(4 * e + q) * RS + out_col + 16 * jt + r];
-          f32x4 acc[4];     // acc[u][i] = d W[unit 16 jt + r][input 16 (4 kg + u) + 4 q + i]
-          float ax[4][4];   // the layer's input [row 4 e + q][16 (4 kg + u) + r]: all sixteen reads ahead of the MFMAs (an absent tile re-reads the last one)
-          const int kt_last = (in_dim - 1) / 16;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int kt = 4 * kg + u < kt_last ? 4 * kg + u : kt_last;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ax[u][e] = ACT[(4 * e + q) * RS + in_col + 16 * kt + r];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (16 * (4 * kg + u) < in_dim) {
-#pragma unroll
-#ifdef GENP_X_NOMF
-              for (int e = 0; e < 4; ++e) acc[u][e] = ax[u][e] * az[e];
-#else
-              for (int e = 0; e < 4; ++e) acc[u] = MFMA_F32(ax[u][e], az[e], acc[u]);
-#endif
-            }
-          }
-          // (an element outside the layer: row or column offset outside the resource — two halves of GENP_OOB, so that one or both
-          // of them push the sum out of range without wrapping — and the store is dropped; no branch in the store stream)
+          for (int e = 0; e < 4; ++e) az[e] = DZ[lane_act + 4 * e * RS + out_col + 16 * jt];
           const int j = 16 * jt + r;
-#ifdef GENP_X_NOST
-          const unsigned jrow = GENP_OOB / 2;
-#else
-          const unsigned jrow = j < out_dim ? 4u * (unsigned)(g * n + w_off + j * in_dim) : GENP_OOB / 2;
-#endif
+          const unsigned jrow = j < out_dim ? 4u * (unsigned)(g * n + w_off + j * in_dim + 4 * q) : GENP_OOB / 2;      // this lane's 16 bytes of tile 0 (outside the layer: dropped)
+          const float* ap = ACT + lane_act + in_col;
+          for (int k0 = 0; k0 < nkt; k0 += 4) {
+            float ax[4][4];   // the layer's input [row 4 e + q][16 (k0 + u) + r]: all sixteen reads ahead of the MFMAs (an absent tile re-reads the last one)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int kt = 4 * kg + u, k = 16 * kt + 4 * q;
-            if (16 * kt < in_dim) {
-              if ((in_dim & 3) == 0 || 16 * kt + 16 <= in_dim) genp_st4<LOCAL>(rsPart, jrow + (k < in_dim ? 4u * (unsigned)k : GENP_OOB / 2), acc[u]);
-              else {
+            for (int u = 0; u < 4; ++u) {
+              const int kt = k0 + u < nkt ? k0 + u : nkt - 1;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) genp_st1<LOCAL>(rsPart, jrow + (k + i < in_dim ? 4u * (unsigned)(k + i) : GENP_OOB / 2), acc[u][i]);
+              for (int e = 0; e < 4; ++e) ax[u][e] = ap[4 * e * RS + 16 * kt];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              if (k0 + u < nkt) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = MFMA_F32(ax[u][e], az[e], acc);
+                const int kt = k0 + u;
+                if (kt < nfull) {      // (a quad is inside the row or outside it as a whole)
+                  const unsigned vo = 16 * kt + 4 * q < in_dim ? jrow : GENP_OOB / 2;
+                  if (LOCAL) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsPart, (int)vo, 64 * kt, 1);
+                  else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc), rsPart, (int)vo, 64 * kt, 16);
+                } else {
+#pragma unroll
+                  for (int i = 0; i < 4; ++i) genp_st1<LOCAL>(rsPart, (16 * kt + 4 * q + i < in_dim ? jrow : GENP_OOB / 2) + 4u * (unsigned)(16 * kt + i), acc[i]);
+                }
               }
             }
           }
-          if (kg == 0) {      // bias: the sum over the 16 rows (lanes r = unit, q, e = row 4 e + q)
-            const float sb = quad_rows_sum((az[0] + az[1]) + (az[2] + az[3]));
-            if (q == 0 && j < out_dim) st_x<LOCAL>(mypart + b_off + j, sb);
-          }
+          // bias: the sum over the 16 rows (lanes r = unit, q, e = row 4 e + q)
+          const float sb = quad_rows_sum((az[0] + az[1]) + (az[2] + az[3]));
+          if (q == 0 && j < out_dim) st_x<LOCAL>(mypart + b_off + j, sb);
         }
-        base += cnt;
+        base += nj;
+        if (wi == 0) { GSTAGE(13) }
       }
+      GSTAGE(14)
       if (w == 6 && !discrete && role0) {      // log_std: sum over the 16 rows — lane (o, q): rows 4 q .. 4 q + 3, then over q
         const float sl = quad_rows_sum((G2[(4 * q) * 16 + r] + G2[(4 * q + 1) * 16 + r]) + (G2[(4 * q + 2) * 16 + r] + G2[(4 * q + 3) * 16 + r]));
         if (q == 0 && r < A) st_x<LOCAL>(mypart + net.log_std + r, sl);
