@@ -1302,6 +1302,288 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
   }
 }
 
+// The persistent rollout for a generic-shape policy (hidden layers above 64 units or an `arch` descriptor; the constraint net one the
+// register image holds): the same loop, phase A's policy forward = the table-driven forward of generic.hip (gen_mlp_forward +
+// gen_policy_head: bit-identical to policy_generic_kernel, i.e. to the per-step launches) on 3 W threads — the workgroup has
+// max(256, 3 W) threads, everything but the forward runs on the first 256 as before (waves 0 / 2 / 3: env step / buffer row / cost net).
+struct GenRolloutArgs {
+  PersistArgs p;
+  GenNet net;
+  const float* P;      // the policy's parameters in their natural layout (log_std of the Gaussian head)
+};
+template <int OCT, int CIT>
+__device__ __forceinline__ void rollout_generic_body(const GenRolloutArgs& ga) {
+  constexpr bool GRAN = true;
+  const PersistArgs& p = ga.p;
+  const GenNet& net = ga.net;
+  __shared__ float gact[GEN_MAX_ROW];
+  extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
+  __shared__ ActShared sh;
+  double* const chunk = dyn_lds;                          // raw observations of the step, TRANSPOSED: [obs][NP], NP = N + 64
+  double* const Bl = dyn_lds + p.act.pl.O * (p.act.env.n_envs + 64);
+  __shared__ double vec[2][128], dev2[2][128], ret_s[128], cret_s[128], rawr_s[128];
+  __shared__ float rawc_s[128];
+  __shared__ double dens[2];
+  __shared__ float noise_s[MAX_ACT], alow_s[MAX_ACT], ahigh_s[MAX_ACT];     // action box: read every step, kept out of global memory
+  __shared__ int done_s[128];
+  __shared__ int last_done_s;
+  const ActStepArgs& a = p.act;
+  // private copies of the structs whose pointers the step loop goes through, every pointer marked as a global-memory pointer
+  // (common.h: as_global — in a batched launch the block comes from LDS / memory and the accesses would be flat_* otherwise)
+  icrl_norm_t nm = p.nm; globalize(nm);
+  icrl_buffer_t buf = a.buf; globalize(buf);
+  icrl_agent_t ag = a.ag; globalize(ag);
+  icrl_costnet_t cnet = a.cn; globalize(cnet);
+  unsigned long long* const xg_all = as_global(p.xg);
+  const float* const noise_g = as_global(a.noise);
+  WaveRegs<OCT, CIT> R;                // one image: policy weights in waves 0..2, cost-net weights in wave 3
+  WaveRegs<OCT, CIT>& C = R;
+  if ((threadIdx.x >> 6) == 3 && a.has_cn) load_cn_regs<CIT>(a.cn, a.cl, C);
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int ctid = tid < 256 ? tid : (1 << 28);      // (the threads beyond the first 256 only take part in the forward)
+  const int g_slot = tid / net.W, g_j = tid - g_slot * net.W;
+  const float* const Pn = as_global(ga.P);
+  const float* const PTn = as_global(a.PT);
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int O = a.pl.O, A = a.pl.A, N = a.env.n_envs, T = p.T;
+  const int AS = buf.act_store;
+  const int NA = a.pl.discrete ? 1 : A;       // noise values per env step
+  const int NP = N + 64;                      // padded column length of the transposed observation block
+  const int G = 2 * O + 4;                    // 8-byte words per env and step of the exchange area
+  // Exchange records (GRAN): 16 bytes {tag, lo, hi, tag} — a float64 with this step's tag at both ends (a torn 16-byte access shows an
+  // old tag in one half).  Per env: obs_dim observation records, one reward record (the done flag in the top bit of its second tag), one
+  // cost record = R16 = obs_dim + 2 records = the same G x 8 bytes as one 8-byte {tag, word} granule per 32-bit word, but HALF the
+  // memory instructions: 64 workgroups x 2560 granule loads per step ran into the chip's rate of uncached loads (~62 G/s).
+  const int R16 = O + 2;
+  typedef unsigned int rec_u4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(xg_all, 0, 2 * N * G * 8, 0x00020000);
+  auto rstore = [&](int byte_off, rec_u4 v) { __builtin_amdgcn_raw_buffer_store_b128(v, xrs, byte_off, 0, 16); };     // sc1
+  auto rload = [&](int byte_off) -> rec_u4 { return __builtin_amdgcn_raw_buffer_load_b128(xrs, byte_off, 0, 16); };
+  for (int i = ctid; i < O * NP; i += 256) chunk[i] = 0.0;
+  const bool has_cost = a.has_cn != 0;
+  const uint32_t e_key = a.env.key[n];
+  uint32_t e_ctr = a.env.step_count[n];
+  int e_tep = a.env.t_ep[n];
+  icrl_env_t env = a.env; globalize(env);
+  for (int i = ctid; i < O * a.env.act_dim; i += 256) Bl[i] = a.env.B[i];
+  env.B = Bl;
+  const bool has_box = a.alow != nullptr && a.ahigh != nullptr;
+  if (tid < MAX_ACT) { alow_s[tid] = (has_box && tid < A) ? a.alow[tid] : 0.f; ahigh_s[tid] = (has_box && tid < A) ? a.ahigh[tid] : 0.f; }
+  for (int i = ctid; i < MAX_OBS; i += 256) {
+    sh.x[i] = i < O ? (float)ag.last_obs[(size_t)n * O + i] : 0.f;
+    if (i < O) sh.s_old[i] = a.env.s[(size_t)n * O + i];
+  }
+  if (tid < N) { ret_s[tid] = nm.ret[tid]; cret_s[tid] = nm.cost_ret[tid]; }
+  if (tid == 0) last_done_s = ag.last_dones[n];
+  // replicated running statistics: observation columns in threads < O, ret_rms in wave 3, cost_rms in wave 2
+  double o_mean = 0.0, o_var = 1.0, o_cnt = 0.0, o_last = 0.0;
+  if (tid < O) { o_mean = nm.obs_mean[tid]; o_var = nm.obs_var[tid]; o_cnt = nm.obs_count[0]; o_last = ag.last_obs[(size_t)n * O + tid]; }
+  double st_m = 0.0, st_v = 1.0, st_c = 0.0;
+  if (w == 3) { st_m = nm.ret_stats[0]; st_v = nm.ret_stats[1]; st_c = nm.ret_stats[2]; }
+  if (w == 2) { st_m = nm.cost_stats[0]; st_v = nm.cost_stats[1]; st_c = nm.cost_stats[2]; }
+  float noise_reg = (tid < NA) ? noise_g[(size_t)n * NA + tid] : 0.f;
+  double fin_rew = 0.0; float fin_cost = 0.f; int fin_done = 0;
+  unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, pc_rounds = 0, tl = p.prof ? prof_now() : 0ull;
+  int spin_limit = 1 << 22;
+  for (int t = 0; t < T; ++t) {
+    const int par = t & 1;
+    const size_t tn = (size_t)t * N + n;
+    const unsigned gtag = (unsigned)(t + 1);
+    if (tid < NA) {
+      noise_s[tid] = noise_reg;
+      if (t + 1 < T) noise_reg = noise_g[((size_t)(t + 1) * N + n) * NA + tid];     // lands during this step
+    }
+    __syncthreads();
+    // ---------------- phase A: kernel A's work for env n ----------------
+    gen_mlp_forward(net, PTn, sh.x, gact, g_slot, g_j);
+    if (tid == 0) {
+      float lp, ent;
+      gen_policy_head(net, Pn, gact + net.layer[net.head[0]].act_off, noise_s, 0, has_box ? alow_s : nullptr, has_box ? ahigh_s : nullptr, nullptr,
+                      sh.act_raw, sh.act_clip, lp, ent);
+      sh.scal[0] = gact[net.layer[net.head[1]].act_off]; sh.scal[1] = gact[net.layer[net.head[2]].act_off]; sh.scal[2] = lp;
+    }
+    __syncthreads();
+    if (w == 0) {
+      double rew; int done;
+      env_step_wave(env, n, sh.s_old, sh.act_clip, e_key, e_ctr, e_tep, sh.s_new, rew, done);
+      float* nob = buf.new_orig_observations + tn * O;
+      if (GRAN) {
+        const int rec0 = ((par * N + n) * R16) * 16;       // byte offset of this env's records of this parity
+        for (int i = lane; i < O; i += WAVE) {
+          const double v = sh.s_new[i];
+          nob[i] = (float)v;
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+          rstore(rec0 + 16 * i, rec_u4{gtag, (unsigned)bits, (unsigned)(bits >> 32), gtag});
+        }
+        if (lane == 0) {       // reward record: the done flag rides in the top bit of its second tag
+          const unsigned long long bits = (unsigned long long)__double_as_longlong(rew);
+          rstore(rec0 + 16 * O, rec_u4{gtag, (unsigned)bits, (unsigned)(bits >> 32), gtag | (done ? 0x80000000u : 0u)});
+        }
+      } else {
+        double* xo = as_global(p.xch_obs) + ((size_t)par * N + n) * O;
+        for (int i = lane; i < O; i += WAVE) { const double v = sh.s_new[i]; nob[i] = (float)v; xstore(xo + i, v); }
+        if (lane == 0) { xstore(as_global(p.xch_rew) + par * N + n, rew); xstore(as_global(p.xch_done) + par * N + n, (unsigned)done); }
+      }
+    } else if (w == 3) {
+      float cost = 0.f;
+      if (a.has_cn) cost = cost_forward_wave<CIT>(cnet, a.cl, C, sh.s_old, sh.act_clip, sh.cx, sh.ch);
+      if (lane == 0) {
+        if (GRAN) rstore(((par * N + n) * R16 + O + 1) * 16, rec_u4{gtag, __float_as_uint(cost), 0u, gtag});
+        else xstore(as_global(p.xch_cost) + par * N + n, cost);
+        buf.orig_costs[tn] = cost;
+      }
+    } else if (w == 2) {
+      float* ob = buf.observations + tn * O;
+      float* oob = buf.orig_observations + tn * O;
+      for (int i = lane; i < O; i += WAVE) { ob[i] = sh.x[i]; oob[i] = (float)sh.s_old[i]; }
+      if (lane < AS) buf.actions[tn * AS + lane] = sh.act_raw[lane];
+      if (lane < A && !a.pl.discrete) ag.act_clipped[(size_t)n * A + lane] = sh.act_clip[lane];
+      if (lane == 0) {
+        buf.dones[tn] = (float)last_done_s;
+        buf.reward_values[tn] = sh.scal[0];
+        buf.cost_values[tn] = sh.scal[1];
+        buf.log_probs[tn] = sh.scal[2];
+        ag.last_v_r[n] = sh.scal[0];
+        ag.last_v_c[n] = sh.scal[1];
+      }
+    }
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }
+    if (p.prof && t == T / 2 && lane == 0) g_wide_trace[4 * n + w] = __builtin_amdgcn_s_memrealtime();   // per wave: end of its phase-A part
+    if (GRAN) {
+      // poll this thread's records of ALL envs until every one carries this step's tag at both ends, then scatter the payloads
+      const int rbase = par * N * R16 * 16;
+      const int total = N * R16;
+      rec_u4 g[REC_MAX];
+#pragma unroll
+      for (int k = 0; k < REC_MAX; ++k) g[k] = (k * 256 + ctid < total) ? rload(rbase + (k * 256 + ctid) * 16) : rec_u4{gtag, 0u, 0u, gtag};
+      bool ok = false;
+      int rounds = 0;
+      for (int spins = 0; spins < spin_limit && !ok; ++spins) {
+        ok = true;
+#pragma unroll
+        for (int k = 0; k < REC_MAX; ++k)
+          if (g[k][0] != gtag || (g[k][3] & 0x7fffffffu) != gtag) { g[k] = rload(rbase + (k * 256 + ctid) * 16); ok = false; }
+        ++rounds;
+      }
+      if (p.prof && tid == 0) { pc_rounds += (unsigned long long)rounds; }
+      if (!ok) spin_limit = 1;      // a peer never showed up (a workgroup was not resident): stop waiting ~2 s per step; reported below
+#pragma unroll
+      for (int k = 0; k < REC_MAX; ++k) {
+        const int idx = k * 256 + ctid;
+        if (idx < total) {
+          unsigned rr = __umulhi((unsigned)idx, p.g_magic);
+          int slot = idx - (int)rr * R16;
+          if (slot >= R16) { slot -= R16; ++rr; }
+          const double v = __longlong_as_double((long long)(((unsigned long long)g[k][2] << 32) | (unsigned long long)g[k][1]));
+          if (slot < O) chunk[slot * NP + (int)rr] = v;
+          else if (slot == O) { rawr_s[rr] = v; done_s[rr] = (int)(g[k][3] >> 31); }
+          else rawc_s[rr] = has_cost ? __uint_as_float(g[k][1]) : 0.f;
+        }
+      }
+      __syncthreads();
+    } else {
+      grid_barrier(as_global(p.counter), N, n, (unsigned)(t + 1), spin_limit);
+    }
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }
+    // ---------------- phase B: kernel B's statistics, replicated; normalise own env ----------------
+    {
+      if (!GRAN) {
+        const double* xo = as_global(p.xch_obs) + (size_t)par * N * O;
+        for (int i = tid; i < N * O; i += 256) { const int rr = i / O, j = i - rr * O; chunk[j * NP + rr] = xload(xo + i); }
+      }
+      if (tid < N) {
+        if (!GRAN) {
+          rawr_s[tid] = xload(as_global(p.xch_rew) + par * N + tid);
+          rawc_s[tid] = has_cost ? xload(as_global(p.xch_cost) + par * N + tid) : 0.f;
+          done_s[tid] = (int)xload(as_global(p.xch_done) + par * N + tid);
+        }
+        const double rr = rawr_s[tid];
+        const float rc = rawc_s[tid];
+        double r = ret_s[tid], c = has_cost ? cret_s[tid] : 0.0;
+        if (nm.training) {
+          r = r * nm.reward_gamma + rr;
+          if (has_cost) c = c * nm.cost_gamma + (double)rc;
+        }
+        vec[0][tid] = r; vec[1][tid] = c;
+      }
+    }
+    __syncthreads();
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc3 += tn_ - tl; tl = tn_; }
+    if (nm.training) {
+      if (tid < O) {           // obs_rms.update: rows added in order (numpy's axis-0 reduction)
+        double bm, bv;
+        column_moments_contig(chunk + tid * NP, N, bm, bv);
+        chan_merge(o_mean, o_var, o_cnt, bm, bv, (double)N);
+        o_cnt = (double)N + o_cnt;
+      }
+      if (w == 3 || (w == 2 && has_cost)) {     // ret_rms / cost_rms: numpy pairwise order
+        const int v = w == 3 ? 0 : 1;
+        const double bm = np_leaf_sum_wave(vec[v], N) / (double)N;
+        for (int i = lane; i < N; i += 64) { const double d = vec[v][i] - bm; dev2[v][i] = d * d; }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        const double bv = np_leaf_sum_wave(dev2[v], N) / (double)N;
+        chan_merge(st_m, st_v, st_c, bm, bv, (double)N);
+        st_c = (double)N + st_c;
+      }
+    }
+    if (lane == 0 && w == 3) dens[0] = sqrt(st_v + nm.epsilon);
+    if (lane == 0 && w == 2) dens[1] = sqrt(st_v + nm.epsilon);
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc4 += tn_ - tl; tl = tn_; }
+    if (tid < O) {             // own env: normalise + clip, next policy input
+      double o = chunk[tid * NP + n];
+      if (nm.norm_obs) o = fmin(fmax((o - o_mean) / sqrt(o_var + nm.epsilon), -nm.clip_obs), nm.clip_obs);
+      o_last = o;
+      sh.x[tid] = (float)o;
+      buf.new_observations[tn * O + tid] = (float)o;
+      sh.s_old[tid] = sh.s_new[tid];
+    }
+    __syncthreads();
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc5 += tn_ - tl; tl = tn_; }
+    if (tid < N) {
+      const int d = done_s[tid];
+      if (nm.training || d) { ret_s[tid] = d ? 0.0 : vec[0][tid]; if (has_cost) cret_s[tid] = d ? 0.0 : vec[1][tid]; }
+    }
+    if (tid == 0) {
+      double r = rawr_s[n];
+      fin_rew = r; fin_cost = rawc_s[n]; fin_done = done_s[n];
+      if (nm.norm_reward) r = fmin(fmax(r / dens[0], -nm.clip_reward), nm.clip_reward);
+      buf.rewards[tn] = (float)r;
+      if (has_cost) {
+        double c = (double)rawc_s[n];
+        if (nm.norm_cost) c = fmin(fmax(c / dens[1], -nm.clip_cost), nm.clip_cost);
+        buf.costs[tn] = (float)c;
+      }
+      last_done_s = done_s[n];
+    }
+    if (p.prof) { const unsigned long long tn_ = prof_now(); pc2 += tn_ - tl; tl = tn_; }
+  }
+  if (p.prof && n == 0 && tid == 0) { g_rollout_prof[0] = pc0; g_rollout_prof[1] = pc1; g_rollout_prof[2] = pc2; g_rollout_prof[3] = (unsigned long long)T; g_rollout_prof[4] = pc3; g_rollout_prof[5] = pc4; g_rollout_prof[6] = pc5; g_rollout_prof[7] = pc_rounds; }
+  // a timed-out exchange means stale granules went into the statistics and the buffer: tell the host (it raises)
+  if (spin_limit == 1 && ag.status != nullptr && (tid & 63) == 0) atomicOr(ag.status, 1);
+  // ---- leave the agent / wrapper state exactly where the per-step path leaves it
+  __syncthreads();
+  if (tid < O) ag.last_obs[(size_t)n * O + tid] = o_last;
+  if (tid == 0) {
+    ag.last_dones[n] = (uint8_t)last_done_s;
+    ag.raw_rew[n] = fin_rew; ag.dones[n] = (uint8_t)fin_done;
+    if (has_cost) ag.raw_cost[n] = fin_cost;
+  }
+  if (n == 0) {
+    if (tid < O) { nm.obs_mean[tid] = o_mean; nm.obs_var[tid] = o_var; }
+    if (tid == 0) nm.obs_count[0] = o_cnt;
+    if (lane == 0 && w == 3) { nm.ret_stats[0] = st_m; nm.ret_stats[1] = st_v; nm.ret_stats[2] = st_c; }
+    if (lane == 0 && w == 2 && has_cost) { nm.cost_stats[0] = st_m; nm.cost_stats[1] = st_v; nm.cost_stats[2] = st_c; }
+    if (tid < N) { nm.ret[tid] = ret_s[tid]; if (has_cost) nm.cost_ret[tid] = cret_s[tid]; }
+  }
+}
+
+template <int OCT, int CIT, int TH>      // TH = the launch's threads (the register budget follows it: at 768 the statistics code spills)
+__global__ void __launch_bounds__(TH) rollout_generic_kernel(GenRolloutArgs ga) {
+  rollout_generic_body<OCT, CIT>(ga);
+}
+
 template <int OCT, int CIT, bool GRAN>
 __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) {
   rollout_persistent_body<OCT, CIT, GRAN>(p);
@@ -3192,6 +3474,62 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
     if (buf->act_store != (pol->discrete ? 1 : pol->act_dim) || (!pol->discrete && env->act_dim != pol->act_dim))
       return fail("icrl_rollout_collect (generic-shape path): buffer act_store %d / env act_dim %d vs policy act_dim %d (discrete: act_store 1)",
                   buf->act_store, env->act_dim, pol->act_dim);
+    // ONE persistent launch (rollout_generic_kernel: the loop of rollout_persistent_kernel around the table-driven forward) when the
+    // shapes are those of the one-workgroup-per-env kernel and the constraint net fits its register image; do_gae & 2 forces the per-step launches
+    if (policy_is_wide(pol) && (cn == nullptr || (!costnet_is_wide(cn) && cn_ok(cn))) && !(do_gae & 2) && N <= 128 && N * O <= NORM_CHUNK &&
+        O * env->act_dim <= MAX_OBS * MAX_ACT && (size_t)N * (2 * O + 4) <= (size_t)256 * GRAN_MAX && pol->params_t != nullptr) {
+      GenRolloutArgs ga;
+      if (int e = make_gen_net(pol, &ga.net, "icrl_rollout_collect")) return e;
+      ga.P = pol->params;
+      const int G2 = 2 * O + 4;
+      const size_t need = (size_t)16 * N * O + (size_t)16 * N + (size_t)8 * N + (size_t)8 * N + 1024 + (size_t)16 * N * G2;
+      char* ws = (ag->xch_ws != nullptr && (size_t)ag->xch_ws_bytes >= need) ? reinterpret_cast<char*>(ag->xch_ws)
+                 : ((size_t)T * N * sizeof(float) >= need ? reinterpret_cast<char*>(buf->reward_advantages) : nullptr);
+      if (ws != nullptr) {
+        PersistArgs& p = ga.p;
+        ActStepArgs& a = p.act;
+        a.env = *env; a.buf = *buf; a.ag = *ag;
+        a.pl = make_pol_layout(pol->obs_dim, pol->act_dim, MAX_H, MAX_H, pol->discrete);      // (only obs / act / discrete are read)
+        a.PT = pol->params_t; a.noise = noise; a.alow = action_low; a.ahigh = action_high;
+        a.has_cn = cn != nullptr;
+        if (cn) { a.cn = *cn; a.cl = make_cn_layout(cn->in_dim, cn->n_hidden, cn->h1, cn->h2); }
+        p.nm = *nm; p.T = T; p.prof = (do_gae & 4) != 0;
+        char* base = ws;
+        p.xch_obs = reinterpret_cast<double*>(base); base += (size_t)16 * N * O;
+        p.xch_rew = reinterpret_cast<double*>(base); base += (size_t)16 * N;
+        p.xch_cost = reinterpret_cast<float*>(base); base += (size_t)8 * N;
+        p.xch_done = reinterpret_cast<unsigned*>(base); base += ((size_t)8 * N + 255) / 256 * 256;
+        p.counter = reinterpret_cast<unsigned*>(base); base += 512;
+        p.xg = reinterpret_cast<unsigned long long*>(base);
+        p.g_magic = (unsigned)((1ull << 32) / (unsigned long long)(G2 / 2));
+        hipError_t e = hipMemsetAsync(p.counter, 0, 512 + (size_t)16 * N * G2, s);
+        if (e != hipSuccess) return (int)e;
+        const bool small = O <= 32 && (!cn || cn->in_dim <= 32);
+        const size_t dyn = persist_dyn_lds(N, O, env->act_dim);
+        const int threads = 3 * ga.net.W > 256 ? 3 * ga.net.W : 256;
+        auto go = [&](auto kernel) -> int {      // -1: the grid is not co-resident
+          int dev = 0, cus = 0, per_cu = 0;
+          if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+          if (dyn > 48 * 1024 && hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) return -1;
+          if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dyn) != hipSuccess || (long long)per_cu * cus < N) return -1;
+          const hipError_t e_ = launch_coresident(kernel, dim3(N), dim3(threads), dyn, s, ga);
+          if (e_ == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return -1; }
+          return (int)e_;
+        };
+        int perr;
+        if (threads <= 256) perr = small ? go(rollout_generic_kernel<2, 2, 256>) : go(rollout_generic_kernel<8, 10, 256>);
+        else if (threads <= 384) perr = small ? go(rollout_generic_kernel<2, 2, 384>) : go(rollout_generic_kernel<8, 10, 384>);
+        else if (threads <= 576) perr = small ? go(rollout_generic_kernel<2, 2, 576>) : go(rollout_generic_kernel<8, 10, 576>);
+        else perr = small ? go(rollout_generic_kernel<2, 2, 768>) : go(rollout_generic_kernel<8, 10, 768>);
+        if (perr >= 0) {
+          const int err = perr != 0 ? perr : (int)hipGetLastError();
+          if (err || !(do_gae & 1)) return err;
+          return icrl_gae_dual_ws(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r, ag->last_v_c,
+                                  ag->last_dones, buf->reward_advantages, buf->cost_advantages, buf->reward_returns, buf->cost_returns, T, N,
+                                  reward_gamma, reward_gae_lambda, cost_gamma, cost_gae_lambda, 0, buf->gae_ws, buf->gae_ws_bytes, stream);
+        }
+      }
+    }
     GenStepArgs g;
     g.env = *env; g.buf = *buf; g.ag = *ag; g.has_cn = cn != nullptr;
     const int AS = buf->act_store;
