@@ -134,6 +134,59 @@ __device__ __forceinline__ void gen_mlp_forward(const GenNet& net, const float* 
   }
 }
 
+// The same forward with FOUR units per lane: wave `slot` runs its slot's layer of the stage, lane l the units 4 l .. 4 l + 3 — one 16-byte
+// load per input from the transposed image (PT[k][4 l ..]: consecutive lanes, consecutive addresses), GEN_QAHEAD inputs in flight, four
+// independent fmaf chains per lane.  Every unit's chain is gen_mlp_forward's (the bias, then its inputs in ascending order): bit-identical
+// results, a quarter of the load instructions and of the threads (a 128-wide layer: 32 lanes).  The inputs are walked in FULLY UNROLLED
+// blocks of 128 / 64 / 32 / 16 (then one by one): the compiler's wait-count bookkeeping gives up at a loop's back edge — a rolled loop of
+// 16-input turns waited for ALL prefetched loads at the top of every turn (measured: ~125 cycles per input, the forward of the persistent
+// rollout at 128-wide layers took 49 k cycles) —, inside a block every wait is vmcnt(GEN_QAHEAD - 1).  Workgroups of >= 192 threads; all call.
+#ifndef GEN_QAHEAD
+#define GEN_QAHEAD 16
+#endif
+typedef float gen_f4 __attribute__((ext_vector_type(4)));
+template <int NB>
+__device__ __forceinline__ void gen_quads_block(__amdgpu_buffer_rsrc_t rs, unsigned w0, unsigned stride, const float* in, int k0, gen_f4& z) {
+  auto ld4 = [&](unsigned off) -> gen_f4 { return __builtin_bit_cast(gen_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0)); };
+  constexpr int AH = NB < GEN_QAHEAD ? NB : GEN_QAHEAD;
+  gen_f4 wv[AH];
+#pragma unroll
+  for (int u = 0; u < AH; ++u) wv[u] = ld4(w0 + stride * (unsigned)(k0 + u));
+#pragma unroll
+  for (int k = 0; k < NB; ++k) {
+    const float xk = in[k0 + k];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) z[i] = fmaf(wv[k % AH][i], xk, z[i]);
+    if (k + AH < NB) wv[k % AH] = ld4(w0 + stride * (unsigned)(k0 + k + AH));
+  }
+}
+__device__ __forceinline__ void gen_mlp_forward_quads(const GenNet& net, const float* __restrict__ PT, const float* x, float* act, int slot, int lane) {
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(PT), 0, net.n * 4, 0x00020000);
+  for (int s = 0; s < net.n_stages; ++s) {
+    const int l = slot < 3 ? gen_my_layer(net, s, slot) : -1;
+    if (l >= 0 && 4 * lane < net.layer[l].out_dim) {
+      const GenLayer& y = net.layer[l];
+      const float* in = y.in_buf < 0 ? x : act + net.layer[y.in_buf].act_off;
+      const int n_in = y.in_dim, n_out = y.out_dim;
+      const unsigned w0 = 4u * (unsigned)(y.w_off + 4 * lane), stride = 4u * (unsigned)n_out;      // bytes: PT[k * n_out + 4 lane ..]
+      gen_f4 z = __builtin_bit_cast(gen_f4, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(4u * (unsigned)(y.b_off + 4 * lane)), 0, 0));
+      int k = 0;
+      for (; k + 128 <= n_in; k += 128) gen_quads_block<128>(rs, w0, stride, in, k, z);
+      if (k + 64 <= n_in) { gen_quads_block<64>(rs, w0, stride, in, k, z); k += 64; }
+      if (k + 32 <= n_in) { gen_quads_block<32>(rs, w0, stride, in, k, z); k += 32; }
+      if (k + 16 <= n_in) { gen_quads_block<16>(rs, w0, stride, in, k, z); k += 16; }
+      if (k + 8 <= n_in) { gen_quads_block<8>(rs, w0, stride, in, k, z); k += 8; }
+      if (k + 4 <= n_in) { gen_quads_block<4>(rs, w0, stride, in, k, z); k += 4; }
+      if (k + 2 <= n_in) { gen_quads_block<2>(rs, w0, stride, in, k, z); k += 2; }
+      if (k < n_in) gen_quads_block<1>(rs, w0, stride, in, k, z);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (4 * lane + i < n_out) act[y.act_off + 4 * lane + i] = y.tanh ? fast_tanh(z[i]) : z[i];
+    }
+    __syncthreads();
+  }
+}
+
 // The action distribution on the head outputs `out` of ONE row (policies.py:716-731 forward: sample / mode, clip, log-prob; :752-767
 // evaluate_actions: `given` action, entropy).  The *_row pointers address this row (global memory or LDS), NULL = not wanted.
 __device__ __forceinline__ void gen_policy_head(const GenNet& net, const float* __restrict__ P, const float* out, const float* noise_row,

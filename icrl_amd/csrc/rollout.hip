@@ -1304,8 +1304,8 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
 
 // The persistent rollout for a generic-shape policy (hidden layers above 64 units or an `arch` descriptor; the constraint net one the
 // register image holds): the same loop, phase A's policy forward = the table-driven forward of generic.hip (gen_mlp_forward +
-// gen_policy_head: bit-identical to policy_generic_kernel, i.e. to the per-step launches) on 3 W threads — the workgroup has
-// max(256, 3 W) threads, everything but the forward runs on the first 256 as before (waves 0 / 2 / 3: env step / buffer row / cost net).
+// gen_policy_head: bit-identical to policy_generic_kernel, i.e. to the per-step launches) in its four-units-per-lane form (generic.h:
+// gen_mlp_forward_quads — waves 0..2 = the three slots of the table).
 struct GenRolloutArgs {
   PersistArgs p;
   GenNet net;
@@ -1342,7 +1342,6 @@ __device__ __forceinline__ void rollout_generic_body(const GenRolloutArgs& ga) {
   const int n = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int ctid = tid < 256 ? tid : (1 << 28);      // (the threads beyond the first 256 only take part in the forward)
-  const int g_slot = tid / net.W, g_j = tid - g_slot * net.W;
   const float* const Pn = as_global(ga.P);
   const float* const PTn = as_global(a.PT);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1396,7 +1395,7 @@ __device__ __forceinline__ void rollout_generic_body(const GenRolloutArgs& ga) {
     }
     __syncthreads();
     // ---------------- phase A: kernel A's work for env n ----------------
-    gen_mlp_forward(net, PTn, sh.x, gact, g_slot, g_j);
+    gen_mlp_forward_quads(net, PTn, sh.x, gact, w, lane);
     if (tid == 0) {
       float lp, ent;
       gen_policy_head(net, Pn, gact + net.layer[net.head[0]].act_off, noise_s, 0, has_box ? alow_s : nullptr, has_box ? ahigh_s : nullptr, nullptr,
@@ -1579,8 +1578,8 @@ __device__ __forceinline__ void rollout_generic_body(const GenRolloutArgs& ga) {
   }
 }
 
-template <int OCT, int CIT, int TH>      // TH = the launch's threads (the register budget follows it: at 768 the statistics code spills)
-__global__ void __launch_bounds__(TH) rollout_generic_kernel(GenRolloutArgs ga) {
+template <int OCT, int CIT>
+__global__ void __launch_bounds__(256) rollout_generic_kernel(GenRolloutArgs ga) {
   rollout_generic_body<OCT, CIT>(ga);
 }
 
@@ -3506,7 +3505,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
         if (e != hipSuccess) return (int)e;
         const bool small = O <= 32 && (!cn || cn->in_dim <= 32);
         const size_t dyn = persist_dyn_lds(N, O, env->act_dim);
-        const int threads = 3 * ga.net.W > 256 ? 3 * ga.net.W : 256;
+        const int threads = 256;
         auto go = [&](auto kernel) -> int {      // -1: the grid is not co-resident
           int dev = 0, cus = 0, per_cu = 0;
           if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
@@ -3516,11 +3515,7 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
           if (e_ == hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); return -1; }
           return (int)e_;
         };
-        int perr;
-        if (threads <= 256) perr = small ? go(rollout_generic_kernel<2, 2, 256>) : go(rollout_generic_kernel<8, 10, 256>);
-        else if (threads <= 384) perr = small ? go(rollout_generic_kernel<2, 2, 384>) : go(rollout_generic_kernel<8, 10, 384>);
-        else if (threads <= 576) perr = small ? go(rollout_generic_kernel<2, 2, 576>) : go(rollout_generic_kernel<8, 10, 576>);
-        else perr = small ? go(rollout_generic_kernel<2, 2, 768>) : go(rollout_generic_kernel<8, 10, 768>);
+        const int perr = small ? go(rollout_generic_kernel<2, 2>) : go(rollout_generic_kernel<8, 10>);
         if (perr >= 0) {
           const int err = perr != 0 ? perr : (int)hipGetLastError();
           if (err || !(do_gae & 1)) return err;
