@@ -90,8 +90,8 @@ typedef struct {
  * group and 1..256 units per layer (a branch without layers feeds its head from the trunk, or from the observation).  h1 / h2 are then
  * ignored and `params` holds the natural, unpadded layout in state_dict order: log_std, the trunk's layers (W[out,in] b[out] each),
  * policy_net's, value_net's, cost_value_net's, then the three heads.  Such a policy is served by icrl_policy_forward,
- * icrl_policy_evaluate, icrl_ppo_lag_train, icrl_rollout_collect(_ex) and icrl_sample_episodes (generic-shape path: plain launches,
- * per step where the fast path has one persistent launch); the *_batch entry points refuse it. */
+ * icrl_policy_evaluate, icrl_ppo_lag_train, icrl_rollout_collect(_ex) and icrl_sample_episodes (generic-shape path: one persistent launch
+ * per update / rollout / sampling call like the fast path, slower per step — DESIGN.md section 8); the *_batch entry points refuse it. */
 typedef struct {
   int32_t obs_dim, act_dim, h1, h2;
   int32_t discrete; /* 1: Categorical over act_dim logits (LGW), 0: DiagGaussian */
@@ -341,8 +341,9 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
  *            chunk of a minibatch, partial gradients exchanged as granules) unless bit 3 is set.
  * Shapes outside the persistent kernels — a policy stored with hidden width h1 = h2 > 64 (a multiple of 64 up to 256: the reference's
  * -pl / -rvl / -cvl flags take any width, icrl/utils.py:636-655), a policy described by `arch` (shared trunk, other depths) or
- * batch_size > 256 (buffers.py:594-612 slices any size) — run through the generic-shape path (csrc/generic.hip): three plain launches
- * per optimiser step, same statistics layout, no hp->_pad options; sync_ws must then hold ICRL_PPO_SYNC_BYTES(...) +
+ * batch_size > 256 (buffers.py:594-612 slices any size) — run through the generic-shape path (csrc/generic.hip): ONE persistent
+ * cooperative launch on one XCD (up to 512-row batches, 131 072 parameters, rows that fit the LDS; otherwise three plain launches per
+ * optimiser step), same statistics layout, hp->_pad & 1 only (phase timers in stats[12..28]); sync_ws must then hold ICRL_PPO_SYNC_BYTES(...) +
  * ICRL_PPO_GENERIC_BYTES(batch_size, icrl_ppo_generic_row_floats(pol), n_params) bytes. */
 int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                        const icrl_buffer_t* buf, const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp,
