@@ -6,7 +6,7 @@
 typedef float f4 __attribute__((ext_vector_type(4)));
 template <int DEPTH, int AUX, int THREADS>
 __global__ void __launch_bounds__(THREADS) stream_kernel(const float* p, int n_floats, int iters, float* out, unsigned long long* cyc) {
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, n_floats * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, n_floats * 4 + 16, 0x00020000);      // (p may be offset by 1..3 floats: the misaligned runs)
   f4 acc = f4{0.f, 0.f, 0.f, 0.f};
   const int tid = threadIdx.x;
   const int per_round = THREADS * 4 * DEPTH;      // floats per round of DEPTH loads per thread
@@ -45,8 +45,13 @@ void run(const char* name, float* d_p, int n_floats, int wgs, float* d_out, unsi
 int main() {
   const int n_floats = 57344;      // 224 KB: three 128-128 branches
   float* d_p; float* d_out; unsigned long long* d_cyc;
-  hipMalloc(&d_p, n_floats * 4); hipMemset(d_p, 0, n_floats * 4);
+  hipMalloc(&d_p, n_floats * 4 + 64); hipMemset(d_p, 0, n_floats * 4 + 64);
   hipMalloc(&d_out, 1024 * 1024 * 4); hipMalloc(&d_cyc, 4096 * 8);
+  for (int mis : {1, 2, 3}) {      // 16-byte loads whose addresses are only dword / 8-byte aligned (parameter blocks at arbitrary offsets)
+    char nm[64]; snprintf(nm, sizeof nm, "plain loads, base + %d floats", mis);
+    run<8, 0, 256>(nm, d_p + mis, n_floats - 4, 1, d_out, d_cyc);
+    run<8, 0, 256>(nm, d_p + mis, n_floats - 4, 64, d_out, d_cyc);
+  }
   for (int wgs : {1, 8, 64}) {
     run<4, 0, 256>("plain loads", d_p, n_floats, wgs, d_out, d_cyc);
     run<8, 0, 256>("plain loads", d_p, n_floats, wgs, d_out, d_cyc);
