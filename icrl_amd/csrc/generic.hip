@@ -1325,7 +1325,9 @@ __global__ void __launch_bounds__(GENP_TH) gen_train_persistent_kernel(GenNet ne
   if (packed && (blockIdx.x & (XCD_STRIDE - 1)) != 0) return;
   const int H = pp.H, wg = packed ? (int)blockIdx.x / XCD_STRIDE : (int)blockIdx.x, tid = threadIdx.x;
   for (int i = tid; i < 32 * pp.RS + GENP_FLOATS; i += GENP_TH) sm[i] = 0.f;
-  if (tid < 3 && wg < pp.G) pp.xflag[wg * 3 + tid] = 0u;
+  // (agent scope: a plain store would sit dirty in THIS XCD's L2, and on a grid spread over several XCDs the owner's polls — served by its own L2 for
+  // lines dirty there — would read that zero for ever: `ICRL_NO_XCD_PACK=1` with a shared trunk hung until this was a write-through store)
+  if (tid < 3 && wg < pp.G) __hip_atomic_store(pp.xflag + wg * 3 + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   // do all workgroups share an XCD?  (every workgroup publishes its XCC id in its norm slot, one barrier, everybody compares)
   unsigned bar_n = 0;

@@ -256,16 +256,19 @@ def test_sync_placement_tuning_leaves_no_trace(kind, N, T, B):
     assert out[0][3] in range(4) and out[1][3] is None
 
 
-def test_generic_shape_update_as_one_persistent_launch():
-    """ICRL_GEN_PERSISTENT=1: the generic-shape update as ONE cooperative launch per train() (csrc/generic.hip: row-tile workgroups, fp32 MFMA
-    tiles, three grid barriers per optimiser step) — measured slower than the three launches per step at the sizes of this suite and
-    therefore not the default — stays correct: the golden and oracle cases of the generic-shape path pass under it
-    (child process: the switch is read once per process)."""
+@pytest.mark.parametrize("switch", ["ICRL_GEN_LAUNCHES", "ICRL_GEN_BRANCH_WGS", "ICRL_NO_XCD_PACK"])
+def test_generic_shape_update_as_one_persistent_launch(switch):
+    """The generic-shape update is ONE cooperative launch per train() by default (csrc/generic.hip: one workgroup per (row tile, branch) on one
+    XCD, fp32 MFMA tiles, three grid barriers per optimiser step).  Its other forms stay correct — the golden and oracle
+    cases of the generic-shape path pass under each of them (child process: the switches are read once per process):
+    ICRL_GEN_LAUNCHES=1 three plain launches per optimiser step (the fallback of shapes the persistent form does not hold),
+    ICRL_GEN_BRANCH_WGS=1 one workgroup per row tile walking all three branches (batches above 160 rows take it anyway),
+    ICRL_NO_XCD_PACK=1 the dense grid: workgroups on several XCDs, agent-scope stores instead of the L2-local exchange."""
     import subprocess, sys
-    env = dict(os.environ, ICRL_GEN_PERSISTENT="1")
+    env = dict(os.environ, **{switch: "1"})
     sel = "g15 or g16 or g17 or g18 or hc-wide or hc-trunk or ant-deep or hc-bare or hc-8-128-512 or hc-5-200-300"
     out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"],
-                         env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+                         env=env, capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:]
 
 
