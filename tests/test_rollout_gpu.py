@@ -292,13 +292,16 @@ def test_stepped_rollout_equals_fused_rollout():
     assert a_s.num_timesteps == a_f.num_timesteps == 2 * N * T
 
 
-@pytest.mark.parametrize("kind,shape", [("hc", "wide"), ("hc", "trunk"), ("ant", "deep"), ("hc", "wide-cn"), ("ant", "deep-cn"), ("hc", "both")])
-def test_generic_shape_rollout_equals_python_loop(kind, shape):
-    """policies / constraint nets of the generic-shape path (layers above 64 units, shared trunk, other depths): icrl_rollout_collect
-    issues the reference's per-step loop itself — four launches per step, no host work in between (csrc/rollout.hip) — and must
-    leave exactly what the Python loop over the fine-grained entry points leaves (same kernels, same order)."""
+@pytest.mark.parametrize("kind,shape,N", [("hc", "wide", 12), ("hc", "trunk", 12), ("ant", "deep", 12), ("hc", "wide-cn", 12), ("ant", "deep-cn", 12), ("hc", "both", 12),
+                                          ("hc", "trunk", 64), ("ant", "deep", 33)])
+def test_generic_shape_rollout_equals_python_loop(kind, shape, N):
+    """policies / constraint nets of the generic-shape path (layers above 64 units, shared trunk, other depths): icrl_rollout_collect runs the
+    whole rollout as ONE persistent launch (rollout_generic_kernel: the one-workgroup-per-env loop around the table-driven forward with four
+    units per lane) — or, for a constraint net beyond the register image, the reference's per-step loop as four launches per step —
+    (csrc/rollout.hip) and must leave exactly what the Python loop over the fine-grained entry points leaves: every unit's value is the same
+    chain of fused multiply-adds in the same order."""
     from helpers.arches import ARCHES
-    N, T = 12, 40
+    T = 40
     net_arch = {"wide": [dict(pi=[128, 96], vf=[80, 128], cvf=[128, 128])], "both": [dict(pi=[128, 96], vf=[80, 128], cvf=[128, 128])]}.get(shape, ARCHES.get(shape))
     hid = {"wide-cn": [128, 100], "deep-cn": [48, 32, 24], "both": [64, 64, 64]}.get(shape)
     akw = dict(policy_kwargs=dict(net_arch=net_arch)) if net_arch else None
