@@ -125,6 +125,9 @@ def _oracle_train(agent_sd, buf, perms, kind, nu, okw=None, **h):
                                              # architectures beyond three two-layer branches (-sl trunk, other depths; torch_layers.py:129-254)
                                              ("hc-trunk", 8, 32, 64, 3, None), ("ant-deep", 6, 40, 128, 2, None), ("hc-trunk-only", 5, 40, 100, 2, None),
                                              ("hc-bare", 4, 30, 40, 2, None), ("hc-deep", 16, 32, 64, 6, 0.002), ("ant-trunk", 4, 100, 400, 2, None),
+                                             # the persistent generic-shape update at the edges of its workgroup layouts: ten row tiles x three branch workgroups
+                                             # (150 rows: the last tile partial), eleven tiles = one workgroup per tile, a trunk whose shares are exchanged at 144 rows
+                                             ("hc-wide", 6, 50, 150, 2, None), ("hc-wide", 7, 50, 175, 2, None), ("hc-trunk", 9, 48, 144, 2, None),
                                              # target-KL stop decided inside an Adam launch of ~3 900 workgroups: the epoch's last step is applied in full
                                              ("hc-huge", 8, 16, 64, 3, 1e-7)])
 def test_train_vs_oracle(kind, N, T, B, E, tk, one_workgroup_per_network=False):
