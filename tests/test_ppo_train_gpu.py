@@ -275,6 +275,38 @@ def test_generic_shape_update_as_one_persistent_launch(switch):
     assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:]
 
 
+@pytest.mark.parametrize("shape,B", [("wide", 64), ("trunk", 64), ("trunk", 144), ("deep", 320)])
+def test_generic_shape_update_is_reproducible(shape, B):
+    """The persistent generic-shape update sums across workgroups in fixed orders only (row tiles in tile order, the trunk's three shares in branch
+    order, fixed trees inside a workgroup): two runs from the same state leave bit-identical parameters, Adam moments and logged sums — whatever
+    order the workgroups reach the barriers in."""
+    from helpers.arches import ARCHES
+    from icrl_amd import logger
+    net_arch = [dict(pi=[128, 96], vf=[80, 128], cvf=[128, 128])] if shape == "wide" else ARCHES[shape]
+    N, T = 8, 160
+    rng = np.random.RandomState(17)
+    out = []
+    for rep in range(3):
+        agent = _agent("hc", N, T, batch_size=B, n_epochs=2, target_kl=None, learning_rate=3e-4, policy_kwargs=dict(net_arch=net_arch))
+        if rep == 0:
+            sd0 = {k: v.clone() for k, v in agent.policy.state_dict().items()}
+            data = dict(observations=rng.randn(T, N, 18), actions=rng.randn(T, N, 6), log_probs=-3 + 0.1 * rng.randn(T, N), reward_advantages=rng.randn(T, N),
+                        cost_advantages=rng.randn(T, N), reward_returns=rng.randn(T, N), cost_returns=rng.randn(T, N), reward_values=rng.randn(T, N),
+                        cost_values=rng.randn(T, N), orig_costs=np.abs(rng.randn(T, N)))
+            perms = np.stack([np.random.RandomState(3 + e).permutation(N * T) for e in range(2)])
+        agent.policy.load_state_dict(sd0)
+        _fill(agent, data)
+        agent.train(perms=perms)
+        lg = logger.Logger.CURRENT.name_to_value
+        out.append(({k: v.clone() for k, v in agent.policy.state_dict().items()}, agent.policy.exp_avg.clone().cpu(), agent.policy.exp_avg_sq.clone().cpu(),
+                    {k: float(v) for k, v in lg.items() if k.startswith("train/")}))
+    for rep in (1, 2):
+        for k in out[0][0]:
+            assert torch.equal(out[0][0][k], out[rep][0][k]), (rep, k)
+        assert torch.equal(out[0][1], out[rep][1]) and torch.equal(out[0][2], out[rep][2]) and out[0][3] == out[rep][3]
+    assert any(float((out[0][0][k] - sd0[k]).abs().max()) > 0 for k in sd0)
+
+
 @pytest.mark.parametrize("tk", [None, 1e-6, 0.02])
 def test_epochwise_update_equals_single_launch(tk):
     """PPOLagrangian._train_epochwise (rollouts of >= LAZY_PERM_ROWS rows: one launch per epoch, the next epoch's np.random.permutation
