@@ -691,13 +691,25 @@ __device__ __forceinline__ void genp_arrive(unsigned* bar) {
 }
 // (the L1 is invalidated behind every wait: an sc0 load is a workgroup-scope load — it MAY be served by the compute unit's L1, and was, with
 // the previous step's parameters, once a network was small enough to stay there: measured, test hc-bare)
-__device__ __forceinline__ void genp_wait(unsigned* bar, unsigned target) {
-  if (threadIdx.x == 0)
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) __builtin_amdgcn_s_sleep(1);
+// A wait gives up after GENP_SPIN_LIMIT polls (~10 s: a workgroup that never arrives — only a defect could cause that, the launch is cooperative —
+// must cost a reported error, not a hung GPU) or as soon as another workgroup has given up (the word behind the counter); everybody then leaves the step
+// loop and stats[11] tells the host, which raises like for the other persistent kernels.
+constexpr int GENP_SPIN_LIMIT = 1 << 24;
+__device__ __forceinline__ bool genp_wait(unsigned* bar, unsigned target, int* ok_lds) {
+  if (threadIdx.x == 0) {
+    int ok = 1, spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > GENP_SPIN_LIMIT || ((spins & 1023) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) { ok = 0; break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (!ok) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *ok_lds = ok;
+  }
   __syncthreads();
+  return *ok_lds != 0;
 }
 template <bool LOCAL>
-__device__ __forceinline__ void genp_grid_barrier(unsigned* bar, unsigned target) { genp_arrive<LOCAL>(bar); genp_wait(bar, target); }
+__device__ __forceinline__ bool genp_grid_barrier(unsigned* bar, unsigned target, int* ok_lds) { genp_arrive<LOCAL>(bar); return genp_wait(bar, target, ok_lds); }
 
 // three sums over the workgroup at once: fixed tree (wave sums by DPP, then the eight in order): every workgroup forms the same values
 __device__ __forceinline__ void genp_block_sum3(float& a, float& b, float& c, float* red24) {
@@ -754,7 +766,7 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
   float acc_ent = 0.f, acc_pg = 0.f, acc_cf = 0.f, acc_vr = 0.f, acc_vc = 0.f, last_pol = 0.f, last_vr = 0.f, last_vc = 0.f, kl_acc = 0.f, mean_kl = 0.f;
   int steps_done = 0, early_stop_epoch = a.hp.n_epochs;
   const float nu = a.nu[0];
-  bool stop = false;
+  bool stop = false, aborted = false;
   const bool prof = (a.hp._pad & 1) != 0 && wg == 0;       // phase timers of workgroup 0, thread 0 (tools/generic_only.py PROF=1): stats[12..21]
   unsigned long long* const PH = reinterpret_cast<unsigned long long*>(IW + GENP_INTS);      // [16] cycles per phase (in LDS: 34 scalar registers otherwise); 10..15: parts of the phases before them (stats[23..28])
   unsigned long long t_last = prof ? stamp() : 0ull;
@@ -1104,8 +1116,13 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
             }
             const int* row = T.LT + 8 * trunk_last;
             if (((SU(row[6]) >> 1) & 3) == 3) {
-              if (tid < 3)
-                while (__hip_atomic_load(pp.xflag + g * 3 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(st + 1)) __builtin_amdgcn_s_sleep(1);
+              if (tid < 3) {
+                int spins = 0;
+                while (__hip_atomic_load(pp.xflag + g * 3 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(st + 1)) {
+                  if (++spins > GENP_SPIN_LIMIT) { __hip_atomic_store(pp.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // (the next barrier ends the launch)
+                  __builtin_amdgcn_s_sleep(1);
+                }
+              }
               __syncthreads();
                           const int nl = SU(row[1]), lcol = SU(row[5]), WT = pp.WTP;
               for (int idx = tid; idx < 4 * WT; idx += GENP_TH) {
@@ -1200,7 +1217,7 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
     bar_n += H; genp_arrive<LOCAL>(pp.bar);
     GSUB(14)  // (arrival at A)
     if (tile_wg) rows_issue1(pn);      // (the next minibatch's rows, under the barriers: first round trip — the row offsets)
-    genp_wait(pp.bar, bar_n);          // (A) every tile's partials are in memory
+    if (!genp_wait(pp.bar, bar_n, T.MISC + 15)) { aborted = true; break; }          // (A) every tile's partials are in memory
     GSTAMP(5)   // barrier A
     // ================= this workgroup's parameter slice: sum over the tiles in tile order, squared norm =================
     // (elements lo + 4 tid .. + 3 stay in registers until Adam; a slice above 2 048 parameters walks the rest through `grad`)
@@ -1239,7 +1256,7 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
     GSTAMP(6)   // reduce + norm
     bar_n += H; genp_arrive<LOCAL>(pp.bar);
     GSUB(10)  // (arrival at B)
-    genp_wait(pp.bar, bar_n);          // (B) every slice's squared norm is in memory
+    if (!genp_wait(pp.bar, bar_n, T.MISC + 15)) { aborted = true; break; }          // (B) every slice's squared norm is in memory
     GSTAMP(7)   // barrier B
     float total = 0.f, q7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     {   // every tile's loss sums and every slice's squared norm fetched side by side (one value per thread), summed by fixed trees;
@@ -1303,7 +1320,7 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
     GSUB(12)  // (arrival at C)
     if (tile_wg) rows_commit(pn);      // (into the image)
     GSUB(13)  // (the rows in the image)
-    genp_wait(pp.bar, bar_n);          // (C) the updated parameters are in memory
+    if (!genp_wait(pp.bar, bar_n, T.MISC + 15)) { aborted = true; break; }          // (C) the updated parameters are in memory
     GSTAMP(9)   // barrier C
   }
   if (prof && tid == 0) a.stats[22] = LOCAL ? 1.f : 0.f;
@@ -1313,7 +1330,7 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
     a.stats[0] = (float)early_stop_epoch;
     a.stats[1] = (float)steps_done;
     a.stats[2] = acc_ent; a.stats[3] = acc_pg; a.stats[4] = acc_vr; a.stats[5] = acc_vc; a.stats[6] = acc_cf;
-    a.stats[7] = mean_kl; a.stats[8] = last_pol; a.stats[9] = last_vr; a.stats[10] = last_vc; a.stats[11] = 0.f;
+    a.stats[7] = mean_kl; a.stats[8] = last_pol; a.stats[9] = last_vr; a.stats[10] = last_vc; a.stats[11] = aborted ? 1.f : 0.f;
     const_cast<int*>(a.adam_t)[0] += steps_done;
   }
 }
@@ -1332,11 +1349,15 @@ __global__ void __launch_bounds__(GENP_TH) gen_train_persistent_kernel(GenNet ne
   // do all workgroups share an XCD?  (every workgroup publishes its XCC id in its norm slot, one barrier, everybody compares)
   unsigned bar_n = 0;
   if (tid == 0) __hip_atomic_store(pp.norm + wg, __uint_as_float(0x100u | xcc_id()), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  bar_n += H; genp_grid_barrier<false>(pp.bar, bar_n);
+  int* const ok_lds = reinterpret_cast<int*>(sm + 32 * pp.RS + GENP_FLOATS - 33);      // (an int of the table region the body does not use before its own first barrier: MISC is rebuilt there)
+  bar_n += H;
+  const bool ok1 = genp_grid_barrier<false>(pp.bar, bar_n, ok_lds);
   bool local = true;
   for (int t = 0; t < H; ++t) local = local && __float_as_uint(ld_sc1(pp.norm + t)) == (0x100u | xcc_id());
   local = __builtin_amdgcn_readfirstlane((int)local) != 0;
-  bar_n += H; genp_grid_barrier<false>(pp.bar, bar_n);      // (the slots are reused by the first step's norms)
+  bar_n += H;
+  const bool ok2 = genp_grid_barrier<false>(pp.bar, bar_n, ok_lds);      // (the slots are reused by the first step's norms)
+  if (!(ok1 && ok2)) { if (wg == 0 && tid == 0) { a.stats[0] = (float)a.hp.n_epochs; a.stats[1] = 0.f; a.stats[11] = 1.f; } return; }
   if (local) genp_body<true>(net, a, pp, wg, sm, bar_n);
   else genp_body<false>(net, a, pp, wg, sm, bar_n);
 }
