@@ -343,7 +343,7 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
  * -pl / -rvl / -cvl flags take any width, icrl/utils.py:636-655), a policy described by `arch` (shared trunk, other depths) or
  * batch_size > 256 (buffers.py:594-612 slices any size) — run through the generic-shape path (csrc/generic.hip): ONE persistent
  * cooperative launch on one XCD (up to 512-row batches, 131 072 parameters, rows that fit the LDS; otherwise three plain launches per
- * optimiser step), same statistics layout, hp->_pad & 1 only (phase timers in stats[12..28]); sync_ws must then hold ICRL_PPO_SYNC_BYTES(...) +
+ * optimiser step), same statistics layout, of hp->_pad only bit 0 (phase timers in stats[12..28]) and bit 6 (tests: one workgroup leaves, the bounded waits must end the launch with stats[11] set); sync_ws must then hold ICRL_PPO_SYNC_BYTES(...) +
  * ICRL_PPO_GENERIC_BYTES(batch_size, icrl_ppo_generic_row_floats(pol), n_params) bytes. */
 int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step,
                        const icrl_buffer_t* buf, const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp,

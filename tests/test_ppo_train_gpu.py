@@ -307,6 +307,23 @@ def test_generic_shape_update_is_reproducible(shape, B):
     assert any(float((out[0][0][k] - sd0[k]).abs().max()) > 0 for k in sd0)
 
 
+def test_generic_shape_update_reports_a_workgroup_that_never_arrives():
+    """Every wait of the persistent generic-shape update is bounded: with hp._pad & 64 the last workgroup leaves before the first optimiser step, the
+    others give up at the first grid barrier and the launch ENDS (no hung GPU) with the status word set — the host raises like for the other persistent kernels."""
+    from helpers.arches import ARCHES
+    agent = _agent("hc", 8, 32, batch_size=64, n_epochs=2, target_kl=None, policy_kwargs=dict(net_arch=ARCHES["trunk"]))
+    rng = np.random.RandomState(2)
+    T, N = 32, 8
+    _fill(agent, dict(observations=rng.randn(T, N, 18), actions=rng.randn(T, N, 6), log_probs=-3 + 0.1 * rng.randn(T, N), reward_advantages=rng.randn(T, N),
+                      cost_advantages=rng.randn(T, N), reward_returns=rng.randn(T, N), cost_returns=rng.randn(T, N), reward_values=rng.randn(T, N),
+                      cost_values=rng.randn(T, N), orig_costs=np.abs(rng.randn(T, N))))
+    agent.profile_phases = 64
+    with pytest.raises(RuntimeError, match="timed out"):
+        agent.train()
+    agent.profile_phases = 0
+    agent.train()      # the next launch is sound
+
+
 @pytest.mark.parametrize("tk", [None, 1e-6, 0.02])
 def test_epochwise_update_equals_single_launch(tk):
     """PPOLagrangian._train_epochwise (rollouts of >= LAZY_PERM_ROWS rows: one launch per epoch, the next epoch's np.random.permutation
