@@ -1374,11 +1374,10 @@ __global__ void ppo_plan_kernel(const int* adam_t, int n_steps, int n_mb, int n_
 
 // the persistent form, when the shape allows it: 0 launched | < 0 not eligible (the caller uses the launch-per-phase form) | > 0 error
 static int launch_train_generic_persistent(const GenNet& net, GenArgs& a, const icrl_ppo_hyper_t* hp, int32_t* adam_step, void* sync_ws, hipStream_t s) {
-  static const bool on = getenv("ICRL_GEN_PERSISTENT") != nullptr, off = getenv("ICRL_GEN_LAUNCHES") != nullptr;
+  static const bool off = getenv("ICRL_GEN_LAUNCHES") != nullptr;      // A/B and tests: the three-launches-per-step form
   static const char* nbr_env = getenv("ICRL_GEN_BRANCH_WGS");      // A/B: "1" keeps one workgroup per row tile
   const int B = hp->batch_size, G = (B + 15) / 16, n = net.n;
   if (off || G > GENP_MAX_TILES || n > GENP_MAX_PARAMS || B > NB_MASK) return -1;
-  (void)on;
   GenPersist pp;
   pp.OB = (net.O + 15) / 16 * 16;
   const long long n_steps = (long long)hp->n_epochs * a.n_mb;
