@@ -125,7 +125,8 @@ class PPOLagrangian:
         if not isinstance(env, VecNormalizeWithCost):
             return None
         # (a policy / constraint net of the generic-shape path — layers above 64 units, shared trunk, other depths — takes the same entry
-        # point; the library then issues the reference's per-step loop as four launches per step, csrc/rollout.hip)
+        # point; the library then runs the rollout as one persistent launch around the table-driven forward — or, for a constraint net beyond
+        # two layers of 64 units, the reference's per-step loop as four launches per step —, csrc/rollout.hip)
         cw = env.venv
         if isinstance(cw, HipSynthVecEnv):           # no cost wrapper in the chain (the GAIL baseline, icrl/gail.py:50-59): costs are 0
             return env, None, cw

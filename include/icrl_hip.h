@@ -242,8 +242,9 @@ int icrl_costnet_prepare(const icrl_costnet_t* cn, void* stream);
  * clipped to [low,high] (on_policy_algorithm.py:381-382; NULL low/high: no clipping).  Any output may be NULL.
  * Policies stored with h1 = h2 > 64 (a multiple of 64 up to 256; obs up to 1024) or described by `arch` run the generic-shape kernel
  * here and in icrl_policy_evaluate (it reads the per-layer transposes icrl_policy_prepare leaves in params_t); icrl_rollout_collect(_ex)
- * then issues the reference's per-step loop itself (policy forward, constraint-net cost, env step, normaliser: four launches per
- * step, the same for a constraint net above 64 units / two layers) and icrl_sample_episodes runs its episode loop with that forward;
+ * then runs the whole rollout as ONE persistent launch around that forward (up to 128 envs with a constraint net of at most two layers
+ * of 64 units; otherwise the reference's per-step loop as four launches per step: policy forward, constraint-net cost, env step,
+ * normaliser) and icrl_sample_episodes runs its episode loop with that forward;
  * the *_batch entry points refuse such shapes with a message. */
 int icrl_policy_forward(const icrl_policy_t* pol, const double* obs, const float* noise, int N, int deterministic,
                         const float* action_low, const float* action_high,

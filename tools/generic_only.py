@@ -30,4 +30,4 @@ for name, kw, B in (("-pl 128 128 -rvl 128 128 -cvl 128 128, batch 64", dict(pol
         agent.profile_phases = 1; agent.train(); torch.cuda.synchronize(); agent.profile_phases = 0
         st_ = agent._train_ws["stats"].cpu().numpy()
         print("   cycles per step of workgroup 0: rows+stats | fwd | loss | bwd | wgrad | barrier A | reduce | barrier B | adam | barrier C:", np.round(st_[12:22]), "one XCD:", bool(st_[22]), "| of them: arrive B + rows | sums + operands | arrive C | rows commit | arrive A:", np.round(st_[23:28]))
-    print(f"{name}: rollout {1e6 * t_roll / T:.0f} us per {N}-env step ({'four launches per step inside icrl_rollout_collect' if agent.policy.wide else 'fused'}; the Python loop over the fine-grained entry points: {1e6 * t_py / T:.0f}), update {1e6 * dt / steps:.1f} us per optimiser step ({steps} steps)")
+    print(f"{name}: rollout {1e6 * t_roll / T:.0f} us per {N}-env step ({'rollout_generic_kernel: one persistent launch' if agent.policy.wide else 'fused'}; the Python loop over the fine-grained entry points: {1e6 * t_py / T:.0f}), update {1e6 * dt / steps:.1f} us per optimiser step ({steps} steps)")
