@@ -23,6 +23,7 @@ SIGNATURES = {
     "icrl_gae_dual": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_void_p],
     "icrl_gae_dual_ex": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_int, c_void_p],
     "icrl_gae_dual_ws": [c_void_p] * 12 + [c_int, c_int] + [c_double] * 4 + [c_int, c_void_p, ctypes.c_longlong, c_void_p],
+    "icrl_gae_dual_ws_bytes": [c_int, c_int],
     "icrl_policy_prepare": [c_void_p, c_void_p],
     "icrl_costnet_prepare": [c_void_p, c_void_p],
     "icrl_policy_forward": [c_void_p, c_void_p, c_void_p, c_int, c_int] + [c_void_p] * 8,
@@ -50,6 +51,7 @@ SIGNATURES = {
     "icrl_adv_stats": [c_void_p, c_void_p, c_int, c_void_p, c_void_p],
     "icrl_ppo_lag_loss_fwd_bwd": [c_void_p] * 13 + [c_int] + [c_void_p] * 6,
     "icrl_clip_adam_step": [c_void_p] * 5 + [ctypes.c_longlong, c_void_p, c_void_p, c_void_p, c_void_p],
+    "icrl_explained_variance": [c_void_p] * 4 + [ctypes.c_longlong, c_void_p, c_void_p, c_void_p],
     "icrl_dual_step": [c_void_p, c_void_p, c_void_p, c_float, c_float, c_float, c_float, c_void_p, c_void_p],
     "icrl_buffer_add": [c_void_p, c_int] + [c_void_p] * 13,
     "icrl_is_weights": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p],
@@ -64,7 +66,7 @@ SIGNATURES = {
     "icrl_ppo_lag_train_batch": [c_int, c_void_p, c_void_p, ctypes.c_longlong, c_void_p],
 }
 BATCH_ARGS_BYTES = 1024      # ICRL_BATCH_ARGS_BYTES
-RESTYPES = {"icrl_cn_train_work_floats": ctypes.c_size_t, "icrl_last_error": ctypes.c_char_p, "icrl_clear_error": None}
+RESTYPES = {"icrl_cn_train_work_floats": ctypes.c_size_t, "icrl_gae_dual_ws_bytes": ctypes.c_size_t, "icrl_last_error": ctypes.c_char_p, "icrl_clear_error": None}
 
 
 class HipExtensionMissing(RuntimeError):

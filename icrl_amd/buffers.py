@@ -42,8 +42,9 @@ class RolloutBufferWithCost:
         self.actions = torch.zeros(T, N, self.action_dim, device=dev)
         for k in _SCALARS:
             setattr(self, k, torch.zeros(T, N, device=dev))
-        from .structs import GAE_WS_BYTES
-        self.gae_ws = torch.zeros(GAE_WS_BYTES // 8 + 1, dtype=torch.int64, device=dev)      # written by GAE launches only
+        # workspace of the GAE launch (icrl_gae_dual_ws): written by GAE launches only; its last 4 bytes are the launch's status word
+        self.gae_ws = torch.zeros(int(_lib.lib().icrl_gae_dual_ws_bytes(T, N)) // 8, dtype=torch.int64, device=dev)
+        self.gae_status = self.gae_ws.view(torch.int32)[-1:]
         self.pos, self.full, self.generator_ready = 0, False, False
 
     def struct(self):
@@ -91,6 +92,12 @@ class RolloutBufferWithCost:
             self.buffer_size, self.n_envs, float(self.reward_gamma), float(self.reward_gae_lambda), float(self.cost_gamma),
             float(self.cost_gae_lambda), int(getattr(self, "gae_shape", 0)), p(self.gae_ws), self.gae_ws.numel() * 8,
             _lib.current_stream()), "icrl_gae_dual")
+
+    def check_gae_status(self):
+        """raise if a GAE launch reported an expired wait (a workgroup's map never arrived): advantages / returns are then invalid."""
+        if int(self.gae_status.item()) != 0:
+            self.gae_status.zero_()
+            raise RuntimeError("icrl_gae_dual: a wait for another workgroup's affine map expired; advantages and returns are invalid")
 
     # ---- reference-compatible sampling ---------------------------------------------------------------------------------
     def env_major(self, name):

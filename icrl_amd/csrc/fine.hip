@@ -149,6 +149,57 @@ __global__ void __launch_bounds__(256) clip_adam_kernel(float* p, const float* _
   }
 }
 
+// common/utils.py:43-59 explained_variance(y_pred, y_true) = 1 - Var[y_true - y_pred] / Var[y_true] (nan when Var[y_true] == 0) for up to two
+// (y_pred, y_true) pairs of n floats in one pass: float64 sums of y, y^2, d, d^2 per block -> part[block][8], then one block folds them.
+__device__ __forceinline__ double block_sum_256d(double v, double* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ void __launch_bounds__(256) ev_partials_kernel(const float* __restrict__ pa, const float* __restrict__ ta, const float* __restrict__ pb,
+                                                          const float* __restrict__ tb, long long n, double* part) {
+  __shared__ double red[256];
+  double q[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const double ya = (double)ta[i], da = ya - (double)pa[i];
+    q[0] += ya; q[1] += ya * ya; q[2] += da; q[3] += da * da;
+    if (pb != nullptr) {
+      const double yb = (double)tb[i], db = yb - (double)pb[i];
+      q[4] += yb; q[5] += yb * yb; q[6] += db; q[7] += db * db;
+    }
+  }
+  for (int k = 0; k < 8; ++k) {
+    const double r = block_sum_256d(q[k], red);
+    if (threadIdx.x == 0) part[(size_t)blockIdx.x * 8 + k] = r;
+  }
+}
+
+__global__ void __launch_bounds__(256) ev_final_kernel(const double* __restrict__ part, int n_part, long long n, int pairs, float* out) {
+  __shared__ double red[256];
+  __shared__ double tot[8];
+  for (int k = 0; k < 8; ++k) {
+    double s = 0.;
+    for (int i = threadIdx.x; i < n_part; i += 256) s += part[(size_t)i * 8 + k];
+    const double r = block_sum_256d(s, red);
+    if (threadIdx.x == 0) tot[k] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x < pairs) {
+    const double* t = tot + 4 * threadIdx.x;
+    const double inv = 1.0 / (double)n, my = t[0] * inv, md = t[2] * inv;
+    const double var_y = t[1] * inv - my * my, var_d = t[3] * inv - md * md;
+    out[threadIdx.x] = var_y > 0.0 ? (float)(1.0 - var_d / var_y) : __builtin_nanf("");
+  }
+}
+
 __global__ void bump_step_kernel(int* adam_t) { adam_t[0] += 1; }
 
 // dual_variable.py:9-57 in float32: state = {log_nu, exp_avg, exp_avg_sq, nu (output)}, t = Adam step count
@@ -327,6 +378,17 @@ extern "C" int icrl_clip_adam_step(float* params, const float* grads, float* exp
   hipLaunchKernelGGL(sqnorm_partials_kernel, dim3(blocks), dim3(256), 0, s, grads, n, work);
   hipLaunchKernelGGL(clip_adam_kernel, dim3(blocks), dim3(256), 0, s, params, grads, exp_avg, exp_avg_sq, adam_step, n, *hp, work, blocks, out2);
   hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, adam_step);
+  return (int)hipGetLastError();
+}
+
+extern "C" int icrl_explained_variance(const float* y_pred_a, const float* y_true_a, const float* y_pred_b, const float* y_true_b, long long n,
+                                       double* work, float* out2, void* stream) {
+  if (n < 1 || !y_pred_a || !y_true_a || !work || !out2 || ((y_pred_b == nullptr) != (y_true_b == nullptr)))
+    return fail("icrl_explained_variance: n = %lld, NULL argument (the second pair may be NULL as a whole; work: 8 x 256 doubles)", n);
+  const int blocks = (int)((n + 255) / 256 < 256 ? (n + 255) / 256 : 256);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ev_partials_kernel, dim3(blocks), dim3(256), 0, s, y_pred_a, y_true_a, y_pred_b, y_true_b, n, work);
+  hipLaunchKernelGGL(ev_final_kernel, dim3(1), dim3(256), 0, s, work, blocks, n, y_pred_b != nullptr ? 2 : 1, out2);
   return (int)hipGetLastError();
 }
 

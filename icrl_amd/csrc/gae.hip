@@ -204,7 +204,10 @@ __global__ void __launch_bounds__(64 * W * G) gae_dual_kernel(GaeArgs a) {
 constexpr int SPLIT_W = 8;         // waves per workgroup
 constexpr int SPLIT_CMAX = 16;     // workgroups per column tile
 
-__device__ __forceinline__ void gae_dual_split_body(const GaeArgs& a, int C, unsigned tag, double* maps, unsigned* flags) {
+constexpr unsigned GAE_SPIN_LIMIT = 1u << 22;   // polls of ~1 us each: seconds, never reached by a healthy launch
+
+__device__ __forceinline__ void gae_dual_split_body(const GaeArgs& a, int C, unsigned tag, double* maps, unsigned* flags, unsigned* status = nullptr,
+                                                    unsigned spin_limit = GAE_SPIN_LIMIT, int fault = 0) {
   constexpr int W = SPLIT_W, U = U_DEFAULT;
   __shared__ double own[W][4][64];
   __shared__ double ext[SPLIT_CMAX - 1][4][64];
@@ -229,7 +232,7 @@ __device__ __forceinline__ void gae_dual_split_body(const GaeArgs& a, int C, uns
   own[wave][2][lane] = s.Pc;
   own[wave][3][lane] = s.Ac;
   __syncthreads();
-  if (wave == 0 && c > 0) {                            // the map of rows [wt0, wt1): needed by the chunks before it
+  if (wave == 0 && c > 0 && !(fault && c == C - 1)) {  // the map of rows [wt0, wt1): needed by the chunks before it (fault: test injection, never published)
     double Pr = 1.0, Qr = 0.0, Pc = 1.0, Qc = 0.0;
     for (int w = W - 1; w >= 0; --w) {
       Qr = own[w][1][lane] + own[w][0][lane] * Qr;  Pr = own[w][0][lane] * Pr;
@@ -240,7 +243,11 @@ __device__ __forceinline__ void gae_dual_split_body(const GaeArgs& a, int C, uns
     __hip_atomic_store(&flags[tile * C + c], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // wave-wide release: after every lane's stores
   }
   for (int j = c + 1 + wave; j < C; j += W) {
-    while (__hip_atomic_load(&flags[tile * C + j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) __builtin_amdgcn_s_sleep(1);
+    unsigned polls = 0;                                // bounded like every other wait of the library (include/icrl_hip.h): a chunk that never
+    while (__hip_atomic_load(&flags[tile * C + j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != tag) {   // arrives ends the wait with the status word set
+      if (++polls >= spin_limit) { if (lane == 0 && status != nullptr) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
     const double* m = maps + (size_t)(tile * C + j) * 256;
 #pragma unroll
     for (int k = 0; k < 4; ++k) ext[j - c - 1][k][lane] = m[k * 64 + lane];
@@ -260,19 +267,168 @@ __device__ __forceinline__ void gae_dual_split_body(const GaeArgs& a, int C, uns
   if (t0 < t1) walk_chunk<true, U, false>(a, n, live, t0, t1, s);
 }
 
-__global__ void __launch_bounds__(64 * SPLIT_W) gae_dual_split_kernel(GaeArgs a, int C, unsigned tag, double* maps, unsigned* flags) {
-  gae_dual_split_body(a, C, tag, maps, flags);
+__global__ void __launch_bounds__(64 * SPLIT_W) gae_dual_split_kernel(GaeArgs a, int C, unsigned tag, double* maps, unsigned* flags, unsigned* status,
+                                                                      unsigned spin_limit, int fault) {
+  gae_dual_split_body(a, C, tag, maps, flags, status, spin_limit, fault);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// REGISTER-RESIDENT split scan (round 6): the mid range between the cache-resident loop sizes and the streaming shapes (and the loop
+// sizes themselves).  One wave per tile has too few bytes in flight below ~65 536 envs (Little's law: 128 tiles x 20 KB against the
+// ~10 MB 8 TB/s needs) and the two-pass split above re-reads its chunk.  Here a workgroup of 8 waves owns 128 rows of one column
+// tile and every wave keeps its 16 rows x 5 arrays IN REGISTERS (80 VGPRs) between the two passes, so every byte is read ONCE:
+//   load 16 rows (all 80 loads issued back to back) -> the chunk's affine map from registers -> level 1 through LDS -> wave 0
+//   publishes the workgroup's map (write-through stores, `s_waitcnt vmcnt(0)`, one relaxed agent-scope flag: no release fence — a
+//   `buffer_wbl2` per workgroup under a streaming grid costs microseconds) -> the maps of the LATER chunks are polled (bounded) and read
+//   with agent-scope loads -> replay from registers, outputs stored once.
+// grid = tiles x ceil(T / 128) workgroups (2 048 .. 16 384 for 8 192 .. 65 536 envs at T = 2048); a workgroup only waits for lower
+// blockIdx (later rows), so the grid need not be co-resident.  Re-association as for the split scan above (<= 1 float32 ulp).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int RS_W = 8, RS_R = 16, RS_TC = RS_W * RS_R;
+constexpr int RS_CMAX = 16;      // T <= 2048
+
+struct HeadRegs {
+  float rew, cost, vr, vc, d, lvr, lvc;
+  int ld;
+};
+
+template <bool NT>
+__device__ __forceinline__ void rs_head_load(const GaeArgs& a, unsigned n, int t1, HeadRegs& h) {
+  if (t1 == a.T) {
+    const size_t off = (size_t)(a.T - 1) * a.N + n;
+    h.rew = ldg<NT>(a.r + off); h.cost = ldg<NT>(a.c + off); h.vr = ldg<NT>(a.vr + off); h.vc = ldg<NT>(a.vc + off); h.d = ldg<NT>(a.d + off);
+    h.lvr = a.lvr[n]; h.lvc = a.lvc[n]; h.ld = a.ld[n];
+  } else {                                           // row t1 belongs to the next wave / workgroup, which streams it too: plain loads
+    const size_t off = (size_t)t1 * a.N + n;
+    h.vr = a.vr[off]; h.vc = a.vc[off]; h.d = a.d[off];
+  }
+}
+
+// walk_chunk's head on values held in registers: row T - 1 bootstraps from the last values (`1.0 - last_dones(bool)` is float64 in the
+// reference, buffers.py:530-531), every other chunk starts from row t1's values
+template <bool WRITE, bool NT>
+__device__ __forceinline__ void rs_head_apply(const GaeArgs& a, unsigned n, bool live, int t1, const HeadRegs& h, Carry& s) {
+  if (t1 == a.T) {
+    const double nnt = 1.0 - (h.ld ? 1.0 : 0.0);
+    const float gvr = a.g_r * h.lvr;
+    const float gvc = a.g_c * h.lvc;
+    s.Ar = ((double)h.rew + (double)gvr * nnt) - (double)h.vr;
+    s.Ac = ((double)h.cost + (double)gvc * nnt) - (double)h.vc;
+    if (WRITE) {
+      if (live) {
+        const size_t off = (size_t)(a.T - 1) * a.N + n;
+        const float fr = (float)s.Ar, fc = (float)s.Ac;
+        stg<NT>(a.ar + off, fr); stg<NT>(a.ac + off, fc); stg<NT>(a.rr + off, fr + h.vr); stg<NT>(a.rc + off, fc + h.vc);
+      }
+    } else {
+      s.Pr = 0.0;
+      s.Pc = 0.0;
+    }
+  }
+  s.vr_next = h.vr;
+  s.vc_next = h.vc;
+  s.d_next = h.d;
+}
+
+template <bool NT>
+__device__ __forceinline__ void gae_dual_regsplit_body(const GaeArgs& a, int C, unsigned tag, double* maps, unsigned* flags, unsigned* status,
+                                                       unsigned spin_limit, int fault) {
+  __shared__ double own[RS_W][4][64];
+  __shared__ double ext[RS_CMAX - 1][4][64];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tile = blockIdx.x / C;
+  const int c = C - 1 - (blockIdx.x - tile * C);       // time chunk of this workgroup: latest rows first
+  const int col = tile * 64 + lane;
+  const bool live = col < a.N;
+  const unsigned n = live ? col : a.N - 1;
+  const int wt0 = c * RS_TC, wt1 = wt0 + RS_TC < a.T ? wt0 + RS_TC : a.T;
+  const int t0 = wt0 + wave * RS_R < wt1 ? wt0 + wave * RS_R : wt1;
+  const int t1 = t0 + RS_R < wt1 ? t0 + RS_R : wt1;
+  const bool any = t0 < t1;
+  const int tb = t1 == a.T ? t1 - 2 : t1 - 1;          // first row of the register batch (row T - 1 is the head)
+  Carry s;
+  s.Ar = 0.0; s.Ac = 0.0; s.Pr = 1.0; s.Pc = 1.0;
+  s.vr_next = 0.f; s.vc_next = 0.f; s.d_next = 0.f;
+  HeadRegs h = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0};
+  Batch<RS_R> b;
+  if (any) {
+    if (tb >= t0) load_batch<RS_R, NT>(a, n, tb, t0, b);
+    rs_head_load<NT>(a, n, t1, h);
+    rs_head_apply<false, NT>(a, n, live, t1, h, s);
+    if (tb >= t0) run_batch<false, RS_R, NT>(a, n, live, tb, t0, b, s);
+  }
+  own[wave][0][lane] = s.Pr;
+  own[wave][1][lane] = s.Ar;
+  own[wave][2][lane] = s.Pc;
+  own[wave][3][lane] = s.Ac;
+  __syncthreads();
+  typedef unsigned long long u64;
+  if (wave == 0 && c > 0 && !(fault && c == C - 1)) {  // the map of rows [wt0, wt1) for the chunks before it (fault: test injection)
+    double Pr = 1.0, Qr = 0.0, Pc = 1.0, Qc = 0.0;
+    for (int w = RS_W - 1; w >= 0; --w) {
+      Qr = own[w][1][lane] + own[w][0][lane] * Qr;  Pr = own[w][0][lane] * Pr;
+      Qc = own[w][3][lane] + own[w][2][lane] * Qc;  Pc = own[w][2][lane] * Pc;
+    }
+    u64* m = reinterpret_cast<u64*>(maps + (size_t)(tile * C + c) * 256);
+    __hip_atomic_store(m + lane, (u64)__double_as_longlong(Pr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // write-through (sc1) stores
+    __hip_atomic_store(m + 64 + lane, (u64)__double_as_longlong(Qr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(m + 128 + lane, (u64)__double_as_longlong(Pc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(m + 192 + lane, (u64)__double_as_longlong(Qc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every lane's stores acknowledged, then ONE flag
+    if (lane == 0) __hip_atomic_store(&flags[tile * C + c], tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  for (int j = c + 1 + wave; j < C; j += RS_W) {
+    unsigned polls = 0;
+    while (__hip_atomic_load(&flags[tile * C + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != tag) {
+      if (++polls >= spin_limit) { if (lane == 0 && status != nullptr) __hip_atomic_store(status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    const u64* m = reinterpret_cast<const u64*>(maps + (size_t)(tile * C + j) * 256);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)                          // agent-scope (L1-bypassing) loads: the bytes were stored write-through
+      ext[j - c - 1][k][lane] = __longlong_as_double((long long)__hip_atomic_load(m + k * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+  __syncthreads();
+  double Ar = 0.0, Ac = 0.0;
+  for (int j = C - 1; j > c; --j) {
+    Ar = ext[j - c - 1][1][lane] + ext[j - c - 1][0][lane] * Ar;
+    Ac = ext[j - c - 1][3][lane] + ext[j - c - 1][2][lane] * Ac;
+  }
+  for (int w = RS_W - 1; w > wave; --w) {
+    Ar = own[w][1][lane] + own[w][0][lane] * Ar;
+    Ac = own[w][3][lane] + own[w][2][lane] * Ac;
+  }
+  if (any) {
+    s.Ar = Ar;
+    s.Ac = Ac;
+    rs_head_apply<true, NT>(a, n, live, t1, h, s);
+    if (tb >= t0) run_batch<true, RS_R, NT>(a, n, live, tb, t0, b, s);
+  }
+}
+
+template <bool NT>
+__global__ void __launch_bounds__(64 * RS_W) gae_dual_regsplit_kernel(GaeArgs a, int C, unsigned tag, double* maps, unsigned* flags, unsigned* status,
+                                                                      unsigned spin_limit, int fault) {
+  gae_dual_regsplit_body<NT>(a, C, tag, maps, flags, status, spin_limit, fault);
+}
+
 
 // several independent [T,N] rollouts of one shape in ONE launch: grid (tiles * C, n_runs), run = blockIdx.y
 struct GaeRun {
   GaeArgs a;
   double* maps;
   unsigned* flags;
+  unsigned* status;
 };
 __global__ void __launch_bounds__(64 * SPLIT_W) gae_dual_split_batch_kernel(const GaeRun* __restrict__ runs, int C, unsigned tag) {
   const GaeRun r = runs[blockIdx.y];
-  gae_dual_split_body(r.a, C, tag, r.maps, r.flags);
+  gae_dual_split_body(r.a, C, tag, r.maps, r.flags, r.status);
+}
+template <bool NT>
+__global__ void __launch_bounds__(64 * RS_W) gae_dual_regsplit_batch_kernel(const GaeRun* __restrict__ runs, int C, unsigned tag) {
+  const GaeRun r = runs[blockIdx.y];
+  gae_dual_regsplit_body<NT>(r.a, C, tag, r.maps, r.flags, r.status, GAE_SPIN_LIMIT, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -456,9 +612,33 @@ extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const 
     while (W > 1 && T / W < 2 * U_DEFAULT) W /= 4;
   }
   hipStream_t s = (hipStream_t)stream;
-  // up to 128 column tiles and a caller-owned workspace: the time axis is split over workgroups too (waves_per_tile 0, or 200 + C
-  // to force C workgroups per tile)
-  if ((waves_per_tile == 0 || waves_per_tile >= 200) && ws != nullptr && tiles * 2 <= 256) {
+  // the last word of the workspace is the launch's STATUS word (0; 1: a bounded wait for another workgroup's map expired — the outputs are
+  // then invalid; icrl_amd/buffers.py reads it next to the update's statistics)
+  unsigned* status = ws != nullptr && ws_bytes >= 16 ? reinterpret_cast<unsigned*>((char*)ws + (ws_bytes & ~7ll) - 4) : nullptr;
+  const long long ws_maps = status != nullptr ? (ws_bytes & ~7ll) - 8 : 0;
+  // codes 300 + C / 501: the split scans with a chunk that never publishes and a short spin limit (fault injection for the tests)
+  const int fault = (waves_per_tile >= 300 && waves_per_tile < 400) || waves_per_tile == 501;
+  if (waves_per_tile >= 300 && waves_per_tile < 400) waves_per_tile -= 100;
+  const unsigned spin_limit = fault ? 2048u : GAE_SPIN_LIMIT;
+  // register-resident split scan (waves_per_tile 0 with enough workspace, or 500 / 501 to force it): T <= 2048, below the streaming shapes
+  if (waves_per_tile == 0 || waves_per_tile == 500 || waves_per_tile == 501) {
+    const int C = (T + RS_TC - 1) / RS_TC;
+    const long long need = (long long)tiles * C * (256 * 8 + 4);
+    const bool fits = C <= RS_CMAX && ws != nullptr && ws_maps >= need && (long long)tiles * C <= 0x7fffffffll;
+    if (fits && (waves_per_tile != 0 || tiles < 1024)) {
+      const unsigned tag = next_split_tag();
+      double* maps = (double*)ws;
+      unsigned* flags = (unsigned*)(maps + (size_t)tiles * C * 256);
+      // non-temporal loads / stores once the arrays are beyond what the caches hold (> 128 tiles x 2048 rows x 36 B = 600 MB)
+      if ((long long)tiles * T > 128ll * 2048) hipLaunchKernelGGL((gae_dual_regsplit_kernel<true>), dim3(tiles * C), dim3(64 * RS_W), 0, s, a, C, tag, maps, flags, status, spin_limit, fault);
+      else hipLaunchKernelGGL((gae_dual_regsplit_kernel<false>), dim3(tiles * C), dim3(64 * RS_W), 0, s, a, C, tag, maps, flags, status, spin_limit, fault);
+      return (int)hipGetLastError();
+    }
+    if (waves_per_tile != 0) return fail("icrl_gae_dual_ws: the register-resident split scan needs T <= %d and %lld B of workspace + 8 (T = %d, %lld given)", RS_TC * RS_CMAX, need, T, ws_bytes);
+  }
+  // up to 128 column tiles and a caller-owned workspace: the time axis is split over workgroups, two passes (waves_per_tile 0 when the
+  // register-resident form does not apply — T > 2048 —, or 200 + C to force C workgroups per tile)
+  if ((waves_per_tile == 0 || waves_per_tile >= 200) && waves_per_tile < 300 && ws != nullptr && tiles * 2 <= 256) {
     int C = waves_per_tile >= 200 ? waves_per_tile - 200 : T / (SPLIT_W * U_DEFAULT);
     if (C > SPLIT_CMAX) C = SPLIT_CMAX;
     // measured (tools/gae_small.py): 1 tile x 16, 4 tiles x 8 (T = 1024) / x 4 (T = 512), 8 tiles x 4 are the fastest splits:
@@ -466,14 +646,14 @@ extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const 
     const int wg_cap = waves_per_tile >= 200 || tiles > 16 ? 256 : 32;
     while (C > 1 && tiles * C > wg_cap) --C;
     const long long need = (long long)tiles * C * (256 * 8 + 4);
-    if (C >= 2 && ws_bytes >= need) {
+    if (C >= 2 && ws_maps >= need) {
       const unsigned tag = next_split_tag();
       double* maps = (double*)ws;
       unsigned* flags = (unsigned*)(maps + (size_t)tiles * C * 256);
-      hipLaunchKernelGGL(gae_dual_split_kernel, dim3(tiles * C), dim3(64 * SPLIT_W), 0, s, a, C, tag, maps, flags);
+      hipLaunchKernelGGL(gae_dual_split_kernel, dim3(tiles * C), dim3(64 * SPLIT_W), 0, s, a, C, tag, maps, flags, status, spin_limit, fault);
       return (int)hipGetLastError();
     }
-    if (waves_per_tile >= 200) return fail("icrl_gae_dual_ws: split %d needs 2..%d workgroups per tile and %lld B of workspace (%lld given)", waves_per_tile - 200, SPLIT_CMAX, need, ws_bytes);
+    if (waves_per_tile >= 200) return fail("icrl_gae_dual_ws: split %d needs 2..%d workgroups per tile and %lld B of workspace + 8 (%lld given)", waves_per_tile - 200, SPLIT_CMAX, need, ws_bytes);
   }
   // one wave per 64-env tile streams T rows; with >= 1024 tiles, 4 neighbouring tiles share a workgroup (1 KB contiguous per
   // row and array, the 4 waves start together) and 16 rows x 5 arrays are in flight per wave: +5..8 % of HBM rate measured.
@@ -499,6 +679,14 @@ extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const 
   else if (shape == 16) hipLaunchKernelGGL((gae_dual_kernel<16, 8, false>), dim3(tiles), dim3(1024), 0, s, a);
   else return fail("icrl_gae_dual_ex: waves_per_tile = %d (0 = automatic, 1, 4, 16 or a shape code 101 / 105 / 106, 107..112 with N %% 4 == 0)", waves_per_tile);
   return (int)hipGetLastError();
+}
+
+extern "C" size_t icrl_gae_dual_ws_bytes(int T, int N) {
+  if (T <= 0 || N <= 0) return 0;
+  const long long tiles = (N + 63) / 64, C = (T + RS_TC - 1) / RS_TC;
+  long long need = ICRL_GAE_WS_BYTES;                                    // the two-pass split's maximum (256 maps)
+  if (C <= RS_CMAX && tiles < 1024 && tiles * C * (256 * 8 + 4) > need - 8) need = tiles * C * (256 * 8 + 4) + 8;
+  return (size_t)((need + 15) & ~7ll);                                   // + the status word, a multiple of 8
 }
 
 extern "C" int icrl_gae_dual_ex(const float* rewards, const float* costs, const float* reward_values,
@@ -538,7 +726,7 @@ extern "C" int icrl_debug_stream_ref(const float* in0, const float* in1, const f
   return (int)hipGetLastError();
 }
 
-extern "C" int icrl_abi_version(void) { return 105; }
+extern "C" int icrl_abi_version(void) { return 106; }
 
 // icrl_gae_dual_ws for n_runs rollouts of one shape in ONE launch (the loop-size launches of several runs sharing a GPU): the
 // two-level scan over workgroups, every run with its own workspace.  Shapes the split scan does not serve (> 128 column tiles, T too
@@ -550,13 +738,18 @@ extern "C" int icrl_gae_dual_batch(int n_runs, const icrl_gae_job_t* jobs, int T
   if (T <= 0 || N <= 0) return fail("icrl_gae_dual_batch: T = %d, N = %d", T, N);
   hipStream_t s = (hipStream_t)stream;
   const int tiles = (N + 63) / 64;
+  // the single-launch heuristic of icrl_gae_dual_ws (same scan structure, same results): the register-resident split scan when it applies,
+  // else the two-pass split
+  const int Cr = (T + RS_TC - 1) / RS_TC;
+  const bool regs = Cr <= RS_CMAX && tiles < 1024;
   int C = T / (SPLIT_W * U_DEFAULT);
   if (C > SPLIT_CMAX) C = SPLIT_CMAX;
-  const int wg_cap = tiles > 16 ? 256 : 32;          // the single-launch heuristic of icrl_gae_dual_ws (same C, same results)
+  const int wg_cap = tiles > 16 ? 256 : 32;
   while (C > 1 && tiles * C > wg_cap) --C;
+  if (regs) C = Cr;
   const long long need = (long long)tiles * C * (256 * 8 + 4);
-  bool split = tiles * 2 <= 256 && C >= 2 && args_ws != nullptr && args_ws_bytes >= (long long)n_runs * ICRL_BATCH_ARGS_BYTES;
-  for (int r = 0; r < n_runs && split; ++r) split = jobs[r].ws != nullptr && jobs[r].ws_bytes >= need;
+  bool split = (regs || (tiles * 2 <= 256 && C >= 2)) && args_ws != nullptr && args_ws_bytes >= (long long)n_runs * ICRL_BATCH_ARGS_BYTES;
+  for (int r = 0; r < n_runs && split; ++r) split = jobs[r].ws != nullptr && (jobs[r].ws_bytes & ~7ll) - 8 >= need;
   if (!split) {
     for (int r = 0; r < n_runs; ++r) {
       const icrl_gae_job_t& j = jobs[r];
@@ -576,10 +769,13 @@ extern "C" int icrl_gae_dual_batch(int n_runs, const icrl_gae_job_t* jobs, int T
                   (float)reward_gamma, (float)(reward_gamma * reward_gae_lambda), (float)cost_gamma, (float)(cost_gamma * cost_gae_lambda)};
     g.maps = (double*)j.ws;
     g.flags = (unsigned*)(g.maps + (size_t)tiles * C * 256);
+    g.status = reinterpret_cast<unsigned*>((char*)j.ws + (j.ws_bytes & ~7ll) - 4);
     const int e = icrl::put_args(g, d_runs + r, s);
     if (e) return e;
   }
-  hipLaunchKernelGGL(gae_dual_split_batch_kernel, dim3(tiles * C, n_runs), dim3(64 * SPLIT_W), 0, s, d_runs, C, next_split_tag());
+  if (!regs) hipLaunchKernelGGL(gae_dual_split_batch_kernel, dim3(tiles * C, n_runs), dim3(64 * SPLIT_W), 0, s, d_runs, C, next_split_tag());
+  else if ((long long)tiles * T > 128ll * 2048) hipLaunchKernelGGL((gae_dual_regsplit_batch_kernel<true>), dim3(tiles * C, n_runs), dim3(64 * RS_W), 0, s, d_runs, C, next_split_tag());
+  else hipLaunchKernelGGL((gae_dual_regsplit_batch_kernel<false>), dim3(tiles * C, n_runs), dim3(64 * RS_W), 0, s, d_runs, C, next_split_tag());
   return (int)hipGetLastError();
 }
 

@@ -227,7 +227,10 @@ class PPOLagrangian:
     def check_rollout_status(self):
         """raise if the persistent rollout kernel reported a timed-out exchange (icrl_agent_t.status): its buffer rows and
         running moments are then invalid.  One 4-byte read; train() calls it next to its own statistics read-back."""
-        if int(self._ag["status"].item()) != 0:
+        both = torch.cat([self._ag["status"].flatten()[:1].to(torch.int32), self.rollout_buffer.gae_status]).cpu()
+        if int(both[1]) != 0:
+            self.rollout_buffer.check_gae_status()
+        if int(both[0]) != 0:
             self._ag["status"].zero_()
             raise RuntimeError("icrl_rollout_collect: inter-workgroup exchange timed out (a workgroup of the persistent "
                                "rollout was not resident); rollout buffer and normaliser statistics are invalid")
@@ -289,6 +292,14 @@ class PPOLagrangian:
             self._last_original_obs = self._vec_normalize_env.get_original_obs() if self._vec_normalize_env is not None else self._last_obs
         return total_timesteps
 
+    def _training_infos(self, itr):
+        """ref: on_policy_algorithm.py:452-457 (Monitor's `rollout/ep_*` episode statistics are not kept: the envs are device-resident)."""
+        elapsed = max(time.time() - self.start_time, 1e-9)
+        logger.record("time/iterations", itr)
+        logger.record("time/fps", int(self.num_timesteps / elapsed))
+        logger.record("time/time_elapsed", int(elapsed))
+        logger.record("time/total_timesteps", self.num_timesteps)
+
     def learn(self, total_timesteps, cost_function="cost", callback=None, log_interval=1, eval_env=None, eval_freq=-1,
               n_eval_episodes=5, tb_log_name="PPOLagrangian", eval_log_path=None, reset_num_timesteps=True):
         """ref: on_policy_algorithm.py:430-492."""
@@ -302,9 +313,11 @@ class PPOLagrangian:
                 break
             iteration += 1
             self._current_progress_remaining = 1.0 - float(self.num_timesteps) / float(total_timesteps)
-            logger.record("time/iterations", iteration)
-            logger.record("time/total_timesteps", self.num_timesteps)
+            if log_interval is not None and iteration % log_interval == 0:
+                self._training_infos(iteration)
+                logger.dump(step=self.num_timesteps)
             self.train()
+        self._training_infos(iteration + 1)       # (the reference's closing call: what icrl() scrapes holds iterations + 1, on_policy_algorithm.py:488)
         if callback is not None:
             callback.on_training_end()
         return self
@@ -482,9 +495,7 @@ class PPOLagrangian:
             self._lazy_pin = torch.empty((2, n), dtype=torch.int32).pin_memory()
             self._lazy_stats = torch.empty((E, 33), dtype=torch.float32).pin_memory()
         job = self._train_begin(device_perms=self._lazy_perm)
-        ws, b = self._train_ws, _lib.byref
-        if not ws["sync_tuned"]:
-            ws["sync_tuned"] = True          # (the placement calibration times whole updates: not for this form)
+        ws, b = self._train_ws, _lib.byref      # (no placement calibration in this form — it times whole updates; a later single-launch train() still makes it)
         hp = PpoHyperT.from_buffer_copy(job["hp"]); hp.n_epochs = 1
         states, events = [], []
 
@@ -635,7 +646,21 @@ class PPOLagrangian:
         rb, pol, ws = self.rollout_buffer, self.policy, self._train_ws
         std = torch.exp(pol.log_std).mean() if pol.log_std is not None else torch.zeros((), device=self.device)
         tail = torch.stack([rb.orig_costs.mean(), rb.orig_costs.sum(), rb.reward_advantages.mean(), rb.cost_advantages.mean(), std])
-        return torch.cat([ws["stats"].double(), ws["t"].double(), tail.double(), self._ag["status"].double()])
+        return torch.cat([ws["stats"].double(), ws["t"].double(), tail.double(), self._ag["status"].double() + 2.0 * self.rollout_buffer.gae_status.double(),
+                          self._explained_variance().double()])
+
+    def _explained_variance(self):
+        """device float32 [2]: `explained_variance(returns.flatten(), values.flatten())` of the reward and of the cost critic as the
+        reference logs them (ref: ppo_lag.py:311-312 -> common/utils.py:43-59; NB its argument order: y_pred = returns, y_true = values,
+        so the figure is 1 - Var[values - returns] / Var[values]) — one pass over the four [T, N] planes (icrl_explained_variance)."""
+        rb, ws = self.rollout_buffer, self._train_ws
+        if "ev_work" not in ws:
+            ws["ev_work"] = torch.zeros(8 * 256, dtype=torch.float64, device=self.device)
+            ws["ev_out"] = torch.zeros(2, dtype=torch.float32, device=self.device)
+        _lib.check(_lib.lib().icrl_explained_variance(p(rb.reward_returns), p(rb.reward_values), p(rb.cost_returns), p(rb.cost_values),
+                                                      rb.buffer_size * rb.n_envs, p(ws["ev_work"]), p(ws["ev_out"]), _lib.current_stream()),
+                   "icrl_explained_variance")
+        return ws["ev_out"]
 
     def _train_end(self, job, host=None):
         """host: this run's row of train_readback() already on the host (numpy float64; float32 values survive the round trip
@@ -654,6 +679,8 @@ class PPOLagrangian:
             raise RuntimeError("icrl_ppo_lag_train: inter-workgroup exchange timed out")
         if host is None:
             self.check_rollout_status()
+        elif int(host[ns + 6]) & 2:
+            self.rollout_buffer.check_gae_status()
         elif host[ns + 6] != 0:
             self._ag["status"].zero_()
             raise RuntimeError("icrl_rollout_collect: inter-workgroup exchange timed out (a workgroup of the persistent "
@@ -670,8 +697,10 @@ class PPOLagrangian:
         if host is None:
             average_cost, total_cost = float(average_cost_t.item()), float(total_cost_t.item())
             mean_ra, mean_ca = float(rb.reward_advantages.mean().item()), float(rb.cost_advantages.mean().item())
+            ev_r, ev_c = (float(x) for x in self._explained_variance().cpu().numpy())
         else:
             average_cost, total_cost, mean_ra, mean_ca = (float(x) for x in host[ns + 1:ns + 5])
+            ev_r, ev_c = float(host[ns + 7]), float(host[ns + 8])
         if self.update_penalty_after is None or ((self._n_updates / self.n_epochs) % self.update_penalty_after == 0):
             self.dual.update_parameter(np.float32(average_cost))
         logger.record("train/entropy_loss", st[2] / steps)
@@ -683,6 +712,8 @@ class PPOLagrangian:
         logger.record("train/loss", float(st[8] + self.reward_vf_coef * st[9] + self.cost_vf_coef * st[10]))
         logger.record("train/mean_reward_advantages", mean_ra)
         logger.record("train/mean_cost_advantages", mean_ca)
+        logger.record("train/reward_explained_variance", ev_r)
+        logger.record("train/cost_explained_variance", ev_c)
         logger.record("train/nu", self.dual.nu().item())
         logger.record("train/nu_loss", self.dual.loss.item())
         logger.record("train/average_cost", average_cost)

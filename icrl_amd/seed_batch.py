@@ -198,8 +198,8 @@ class SeedBatch:
                 with _as_run(st):
                     a._rollout_end(j, a.env, None, a.rollout_buffer, a.n_steps)
                     a._current_progress_remaining = 1.0 - float(a.num_timesteps) / float(totals[0])
-                    logger.record("time/iterations", iteration)
-                    logger.record("time/total_timesteps", a.num_timesteps)
+                    a._training_infos(iteration)
+                    logger.dump(step=a.num_timesteps)
                     tjobs.append(a._train_begin(None))
             before_update = torch.cuda.Event()
             before_update.record()
@@ -214,6 +214,9 @@ class SeedBatch:
             for st, a, j, h in zip(sts, agents, tjobs, host):
                 with _as_run(st):
                     a._train_end(j, host=h)
+        for st, a in zip(sts, agents):
+            with _as_run(st):
+                a._training_infos(iteration + 1)
 
     def _episodes(self, envs, n_episodes, deterministic, noises, parallel):
         """n_episodes of the 1-env loop of every run (utils.EpisodeRun) in one launch; runs whose speculation failed repeat

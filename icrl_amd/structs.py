@@ -93,4 +93,4 @@ def p(t):
     assert t.is_contiguous()
     return t.data_ptr()
 
-GAE_WS_BYTES = 256 * (256 * 8 + 4)       # ICRL_GAE_WS_BYTES
+GAE_WS_BYTES = 256 * (256 * 8 + 4) + 64       # ICRL_GAE_WS_BYTES

@@ -131,7 +131,7 @@ typedef struct {
   void* gae_ws;             /* optional workspace of the GAE launch (see icrl_gae_dual_ws): device memory, zeroed once when */
   long long gae_ws_bytes;   /* allocated, afterwards written by GAE launches only.  NULL: one workgroup per column tile */
 } icrl_buffer_t;
-#define ICRL_GAE_WS_BYTES (256 * (256 * 8 + 4))
+#define ICRL_GAE_WS_BYTES (256 * (256 * 8 + 4) + 64)   /* 256 maps + flags, + the status word */
 
 /* What OnPolicyWithCostAlgorithm carries between steps (common/on_policy_algorithm.py:367-416, base_class.py:346-353)
  * plus per-step scratch. */
@@ -189,7 +189,7 @@ typedef struct {
  * ------------------------------------------------------------------------------------------------------------------ */
 
 /* ABI version (major*100+minor). */
-int icrl_abi_version(void);   /* 105: icrl_buffer_add, icrl_is_weights, icrl_cn_loss_fwd_bwd; 104: the fine-grained update entry points (csrc/fine.hip); 103: icrl_debug_stream_ref; 102: icrl_policy_t.arch; 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
+int icrl_abi_version(void);   /* 106: icrl_explained_variance, icrl_gae_dual_ws_bytes + the status word of the GAE workspace; 105: icrl_buffer_add, icrl_is_weights, icrl_cn_loss_fwd_bwd; 104: the fine-grained update entry points (csrc/fine.hip); 103: icrl_debug_stream_ref; 102: icrl_policy_t.arch; 101: icrl_sample_episodes takes stream_row0 / total_rows; the *_batch entry points */
 
 /* Every entry point returns a hipError_t.  When it is hipErrorInvalidValue because the arguments are outside what the
  * kernels were built for (env count, widths, batch size ...; the reference's Python raises ValueError / AssertionError with a
@@ -220,10 +220,17 @@ int icrl_gae_dual_ex(const float* rewards, const float* costs, const float* rewa
                      int T, int N, double reward_gamma, double reward_gae_lambda, double cost_gamma, double cost_gae_lambda,
                      int waves_per_tile, void* stream);
 
-/* The same scan with a caller-owned workspace (ICRL_GAE_WS_BYTES always suffices; zeroed once at allocation and written by
- * these launches only): for up to 128 column tiles the time axis is additionally split over up to 16 workgroups per tile, a
- * two-level scan over affine maps (the BASELINE-size launch, 64 envs x 2048 rows, walks 16 rows per wave instead of 128).
- * waves_per_tile as above, or 200 + C to force C workgroups per tile.  ws == NULL: identical to icrl_gae_dual_ex. */
+/* The same scan with a caller-owned workspace (zeroed once at allocation and written by these launches only).  Up to 65 472 envs and
+ * T <= 2048 (round 6): the REGISTER-RESIDENT split scan — ceil(T / 128) workgroups per 64-env column tile, each wave keeps its 16 rows in
+ * registers between the two passes of a two-level scan over affine maps, so every byte is read once (the BASELINE-size launch, 64 envs x
+ * 2048 rows, walks 16 rows per wave instead of 128; 8 192 .. 65 472 envs get 2 048 .. 16 368 workgroups instead of one wave per tile).
+ * It needs icrl_gae_dual_ws_bytes(T, N) bytes; ICRL_GAE_WS_BYTES suffices for up to 1024 envs at T <= 2048.  With less (or T > 2048) and up
+ * to 128 column tiles: the older two-pass split over up to 16 workgroups per tile.
+ * The LAST 4 bytes of the workspace (of its size rounded down to 8) are the launch's STATUS word: every wait for another workgroup's map is
+ * bounded (~seconds); a map that never arrives ends the wait with status = 1 and invalid outputs — the caller checks and clears it.
+ * waves_per_tile as above, or 200 + C to force the two-pass split with C workgroups per tile, 500 the register-resident split; 300 + C and
+ * 501 are those two with one map withheld and a short limit (fault injection for the tests).  ws == NULL: identical to icrl_gae_dual_ex. */
+size_t icrl_gae_dual_ws_bytes(int T, int N);
 int icrl_gae_dual_ws(const float* rewards, const float* costs, const float* reward_values, const float* cost_values,
                      const float* dones, const float* last_v_r, const float* last_v_c, const uint8_t* last_dones,
                      float* adv_r, float* adv_c, float* ret_r, float* ret_c,
@@ -493,6 +500,12 @@ int icrl_minibatch_gather(const icrl_buffer_t* buf, const int32_t* flat_idx, int
                           float* adv_r, float* adv_c, float* ret_r, float* ret_c, float* old_v_r, float* old_v_c, void* stream);
 /* out4 = {mean(adv_r), 1 / (std(adv_r) + 1e-8) with torch's unbiased std, mean(adv_c), std(adv_r)}; n >= 2. */
 int icrl_adv_stats(const float* adv_r, const float* adv_c, int n, float* out4, void* stream);
+/* common/utils.py:43-59 `explained_variance(y_pred, y_true)` = 1 - Var[y_true - y_pred] / Var[y_true] (NaN when Var[y_true] == 0), float64
+ * sums over n float32 values, for one or two pairs in one pass (the second pair may be NULL as a whole; then out2[1] is not written).
+ * Call site replaced: ppo_lag/ppo_lag.py:311-312 — NB the reference passes (returns, values), i.e. y_pred = returns, y_true = values.
+ * work: 8 x 256 doubles of device scratch; out2: device float32. */
+int icrl_explained_variance(const float* y_pred_a, const float* y_true_a, const float* y_pred_b, const float* y_true_b, long long n,
+                            double* work, float* out2, void* stream);
 /* The PPO-Lagrangian loss of ONE minibatch on the networks' outputs (all [n] float32; adv_r / adv_c RAW: they are normalised /
  * centred inside as ppo_lag.py:219-222 does): terms8 = {loss, policy_loss, reward_value_loss, cost_value_loss, entropy_loss,
  * approx_kl, clip_fraction, 0}; d_log_prob / d_v_r / d_v_c / d_entropy = d loss / d that output, what loss.backward() would send

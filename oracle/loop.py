@@ -75,6 +75,12 @@ class Rollout:
         return {k: v for k, v in self.__dict__.items() if isinstance(v, np.ndarray)}
 
 
+def explained_variance(y_pred, y_true):
+    """ref: stable_baselines3/common/utils.py:43-59."""
+    var_y = np.var(y_true)
+    return float(np.nan if var_y == 0 else 1 - np.var(y_true - y_pred) / var_y)
+
+
 class PortAgent:
     """PPO-Lagrangian agent of the CPU port."""
 
@@ -160,6 +166,9 @@ class PortAgent:
                     "train/average_cost": float(average_cost), "train/total_cost": float(np.sum(self.buf.orig_costs)),
                     "train/mean_reward_advantages": float(np.mean(self.buf.reward_advantages.flatten())),
                     "train/mean_cost_advantages": float(np.mean(self.buf.cost_advantages.flatten())),
+                    # ref: ppo_lag.py:311-312 — explained_variance(returns, values): y_pred = returns, y_true = values (argument order kept)
+                    "train/reward_explained_variance": explained_variance(self.buf.reward_returns.flatten(), self.buf.reward_values.flatten()),
+                    "train/cost_explained_variance": explained_variance(self.buf.cost_returns.flatten(), self.buf.cost_values.flatten()),
                     "train/n_updates": self._n_updates})
         if not self.discrete:
             out["train/std"] = th.exp(self.policy.params["log_std"]).mean().item()
@@ -175,7 +184,7 @@ class PortAgent:
         self._last_original_obs = self.stack.old_obs.copy()
         T, N, n_epochs = self.h["n_steps"], self.stack.num_envs, self.h["n_epochs"]
         A = 1 if self.discrete else self.act_dim
-        it = 0
+        it, t_start = 0, time.time()
         while self.num_timesteps < total_timesteps:
             if streams is not None:
                 self.collect_rollouts(streams.rollout_noise(T, N, A))
@@ -185,6 +194,10 @@ class PortAgent:
                 self.collect_rollouts(None if noise_fn is None else noise_fn(it))
                 self.train(None if perms_fn is None else perms_fn(it))
             it += 1
+        # ref: on_policy_algorithm.py:452-457,488 — the closing training_infos(iteration + 1); wall-clock keys, never compared
+        el = max(time.time() - t_start, 1e-9)
+        self.logs.update({"time/iterations": it + 1, "time/fps": int(self.num_timesteps / el), "time/time_elapsed": int(el),
+                          "time/total_timesteps": self.num_timesteps})
         return self
 
     # -- inference -----------------------------------------------------------------------------
@@ -376,7 +389,7 @@ def icrl_port(cfg, expert_obs, expert_acs, expert_policy_sd=None, n_iters=None, 
         if expert_policy is not None:
             m["true/forward_kl"] = compute_kl(agent.policy, expert_obs, expert_acs, expert_policy)
             m["true/reverse_kl"] = compute_kl(expert_policy, orig_obs, acts, agent.policy)
-        m.update({k.replace("train/", "forward/"): v for k, v in fwd.items() if k.startswith("train/")})
+        m.update({k.replace("train/", "forward/"): v for k, v in fwd.items() if k.startswith(("train/", "time/"))})      # ref: icrl.py:299
         m.update(bw)
         m["time/forward_s"], m["time/rest_s"] = t_fwd, time.time() - t_it - t_fwd      # wall clock (bench.py's cpu_baseline)
         out.append(m)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), f"{name} declared in include/icrl_hip.h but not exported"
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert L.icrl_abi_version() == 105
+    assert L.icrl_abi_version() == 106
     assert L.icrl_cn_train_work_floats(521, 10000, 5000, 10) > 521 * 235
 
 

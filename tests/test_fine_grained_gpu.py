@@ -223,3 +223,36 @@ def test_cn_loss_fwd_bwd_vs_autograd(mode, weights):
         assert abs(got - ref) <= 2e-6 + 2e-5 * abs(ref), (t, loss.item(), e_l.item(), n_l.item(), float(r_l))
     assert np.allclose(d_nom.cpu().numpy(), nom.grad.numpy().ravel(), rtol=2e-5, atol=1e-8)
     assert np.allclose(d_exp.cpu().numpy(), exp.grad.numpy().ravel(), rtol=2e-5, atol=1e-8)
+
+
+@pytest.mark.parametrize("n", [1, 7, 2048 * 64, 2048 * 512 + 3])
+def test_explained_variance_vs_the_reference_formula(n):
+    """icrl_explained_variance against common/utils.py:43-59 (oracle.loop.explained_variance) in the reference's argument order
+    (ppo_lag.py:311-312: y_pred = returns, y_true = values), one and two pairs, and the NaN of a constant y_true."""
+    from icrl_amd import _lib
+    from oracle.loop import explained_variance
+    L = _lib.lib()
+    rng = np.random.RandomState(n)
+    ret_r, val_r = (3 + 2 * rng.randn(n)).astype(np.float32), (3 + 2 * rng.randn(n)).astype(np.float32)
+    val_c = (0.3 * rng.randn(n) + 1).astype(np.float32)
+    ret_c = (val_c + 0.1 * rng.randn(n)).astype(np.float32)
+    d = [_dev(x) for x in (ret_r, val_r, ret_c, val_c)]
+    work, out = torch.zeros(8 * 256, dtype=torch.float64, device="cuda"), torch.full((2,), 7.0, device="cuda")
+    _lib.check(L.icrl_explained_variance(_lib.ptr(d[0]), _lib.ptr(d[1]), _lib.ptr(d[2]), _lib.ptr(d[3]), n, _lib.ptr(work), _lib.ptr(out),
+                                         _lib.current_stream()), "icrl_explained_variance")
+    got = out.cpu().numpy()
+    for g_, (yp, yt) in zip(got, ((ret_r, val_r), (ret_c, val_c))):
+        want = explained_variance(yp.astype(np.float64), yt.astype(np.float64))
+        if n == 1:
+            assert np.isnan(g_) and np.isnan(want)
+        else:
+            assert abs(g_ - want) <= 1e-6 * max(1.0, abs(want)), (g_, want)
+            assert abs(g_ - explained_variance(yp, yt)) <= 1e-4 * max(1.0, abs(want))      # numpy's own float32 evaluation
+    # one pair: out[1] untouched; a constant y_true: NaN
+    out.fill_(7.0)
+    const = torch.full((max(n, 2),), 1.5, device="cuda")
+    _lib.check(L.icrl_explained_variance(_lib.ptr(d[0]) if n > 1 else _lib.ptr(const), _lib.ptr(const), None, None, max(n, 2) if n == 1 else n,
+                                         _lib.ptr(work), _lib.ptr(out), _lib.current_stream()), "icrl_explained_variance") if n <= 7 else None
+    if n <= 7:
+        got = out.cpu().numpy()
+        assert np.isnan(got[0]) and got[1] == 7.0

@@ -179,3 +179,133 @@ def test_configs2_widths_long_chain():
                              learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9, cost_gae_lambda=0.9,
                              penalty_initial_value=0.1, penalty_learning_rate=0.05)
     _forward_step(agent, port, env, 2, 3e-5, 0.02, calibrated="configs2")
+
+
+# ---- round 6: the FULL row counts of BASELINE configs[2] and of the per-GPU shards of configs[3] / configs[4] -------------------------------
+# (VERDICT r5 missing #3).  T = 2048 rows per env: 524 288 - 1 048 576 rows per rollout — PPOLagrangian._train_epochwise (one launch per epoch
+# from 262 144 rows on, np.random.permutation drawn beside the running epoch), the 48 B / step schedule tables at up to 81 920 steps, storage
+# offsets into 118 M-float observation planes and rollout_wide_kernel over 2048 steps; until round 6 these shapes had only run inside bench.py.
+# One rollout + one train() each, against oracle.loop.PortAgent on the same noise and permutations (ref: ppo_lag.py:196-299,
+# buffers.py:594-627, on_policy_algorithm.py:340-421).  Bounds = 2 x the largest port-vs-port figure of tools/calibrate_drift.py on THESE
+# schedules (`configs2full`, `configs3shard`, `configs4shard`; profiles/r06_drift_calibration.md); the value losses of the two AntWall-width
+# schedules get half the kernel-level tolerance instead, as in test_configs2_widths_long_chain (v_exp-based tanh against libm's: not a drift).
+FULL_ROWS = {
+    #                 max |dp| / (lr x steps)   pg loss   value losses (abs | None -> ANT_LOSS_RTOL)   average_cost   nu
+    "configs2full": dict(dev=8.3e-3, pg=5.6e-6, vl=None, average_cost=1.2e-7, nu=1.5e-8),
+    "configs3shard": dict(dev=1.8e-3, pg=2.4e-6, vl=1.7e-5, average_cost=1.2e-7, nu=2.4e-7),
+    "configs4shard": dict(dev=8.3e-3, pg=5.6e-6, vl=None, average_cost=1.2e-7, nu=2.4e-7),
+}
+
+
+def _full_rows_step(agent, port, env, name, lr, monkeypatch):
+    """one rollout + one train() of both sides at the schedule `name`; the HIP side runs the way bench.py runs it — no stream object, the
+    update draws np.random.permutation itself (here: patched to hand out SeededStreams(77)'s permutations, the ones the calibration used)."""
+    from icrl_amd import logger
+    from icrl_amd.ppo_lag import PPOLagrangian
+    T, N, B = agent.n_steps, agent.n_envs, int(agent.batch_size)
+    rows = T * N
+    assert rows >= PPOLagrangian.LAZY_PERM_ROWS and agent.streams is None
+    streams, pstreams = SeededStreams(77), SeededStreams(77)
+    noise = streams.rollout_noise(T, N, port.act_dim)
+    drawn, epochwise_calls = [], []
+    monkeypatch.setattr(np.random, "permutation", lambda n: (drawn.append(len(drawn)), np.asarray(streams.permutation(drawn[-1], n)))[1])
+    orig = agent._train_epochwise
+    monkeypatch.setattr(agent, "_train_epochwise", lambda: (epochwise_calls.append(1), orig())[1])
+    agent._setup_learn(rows)
+    t0 = time.time()
+    agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost", noise=torch.as_tensor(noise, device="cuda"))
+    agent.train()
+    torch.cuda.synchronize()
+    t_hip = time.time() - t0
+    monkeypatch.undo()
+    lg = dict(logger.Logger.CURRENT.name_to_value)
+    assert epochwise_calls == [1], "the update did not take the epoch-wise path"
+    executed = min(int(lg["train/early_stop_epoch"]) + 1, agent.n_epochs)
+    assert executed <= len(drawn) <= min(executed + 1, agent.n_epochs), (executed, len(drawn))       # at most one permutation drawn in vain
+    port.num_timesteps = 0
+    port._last_obs = port.stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = port.stack.old_obs.copy()
+    pstreams.rollout_noise(T, N, port.act_dim)
+    t0 = time.time()
+    b = port.collect_rollouts(noise)
+    out = port.train(lambda e: pstreams.permutation(e, rows))
+    t_port = time.time() - t0
+    steps = agent.policy.adam_step
+    assert steps == int(next(iter(port.optimizer.state.values()))["step"]) == executed * (-(-rows // B))
+    # ---- the rollout: [T, N] planes of both sides (the float64 env / normaliser arithmetic is bit-exact; the MLP outputs are fp32)
+    rb = agent.rollout_buffer
+    buf_dev = {f: float(np.abs(getattr(rb, f).cpu().numpy().reshape(getattr(b, f).shape) - getattr(b, f)).max())
+               for f in ("rewards", "costs", "orig_costs", "log_probs", "reward_values", "reward_advantages", "cost_advantages", "reward_returns", "cost_returns")}
+    i_last = (T - 1, N - 1)
+    assert np.allclose(rb.observations[T - 1].cpu().numpy(), b.observations[T - 1], rtol=0, atol=5e-5), "last row of the observation plane"
+    assert np.array_equal(rb.dones.cpu().numpy().reshape(T, N), b.dones), "episode boundaries"
+    for f, tol in (("rewards", 2e-5), ("orig_costs", 2e-5), ("log_probs", 2e-4), ("reward_values", 2e-4), ("reward_advantages", 5e-4), ("cost_advantages", 5e-4)):
+        assert buf_dev[f] <= tol, (f, buf_dev[f])
+    # ---- the update
+    worst_abs = max(float(np.abs(v.numpy() - port.policy.params[k].detach().numpy()).max()) for k, v in agent.policy.state_dict().items())
+    d = lambda key: abs(float(lg[key]) - float(out[key]))
+    print(f"[{name}] {N} envs x {T} rows = {rows} rows, batch {B}: {steps} optimiser steps ({executed} of {agent.n_epochs} epochs, {len(drawn)} permutations drawn); "
+          f"HIP {t_hip:.2f} s, CPU port {t_port:.1f} s; nu {lg['train/nu']:.9f} vs {out['train/nu']:.9f}; average_cost d {d('train/average_cost'):.2e}; "
+          f"losses d pg {d('train/policy_gradient_loss'):.2e} rv {d('train/reward_value_loss'):.2e} cv {d('train/cost_value_loss'):.2e} "
+          f"(values {out['train/policy_gradient_loss']:.3g} / {out['train/reward_value_loss']:.3g} / {out['train/cost_value_loss']:.3g}); approx_kl d {d('train/approx_kl'):.2e}; "
+          f"explained variances d {d('train/reward_explained_variance'):.2e} / {d('train/cost_explained_variance'):.2e}; "
+          f"max |d param| {worst_abs:.3e} = {worst_abs / (lr * steps):.2e} x lr x steps; buffer: " + ", ".join(f"{f} {v:.1e}" for f, v in buf_dev.items()))
+    bd = FULL_ROWS[name]
+    assert int(lg["train/early_stop_epoch"]) == int(out["train/early_stop_epoch"]), (lg["train/early_stop_epoch"], out["train/early_stop_epoch"], agent.epoch_kls, out.get("epoch_kls"))
+    assert d("train/nu") <= bd["nu"] and d("train/average_cost") <= bd["average_cost"]
+    assert worst_abs <= (bd["dev"] or ANT_DEV_BOUND) * lr * steps + 1e-9, (worst_abs, steps)
+    for key in ("train/policy_gradient_loss", "train/reward_value_loss", "train/cost_value_loss"):
+        tol = bd["pg" if "policy" in key else "vl"]
+        assert d(key) <= (tol if tol is not None else 2e-8 + ANT_LOSS_RTOL * abs(out[key])), (key, lg[key], out[key])
+    for key in ("train/reward_explained_variance", "train/cost_explained_variance"):
+        assert d(key) <= 2e-5 + 1e-4 * abs(out[key]), (key, lg[key], out[key])
+    return lg, out
+
+
+def _pair_rows(env_id, kind, N, T, od, ad, cn_spec, seed, broken=False, **kw):
+    """_pair without a stream object on the HIP side (so that train() takes the path bench.py takes)."""
+    from icrl_amd import utils
+    from icrl_amd.constraint_net import ConstraintNet
+    from icrl_amd.ppo_lag import PPOLagrangian
+    env = utils.make_train_env(env_id, None, True, seed, N, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    if isinstance(cn_spec, str):          # the reference's AntBroken checkpoint through its off-by-one load() (constraint_net.py:394-399)
+        cn = ConstraintNet.load(os.path.join(HERE, "golden", cn_spec))
+        ocn = o_nets.CostNet(od, ad, [40, 40], False, None, None, None, None, None)
+    else:
+        lo = -np.ones(ad, np.float32)
+        torch.manual_seed(seed + 1)
+        cn = ConstraintNet(od, ad, cn_spec, None, lambda x: 0.05, None, None, False, 0.5, clip_obs=20, action_low=lo, action_high=-lo)
+        ocn = o_nets.CostNet(od, ad, cn_spec, False, None, None, 20, lo, -lo)
+    ocn.load_state_dict(cn.state_dict())
+    env.set_cost_function(cn.cost_function)
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=seed, **kw)
+    stack = o_loop.make_stack(N, kind, seed, broken=broken); stack.cost_fn = ocn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=T, seed=seed, **kw)
+    port.policy.load_state_dict(agent.policy.state_dict())
+    return agent, port, env
+
+
+def test_configs2_full_rows(monkeypatch):
+    """BASELINE configs[2] at its full row count: AntWall, 256 envs x 2048 steps = 524 288 rows, README.md:50 flags (batch 128 -> two
+    workgroups per network, 20 epochs of 4 096 minibatches, lr 3e-5, clip 0.4, lambdas 0.9, target_kl 0.02), constraint net [40, 40]."""
+    agent, port, env = _pair_rows("AntWall-v0", "ant", 256, 2048, 113, 8, [40, 40], 3, batch_size=128, n_epochs=20, target_kl=0.02,
+                                  learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9, cost_gae_lambda=0.9,
+                                  penalty_initial_value=0.1, penalty_learning_rate=0.05)
+    _full_rows_step(agent, port, env, "configs2full", 3e-5, monkeypatch)
+
+
+def test_configs3_shard_full_rows(monkeypatch):
+    """BASELINE configs[3] as ONE GPU sees it: HCWithPos, 2048 / 8 = 256 envs x 2048 steps = 524 288 rows, README.md:38 flags (batch 64,
+    10 epochs of 8 192 minibatches = up to 81 920 dependent optimiser steps, target_kl 0.01)."""
+    agent, port, env = _pair_rows("HCWithPos-v0", "hc", 256, 2048, 18, 6, [20], 0, batch_size=64, n_epochs=10, target_kl=0.01,
+                                  penalty_learning_rate=0.1)
+    lg, out = _full_rows_step(agent, port, env, "configs3shard", 3e-4, monkeypatch)
+    assert agent.policy.adam_step > 8192          # more than one whole epoch ran at full size
+
+
+def test_configs4_shard_full_rows(monkeypatch):
+    """BASELINE configs[4] as ONE GPU sees it: AntWallBroken, 4096 / 8 = 512 envs x 2048 steps = 1 048 576 rows, the reference's frozen
+    AntBroken constraint net, README.md:78 flags (batch 128, 20 epochs of 8 192 minibatches, lr 3e-5, clip 0.4, reward lambda 0.9,
+    target_kl 0.01, nu learning rate 1.0)."""
+    agent, port, env = _pair_rows("AntWallBroken-v0", "ant", 512, 2048, 113, 8, "cn_antbroken.npz", 4, broken=True, batch_size=128, n_epochs=20,
+                                  target_kl=0.01, learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9, penalty_learning_rate=1.0)
+    _full_rows_step(agent, port, env, "configs4shard", 3e-5, monkeypatch)

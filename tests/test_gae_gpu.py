@@ -111,9 +111,11 @@ def _run_ws(arrs, params, shape, ws):
     return [o.cpu().numpy() for o in outs]
 
 
-def _ws():
+def _ws(T=2048, N=1024):
+    """a zeroed workspace of the size the library asks for at this shape (never below ICRL_GAE_WS_BYTES)."""
+    from icrl_amd import _lib
     from icrl_amd.structs import GAE_WS_BYTES
-    return torch.zeros(GAE_WS_BYTES // 8 + 1, dtype=torch.int64, device="cuda:0")
+    return torch.zeros(max(int(_lib.lib().icrl_gae_dual_ws_bytes(T, N)), GAE_WS_BYTES) // 8, dtype=torch.int64, device="cuda:0")
 
 
 @pytest.mark.parametrize("case", ["t8n3", "t2000n1", "t256n16", "t1n4", "t64n5"])
@@ -141,9 +143,76 @@ def test_gae_split_vs_oracle_random(T, N):
     params = (0.99, 0.95, 0.99, 0.9)
     o = o_gae.dual_gae(arrs["rewards"], arrs["costs"], arrs["reward_values"], arrs["cost_values"],
                        arrs["dones"].astype(np.float32), arrs["last_v_r"], arrs["last_v_c"], arrs["last_dones"], *params)
-    ws = _ws()
+    ws = _ws(T, N)
     for rep in range(3):
         outs = _run_ws(arrs, params, 0, ws)
         for got, key in zip(outs, ("reward_advantages", "cost_advantages", "reward_returns", "cost_returns")):
             assert np.allclose(got, o[key], rtol=2e-7, atol=1e-7), (key, rep)
             assert (got != o[key]).mean() < 1e-5
+
+
+def _random_arrs(T, N, seed=None):
+    rng = np.random.RandomState(T + N if seed is None else seed)
+    arrs = dict(rewards=rng.randn(T, N), costs=rng.rand(T, N), reward_values=rng.randn(T, N), cost_values=rng.randn(T, N),
+                dones=(rng.rand(T, N) < 0.002), last_v_r=rng.randn(N), last_v_c=rng.randn(N), last_dones=rng.rand(N) < 0.2)
+    return {k: (v.astype(np.float32) if v.dtype != bool else v) for k, v in arrs.items()}
+
+
+@pytest.mark.parametrize("case", ["t8n3", "t2000n1", "t256n16", "t1n4", "t64n5"])
+def test_gae_register_resident_split_golden(golden, case):
+    """the register-resident split scan (round 6; shape code 500) on the reference's golden vectors: T = 1 (head row only), T = 8 (one wave),
+    T = 2000 (16 chunks, the last ragged), one workspace reused by consecutive launches."""
+    g = golden("g1_gae")
+    arrs = {k.split("/")[1]: g[k] for k in g.files if k.startswith(case + "/")}
+    T, N = arrs["rewards"].shape
+    ws = _ws(T, N)
+    for _ in range(2):
+        outs = _run_ws(arrs, arrs["params"], 500, ws)
+        for got, key in zip(outs, ("reward_advantages", "cost_advantages", "reward_returns", "cost_returns")):
+            assert np.allclose(got, arrs[key], rtol=2e-7, atol=1e-7), key
+    assert int(ws.view(torch.int32)[-1].item()) == 0
+
+
+@pytest.mark.parametrize("T,N", [(2048, 8192), (1024, 32768), (1000, 16390), (129, 9000), (256, 65472)])
+def test_gae_mid_range_vs_oracle(T, N):
+    """8 192 .. 65 472 envs (between the cache-resident and the streaming regime) through the DEFAULT heuristic with the
+    workspace the library asks for: 2 048 .. 16 368 workgroups of the register-resident split scan, non-temporal accesses; ragged tiles and
+    ragged chunks; <= 1 ulp of float32 from the sequential scan and almost everywhere equal (ref: buffers.py:493-552)."""
+    arrs = _random_arrs(T, N)
+    params = (0.99, 0.95, 0.99, 0.9)
+    o = o_gae.dual_gae(arrs["rewards"], arrs["costs"], arrs["reward_values"], arrs["cost_values"],
+                       arrs["dones"].astype(np.float32), arrs["last_v_r"], arrs["last_v_c"], arrs["last_dones"], *params)
+    ws = _ws(T, N)
+    for rep in range(2):
+        outs = _run_ws(arrs, params, 0, ws)
+        for got, key in zip(outs, ("reward_advantages", "cost_advantages", "reward_returns", "cost_returns")):
+            assert np.allclose(got, o[key], rtol=2e-7, atol=1e-7), (key, rep)
+            assert (got != o[key]).mean() < 1e-5
+    assert int(ws.view(torch.int32)[-1].item()) == 0
+    # and it IS the split scan that ran: the same launch with the sequential shape forced is bit-exact, this one is not required to be
+    seq = _run_ws(arrs, params, 1, ws)
+    assert np.array_equal(seq[0], o["reward_advantages"])
+
+
+@pytest.mark.parametrize("shape", [501, 304])
+def test_gae_split_wait_is_bounded_and_reported(shape):
+    """every wait of the split scans ends.  Shape codes 501 (register-resident) / 300 + C (two-pass) withhold the map of the
+    workgroup holding the LATEST rows and shorten the poll limit: the launch must end, the workspace's status word must be 1, and
+    RolloutBufferWithCost.check_gae_status must raise and clear it; the next healthy launch on the same workspace is correct again."""
+    T, N = 1024, 192
+    arrs = _random_arrs(T, N, 7)
+    params = (0.99, 0.95, 0.99, 0.95)
+    ws = _ws(T, N)
+    _run_ws(arrs, params, shape, ws)                      # returns (synchronised) instead of hanging
+    status = ws.view(torch.int32)[-1:]
+    assert int(status.item()) == 1
+    from icrl_amd.buffers import RolloutBufferWithCost
+    rb = RolloutBufferWithCost.__new__(RolloutBufferWithCost)
+    rb.gae_status = status
+    with pytest.raises(RuntimeError, match="affine map"):
+        rb.check_gae_status()
+    assert int(status.item()) == 0
+    o = o_gae.dual_gae(arrs["rewards"], arrs["costs"], arrs["reward_values"], arrs["cost_values"],
+                       arrs["dones"].astype(np.float32), arrs["last_v_r"], arrs["last_v_c"], arrs["last_dones"], *params)
+    outs = _run_ws(arrs, params, 500 if shape == 501 else 204, ws)
+    assert np.allclose(outs[0], o["reward_advantages"], rtol=2e-7, atol=1e-7) and int(status.item()) == 0

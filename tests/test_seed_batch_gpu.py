@@ -28,7 +28,7 @@ def _snapshot(st, metrics):
     return dict(params=pol.params.cpu().numpy().copy(), exp_avg_sq=pol.exp_avg_sq.cpu().numpy().copy(), cn=cn.params.cpu().numpy().copy(),
                 obs_mean=np.asarray(env.obs_rms.mean).copy(), ret_var=float(env.ret_rms.var), nu=st["agent"].dual.nu().item(),
                 rewards=st["agent"].rollout_buffer.rewards.cpu().numpy().copy(),
-                metrics=[{k: v for k, v in m.items() if k != "time(m)"} for m in metrics])
+                metrics=[{k: v for k, v in m.items() if k not in ("time(m)", "time/fps", "time/time_elapsed")} for m in metrics])      # wall clock
 
 
 def _solo(cfg, n_iters):

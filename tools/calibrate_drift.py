@@ -31,7 +31,33 @@ SCHEDULES = {      # the arguments of tests/test_fullsize_parity_gpu.py's two te
     "configs2": dict(kind="ant", N=256, T=128, od=113, ad=8, cn=[40, 40], seed=3, lr=3e-5,
                      kw=dict(batch_size=128, n_epochs=20, target_kl=0.02, learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9, cost_gae_lambda=0.9,
                              penalty_initial_value=0.1, penalty_learning_rate=0.05)),
+    # round 6: the FULL row counts of BASELINE configs[2] and of the per-GPU shards of configs[3] / configs[4] (tests/test_fullsize_parity_gpu.py:
+    # test_configs2_full_rows, test_configs3_shard_full_rows, test_configs4_shard_full_rows) — one rollout + one train() each
+    "configs2full": dict(kind="ant", N=256, T=2048, od=113, ad=8, cn=[40, 40], seed=3, lr=3e-5, rollouts=1,
+                         kw=dict(batch_size=128, n_epochs=20, target_kl=0.02, learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9, cost_gae_lambda=0.9,
+                                 penalty_initial_value=0.1, penalty_learning_rate=0.05)),
+    "configs3shard": dict(kind="hc", N=256, T=2048, od=18, ad=6, cn=[20], seed=0, lr=3e-4, rollouts=1,
+                          kw=dict(batch_size=64, n_epochs=10, target_kl=0.01, penalty_learning_rate=0.1)),
+    "configs4shard": dict(kind="ant", broken=True, N=512, T=2048, od=113, ad=8, cn="tests/golden/cn_antbroken.npz", seed=4, lr=3e-5, rollouts=1,
+                          kw=dict(batch_size=128, n_epochs=20, target_kl=0.01, learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9,
+                                  penalty_learning_rate=1.0)),
 }
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def make_cost_net(sc):
+    """the schedule's constraint net on the CPU: a seeded fresh one, or the reference's AntBroken checkpoint through its off-by-one load()
+    (no clipping, no normalisation: constraint_net.py:394-399)."""
+    from oracle import nets as o_nets
+    od, ad = sc["od"], sc["ad"]
+    if isinstance(sc["cn"], str):
+        z = np.load(os.path.join(ROOT, sc["cn"]))
+        ocn = o_nets.CostNet(od, ad, [int(h) for h in z["hidden_sizes"]], False, None, None, None, None, None)
+        ocn.load_state_dict({k[len("cn_network/"):]: z[k] for k in z.files if k.startswith("cn_network/")})
+        return ocn
+    lo = -np.ones(ad, np.float32)
+    torch.manual_seed(sc["seed"] + 1)
+    return o_nets.CostNet(od, ad, sc["cn"], False, None, None, 20, lo, -lo)
 
 
 def run(variant, out_path, schedule="configs1"):
@@ -40,10 +66,8 @@ def run(variant, out_path, schedule="configs1"):
     torch.set_num_threads(8 if variant == "threads8" else 1)
     sc = SCHEDULES[schedule]
     N, T, od, ad, seed = sc["N"], sc["T"], sc["od"], sc["ad"], sc["seed"]
-    lo = -np.ones(ad, np.float32)
-    torch.manual_seed(seed + 1)
-    ocn = o_nets.CostNet(od, ad, sc["cn"], False, None, None, 20, lo, -lo)
-    stack = o_loop.make_stack(N, sc["kind"], seed); stack.cost_fn = ocn.cost_function
+    ocn = make_cost_net(sc)
+    stack = o_loop.make_stack(N, sc["kind"], seed, broken=sc.get("broken", False)); stack.cost_fn = ocn.cost_function
     port = o_loop.PortAgent(stack, n_steps=T, seed=seed, **sc["kw"])
     n_epochs = sc["kw"]["n_epochs"]
     with torch.no_grad():
@@ -70,7 +94,7 @@ def run(variant, out_path, schedule="configs1"):
     port.num_timesteps = 0
     port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
     res, t0 = [], time.time()
-    for k in range(2):
+    for k in range(sc.get("rollouts", 2)):
         b = port.collect_rollouts(streams.rollout_noise(T, N, port.act_dim))
         B = sc["kw"]["batch_size"]
 
@@ -103,7 +127,7 @@ def compare(base_path, others):
     worst = [dict(), dict()]
     for path in others:
         o = json.load(open(path))
-        for k in range(2):
+        for k in range(len(base)):
             a, b = base[k], o[k]
             d = lambda key: abs(a["scalars"][key] - b["scalars"][key])
             dp = max(float(np.abs(np.asarray(a["params"][n]) - np.asarray(b["params"][n])).max()) for n in a["params"])
@@ -117,7 +141,7 @@ def compare(base_path, others):
                   f"{d('train/clip_fraction'):.1e} | {int(a['scalars']['train/early_stop_epoch'])}, {int(b['scalars']['train/early_stop_epoch'])} | "
                   f"{dp:.2e} = {dp / (lr * steps):.1e} x lr x steps | {db['reward_values']:.1e} / {db['reward_advantages']:.1e} |")
     print()
-    for k in range(2):
+    for k in range(len(base)):
         r = np.sort(np.asarray(rates[k]))
         print(f"after train() #{k + 1} ({len(r)} disturbances): max |d param| / (lr x steps): min {r[0]:.2e}, median {np.median(r):.2e}, "
               f"90th percentile {np.percentile(r, 90):.2e}, max {r[-1]:.2e}; sorted: " + " ".join(f"{x:.2e}" for x in r))
