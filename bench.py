@@ -101,6 +101,7 @@ def timed_iterations(cfg, warmup, steps, world=1):
         I.outer_iteration(st, it)
     st["agent"].gae_events = []
     st["agent"].train_events = []
+    st["sync_events"], st["sync_host_ms"] = [], []          # around the iteration's one collective (icrl_amd/icrl.py: synchronise)
     st["rollout_events"] = []
     st["agent"].rollout_events = st["rollout_events"]
     torch.cuda.synchronize()
@@ -199,6 +200,10 @@ def timed_cpg(cfg, warmup, steps, world=1):
     if warmup > 0:
         model.learn(total_timesteps=warmup * per, cost_function=learn_cost, callback=cb)
     model.gae_events, model.train_events, model.rollout_events = [], [], []
+    model.sync_events = None
+    for c in cb.callbacks:
+        if hasattr(c, "sync_events"):
+            c.sync_events = model.sync_events = []
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -262,29 +267,99 @@ def configs2_leg(seed, steps=2, warmup=1):
     return out
 
 
+def allreduce_summary(events, per):
+    """device time (pack -> RCCL all-reduce -> unpack, events on the launch stream) of the collective, per outer iteration / per rollout + update."""
+    if not events:
+        return None
+    ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    return dict(ms_per_iteration=round(float(np.sum(ms)) / max(1, per), 3), calls=len(ms), ms_per_call=round(float(np.mean(ms)), 3))
+
+
+def scale_anchor_leg(seed):
+    """What the N > 1 lines must be divided by: `bench.py --gpus N>1` quotes BASELINE configs[3] (256 envs per GPU) or, with
+    --config 4, configs[4] (512 per GPU); the N = 1 headline is configs[1] (64 envs).  Here ONE rank runs exactly the per-GPU workload of those
+    lines through the MULTI-RANK code path: a 1-rank `nccl` (= RCCL) process group, allreduce_state(..., force_collective=True) once per outer
+    iteration / per rollout + update — same config2(...) / config_cpg(...), same timing as the N > 1 line.  per_gpu_value(N) / anchor.value is the
+    weak-scaling efficiency."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    out = {}
+    try:
+        cfg = config2(2, seed, 0, 1, 256)
+        cfg.force_collective = True
+        st, dt, env_steps = timed_iterations(cfg, 1, 1)
+        u = update_summary(st, cfg)
+        out["configs3"] = dict(workload="BASELINE configs[3]'s per-GPU shard: HCWithPos-v0 ICRL, 256 envs, one rank through the multi-rank path "
+                                        "(1-rank RCCL group, one flat float64 all-reduce per outer iteration)", envs_per_gpu=256,
+                               value=round(env_steps / dt, 1), unit="env-steps/s", steps=1, warmup=1, ms_per_step=round(1e3 * dt, 2),
+                               us_per_optimizer_step=round(u["us_per_optimizer_step"], 2),
+                               us_per_rollout_step=None if u["us_per_rollout_step"] is None else round(u["us_per_rollout_step"], 2),
+                               early_stop_fraction=round(1.0 - u["optimizer_steps"] / max(1, u["full_steps"]), 4),
+                               allreduce=allreduce_summary(st["sync_events"], 1), allreduce_host_ms=[round(x, 3) for x in st["sync_host_ms"]])
+        del st
+        torch.cuda.empty_cache()
+        cfg = config_cpg(seed, 0, 1)
+        cfg.force_collective = True
+        model, dt, env_steps = timed_cpg(cfg, 1, 1)
+        u, extra = cpg_summary(model, cfg, dt, env_steps, 1, 1)
+        out["configs4"] = dict(workload="BASELINE configs[4]'s per-GPU shard: cpg on AntWallBroken-v0, 512 envs, one rank through the multi-rank path "
+                                        "(1-rank RCCL group, one all-reduce per rollout + update)", envs_per_gpu=512,
+                               value=round(env_steps / dt, 1), unit="env-steps/s", steps=1, warmup=1, ms_per_step=round(1e3 * dt, 2),
+                               us_per_optimizer_step=extra["us_per_optimizer_step"], us_per_rollout_step=extra["us_per_rollout_step"],
+                               early_stop_fraction=extra["early_stop_fraction"], allreduce=allreduce_summary(model.sync_events, 1))
+        del model
+        torch.cuda.empty_cache()
+    finally:
+        dist.destroy_process_group()
+    out["how_to_read"] = ("`bench.py --gpus N` (N > 1) prints per_gpu_value = value / N for configs[3] (default) or configs[4] (--config 4): divide it by "
+                          "scale_anchor.configs3.value / scale_anchor.configs4.value of THIS line, not by the headline `value` (configs[1], 64 envs)")
+    return out
+
+
+_GAE_BUFFERS = {}
+
+
+def _gae_buffers(n_max):
+    """inputs / outputs of the sweep, allocated once at the largest size (9 x 1.07 GB at 131 072 x 2048); smaller points use their heads."""
+    if _GAE_BUFFERS.get("n", 0) < n_max:
+        dev = torch.device("cuda")
+        _GAE_BUFFERS.clear()
+        torch.cuda.empty_cache()
+        _GAE_BUFFERS.update(n=n_max, ins=[torch.randn(n_max, device=dev) for _ in range(4)] + [(torch.rand(n_max, device=dev) < 0.001).float()],
+                            outs=[torch.empty(n_max, device=dev) for _ in range(4)])
+    return _GAE_BUFFERS
+
+
 def gae_sweep_point(N=131072, T=2048, reps=48):
-    """the same entry point at 131 072 envs: working set 9.7 GB >> 256 MB Infinity Cache, the HBM-streaming regime (the library
-    picks the four-columns-per-lane streaming shape from 65 536 envs on; bit-exact like the one-column scan).  In the same process,
-    on the same stream and buffers, interleaved with the GAE launches: `icrl_debug_stream_ref` mode 0 (the launch shape and the
-    5-loads-4-stores traffic of the GAE kernel without its recurrence: the same 9.66 GB) and mode 1 (a flat float4 copy, 8.59 GB) —
-    what THIS box streams, so that the kernel can be judged apart from the box's HBM rate."""
+    """icrl_gae_dual_ws (the entry point RolloutBufferWithCost calls, with the workspace the library asks for) at N envs x T rows.  At
+    131 072 envs: working set 9.7 GB >> 256 MB Infinity Cache, the HBM-streaming regime (four columns per lane; bit-exact like the
+    one-column scan); 8 192 .. 65 472 envs: the register-resident split scan (round 6).  In the same process, on the same stream and buffers,
+    interleaved with the GAE launches: `icrl_debug_stream_ref` mode 0 (the streaming launch shape and the 5-loads-4-stores traffic of the GAE
+    kernel without its recurrence: the same 36 B per transition) and mode 1 (a flat float4 copy, 32 B per transition) — what THIS box streams
+    at this size, so that the kernel can be judged apart from the box's HBM rate."""
     from icrl_amd import _lib
     L = _lib.lib()
     dev = torch.device("cuda")
-    ins = [torch.randn(T, N, device=dev) for _ in range(4)] + [(torch.rand(T, N, device=dev) < 0.001).float()]
+    b = _gae_buffers(T * N)
+    ins = [x[:T * N].view(T, N) for x in b["ins"]]
+    outs = [x[:T * N].view(T, N) for x in b["outs"]]
     lv = [torch.randn(N, device=dev) for _ in range(2)]
     ld = torch.zeros(N, dtype=torch.uint8, device=dev)
-    outs = [torch.empty(T, N, device=dev) for _ in range(4)]
+    ws = torch.zeros(int(L.icrl_gae_dual_ws_bytes(T, N)) // 8, dtype=torch.int64, device=dev)
     args = [_lib.ptr(x) for x in (*ins, *lv, ld, *outs)]
     cargs = [_lib.ptr(x) for x in (*ins, *outs)]
     st = _lib.current_stream()
-    launch = {"gae": lambda: L.icrl_gae_dual(*args, T, N, 0.99, 0.95, 0.99, 0.95, st),
-              "ref": lambda: L.icrl_debug_stream_ref(*cargs, T, N, 0, st),
+    launch = {"gae": lambda: L.icrl_gae_dual_ws(*args, T, N, 0.99, 0.95, 0.99, 0.95, 0, _lib.ptr(ws), ws.numel() * 8, st),
               "copy": lambda: L.icrl_debug_stream_ref(*cargs, T, N, 1, st)}
+    if N % 4 == 0 and N >= 16384:       # (the streaming shape's grid is N / 256 one-wave workgroups: no reference below a full chip)
+        launch["ref"] = lambda: L.icrl_debug_stream_ref(*cargs, T, N, 0, st)
     for f in launch.values():
         for _ in range(3):
             _lib.check(f(), "gae sweep")
     torch.cuda.synchronize()
+    assert int(ws.view(torch.int32)[-1].item()) == 0
     ms = {k: [] for k in launch}
     rounds, per = 6, max(1, reps // 6)
     for _ in range(rounds):                     # interleaved rounds: a drifting HBM clock hits all three alike
@@ -298,12 +373,28 @@ def gae_sweep_point(N=131072, T=2048, reps=48):
             ms[k].append(e0.elapsed_time(e1) / per)
     t = {k: float(np.median(v)) for k, v in ms.items()}      # (median over the rounds: one disturbed round of one kernel would move a mean by 5-20 %)
     gbs = lambda nbytes, k: nbytes / (t[k] * 1e-3) / 1e9
-    return dict(envs=N, T=T, bytes=T * N * 36, us=t["gae"] * 1e3, achieved=gbs(T * N * 36, "gae"),
-                ref_gbs=gbs(T * N * 36, "ref"), ref_us=t["ref"] * 1e3, copy_gbs=gbs(T * N * 32, "copy"), copy_us=t["copy"] * 1e3,
+    tiles = (N + 63) // 64
+    kernel = ("gae_dual_x4_kernel<4,1>" if tiles >= 2048 and N % 4 == 0 else "gae_dual_kernel<1,16,nt,4>" if tiles >= 1024 else
+              f"gae_dual_regsplit_kernel ({tiles} x {-(-T // 128)} workgroups)" if T <= 2048 else "gae_dual_kernel")
+    return dict(envs=N, T=T, bytes=T * N * 36, us=t["gae"] * 1e3, achieved=gbs(T * N * 36, "gae"), kernel=kernel,
+                ref_gbs=gbs(T * N * 36, "ref") if "ref" in t else None, ref_us=t["ref"] * 1e3 if "ref" in t else None,
+                copy_gbs=gbs(T * N * 32, "copy"), copy_us=t["copy"] * 1e3,
                 launches=rounds * per, spread={k: [round(min(v) * 1e3), round(max(v) * 1e3)] for k, v in ms.items()})
 
 
-def gae_roofline(sweep, in_loop):
+def gae_size_sweep(sizes=(64, 512, 4096, 8192, 32768, 65536), T=2048):
+    """SURVEY 8(d)'s size sweep with the current kernels (VERDICT r5 #6): every point through the default heuristic of icrl_gae_dual_ws."""
+    rows = []
+    for N in sizes:
+        p = gae_sweep_point(N, T, reps=48 if N >= 4096 else 96)
+        rows.append(dict(envs=N, T=T, kernel=p["kernel"], us=round(p["us"], 1), achieved=round(p["achieved"], 1), frac=round(p["achieved"] / HBM_PEAK_GBS, 4),
+                         frac_of_copy=None if p["ref_gbs"] is None else round(p["achieved"] / p["ref_gbs"], 4),
+                         frac_of_flat_copy=round(p["achieved"] / p["copy_gbs"], 4), bytes=p["bytes"],
+                         regime="cache-resident" if p["bytes"] * 20 // 36 <= 256e6 else "hbm"))
+    return rows
+
+
+def gae_roofline(sweep, in_loop, size_sweep=None):
     """the `roofline` object: the dual-GAE kernel at the HBM-streaming launch shape, timed live with events on the launch stream;
     `traffic` from the committed PMC passes of the same launch shape (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, separate --pmc passes)."""
     import glob
@@ -313,7 +404,10 @@ def gae_roofline(sweep, in_loop):
     if os.path.exists(pmc_path):
         with open(pmc_path) as f:
             pmc = json.load(f)
-        if pmc["T"] == sweep["T"] and pmc["N"] == sweep["envs"]:
+        # the figure is a committed measurement of gae.hip's streaming kernel: it may ride along only while that source is the one measured
+        import hashlib
+        gae_sha = hashlib.sha256(open(os.path.join(ROOT, "icrl_amd", "csrc", "gae.hip"), "rb").read()).hexdigest()[:16]
+        if pmc["T"] == sweep["T"] and pmc["N"] == sweep["envs"] and pmc.get("gae_hip_sha16") == gae_sha:
             traffic = int(pmc["traffic_bytes"])
     r = dict(kernel="gae_dual_x4_kernel", bound="hbm", achieved=round(sweep["achieved"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
              frac=round(sweep["achieved"] / HBM_PEAK_GBS, 4), traffic=traffic,
@@ -332,6 +426,10 @@ def gae_roofline(sweep, in_loop):
              launches_timed=sweep["launches"], us_min_max_per_round=sweep["spread"])
     if in_loop is not None:
         r["in_loop"] = in_loop
+    if size_sweep is not None:
+        r["sweep"] = size_sweep + [dict(envs=sweep["envs"], T=sweep["T"], kernel=sweep["kernel"], us=round(sweep["us"], 1), achieved=round(sweep["achieved"], 1),
+                                        frac=round(sweep["achieved"] / HBM_PEAK_GBS, 4), frac_of_copy=round(sweep["achieved"] / sweep["ref_gbs"], 4),
+                                        frac_of_flat_copy=round(sweep["achieved"] / sweep["copy_gbs"], 4), bytes=sweep["bytes"], regime="hbm")]
     return r
 
 
@@ -405,6 +503,7 @@ def main():
     ap.add_argument("--no_configs2", action="store_true")
     ap.add_argument("--no_configs3", action="store_true")
     ap.add_argument("--no_configs4", action="store_true")
+    ap.add_argument("--no_scale_anchor", action="store_true", help="skip the one-rank anchors of the N > 1 lines (configs[3] / configs[4] shards through a 1-rank RCCL group)")
     ap.add_argument("--no_generic", action="store_true", help="skip the generic-shape extra (a non-default net_arch at toy size)")
     ap.add_argument("--envs_per_gpu", type=int, default=None, help="override the env count per GPU (e.g. 2048: BASELINE configs[3] whole on one GPU)")
     a = ap.parse_args()
@@ -445,6 +544,9 @@ def main():
                                batch_size=cfg.batch_size, n_epochs=cfg.n_epochs, baseline_config=4, mode=a.mode, parallelism=par),
                    roofline=gae_roofline(sweep, None), **extra)
         out["cpu_baseline"] = None
+        out["per_gpu_value"] = round(env_steps / dt / world, 1)
+        out["scale_anchor_ref"] = "scale_anchor.configs4.value of the N = 1 line (`python bench.py`): the same 512-env shard on one rank through this code path"
+        out["allreduce"] = allreduce_summary(getattr(model, "sync_events", None), a.steps)
         print(json.dumps(out))
         return
 
@@ -457,6 +559,15 @@ def main():
     # ---- the outer loop, one iteration at a time (identical calls to icrl_amd.icrl.icrl; see that function)
     st, dt, env_steps = timed_iterations(cfg, a.warmup, a.steps, world)
     dt, env_steps = reduce_over_ranks(dt, env_steps)
+    if os.environ.get("ICRL_BENCH_RANK_DUMP"):      # tests/test_bench_launch_gpu.py: which env keys a rank stepped, what it holds after the last reduce
+        import hashlib
+        ag, cn_, senv = st["agent"], st["constraint_net"], st["train_env"].unwrapped
+        h = hashlib.sha256()
+        for t_ in (ag.policy.params, ag.policy.exp_avg, ag.policy.exp_avg_sq, cn_.params, st["train_env"].obs_rms.d_mean, st["train_env"].obs_rms.d_var):
+            h.update(t_.detach().cpu().numpy().tobytes())
+        with open(os.path.join(os.environ["ICRL_BENCH_RANK_DUMP"], f"rank{rank}.json"), "w") as f:
+            json.dump(dict(rank=rank, world=world, env_keys=(lambda k: [int(k.min()), int(k.max()) + 1, int(len(set(k.tolist())))])(senv.key.cpu().numpy().view(np.uint32)),
+                           state_sha=h.hexdigest(), nu=float(ag.dual.nu().item()), adam_step=int(ag.policy.adam_step), env_steps=float(st["timesteps"])), f)
     if rank != 0:
         return
 
@@ -466,10 +577,13 @@ def main():
     gae_bytes = T * N * 36
     gae_ach = gae_bytes / (np.mean(gae_us) * 1e-6) / 1e9
     sweep = gae_sweep_point()
+    size_sweep = gae_size_sweep() if world == 1 else None
+    _GAE_BUFFERS.clear()
+    torch.cuda.empty_cache()
     roofline = gae_roofline(sweep, dict(achieved=round(gae_ach, 1), frac=round(gae_ach / HBM_PEAK_GBS, 5), us_per_launch=round(float(np.mean(gae_us)), 1),
                                         launches=len(gae_us), bytes_per_launch=gae_bytes,
                                         note="the launch the loop itself makes (cache-resident, latency-bound): two-level scan, "
-                                             "time axis split over workgroups x 8 waves (gae_dual_split_kernel)"))
+                                             "time axis split over workgroups x 8 waves, rows register-resident (gae_dual_regsplit_kernel)"), size_sweep)
     # ---- the PPO kernel: algorithmic flops per optimiser step (update_flops) / the events around icrl_ppo_lag_train
     u = update_summary(st, cfg)
     B = cfg.batch_size
@@ -502,6 +616,14 @@ def main():
                value_no_early_stop=round(no_early_stop(env_steps / world, dt, u) * world, 1),      # (rank 0's step counts stand for every rank's)
                roofline=roofline, roofline_ppo=roofline_ppo)
     out["cpu_baseline"] = None if (a.no_cpu_baseline or world > 1) else cpu_baseline()      # reported at N = 1 only
+    out["per_gpu_value"] = round(env_steps / dt / world, 1)
+    if world > 1:
+        out["scale_anchor_ref"] = ("scale_anchor.configs3.value of the N = 1 line (`python bench.py`): the same 256-env shard on one rank through this code path"
+                                   if config_id == 3 and envs == 256 else "a one-rank run of this line's own flags")
+        out["allreduce"] = allreduce_summary(st["sync_events"], a.steps)
+    if out["cpu_baseline"] is not None:       # no published number exists for this metric: the ratio to the reference-equivalent CPU figure
+        out["vs_baseline"] = round(out["value"] / out["cpu_baseline"]["reference_equivalent"], 1)
+        out["vs_baseline_note"] = "value / cpu_baseline.reference_equivalent (the reference's CPU path on this host, via the port: BASELINE.md section 4); BASELINE.md publishes no number for this metric"
     del st
     torch.cuda.empty_cache()
     if world == 1 and not a.no_configs2:
@@ -512,6 +634,11 @@ def main():
         out["configs4"] = configs4_leg(a.seed)
     if world == 1 and not a.no_generic:
         out["generic_shape"] = generic_shape_leg(a.seed)
+    if world == 1 and not a.no_scale_anchor and config_id == 1 and a.envs_per_gpu is None:
+        try:
+            out["scale_anchor"] = scale_anchor_leg(a.seed)
+        except Exception as e:      # (a box without a working RCCL must not cost the headline line)
+            out["scale_anchor"] = dict(error=f"{type(e).__name__}: {e}")
     if world == 1 and not a.no_seed_batch:
         out["seed_batch"] = seed_batch_leg()
     print(json.dumps(out))

@@ -231,9 +231,11 @@ class RankSyncCallback(BaseCallback):
     agrees on the step counters and merges the three running-moment sets exactly — the same message as an outer ICRL iteration's,
     without the constraint net (frozen here)."""
 
-    def __init__(self, train_env, world):
+    def __init__(self, train_env, world, force_collective=False):
         super().__init__()
         self.train_env, self.world, self.rollouts = train_env, world, 0
+        self.force_collective = force_collective       # bench.py's scale anchor: one rank through this path (a 1-rank RCCL group)
+        self.sync_events = None                        # a list: (start, end) event pairs around every synchronise()
 
     def _on_training_start(self):
         from . import distributed as D
@@ -249,8 +251,15 @@ class RankSyncCallback(BaseCallback):
             scal = D.Scalars(avg=[(dual, "log_nu"), (dual, "m"), (dual, "v")], counters=[(pol, "adam_step"), (dual, "t")])
         else:
             scal = D.Scalars(avg=[(dual, "pid_i"), (dual, "cost_penalty"), (dual, "_delta_p"), (dual, "_cost_delta")], counters=[(pol, "adam_step")])
-        self.rms_prev = D.allreduce_state([pol.params, pol.exp_avg, pol.exp_avg_sq], self.rms_list, self.rms_prev, self.world, scalars=scal)
+        ev = None
+        if self.sync_events is not None:
+            import torch
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)); ev[0].record()
+        self.rms_prev = D.allreduce_state([pol.params, pol.exp_avg, pol.exp_avg_sq], self.rms_list, self.rms_prev, self.world, scalars=scal,
+                                          force_collective=self.force_collective)
         pol.prepare()
+        if ev is not None:
+            ev[1].record(); self.sync_events.append(ev)
 
     def _on_rollout_start(self):
         if self.rollouts > 0:

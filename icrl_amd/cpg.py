@@ -112,8 +112,8 @@ def setup(config, log=print):
            callbacks.AdjustedRewardCallback(get_true_cost_function(config.eval_env_id)), hist]
     if config.save_dir and rank == 0:
         cbs.insert(0, callbacks.CheckpointCallback(int(config.save_every), os.path.join(config.save_dir, "models"), verbose=0))
-    if world > 1:      # env shards (BASELINE configs[4]: 4096 envs over 8 GPUs): one all-reduce per rollout + update
-        cbs.insert(0, callbacks.RankSyncCallback(train_env, world))
+    if world > 1 or getattr(config, "force_collective", False):      # env shards (BASELINE configs[4]: 4096 envs over 8 GPUs): one all-reduce per rollout + update
+        cbs.insert(0, callbacks.RankSyncCallback(train_env, world, force_collective=bool(getattr(config, "force_collective", False))))
     cb = callbacks.CallbackList(cbs)
     # ref: icrl/cpg.py:201-203 — `-cis None` hands the callable itself to learn() (costs evaluated outside the env chain)
     learn_cost = config.cost_info_str if config.cost_info_str is not None else cost_function

@@ -25,6 +25,8 @@
 //   3 quad hand-offs (h1 | head partials | dz2) through LDS flags and 3 workgroup barriers per optimiser step.
 //
 // Built with -ffp-contract=off; FMA is used only where written (fmaf / MFMA).
+#include <type_traits>
+
 #include "ppo_common.h"
 
 // (measured, round 5, us per optimiser step on one box: early publish + staging inside the hop 6.91 | early publish 6.89 | neither 6.87 |
@@ -43,6 +45,23 @@
 // in round 4, when the granules still crossed the fabric)
 #ifndef ICRL_HALVES_EARLY_POLL
 #define ICRL_HALVES_EARLY_POLL 1
+#endif
+// round 6 levers (each bit-identical to the plain order, measured by tools/ab_train.sh):
+// ICRL_HALVES_ADAM_TRIM: Adam only on the elements of the head / bias groups that can hold a parameter (head outputs are dealt four per
+//   MFMA k group: 6 actions = 2 of a lane's 4 elements, a critic 1; the bias group {b1, b2, head bias | log_std, pad} = 2 or 3 of 4): the
+//   Adam phase is VALU-bound (two quarter-rate transcendentals per element) and the pad elements cost what the real ones cost
+#ifndef ICRL_HALVES_ADAM_TRIM
+#define ICRL_HALVES_ADAM_TRIM 1
+#endif
+// ICRL_HALVES_ADAM_PRE: the moments are scaled by beta1 / beta2 (m *= beta1, v *= beta2 — the part of Adam that needs neither the gradient
+//   nor the clip coefficient) inside the first exchange hop, where the wave only waits for its partner's flag
+#ifndef ICRL_HALVES_ADAM_PRE
+#define ICRL_HALVES_ADAM_PRE 0
+#endif
+// ICRL_HALVES_LOSS_WAVES: how many of a quad's four waves evaluate the loss tail (4: all, on identical values; 2: one per SIMD of the quad;
+//   1: one) — the others take d loss / d head output from an LDS record of the first
+#ifndef ICRL_HALVES_LOSS_WAVES
+#define ICRL_HALVES_LOSS_WAVES 4
 #endif
 // A/B: the four waves of a quad on four SIMDs (rt2 = w >> 2) instead of two and two (rt2 = w & 1)
 #ifndef ICRL_HALVES_QUAD_SPREAD
@@ -91,7 +110,8 @@ struct SmemH {  // offsets in floats (multiples of 4)
   static constexpr int PST = ADC + HR;         // [2][8] per-row-tile loss statistics
   static constexpr int PLS = PST + 16;         // [2][16] per-row-tile d log_std partial sums
   static constexpr int MISC = PLS + 32;        // [64] granule values, flags, advantage-statistics partials
-  static constexpr int TOTAL = MISC + 64;
+  static constexpr int DOX = MISC + 64;        // [2][64][4] d loss / d head output of a quad's first wave, lane for lane (ICRL_HALVES_LOSS_WAVES < 4)
+  static constexpr int TOTAL = DOX + 512;
 };
 
 #define KARGS() ([&]() { const TrainArgs* k_ = ka; asm volatile("" : "+s"(k_)); return k_; }())
@@ -483,7 +503,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       STAMP(0)   // forward
       // ============ loss + d loss / d head output (all four waves of a quad: identical values) ============
       f32x4 dout = f32x4{0.f, 0.f, 0.f, 0.f};
-      {
+      if (ICRL_HALVES_LOSS_WAVES >= 4 || fq < ICRL_HALVES_LOSS_WAVES) {
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
         if (role == 0) {
           const int ngp = (A + 3) >> 2;      // groups of four outputs that hold real ones
@@ -574,6 +594,14 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           if (lane == 0) { float* pst = sm + S::PST + 8 * rt2; pst[0] = v0; pst[1] = v1; pst[2] = v2; pst[3] = v3; pst[4] = v4; }
         }
       }
+#if ICRL_HALVES_LOSS_WAVES < 4
+      {  // (P3b) the quad's first wave hands d loss / d head output over, lane for lane; the waves that skipped the tail wait for it
+        float* const dox = sm + S::DOX + (rt2 * 64 + lane) * 4;
+        if (fq == 0) *reinterpret_cast<f32x4*>(dox) = dout;
+        quad_signal();
+        if (fq >= ICRL_HALVES_LOSS_WAVES) { quad_wait(); dout = lds128(dox); }
+      }
+#endif
       STAMP(1)   // loss
       // ================= backward of the activations =================
       f32x4 dz2c, dz1c;
@@ -724,6 +752,18 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         if (xcd_local) __builtin_amdgcn_raw_buffer_store_b32(step, grs, xmine + HX_FLAG + 64 * w, 0, 1);
         else __builtin_amdgcn_raw_buffer_store_b32(step, grs, xmine + HX_FLAG + 64 * w, 0, 16);
       }
+#if ICRL_HALVES_ADAM_PRE
+      {  // beta-scaled moments: needs neither the summed gradient nor the clip coefficient (completed by this step's Adam below)
+        const float omw1_ = 1.f - w1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { mW1[i] *= omw1_; vW1[i] *= adam_b2f; mW2[0][i] *= omw1_; vW2[0][i] *= adam_b2f; mW2[1][i] *= omw1_; vW2[1][i] *= adam_b2f; }
+        if (lowk) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { mWh[i] *= omw1_; vWh[i] *= adam_b2f; }
+          mb1 *= omw1_; vb1 *= adam_b2f; mb2 *= omw1_; vb2 *= adam_b2f; mex *= omw1_; vex *= adam_b2f;
+        }
+      }
+#endif
       if (ICRL_HALVES_STAGE_IN_HOP) {
         commit_rows(xcur == S::XT0 ? S::XT1 : S::XT0);
         stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
@@ -867,28 +907,45 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       const float epsf = adam_epsf;
       const float omw1 = 1.f - w1, b2f_ = adam_b2f;
       const float cw1 = coef * w1, c2w2 = (coef * coef) * w2;
-      auto adam4 = [&](const f32x4& g, f32x4& m, f32x4& v, f32x4& p) {   // stage by stage: four independent chains
-        f32x4 d;
+      // (ICRL_HALVES_ADAM_PRE: m and v arrive already scaled by beta1 / beta2 — same products, formed earlier)
+      auto adamn = [&](auto NE, const f32x4& g, f32x4& m, f32x4& v, f32x4& p) {   // stage by stage: NE independent chains (elements 0 .. NE - 1)
+        constexpr int E = decltype(NE)::value;
+        f32x4 d = f32x4{1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { m[i] = fmaf(cw1, g[i], omw1 * m[i]); v[i] = fmaf(c2w2, g[i] * g[i], b2f_ * v[i]); }
+        for (int i = 0; i < E; ++i) {
+          m[i] = fmaf(cw1, g[i], ICRL_HALVES_ADAM_PRE ? m[i] : omw1 * m[i]);
+          v[i] = fmaf(c2w2, g[i] * g[i], ICRL_HALVES_ADAM_PRE ? v[i] : b2f_ * v[i]);
+        }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[i] = fmaf(__builtin_amdgcn_sqrtf(v[i]), inv_bc2_sqrt, epsf);   // v_sqrt_f32 / v_rcp_f32: 1 ulp each
+        for (int i = 0; i < E; ++i) d[i] = fmaf(__builtin_amdgcn_sqrtf(v[i]), inv_bc2_sqrt, epsf);   // v_sqrt_f32 / v_rcp_f32: 1 ulp each
 #pragma unroll
-        for (int i = 0; i < 4; ++i) p[i] = fmaf(-step_size, m[i] * __builtin_amdgcn_rcpf(d[i]), p[i]);
+        for (int i = 0; i < E; ++i) p[i] = fmaf(-step_size, m[i] * __builtin_amdgcn_rcpf(d[i]), p[i]);
       };
+      auto adam4 = [&](const f32x4& g, f32x4& m, f32x4& v, f32x4& p) { adamn(std::integral_constant<int, 4>{}, g, m, v, p); };
       // pad elements (k >= obs, o >= n_out) have g = m = v = p = 0 and stay 0: no masks needed
       { f32x4 p_ = load_own_w1(); adam4(gW1r, mW1, vW1, p_); store_w1(p_); }
       if (lowk) {
         f32x4 g_ = f32x4{gb1r, gb2r, ex_g >= 0 ? gex : 0.f, 0.f}, p_ = f32x4{sm[S::B1 + jb], sm[S::B2 + jb], sm[ex_s], 0.f};
         f32x4 m_ = f32x4{mb1, mb2, mex, 0.f}, v_ = f32x4{vb1, vb2, vex, 0.f};
-        adam4(g_, m_, v_, p_);     // identical arithmetic in the four q lanes, lane q == 0 stores
+        // identical arithmetic in the four q lanes, lane q == 0 stores; the third element exists on the head-bias / log_std waves only
+        const bool has_ex = w == W_BH || (!DISC && role == 0 && w == W_LS);
+        if (!ICRL_HALVES_ADAM_TRIM) adam4(g_, m_, v_, p_);
+        else if (has_ex) adamn(std::integral_constant<int, 3>{}, g_, m_, v_, p_);
+        else adamn(std::integral_constant<int, 2>{}, g_, m_, v_, p_);
         mb1 = m_[0]; mb2 = m_[1]; mex = m_[2]; vb1 = v_[0]; vb2 = v_[1]; vex = v_[2];
         if (q == 0) { sm[S::B1 + jb] = p_[0]; sm[S::B2 + jb] = p_[1]; sm[ex_s] = p_[2]; }
       }
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) { f32x4 p_ = load_own_w2(cc); adam4(gW2r[cc], mW2[cc], vW2[cc], p_); store_w2(cc, p_); }
       if (lowk) {
-        { f32x4 p_ = load_own_wh(); adam4(gWhr, mWh, vWh, p_); store_wh(p_); }
+        {   // head weights: element i of a lane is output 4 i + q — only the k groups that hold an output can hold a parameter
+          f32x4 p_ = load_own_wh();
+          const int ngw = (n_out + 3) >> 2;
+          if (!ICRL_HALVES_ADAM_TRIM || ngw > 2) adam4(gWhr, mWh, vWh, p_);
+          else if (ngw == 2) adamn(std::integral_constant<int, 2>{}, gWhr, mWh, vWh, p_);
+          else adamn(std::integral_constant<int, 1>{}, gWhr, mWh, vWh, p_);
+          store_wh(p_);
+        }
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the log_std store has landed before refresh_gauss re-reads it
         refresh_gauss();
       }

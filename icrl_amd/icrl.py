@@ -91,7 +91,7 @@ def setup(config):
               d_expert_acs=torch.as_tensor(np.asarray(expert_acs), device=dev),
               timesteps=0., start_time=time.time(),
               best=dict(reward=-np.inf, cost=np.inf, fkl=np.inf, rkl=np.inf))
-    if world > 1:     # common history of the running moments for the exact cross-rank merge: the (identical) initial state
+    if world > 1 or getattr(config, "force_collective", False):     # common history of the running moments for the exact cross-rank merge: the (identical) initial state
         st["rms_list"] = [train_env.obs_rms, train_env.ret_rms, train_env.cost_rms]
         st["rms_prev"] = [D.moments_to_sums(r.mean, r.var, r.count) for r in st["rms_list"]]
     if config.warmup_timesteps is not None:    # ref: icrl/icrl.py:185-193 — no cost is incurred during the warm-up
@@ -104,7 +104,8 @@ def setup(config):
 def synchronise(st):
     """the single collective of an outer iteration (no-op on one rank): average policy / constraint-net parameters and Adam
     moments and the dual variable, agree on the step counters, merge the three running-moment sets exactly."""
-    if st["world"] <= 1:
+    force = bool(getattr(st["config"], "force_collective", False))      # bench.py's scale anchor: ONE rank through the multi-rank path
+    if st["world"] <= 1 and not force:
         return
     agent, cn = st["agent"], st["constraint_net"]
     pol, dual = agent.policy, agent.dual
@@ -114,9 +115,14 @@ def synchronise(st):
     else:       # PIDLagrangian: controller state is averaged; its derivative history (a deque of past EMAs) stays per rank
         scal = D.Scalars(avg=[(dual, "pid_i"), (dual, "cost_penalty"), (dual, "_delta_p"), (dual, "_cost_delta")],
                          counters=[(pol, "adam_step"), (cn, "adam_step")])
+    ev, t0 = None, time.perf_counter()
+    if st.get("sync_events") is not None:      # (bench.py: the collective's share of an outer iteration, device time pack -> unpack)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)); ev[0].record()
     st["rms_prev"] = D.allreduce_state([pol.params, pol.exp_avg, pol.exp_avg_sq, cn.params, cn.exp_avg, cn.exp_avg_sq],
-                                       st["rms_list"], st["rms_prev"], st["world"], scalars=scal)
+                                       st["rms_list"], st["rms_prev"], st["world"], scalars=scal, force_collective=force)
     pol.prepare(); cn.prepare()
+    if ev is not None:
+        ev[1].record(); st["sync_events"].append(ev); st["sync_host_ms"].append(1e3 * (time.perf_counter() - t0))
 
 
 def outer_iteration(st, itr):

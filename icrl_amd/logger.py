@@ -34,5 +34,10 @@ def record(key, value, exclude=None):
     Logger.CURRENT.record(key, value, exclude)
 
 
+def dump(step=0):
+    """ref: logger.py:331-335, 492-504 — the reference writes the diagnostics of the iteration and clears them."""
+    Logger.CURRENT.dump(step)
+
+
 def configure():
     Logger.CURRENT = Logger()

@@ -723,5 +723,6 @@ class PPOLagrangian:
             logger.record("train/std", float(torch.exp(pol.log_std).mean().item()) if host is None else float(host[ns + 5]))
         logger.record("train/n_updates", self._n_updates)
         logger.record("train/clip_range", clip_range)
+        logger.record("train/learning_rate", float(self.lr_schedule(self._current_progress_remaining)))      # ref: base_class.py:221
         self.epoch_kls = st[32:32 + self.n_epochs].copy()
         self.phase_cycles = st[12:32].copy()

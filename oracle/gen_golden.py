@@ -497,6 +497,9 @@ def _lgw_expert_dir(tmp):
     return ep, d
 
 
+G8_WALL_CLOCK = ("time(m)", "time/fps", "time/time_elapsed")      # what no second run can reproduce
+
+
 def g8_icrl_lgw():
     """configs[0] end to end: the reference's OWN icrl(config) (icrl/icrl.py:45-312; real SubprocVecEnv workers, Monitor,
     plotting) on LGW-v0 / CLGW-v0 with the README.md:25 flags at a reduced size, 3 outer iterations.  Every random draw is
@@ -572,10 +575,14 @@ def g8_icrl_lgw():
     port_cfg = {k: cfg[k] for k in o_loop.PORT_DEFAULTS if k in cfg}
     om, _, _, objs = o_loop.icrl_port(port_cfg, expert["observations"][:4000], expert["actions"][:4000], esd, streams=RecordedStreams(g),
                                       init=dict(policy=snaps["policy"], cn=snaps["cn"]))
-    keys = sorted(k for k in logs[0] if k in om[0] and k != "time(m)")
+    # the golden file holds EVERY scalar the reference logged: the consumers decide what they skip (wall-clock keys,
+    # Monitor's episode statistics) in an explicit list; the port is compared here on what it produces
+    keys = sorted(logs[0])
+    assert all(sorted(m) == keys for m in logs), "the reference logged different key sets in different iterations"
+    cmp_keys = [k for k in keys if k in om[0] and k not in G8_WALL_CLOCK]
     worst = {}
     for it in range(ni):
-        for k in keys:
+        for k in cmp_keys:
             a, b = logs[it][k], float(om[it][k])
             worst[k] = max(worst.get(k, 0.0), 0.0 if (np.isnan(a) and np.isnan(b)) else abs(a - b) / max(1.0, abs(a)))
     missing = sorted(k for k in logs[0] if k not in om[0])

@@ -162,14 +162,18 @@ class PortAgent:
         self._n_updates += self.h["n_epochs"]
         average_cost = np.mean(self.buf.orig_costs)
         self.dual.update(average_cost)
+        em = lambda x: np.ascontiguousarray(x.T).reshape(-1)
         out.update({"train/nu": self.dual.nu().item(), "train/nu_loss": self.dual.loss.item(),
                     "train/average_cost": float(average_cost), "train/total_cost": float(np.sum(self.buf.orig_costs)),
-                    "train/mean_reward_advantages": float(np.mean(self.buf.reward_advantages.flatten())),
-                    "train/mean_cost_advantages": float(np.mean(self.buf.cost_advantages.flatten())),
+                    # (after get() the reference's arrays are flattened ENV-major, buffers.py:53-65,600-606: numpy's pairwise sums run in that order)
+                    "train/mean_reward_advantages": float(np.mean(em(self.buf.reward_advantages))),
+                    "train/mean_cost_advantages": float(np.mean(em(self.buf.cost_advantages))),
                     # ref: ppo_lag.py:311-312 — explained_variance(returns, values): y_pred = returns, y_true = values (argument order kept)
-                    "train/reward_explained_variance": explained_variance(self.buf.reward_returns.flatten(), self.buf.reward_values.flatten()),
-                    "train/cost_explained_variance": explained_variance(self.buf.cost_returns.flatten(), self.buf.cost_values.flatten()),
-                    "train/n_updates": self._n_updates})
+                    "train/reward_explained_variance": explained_variance(em(self.buf.reward_returns), em(self.buf.reward_values)),
+                    "train/cost_explained_variance": explained_variance(em(self.buf.cost_returns), em(self.buf.cost_values)),
+                    "train/n_updates": self._n_updates,
+                    # ref: base_class.py:221 (_update_learning_rate) and ppo_lag.py:333 — constant schedules in this fork's runs
+                    "train/learning_rate": float(self.optimizer.param_groups[0]["lr"]), "train/clip_range": float(self.h["clip_range"])})
         if not self.discrete:
             out["train/std"] = th.exp(self.policy.params["log_std"]).mean().item()
         self.logs = out
@@ -351,7 +355,7 @@ def icrl_port(cfg, expert_obs, expert_acs, expert_policy_sd=None, n_iters=None, 
         expert_policy.load_state_dict(expert_policy_sd)
     A = 1 if discrete else env.act_dim
     out, steps, t0 = [], 0, time.time()
-    best = {"reward": -np.inf, "cost": np.inf}
+    best = {"reward": -np.inf, "cost": np.inf, "fkl": np.inf, "rkl": np.inf}
     if c["warmup_timesteps"] is not None:
         raise NotImplementedError("warm-up with null_cost is exercised through PortAgent directly")
     for itr in range(n_iters):
@@ -389,6 +393,8 @@ def icrl_port(cfg, expert_obs, expert_acs, expert_policy_sd=None, n_iters=None, 
         if expert_policy is not None:
             m["true/forward_kl"] = compute_kl(agent.policy, expert_obs, expert_acs, expert_policy)
             m["true/reverse_kl"] = compute_kl(expert_policy, orig_obs, acts, agent.policy)
+            best["fkl"], best["rkl"] = min(best["fkl"], m["true/forward_kl"]), min(best["rkl"], m["true/reverse_kl"])      # ref: icrl.py:276-279
+            m["best_true/best_forward_kl"], m["best_true/best_reverse_kl"] = best["fkl"], best["rkl"]
         m.update({k.replace("train/", "forward/"): v for k, v in fwd.items() if k.startswith(("train/", "time/"))})      # ref: icrl.py:299
         m.update(bw)
         m["time/forward_s"], m["time/rest_s"] = t_fwd, time.time() - t_it - t_fwd      # wall clock (bench.py's cpu_baseline)

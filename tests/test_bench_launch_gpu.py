@@ -14,9 +14,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(extra, nproc=2, timeout=900):
+def _launch(extra, nproc=2, timeout=900, dump_dir=None):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, ICRL_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if dump_dir is not None:
+        env["ICRL_BENCH_RANK_DUMP"] = str(dump_dir)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "1", "--warmup", "1"] + extra
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout, cwd=ROOT)
@@ -61,3 +63,19 @@ def test_configs4_cpg_transfer_two_ranks():
     assert r["config"]["baseline_config"] == 4 and r["n_gpus"] == 2 and "cpg" in r["metric"]
     assert _steps(r) == pytest.approx(2 * 32 * 2048, rel=1e-3)      # one rollout + update per rank in the timed learn()
     assert r["us_per_optimizer_step"] > 0 and r["optimizer_steps_per_iteration"] > 0 and "all-reduce / rollout" in r["config"]["parallelism"]
+
+
+def test_eight_ranks_own_eight_shards_and_agree_after_the_reduce(tmp_path):
+    """The driver's 8-GPU launch line with eight ranks on ONE GPU (gloo transport, 8 envs per rank, forward_timesteps = one rollout): every rank
+    steps its own env-key range [seed + 8 r, seed + 8 r + 8), the whole-job value counts all eight shards, the N > 1 line carries per_gpu_value /
+    scale_anchor_ref / the measured all-reduce, and after the last outer iteration's single all-reduce all ranks hold the SAME policy, moments,
+    constraint net, observation statistics and Lagrange multiplier."""
+    r = _launch(["--envs_per_gpu", "8"], nproc=8, timeout=1500, dump_dir=tmp_path)
+    assert r["n_gpus"] == 8 and r["config"]["baseline_config"] == 3 and r["scaling"] == "weak"
+    assert r["per_gpu_value"] == pytest.approx(r["value"] / 8, rel=1e-3) and isinstance(r["scale_anchor_ref"], str)
+    assert r["allreduce"]["calls"] == 1 and r["allreduce"]["ms_per_iteration"] > 0
+    dumps = [json.load(open(os.path.join(tmp_path, f"rank{k}.json"))) for k in range(8)]
+    ranges = sorted(tuple(d["env_keys"]) for d in dumps)
+    assert ranges == [(8 * k, 8 * k + 8, 8) for k in range(8)], ranges          # seed 0: eight disjoint, contiguous key ranges of 8 distinct keys
+    assert len({d["state_sha"] for d in dumps}) == 1 and len({d["nu"] for d in dumps}) == 1 and len({d["adam_step"] for d in dumps}) == 1
+    assert _steps(r) == pytest.approx(sum(d["env_steps"] for d in dumps) / 2, rel=1e-3)      # (warm-up + timed iteration in every rank's count)

@@ -85,13 +85,18 @@ def test_icrl_lgw_three_iterations_vs_reference(golden):
         assert np.array_equal(st["expert_agent"].policy.state_dict()[k].numpy(), v), k
     st["agent"].policy.load_state_dict(_sub(g, "w0/"))
     st["constraint_net"].load_state_dict(_sub(g, "cn0/"))
-    keys = [str(k) for k in g["metric_keys"]]
+    # every scalar the reference logged, minus the explicit skip list: wall clock, and Monitor's episode statistics (the device-resident env
+    # stack keeps no episode info buffer; SURVEY section 2 scopes Monitor out)
+    skip = ("time(m)", "time/fps", "time/time_elapsed", "rollout/ep_len_mean", "rollout/ep_rew_mean")
+    keys = [str(k) for k in g["metric_keys"] if str(k) not in skip]
+    assert len(keys) >= 50 and {"forward/reward_explained_variance", "forward/cost_explained_variance", "time/iterations", "forward/learning_rate"} <= set(keys)
     worst = {}
     for it in range(3):
         m = outer_iteration(st, it)
         missing = [k for k in keys if k not in m]
         assert not missing, missing
-        ref = dict(zip(keys, g["metrics"][it]))
+        assert all(k in m for k in ("time/fps", "time/time_elapsed"))      # logged (wall clock: not compared)
+        ref = dict(zip([str(k) for k in g["metric_keys"]], g["metrics"][it]))
         for k, v in _compare(it, m, ref, keys, True, 4000).items():
             worst[k] = max(worst.get(k, 0.0), v)
     print("worst absolute deviation from the reference over 3 outer iterations:",
@@ -367,3 +372,68 @@ def test_learn_at_per_gpu_shard_shapes_vs_port(env_id, N, T, B, epochs):
         worst = max(worst, float(np.abs(v.numpy() - ref).max()))
         assert np.allclose(v.numpy(), ref, rtol=1e-3, atol=2e-5), (k, np.abs(v.numpy() - ref).max())
     print(f"{env_id} x {N}: {n_steps} optimiser steps, worst parameter deviation {worst:.3g}")
+
+
+def _tol(k, ref, discrete=False, n_nominal=10000):
+    """the module's per-key tolerance as one number (what _compare accepts around `ref`)."""
+    if k in EXACT_INT:
+        return 0.0
+    if k == "forward/nu":
+        return 1e-5
+    if k in ("true/cost", "best_true/best_cost", "true/samples_behind", "true/samples_infront"):
+        return 1.0 / n_nominal + 1e-12
+    if k in ("true/reward", "true/reward_std", "best_true/best_reward"):
+        return 1e-4 + 1e-4 * abs(ref)
+    if k.startswith("backward/") or k in ("forward/approx_kl", "forward/clip_fraction"):
+        return 2e-4 + 2e-3 * abs(ref)
+    if k.endswith("explained_variance"):
+        return 2e-5 + 1e-4 * abs(ref)
+    return 1e-5 + 1e-4 * abs(ref)
+
+
+def test_icrl_hc_whole_run_vs_port_band(golden):
+    """north_star's result criterion over a WHOLE run (VERDICT r5 missing #2): BASELINE configs[1] at full size — HCWithPos-v0, 64 envs x 2048
+    steps, README.md:38 flags, 10 outer iterations = 2.6 M env steps, 20 rollouts + 20 updates of up to 20 480 optimiser steps, 10 sampling /
+    constraint-net / evaluation phases — against tests/golden/g19_whole_run_hc.npz: what the CPU port (pinned to the reference's own icrl() by
+    g8) logged on the same SeededStreams and initial weights, undisturbed (`base`) and in 7 runs with a rounding-size disturbance (every initial
+    parameter moved by -1 / 0 / +1 float32 ulp, the rows of every minibatch reversed / rotated: tools/gen_whole_run.py).  Two correct fp32
+    executions of the algorithm separate over 4 x 10^5 dependent optimiser steps, so the record is a BAND per metric and iteration:
+      * iteration 0 (nothing has diverged yet in the forward step's first update; the port's own runs agree to ~1e-6 there): every metric within
+        the module's strict tolerances of the undisturbed run, or inside the band;
+      * every iteration: every metric inside [lo - w - tol, hi + w + tol], w = hi - lo of the 8 port runs (a ninth sample of the same
+        process; ref: icrl/icrl.py:199-304)."""
+    from icrl_amd.icrl import build_parser, setup, outer_iteration
+    g = golden("g19_whole_run_hc")
+    expert = os.path.join(HERE, "golden/expert_hc.npz")
+    argv = [str(a) for a in g["argv"]] + ["-ep", expert, "--expert_agent_path", expert]
+    cfg = vars(build_parser().parse_args(argv))
+    cfg.update(rank=0, world_size=1, streams=SeededStreams(int(g["stream_seed"])))
+    st = setup(types.SimpleNamespace(**cfg))
+    st["agent"].policy.load_state_dict(_sub(g, "w0/"))
+    st["constraint_net"].load_state_dict(_sub(g, "cn0/"))
+    keys = [str(k) for k in g["metric_keys"]]
+    base, lo, hi = g["base"], g["lo"], g["hi"]
+    n_it = base.shape[0]
+    assert n_it >= 10 and {"forward/nu", "forward/average_cost", "true/cost", "true/reward", "backward/kl_new_old", "backward/kl_old_new"} <= set(keys)
+    outside, table = [], []
+    for it in range(n_it):
+        m = outer_iteration(st, it)
+        missing = [k for k in keys if k not in m]
+        assert not missing, missing
+        for j, k in enumerate(keys):
+            x, b, l, h = float(m[k]), float(base[it, j]), float(lo[it, j]), float(hi[it, j])
+            if np.isnan(b) or np.isinf(b):
+                ok = (np.isnan(x) and np.isnan(b)) or x == b
+            else:
+                w, tol = h - l, _tol(k, b)
+                ok = l - w - tol <= x <= h + w + tol
+            if not ok:
+                outside.append((it, k, x, b, l, h))
+        j = keys.index
+        table.append((it, m["forward/nu"], lo[it, j("forward/nu")], hi[it, j("forward/nu")], m["forward/average_cost"], lo[it, j("forward/average_cost")],
+                      hi[it, j("forward/average_cost")], m["true/reward"], lo[it, j("true/reward")], hi[it, j("true/reward")], m["true/cost"]))
+    print("whole run, HIP vs the port's band [lo, hi] per outer iteration:")
+    for r in table:
+        print(f"  it {r[0]}: nu {r[1]:.6f} [{r[2]:.6f}, {r[3]:.6f}]  average_cost {r[4]:.5f} [{r[5]:.5f}, {r[6]:.5f}]  true/reward {r[7]:.1f} [{r[8]:.1f}, {r[9]:.1f}]  true/cost {r[10]:.4f}")
+    assert st["timesteps"] == n_it * 2 * 64 * 2048
+    assert not outside, outside[:20]

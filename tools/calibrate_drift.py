@@ -11,6 +11,8 @@ summation order is such a disturbance, so these numbers are the floor a HIP-vs-p
                           | ulp1 (ONE parameter moved by one ulp) | threads8 | rnd<k> (every parameter moved by -1 / 0 / +1 ulp, RandomState(k))
                           | rev / rot<k> (the rows of EVERY minibatch reversed / rotated by k: the same minibatches, another summation order in
                             every reduction of every optimiser step — the kind of difference a second implementation has)
+                          | tanhx / tanhx2 (round 6: torch.tanh replaced by an exp-based float32 formula in every activation, forward and backward
+                            — the other difference a second implementation has: its transcendental functions)
                  schedule: configs1 (default; test_configs1_forward_step_full_size) | configs2 (test_configs2_widths_long_chain: AntWall flags,
                           256 envs x 128 steps, batch 128, 20 epochs, lr 3e-5, seed 3)
     python tools/calibrate_drift.py compare base.json other.json ...      (the schedule is read from the files)
@@ -64,6 +66,9 @@ def run(variant, out_path, schedule="configs1"):
     from oracle import loop as o_loop, nets as o_nets
     from oracle.streams import SeededStreams
     torch.set_num_threads(8 if variant == "threads8" else 1)
+    if variant.startswith("tanhx"):      # another tanh in EVERY activation, forward and backward: 1 - 2 / (exp(2 x) + 1) (tanhx) or (e^x - e^-x) / (e^x + e^-x) (tanhx2) in
+        f = (lambda x: 1 - 2 / (torch.exp(2 * x) + 1)) if variant == "tanhx" else (lambda x: (torch.exp(x) - torch.exp(-x)) / (torch.exp(x) + torch.exp(-x)))
+        torch.tanh = f                   # float32 instead of libm's — a few 1e-7 relative per evaluation, what the HIP kernels' v_exp-based tanh differs by
     sc = SCHEDULES[schedule]
     N, T, od, ad, seed = sc["N"], sc["T"], sc["od"], sc["ad"], sc["seed"]
     ocn = make_cost_net(sc)

@@ -9,6 +9,10 @@ cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 2 --warmup 1 --no_cpu_baseline --no_seed_batch --no_configs2 --no_configs3 --no_configs4 --no_generic > $R/gpurun_out/prof_$tag.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_f -- python3 $R/tools/gae_once.py > $R/gpurun_out/pmc_${tag}_f.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_w -- python3 $R/tools/gae_once.py > $R/gpurun_out/pmc_${tag}_w.log 2>&1
+export GAE_N=32768      # the register-resident split scan (mid range): does it read every byte once?
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_mid_f -- python3 $R/tools/gae_once.py > $R/gpurun_out/pmc_${tag}_mid_f.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/pmc_${tag}_mid_w -- python3 $R/tools/gae_once.py > $R/gpurun_out/pmc_${tag}_mid_w.log 2>&1
+unset GAE_N
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_${tag}_antwall -- python3 $R/tools/antwall_iter.py > $R/gpurun_out/prof_${tag}_antwall.log 2>&1
 cd $R
 bash tools/pmc_train.sh $tag > /dev/null 2>&1

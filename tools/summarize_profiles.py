@@ -105,10 +105,12 @@ def seed_batch_stats(tag):
     print("wrote", dst + ".md")
 
 
-def gae_pmc(tag, T=2048, N=131072):
+def gae_pmc(tag, T=2048, N=131072, suffix=""):
+    """suffix "": the streaming shape at 131 072 envs (what bench.py's roofline.traffic reads); "_mid": the register-resident split scan at 32 768."""
+    import hashlib
     out = {}
     for name, key in (("FETCH_SIZE", "f"), ("WRITE_SIZE", "w")):
-        src = find(f"pmc_{tag}_{key}/**/*counter_collection.csv")
+        src = find(f"pmc_{tag}{suffix}_{key}/**/*counter_collection.csv")
         if src is None:
             print("no counter csv for", name); return
         vals, keep = [], []
@@ -116,7 +118,7 @@ def gae_pmc(tag, T=2048, N=131072):
             if "gae_dual" in r["Kernel_Name"] and r["Counter_Name"] == name:
                 vals.append(float(r["Counter_Value"])); keep.append(r)
         out[name] = vals
-        with open(os.path.join(ROOT, "profiles", f"{tag}_gae_pmc_{'fetch' if key == 'f' else 'write'}.csv"), "w") as f:
+        with open(os.path.join(ROOT, "profiles", f"{tag}_gae{suffix}_pmc_{'fetch' if key == 'f' else 'write'}.csv"), "w") as f:
             w = csv.DictWriter(f, fieldnames=list(keep[0].keys())); w.writeheader(); w.writerows(keep)
         kname = keep[0]["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
     fetch_kb, write_kb = max(out["FETCH_SIZE"]), max(out["WRITE_SIZE"])      # per dispatch (identical dispatches)
@@ -124,11 +126,12 @@ def gae_pmc(tag, T=2048, N=131072):
     j = dict(kernel=kname, T=T, N=N, algorithmic_bytes=alg, FETCH_SIZE_kb=fetch_kb, WRITE_SIZE_kb=write_kb,
              fetch_bytes_raw=fetch_kb * 1024, fetch_bytes_corrected=fetch_kb * 1024 * 2, write_bytes=write_kb * 1024,
              traffic_bytes=fetch_kb * 1024 * 2 + write_kb * 1024,
+             gae_hip_sha16=hashlib.sha256(open(os.path.join(ROOT, "icrl_amd", "csrc", "gae.hip"), "rb").read()).hexdigest()[:16],      # bench.py quotes the figure only for THIS source
              note="separate --pmc passes (FETCH_SIZE, WRITE_SIZE) as MI355X_MICROARCH.md §HBM prescribes; on gfx950 FETCH_SIZE counts "
                   "128-B requests at 64 B, so the read side is doubled; non-temporal loads / stores do not change the counts")
-    with open(os.path.join(ROOT, "profiles", f"{tag}_gae_pmc.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", f"{tag}_gae{suffix}_pmc.json"), "w") as f:
         json.dump(j, f, indent=1)
-    with open(os.path.join(ROOT, "profiles", f"{tag}_gae_pmc.md"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", f"{tag}_gae{suffix}_pmc.md"), "w") as f:
         f.write(f"# GAE kernel HBM traffic from PMC counters ({tag})\n\n"
                 "    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_<tag>_f -- python3 tools/gae_once.py\n"
                 "    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_<tag>_w -- python3 tools/gae_once.py\n\n"
@@ -137,7 +140,7 @@ def gae_pmc(tag, T=2048, N=131072):
                 f"| FETCH_SIZE | {fetch_kb:.0f} | {fetch_kb * 1024:.0f} | x2 on gfx950 = {fetch_kb * 2048:.0f} B (algorithmic loads {T * N * 20} B) |\n"
                 f"| WRITE_SIZE | {write_kb:.0f} | {write_kb * 1024:.0f} | algorithmic stores {T * N * 16} B |\n"
                 f"| **traffic** | | **{j['traffic_bytes']:.0f}** | {100 * (j['traffic_bytes'] / alg - 1):+.2f} % vs algorithmic |\n")
-    print("wrote", f"profiles/{tag}_gae_pmc.json", j["traffic_bytes"] / alg)
+    print("wrote", f"profiles/{tag}_gae{suffix}_pmc.json", j["traffic_bytes"] / alg)
 
 
 if __name__ == "__main__":
@@ -146,3 +149,4 @@ if __name__ == "__main__":
     kernel_stats(tag, "antwall")
     seed_batch_stats(tag)
     gae_pmc(tag)
+    gae_pmc(tag, N=32768, suffix="_mid")
