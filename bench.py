@@ -508,6 +508,17 @@ def main():
     ap.add_argument("--envs_per_gpu", type=int, default=None, help="override the env count per GPU (e.g. 2048: BASELINE configs[3] whole on one GPU)")
     a = ap.parse_args()
 
+    # ONE JSON line on stdout, whatever the libraries print: RCCL writes its version banner to the C-level stdout when its first
+    # communicator is created (5 lines, flushed at exit).  File descriptor 1 is pointed at stderr for the whole run; the line goes to a
+    # duplicate of the original stdout.
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+    def emit(obj):
+        json_out.write(json.dumps(obj) + "\n")
+        json_out.flush()
+
     import torch.distributed as dist
     from icrl_amd import distributed as D
     rank, world = D.init_from_env()
@@ -547,7 +558,7 @@ def main():
         out["per_gpu_value"] = round(env_steps / dt / world, 1)
         out["scale_anchor_ref"] = "scale_anchor.configs4.value of the N = 1 line (`python bench.py`): the same 512-env shard on one rank through this code path"
         out["allreduce"] = allreduce_summary(getattr(model, "sync_events", None), a.steps)
-        print(json.dumps(out))
+        emit(out)
         return
 
     envs = a.envs_per_gpu or (64 if config_id == 1 else 256)
@@ -641,7 +652,7 @@ def main():
             out["scale_anchor"] = dict(error=f"{type(e).__name__}: {e}")
     if world == 1 and not a.no_seed_batch:
         out["seed_batch"] = seed_batch_leg()
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":

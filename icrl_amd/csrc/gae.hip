@@ -284,8 +284,11 @@ __global__ void __launch_bounds__(64 * SPLIT_W) gae_dual_split_kernel(GaeArgs a,
 // grid = tiles x ceil(T / 128) workgroups (2 048 .. 16 384 for 8 192 .. 65 536 envs at T = 2048); a workgroup only waits for lower
 // blockIdx (later rows), so the grid need not be co-resident.  Re-association as for the split scan above (<= 1 float32 ulp).
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int RS_W = 8, RS_R = 16, RS_TC = RS_W * RS_R;
-constexpr int RS_CMAX = 16;      // T <= 2048
+#ifndef ICRL_RS_R
+#define ICRL_RS_R 16             // rows a wave holds in registers (A/B: 8 -> 64-row chunks, twice the workgroups and maps)
+#endif
+constexpr int RS_W = 8, RS_R = ICRL_RS_R, RS_TC = RS_W * RS_R;
+constexpr int RS_CMAX = 2048 / RS_TC;      // T <= 2048
 
 struct HeadRegs {
   float rew, cost, vr, vc, d, lvr, lvc;
@@ -332,13 +335,17 @@ __device__ __forceinline__ void rs_head_apply(const GaeArgs& a, unsigned n, bool
 
 template <bool NT>
 __device__ __forceinline__ void gae_dual_regsplit_body(const GaeArgs& a, int C, unsigned tag, double* maps, unsigned* flags, unsigned* status,
-                                                       unsigned spin_limit, int fault) {
+                                                       unsigned spin_limit, int fault, int tile_major = 0) {
   __shared__ double own[RS_W][4][64];
   __shared__ double ext[RS_CMAX - 1][4][64];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = blockIdx.x / C;
-  const int c = C - 1 - (blockIdx.x - tile * C);       // time chunk of this workgroup: latest rows first
+  // CHUNK-major order: workgroups with consecutive blockIdx own ADJACENT column tiles of the same 128 rows — what runs at the same time reads
+  // and writes whole rows (DRAM pages) instead of 256-byte pieces 4 N bytes apart, and the maps of the later chunks (lower blockIdx: a whole
+  // sweep over the tiles earlier) have long been published when a workgroup asks for them.  (tile_major: the tile's chunks back to back, A/B)
+  const int n_tiles = (int)gridDim.x / C;
+  const int tile = tile_major ? (int)blockIdx.x / C : (int)blockIdx.x % n_tiles;
+  const int c = C - 1 - (tile_major ? (int)blockIdx.x - tile * C : (int)blockIdx.x / n_tiles);       // time chunk of this workgroup: latest rows first
   const int col = tile * 64 + lane;
   const bool live = col < a.N;
   const unsigned n = live ? col : a.N - 1;
@@ -409,8 +416,8 @@ __device__ __forceinline__ void gae_dual_regsplit_body(const GaeArgs& a, int C, 
 
 template <bool NT>
 __global__ void __launch_bounds__(64 * RS_W) gae_dual_regsplit_kernel(GaeArgs a, int C, unsigned tag, double* maps, unsigned* flags, unsigned* status,
-                                                                      unsigned spin_limit, int fault) {
-  gae_dual_regsplit_body<NT>(a, C, tag, maps, flags, status, spin_limit, fault);
+                                                                      unsigned spin_limit, int fault, int tile_major) {
+  gae_dual_regsplit_body<NT>(a, C, tag, maps, flags, status, spin_limit, fault, tile_major);
 }
 
 
@@ -621,6 +628,8 @@ extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const 
   if (waves_per_tile >= 300 && waves_per_tile < 400) waves_per_tile -= 100;
   const unsigned spin_limit = fault ? 2048u : GAE_SPIN_LIMIT;
   // register-resident split scan (waves_per_tile 0 with enough workspace, or 500 / 501 to force it): T <= 2048, below the streaming shapes
+  const int tile_major = waves_per_tile == 502;          // A/B: the tile's chunks on consecutive workgroups (500: chunk-major, the default)
+  if (tile_major) waves_per_tile = 500;
   if (waves_per_tile == 0 || waves_per_tile == 500 || waves_per_tile == 501) {
     const int C = (T + RS_TC - 1) / RS_TC;
     const long long need = (long long)tiles * C * (256 * 8 + 4);
@@ -630,8 +639,8 @@ extern "C" int icrl_gae_dual_ws(const float* rewards, const float* costs, const 
       double* maps = (double*)ws;
       unsigned* flags = (unsigned*)(maps + (size_t)tiles * C * 256);
       // non-temporal loads / stores once the arrays are beyond what the caches hold (> 128 tiles x 2048 rows x 36 B = 600 MB)
-      if ((long long)tiles * T > 128ll * 2048) hipLaunchKernelGGL((gae_dual_regsplit_kernel<true>), dim3(tiles * C), dim3(64 * RS_W), 0, s, a, C, tag, maps, flags, status, spin_limit, fault);
-      else hipLaunchKernelGGL((gae_dual_regsplit_kernel<false>), dim3(tiles * C), dim3(64 * RS_W), 0, s, a, C, tag, maps, flags, status, spin_limit, fault);
+      if ((long long)tiles * T > 128ll * 2048) hipLaunchKernelGGL((gae_dual_regsplit_kernel<true>), dim3(tiles * C), dim3(64 * RS_W), 0, s, a, C, tag, maps, flags, status, spin_limit, fault, tile_major);
+      else hipLaunchKernelGGL((gae_dual_regsplit_kernel<false>), dim3(tiles * C), dim3(64 * RS_W), 0, s, a, C, tag, maps, flags, status, spin_limit, fault, tile_major);
       return (int)hipGetLastError();
     }
     if (waves_per_tile != 0) return fail("icrl_gae_dual_ws: the register-resident split scan needs T <= %d and %lld B of workspace + 8 (T = %d, %lld given)", RS_TC * RS_CMAX, need, T, ws_bytes);

@@ -1119,10 +1119,13 @@ __device__ __forceinline__ void genp_body(const GenNet& net, const GenArgs& a, c
             }
             const int* row = T.LT + 8 * trunk_last;
             if (((SU(row[6]) >> 1) & 3) == 3) {
-              if (tid < 3) {
+              if (tid < 3) {      // bounded like genp_wait: the launch's spin limit, and the abort word of a workgroup that already gave up
                 int spins = 0;
                 while (__hip_atomic_load(pp.xflag + g * 3 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(st + 1)) {
-                  if (++spins > GENP_SPIN_LIMIT) { __hip_atomic_store(pp.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // (the next barrier ends the launch)
+                  if (++spins > spin_limit || ((spins & 1023) == 0 && __hip_atomic_load(pp.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                    __hip_atomic_store(pp.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next barrier ends the launch)
+                    break;
+                  }
                   __builtin_amdgcn_s_sleep(1);
                 }
               }
@@ -1420,11 +1423,22 @@ static int launch_train_generic_persistent(const GenNet& net, GenArgs& a, const 
   static const bool nopack = getenv("ICRL_NO_XCD_PACK") != nullptr;
   int packed = nopack ? 0 : 1;
   void* params[] = {(void*)&net_, (void*)&a_, (void*)&pp, (void*)&packed};
+  if (H > GENP_MAX_WGS) {      // 481..512-row batches: more workgroups than packed_grid leaves free on an XCD — only if two fit a CU
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gen_train_persistent_kernel, GENP_TH, lds) != hipSuccess || per_cu < 2) {
+      (void)hipGetLastError();
+      return -1;               // (the launch-per-phase form below the caller)
+    }
+  }
   e = hipLaunchCooperativeKernel((const void*)gen_train_persistent_kernel, dim3(packed ? XCD_STRIDE * (H - 1) + 1 : H), dim3(GENP_TH), params, (unsigned)lds, s);
   if (e == hipErrorCooperativeLaunchTooLarge && packed) {      // (a partition that cannot hold the sparse grid: the dense one, agent-scope stores)
     (void)hipGetLastError();
     packed = 0;
     e = hipLaunchCooperativeKernel((const void*)gen_train_persistent_kernel, dim3(H), dim3(GENP_TH), params, (unsigned)lds, s);
+  }
+  if (e == hipErrorCooperativeLaunchTooLarge || e == hipErrorNotSupported || e == hipErrorInvalidConfiguration) {
+    (void)hipGetLastError();   // no co-resident grid on this device / partition: the three launches per optimiser step the header documents
+    return -1;
   }
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(gen_transpose_kernel, dim3((n + 255) / 256), dim3(256), 0, s, net, a.params, a.params_t);      // the forward / sampling kernels read params_t

@@ -46,12 +46,14 @@
 #ifndef ICRL_HALVES_EARLY_POLL
 #define ICRL_HALVES_EARLY_POLL 1
 #endif
-// round 6 levers (each bit-identical to the plain order, measured by tools/ab_train.sh):
+// round 6 levers, all bit-identical to the plain order, all MEASURED SLOWER and off (tools/ab_train.sh, one box, us per
+// optimiser step, two rounds of three launches: plain 6.74-6.78 | ADAM_TRIM 6.82-6.86 | ADAM_PRE 6.81-6.83 | LOSS_WAVES 2: 6.86-6.88 |
+// LOSS_WAVES 1: 6.92-6.94 | ADAM_PRE + LOSS_WAVES 2: 6.94-6.97).  Fewer instructions do not shorten the step: the waves a lever relieves
+// were not the ones the next hand-off waits for, and every lever adds a wave-uniform branch or a hand-off of its own.
 // ICRL_HALVES_ADAM_TRIM: Adam only on the elements of the head / bias groups that can hold a parameter (head outputs are dealt four per
-//   MFMA k group: 6 actions = 2 of a lane's 4 elements, a critic 1; the bias group {b1, b2, head bias | log_std, pad} = 2 or 3 of 4): the
-//   Adam phase is VALU-bound (two quarter-rate transcendentals per element) and the pad elements cost what the real ones cost
+//   MFMA k group: 6 actions = 2 of a lane's 4 elements, a critic 1; the bias group {b1, b2, head bias | log_std, pad} = 2 or 3 of 4)
 #ifndef ICRL_HALVES_ADAM_TRIM
-#define ICRL_HALVES_ADAM_TRIM 1
+#define ICRL_HALVES_ADAM_TRIM 0
 #endif
 // ICRL_HALVES_ADAM_PRE: the moments are scaled by beta1 / beta2 (m *= beta1, v *= beta2 — the part of Adam that needs neither the gradient
 //   nor the clip coefficient) inside the first exchange hop, where the wave only waits for its partner's flag

@@ -355,8 +355,13 @@ class PPOLagrangian:
                     _current_progress_remaining=float(getattr(self, "_current_progress_remaining", 1.0)))
         data.update(policy_class=U.sb3_policy_class_entry(), observation_space=U.sb3_space_entry(self.observation_space),
                     action_space=U.sb3_space_entry(self.action_space))
+        def space_exact(sp):      # shape and bounds EXACTLY (the printable `low` / `high` fields of `data` are str(ndarray): numpy elides arrays
+            if hasattr(sp, "n"):  # above 1000 elements and prints 8 decimals) — load() prefers this entry; the reference ignores the member
+                return dict(kind="discrete", n=int(sp.n))
+            return dict(kind="box", shape=[int(x) for x in sp.shape], dtype=str(np.dtype(sp.dtype)),
+                        low=np.asarray(sp.low, np.float64).reshape(-1).tolist(), high=np.asarray(sp.high, np.float64).reshape(-1).tolist())
         extra = dict(dual=self.dual.state_dict() if hasattr(self.dual, "state_dict") else {}, adam_step=int(self.policy.adam_step),
-                     writer="icrl_amd")
+                     writer="icrl_amd", spaces=dict(observation=space_exact(self.observation_space), action=space_exact(self.action_space)))
         with zipfile.ZipFile(path, "w") as z:
             z.writestr("data", json.dumps(data, indent=4, default=lambda o: str(o)))
             z.writestr("pytorch_variables.pth", blob({}))
@@ -380,7 +385,20 @@ class PPOLagrangian:
         if not os.path.exists(path) and os.path.exists(path + ".zip"):      # save_util.open_path appends the suffix (save_util.py:215-229)
             path += ".zip"
         with zipfile.ZipFile(path) as z:
-            data = parse_sb3_data(z.read("data"))
+            exact = {}
+            if "dual_state.json" in z.namelist():      # archives of this build carry their spaces exactly (any size, full precision)
+                import json
+                exact = json.loads(z.read("dual_state.json")).get("spaces", {})
+            raw = json.loads(z.read("data")) if exact else z.read("data")
+            if exact:                                  # (then the printable fields are not parsed at all)
+                raw = {k: v for k, v in raw.items() if k not in ("observation_space", "action_space")}
+            data = parse_sb3_data(raw)
+            for key, name in (("observation", "observation_space"), ("action", "action_space")):
+                e = exact.get(key)
+                if e is not None:
+                    data[name] = (spaces.Discrete(int(e["n"])) if e["kind"] == "discrete" else
+                                  spaces.Box(np.asarray(e["low"], np.float64).reshape(e["shape"]), np.asarray(e["high"], np.float64).reshape(e["shape"]),
+                                             tuple(e["shape"]), np.dtype(e["dtype"]).type))
             # a state dict of tensors: weights_only refuses anything else (an archive is untrusted input; the `data` entry next to it
             # goes through the allow-list unpickler of utils.parse_sb3_data for the same reason)
             sd = torch.load(io.BytesIO(z.read("policy.pth")), map_location="cpu", weights_only=True)

@@ -200,3 +200,29 @@ def test_agent_archive_for_the_reference_loader(tmp_path):
         exp = np.load(os.path.join(HERE, "golden", "hip_agent_archive_expected.npz"))
         got, _ = d.predict(exp["obs"], deterministic=True)
         assert np.allclose(got.cpu().numpy(), exp["actions"], rtol=1e-6, atol=1e-7)
+
+
+def test_agent_archive_round_trip_above_1000_observation_components(tmp_path):
+    """an agent whose observation space has more than 1000 components (numpy elides the printable `low` / `high` fields of the
+    archive's `data` entry: '[-3.14 -3.14 ... 3.14]') and bounds that need all 17 digits survives save() -> load(): the exact shape and
+    bounds ride in dual_state.json and load() prefers them; the reference-style `data` entry is still written."""
+    import json, zipfile
+    from icrl_amd import spaces
+    from icrl_amd.ppo_lag import PPOLagrangian, _SpacesOnlyEnv
+    O = 1024
+    low = -np.pi * (1.0 + np.arange(O) / 7.0)
+    high = np.e * (1.0 + np.arange(O) / 3.0)
+    env = _SpacesOnlyEnv(1, spaces.Box(low, high, (O,), np.float64), spaces.Box(-1.0, 1.0, (3,), np.float32))
+    a = PPOLagrangian("TwoCriticsMlpPolicy", env, seed=1, n_steps=8, batch_size=8, policy_kwargs=dict(net_arch=[dict(pi=[64, 64], vf=[64, 64], cvf=[64, 64])]))
+    path = a.save(str(tmp_path / "big"))
+    with zipfile.ZipFile(path) as z:
+        printable = json.loads(z.read("data"))["observation_space"]["low"]
+        assert "..." in printable                                  # (what made the printable field useless)
+    b = PPOLagrangian.load(path)
+    assert tuple(b.observation_space.shape) == (O,) and np.array_equal(np.asarray(b.observation_space.low, np.float64), low)
+    assert np.array_equal(np.asarray(b.observation_space.high, np.float64), high)
+    assert torch.equal(b.policy.params, a.policy.params)
+    obs = np.random.RandomState(0).randn(3, O)
+    a0, _ = a.predict(obs, deterministic=True)
+    b0, _ = b.predict(obs, deterministic=True)
+    assert torch.equal(torch.as_tensor(a0).cpu(), torch.as_tensor(b0).cpu())
