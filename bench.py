@@ -353,7 +353,7 @@ def gae_sweep_point(N=131072, T=2048, reps=48):
     st = _lib.current_stream()
     launch = {"gae": lambda: L.icrl_gae_dual_ws(*args, T, N, 0.99, 0.95, 0.99, 0.95, 0, _lib.ptr(ws), ws.numel() * 8, st),
               "copy": lambda: L.icrl_debug_stream_ref(*cargs, T, N, 1, st)}
-    if N % 4 == 0 and N >= 16384:       # (the streaming shape's grid is N / 256 one-wave workgroups: no reference below a full chip)
+    if N % 4 == 0 and N >= 65536:       # (the streaming shape's grid is N / 256 one-wave workgroups: no reference below a full chip)
         launch["ref"] = lambda: L.icrl_debug_stream_ref(*cargs, T, N, 0, st)
     for f in launch.values():
         for _ in range(3):
