@@ -19,14 +19,18 @@ import numpy as np
 class SeededStreams:
     """draws keyed by (kind, call index): independent of how many values an implementation happens to request."""
 
-    def __init__(self, seed, discrete=False):
-        self.seed, self.discrete = int(seed), discrete
+    def __init__(self, seed, discrete=False, uniform=False):
+        # uniform: draws in [0, 1) with the continuous shapes ([T, N, 1] for a Discrete action space): the inverse-CDF uniforms of a Categorical policy
+        # (standard normals used as "uniforms" force the action whenever they fall outside [0, 1], i.e. in 58 % of the steps)
+        self.seed, self.discrete, self.uniform = int(seed), discrete, uniform
         self.calls = dict(rollout=0, train=0, sample=0, eval=0)
 
     def _rng(self, kind, *idx):
         return np.random.RandomState([self.seed, dict(rollout=1, train=2, sample=3, eval=4)[kind], *idx])
 
     def _draw(self, rng, shape):
+        if self.uniform:
+            return rng.rand(*shape).astype(np.float32)
         return rng.rand(*shape[:-1]).astype(np.float32) if self.discrete else rng.randn(*shape).astype(np.float32)
 
     def rollout_noise(self, T, N, A):

@@ -141,24 +141,15 @@ def test_icrl_lgw_full_size_vs_port(golden):
     steps), and part somewhere in rollouts 16-25.  The port against ITSELF (5 runs with every initial parameter moved by -1 / 0 / +1
     ulp, tools/calibrate_lgw.py, profiles/r05_lgw_calibration.md) holds all of iteration 0 (forward metrics within 6e-5) and is
     chaotic in iteration 1 (early_stop_epoch 0 vs 10, true/cost 0.39 vs 0.20, nu +- 3.9e-3, average_cost +- 2.8e-2).  So:
-      (A) one outer iteration with forward_timesteps 30 000: EVERY metric strict — forward, sampled episodes, constraint-net update, KLs;
-      (B) two outer iterations at the README's 0.5e5: step counts exact, everything finite, nu within 2e-2 and average_cost within
-          0.15 (5 x the port-vs-port spread of iteration 1) in both iterations."""
+      (A) here: one outer iteration with forward_timesteps 30 000: EVERY metric strict — forward, sampled episodes, constraint-net update, KLs;
+      (B) the README's 0.5e5 over 5 outer iterations: test_icrl_whole_run_vs_port_band[g20_whole_run_lgw] (round 6: a band of 8 port runs instead of one
+          pair of runs with hand-set bounds — VERDICT r5 weak #1b)."""
     st, om, steps, ms = _lgw_full_size(golden, 30000, 1)
     keys = sorted(k for k in om[0] if k in ms[0] and k not in ("forward/std",) and not k.startswith("time/"))
     worst = _compare(0, ms[0], om[0], keys, True, 4000)
     assert st["timesteps"] == steps == 15 * 2000 and ms[0]["forward/n_updates"] == om[0]["forward/n_updates"] == 150
     print("LGW full size (A), 15 rollouts + updates + sampling + constraint-net update: worst absolute deviation from the CPU port",
           {k: float(f"{v:.3g}") for k, v in sorted(worst.items()) if v > 0})
-    st, om, steps, ms = _lgw_full_size(golden, "0.5e5", 2)
-    assert st["timesteps"] == steps == 2 * 25 * 2000
-    for it in range(2):
-        assert ms[it]["forward/n_updates"] == om[it]["forward/n_updates"] == 250 * (it + 1)
-        assert all(np.isfinite(float(v)) for k, v in ms[it].items() if k.startswith("forward/"))
-        assert abs(ms[it]["forward/nu"] - om[it]["forward/nu"]) <= 2e-2 and abs(ms[it]["forward/average_cost"] - om[it]["forward/average_cost"]) <= 0.15
-    print("LGW full size (B), README size: " + "; ".join(f"iteration {it}: nu {ms[it]['forward/nu']:.5f} vs {om[it]['forward/nu']:.5f}, average_cost "
-                                                         f"{ms[it]['forward/average_cost']:.4f} vs {om[it]['forward/average_cost']:.4f}, true/cost "
-                                                         f"{ms[it]['true/cost']:.4f} vs {om[it]['true/cost']:.4f}" for it in range(2)))
 
 
 def test_icrl_hc_three_iterations_vs_port(golden):
@@ -391,30 +382,44 @@ def _tol(k, ref, discrete=False, n_nominal=10000):
     return 1e-5 + 1e-4 * abs(ref)
 
 
-def test_icrl_hc_whole_run_vs_port_band(golden):
-    """north_star's result criterion over a WHOLE run (VERDICT r5 missing #2): BASELINE configs[1] at full size — HCWithPos-v0, 64 envs x 2048
-    steps, README.md:38 flags, 10 outer iterations = 2.6 M env steps, 20 rollouts + 20 updates of up to 20 480 optimiser steps, 10 sampling /
-    constraint-net / evaluation phases — against tests/golden/g19_whole_run_hc.npz: what the CPU port (pinned to the reference's own icrl() by
-    g8) logged on the same SeededStreams and initial weights, undisturbed (`base`) and in 7 runs with a rounding-size disturbance (every initial
-    parameter moved by -1 / 0 / +1 float32 ulp, the rows of every minibatch reversed / rotated: tools/gen_whole_run.py).  Two correct fp32
-    executions of the algorithm separate over 4 x 10^5 dependent optimiser steps, so the record is a BAND per metric and iteration:
-      * iteration 0 (nothing has diverged yet in the forward step's first update; the port's own runs agree to ~1e-6 there): every metric within
-        the module's strict tolerances of the undisturbed run, or inside the band;
-      * every iteration: every metric inside [lo - w - tol, hi + w + tol], w = hi - lo of the 8 port runs (a ninth sample of the same
-        process; ref: icrl/icrl.py:199-304)."""
+@pytest.mark.parametrize("name", ["g19_whole_run_hc", "g20_whole_run_lgw", "g21_whole_run_ant"])
+def test_icrl_whole_run_vs_port_band(golden, name):
+    """north_star's result criterion over a WHOLE run (VERDICT r5 missing #2), for every single-GPU BASELINE config at FULL size:
+      g19  configs[1]: HCWithPos-v0, 64 envs x 2048 steps, README.md:38 flags, 10 outer iterations = 2.6 M env steps, 20 rollouts + 20 updates of up to
+           20 480 optimiser steps, 10 sampling / constraint-net / evaluation phases;
+      g20  configs[0]: LGW-v0 / CLGW-v0, 1 env, n_steps 2000, README.md:25 flags, 5 outer iterations of 25 rollouts + updates (Categorical policy; the
+           action uniforms are real uniforms here: SeededStreams(uniform=True));
+      g21  configs[2]: AntWall-v0, 256 envs x 2048 steps, README.md:50 flags (batch 128, 20 epochs, constraint net [40, 40], 45 expert / nominal rollouts),
+           6 outer iterations = 3.1 M env steps
+    against tests/golden/<name>.npz: what the CPU port (pinned to the reference's own icrl() by g8) logged on the same SeededStreams and initial weights,
+    undisturbed (`base`) and in 7 runs with a rounding-size disturbance (every initial parameter moved by -1 / 0 / +1 float32 ulp, the rows of every minibatch
+    reversed / rotated, and — g20 / g21, where single discrete events carry the drift — a 1e-6-relative error in every tanh: tools/gen_whole_run.py).  Two
+    correct fp32 executions of the algorithm separate over 10^5 dependent optimiser steps (LapGridWorld within ONE outer iteration), so the record is a
+    BAND per metric and iteration: every metric of every iteration must lie in [lo - w - tol, hi + w + tol], w = hi - lo of the 8 port runs (a ninth sample
+    of the same process), tol = the module's per-key tolerance (ref: icrl/icrl.py:199-304)."""
+    import sys
     from icrl_amd.icrl import build_parser, setup, outer_iteration
-    g = golden("g19_whole_run_hc")
-    expert = os.path.join(HERE, "golden/expert_hc.npz")
+    g = golden(name)
+    spec = str(g["expert"]) if "expert" in g.files else "tests/golden/expert_hc.npz"
+    if spec == "antwall45":
+        sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+        import gen_whole_run
+        expert = gen_whole_run.antwall45_expert(os.path.join("/tmp", f"icrl_whole_run_expert_ant45_{os.getpid()}.npz"))
+    else:
+        expert = os.path.join(os.path.dirname(HERE), spec)
     argv = [str(a) for a in g["argv"]] + ["-ep", expert, "--expert_agent_path", expert]
     cfg = vars(build_parser().parse_args(argv))
-    cfg.update(rank=0, world_size=1, streams=SeededStreams(int(g["stream_seed"])))
+    uniform = bool(g["uniform_streams"]) if "uniform_streams" in g.files else False
+    cfg.update(rank=0, world_size=1, streams=SeededStreams(int(g["stream_seed"]), uniform=uniform))
     st = setup(types.SimpleNamespace(**cfg))
     st["agent"].policy.load_state_dict(_sub(g, "w0/"))
     st["constraint_net"].load_state_dict(_sub(g, "cn0/"))
     keys = [str(k) for k in g["metric_keys"]]
     base, lo, hi = g["base"], g["lo"], g["hi"]
     n_it = base.shape[0]
-    assert n_it >= 10 and {"forward/nu", "forward/average_cost", "true/cost", "true/reward", "backward/kl_new_old", "backward/kl_old_new"} <= set(keys)
+    discrete = cfg["train_env_id"] == "LGW-v0"
+    n_nominal = {"HCWithPos-v0": 10000, "LGW-v0": 4000, "AntWall-v0": 22500}[cfg["train_env_id"]]
+    assert n_it >= 5 and {"forward/nu", "forward/average_cost", "true/cost", "true/reward", "backward/kl_new_old", "backward/kl_old_new"} <= set(keys)
     outside, table = [], []
     for it in range(n_it):
         m = outer_iteration(st, it)
@@ -422,18 +427,21 @@ def test_icrl_hc_whole_run_vs_port_band(golden):
         assert not missing, missing
         for j, k in enumerate(keys):
             x, b, l, h = float(m[k]), float(base[it, j]), float(lo[it, j]), float(hi[it, j])
-            if np.isnan(b) or np.isinf(b):
-                ok = (np.isnan(x) and np.isnan(b)) or x == b
+            if np.isnan(b) or np.isinf(b) or np.isnan(l) or np.isinf(l) or np.isinf(h):
+                ok = True if not (np.isnan(b) or np.isinf(b)) else ((np.isnan(x) and np.isnan(b)) or x == b)      # (a band with a non-finite edge binds nothing)
             else:
-                w, tol = h - l, _tol(k, b)
+                w, tol = h - l, _tol(k, b, discrete, n_nominal)
                 ok = l - w - tol <= x <= h + w + tol
             if not ok:
                 outside.append((it, k, x, b, l, h))
         j = keys.index
         table.append((it, m["forward/nu"], lo[it, j("forward/nu")], hi[it, j("forward/nu")], m["forward/average_cost"], lo[it, j("forward/average_cost")],
-                      hi[it, j("forward/average_cost")], m["true/reward"], lo[it, j("true/reward")], hi[it, j("true/reward")], m["true/cost"]))
-    print("whole run, HIP vs the port's band [lo, hi] per outer iteration:")
+                      hi[it, j("forward/average_cost")], m["true/reward"], lo[it, j("true/reward")], hi[it, j("true/reward")], m["true/cost"],
+                      lo[it, j("true/cost")], hi[it, j("true/cost")]))
+    print(f"whole run ({name}), HIP vs the port's band [lo, hi] per outer iteration:")
     for r in table:
-        print(f"  it {r[0]}: nu {r[1]:.6f} [{r[2]:.6f}, {r[3]:.6f}]  average_cost {r[4]:.5f} [{r[5]:.5f}, {r[6]:.5f}]  true/reward {r[7]:.1f} [{r[8]:.1f}, {r[9]:.1f}]  true/cost {r[10]:.4f}")
-    assert st["timesteps"] == n_it * 2 * 64 * 2048
+        print(f"  it {r[0]}: nu {r[1]:.6f} [{r[2]:.6f}, {r[3]:.6f}]  average_cost {r[4]:.5f} [{r[5]:.5f}, {r[6]:.5f}]  true/reward {r[7]:.1f} [{r[8]:.1f}, {r[9]:.1f}]  "
+              f"true/cost {r[10]:.4f} [{r[11]:.4f}, {r[12]:.4f}]")
+    per_it = {"HCWithPos-v0": 2 * 64 * 2048, "LGW-v0": 25 * 2000, "AntWall-v0": 256 * 2048}[cfg["train_env_id"]]
+    assert st["timesteps"] == n_it * per_it
     assert not outside, outside[:20]

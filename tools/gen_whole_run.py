@@ -6,7 +6,7 @@ so a single pair of runs says little; this tool records what the CPU port (oracl
 by g8) logs per outer iteration at FULL size — HCWithPos-v0, 64 envs x 2048 steps, README.md:38 flags, SeededStreams(19) — once
 undisturbed and several times with a rounding-size disturbance (every initial parameter moved by -1 / 0 / +1 float32 ulp, the rows of every
 minibatch reversed / rotated: another summation order in every optimiser step), and stores per metric and iteration the undisturbed value and
-the port-vs-port minimum / maximum.  tests/test_icrl_trajectory_gpu.py::test_icrl_hc_whole_run_vs_port_band runs the HIP loop on the same
+the port-vs-port minimum / maximum.  tests/test_icrl_trajectory_gpu.py::test_icrl_whole_run_vs_port_band runs the HIP loop on the same
 streams and initial weights and must stay inside that band (widened by its own width) at every iteration.
 
     python tools/gen_whole_run.py run <variant> <out.json> [n_iters]      variant: base | ulp | ulpm | rnd<k> | rev | rot<k>
@@ -33,27 +33,74 @@ CFG = dict(train_env_id="HCWithPos-v0", eval_env_id="HCWithPosTest-v0", num_thre
 ARGV = ["icrl", "-er", "10", "-tk", "0.01", "-cl", "20", "-bi", "10", "-ft", "2e5", "-ni", "30", "-tei", "HCWithPos-v0", "-eei", "HCWithPosTest-v0",
         "-clr", "0.05", "-aclr", "0.9", "-crc", "0.5", "-psis", "-ctkno", "2.5", "-nt", str(N_ENVS), "-s", "0", "-v", "0"]
 
+# ---- the other two single-GPU BASELINE configs (round 6, second half): the flag list is the definition, the port's keys are read off it through
+# the product's own parser (host code).  `run2 <config> <variant> out.json [n_iters]` / `band2 <config> base.json other.json ...`
+CONFIGS = {
+    # BASELINE configs[0]: README.md:25 — LapGridWorld, 1 env, n_steps 2000, 25 rollouts + updates per outer iteration
+    "lgw": dict(golden="g20_whole_run_lgw", stream_seed=5, batch=64, uniform=True, expert="tests/golden/expert_lgw.npz", n_iters=6,
+                argv=["icrl", "-er", "20", "-tei", "LGW-v0", "-eei", "CLGW-v0", "-tk", "0.01", "-cl", "20", "-clr", "0.003", "-ft", "0.5e5", "-ni", "10", "-bi", "20",
+                      "-dno", "-dnr", "-dnc", "--n_steps", "2000", "-nt", "1", "-s", "0", "-v", "0"]),
+    # BASELINE configs[2]: README.md:50 — AntWall, 256 envs, batch 128, 20 epochs, constraint net [40, 40], 45 expert / nominal rollouts (bench.py: config_antwall)
+    "ant": dict(golden="g21_whole_run_ant", stream_seed=23, batch=128, expert="antwall45", n_iters=6,
+                argv=["icrl", "-er", "45", "-cl", "40", "40", "-clr", "0.005", "-aclr", "0.9", "-crc", "0.6", "-bi", "5", "-ft", "2e5", "-ni", "20", "-tei", "AntWall-v0",
+                      "-eei", "AntWallTest-v0", "--batch_size", "128", "--reward_gae_lambda", "0.9", "--cost_gae_lambda", "0.9", "--n_epochs", "20", "--learning_rate", "3e-5",
+                      "--clip_range", "0.4", "-piv", "0.1", "-plr", "0.05", "-psis", "-tk", "0.02", "-ctkno", "2.5", "-nt", "256", "-s", "0", "-v", "0"]),
+}
+
+
+def antwall45_expert(path):
+    """45 expert rollouts of 500 steps (22 500 x 121) from the committed 5: the fixture's rollouts nine times with a deterministic perturbation
+    (what bench.py: antwall_expert_path writes) — both the tool and the GPU test build the file with this function."""
+    if not os.path.exists(path):
+        d = np.load(os.path.join(ROOT, "tests/golden/expert_ant.npz"))
+        rng = np.random.RandomState(45)
+        obs = np.concatenate([d["observations"] + 0.01 * rng.randn(*d["observations"].shape) for _ in range(9)])
+        acs = np.concatenate([np.clip(d["actions"] + 0.01 * rng.randn(*d["actions"].shape).astype(np.float32), -1, 1) for _ in range(9)])
+        extra = {k: d[k] for k in d.files if k.startswith("policy/")}
+        np.savez(path, observations=obs, actions=acs.astype(np.float32), rewards=np.tile(d["rewards"], 9), lengths=np.tile(d["lengths"], 9), **extra)
+    return path
+
+
+def config2(name, tmp_dir="/tmp"):
+    """(port cfg dict, expert obs, expert acs, expert policy state dict, expert path) of CONFIGS[name]."""
+    from icrl_amd.icrl import build_parser          # host code only: the reference's flag names and defaults
+    from icrl_amd import utils
+    from oracle import loop as o_loop
+    c = CONFIGS[name]
+    ex_path = antwall45_expert(os.path.join(tmp_dir, "icrl_whole_run_expert_ant45.npz")) if c["expert"] == "antwall45" else os.path.join(ROOT, c["expert"])
+    cfg = vars(build_parser().parse_args(c["argv"] + ["-ep", ex_path, "--expert_agent_path", ex_path]))
+    port_cfg = {k: cfg[k] for k in o_loop.PORT_DEFAULTS if k in cfg}
+    (eo, ea), _ = utils.load_expert_data(ex_path, cfg["expert_rollouts"])
+    d = np.load(ex_path)
+    esd = {k[len("policy/"):]: d[k] for k in d.files if k.startswith("policy/")}
+    return port_cfg, eo, ea, esd, ex_path
+
 
 class PermutedRows:
     """SeededStreams whose minibatches keep their rows but change their order (rev / rot<k>)."""
 
-    def __init__(self, inner, variant):
-        self.inner, self.variant = inner, variant
+    def __init__(self, inner, variant, batch=BATCH):
+        self.inner, self.variant, self.batch = inner, variant, batch
 
     def __getattr__(self, name):
         return getattr(self.inner, name)
 
     def permutation(self, epoch, n):
         p = np.asarray(self.inner.permutation(epoch, n))
-        m = (n // BATCH) * BATCH
-        head = p[:m].reshape(-1, BATCH)
+        m = (n // self.batch) * self.batch
+        head = p[:m].reshape(-1, self.batch)
         head = head[:, ::-1] if self.variant == "rev" else np.roll(head, int(self.variant[3:]), axis=1)
         return np.concatenate([head.reshape(-1), p[m:]])
 
 
-def base_init():
-    """the port's own initial networks for CFG (seed 0): built exactly as icrl_port builds them, no iteration run."""
+def base_init(name=None):
+    """the port's own initial networks for CFG / CONFIGS[name] (seed 0): built exactly as icrl_port builds them, no iteration run."""
     from oracle import loop as o_loop
+    if name is not None:
+        port_cfg, eo, ea, _, _ = config2(name)
+        _, _, _, objs = o_loop.icrl_port(port_cfg, eo, ea, None, n_iters=0)
+        return (dict((k, v.detach().numpy().copy()) for k, v in objs["agent"].policy.params.items()),
+                dict((k, v.detach().numpy().copy()) for k, v in objs["cn"].params.items()))
     ex = np.load(os.path.join(ROOT, "tests/golden/expert_hc.npz"))
     _, _, _, objs = o_loop.icrl_port(CFG, ex["observations"], ex["actions"], None, n_iters=0)
     return (dict((k, v.detach().numpy().copy()) for k, v in objs["agent"].policy.params.items()),
@@ -101,10 +148,37 @@ def run(variant, out_path, n_iters=10):
     o_loop.icrl_port(CFG, ex["observations"], ex["actions"], esd, n_iters=n_iters, streams=streams, init=init, log=log)
 
 
+def run2(name, variant, out_path, n_iters=None):
+    from oracle import loop as o_loop
+    from oracle.streams import SeededStreams
+    torch.set_num_threads(1)
+    c = CONFIGS[name]
+    port_cfg, eo, ea, esd, _ = config2(name)
+    w0, cn0 = base_init(name)
+    if variant.startswith("tanhe6"):     # a 1e-6-relative pseudo-random error in EVERY tanh evaluation (tools/calibrate_drift.py: the documented size of the
+        orig, ph = torch.tanh, float(variant[6:] or 0)      # kernels' v_exp-based tanh against libm's) — the disturbance class that is representative of the HIP path where
+        torch.tanh = lambda x: orig(x) * (1 + 1e-6 * torch.sin(12345.678 * x + ph))      # single discrete events (an action / a clip decision flipping) carry the drift
+    streams = SeededStreams(c["stream_seed"], uniform=c.get("uniform", False))
+    if variant in ("ulp", "ulpm") or variant.startswith("rnd"):
+        init = dict(policy=disturb(w0, variant), cn=cn0)
+    else:
+        init = dict(policy=w0, cn=cn0)
+        if variant not in ("base",) and not variant.startswith("tanhe6"):
+            streams = PermutedRows(streams, variant, c["batch"])
+    t0, rows = time.time(), []
+
+    def log(m):
+        rows.append({k: float(v) for k, v in m.items() if np.ndim(v) == 0})
+        print(name, variant, "iteration", int(m["iteration"]), "nu", round(m["forward/nu"], 6), "true/reward", round(m["true/reward"], 2), "true/cost", round(m["true/cost"], 4),
+              round(time.time() - t0, 1), "s", flush=True)
+        json.dump(dict(variant=variant, config=name, metrics=rows), open(out_path, "w"))
+    o_loop.icrl_port(port_cfg, eo, ea, esd, n_iters=n_iters or c["n_iters"], streams=streams, init=init, log=log)
+
+
 SKIP = ("time/", "time(m)")
 
 
-def band(base_path, others):
+def band(base_path, others, name=None):
     base = json.load(open(base_path))["metrics"]
     runs = [json.load(open(p))["metrics"] for p in others]
     n_it = min([len(base)] + [len(r) for r in runs])
@@ -112,14 +186,16 @@ def band(base_path, others):
     val = np.array([[base[i][k] for k in keys] for i in range(n_it)])
     allv = np.array([[[r[i][k] for k in keys] for i in range(n_it)] for r in [base] + runs])
     lo, hi = np.nanmin(allv, axis=0), np.nanmax(allv, axis=0)
-    w0, cn0 = base_init()
-    out = os.path.join(ROOT, "tests/golden/g19_whole_run_hc.npz")
+    w0, cn0 = base_init(name)
+    out = os.path.join(ROOT, "tests/golden", ("g19_whole_run_hc" if name is None else CONFIGS[name]["golden"]) + ".npz")
     np.savez_compressed(out, meta=np.array(repr(dict(torch=torch.__version__, numpy=np.__version__, runs=1 + len(runs), variants=[os.path.basename(p) for p in others]))),
-                        argv=np.array(ARGV), stream_seed=STREAM_SEED, metric_keys=np.array(keys), base=val, lo=lo, hi=hi,
+                        argv=np.array(ARGV if name is None else CONFIGS[name]["argv"]), stream_seed=STREAM_SEED if name is None else CONFIGS[name]["stream_seed"],
+                        expert=np.array("tests/golden/expert_hc.npz" if name is None else CONFIGS[name]["expert"]),
+                        uniform_streams=bool(name is not None and CONFIGS[name].get("uniform", False)), metric_keys=np.array(keys), base=val, lo=lo, hi=hi,
                         **{f"w0/{k}": v for k, v in w0.items()}, **{f"cn0/{k}": v for k, v in cn0.items()})
     print(f"wrote {out} ({os.path.getsize(out) / 1024:.0f} KB): {n_it} outer iterations, {len(keys)} metrics, {1 + len(runs)} runs of the CPU port\n")
-    show = ("forward/nu", "forward/average_cost", "true/cost", "true/reward", "forward/early_stop_epoch", "forward/reward_explained_variance",
-            "backward/cn_loss", "backward/kl_new_old", "backward/kl_old_new", "true/forward_kl", "true/reverse_kl")
+    show = [k for k in ("forward/nu", "forward/average_cost", "true/cost", "true/reward", "forward/early_stop_epoch", "forward/reward_explained_variance",
+                        "backward/cn_loss", "backward/kl_new_old", "backward/kl_old_new", "true/forward_kl", "true/reverse_kl") if k in keys]
     print("| iteration | " + " | ".join(show) + " |")
     print("|---|" + "---|" * len(show))
     for i in range(n_it):
@@ -133,5 +209,9 @@ def band(base_path, others):
 if __name__ == "__main__":
     if sys.argv[1] == "run":
         run(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 10)
+    elif sys.argv[1] == "run2":
+        run2(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else None)
+    elif sys.argv[1] == "band2":
+        band(sys.argv[3], sys.argv[4:], sys.argv[2])
     else:
         band(sys.argv[2], sys.argv[3:])
