@@ -427,6 +427,10 @@ def test_icrl_whole_run_vs_port_band(golden, name):
         assert not missing, missing
         for j, k in enumerate(keys):
             x, b, l, h = float(m[k]), float(base[it, j]), float(lo[it, j]), float(hi[it, j])
+            if k.endswith("explained_variance") and max(x, b, l, h) < 1.0:
+                # 1 - Var[values - returns] / Var[values] is an ill-conditioned ratio when the critic is nearly constant (LapGridWorld: -28 .. -2e5 in the
+                # port's own runs, -8e7 on the GPU): compared as Var[values] / Var[values - returns] = 1 / (1 - ev), monotone in ev and bounded
+                x, b, l, h = (1.0 / (1.0 - v) for v in (x, b, l, h))
             if np.isnan(b) or np.isinf(b) or np.isnan(l) or np.isinf(l) or np.isinf(h):
                 ok = True if not (np.isnan(b) or np.isinf(b)) else ((np.isnan(x) and np.isnan(b)) or x == b)      # (a band with a non-finite edge binds nothing)
             else:
