@@ -213,7 +213,7 @@ def test_agent_archive_round_trip_above_1000_observation_components(tmp_path):
     low = -np.pi * (1.0 + np.arange(O) / 7.0)
     high = np.e * (1.0 + np.arange(O) / 3.0)
     env = _SpacesOnlyEnv(1, spaces.Box(low, high, (O,), np.float64), spaces.Box(-1.0, 1.0, (3,), np.float32))
-    a = PPOLagrangian("TwoCriticsMlpPolicy", env, seed=1, n_steps=8, batch_size=8, policy_kwargs=dict(net_arch=[dict(pi=[64, 64], vf=[64, 64], cvf=[64, 64])]))
+    a = PPOLagrangian("TwoCriticsMlpPolicy", env, seed=1, n_steps=8, batch_size=8, policy_kwargs=dict(net_arch=[dict(pi=[128, 128], vf=[128, 128], cvf=[128, 128])]))      # (observations above 128 components: the generic-shape path)
     path = a.save(str(tmp_path / "big"))
     with zipfile.ZipFile(path) as z:
         printable = json.loads(z.read("data"))["observation_space"]["low"]
