@@ -108,16 +108,18 @@ struct Cursor {
 constexpr int XCD_STRIDE = 8;
 // spare words of the 64-word norm exchange area (both kernels' layouts leave 28..31 and 60..63 unused; zeroed before every launch)
 __device__ __forceinline__ int xcc_word(int j) { return j < 4 ? 28 + j : 56 + j; }
-// called by ONE thread of workgroup j (of M <= 6) of a run: true when all M report the same XCD (common.h: all_on_one_xcd)
-__device__ __forceinline__ bool run_on_one_xcd(unsigned long long* xch, int j, int M) {
+// the wave-quad kernel with FOUR workgroups per network (12 per run): its norm granules use words 0..23 and 32..55 of the area, 24..31 and 56..63 are free
+__device__ __forceinline__ int xcc_word12(int j) { return j < 8 ? 24 + j : 48 + j; }
+// called by ONE thread of workgroup j (of M <= 6; M <= 12 with `wide`) of a run: true when all M report the same XCD (common.h: all_on_one_xcd)
+__device__ __forceinline__ bool run_on_one_xcd(unsigned long long* xch, int j, int M, bool wide = false) {
   const unsigned long long me = 0x100ull | (unsigned long long)xcc_id();
-  __hip_atomic_store(xch + xcc_word(j), me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(xch + (wide ? xcc_word12(j) : xcc_word(j)), me, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   bool same = true;
   for (int o = 0; o < M; ++o) {
     if (o == j) continue;
     unsigned long long v = 0;
     for (int spins = 0; spins < (1 << 18); ++spins) {
-      v = __hip_atomic_load(xch + xcc_word(o), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = __hip_atomic_load(xch + (wide ? xcc_word12(o) : xcc_word(o)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (v != 0) break;
       __builtin_amdgcn_s_sleep(8);
     }
@@ -171,9 +173,11 @@ int launch_train_rows(const TrainArgs& a, int nt1, bool discrete, bool split, hi
 // ppo_train_pairs.hip: wave-pair kernel, two waves per SIMD (nt1 rounded up to an even tile count)
 int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s);
 // ppo_train_halves.hip: two workgroups per network, wave quads (nt1 <= 2; single-run launches; a.gx set)
-int launch_train_halves(const TrainArgs& a, bool discrete, hipStream_t s);
-int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, hipStream_t s);
+// parts = 2 | 4 workgroups per network (round 6: four — 16 rows of every chunk each)
+int launch_train_halves(const TrainArgs& a, bool discrete, int parts, hipStream_t s);
+int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, int parts, hipStream_t s);
 constexpr int HALVES_MAX_RUNS = 40;      // batched launches: 6 workgroups per run, 5 groups of 8 runs = 30 workgroups per XCD (packed_grid)
+constexpr int QUARTERS_MAX_RUNS = 16;    // 12 workgroups per run, 2 groups of 8 runs = 24 workgroups per XCD
 // batched forms: n_runs argument blocks in DEVICE memory, grid.y = run
 int launch_train_rows_batch(const TrainArgs* d_args, int n_runs, int nt1, bool discrete, bool split, hipStream_t s);
 int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, hipStream_t s);

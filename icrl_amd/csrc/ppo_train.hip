@@ -917,6 +917,12 @@ static int launch_train(const TrainArgs& a, hipStream_t s) {
 // reports which persistent kernel runs it: 0 wave pairs, 1 row-owning waves, 2 row-owning waves with two workgroups per network,
 // 3 column-split tiles, 4 wave quads with two workgroups per network (obs <= 32, launches of up to HALVES_MAX_RUNS runs: beyond that the
 // compute units are what runs out and a run keeps one per network).  < 0: refused (return value of fail()) or a HIP error, in *err.
+// four workgroups per network where two would run: ICRL_QUARTERS=1 (A/B until measured; the default is decided below)
+static bool quarters_default() {
+  static const int v = [] { const char* e = getenv("ICRL_QUARTERS"); return e != nullptr ? (e[0] == '1' ? 1 : 0) : 0; }();
+  return v != 0;
+}
+
 static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_avg_sq, int32_t* adam_step, const icrl_buffer_t* buf,
                          const int32_t* perms, const float* nu, const icrl_ppo_hyper_t* hp, float* stats, void* sync_ws,
                          hipStream_t s, TrainArgs& a, int* err, int n_runs) {
@@ -973,7 +979,9 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   const bool rows = (hp->_pad & 4) || nt1 > 4;
   const bool split = rows && hp->batch_size > RB && hp->batch_size <= 2 * RB && !(hp->_pad & 8);     // (three or four chunks: one workgroup walks them)
   // hp._pad & 16: the wave-pair kernel (one workgroup per network) where the wave-quad kernel would run
+  // (5: four workgroups per network — round 6; hp._pad & 32 keeps two)
   const bool halves = !rows && n_runs <= HALVES_MAX_RUNS && nt1 <= 2 && !(hp->_pad & 16);
+  const bool quarters = halves && n_runs <= QUARTERS_MAX_RUNS && !(hp->_pad & 32) && quarters_default();
   hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
                      n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks, (int)split);
   if (split || halves) {
@@ -982,7 +990,7 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
     e = hipMemsetAsync(a.gx, 0, ICRL_PPO_SPLIT_BYTES, s);
     if (e != hipSuccess) return bad((int)e);
   }
-  return rows ? (split ? 2 : 1) : (halves ? 4 : 0);
+  return rows ? (split ? 2 : 1) : (halves ? (quarters ? 5 : 4) : 0);
 }
 
 // shapes the persistent kernels refuse (hidden widths above 64, architectures given by icrl_policy_t.arch, minibatches above 256 rows):
@@ -1029,7 +1037,7 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
   const int kind = prepare_train(pol, exp_avg, exp_avg_sq, adam_step, buf, perms, nu, hp, stats, sync_ws, s, a, &err, 1);
   if (kind < 0) return err;
   const int nt1 = (pol->obs_dim + 15) / 16;
-  if (kind == 4) return launch_train_halves(a, pol->discrete != 0, s);
+  if (kind == 4 || kind == 5) return launch_train_halves(a, pol->discrete != 0, kind == 5 ? 4 : 2, s);
   if (kind == 0) return launch_train_pairs(a, nt1, pol->discrete != 0, s);
   if (kind <= 2) return launch_train_rows(a, nt1, pol->discrete != 0, kind == 2, s);
   if (pol->discrete) {
@@ -1069,7 +1077,7 @@ extern "C" int icrl_ppo_lag_train_batch(int n_runs, const icrl_ppo_train_job_t* 
     if (e != 0) return e;
   }
   const int nt1 = (j0.pol->obs_dim + 15) / 16;
-  if (kind0 == 4) return launch_train_halves_batch(d_args, n_runs, j0.pol->obs_dim, j0.pol->discrete != 0, s);
+  if (kind0 == 4 || kind0 == 5) return launch_train_halves_batch(d_args, n_runs, j0.pol->obs_dim, j0.pol->discrete != 0, kind0 == 5 ? 4 : 2, s);
   if (kind0 == 0) return launch_train_pairs_batch(d_args, n_runs, j0.pol->obs_dim, nt1, j0.pol->discrete != 0, s);
   return launch_train_rows_batch(d_args, n_runs, nt1, j0.pol->discrete != 0, kind0 == 2, s);
 }

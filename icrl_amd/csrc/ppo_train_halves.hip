@@ -85,7 +85,7 @@ constexpr int SAH = 24;    // row stride of the per-row action block and of the 
 constexpr int HX_GROUPS = 7;                                   // exchange slots per thread: W1 tile, 2 W2 tiles, head, {b1, b2, extra}, 2 book-keeping records
 constexpr int HX_FLAG = HX_GROUPS * THH * 16;                  // byte offset of the 8 flag words (64 B apart) of a block
 constexpr int HX_BLK = HX_FLAG + 8 * 64;                       // bytes of one (parity, role, half) block
-static_assert(12 * HX_BLK + 512 <= (int)ICRL_PPO_SPLIT_BYTES, "the halves' exchange lives in the split workspace");
+static_assert(24 * HX_BLK + 3 * 512 <= (int)ICRL_PPO_SPLIT_BYTES, "the exchange of up to four row parts per network lives in the split workspace");
 
 template <int NT1>
 struct SmemH {  // offsets in floats (multiples of 4)
@@ -125,25 +125,29 @@ struct SmemH {  // offsets in floats (multiples of 4)
 
 // BATCH: the argument block was read from memory (batched launch): its pointers are marked as global-memory pointers (common.h:
 // as_global; a pointer a kernel LOADS has no known address space and every access through it is a flat_load / flat_store)
-template <int NT1, bool DISC, int OBS, bool BATCH>
+// NQ = 2: two workgroups per network, 32 rows of every 64-row chunk each (round 5).  NQ = 4 (round 6): FOUR workgroups per network, 16 rows = ONE
+// row tile each — the forward / loss / activation backward run on waves 0..3 alone, one per SIMD (the other four wait at the barrier), the
+// weight-gradient GEMMs have K = 16, and the four partial gradients are summed in the fixed order (q0 + q1) + (q2 + q3) by all four.
+template <int NT1, bool DISC, int OBS, bool BATCH, int NQ>
 __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const TrainArgs* const ka, const int slot_j) {
 #define GPH(x) (BATCH ? as_global(x) : (x))
   using S = SmemH<NT1>;
   constexpr int SX = S::SX;
   static_assert(NT1 == 2, "one observation tile per weight-gradient wave half");
   __shared__ __attribute__((aligned(16))) float sm[S::TOTAL];      // static: every image offset folds into an immediate (ppo_train_pairs.hip)
+  static_assert(NQ == 2 || NQ == 4, "two or four row parts per network");
+  constexpr int HRQ = RB / NQ;   // rows of a 64-row chunk this workgroup computes
+  constexpr int NJS = HRQ / 16;  // 16-row tiles among them
   const int role = slot_j % 3;   // 0 policy, 1 reward critic, 2 cost critic
-  const int half = slot_j / 3;   // which 32 rows of every 64-row chunk
+  const int half = slot_j / 3;   // which HRQ rows of every 64-row chunk (the "part")
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-#if ICRL_HALVES_QUAD_SPREAD
-  const int rt2 = w >> 2, fq = w & 3;
-  const int qp0 = w ^ 1, qp1 = w ^ 2, qp2 = w ^ 3;
-#else
-  const int rt2 = w & 1, fq = w >> 1;      // forward / activation backward: row tile, feature tile
-  const int qp0 = w ^ 2, qp1 = w ^ 4, qp2 = w ^ 6;      // the other three waves of the quad
-#endif
+  // NQ == 4: the one quad on waves 0..3 (four SIMDs); NQ == 2: two quads, two SIMDs each (ICRL_HALVES_QUAD_SPREAD: A/B of the other mapping)
+  constexpr bool SPREAD = NQ == 4 || ICRL_HALVES_QUAD_SPREAD;
+  const int rt2 = SPREAD ? w >> 2 : w & 1, fq = SPREAD ? w & 3 : w >> 1;      // forward / activation backward: row tile, feature tile
+  const int qp0 = SPREAD ? w ^ 1 : w ^ 2, qp1 = SPREAD ? w ^ 2 : w ^ 4, qp2 = SPREAD ? w ^ 3 : w ^ 6;      // the other three waves of the quad
+  const bool fwd_wave = rt2 < NJS;         // (NQ == 4: waves 4..7 take no part in forward / loss / activation backward)
   const int jt = w & 3, kh = w >> 2;       // weight gradients / Adam: parameter row block, column half
   const int r = lane & 15, q = lane >> 4;
   const int O = a.L.O, A = a.L.A;
@@ -260,12 +264,13 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   const float max_grad_norm = a.hp.max_grad_norm, adam_epsf = a.hp.adam_eps, adam_b2f = a.hp.adam_beta2;
   u64* const xch0 = GPH(a.xch);                                                                    // XCD words of all six workgroups, half 0's norm granules
   u64* const gxp = GPH(a.gx);
-  u64* const nx = half == 0 ? xch0 : reinterpret_cast<u64*>(reinterpret_cast<char*>(gxp) + ICRL_PPO_SPLIT_BYTES - 512);      // this half's norm granules
+  u64* const nx = half == 0 ? xch0 : reinterpret_cast<u64*>(reinterpret_cast<char*>(gxp) + ICRL_PPO_SPLIT_BYTES - 512 * half);      // this part's norm granules
 
   // ---- row stream: the 32 rows of this half are staged by the 512 threads, 16 per row (see ppo_train_pairs.hip for the rules the
   // index / row loads follow: unconditional, clamped, untouched until consumed)
   const int gb_row = tid >> 4, gpart = tid & 15;
-  const int gpos = HR * half + gb_row;            // position of that row in its 64-row chunk
+  const int gpos = HRQ * half + (gb_row < HRQ ? gb_row : 0);      // position of that row in its 64-row chunk
+  const bool stager = gb_row < HRQ;               // (NQ == 4: 16 rows, the threads of waves 0..3 stage them)
   constexpr int SW0 = 1;                          // advantage statistics: row stid of the minibatch on waves SW0 .. SW0 + 3
   const int stid = tid - 64 * SW0;
   auto ld_step = [&](int i) -> int4 {
@@ -294,6 +299,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     psc = p_sc[off];
   };
   auto commit_rows = [&](int xbase) {
+    if (NQ == 4 && !stager) return;
 #pragma unroll
     for (int i = 0; i < XRL; ++i) { const int k = gpart + 16 * i; if (OBS > 0 ? k < OBS : k < S::O16) sm[xbase + k * STH + gb_row] = px[i]; }
     if (role == 0) sm[S::ACT + gb_row * SAH + pos_of(gpart)] = gpart < AS ? pact : 0.f;
@@ -376,7 +382,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   int4 ps_next = ld_step(0), ps_nx2 = ld_step(1), ps_nx3 = ld_step(2);
   issue_stats(stat_idx(ps_next));
   int sidx_next = stat_idx(ps_nx2);
-  if (tid == 0) sm[S::MISC + 14] = run_on_one_xcd(xch0, slot_j, 6) ? 1.f : 0.f;
+  if (tid == 0) sm[S::MISC + 14] = run_on_one_xcd(xch0, slot_j, 3 * NQ, NQ == 4) ? 1.f : 0.f;
   __syncthreads();                      // initial weights visible (refresh_gauss reads log_std)
   const bool xcd_local = __builtin_amdgcn_readfirstlane(__float_as_int(sm[S::MISC + 14])) != 0;
   refresh_gauss();
@@ -424,7 +430,8 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     issue_stats(sidx_next);
     sidx_next = stat_idx(ps_nx2);
     float mb_s0 = 0.f, mb_s1 = 0.f, mb_s2 = 0.f, mb_s3 = 0.f, mb_s4 = 0.f;
-    const int xmine = (((int)(step & 1) * 3 + role) * 2 + half) * HX_BLK, xtheirs = (((int)(step & 1) * 3 + role) * 2 + (1 - half)) * HX_BLK;
+    const int xrole = ((int)(step & 1) * 3 + role) * NQ * HX_BLK;      // the NQ blocks of this role and step parity
+    const int xmine = xrole + half * HX_BLK, xtheirs = xrole + (1 - half) * HX_BLK;      // (xtheirs: NQ == 2)
 
     const int n_chunks = (nb + RB - 1) / RB;
     for (int ch = 0; ch < n_chunks; ++ch, ++g_chunk) {
@@ -434,10 +441,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         commit_rows(xcur);
         lds_barrier();                    // a row is staged by threads of several waves
       }
-      const bool valid = HR * half + b < nrows;
+      const bool valid = HRQ * half + b < nrows;
       // ================= forward =================
-      f32x4 h1c, h2c, outc;               // own feature tile t = fq
-      {  // layer 1
+      f32x4 h1c = f32x4{0.f, 0.f, 0.f, 0.f}, h2c = h1c, outc = h1c;               // own feature tile t = fq
+      if (fwd_wave) {  // layer 1
         float bx[NT1][4];                 // x[row b][k = 16 js + 4 q + e]
         const float* pb = sm + xcur + (4 * q) * STH + b;
 #pragma unroll
@@ -471,6 +478,8 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         pc_nx3 = ld_chunk(g_chunk + 4);
         issue_rows(idx_now);
       }
+      f32x4 dout = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (fwd_wave) {      // ---- the rest of forward, the loss tail and the activation backward: the waves of the row tiles (NQ == 4: waves 0..3)
       quad_signal();               // (P1) this wave's features of h1 are complete
       {  // layer 2: own quarter of K from registers, the other three from the row-major image
         const float* pa = sm + S::W2 + (16 * fq + r) * SH + 4 * q;
@@ -509,7 +518,6 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       }
       STAMP(0)   // forward
       // ============ loss + d loss / d head output (all four waves of a quad: identical values) ============
-      f32x4 dout = f32x4{0.f, 0.f, 0.f, 0.f};
       if (ICRL_HALVES_LOSS_WAVES >= 4 || fq < ICRL_HALVES_LOSS_WAVES) {
         float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
         if (role == 0) {
@@ -654,27 +662,28 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) pt[S::DZ1T + (16 * fq + i) * STH] = dz1c[i];
+      }      // fwd_wave
       STAMP(2)   // activation backward
       if (ch == 0) {   // gradient accumulators start their life here
         gW1r = gW2r[0] = gW2r[1] = gWhr = f32x4{0.f, 0.f, 0.f, 0.f};
         gb1r = 0.f; gb2r = 0.f; gex = 0.f;
       }
       lds_barrier();  // (S5) every quad's columns of h1^T, h2^T, dz1^T, dz2^T, dOut^T (and the loss partials) are complete
-      // ================= weight gradients (K = this half's 32 rows) =================
+      // ================= weight gradients (K = this part's HRQ rows) =================
       const bool last_chunk = ch + 1 == n_chunks;
       {  // dW2 rows 16 jt.., column tiles 2 kh, 2 kh + 1
-        f32x4 az[2];   // dz2^T[j = 16 jt + r][rows 16 js + 4 q + e]
+        f32x4 az[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // dz2^T[j = 16 jt + r][rows 16 js + 4 q + e]
         const float* pa = sm + S::DZ2T + (16 * jt + r) * STH + 4 * q;
 #pragma unroll
-        for (int js = 0; js < 2; ++js) az[js] = lds128(pa + 16 * js);
+        for (int js = 0; js < NJS; ++js) az[js] = lds128(pa + 16 * js);
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
           const float* pb = sm + S::H1T + (16 * (2 * kh + cc) + r) * STH + 4 * q;
           f32x4 bh[2];
 #pragma unroll
-          for (int js = 0; js < 2; ++js) bh[js] = lds128(pb + 16 * js);
+          for (int js = 0; js < NJS; ++js) bh[js] = lds128(pb + 16 * js);
 #pragma unroll
-          for (int js = 0; js < 2; ++js)
+          for (int js = 0; js < NJS; ++js)
 #pragma unroll
             for (int e = 0; e < 4; ++e) gW2r[cc] = MFMA_F32(az[js][e], bh[js][e], gW2r[cc]);
         }
@@ -684,16 +693,16 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         }
       }
       {  // dW1 rows 16 jt.., observation tile kh
-        f32x4 az[2];   // dz1^T[j = 16 jt + r][rows]
+        f32x4 az[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};   // dz1^T[j = 16 jt + r][rows]
         const float* pa = sm + S::DZ1T + (16 * jt + r) * STH + 4 * q;
 #pragma unroll
-        for (int js = 0; js < 2; ++js) az[js] = lds128(pa + 16 * js);
+        for (int js = 0; js < NJS; ++js) az[js] = lds128(pa + 16 * js);
         const float* pb = sm + xcur + (16 * kh + r) * STH + 4 * q;     // x^T[k][rows 16 js + 4 q + e]
         f32x4 bx[2];
 #pragma unroll
-        for (int js = 0; js < 2; ++js) bx[js] = lds128(pb + 16 * js);
+        for (int js = 0; js < NJS; ++js) bx[js] = lds128(pb + 16 * js);
 #pragma unroll
-        for (int js = 0; js < 2; ++js)
+        for (int js = 0; js < NJS; ++js)
 #pragma unroll
           for (int e = 0; e < 4; ++e) gW1r = MFMA_F32(az[js][e], bx[js][e], gW1r);
         // observation pad columns (k >= obs): X holds unmasked fill there; their weights, gradients and moments stay 0
@@ -709,14 +718,14 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         raw_store(xmine + (2 * THH + tid) * 16, gW2r[1]);
       }
       if (lowk) {   // dWh columns 16 jt..: A = dOut^T[position r][rows], B = h2^T[j = 16 jt + r][rows]
-        f32x4 ao[2], bh[2];
+        f32x4 ao[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, bh[2];
         const float* pa = sm + S::DOT + r * STH + 4 * q;
         const float* pb = sm + S::H2T + (16 * jt + r) * STH + 4 * q;
 #pragma unroll
-        for (int js = 0; js < 2; ++js) { ao[js] = lds128(pa + 16 * js); bh[js] = lds128(pb + 16 * js); }
+        for (int js = 0; js < NJS; ++js) { ao[js] = lds128(pa + 16 * js); bh[js] = lds128(pb + 16 * js); }
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-        for (int js = 0; js < 2; ++js)
+        for (int js = 0; js < NJS; ++js)
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc[js] = MFMA_F32(ao[js][e], bh[js][e], acc[js]);
 #pragma unroll
@@ -776,6 +785,47 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
       }
       bool timed_out = false;
+      if constexpr (NQ == 4) {
+        // four parts: every workgroup forms (q0 + q1) + (q2 + q3) from the three others' blocks and its own registers — the same floats in the same
+        // order on all four, so they stay replicas.  One pair at a time (register pressure): flags of this wave's peers, then their groups.
+        auto wait_flag = [&](int k) {
+          int spins = 0;
+          while (true) {
+            const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(grs, xrole + k * HX_BLK + HX_FLAG + 64 * w, 0, 16);
+            if (f == step) break;
+            if (++spins >= (1 << 22)) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          asm volatile("" ::: "memory");
+        };
+        struct Part { f32x4 g0, g1, g2, g3, g4, b0, b1; };
+        const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        const Part own = {gW1r, gW2r[0], gW2r[1], gWhr, gsc, f32x4{mb_s0, mb_s1, mb_s2, mb_s3}, f32x4{mb_s4, 0.f, 0.f, 0.f}};
+        auto fetch = [&](int k) -> Part {
+          if (k == half) return own;
+          wait_flag(k);
+          const int xb = xrole + k * HX_BLK;
+          Part p = {raw_load(xb + (0 * THH + tid) * 16), raw_load(xb + (1 * THH + tid) * 16), raw_load(xb + (2 * THH + tid) * 16), z4, z4, z4, z4};
+          if (lowk) { p.g3 = raw_load(xb + (3 * THH + tid) * 16); p.g4 = raw_load(xb + (4 * THH + tid) * 16); }
+          if (book) { p.b0 = raw_load(xb + (5 * THH + tid) * 16); if (DISC) p.b1 = raw_load(xb + (6 * THH + tid) * 16); }
+          return p;
+        };
+        auto add = [&](const Part& x, const Part& y) -> Part {
+          Part r;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            r.g0[i] = x.g0[i] + y.g0[i]; r.g1[i] = x.g1[i] + y.g1[i]; r.g2[i] = x.g2[i] + y.g2[i]; r.g3[i] = x.g3[i] + y.g3[i];
+            r.g4[i] = x.g4[i] + y.g4[i]; r.b0[i] = x.b0[i] + y.b0[i]; r.b1[i] = x.b1[i] + y.b1[i];
+          }
+          return r;
+        };
+        const Part s01 = add(fetch(0), fetch(1));
+        const Part s23 = add(fetch(2), fetch(3));
+        const Part t = add(s01, s23);
+        gW1r = t.g0; gW2r[0] = t.g1; gW2r[1] = t.g2; gWhr = t.g3; gsc = t.g4;
+        gb1r = gsc[0]; gb2r = gsc[1]; gex = gsc[2];
+        mb_s0 = t.b0[0]; mb_s1 = t.b0[1]; mb_s2 = t.b0[2]; mb_s3 = t.b0[3]; mb_s4 = t.b1[0];
+      } else {
 #if ICRL_HALVES_POLL_ROLL
       unsigned pq0, pq1, pq2, pq3;
 #endif
@@ -852,6 +902,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
 #endif
       gb1r = gsc[0]; gb2r = gsc[1]; gex = gsc[2];
       mb_s0 += c5[0]; mb_s1 += c5[1]; mb_s2 += c5[2]; mb_s3 += c5[3]; mb_s4 += c6[0];
+      }      // NQ == 2
       if (timed_out) sm[S::MISC + 13] = 1.f;       // reported through the status word like a timed-out norm exchange
     }
 
@@ -1083,43 +1134,48 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   }
 }
 
-template <int NT1, bool DISC, int OBS>
+template <int NT1, bool DISC, int OBS, int NQ>
 __global__ void __launch_bounds__(THH) ppo_train_halves_kernel(TrainArgs a, int packed) {
   int run = 0, j = (int)blockIdx.x;
-  if (packed && !packed_slot(6, 1, run, j)) return;
-  ppo_train_halves_body<NT1, DISC, OBS, false>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), j);
+  if (packed && !packed_slot(3 * NQ, 1, run, j)) return;
+  ppo_train_halves_body<NT1, DISC, OBS, false, NQ>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), j);
 }
 
-// several independent runs in ONE launch: the packed 1-D grid of ppo_common.h (a run's six workgroups on one XCD), or grid (6, n_runs)
+// several independent runs in ONE launch: the packed 1-D grid of ppo_common.h (a run's workgroups on one XCD), or grid (3 NQ, n_runs)
 // with run = blockIdx.y when that many workgroups are not resident on their XCDs at once; the argument blocks live in device memory
-template <int NT1, bool DISC, int OBS>
+template <int NT1, bool DISC, int OBS, int NQ>
 __global__ void __launch_bounds__(THH) ppo_train_halves_batch_kernel(const TrainArgs* __restrict__ runs, int n_runs, int packed) {
   int run = (int)blockIdx.y, j = (int)blockIdx.x;
-  if (packed && !packed_slot(6, n_runs, run, j)) return;
+  if (packed && !packed_slot(3 * NQ, n_runs, run, j)) return;
   const TrainArgs* const ka = as_global(runs + run);
-  ppo_train_halves_body<NT1, DISC, OBS, true>(*ka, ka, j);
+  ppo_train_halves_body<NT1, DISC, OBS, true, NQ>(*ka, ka, j);
 }
 
-template <int NT1, bool DISC, int OBS>
+template <int NT1, bool DISC, int OBS, int NQ>
 static int launch_halves(const TrainArgs* one, const TrainArgs* d_args, int n_runs, hipStream_t s) {
   static_assert(SmemH<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
   if (one != nullptr) {
     TrainArgs arg = *one;
-    return launch_update_single(ppo_train_halves_kernel<NT1, DISC, OBS>, 6, dim3(THH), 0, s, arg);
+    return launch_update_single(ppo_train_halves_kernel<NT1, DISC, OBS, NQ>, 3 * NQ, dim3(THH), 0, s, arg);
   }
-  const int pg = packed_grid(6, n_runs);
-  hipLaunchKernelGGL((ppo_train_halves_batch_kernel<NT1, DISC, OBS>), pg ? dim3(pg) : dim3(6, n_runs), dim3(THH), 0, s, d_args, n_runs, pg ? 1 : 0);
+  const int pg = packed_grid(3 * NQ, n_runs);
+  hipLaunchKernelGGL((ppo_train_halves_batch_kernel<NT1, DISC, OBS, NQ>), pg ? dim3(pg) : dim3(3 * NQ, n_runs), dim3(THH), 0, s, d_args, n_runs, pg ? 1 : 0);
   return (int)hipGetLastError();
 }
 
+template <int NQ>
 static int dispatch_halves(const TrainArgs* one, const TrainArgs* d_args, int n_runs, int obs, bool discrete, hipStream_t s) {
-  if (!discrete && obs == 18) return launch_halves<2, false, 18>(one, d_args, n_runs, s);      // HCWithPos (BASELINE configs[1], [3])
-  if (discrete && obs == 1) return launch_halves<2, true, 1>(one, d_args, n_runs, s);          // LapGridWorld (configs[0])
-  return discrete ? launch_halves<2, true, 0>(one, d_args, n_runs, s) : launch_halves<2, false, 0>(one, d_args, n_runs, s);
+  if (!discrete && obs == 18) return launch_halves<2, false, 18, NQ>(one, d_args, n_runs, s);      // HCWithPos (BASELINE configs[1], [3])
+  if (discrete && obs == 1) return launch_halves<2, true, 1, NQ>(one, d_args, n_runs, s);          // LapGridWorld (configs[0])
+  return discrete ? launch_halves<2, true, 0, NQ>(one, d_args, n_runs, s) : launch_halves<2, false, 0, NQ>(one, d_args, n_runs, s);
 }
 
-// obs <= 32 (nt1 <= 2), a.gx set and zeroed (prepare_train)
-int launch_train_halves(const TrainArgs& a, bool discrete, hipStream_t s) { return dispatch_halves(&a, nullptr, 1, a.L.O, discrete, s); }
-int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, hipStream_t s) { return dispatch_halves(nullptr, d_args, n_runs, obs, discrete, s); }
+// obs <= 32 (nt1 <= 2), a.gx set and zeroed (prepare_train); parts = 2 | 4 workgroups per network
+int launch_train_halves(const TrainArgs& a, bool discrete, int parts, hipStream_t s) {
+  return parts == 4 ? dispatch_halves<4>(&a, nullptr, 1, a.L.O, discrete, s) : dispatch_halves<2>(&a, nullptr, 1, a.L.O, discrete, s);
+}
+int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, int parts, hipStream_t s) {
+  return parts == 4 ? dispatch_halves<4>(nullptr, d_args, n_runs, obs, discrete, s) : dispatch_halves<2>(nullptr, d_args, n_runs, obs, discrete, s);
+}
 
 }  // namespace icrl
