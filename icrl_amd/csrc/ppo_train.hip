@@ -917,9 +917,9 @@ static int launch_train(const TrainArgs& a, hipStream_t s) {
 // reports which persistent kernel runs it: 0 wave pairs, 1 row-owning waves, 2 row-owning waves with two workgroups per network,
 // 3 column-split tiles, 4 wave quads with two workgroups per network (obs <= 32, launches of up to HALVES_MAX_RUNS runs: beyond that the
 // compute units are what runs out and a run keeps one per network).  < 0: refused (return value of fail()) or a HIP error, in *err.
-// four workgroups per network where two would run: ICRL_QUARTERS=1 (A/B until measured; the default is decided below)
+// FOUR workgroups per network where two would run (round 6: 6.46 against 6.74 us per optimiser step at HC shapes); ICRL_QUARTERS=0 keeps two (A/B)
 static bool quarters_default() {
-  static const int v = [] { const char* e = getenv("ICRL_QUARTERS"); return e != nullptr ? (e[0] == '1' ? 1 : 0) : 0; }();
+  static const int v = [] { const char* e = getenv("ICRL_QUARTERS"); return e != nullptr ? (e[0] == '1' ? 1 : 0) : 1; }();
   return v != 0;
 }
 

@@ -591,7 +591,7 @@ class PPOLagrangian:
         ws = self._train_ws
         ws["nu"].fill_(current_penalty)
         ws["t"].fill_(pol.adam_step)
-        hp = PpoHyperT(int(self.batch_size), int(self.n_epochs), int(self.target_kl is not None), int(getattr(self, "profile_phases", 0)) | {"tiles": 2, "rows": 4, "rows1": 12, "pairs": 16}.get(getattr(self, "train_kernel", "auto"), 0), clip_range, float(self.ent_coef),
+        hp = PpoHyperT(int(self.batch_size), int(self.n_epochs), int(self.target_kl is not None), int(getattr(self, "profile_phases", 0)) | {"tiles": 2, "rows": 4, "rows1": 12, "pairs": 16, "halves": 32}.get(getattr(self, "train_kernel", "auto"), 0), clip_range, float(self.ent_coef),
                        float(self.reward_vf_coef), float(self.cost_vf_coef), float(self.max_grad_norm),
                        float(self.target_kl or 0.0), crv, ccv, lr, 0.9, 0.999, float(pol.optimizer_kwargs.get("eps", 1e-8)))
         return dict(ps=pol.struct(), bs=rb.struct(), hp=hp, perms=perms, rng_state=rng_state, injected=injected, clip_range=clip_range)
