@@ -1,12 +1,12 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): SQ counters of the PPO-Lagrangian update kernels, three passes of <= 8 SQ counters each.
-#   bash tools/pmc_train.sh <tag>            HC shapes: the wave-pair kernel (one workgroup per network: 24 waves on 3 CUs) and the default wave-quad kernel (two: 48 waves on 6 CUs)
+#   bash tools/pmc_train.sh <tag>            HC shapes: the wave-quad kernel with two workgroups per network (48 waves on 6 CUs) and with four (the default: 96 waves on 12 CUs)
 #   bash tools/pmc_train.sh <tag> ant        AntWall shapes, batch 128: one workgroup per network (rows1) and two (default)
 # Outputs under gpurun_out/pmc_train_<tag>[_antwall]_{a,b}; summarised by tools/summarize_pmc_train.py <tag> [ant].
 tag=$1
 kind=${2:-hc}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-sfx=""; variants="pairs,auto"
+sfx=""; variants="halves,auto"
 if [ "$kind" = "ant" ]; then sfx="_antwall"; variants="rows1,auto"; fi
 cd /tmp && export TMPDIR=/tmp
 export KIND=$kind VARIANTS=$variants EPOCHS=2

@@ -18,7 +18,7 @@ cd $R
 bash tools/pmc_train.sh $tag > /dev/null 2>&1
 bash tools/pmc_train.sh $tag ant > /dev/null 2>&1
 timeout 300 python3 tools/rollout_only.py > gpurun_out/rollout_$tag.log 2>&1
-VARIANTS=pairs,auto,pairs,auto timeout 300 python3 tools/train_only.py > gpurun_out/train_$tag.log 2>&1
+VARIANTS=pairs,halves,auto,pairs,halves,auto timeout 300 python3 tools/train_only.py > gpurun_out/train_$tag.log 2>&1
 KIND=ant timeout 300 python3 tools/train_only.py >> gpurun_out/train_$tag.log 2>&1
 timeout 600 python3 tools/seed_batch_bench.py > gpurun_out/seeds_$tag.log 2>&1
 bash tools/profile_seed_batch.sh $tag > /dev/null 2>&1

@@ -33,15 +33,15 @@ for f in _passes:
         k = r["Kernel_Name"]
         if "ppo_train_" not in k or "perm" in k or "plan" in k:
             continue
-        name = k.split("<")[0].split("::")[-1].replace("void ", "")
-        if kind != "hc":      # the SPLIT template argument tells the two launch shapes of the row-owning kernel apart
-            name = k.split("(")[0].split("::")[-1].replace("void ", "")
+        # with its template arguments: the SPLIT argument tells the two launch shapes of the row-owning kernel apart, the last argument of the
+        # wave-quad kernel its two (round 5) and four (round 6) workgroups per network
+        name = k.split("(")[0].split("::")[-1].replace("void ", "")
         per[(name, r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
         dur[(name, r["Dispatch_Id"])] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
         # the WORKING waves: the update launches are 1-D grids of 8 (M - 1) + 1 workgroups of which M = 3 or 6 (the run's, at b, b + 8,
         # ...: one XCD) do the work and the others leave at once (their cycles are noise in the sums)
         wgs = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
-        wgs = (wgs - 1) // 8 + 1 if wgs > 6 else wgs
+        wgs = (wgs - 1) // 8 + 1 if wgs > 12 else wgs
         waves[name] = int(r["Workgroup_Size"]) // 64 * wgs
     # Only the FULL launches (STEPS optimiser steps) count: every process also makes 8 short calibration launches of the same kernel
     # (PPOLagrangian._tune_sync_placement: 256 steps each at HC), and a median over all launches divided by STEPS would describe those
@@ -65,8 +65,8 @@ for f in _passes:
 shape = "HCWithPos shapes, batch 64" if kind == "hc" else "AntWall shapes (obs 113, act 8), batch 128 = two 64-row chunks"
 lines = [f"# SQ counters of the PPO-Lagrangian update kernels ({tag}) — {shape}, per WAVE and optimiser step",
          "", "command: `bash tools/pmc_train.sh <tag>` on the GPU box = two `rocprofv3 --pmc <8 SQ counters> --kernel-trace` passes over "
-         "`tools/train_only.py` (HC: VARIANTS=pairs,auto = the wave-pair kernel, one workgroup per network, 24 waves on 3 CUs, and the wave-quad kernel "
-         "of round 5, two workgroups per network, 48 waves on 6 CUs, 4096 optimiser steps per launch; until round 4 the columns were the row-owning and the wave-pair kernel; KIND=ant: VARIANTS=rows1,auto = one workgroup per network walking both chunks, 12 waves, and "
+         "`tools/train_only.py` (HC, round 6: VARIANTS=halves,auto = the wave-quad kernel with TWO workgroups per network, `<2, false, 18, 2>`: 48 waves on 6 CUs, "
+         "and with FOUR, `<2, false, 18, 4>`, the default: 96 waves on 12 CUs, 4096 optimiser steps per launch; until round 5 the columns were the wave-pair and the two-workgroup kernel; KIND=ant: VARIANTS=rows1,auto = one workgroup per network walking both chunks, 12 waves, and "
          "the default two workgroups per network, 24 waves, 512 steps per launch); raw csv: gpurun_out/pmc_train_<tag>_{a,b} (scratch).  Values "
          f"below = median over the FULL launches ({STEPS} optimiser steps; the short sync-placement calibration launches every process makes are dropped by duration) "
          f"/ waves of the kernel / {STEPS}; cycle-type counters converted from quad-cycles to shader cycles.", ""]
@@ -101,8 +101,9 @@ if kind != "hc":
     raise SystemExit(0)
 lines += ["", "Reading: SQ_WAVE_CYCLES = ACTIVE_INST_ANY (issuing) + WAIT_INST_ANY (issue stalled: here the SIMD's one fp32 lane array, which the fp32 MFMA "
           "occupies alone: SQ_VALU_MFMA_COEXEC_CYCLES = 0, MFMA_BUSY = 32 cycles x SQ_INSTS_MFMA) + WAIT_ANY (parked at s_waitcnt / s_barrier).  "
-          "`ppo_train_halves_kernel` (two workgroups per network, 32 rows each): per wave about half the MFMAs of the pair kernel's waves "
-          "(each SIMD's fp32 pipe is busy 2 x that), the VALU work of the loss tail and of Adam is NOT halved (both halves run them on their replicas); "
-          "what it adds is parked time in the raw 16-byte gradient exchange (one trip through the XCD's L2 per step)."]
+          "Four workgroups per network (`<.., 4>`, 16 rows = one row tile each): the per-wave figures average over waves 0..3, which run forward / loss / "
+          "backward alone on their SIMDs, and waves 4..7, which only take part in the weight-gradient GEMMs, the exchange and Adam (and are parked meanwhile); "
+          "the MFMAs per wave halve again, the VALU work of the loss tail and of Adam does not (all four parts run them on their replicas), and the exchange "
+          "now pulls three partners' blocks through the compute unit's L2 port (SQ_INSTS_VMEM_RD)."]
 open(os.path.join(ROOT, "profiles", f"{tag}_train_pmc{suffix}.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
