@@ -601,17 +601,18 @@ def main():
     flops_step = update_flops(18, 6, 64, B)
     us_per_step = u["us_per_optimizer_step"]
     ppo_tflops = flops_step / (us_per_step * 1e-6) / 1e12
-    n_cu = 6      # ppo_train_halves_kernel: two workgroups per network (round 5; the wave-pair kernel of rounds 2-4 ran on 3)
-    roofline_ppo = dict(kernel="ppo_train_halves_kernel", bound="mfma", achieved=round(ppo_tflops, 4), peak=round(F32_MFMA_PEAK_TFLOPS * n_cu / 256, 3),
+    quarters = os.environ.get("ICRL_QUARTERS", "1") != "0"      # (csrc/ppo_train.hip: quarters_default)
+    n_cu = 12 if quarters else 6      # ppo_train_halves_kernel: four workgroups per network (round 6; two in round 5, the wave-pair kernel of rounds 2-4 ran on 3)
+    roofline_ppo = dict(kernel=f"ppo_train_halves_kernel<2, false, 18, {4 if quarters else 2}>", bound="mfma", achieved=round(ppo_tflops, 4), peak=round(F32_MFMA_PEAK_TFLOPS * n_cu / 256, 3),
                         unit="TFLOP/s", frac=round(ppo_tflops / (F32_MFMA_PEAK_TFLOPS * n_cu / 256), 4), compute_units=n_cu,
                         chip_peak=F32_MFMA_PEAK_TFLOPS, frac_chip=round(ppo_tflops / F32_MFMA_PEAK_TFLOPS, 5),
                         us_per_optimizer_step=round(us_per_step, 2), optimizer_steps=u["optimizer_steps"], flops_per_step=flops_step,
                         us_per_rollout_step=None if u["us_per_rollout_step"] is None else round(u["us_per_rollout_step"], 2),
-                        note="dependent optimiser steps of the reference algorithm, step LATENCY is what counts: 6 workgroups (two per MLP, 32 rows of the "
-                             "minibatch each, partial gradients exchanged through the XCD's L2) = 6 of 256 CUs; peak = fp32 MFMA rate of those 6 CUs — the "
-                             "same algorithmic flops on twice the compute units of rounds 2-4 in 0.82 x the time: the fraction of peak halves, the step "
-                             "shortens; flops_per_step is the algorithmic count (DESIGN.md section 5), the padded 16x16x4 MFMA work actually issued is "
-                             "2 x 70 instructions per SIMD, workgroup and step (SQ counters: profiles/r05_train_pmc.md)")
+                        note="dependent optimiser steps of the reference algorithm, step LATENCY is what counts: 12 workgroups (four per MLP, 16 rows = one row tile of the "
+                             "minibatch each, the four partial gradients exchanged through the XCD's L2 and summed in a fixed order by all four) = 12 of 256 CUs; peak = fp32 MFMA "
+                             "rate of those 12 CUs — the same algorithmic flops on twice the compute units of round 5 in 0.96 x the time: the fraction of peak halves again, the "
+                             "step shortens (6.74 -> 6.46 us); flops_per_step is the algorithmic count (DESIGN.md section 5), the padded 16x16x4 MFMA work actually issued is "
+                             "35 instructions per wave and step (SQ counters: profiles/r06_train_pmc.md)")
     par = (f"env-shards x{world}, 1 all-reduce / outer iteration" if a.mode == "shards" else f"independent seeds x{world}, no collective")
     out = dict(metric="env-steps/sec (ICRL outer loop, HCWithPos-v0)", value=round(env_steps / dt, 1), unit="env-steps/s",
                n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(1e3 * dt / a.steps, 2), higher_is_better=True,
