@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ICRL_HIP_LIB") or os.path.join(_HERE, "lib", "libicrl_hip.so")      # ICRL_HIP_LIB: a variant build (A/B timing)
 
 _lib = None
-PPO_SPLIT_BYTES = 2 * 3 * 2 * (4 * 8 + 23 + 5) * 256 * 8      # ICRL_PPO_SPLIT_BYTES
+PPO_SPLIT_BYTES = 2560 * 1024      # ICRL_PPO_SPLIT_BYTES
 
 c_void_p, c_int, c_double, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_float
 

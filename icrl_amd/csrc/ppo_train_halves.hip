@@ -70,6 +70,13 @@
 #ifndef ICRL_HALVES_POLL_ROLL
 #define ICRL_HALVES_POLL_ROLL 0
 #endif
+// ICRL_HALVES_OWNER_ADAM (four parts only): a wave's parameters are summed, norm-ed and Adam-updated by ONE of the four parts — the OWNER of wave w
+//   is part w / 2 — instead of by all four on replicas: only the owner fetches the three peers' partial gradients of that wave (a quarter of the
+//   exchange's bytes per workgroup), Adam runs on one wave per SIMD, and the updated parameters travel back to the other three parts in a third hop
+//   (the Adam moments live in the owner's registers only).  Same sums in the same order: the results are bit-identical to the replicated form.
+#ifndef ICRL_HALVES_OWNER_ADAM
+#define ICRL_HALVES_OWNER_ADAM 0
+#endif
 // A/B: the four waves of a quad on four SIMDs (rt2 = w >> 2) instead of two and two (rt2 = w & 1)
 #ifndef ICRL_HALVES_QUAD_SPREAD
 #define ICRL_HALVES_QUAD_SPREAD 0
@@ -85,7 +92,10 @@ constexpr int SAH = 24;    // row stride of the per-row action block and of the 
 constexpr int HX_GROUPS = 7;                                   // exchange slots per thread: W1 tile, 2 W2 tiles, head, {b1, b2, extra}, 2 book-keeping records
 constexpr int HX_FLAG = HX_GROUPS * THH * 16;                  // byte offset of the 8 flag words (64 B apart) of a block
 constexpr int HX_BLK = HX_FLAG + 8 * 64;                       // bytes of one (parity, role, half) block
-static_assert(24 * HX_BLK + 3 * 512 <= (int)ICRL_PPO_SPLIT_BYTES, "the exchange of up to four row parts per network lives in the split workspace");
+constexpr int H3_FLAG = 5 * THH * 16;                          // third hop (owner -> the other parts): 5 parameter groups per thread + 8 flag words per block
+constexpr int H3_BLK = H3_FLAG + 8 * 64;
+constexpr int H3_BASE = 24 * HX_BLK;
+static_assert(H3_BASE + 24 * H3_BLK + 3 * 512 <= (int)ICRL_PPO_SPLIT_BYTES, "the exchange of up to four row parts per network lives in the split workspace");
 
 template <int NT1>
 struct SmemH {  // offsets in floats (multiples of 4)
@@ -148,6 +158,8 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   const int rt2 = SPREAD ? w >> 2 : w & 1, fq = SPREAD ? w & 3 : w >> 1;      // forward / activation backward: row tile, feature tile
   const int qp0 = SPREAD ? w ^ 1 : w ^ 2, qp1 = SPREAD ? w ^ 2 : w ^ 4, qp2 = SPREAD ? w ^ 3 : w ^ 6;      // the other three waves of the quad
   const bool fwd_wave = rt2 < NJS;         // (NQ == 4: waves 4..7 take no part in forward / loss / activation backward)
+  constexpr bool OWNER = NQ == 4 && ICRL_HALVES_OWNER_ADAM;
+  const bool owner = !OWNER || (w >> 1) == half;      // this part sums, norms and Adam-updates wave w's parameters (OWNER: one part per wave)
   // the next minibatch is staged INSIDE the first exchange hop when there are four parts: that hop then moves three partners' blocks through the
   // compute unit's L2 port and is long enough to hide the staging (6.43-6.47 -> 6.34-6.40 us per step; with two parts 6.96 against 6.87)
   constexpr bool STAGE_HOP = ICRL_HALVES_STAGE_IN_HOP || NQ == 4;
@@ -267,7 +279,8 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   const float max_grad_norm = a.hp.max_grad_norm, adam_epsf = a.hp.adam_eps, adam_b2f = a.hp.adam_beta2;
   u64* const xch0 = GPH(a.xch);                                                                    // XCD words of all six workgroups, half 0's norm granules
   u64* const gxp = GPH(a.gx);
-  u64* const nx = half == 0 ? xch0 : reinterpret_cast<u64*>(reinterpret_cast<char*>(gxp) + ICRL_PPO_SPLIT_BYTES - 512 * half);      // this part's norm granules
+  // this part's norm granules (OWNER: ONE area for all four parts — the eight wave granules of a role come from the four owners)
+  u64* const nx = (half == 0 || OWNER) ? xch0 : reinterpret_cast<u64*>(reinterpret_cast<char*>(gxp) + ICRL_PPO_SPLIT_BYTES - 512 * half);
 
   // ---- row stream: the 32 rows of this half are staged by the 512 threads, 16 per row (see ppo_train_pairs.hip for the rules the
   // index / row loads follow: unconditional, clamped, untouched until consumed)
@@ -822,12 +835,14 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           }
           return r;
         };
-        const Part s01 = add(fetch(0), fetch(1));
-        const Part s23 = add(fetch(2), fetch(3));
-        const Part t = add(s01, s23);
-        gW1r = t.g0; gW2r[0] = t.g1; gW2r[1] = t.g2; gWhr = t.g3; gsc = t.g4;
-        gb1r = gsc[0]; gb2r = gsc[1]; gex = gsc[2];
-        mb_s0 = t.b0[0]; mb_s1 = t.b0[1]; mb_s2 = t.b0[2]; mb_s3 = t.b0[3]; mb_s4 = t.b1[0];
+        if (owner) {      // (OWNER: the other three parts keep their partials — they receive this wave's updated parameters instead)
+          const Part s01 = add(fetch(0), fetch(1));
+          const Part s23 = add(fetch(2), fetch(3));
+          const Part t = add(s01, s23);
+          gW1r = t.g0; gW2r[0] = t.g1; gW2r[1] = t.g2; gWhr = t.g3; gsc = t.g4;
+          gb1r = gsc[0]; gb2r = gsc[1]; gex = gsc[2];
+          mb_s0 = t.b0[0]; mb_s1 = t.b0[1]; mb_s2 = t.b0[2]; mb_s3 = t.b0[3]; mb_s4 = t.b1[0];
+        }
       } else {
 #if ICRL_HALVES_POLL_ROLL
       unsigned pq0, pq1, pq2, pq3;
@@ -931,7 +946,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       ss += q == 0 ? sb : 0.f;
     }
     ss = wave_sum_fast(ss);
-    if (lane == 0) {
+    if (lane == 0 && owner) {
       bool want_stop = false;
       float mean_kl = 0.f;
       const bool last_mb = (ps.nb_flags >> NB_LAST) & 1;
@@ -949,8 +964,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       if (xcd_local) __hip_atomic_store(nx + (step & 1) * 32 + role * 8 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       else __hip_atomic_store(nx + (step & 1) * 32 + role * 8 + w, ((u64)tag << 32) | (u64)__float_as_uint(ss), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       // this workgroup reads its OWN eight partials from LDS (same floats, same summation order as everybody else's view of them)
-      sm[S::MISC + 24 + role * 8 + w] = ss;
-      if (book && role == 0) sm[S::MISC + 12] = want_stop ? 1.f : 0.f;
+      if (!OWNER) {      // (OWNER: a role's eight granules come from four workgroups: all 24 are read from the shared area)
+        sm[S::MISC + 24 + role * 8 + w] = ss;
+        if (book && role == 0) sm[S::MISC + 12] = want_stop ? 1.f : 0.f;
+      }
       if (book) {
         ++steps_done;
         if (role == 0) {
@@ -961,7 +978,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           const float pl = (-(mb_s0 * inv_nb) + nu * (mb_s1 * inv_nb)) * __builtin_amdgcn_rcpf(1.f + nu);
           lds_add(acc_ent, entropy_loss); lds_add(acc_pg, pl); lds_add(acc_cf, mb_s2 * inv_nb);
           *acc_last = pl + ent_coef * entropy_loss;
-          if (last_mb && half == 0) { float* stats = KARGS()->stats; stats[32 + epoch] = mean_kl; stats[7] = mean_kl; }
+          if (last_mb && (OWNER || half == 0)) { float* stats = KARGS()->stats; stats[32 + epoch] = mean_kl; stats[7] = mean_kl; }
         } else {
           const float vl = mb_s0 * inv_nb;
           lds_add(acc_vl, vl);
@@ -973,7 +990,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     // ---- while the granules travel: stage the next minibatch (rows -> the other X^T buffer, advantage statistics)
     const int xnext = xcur == S::XT0 ? S::XT1 : S::XT0;
     const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK;
-    const bool poller = tid < 24 && (tid >> 3) != role;
+    const bool poller = tid < 24 && (OWNER || (tid >> 3) != role);
     const u64* const slot = nx + (step & 1) * 32 + (tid < 24 ? tid : 0);
 #if ICRL_HALVES_EARLY_POLL
     u64 v_first = 0;
@@ -1042,6 +1059,48 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       };
       auto adam4 = [&](const f32x4& g, f32x4& m, f32x4& v, f32x4& p) { adamn(std::integral_constant<int, 4>{}, g, m, v, p); };
       // pad elements (k >= obs, o >= n_out) have g = m = v = p = 0 and stay 0: no masks needed
+      if constexpr (OWNER) {
+        // ---- one part per wave: the owner runs Adam and sends the updated parameters to the same wave of the other three parts
+        const int h3 = H3_BASE + (((int)(step & 1) * 3 + role) * 4 + (w >> 1)) * H3_BLK;      // the owner's block of this step parity
+        f32x4 pW1, pW2a, pW2b, pWh = f32x4{0.f, 0.f, 0.f, 0.f}, pB = pWh;
+        if (owner) {
+          pW1 = load_own_w1(); adam4(gW1r, mW1, vW1, pW1);
+          pW2a = load_own_w2(0); adam4(gW2r[0], mW2[0], vW2[0], pW2a);
+          pW2b = load_own_w2(1); adam4(gW2r[1], mW2[1], vW2[1], pW2b);
+          raw_store(h3 + (0 * THH + tid) * 16, pW1); raw_store(h3 + (1 * THH + tid) * 16, pW2a); raw_store(h3 + (2 * THH + tid) * 16, pW2b);
+          if (lowk) {
+            f32x4 g_ = f32x4{gb1r, gb2r, ex_g >= 0 ? gex : 0.f, 0.f}, m_ = f32x4{mb1, mb2, mex, 0.f}, v_ = f32x4{vb1, vb2, vex, 0.f};
+            pB = f32x4{sm[S::B1 + jb], sm[S::B2 + jb], sm[ex_s], 0.f};
+            adam4(g_, m_, v_, pB);
+            mb1 = m_[0]; mb2 = m_[1]; mex = m_[2]; vb1 = v_[0]; vb2 = v_[1]; vex = v_[2];
+            pWh = load_own_wh(); adam4(gWhr, mWh, vWh, pWh);
+            raw_store(h3 + (3 * THH + tid) * 16, pWh); raw_store(h3 + (4 * THH + tid) * 16, pB);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // acknowledged by the L2 the others read through -> this wave's flag
+          if (lane == 0) {
+            if (xcd_local) __builtin_amdgcn_raw_buffer_store_b32(step, grs, h3 + H3_FLAG + 64 * w, 0, 1);
+            else __builtin_amdgcn_raw_buffer_store_b32(step, grs, h3 + H3_FLAG + 64 * w, 0, 16);
+          }
+        } else {
+          int spins = 0;
+          while (true) {
+            const unsigned f = __builtin_amdgcn_raw_buffer_load_b32(grs, h3 + H3_FLAG + 64 * w, 0, 16);
+            if (f == step) break;
+            if (++spins >= (1 << 22)) { sm[S::MISC + 13] = 1.f; status = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          asm volatile("" ::: "memory");
+          pW1 = raw_load(h3 + (0 * THH + tid) * 16); pW2a = raw_load(h3 + (1 * THH + tid) * 16); pW2b = raw_load(h3 + (2 * THH + tid) * 16);
+          if (lowk) { pWh = raw_load(h3 + (3 * THH + tid) * 16); pB = raw_load(h3 + (4 * THH + tid) * 16); }
+        }
+        store_w1(pW1); store_w2(0, pW2a); store_w2(1, pW2b);
+        if (lowk) {
+          if (q == 0) { sm[S::B1 + jb] = pB[0]; sm[S::B2 + jb] = pB[1]; sm[ex_s] = pB[2]; }
+          store_wh(pWh);
+          __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the log_std store has landed before refresh_gauss re-reads it
+          refresh_gauss();
+        }
+      } else {
       { f32x4 p_ = load_own_w1(); adam4(gW1r, mW1, vW1, p_); store_w1(p_); }
       if (lowk) {
         f32x4 g_ = f32x4{gb1r, gb2r, ex_g >= 0 ? gex : 0.f, 0.f}, p_ = f32x4{sm[S::B1 + jb], sm[S::B2 + jb], sm[ex_s], 0.f};
@@ -1068,14 +1127,15 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the log_std store has landed before refresh_gauss re-reads it
         refresh_gauss();
       }
+      }      // replicated Adam
     }
     lds_barrier();   // (S7) updated weights visible
     STAMP(6)   // Adam
   }  // optimiser steps
 
   __syncthreads();
-  // ---- write back weights, moments, statistics: the two halves are replicas, half 0 writes
-  if (half == 0) {
+  // ---- write back weights, moments, statistics: the parts are replicas, part 0 writes (OWNER: every wave's owner — the moments live there only)
+  if (OWNER ? owner : half == 0) {
   const TrainArgs* kw = ka;
   asm volatile("" : "+s"(kw));
   const TrainArgs& a = *kw;

@@ -168,7 +168,7 @@ typedef struct {
   float lr, adam_beta1, adam_beta2, adam_eps;
 } icrl_cn_hyper_t;
 
-#define ICRL_PPO_SPLIT_BYTES (2 * 3 * 2 * (4 * 8 + 23 + 5) * 256 * 8) /* partial-gradient granules: 2 step parities x 3 networks x 2 halves */
+#define ICRL_PPO_SPLIT_BYTES (2560 * 1024) /* exchange space of the multi-workgroup updates: partial gradients (2 step parities x 3 networks x up to 4 parts), updated parameters */
 /* granule slots (512 B) + the schedule tables: 16 B per optimiser step and 8 B per 64-row chunk (up to four per step) */
 #define ICRL_PPO_PLAN_BYTES(n_steps) (768 + 48 * (size_t)(n_steps))
 #define ICRL_PPO_SYNC_BYTES(n_epochs, n_minibatches, n_rows) \
