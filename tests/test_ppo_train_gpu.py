@@ -130,7 +130,7 @@ def _oracle_train(agent_sd, buf, perms, kind, nu, okw=None, **h):
                                              ("hc-wide", 6, 50, 150, 2, None), ("hc-wide", 7, 50, 175, 2, None), ("hc-trunk", 9, 48, 144, 2, None),
                                              # target-KL stop decided inside an Adam launch of ~3 900 workgroups: the epoch's last step is applied in full
                                              ("hc-huge", 8, 16, 64, 3, 1e-7)])
-def test_train_vs_oracle(kind, N, T, B, E, tk, one_workgroup_per_network=False):
+def test_train_vs_oracle(kind, N, T, B, E, tk, one_workgroup_per_network=False, train_kernel=None):
     from helpers.arches import ARCHES, oracle_arch_kwargs
     rng = np.random.RandomState(N * T)
     kind, _, shape = kind.partition("-")
@@ -142,6 +142,8 @@ def test_train_vs_oracle(kind, N, T, B, E, tk, one_workgroup_per_network=False):
     agent = _agent(kind, N, T, batch_size=B, n_epochs=E, target_kl=tk, learning_rate=lr, clip_range=0.2, **akw)
     if one_workgroup_per_network:
         agent.train_kernel = "rows1"
+    if train_kernel is not None:
+        agent.train_kernel = train_kernel
     sd0 = agent.policy.state_dict()
     obs = rng.randn(T, N, od).astype(np.float32)
     # old log-probs from the current policy on sampled actions so that ratios start near 1 (as in a real rollout)
@@ -215,6 +217,15 @@ def test_two_chunk_minibatches_on_one_workgroup_per_network(N, T, B):
     partial gradients (covered by test_train_vs_oracle above); hp._pad bit 3 keeps the sequential two-chunk loop of a single
     workgroup — same tolerances against the oracle."""
     test_train_vs_oracle("ant", N, T, B, 2, None, one_workgroup_per_network=True)
+
+
+@pytest.mark.parametrize("kernel", ["halves", "pairs"])
+@pytest.mark.parametrize("N,T,B,E,tk", [(8, 32, 64, 3, None), (16, 32, 64, 6, 0.002), (5, 40, 128, 2, None), (5, 60, 200, 2, None), (4, 8, 16, 2, None)])
+def test_hc_update_kernels_behind_the_default(kernel, N, T, B, E, tk):
+    """obs <= 32: the default is the wave-quad kernel with FOUR workgroups per network (round 6; test_train_vs_oracle above); batches of 17 .. 40 runs
+    get its two-workgroup form (`train_kernel = "halves"`, hp._pad & 32: round 5's default), larger ones the wave-pair kernel (`"pairs"`, hp._pad & 16:
+    rounds 2-4) — the same oracle cases through both, incl. ragged and multi-chunk minibatches and a target-KL stop."""
+    test_train_vs_oracle("hc", N, T, B, E, tk, train_kernel=kernel)
 
 
 def test_run_major_layout_equals_packed_layout():
