@@ -317,3 +317,48 @@ def test_configs4_shard_full_rows(monkeypatch):
     agent, port, env = _pair_rows("AntWallBroken-v0", "ant", 512, 2048, 113, 8, "cn_antbroken.npz", 4, broken=True, batch_size=128, n_epochs=20,
                                   target_kl=0.01, learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9, penalty_learning_rate=1.0)
     _full_rows_step(agent, port, env, "configs4shard", 3e-5, monkeypatch)
+
+
+def test_configs4_shard_whole_learn_vs_port_band(golden):
+    """BASELINE configs[4] as ONE GPU sees it, over a whole learn(): AntWallBroken-v0, 512 envs x 2048 steps, the reference's frozen AntBroken constraint
+    net, README.md:78 flags, FOUR rollouts + updates = 4.2 M env steps (icrl/cpg.py:203 is one learn() call; the Lagrange multiplier moves with nu learning
+    rate 1.0) against tests/golden/g22_whole_run_cpg.npz: what PortAgent's train() logged per rollout in 8 runs of the CPU port on the same SeededStreams(31)
+    and initial weights — undisturbed and with ulp-sized / summation-order / 1e-6-tanh disturbances (tools/gen_whole_run.py run3 / band3).  Every scalar of
+    every rollout must lie in [lo - w - tol, hi + w + tol], w = hi - lo (ref: ppo_lag.py:196-338, on_policy_algorithm.py:430-492)."""
+    from icrl_amd import logger, utils
+    from icrl_amd.constraint_net import ConstraintNet
+    from icrl_amd.ppo_lag import PPOLagrangian
+    g = golden("g22_whole_run_cpg")
+    N, T, seed = int(g["N"]), int(g["T"]), int(g["seed"])
+    env = utils.make_train_env("AntWallBroken-v0", None, True, seed, N, cost_info_str="cost", reward_gamma=0.99, cost_gamma=0.99)
+    cn = ConstraintNet.load(os.path.join(HERE, "golden", "cn_antbroken.npz"))
+    env.set_cost_function(cn.cost_function)
+    agent = PPOLagrangian("TwoCriticsMlpPolicy", env, n_steps=T, seed=seed, streams=SeededStreams(int(g["stream_seed"])), batch_size=128, n_epochs=20, target_kl=0.01,
+                          learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9, penalty_learning_rate=1.0)
+    agent.policy.load_state_dict({k[len("w0/"):]: g[k] for k in g.files if k.startswith("w0/")})
+    keys = [str(k) for k in g["metric_keys"]]
+    base, lo, hi = g["base"], g["lo"], g["hi"]
+    n_it = base.shape[0]
+    assert n_it >= 4 and {"train/nu", "train/average_cost", "train/early_stop_epoch", "train/policy_gradient_loss"} <= set(keys)
+    agent._setup_learn(n_it * N * T)
+    outside = []
+    for it in range(n_it):
+        agent.collect_rollouts(env, None, agent.rollout_buffer, T, "cost")
+        agent.train()
+        lg = dict(logger.Logger.CURRENT.name_to_value)
+        missing = [k for k in keys if k not in lg]
+        assert not missing, missing
+        for j, k in enumerate(keys):
+            x, b, l, h = float(lg[k]), float(base[it, j]), float(lo[it, j]), float(hi[it, j])
+            if k.endswith("explained_variance") and max(x, b, l, h) < 1.0:
+                x, b, l, h = (1.0 / (1.0 - v) for v in (x, b, l, h))
+            tol = 0.0 if k in ("train/early_stop_epoch", "train/n_updates") else (1e-6 if k == "train/nu" else 1e-5 + 1e-4 * abs(b))
+            if k in ("train/approx_kl", "train/clip_fraction"):
+                tol = 2e-4 + 2e-3 * abs(b)
+            if not (l - (h - l) - tol <= x <= h + (h - l) + tol):
+                outside.append((it, k, x, b, l, h))
+        j = keys.index
+        print(f"[cpg whole learn] rollout {it}: nu {lg['train/nu']:.6f} [{lo[it, j('train/nu')]:.6f}, {hi[it, j('train/nu')]:.6f}]  average_cost {lg['train/average_cost']:.6f} "
+              f"[{lo[it, j('train/average_cost')]:.6f}, {hi[it, j('train/average_cost')]:.6f}]  early_stop_epoch {lg['train/early_stop_epoch']} "
+              f"[{lo[it, j('train/early_stop_epoch')]:.0f}, {hi[it, j('train/early_stop_epoch')]:.0f}]")
+    assert not outside, outside[:20]

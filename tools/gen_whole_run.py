@@ -175,6 +175,74 @@ def run2(name, variant, out_path, n_iters=None):
     o_loop.icrl_port(port_cfg, eo, ea, esd, n_iters=n_iters or c["n_iters"], streams=streams, init=init, log=log)
 
 
+# ---- BASELINE configs[4]'s per-GPU shard: cpg's learn() (icrl/cpg.py:203: ONE learn() call) on AntWallBroken-v0, 512 envs x 2048 steps, the reference's frozen
+# AntBroken constraint net, README.md:78 flags — per ROLLOUT + update: what PPOLagrangian.train() logs.  `run3 <variant> out.json [n_rollouts]`, `band3 base.json ...`
+CPG = dict(golden="g22_whole_run_cpg", stream_seed=31, N=512, T=2048, seed=0, n_rollouts=4, cn="tests/golden/cn_antbroken.npz",
+           kw=dict(batch_size=128, n_epochs=20, target_kl=0.01, learning_rate=3e-5, clip_range=0.4, reward_gae_lambda=0.9, penalty_learning_rate=1.0))
+
+
+def cpg_port(w0=None):
+    """(PortAgent, its EnvStack) of CPG; w0: initial policy weights (None: the port's own for the seed)."""
+    from oracle import loop as o_loop, nets as o_nets
+    z = np.load(os.path.join(ROOT, CPG["cn"]))
+    ocn = o_nets.CostNet(113, 8, [int(h) for h in z["hidden_sizes"]], False, None, None, None, None, None)      # the off-by-one load(): no clipping, no normalisation
+    ocn.load_state_dict({k[len("cn_network/"):]: z[k] for k in z.files if k.startswith("cn_network/")})
+    stack = o_loop.make_stack(CPG["N"], "ant", CPG["seed"], broken=True); stack.cost_fn = ocn.cost_function
+    port = o_loop.PortAgent(stack, n_steps=CPG["T"], seed=CPG["seed"], **CPG["kw"])
+    if w0 is not None:
+        port.policy.load_state_dict(w0)
+    return port, stack
+
+
+def run3(variant, out_path, n_rollouts=None):
+    from oracle.streams import SeededStreams
+    torch.set_num_threads(1)
+    if variant.startswith("tanhe6"):
+        orig, ph = torch.tanh, float(variant[6:] or 0)
+        torch.tanh = lambda x: orig(x) * (1 + 1e-6 * torch.sin(12345.678 * x + ph))
+    port, stack = cpg_port()
+    w0 = {k: v.detach().numpy().copy() for k, v in port.policy.params.items()}
+    if variant in ("ulp", "ulpm") or variant.startswith("rnd"):
+        port.policy.load_state_dict(disturb(w0, variant))
+    streams = SeededStreams(CPG["stream_seed"])
+    if variant in ("rev",) or variant.startswith("rot"):
+        streams = PermutedRows(streams, variant, CPG["kw"]["batch_size"])
+    N, T = CPG["N"], CPG["T"]
+    port.num_timesteps = 0
+    port._last_obs = stack.reset(); port._last_dones = np.zeros(N, bool); port._last_original_obs = stack.old_obs.copy()
+    rows, t0 = [], time.time()
+    for k in range(n_rollouts or CPG["n_rollouts"]):
+        port.collect_rollouts(streams.rollout_noise(T, N, port.act_dim))
+        out = port.train(lambda e: streams.permutation(e, T * N))
+        streams.consumed(min(int(out["train/early_stop_epoch"]) + 1, CPG["kw"]["n_epochs"]))
+        rows.append({k_: float(v) for k_, v in out.items() if np.ndim(v) == 0 and k_.startswith("train/")})
+        print("cpg", variant, "rollout", k, "nu", round(out["train/nu"], 6), "average_cost", round(out["train/average_cost"], 5), "epochs", out["train/early_stop_epoch"], round(time.time() - t0, 1), "s", flush=True)
+        json.dump(dict(variant=variant, config="cpg", metrics=rows), open(out_path, "w"))
+
+
+def band3(base_path, others):
+    base = json.load(open(base_path))["metrics"]
+    runs = [json.load(open(p))["metrics"] for p in others]
+    n_it = min([len(base)] + [len(r) for r in runs])
+    keys = sorted(base[0])
+    val = np.array([[base[i][k] for k in keys] for i in range(n_it)])
+    allv = np.array([[[r[i][k] for k in keys] for i in range(n_it)] for r in [base] + runs])
+    lo, hi = np.nanmin(allv, axis=0), np.nanmax(allv, axis=0)
+    port, _ = cpg_port()
+    w0 = {k: v.detach().numpy().copy() for k, v in port.policy.params.items()}
+    out = os.path.join(ROOT, "tests/golden", CPG["golden"] + ".npz")
+    np.savez_compressed(out, meta=np.array(repr(dict(torch=torch.__version__, numpy=np.__version__, runs=1 + len(runs), variants=[os.path.basename(p) for p in others]))),
+                        stream_seed=CPG["stream_seed"], N=CPG["N"], T=CPG["T"], seed=CPG["seed"], metric_keys=np.array(keys), base=val, lo=lo, hi=hi,
+                        **{f"w0/{k}": v for k, v in w0.items()})
+    print(f"wrote {out} ({os.path.getsize(out) / 1024:.0f} KB): {n_it} rollouts + updates, {len(keys)} scalars, {1 + len(runs)} runs of the CPU port\n")
+    show = [k for k in ("train/nu", "train/average_cost", "train/early_stop_epoch", "train/policy_gradient_loss", "train/reward_value_loss", "train/cost_value_loss", "train/approx_kl",
+                        "train/reward_explained_variance", "train/std") if k in keys]
+    print("| rollout | " + " | ".join(show) + " |")
+    print("|---|" + "---|" * len(show))
+    for i in range(n_it):
+        print(f"| {i} | " + " | ".join(f"{val[i, keys.index(k)]:.6g} [{lo[i, keys.index(k)]:.6g}, {hi[i, keys.index(k)]:.6g}]" for k in show) + " |")
+
+
 SKIP = ("time/", "time(m)")
 
 
@@ -213,5 +281,9 @@ if __name__ == "__main__":
         run2(sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5]) if len(sys.argv) > 5 else None)
     elif sys.argv[1] == "band2":
         band(sys.argv[3], sys.argv[4:], sys.argv[2])
+    elif sys.argv[1] == "run3":
+        run3(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else None)
+    elif sys.argv[1] == "band3":
+        band3(sys.argv[2], sys.argv[3:])
     else:
         band(sys.argv[2], sys.argv[3:])
