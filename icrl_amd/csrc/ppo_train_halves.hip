@@ -77,6 +77,11 @@
 #ifndef ICRL_HALVES_OWNER_ADAM
 #define ICRL_HALVES_OWNER_ADAM 0
 #endif
+// ICRL_HALVES_FLAGS_TOGETHER (four parts): the three peers' flags polled in one look instead of one blocking look each (three trips through the L2 even
+//   when all three are long set): 6.36-6.40 -> 6.25-6.30 us per step; on
+#ifndef ICRL_HALVES_FLAGS_TOGETHER
+#define ICRL_HALVES_FLAGS_TOGETHER 1
+#endif
 // A/B: the four waves of a quad on four SIMDs (rt2 = w >> 2) instead of two and two (rt2 = w & 1)
 #ifndef ICRL_HALVES_QUAD_SPREAD
 #define ICRL_HALVES_QUAD_SPREAD 0
@@ -804,6 +809,25 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       if constexpr (NQ == 4) {
         // four parts: every workgroup forms (q0 + q1) + (q2 + q3) from the three others' blocks and its own registers — the same floats in the same
         // order on all four, so they stay replicas.  One pair at a time (register pressure): flags of this wave's peers, then their groups.
+#if ICRL_HALVES_FLAGS_TOGETHER
+        // the flags of this wave's THREE peers in flight together: three blocking looks in a row cost three trips through the L2 even when all
+        // three flags are long set; the groups are still fetched pair by pair (register pressure)
+        if (owner) {
+          const int fo = xrole + HX_FLAG + 64 * w;
+          const int ka = (half + 1) & 3, kb = (half + 2) & 3, kc = (half + 3) & 3;
+          int spins = 0;
+          while (true) {
+            const unsigned fa = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + ka * HX_BLK, 0, 16);
+            const unsigned fb = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + kb * HX_BLK, 0, 16);
+            const unsigned fc = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + kc * HX_BLK, 0, 16);
+            if (fa == step && fb == step && fc == step) break;
+            if (++spins >= (1 << 22)) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          asm volatile("" ::: "memory");
+        }
+        auto wait_flag = [&](int) {};
+#else
         auto wait_flag = [&](int k) {
           int spins = 0;
           while (true) {
@@ -814,6 +838,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           }
           asm volatile("" ::: "memory");
         };
+#endif
         struct Part { f32x4 g0, g1, g2, g3, g4, b0, b1; };
         const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
         const Part own = {gW1r, gW2r[0], gW2r[1], gWhr, gsc, f32x4{mb_s0, mb_s1, mb_s2, mb_s3}, f32x4{mb_s4, 0.f, 0.f, 0.f}};
