@@ -82,6 +82,9 @@
 #ifndef ICRL_HALVES_FLAGS_TOGETHER
 #define ICRL_HALVES_FLAGS_TOGETHER 1
 #endif
+#ifndef ICRL_HALVES_FIRST_LOOK
+#define ICRL_HALVES_FIRST_LOOK 0
+#endif
 // A/B: the four waves of a quad on four SIMDs (rt2 = w >> 2) instead of two and two (rt2 = w & 1)
 #ifndef ICRL_HALVES_QUAD_SPREAD
 #define ICRL_HALVES_QUAD_SPREAD 0
@@ -801,6 +804,16 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         }
       }
 #endif
+#if ICRL_HALVES_FIRST_LOOK
+      // (four parts) the first look at the three peers' flags is ISSUED before the staging and read behind it
+      unsigned fl_a = 0, fl_b = 0, fl_c = 0;
+      if (NQ == 4 && owner) {
+        const int fo = xrole + HX_FLAG + 64 * w;
+        fl_a = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + ((half + 1) & 3) * HX_BLK, 0, 16);
+        fl_b = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + ((half + 2) & 3) * HX_BLK, 0, 16);
+        fl_c = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + ((half + 3) & 3) * HX_BLK, 0, 16);
+      }
+#endif
       if (STAGE_HOP) {
         commit_rows(xcur == S::XT0 ? S::XT1 : S::XT0);
         stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
@@ -816,7 +829,12 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           const int fo = xrole + HX_FLAG + 64 * w;
           const int ka = (half + 1) & 3, kb = (half + 2) & 3, kc = (half + 3) & 3;
           int spins = 0;
-          while (true) {
+#if ICRL_HALVES_FIRST_LOOK
+          const bool first_ok = fl_a == step && fl_b == step && fl_c == step;
+#else
+          const bool first_ok = false;
+#endif
+          while (!first_ok) {
             const unsigned fa = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + ka * HX_BLK, 0, 16);
             const unsigned fb = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + kb * HX_BLK, 0, 16);
             const unsigned fc = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + kc * HX_BLK, 0, 16);
