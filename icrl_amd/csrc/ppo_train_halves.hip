@@ -82,8 +82,14 @@
 #ifndef ICRL_HALVES_FLAGS_TOGETHER
 #define ICRL_HALVES_FLAGS_TOGETHER 1
 #endif
+// ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
+#endif
+// ICRL_HALVES_NORM_LOOK_EARLY (four parts): the first look at the other networks' norm granules issued in front of the partial-gradient sums: 6.38-6.43 against
+//   6.29-6.33 — the look queues in front of the partners' blocks in the L2 port that bounds the hop; off
+#ifndef ICRL_HALVES_NORM_LOOK_EARLY
+#define ICRL_HALVES_NORM_LOOK_EARLY 0
 #endif
 // A/B: the four waves of a quad on four SIMDs (rt2 = w >> 2) instead of two and two (rt2 = w & 1)
 #ifndef ICRL_HALVES_QUAD_SPREAD
@@ -771,6 +777,9 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     }  // chunks
 
     // ================= partial gradients of this half <-> the other half of the same network =================
+#if ICRL_HALVES_NORM_LOOK_EARLY
+    u64 v_early = 0;
+#endif
     {
       f32x4 gsc = f32x4{gb1r, gb2r, gex, 0.f};
       if (!ICRL_HALVES_EARLY_PUBLISH) {
@@ -819,6 +828,11 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
       }
       bool timed_out = false;
+#if ICRL_HALVES_NORM_LOOK_EARLY
+      // (four parts) the first look at the OTHER networks' norm granules is issued here, in front of the partial-gradient sums: the critics' workgroups
+      // are 1-2 k cycles ahead of the policy's, whose own look then costs no trip of its own
+      if (NQ == 4 && tid < 24 && (tid >> 3) != role) v_early = __hip_atomic_load(nx + (step & 1) * 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
       if constexpr (NQ == 4) {
         // four parts: every workgroup forms (q0 + q1) + (q2 + q3) from the three others' blocks and its own registers — the same floats in the same
         // order on all four, so they stay replicas.  One pair at a time (register pressure): flags of this wave's peers, then their groups.
@@ -1037,7 +1051,12 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     const u64* const slot = nx + (step & 1) * 32 + (tid < 24 ? tid : 0);
 #if ICRL_HALVES_EARLY_POLL
     u64 v_first = 0;
+#if ICRL_HALVES_NORM_LOOK_EARLY
+    if (NQ == 4 && !OWNER) v_first = v_early;
+    if (poller && (unsigned)((v_first >> 32) & 0x7fffffffu) != step) v_first = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
     if (poller) v_first = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
 #endif
     if (!STAGE_HOP) {
       commit_rows(xnext);
