@@ -176,6 +176,8 @@ int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s
 // parts = 2 | 4 workgroups per network (round 6: four — 16 rows of every chunk each)
 int launch_train_halves(const TrainArgs& a, bool discrete, int parts, hipStream_t s);
 int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, int parts, hipStream_t s);
+// ppo_train_quarters.hip: four workgroups per network at obs 65..128 (wave quads, the row-owning kernel's parameter ownership); single-run launches
+int launch_train_quarters_wide(const TrainArgs& a, bool discrete, hipStream_t s);
 constexpr int HALVES_MAX_RUNS = 40;      // batched launches: 6 workgroups per run, 5 groups of 8 runs = 30 workgroups per XCD (packed_grid)
 constexpr int QUARTERS_MAX_RUNS = 16;    // 12 workgroups per run, 2 groups of 8 runs = 24 workgroups per XCD
 // batched forms: n_runs argument blocks in DEVICE memory, grid.y = run
