@@ -178,6 +178,8 @@ int launch_train_halves(const TrainArgs& a, bool discrete, int parts, hipStream_
 int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, int parts, hipStream_t s);
 // ppo_train_quarters.hip: four workgroups per network at obs 65..128 (wave quads, the row-owning kernel's parameter ownership); single-run launches
 int launch_train_quarters_wide(const TrainArgs& a, bool discrete, hipStream_t s);
+// ppo_train_quarters2.hip: the same for minibatches of 65..128 rows: both chunks in one pass, two row tiles per wave (chunk plan with two entries per step)
+int launch_train_quarters_wide2(const TrainArgs& a, bool discrete, hipStream_t s);
 constexpr int HALVES_MAX_RUNS = 40;      // batched launches: 6 workgroups per run, 5 groups of 8 runs = 30 workgroups per XCD (packed_grid)
 constexpr int QUARTERS_MAX_RUNS = 16;    // 12 workgroups per run, 2 groups of 8 runs = 24 workgroups per XCD
 // batched forms: n_runs argument blocks in DEVICE memory, grid.y = run

@@ -915,7 +915,7 @@ static int launch_train(const TrainArgs& a, hipStream_t s) {
 
 // argument checks + the pre-kernels (granule / statistics reset, permutation offsets, schedule tables) of ONE run; fills `a` and
 // reports which persistent kernel runs it: 0 wave pairs, 1 row-owning waves, 2 row-owning waves with two workgroups per network,
-// 3 column-split tiles, 6 four workgroups per network at obs 65..128 (single-run launches), 4 wave quads with two workgroups per network (obs <= 32, launches of up to HALVES_MAX_RUNS runs: beyond that the
+// 3 column-split tiles, 6 / 7 four workgroups per network at obs 65..128 (single-run launches; 7: minibatches of 65..128 rows in one pass), 4 wave quads with two workgroups per network (obs <= 32, launches of up to HALVES_MAX_RUNS runs: beyond that the
 // compute units are what runs out and a run keeps one per network).  < 0: refused (return value of fail()) or a HIP error, in *err.
 // FOUR workgroups per network where two would run (round 6: 6.46 against 6.74 us per optimiser step at HC shapes); ICRL_QUARTERS=0 keeps two (A/B)
 static bool quarters_default() {
@@ -979,6 +979,10 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   // obs 65..128, single-run launches: FOUR workgroups per network, wave quads + the row-owning kernel's parameter ownership
   // (ppo_train_quarters.hip; round 6); hp._pad & 4 keeps the row-owning kernel, hp._pad & 32 / ICRL_QUARTERS=0 its two-workgroup form
   const bool quarters_wide = nt1 > 4 && n_runs == 1 && !(hp->_pad & (4 | 32)) && quarters_default();
+  // ... minibatches of 65..128 rows (the reference's AntWall batch size): both 64-row chunks in ONE pass, two row tiles per wave (ppo_train_quarters2.hip;
+  // the chunk plan with two entries per step); ICRL_QUARTERS_PASSES=1 keeps the chunk-by-chunk form (A/B)
+  static const bool one_pass = [] { const char* e = getenv("ICRL_QUARTERS_PASSES"); return e == nullptr || e[0] != '1'; }();
+  const bool quarters_wide2 = quarters_wide && one_pass && hp->batch_size > RB && hp->batch_size <= 2 * RB;
   const bool rows = !quarters_wide && ((hp->_pad & 4) || nt1 > 4);
   const bool split = rows && hp->batch_size > RB && hp->batch_size <= 2 * RB && !(hp->_pad & 8);     // (three or four chunks: one workgroup walks them)
   // hp._pad & 16: the wave-pair kernel (one workgroup per network) where the wave-quad kernel would run
@@ -986,14 +990,14 @@ static int prepare_train(const icrl_policy_t* pol, float* exp_avg, float* exp_av
   const bool halves = !rows && n_runs <= HALVES_MAX_RUNS && nt1 <= 2 && !(hp->_pad & 16);
   const bool quarters = halves && n_runs <= QUARTERS_MAX_RUNS && !(hp->_pad & 32) && quarters_default();
   hipLaunchKernelGGL(ppo_plan_kernel, dim3((unsigned)((n_steps + 2 + 255) / 256)), dim3(256), 0, s, adam_step, (int)n_steps, n_mb,
-                     n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks, (int)split);
+                     n_total, hp->batch_size, (double)hp->lr, (double)hp->adam_beta1, (double)hp->adam_beta2, steps, chunks, (int)(split || quarters_wide2));
   if (split || halves || quarters_wide) {
     const size_t off = (ICRL_PPO_PLAN_BYTES(n_steps) + 4 * (size_t)hp->n_epochs * n_total + 255) / 256 * 256;      // behind the permutation offsets
     a.gx = reinterpret_cast<u64*>((char*)sync_ws + off);
     e = hipMemsetAsync(a.gx, 0, ICRL_PPO_SPLIT_BYTES, s);
     if (e != hipSuccess) return bad((int)e);
   }
-  if (quarters_wide) return 6;
+  if (quarters_wide) return quarters_wide2 ? 7 : 6;
   return rows ? (split ? 2 : 1) : (halves ? (quarters ? 5 : 4) : 0);
 }
 
@@ -1043,6 +1047,7 @@ extern "C" int icrl_ppo_lag_train(const icrl_policy_t* pol, float* exp_avg, floa
   const int nt1 = (pol->obs_dim + 15) / 16;
   if (kind == 4 || kind == 5) return launch_train_halves(a, pol->discrete != 0, kind == 5 ? 4 : 2, s);
   if (kind == 6) return launch_train_quarters_wide(a, pol->discrete != 0, s);
+  if (kind == 7) return launch_train_quarters_wide2(a, pol->discrete != 0, s);
   if (kind == 0) return launch_train_pairs(a, nt1, pol->discrete != 0, s);
   if (kind <= 2) return launch_train_rows(a, nt1, pol->discrete != 0, kind == 2, s);
   if (pol->discrete) {
@@ -1079,6 +1084,7 @@ extern "C" int icrl_ppo_lag_train_batch(int n_runs, const icrl_ppo_train_job_t* 
     if (kind == 3) return fail("icrl_ppo_lag_train_batch: the column-split tiles kernel (hp->_pad & 2) has no batched form");
     if (r == 0) kind0 = kind;
     if (kind == 6) return launch_train_quarters_wide(a, j.pol->discrete != 0, s);      // (a one-run batch at obs 65..128: the single-run launch)
+    if (kind == 7) return launch_train_quarters_wide2(a, j.pol->discrete != 0, s);
     const int e = put_args(a, d_args + r, s);
     if (e != 0) return e;
   }

@@ -33,6 +33,10 @@
 #define ICRL_QW_DEP 4
 #endif
 
+#ifndef ICRL_QW_STATIC_LDS
+#define ICRL_QW_STATIC_LDS 0
+#endif
+
 namespace icrl {
 
 constexpr int THQ = 256;   // 4 waves, one per SIMD
@@ -81,7 +85,11 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
   using S = SmemQ<NT1>;
   constexpr int SX = S::SX;
   static_assert(OBS == 0 || (OBS > 16 * (NT1 - 1) && OBS <= 16 * NT1), "OBS names the observation width of an NT1-tile instantiation");
+#if ICRL_QW_STATIC_LDS
   __shared__ __attribute__((aligned(16))) float sm[S::TOTAL];
+#else
+  extern __shared__ __attribute__((aligned(16))) float sm[];      // dynamic: with a static array the folded offsets let the optimiser hoist more addresses than the register file holds (ppo_train_rows.hip)
+#endif
   const int role = slot_j % 3;   // 0 policy, 1 reward critic, 2 cost critic
   const int part = slot_j / 3;   // rows 16 part .. 16 part + 15 of every 64-row chunk
   const int tid = threadIdx.x;
@@ -405,6 +413,9 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
 #pragma unroll
         for (int js = 0; js < NT1; ++js) aw[js] = lds128(pa + 16 * js);
         f32x4 z = lds128(sm + S::B1 + 16 * w + 4 * q);      // the bias is the accumulator's initial value
+        // every operand fetch is issued before the first MFMA (left to itself the compiler fetches one k step, waits for it, issues its MFMA: the
+        // full LDS latency in front of each of the 29 steps)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int js = 0; js < NT1; ++js)
 #pragma unroll
@@ -438,6 +449,7 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
         const float* ph1 = sm + S::H1R + b * SRQ + 4 * q;
 #pragma unroll
         for (int d = 1; d < 4; ++d) hp[d - 1] = lds128(ph1 + 16 * ((w + d) & 3));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -584,6 +596,7 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
         const float* pz = sm + S::DZ2R + b * SRQ + 4 * q;
 #pragma unroll
         for (int d = 1; d < 4; ++d) dp[d - 1] = lds128(pz + 16 * ((w + d) & 3));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -611,6 +624,7 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
         f32x4 bh[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) bh[t] = lds128(pb + t * 16 * STQ);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
 #pragma unroll
@@ -637,11 +651,14 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
       {
         const f32x4 az = lds128(sm + S::DZ1T + (16 * w + r) * STQ + 4 * q);   // dz1^T[j = 16 w + r][rows]
         const float* pb = sm + xcur + r * STQ + 4 * q;                        // x^T[k = 16 c + r][rows 4 q + e]
+        f32x4 bx[NT1];
+#pragma unroll
+        for (int c = 0; c < NT1; ++c) bx[c] = lds128(pb + c * 16 * STQ);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int c = 0; c < NT1; ++c) {
-          const f32x4 bx = lds128(pb + c * 16 * STQ);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) gW1r[c] = MFMA_F32(az[e], bx[e], gW1r[c]);
+          for (int e = 0; e < 4; ++e) gW1r[c] = MFMA_F32(az[e], bx[c][e], gW1r[c]);
           if (c == 0) publish4(last_chunk, NT1 + 4, gWhr); else publish4(last_chunk, c - 1, gW1r[c - 1]);
         }
         const float s = (az[0] + az[1]) + (az[2] + az[3]);
@@ -936,8 +953,11 @@ __global__ void __launch_bounds__(THQ) ppo_train_quarters_kernel(TrainArgs a, in
 template <int NT1, bool DISC, int OBS>
 static int launch_quarters(const TrainArgs& a, hipStream_t s) {
   static_assert(SmemQ<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
+  const size_t bytes = ICRL_QW_STATIC_LDS ? 0 : (size_t)SmemQ<NT1>::TOTAL * sizeof(float);
+  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_quarters_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) return (int)e;
   TrainArgs arg = a;
-  return launch_update_single(ppo_train_quarters_kernel<NT1, DISC, OBS>, 12, dim3(THQ), 0, s, arg);
+  return launch_update_single(ppo_train_quarters_kernel<NT1, DISC, OBS>, 12, dim3(THQ), bytes, s, arg);
 }
 
 // obs 65..128 (nt1 5..8: run on the eight-tile instantiation, pad columns zero), a.gx set and zeroed (prepare_train), the chunk plan with one

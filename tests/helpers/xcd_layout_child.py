@@ -1,5 +1,5 @@
 """child of tests/test_ppo_train_gpu.py::test_run_major_layout_equals_packed_layout: one update at HC shapes (wave pairs), one at AntWall
-shapes with batch 128 (two workgroups per network exchanging partial gradients) and one rollout through the multi-env kernel; prints a
+shapes with batch 128 (four workgroups per network exchanging partial gradients, then the row-owning kernel's two) and one rollout through the multi-env kernel; prints a
 digest of everything they leave.  Run once as is (a run's workgroups on one XCD, workgroup-scope granule stores) and once with
 ICRL_NO_XCD_PACK=1 (run-major grids, agent-scope stores): the digests must agree."""
 import hashlib
@@ -38,5 +38,11 @@ for kind, N, T, B in (("hc", 16, 64, 64), ("ant", 16, 64, 128)):
     for t in (agent.policy.params, agent.policy.exp_avg, agent.policy.exp_avg_sq):
         h.update(t.cpu().numpy().tobytes())
     print("PIECE", kind, "update", h.hexdigest()[:12])
+    if kind == "ant":      # the row-owning kernel's two-workgroup form behind the default (four workgroups per network since round 6)
+        agent.train_kernel = "rows"
+        agent.train(perms=perms)
+        for t in (agent.policy.params, agent.policy.exp_avg, agent.policy.exp_avg_sq):
+            h.update(t.cpu().numpy().tobytes())
+        print("PIECE", kind, "update (rows)", h.hexdigest()[:12])
     h.update(np.asarray(env.obs_rms.mean).tobytes())
 print("DIGEST", h.hexdigest())

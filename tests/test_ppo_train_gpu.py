@@ -115,6 +115,9 @@ def _oracle_train(agent_sd, buf, perms, kind, nu, okw=None, **h):
                                              ("hc", 5, 60, 200, 2, None),      # 300 rows: 200 (64 + 64 + 64 + 8) and 100 (64 + 36)
                                              ("ant", 4, 80, 256, 2, None),     # 320 rows: 256 and 64 (row-owning waves, obs 113)
                                              ("ant", 3, 70, 160, 2, None),     # 210 rows: 160 (3 chunks) and 50
+                                             # obs 113 with minibatches of one chunk: four workgroups per network walking chunk by chunk (ppo_train_quarters.hip)
+                                             ("ant", 6, 32, 64, 2, None), ("ant", 5, 20, 40, 2, None),
+                                             ("ant", 16, 32, 128, 6, 0.002),   # target-KL stop through the four-workgroup form (the stop flag rides on a norm granule)
                                              # many steps at > 2 chunks per step: the schedule tables (16 B per step + 8 B per chunk)
                                              # must not reach the permutation offsets behind them (ICRL_PPO_PLAN_BYTES)
                                              ("hc", 8, 512, 256, 2, None),     # 32 steps x 4 chunks
@@ -217,6 +220,24 @@ def test_two_chunk_minibatches_on_one_workgroup_per_network(N, T, B):
     partial gradients (covered by test_train_vs_oracle above); hp._pad bit 3 keeps the sequential two-chunk loop of a single
     workgroup — same tolerances against the oracle."""
     test_train_vs_oracle("ant", N, T, B, 2, None, one_workgroup_per_network=True)
+
+
+@pytest.mark.parametrize("N,T,B,E,tk", [(24, 16, 128, 2, None), (3, 50, 100, 2, None), (4, 80, 256, 2, None), (6, 32, 64, 2, None), (16, 32, 128, 6, 0.002)])
+def test_ant_update_kernel_behind_the_default(N, T, B, E, tk):
+    """obs 65..128: the default is FOUR workgroups per network (round 6: ppo_train_quarters2.hip for minibatches of 65..128 rows, both chunks in one
+    pass; ppo_train_quarters.hip chunk by chunk otherwise — test_train_vs_oracle above).  `train_kernel = "rows"` (hp._pad & 4) keeps the row-owning
+    kernel: two workgroups per network at 65..128 rows (rounds 3-5's default, and what a batched launch of several runs still uses), one otherwise."""
+    test_train_vs_oracle("ant", N, T, B, E, tk, train_kernel="rows")
+
+
+def test_ant_chunk_by_chunk_form_at_128_rows():
+    """ICRL_QUARTERS_PASSES=1 keeps ppo_train_quarters.hip (16 rows of each 64-row chunk, one chunk after the other) where ppo_train_quarters2.hip
+    would run: the oracle cases with 100- and 128-row minibatches through it (child process: the switch is read once per process)."""
+    import subprocess, sys
+    env = dict(os.environ, ICRL_QUARTERS_PASSES="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_train_vs_oracle and (ant-24-16-128 or ant-3-50-100)",
+                          "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=300, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "2 passed" in out.stdout, out.stdout[-3000:]
 
 
 @pytest.mark.parametrize("kernel", ["halves", "pairs"])
