@@ -215,6 +215,10 @@ def timed_cpg(cfg, warmup, steps, world=1):
     return model, time.time() - t0, float(model.num_timesteps)
 
 
+# round 6: obs 65..128, minibatches of 65..128 rows (csrc/ppo_train_quarters2.hip; the row-owning kernel's two-workgroup form before: 18.0 us per step)
+ANT_UPDATE_KERNEL = "ppo_train_quarters2_kernel (four workgroups per network, 32 rows each as two row tiles per wave: 12 CUs)"
+
+
 def cpg_summary(model, cfg, dt, env_steps, steps, warmup):
     st = dict(agent=model)
     u = update_summary(st, cfg)
@@ -225,8 +229,8 @@ def cpg_summary(model, cfg, dt, env_steps, steps, warmup):
                    optimizer_steps_per_iteration=round(u["optimizer_steps"] / steps, 1),
                    early_stop_fraction=round(1.0 - u["optimizer_steps"] / max(1, u["full_steps"]), 4),
                    value_no_early_stop=round(no_early_stop(env_steps, dt, u), 1),
-                   update_kernel="ppo_train_rows_kernel (two workgroups per network: 6 CUs)", rollout_kernel="rollout_wide_kernel",
-                   update_tflops=round(tf, 4), update_frac_of_6cu_fp32_mfma_peak=round(tf / (F32_MFMA_PEAK_TFLOPS * 6 / 256), 4))
+                   update_kernel=ANT_UPDATE_KERNEL, rollout_kernel="rollout_wide_kernel",
+                   update_tflops=round(tf, 4), update_frac_of_12cu_fp32_mfma_peak=round(tf / (F32_MFMA_PEAK_TFLOPS * 12 / 256), 4))
 
 
 CPG_WORKLOAD = ("AntWall -> AntBroken constraint transfer (cpg, BASELINE configs[4], README.md:78 flags): AntWallBroken-v0, frozen constraint net "
@@ -260,8 +264,8 @@ def configs2_leg(seed, steps=2, warmup=1):
                us_per_optimizer_step=round(u["us_per_optimizer_step"], 2), us_per_rollout_step=None if u["us_per_rollout_step"] is None else round(u["us_per_rollout_step"], 2),
                optimizer_steps_per_iteration=round(u["optimizer_steps"] / steps, 1), early_stop_fraction=round(1.0 - u["optimizer_steps"] / max(1, u["full_steps"]), 4),
                value_no_early_stop=round(no_early_stop(env_steps, dt, u), 1),
-               update_kernel="ppo_train_rows_kernel (two workgroups per network: 6 CUs)", rollout_kernel="rollout_wide_kernel",
-               update_tflops=round(tf, 4), update_frac_of_6cu_fp32_mfma_peak=round(tf / (F32_MFMA_PEAK_TFLOPS * 6 / 256), 4))
+               update_kernel=ANT_UPDATE_KERNEL, rollout_kernel="rollout_wide_kernel",
+               update_tflops=round(tf, 4), update_frac_of_12cu_fp32_mfma_peak=round(tf / (F32_MFMA_PEAK_TFLOPS * 12 / 256), 4))
     del st
     torch.cuda.empty_cache()
     return out

@@ -82,6 +82,13 @@
 #ifndef ICRL_HALVES_FLAGS_TOGETHER
 #define ICRL_HALVES_FLAGS_TOGETHER 1
 #endif
+// ICRL_HALVES_PARTNER_SUM (four parts, late round 6): the four-way sum written as (own + partner) + (the other pair) on this wave's registers and three
+//   straight-line fetches — part p's partner is p ^ 1, the other pair {p ^ 2, p ^ 3} — instead of add(fetch(0), fetch(1)) + add(fetch(2), fetch(3)) with a
+//   run-time "is it my own block" branch and a struct copy per fetch (~1 000 instructions in the exchange phase).  Float addition is commutative bit for
+//   bit, so every part still holds (q0 + q1) + (q2 + q3): results are bit-identical to the branchy form.
+#ifndef ICRL_HALVES_PARTNER_SUM
+#define ICRL_HALVES_PARTNER_SUM 1
+#endif
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -871,6 +878,40 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           asm volatile("" ::: "memory");
         };
 #endif
+#if ICRL_HALVES_PARTNER_SUM && !ICRL_HALVES_OWNER_ADAM && ICRL_HALVES_FLAGS_TOGETHER
+        {
+          (void)wait_flag;
+          const int xa = xrole + (half ^ 1) * HX_BLK + tid * 16, xb = xrole + (half ^ 2) * HX_BLK + tid * 16, xc = xrole + (half ^ 3) * HX_BLK + tid * 16;
+          const f32x4 a0 = raw_load(xa + 0 * THH * 16), b0 = raw_load(xb + 0 * THH * 16), c0 = raw_load(xc + 0 * THH * 16);
+          const f32x4 a1 = raw_load(xa + 1 * THH * 16), b1 = raw_load(xb + 1 * THH * 16), c1 = raw_load(xc + 1 * THH * 16);
+          const f32x4 a2 = raw_load(xa + 2 * THH * 16), b2 = raw_load(xb + 2 * THH * 16), c2 = raw_load(xc + 2 * THH * 16);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            gW1r[i] = (gW1r[i] + a0[i]) + (b0[i] + c0[i]);
+            gW2r[0][i] = (gW2r[0][i] + a1[i]) + (b1[i] + c1[i]);
+            gW2r[1][i] = (gW2r[1][i] + a2[i]) + (b2[i] + c2[i]);
+          }
+          if (lowk) {      // (wave-uniform)
+            const f32x4 a3 = raw_load(xa + 3 * THH * 16), b3 = raw_load(xb + 3 * THH * 16), c3 = raw_load(xc + 3 * THH * 16);
+            const f32x4 a4 = raw_load(xa + 4 * THH * 16), b4 = raw_load(xb + 4 * THH * 16), c4 = raw_load(xc + 4 * THH * 16);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              gWhr[i] = (gWhr[i] + a3[i]) + (b3[i] + c3[i]);
+              gsc[i] = (gsc[i] + a4[i]) + (b4[i] + c4[i]);
+            }
+            gb1r = gsc[0]; gb2r = gsc[1]; gex = gsc[2];
+          }
+          if (w == 7) {    // the book-keeping lane's wave: every lane fetches (lane 0's slots hold the sums; the other lanes' words are never written and stay zero)
+            const f32x4 a5 = raw_load(xa + 5 * THH * 16), b5 = raw_load(xb + 5 * THH * 16), c5 = raw_load(xc + 5 * THH * 16);
+            mb_s0 = (mb_s0 + a5[0]) + (b5[0] + c5[0]); mb_s1 = (mb_s1 + a5[1]) + (b5[1] + c5[1]);
+            mb_s2 = (mb_s2 + a5[2]) + (b5[2] + c5[2]); mb_s3 = (mb_s3 + a5[3]) + (b5[3] + c5[3]);
+            if (DISC) {
+              const f32x4 a6 = raw_load(xa + 6 * THH * 16), b6 = raw_load(xb + 6 * THH * 16), c6 = raw_load(xc + 6 * THH * 16);
+              mb_s4 = (mb_s4 + a6[0]) + (b6[0] + c6[0]);
+            }
+          }
+        }
+#else
         struct Part { f32x4 g0, g1, g2, g3, g4, b0, b1; };
         const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
         const Part own = {gW1r, gW2r[0], gW2r[1], gWhr, gsc, f32x4{mb_s0, mb_s1, mb_s2, mb_s3}, f32x4{mb_s4, 0.f, 0.f, 0.f}};
@@ -900,6 +941,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           gb1r = gsc[0]; gb2r = gsc[1]; gex = gsc[2];
           mb_s0 = t.b0[0]; mb_s1 = t.b0[1]; mb_s2 = t.b0[2]; mb_s3 = t.b0[3]; mb_s4 = t.b1[0];
         }
+#endif
       } else {
 #if ICRL_HALVES_POLL_ROLL
       unsigned pq0, pq1, pq2, pq3;

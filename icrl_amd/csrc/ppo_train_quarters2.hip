@@ -649,15 +649,16 @@ __device__ __forceinline__ void ppo_train_quarters2_body(const TrainArgs& a, con
 #pragma unroll
         for (int t = 0; t < 2; ++t) bh[c][t] = lds128(pb + c * 16 * STX + 16 * t);
       __builtin_amdgcn_sched_barrier(0);
+      // two output tiles at a time: their MFMA chains (8 dependent steps each) interleave
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < 4; c += 2) {
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = MFMA_F32(az[t][e], bh[c][t][e], acc);
-        gW2r[c] = acc;
-        if (c > 0) publish4(NT1 + c - 1, gW2r[c - 1]);
+          for (int e = 0; e < 4; ++e) { acc0 = MFMA_F32(az[t][e], bh[c][t][e], acc0); acc1 = MFMA_F32(az[t][e], bh[c + 1][t][e], acc1); }
+        gW2r[c] = acc0; gW2r[c + 1] = acc1;
+        if (c > 0) { publish4(NT1 + c - 2, gW2r[c - 2]); publish4(NT1 + c - 1, gW2r[c - 1]); }
       }
       const float s = ((az[0][0] + az[0][1]) + (az[0][2] + az[0][3])) + ((az[1][0] + az[1][1]) + (az[1][2] + az[1][3]));     // d b2[16 w + r]
       gb2r = quad_rows_sum(s);
@@ -671,7 +672,7 @@ __device__ __forceinline__ void ppo_train_quarters2_body(const TrainArgs& a, con
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc[t] = MFMA_F32(ao[t][e], bh[t][e], acc[t]);
-      publish4(NT1 + 3, gW2r[3]);
+      publish4(NT1 + 2, gW2r[2]); publish4(NT1 + 3, gW2r[3]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) gWhr[i] = acc[0][i] + acc[1][i];
       float s = ((ao[0][0] + ao[0][1]) + (ao[0][2] + ao[0][3])) + ((ao[1][0] + ao[1][1]) + (ao[1][2] + ao[1][3]));      // head bias (wave 0 keeps it)
@@ -690,19 +691,20 @@ __device__ __forceinline__ void ppo_train_quarters2_body(const TrainArgs& a, con
 #pragma unroll
         for (int t = 0; t < 2; ++t) bx[c][t] = lds128(pb + c * 16 * STX + 16 * t);
       __builtin_amdgcn_sched_barrier(0);
+      static_assert(NT1 % 2 == 0, "observation tiles are walked in pairs");
 #pragma unroll
-      for (int c = 0; c < NT1; ++c) {
-        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < NT1; c += 2) {
+        f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc = MFMA_F32(az[t][e], bx[c][t][e], acc);
-        gW1r[c] = acc;
-        if (c == 0) publish4(NT1 + 4, gWhr); else publish4(c - 1, gW1r[c - 1]);
+          for (int e = 0; e < 4; ++e) { acc0 = MFMA_F32(az[t][e], bx[c][t][e], acc0); acc1 = MFMA_F32(az[t][e], bx[c + 1][t][e], acc1); }
+        gW1r[c] = acc0; gW1r[c + 1] = acc1;
+        if (c == 0) publish4(NT1 + 4, gWhr); else { publish4(c - 2, gW1r[c - 2]); publish4(c - 1, gW1r[c - 1]); }
       }
       const float s = ((az[0][0] + az[0][1]) + (az[0][2] + az[0][3])) + ((az[1][0] + az[1][1]) + (az[1][2] + az[1][3]));
       gb1r = quad_rows_sum(s);
-      publish4(NT1 - 1, gW1r[NT1 - 1]);
+      publish4(NT1 - 2, gW1r[NT1 - 2]); publish4(NT1 - 1, gW1r[NT1 - 1]);
     }
     if (book) {
       const float* pst = sm + o_msc + (S::PST - S::MISC);

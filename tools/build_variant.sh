@@ -15,6 +15,6 @@ for f in ppo_train_pairs ppo_train_rows ppo_train_halves; do
 done
 wait
 objs=""
-for f in cn_train errors fine gae generic ppo_train rollout; do objs="$objs ../lib/obj/$f.o"; done
+for f in cn_train errors fine gae generic ppo_train ppo_train_quarters ppo_train_quarters2 rollout; do objs="$objs ../lib/obj/$f.o"; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/var/libicrl_$name.so $objs ../lib/var/ppo_train_pairs_$name.o ../lib/var/ppo_train_rows_$name.o ../lib/var/ppo_train_halves_$name.o
 echo built icrl_amd/lib/var/libicrl_$name.so
