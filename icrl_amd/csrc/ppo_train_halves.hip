@@ -859,7 +859,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
             const unsigned fa = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + ka * HX_BLK, 0, 16);
             const unsigned fb = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + kb * HX_BLK, 0, 16);
             const unsigned fc = __builtin_amdgcn_raw_buffer_load_b32(grs, fo + kc * HX_BLK, 0, 16);
-            if (fa == step && fb == step && fc == step) break;
+            if (((fa ^ step) | (fb ^ step) | (fc ^ step)) == 0u) break;      // (no short-circuit: `fa == step && ...` lets the compiler sink the second and third look behind the first compare)
             if (++spins >= (1 << 22)) { timed_out = true; break; }
             __builtin_amdgcn_s_sleep(1);
           }

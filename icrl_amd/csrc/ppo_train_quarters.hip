@@ -703,7 +703,7 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
           const unsigned fa = __builtin_amdgcn_raw_buffer_load_b32(grs, xa + fo, 0, 16);
           const unsigned fb = __builtin_amdgcn_raw_buffer_load_b32(grs, xb + fo, 0, 16);
           const unsigned fc = __builtin_amdgcn_raw_buffer_load_b32(grs, xc + fo, 0, 16);
-          if (fa == step && fb == step && fc == step) break;
+          if (((fa ^ step) | (fb ^ step) | (fc ^ step)) == 0u) break;      // (no short-circuit: `fa == step && ...` lets the compiler sink the second and third look behind the first compare)
           if (++spins >= (1 << 22)) { timed_out = true; break; }
           __builtin_amdgcn_s_sleep(1);
         }
