@@ -89,6 +89,12 @@
 #ifndef ICRL_HALVES_PARTNER_SUM
 #define ICRL_HALVES_PARTNER_SUM 1
 #endif
+// ICRL_HALVES_FENCES (late round 6): every LDS operand fetch of a GEMM is issued before its first MFMA (a scheduling fence between the fetches and the
+//   MFMA stream): left to itself the compiler fetches one k step, waits for it and issues its MFMA — the full LDS latency in front of each step
+#ifndef ICRL_HALVES_FENCES
+#define ICRL_HALVES_FENCES 1
+#endif
+#define HFENCE() do { if (ICRL_HALVES_FENCES) __builtin_amdgcn_sched_barrier(0); } while (0)
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -496,6 +502,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           if (!(TAILQ && js >= JT)) aw[js] = lds128(pa + 16 * js);
         const float at = TAILQ ? sm[S::W1 + (16 * fq + r) * SX + 16 * JT + q] : 0.f;
         f32x4 z = lds128(sm + S::B1 + 16 * fq + 4 * q);      // the bias is the accumulator's initial value
+        HFENCE();
 #pragma unroll
         for (int js = 0; js < NT1; ++js)
 #pragma unroll
@@ -532,6 +539,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         const float* ph1 = sm + S::H1R + b * SRM + 4 * q;
 #pragma unroll
         for (int d = 1; d < 4; ++d) hp[d - 1] = lds128(ph1 + 16 * ((fq + d) & 3));
+        HFENCE();
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -690,6 +698,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         const float* pz = sm + S::DZ2R + b * SRM + 4 * q;
 #pragma unroll
         for (int d = 1; d < 4; ++d) dp[d - 1] = lds128(pz + 16 * ((fq + d) & 3));
+        HFENCE();
 #pragma unroll
         for (int d = 0; d < 3; ++d)
 #pragma unroll
@@ -713,16 +722,20 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         const float* pa = sm + S::DZ2T + (16 * jt + r) * STH + 4 * q;
 #pragma unroll
         for (int js = 0; js < NJS; ++js) az[js] = lds128(pa + 16 * js);
+        f32x4 bh[2][2];
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
           const float* pb = sm + S::H1T + (16 * (2 * kh + cc) + r) * STH + 4 * q;
-          f32x4 bh[2];
 #pragma unroll
-          for (int js = 0; js < NJS; ++js) bh[js] = lds128(pb + 16 * js);
+          for (int js = 0; js < NJS; ++js) bh[cc][js] = lds128(pb + 16 * js);
+        }
+        HFENCE();
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
 #pragma unroll
           for (int js = 0; js < NJS; ++js)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) gW2r[cc] = MFMA_F32(az[js][e], bh[js][e], gW2r[cc]);
+            for (int e = 0; e < 4; ++e) gW2r[cc] = MFMA_F32(az[js][e], bh[cc][js][e], gW2r[cc]);
         }
         if (lowk) {
           const float s = ((az[0][0] + az[0][1]) + (az[0][2] + az[0][3])) + ((az[1][0] + az[1][1]) + (az[1][2] + az[1][3]));     // d b2[16 jt + r]
@@ -738,6 +751,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         f32x4 bx[2];
 #pragma unroll
         for (int js = 0; js < NJS; ++js) bx[js] = lds128(pb + 16 * js);
+        HFENCE();
 #pragma unroll
         for (int js = 0; js < NJS; ++js)
 #pragma unroll
@@ -760,6 +774,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         const float* pb = sm + S::H2T + (16 * jt + r) * STH + 4 * q;
 #pragma unroll
         for (int js = 0; js < NJS; ++js) { ao[js] = lds128(pa + 16 * js); bh[js] = lds128(pb + 16 * js); }
+        HFENCE();
         f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int js = 0; js < NJS; ++js)
