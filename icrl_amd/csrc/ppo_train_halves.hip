@@ -95,6 +95,17 @@
 #define ICRL_HALVES_FENCES 1
 #endif
 #define HFENCE() do { if (ICRL_HALVES_FENCES) __builtin_amdgcn_sched_barrier(0); } while (0)
+// ICRL_HALVES_LOSS_PRELOAD (late round 6): the loss tail's per-row operands (actions, old log-prob / value, advantages / return, the Gaussian head's
+//   constants) and the A operand of dH2 are fetched from LDS BEFORE the head hand-off (P3) instead of behind it: their latency runs under the wait
+#ifndef ICRL_HALVES_LOSS_PRELOAD
+#define ICRL_HALVES_LOSS_PRELOAD 1
+#endif
+// ICRL_HALVES_ADAM_PRELOAD (late round 6): a wave's own master weights (the LDS operand copies it updates) are fetched BEFORE the norm barrier (S6) instead
+//   of at the top of Adam: nobody writes them between the two points, and their latency runs under the wait for the other networks' norm granules.
+//   Measured SLOWER (6.09 against 5.98 us per step, three alternating rounds): off.  ICRL_HALVES_LOSS_PRELOAD: 6.00 -> 5.98, on.
+#ifndef ICRL_HALVES_ADAM_PRELOAD
+#define ICRL_HALVES_ADAM_PRELOAD 0
+#endif
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -523,6 +534,8 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         issue_rows(idx_now);
       }
       f32x4 dout = f32x4{0.f, 0.f, 0.f, 0.f};
+      float pl_olp = 0.f, pl_adr = 0.f, pl_adc = 0.f;      // (ICRL_HALVES_LOSS_PRELOAD)
+      f32x4 pl_act = dout, pl_iv = dout, pl_hiv = dout, pl_lsd = dout, pl_wht = dout;
       if (fwd_wave) {      // ---- the rest of forward, the loss tail and the activation backward: the waves of the row tiles (NQ == 4: waves 0..3)
       quad_signal();               // (P1) this wave's features of h1 are complete
       {  // layer 2: own quarter of K from registers, the other three from the row-major image
@@ -556,6 +569,14 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         for (int e = 0; e < 4; ++e) acc = MFMA_F32(aw[e], h2c[e], acc);
         float* const hpx = sm + S::HPX + (rt2 * 4 * 64 + lane) * 4;
         *reinterpret_cast<f32x4*>(hpx + fq * 256) = acc;
+        if (ICRL_HALVES_LOSS_PRELOAD) {
+          pl_olp = sm[S::OLP + b]; pl_adr = sm[S::ADR + b]; pl_adc = sm[S::ADC + b];
+          if (role == 0 && !DISC) {
+            pl_act = lds128(sm + S::ACT + b * SAH + 4 * q);
+            pl_iv = lds128(sm + S::GAU + 4 * q); pl_hiv = lds128(sm + S::GAU + 16 + 4 * q); pl_lsd = lds128(sm + S::GAU + 32 + 4 * q);
+          }
+          pl_wht = lds128(sm + S::WHT + (16 * fq + r) * SAH + 4 * q);
+        }
         quad_signal(); quad_wait();  // (P3) all four partial tiles stored
         const f32x4 p0 = lds128(hpx), p1 = lds128(hpx + 256), p2 = lds128(hpx + 512), p3 = lds128(hpx + 768);
 #pragma unroll
@@ -598,8 +619,9 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
               g2[i] = k < A ? pr[i] * (lg[i] + ent) : 0.f;
             }
           } else {
-            const f32x4 actv = lds128(sm + S::ACT + b * SAH + 4 * q);
-            const f32x4 iv = lds128(sm + S::GAU + 4 * q), hiv = lds128(sm + S::GAU + 16 + 4 * q), lsd = lds128(sm + S::GAU + 32 + 4 * q);
+            const f32x4 actv = ICRL_HALVES_LOSS_PRELOAD ? pl_act : lds128(sm + S::ACT + b * SAH + 4 * q);
+            const f32x4 iv = ICRL_HALVES_LOSS_PRELOAD ? pl_iv : lds128(sm + S::GAU + 4 * q), hiv = ICRL_HALVES_LOSS_PRELOAD ? pl_hiv : lds128(sm + S::GAU + 16 + 4 * q),
+                        lsd = ICRL_HALVES_LOSS_PRELOAD ? pl_lsd : lds128(sm + S::GAU + 32 + 4 * q);
             auto elem = [&](int i) {
               const float dd = actv[i] - outc[i];
               lp += -(dd * dd) * hiv[i] - lsd[i];
@@ -610,10 +632,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
             if (ngp > 1) { elem(1); if (ngp > 2) { elem(2); elem(3); } }
             lp = quad_rows_sum(lp);
           }
-          const float old_lp = sm[S::OLP + b];
+          const float old_lp = ICRL_HALVES_LOSS_PRELOAD ? pl_olp : sm[S::OLP + b];
           const float ratio = __expf(lp - old_lp);
-          const float Ar = (sm[S::ADR + b] - c_mean_r) * c_istd_r;
-          const float Ac = sm[S::ADC + b] - c_mean_c;
+          const float Ar = ((ICRL_HALVES_LOSS_PRELOAD ? pl_adr : sm[S::ADR + b]) - c_mean_r) * c_istd_r;
+          const float Ac = (ICRL_HALVES_LOSS_PRELOAD ? pl_adc : sm[S::ADC + b]) - c_mean_c;
           const float s1 = Ar * ratio;
           const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
           const float s2 = Ar * rc;
@@ -635,10 +657,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           v3 = cnt ? old_lp - lp : 0.f; v4 = cnt ? ent : 0.f;
         } else {
           const float v = quad_rows_sum(q == 0 ? outc[0] : 0.f);
-          const float R = sm[S::ADR + b];
+          const float R = ICRL_HALVES_LOSS_PRELOAD ? pl_adr : sm[S::ADR + b];
           float vp = v, pass = 1.f;
           if (vclip >= 0.f) {
-            const float old = sm[S::OLP + b];
+            const float old = ICRL_HALVES_LOSS_PRELOAD ? pl_olp : sm[S::OLP + b];
             const float dv = v - old;
             vp = old + fminf(fmaxf(dv, -vclip), vclip);
             pass = (dv >= -vclip && dv <= vclip) ? 1.f : 0.f;
@@ -667,7 +689,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       f32x4 dz2c, dz1c;
       {  // dH2^T = Wh^T . dOut^T for the own feature tile: A = WHT[j = 16 fq + r][position 4 q + e]; MFMA e covers the outputs 4 e .. 4 e + 3
         const int ng = (n_out + 3) >> 2;
-        const f32x4 aw = lds128(sm + S::WHT + (16 * fq + r) * SAH + 4 * q);
+        const f32x4 aw = ICRL_HALVES_LOSS_PRELOAD ? pl_wht : lds128(sm + S::WHT + (16 * fq + r) * SAH + 4 * q);
         f32x4 acc = MFMA_F32(aw[0], dout[0], (f32x4{0.f, 0.f, 0.f, 0.f}));
         if (ng > 1) {
           acc = MFMA_F32(aw[1], dout[1], acc);
@@ -1101,6 +1123,12 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       }
     }
     STAMP(4)   // exchange + gradient norm + publish
+    constexpr bool APRE = ICRL_HALVES_ADAM_PRELOAD && !OWNER;
+    f32x4 ap_w1 = f32x4{0.f, 0.f, 0.f, 0.f}, ap_w2a = ap_w1, ap_w2b = ap_w1, ap_wh = ap_w1, ap_b = ap_w1;
+    if (APRE) {
+      ap_w1 = load_own_w1(); ap_w2a = load_own_w2(0); ap_w2b = load_own_w2(1);
+      if (lowk) { ap_wh = load_own_wh(); ap_b = f32x4{sm[S::B1 + jb], sm[S::B2 + jb], sm[ex_s], 0.f}; }
+    }
     // ---- while the granules travel: stage the next minibatch (rows -> the other X^T buffer, advantage statistics)
     const int xnext = xcur == S::XT0 ? S::XT1 : S::XT0;
     const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK;
@@ -1220,9 +1248,9 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           refresh_gauss();
         }
       } else {
-      { f32x4 p_ = load_own_w1(); adam4(gW1r, mW1, vW1, p_); store_w1(p_); }
+      { f32x4 p_ = APRE ? ap_w1 : load_own_w1(); adam4(gW1r, mW1, vW1, p_); store_w1(p_); }
       if (lowk) {
-        f32x4 g_ = f32x4{gb1r, gb2r, ex_g >= 0 ? gex : 0.f, 0.f}, p_ = f32x4{sm[S::B1 + jb], sm[S::B2 + jb], sm[ex_s], 0.f};
+        f32x4 g_ = f32x4{gb1r, gb2r, ex_g >= 0 ? gex : 0.f, 0.f}, p_ = APRE ? ap_b : f32x4{sm[S::B1 + jb], sm[S::B2 + jb], sm[ex_s], 0.f};
         f32x4 m_ = f32x4{mb1, mb2, mex, 0.f}, v_ = f32x4{vb1, vb2, vex, 0.f};
         // identical arithmetic in the four q lanes, lane q == 0 stores; the third element exists on the head-bias / log_std waves only
         const bool has_ex = w == W_BH || (!DISC && role == 0 && w == W_LS);
@@ -1233,10 +1261,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         if (q == 0) { sm[S::B1 + jb] = p_[0]; sm[S::B2 + jb] = p_[1]; sm[ex_s] = p_[2]; }
       }
 #pragma unroll
-      for (int cc = 0; cc < 2; ++cc) { f32x4 p_ = load_own_w2(cc); adam4(gW2r[cc], mW2[cc], vW2[cc], p_); store_w2(cc, p_); }
+      for (int cc = 0; cc < 2; ++cc) { f32x4 p_ = APRE ? (cc == 0 ? ap_w2a : ap_w2b) : load_own_w2(cc); adam4(gW2r[cc], mW2[cc], vW2[cc], p_); store_w2(cc, p_); }
       if (lowk) {
         {   // head weights: element i of a lane is output 4 i + q — only the k groups that hold an output can hold a parameter
-          f32x4 p_ = load_own_wh();
+          f32x4 p_ = APRE ? ap_wh : load_own_wh();
           const int ngw = (n_out + 3) >> 2;
           if (!ICRL_HALVES_ADAM_TRIM || ngw > 2) adam4(gWhr, mWh, vWh, p_);
           else if (ngw == 2) adamn(std::integral_constant<int, 2>{}, gWhr, mWh, vWh, p_);
