@@ -106,6 +106,21 @@
 #ifndef ICRL_HALVES_ADAM_PRELOAD
 #define ICRL_HALVES_ADAM_PRELOAD 0
 #endif
+// ICRL_HALVES_LATE_PREFETCH (late round 6): a forward wave issues the next chunk's row loads (index pipeline + ~60 instructions of address arithmetic) BEHIND
+//   its h1 hand-off (P1) and layer 2's operand fetches, under their latency, instead of in front of the hand-off the other three waves wait for
+//   — measured 6.23 against 5.97 us per step: the gathered rows are what the exchange's `s_waitcnt vmcnt(0)` (store acknowledgement in front of the flag)
+//   ends up waiting for, ~2.8 us after their issue; every cycle they start later is a cycle on the step.  Off.
+#ifndef ICRL_HALVES_LATE_PREFETCH
+#define ICRL_HALVES_LATE_PREFETCH 0
+#endif
+// ICRL_HALVES_PREFETCH_AT_ADAM (late round 6): the rows of the NEXT step's first chunk are requested at the top of Adam (right behind the norm barrier, when
+//   the previous rows have been committed and no poll is in flight whose in-order return they could delay) and ONE STEP EARLIER — the rows a step's hop
+//   stages were requested at the top of the previous step's Adam, ~5 us before the store drain in front of that hop has to wait for them, instead of
+//   behind layer 1 of the same step, ~2.8 us before.  Minibatches of one chunk only (batch_size <= 64: HCWithPos, LapGridWorld; one register set).
+//   Measured SLOWER as well (6.03 against 5.94 us per step, three alternating rounds; bit-identical results): the drain does not wait for the rows. Off.
+#ifndef ICRL_HALVES_PREFETCH_AT_ADAM
+#define ICRL_HALVES_PREFETCH_AT_ADAM 0
+#endif
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -446,6 +461,14 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   __syncthreads();
   read_stats(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
   const float inv_n_mb = 1.f / (float)((T * N + a.hp.batch_size - 1) / a.hp.batch_size);
+  const bool deep_pf = ICRL_HALVES_PREFETCH_AT_ADAM && a.hp.batch_size <= RB;      // one chunk per step: the row stream runs one step deeper
+  if (deep_pf) {      // step 1's rows are in flight while step 0 runs (its hop commits them)
+    const int idx_now = idx_next;
+    idx_next = idx_nx2;
+    idx_nx2 = chunk_idx(pc_nx3);
+    pc_nx3 = ld_chunk(4);
+    issue_rows(idx_now);
+  }
 
   const int b = 16 * rt2 + r;           // this lane's row of the half-chunk (all four q lanes share it)
   float* const pt = sm + (4 * q) * STH + b;     // + image + (16 t + i) STH: element [feature 16 t + 4 q + i][row b]
@@ -526,13 +549,15 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         for (int i = 0; i < 4; ++i) pt[S::H1T + (16 * fq + i) * STH] = h1c[i];
         *reinterpret_cast<f32x4*>(sm + S::H1R + b * SRM + 16 * fq + 4 * q) = h1c;
       }
-      {  // prefetch the next chunk's rows (random pieces of the rollout buffer: several microseconds away)
+      auto prefetch_next = [&]() {  // the next chunk's rows (random pieces of the rollout buffer: several microseconds away)
         const int idx_now = idx_next;
         idx_next = idx_nx2;
         idx_nx2 = chunk_idx(pc_nx3);
         pc_nx3 = ld_chunk(g_chunk + 4);
         issue_rows(idx_now);
-      }
+      };
+      const bool pf_here = !deep_pf;      // (deep_pf: at the top of Adam)
+      if (pf_here && (!ICRL_HALVES_LATE_PREFETCH || !fwd_wave)) prefetch_next();
       f32x4 dout = f32x4{0.f, 0.f, 0.f, 0.f};
       float pl_olp = 0.f, pl_adr = 0.f, pl_adc = 0.f;      // (ICRL_HALVES_LOSS_PRELOAD)
       f32x4 pl_act = dout, pl_iv = dout, pl_hiv = dout, pl_lsd = dout, pl_wht = dout;
@@ -545,6 +570,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
 #pragma unroll
         for (int d = 1; d < 4; ++d) awp[d - 1] = lds128(pa + 16 * ((fq + d) & 3));
         f32x4 z = lds128(sm + S::B2 + 16 * fq + 4 * q);
+        if (ICRL_HALVES_LATE_PREFETCH && pf_here) { HFENCE(); prefetch_next(); HFENCE(); }
 #pragma unroll
         for (int e = 0; e < 4; ++e) z = MFMA_F32(awo[e], h1c[e], z);
         quad_wait();               // the other three waves' features of h1 are complete
@@ -1168,6 +1194,13 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     }
     lds_barrier();   // (S6) norm partials, next minibatch and its statistics visible
     STAMP(5)   // staging + granule wait
+    if (deep_pf) {      // the rows of step st + 2 (g_chunk = st + 1 here; this step's hop has just committed those of st + 1)
+      const int idx_now = idx_next;
+      idx_next = idx_nx2;
+      idx_nx2 = chunk_idx(pc_nx3);
+      pc_nx3 = ld_chunk(g_chunk + 4);
+      issue_rows(idx_now);
+    }
     float total = 0.f;
     {
 #pragma unroll
