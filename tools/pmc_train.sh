@@ -1,13 +1,13 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun): SQ counters of the PPO-Lagrangian update kernels, three passes of <= 8 SQ counters each.
 #   bash tools/pmc_train.sh <tag>            HC shapes: the wave-quad kernel with two workgroups per network (48 waves on 6 CUs) and with four (the default: 96 waves on 12 CUs)
-#   bash tools/pmc_train.sh <tag> ant        AntWall shapes, batch 128: one workgroup per network (rows1) and two (default)
+#   bash tools/pmc_train.sh <tag> ant        AntWall shapes, batch 128: the row-owning kernel with two workgroups per network (rows: rounds 3-5's default) and four workgroups per network, both chunks in one pass (round 6's default)
 # Outputs under gpurun_out/pmc_train_<tag>[_antwall]_{a,b}; summarised by tools/summarize_pmc_train.py <tag> [ant].
 tag=$1
 kind=${2:-hc}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 sfx=""; variants="halves,auto"
-if [ "$kind" = "ant" ]; then sfx="_antwall"; variants="rows1,auto"; fi
+if [ "$kind" = "ant" ]; then sfx="_antwall"; variants="rows,auto"; fi
 cd /tmp && export TMPDIR=/tmp
 export KIND=$kind VARIANTS=$variants EPOCHS=2
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/gpurun_out/pmc_train_${tag}${sfx}_a -- python3 $R/tools/train_only.py > $R/gpurun_out/pmc_train_${tag}${sfx}_a.log 2>&1

@@ -66,8 +66,8 @@ shape = "HCWithPos shapes, batch 64" if kind == "hc" else "AntWall shapes (obs 1
 lines = [f"# SQ counters of the PPO-Lagrangian update kernels ({tag}) — {shape}, per WAVE and optimiser step",
          "", "command: `bash tools/pmc_train.sh <tag>` on the GPU box = two `rocprofv3 --pmc <8 SQ counters> --kernel-trace` passes over "
          "`tools/train_only.py` (HC, round 6: VARIANTS=halves,auto = the wave-quad kernel with TWO workgroups per network, `<2, false, 18, 2>`: 48 waves on 6 CUs, "
-         "and with FOUR, `<2, false, 18, 4>`, the default: 96 waves on 12 CUs, 4096 optimiser steps per launch; until round 5 the columns were the wave-pair and the two-workgroup kernel; KIND=ant: VARIANTS=rows1,auto = one workgroup per network walking both chunks, 12 waves, and "
-         "the default two workgroups per network, 24 waves, 512 steps per launch); raw csv: gpurun_out/pmc_train_<tag>_{a,b} (scratch).  Values "
+         "and with FOUR, `<2, false, 18, 4>`, the default: 96 waves on 12 CUs, 4096 optimiser steps per launch; until round 5 the columns were the wave-pair and the two-workgroup kernel; KIND=ant, round 6: VARIANTS=rows,auto = the row-owning kernel with two workgroups per network, 24 waves on 6 CUs, and "
+         "the default `ppo_train_quarters2_kernel`: four workgroups per network, 48 waves on 12 CUs, 512 steps per launch; until round 5 the columns were one and two workgroups per network); raw csv: gpurun_out/pmc_train_<tag>_{a,b} (scratch).  Values "
          f"below = median over the FULL launches ({STEPS} optimiser steps; the short sync-placement calibration launches every process makes are dropped by duration) "
          f"/ waves of the kernel / {STEPS}; cycle-type counters converted from quad-cycles to shader cycles.", ""]
 names = sorted(agg)
@@ -92,10 +92,11 @@ for c in cols:
         row.append(f"{med:,.0f}")
     lines.append(f"| {c}{' (cycles)' if c in QUAD else ''} | " + " | ".join(row) + " |")
 if kind != "hc":
-    lines += ["", "`ppo_train_rows_kernel<8, false, true>` = the default at batch 128: TWO workgroups per network (24 waves on 6 CUs), each computes one 64-row "
-              "chunk of a minibatch and the partial gradients are exchanged as granules; `<8, false, false>` = one workgroup per network walking both "
-              "chunks (hp._pad & 8).  Per wave and step the split kernel issues about half the MFMAs (1 936 / 4 = 484 vs the single workgroup's) and "
-              "spends the difference parked (SQ_WAIT_ANY) in the gradient exchange."]
+    lines += ["", "`ppo_train_rows_kernel<8, false, true>` = rounds 3-5's default at batch 128 (`train_kernel = \"rows\"`): TWO workgroups per network (24 waves on 6 CUs), "
+              "each wave carries 16 rows of one 64-row chunk through all features; `ppo_train_quarters2_kernel<8, false, 113>` = round 6's default: FOUR workgroups per "
+              "network (48 waves on 12 CUs), part p takes rows 16 p .. of both chunks as two row tiles per wave of a wave quad, K = 32 weight-gradient GEMMs, "
+              "the four partial gradients summed as (own + partner) + (the other pair) by all four.  Per wave and step a quarter of the MFMAs of one "
+              "workgroup per network; the loss tail and Adam are replicated (VALU per wave does not drop), the exchange pulls three peers' blocks."]
     open(os.path.join(ROOT, "profiles", f"{tag}_train_pmc{suffix}.md"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines))
     raise SystemExit(0)
