@@ -24,11 +24,27 @@
 #define ICRL_QW2_DEP 4
 #endif
 
+// the Adam moments as plain values (the register allocator places them) instead of pinned to accumulation registers with explicit moves
+// (ppo_train_rows.hip's scheme): the step loop loses ~150 instructions net — 12.30 -> 12.07 us per step (two alternating rounds), no scratch traffic in the loop
+#ifndef ICRL_QW2_MOMENTS_PLAIN
+#define ICRL_QW2_MOMENTS_PLAIN 1
+#endif
+// the loss tail's per-row operands and dH2's A operand fetched from LDS before the head hand-off (P3) instead of behind it (ppo_train_halves.hip:
+// 6.00 -> 5.98 us there); here 12.30 vs 12.31 — nothing; off
+#ifndef ICRL_QW2_LOSS_PRELOAD
+#define ICRL_QW2_LOSS_PRELOAD 0
+#endif
 #ifndef ICRL_QW_STATIC_LDS
 #define ICRL_QW_STATIC_LDS 0
 #endif
 
 namespace icrl {
+
+#if ICRL_QW2_MOMENTS_PLAIN
+#define acc_put(slot, v) ((slot) = (v))
+#define acc_set(slot, v) ((slot) = (v))
+#define acc_get(slot) (slot)
+#endif
 
 constexpr int THQ2 = 256;  // 4 waves, one per SIMD
 constexpr int STX = 36;    // row stride of the [feature][row] images (32 rows + 4: conflict-free ds_read_b128 and column stores)
@@ -399,6 +415,9 @@ __device__ __forceinline__ void ppo_train_quarters2_body(const TrainArgs& a, con
 
     // ================= forward: feature tile w of every layer, both row tiles =================
     f32x4 h1c[2], h2c[2], outc[2];
+    float pl_olp[2] = {0.f, 0.f}, pl_adr[2] = {0.f, 0.f}, pl_adc[2] = {0.f, 0.f};      // (ICRL_QW2_LOSS_PRELOAD)
+    f32x4 pl_act[2], pl_iv, pl_hiv, pl_lsd, pl_wht;
+    pl_act[0] = pl_act[1] = pl_iv = pl_hiv = pl_lsd = pl_wht = f32x4{0.f, 0.f, 0.f, 0.f};
     {  // layer 1: the weight operands once, two independent MFMA chains
       const float* pa = sm + o_w1a;
       f32x4 aw[NT1];
@@ -483,6 +502,15 @@ __device__ __forceinline__ void ppo_train_quarters2_body(const TrainArgs& a, con
       float* const hpx = sm + o_hpx;
       *reinterpret_cast<f32x4*>(hpx + w * 256) = acc[0];
       *reinterpret_cast<f32x4*>(hpx + 1024 + w * 256) = acc[1];
+      if (ICRL_QW2_LOSS_PRELOAD) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          pl_olp[t] = sm[o_sid + 16 * t]; pl_adr[t] = sm[o_sid + 32 + 16 * t]; pl_adc[t] = sm[o_sid + 64 + 16 * t];
+          if (role == 0 && !DISC) pl_act[t] = lds128(sm + o_act + 16 * t * SAX);
+        }
+        if (role == 0 && !DISC) { pl_iv = lds128(sm + o_gau); pl_hiv = lds128(sm + o_gau + 16); pl_lsd = lds128(sm + o_gau + 32); }
+        pl_wht = lds128(sm + o_wht);
+      }
       quad_signal(); quad_wait();  // (P3) all four partial tiles of both row tiles stored
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -531,8 +559,9 @@ __device__ __forceinline__ void ppo_train_quarters2_body(const TrainArgs& a, con
             g2[i] = k < A ? pr[i] * (lg[i] + ent) : 0.f;     // d(-H)/dz_k = p_k (log p_k + H)
           }
         } else {
-          const f32x4 actv = lds128(sm + o_act + 16 * t * SAX);
-          const f32x4 iv = lds128(sm + o_gau), hiv = lds128(sm + o_gau + 16), lsd = lds128(sm + o_gau + 32);
+          const f32x4 actv = ICRL_QW2_LOSS_PRELOAD ? pl_act[t] : lds128(sm + o_act + 16 * t * SAX);
+          const f32x4 iv = ICRL_QW2_LOSS_PRELOAD ? pl_iv : lds128(sm + o_gau), hiv = ICRL_QW2_LOSS_PRELOAD ? pl_hiv : lds128(sm + o_gau + 16),
+                      lsd = ICRL_QW2_LOSS_PRELOAD ? pl_lsd : lds128(sm + o_gau + 32);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const float dd = actv[i] - outc[t][i];                 // pad actions / outputs are 0
@@ -542,10 +571,10 @@ __device__ __forceinline__ void ppo_train_quarters2_body(const TrainArgs& a, con
           }
           lp = quad_rows_sum(lp);
         }
-        const float old_lp = sm[o_sid + 16 * t];
+        const float old_lp = ICRL_QW2_LOSS_PRELOAD ? pl_olp[t] : sm[o_sid + 16 * t];
         const float ratio = __expf(lp - old_lp);
-        const float Ar = (sm[o_sid + 32 + 16 * t] - c_mean_r) * c_istd_r;
-        const float Ac = sm[o_sid + 64 + 16 * t] - c_mean_c;
+        const float Ar = ((ICRL_QW2_LOSS_PRELOAD ? pl_adr[t] : sm[o_sid + 32 + 16 * t]) - c_mean_r) * c_istd_r;
+        const float Ac = (ICRL_QW2_LOSS_PRELOAD ? pl_adc[t] : sm[o_sid + 64 + 16 * t]) - c_mean_c;
         const float s1 = Ar * ratio;
         const float rc = fminf(fmaxf(ratio, 1.f - clip), 1.f + clip);
         const float s2 = Ar * rc;
@@ -566,10 +595,10 @@ __device__ __forceinline__ void ppo_train_quarters2_body(const TrainArgs& a, con
         v3 = cnt ? old_lp - lp : 0.f; v4 = cnt ? ent : 0.f;
       } else {
         const float v = quad_rows_sum(q == 0 ? outc[t][0] : 0.f);      // lane (r, q = 0) holds output 0 of row b
-        const float R = sm[o_sid + 32 + 16 * t];
+        const float R = ICRL_QW2_LOSS_PRELOAD ? pl_adr[t] : sm[o_sid + 32 + 16 * t];
         float vp = v, pass = 1.f;
         if (vclip >= 0.f) {
-          const float old = sm[o_sid + 16 * t];
+          const float old = ICRL_QW2_LOSS_PRELOAD ? pl_olp[t] : sm[o_sid + 16 * t];
           const float dv = v - old;
           vp = old + fminf(fmaxf(dv, -vclip), vclip);
           pass = (dv >= -vclip && dv <= vclip) ? 1.f : 0.f;
@@ -589,7 +618,7 @@ __device__ __forceinline__ void ppo_train_quarters2_body(const TrainArgs& a, con
     // ================= backward of the activations =================
     f32x4 dz2c[2], dz1c[2];
     {  // dH2^T = Wh^T . dOut^T for the own feature tile: A = WHT[j = 16 w + r][o = 4 q + e] (K = 16 outputs)
-      const f32x4 aw = lds128(sm + o_wht);
+      const f32x4 aw = ICRL_QW2_LOSS_PRELOAD ? pl_wht : lds128(sm + o_wht);
       f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int e = 0; e < 4; ++e) { acc[0] = MFMA_F32(aw[e], dout[0][e], acc[0]); acc[1] = MFMA_F32(aw[e], dout[1][e], acc[1]); }
