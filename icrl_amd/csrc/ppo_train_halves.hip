@@ -121,6 +121,11 @@
 #ifndef ICRL_HALVES_PREFETCH_AT_ADAM
 #define ICRL_HALVES_PREFETCH_AT_ADAM 0
 #endif
+// ICRL_HALVES_ROLE_SPEC: see ROLE_T at ppo_train_halves_body — measured: the critics' step loops shrink from ~2 100 to ~1 500 instructions, the policy's
+//   (the one the others wait for) to 1 984 with 6 scratch reloads: 6.03 against 6.01 us per step, nothing; off
+#ifndef ICRL_HALVES_ROLE_SPEC
+#define ICRL_HALVES_ROLE_SPEC 0
+#endif
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -191,17 +196,26 @@ struct SmemH {  // offsets in floats (multiples of 4)
 // NQ = 2: two workgroups per network, 32 rows of every 64-row chunk each (round 5).  NQ = 4 (round 6): FOUR workgroups per network, 16 rows = ONE
 // row tile each — the forward / loss / activation backward run on waves 0..3 alone, one per SIMD (the other four wait at the barrier), the
 // weight-gradient GEMMs have K = 16, and the four partial gradients are summed in the fixed order (q0 + q1) + (q2 + q3) by all four.
-template <int NT1, bool DISC, int OBS, bool BATCH, int NQ>
+template <int NT1>
+__device__ __forceinline__ float* halves_smem() {
+  __shared__ __attribute__((aligned(16))) float sm[SmemH<NT1>::TOTAL];
+  return sm;
+}
+
+// ROLE_T >= 0 (late round 6, the single-run HCWithPos launch): the network this workgroup serves as a compile-time constant — the body is instantiated once
+// per role and the kernel picks by blockIdx: every `role == 0` test, the role-dependent pointer / coefficient selects and the dead half of the loss
+// tail fold away (fewer scalar registers live across the step loop, whose spills were ~100 v_readlane per step)
+template <int NT1, bool DISC, int OBS, bool BATCH, int NQ, int ROLE_T = -1>
 __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const TrainArgs* const ka, const int slot_j) {
 #define GPH(x) (BATCH ? as_global(x) : (x))
   using S = SmemH<NT1>;
   constexpr int SX = S::SX;
   static_assert(NT1 == 2, "one observation tile per weight-gradient wave half");
-  __shared__ __attribute__((aligned(16))) float sm[S::TOTAL];      // static: every image offset folds into an immediate (ppo_train_pairs.hip)
+  float* const sm = halves_smem<NT1>();      // static: every image offset folds into an immediate (ppo_train_pairs.hip); ONE array for the per-role instantiations
   static_assert(NQ == 2 || NQ == 4, "two or four row parts per network");
   constexpr int HRQ = RB / NQ;   // rows of a 64-row chunk this workgroup computes
   constexpr int NJS = HRQ / 16;  // 16-row tiles among them
-  const int role = slot_j % 3;   // 0 policy, 1 reward critic, 2 cost critic
+  const int role = ROLE_T >= 0 ? ROLE_T : slot_j % 3;   // 0 policy, 1 reward critic, 2 cost critic
   const int half = slot_j / 3;   // which HRQ rows of every 64-row chunk (the "part")
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1381,7 +1395,15 @@ template <int NT1, bool DISC, int OBS, int NQ>
 __global__ void __launch_bounds__(THH) ppo_train_halves_kernel(TrainArgs a, int packed) {
   int run = 0, j = (int)blockIdx.x;
   if (packed && !packed_slot(3 * NQ, 1, run, j)) return;
-  ppo_train_halves_body<NT1, DISC, OBS, false, NQ>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), j);
+  const TrainArgs* const ka = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+  if constexpr (ICRL_HALVES_ROLE_SPEC && OBS == 18 && NQ == 4 && !DISC) {      // HCWithPos (BASELINE configs[1], [3]): one body per role
+    const int role = j % 3;
+    if (role == 0) ppo_train_halves_body<NT1, DISC, OBS, false, NQ, 0>(a, ka, j);
+    else if (role == 1) ppo_train_halves_body<NT1, DISC, OBS, false, NQ, 1>(a, ka, j);
+    else ppo_train_halves_body<NT1, DISC, OBS, false, NQ, 2>(a, ka, j);
+  } else {
+    ppo_train_halves_body<NT1, DISC, OBS, false, NQ>(a, ka, j);
+  }
 }
 
 // several independent runs in ONE launch: the packed 1-D grid of ppo_common.h (a run's workgroups on one XCD), or grid (3 NQ, n_runs)
