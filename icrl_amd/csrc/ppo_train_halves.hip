@@ -126,6 +126,11 @@
 #ifndef ICRL_HALVES_ROLE_SPEC
 #define ICRL_HALVES_ROLE_SPEC 0
 #endif
+// ICRL_HALVES_IMAGES_FIRST: the LDS layout with the [feature][row] / [row][feature] images in front of the weights, as in ppo_train_quarters2.hip — at two
+//   observation tiles the ISA of the step loop does not change (2 386 against 2 392 lines, no scratch traffic either way): not timed, off
+#ifndef ICRL_HALVES_IMAGES_FIRST
+#define ICRL_HALVES_IMAGES_FIRST 0
+#endif
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -158,6 +163,38 @@ static_assert(H3_BASE + 24 * H3_BLK + 3 * 512 <= (int)ICRL_PPO_SPLIT_BYTES, "the
 template <int NT1>
 struct SmemH {  // offsets in floats (multiples of 4)
   static constexpr int O16 = 16 * NT1, SX = O16 + 8;
+#if ICRL_HALVES_IMAGES_FIRST
+  // images first (ppo_train_quarters2.hip: a ds instruction reaches 64 KB beyond its address register)
+  static constexpr int XT0 = 0;                // [16 NT1][STH] x^T of this half's rows: XT[k][row]
+  static constexpr int XT1 = XT0 + O16 * STH;
+  static constexpr int H1T = XT1 + O16 * STH;  // [64][STH] h1^T
+  static constexpr int H2T = H1T + HD * STH;
+  static constexpr int DZ1T = H2T + HD * STH;
+  static constexpr int DZ2T = DZ1T + HD * STH;
+  static constexpr int DOT = DZ2T + HD * STH;  // [16][STH] d loss / d head output, transposed
+  static constexpr int H1R = DOT + 16 * STH;   // [32][SRM] h1, row-major
+  static constexpr int DZ2R = H1R + HR * SRM;  // [32][SRM] dz2, row-major
+  static constexpr int ACT = DZ2R + HR * SRM;  // [32][SAH] actions of this half's rows
+  static constexpr int OLP = ACT + HR * SAH;   // [32] old log-prob | old value
+  static constexpr int ADR = OLP + HR;         // [32] raw reward advantage | return
+  static constexpr int ADC = ADR + HR;         // [32] raw cost advantage
+  static constexpr int PST = ADC + HR;         // [2][8] per-row-tile loss statistics
+  static constexpr int PLS = PST + 16;         // [2][16] per-row-tile d log_std partial sums
+  static constexpr int MISC = PLS + 32;        // [64] granule values, flags, advantage-statistics partials
+  static constexpr int GAU = MISC + 64;        // [3][16]
+  static constexpr int B1 = GAU + 48;
+  static constexpr int B2 = B1 + HD;
+  static constexpr int BH = B2 + HD;
+  static constexpr int LS = BH + 16;
+  static constexpr int HPX = LS + 16;          // [2][4][64][4] head partial tiles of the quads
+  static constexpr int DOX = HPX + 2048;       // [2][64][4]
+  static constexpr int WH = DOX + 512;         // [16][SH]
+  static constexpr int WHT = WH + 16 * SH;     // [64][SAH]
+  static constexpr int W1 = WHT + HD * SAH;    // [64][SX]
+  static constexpr int W2 = W1 + HD * SX;      // [64][SH]
+  static constexpr int W2T = W2 + HD * SH;     // [64][SH]
+  static constexpr int TOTAL = W2T + HD * SH;
+#else
   static constexpr int W1 = 0;                 // [64][SX]
   static constexpr int W2 = W1 + HD * SX;      // [64][SH]
   static constexpr int W2T = W2 + HD * SH;     // [64][SH]  W2T[k][j] = W2[j][k]
@@ -187,6 +224,7 @@ struct SmemH {  // offsets in floats (multiples of 4)
   static constexpr int MISC = PLS + 32;        // [64] granule values, flags, advantage-statistics partials
   static constexpr int DOX = MISC + 64;        // [2][64][4] d loss / d head output of a quad's first wave, lane for lane (ICRL_HALVES_LOSS_WAVES < 4)
   static constexpr int TOTAL = DOX + 512;
+#endif
 };
 
 #define KARGS() ([&]() { const TrainArgs* k_ = ka; asm volatile("" : "+s"(k_)); return k_; }())
