@@ -175,7 +175,7 @@ int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s
 // ppo_train_halves.hip: two workgroups per network, wave quads (nt1 <= 2; single-run launches; a.gx set)
 // parts = 2 | 4 workgroups per network (round 6: four — 16 rows of every chunk each)
 int launch_train_halves(const TrainArgs& a, bool discrete, int parts, hipStream_t s);
-int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, int parts, hipStream_t s);
+int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, int parts, bool prof, hipStream_t s);      // prof: hp._pad & 1 (the runs of a batch share it)
 // ppo_train_quarters.hip: four workgroups per network at obs 65..128 (wave quads, the row-owning kernel's parameter ownership); single-run launches
 int launch_train_quarters_wide(const TrainArgs& a, bool discrete, hipStream_t s);
 // ppo_train_quarters2.hip: the same for minibatches of 65..128 rows: both chunks in one pass, two row tiles per wave (chunk plan with two entries per step)

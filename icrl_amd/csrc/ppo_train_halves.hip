@@ -243,7 +243,9 @@ __device__ __forceinline__ float* halves_smem() {
 // ROLE_T >= 0 (late round 6, the single-run HCWithPos launch): the network this workgroup serves as a compile-time constant — the body is instantiated once
 // per role and the kernel picks by blockIdx: every `role == 0` test, the role-dependent pointer / coefficient selects and the dead half of the loss
 // tail fold away (fewer scalar registers live across the step loop, whose spills were ~100 v_readlane per step)
-template <int NT1, bool DISC, int OBS, bool BATCH, int NQ, int ROLE_T = -1>
+// PROF (late round 6): the diagnostic phase timers (hp._pad & 1) are a compile-time variant — as a run-time flag their eight 64-bit accumulators and the
+// flag's lane mask sat in scalar registers across the step loop of EVERY launch (~100 instructions and 15 scalar reloads per step: 5.96 -> 5.81 us)
+template <int NT1, bool DISC, int OBS, bool BATCH, int NQ, int ROLE_T = -1, bool PROF = false>
 __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const TrainArgs* const ka, const int slot_j) {
 #define GPH(x) (BATCH ? as_global(x) : (x))
   using S = SmemH<NT1>;
@@ -538,7 +540,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   };
   auto raw_load = [&](int byte_off) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, byte_off, 0, 16)); };
 
-  const bool prof = (a.hp._pad & 1) != 0;
+  constexpr bool prof = PROF;
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = prof ? stamp() : 0ull;
 
@@ -1429,56 +1431,62 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   }
 }
 
-template <int NT1, bool DISC, int OBS, int NQ>
+template <int NT1, bool DISC, int OBS, int NQ, bool PROF>
 __global__ void __launch_bounds__(THH) ppo_train_halves_kernel(TrainArgs a, int packed) {
   int run = 0, j = (int)blockIdx.x;
   if (packed && !packed_slot(3 * NQ, 1, run, j)) return;
   const TrainArgs* const ka = (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr();
   if constexpr (ICRL_HALVES_ROLE_SPEC && OBS == 18 && NQ == 4 && !DISC) {      // HCWithPos (BASELINE configs[1], [3]): one body per role
     const int role = j % 3;
-    if (role == 0) ppo_train_halves_body<NT1, DISC, OBS, false, NQ, 0>(a, ka, j);
-    else if (role == 1) ppo_train_halves_body<NT1, DISC, OBS, false, NQ, 1>(a, ka, j);
-    else ppo_train_halves_body<NT1, DISC, OBS, false, NQ, 2>(a, ka, j);
+    if (role == 0) ppo_train_halves_body<NT1, DISC, OBS, false, NQ, 0, PROF>(a, ka, j);
+    else if (role == 1) ppo_train_halves_body<NT1, DISC, OBS, false, NQ, 1, PROF>(a, ka, j);
+    else ppo_train_halves_body<NT1, DISC, OBS, false, NQ, 2, PROF>(a, ka, j);
   } else {
-    ppo_train_halves_body<NT1, DISC, OBS, false, NQ>(a, ka, j);
+    ppo_train_halves_body<NT1, DISC, OBS, false, NQ, -1, PROF>(a, ka, j);
   }
 }
 
 // several independent runs in ONE launch: the packed 1-D grid of ppo_common.h (a run's workgroups on one XCD), or grid (3 NQ, n_runs)
 // with run = blockIdx.y when that many workgroups are not resident on their XCDs at once; the argument blocks live in device memory
-template <int NT1, bool DISC, int OBS, int NQ>
+template <int NT1, bool DISC, int OBS, int NQ, bool PROF>
 __global__ void __launch_bounds__(THH) ppo_train_halves_batch_kernel(const TrainArgs* __restrict__ runs, int n_runs, int packed) {
   int run = (int)blockIdx.y, j = (int)blockIdx.x;
   if (packed && !packed_slot(3 * NQ, n_runs, run, j)) return;
   const TrainArgs* const ka = as_global(runs + run);
-  ppo_train_halves_body<NT1, DISC, OBS, true, NQ>(*ka, ka, j);
+  ppo_train_halves_body<NT1, DISC, OBS, true, NQ, -1, PROF>(*ka, ka, j);
 }
 
-template <int NT1, bool DISC, int OBS, int NQ>
+template <int NT1, bool DISC, int OBS, int NQ, bool PROF>
 static int launch_halves(const TrainArgs* one, const TrainArgs* d_args, int n_runs, hipStream_t s) {
   static_assert(SmemH<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
   if (one != nullptr) {
     TrainArgs arg = *one;
-    return launch_update_single(ppo_train_halves_kernel<NT1, DISC, OBS, NQ>, 3 * NQ, dim3(THH), 0, s, arg);
+    return launch_update_single(ppo_train_halves_kernel<NT1, DISC, OBS, NQ, PROF>, 3 * NQ, dim3(THH), 0, s, arg);
   }
   const int pg = packed_grid(3 * NQ, n_runs);
-  hipLaunchKernelGGL((ppo_train_halves_batch_kernel<NT1, DISC, OBS, NQ>), pg ? dim3(pg) : dim3(3 * NQ, n_runs), dim3(THH), 0, s, d_args, n_runs, pg ? 1 : 0);
+  hipLaunchKernelGGL((ppo_train_halves_batch_kernel<NT1, DISC, OBS, NQ, PROF>), pg ? dim3(pg) : dim3(3 * NQ, n_runs), dim3(THH), 0, s, d_args, n_runs, pg ? 1 : 0);
   return (int)hipGetLastError();
 }
 
+template <int NQ, bool PROF>
+static int dispatch_halves_p(const TrainArgs* one, const TrainArgs* d_args, int n_runs, int obs, bool discrete, hipStream_t s) {
+  if (!discrete && obs == 18) return launch_halves<2, false, 18, NQ, PROF>(one, d_args, n_runs, s);      // HCWithPos (BASELINE configs[1], [3])
+  if (discrete && obs == 1) return launch_halves<2, true, 1, NQ, PROF>(one, d_args, n_runs, s);          // LapGridWorld (configs[0])
+  return discrete ? launch_halves<2, true, 0, NQ, PROF>(one, d_args, n_runs, s) : launch_halves<2, false, 0, NQ, PROF>(one, d_args, n_runs, s);
+}
+// prof: hp._pad & 1 of the run(s) — the instantiation with the phase timers (tools only)
 template <int NQ>
-static int dispatch_halves(const TrainArgs* one, const TrainArgs* d_args, int n_runs, int obs, bool discrete, hipStream_t s) {
-  if (!discrete && obs == 18) return launch_halves<2, false, 18, NQ>(one, d_args, n_runs, s);      // HCWithPos (BASELINE configs[1], [3])
-  if (discrete && obs == 1) return launch_halves<2, true, 1, NQ>(one, d_args, n_runs, s);          // LapGridWorld (configs[0])
-  return discrete ? launch_halves<2, true, 0, NQ>(one, d_args, n_runs, s) : launch_halves<2, false, 0, NQ>(one, d_args, n_runs, s);
+static int dispatch_halves(const TrainArgs* one, const TrainArgs* d_args, int n_runs, int obs, bool discrete, bool prof, hipStream_t s) {
+  return prof ? dispatch_halves_p<NQ, true>(one, d_args, n_runs, obs, discrete, s) : dispatch_halves_p<NQ, false>(one, d_args, n_runs, obs, discrete, s);
 }
 
 // obs <= 32 (nt1 <= 2), a.gx set and zeroed (prepare_train); parts = 2 | 4 workgroups per network
 int launch_train_halves(const TrainArgs& a, bool discrete, int parts, hipStream_t s) {
-  return parts == 4 ? dispatch_halves<4>(&a, nullptr, 1, a.L.O, discrete, s) : dispatch_halves<2>(&a, nullptr, 1, a.L.O, discrete, s);
+  const bool prof = (a.hp._pad & 1) != 0;
+  return parts == 4 ? dispatch_halves<4>(&a, nullptr, 1, a.L.O, discrete, prof, s) : dispatch_halves<2>(&a, nullptr, 1, a.L.O, discrete, prof, s);
 }
-int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, int parts, hipStream_t s) {
-  return parts == 4 ? dispatch_halves<4>(nullptr, d_args, n_runs, obs, discrete, s) : dispatch_halves<2>(nullptr, d_args, n_runs, obs, discrete, s);
+int launch_train_halves_batch(const TrainArgs* d_args, int n_runs, int obs, bool discrete, int parts, bool prof, hipStream_t s) {
+  return parts == 4 ? dispatch_halves<4>(nullptr, d_args, n_runs, obs, discrete, prof, s) : dispatch_halves<2>(nullptr, d_args, n_runs, obs, discrete, prof, s);
 }
 
 }  // namespace icrl

@@ -80,7 +80,8 @@ struct SmemQ {  // offsets in floats (multiples of 4)
 
 #define KARGS() ([&]() { const TrainArgs* k_ = ka; asm volatile("" : "+s"(k_)); return k_; }())
 
-template <int NT1, bool DISC, int OBS>
+// PROF: the diagnostic phase timers (hp._pad & 1) as a compile-time variant (ppo_train_halves.hip: as a run-time flag they cost every launch ~2.5 %)
+template <int NT1, bool DISC, int OBS, bool PROF>
 __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, const TrainArgs* const ka, const int slot_j) {
   using S = SmemQ<NT1>;
   constexpr int SX = S::SX;
@@ -362,7 +363,7 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
   };
   auto raw_load = [&](int byte_off) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, byte_off, 0, 16)); };
 
-  const bool prof = (a.hp._pad & 1) != 0;
+  constexpr bool prof = PROF;
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t_last = prof ? stamp() : 0ull;
 
@@ -943,21 +944,25 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
   }
 }
 
-template <int NT1, bool DISC, int OBS>
+template <int NT1, bool DISC, int OBS, bool PROF>
 __global__ void __launch_bounds__(THQ) ppo_train_quarters_kernel(TrainArgs a, int packed) {
   int run = 0, j = (int)blockIdx.x;
   if (packed && !packed_slot(12, 1, run, j)) return;
-  ppo_train_quarters_body<NT1, DISC, OBS>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), j);
+  ppo_train_quarters_body<NT1, DISC, OBS, PROF>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), j);
 }
 
-template <int NT1, bool DISC, int OBS>
-static int launch_quarters(const TrainArgs& a, hipStream_t s) {
+template <int NT1, bool DISC, int OBS, bool PROF>
+static int launch_quarters_p(const TrainArgs& a, hipStream_t s) {
   static_assert(SmemQ<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
   const size_t bytes = ICRL_QW_STATIC_LDS ? 0 : (size_t)SmemQ<NT1>::TOTAL * sizeof(float);
-  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_quarters_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  hipError_t e = hipFuncSetAttribute((const void*)ppo_train_quarters_kernel<NT1, DISC, OBS, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   if (e != hipSuccess) return (int)e;
   TrainArgs arg = a;
-  return launch_update_single(ppo_train_quarters_kernel<NT1, DISC, OBS>, 12, dim3(THQ), bytes, s, arg);
+  return launch_update_single(ppo_train_quarters_kernel<NT1, DISC, OBS, PROF>, 12, dim3(THQ), bytes, s, arg);
+}
+template <int NT1, bool DISC, int OBS>
+static int launch_quarters(const TrainArgs& a, hipStream_t s) {
+  return (a.hp._pad & 1) ? launch_quarters_p<NT1, DISC, OBS, true>(a, s) : launch_quarters_p<NT1, DISC, OBS, false>(a, s);
 }
 
 // obs 65..128 (nt1 5..8: run on the eight-tile instantiation, pad columns zero), a.gx set and zeroed (prepare_train), the chunk plan with one
