@@ -1047,7 +1047,9 @@ constexpr int REC_MAX = GRAN_MAX / 2;   // ... = 16-byte records a thread polls 
 // several runs of a batched launch — share a CU)
 static inline size_t persist_dyn_lds(int N, int O, int A) { return ((size_t)O * (size_t)(N + 64) + (size_t)O * (size_t)A) * sizeof(double); }
 
-template <int OCT, int CIT, bool GRAN>
+// PROF: the diagnostic phase timers (do_gae bit 2) as a compile-time variant: as a run-time flag their seven 64-bit accumulators sat in scalar registers
+// across the step loop of every launch (ppo_train_halves.hip: 2.5 % there)
+template <int OCT, int CIT, bool GRAN, bool PROF = false>
 __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
   extern __shared__ __attribute__((aligned(16))) double dyn_lds[];
   __shared__ ActShared sh;
@@ -1113,7 +1115,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
   if (w == 2) { st_m = nm.cost_stats[0]; st_v = nm.cost_stats[1]; st_c = nm.cost_stats[2]; }
   float noise_reg = (tid < NA) ? noise_g[(size_t)n * NA + tid] : 0.f;
   double fin_rew = 0.0; float fin_cost = 0.f; int fin_done = 0;
-  unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, pc_rounds = 0, tl = p.prof ? prof_now() : 0ull;
+  unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, pc5 = 0, pc_rounds = 0, tl = PROF ? prof_now() : 0ull;
   int spin_limit = 1 << 22;
   for (int t = 0; t < T; ++t) {
     const int par = t & 1;
@@ -1171,8 +1173,8 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
         ag.last_v_c[n] = sh.scal[1];
       }
     }
-    if (p.prof) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }
-    if (p.prof && t == T / 2 && lane == 0) g_wide_trace[4 * n + w] = __builtin_amdgcn_s_memrealtime();   // per wave: end of its phase-A part
+    if (PROF) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }
+    if (PROF && t == T / 2 && lane == 0) g_wide_trace[4 * n + w] = __builtin_amdgcn_s_memrealtime();   // per wave: end of its phase-A part
     if (GRAN) {
       // poll this thread's records of ALL envs until every one carries this step's tag at both ends, then scatter the payloads
       const int rbase = par * N * R16 * 16;
@@ -1189,7 +1191,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
           if (g[k][0] != gtag || (g[k][3] & 0x7fffffffu) != gtag) { g[k] = rload(rbase + (k * 256 + tid) * 16); ok = false; }
         ++rounds;
       }
-      if (p.prof && tid == 0) { pc_rounds += (unsigned long long)rounds; }
+      if (PROF && tid == 0) { pc_rounds += (unsigned long long)rounds; }
       if (!ok) spin_limit = 1;      // a peer never showed up (a workgroup was not resident): stop waiting ~2 s per step; reported below
 #pragma unroll
       for (int k = 0; k < REC_MAX; ++k) {
@@ -1208,7 +1210,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
     } else {
       grid_barrier(as_global(p.counter), N, n, (unsigned)(t + 1), spin_limit);
     }
-    if (p.prof) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }
+    if (PROF) { const unsigned long long tn_ = prof_now(); pc1 += tn_ - tl; tl = tn_; }
     // ---------------- phase B: kernel B's statistics, replicated; normalise own env ----------------
     {
       if (!GRAN) {
@@ -1232,7 +1234,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
       }
     }
     __syncthreads();
-    if (p.prof) { const unsigned long long tn_ = prof_now(); pc3 += tn_ - tl; tl = tn_; }
+    if (PROF) { const unsigned long long tn_ = prof_now(); pc3 += tn_ - tl; tl = tn_; }
     if (nm.training) {
       if (tid < O) {           // obs_rms.update: rows added in order (numpy's axis-0 reduction)
         double bm, bv;
@@ -1253,7 +1255,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
     }
     if (lane == 0 && w == 3) dens[0] = sqrt(st_v + nm.epsilon);
     if (lane == 0 && w == 2) dens[1] = sqrt(st_v + nm.epsilon);
-    if (p.prof) { const unsigned long long tn_ = prof_now(); pc4 += tn_ - tl; tl = tn_; }
+    if (PROF) { const unsigned long long tn_ = prof_now(); pc4 += tn_ - tl; tl = tn_; }
     if (tid < O) {             // own env: normalise + clip, next policy input
       double o = chunk[tid * NP + n];
       if (nm.norm_obs) o = fmin(fmax((o - o_mean) / sqrt(o_var + nm.epsilon), -nm.clip_obs), nm.clip_obs);
@@ -1263,7 +1265,7 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
       sh.s_old[tid] = sh.s_new[tid];
     }
     __syncthreads();
-    if (p.prof) { const unsigned long long tn_ = prof_now(); pc5 += tn_ - tl; tl = tn_; }
+    if (PROF) { const unsigned long long tn_ = prof_now(); pc5 += tn_ - tl; tl = tn_; }
     if (tid < N) {
       const int d = done_s[tid];
       if (nm.training || d) { ret_s[tid] = d ? 0.0 : vec[0][tid]; if (has_cost) cret_s[tid] = d ? 0.0 : vec[1][tid]; }
@@ -1280,9 +1282,9 @@ __device__ __forceinline__ void rollout_persistent_body(const PersistArgs& p) {
       }
       last_done_s = done_s[n];
     }
-    if (p.prof) { const unsigned long long tn_ = prof_now(); pc2 += tn_ - tl; tl = tn_; }
+    if (PROF) { const unsigned long long tn_ = prof_now(); pc2 += tn_ - tl; tl = tn_; }
   }
-  if (p.prof && n == 0 && tid == 0) { g_rollout_prof[0] = pc0; g_rollout_prof[1] = pc1; g_rollout_prof[2] = pc2; g_rollout_prof[3] = (unsigned long long)T; g_rollout_prof[4] = pc3; g_rollout_prof[5] = pc4; g_rollout_prof[6] = pc5; g_rollout_prof[7] = pc_rounds; }
+  if (PROF && n == 0 && tid == 0) { g_rollout_prof[0] = pc0; g_rollout_prof[1] = pc1; g_rollout_prof[2] = pc2; g_rollout_prof[3] = (unsigned long long)T; g_rollout_prof[4] = pc3; g_rollout_prof[5] = pc4; g_rollout_prof[6] = pc5; g_rollout_prof[7] = pc_rounds; }
   // a timed-out exchange means stale granules went into the statistics and the buffer: tell the host (it raises)
   if (spin_limit == 1 && ag.status != nullptr && (tid & 63) == 0) atomicOr(ag.status, 1);
   // ---- leave the agent / wrapper state exactly where the per-step path leaves it
@@ -1583,9 +1585,9 @@ __global__ void __launch_bounds__(256) rollout_generic_kernel(GenRolloutArgs ga)
   rollout_generic_body<OCT, CIT>(ga);
 }
 
-template <int OCT, int CIT, bool GRAN>
+template <int OCT, int CIT, bool GRAN, bool PROF = false>
 __global__ void __launch_bounds__(256) rollout_persistent_kernel(PersistArgs p) {
-  rollout_persistent_body<OCT, CIT, GRAN>(p);
+  rollout_persistent_body<OCT, CIT, GRAN, PROF>(p);
 }
 
 // several independent runs in ONE launch: grid (N, n_runs), run = blockIdx.y, argument blocks in device memory.  Workgroups are
@@ -3651,7 +3653,12 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
         return true;
       };
       bool launched;
-      if (small && gran) launched = go(rollout_persistent_kernel<2, 2, true>);
+      if (p.prof) {      // (tools: the instantiations with the phase timers)
+        if (small && gran) launched = go(rollout_persistent_kernel<2, 2, true, true>);
+        else if (small) launched = go(rollout_persistent_kernel<2, 2, false, true>);
+        else if (gran) launched = go(rollout_persistent_kernel<8, 10, true, true>);
+        else launched = go(rollout_persistent_kernel<8, 10, false, true>);
+      } else if (small && gran) launched = go(rollout_persistent_kernel<2, 2, true>);
       else if (small) launched = go(rollout_persistent_kernel<2, 2, false>);
       else if (gran) launched = go(rollout_persistent_kernel<8, 10, true>);
       else launched = go(rollout_persistent_kernel<8, 10, false>);
