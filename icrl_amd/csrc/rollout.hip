@@ -1632,7 +1632,7 @@ struct WideArgs {
   unsigned long long* xcc;     // multi-env kernel, packed batched launches: G zeroed words (the workgroups' XCD ids), else NULL
 };
 
-template <int OCT, int CIT>
+template <int OCT, int CIT, bool PROF = false>      // PROF: the phase timers (do_gae bits 2 / 3) as a compile-time variant (rollout_persistent_body)
 __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
   __shared__ ActShared sh[WIDE_E];
   __shared__ double Bl[MAX_OBS * MAX_ACT];
@@ -1695,7 +1695,7 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
   }
   int spin_limit = 1 << 22;
   __syncthreads();
-  const bool prof = p.prof != 0 && g == p.prof - 1;
+  const bool prof = PROF && p.prof != 0 && g == p.prof - 1;
   unsigned long long pc0 = 0, pc1 = 0, pc2 = 0, pc3 = 0, pc4 = 0, tl = prof ? prof_now() : 0ull;
   for (int t = 0; t < T; ++t) {
     const int par = t & 1;
@@ -1754,7 +1754,7 @@ __global__ void __launch_bounds__(256) rollout_wide_kernel(WideArgs p) {
       }
     }
     if (prof) { const unsigned long long tn_ = prof_now(); pc0 += tn_ - tl; tl = tn_; }     // policy + env + rows (this wave's part)
-    const bool trace = p.prof != 0 && t == T / 2 && lane == 0;
+    const bool trace = PROF && p.prof != 0 && t == T / 2 && lane == 0;
     if (trace && w == 0) g_wide_trace[4 * g + 0] = __builtin_amdgcn_s_memrealtime();
     // ---------------- phase B1: the owners (wave 1) gather their statistic from all envs and publish it ----------------
     if (w == 1 && (own_col >= 0 || own_ret || own_cost)) {
@@ -3610,8 +3610,10 @@ extern "C" int icrl_rollout_collect_ex(const icrl_env_t* env, const icrl_norm_t*
         p.xcc = nullptr;
         hipError_t e = hipMemsetAsync(p.xg, 0, 16 * (size_t)N * GX + 16 * GS, s);
         if (e != hipSuccess) return (int)e;
-        int err = (int)(small ? launch_coresident(rollout_wide_kernel<2, 2>, dim3(G), dim3(256), 0, s, p)
-                              : launch_coresident(rollout_wide_kernel<8, 10>, dim3(G), dim3(256), 0, s, p));
+        int err = p.prof ? (int)(small ? launch_coresident(rollout_wide_kernel<2, 2, true>, dim3(G), dim3(256), 0, s, p)
+                                       : launch_coresident(rollout_wide_kernel<8, 10, true>, dim3(G), dim3(256), 0, s, p))
+                         : (int)(small ? launch_coresident(rollout_wide_kernel<2, 2>, dim3(G), dim3(256), 0, s, p)
+                                       : launch_coresident(rollout_wide_kernel<8, 10>, dim3(G), dim3(256), 0, s, p));
         if (err == (int)hipErrorCooperativeLaunchTooLarge) { (void)hipGetLastError(); goto per_step; }
         if (err || !(do_gae & 1)) return err;
         return icrl_gae_dual_ws(buf->rewards, buf->costs, buf->reward_values, buf->cost_values, buf->dones, ag->last_v_r,
