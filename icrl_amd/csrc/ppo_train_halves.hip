@@ -131,6 +131,13 @@
 #ifndef ICRL_HALVES_IMAGES_FIRST
 #define ICRL_HALVES_IMAGES_FIRST 0
 #endif
+// ICRL_HALVES_STAGE_IDLE (four parts, late round 6): the row stream — index pipeline, ~60 instructions of address arithmetic and the gather loads per
+//   step, the commit of the staged rows — runs on waves 4..7, which sit at the barrier during forward / loss / backward, instead of on waves 0..3,
+//   where it stood between layer 1 and the h1 hand-off of every forward wave.  Measured SLOWER (5.98 against 5.81 us per step, three alternating rounds;
+//   bit-identical): waves 4..7 then reach the exchange with the commit still to do.  Off.
+#ifndef ICRL_HALVES_STAGE_IDLE
+#define ICRL_HALVES_STAGE_IDLE 0
+#endif
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -391,9 +398,11 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
 
   // ---- row stream: the 32 rows of this half are staged by the 512 threads, 16 per row (see ppo_train_pairs.hip for the rules the
   // index / row loads follow: unconditional, clamped, untouched until consumed)
-  const int gb_row = tid >> 4, gpart = tid & 15;
+  constexpr bool STAGE_IDLE = ICRL_HALVES_STAGE_IDLE && NQ == 4;
+  const int gb_row = STAGE_IDLE ? (tid >> 4) & 15 : tid >> 4, gpart = tid & 15;
   const int gpos = HRQ * half + (gb_row < HRQ ? gb_row : 0);      // position of that row in its 64-row chunk
-  const bool stager = gb_row < HRQ;               // (NQ == 4: 16 rows, the threads of waves 0..3 stage them)
+  const bool stager = STAGE_IDLE ? tid >= 256 : gb_row < HRQ;     // (NQ == 4: 16 rows, staged by the threads of waves 0..3 — STAGE_IDLE: of waves 4..7)
+  const bool stager_wave = !STAGE_IDLE || w >= 4;
   constexpr int SW0 = 1;                          // advantage statistics: row stid of the minibatch on waves SW0 .. SW0 + 3
   const int stid = tid - 64 * SW0;
   auto ld_step = [&](int i) -> int4 {
@@ -611,7 +620,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         issue_rows(idx_now);
       };
       const bool pf_here = !deep_pf;      // (deep_pf: at the top of Adam)
-      if (pf_here && (!ICRL_HALVES_LATE_PREFETCH || !fwd_wave)) prefetch_next();
+      if (pf_here && stager_wave && (!ICRL_HALVES_LATE_PREFETCH || !fwd_wave)) prefetch_next();
       f32x4 dout = f32x4{0.f, 0.f, 0.f, 0.f};
       float pl_olp = 0.f, pl_adr = 0.f, pl_adc = 0.f;      // (ICRL_HALVES_LOSS_PRELOAD)
       f32x4 pl_act = dout, pl_iv = dout, pl_hiv = dout, pl_lsd = dout, pl_wht = dout;
