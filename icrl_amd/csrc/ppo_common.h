@@ -184,7 +184,7 @@ constexpr int HALVES_MAX_RUNS = 40;      // batched launches: 6 workgroups per r
 constexpr int QUARTERS_MAX_RUNS = 16;    // 12 workgroups per run, 2 groups of 8 runs = 24 workgroups per XCD
 // batched forms: n_runs argument blocks in DEVICE memory, grid.y = run
 int launch_train_rows_batch(const TrainArgs* d_args, int n_runs, int nt1, bool discrete, bool split, hipStream_t s);
-int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, hipStream_t s);
+int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, bool prof, hipStream_t s);
 
 
 }  // namespace icrl

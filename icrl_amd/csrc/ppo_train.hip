@@ -1090,6 +1090,6 @@ extern "C" int icrl_ppo_lag_train_batch(int n_runs, const icrl_ppo_train_job_t* 
   }
   const int nt1 = (j0.pol->obs_dim + 15) / 16;
   if (kind0 == 4 || kind0 == 5) return launch_train_halves_batch(d_args, n_runs, j0.pol->obs_dim, j0.pol->discrete != 0, kind0 == 5 ? 4 : 2, (j0.hp->_pad & 1) != 0, s);
-  if (kind0 == 0) return launch_train_pairs_batch(d_args, n_runs, j0.pol->obs_dim, nt1, j0.pol->discrete != 0, s);
+  if (kind0 == 0) return launch_train_pairs_batch(d_args, n_runs, j0.pol->obs_dim, nt1, j0.pol->discrete != 0, (j0.hp->_pad & 1) != 0, s);
   return launch_train_rows_batch(d_args, n_runs, nt1, j0.pol->discrete != 0, kind0 == 2, s);
 }

@@ -159,7 +159,8 @@ struct SmemP {  // offsets in floats (multiples of 4); same images as SmemR in p
 // OBS > 0: the observation width is known at compile time (the widths of the BASELINE configs get their own instantiation): layer-1
 // MFMAs whose four k values are all padding (k = 16 js + 4 q + e >= obs for every q, i.e. 16 js + e >= obs) are not issued — at
 // obs 18 six of eight per tile remain, at obs 1 (LapGridWorld) one.  OBS == 0: every k step runs against the zero pad weights.
-template <int NT1, bool DISC, int OBS = 0>
+// PROF: the diagnostic phase timers (hp._pad & 1) as a compile-time variant (ppo_train_halves.hip: as a run-time flag they cost every launch ~2.5 %)
+template <int NT1, bool DISC, int OBS = 0, bool PROF = false>
 __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const TrainArgs* const ka, const int role_arg) {
   using S = SmemP<NT1>;
   constexpr int SX = S::SX;
@@ -593,7 +594,7 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
 #elif ICRL_LOW_PRIO
   if (fh == 0) __builtin_amdgcn_s_setprio(ICRL_LOW_PRIO);
 #endif
-  const bool prof = (a.hp._pad & 1) != 0;
+  constexpr bool prof = PROF;
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #ifdef ICRL_FINE_PROF
   unsigned long long fph[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1306,58 +1307,62 @@ __device__ __forceinline__ void ppo_train_pairs_body(const TrainArgs& a, const T
   }
 }
 
-template <int NT1, bool DISC, int OBS>
+template <int NT1, bool DISC, int OBS, bool PROF>
 __global__ void __launch_bounds__(TH8) ppo_train_pairs_kernel(TrainArgs a, int packed) {
   int run = 0, role = (int)blockIdx.x;
   if (packed && !packed_slot(3, 1, run, role)) return;
-  ppo_train_pairs_body<NT1, DISC, OBS>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), role);
+  ppo_train_pairs_body<NT1, DISC, OBS, PROF>(a, (const TrainArgs*)__builtin_amdgcn_kernarg_segment_ptr(), role);
 }
 
 // several independent runs in ONE launch: the packed 1-D grid of ppo_common.h (a run's workgroups on one XCD), or grid (3, n_runs) with
 // run = blockIdx.y when that many workgroups are not resident at once; the argument blocks live in device memory
-template <int NT1, bool DISC, int OBS>
+template <int NT1, bool DISC, int OBS, bool PROF>
 __global__ void __launch_bounds__(TH8) ppo_train_pairs_batch_kernel(const TrainArgs* __restrict__ runs, int n_runs, int packed) {
   int run = (int)blockIdx.y, role = (int)blockIdx.x;      // run-major layout: grid (3, n_runs)
   if (packed && !packed_slot(3, n_runs, run, role)) return;
   const TrainArgs* const ka = as_global(runs + run);
-  ppo_train_pairs_body<NT1, DISC, OBS>(*ka, ka, role);
+  ppo_train_pairs_body<NT1, DISC, OBS, PROF>(*ka, ka, role);
 }
 
 // one: single-run launch (argument block by value) | d_args: n_runs blocks in device memory
-template <int NT1, bool DISC, int OBS>
-static int launch_pairs(const TrainArgs* one, const TrainArgs* d_args, int n_runs, hipStream_t s) {
+template <int NT1, bool DISC, int OBS, bool PROF>
+static int launch_pairs_p(const TrainArgs* one, const TrainArgs* d_args, int n_runs, hipStream_t s) {
   static_assert(SmemP<NT1>::TOTAL * sizeof(float) <= 160 * 1024, "LDS budget");
   const size_t bytes = ICRL_STATIC_LDS ? 0 : (size_t)SmemP<NT1>::TOTAL * sizeof(float);
   if (one != nullptr) {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_kernel<NT1, DISC, OBS, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
     TrainArgs arg = *one;
-    return launch_update_single(ppo_train_pairs_kernel<NT1, DISC, OBS>, 3, dim3(TH8), bytes, s, arg);
+    return launch_update_single(ppo_train_pairs_kernel<NT1, DISC, OBS, PROF>, 3, dim3(TH8), bytes, s, arg);
   } else {
-    hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_batch_kernel<NT1, DISC, OBS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipError_t e = hipFuncSetAttribute((const void*)ppo_train_pairs_batch_kernel<NT1, DISC, OBS, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return (int)e;
     const int pg = packed_grid(3, n_runs);      // the runs' workgroups on one XCD each (ppo_common.h) when the whole grid is resident at once
-    hipLaunchKernelGGL((ppo_train_pairs_batch_kernel<NT1, DISC, OBS>), pg ? dim3(pg) : dim3(3, n_runs), dim3(TH8), bytes, s, d_args, n_runs, pg ? 1 : 0);
+    hipLaunchKernelGGL((ppo_train_pairs_batch_kernel<NT1, DISC, OBS, PROF>), pg ? dim3(pg) : dim3(3, n_runs), dim3(TH8), bytes, s, d_args, n_runs, pg ? 1 : 0);
   }
   return (int)hipGetLastError();
 }
 
-static int dispatch_pairs(const TrainArgs* one, const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, hipStream_t s) {
+template <bool PROF>
+static int dispatch_pairs_p(const TrainArgs* one, const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, hipStream_t s) {
   if (nt1 <= 2) {
-    if (!discrete && obs == 18) return launch_pairs<2, false, 18>(one, d_args, n_runs, s);      // HCWithPos (BASELINE configs[1], [3])
-    if (discrete && obs == 1) return launch_pairs<2, true, 1>(one, d_args, n_runs, s);          // LapGridWorld (configs[0])
-    return discrete ? launch_pairs<2, true, 0>(one, d_args, n_runs, s) : launch_pairs<2, false, 0>(one, d_args, n_runs, s);
+    if (!discrete && obs == 18) return launch_pairs_p<2, false, 18, PROF>(one, d_args, n_runs, s);      // HCWithPos (BASELINE configs[1], [3])
+    if (discrete && obs == 1) return launch_pairs_p<2, true, 1, PROF>(one, d_args, n_runs, s);          // LapGridWorld (configs[0])
+    return discrete ? launch_pairs_p<2, true, 0, PROF>(one, d_args, n_runs, s) : launch_pairs_p<2, false, 0, PROF>(one, d_args, n_runs, s);
   }
-  if (nt1 <= 4) return discrete ? launch_pairs<4, true, 0>(one, d_args, n_runs, s) : launch_pairs<4, false, 0>(one, d_args, n_runs, s);
+  if (nt1 <= 4) return discrete ? launch_pairs_p<4, true, 0, PROF>(one, d_args, n_runs, s) : launch_pairs_p<4, false, 0, PROF>(one, d_args, n_runs, s);
   return fail("update (wave pairs): obs_dim tiles %d > 4", nt1);
 }
+static int dispatch_pairs(const TrainArgs* one, const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, bool prof, hipStream_t s) {
+  return prof ? dispatch_pairs_p<true>(one, d_args, n_runs, obs, nt1, discrete, s) : dispatch_pairs_p<false>(one, d_args, n_runs, obs, nt1, discrete, s);
+}
 
-int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, hipStream_t s) {
-  return dispatch_pairs(nullptr, d_args, n_runs, obs, nt1, discrete, s);
+int launch_train_pairs_batch(const TrainArgs* d_args, int n_runs, int obs, int nt1, bool discrete, bool prof, hipStream_t s) {
+  return dispatch_pairs(nullptr, d_args, n_runs, obs, nt1, discrete, prof, s);
 }
 
 int launch_train_pairs(const TrainArgs& a, int nt1, bool discrete, hipStream_t s) {
-  return dispatch_pairs(&a, nullptr, 1, a.L.O, nt1, discrete, s);
+  return dispatch_pairs(&a, nullptr, 1, a.L.O, nt1, discrete, (a.hp._pad & 1) != 0, s);
 }
 
 }  // namespace icrl
