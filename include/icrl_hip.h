@@ -349,7 +349,10 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
  *            chunk of a minibatch, partial gradients exchanged as granules) unless bit 3 is set.  obs <= 32 (HCWithPos, LapGridWorld): the
  *            wave-quad kernel — FOUR workgroups per network (12 per run on one XCD; 16 rows of every 64-row chunk each, the four partial
  *            gradients summed as (q0 + q1) + (q2 + q3) by all four; round 6), TWO with bit 5 (32 rows each; also what batches of 17..40
- *            runs get), the wave-pair kernel (one) with bit 4.
+ *            runs get), the wave-pair kernel (one) with bit 4.  obs 65..128 (AntWall), single-run calls: FOUR workgroups per network as well
+ *            (wave quads with the row-owning kernel's parameter ownership; minibatches of 65..128 rows take both 64-row chunks in one pass);
+ *            bit 2 or bit 5 keep the row-owning kernel there.  Bit 0 selects separate instantiations of the kernels (the timers cost every
+ *            launch ~2.5 % as a run-time flag).
  * Shapes outside the persistent kernels — a policy stored with hidden width h1 = h2 > 64 (a multiple of 64 up to 256: the reference's
  * -pl / -rvl / -cvl flags take any width, icrl/utils.py:636-655), a policy described by `arch` (shared trunk, other depths) or
  * batch_size > 256 (buffers.py:594-612 slices any size) — run through the generic-shape path (csrc/generic.hip): ONE persistent
