@@ -262,6 +262,9 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   static_assert(NQ == 2 || NQ == 4, "two or four row parts per network");
   constexpr int HRQ = RB / NQ;   // rows of a 64-row chunk this workgroup computes
   constexpr int NJS = HRQ / 16;  // 16-row tiles among them
+  // fault injection for the tests (hp._pad & 64): the last workgroup of the run leaves at once — every wait of the others is bounded, the launch ENDS
+  // with the status word set and the host raises
+  if ((a.hp._pad & 64) && slot_j == 3 * NQ - 1) return;
   const int role = ROLE_T >= 0 ? ROLE_T : slot_j % 3;   // 0 policy, 1 reward critic, 2 cost critic
   const int half = slot_j / 3;   // which HRQ rows of every 64-row chunk (the "part")
   const int tid = threadIdx.x;

@@ -91,6 +91,9 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
 #else
   extern __shared__ __attribute__((aligned(16))) float sm[];      // dynamic: with a static array the folded offsets let the optimiser hoist more addresses than the register file holds (ppo_train_rows.hip)
 #endif
+  // fault injection for the tests (hp._pad & 64): the last workgroup of the run leaves at once — every wait of the others is bounded, the launch ENDS
+  // with the status word set and the host raises
+  if ((a.hp._pad & 64) && slot_j == 11) return;
   const int role = slot_j % 3;   // 0 policy, 1 reward critic, 2 cost critic
   const int part = slot_j / 3;   // rows 16 part .. 16 part + 15 of every 64-row chunk
   const int tid = threadIdx.x;

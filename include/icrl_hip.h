@@ -352,7 +352,8 @@ int icrl_rollout_collect(const icrl_env_t* env, const icrl_norm_t* nm, const icr
  *            runs get), the wave-pair kernel (one) with bit 4.  obs 65..128 (AntWall), single-run calls: FOUR workgroups per network as well
  *            (wave quads with the row-owning kernel's parameter ownership; minibatches of 65..128 rows take both 64-row chunks in one pass);
  *            bit 2 or bit 5 keep the row-owning kernel there.  Bit 0 selects separate instantiations of the kernels (the timers cost every
- *            launch ~2.5 % as a run-time flag).
+ *            launch ~2.5 % as a run-time flag).  Bit 6 (tests): the last workgroup of a four-workgroups-per-network launch leaves at once —
+ *            the others' bounded waits must end the launch with stats[11] set.
  * Shapes outside the persistent kernels — a policy stored with hidden width h1 = h2 > 64 (a multiple of 64 up to 256: the reference's
  * -pl / -rvl / -cvl flags take any width, icrl/utils.py:636-655), a policy described by `arch` (shared trunk, other depths) or
  * batch_size > 256 (buffers.py:594-612 slices any size) — run through the generic-shape path (csrc/generic.hip): ONE persistent

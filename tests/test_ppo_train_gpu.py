@@ -339,6 +339,29 @@ def test_generic_shape_update_is_reproducible(shape, B):
     assert any(float((out[0][0][k] - sd0[k]).abs().max()) > 0 for k in sd0)
 
 
+@pytest.mark.parametrize("kind,B", [("hc", 64), ("ant", 128)])
+def test_multi_workgroup_update_reports_a_workgroup_that_never_arrives(kind, B):
+    """The four-workgroups-per-network update kernels (ppo_train_halves.hip at HC widths, ppo_train_quarters2.hip at AntWall's) exchange partial gradients and
+    norm granules between twelve workgroups; every one of those waits is bounded.  With hp._pad & 64 the run's last workgroup leaves before the first
+    optimiser step: the others give up at their flag / granule polls (seconds), the launch ENDS with the status word set and the host raises — no hung GPU."""
+    import time
+    od, ad = (18, 6) if kind == "hc" else (113, 8)
+    N, T = 8, 32
+    agent = _agent(kind, N, T, batch_size=B, n_epochs=2, target_kl=None)
+    rng = np.random.RandomState(2)
+    _fill(agent, dict(observations=rng.randn(T, N, od), actions=rng.randn(T, N, ad), log_probs=-3 + 0.1 * rng.randn(T, N), reward_advantages=rng.randn(T, N),
+                      cost_advantages=rng.randn(T, N), reward_returns=rng.randn(T, N), cost_returns=rng.randn(T, N), reward_values=rng.randn(T, N),
+                      cost_values=rng.randn(T, N), orig_costs=np.abs(rng.randn(T, N))))
+    agent.tune_sync_placement = False
+    agent.profile_phases = 64
+    t0 = time.time()
+    with pytest.raises(RuntimeError, match="timed out"):
+        agent.train()
+    print(f"{kind}: the launch with a missing workgroup ended after {time.time() - t0:.1f} s")
+    assert time.time() - t0 < 120
+    agent.profile_phases = 0
+
+
 def test_generic_shape_update_reports_a_workgroup_that_never_arrives():
     """Every wait of the persistent generic-shape update is bounded: with hp._pad & 64 the last workgroup leaves before the first optimiser step, the
     others give up at the first grid barrier and the launch ENDS (no hung GPU) with the status word set — the host raises like for the other persistent kernels."""
