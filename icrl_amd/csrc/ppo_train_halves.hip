@@ -138,6 +138,12 @@
 #ifndef ICRL_HALVES_STAGE_IDLE
 #define ICRL_HALVES_STAGE_IDLE 0
 #endif
+// ICRL_HALVES_SOFFSET: the exchange's loads / stores with the uniform part of the address in the scalar-offset operand (no vector add per access) — measured
+//   SLOWER (5.94 against 5.85 us per step; the offsets cost scalar registers, which this kernel has none to spare); off.  The same in
+//   ppo_train_quarters2.hip (with the row gather through one 64-bit base and immediate offsets): 11.70 against 11.66, nothing; not kept.
+#ifndef ICRL_HALVES_SOFFSET
+#define ICRL_HALVES_SOFFSET 0
+#endif
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -551,6 +557,19 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     else __builtin_amdgcn_raw_buffer_store_b128(u, grs, byte_off, 0, 16);
   };
   auto raw_load = [&](int byte_off) -> f32x4 { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, byte_off, 0, 16)); };
+  // the same with the address split into the lane's slot (one loop-invariant register) + a UNIFORM offset in the instruction's scalar-offset operand: no
+  // vector add per access (late round 6; ICRL_HALVES_SOFFSET)
+  const int lane_slot = tid * 16;
+  auto raw_store_u = [&](int uni_off, const f32x4& v) {
+    if (!ICRL_HALVES_SOFFSET) { raw_store(uni_off + lane_slot, v); return; }
+    const raw_u4 u = __builtin_bit_cast(raw_u4, v);
+    if (xcd_local) __builtin_amdgcn_raw_buffer_store_b128(u, grs, lane_slot, uni_off, 1);
+    else __builtin_amdgcn_raw_buffer_store_b128(u, grs, lane_slot, uni_off, 16);
+  };
+  auto raw_load_u = [&](int uni_off) -> f32x4 {
+    if (!ICRL_HALVES_SOFFSET) return raw_load(uni_off + lane_slot);
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(grs, lane_slot, uni_off, 16));
+  };
 
   constexpr bool prof = PROF;
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -879,8 +898,8 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       }
       // the W2 tiles go out to the other half while the remaining GEMMs run (their MFMA chains are complete by now)
       if (ICRL_HALVES_EARLY_PUBLISH && last_chunk) {
-        raw_store(xmine + (1 * THH + tid) * 16, gW2r[0]);
-        raw_store(xmine + (2 * THH + tid) * 16, gW2r[1]);
+        raw_store_u(xmine + 1 * THH * 16, gW2r[0]);
+        raw_store_u(xmine + 2 * THH * 16, gW2r[1]);
       }
       if (lowk) {   // dWh columns 16 jt..: A = dOut^T[position r][rows], B = h2^T[j = 16 jt + r][rows]
         f32x4 ao[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, bh[2];
@@ -919,17 +938,17 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     {
       f32x4 gsc = f32x4{gb1r, gb2r, gex, 0.f};
       if (!ICRL_HALVES_EARLY_PUBLISH) {
-        raw_store(xmine + (1 * THH + tid) * 16, gW2r[0]);
-        raw_store(xmine + (2 * THH + tid) * 16, gW2r[1]);
+        raw_store_u(xmine + 1 * THH * 16, gW2r[0]);
+        raw_store_u(xmine + 2 * THH * 16, gW2r[1]);
       }
-      raw_store(xmine + (0 * THH + tid) * 16, gW1r);
+      raw_store_u(xmine + 0 * THH * 16, gW1r);
       if (lowk) {
-        raw_store(xmine + (3 * THH + tid) * 16, gWhr);
-        raw_store(xmine + (4 * THH + tid) * 16, gsc);
+        raw_store_u(xmine + 3 * THH * 16, gWhr);
+        raw_store_u(xmine + 4 * THH * 16, gsc);
       }
       if (book) {
-        raw_store(xmine + (5 * THH + tid) * 16, f32x4{mb_s0, mb_s1, mb_s2, mb_s3});
-        if (DISC) raw_store(xmine + (6 * THH + tid) * 16, f32x4{mb_s4, 0.f, 0.f, 0.f});
+        raw_store_u(xmine + 5 * THH * 16, f32x4{mb_s0, mb_s1, mb_s2, mb_s3});
+        if (DISC) raw_store_u(xmine + 6 * THH * 16, f32x4{mb_s4, 0.f, 0.f, 0.f});
       }
       // every store of this wave has been acknowledged (it is in the L2 the partner reads through, or beyond) -> the wave's flag
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1010,10 +1029,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
 #if ICRL_HALVES_PARTNER_SUM && !ICRL_HALVES_OWNER_ADAM && ICRL_HALVES_FLAGS_TOGETHER
         {
           (void)wait_flag;
-          const int xa = xrole + (half ^ 1) * HX_BLK + tid * 16, xb = xrole + (half ^ 2) * HX_BLK + tid * 16, xc = xrole + (half ^ 3) * HX_BLK + tid * 16;
-          const f32x4 a0 = raw_load(xa + 0 * THH * 16), b0 = raw_load(xb + 0 * THH * 16), c0 = raw_load(xc + 0 * THH * 16);
-          const f32x4 a1 = raw_load(xa + 1 * THH * 16), b1 = raw_load(xb + 1 * THH * 16), c1 = raw_load(xc + 1 * THH * 16);
-          const f32x4 a2 = raw_load(xa + 2 * THH * 16), b2 = raw_load(xb + 2 * THH * 16), c2 = raw_load(xc + 2 * THH * 16);
+          const int xa = xrole + (half ^ 1) * HX_BLK, xb = xrole + (half ^ 2) * HX_BLK, xc = xrole + (half ^ 3) * HX_BLK;
+          const f32x4 a0 = raw_load_u(xa + 0 * THH * 16), b0 = raw_load_u(xb + 0 * THH * 16), c0 = raw_load_u(xc + 0 * THH * 16);
+          const f32x4 a1 = raw_load_u(xa + 1 * THH * 16), b1 = raw_load_u(xb + 1 * THH * 16), c1 = raw_load_u(xc + 1 * THH * 16);
+          const f32x4 a2 = raw_load_u(xa + 2 * THH * 16), b2 = raw_load_u(xb + 2 * THH * 16), c2 = raw_load_u(xc + 2 * THH * 16);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             gW1r[i] = (gW1r[i] + a0[i]) + (b0[i] + c0[i]);
@@ -1021,8 +1040,8 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
             gW2r[1][i] = (gW2r[1][i] + a2[i]) + (b2[i] + c2[i]);
           }
           if (lowk) {      // (wave-uniform)
-            const f32x4 a3 = raw_load(xa + 3 * THH * 16), b3 = raw_load(xb + 3 * THH * 16), c3 = raw_load(xc + 3 * THH * 16);
-            const f32x4 a4 = raw_load(xa + 4 * THH * 16), b4 = raw_load(xb + 4 * THH * 16), c4 = raw_load(xc + 4 * THH * 16);
+            const f32x4 a3 = raw_load_u(xa + 3 * THH * 16), b3 = raw_load_u(xb + 3 * THH * 16), c3 = raw_load_u(xc + 3 * THH * 16);
+            const f32x4 a4 = raw_load_u(xa + 4 * THH * 16), b4 = raw_load_u(xb + 4 * THH * 16), c4 = raw_load_u(xc + 4 * THH * 16);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
               gWhr[i] = (gWhr[i] + a3[i]) + (b3[i] + c3[i]);
@@ -1031,11 +1050,11 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
             gb1r = gsc[0]; gb2r = gsc[1]; gex = gsc[2];
           }
           if (w == 7) {    // the book-keeping lane's wave: every lane fetches (lane 0's slots hold the sums; the other lanes' words are never written and stay zero)
-            const f32x4 a5 = raw_load(xa + 5 * THH * 16), b5 = raw_load(xb + 5 * THH * 16), c5 = raw_load(xc + 5 * THH * 16);
+            const f32x4 a5 = raw_load_u(xa + 5 * THH * 16), b5 = raw_load_u(xb + 5 * THH * 16), c5 = raw_load_u(xc + 5 * THH * 16);
             mb_s0 = (mb_s0 + a5[0]) + (b5[0] + c5[0]); mb_s1 = (mb_s1 + a5[1]) + (b5[1] + c5[1]);
             mb_s2 = (mb_s2 + a5[2]) + (b5[2] + c5[2]); mb_s3 = (mb_s3 + a5[3]) + (b5[3] + c5[3]);
             if (DISC) {
-              const f32x4 a6 = raw_load(xa + 6 * THH * 16), b6 = raw_load(xb + 6 * THH * 16), c6 = raw_load(xc + 6 * THH * 16);
+              const f32x4 a6 = raw_load_u(xa + 6 * THH * 16), b6 = raw_load_u(xb + 6 * THH * 16), c6 = raw_load_u(xc + 6 * THH * 16);
               mb_s4 = (mb_s4 + a6[0]) + (b6[0] + c6[0]);
             }
           }
