@@ -144,6 +144,12 @@
 #ifndef ICRL_HALVES_SOFFSET
 #define ICRL_HALVES_SOFFSET 0
 #endif
+// ICRL_HALVES_DEFER_STATS (late round 6): the reductions that only feed LOGGED sums and the d log_std partial (row sums over the tile, executed by the quad's
+//   first wave) run BEHIND that wave's dz2 hand-off (P4) instead of in front of it — the other three waves wait for that hand-off.  Measured: 5.91 against
+//   5.88 us per step (bit-identical): nothing; off
+#ifndef ICRL_HALVES_DEFER_STATS
+#define ICRL_HALVES_DEFER_STATS 0
+#endif
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -695,8 +701,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       }
       STAMP(0)   // forward
       // ============ loss + d loss / d head output (all four waves of a quad: identical values) ============
+      float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
+      f32x4 dls_p = f32x4{0.f, 0.f, 0.f, 0.f};      // (ICRL_HALVES_DEFER_STATS: dlp * d log-prob / d log_std per element, reduced behind P4)
+      constexpr bool DEFER = ICRL_HALVES_DEFER_STATS && ICRL_HALVES_LOSS_WAVES >= 4;
       if (ICRL_HALVES_LOSS_WAVES >= 4 || fq < ICRL_HALVES_LOSS_WAVES) {
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f;
         if (role == 0) {
           const int ngp = (A + 3) >> 2;      // groups of four outputs that hold real ones
           float lp = 0.f, ent = 0.f;
@@ -758,10 +766,10 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
             for (int i = 0; i < 4; ++i) dout[i] = dlp * g1[i] + dent * g2[i];
           } else {
             f32x4 t = f32x4{0.f, 0.f, 0.f, 0.f};       // d log_std: sum over this tile's 16 rows, per element i (output out_of(i))
-            auto dls = [&](int i) { dout[i] = dlp * g1[i]; t[i] = row_sum(dlp * g2[i]); };
+            auto dls = [&](int i) { dout[i] = dlp * g1[i]; if (DEFER) dls_p[i] = dlp * g2[i]; else t[i] = row_sum(dlp * g2[i]); };
             dls(0);
             if (ngp > 1) { dls(1); if (ngp > 2) { dls(2); dls(3); } }
-            if (fq == 0 && r == 0) *reinterpret_cast<f32x4*>(sm + S::PLS + 16 * rt2 + 4 * q) = t;
+            if (!DEFER && fq == 0 && r == 0) *reinterpret_cast<f32x4*>(sm + S::PLS + 16 * rt2 + 4 * q) = t;
           }
           const bool cnt = valid && q == 0;
           v0 = cnt ? fminf(s1, s2) : 0.f; v1 = cnt ? Ac * ratio : 0.f; v2 = (cnt && fabsf(ratio - 1.f) > clip) ? 1.f : 0.f;
@@ -781,7 +789,7 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
           dout[0] = q == 0 ? d0 : 0.f;
           v0 = (valid && q == 0) ? e * e : 0.f;
         }
-        if (fq == 0) {     // one wave of the quad reports the tile's statistics
+        if (!DEFER && fq == 0) {     // one wave of the quad reports the tile's statistics
           v0 = row_sum(v0); v1 = row_sum(v1); v2 = row_sum(v2); v3 = row_sum(v3);
           if (DISC) v4 = row_sum(v4);
           if (lane == 0) { float* pst = sm + S::PST + 8 * rt2; pst[0] = v0; pst[1] = v1; pst[2] = v2; pst[3] = v3; pst[4] = v4; }
@@ -817,6 +825,17 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         }
       }
       quad_signal();               // (P4) this wave's features of dz2 complete
+      if (DEFER && fq == 0) {      // the tile's logged statistics and d log_std partial (read behind the barrier (S5))
+        if (role == 0 && !DISC) {
+          f32x4 t;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) t[i] = row_sum(dls_p[i]);
+          if (r == 0) *reinterpret_cast<f32x4*>(sm + S::PLS + 16 * rt2 + 4 * q) = t;
+        }
+        v0 = row_sum(v0); v1 = row_sum(v1); v2 = row_sum(v2); v3 = row_sum(v3);
+        if (DISC) v4 = row_sum(v4);
+        if (lane == 0) { float* pst = sm + S::PST + 8 * rt2; pst[0] = v0; pst[1] = v1; pst[2] = v2; pst[3] = v3; pst[4] = v4; }
+      }
       {  // dH1^T = W2^T . dz2^T: A = W2T[k = 16 fq + r][j = 16 js + 4 q + e]; own quarter of K before the wait for the others
         const float* pa = sm + S::W2T + (16 * fq + r) * SH + 4 * q;
         const f32x4 awo = lds128(pa + 16 * fq);
