@@ -33,6 +33,9 @@
 #define ICRL_QW_DEP 4
 #endif
 
+#ifndef ICRL_QW_QUAD_BARRIER
+#define ICRL_QW_QUAD_BARRIER 1
+#endif
 #ifndef ICRL_QW_STATIC_LDS
 #define ICRL_QW_STATIC_LDS 0
 #endif
@@ -306,12 +309,15 @@ __device__ __forceinline__ void ppo_train_quarters_body(const TrainArgs& a, cons
   // consumer polls the three others' counters, then reads (ppo_train_halves.hip)
   int* const pflag = reinterpret_cast<int*>(sm + S::MISC + 48);      // [4] one word per wave
   int pphase = 0;
+  // (ICRL_QW_QUAD_BARRIER: the quad is the whole workgroup here — a workgroup barrier does the hand-off; ppo_train_quarters2.hip: 11.68 -> 11.53 us)
   auto quad_signal = [&]() {
+    if (ICRL_QW_QUAD_BARRIER) return;
     ++pphase;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(pflag + w, pphase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   auto quad_wait = [&]() {
+    if (ICRL_QW_QUAD_BARRIER) { lds_barrier(); return; }
     while (true) {
       const int f0 = __hip_atomic_load(pflag + qp0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const int f1 = __hip_atomic_load(pflag + qp1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
