@@ -150,6 +150,13 @@
 #ifndef ICRL_HALVES_DEFER_STATS
 #define ICRL_HALVES_DEFER_STATS 0
 #endif
+// ICRL_HALVES_QUAD_BARRIER (four parts, late round 6): the quad's three hand-offs (h1 | head partials | dz2) as WORKGROUP barriers — waves 4..7, which take no
+//   part in forward / loss / backward, simply execute the same three `s_barrier`s on their way to (S5); `s_waitcnt lgkmcnt(0); s_barrier` replaces a flag
+//   store plus a polling loop of three LDS loads per look (ppo_train_quarters2.hip, where the quad is the whole workgroup: 11.68 -> 11.53 us)
+//   — here 5.888 -> 5.872 us (three alternating rounds): forward + backward lose ~380 cycles, the wait for the other networks' norm granules gains ~300; on
+#ifndef ICRL_HALVES_QUAD_BARRIER
+#define ICRL_HALVES_QUAD_BARRIER 1
+#endif
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -498,12 +505,15 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
   // producer drains its LDS stores and raises its counter, a consumer polls the three others' counters, then reads
   int* const pflag = reinterpret_cast<int*>(sm + S::MISC + 48);      // [8] one word per wave
   int pphase = 0;
+  constexpr bool QBAR = ICRL_HALVES_QUAD_BARRIER && NQ == 4 && ICRL_HALVES_LOSS_WAVES >= 4;
   auto quad_signal = [&]() {
+    if (QBAR) return;      // (the barrier in quad_wait does both)
     ++pphase;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_store(pflag + w, pphase, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   auto quad_wait = [&]() {
+    if (QBAR) { lds_barrier(); return; }
     while (true) {
       const int f0 = __hip_atomic_load(pflag + qp0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       const int f1 = __hip_atomic_load(pflag + qp1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -860,6 +870,8 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) pt[S::DZ1T + (16 * fq + i) * STH] = dz1c[i];
+      } else if (QBAR) {      // waves 4..7: the quad's three hand-off barriers
+        lds_barrier(); lds_barrier(); lds_barrier();
       }      // fwd_wave
       STAMP(2)   // activation backward
       if (ch == 0) {   // gradient accumulators start their life here
