@@ -369,7 +369,11 @@ __device__ __forceinline__ void ppo_train_quarters2_body(const TrainArgs& a, con
   int sidx_next = stat_idx(ps_nx2);
   if (tid == 0) sm[o_msc + 14] = run_on_one_xcd(xch0, slot_j, 12, true) ? 1.f : 0.f;
   __syncthreads();                      // initial weights visible (refresh_gauss reads log_std)
+#ifdef ICRL_ASSUME_XCD_LOCAL      // (measurement only: what a compile-time store scope would buy — no branch per exchange store: 11.61 -> 11.48 us per step (-1.1 %): not worth a verify-and-relaunch protocol in the ABI)
+  constexpr bool xcd_local = true;
+#else
   const bool xcd_local = __builtin_amdgcn_readfirstlane(__float_as_int(sm[o_msc + 14])) != 0;
+#endif
   refresh_gauss();
   commit_rows();
   stats_partials(__builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK);
