@@ -157,6 +157,12 @@
 #ifndef ICRL_HALVES_QUAD_BARRIER
 #define ICRL_HALVES_QUAD_BARRIER 1
 #endif
+// ICRL_HALVES_POLL_WAVE (late round 6): which wave polls the other networks' norm granules.  Wave 0 carries the most work of the exchange (five gradient
+//   groups to sum, 20 elements of the norm partial) and polled behind it; a kh = 1 wave (three groups) is through its own part several hundred cycles
+//   earlier, so its look is in flight while the others finish: 5.880 -> 5.860 us per step (three alternating rounds; wave 7, the book-keeping wave: 5.99)
+#ifndef ICRL_HALVES_POLL_WAVE
+#define ICRL_HALVES_POLL_WAVE 4
+#endif
 // ICRL_HALVES_FIRST_LOOK (four parts): the first look at the peers' flags issued before the staging and read behind it: 6.20-6.25 against 6.21-6.26 (noise); off
 #ifndef ICRL_HALVES_FIRST_LOOK
 #define ICRL_HALVES_FIRST_LOOK 0
@@ -1278,8 +1284,9 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
     // ---- while the granules travel: stage the next minibatch (rows -> the other X^T buffer, advantage statistics)
     const int xnext = xcur == S::XT0 ? S::XT1 : S::XT0;
     const int nb_next = __builtin_amdgcn_readfirstlane(ps_next.z) & NB_MASK;
-    const bool poller = tid < 24 && (OWNER || (tid >> 3) != role);
-    const u64* const slot = nx + (step & 1) * 32 + (tid < 24 ? tid : 0);
+    const int ptid = tid - 64 * ((NQ == 4 && !ICRL_HALVES_NORM_LOOK_EARLY) ? ICRL_HALVES_POLL_WAVE : 0);      // lane of the polling wave <-> granule
+    const bool poller = ptid >= 0 && ptid < 24 && (OWNER || (ptid >> 3) != role);
+    const u64* const slot = nx + (step & 1) * 32 + ((ptid >= 0 && ptid < 24) ? ptid : 0);
 #if ICRL_HALVES_EARLY_POLL
     u64 v_first = 0;
 #if ICRL_HALVES_NORM_LOOK_EARLY
@@ -1308,8 +1315,8 @@ __device__ __forceinline__ void ppo_train_halves_body(const TrainArgs& a, const 
         __builtin_amdgcn_s_sleep(1);
         ++spins;
       }
-      sm[S::MISC + 24 + tid] = __uint_as_float((unsigned)(v & 0xffffffffu));
-      if (tid == 7) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;     // the granule of the policy's book-keeping wave carries the stop flag
+      sm[S::MISC + 24 + ptid] = __uint_as_float((unsigned)(v & 0xffffffffu));
+      if (ptid == 7) sm[S::MISC + 12] = (v >> 63) ? 1.f : 0.f;     // the granule of the policy's book-keeping wave carries the stop flag
       if (!ok) sm[S::MISC + 13] = 1.f;
     }
     lds_barrier();   // (S6) norm partials, next minibatch and its statistics visible
